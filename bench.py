@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- ganon read classification on MI355X: Mreads/s classified + IBF-lookup GB/s vs the HBM roofline.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload flat8g|flat1g|tiny]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (minimiser kernel -> IBF count+select kernel -> match grouping) over one
+batch of synthetic 150 bp reads that is already resident in HBM; the filter is resident too.  The default
+workload is BASELINE.json configs[1]: 8 GiB flat IBF, 4096 technical bins, h=4, 10 M reads (k=19, w=31).
+With N > 1 ranks the reads are sharded (each rank classifies its own 10 M reads against its own filter
+replica, no data-path collective) -> "scaling": "weak".
+
+Rank 0 prints ONE JSON line (driver contract) with two extra objects:
+  roofline     achieved = algorithmic row bytes (n_hashes * h * W * 8 per launch) / average count-kernel duration,
+               measured with hipEvents on the library's own HIP stream (gn_stream_timings); peak = 8000 GB/s
+  cpu_baseline the CPU oracle (kind "port": OpenMP restatement of the reference loop) on a bounded sample of the
+               same reads against the same filter bits, timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (bins, rows, h, n_reads)
+    "flat8g": (4096, 1 << 24, 4, 10_000_000),   # BASELINE.json configs[1]: 2^24 rows x 512 B = 8 GiB
+    "flat1g": (4096, 1 << 21, 4, 2_000_000),    # same shape, 1 GiB (quick runs; still >> 256 MiB Infinity Cache)
+    "tiny": (4096, 1 << 14, 4, 100_000),        # smoke-sized
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("GANON_BENCH_WORKLOAD", "flat8g"), choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s)")
+    ap.add_argument("--check", type=int, default=2000, help="reads re-checked against the oracle (rank 0)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        log("bench.py: no GPU visible -- the hot path has no CPU fallback")
+        return 2
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import ganon_amd
+    import bench_workload as bw
+
+    bins, rows, h, n_reads = WORKLOADS[args.workload]
+    if args.reads:
+        n_reads = args.reads
+    t0 = time.time()
+    wl = bw.make_flat_workload(args.workload, bins, rows, h, n_reads, seed=42, shard=rank)
+    log(f"[rank {rank}] workload {args.workload}: filter {wl.filter_bytes / 2**30:.2f} GiB, {n_reads} reads, "
+        f"generated in {time.time() - t0:.1f}s")
+
+    t0 = time.time()
+    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs, device=local_rank)
+    n_planted = bw.plant_genomes(flt, wl)
+    log(f"[rank {rank}] filter uploaded + {n_planted} genome minimisers emplaced on device in {time.time() - t0:.1f}s")
+
+    st = ganon_amd.HipStream(flt, n_reads, wl.bases.size, max_matches=n_reads * 2)
+    st.upload(wl.bases, wl.off, None)
+    st.sync()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        st.classify(wl.k, wl.w, wl.rel_cutoff)
+        st.sync()
+
+    count_ms, mini_ms, total_ms = [], [], []
+    barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        st.classify(wl.k, wl.w, wl.rel_cutoff)
+        st.sync()
+        tm = st.timings()           # hipEvent durations on the stream the kernels ran on
+        count_ms.append(tm["ms_count"])
+        mini_ms.append(tm["ms_minimiser"])
+        total_ms.append(tm["ms_total"])
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tm = st.timings()
+    nh, status, mo, matches = st.fetch()
+    n_class = int(np.count_nonzero(np.diff(mo)))
+    ms_per_step = elapsed * 1e3 / max(1, args.steps)
+    value = world * n_reads / (elapsed / max(1, args.steps)) / 1e6  # Mreads/s, whole job
+    avg_count_ms = float(np.mean(count_ms)) if count_ms else float("nan")
+    achieved = tm["algo_bytes"] / (avg_count_ms * 1e-3) / 1e9 if count_ms else float("nan")
+
+    result = {
+        "metric": "Mreads/s classified (150 bp) + IBF-lookup GB/s vs HBM roofline",
+        "value": round(value, 3),
+        "unit": "Mreads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: flat IBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {wl.bins} technical "
+                        f"bins (W={wl.bin_words}, {wl.bin_words * 8} B rows), S={wl.rows} rows, h={wl.hash_funs}, "
+                        f"k={wl.k} w={wl.w}, {n_reads} synthetic {wl.read_len} bp reads per GPU ({wl.planted_fraction:.0%} "
+                        f"planted), rel_cutoff={wl.rel_cutoff}, Bernoulli(0.5) fill, seed {wl.seed}",
+            "reads_per_gpu": n_reads,
+            "parallelism": f"read-sharded x{world}, filter replicated",
+            "mean_minimisers_per_read": round(tm["n_hashes"] / max(1, n_reads), 3),
+            "classified_reads_rank0": n_class,
+            "matches_rank0": int(tm["n_matches"]),
+            "kernel_ms": {"minimiser": round(float(np.mean(mini_ms)), 3), "count_select": round(avg_count_ms, 3),
+                          "device_total": round(float(np.mean(total_ms)), 3)},
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "gn_ibf_count_kernel",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "algo_bytes_per_launch": int(tm["algo_bytes"]),
+            "avg_launch_ms": round(avg_count_ms, 4),
+            "traffic": None,
+        },
+    }
+
+    if rank == 0:
+        import bench_cpu
+        if args.check:
+            ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check)
+            result["config"]["oracle_spot_check"] = detail
+            if not ok:
+                log("bench.py: ORACLE SPOT CHECK FAILED:", detail)
+                result["value"] = None
+        if not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = bench_cpu.cpu_baseline(wl, flt, args.cpu_sample)
+            except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
+                log("bench.py: cpu_baseline failed:", repr(e))
+                result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    st.destroy()
+    flt.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

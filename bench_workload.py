@@ -1,0 +1,144 @@
+"""Synthetic workload builders shared by bench.py, __graft_entry__.smoke() and the full-size GPU tests.
+
+Everything is seeded and generated with numpy on the host; planted genomes are hashed and emplaced on the
+device through the C ABI, and the filter is downloaded back before the CPU oracle looks at it, so parity is
+checked on exactly the device's bits (SURVEY.md 8d 'Synthetic inputs').  Nothing here touches oracle/ except
+oracle_filter(), which only the checker legs (smoke, tests, cpu_baseline) call.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _fill_random_u64(out: np.ndarray, seed: int, threads: int) -> None:
+    """iid Bernoulli(0.5) bits, generated in parallel chunks (PCG64 streams keyed by (seed, chunk))."""
+    flat = out.reshape(-1)
+    n = flat.size
+    chunk = 1 << 24  # 128 MiB
+    spans = [(i, min(n, i + chunk)) for i in range(0, n, chunk)]
+
+    def work(idx_span):
+        idx, (a, b) = idx_span
+        rng = np.random.Generator(np.random.PCG64([seed, idx]))
+        flat[a:b] = rng.integers(0, 1 << 64, size=b - a, dtype=np.uint64)
+
+    with cf.ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        list(ex.map(work, enumerate(spans)))
+
+
+@dataclass
+class FlatWorkload:
+    name: str
+    bins: int
+    rows: int          # bin_size S
+    hash_funs: int
+    k: int
+    w: int
+    rel_cutoff: float
+    read_len: int
+    n_reads: int
+    planted_fraction: float
+    seed: int
+    filter_rows: np.ndarray      # uint64 [S, W] host copy == device content
+    bases: np.ndarray            # uint8 ASCII [n_reads*read_len]
+    off: np.ndarray              # uint64 [n_reads+1]
+    density: float = 0.5
+    genomes: Optional[np.ndarray] = None      # uint8 ASCII [n_genomes, genome_len]
+    genome_bins: Optional[np.ndarray] = None  # uint32 [n_genomes]
+
+    @property
+    def bin_words(self) -> int:
+        return (self.bins + 63) >> 6
+
+    @property
+    def filter_bytes(self) -> int:
+        return self.rows * self.bin_words * 8
+
+
+def make_flat_workload(name: str, bins: int, rows: int, hash_funs: int, n_reads: int, read_len: int = 150, k: int = 19,
+                       w: int = 31, rel_cutoff: float = 0.75, planted_fraction: float = 0.5, genome_len: int = 3000,
+                       n_genomes: Optional[int] = None, seed: int = 42, threads: Optional[int] = None,
+                       shard: int = 0) -> FlatWorkload:
+    """Flat IBF whose bit matrix is iid Bernoulli(0.5) (per-hash per-bin false-positive rate 0.5**h); reads are
+    uniform iid ACGT with `planted_fraction` of them cut from `n_genomes` random genomes.  The genomes'
+    minimisers still have to be OR-ed into the filter: `plant_genomes()` does that on the device through the C
+    ABI (gn_submit_batch -> hashes -> gn_filter_emplace).  `shard` only changes the read stream (filter
+    replicas are identical on every rank)."""
+    threads = threads or min(32, os.cpu_count() or 1)
+    W = (bins + 63) >> 6
+    data = np.empty((rows, W), dtype=np.uint64)
+    _fill_random_u64(data, seed, threads)
+    if bins & 63:
+        data[:, W - 1] &= np.uint64((1 << (bins & 63)) - 1)
+
+    rng = np.random.default_rng([seed, 1])
+    n_genomes = n_genomes if n_genomes is not None else min(bins, 4096)
+    genomes = rng.integers(0, 4, size=(n_genomes, genome_len), dtype=np.uint8)
+    gbins = ((np.arange(n_genomes, dtype=np.uint64) * np.uint64(max(1, bins // n_genomes))) % np.uint64(bins)).astype(np.uint32)
+
+    rrng = np.random.default_rng([seed, 2, shard])
+    reads = rrng.integers(0, 4, size=(n_reads, read_len), dtype=np.uint8)
+    n_pl = int(n_reads * planted_fraction)
+    if n_pl and genome_len > read_len:
+        which = rrng.integers(0, n_genomes, size=n_pl)
+        pos = rrng.integers(0, genome_len - read_len, size=n_pl)
+        idx = pos[:, None] + np.arange(read_len)[None, :]
+        sel = np.arange(n_pl) * 2 if n_pl * 2 <= n_reads else np.arange(n_pl)  # interleave planted / random reads
+        reads[sel] = genomes[which[:, None], idx]
+    bases = ACGT[reads].reshape(-1)
+    off = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len))
+    wl = FlatWorkload(name, bins, rows, hash_funs, k, w, rel_cutoff, read_len, n_reads, planted_fraction, seed,
+                      data, bases, off)
+    wl.genomes = ACGT[genomes]
+    wl.genome_bins = gbins
+    return wl
+
+
+def plant_genomes(hip_filter, wl: FlatWorkload) -> int:
+    """OR the minimisers of wl.genomes into their bins ON THE DEVICE (product path only): the genomes are
+    hashed by gn_minimiser_kernel and scattered by gn_emplace_kernel.  Returns the number of (hash, bin) pairs."""
+    from ganon_amd import HipStream
+    g = wl.genomes
+    n, L = g.shape
+    st = HipStream(hip_filter, n, n * L)
+    st.submit(g.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L), None, wl.k, wl.w, 1.0)
+    ho, hs = st.fetch_hashes()
+    st.destroy()
+    bins = np.repeat(wl.genome_bins, np.diff(ho).astype(np.int64)).astype(np.uint32)
+    hip_filter.emplace(hs, bins)
+    return len(hs)
+
+
+def download_filter(hip_filter, wl: FlatWorkload) -> None:
+    """refresh the host copy of the filter from the device (so the CPU oracle sees exactly the device bits)"""
+    step = max(1, (1 << 30) // (wl.bin_words * 8))
+    for r0 in range(0, wl.rows, step):
+        n = min(step, wl.rows - r0)
+        wl.filter_rows[r0:r0 + n] = hip_filter.download_rows(r0, n, wl.bin_words)
+
+
+def oracle_filter(wl: FlatWorkload):
+    """oracle.Filter over the workload's flat IBF (identity bin->target map)."""
+    import oracle
+    ibf = oracle.Ibf(wl.bins, wl.rows, wl.hash_funs, wl.filter_rows)
+    return oracle.Filter(ibf=ibf, targets=[str(i) for i in range(wl.bins)], target_bins=[[i] for i in range(wl.bins)],
+                         rel_cutoff=wl.rel_cutoff), ibf
+
+
+def checksum_matches(matches: np.ndarray) -> int:
+    """order-independent checksum of (read, target, count) records; same formula as gno_baseline_classify."""
+    if len(matches) == 0:
+        return 0
+    r = matches["read"].astype(np.uint64) + np.uint64(1)
+    t = matches["target"].astype(np.uint64)
+    c = matches["count"].astype(np.uint64)
+    with np.errstate(over="ignore"):
+        v = r * np.uint64(0x9E3779B97F4A7C15) + t * np.uint64(1000003) + c
+        return int(np.sum(v, dtype=np.uint64))

@@ -1,0 +1,73 @@
+"""Builds the native pieces in-tree with hipcc (gfx950 only) and g++.
+
+  ganon_amd/csrc/libganon_hip.so   HIP kernels + C ABI (include/ganon_hip.h)
+  ganon_amd/host/ganon-classify    C++ host binary (drop-in CLI), links libganon_hip.so
+
+No JIT cache: the .so / binary live next to their sources so they travel with a repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+LIB = os.path.join(CSRC, "libganon_hip.so")
+BIN = os.path.join(HOST, "ganon-classify")
+
+HIP_SOURCES = ["gn_kernels.hip", "gn_hibf.hip", "gn_capi.hip"]
+HIP_HEADERS = ["gn_internal.h", os.path.join(ROOT, "include", "ganon_hip.h")]
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libganon_hip.so cannot be built (there is no CPU fallback)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    if force or _stale(LIB, deps):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+               "-o", LIB] + srcs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cpp")) if os.path.isdir(HOST) else []
+    if not srcs:
+        return ""
+    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "ganon_hip.h")]
+    build_hip(force=False, verbose=verbose)
+    if force or _stale(BIN, srcs + hdrs + [LIB]):
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", BIN] + srcs + \
+              ["-L", CSRC, "-lganon_hip", "-lz", "-Wl,-rpath,$ORIGIN/../csrc"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return BIN
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_hip(force, verbose)
+    build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,779 @@
+// gn_capi.hip -- C ABI of libganon_hip.so (include/ganon_hip.h): filter upload, batch submit, sparse-match fetch.
+// Host-side HIP runtime code only; the kernels live in gn_kernels.hip / gn_hibf.hip.
+#include "gn_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int gn_fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* gn_last_error(void)
+{
+    return g_err;
+}
+
+extern "C" int gn_device_count(int* n)
+{
+    if (!n)
+        return gn_fail(GN_EINVAL, "gn_device_count: null argument");
+    int        c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess)
+    {
+        *n = 0;
+        return gn_fail(GN_ENODEV, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// objects
+// ------------------------------------------------------------------------------------------------
+static int gn_set_device(int dev)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+        return gn_fail(GN_ENODEV, "no HIP device available (libganon_hip has no CPU fallback)");
+    if (dev < 0 || dev >= c)
+        return gn_fail(GN_EINVAL, "device %d out of range (%d devices)", dev, c);
+    GN_HIP(hipSetDevice(dev));
+    return GN_OK;
+}
+
+static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* bytes_acc)
+{
+    if (!d || d->bin_size == 0 || d->bins == 0)
+        return gn_fail(GN_EINVAL, "empty IBF description");
+    if (d->bin_words != ((d->bins + 63) >> 6))
+        return gn_fail(GN_EINVAL, "bin_words (%llu) != ceil(bins/64) (%llu)", (unsigned long long)d->bin_words,
+                       (unsigned long long)((d->bins + 63) >> 6));
+    if (d->hash_funs < 1 || d->hash_funs > 5)
+        return gn_fail(GN_EINVAL, "hash_funs %u outside 1..5", d->hash_funs);
+    if (d->hash_shift != (uint32_t)__builtin_clzll(d->bin_size))
+        return gn_fail(GN_EINVAL, "hash_shift %u != countl_zero(bin_size) %d", d->hash_shift,
+                       __builtin_clzll(d->bin_size));
+    if (d->bin_size > 0xFFFFFFFFull)
+        return gn_fail(GN_ERANGE, "bin_size > 2^32 rows is not supported");
+    if (d->bin_words > 0xFFFFFFFFull || d->bins > 0xFFFFFFF0ull)
+        return gn_fail(GN_ERANGE, "too many bins");
+    const uint64_t bytes = d->bin_size * d->bin_words * 8ull;
+    uint64_t*      dp    = nullptr;
+    GN_HIP(hipMalloc(reinterpret_cast<void**>(&dp), bytes + 64)); // +64: tail pad for 16-byte loads
+    if (d->rows)
+    {
+        // chunked copy keeps pinned-staging pressure low for multi-GiB filters
+        const uint64_t chunk = 1ull << 30;
+        for (uint64_t o = 0; o < bytes; o += chunk)
+        {
+            const uint64_t nb = std::min(chunk, bytes - o);
+            hipError_t     e  = hipMemcpy(reinterpret_cast<uint8_t*>(dp) + o, reinterpret_cast<const uint8_t*>(d->rows) + o,
+                                          nb, hipMemcpyHostToDevice);
+            if (e != hipSuccess)
+            {
+                hipFree(dp);
+                return gn_fail(GN_ENODEV, "filter upload failed: %s", hipGetErrorString(e));
+            }
+        }
+        GN_HIP(hipMemset(reinterpret_cast<uint8_t*>(dp) + bytes, 0, 64));
+    }
+    else
+    {
+        GN_HIP(hipMemset(dp, 0, bytes + 64));
+    }
+    out->d_rows = dp;
+    out->S      = d->bin_size;
+    out->W      = d->bin_words;
+    out->B      = d->bins;
+    out->h      = d->hash_funs;
+    out->shift  = d->hash_shift;
+    *bytes_acc += bytes;
+    return GN_OK;
+}
+
+extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const uint32_t* bin2target, uint32_t n_targets,
+                                    gn_filter** out)
+{
+    if (!out || !ibf || !bin2target)
+        return gn_fail(GN_EINVAL, "gn_filter_upload_ibf: null argument");
+    *out = nullptr;
+    int rc = gn_set_device(device);
+    if (rc)
+        return rc;
+    GnCountGeometry geom{};
+    const char*     why = "";
+    if (!gn_count_geometry(ibf->bin_words, ibf->hash_funs, &geom, &why))
+        return gn_fail(GN_ERANGE, "unsupported IBF shape: %s", why);
+
+    gn_filter* f = new (std::nothrow) gn_filter();
+    if (!f)
+        return gn_fail(GN_ENOMEM, "out of host memory");
+    f->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        f->n_cu = prop.multiProcessorCount;
+    f->geom = geom;
+    rc      = gn_upload_ibf_rows(ibf, &f->ibf, &f->device_bytes);
+    if (rc)
+    {
+        delete f;
+        return rc;
+    }
+    // bin -> target map as CSR indexed by target id (replaces Filter::map, GanonClassify.cpp:1021-1025)
+    bool identity = (n_targets == ibf->bins);
+    for (uint64_t b = 0; b < ibf->bins; ++b)
+    {
+        const uint32_t t = bin2target[b];
+        if (t != 0xFFFFFFFFu && t >= n_targets)
+        {
+            gn_filter_free(f);
+            return gn_fail(GN_EINVAL, "bin2target[%llu] = %u >= n_targets %u", (unsigned long long)b, t, n_targets);
+        }
+        if (t != b)
+            identity = false;
+    }
+    f->n_targets = n_targets;
+    f->identity  = identity;
+    if (!identity)
+    {
+        std::vector<uint32_t> off(n_targets + 1, 0), bins(ibf->bins ? ibf->bins : 1, 0);
+        for (uint64_t b = 0; b < ibf->bins; ++b)
+            if (bin2target[b] != 0xFFFFFFFFu)
+                off[bin2target[b] + 1]++;
+        for (uint32_t t = 0; t < n_targets; ++t)
+            off[t + 1] += off[t];
+        std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+        for (uint64_t b = 0; b < ibf->bins; ++b)
+            if (bin2target[b] != 0xFFFFFFFFu)
+                bins[fill[bin2target[b]]++] = (uint32_t)b;
+        hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&f->d_tgt_off), off.size() * 4);
+        hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&f->d_tgt_bins), bins.size() * 4);
+        if (e1 != hipSuccess || e2 != hipSuccess)
+        {
+            gn_filter_free(f);
+            return gn_fail(GN_ENOMEM, "target map allocation failed");
+        }
+        hipMemcpy(f->d_tgt_off, off.data(), off.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(f->d_tgt_bins, bins.data(), bins.size() * 4, hipMemcpyHostToDevice);
+    }
+    *out = f;
+    return GN_OK;
+}
+
+int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const int64_t* const* next_ibf_id,
+                  const int64_t* const* bin2userbin, uint64_t n_user_bins); // gn_hibf.hip
+
+extern "C" int gn_filter_upload_hibf(int device, uint32_t n_ibf, const gn_ibf_desc* ibfs, const int64_t* const* next_ibf_id,
+                                     const int64_t* const* bin2userbin, uint64_t n_user_bins, gn_filter** out)
+{
+    if (!out || !ibfs || !next_ibf_id || !bin2userbin || n_ibf == 0)
+        return gn_fail(GN_EINVAL, "gn_filter_upload_hibf: null/empty argument");
+    *out = nullptr;
+    int rc = gn_set_device(device);
+    if (rc)
+        return rc;
+    gn_filter* f = new (std::nothrow) gn_filter();
+    if (!f)
+        return gn_fail(GN_ENOMEM, "out of host memory");
+    f->device  = device;
+    f->is_hibf = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        f->n_cu = prop.multiProcessorCount;
+    f->ibfs.resize(n_ibf);
+    for (uint32_t i = 0; i < n_ibf; ++i)
+    {
+        rc = gn_upload_ibf_rows(&ibfs[i], &f->ibfs[i], &f->device_bytes);
+        if (rc)
+        {
+            gn_filter_free(f);
+            return rc;
+        }
+    }
+    rc = gn_hibf_build(f, n_ibf, ibfs, next_ibf_id, bin2userbin, n_user_bins);
+    if (rc)
+    {
+        gn_filter_free(f);
+        return rc;
+    }
+    *out = f;
+    return GN_OK;
+}
+
+extern "C" int gn_filter_free(gn_filter* f)
+{
+    if (!f)
+        return GN_OK;
+    hipSetDevice(f->device);
+    if (f->ibf.d_rows)
+        hipFree(f->ibf.d_rows);
+    if (f->d_tgt_off)
+        hipFree(f->d_tgt_off);
+    if (f->d_tgt_bins)
+        hipFree(f->d_tgt_bins);
+    for (auto& i : f->ibfs)
+        if (i.d_rows)
+            hipFree(i.d_rows);
+    for (void* p : f->hibf_allocs)
+        hipFree(p);
+    if (f->d_hibf)
+        hipFree(f->d_hibf);
+    delete f;
+    return GN_OK;
+}
+
+extern "C" int gn_filter_info(const gn_filter* f, int* is_hibf, uint32_t* n_ibf, uint64_t* n_targets, uint64_t* device_bytes)
+{
+    if (!f)
+        return gn_fail(GN_EINVAL, "null filter");
+    if (is_hibf)
+        *is_hibf = f->is_hibf ? 1 : 0;
+    if (n_ibf)
+        *n_ibf = f->is_hibf ? (uint32_t)f->ibfs.size() : 1u;
+    if (n_targets)
+        *n_targets = f->is_hibf ? f->n_user_bins : f->n_targets;
+    if (device_bytes)
+        *device_bytes = f->device_bytes;
+    return GN_OK;
+}
+
+extern "C" int gn_filter_emplace(gn_filter* f, const uint64_t* hashes, const uint32_t* bins, uint64_t n)
+{
+    if (!f || f->is_hibf)
+        return gn_fail(GN_EINVAL, "gn_filter_emplace needs a flat IBF filter");
+    if (n == 0)
+        return GN_OK;
+    if (!hashes || !bins)
+        return gn_fail(GN_EINVAL, "null argument");
+    for (uint64_t i = 0; i < n; ++i)
+        if (bins[i] >= f->ibf.B)
+            return gn_fail(GN_EINVAL, "bin %u out of range", bins[i]);
+    GN_HIP(hipSetDevice(f->device));
+    uint64_t* dh = nullptr;
+    uint32_t* db = nullptr;
+    GN_HIP(hipMalloc(reinterpret_cast<void**>(&dh), n * 8));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&db), n * 4);
+    if (e != hipSuccess)
+    {
+        hipFree(dh);
+        return gn_fail(GN_ENOMEM, "emplace staging allocation failed");
+    }
+    hipMemcpy(dh, hashes, n * 8, hipMemcpyHostToDevice);
+    hipMemcpy(db, bins, n * 4, hipMemcpyHostToDevice);
+    e = gn_launch_emplace(f->ibf.d_rows, f->ibf.S, (uint32_t)f->ibf.W, f->ibf.shift, f->ibf.h, dh, db, n, nullptr);
+    hipError_t e2 = hipDeviceSynchronize();
+    hipFree(dh);
+    hipFree(db);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return gn_fail(GN_ENODEV, "emplace kernel failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return GN_OK;
+}
+
+extern "C" int gn_filter_download_rows(const gn_filter* f, uint32_t ibf_idx, uint64_t row_begin, uint64_t n_rows, uint64_t* out)
+{
+    if (!f || !out)
+        return gn_fail(GN_EINVAL, "null argument");
+    const GnIbfHost* ib = nullptr;
+    if (f->is_hibf)
+    {
+        if (ibf_idx >= f->ibfs.size())
+            return gn_fail(GN_EINVAL, "ibf index out of range");
+        ib = &f->ibfs[ibf_idx];
+    }
+    else
+    {
+        if (ibf_idx != 0)
+            return gn_fail(GN_EINVAL, "ibf index out of range");
+        ib = &f->ibf;
+    }
+    if (row_begin + n_rows > ib->S)
+        return gn_fail(GN_EINVAL, "row range out of bounds");
+    GN_HIP(hipSetDevice(f->device));
+    GN_HIP(hipMemcpy(out, ib->d_rows + row_begin * ib->W, n_rows * ib->W * 8, hipMemcpyDeviceToHost));
+    return GN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// streams
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static hipError_t gn_dmalloc(T** p, size_t n)
+{
+    return hipMalloc(reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T));
+}
+
+extern "C" int gn_stream_destroy(gn_stream* s)
+{
+    if (!s)
+        return GN_OK;
+    hipSetDevice(s->f->device);
+    if (s->st)
+        hipStreamSynchronize(s->st);
+    void* ptrs[] = { s->d_bases,  s->d_off1,    s->d_off2,      s->d_slot_cnt,  s->d_slot_off, s->d_hashes, s->d_nh,
+                     s->d_status, s->d_matches, s->d_sorted,    s->d_ctr,       s->d_seg_begin, s->d_seg_count,
+                     s->d_seg_off, s->d_scan_tmp, s->d_work[0], s->d_work[1] };
+    for (void* p : ptrs)
+        if (p)
+            hipFree(p);
+    if (s->h_ctr)
+        hipHostFree(s->h_ctr);
+    for (auto& e : s->ev)
+        if (e)
+            hipEventDestroy(e);
+    if (s->st)
+        hipStreamDestroy(s->st);
+    delete s;
+    return GN_OK;
+}
+
+extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_bases, uint64_t max_matches, gn_stream** out)
+{
+    if (!f || !out || max_reads == 0 || max_bases == 0)
+        return gn_fail(GN_EINVAL, "gn_stream_create: bad argument");
+    *out = nullptr;
+    GN_HIP(hipSetDevice(f->device));
+    gn_stream* s = new (std::nothrow) gn_stream();
+    if (!s)
+        return gn_fail(GN_ENOMEM, "out of host memory");
+    s->f         = f;
+    s->max_reads = max_reads;
+    s->max_bases = max_bases;
+    s->match_cap = max_matches ? max_matches : (uint64_t)max_reads * 4;
+    const uint32_t wpr  = f->is_hibf ? 1 : f->geom.wpr;
+    const size_t   nseg = (size_t)max_reads * wpr;
+    hipError_t     e    = hipSuccess;
+    auto           ok   = [&](hipError_t x) {
+        if (e == hipSuccess)
+            e = x;
+    };
+    ok(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    for (auto& ev : s->ev)
+        ok(hipEventCreate(&ev));
+    ok(gn_dmalloc(&s->d_bases, max_bases + 64));
+    ok(gn_dmalloc(&s->d_off1, (size_t)max_reads + 1));
+    ok(gn_dmalloc(&s->d_off2, (size_t)max_reads + 1));
+    ok(gn_dmalloc(&s->d_slot_cnt, (size_t)max_reads + 1));
+    ok(gn_dmalloc(&s->d_slot_off, (size_t)max_reads + 1));
+    ok(gn_dmalloc(&s->d_hashes, max_bases)); // #windows <= #bases
+    ok(gn_dmalloc(&s->d_nh, max_reads));
+    ok(gn_dmalloc(&s->d_status, max_reads));
+    ok(gn_dmalloc(&s->d_matches, s->match_cap));
+    ok(gn_dmalloc(&s->d_sorted, s->match_cap));
+    ok(gn_dmalloc(&s->d_ctr, 8));
+    ok(gn_dmalloc(&s->d_seg_begin, nseg));
+    ok(gn_dmalloc(&s->d_seg_count, nseg + 1));
+    ok(gn_dmalloc(&s->d_seg_off, nseg + 1));
+    size_t tmp1 = 0, tmp2 = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tmp1, s->d_slot_cnt, s->d_slot_off, (int)(max_reads + 1), s->st);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st);
+    s->scan_tmp_bytes = std::max(tmp1, tmp2) + 256;
+    ok(hipMalloc(&s->d_scan_tmp, s->scan_tmp_bytes));
+    if (f->is_hibf)
+    {
+        s->work_cap = max_reads * 4u > 1024u ? max_reads * 4u : 1024u;
+        ok(gn_dmalloc(&s->d_work[0], s->work_cap));
+        ok(gn_dmalloc(&s->d_work[1], s->work_cap));
+    }
+    ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (e != hipSuccess)
+    {
+        gn_stream_destroy(s);
+        return gn_fail(e == hipErrorOutOfMemory ? GN_ENOMEM : GN_ENODEV, "gn_stream_create: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return GN_OK;
+}
+
+extern "C" int gn_stream_upload_reads(gn_stream* s, const uint8_t* bases, uint64_t n_bases, const uint64_t* off1,
+                                      const uint64_t* off2, uint32_t n_reads)
+{
+    if (!s || !off1 || (!bases && n_bases))
+        return gn_fail(GN_EINVAL, "gn_stream_upload_reads: null argument");
+    if (n_reads > s->max_reads || n_bases > s->max_bases)
+        return gn_fail(GN_EINVAL, "batch (%u reads, %llu bases) exceeds the stream capacity (%u, %llu)", n_reads,
+                       (unsigned long long)n_bases, s->max_reads, (unsigned long long)s->max_bases);
+    if (n_reads && (off1[n_reads] > n_bases || (off2 && off2[n_reads] > n_bases)))
+        return gn_fail(GN_EINVAL, "read offsets exceed n_bases");
+    GN_HIP(hipSetDevice(s->f->device));
+    GN_HIP(hipStreamSynchronize(s->st)); // previous batch must be done before its inputs are overwritten
+    if (n_bases)
+        GN_HIP(hipMemcpyAsync(s->d_bases, bases, n_bases, hipMemcpyHostToDevice, s->st));
+    GN_HIP(hipMemcpyAsync(s->d_off1, off1, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s->st));
+    if (off2)
+        GN_HIP(hipMemcpyAsync(s->d_off2, off2, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s->st));
+    s->n_reads    = n_reads;
+    s->n_bases    = n_bases;
+    s->paired     = off2 != nullptr;
+    s->have_reads = true;
+    s->classified = false;
+    return GN_OK;
+}
+
+// small helper kernels (batch bookkeeping) ---------------------------------------------------------
+__global__ void gn_slot_count_kernel(const uint64_t* off1, const uint64_t* off2, uint32_t n_reads, uint32_t w, uint64_t* cnt)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads)
+        return;
+    uint64_t c = 0;
+    if (r < n_reads)
+    {
+        const uint64_t l1 = off1[r + 1] - off1[r];
+        if (l1 >= w)
+        {
+            c = l1 - w + 1;
+            if (off2)
+            {
+                const uint64_t l2 = off2[r + 1] - off2[r];
+                if (l2 >= w)
+                    c += l2 - w + 1;
+            }
+        }
+    }
+    cnt[r] = c;
+}
+
+__global__ void gn_gather_kernel(const gn_match* __restrict__ in, gn_match* __restrict__ out, const uint64_t* __restrict__ seg_begin,
+                                 const uint32_t* __restrict__ seg_count, const uint64_t* __restrict__ seg_off, uint64_t nseg)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseg)
+        return;
+    const uint32_t c = seg_count[i];
+    const uint64_t b = seg_begin[i], o = seg_off[i];
+    for (uint32_t j = 0; j < c; ++j)
+        out[o + j] = in[b + j];
+}
+
+int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st); // gn_hibf.hip
+
+static int gn_run_count(gn_stream* s)
+{
+    gn_filter* f = s->f;
+    GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), s->st)); // cursor
+    if (f->is_hibf)
+        return gn_hibf_classify(s, f, s->st);
+    GnCountParams p{};
+    p.rows       = f->ibf.d_rows;
+    p.S          = f->ibf.S;
+    p.W          = (uint32_t)f->ibf.W;
+    p.B          = (uint32_t)f->ibf.B;
+    p.shift      = f->ibf.shift;
+    p.tgt_off    = f->identity ? nullptr : f->d_tgt_off;
+    p.tgt_bins   = f->d_tgt_bins;
+    p.tgt_ids    = nullptr;
+    p.n_targets  = f->n_targets;
+    p.hashes     = s->d_hashes;
+    p.slot_off   = s->d_slot_off;
+    p.n_hashes   = s->d_nh;
+    p.status     = s->d_status;
+    p.n_reads    = s->n_reads;
+    p.rel_cutoff = s->rel_cutoff;
+    p.wpr        = f->geom.wpr;
+    p.gp_log2    = f->geom.gp_log2;
+    p.slice_dwords = f->geom.slice_dwords;
+    p.matches    = s->d_matches;
+    p.match_cap  = s->match_cap;
+    p.cursor     = s->d_ctr;
+    p.seg_begin  = s->d_seg_begin;
+    p.seg_count  = s->d_seg_count;
+    p.dense      = nullptr;
+    GN_HIP(gn_launch_count(p, f->geom, f->ibf.h, s->st));
+    return GN_OK;
+}
+
+static int gn_run_group(gn_stream* s)
+{
+    // group matches by read on the device: exclusive scan of the segment sizes + gather
+    if (s->f->is_hibf)
+        return GN_OK; // HIBF matches are grouped by gn_hibf_classify
+    const size_t nseg = (size_t)s->n_reads * s->f->geom.wpr;
+    GN_HIP(hipMemsetAsync(s->d_seg_count + nseg, 0, 4, s->st));
+    size_t tmp = s->scan_tmp_bytes;
+    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st));
+    if (nseg)
+        hipLaunchKernelGGL(gn_gather_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, s->st, s->d_matches,
+                           s->d_sorted, s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)nseg);
+    GN_HIP(hipGetLastError());
+    return GN_OK;
+}
+
+extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double rel_cutoff)
+{
+    if (!s)
+        return gn_fail(GN_EINVAL, "null stream");
+    if (!s->have_reads)
+        return gn_fail(GN_EINVAL, "gn_stream_classify: no reads uploaded");
+    if (k < 1 || k > 32 || w < k)
+        return gn_fail(GN_EINVAL, "need 1 <= k <= 32 and w >= k (k=%u w=%u)", k, w);
+    if (w - k + 1 > 448 || w > 4096)
+        return gn_fail(GN_ERANGE, "window of %u k-mers exceeds the LDS sliding window (max 448)", w - k + 1);
+    if (!(rel_cutoff >= 0.0 && rel_cutoff <= 1.0))
+        return gn_fail(GN_EINVAL, "rel_cutoff must be within [0,1]");
+    gn_filter* f = s->f;
+    GN_HIP(hipSetDevice(f->device));
+    s->k          = k;
+    s->w          = w;
+    s->rel_cutoff = rel_cutoff;
+
+    GN_HIP(hipEventRecord(s->ev[0], s->st));
+    GN_HIP(hipMemsetAsync(s->d_ctr, 0, 8 * sizeof(unsigned long long), s->st));
+    // hash slots: #windows per read, exclusive scan
+    hipLaunchKernelGGL(gn_slot_count_kernel, dim3((s->n_reads + 1 + 255) / 256), dim3(256), 0, s->st, s->d_off1,
+                       s->paired ? s->d_off2 : nullptr, s->n_reads, w, s->d_slot_cnt);
+    size_t tmp = s->scan_tmp_bytes;
+    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_slot_cnt, s->d_slot_off, (int)(s->n_reads + 1), s->st));
+
+    GnMinimiserParams mp{};
+    mp.bases        = s->d_bases;
+    mp.off1         = s->d_off1;
+    mp.off2         = s->paired ? s->d_off2 : nullptr;
+    mp.slot_off     = s->d_slot_off;
+    mp.n_reads      = s->n_reads;
+    mp.k            = k;
+    mp.w            = w;
+    mp.hashes       = s->d_hashes;
+    mp.n_hashes     = s->d_nh;
+    mp.status       = s->d_status;
+    mp.total_hashes = s->d_ctr + 1;
+    GN_HIP(gn_launch_minimiser(mp, f->n_cu, s->st));
+    GN_HIP(hipEventRecord(s->ev[1], s->st));
+
+    int rc = gn_run_count(s);
+    if (rc)
+        return rc;
+    GN_HIP(hipEventRecord(s->ev[2], s->st));
+    rc = gn_run_group(s);
+    if (rc)
+        return rc;
+    GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
+    GN_HIP(hipEventRecord(s->ev[3], s->st));
+    s->classified = true;
+    return GN_OK;
+}
+
+extern "C" int gn_submit_batch(gn_stream* s, const uint8_t* bases, uint64_t n_bases, const uint64_t* off1, const uint64_t* off2,
+                               uint32_t n_reads, uint32_t k, uint32_t w, double rel_cutoff)
+{
+    int rc = gn_stream_upload_reads(s, bases, n_bases, off1, off2, n_reads);
+    if (rc)
+        return rc;
+    return gn_stream_classify(s, k, w, rel_cutoff);
+}
+
+// Waits for the batch; if the device match buffer overflowed, grows it and re-runs count+group.
+static int gn_finish(gn_stream* s)
+{
+    if (!s->classified)
+        return gn_fail(GN_EINVAL, "no classified batch on this stream");
+    GN_HIP(hipSetDevice(s->f->device));
+    for (int attempt = 0; attempt < 4; ++attempt)
+    {
+        GN_HIP(hipStreamSynchronize(s->st));
+        const uint64_t need = s->h_ctr[0];
+        if (need <= s->match_cap)
+        {
+            s->n_matches = need;
+            return GN_OK;
+        }
+        const uint64_t ncap = need + need / 8 + 1024;
+        hipFree(s->d_matches);
+        hipFree(s->d_sorted);
+        s->d_matches = s->d_sorted = nullptr;
+        GN_HIP(gn_dmalloc(&s->d_matches, ncap));
+        GN_HIP(gn_dmalloc(&s->d_sorted, ncap));
+        s->match_cap = ncap;
+        int rc       = gn_run_count(s);
+        if (rc)
+            return rc;
+        rc = gn_run_group(s);
+        if (rc)
+            return rc;
+        GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
+    }
+    return gn_fail(GN_ENODEV, "match buffer kept overflowing");
+}
+
+extern "C" int gn_stream_sync(gn_stream* s)
+{
+    if (!s)
+        return gn_fail(GN_EINVAL, "null stream");
+    if (s->classified)
+        return gn_finish(s);
+    GN_HIP(hipSetDevice(s->f->device));
+    GN_HIP(hipStreamSynchronize(s->st));
+    return GN_OK;
+}
+
+__global__ void gn_pick_offsets_kernel(const uint64_t* seg_off, uint32_t wpr, uint32_t n_reads, uint64_t* match_off)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r <= n_reads)
+        match_off[r] = seg_off[(size_t)r * wpr];
+}
+
+extern "C" int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status, uint64_t* match_off, gn_match* matches,
+                              uint64_t cap, uint64_t* n_matches)
+{
+    if (!s)
+        return gn_fail(GN_EINVAL, "null stream");
+    int rc = gn_finish(s);
+    if (rc)
+        return rc;
+    if (n_matches)
+        *n_matches = s->n_matches;
+    const uint32_t n = s->n_reads;
+    if (n_hashes && n)
+        GN_HIP(hipMemcpyAsync(n_hashes, s->d_nh, (size_t)n * 4, hipMemcpyDeviceToHost, s->st));
+    if (status && n)
+        GN_HIP(hipMemcpyAsync(status, s->d_status, (size_t)n, hipMemcpyDeviceToHost, s->st));
+    if (match_off)
+    {
+        const uint32_t wpr = s->f->is_hibf ? 1 : s->f->geom.wpr;
+        if (wpr == 1)
+            GN_HIP(hipMemcpyAsync(match_off, s->d_seg_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s->st));
+        else
+        {
+            // d_slot_cnt is free after the minimiser kernel: reuse it for the strided pick
+            hipLaunchKernelGGL(gn_pick_offsets_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s->st, s->d_seg_off, wpr, n,
+                               s->d_slot_cnt);
+            GN_HIP(hipMemcpyAsync(match_off, s->d_slot_cnt, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s->st));
+        }
+    }
+    if (matches)
+    {
+        if (cap < s->n_matches)
+        {
+            hipStreamSynchronize(s->st);
+            return gn_fail(GN_EOVERFLOW, "match buffer too small: need %llu, have %llu", (unsigned long long)s->n_matches,
+                           (unsigned long long)cap);
+        }
+        if (s->n_matches)
+            GN_HIP(hipMemcpyAsync(matches, s->d_sorted, s->n_matches * sizeof(gn_match), hipMemcpyDeviceToHost, s->st));
+    }
+    GN_HIP(hipStreamSynchronize(s->st));
+    return GN_OK;
+}
+
+extern "C" int gn_stream_fetch_hashes(gn_stream* s, uint64_t* hash_off, uint64_t* hashes, uint64_t cap, uint64_t* n_total)
+{
+    if (!s || !hash_off)
+        return gn_fail(GN_EINVAL, "null argument");
+    int rc = gn_finish(s);
+    if (rc)
+        return rc;
+    const uint32_t        n = s->n_reads;
+    std::vector<uint64_t> slot(n + 1);
+    std::vector<uint32_t> nh(n);
+    GN_HIP(hipMemcpy(slot.data(), s->d_slot_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+    if (n)
+        GN_HIP(hipMemcpy(nh.data(), s->d_nh, (size_t)n * 4, hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < n; ++r)
+    {
+        hash_off[r] = total;
+        total += nh[r];
+    }
+    hash_off[n] = total;
+    if (n_total)
+        *n_total = total;
+    if (!hashes)
+        return GN_OK;
+    if (cap < total)
+        return gn_fail(GN_EOVERFLOW, "hash buffer too small: need %llu", (unsigned long long)total);
+    std::vector<uint64_t> all(slot[n] ? slot[n] : 1);
+    if (slot[n])
+        GN_HIP(hipMemcpy(all.data(), s->d_hashes, slot[n] * 8, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < n; ++r)
+        if (nh[r])
+            memcpy(hashes + hash_off[r], all.data() + slot[r], (size_t)nh[r] * 8);
+    return GN_OK;
+}
+
+int gn_hibf_dense(gn_stream* s, uint32_t rb, uint32_t re, uint16_t* counts); // gn_hibf.hip
+
+extern "C" int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_t read_end, uint16_t* counts)
+{
+    if (!s || !counts)
+        return gn_fail(GN_EINVAL, "null argument");
+    int rc = gn_finish(s);
+    if (rc)
+        return rc;
+    if (read_begin > read_end || read_end > s->n_reads)
+        return gn_fail(GN_EINVAL, "read range out of bounds");
+    if (read_begin == read_end)
+        return GN_OK;
+    gn_filter* f = s->f;
+    if (f->is_hibf)
+        return gn_hibf_dense(s, read_begin, read_end, counts);
+    const size_t nel = (size_t)(read_end - read_begin) * f->ibf.B;
+    uint16_t*    dd  = nullptr;
+    GN_HIP(gn_dmalloc(&dd, nel));
+    // re-run the count kernel with the dense tap on (matches of this run are discarded)
+    unsigned long long saved[8];
+    memcpy(saved, s->h_ctr, sizeof(saved));
+    GnCountParams p{};
+    p.rows = f->ibf.d_rows; p.S = f->ibf.S; p.W = (uint32_t)f->ibf.W; p.B = (uint32_t)f->ibf.B; p.shift = f->ibf.shift;
+    p.tgt_off = f->identity ? nullptr : f->d_tgt_off; p.tgt_bins = f->d_tgt_bins; p.n_targets = f->n_targets;
+    p.hashes = s->d_hashes; p.slot_off = s->d_slot_off; p.n_hashes = s->d_nh; p.status = s->d_status;
+    p.n_reads = s->n_reads; p.rel_cutoff = s->rel_cutoff; p.wpr = f->geom.wpr; p.gp_log2 = f->geom.gp_log2;
+    p.slice_dwords = f->geom.slice_dwords;
+    p.matches = s->d_matches; p.match_cap = 0; // no writes
+    unsigned long long* dctr = nullptr;
+    hipError_t e = gn_dmalloc(&dctr, 1);
+    if (e != hipSuccess) { hipFree(dd); return gn_fail(GN_ENOMEM, "alloc failed"); }
+    hipMemsetAsync(dctr, 0, 8, s->st);
+    uint64_t* segb = nullptr; uint32_t* segc = nullptr;
+    gn_dmalloc(&segb, (size_t)s->n_reads * f->geom.wpr);
+    gn_dmalloc(&segc, (size_t)s->n_reads * f->geom.wpr);
+    p.cursor = dctr; p.seg_begin = segb; p.seg_count = segc;
+    p.dense = dd; p.dense_begin = read_begin; p.dense_end = read_end;
+    e = gn_launch_count(p, f->geom, f->ibf.h, s->st);
+    hipError_t e2 = hipStreamSynchronize(s->st);
+    if (e == hipSuccess && e2 == hipSuccess)
+        e = hipMemcpy(counts, dd, nel * 2, hipMemcpyDeviceToHost);
+    hipFree(dd); hipFree(dctr); hipFree(segb); hipFree(segc);
+    memcpy(s->h_ctr, saved, sizeof(saved));
+    if (e != hipSuccess || e2 != hipSuccess)
+        return gn_fail(GN_ENODEV, "dense count tap failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return GN_OK;
+}
+
+extern "C" int gn_stream_timings(gn_stream* s, gn_timings* t)
+{
+    if (!s || !t)
+        return gn_fail(GN_EINVAL, "null argument");
+    int rc = gn_finish(s);
+    if (rc)
+        return rc;
+    gn_timings tm{};
+    hipEventElapsedTime(&tm.ms_minimiser, s->ev[0], s->ev[1]);
+    hipEventElapsedTime(&tm.ms_count, s->ev[1], s->ev[2]);
+    hipEventElapsedTime(&tm.ms_total, s->ev[0], s->ev[3]);
+    tm.n_hashes  = s->h_ctr[1];
+    tm.n_matches = s->n_matches;
+    if (s->f->is_hibf)
+        tm.algo_bytes = s->h_ctr[2];
+    else
+        tm.algo_bytes = tm.n_hashes * (uint64_t)s->f->ibf.h * s->f->ibf.W * 8ull;
+    *t = tm;
+    return GN_OK;
+}

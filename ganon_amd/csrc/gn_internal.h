@@ -1,0 +1,201 @@
+// gn_internal.h -- device-side parameter blocks and launchers shared by gn_kernels.hip and gn_capi.hip.
+// gfx950 (MI355X) only.  Not part of the public ABI (that is include/ganon_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/ganon_hip.h"
+
+// ---- minimiser kernel -----------------------------------------------------------------------
+struct GnMinimiserParams
+{
+    const uint8_t*      bases;     // ASCII
+    const uint64_t*     off1;      // n_reads+1
+    const uint64_t*     off2;      // n_reads+1 or nullptr
+    const uint64_t*     slot_off;  // n_reads+1: first hash slot of each read (upper bound = #windows)
+    uint32_t            n_reads;
+    uint32_t            k, w;
+    uint64_t*           hashes;    // slot_off[n_reads] slots
+    uint32_t*           n_hashes;  // per read
+    uint8_t*            status;    // per read GN_READ_*
+    unsigned long long* total_hashes; // sum of n over GN_READ_OK reads
+};
+
+// ---- flat IBF count + select kernel ---------------------------------------------------------
+struct GnCountParams
+{
+    // filter
+    const uint64_t* rows;
+    uint64_t        S;        // rows
+    uint32_t        W;        // words per row
+    uint32_t        B;        // bins
+    uint32_t        shift;    // hash_shift
+    const uint32_t* tgt_off;  // CSR over targets (n_targets+1); nullptr when identity
+    const uint32_t* tgt_bins;
+    const uint32_t* tgt_ids;  // id reported for CSR target t (nullptr = t)
+    uint32_t        n_targets;
+    // batch
+    const uint64_t* hashes;
+    const uint64_t* slot_off;
+    const uint32_t* n_hashes;
+    const uint8_t*  status;
+    uint32_t        n_reads;
+    double          rel_cutoff;
+    // geometry (host-chosen, see gn_count_geometry)
+    uint32_t wpr;      // waves cooperating on one read (power of two)
+    uint32_t gp_log2;  // lanes per hash group = 1 << gp_log2
+    uint32_t slice_dwords; // LDS dwords of one wave's count slice = 32*LW*(Gp+1)
+    // output
+    gn_match*           matches;
+    uint64_t            match_cap;
+    unsigned long long* cursor;
+    uint64_t*           seg_begin;  // n_reads*wpr
+    uint32_t*           seg_count;  // n_reads*wpr
+    // debug tap: dense counts of reads [dense_begin, dense_end)
+    uint16_t* dense;
+    uint32_t  dense_begin, dense_end;
+};
+
+struct GnCountGeometry
+{
+    uint32_t lw;       // words per lane per row (1 or 2)
+    uint32_t wpr;      // waves per read
+    uint32_t gp_log2;  // lanes per group
+    uint32_t block;    // threads per block
+    uint32_t rpb;      // reads per block
+    uint32_t slice_dwords;
+    size_t   lds_bytes;
+};
+
+// returns false (and a message) when the IBF shape is outside what the kernel supports
+bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const char** why);
+
+hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t st);
+hipError_t gn_launch_count(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
+
+// ---- HIBF -----------------------------------------------------------------------------------
+struct GnHibfIbfDev
+{
+    const uint64_t* rows;
+    uint64_t        S;
+    uint32_t        W, B, shift, h;
+    const int32_t*  next_ibf;   // per bin: child ibf index (only meaningful for merged bins)
+    const int32_t*  bin2user;   // per bin: user bin, -1 merged
+    const uint8_t*  run_end;    // per bin: 1 when the running sum is evaluated+reset after this bin
+};
+
+struct GnHibfParams
+{
+    const GnHibfIbfDev* ibfs;    // device array
+    uint32_t            n_ibf;
+    const uint64_t*     hashes;
+    const uint64_t*     slot_off;
+    const uint32_t*     n_hashes;
+    const uint8_t*      status;
+    double              rel_cutoff;
+    // work queue of (read, ibf) items for this level
+    const uint2*        work_in;
+    uint32_t            n_work;
+    uint2*              work_out;
+    uint32_t            work_cap;
+    unsigned int*       work_out_count;
+    // output
+    gn_match*           matches;
+    uint64_t            match_cap;
+    unsigned long long* cursor;
+    unsigned long long* algo_bytes;
+    uint32_t            max_bins; // LDS sizing: max technical bins of any IBF
+};
+
+hipError_t gn_launch_hibf_level(const GnHibfParams& p, hipStream_t st);
+hipError_t gn_launch_hibf_seed(uint2* work, const uint8_t* status, uint32_t n_reads, unsigned int* count, hipStream_t st);
+
+// ---- misc kernels ---------------------------------------------------------------------------
+hipError_t gn_launch_emplace(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h, const uint64_t* hashes,
+                             const uint32_t* bins, uint64_t n, hipStream_t st);
+
+// ---- host-side objects behind the opaque C handles --------------------------------------------
+int gn_fail(int code, const char* fmt, ...);
+
+#define GN_HIP(expr)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e__ = (expr);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return gn_fail(e__ == hipErrorOutOfMemory ? GN_ENOMEM : GN_ENODEV, "%s failed: %s (%s:%d)", #expr,         \
+                           hipGetErrorString(e__), __FILE__, __LINE__);                                                \
+    } while (0)
+
+struct GnIbfHost
+{
+    uint64_t* d_rows = nullptr;
+    uint64_t  S = 0, W = 0, B = 0;
+    uint32_t  h = 0, shift = 0;
+};
+
+struct gn_filter
+{
+    int      device  = 0;
+    int      n_cu    = 256;
+    bool     is_hibf = false;
+    uint64_t device_bytes = 0;
+    // flat
+    GnIbfHost       ibf;
+    uint32_t*       d_tgt_off  = nullptr;
+    uint32_t*       d_tgt_bins = nullptr;
+    uint32_t        n_targets  = 0;
+    bool            identity   = false;
+    GnCountGeometry geom{};
+    // hibf
+    std::vector<GnIbfHost> ibfs;
+    std::vector<void*>     hibf_allocs;
+    GnHibfIbfDev*          d_hibf   = nullptr;
+    uint64_t               n_user_bins = 0;
+    uint32_t               max_bins = 0;
+    uint32_t               max_depth = 0;
+};
+
+struct gn_stream
+{
+    gn_filter*  f  = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t  ev[4]{};
+    uint32_t    max_reads = 0;
+    uint64_t    max_bases = 0;
+    uint64_t    match_cap = 0;
+    // device buffers
+    uint8_t*            d_bases    = nullptr;
+    uint64_t*           d_off1     = nullptr;
+    uint64_t*           d_off2     = nullptr;
+    uint64_t*           d_slot_cnt = nullptr; // n+1 window counts (scan input)
+    uint64_t*           d_slot_off = nullptr; // n+1
+    uint64_t*           d_hashes   = nullptr;
+    uint32_t*           d_nh       = nullptr;
+    uint8_t*            d_status   = nullptr;
+    gn_match*           d_matches  = nullptr; // unordered (reservation order)
+    gn_match*           d_sorted   = nullptr; // grouped by read
+    unsigned long long* d_ctr      = nullptr; // [0] cursor [1] total_hashes [2] algo_bytes [3] work count
+    uint64_t*           d_seg_begin = nullptr;
+    uint32_t*           d_seg_count = nullptr;
+    uint64_t*           d_seg_off   = nullptr; // n*wpr+1 exclusive scan of seg_count
+    void*               d_scan_tmp  = nullptr;
+    size_t              scan_tmp_bytes = 0;
+    // hibf work queues
+    uint2*        d_work[2]{ nullptr, nullptr };
+    uint32_t      work_cap = 0;
+    // pinned host
+    unsigned long long* h_ctr = nullptr;
+    // state
+    uint32_t n_reads = 0;
+    uint64_t n_bases = 0;
+    bool     paired  = false;
+    bool     have_reads = false, classified = false;
+    uint32_t k = 0, w = 0;
+    double   rel_cutoff = 0;
+    uint64_t n_matches = 0;
+    gn_timings tm{};
+};
+

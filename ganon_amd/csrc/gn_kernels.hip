@@ -1,0 +1,631 @@
+// gn_kernels.hip -- hand-written CDNA4 (gfx950, wave64) kernels of the read-classification hot path.
+//
+//   gn_minimiser_kernel   canonical (k,w)-minimiser hashes per read: one wavefront per read, 64 windows
+//                         per tile, k-mer values staged in LDS (sliding window), rightmost-min scan per
+//                         lane, emission resolved with ballots + a scalar expiry chain.
+//                         == seqan3::views::minimiser_hash at /root/reference/src/ganon-classify/GanonClassify.cpp:647-650,693-700
+//   gn_ibf_count_kernel   IBF bulk_count + select_matches: per hash, h row addresses -> coalesced 16 B/lane
+//                         row loads (a 512 B row = 32 lanes x dwordx4), AND-reduced in registers, counted
+//                         with bit-sliced SWAR nibble/byte counters, flushed to LDS, summed per target,
+//                         capped, compared with the per-read cutoff and compacted to sparse matches.
+//                         == counting_agent::bulk_count (GanonClassify.cpp:514) + :516-540
+//   gn_emplace_kernel     IBF emplace (src/ganon-build/GanonBuild.cpp:694) as an atomic OR scatter.
+//
+// Pure integer / bit-vector work: HBM-bound random row gathers, no MFMA anywhere.
+#include "gn_internal.h"
+
+#define GN_WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// dna4 rank table (seqan3::dna4 char_to_rank): ACGT(U) exact, IUPAC collapse, else A
+// ------------------------------------------------------------------------------------------------
+struct GnRankLut
+{
+    uint8_t t[256];
+    constexpr GnRankLut() : t{}
+    {
+        for (int i = 0; i < 256; ++i)
+            t[i] = 0;
+        t['C'] = t['c'] = 1;
+        t['G'] = t['g'] = 2;
+        t['T'] = t['t'] = t['U'] = t['u'] = 3;
+        t['Y'] = t['y'] = 1;
+        t['S'] = t['s'] = 1;
+        t['K'] = t['k'] = 2;
+        t['B'] = t['b'] = 1;
+    }
+};
+__constant__ GnRankLut GN_RANK_LUT = GnRankLut();
+
+// seqan3::interleaved_bloom_filter hash seeds
+__constant__ uint64_t GN_IBF_SEEDS[5] = { 13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL,
+                                          16499269484942379435ULL, 4893150838803335377ULL };
+
+// LDS written by some lanes of a wave and read by other lanes of the SAME wave: the LDS unit executes a
+// wave's DS instructions in issue order, so only compiler reordering has to be prevented.
+__device__ __forceinline__ void gn_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint64_t gn_readlane64(uint64_t v, uint32_t lane_uniform)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, (int)lane_uniform);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)lane_uniform);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// hash_and_fit without the final "* technical_bins": row index of hash function i
+__device__ __forceinline__ uint32_t gn_ibf_row(uint64_t v, uint32_t i, uint32_t shift, uint64_t S)
+{
+    uint64_t x = v * GN_IBF_SEEDS[i];
+    x ^= x >> shift;
+    x *= 11400714819323198485ULL;
+    return (uint32_t)__umul64hi(x, S);
+}
+
+// ================================================================================================
+// minimiser kernel
+// ================================================================================================
+// One mate sequence.  rk: LDS bytes [64 + w - 1], vv: LDS u64 [64 + K - 1].  Returns the number of emitted
+// minimisers (uniform).  Restates SURVEY App. A.1 / App. D in parallel form:
+//   W_j, R_j    = value / absolute position of the RIGHTMOST minimum of window j
+//   seed(j)     = j == 0 || v[j+K-1] < W_{j-1}          (a strictly smaller value enters)
+//   emission e  -> remembered position R_e; the next emission is min(next seed, R_e + 1 (expiry))
+// which is exactly the state machine of seqan3's minimiser view (validated against the oracle).
+__device__ uint32_t gn_mate_minimisers(const uint8_t* __restrict__ seq, uint32_t L, uint32_t k, uint32_t w, uint64_t seed,
+                                       uint8_t* rk, uint64_t* vv, uint64_t* __restrict__ out, int lane)
+{
+    const uint32_t K    = w - k + 1;
+    const uint32_t M    = L - k + 1;
+    const uint32_t nwin = L - w + 1;
+    uint32_t       nout = 0;
+    uint32_t       expiry = 0xFFFFFFFFu; // absolute window index at which the remembered minimiser leaves
+    uint64_t       carryW = 0;
+
+    for (uint32_t T0 = 0; T0 < nwin; T0 += GN_WAVE)
+    {
+        // stage dna4 ranks of bases [T0, T0 + 64 + w - 1)
+        const uint32_t nb = min(GN_WAVE + w - 1, L - T0);
+        for (uint32_t i = lane; i < nb; i += GN_WAVE)
+            rk[i] = GN_RANK_LUT.t[seq[T0 + i]];
+        gn_wave_lds_sync();
+
+        // canonical k-mer values v[T0 .. T0 + 64 + K - 1)
+        const uint32_t nv = min(GN_WAVE + K - 1, M - T0);
+        for (uint32_t i = lane; i < nv; i += GN_WAVE)
+        {
+            uint64_t f = 0, r = 0;
+            for (uint32_t j = 0; j < k; ++j)
+            {
+                const uint64_t b = rk[i + j];
+                f                = (f << 2) | b;
+                r                = (r >> 2) | ((3ULL - b) << (2 * (k - 1)));
+            }
+            const uint64_t a = f ^ seed, c = r ^ seed;
+            vv[i]            = a < c ? a : c;
+        }
+        gn_wave_lds_sync();
+
+        // sliding window: rightmost minimum of v[j .. j+K-1]
+        const uint32_t j     = T0 + lane;
+        const bool     valid = j < nwin;
+        uint64_t       m     = ~0ULL;
+        uint32_t       pos   = 0;
+        if (valid)
+        {
+            m = vv[lane];
+            for (uint32_t i = 1; i < K; ++i)
+            {
+                const uint64_t x = vv[lane + i];
+                if (x <= m)
+                {
+                    m   = x;
+                    pos = i;
+                }
+            }
+        }
+        const uint32_t R = j + pos;
+        uint64_t prevW = __shfl_up((unsigned long long)m, 1);
+        if (lane == 0)
+            prevW = carryW;
+        const bool enters = valid && j > 0 && vv[lane + K - 1] < prevW;
+        uint64_t   seeds  = __ballot(enters);
+        if (T0 == 0)
+            seeds |= 1ULL;
+        const uint32_t tile_n = min((uint32_t)GN_WAVE, nwin - T0);
+
+        // expiry chain (wave-uniform scalar loop; one iteration per emitted minimiser)
+        uint64_t EM = 0;
+        uint32_t p  = 0;
+        while (true)
+        {
+            uint32_t s = GN_WAVE;
+            if (p < GN_WAVE)
+            {
+                const uint64_t rem = seeds >> p;
+                if (rem)
+                    s = p + (uint32_t)__builtin_ctzll(rem);
+            }
+            const uint32_t e2 = (expiry - T0 < (uint32_t)GN_WAVE) ? expiry - T0 : (uint32_t)GN_WAVE; // expiry >= T0 + p
+            uint32_t       e  = s < e2 ? s : e2;
+            e                 = __builtin_amdgcn_readfirstlane(e);
+            if (e >= tile_n)
+                break;
+            EM |= 1ULL << e;
+            expiry = (uint32_t)__builtin_amdgcn_readlane((int)R, (int)e) + 1u;
+            p      = e + 1;
+        }
+
+        if ((EM >> lane) & 1ULL)
+            out[nout + __popcll(EM & ((1ULL << lane) - 1ULL))] = m;
+        nout += __popcll(EM);
+        carryW = gn_readlane64(m, GN_WAVE - 1);
+        gn_wave_lds_sync(); // rk / vv are overwritten by the next tile
+    }
+    return nout;
+}
+
+__global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t gn_smem[];
+    const int      lane      = threadIdx.x & (GN_WAVE - 1);
+    const int      wave      = threadIdx.x >> 6;
+    const uint32_t K         = p.w - p.k + 1;
+    const uint32_t vv_bytes  = (GN_WAVE + K) * 8;
+    const uint32_t rk_bytes  = (GN_WAVE + p.w + 15) & ~15u;
+    uint8_t*       base      = gn_smem + (size_t)wave * (vv_bytes + rk_bytes);
+    uint64_t*      vv        = reinterpret_cast<uint64_t*>(base);
+    uint8_t*       rk        = base + vv_bytes;
+    const uint64_t seed      = 0x8F3F73B5CF1C9ADEULL >> (64u - 2u * p.k); // adjust_seed.hpp:33-37
+    const uint32_t waves_all = gridDim.x * (blockDim.x >> 6);
+    unsigned long long my_total = 0;
+
+    for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + wave; r < p.n_reads; r += waves_all)
+    {
+        const uint64_t b1   = p.off1[r];
+        const uint64_t len1 = p.off1[r + 1] - b1;
+        uint64_t       b2 = 0, len2 = 0;
+        if (p.off2)
+        {
+            b2   = p.off2[r];
+            len2 = p.off2[r + 1] - b2;
+        }
+        uint32_t n  = 0;
+        uint8_t  st = GN_READ_OK;
+        if (len1 < p.w) // GanonClassify.cpp:690,743-747 -- regardless of the mate
+        {
+            st = GN_READ_SMALL;
+        }
+        else
+        {
+            uint64_t* out = p.hashes + p.slot_off[r];
+            n             = gn_mate_minimisers(p.bases + b1, (uint32_t)len1, p.k, p.w, seed, rk, vv, out, lane);
+            if (len2 >= p.w) // :695-700 mate hashes appended
+                n += gn_mate_minimisers(p.bases + b2, (uint32_t)len2, p.k, p.w, seed, rk, vv, out + n, lane);
+            if (n > 65535u) // :674,706 TIntCount = uint16_t
+                st = GN_READ_BIG;
+            else
+                my_total += n;
+        }
+        if (lane == 0)
+        {
+            p.n_hashes[r] = n;
+            p.status[r]   = st;
+        }
+    }
+    if (lane == 0 && my_total)
+        atomicAdd(p.total_hashes, my_total);
+}
+
+hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t st)
+{
+    if (p.n_reads == 0)
+        return hipSuccess;
+    const uint32_t K        = p.w - p.k + 1;
+    const uint32_t per_wave = (GN_WAVE + K) * 8 + ((GN_WAVE + p.w + 15) & ~15u);
+    const size_t   lds      = (size_t)per_wave * 4;
+    uint32_t       blocks   = (p.n_reads + 3) / 4;
+    const uint32_t cap      = (uint32_t)n_cu * 16;
+    if (blocks > cap)
+        blocks = cap;
+    hipLaunchKernelGGL(gn_minimiser_kernel, dim3(blocks), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// IBF count + select kernel
+// ================================================================================================
+// Geometry.  A lane owns LW consecutive 64-bit words (LW*64 bins) of the row; Gp lanes (power of two)
+// cover one wave's share of the row, so H = 64/Gp hashes are processed per wave iteration (for the
+// 512-byte rows of a 4096-bin IBF: LW = 2 -> 16 B per lane, Gp = 32, H = 2).  Rows wider than 64*LW words
+// are split over `wpr` cooperating waves (column slices).
+//
+// Counting.  The AND-ed 32-bit mask words are added into bit-sliced SWAR counters: 4 nibble registers
+// per mask dword (bits j, j+4, ...), flushed every 15 iterations (and at the end) into 16-bit LDS
+// counters with ds_add_u32 on u16 pairs.  LDS layout of a slice: dword(q, gl) at q*(Gp+1)+gl where gl is
+// the lane in its group and q = 16*d + t/2 indexes the lane's u16 pairs (d mask dword, t bit) --
+// bank-conflict free for the flush (fixed q, consecutive gl) and for the select scan (fixed gl,
+// consecutive q; stride Gp+1 is odd).
+bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const char** why)
+{
+    if (hash_funs < 1 || hash_funs > 5)
+    {
+        *why = "hash_funs must be 1..5";
+        return false;
+    }
+    if (W == 0)
+    {
+        *why = "empty filter";
+        return false;
+    }
+    g->lw                 = (W % 2 == 0) ? 2u : 1u;
+    const uint64_t per_wv = 64ull * g->lw; // words per wave slice
+    uint64_t       wpr    = (W + per_wv - 1) / per_wv;
+    uint32_t       wpr2   = 1;
+    while (wpr2 < wpr)
+        wpr2 <<= 1;
+    if (wpr2 > 16)
+    {
+        *why = "rows wider than 16 wave slices (bins > 131072 for even bin_words) are not supported by the flat "
+               "count kernel yet; partition the filter by bin range";
+        return false;
+    }
+    g->wpr           = wpr2;
+    uint64_t lanes   = (W < per_wv ? W : per_wv) / g->lw; // lanes needed in a wave (exact: W even if lw==2)
+    if ((W < per_wv ? W : per_wv) % g->lw)
+        ++lanes;
+    uint32_t gp_log2 = 0;
+    while ((1u << gp_log2) < lanes)
+        ++gp_log2;
+    g->gp_log2       = gp_log2;
+    g->block         = wpr2 * 64 > 256 ? wpr2 * 64 : 256;
+    g->rpb           = (g->block / 64) / wpr2;
+    g->slice_dwords  = 32 * g->lw * ((1u << gp_log2) + 1);
+    const size_t cnt = (size_t)g->rpb * wpr2 * g->slice_dwords * 4;
+    const size_t tab = (size_t)(g->block / 64) * 64 * 8 * 4; // row table: 64 hashes x (up to 8 padded) u32
+    g->lds_bytes     = cnt + tab;
+    if (g->lds_bytes > 160 * 1024)
+    {
+        *why = "per-read count vector does not fit LDS";
+        return false;
+    }
+    return true;
+}
+
+template <int HF, int LW>
+struct GnRowRegs
+{
+    uint32_t m[HF][2 * LW];
+};
+
+template <int HF, int LW, int MAXT>
+__global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t gn_lds[];
+    constexpr int ND  = 2 * LW;      // mask dwords per lane
+    constexpr int HFP = HF <= 4 ? 4 : 8; // padded row-table stride (u32)
+
+    const int      lane   = threadIdx.x & (GN_WAVE - 1);
+    const int      wave   = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint32_t wpr    = p.wpr;
+    const uint32_t rpb    = nwaves / wpr;
+    const uint32_t rslot  = wave / wpr;
+    const uint32_t slice  = wave % wpr;
+    const uint32_t Gp     = 1u << p.gp_log2;
+    const uint32_t H      = GN_WAVE >> p.gp_log2;
+    const uint32_t gl     = lane & (Gp - 1);
+    const uint32_t hsub   = lane >> p.gp_log2;
+
+    uint32_t* cnt_read = gn_lds + (size_t)rslot * wpr * p.slice_dwords; // all slices of my read
+    uint32_t* cnt      = cnt_read + (size_t)slice * p.slice_dwords;     // my slice
+    uint32_t* rowtab   = gn_lds + (size_t)rpb * wpr * p.slice_dwords + (size_t)wave * 64 * 8;
+
+    const uint32_t read = blockIdx.x * rpb + rslot;
+    uint32_t       n    = 0;
+    if (read < p.n_reads && p.status[read] == GN_READ_OK)
+        n = p.n_hashes[read];
+
+    // zero my slice
+    for (uint32_t i = lane; i < p.slice_dwords; i += GN_WAVE)
+        cnt[i] = 0;
+
+    const uint32_t wi      = slice * 64 * LW + gl * LW; // first word of this lane in the row
+    const bool     col_act = wi < p.W;
+    const uint64_t* hs     = p.hashes + (n ? p.slot_off[read] : 0);
+
+    uint32_t nib[ND][4];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            nib[d][j] = 0;
+    uint32_t acc_n = 0; // iterations since the last flush (wave-uniform)
+
+    // nibble counters -> 16-bit LDS counters.  nib[d][j] nibble i counts bit t = 4i + j of mask dword d; the u16
+    // pair (t, t+1), t = 4i + 2jp, lives in LDS dword q = 16d + 2i + jp.  Every register index is a
+    // compile-time constant (macro expansion) so nothing is demoted to scratch.
+#define GN_FLUSH_PAIR(d, jp, src_b, src_a, y, i)                                                                       \
+    atomicAdd(&cnt[(16 * (d) + 2 * (i) + (jp)) * (Gp + 1) + gl],                                                       \
+              __builtin_amdgcn_perm(src_b, src_a, 0x0C000C00u | ((4u + (y)) << 16) | (uint32_t)(y)));
+#define GN_FLUSH_DJ(d, jp)                                                                                             \
+    {                                                                                                                  \
+        const uint32_t a0_ = nib[d][2 * (jp)] & 0x0F0F0F0Fu, a1_ = (nib[d][2 * (jp)] >> 4) & 0x0F0F0F0Fu;              \
+        const uint32_t b0_ = nib[d][2 * (jp) + 1] & 0x0F0F0F0Fu, b1_ = (nib[d][2 * (jp) + 1] >> 4) & 0x0F0F0F0Fu;      \
+        GN_FLUSH_PAIR(d, jp, b0_, a0_, 0, 0)                                                                           \
+        GN_FLUSH_PAIR(d, jp, b1_, a1_, 0, 1)                                                                           \
+        GN_FLUSH_PAIR(d, jp, b0_, a0_, 1, 2)                                                                           \
+        GN_FLUSH_PAIR(d, jp, b1_, a1_, 1, 3)                                                                           \
+        GN_FLUSH_PAIR(d, jp, b0_, a0_, 2, 4)                                                                           \
+        GN_FLUSH_PAIR(d, jp, b1_, a1_, 2, 5)                                                                           \
+        GN_FLUSH_PAIR(d, jp, b0_, a0_, 3, 6)                                                                           \
+        GN_FLUSH_PAIR(d, jp, b1_, a1_, 3, 7)                                                                           \
+        nib[d][2 * (jp)]     = 0;                                                                                      \
+        nib[d][2 * (jp) + 1] = 0;                                                                                      \
+    }
+    auto flush_nibbles = [&]() {
+        if (col_act)
+        {
+            GN_FLUSH_DJ(0, 0)
+            GN_FLUSH_DJ(0, 1)
+            GN_FLUSH_DJ(1, 0)
+            GN_FLUSH_DJ(1, 1)
+            if constexpr (ND == 4)
+            {
+                GN_FLUSH_DJ(2, 0)
+                GN_FLUSH_DJ(2, 1)
+                GN_FLUSH_DJ(3, 0)
+                GN_FLUSH_DJ(3, 1)
+            }
+        }
+    };
+
+    // ---- hashes in chunks of 64: row table in LDS, then H hashes per wave iteration ----
+    for (uint32_t c0 = 0; c0 < n; c0 += 64)
+    {
+        const uint32_t mch = min(64u, n - c0);
+        gn_wave_lds_sync();
+        for (uint32_t idx = lane; idx < mch * HF; idx += GN_WAVE)
+        {
+            const uint32_t q = idx / HF, i = idx - q * HF;
+            rowtab[q * HFP + i] = gn_ibf_row(hs[c0 + q], i, p.shift, p.S);
+        }
+        gn_wave_lds_sync();
+
+        const uint32_t iters = (mch + H - 1) / H;
+
+        auto issue = [&](uint32_t it, GnRowRegs<HF, LW>& R) {
+            const uint32_t q   = it * H + hsub;
+            const bool     act = col_act && q < mch;
+            if (act) // one exec-masked region: all HF row loads are issued back to back
+            {
+                uint32_t row[HF];
+#pragma unroll
+                for (int i = 0; i < HF; ++i)
+                    row[i] = rowtab[q * HFP + i];
+#pragma unroll
+                for (int i = 0; i < HF; ++i)
+                {
+                    const uint64_t* ptr = p.rows + ((uint64_t)row[i] * p.W + wi);
+                    if constexpr (LW == 2)
+                    {
+                        const uint4 v = *reinterpret_cast<const uint4*>(ptr);
+                        R.m[i][0] = v.x;
+                        R.m[i][1] = v.y;
+                        R.m[i][2] = v.z;
+                        R.m[i][3] = v.w;
+                    }
+                    else
+                    {
+                        const uint2 v = *reinterpret_cast<const uint2*>(ptr);
+                        R.m[i][0] = v.x;
+                        R.m[i][1] = v.y;
+                    }
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < HF; ++i)
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        R.m[i][d] = 0;
+            }
+        };
+        auto consume = [&](const GnRowRegs<HF, LW>& R) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+            {
+                uint32_t a = R.m[0][d];
+#pragma unroll
+                for (int i = 1; i < HF; ++i)
+                    a &= R.m[i][d];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    nib[d][j] += (a >> j) & 0x11111111u;
+            }
+            if (++acc_n == 15)
+            {
+                flush_nibbles();
+                acc_n = 0;
+            }
+        };
+
+        GnRowRegs<HF, LW> A, Bq;
+        issue(0, A);
+        for (uint32_t it = 0; it < iters; it += 2)
+        {
+            if (it + 1 < iters)
+                issue(it + 1, Bq);
+            consume(A);
+            if (it + 1 < iters)
+            {
+                if (it + 2 < iters)
+                    issue(it + 2, A);
+                consume(Bq);
+            }
+        }
+    }
+    if (acc_n)
+        flush_nibbles();
+    __syncthreads();
+
+    // ---- count of bin b of my read from the sliced LDS layout ----
+    auto bin_count = [&](uint32_t b) -> uint32_t {
+        const uint32_t word = b >> 6;
+        const uint32_t sl   = word / (64 * LW);
+        const uint32_t wl   = word - sl * 64 * LW;
+        const uint32_t g    = wl / LW;
+        const uint32_t tp   = (wl - g * LW) * 64 + (b & 63); // bit inside the lane's LW*64 bits
+        const uint32_t d = tp >> 5, t = tp & 31;
+        const uint32_t q = 16 * d + (t >> 1), half = t & 1;
+        const uint32_t v = cnt_read[(size_t)sl * p.slice_dwords + q * (Gp + 1) + g];
+        return half ? (v >> 16) : (v & 0xFFFFu);
+    };
+
+    const uint32_t tir   = slice * GN_WAVE + lane; // thread in read
+    const uint32_t lanes = wpr * GN_WAVE;
+
+    if (p.dense && read >= p.dense_begin && read < p.dense_end && read < p.n_reads)
+    {
+        uint16_t* dst = p.dense + (size_t)(read - p.dense_begin) * p.B;
+        for (uint32_t b = tir; b < p.B; b += lanes)
+            dst[b] = (uint16_t)(n ? bin_count(b) : 0);
+    }
+
+    // ---- select_matches: sum target bins, cap at n, cutoff, compact (GanonClassify.cpp:516-540) ----
+    if (read < p.n_reads)
+    {
+        // threshold_cutoff = max(1, ceil(n * rel_cutoff)) in IEEE double (:492-495,720-724)
+        uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
+        if (T == 0)
+            T = 1;
+        // targets of this wave: [t_lo, t_hi), chunk-major inside the wave so that LDS reads are conflict free
+        const uint32_t per_wave = (p.n_targets + wpr - 1) / wpr;
+        const uint32_t t_lo     = min(p.n_targets, slice * per_wave);
+        const uint32_t t_hi     = min(p.n_targets, t_lo + per_wave);
+
+        auto target_count = [&](uint32_t t) -> uint32_t {
+            uint32_t s;
+            if (p.tgt_off == nullptr)
+                s = bin_count(t);
+            else
+            {
+                s = 0;
+                const uint32_t e = p.tgt_off[t + 1];
+                for (uint32_t x = p.tgt_off[t]; x < e; ++x)
+                    s += bin_count(p.tgt_bins[x]);
+            }
+            return s > n ? n : s; // :525-526
+        };
+
+        uint32_t total = 0;
+        if (n)
+            for (uint32_t t0 = t_lo; t0 < t_hi; t0 += GN_WAVE)
+            {
+                const uint32_t t   = t0 + lane;
+                const bool     hit = t < t_hi && target_count(t) >= T;
+                total += __popcll(__ballot(hit));
+            }
+        unsigned long long base = 0;
+        if (total)
+        {
+            if (lane == 0)
+                base = atomicAdd(p.cursor, (unsigned long long)total);
+            base = gn_readlane64(base, 0);
+            if (base + total <= p.match_cap)
+            {
+                uint32_t run = 0;
+                for (uint32_t t0 = t_lo; t0 < t_hi; t0 += GN_WAVE)
+                {
+                    const uint32_t t   = t0 + lane;
+                    uint32_t       c   = 0;
+                    bool           hit = false;
+                    if (t < t_hi)
+                    {
+                        c   = target_count(t);
+                        hit = c >= T;
+                    }
+                    const uint64_t bm = __ballot(hit);
+                    if (hit)
+                    {
+                        gn_match mt;
+                        mt.read   = read;
+                        mt.target = p.tgt_ids ? p.tgt_ids[t] : t;
+                        mt.count  = c;
+                        p.matches[base + run + __popcll(bm & ((1ULL << lane) - 1ULL))] = mt;
+                    }
+                    run += __popcll(bm);
+                }
+            }
+        }
+        if (lane == 0)
+        {
+            p.seg_begin[(size_t)read * wpr + slice] = base;
+            p.seg_count[(size_t)read * wpr + slice] = total;
+        }
+    }
+}
+
+template <int HF, int LW, int MAXT>
+static hipError_t gn_launch_count_one(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
+{
+    const uint32_t blocks = (p.n_reads + g.rpb - 1) / g.rpb;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_ibf_count_kernel<HF, LW, MAXT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
+    hipLaunchKernelGGL((gn_ibf_count_kernel<HF, LW, MAXT>), dim3(blocks), dim3(g.block), g.lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+template <int HF>
+static hipError_t gn_launch_count_hf(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
+{
+    if (g.block <= 256)
+        return g.lw == 2 ? gn_launch_count_one<HF, 2, 256>(p, g, st) : gn_launch_count_one<HF, 1, 256>(p, g, st);
+    return g.lw == 2 ? gn_launch_count_one<HF, 2, 1024>(p, g, st) : gn_launch_count_one<HF, 1, 1024>(p, g, st);
+}
+
+hipError_t gn_launch_count(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st)
+{
+    if (p.n_reads == 0)
+        return hipSuccess;
+    switch (hash_funs)
+    {
+        case 1: return gn_launch_count_hf<1>(p, g, st);
+        case 2: return gn_launch_count_hf<2>(p, g, st);
+        case 3: return gn_launch_count_hf<3>(p, g, st);
+        case 4: return gn_launch_count_hf<4>(p, g, st);
+        case 5: return gn_launch_count_hf<5>(p, g, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ================================================================================================
+// emplace (GPU side of the fixture/bench filter builder): set bit (row_i(v), bin) for i < h
+// ================================================================================================
+__global__ void gn_emplace_kernel(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h,
+                                  const uint64_t* __restrict__ hashes, const uint32_t* __restrict__ bins, uint64_t n)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * h)
+        return;
+    const uint64_t q   = idx / h;
+    const uint32_t i   = (uint32_t)(idx - q * h);
+    const uint32_t bin = bins[q];
+    const uint32_t row = gn_ibf_row(hashes[q], i, shift, S);
+    atomicOr(reinterpret_cast<unsigned long long*>(rows + ((uint64_t)row * W + (bin >> 6))), 1ULL << (bin & 63));
+}
+
+hipError_t gn_launch_emplace(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h, const uint64_t* hashes,
+                             const uint32_t* bins, uint64_t n, hipStream_t st)
+{
+    if (n == 0)
+        return hipSuccess;
+    const uint64_t total  = n * h;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256);
+    hipLaunchKernelGGL(gn_emplace_kernel, dim3(blocks), dim3(256), 0, st, rows, S, W, shift, h, hashes, bins, n);
+    return hipGetLastError();
+}

@@ -1,0 +1,239 @@
+"""ctypes mirror of include/ganon_hip.h (the C ABI of libganon_hip.so).  No torch types, no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "csrc", "libganon_hip.so")
+
+READ_OK, READ_SMALL, READ_BIG = 0, 1, 2
+MATCH_DTYPE = np.dtype([("read", "<u4"), ("target", "<u4"), ("count", "<u4")])
+
+# every symbol include/ganon_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_filter_upload_hibf", "gn_filter_emplace",
+               "gn_filter_download_rows", "gn_filter_info", "gn_filter_free", "gn_stream_create", "gn_stream_destroy",
+               "gn_stream_upload_reads", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch",
+               "gn_stream_fetch_hashes", "gn_stream_dense_counts", "gn_stream_timings"]
+
+
+class GanonHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libganon_hip error {code}: {msg}")
+        self.code = code
+
+
+class IbfDesc(C.Structure):
+    _fields_ = [("rows", C.c_void_p), ("bin_size", C.c_uint64), ("bin_words", C.c_uint64), ("bins", C.c_uint64),
+                ("hash_funs", C.c_uint32), ("hash_shift", C.c_uint32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms_minimiser", C.c_float), ("ms_count", C.c_float), ("ms_total", C.c_float),
+                ("n_hashes", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_matches", C.c_uint64)]
+
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree libganon_hip.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise GanonHipError(-19, f"{_LIB_PATH} is missing: run `python -m ganon_amd.build` (hipcc, gfx950). "
+                                 "There is no CPU fallback.")
+    L = C.CDLL(_LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.gn_last_error.restype = C.c_char_p
+    L.gn_device_count.argtypes = [C.POINTER(i32)]
+    L.gn_filter_upload_ibf.argtypes = [i32, C.POINTER(IbfDesc), vp, u32, C.POINTER(vp)]
+    L.gn_filter_upload_hibf.argtypes = [i32, u32, C.POINTER(IbfDesc), C.POINTER(vp), C.POINTER(vp), u64, C.POINTER(vp)]
+    L.gn_filter_emplace.argtypes = [vp, vp, vp, u64]
+    L.gn_filter_download_rows.argtypes = [vp, u32, u64, u64, vp]
+    L.gn_filter_info.argtypes = [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+    L.gn_filter_free.argtypes = [vp]
+    L.gn_stream_create.argtypes = [vp, u32, u64, u64, C.POINTER(vp)]
+    L.gn_stream_destroy.argtypes = [vp]
+    L.gn_stream_upload_reads.argtypes = [vp, vp, u64, vp, vp, u32]
+    L.gn_stream_classify.argtypes = [vp, u32, u32, C.c_double]
+    L.gn_submit_batch.argtypes = [vp, vp, u64, vp, vp, u32, u32, u32, C.c_double]
+    L.gn_stream_sync.argtypes = [vp]
+    L.gn_fetch_batch.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
+    L.gn_stream_fetch_hashes.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+    L.gn_stream_dense_counts.argtypes = [vp, u32, u32, vp]
+    L.gn_stream_timings.argtypes = [vp, C.POINTER(Timings)]
+    for name in ABI_SYMBOLS:
+        if name != "gn_last_error":
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise GanonHipError(rc, load_library().gn_last_error().decode(errors="replace"))
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(load_library().gn_device_count(C.byref(n)))
+    return n.value
+
+
+def _desc(rows: Optional[np.ndarray], bins: int, bin_size: int, hash_funs: int) -> IbfDesc:
+    W = (bins + 63) >> 6
+    shift = 64 - int(bin_size).bit_length()
+    if rows is not None:
+        assert rows.dtype == np.uint64 and rows.size == bin_size * W and rows.flags["C_CONTIGUOUS"]
+    return IbfDesc(rows.ctypes.data if rows is not None else None, bin_size, W, bins, hash_funs, shift)
+
+
+class HipFilter:
+    """Device-resident, immutable IBF / HIBF (gn_filter)."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep
+
+    @classmethod
+    def ibf(cls, rows: Optional[np.ndarray], bins: int, bin_size: int, hash_funs: int,
+            bin2target: Optional[np.ndarray] = None, n_targets: Optional[int] = None, device: int = 0) -> "HipFilter":
+        if bin2target is None:
+            bin2target = np.arange(bins, dtype=np.uint32)
+            n_targets = bins
+        bin2target = np.ascontiguousarray(bin2target, dtype=np.uint32)
+        if n_targets is None:
+            n_targets = int(bin2target[bin2target != 0xFFFFFFFF].max()) + 1
+        d = _desc(rows, bins, bin_size, hash_funs)
+        h = C.c_void_p()
+        _check(load_library().gn_filter_upload_ibf(device, C.byref(d), _p(bin2target), n_targets, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def hibf(cls, ibfs: Sequence[Tuple[np.ndarray, int, int, int]], next_ibf_id: Sequence[np.ndarray],
+             bin2user: Sequence[np.ndarray], n_user_bins: int, device: int = 0) -> "HipFilter":
+        """ibfs: sequence of (rows, bins, bin_size, hash_funs)."""
+        n = len(ibfs)
+        descs = (IbfDesc * n)(*[_desc(r, b, s, hf) for r, b, s, hf in ibfs])
+        nx = [np.ascontiguousarray(a, dtype=np.int64) for a in next_ibf_id]
+        bu = [np.ascontiguousarray(a, dtype=np.int64) for a in bin2user]
+        nxp = (C.c_void_p * n)(*[a.ctypes.data for a in nx])
+        bup = (C.c_void_p * n)(*[a.ctypes.data for a in bu])
+        h = C.c_void_p()
+        _check(load_library().gn_filter_upload_hibf(device, n, descs, nxp, bup, n_user_bins, C.byref(h)))
+        return cls(h, keep=(nx, bu))
+
+    def emplace(self, hashes: np.ndarray, bins: np.ndarray) -> None:
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        bins = np.ascontiguousarray(bins, dtype=np.uint32)
+        assert len(hashes) == len(bins)
+        _check(load_library().gn_filter_emplace(self._h, _p(hashes), _p(bins), len(hashes)))
+
+    def download_rows(self, row_begin: int, n_rows: int, words: int, ibf_idx: int = 0) -> np.ndarray:
+        out = np.empty((n_rows, words), dtype=np.uint64)
+        _check(load_library().gn_filter_download_rows(self._h, ibf_idx, row_begin, n_rows, _p(out)))
+        return out
+
+    def info(self) -> dict:
+        a, b, c, d = C.c_int(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(load_library().gn_filter_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(is_hibf=bool(a.value), n_ibf=b.value, n_targets=c.value, device_bytes=d.value)
+
+    def free(self) -> None:
+        if self._h:
+            load_library().gn_filter_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class HipStream:
+    """Batch context (gn_stream): upload reads, classify, fetch sparse matches."""
+
+    def __init__(self, flt: HipFilter, max_reads: int, max_bases: int, max_matches: int = 0):
+        self._f = flt
+        self._h = C.c_void_p()
+        _check(load_library().gn_stream_create(flt._h, max_reads, max_bases, max_matches, C.byref(self._h)))
+        self.n_reads = 0
+
+    def upload(self, bases: np.ndarray, off1: np.ndarray, off2: Optional[np.ndarray] = None) -> None:
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off1 = np.ascontiguousarray(off1, dtype=np.uint64)
+        if off2 is not None:
+            off2 = np.ascontiguousarray(off2, dtype=np.uint64)
+        self.n_reads = len(off1) - 1
+        self._keep = (bases, off1, off2)
+        _check(load_library().gn_stream_upload_reads(self._h, _p(bases), bases.size, _p(off1), _p(off2), self.n_reads))
+
+    def classify(self, k: int, w: int, rel_cutoff: float) -> None:
+        _check(load_library().gn_stream_classify(self._h, k, w, float(rel_cutoff)))
+
+    def submit(self, bases, off1, off2, k: int, w: int, rel_cutoff: float) -> None:
+        self.upload(bases, off1, off2)
+        self.classify(k, w, rel_cutoff)
+
+    def sync(self) -> None:
+        _check(load_library().gn_stream_sync(self._h))
+
+    def fetch(self):
+        """-> (n_hashes u32[n], status u8[n], match_off u64[n+1], matches MATCH_DTYPE[m])"""
+        L = load_library()
+        n = self.n_reads
+        nh = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8)
+        mo = np.zeros(n + 1, dtype=np.uint64)
+        need = C.c_uint64(0)
+        _check(L.gn_fetch_batch(self._h, _p(nh), _p(st), _p(mo), None, 0, C.byref(need)))
+        m = np.zeros(max(int(need.value), 1), dtype=MATCH_DTYPE)
+        _check(L.gn_fetch_batch(self._h, None, None, None, _p(m), len(m), C.byref(need)))
+        return nh, st, mo, m[: int(need.value)]
+
+    def fetch_hashes(self):
+        """-> (hash_off u64[n+1], hashes u64[total]) in emission order (parity tap)."""
+        L = load_library()
+        n = self.n_reads
+        ho = np.zeros(n + 1, dtype=np.uint64)
+        tot = C.c_uint64(0)
+        _check(L.gn_stream_fetch_hashes(self._h, _p(ho), None, 0, C.byref(tot)))
+        hs = np.zeros(max(int(tot.value), 1), dtype=np.uint64)
+        _check(L.gn_stream_fetch_hashes(self._h, _p(ho), _p(hs), len(hs), C.byref(tot)))
+        return ho, hs[: int(tot.value)]
+
+    def dense_counts(self, read_begin: int, read_end: int, width: int) -> np.ndarray:
+        out = np.zeros((read_end - read_begin, width), dtype=np.uint16)
+        _check(load_library().gn_stream_dense_counts(self._h, read_begin, read_end, _p(out)))
+        return out
+
+    def timings(self) -> dict:
+        t = Timings()
+        _check(load_library().gn_stream_timings(self._h, C.byref(t)))
+        return dict(ms_minimiser=t.ms_minimiser, ms_count=t.ms_count, ms_total=t.ms_total, n_hashes=t.n_hashes,
+                    algo_bytes=t.algo_bytes, n_matches=t.n_matches)
+
+    def destroy(self) -> None:
+        if self._h:
+            load_library().gn_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

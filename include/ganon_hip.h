@@ -1,0 +1,149 @@
+/*
+ * ganon_hip.h -- C ABI of libganon_hip.so: ganon's read-classification hot path on MI355X.
+ *
+ * This is the drop-in boundary.  It replaces exactly the two SeqAn3 call sites
+ * of the reference's per-read loop and the per-read target selection that consumes them:
+ *
+ *   /root/reference/src/ganon-classify/GanonClassify.cpp:693-700
+ *        hashes = seq | seqan3::views::minimiser_hash(k, w, adjust_seed(k))       -> gn_submit_batch
+ *   /root/reference/src/ganon-classify/GanonClassify.cpp:514   (IBF)  agent.bulk_count(hashes)
+ *   /root/reference/src/ganon-classify/GanonClassify.cpp:553   (HIBF) agent.bulk_count(hashes, thr)
+ *   /root/reference/src/ganon-classify/GanonClassify.cpp:516-540 / :556-576  per-target sum, cap,
+ *        cutoff test of select_matches                                              -> gn_fetch_batch
+ *
+ * Plain C: caller-owned host buffers, no exceptions, no globals besides a thread-local error
+ * string.  Every function returns 0 on success or a negative GN_E* code; gn_last_error() gives
+ * the message.  A gn_filter is immutable after upload and may be shared by any number of
+ * gn_streams / host threads (mirrors "const member functions are thread-safe, one agent per
+ * thread", hierarchical_interleaved_bloom_filter.hpp:79-83,501-504).  One gn_stream per host
+ * worker thread; a stream owns a HIP stream, device batch buffers and pinned staging.
+ *
+ * There is no CPU fallback: every entry point fails (GN_ENODEV) when no HIP device is usable.
+ */
+#ifndef GANON_HIP_H
+#define GANON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GN_OK 0
+#define GN_EINVAL (-22)   /* bad argument */
+#define GN_ENOMEM (-12)   /* host/device allocation failed */
+#define GN_ENODEV (-19)   /* no usable HIP device / HIP runtime error */
+#define GN_ERANGE (-34)   /* configuration outside what the kernels support (message says which) */
+#define GN_EOVERFLOW (-75) /* caller's match buffer too small; *n_matches holds the needed size */
+
+typedef struct gn_filter gn_filter;
+typedef struct gn_stream gn_stream;
+
+/* One flat interleaved Bloom filter as laid out by seqan3::interleaved_bloom_filter<uncompressed>
+ * (the .ibf payload verbatim): word(row r, batch b) = rows[r*bin_words + b],
+ * bit j of that word <-> bin 64*b + j. */
+typedef struct
+{
+    const uint64_t* rows;      /* host pointer, bin_size*bin_words words; NULL = allocate zero-filled on device */
+    uint64_t        bin_size;  /* S: rows (bin_size_, the number of bits of one Bloom filter) */
+    uint64_t        bin_words; /* W = ceil(bins/64) */
+    uint64_t        bins;      /* B: bin_count() */
+    uint32_t        hash_funs; /* h <= 5 */
+    uint32_t        hash_shift; /* countl_zero(bin_size) */
+} gn_ibf_desc;
+
+/* sparse result of select_matches for one (read, target): count already summed over the target's
+ * bins and capped at n_hashes (GanonClassify.cpp:519-526 / :561-564), and >= the read's cutoff. */
+typedef struct
+{
+    uint32_t read;   /* index in the batch */
+    uint32_t target; /* caller's target id (IBF: bin2target[], HIBF: user bin index) */
+    uint32_t count;
+} gn_match;
+
+/* per-read status written by gn_fetch_batch (GanonClassify.cpp:690,706) */
+#define GN_READ_OK 0
+#define GN_READ_SMALL 1 /* len(read1) < window_size: skipped, regardless of the mate (:690,743-747) */
+#define GN_READ_BIG 2   /* more than 65535 minimisers: skipped (:674,706,737-741) */
+
+/* device timings of the last gn_stream_classify, measured with hipEvents on the stream's HIP stream */
+typedef struct
+{
+    float    ms_minimiser; /* gn_minimiser_kernel */
+    float    ms_count;     /* IBF/HIBF count + select kernels */
+    float    ms_total;     /* first kernel start -> last kernel end */
+    uint64_t n_hashes;     /* minimisers of the batch (sum over reads that were counted) */
+    uint64_t algo_bytes;   /* algorithmic row bytes: sum n*h*W*8 over every IBF visited */
+    uint64_t n_matches;
+} gn_timings;
+
+int         gn_device_count(int* n);
+const char* gn_last_error(void);
+
+/* ---- filters ------------------------------------------------------------------------------- */
+
+/* Flat IBF.  bin2target[b] (b < bins) = caller's target id of technical bin b, or 0xFFFFFFFF for
+ * bins that belong to no target (replaces Filter::map, GanonClassify.cpp:279-287,1021-1025);
+ * target ids must be < n_targets.  A target may own any set of bins (split bins, :516-523). */
+int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const uint32_t* bin2target, uint32_t n_targets,
+                         gn_filter** out);
+
+/* HIBF (raptor 3.0.1 layout, hierarchical_interleaved_bloom_filter.hpp:124-136,188):
+ * next_ibf_id[i][b] and bin2userbin[i][b] (-1 = merged bin) for every bin b < ibfs[i].bins.
+ * Reported target id = user bin index (ibf_bin_to_filename_position). */
+int gn_filter_upload_hibf(int device, uint32_t n_ibf, const gn_ibf_desc* ibfs, const int64_t* const* next_ibf_id,
+                          const int64_t* const* bin2userbin, uint64_t n_user_bins, gn_filter** out);
+
+/* OR minimiser hashes into technical bins of a flat IBF on the device (interleaved_bloom_filter::emplace,
+ * call site src/ganon-build/GanonBuild.cpp:694).  n (hash, bin) pairs in host memory. */
+int gn_filter_emplace(gn_filter* f, const uint64_t* hashes, const uint32_t* bins, uint64_t n);
+
+/* copy rows [row_begin, row_begin+n_rows) of IBF `ibf_idx` back to the host (tests / sampling parity) */
+int gn_filter_download_rows(const gn_filter* f, uint32_t ibf_idx, uint64_t row_begin, uint64_t n_rows, uint64_t* out);
+
+int gn_filter_info(const gn_filter* f, int* is_hibf, uint32_t* n_ibf, uint64_t* n_targets, uint64_t* device_bytes);
+int gn_filter_free(gn_filter* f);
+
+/* ---- streams ------------------------------------------------------------------------------- */
+
+/* max_matches = capacity of the device match buffer; 0 picks max_reads*4 (it grows on demand). */
+int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_bases, uint64_t max_matches, gn_stream** out);
+int gn_stream_destroy(gn_stream* s);
+
+/* Batch layout: `bases` holds ASCII nucleotides (dna15 alphabet, any case; converted to dna4 ranks on
+ * the device exactly like seqan3::dna4).  Read i = bases[off1[i] .. off1[i+1]) and, if
+ * off2 != NULL, its mate = bases[off2[i] .. off2[i+1]).  off1/off2 have n_reads+1 entries.
+ * k, w: minimiser shape; the seed is adjust_seed(k) (src/utils/include/utils/adjust_seed.hpp:33-37).
+ * rel_cutoff: per-read cutoff T = max(1, ceil(n_hashes*rel_cutoff)) computed in IEEE double on the
+ * device, bit-identical to GanonClassify.cpp:492-495,720-724. */
+
+/* H2D only (asynchronous on the stream). */
+int gn_stream_upload_reads(gn_stream* s, const uint8_t* bases, uint64_t n_bases, const uint64_t* off1,
+                           const uint64_t* off2, uint32_t n_reads);
+/* Kernels only, on the reads currently resident in the stream (asynchronous). */
+int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double rel_cutoff);
+/* upload + classify (asynchronous) -- the call the reference's loop body maps to */
+int gn_submit_batch(gn_stream* s, const uint8_t* bases, uint64_t n_bases, const uint64_t* off1, const uint64_t* off2,
+                    uint32_t n_reads, uint32_t k, uint32_t w, double rel_cutoff);
+int gn_stream_sync(gn_stream* s);
+
+/* Wait for the batch and copy results out.  n_hashes[n_reads], status[n_reads], match_off[n_reads+1]
+ * (any may be NULL); matches[cap] receives the matches grouped by read (ascending read, then ascending
+ * target).  Returns GN_EOVERFLOW with *n_matches = required capacity if cap is too small. */
+int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status, uint64_t* match_off, gn_match* matches,
+                   uint64_t cap, uint64_t* n_matches);
+
+/* Parity / debugging taps (tests only): minimiser hashes of the resident batch in emission order
+ * (hash_off[n_reads+1]; hashes[cap]) and dense per-bin counts of reads [read_begin, read_end)
+ * (flat IBF: uint16[bins] per read == counting_agent::bulk_count; HIBF: uint16[n_user_bins] per read
+ * == counting_agent_type::bulk_count(values, T)). */
+int gn_stream_fetch_hashes(gn_stream* s, uint64_t* hash_off, uint64_t* hashes, uint64_t cap, uint64_t* n_total);
+int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_t read_end, uint16_t* counts);
+
+int gn_stream_timings(gn_stream* s, gn_timings* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -71,6 +71,8 @@ def lib():
         L.gno_ibf_row.argtypes = [C.POINTER(_IbfS), C.c_uint64, C.c_uint32]
         L.gno_ibf_emplace.restype = None
         L.gno_ibf_emplace.argtypes = [C.POINTER(_IbfS), C.c_uint64, C.c_uint64]
+        L.gno_ibf_emplace_many.restype = None
+        L.gno_ibf_emplace_many.argtypes = [C.POINTER(_IbfS), C.c_void_p, C.c_void_p, C.c_size_t]
         L.gno_ibf_bulk_count.restype = None
         L.gno_ibf_bulk_count.argtypes = [C.POINTER(_IbfS), C.c_void_p, C.c_size_t, C.c_void_p]
         L.gno_hibf_bulk_count.restype = None
@@ -186,10 +188,11 @@ class Ibf:
     def emplace(self, v: int, b: int) -> None:
         lib().gno_ibf_emplace(C.byref(self._s), int(v), int(b))
 
-    def emplace_many(self, hashes: np.ndarray, b: int) -> None:
-        L = lib()
-        for v in np.asarray(hashes, dtype=np.uint64).tolist():
-            L.gno_ibf_emplace(C.byref(self._s), v, int(b))
+    def emplace_many(self, hashes: np.ndarray, b) -> None:
+        """b: one bin for all hashes, or an array of bins (one per hash)."""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        bins = np.ascontiguousarray(np.broadcast_to(np.asarray(b, dtype=np.uint32), hashes.shape))
+        lib().gno_ibf_emplace_many(C.byref(self._s), _ptr(hashes), _ptr(bins), len(hashes))
 
     def bulk_count(self, hashes: np.ndarray) -> np.ndarray:
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)

@@ -176,6 +176,12 @@ void gno_ibf_emplace(gno_ibf* f, uint64_t v, uint64_t bin)
     }
 }
 
+void gno_ibf_emplace_many(gno_ibf* f, const uint64_t* v, const uint32_t* bins, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        gno_ibf_emplace(f, v[i], bins[i]);
+}
+
 /* counting_agent::bulk_count == for each value: counts += bulk_contains(value)
  * (call site GanonClassify.cpp:514).  Bits beyond `bins` in the last word are never set by
  * emplace and never counted (counting_vector has `bins` entries). */

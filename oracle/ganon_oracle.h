@@ -61,6 +61,7 @@ uint64_t gno_ibf_hash_shift(uint64_t bin_size);
 /* row index (0..S) of hash function i for value v */
 uint64_t gno_ibf_row(const gno_ibf* f, uint64_t v, uint32_t i);
 void     gno_ibf_emplace(gno_ibf* f, uint64_t v, uint64_t bin);
+void     gno_ibf_emplace_many(gno_ibf* f, const uint64_t* v, const uint32_t* bins, size_t n);
 /* counts[0..B) u16, zeroed then += bulk_contains(v) for each hash (GanonClassify.cpp:514) */
 void gno_ibf_bulk_count(const gno_ibf* f, const uint64_t* hashes, size_t n, uint16_t* counts);
 

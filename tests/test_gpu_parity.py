@@ -1,0 +1,199 @@
+"""GPU parity tests proper: every result comes through the C ABI (libganon_hip.so) and is compared
+bit-exactly with the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import ganon_fixtures as gf
+import gpu_util as gu
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import ganon_amd
+    ganon_amd.load_library()
+    assert ganon_amd.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return ganon_amd
+
+
+def _classify(hip, flt, seqs1, seqs2, k, w, rel_cutoff):
+    bases, off1, off2 = gu.pack_reads(seqs1, seqs2)
+    st = hip.HipStream(flt, max(len(seqs1), 1), max(bases.size, 1))
+    st.submit(bases, off1, off2, k, w, rel_cutoff)
+    nh, status, mo, m = st.fetch()
+    return st, nh, status, mo, m
+
+
+def _tiny_filter(hip):
+    ibf = gf.random_ibf(64, 257, 3, 0.3, 1)
+    return hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs), ibf
+
+
+# --------------------------------------------------------------------------------------------- minimiser
+@pytest.mark.parametrize("k,w", [(19, 31), (4, 4), (10, 12), (32, 32), (1, 5), (21, 40), (4, 6), (31, 35), (8, 200)])
+def test_minimiser_parity(hip, k, w):
+    rng = np.random.default_rng(1000 * k + w)
+    seqs = []
+    for length in [0, 1, w - 1, w, w + 1, 64, 63 + w, 64 + w, 65 + w, 150, 151, 300, 1000, 5000]:
+        if length < 0:
+            continue
+        seqs.append(gu.random_seq(rng, length))
+    # low complexity / ties / IUPAC / lower case
+    seqs += [b"A" * 150, b"ACACACACAC" * 20, b"AAAAACCCCC" * 15, gu.random_seq(rng, 200, b"AC"),
+             gu.random_seq(rng, 200, b"ACGTNRYKMSWBDHVacgtnu"), gu.random_seq(rng, 333, b"AT")]
+    seqs += [gu.random_seq(rng, int(rng.integers(0, 400))) for _ in range(300)]
+    flt, _ = _tiny_filter(hip)
+    st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, 0.5)
+    ho, hs = st.fetch_hashes()
+    exp = gu.oracle_hashes(seqs, None, k, w)
+    for i, (es, eh) in enumerate(exp):
+        assert status[i] == es, (i, len(seqs[i]))
+        got = hs[int(ho[i]):int(ho[i + 1])]
+        assert nh[i] == len(eh), (i, len(seqs[i]), nh[i], len(eh))
+        assert np.array_equal(got, eh), (i, len(seqs[i]))
+
+
+def test_minimiser_paired_parity(hip):
+    k, w = 19, 31
+    rng = np.random.default_rng(7)
+    s1 = [gu.random_seq(rng, int(rng.integers(0, 300))) for _ in range(200)]
+    s2 = [gu.random_seq(rng, int(rng.integers(0, 300))) for _ in range(200)]
+    s1[0], s2[0] = b"ACGT" * 5, gu.random_seq(rng, 150)      # mate 1 shorter than w -> skipped regardless of mate 2
+    s1[1], s2[1] = gu.random_seq(rng, 150), b"ACGT" * 5      # short mate 2 contributes nothing
+    flt, _ = _tiny_filter(hip)
+    st, nh, status, mo, m = _classify(hip, flt, s1, s2, k, w, 0.5)
+    ho, hs = st.fetch_hashes()
+    for i, (es, eh) in enumerate(gu.oracle_hashes(s1, s2, k, w)):
+        assert status[i] == es
+        assert np.array_equal(hs[int(ho[i]):int(ho[i + 1])], eh), i
+
+
+def test_read_too_big(hip):
+    # > 65535 minimisers -> GN_READ_BIG (GanonClassify.cpp:674,706); k == w emits every k-mer
+    k = w = 8
+    rng = np.random.default_rng(3)
+    seqs = [gu.random_seq(rng, 65535 + 8), gu.random_seq(rng, 65535 + 7), gu.random_seq(rng, 100)]
+    flt, _ = _tiny_filter(hip)
+    st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, 1.0)
+    assert list(status) == [hip.READ_BIG, hip.READ_OK, hip.READ_OK]
+    assert list(nh) == [65536, 65535, 93]
+    assert mo[1] - mo[0] == 0
+
+
+def test_empty_batch(hip):
+    flt, _ = _tiny_filter(hip)
+    st, nh, status, mo, m = _classify(hip, flt, [], None, 19, 31, 0.2)
+    assert len(nh) == 0 and len(m) == 0 and list(mo) == [0]
+
+
+# --------------------------------------------------------------------------------------------- IBF counts
+SHAPES = [  # bins, rows, h
+    (1, 97, 1), (3, 211, 2), (64, 1000, 3), (100, 1531, 4), (128, 900, 5), (130, 777, 3), (500, 2048, 4),
+    (4096, 4099, 4), (4100, 1200, 2), (8192, 1024, 3), (8256, 700, 4), (20000, 300, 2), (32768, 257, 4),
+    (65536, 130, 3),
+]
+
+
+@pytest.mark.parametrize("bins,rows,h", SHAPES)
+def test_ibf_dense_counts_parity(hip, bins, rows, h):
+    k, w = 19, 31
+    rng = np.random.default_rng(bins * 31 + h)
+    ibf = gf.random_ibf(bins, rows, h, 0.4, seed=bins + h)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h)
+    seqs = [gu.random_seq(rng, int(L)) for L in [31, 40, 150, 150, 150, 151, 299, 1000, 20, 4000]]
+    st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, 0.3)
+    ho, hs = st.fetch_hashes()
+    dense = st.dense_counts(0, len(seqs), bins)
+    b2t = np.arange(bins, dtype=np.uint32)
+    for i in range(len(seqs)):
+        hh = hs[int(ho[i]):int(ho[i + 1])]
+        exp_m, exp_counts = gu.oracle_matches(ibf, b2t, bins, hh, 0.3) if status[i] == 0 else ([], np.zeros(bins, np.uint16))
+        assert np.array_equal(dense[i], exp_counts), (i, np.nonzero(dense[i] != exp_counts)[0][:10])
+        got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+        assert all(int(x["read"]) == i for x in m[int(mo[i]):int(mo[i + 1])])
+        assert got == exp_m, (i, got[:5], exp_m[:5])
+
+
+@pytest.mark.parametrize("rel_cutoff", [0.0, 0.2, 0.45, 0.75, 1.0])
+def test_split_bins_and_cutoffs(hip, rel_cutoff):
+    # targets own several (also non-contiguous) technical bins, some bins unassigned (GanonClassify.cpp:516-527)
+    k, w = 19, 31
+    bins, rows, h = 1000, 3001, 3
+    rng = np.random.default_rng(11)
+    ibf = gf.random_ibf(bins, rows, h, 0.35, seed=5)
+    n_targets = 300
+    b2t = rng.integers(0, n_targets, size=bins).astype(np.uint32)
+    b2t[rng.integers(0, bins, size=50)] = 0xFFFFFFFF
+    genomes = [gu.random_seq(rng, 2000) for _ in range(20)]
+    for gi, g in enumerate(genomes):  # plant genomes so that real matches exist
+        for hv in np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)):
+            ibf.emplace(int(hv), gi * 7 % bins)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
+    seqs = []
+    for i in range(200):
+        if i % 2:
+            g = genomes[i % 20]
+            p = int(rng.integers(0, 1800))
+            seqs.append(g[p:p + 150])
+        else:
+            seqs.append(gu.random_seq(rng, 150))
+    st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
+    ho, hs = st.fetch_hashes()
+    total = 0
+    for i in range(len(seqs)):
+        exp_m, _ = gu.oracle_matches(ibf, b2t, n_targets, hs[int(ho[i]):int(ho[i + 1])], rel_cutoff)
+        got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+        assert got == exp_m, (i, got[:5], exp_m[:5])
+        total += len(exp_m)
+    assert total == len(m) and total > 0
+
+
+def test_long_reads_many_flushes(hip):
+    # thousands of minimisers per read: exercises the 15-iteration nibble flush many times
+    k, w = 19, 23
+    bins, rows, h = 4096, 2048, 4
+    rng = np.random.default_rng(5)
+    ibf = gf.random_ibf(bins, rows, h, 0.5, seed=9)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h)
+    seqs = [gu.random_seq(rng, 30000), gu.random_seq(rng, 12345), gu.random_seq(rng, 150)]
+    st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, 0.1)
+    ho, hs = st.fetch_hashes()
+    dense = st.dense_counts(0, 3, bins)
+    for i in range(3):
+        assert nh[i] > (1000 if i < 2 else 10)
+        assert np.array_equal(dense[i], ibf.bulk_count(hs[int(ho[i]):int(ho[i + 1])]))
+
+
+def test_emplace_and_download(hip):
+    bins, rows, h = 200, 1000, 3
+    ibf = oracle.Ibf(bins, rows, h)
+    flt = hip.HipFilter.ibf(None, bins, rows, h)
+    rng = np.random.default_rng(2)
+    hashes = rng.integers(0, 1 << 38, size=5000, dtype=np.uint64)
+    bb = rng.integers(0, bins, size=5000).astype(np.uint32)
+    flt.emplace(hashes, bb)
+    for v, b in zip(hashes.tolist(), bb.tolist()):
+        ibf.emplace(v, b)
+    assert np.array_equal(flt.download_rows(0, rows, ibf.bin_words), ibf.data)
+
+
+def test_kat_per_filter_matches(hip, kat):
+    # reference KAT filters through the C ABI: GPU select_matches == oracle select_matches for every read
+    for bname, b in kat["builds"].items():
+        built = gf.build_ibf(b["targets"], b["k"], b["w"], max_fp=b["max_fp"])
+        names = list(dict.fromkeys(t for _, t in built.bin_map))
+        b2t = np.full(built.ibf.bins, 0xFFFFFFFF, dtype=np.uint32)
+        for binno, t in built.bin_map:
+            b2t[binno] = names.index(t)
+        flt = hip.HipFilter.ibf(built.ibf.data, built.ibf.bins, built.ibf.bin_size, built.ibf.hash_funs, b2t, len(names))
+        rnames = list(kat["reads"])
+        seqs = [kat["reads"][r].replace("-", "A").encode() for r in rnames]
+        for rc in (0.0, 0.2, 0.45, 0.6, 0.7, 1.0):
+            st, nh, status, mo, m = _classify(hip, flt, seqs, None, b["k"], b["w"], rc)
+            for i, s in enumerate(seqs):
+                hh = oracle.minimiser_hash(oracle.to_ranks(s), b["k"], b["w"]) if len(s) >= b["w"] else np.zeros(0, np.uint64)
+                exp_m, _ = gu.oracle_matches(built.ibf, b2t, len(names), hh, rc) if len(hh) else ([], None)
+                got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+                assert got == exp_m, (bname, rnames[i], rc, got, exp_m)
