@@ -329,7 +329,8 @@ extern "C" int gn_stream_destroy(gn_stream* s)
         hipStreamSynchronize(s->st);
     void* ptrs[] = { s->d_bases,  s->d_off1,    s->d_off2,      s->d_slot_cnt,  s->d_slot_off, s->d_hashes, s->d_nh,
                      s->d_status, s->d_matches, s->d_sorted,    s->d_ctr,       s->d_seg_begin, s->d_seg_count,
-                     s->d_seg_off, s->d_scan_tmp, s->d_work[0], s->d_work[1] };
+                     s->d_seg_off, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_keys[0], s->d_keys[1], s->d_vals[0],
+                     s->d_vals[1], s->d_sort_tmp };
     for (void* p : ptrs)
         if (p)
             hipFree(p);
@@ -452,10 +453,11 @@ __global__ void gn_slot_count_kernel(const uint64_t* off1, const uint64_t* off2,
 }
 
 __global__ void gn_gather_kernel(const gn_match* __restrict__ in, gn_match* __restrict__ out, const uint64_t* __restrict__ seg_begin,
-                                 const uint32_t* __restrict__ seg_count, const uint64_t* __restrict__ seg_off, uint64_t nseg)
+                                 const uint32_t* __restrict__ seg_count, const uint64_t* __restrict__ seg_off, uint64_t nseg,
+                                 const unsigned long long* __restrict__ cursor, uint64_t cap)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nseg)
+    if (i >= nseg || *cursor > cap) // overflowed batch: nothing was written, gn_finish() grows the buffers and re-runs
         return;
     const uint32_t c = seg_count[i];
     const uint64_t b = seg_begin[i], o = seg_off[i];
@@ -511,7 +513,7 @@ static int gn_run_group(gn_stream* s)
     GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st));
     if (nseg)
         hipLaunchKernelGGL(gn_gather_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, s->st, s->d_matches,
-                           s->d_sorted, s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)nseg);
+                           s->d_sorted, s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)nseg, s->d_ctr, s->match_cap);
     GN_HIP(hipGetLastError());
     return GN_OK;
 }

@@ -82,36 +82,9 @@ struct GnHibfIbfDev
     const uint64_t* rows;
     uint64_t        S;
     uint32_t        W, B, shift, h;
-    const int32_t*  next_ibf;   // per bin: child ibf index (only meaningful for merged bins)
-    const int32_t*  bin2user;   // per bin: user bin, -1 merged
-    const uint8_t*  run_end;    // per bin: 1 when the running sum is evaluated+reset after this bin
+    const uint4*    runs;   // per run: first bin, n bins, user bin (0xFFFFFFFF = merged), child ibf
+    uint32_t        n_runs;
 };
-
-struct GnHibfParams
-{
-    const GnHibfIbfDev* ibfs;    // device array
-    uint32_t            n_ibf;
-    const uint64_t*     hashes;
-    const uint64_t*     slot_off;
-    const uint32_t*     n_hashes;
-    const uint8_t*      status;
-    double              rel_cutoff;
-    // work queue of (read, ibf) items for this level
-    const uint2*        work_in;
-    uint32_t            n_work;
-    uint2*              work_out;
-    uint32_t            work_cap;
-    unsigned int*       work_out_count;
-    // output
-    gn_match*           matches;
-    uint64_t            match_cap;
-    unsigned long long* cursor;
-    unsigned long long* algo_bytes;
-    uint32_t            max_bins; // LDS sizing: max technical bins of any IBF
-};
-
-hipError_t gn_launch_hibf_level(const GnHibfParams& p, hipStream_t st);
-hipError_t gn_launch_hibf_seed(uint2* work, const uint8_t* status, uint32_t n_reads, unsigned int* count, hipStream_t st);
 
 // ---- misc kernels ---------------------------------------------------------------------------
 hipError_t gn_launch_emplace(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h, const uint64_t* hashes,
@@ -183,9 +156,14 @@ struct gn_stream
     uint64_t*           d_seg_off   = nullptr; // n*wpr+1 exclusive scan of seg_count
     void*               d_scan_tmp  = nullptr;
     size_t              scan_tmp_bytes = 0;
-    // hibf work queues
+    // hibf work queues + sort buffers
     uint2*        d_work[2]{ nullptr, nullptr };
     uint32_t      work_cap = 0;
+    uint64_t*     d_keys[2]{ nullptr, nullptr };
+    uint32_t*     d_vals[2]{ nullptr, nullptr };
+    void*         d_sort_tmp = nullptr;
+    size_t        sort_tmp_bytes = 0;
+    uint64_t      hibf_cap = 0;
     // pinned host
     unsigned long long* h_ctr = nullptr;
     // state

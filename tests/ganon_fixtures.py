@@ -341,3 +341,79 @@ def random_ibf(bins: int, bin_size_rows: int, hash_funs: int, density: float, se
     if bins & 63:
         data[:, W - 1] &= np.uint64((1 << (bins & 63)) - 1)
     return oracle.Ibf(bins, bin_size_rows, hash_funs, data)
+
+
+# ----------------------------------------------------------------------------- synthetic HIBF
+def random_hibf(n_user_bins: int, tmax: int, max_depth: int, seed: int, density: float = 0.3, hash_funs: int = 3,
+                rows=(300, 900), user_hashes: Optional[Dict[int, np.ndarray]] = None) -> oracle.Hibf:
+    """Random raptor-style layout: every IBF has <= tmax technical bins holding single user bins, user bins split
+    over 2-3 consecutive technical bins, and merged bins that point to a child IBF (hibf.hpp:124-136,188).  Bit
+    matrices are Bernoulli(density); `user_hashes[ub]` (optional) are emplaced into the user bin's leaf bin(s) and
+    into every merged bin above it, the way raptor builds the hierarchy."""
+    rng = np.random.default_rng(seed)
+    ibfs: List[oracle.Ibf] = []
+    next_ids: List[List[int]] = []
+    b2u: List[List[int]] = []
+    plant: List[List[tuple]] = []  # per ibf: (bin, user bins whose hashes go there)
+
+    def build(ubs: List[int], depth: int) -> int:
+        idx = len(ibfs)
+        ibfs.append(None)
+        next_ids.append([])
+        b2u.append([])
+        plant.append([])
+        bins_nxt, bins_usr, pl = [], [], []
+        pending = list(ubs)
+        slots_left = tmax
+        pending_children = []
+        while pending:
+            remaining_slots = slots_left - len(bins_usr)
+            if depth + 1 < max_depth and len(pending) > remaining_slots - 3 and len(pending) > 1:
+                # merged bin: put a chunk of user bins below
+                take = max(2, int(np.ceil(len(pending) / max(1, remaining_slots - 2))))
+                take = min(take + int(rng.integers(0, 3)), len(pending))
+                group, pending = pending[:take], pending[take:]
+                pl.append((len(bins_usr), group))
+                bins_usr.append(-1)
+                bins_nxt.append(None)
+                pending_children.append((len(bins_usr) - 1, group))
+            else:
+                ub = pending.pop(0)
+                nsplit = int(rng.choice([1, 1, 1, 2, 3])) if remaining_slots - len(pending) > 3 else 1
+                for _ in range(nsplit):
+                    pl.append((len(bins_usr), [ub]))
+                    bins_usr.append(ub)
+                    bins_nxt.append(idx)
+        for pos, group in pending_children:
+            bins_nxt[pos] = build(group, depth + 1)
+        nb = len(bins_usr)
+        S = int(rng.integers(rows[0], rows[1]))
+        ibfs[idx] = random_ibf(nb, S, hash_funs, density, seed=int(rng.integers(0, 1 << 30)))
+        next_ids[idx] = bins_nxt
+        b2u[idx] = bins_usr
+        plant[idx] = pl
+        return idx
+
+    build(list(range(n_user_bins)), 0)
+    if user_hashes:
+        for i, pl in enumerate(plant):
+            seen_split = {}
+            for b, group in pl:
+                for ub in group:
+                    hv = user_hashes.get(ub)
+                    if hv is None or len(hv) == 0:
+                        continue
+                    if len(group) == 1 and b2u[i][b] == ub:
+                        # split bins share the user bin's hashes round-robin
+                        bins_of = [bb for bb, g in pl if g == [ub]]
+                        part = hv[bins_of.index(b)::len(bins_of)]
+                        ibfs[i].emplace_many(part, b)
+                    else:
+                        ibfs[i].emplace_many(hv, b)
+    return oracle.Hibf(ibfs, next_ids, b2u, n_user_bins)
+
+
+def hibf_upload_args(h: oracle.Hibf):
+    """arguments of ganon_amd.HipFilter.hibf for an oracle.Hibf"""
+    return ([(f.data.reshape(-1), f.bins, f.bin_size, f.hash_funs) for f in h.ibfs], h.next_ibf_id, h.bin_to_user,
+            h.n_user_bins)

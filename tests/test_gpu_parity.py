@@ -197,3 +197,48 @@ def test_kat_per_filter_matches(hip, kat):
                 exp_m, _ = gu.oracle_matches(built.ibf, b2t, len(names), hh, rc) if len(hh) else ([], None)
                 got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
                 assert got == exp_m, (bname, rnames[i], rc, got, exp_m)
+
+
+# --------------------------------------------------------------------------------------------- HIBF
+@pytest.mark.parametrize("n_ub,tmax,depth,rel_cutoff", [(40, 64, 1, 0.2), (300, 64, 2, 0.3), (1000, 64, 3, 0.1),
+                                                         (500, 192, 2, 0.0), (200, 64, 2, 0.75), (2000, 128, 3, 0.5)])
+def test_hibf_parity(hip, n_ub, tmax, depth, rel_cutoff):
+    # counting_agent_type::bulk_count(values, T) (hibf.hpp:432-460,506-523) + select_matches (GanonClassify.cpp:543-577)
+    k, w = 19, 31
+    rng = np.random.default_rng(n_ub + tmax)
+    genomes = {ub: gu.random_seq(rng, 1500) for ub in range(0, n_ub, 3)}
+    uh = {ub: np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)) for ub, g in genomes.items()}
+    hb = gf.random_hibf(n_ub, tmax, depth, seed=n_ub, density=0.3, hash_funs=3, user_hashes=uh)
+    flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+    assert flt.info()["is_hibf"] and flt.info()["n_targets"] == n_ub
+    seqs = []
+    keys = sorted(genomes)
+    for i in range(300):
+        if i % 3 == 0:
+            seqs.append(gu.random_seq(rng, 150))
+        elif i % 3 == 1:
+            g = genomes[keys[i % len(keys)]]
+            p = int(rng.integers(0, 1300))
+            seqs.append(g[p:p + 150])
+        else:
+            seqs.append(gu.random_seq(rng, int(rng.integers(0, 60))))
+    st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
+    ho, hs = st.fetch_hashes()
+    dense = st.dense_counts(0, len(seqs), n_ub)
+    n_true = 0
+    algo = 0
+    for i in range(len(seqs)):
+        hh = hs[int(ho[i]):int(ho[i + 1])]
+        got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+        if status[i] != 0:
+            assert got == [] and not dense[i].any()
+            continue
+        thr = oracle.threshold_cutoff(len(hh), rel_cutoff)
+        exp_counts = hb.bulk_count(hh, thr)
+        assert np.array_equal(dense[i], exp_counts), (i, np.nonzero(dense[i] != exp_counts)[0][:10])
+        exp = [(int(u), int(min(c, len(hh)))) for u, c in enumerate(exp_counts) if c > 0]
+        assert got == exp, (i, got[:5], exp[:5])
+        n_true += len(exp)
+        algo += hb.visited_bytes(hh, thr)
+    assert n_true > 0
+    assert st.timings()["algo_bytes"] == algo
