@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -590,7 +591,12 @@ static int gn_finish(gn_stream* s)
     for (int attempt = 0; attempt < 4; ++attempt)
     {
         GN_HIP(hipStreamSynchronize(s->st));
+        // blocking read-back of the counters (the async copy into h_ctr is only used for timing-free fast paths)
+        GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         const uint64_t need = s->h_ctr[0];
+        if (getenv("GANON_HIP_DEBUG"))
+            fprintf(stderr, "[gn_finish] attempt %d need %llu cap %llu nh %llu\n", attempt, (unsigned long long)need,
+                    (unsigned long long)s->match_cap, (unsigned long long)s->h_ctr[1]);
         if (need <= s->match_cap)
         {
             s->n_matches = need;
