@@ -60,6 +60,15 @@ static int gn_set_device(int dev)
     return GN_OK;
 }
 
+// Padding bins (>= bins) of the last word are never set by emplace and never reported by the reference
+// (counting_vector has `bins` entries); clear them in the device copy so kernels need no per-word mask.
+__global__ void gn_clear_padding_kernel(uint64_t* rows, uint64_t S, uint64_t W, uint64_t mask)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < S)
+        rows[r * W + (W - 1)] &= mask;
+}
+
 static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* bytes_acc)
 {
     if (!d || d->bin_size == 0 || d->bins == 0)
@@ -99,6 +108,12 @@ static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* by
     else
     {
         GN_HIP(hipMemset(dp, 0, bytes + 64));
+    }
+    if (d->rows && (d->bins & 63))
+    {
+        hipLaunchKernelGGL(gn_clear_padding_kernel, dim3((unsigned)((d->bin_size + 255) / 256)), dim3(256), 0, nullptr, dp,
+                           d->bin_size, d->bin_words, (1ull << (d->bins & 63)) - 1ull);
+        GN_HIP(hipDeviceSynchronize());
     }
     out->d_rows = dp;
     out->S      = d->bin_size;
@@ -330,7 +345,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
         hipStreamSynchronize(s->st);
     void* ptrs[] = { s->d_bases,  s->d_off1,    s->d_off2,      s->d_slot_cnt,  s->d_slot_off, s->d_hashes, s->d_nh,
                      s->d_status, s->d_matches, s->d_sorted,    s->d_ctr,       s->d_seg_begin, s->d_seg_count,
-                     s->d_seg_off, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_keys[0], s->d_keys[1], s->d_vals[0],
+                     s->d_seg_off, s->d_deferred, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_keys[0], s->d_keys[1], s->d_vals[0],
                      s->d_vals[1], s->d_sort_tmp };
     for (void* p : ptrs)
         if (p)
@@ -383,6 +398,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
     ok(gn_dmalloc(&s->d_seg_begin, nseg));
     ok(gn_dmalloc(&s->d_seg_count, nseg + 1));
     ok(gn_dmalloc(&s->d_seg_off, nseg + 1));
+    ok(gn_dmalloc(&s->d_deferred, max_reads));
     size_t tmp1 = 0, tmp2 = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, tmp1, s->d_slot_cnt, s->d_slot_off, (int)(max_reads + 1), s->st);
     hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st);
@@ -462,8 +478,20 @@ __global__ void gn_gather_kernel(const gn_match* __restrict__ in, gn_match* __re
         return;
     const uint32_t c = seg_count[i];
     const uint64_t b = seg_begin[i], o = seg_off[i];
+    // copy with an insertion sort by target: the generic kernel emits ascending targets already (O(c)); the fast
+    // kernel emits ascending 64/128-bin column chunks with unordered bins inside a chunk, so an element moves
+    // left by at most one chunk's worth of matches
     for (uint32_t j = 0; j < c; ++j)
-        out[o + j] = in[b + j];
+    {
+        const gn_match m = in[b + j];
+        uint32_t       k = j;
+        while (k > 0 && out[o + k - 1].target > m.target)
+        {
+            out[o + k] = out[o + k - 1];
+            --k;
+        }
+        out[o + k] = m;
+    }
 }
 
 int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st); // gn_hibf.hip
@@ -499,6 +527,18 @@ static int gn_run_count(gn_stream* s)
     p.seg_begin  = s->d_seg_begin;
     p.seg_count  = s->d_seg_count;
     p.dense      = nullptr;
+    p.max_blocks = (uint32_t)f->n_cu * 16u;
+    const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
+    if (fast)
+    {
+        // register-resident fast path for reads with <= 30 minimisers; the rest lands in d_deferred
+        GN_HIP(hipMemsetAsync(s->d_ctr + 4, 0, sizeof(unsigned long long), s->st));
+        p.work_list_out  = s->d_deferred;
+        p.work_count_out = s->d_ctr + 4;
+        GN_HIP(gn_launch_count_fast(p, f->geom, f->ibf.h, s->st));
+        p.work_list  = s->d_deferred;
+        p.work_count = s->d_ctr + 4;
+    }
     GN_HIP(gn_launch_count(p, f->geom, f->ibf.h, s->st));
     return GN_OK;
 }
@@ -754,6 +794,7 @@ extern "C" int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_
     gn_dmalloc(&segc, (size_t)s->n_reads * f->geom.wpr);
     p.cursor = dctr; p.seg_begin = segb; p.seg_count = segc;
     p.dense = dd; p.dense_begin = read_begin; p.dense_end = read_end;
+    p.max_blocks = (uint32_t)f->n_cu * 16u;
     e = gn_launch_count(p, f->geom, f->ibf.h, s->st);
     hipError_t e2 = hipStreamSynchronize(s->st);
     if (e == hipSuccess && e2 == hipSuccess)

@@ -57,6 +57,12 @@ struct GnCountParams
     // debug tap: dense counts of reads [dense_begin, dense_end)
     uint16_t* dense;
     uint32_t  dense_begin, dense_end;
+    // work list: generic kernel input (nullptr = every read), fast kernel output (reads it defers)
+    const uint32_t*           work_list;
+    const unsigned long long* work_count;
+    uint32_t*                 work_list_out;
+    unsigned long long*       work_count_out;
+    uint32_t                  max_blocks; // generic kernel: persistent grid size
 };
 
 struct GnCountGeometry
@@ -75,6 +81,7 @@ bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const
 
 hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t st);
 hipError_t gn_launch_count(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
+hipError_t gn_launch_count_fast(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
 
 // ---- HIBF -----------------------------------------------------------------------------------
 struct GnHibfIbfDev
@@ -154,6 +161,7 @@ struct gn_stream
     uint64_t*           d_seg_begin = nullptr;
     uint32_t*           d_seg_count = nullptr;
     uint64_t*           d_seg_off   = nullptr; // n*wpr+1 exclusive scan of seg_count
+    uint32_t*           d_deferred  = nullptr; // reads the fast count kernel left to the generic one
     void*               d_scan_tmp  = nullptr;
     size_t              scan_tmp_bytes = 0;
     // hibf work queues + sort buffers

@@ -324,7 +324,13 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
     uint32_t* cnt      = cnt_read + (size_t)slice * p.slice_dwords;     // my slice
     uint32_t* rowtab   = gn_lds + (size_t)rpb * wpr * p.slice_dwords + (size_t)wave * 64 * 8;
 
-    const uint32_t read = blockIdx.x * rpb + rslot;
+    // Work items: either every read of the batch (work_list == nullptr) or the reads the fast kernel deferred.
+    // Blocks stride over rounds of rpb reads; the trip count is block-uniform, so __syncthreads() is safe.
+    const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads;
+    for (uint32_t round0 = blockIdx.x * rpb; round0 < n_work; round0 += gridDim.x * rpb)
+    {
+    const uint32_t widx = round0 + rslot;
+    const uint32_t read = widx < n_work ? (p.work_list ? p.work_list[widx] : widx) : 0xFFFFFFFFu;
     uint32_t       n    = 0;
     if (read < p.n_reads && p.status[read] == GN_READ_OK)
         n = p.n_hashes[read];
@@ -568,16 +574,264 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
             p.seg_count[(size_t)read * wpr + slice] = total;
         }
     }
+    __syncthreads(); // the next round zeroes the count slices
+    } // rounds
+}
+
+// ================================================================================================
+// fast count + select kernel: identity bin->target map, reads with at most 30 minimisers
+// ================================================================================================
+// Same row-gather main loop, but the per-bin counters never leave the registers: with H = 2 hashes per wave
+// iteration a read of n <= 30 minimisers needs <= 15 iterations, so the 4-bit SWAR counters cannot overflow.
+// Epilogue: nibbles -> bytes, partial counts of the H hash groups added with lane-xor shuffles, SWAR
+// compare of every byte against the read's cutoff T ((x + 0x80 - T) & 0x80), ballot; only lanes that own a
+// bin >= T extract (bin, count) pairs.  Reads with more minimisers are appended to `deferred` and handled by
+// gn_ibf_count_kernel.  One wave per (read, column slice); no LDS counters, no block barriers.
+template <int HF, int LW>
+__global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t gn_lds[];
+    constexpr int      ND   = 2 * LW;
+    constexpr int      HFP  = HF <= 4 ? 4 : 8;
+    constexpr uint32_t NMAX = 30;
+
+    const int      lane  = threadIdx.x & (GN_WAVE - 1);
+    const int      wave  = threadIdx.x >> 6;
+    const uint32_t wpr   = p.wpr;
+    const uint32_t unit  = blockIdx.x * (blockDim.x >> 6) + wave;
+    const uint32_t read  = unit / wpr;
+    const uint32_t slice = unit - read * wpr;
+    if (read >= p.n_reads)
+        return;
+    const uint32_t Gp   = 1u << p.gp_log2;
+    const uint32_t H    = GN_WAVE >> p.gp_log2;
+    const uint32_t gl   = lane & (Gp - 1);
+    const uint32_t hsub = lane >> p.gp_log2;
+    uint32_t*      rowtab = gn_lds + (size_t)wave * 32 * HFP;
+
+    uint32_t n = 0;
+    if (p.status[read] == GN_READ_OK)
+        n = p.n_hashes[read];
+    if (n > NMAX || n == 0)
+    {
+        if (lane == 0)
+        {
+            if (n > NMAX && slice == 0)
+                p.work_list_out[atomicAdd(p.work_count_out, 1ULL)] = read;
+            p.seg_begin[(size_t)read * wpr + slice] = 0;
+            p.seg_count[(size_t)read * wpr + slice] = 0;
+        }
+        return;
+    }
+    const uint32_t  wi      = slice * 64 * LW + gl * LW;
+    const bool      col_act = wi < p.W;
+    const uint64_t* hs      = p.hashes + p.slot_off[read];
+
+    for (uint32_t idx = lane; idx < n * HF; idx += GN_WAVE)
+    {
+        const uint32_t q = idx / HF, i = idx - q * HF;
+        rowtab[q * HFP + i] = gn_ibf_row(hs[q], i, p.shift, p.S);
+    }
+    gn_wave_lds_sync();
+
+    uint32_t nib[ND][4];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            nib[d][j] = 0;
+
+    const uint32_t iters = (n + H - 1) / H;
+    auto issue = [&](uint32_t it, GnRowRegs<HF, LW>& R) {
+        const uint32_t q   = it * H + hsub;
+        const bool     act = col_act && q < n;
+        if (act)
+        {
+            uint32_t row[HF];
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+                row[i] = rowtab[q * HFP + i];
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+            {
+                const uint64_t* ptr = p.rows + ((uint64_t)row[i] * p.W + wi);
+                if constexpr (LW == 2)
+                {
+                    const uint4 v = *reinterpret_cast<const uint4*>(ptr);
+                    R.m[i][0] = v.x;
+                    R.m[i][1] = v.y;
+                    R.m[i][2] = v.z;
+                    R.m[i][3] = v.w;
+                }
+                else
+                {
+                    const uint2 v = *reinterpret_cast<const uint2*>(ptr);
+                    R.m[i][0] = v.x;
+                    R.m[i][1] = v.y;
+                }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    R.m[i][d] = 0;
+        }
+    };
+    auto consume = [&](const GnRowRegs<HF, LW>& R) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+        {
+            uint32_t a = R.m[0][d];
+#pragma unroll
+            for (int i = 1; i < HF; ++i)
+                a &= R.m[i][d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                nib[d][j] += (a >> j) & 0x11111111u;
+        }
+    };
+    {
+        GnRowRegs<HF, LW> A, Bq;
+        issue(0, A);
+        for (uint32_t it = 0; it < iters; it += 2)
+        {
+            if (it + 1 < iters)
+                issue(it + 1, Bq);
+            consume(A);
+            if (it + 1 < iters)
+            {
+                if (it + 2 < iters)
+                    issue(it + 2, A);
+                consume(Bq);
+            }
+        }
+    }
+
+    // ---- epilogue: bytes, cross-group sum, SWAR threshold ----
+    uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff)); // GanonClassify.cpp:492-495,720-724
+    if (T == 0)
+        T = 1;
+    const uint32_t Kc = (0x80u - T) * 0x01010101u; // T <= n <= 30, counts <= 30: no carry between bytes
+    uint32_t       byt[ND][4][2];
+    uint32_t       any = 0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+            {
+                uint32_t x = (nib[d][j] >> (4 * pp)) & 0x0F0F0F0Fu;
+                for (uint32_t off = Gp; off < GN_WAVE; off <<= 1) // partial counts of the H hash groups
+                    x += __shfl_xor(x, (int)off);
+                byt[d][j][pp] = x;
+                any |= (x + Kc) & 0x80808080u;
+            }
+    const bool     owner = hsub == 0 && col_act; // one lane per column chunk reports
+    const uint64_t hm    = __ballot(owner && any != 0);
+    uint32_t       total = 0;
+    unsigned long long base = 0;
+    if (hm)
+    {
+        // matches of this lane (counts are capped at n by construction: a bin is hit at most once per hash)
+        uint32_t mine = 0;
+        if (owner && any)
+        {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                        mine += __popc((byt[d][j][pp] + Kc) & 0x80808080u);
+        }
+        // exclusive prefix over the few lanes that have matches (scalar loop over the ballot)
+        uint32_t my_off = 0;
+        uint64_t rem    = hm;
+        while (rem)
+        {
+            const uint32_t L = (uint32_t)__builtin_ctzll(rem);
+            rem &= rem - 1;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)L);
+            if ((uint32_t)lane == L)
+                my_off = total;
+            total += c;
+        }
+        // padding bins (>= B) of the last word never count: real filters keep them zero; be exact anyway
+        if (lane == 0)
+            base = atomicAdd(p.cursor, (unsigned long long)total);
+        base = gn_readlane64(base, 0);
+        if (base + total <= p.match_cap && owner && any)
+        {
+            gn_match* out = p.matches + base + my_off;
+            uint32_t  k   = 0;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                    {
+                        uint32_t hbits = (byt[d][j][pp] + Kc) & 0x80808080u;
+                        while (hbits)
+                        {
+                            const uint32_t y = (uint32_t)__builtin_ctz(hbits) >> 3;
+                            hbits &= hbits - 1;
+                            gn_match mt;
+                            mt.read   = read;
+                            mt.target = wi * 64 + 32 * d + 8 * y + 4 * pp + j; // bit t = 4*(2y+pp) + j of dword d
+                            mt.count  = (byt[d][j][pp] >> (8 * y)) & 0xFFu;
+                            out[k++]  = mt;
+                        }
+                    }
+        }
+    }
+    if (lane == 0)
+    {
+        p.seg_begin[(size_t)read * wpr + slice] = base;
+        p.seg_count[(size_t)read * wpr + slice] = total;
+    }
 }
 
 template <int HF, int LW, int MAXT>
 static hipError_t gn_launch_count_one(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
 {
-    const uint32_t blocks = (p.n_reads + g.rpb - 1) / g.rpb;
+    uint32_t blocks = (p.n_reads + g.rpb - 1) / g.rpb;
+    if (blocks > p.max_blocks)
+        blocks = p.max_blocks;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_ibf_count_kernel<HF, LW, MAXT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes);
     hipLaunchKernelGGL((gn_ibf_count_kernel<HF, LW, MAXT>), dim3(blocks), dim3(g.block), g.lds_bytes, st, p);
     return hipGetLastError();
+}
+
+template <int HF, int LW>
+static hipError_t gn_launch_fast_one(const GnCountParams& p, hipStream_t st)
+{
+    const uint64_t units  = (uint64_t)p.n_reads * p.wpr;
+    const uint32_t blocks = (uint32_t)((units + 3) / 4);
+    const size_t   lds    = 4 * 32 * (HF <= 4 ? 4 : 8) * 4;
+    hipLaunchKernelGGL((gn_ibf_count_fast_kernel<HF, LW>), dim3(blocks), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t gn_launch_count_fast(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st)
+{
+    if (p.n_reads == 0)
+        return hipSuccess;
+    const bool two = g.lw == 2;
+    switch (hash_funs)
+    {
+        case 1: return two ? gn_launch_fast_one<1, 2>(p, st) : gn_launch_fast_one<1, 1>(p, st);
+        case 2: return two ? gn_launch_fast_one<2, 2>(p, st) : gn_launch_fast_one<2, 1>(p, st);
+        case 3: return two ? gn_launch_fast_one<3, 2>(p, st) : gn_launch_fast_one<3, 1>(p, st);
+        case 4: return two ? gn_launch_fast_one<4, 2>(p, st) : gn_launch_fast_one<4, 1>(p, st);
+        case 5: return two ? gn_launch_fast_one<5, 2>(p, st) : gn_launch_fast_one<5, 1>(p, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <int HF>

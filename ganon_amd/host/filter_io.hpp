@@ -1,0 +1,78 @@
+// filter_io.hpp -- readers for the reference's on-disk filters (no SeqAn3 / cereal dependency).
+//
+//   .ibf   ganon-build output: cereal BinaryOutputArchive of version tuple, IBFConfig, hashes_count, bin_map and a
+//          seqan3::interleaved_bloom_filter<uncompressed>  (writer /root/reference/src/ganon-build/GanonBuild.cpp:251-288,
+//          reader /root/reference/src/ganon-classify/GanonClassify.cpp:949-986, IBFConfig.hpp:28-40)
+//   .hibf  raptor 3.0.1 index (reader GanonClassify.cpp:875-938, hibf.hpp:163-169,293-298)
+//
+// The byte layout of the SeqAn3/sdsl parts is restated from the published serialisation code and is NOT pinned by
+// any binary fixture in the reference tree, so the readers self-check every redundant quantity (technical_bins ==
+// 64*bin_words, hash_shift == clz(bin_size), bit_vector size == technical_bins*bin_size, file size arithmetic) and
+// fail loudly on a mismatch instead of classifying against a misread filter.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace gnhost
+{
+
+struct IbfMatrix
+{
+    uint64_t  bins = 0, technical_bins = 0, bin_size = 0, hash_shift = 0, bin_words = 0, hash_funs = 0;
+    uint64_t* rows = nullptr; // bin_size * bin_words words, 64-byte aligned, owned
+    IbfMatrix()    = default;
+    IbfMatrix(IbfMatrix&& o) noexcept { *this = std::move(o); }
+    IbfMatrix& operator=(IbfMatrix&& o) noexcept;
+    IbfMatrix(const IbfMatrix&)            = delete;
+    IbfMatrix& operator=(const IbfMatrix&) = delete;
+    ~IbfMatrix();
+};
+
+// IBFConfig.hpp:3-41
+struct IBFConfig
+{
+    uint64_t n_bins = 0, max_hashes_bin = 0;
+    uint8_t  hash_functions = 0, kmer_size = 0;
+    uint16_t window_size = 0;
+    uint64_t bin_size_bits = 0;
+    double   max_fp = 0, true_max_fp = 0, true_avg_fp = 0;
+};
+
+// What load_files() (GanonClassify.cpp:1007-1039) produces for one --ibf argument.
+struct LoadedFilter
+{
+    bool      is_hibf = false;
+    IBFConfig ibf_config;
+    // targets in first-appearance order of (bin number ascending); bins per target
+    std::vector<std::string>           targets;
+    std::vector<std::vector<uint64_t>> target_bins; // IBF: technical bins; HIBF: user bin index (one)
+    std::vector<double>                target_fpr;  // :968-982 (IBF) / :932 (HIBF)
+    uint64_t                           bin_count = 0;
+    // flat
+    IbfMatrix ibf;
+    // hibf
+    std::vector<IbfMatrix>            ibfs;
+    std::vector<std::vector<int64_t>> next_ibf_id;
+    std::vector<std::vector<int64_t>> bin_to_user;
+    uint64_t                          n_user_bins = 0;
+};
+
+// throw std::runtime_error with a descriptive message on malformed input
+void load_ibf_file(const std::string& path, LoadedFilter& out);
+void load_hibf_file(const std::string& path, LoadedFilter& out);
+
+// GanonClassify.cpp:940-947
+double false_positive(uint64_t bin_size_bits, uint8_t hash_functions, uint64_t n_hashes);
+
+// node -> (parent, rank, name); GanonClassify.cpp:988-1005
+struct TaxNode
+{
+    std::string parent, rank, name;
+};
+std::map<std::string, TaxNode> load_tax(const std::string& path);
+
+} // namespace gnhost
