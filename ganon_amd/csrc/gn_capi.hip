@@ -597,6 +597,7 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     mp.n_hashes     = s->d_nh;
     mp.status       = s->d_status;
     mp.total_hashes = s->d_ctr + 1;
+    mp.force_generic = getenv("GANON_HIP_MINIMISER_GENERIC") ? 1u : 0u;
     GN_HIP(gn_launch_minimiser(mp, f->n_cu, s->st));
     GN_HIP(hipEventRecord(s->ev[1], s->st));
 

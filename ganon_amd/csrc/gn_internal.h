@@ -22,6 +22,7 @@ struct GnMinimiserParams
     uint32_t*           n_hashes;  // per read
     uint8_t*            status;    // per read GN_READ_*
     unsigned long long* total_hashes; // sum of n over GN_READ_OK reads
+    uint32_t            force_generic; // tests: take the byte-staged path even for narrow windows
 };
 
 // ---- flat IBF count + select kernel ---------------------------------------------------------

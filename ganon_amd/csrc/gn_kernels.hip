@@ -75,6 +75,140 @@ __device__ __forceinline__ uint32_t gn_ibf_row(uint64_t v, uint32_t i, uint32_t 
 //   seed(j)     = j == 0 || v[j+K-1] < W_{j-1}          (a strictly smaller value enters)
 //   emission e  -> remembered position R_e; the next emission is min(next seed, R_e + 1 (expiry))
 // which is exactly the state machine of seqan3's minimiser view (validated against the oracle).
+// bit b of x -> bit 2b (Morton spread of a 32-bit word into 64 bits)
+__device__ __forceinline__ uint32_t gn_spread16(uint32_t v)
+{
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+__device__ __forceinline__ uint64_t gn_spread32(uint32_t x)
+{
+    return ((uint64_t)gn_spread16(x >> 16) << 32) | gn_spread16(x & 0xFFFFu);
+}
+// bits [i, i+32) of the 128-bit string nxt:cur (cur, nxt wave-uniform; i = lane-dependent, 0..63)
+__device__ __forceinline__ uint32_t gn_window32(uint64_t cur, uint64_t nxt, uint32_t i)
+{
+    const uint32_t lo = i < 32 ? (uint32_t)cur : (uint32_t)(cur >> 32);
+    const uint32_t hi = i < 32 ? (uint32_t)(cur >> 32) : (uint32_t)nxt;
+    return __builtin_amdgcn_alignbit(hi, lo, i & 31u);
+}
+
+// Fast minimiser path for windows of at most 65 k-mers (w - k <= 64; ganon's defaults are 12 and 16).
+//   * bases are read coalesced, 64 per step; their dna4 ranks become two wave-uniform 64-bit bit planes (ballots)
+//   * lane i of a chunk builds its k-mer from the planes: forward hash = Morton interleave of the bit-reversed
+//     k-bit windows, reverse-complement hash = complement of the Morton interleave of the plain windows
+//     (rc digit at weight 4^m is 3 - rank[p+m]); v = min(f ^ seed, rc ^ seed) goes to a two-chunk LDS ring
+//   * the sliding-window / emission logic is the same as in the generic version below
+__device__ uint32_t gn_mate_minimisers_fast(const uint8_t* __restrict__ seq, uint32_t L, uint32_t k, uint32_t w, uint64_t seed,
+                                            uint64_t* vv, uint64_t* __restrict__ out, int lane)
+{
+    const uint32_t K      = w - k + 1;
+    const uint32_t M      = L - k + 1;
+    const uint32_t nwin   = L - w + 1;
+    const uint32_t nchunk = (M + GN_WAVE - 1) / GN_WAVE;
+    const uint32_t kmask  = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const uint64_t dmask  = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+
+    auto load_planes = [&](uint32_t c, uint64_t& lo, uint64_t& hi) {
+        const uint32_t pos = c * GN_WAVE + lane;
+        uint32_t       r   = 0;
+        if (pos < L)
+            r = GN_RANK_LUT.t[seq[pos]];
+        lo = __ballot(r & 1u);
+        hi = __ballot(r & 2u);
+    };
+    auto compute_chunk = [&](uint32_t c, uint64_t lo_c, uint64_t hi_c, uint64_t lo_n, uint64_t hi_n) {
+        const uint32_t xl = gn_window32(lo_c, lo_n, lane) & kmask;
+        const uint32_t xh = gn_window32(hi_c, hi_n, lane) & kmask;
+        const uint64_t P  = (gn_spread32(xh) << 1) | gn_spread32(xl);                       // sum d_m 4^m
+        const uint32_t rl = __brev(xl) >> (32 - k), rh = __brev(xh) >> (32 - k);
+        const uint64_t f  = (gn_spread32(rh) << 1) | gn_spread32(rl);                       // sum d_j 4^(k-1-j)
+        const uint64_t a = f ^ seed, b = ((~P) & dmask) ^ seed;
+        vv[(c & 1u) * GN_WAVE + lane] = a < b ? a : b;
+    };
+
+    uint64_t lo0, hi0, lo1, hi1;
+    load_planes(0, lo0, hi0);
+    load_planes(1, lo1, hi1);
+    compute_chunk(0, lo0, hi0, lo1, hi1);
+
+    uint32_t nout   = 0;
+    uint32_t expiry = 0xFFFFFFFFu;
+    uint64_t carryW = 0;
+    uint32_t tile   = 0;
+    for (uint32_t T0 = 0; T0 < nwin; T0 += GN_WAVE, ++tile)
+    {
+        // planes tile+1 are in (lo1, hi1); chunk tile+1 needs planes tile+1 and tile+2
+        uint64_t lo2, hi2;
+        load_planes(tile + 2, lo2, hi2);
+        if (tile + 1 < nchunk)
+            compute_chunk(tile + 1, lo1, hi1, lo2, hi2);
+        lo1 = lo2;
+        hi1 = hi2;
+        gn_wave_lds_sync();
+
+        const uint32_t j     = T0 + lane;
+        const bool     valid = j < nwin;
+        uint64_t       m     = ~0ULL, last = ~0ULL;
+        uint32_t       pos   = 0;
+        if (valid)
+        {
+            m    = vv[j & 127u];
+            last = m;
+            for (uint32_t i = 1; i < K; ++i)
+            {
+                const uint64_t x = vv[(j + i) & 127u];
+                if (x <= m)
+                {
+                    m   = x;
+                    pos = i;
+                }
+                last = x;
+            }
+        }
+        const uint32_t R     = j + pos;
+        uint64_t       prevW = __shfl_up((unsigned long long)m, 1);
+        if (lane == 0)
+            prevW = carryW;
+        const bool enters = valid && j > 0 && last < prevW;
+        uint64_t   seeds  = __ballot(enters);
+        if (T0 == 0)
+            seeds |= 1ULL;
+        const uint32_t tile_n = min((uint32_t)GN_WAVE, nwin - T0);
+
+        uint64_t EM = 0;
+        uint32_t p  = 0;
+        while (true)
+        {
+            uint32_t s = GN_WAVE;
+            if (p < GN_WAVE)
+            {
+                const uint64_t rem = seeds >> p;
+                if (rem)
+                    s = p + (uint32_t)__builtin_ctzll(rem);
+            }
+            const uint32_t e2 = (expiry - T0 < (uint32_t)GN_WAVE) ? expiry - T0 : (uint32_t)GN_WAVE;
+            uint32_t       e  = s < e2 ? s : e2;
+            e                 = __builtin_amdgcn_readfirstlane(e);
+            if (e >= tile_n)
+                break;
+            EM |= 1ULL << e;
+            expiry = (uint32_t)__builtin_amdgcn_readlane((int)R, (int)e) + 1u;
+            p      = e + 1;
+        }
+        if ((EM >> lane) & 1ULL)
+            out[nout + __popcll(EM & ((1ULL << lane) - 1ULL))] = m;
+        nout += __popcll(EM);
+        carryW = gn_readlane64(m, GN_WAVE - 1);
+        gn_wave_lds_sync(); // the next tile overwrites the older ring slot
+    }
+    return nout;
+}
+
+// Generic version (any window up to 448 k-mers): ranks staged as bytes in LDS, k-step rolling hash per lane.
 __device__ uint32_t gn_mate_minimisers(const uint8_t* __restrict__ seq, uint32_t L, uint32_t k, uint32_t w, uint64_t seed,
                                        uint8_t* rk, uint64_t* vv, uint64_t* __restrict__ out, int lane)
 {
@@ -174,8 +308,9 @@ __global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
     const int      lane      = threadIdx.x & (GN_WAVE - 1);
     const int      wave      = threadIdx.x >> 6;
     const uint32_t K         = p.w - p.k + 1;
-    const uint32_t vv_bytes  = (GN_WAVE + K) * 8;
-    const uint32_t rk_bytes  = (GN_WAVE + p.w + 15) & ~15u;
+    const bool     fastp     = K <= 65 && !p.force_generic; // two-chunk LDS ring + bit-plane k-mers
+    const uint32_t vv_bytes  = fastp ? 128u * 8u : (GN_WAVE + K) * 8;
+    const uint32_t rk_bytes  = fastp ? 0u : ((GN_WAVE + p.w + 15) & ~15u);
     uint8_t*       base      = gn_smem + (size_t)wave * (vv_bytes + rk_bytes);
     uint64_t*      vv        = reinterpret_cast<uint64_t*>(base);
     uint8_t*       rk        = base + vv_bytes;
@@ -202,9 +337,11 @@ __global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
         else
         {
             uint64_t* out = p.hashes + p.slot_off[r];
-            n             = gn_mate_minimisers(p.bases + b1, (uint32_t)len1, p.k, p.w, seed, rk, vv, out, lane);
+            n = fastp ? gn_mate_minimisers_fast(p.bases + b1, (uint32_t)len1, p.k, p.w, seed, vv, out, lane)
+                      : gn_mate_minimisers(p.bases + b1, (uint32_t)len1, p.k, p.w, seed, rk, vv, out, lane);
             if (len2 >= p.w) // :695-700 mate hashes appended
-                n += gn_mate_minimisers(p.bases + b2, (uint32_t)len2, p.k, p.w, seed, rk, vv, out + n, lane);
+                n += fastp ? gn_mate_minimisers_fast(p.bases + b2, (uint32_t)len2, p.k, p.w, seed, vv, out + n, lane)
+                           : gn_mate_minimisers(p.bases + b2, (uint32_t)len2, p.k, p.w, seed, rk, vv, out + n, lane);
             if (n > 65535u) // :674,706 TIntCount = uint16_t
                 st = GN_READ_BIG;
             else
@@ -225,7 +362,8 @@ hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t
     if (p.n_reads == 0)
         return hipSuccess;
     const uint32_t K        = p.w - p.k + 1;
-    const uint32_t per_wave = (GN_WAVE + K) * 8 + ((GN_WAVE + p.w + 15) & ~15u);
+    const bool     fastp    = K <= 65 && !p.force_generic;
+    const uint32_t per_wave = fastp ? 128u * 8u : (GN_WAVE + K) * 8 + ((GN_WAVE + p.w + 15) & ~15u);
     const size_t   lds      = (size_t)per_wave * 4;
     uint32_t       blocks   = (p.n_reads + 3) / 4;
     const uint32_t cap      = (uint32_t)n_cu * 16;
