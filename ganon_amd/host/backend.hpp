@@ -1,0 +1,65 @@
+// backend.hpp -- the seam between the host pipeline and the device hot path.  The host hands a batch of reads and
+// gets, per filter, the sparse result of select_matches (GanonClassify.cpp:504-577): for every read the targets whose
+// summed, capped count reached the read's cutoff.  The product binary links exactly one implementation,
+// backend_hip.cpp (libganon_hip.so through include/ganon_hip.h); there is no CPU implementation in ganon_amd/.
+// (tests/host_oracle/ links a checker backend built on the CPU oracle to exercise the host logic without a GPU.)
+#pragma once
+
+#include "filter_io.hpp"
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace gnhost
+{
+
+// A batch of reads in the layout the C ABI takes: ASCII bases, mate-1 block then mate-2 block.
+struct ReadBatch
+{
+    bool                     paired = false;
+    std::string              prefix;
+    std::vector<std::string> ids;
+    std::vector<uint8_t>     bases;
+    std::vector<uint64_t>    off1; // n+1
+    std::vector<uint64_t>    off2; // n+1 when paired (offsets into `bases`)
+    size_t                   size() const { return ids.size(); }
+    uint64_t len1(size_t i) const { return off1[i + 1] - off1[i]; }
+    uint64_t len2(size_t i) const { return paired ? off2[i + 1] - off2[i] : 0; }
+};
+
+struct Match
+{
+    uint32_t read, target, count; // target = index into LoadedFilter::targets
+};
+
+struct FilterResult
+{
+    std::vector<uint64_t> match_off; // n+1
+    std::vector<Match>    matches;   // grouped by read, ascending target
+};
+
+struct BatchResult
+{
+    std::vector<uint32_t>     n_hashes; // per read
+    std::vector<uint8_t>      status;   // 0 ok, 1 small, 2 big (GN_READ_*)
+    std::vector<FilterResult> per_filter;
+};
+
+class Backend
+{
+public:
+    virtual ~Backend() = default;
+    // takes over the filter's bit matrices (they are released after the upload); returns false + message on error
+    virtual bool add_filter(LoadedFilter& f, std::string& err) = 0;
+    virtual void clear_filters()                               = 0;
+    // classify `batch` against every added filter with minimiser shape (k, w); rel_cutoff[i] belongs to filter i
+    virtual bool classify(const ReadBatch& batch, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff,
+                          BatchResult& out, std::string& err) = 0;
+    virtual std::string describe() const                      = 0;
+};
+
+std::unique_ptr<Backend> make_backend(int device, std::string& err); // backend_hip.cpp (or the test checker)
+
+} // namespace gnhost

@@ -3,6 +3,7 @@
 // T), std::tuple = elements in index order, bool = 1 byte.
 #include "filter_io.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

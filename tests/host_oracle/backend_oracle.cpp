@@ -1,0 +1,156 @@
+// backend_oracle.cpp -- TEST-ONLY Backend built on the CPU oracle (oracle/ganon_oracle.c).
+// Lets the CPU test-suite run the host pipeline (CLI, file formats, readers, post-processing, writers) of
+// ganon_amd/host end to end on the reference's known-answer scenarios without a GPU.  It is compiled only into
+// tests/host_oracle/ganon-classify-oracle; the product binary links ganon_amd/host/backend_hip.cpp instead.
+#include "../../ganon_amd/host/backend.hpp"
+#include "../../oracle/ganon_oracle.h"
+
+#include <algorithm>
+
+namespace gnhost
+{
+namespace
+{
+class OracleBackend final : public Backend
+{
+public:
+    bool add_filter(LoadedFilter& f, std::string&) override
+    {
+        Held h;
+        h.is_hibf = f.is_hibf;
+        if (!f.is_hibf)
+        {
+            h.mats.push_back(std::move(f.ibf));
+        }
+        else
+        {
+            for (auto& m : f.ibfs)
+                h.mats.push_back(std::move(m));
+            h.next = f.next_ibf_id;
+            h.b2u  = f.bin_to_user;
+            h.n_user_bins = f.n_user_bins;
+        }
+        for (auto& m : h.mats)
+            h.ibfs.push_back(gno_ibf{ m.rows, m.bins, m.bin_size, m.bin_words, m.hash_shift, (uint32_t)m.hash_funs });
+        h.off.push_back(0);
+        for (auto const& b : f.target_bins)
+        {
+            for (auto x : b)
+                h.bins.push_back((uint32_t)x);
+            h.off.push_back((uint32_t)h.bins.size());
+        }
+        h.n_targets = (uint32_t)f.targets.size();
+        held_.push_back(std::move(h));
+        return true;
+    }
+    void clear_filters() override { held_.clear(); }
+
+    bool classify(const ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
+                  std::string&) override
+    {
+        const size_t n = b.size();
+        out.n_hashes.assign(n, 0);
+        out.status.assign(n, 0);
+        out.per_filter.assign(held_.size(), FilterResult{});
+        for (auto& fr : out.per_filter)
+            fr.match_off.assign(n + 1, 0);
+        std::vector<uint8_t>  r1, r2;
+        std::vector<uint64_t> hashes;
+        std::vector<uint16_t> counts;
+        for (size_t r = 0; r < n; ++r)
+        {
+            auto ranks = [&](uint64_t o, uint64_t len, std::vector<uint8_t>& dst) {
+                dst.resize(len);
+                for (uint64_t i = 0; i < len; ++i)
+                    dst[i] = gno_char_to_rank(b.bases[o + i], nullptr);
+            };
+            ranks(b.off1[r], b.len1(r), r1);
+            if (b.paired)
+                ranks(b.off2[r], b.len2(r), r2);
+            else
+                r2.clear();
+            size_t nh = 0;
+            if (r1.size() < w)
+                out.status[r] = 1;
+            else
+            {
+                hashes.resize(r1.size() + r2.size() + 1);
+                nh = gno_minimiser_hash(r1.data(), r1.size(), k, w, hashes.data(), hashes.size());
+                if (r2.size() >= w)
+                    nh += gno_minimiser_hash(r2.data(), r2.size(), k, w, hashes.data() + nh, hashes.size() - nh);
+                if (nh > 65535)
+                    out.status[r] = 2;
+            }
+            out.n_hashes[r] = (uint32_t)nh;
+            for (size_t i = 0; i < held_.size(); ++i)
+            {
+                FilterResult& fr = out.per_filter[i];
+                if (out.status[r] == 0)
+                {
+                    Held&          h   = held_[i];
+                    const uint64_t thr = gno_threshold_cutoff(nh, rel_cutoff[i]);
+                    if (!h.is_hibf)
+                    {
+                        counts.assign(h.ibfs[0].bins, 0);
+                        gno_ibf_bulk_count(&h.ibfs[0], hashes.data(), nh, counts.data());
+                        for (uint32_t t = 0; t < h.n_targets; ++t)
+                        {
+                            uint64_t s = 0;
+                            for (uint32_t x = h.off[t]; x < h.off[t + 1]; ++x)
+                                s += counts[h.bins[x]];
+                            if (s > nh)
+                                s = nh;
+                            if (s >= thr)
+                                fr.matches.push_back(Match{ (uint32_t)r, t, (uint32_t)s });
+                        }
+                    }
+                    else
+                    {
+                        std::vector<const int64_t*> nx, bu;
+                        for (size_t j = 0; j < h.ibfs.size(); ++j)
+                        {
+                            nx.push_back(h.next[j].data());
+                            bu.push_back(h.b2u[j].data());
+                        }
+                        gno_hibf hb{ (uint32_t)h.ibfs.size(), h.ibfs.data(), nx.data(), bu.data(), h.n_user_bins };
+                        counts.assign(h.n_user_bins ? h.n_user_bins : 1, 0);
+                        gno_hibf_bulk_count(&hb, hashes.data(), nh, thr, counts.data());
+                        for (uint32_t t = 0; t < h.n_targets; ++t)
+                        {
+                            uint64_t s = counts[h.bins[h.off[t]]];
+                            if (s > 0)
+                            {
+                                if (s > nh)
+                                    s = nh;
+                                fr.matches.push_back(Match{ (uint32_t)r, t, (uint32_t)s });
+                            }
+                        }
+                    }
+                }
+                fr.match_off[r + 1] = fr.matches.size();
+            }
+        }
+        return true;
+    }
+    std::string describe() const override { return "CPU oracle (test-only checker backend)"; }
+
+private:
+    struct Held
+    {
+        bool                              is_hibf = false;
+        std::vector<IbfMatrix>            mats;
+        std::vector<gno_ibf>              ibfs;
+        std::vector<std::vector<int64_t>> next, b2u;
+        uint64_t                          n_user_bins = 0;
+        std::vector<uint32_t>             off, bins;
+        uint32_t                          n_targets = 0;
+    };
+    std::vector<Held> held_;
+};
+} // namespace
+
+std::unique_ptr<Backend> make_backend(int, std::string&)
+{
+    return std::unique_ptr<Backend>(new OracleBackend());
+}
+} // namespace gnhost
