@@ -165,6 +165,17 @@ def main() -> int:
         },
     }
 
+    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass (counter collection
+    # cannot share a run with timing); its committed summary is attached when it was taken on this workload.
+    pmc_path = os.path.join(ROOT, "profiles", f"pmc_fetch_{args.workload}.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            result["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = pmc["source"]
+        except Exception as e:
+            log("bench.py: could not read", pmc_path, repr(e))
+
     if rank == 0:
         import bench_cpu
         if args.check:

@@ -83,9 +83,10 @@ def cpu_baseline(wl, flt, n_sample: int = 0):
         return n, time.perf_counter() - t0, total
 
     if n_sample <= 0:
-        n, dt, _ = run(20_000)                       # probe
+        run(20_000)                                  # warm-up (page-in, thread pool)
+        n, dt, _ = run(200_000)                      # probe
         rate = n / max(dt, 1e-6)
-        n_sample = int(min(wl.n_reads, max(20_000, rate * 15.0)))  # ~15 s of CPU work
+        n_sample = int(min(wl.n_reads, max(200_000, rate * 20.0)))  # ~20 s of CPU work
     n, dt, total = run(n_sample)
     return {
         "value": round(n / dt / 1e6, 4),

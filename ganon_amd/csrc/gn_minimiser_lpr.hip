@@ -1,0 +1,213 @@
+// gn_minimiser_lpr.hip -- lane-per-read minimiser kernel for short reads (Illumina-style batches).
+//
+// Same semantics as gn_minimiser_kernel (seqan3::views::minimiser_hash, call sites
+// /root/reference/src/ganon-classify/GanonClassify.cpp:647-650,693-700) but organised the
+// other way round: every LANE owns one read and rolls its canonical k-mer hash base by base, so a wavefront
+// handles 64 reads with ~50 VALU instructions per base instead of ~700 per read-tile.  All lanes sit at the same
+// position index, which makes the sliding-window bookkeeping wave-uniform:
+//   * window minimum in O(1) per base with the van Herk / Gil-Werman block decomposition: k-mer values are cut
+//     into blocks of K = w-k+1; a running prefix minimum (registers) covers the current block, a suffix-minimum
+//     table of the previous block lives in an LDS sliding window laid out [slot][lane] (conflict free); the
+//     table is rebuilt once per block by a K-step backward scan that every lane executes at the same time
+//   * ties keep the RIGHTMOST position (less_equal forward, strict-less backward), as seqan3 does
+//   * emission = the state machine of App. D in its seed/expiry form: emit window j when j == 0, when the
+//     remembered minimiser leaves (j == expiry) or when a strictly smaller value enters; expiry = R_j + 1
+// Reads longer than lpr_max_len (or windows wider than 65 k-mers) are appended to a deferred list that the
+// wave-per-read kernel (gn_kernels.hip) processes.
+#include "gn_internal.h"
+
+#define GN_WAVE 64
+
+namespace
+{
+struct LprRankLut
+{
+    uint8_t t[256];
+    constexpr LprRankLut() : t{}
+    {
+        for (int i = 0; i < 256; ++i)
+            t[i] = 0;
+        t['C'] = t['c'] = 1;
+        t['G'] = t['g'] = 2;
+        t['T'] = t['t'] = t['U'] = t['u'] = 3;
+        t['Y'] = t['y'] = 1;
+        t['S'] = t['s'] = 1;
+        t['K'] = t['k'] = 2;
+        t['B'] = t['b'] = 1;
+    }
+};
+} // namespace
+__constant__ LprRankLut GN_LPR_RANK_LUT = LprRankLut();
+
+__device__ __forceinline__ uint32_t gn_lpr_wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        const uint32_t o = __shfl_xor(v, off);
+        v                = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long gn_lpr_wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t gn_lpr_smem[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = p.k, w = p.w;
+    const uint32_t K = w - k + 1;
+    uint64_t*      bufV = reinterpret_cast<uint64_t*>(gn_lpr_smem);   // [2][K][64] values (then suffix minima)
+    uint8_t*       bufP = gn_lpr_smem + (size_t)2 * K * GN_WAVE * 8;  // [2][K][64] suffix argmin, offset in block
+    const uint64_t seed = 0x8F3F73B5CF1C9ADEULL >> (64u - 2u * k);    // adjust_seed.hpp:33-37
+    const uint64_t mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+
+    const uint32_t r   = blockIdx.x * GN_WAVE + lane;
+    const bool     inr = r < p.n_reads;
+    uint64_t       b1 = 0, len1 = 0, b2 = 0, len2 = 0;
+    if (inr)
+    {
+        b1   = p.off1[r];
+        len1 = p.off1[r + 1] - b1;
+        if (p.off2)
+        {
+            b2   = p.off2[r];
+            len2 = p.off2[r + 1] - b2;
+        }
+    }
+    const bool too_long = len1 > p.lpr_max_len || len2 > p.lpr_max_len;
+    const bool mine     = inr && !too_long;
+    if (inr && too_long)
+        p.defer_list[atomicAdd(p.defer_count, 1ULL)] = r;
+
+    uint8_t  st = GN_READ_OK;
+    uint32_t n  = 0;
+    if (mine && len1 < w) // GanonClassify.cpp:690,743-747
+        st = GN_READ_SMALL;
+    uint64_t* out = p.hashes + (mine ? p.slot_off[r] : 0);
+
+    for (uint32_t seg = 0; seg < 2; ++seg)
+    {
+        const uint64_t L64  = seg ? len2 : len1;
+        const bool     act  = mine && st == GN_READ_OK && L64 >= w; // :690 / :695
+        const uint32_t Leff = act ? (uint32_t)L64 : 0u;
+        const uint32_t Lmax = gn_lpr_wave_max(Leff);
+        if (Lmax == 0)
+            continue;
+        const uint8_t* seq = p.bases + (seg ? b2 : b1);
+
+        uint64_t f = 0, rc = 0;
+        uint32_t cur = 0;
+        uint64_t pre_v = ~0ULL, Wprev = 0;
+        uint32_t pre_p = 0, expiry = 0xFFFFFFFFu;
+        uint32_t blk = 0, pin = 0; // collecting buffer, position inside the current block (both wave-uniform)
+
+        for (uint32_t i = 0; i < Lmax; ++i)
+        {
+            const bool on = i < Leff;
+            uint64_t   v  = ~0ULL;
+            if (on)
+            {
+                const uintptr_t a = reinterpret_cast<uintptr_t>(seq + i);
+                if ((a & 3u) == 0 || i == 0)
+                    cur = *reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+                const uint32_t c = (cur >> (8u * (uint32_t)(a & 3u))) & 0xFFu;
+                const uint64_t b = GN_LPR_RANK_LUT.t[c];
+                f                = ((f << 2) | b) & mask;
+                rc               = (rc >> 2) | ((3ULL - b) << (2 * (k - 1)));
+                const uint64_t x = f ^ seed, y = rc ^ seed;
+                v                = x < y ? x : y;
+            }
+            if (i + 1 < k)
+                continue;
+            const uint32_t pk = i + 1 - k; // k-mer position (uniform)
+            // collect the value, update the running prefix minimum of this block (rightmost on ties)
+            bufV[((size_t)blk * K + pin) * GN_WAVE + lane] = v;
+            if (pin == 0 || v <= pre_v)
+            {
+                pre_v = v;
+                pre_p = pk;
+            }
+            if (pk + 1 >= K)
+            {
+                const uint32_t j = pk + 1 - K; // window index (uniform); valid for this lane iff `on`
+                uint64_t       W = pre_v;
+                uint32_t       R = pre_p;
+                if (pin != K - 1)
+                {
+                    // window starts inside the previous block: suffix minimum from slot (j mod K) = pin + 1
+                    const size_t   s  = ((size_t)(blk ^ 1u) * K + (pin + 1)) * GN_WAVE + lane;
+                    const uint64_t sv = bufV[s];
+                    if (sv < pre_v) // tie -> the prefix side (further right)
+                    {
+                        W = sv;
+                        R = (pk - pin - K) + bufP[s];
+                    }
+                }
+                if (on)
+                {
+                    const bool emit = j == 0 || j == expiry || v < Wprev;
+                    if (emit)
+                    {
+                        out[n++] = W;
+                        expiry   = R + 1u;
+                    }
+                    Wprev = W;
+                }
+            }
+            if (pin == K - 1)
+            {
+                // block complete: turn its values into suffix minima (backward, strict less keeps the rightmost)
+                uint64_t run_v = ~0ULL;
+                uint32_t run_p = K - 1;
+                for (int t = (int)K - 1; t >= 0; --t)
+                {
+                    const size_t   s = ((size_t)blk * K + (uint32_t)t) * GN_WAVE + lane;
+                    const uint64_t x = bufV[s];
+                    if (x < run_v || t == (int)K - 1)
+                    {
+                        run_v = x;
+                        run_p = (uint32_t)t;
+                    }
+                    bufV[s] = run_v;
+                    bufP[s] = (uint8_t)run_p;
+                }
+                blk ^= 1u;
+                pin = 0;
+            }
+            else
+                ++pin;
+        }
+    }
+    unsigned long long mine_total = 0;
+    if (mine)
+    {
+        if (n > 65535u) // :674,706
+            st = GN_READ_BIG;
+        else if (st == GN_READ_OK)
+            mine_total = n;
+        p.n_hashes[r] = n;
+        p.status[r]   = st;
+    }
+    mine_total = gn_lpr_wave_sum(mine_total);
+    if (lane == 0 && mine_total)
+        atomicAdd(p.total_hashes, mine_total);
+}
+
+hipError_t gn_launch_minimiser_lpr(const GnMinimiserParams& p, hipStream_t st)
+{
+    if (p.n_reads == 0)
+        return hipSuccess;
+    const uint32_t K   = p.w - p.k + 1;
+    const size_t   lds = (size_t)2 * K * GN_WAVE * 9;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_minimiser_lpr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(gn_minimiser_lpr_kernel, dim3((p.n_reads + GN_WAVE - 1) / GN_WAVE), dim3(GN_WAVE), lds, st, p);
+    return hipGetLastError();
+}
