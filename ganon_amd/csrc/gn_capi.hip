@@ -598,6 +598,16 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     mp.status       = s->d_status;
     mp.total_hashes = s->d_ctr + 1;
     mp.force_generic = getenv("GANON_HIP_MINIMISER_GENERIC") ? 1u : 0u;
+    if (w - k + 1 <= 65 && !mp.force_generic && !getenv("GANON_HIP_NO_LPR"))
+    {
+        // short reads: lane-per-read kernel; longer ones are deferred to the wave-per-read kernel below
+        mp.lpr_max_len = 640;
+        mp.defer_list  = s->d_deferred;
+        mp.defer_count = s->d_ctr + 5;
+        GN_HIP(gn_launch_minimiser_lpr(mp, s->st));
+        mp.work_list  = s->d_deferred;
+        mp.work_count = s->d_ctr + 5;
+    }
     GN_HIP(gn_launch_minimiser(mp, f->n_cu, s->st));
     GN_HIP(hipEventRecord(s->ev[1], s->st));
 

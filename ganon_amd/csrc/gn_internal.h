@@ -23,7 +23,15 @@ struct GnMinimiserParams
     uint8_t*            status;    // per read GN_READ_*
     unsigned long long* total_hashes; // sum of n over GN_READ_OK reads
     uint32_t            force_generic; // tests: take the byte-staged path even for narrow windows
+    // lane-per-read kernel: reads longer than lpr_max_len go to defer_list; wave-per-read kernel: work_list input
+    uint32_t                  lpr_max_len;
+    uint32_t*                 defer_list;
+    unsigned long long*       defer_count;
+    const uint32_t*           work_list;  // nullptr = every read
+    const unsigned long long* work_count;
 };
+
+hipError_t gn_launch_minimiser_lpr(const GnMinimiserParams& p, hipStream_t st);
 
 // ---- flat IBF count + select kernel ---------------------------------------------------------
 struct GnCountParams

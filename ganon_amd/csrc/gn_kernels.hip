@@ -318,8 +318,10 @@ __global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
     const uint32_t waves_all = gridDim.x * (blockDim.x >> 6);
     unsigned long long my_total = 0;
 
-    for (uint32_t r = blockIdx.x * (blockDim.x >> 6) + wave; r < p.n_reads; r += waves_all)
+    const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads;
+    for (uint32_t widx = blockIdx.x * (blockDim.x >> 6) + wave; widx < n_work; widx += waves_all)
     {
+        const uint32_t r    = p.work_list ? p.work_list[widx] : widx;
         const uint64_t b1   = p.off1[r];
         const uint64_t len1 = p.off1[r + 1] - b1;
         uint64_t       b2 = 0, len2 = 0;
