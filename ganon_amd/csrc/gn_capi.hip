@@ -528,6 +528,7 @@ static int gn_run_count(gn_stream* s)
     p.seg_count  = s->d_seg_count;
     p.dense      = nullptr;
     p.max_blocks = (uint32_t)f->n_cu * 16u;
+    p.max_blocks_fast = (uint32_t)f->n_cu * (getenv("GANON_HIP_FAST_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_FAST_BPC")) : 6u);
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
     if (fast)
     {
@@ -556,6 +557,8 @@ static int gn_run_group(gn_stream* s)
         hipLaunchKernelGGL(gn_gather_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, s->st, s->d_matches,
                            s->d_sorted, s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)nseg, s->d_ctr, s->match_cap);
     GN_HIP(hipGetLastError());
+    // exact number of matches = scan total (the cursor counts allocated space including chunk holes)
+    GN_HIP(hipMemcpyAsync(s->d_ctr + 6, s->d_seg_off + nseg, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->st));
     return GN_OK;
 }
 
@@ -650,7 +653,7 @@ static int gn_finish(gn_stream* s)
                     (unsigned long long)s->match_cap, (unsigned long long)s->h_ctr[1]);
         if (need <= s->match_cap)
         {
-            s->n_matches = need;
+            s->n_matches = s->f->is_hibf ? need : s->h_ctr[6];
             return GN_OK;
         }
         const uint64_t ncap = need + need / 8 + 1024;

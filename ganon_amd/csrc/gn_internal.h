@@ -72,6 +72,7 @@ struct GnCountParams
     uint32_t*                 work_list_out;
     unsigned long long*       work_count_out;
     uint32_t                  max_blocks; // generic kernel: persistent grid size
+    uint32_t                  max_blocks_fast; // fast kernel: persistent grid size
 };
 
 struct GnCountGeometry

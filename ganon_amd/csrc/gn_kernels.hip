@@ -15,6 +15,7 @@
 #include "gn_internal.h"
 
 #define GN_WAVE 64
+#define GN_MATCH_CHUNK 256u
 
 // ------------------------------------------------------------------------------------------------
 // dna4 rank table (seqan3::dna4 char_to_rank): ACGT(U) exact, IUPAC collapse, else A
@@ -733,25 +734,62 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_lds[];
     constexpr int      ND   = 2 * LW;
     constexpr int      HFP  = HF <= 4 ? 4 : 8;
-    constexpr uint32_t NMAX = 30;
+    // n <= 30 keeps the nibble counters exact for H = 2; the two-entries-per-lane row table needs n*HF <= 128
+    constexpr uint32_t NMAX = HF <= 4 ? 30 : 25;
 
     const int      lane  = threadIdx.x & (GN_WAVE - 1);
     const int      wave  = threadIdx.x >> 6;
     const uint32_t wpr   = p.wpr;
-    const uint32_t unit  = blockIdx.x * (blockDim.x >> 6) + wave;
-    const uint32_t read  = unit / wpr;
-    const uint32_t slice = unit - read * wpr;
-    if (read >= p.n_reads)
-        return;
-    const uint32_t Gp   = 1u << p.gp_log2;
-    const uint32_t H    = GN_WAVE >> p.gp_log2;
-    const uint32_t gl   = lane & (Gp - 1);
-    const uint32_t hsub = lane >> p.gp_log2;
+    const uint32_t Gp    = 1u << p.gp_log2;
+    const uint32_t H     = GN_WAVE >> p.gp_log2;
+    const uint32_t gl    = lane & (Gp - 1);
+    const uint32_t hsub  = lane >> p.gp_log2;
     uint32_t*      rowtab = gn_lds + (size_t)wave * 32 * HFP;
 
-    uint32_t n = 0;
-    if (p.status[read] == GN_READ_OK)
-        n = p.n_hashes[read];
+    // Persistent waves: unit = (read, column slice), strided over the grid.  The metadata of the NEXT unit
+    // (status, n, hash slot) is loaded at the top of the current one and its hashes right after the current
+    // main loop, so the chain status -> n -> slot -> hashes -> rows of dependent HBM latencies that a fresh
+    // wave would pay before its first row load is hidden behind the previous read's work.
+    const uint64_t n_units = (uint64_t)p.n_reads * wpr;
+    const uint64_t stride  = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    uint64_t       unit    = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (unit >= n_units)
+        return;
+    // hash q of a unit feeds row-table entries idx = lane and lane + 64 (idx = q*HF + i)
+    const uint32_t q0 = (uint32_t)lane / HF, q1 = ((uint32_t)lane + GN_WAVE) / HF;
+    auto load_meta = [&](uint64_t u, uint32_t& rd, uint32_t& nn, uint64_t& so) {
+        rd = (uint32_t)(u / wpr);
+        nn = p.status[rd] == GN_READ_OK ? p.n_hashes[rd] : 0u;
+        so = p.slot_off[rd];
+    };
+    auto load_hashes = [&](uint32_t nn, uint64_t so, uint64_t& h0, uint64_t& h1) {
+        h0 = h1 = 0;
+        if (nn >= 1 && nn <= NMAX)
+        {
+            if (q0 < nn)
+                h0 = p.hashes[so + q0];
+            if (q1 < nn)
+                h1 = p.hashes[so + q1];
+        }
+    };
+    unsigned long long chunk_base = 0; // wave-private slice of the match buffer
+    uint32_t           chunk_left = 0;
+    uint32_t read, n;
+    uint64_t slot, hA, hB;
+    load_meta(unit, read, n, slot);
+    load_hashes(n, slot, hA, hB);
+
+    for (;;)
+    {
+    const uint32_t slice = (uint32_t)(unit - (uint64_t)read * wpr);
+    // prefetch the next unit's metadata (consumed after the main loop)
+    const uint64_t unit_n = unit + stride;
+    const bool     more   = unit_n < n_units;
+    uint32_t       read_n = 0, n_n = 0;
+    uint64_t       slot_n = 0, hA_n = 0, hB_n = 0;
+    if (more)
+        load_meta(unit_n, read_n, n_n, slot_n);
+
     if (n > NMAX || n == 0)
     {
         if (lane == 0)
@@ -761,17 +799,20 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
             p.seg_begin[(size_t)read * wpr + slice] = 0;
             p.seg_count[(size_t)read * wpr + slice] = 0;
         }
-        return;
+        if (!more)
+            break;
+        load_hashes(n_n, slot_n, hA_n, hB_n);
+        unit = unit_n; read = read_n; n = n_n; slot = slot_n; hA = hA_n; hB = hB_n;
+        continue;
     }
     const uint32_t  wi      = slice * 64 * LW + gl * LW;
     const bool      col_act = wi < p.W;
-    const uint64_t* hs      = p.hashes + p.slot_off[read];
 
-    for (uint32_t idx = lane; idx < n * HF; idx += GN_WAVE)
-    {
-        const uint32_t q = idx / HF, i = idx - q * HF;
-        rowtab[q * HFP + i] = gn_ibf_row(hs[q], i, p.shift, p.S);
-    }
+    gn_wave_lds_sync(); // previous unit's row-table reads are done
+    if ((uint32_t)lane < n * HF)
+        rowtab[q0 * HFP + ((uint32_t)lane - q0 * HF)] = gn_ibf_row(hA, (uint32_t)lane - q0 * HF, p.shift, p.S);
+    if ((uint32_t)lane + GN_WAVE < n * HF)
+        rowtab[q1 * HFP + ((uint32_t)lane + GN_WAVE - q1 * HF)] = gn_ibf_row(hB, (uint32_t)lane + GN_WAVE - q1 * HF, p.shift, p.S);
     gn_wave_lds_sync();
 
     uint32_t nib[ND][4];
@@ -850,6 +891,9 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
         }
     }
 
+    if (more) // next unit's hashes: the loads fly while this unit's epilogue runs
+        load_hashes(n_n, slot_n, hA_n, hB_n);
+
     // ---- epilogue: bytes, cross-group sum, SWAR threshold ----
     uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff)); // GanonClassify.cpp:492-495,720-724
     if (T == 0)
@@ -901,9 +945,21 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
             total += c;
         }
         // padding bins (>= B) of the last word never count: real filters keep them zero; be exact anyway
-        if (lane == 0)
-            base = atomicAdd(p.cursor, (unsigned long long)total);
-        base = gn_readlane64(base, 0);
+        // Output space comes from a wave-private chunk: one returning atomic on the global cursor per
+        // GN_MATCH_CHUNK matches instead of one per read (a single address sustains only ~90 atomics/us, which
+        // would cap the kernel at a few M reads/ms).  Unused chunk tails are holes; the gather pass compacts.
+        if (total > chunk_left)
+        {
+            const uint32_t need = total > GN_MATCH_CHUNK ? total : GN_MATCH_CHUNK;
+            unsigned long long nb = 0;
+            if (lane == 0)
+                nb = atomicAdd(p.cursor, (unsigned long long)need);
+            chunk_base = gn_readlane64(nb, 0);
+            chunk_left = need;
+        }
+        base = chunk_base;
+        chunk_base += total;
+        chunk_left -= total;
         if (base + total <= p.match_cap && owner && any)
         {
             gn_match* out = p.matches + base + my_off;
@@ -934,6 +990,10 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
         p.seg_begin[(size_t)read * wpr + slice] = base;
         p.seg_count[(size_t)read * wpr + slice] = total;
     }
+    if (!more)
+        break;
+    unit = unit_n; read = read_n; n = n_n; slot = slot_n; hA = hA_n; hB = hB_n;
+    } // persistent loop
 }
 
 template <int HF, int LW, int MAXT>
@@ -952,7 +1012,9 @@ template <int HF, int LW>
 static hipError_t gn_launch_fast_one(const GnCountParams& p, hipStream_t st)
 {
     const uint64_t units  = (uint64_t)p.n_reads * p.wpr;
-    const uint32_t blocks = (uint32_t)((units + 3) / 4);
+    uint32_t       blocks = (uint32_t)((units + 3) / 4);
+    if (blocks > p.max_blocks_fast)
+        blocks = p.max_blocks_fast;
     const size_t   lds    = 4 * 32 * (HF <= 4 ? 4 : 8) * 4;
     hipLaunchKernelGGL((gn_ibf_count_fast_kernel<HF, LW>), dim3(blocks), dim3(256), lds, st, p);
     return hipGetLastError();
