@@ -394,7 +394,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
     ok(gn_dmalloc(&s->d_status, max_reads));
     ok(gn_dmalloc(&s->d_matches, s->match_cap));
     ok(gn_dmalloc(&s->d_sorted, s->match_cap));
-    ok(gn_dmalloc(&s->d_ctr, 8));
+    ok(gn_dmalloc(&s->d_ctr, GN_NCTR));
     ok(gn_dmalloc(&s->d_seg_begin, nseg));
     ok(gn_dmalloc(&s->d_seg_count, nseg + 1));
     ok(gn_dmalloc(&s->d_seg_off, nseg + 1));
@@ -410,7 +410,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
         ok(gn_dmalloc(&s->d_work[0], s->work_cap));
         ok(gn_dmalloc(&s->d_work[1], s->work_cap));
     }
-    ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), GN_NCTR * sizeof(unsigned long long), hipHostMallocDefault));
     if (e != hipSuccess)
     {
         gn_stream_destroy(s);
@@ -581,7 +581,7 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     s->rel_cutoff = rel_cutoff;
 
     GN_HIP(hipEventRecord(s->ev[0], s->st));
-    GN_HIP(hipMemsetAsync(s->d_ctr, 0, 8 * sizeof(unsigned long long), s->st));
+    GN_HIP(hipMemsetAsync(s->d_ctr, 0, GN_NCTR * sizeof(unsigned long long), s->st));
     // hash slots: #windows per read, exclusive scan
     hipLaunchKernelGGL(gn_slot_count_kernel, dim3((s->n_reads + 1 + 255) / 256), dim3(256), 0, s->st, s->d_off1,
                        s->paired ? s->d_off2 : nullptr, s->n_reads, w, s->d_slot_cnt);
@@ -599,7 +599,7 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     mp.hashes       = s->d_hashes;
     mp.n_hashes     = s->d_nh;
     mp.status       = s->d_status;
-    mp.total_hashes = s->d_ctr + 1;
+    mp.total_hashes = s->d_ctr + 8; // 64 shards
     mp.force_generic = getenv("GANON_HIP_MINIMISER_GENERIC") ? 1u : 0u;
     if (w - k + 1 <= 65 && !mp.force_generic && !getenv("GANON_HIP_NO_LPR"))
     {
@@ -621,7 +621,7 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     rc = gn_run_group(s);
     if (rc)
         return rc;
-    GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
+    GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
     GN_HIP(hipEventRecord(s->ev[3], s->st));
     s->classified = true;
     return GN_OK;
@@ -646,7 +646,7 @@ static int gn_finish(gn_stream* s)
     {
         GN_HIP(hipStreamSynchronize(s->st));
         // blocking read-back of the counters (the async copy into h_ctr is only used for timing-free fast paths)
-        GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         const uint64_t need = s->h_ctr[0];
         if (getenv("GANON_HIP_DEBUG"))
             fprintf(stderr, "[gn_finish] attempt %d need %llu cap %llu nh %llu\n", attempt, (unsigned long long)need,
@@ -669,7 +669,7 @@ static int gn_finish(gn_stream* s)
         rc = gn_run_group(s);
         if (rc)
             return rc;
-        GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
+        GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
     }
     return gn_fail(GN_ENODEV, "match buffer kept overflowing");
 }
@@ -790,7 +790,7 @@ extern "C" int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_
     uint16_t*    dd  = nullptr;
     GN_HIP(gn_dmalloc(&dd, nel));
     // re-run the count kernel with the dense tap on (matches of this run are discarded)
-    unsigned long long saved[8];
+    unsigned long long saved[GN_NCTR];
     memcpy(saved, s->h_ctr, sizeof(saved));
     GnCountParams p{};
     p.rows = f->ibf.d_rows; p.S = f->ibf.S; p.W = (uint32_t)f->ibf.W; p.B = (uint32_t)f->ibf.B; p.shift = f->ibf.shift;
@@ -831,7 +831,9 @@ extern "C" int gn_stream_timings(gn_stream* s, gn_timings* t)
     hipEventElapsedTime(&tm.ms_minimiser, s->ev[0], s->ev[1]);
     hipEventElapsedTime(&tm.ms_count, s->ev[1], s->ev[2]);
     hipEventElapsedTime(&tm.ms_total, s->ev[0], s->ev[3]);
-    tm.n_hashes  = s->h_ctr[1];
+    tm.n_hashes = 0;
+    for (int i = 8; i < GN_NCTR; ++i)
+        tm.n_hashes += s->h_ctr[i];
     tm.n_matches = s->n_matches;
     if (s->f->is_hibf)
         tm.algo_bytes = s->h_ctr[2];

@@ -311,7 +311,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     while (true)
     {
         GN_HIP(hipStreamSynchronize(st));
-        GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         uint64_t n_work = s->h_ctr[3];
         if (n_work == 0)
             break;

@@ -9,6 +9,9 @@
 
 #include "../../include/ganon_hip.h"
 
+#define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
+                   // [6] exact match total [8..71] total-hashes shards
+
 // ---- minimiser kernel -----------------------------------------------------------------------
 struct GnMinimiserParams
 {
@@ -21,7 +24,7 @@ struct GnMinimiserParams
     uint64_t*           hashes;    // slot_off[n_reads] slots
     uint32_t*           n_hashes;  // per read
     uint8_t*            status;    // per read GN_READ_*
-    unsigned long long* total_hashes; // sum of n over GN_READ_OK reads
+    unsigned long long* total_hashes; // 64 shards (indexed by blockIdx & 63): sum of n over GN_READ_OK reads
     uint32_t            force_generic; // tests: take the byte-staged path even for narrow windows
     // lane-per-read kernel: reads longer than lpr_max_len go to defer_list; wave-per-read kernel: work_list input
     uint32_t                  lpr_max_len;

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
         }
     }
     if (lane == 0 && my_total)
-        atomicAdd(p.total_hashes, my_total);
+        atomicAdd(p.total_hashes + (blockIdx.x & 63u), my_total);
 }
 
 hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t st)
@@ -468,6 +468,8 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
     // Work items: either every read of the batch (work_list == nullptr) or the reads the fast kernel deferred.
     // Blocks stride over rounds of rpb reads; the trip count is block-uniform, so __syncthreads() is safe.
     const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads;
+    unsigned long long chunk_base = 0; // wave-private slice of the match buffer
+    uint32_t           chunk_left = 0;
     for (uint32_t round0 = blockIdx.x * rpb; round0 < n_work; round0 += gridDim.x * rpb)
     {
     const uint32_t widx = round0 + rslot;
@@ -680,9 +682,19 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
         unsigned long long base = 0;
         if (total)
         {
-            if (lane == 0)
-                base = atomicAdd(p.cursor, (unsigned long long)total);
-            base = gn_readlane64(base, 0);
+            // wave-private chunk of the match buffer (see the fast kernel): one global atomic per GN_MATCH_CHUNK
+            if (total > chunk_left)
+            {
+                const uint32_t need = total > GN_MATCH_CHUNK ? total : GN_MATCH_CHUNK;
+                unsigned long long nb = 0;
+                if (lane == 0)
+                    nb = atomicAdd(p.cursor, (unsigned long long)need);
+                chunk_base = gn_readlane64(nb, 0);
+                chunk_left = need;
+            }
+            base = chunk_base;
+            chunk_base += total;
+            chunk_left -= total;
             if (base + total <= p.match_cap)
             {
                 uint32_t run = 0;

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams 
     }
     mine_total = gn_lpr_wave_sum(mine_total);
     if (lane == 0 && mine_total)
-        atomicAdd(p.total_hashes, mine_total);
+        atomicAdd(p.total_hashes + (blockIdx.x & 63u), mine_total);
 }
 
 hipError_t gn_launch_minimiser_lpr(const GnMinimiserParams& p, hipStream_t st)
