@@ -58,21 +58,18 @@ def main() -> int:
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import ganon_amd
+    import bench_workload as bw
+    from ganon_amd import dist as gdist
+
+    rank, local_rank, world = gdist.env_rank_world()
     if not torch.cuda.is_available():
         log("bench.py: no GPU visible -- the hot path has no CPU fallback")
         return 2
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    import ganon_amd
-    import bench_workload as bw
+        gdist.init("nccl", torch.device("cuda", local_rank))
 
     bins, rows, h, n_reads = WORKLOADS[args.workload]
     if args.reads:
@@ -93,8 +90,7 @@ def main() -> int:
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        gdist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -113,16 +109,14 @@ def main() -> int:
         total_ms.append(tm["ms_total"])
     barrier()
     elapsed = time.perf_counter() - t_begin
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = gdist.max_over_ranks(elapsed, device="cuda")       # slowest rank defines the step time
+    total_reads = gdist.sum_over_ranks(n_reads, device="cuda")    # whole-job reads per step
 
     tm = st.timings()
     nh, status, mo, matches = st.fetch()
     n_class = int(np.count_nonzero(np.diff(mo)))
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    value = world * n_reads / (elapsed / max(1, args.steps)) / 1e6  # Mreads/s, whole job
+    value = total_reads / (elapsed / max(1, args.steps)) / 1e6  # Mreads/s, whole job
     avg_count_ms = float(np.mean(count_ms)) if count_ms else float("nan")
     achieved = tm["algo_bytes"] / (avg_count_ms * 1e-3) / 1e9 if count_ms else float("nan")
 
@@ -194,7 +188,8 @@ def main() -> int:
     st.destroy()
     flt.free()
     if world > 1:
-        dist.barrier()
+        import torch.distributed as dist
+        gdist.barrier()
         dist.destroy_process_group()
     return 0
 

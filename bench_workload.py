@@ -108,7 +108,8 @@ def plant_genomes(hip_filter, wl: FlatWorkload) -> int:
     g = wl.genomes
     n, L = g.shape
     st = HipStream(hip_filter, n, n * L)
-    st.submit(g.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L), None, wl.k, wl.w, 1.0)
+    st.upload(g.reshape(-1), np.arange(n + 1, dtype=np.uint64) * np.uint64(L), None)
+    st.minimisers(wl.k, wl.w)
     ho, hs = st.fetch_hashes()
     st.destroy()
     bins = np.repeat(wl.genome_bins, np.diff(ho).astype(np.int64)).astype(np.uint32)

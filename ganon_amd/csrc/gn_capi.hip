@@ -442,6 +442,7 @@ extern "C" int gn_stream_upload_reads(gn_stream* s, const uint8_t* bases, uint64
     s->paired     = off2 != nullptr;
     s->have_reads = true;
     s->classified = false;
+    s->hashed     = false;
     return GN_OK;
 }
 
@@ -562,24 +563,19 @@ static int gn_run_group(gn_stream* s)
     return GN_OK;
 }
 
-extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double rel_cutoff)
+// slot scan + minimiser kernels (shared by classify and the hash-only entry point)
+static int gn_run_minimisers(gn_stream* s, uint32_t k, uint32_t w)
 {
-    if (!s)
-        return gn_fail(GN_EINVAL, "null stream");
     if (!s->have_reads)
-        return gn_fail(GN_EINVAL, "gn_stream_classify: no reads uploaded");
+        return gn_fail(GN_EINVAL, "no reads uploaded on this stream");
     if (k < 1 || k > 32 || w < k)
         return gn_fail(GN_EINVAL, "need 1 <= k <= 32 and w >= k (k=%u w=%u)", k, w);
     if (w - k + 1 > 448 || w > 4096)
         return gn_fail(GN_ERANGE, "window of %u k-mers exceeds the LDS sliding window (max 448)", w - k + 1);
-    if (!(rel_cutoff >= 0.0 && rel_cutoff <= 1.0))
-        return gn_fail(GN_EINVAL, "rel_cutoff must be within [0,1]");
     gn_filter* f = s->f;
     GN_HIP(hipSetDevice(f->device));
-    s->k          = k;
-    s->w          = w;
-    s->rel_cutoff = rel_cutoff;
-
+    s->k = k;
+    s->w = w;
     GN_HIP(hipEventRecord(s->ev[0], s->st));
     GN_HIP(hipMemsetAsync(s->d_ctr, 0, GN_NCTR * sizeof(unsigned long long), s->st));
     // hash slots: #windows per read, exclusive scan
@@ -613,8 +609,29 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     }
     GN_HIP(gn_launch_minimiser(mp, f->n_cu, s->st));
     GN_HIP(hipEventRecord(s->ev[1], s->st));
+    s->hashed     = true;
+    s->classified = false;
+    return GN_OK;
+}
 
-    int rc = gn_run_count(s);
+extern "C" int gn_stream_minimisers(gn_stream* s, uint32_t k, uint32_t w)
+{
+    if (!s)
+        return gn_fail(GN_EINVAL, "null stream");
+    return gn_run_minimisers(s, k, w);
+}
+
+extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double rel_cutoff)
+{
+    if (!s)
+        return gn_fail(GN_EINVAL, "null stream");
+    if (!(rel_cutoff >= 0.0 && rel_cutoff <= 1.0))
+        return gn_fail(GN_EINVAL, "rel_cutoff must be within [0,1]");
+    s->rel_cutoff = rel_cutoff;
+    int rc        = gn_run_minimisers(s, k, w);
+    if (rc)
+        return rc;
+    rc = gn_run_count(s);
     if (rc)
         return rc;
     GN_HIP(hipEventRecord(s->ev[2], s->st));
@@ -739,9 +756,10 @@ extern "C" int gn_stream_fetch_hashes(gn_stream* s, uint64_t* hash_off, uint64_t
 {
     if (!s || !hash_off)
         return gn_fail(GN_EINVAL, "null argument");
-    int rc = gn_finish(s);
-    if (rc)
-        return rc;
+    if (!s->hashed)
+        return gn_fail(GN_EINVAL, "no minimisers computed on this stream");
+    GN_HIP(hipSetDevice(s->f->device));
+    GN_HIP(hipStreamSynchronize(s->st));
     const uint32_t        n = s->n_reads;
     std::vector<uint64_t> slot(n + 1);
     std::vector<uint32_t> nh(n);

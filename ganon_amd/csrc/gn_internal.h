@@ -191,7 +191,7 @@ struct gn_stream
     uint32_t n_reads = 0;
     uint64_t n_bases = 0;
     bool     paired  = false;
-    bool     have_reads = false, classified = false;
+    bool     have_reads = false, classified = false, hashed = false;
     uint32_t k = 0, w = 0;
     double   rel_cutoff = 0;
     uint64_t n_matches = 0;

@@ -16,7 +16,7 @@ MATCH_DTYPE = np.dtype([("read", "<u4"), ("target", "<u4"), ("count", "<u4")])
 # every symbol include/ganon_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_filter_upload_hibf", "gn_filter_emplace",
                "gn_filter_download_rows", "gn_filter_info", "gn_filter_free", "gn_stream_create", "gn_stream_destroy",
-               "gn_stream_upload_reads", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch",
+               "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch",
                "gn_stream_fetch_hashes", "gn_stream_dense_counts", "gn_stream_timings"]
 
 
@@ -64,6 +64,7 @@ def load_library():
     L.gn_stream_create.argtypes = [vp, u32, u64, u64, C.POINTER(vp)]
     L.gn_stream_destroy.argtypes = [vp]
     L.gn_stream_upload_reads.argtypes = [vp, vp, u64, vp, vp, u32]
+    L.gn_stream_minimisers.argtypes = [vp, u32, u32]
     L.gn_stream_classify.argtypes = [vp, u32, u32, C.c_double]
     L.gn_submit_batch.argtypes = [vp, vp, u64, vp, vp, u32, u32, u32, C.c_double]
     L.gn_stream_sync.argtypes = [vp]
@@ -181,6 +182,10 @@ class HipStream:
         self.n_reads = len(off1) - 1
         self._keep = (bases, off1, off2)
         _check(load_library().gn_stream_upload_reads(self._h, _p(bases), bases.size, _p(off1), _p(off2), self.n_reads))
+
+    def minimisers(self, k: int, w: int) -> None:
+        """hash only (no filter lookup); results via fetch_hashes()"""
+        _check(load_library().gn_stream_minimisers(self._h, k, w))
 
     def classify(self, k: int, w: int, rel_cutoff: float) -> None:
         _check(load_library().gn_stream_classify(self._h, k, w, float(rel_cutoff)))

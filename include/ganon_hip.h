@@ -121,6 +121,9 @@ int gn_stream_destroy(gn_stream* s);
 /* H2D only (asynchronous on the stream). */
 int gn_stream_upload_reads(gn_stream* s, const uint8_t* bases, uint64_t n_bases, const uint64_t* off1,
                            const uint64_t* off2, uint32_t n_reads);
+/* Minimiser hashes only (asynchronous): the build-side use of the same view
+ * (/root/reference/src/ganon-build/GanonBuild.cpp:198-200,236); results via gn_stream_fetch_hashes. */
+int gn_stream_minimisers(gn_stream* s, uint32_t k, uint32_t w);
 /* Kernels only, on the reads currently resident in the stream (asynchronous). */
 int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double rel_cutoff);
 /* upload + classify (asynchronous) -- the call the reference's loop body maps to */

@@ -242,3 +242,29 @@ def test_hibf_parity(hip, n_ub, tmax, depth, rel_cutoff):
         algo += hb.visited_bytes(hh, thr)
     assert n_true > 0
     assert st.timings()["algo_bytes"] == algo
+
+
+# --------------------------------------------------------------------------------------------- bin-range partition
+def test_partition_slices_hip(hip):
+    # config-5 style column slices on ONE GPU: the union of the per-slice results == the unpartitioned filter
+    import dist_worker as dw
+    from ganon_amd import partition as gp
+    ibf, b2t, n_targets, seqs = dw.make_case(seed=9)
+    bases, off1, _ = gu.pack_reads(seqs, None)
+    full = hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, n_targets)
+    st, nh, status, mo, m_full = _classify(hip, full, seqs, None, dw.K, dw.W, 0.25)
+    run = gp.hip_local_classify(0)
+    for world in (2, 4):
+        parts = []
+        for sl in gp.plan_partition(b2t, ibf.bins, world):
+            rows = gp.slice_rows(ibf.data, ibf.bin_words, sl)
+            nh2, st2, mo2, m = run(rows, sl.bins_local, ibf.bin_size, ibf.hash_funs, sl.bin2target_local,
+                                   max(1, len(sl.targets_global)), bases, off1, None, dw.K, dw.W, 0.25)
+            assert np.array_equal(nh2, nh)
+            g = np.zeros(len(m), dtype=hip.MATCH_DTYPE)
+            g["read"], g["count"] = m["read"], m["count"]
+            g["target"] = sl.targets_global[m["target"]] if len(m) else 0
+            parts.append(g)
+        got = np.concatenate(parts)
+        got = got[np.lexsort((got["target"], got["read"]))]
+        assert len(m_full) > 50 and np.array_equal(got, m_full), world
