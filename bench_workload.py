@@ -143,3 +143,107 @@ def checksum_matches(matches: np.ndarray) -> int:
     with np.errstate(over="ignore"):
         v = r * np.uint64(0x9E3779B97F4A7C15) + t * np.uint64(1000003) + c
         return int(np.sum(v, dtype=np.uint64))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# numpy restatement of the IBF row hash (only used to build synthetic HIBF workloads on the host; the flat
+# workloads plant their genomes through the device path instead)
+# ---------------------------------------------------------------------------------------------------------------
+_IBF_SEEDS = np.array([13572355802537770549, 13043817825332782213, 10650232656628343401, 16499269484942379435,
+                       4893150838803335377], dtype=np.uint64)
+
+
+def np_ibf_row(v: np.ndarray, i: int, rows: int) -> np.ndarray:
+    """row index of hash function i for uint64 values v; 64x64->high-64 multiply in 32-bit limbs"""
+    shift = np.uint64(64 - int(rows).bit_length())
+    with np.errstate(over="ignore"):
+        x = v * _IBF_SEEDS[i]
+        x ^= x >> shift
+        x = x * np.uint64(11400714819323198485)
+        S = np.uint64(rows)
+        m32 = np.uint64(0xFFFFFFFF)
+        xl, xh = x & m32, x >> np.uint64(32)
+        sl, sh = S & m32, S >> np.uint64(32)
+        ll, lh, hl, hh = xl * sl, xl * sh, xh * sl, xh * sh
+        mid = (ll >> np.uint64(32)) + (lh & m32) + (hl & m32)
+        return hh + (lh >> np.uint64(32)) + (hl >> np.uint64(32)) + (mid >> np.uint64(32))
+
+
+def np_emplace(rows_arr: np.ndarray, hashes: np.ndarray, bins: np.ndarray, hash_funs: int) -> None:
+    S, W = rows_arr.shape
+    for i in range(hash_funs):
+        r = np_ibf_row(hashes, i, S).astype(np.int64)
+        np.bitwise_or.at(rows_arr, (r, (bins >> 6).astype(np.int64)), np.uint64(1) << (bins & 63).astype(np.uint64))
+
+
+@dataclass
+class HibfWorkload:
+    name: str
+    k: int
+    w: int
+    rel_cutoff: float
+    read_len: int
+    n_reads: int
+    ibfs: list               # [(rows uint64[S*W], bins, S, h)]
+    next_ibf_id: list
+    bin_to_user: list
+    n_user_bins: int
+    bases: np.ndarray
+    off: np.ndarray
+    filter_bytes: int
+
+
+def make_hibf_workload(hip, name: str, n_user_bins: int, tmax: int, rows_top: int, rows_child: int, hash_funs: int,
+                       n_reads: int, read_len: int = 150, k: int = 19, w: int = 31, rel_cutoff: float = 0.75,
+                       planted_fraction: float = 0.5, genome_len: int = 3000, n_genomes: int = 4096, seed: int = 42,
+                       shard: int = 0) -> HibfWorkload:
+    """2-level HIBF as `raptor layout` makes it for tmax = sqrt(user bins) (src/ganon/build_update.py:487): a top IBF
+    of `tmax` merged bins, each pointing to a child IBF of n_user_bins/tmax leaf bins.  Bit matrices are
+    Bernoulli(0.5); the minimisers of `n_genomes` genomes (hashed on the device through gn_stream_minimisers) are
+    OR-ed into their leaf bin and into the merged bin above it."""
+    per_child = n_user_bins // tmax
+    assert per_child * tmax == n_user_bins
+    threads = min(32, os.cpu_count() or 1)
+    Wt, Wc = (tmax + 63) >> 6, (per_child + 63) >> 6
+    top = np.empty((rows_top, Wt), dtype=np.uint64)
+    _fill_random_u64(top, seed, threads)
+    children = []
+    for c in range(tmax):
+        a = np.empty((rows_child, Wc), dtype=np.uint64)
+        _fill_random_u64(a, seed + 1 + c, threads)
+        children.append(a)
+
+    rng = np.random.default_rng([seed, 1])
+    genomes = rng.integers(0, 4, size=(n_genomes, genome_len), dtype=np.uint8)
+    g_user = (np.arange(n_genomes, dtype=np.int64) * (n_user_bins // n_genomes)) % n_user_bins
+    # hash the genomes on the device (any filter will do for a hash-only stream)
+    tmpf = hip.HipFilter.ibf(None, 64, 64, 1)
+    st = hip.HipStream(tmpf, n_genomes, n_genomes * genome_len)
+    st.upload(ACGT[genomes].reshape(-1), np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(genome_len), None)
+    st.minimisers(k, w)
+    ho, hs = st.fetch_hashes()
+    st.destroy()
+    tmpf.free()
+    cnt = np.diff(ho).astype(np.int64)
+    ub = np.repeat(g_user, cnt)
+    np_emplace(top, hs, (ub // per_child).astype(np.uint64), hash_funs)
+    order = np.argsort(ub // per_child, kind="stable")
+    hs_s, ub_s = hs[order], ub[order]
+    bounds = np.searchsorted(ub_s // per_child, np.arange(tmax + 1))
+    for c in range(tmax):
+        a, b = bounds[c], bounds[c + 1]
+        if b > a:
+            np_emplace(children[c], hs_s[a:b], (ub_s[a:b] % per_child).astype(np.uint64), hash_funs)
+
+    rrng = np.random.default_rng([seed, 2, shard])
+    reads = rrng.integers(0, 4, size=(n_reads, read_len), dtype=np.uint8)
+    n_pl = int(n_reads * planted_fraction)
+    which = rrng.integers(0, n_genomes, size=n_pl)
+    pos = rrng.integers(0, genome_len - read_len, size=n_pl)
+    reads[np.arange(n_pl) * 2 if n_pl * 2 <= n_reads else np.arange(n_pl)] = genomes[which[:, None], pos[:, None] + np.arange(read_len)[None, :]]
+    ibfs = [(top.reshape(-1), tmax, rows_top, hash_funs)] + [(a.reshape(-1), per_child, rows_child, hash_funs) for a in children]
+    next_ids = [np.arange(1, tmax + 1, dtype=np.int64)] + [np.full(per_child, c + 1, dtype=np.int64) for c in range(tmax)]
+    b2u = [np.full(tmax, -1, dtype=np.int64)] + [np.arange(c * per_child, (c + 1) * per_child, dtype=np.int64) for c in range(tmax)]
+    fbytes = top.nbytes + sum(a.nbytes for a in children)
+    return HibfWorkload(name, k, w, rel_cutoff, read_len, n_reads, ibfs, next_ids, b2u, n_user_bins, ACGT[reads].reshape(-1),
+                        np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len), fbytes)

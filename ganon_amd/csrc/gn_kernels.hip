@@ -732,11 +732,11 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
 }
 
 // ================================================================================================
-// fast count + select kernel: identity bin->target map, reads with at most 30 minimisers
+// fast count + select kernel: identity bin->target map, reads with at most 127 minimisers
 // ================================================================================================
-// Same row-gather main loop, but the per-bin counters never leave the registers: with H = 2 hashes per wave
-// iteration a read of n <= 30 minimisers needs <= 15 iterations, so the 4-bit SWAR counters cannot overflow.
-// Epilogue: nibbles -> bytes, partial counts of the H hash groups added with lane-xor shuffles, SWAR
+// Same row-gather main loop, but the per-bin counters never leave the registers: 4-bit SWAR counters take 15
+// iterations and are then spilled into 8-bit SWAR registers (single 150 bp reads with H = 2 never spill in the loop).
+// Epilogue: partial counts of the H hash groups added with lane-xor shuffles, SWAR
 // compare of every byte against the read's cutoff T ((x + 0x80 - T) & 0x80), ballot; only lanes that own a
 // bin >= T extract (bin, count) pairs.  Reads with more minimisers are appended to `deferred` and handled by
 // gn_ibf_count_kernel.  One wave per (read, column slice); no LDS counters, no block barriers.
@@ -746,8 +746,9 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_lds[];
     constexpr int      ND   = 2 * LW;
     constexpr int      HFP  = HF <= 4 ? 4 : 8;
-    // n <= 30 keeps the nibble counters exact for H = 2; the two-entries-per-lane row table needs n*HF <= 128
-    constexpr uint32_t NMAX = HF <= 4 ? 30 : 25;
+    // counts live in 8-bit SWAR registers (4-bit first level, spilled every 15 iterations): exact up to 127, which
+    // also keeps the byte-wise compare below carry-free.  Reads with more minimisers go to the generic kernel.
+    constexpr uint32_t NMAX = 127;
 
     const int      lane  = threadIdx.x & (GN_WAVE - 1);
     const int      wave  = threadIdx.x >> 6;
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
     const uint32_t H     = GN_WAVE >> p.gp_log2;
     const uint32_t gl    = lane & (Gp - 1);
     const uint32_t hsub  = lane >> p.gp_log2;
-    uint32_t*      rowtab = gn_lds + (size_t)wave * 32 * HFP;
+    uint32_t*      rowtab = gn_lds + (size_t)wave * 128 * HFP;
 
     // Persistent waves: unit = (read, column slice), strided over the grid.  The metadata of the NEXT unit
     // (status, n, hash slot) is loaded at the top of the current one and its hashes right after the current
@@ -825,14 +826,36 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
         rowtab[q0 * HFP + ((uint32_t)lane - q0 * HF)] = gn_ibf_row(hA, (uint32_t)lane - q0 * HF, p.shift, p.S);
     if ((uint32_t)lane + GN_WAVE < n * HF)
         rowtab[q1 * HFP + ((uint32_t)lane + GN_WAVE - q1 * HF)] = gn_ibf_row(hB, (uint32_t)lane + GN_WAVE - q1 * HF, p.shift, p.S);
+    for (uint32_t idx = (uint32_t)lane + 2 * GN_WAVE; idx < n * HF; idx += GN_WAVE) // reads with more than 128/HF minimisers
+    {
+        const uint32_t q = idx / HF, i = idx - q * HF;
+        rowtab[q * HFP + i] = gn_ibf_row(p.hashes[slot + q], i, p.shift, p.S);
+    }
     gn_wave_lds_sync();
 
     uint32_t nib[ND][4];
+    uint32_t byt[ND][4][2];
 #pragma unroll
     for (int d = 0; d < ND; ++d)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            nib[d][j] = 0;
+        {
+            nib[d][j]    = 0;
+            byt[d][j][0] = 0;
+            byt[d][j][1] = 0;
+        }
+    uint32_t acc_n = 0; // iterations since the nibbles were last spilled into the byte counters (wave-uniform)
+    auto spill_nibbles = [&]() {
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                byt[d][j][0] += nib[d][j] & 0x0F0F0F0Fu;
+                byt[d][j][1] += (nib[d][j] >> 4) & 0x0F0F0F0Fu;
+                nib[d][j] = 0;
+            }
+    };
 
     const uint32_t iters = (n + H - 1) / H;
     auto issue = [&](uint32_t it, GnRowRegs<HF, LW>& R) {
@@ -885,6 +908,11 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
             for (int j = 0; j < 4; ++j)
                 nib[d][j] += (a >> j) & 0x11111111u;
         }
+        if (++acc_n == 15)
+        {
+            spill_nibbles();
+            acc_n = 0;
+        }
     };
     {
         GnRowRegs<HF, LW> A, Bq;
@@ -910,9 +938,10 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
     uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff)); // GanonClassify.cpp:492-495,720-724
     if (T == 0)
         T = 1;
-    const uint32_t Kc = (0x80u - T) * 0x01010101u; // T <= n <= 30, counts <= 30: no carry between bytes
-    uint32_t       byt[ND][4][2];
+    const uint32_t Kc = (0x80u - T) * 0x01010101u; // 1 <= T <= n <= 127 and counts <= 127: no carry between bytes
     uint32_t       any = 0;
+    if (acc_n)
+        spill_nibbles();
 #pragma unroll
     for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -920,7 +949,7 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp)
             {
-                uint32_t x = (nib[d][j] >> (4 * pp)) & 0x0F0F0F0Fu;
+                uint32_t x = byt[d][j][pp];
                 for (uint32_t off = Gp; off < GN_WAVE; off <<= 1) // partial counts of the H hash groups
                     x += __shfl_xor(x, (int)off);
                 byt[d][j][pp] = x;
@@ -1027,7 +1056,7 @@ static hipError_t gn_launch_fast_one(const GnCountParams& p, hipStream_t st)
     uint32_t       blocks = (uint32_t)((units + 3) / 4);
     if (blocks > p.max_blocks_fast)
         blocks = p.max_blocks_fast;
-    const size_t   lds    = 4 * 32 * (HF <= 4 ? 4 : 8) * 4;
+    const size_t   lds    = 4 * 128 * (HF <= 4 ? 4 : 8) * 4;
     hipLaunchKernelGGL((gn_ibf_count_fast_kernel<HF, LW>), dim3(blocks), dim3(256), lds, st, p);
     return hipGetLastError();
 }

@@ -268,3 +268,40 @@ def test_partition_slices_hip(hip):
         got = np.concatenate(parts)
         got = got[np.lexsort((got["target"], got["read"]))]
         assert len(m_full) > 50 and np.array_equal(got, m_full), world
+
+
+@pytest.mark.parametrize("bins,rows,h,paired", [(4096, 5003, 4, False), (4096, 5003, 4, True), (32768, 1201, 4, False),
+                                                  (32768, 1201, 3, True), (8192, 2003, 5, False), (640, 3001, 2, True)])
+def test_planted_matches_many_reads(hip, bins, rows, h, paired):
+    # thousands of reads per launch (persistent waves loop over many reads), true matches with counts up to n
+    # (> 15: the 4-bit first-level counters must spill correctly), single and paired (n ~ 35) reads
+    k, w = 19, 31
+    rng = np.random.default_rng(bins + h + paired)
+    ibf = gf.random_ibf(bins, rows, h, 0.3, seed=bins + 7 * h)
+    genomes = [gu.random_seq(rng, 1200) for _ in range(64)]
+    gb = rng.integers(0, bins, size=64)
+    for g, b in zip(genomes, gb):
+        ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), int(b))
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h)
+    n = 3000
+    s1, s2 = [], []
+    for i in range(n):
+        if i % 3 == 2:
+            s1.append(gu.random_seq(rng, 150))
+            s2.append(gu.random_seq(rng, 150))
+        else:
+            g = genomes[i % 64]
+            p = int(rng.integers(0, 900))
+            s1.append(g[p:p + 150])
+            s2.append(g[p + 100:p + 250])
+    st, nh, status, mo, m = _classify(hip, flt, s1, s2 if paired else None, k, w, 0.75)
+    ho, hs = st.fetch_hashes()
+    b2t = np.arange(bins, dtype=np.uint32)
+    tot = 0
+    for i in range(n):
+        exp_m, _ = gu.oracle_matches(ibf, b2t, bins, hs[int(ho[i]):int(ho[i + 1])], 0.75)
+        got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+        assert got == exp_m, (i, nh[i], got[:4], exp_m[:4])
+        tot += len(exp_m)
+    assert tot >= n // 2 and tot == len(m)
+    assert nh.max() > (30 if paired else 15)
