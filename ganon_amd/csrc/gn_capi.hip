@@ -670,7 +670,7 @@ static int gn_finish(gn_stream* s)
                     (unsigned long long)s->match_cap, (unsigned long long)s->h_ctr[1]);
         if (need <= s->match_cap)
         {
-            s->n_matches = s->f->is_hibf ? need : s->h_ctr[6];
+            s->n_matches = s->h_ctr[6]; // exact (the cursor `need` counts allocated space including chunk holes)
             return GN_OK;
         }
         const uint64_t ncap = need + need / 8 + 1024;

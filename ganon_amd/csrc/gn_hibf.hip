@@ -55,123 +55,167 @@ struct GnHibfLevelParams
     uint32_t            lds_bins;  // LDS counters per wave
 };
 
+#define GN_HIBF_CHUNK 64u // wave-private slices of the work queue / match buffer (one global atomic per slice)
+
+// Persistent: waves stride over the (read, ibf) items of this level.  Queue appends and matches go to wave-private
+// chunks (a single counter address only sustains ~90 atomics/us); unused chunk tails hold sentinels
+// (read = 0xFFFFFFFF / key = ~0) that the next level and the final sort ignore.
 __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_hl[];
-    const int      lane = threadIdx.x & (GN_WAVE - 1);
-    const int      wave = threadIdx.x >> 6;
-    const uint32_t item = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (item >= p.n_work)
-        return;
-    uint32_t* cnt = gn_hl + (size_t)wave * p.lds_bins;
+    const int      lane   = threadIdx.x & (GN_WAVE - 1);
+    const int      wave   = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    uint32_t*      cnt    = gn_hl + (size_t)wave * p.lds_bins;
 
-    const uint2         wk   = p.work_in[item];
-    const uint32_t      read = wk.x;
-    const GnHibfIbfDev  f    = p.ibfs[wk.y];
-    const uint32_t      n    = p.n_hashes[read];
-    const uint64_t*     hs   = p.hashes + p.slot_off[read];
-    const uint32_t      TB   = f.W * 64;
+    unsigned long long my_bytes = 0, my_matches = 0;
+    unsigned long long wq_base = 0, mq_base = 0; // current chunk cursors (wave-uniform)
+    uint32_t           wq_left = 0, mq_left = 0;
 
-    for (uint32_t i = lane; i < TB; i += GN_WAVE)
-        cnt[i] = 0;
-    gn_hibf_wave_sync();
-
-    // lanes = (hash sub-index, word): Gp lanes cover the W words of a row (W <= 64), or the row is walked in
-    // 64-word chunks with one hash per iteration (W > 64)
-    uint32_t gp_log2 = 0;
-    while ((1u << gp_log2) < f.W && gp_log2 < 6)
-        ++gp_log2;
-    const uint32_t Gp   = 1u << gp_log2;
-    const uint32_t H    = GN_WAVE >> gp_log2;
-    const uint32_t gl   = lane & (Gp - 1);
-    const uint32_t hsub = lane >> gp_log2;
-
-    for (uint32_t q0 = 0; q0 < n; q0 += H)
+    for (uint32_t item = blockIdx.x * (blockDim.x >> 6) + wave; item < p.n_work; item += nwaves)
     {
-        const uint32_t q = q0 + hsub;
-        if (q < n)
+        const uint2    wk   = p.work_in[item];
+        const uint32_t read = wk.x;
+        if (read == 0xFFFFFFFFu) // hole left by a chunked append of the previous level
+            continue;
+        const GnHibfIbfDev f  = p.ibfs[wk.y];
+        const uint32_t     n  = p.n_hashes[read];
+        const uint64_t*    hs = p.hashes + p.slot_off[read];
+        const uint32_t     TB = f.W * 64;
+
+        gn_hibf_wave_sync();
+        for (uint32_t i = lane; i < TB; i += GN_WAVE)
+            cnt[i] = 0;
+        gn_hibf_wave_sync();
+
+        // lanes = (hash sub-index, word): Gp lanes cover the W words of a row (W <= 64), or the row is walked in
+        // 64-word chunks with one hash per iteration (W > 64)
+        uint32_t gp_log2 = 0;
+        while ((1u << gp_log2) < f.W && gp_log2 < 6)
+            ++gp_log2;
+        const uint32_t Gp   = 1u << gp_log2;
+        const uint32_t H    = GN_WAVE >> gp_log2;
+        const uint32_t gl   = lane & (Gp - 1);
+        const uint32_t hsub = lane >> gp_log2;
+
+        for (uint32_t q0 = 0; q0 < n; q0 += H)
         {
-            const uint64_t v = hs[q];
-            uint32_t       rows[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-                rows[i] = (uint32_t)i < f.h ? gn_hibf_row(v, i, f.shift, f.S) : 0u;
-            for (uint32_t wd = gl; wd < f.W; wd += Gp)
+            const uint32_t q = q0 + hsub;
+            if (q < n)
             {
-                uint64_t m = ~0ULL;
+                const uint64_t v = hs[q];
+                uint32_t       rows[5];
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
-                    if ((uint32_t)i < f.h)
-                        m &= f.rows[(uint64_t)rows[i] * f.W + wd];
-                while (m)
+                    rows[i] = (uint32_t)i < f.h ? gn_hibf_row(v, i, f.shift, f.S) : 0u;
+                for (uint32_t wd = gl; wd < f.W; wd += Gp)
                 {
-                    const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                    m &= m - 1;
-                    atomicAdd(&cnt[wd * 64 + b], 1u);
+                    uint64_t m = ~0ULL;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        if ((uint32_t)i < f.h)
+                            m &= f.rows[(uint64_t)rows[i] * f.W + wd];
+                    while (m)
+                    {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        atomicAdd(&cnt[wd * 64 + b], 1u);
+                    }
                 }
             }
         }
-    }
-    gn_hibf_wave_sync();
+        gn_hibf_wave_sync();
 
-    // threshold_cutoff = max(1, ceil(n * rel_cutoff))  (GanonClassify.cpp:492-495,720-724); passed to bulk_count (:553)
-    uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
-    if (T == 0)
-        T = 1;
+        // threshold_cutoff = max(1, ceil(n * rel_cutoff))  (GanonClassify.cpp:492-495,720-724); passed to bulk_count (:553)
+        uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
+        if (T == 0)
+            T = 1;
 
-    for (uint32_t r0 = 0; r0 < f.n_runs; r0 += GN_WAVE)
-    {
-        const uint32_t r = r0 + lane;
-        bool           hit = false, merged = false;
-        uint32_t       sum = 0;
-        int32_t        tgt = 0;
-        if (r < f.n_runs)
+        for (uint32_t r0 = 0; r0 < f.n_runs; r0 += GN_WAVE)
         {
-            const uint4 run = f.runs[r]; // first bin, n bins, user bin (-1 merged), child ibf
-            for (uint32_t b = 0; b < run.y; ++b)
-                sum = (sum + cnt[run.x + b]) & 0xFFFFu; // value_t = uint16_t wraps (hibf.hpp:438,442)
-            merged = (int32_t)run.z < 0;
-            tgt    = merged ? (int32_t)run.w : (int32_t)run.z;
-            hit    = sum >= T; // :447 / :455
-        }
-        // merged bins -> next level queue
-        const uint64_t mm = __ballot(hit && merged);
-        if (mm)
-        {
-            unsigned long long base = 0;
-            if (lane == 0)
-                base = atomicAdd(&p.ctr[3], (unsigned long long)__popcll(mm));
-            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-            if (hit && merged)
+            const uint32_t r = r0 + lane;
+            bool           hit = false, merged = false;
+            uint32_t       sum = 0;
+            int32_t        tgt = 0;
+            if (r < f.n_runs)
             {
-                const unsigned long long o = base + __popcll(mm & ((1ULL << lane) - 1ULL));
-                if (o < p.work_cap)
-                    p.work_out[o] = make_uint2(read, (uint32_t)tgt);
+                const uint4 run = f.runs[r]; // first bin, n bins, user bin (-1 merged), child ibf
+                for (uint32_t b = 0; b < run.y; ++b)
+                    sum = (sum + cnt[run.x + b]) & 0xFFFFu; // value_t = uint16_t wraps (hibf.hpp:438,442)
+                merged = (int32_t)run.z < 0;
+                tgt    = merged ? (int32_t)run.w : (int32_t)run.z;
+                hit    = sum >= T; // :447 / :455
             }
-        }
-        // leaf runs -> matches
-        const uint64_t lm = __ballot(hit && !merged);
-        if (lm)
-        {
-            unsigned long long base = 0;
-            if (lane == 0)
-                base = atomicAdd(&p.ctr[0], (unsigned long long)__popcll(lm));
-            base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
-            if (hit && !merged)
+            // merged bins -> next level queue
+            const uint64_t mm = __ballot(hit && merged);
+            if (mm)
             {
-                const unsigned long long o = base + __popcll(lm & ((1ULL << lane) - 1ULL));
-                if (o < p.match_cap)
+                const uint32_t need = (uint32_t)__popcll(mm);
+                if (need > wq_left)
                 {
-                    p.keys[o] = ((uint64_t)read << 32) | (uint32_t)tgt;
-                    p.vals[o] = sum;
+                    const uint32_t     take = need > GN_HIBF_CHUNK ? need : GN_HIBF_CHUNK;
+                    unsigned long long nb   = 0;
+                    if (lane == 0)
+                        nb = atomicAdd(&p.ctr[3], (unsigned long long)take);
+                    nb = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(nb >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
+                    for (uint32_t i = lane; i < take; i += GN_WAVE) // sentinels first; real entries overwrite them
+                        if (nb + i < p.work_cap)
+                            p.work_out[nb + i] = make_uint2(0xFFFFFFFFu, 0u);
+                    wq_base = nb;
+                    wq_left = take;
                 }
+                if (hit && merged)
+                {
+                    const unsigned long long o = wq_base + __popcll(mm & ((1ULL << lane) - 1ULL));
+                    if (o < p.work_cap)
+                        p.work_out[o] = make_uint2(read, (uint32_t)tgt);
+                }
+                wq_base += need;
+                wq_left -= need;
+            }
+            // leaf runs -> matches
+            const uint64_t lm = __ballot(hit && !merged);
+            if (lm)
+            {
+                const uint32_t need = (uint32_t)__popcll(lm);
+                if (need > mq_left)
+                {
+                    const uint32_t     take = need > GN_HIBF_CHUNK ? need : GN_HIBF_CHUNK;
+                    unsigned long long nb   = 0;
+                    if (lane == 0)
+                        nb = atomicAdd(&p.ctr[0], (unsigned long long)take);
+                    nb = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(nb >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
+                    for (uint32_t i = lane; i < take; i += GN_WAVE)
+                        if (nb + i < p.match_cap)
+                            p.keys[nb + i] = ~0ULL; // sentinel: sorts last
+                    mq_base = nb;
+                    mq_left = take;
+                }
+                if (hit && !merged)
+                {
+                    const unsigned long long o = mq_base + __popcll(lm & ((1ULL << lane) - 1ULL));
+                    if (o < p.match_cap)
+                    {
+                        p.keys[o] = ((uint64_t)read << 32) | (uint32_t)tgt;
+                        p.vals[o] = sum;
+                    }
+                }
+                mq_base += need;
+                mq_left -= need;
+                my_matches += need;
             }
         }
+        my_bytes += (unsigned long long)n * f.h * f.W * 8ull; // algorithmic bytes of this visit
     }
     if (lane == 0)
-        atomicAdd(&p.ctr[2], (unsigned long long)n * f.h * f.W * 8ull); // algorithmic bytes of this visit
+    {
+        if (my_bytes)
+            atomicAdd(&p.ctr[2], my_bytes);
+        if (my_matches)
+            atomicAdd(&p.ctr[6], my_matches);
+    }
 }
 
 __global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t n_reads, unsigned long long* count)
@@ -195,6 +239,8 @@ __global__ void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
+        return;
+    if (keys[i] == ~0ULL) // chunk hole (sorted to the end)
         return;
     const uint32_t read = (uint32_t)(keys[i] >> 32);
     const uint32_t nh   = n_hashes[read];
@@ -302,6 +348,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         return rc;
     const uint32_t n = s->n_reads;
     GN_HIP(hipMemsetAsync(s->d_ctr + 2, 0, 2 * sizeof(unsigned long long), st)); // algo bytes, work count
+    GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
     if (n)
         hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n,
@@ -351,7 +398,11 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         const size_t   lds = (size_t)f->max_bins * 4 * wpb;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_hibf_level_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(gn_hibf_level_kernel, dim3((p.n_work + wpb - 1) / wpb), dim3(wpb * 64), lds, st, p);
+        uint32_t blocks = (p.n_work + wpb - 1) / wpb;
+        const uint32_t max_blocks = (uint32_t)f->n_cu * (wpb == 4 ? 8u : 16u);
+        if (blocks > max_blocks)
+            blocks = max_blocks;
+        hipLaunchKernelGGL(gn_hibf_level_kernel, dim3(blocks), dim3(wpb * 64), lds, st, p);
         GN_HIP(hipGetLastError());
         cur ^= 1;
     }

@@ -1,6 +1,6 @@
 """Perf ablation of the count kernel (GANON_HIP_ABLATE flags) on the flat8g shape with fewer reads."""
 import os, sys, time
-sys.path[:0] = ['.']
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import numpy as np
 import ganon_amd, bench_workload as bw
 n_reads = int(os.environ.get("N_READS", 4_000_000))

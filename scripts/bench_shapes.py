@@ -1,6 +1,6 @@
 """Quick timing of the other BASELINE.json shapes (wide rows, HIBF) -- exploration, not the driver bench."""
 import os, sys, time
-sys.path[:0] = ['.']
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
 import numpy as np
 import ganon_amd, bench_workload as bw
 which = os.environ.get("SHAPES", "flat32k,hibf64k").split(",")
