@@ -180,15 +180,32 @@ extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const ui
         for (uint64_t b = 0; b < ibf->bins; ++b)
             if (bin2target[b] != 0xFFFFFFFFu)
                 bins[fill[bin2target[b]]++] = (uint32_t)b;
+        std::vector<uint32_t> lds_idx(bins.size());
+        for (size_t x = 0; x < bins.size(); ++x)
+            lds_idx[x] = gn_count_lds_index(geom, bins[x]);
         hipError_t e1 = hipMalloc(reinterpret_cast<void**>(&f->d_tgt_off), off.size() * 4);
         hipError_t e2 = hipMalloc(reinterpret_cast<void**>(&f->d_tgt_bins), bins.size() * 4);
-        if (e1 != hipSuccess || e2 != hipSuccess)
+        hipError_t e3 = hipMalloc(reinterpret_cast<void**>(&f->d_tgt_lds), bins.size() * 4);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
         {
             gn_filter_free(f);
             return gn_fail(GN_ENOMEM, "target map allocation failed");
         }
         hipMemcpy(f->d_tgt_off, off.data(), off.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(f->d_tgt_bins, bins.data(), bins.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(f->d_tgt_lds, lds_idx.data(), lds_idx.size() * 4, hipMemcpyHostToDevice);
+        std::vector<uint4> rec(n_targets ? n_targets : 1);
+        for (uint32_t t = 0; t < n_targets; ++t)
+        {
+            const uint32_t len = off[t + 1] - off[t];
+            rec[t] = make_uint4(off[t], len, len >= 1 ? lds_idx[off[t]] : 0u, len >= 2 ? lds_idx[off[t] + 1] : 0u);
+        }
+        if (hipMalloc(reinterpret_cast<void**>(&f->d_tgt_rec), rec.size() * sizeof(uint4)) != hipSuccess)
+        {
+            gn_filter_free(f);
+            return gn_fail(GN_ENOMEM, "target map allocation failed");
+        }
+        hipMemcpy(f->d_tgt_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice);
     }
     *out = f;
     return GN_OK;
@@ -245,6 +262,10 @@ extern "C" int gn_filter_free(gn_filter* f)
         hipFree(f->d_tgt_off);
     if (f->d_tgt_bins)
         hipFree(f->d_tgt_bins);
+    if (f->d_tgt_lds)
+        hipFree(f->d_tgt_lds);
+    if (f->d_tgt_rec)
+        hipFree(f->d_tgt_rec);
     for (auto& i : f->ibfs)
         if (i.d_rows)
             hipFree(i.d_rows);
@@ -511,6 +532,8 @@ static int gn_run_count(gn_stream* s)
     p.shift      = f->ibf.shift;
     p.tgt_off    = f->identity ? nullptr : f->d_tgt_off;
     p.tgt_bins   = f->d_tgt_bins;
+    p.tgt_lds    = f->d_tgt_lds;
+    p.tgt_rec    = f->d_tgt_rec;
     p.tgt_ids    = nullptr;
     p.n_targets  = f->n_targets;
     p.hashes     = s->d_hashes;
@@ -812,7 +835,7 @@ extern "C" int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_
     memcpy(saved, s->h_ctr, sizeof(saved));
     GnCountParams p{};
     p.rows = f->ibf.d_rows; p.S = f->ibf.S; p.W = (uint32_t)f->ibf.W; p.B = (uint32_t)f->ibf.B; p.shift = f->ibf.shift;
-    p.tgt_off = f->identity ? nullptr : f->d_tgt_off; p.tgt_bins = f->d_tgt_bins; p.n_targets = f->n_targets;
+    p.tgt_off = f->identity ? nullptr : f->d_tgt_off; p.tgt_bins = f->d_tgt_bins; p.tgt_lds = f->d_tgt_lds; p.tgt_rec = f->d_tgt_rec; p.n_targets = f->n_targets;
     p.hashes = s->d_hashes; p.slot_off = s->d_slot_off; p.n_hashes = s->d_nh; p.status = s->d_status;
     p.n_reads = s->n_reads; p.rel_cutoff = s->rel_cutoff; p.wpr = f->geom.wpr; p.gp_log2 = f->geom.gp_log2;
     p.slice_dwords = f->geom.slice_dwords;

@@ -47,6 +47,8 @@ struct GnCountParams
     uint32_t        shift;    // hash_shift
     const uint32_t* tgt_off;  // CSR over targets (n_targets+1); nullptr when identity
     const uint32_t* tgt_bins;
+    const uint4*    tgt_rec;  // per target: {first CSR entry, #bins, LDS slot of bin 0, LDS slot of bin 1}
+    const uint32_t* tgt_lds;  // per CSR entry: (LDS dword of the bin's u16 pair) * 2 + half (see gn_count_lds_index)
     const uint32_t* tgt_ids;  // id reported for CSR target t (nullptr = t)
     uint32_t        n_targets;
     // batch
@@ -91,6 +93,8 @@ struct GnCountGeometry
 
 // returns false (and a message) when the IBF shape is outside what the kernel supports
 bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const char** why);
+// LDS position of bin b inside a read's count area for geometry g: dword index * 2 + u16 half
+uint32_t gn_count_lds_index(const GnCountGeometry& g, uint32_t b);
 
 hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t st);
 hipError_t gn_launch_count(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
@@ -139,6 +143,8 @@ struct gn_filter
     GnIbfHost       ibf;
     uint32_t*       d_tgt_off  = nullptr;
     uint32_t*       d_tgt_bins = nullptr;
+    uint32_t*       d_tgt_lds  = nullptr;
+    uint4*          d_tgt_rec  = nullptr;
     uint32_t        n_targets  = 0;
     bool            identity   = false;
     GnCountGeometry geom{};

@@ -16,6 +16,7 @@
 
 #define GN_WAVE 64
 #define GN_MATCH_CHUNK 256u
+#define GN_STAGE_CAP 128u // per-wave LDS staging of (target, count) hits in the generic select pass
 
 // ------------------------------------------------------------------------------------------------
 // dna4 rank table (seqan3::dna4 char_to_rank): ACGT(U) exact, IUPAC collapse, else A
@@ -427,13 +428,29 @@ bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const
     g->slice_dwords  = 32 * g->lw * ((1u << gp_log2) + 1);
     const size_t cnt = (size_t)g->rpb * wpr2 * g->slice_dwords * 4;
     const size_t tab = (size_t)(g->block / 64) * 64 * 8 * 4; // row table: 64 hashes x (up to 8 padded) u32
-    g->lds_bytes     = cnt + tab;
+    const size_t stg = (size_t)(g->block / 64) * 2 * GN_STAGE_CAP * 4; // match staging
+    g->lds_bytes     = cnt + tab + stg;
     if (g->lds_bytes > 160 * 1024)
     {
         *why = "per-read count vector does not fit LDS";
         return false;
     }
     return true;
+}
+
+uint32_t gn_count_lds_index(const GnCountGeometry& g, uint32_t b)
+{
+    // mirrors bin_count() in gn_ibf_count_kernel
+    const uint32_t LW   = g.lw;
+    const uint32_t Gp   = 1u << g.gp_log2;
+    const uint32_t word = b >> 6;
+    const uint32_t sl   = word / (64 * LW);
+    const uint32_t wl   = word - sl * 64 * LW;
+    const uint32_t gg   = wl / LW;
+    const uint32_t tp   = (wl - gg * LW) * 64 + (b & 63);
+    const uint32_t d = tp >> 5, t = tp & 31;
+    const uint32_t q = 16 * d + (t >> 1), half = t & 1;
+    return (uint32_t)(((size_t)sl * g.slice_dwords + q * (Gp + 1) + gg) * 2 + half);
 }
 
 template <int HF, int LW>
@@ -464,6 +481,7 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
     uint32_t* cnt_read = gn_lds + (size_t)rslot * wpr * p.slice_dwords; // all slices of my read
     uint32_t* cnt      = cnt_read + (size_t)slice * p.slice_dwords;     // my slice
     uint32_t* rowtab   = gn_lds + (size_t)rpb * wpr * p.slice_dwords + (size_t)wave * 64 * 8;
+    uint32_t* stage    = gn_lds + (size_t)rpb * wpr * p.slice_dwords + (size_t)nwaves * 64 * 8 + (size_t)wave * 2 * GN_STAGE_CAP;
 
     // Work items: either every read of the batch (work_list == nullptr) or the reads the fast kernel deferred.
     // Blocks stride over rounds of rpb reads; the trip count is block-uniform, so __syncthreads() is safe.
@@ -657,27 +675,84 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
         const uint32_t t_lo     = min(p.n_targets, slice * per_wave);
         const uint32_t t_hi     = min(p.n_targets, t_lo + per_wave);
 
-        auto target_count = [&](uint32_t t) -> uint32_t {
-            uint32_t s;
-            if (p.tgt_off == nullptr)
-                s = bin_count(t);
-            else
-            {
-                s = 0;
-                const uint32_t e = p.tgt_off[t + 1];
-                for (uint32_t x = p.tgt_off[t]; x < e; ++x)
-                    s += bin_count(p.tgt_bins[x]);
-            }
+        // Per-target record (host-built, one 16-byte load): {first CSR entry, #bins, LDS slot of bin 0, LDS slot of
+        // bin 1}; an LDS slot = (dword of the bin's u16 pair inside the read's count area) * 2 + half, the same
+        // mapping as bin_count().  Targets with more than two bins read the rest through tgt_lds.
+        auto lds_count = [&](uint32_t a) -> uint32_t {
+            const uint32_t v = cnt_read[a >> 1];
+            return (a & 1u) ? (v >> 16) : (v & 0xFFFFu);
+        };
+        auto rec_count = [&](const uint4& rec) -> uint32_t {
+            uint32_t s = 0;
+            if (rec.y >= 1)
+                s += lds_count(rec.z);
+            if (rec.y >= 2)
+                s += lds_count(rec.w);
+            for (uint32_t x = 2; x < rec.y; ++x)
+                s += lds_count(p.tgt_lds[rec.x + x]);
             return s > n ? n : s; // :525-526
         };
-
-        uint32_t total = 0;
-        if (n)
-            for (uint32_t t0 = t_lo; t0 < t_hi; t0 += GN_WAVE)
+        auto target_count = [&](uint32_t t) -> uint32_t {
+            if (p.tgt_off == nullptr)
             {
-                const uint32_t t   = t0 + lane;
-                const bool     hit = t < t_hi && target_count(t) >= T;
-                total += __popcll(__ballot(hit));
+                const uint32_t s = bin_count(t);
+                return s > n ? n : s;
+            }
+            return rec_count(p.tgt_rec[t]);
+        };
+
+        // Single pass: hits are staged in a small per-wave LDS list (ascending target order) and copied to one
+        // reserved segment at the end; a read with more than GN_STAGE_CAP hits in this slice falls back to
+        // count-then-write (two passes).
+        uint32_t total    = 0;
+        bool     overflow = false;
+        if (n)
+            for (uint32_t t0 = t_lo; t0 < t_hi; t0 += 4 * GN_WAVE)
+            {
+                // four 64-target chunks per trip: their records are fetched together so that the (L2-resident) table
+                // latency is paid once per four chunks
+                uint4 rec[4];
+                if (p.tgt_off != nullptr)
+                {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                    {
+                        const uint32_t t = t0 + u * GN_WAVE + lane;
+                        rec[u]           = t < t_hi ? p.tgt_rec[t] : make_uint4(0, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    const uint32_t t   = t0 + u * GN_WAVE + lane;
+                    uint32_t       c   = 0;
+                    bool           hit = false;
+                    if (t < t_hi)
+                    {
+                        if (p.tgt_off != nullptr)
+                            c = rec_count(rec[u]);
+                        else
+                        {
+                            c = bin_count(t);
+                            c = c > n ? n : c;
+                        }
+                        hit = c >= T;
+                    }
+                    const uint64_t bm = __ballot(hit);
+                    const uint32_t nb = (uint32_t)__popcll(bm);
+                    if (!overflow && total + nb <= GN_STAGE_CAP)
+                    {
+                        if (hit)
+                        {
+                            const uint32_t o = total + __popcll(bm & ((1ULL << lane) - 1ULL));
+                            stage[2 * o]     = p.tgt_ids ? p.tgt_ids[t] : t;
+                            stage[2 * o + 1] = c;
+                        }
+                    }
+                    else
+                        overflow = true;
+                    total += nb;
+                }
             }
         unsigned long long base = 0;
         if (total)
@@ -697,27 +772,43 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
             chunk_left -= total;
             if (base + total <= p.match_cap)
             {
-                uint32_t run = 0;
-                for (uint32_t t0 = t_lo; t0 < t_hi; t0 += GN_WAVE)
+                if (!overflow)
                 {
-                    const uint32_t t   = t0 + lane;
-                    uint32_t       c   = 0;
-                    bool           hit = false;
-                    if (t < t_hi)
-                    {
-                        c   = target_count(t);
-                        hit = c >= T;
-                    }
-                    const uint64_t bm = __ballot(hit);
-                    if (hit)
+                    gn_wave_lds_sync();
+                    for (uint32_t o = lane; o < total; o += GN_WAVE)
                     {
                         gn_match mt;
                         mt.read   = read;
-                        mt.target = p.tgt_ids ? p.tgt_ids[t] : t;
-                        mt.count  = c;
-                        p.matches[base + run + __popcll(bm & ((1ULL << lane) - 1ULL))] = mt;
+                        mt.target = stage[2 * o];
+                        mt.count  = stage[2 * o + 1];
+                        p.matches[base + o] = mt;
                     }
-                    run += __popcll(bm);
+                    gn_wave_lds_sync();
+                }
+                else
+                {
+                    uint32_t run = 0;
+                    for (uint32_t t0 = t_lo; t0 < t_hi; t0 += GN_WAVE)
+                    {
+                        const uint32_t t   = t0 + lane;
+                        uint32_t       c   = 0;
+                        bool           hit = false;
+                        if (t < t_hi)
+                        {
+                            c   = target_count(t);
+                            hit = c >= T;
+                        }
+                        const uint64_t bm = __ballot(hit);
+                        if (hit)
+                        {
+                            gn_match mt;
+                            mt.read   = read;
+                            mt.target = p.tgt_ids ? p.tgt_ids[t] : t;
+                            mt.count  = c;
+                            p.matches[base + run + __popcll(bm & ((1ULL << lane) - 1ULL))] = mt;
+                        }
+                        run += __popcll(bm);
+                    }
                 }
             }
         }

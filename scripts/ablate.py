@@ -6,7 +6,11 @@ import ganon_amd, bench_workload as bw
 n_reads = int(os.environ.get("N_READS", 4_000_000))
 rows = int(os.environ.get("ROWS", 1 << 24))
 wl = bw.make_flat_workload("ablate", 4096, rows, 4, n_reads, seed=42)
-flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs)
+if os.environ.get("MAP") == "split2":   # every target owns two contiguous technical bins -> generic (CSR) kernel
+    b2t = (np.arange(wl.bins) // 2).astype(np.uint32)
+    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs, b2t, wl.bins // 2)
+else:
+    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs)
 bw.plant_genomes(flt, wl)
 st = ganon_amd.HipStream(flt, n_reads, wl.bases.size, n_reads * 2)
 st.upload(wl.bases, wl.off, None)
