@@ -1,0 +1,102 @@
+"""BASELINE.json configs[1] at FULL size (8 GiB flat IBF, 4096 bins, h=4, 10 M reads of 150 bp) through the C ABI:
+size-independent properties + an oracle check on a random sample of reads against the device's own filter bits.
+Set GANON_FULLSIZE_ROWS / GANON_FULLSIZE_READS to shrink it for a quick run."""
+import os
+
+import numpy as np
+import pytest
+
+import bench_workload as bw
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROWS = int(os.environ.get("GANON_FULLSIZE_ROWS", 1 << 24))
+READS = int(os.environ.get("GANON_FULLSIZE_READS", 10_000_000))
+
+
+@pytest.fixture(scope="module")
+def full():
+    import ganon_amd
+    wl = bw.make_flat_workload("full", 4096, ROWS, 4, READS, seed=1234)
+    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs)
+    bw.plant_genomes(flt, wl)
+    st = ganon_amd.HipStream(flt, READS, wl.bases.size, READS * 2)
+    st.upload(wl.bases, wl.off, None)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    out = st.fetch()
+    yield ganon_amd, wl, flt, st, out
+    st.destroy()
+    flt.free()
+
+
+def test_structure(full):
+    hip, wl, flt, st, (nh, status, mo, m) = full
+    assert flt.info()["device_bytes"] == ROWS * 512
+    assert (status == 0).all() and nh.min() >= 1 and nh.max() <= 120
+    assert int(nh.sum(dtype=np.uint64)) == st.timings()["n_hashes"]
+    assert st.timings()["algo_bytes"] == int(nh.sum(dtype=np.uint64)) * 4 * 512
+    assert mo[0] == 0 and mo[-1] == len(m) and (np.diff(mo.astype(np.int64)) >= 0).all()
+    key = m["read"].astype(np.uint64) << np.uint64(32) | m["target"].astype(np.uint64)
+    assert (np.diff(key.astype(np.int64)) > 0).all()          # grouped by read, ascending target, no duplicates
+    assert (m["count"] <= nh[m["read"]]).all()                 # capped at n_hashes (GanonClassify.cpp:525-526)
+    thr = np.maximum(1, np.ceil(nh[m["read"]].astype(np.float64) * wl.rel_cutoff)).astype(np.uint32)
+    assert (m["count"] >= thr).all()                           # every reported match reaches the read's cutoff
+
+
+def test_planted_reads_are_found(full):
+    # reads cut from a planted genome must report the genome's bin with count == n_hashes (no false negatives)
+    hip, wl, flt, st, (nh, status, mo, m) = full
+    n_pl = int(wl.n_reads * wl.planted_fraction)
+    rrng = np.random.default_rng([wl.seed, 2, 0])
+    rrng.integers(0, 4, size=(wl.n_reads, wl.read_len), dtype=np.uint8)    # replay the generator of make_flat_workload
+    which = rrng.integers(0, len(wl.genome_bins), size=n_pl)
+    sel = np.arange(n_pl) * 2
+    first = mo[sel].astype(np.int64)
+    assert (mo[sel + 1].astype(np.int64) > first).all()
+    # the genome's bin is among the read's matches with the full count
+    ok = np.zeros(n_pl, dtype=bool)
+    for off in range(0, 4):
+        idx = np.minimum(first + off, len(m) - 1)
+        hit = (m["read"][idx] == sel) & (m["target"][idx] == wl.genome_bins[which]) & (m["count"][idx] == nh[sel])
+        ok |= hit
+    assert ok.mean() > 0.9999, ok.mean()
+
+
+def test_idempotent_and_order_independent(full):
+    hip, wl, flt, st, (nh, status, mo, m) = full
+    ck = bw.checksum_matches(m)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    nh2, status2, mo2, m2 = st.fetch()
+    assert np.array_equal(nh, nh2) and np.array_equal(mo, mo2) and np.array_equal(m, m2)
+    assert bw.checksum_matches(m2) == ck
+    # a shuffled sub-batch gives the same per-read answers (reads are independent, GanonClassify.cpp:676-831)
+    rng = np.random.default_rng(3)
+    pick = rng.choice(wl.n_reads, size=200_000, replace=False)
+    reads = wl.bases.reshape(wl.n_reads, wl.read_len)[pick]
+    st2 = hip.HipStream(flt, len(pick), reads.size)
+    st2.submit(reads.reshape(-1), np.arange(len(pick) + 1, dtype=np.uint64) * np.uint64(wl.read_len), None, wl.k, wl.w, wl.rel_cutoff)
+    nh3, _, mo3, m3 = st2.fetch()
+    assert np.array_equal(nh3, nh[pick])
+    assert np.array_equal(np.diff(mo3.astype(np.int64)), np.diff(mo.astype(np.int64))[pick])
+    j = rng.integers(0, len(pick), size=2000)
+    for x in j.tolist():
+        a = m3[int(mo3[x]):int(mo3[x + 1])]
+        b = m[int(mo[pick[x]]):int(mo[pick[x] + 1])]
+        assert np.array_equal(a["target"], b["target"]) and np.array_equal(a["count"], b["count"])
+    st2.destroy()
+
+
+def test_sample_against_oracle(full):
+    hip, wl, flt, st, (nh, status, mo, m) = full
+    bw.download_filter(flt, wl)
+    _, ibf = bw.oracle_filter(wl)
+    rng = np.random.default_rng(77)
+    for r in np.unique(rng.integers(0, wl.n_reads, size=3000)).tolist():
+        seq = wl.bases[int(wl.off[r]):int(wl.off[r + 1])]
+        hh = oracle.minimiser_hash(oracle.to_ranks(seq), wl.k, wl.w)
+        counts = np.minimum(ibf.bulk_count(hh).astype(np.int64), len(hh))
+        thr = oracle.threshold_cutoff(len(hh), wl.rel_cutoff)
+        exp = [(int(t), int(counts[t])) for t in np.nonzero(counts >= thr)[0]]
+        got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[r]):int(mo[r + 1])]]
+        assert nh[r] == len(hh) and got == exp, (r, got, exp)
