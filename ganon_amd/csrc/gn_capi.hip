@@ -553,6 +553,7 @@ static int gn_run_count(gn_stream* s)
     p.dense      = nullptr;
     p.max_blocks = (uint32_t)f->n_cu * 16u;
     p.max_blocks_fast = (uint32_t)f->n_cu * (getenv("GANON_HIP_FAST_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_FAST_BPC")) : 6u);
+    p.nt_loads = getenv("GANON_HIP_NT") ? (uint32_t)atoi(getenv("GANON_HIP_NT")) : 0u;
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
     if (fast)
     {
@@ -624,6 +625,7 @@ static int gn_run_minimisers(gn_stream* s, uint32_t k, uint32_t w)
     {
         // short reads: lane-per-read kernel; longer ones are deferred to the wave-per-read kernel below
         mp.lpr_max_len = 640;
+        mp.force_lds   = getenv("GANON_HIP_LPR_LDS") ? 1u : 0u;
         mp.defer_list  = s->d_deferred;
         mp.defer_count = s->d_ctr + 5;
         GN_HIP(gn_launch_minimiser_lpr(mp, s->st));

@@ -28,6 +28,7 @@ struct GnMinimiserParams
     uint32_t            force_generic; // tests: take the byte-staged path even for narrow windows
     // lane-per-read kernel: reads longer than lpr_max_len go to defer_list; wave-per-read kernel: work_list input
     uint32_t                  lpr_max_len;
+    uint32_t                  force_lds; // tests: lane-per-read kernel with the LDS tables even for templated widths
     uint32_t*                 defer_list;
     unsigned long long*       defer_count;
     const uint32_t*           work_list;  // nullptr = every read
@@ -78,6 +79,7 @@ struct GnCountParams
     unsigned long long*       work_count_out;
     uint32_t                  max_blocks; // generic kernel: persistent grid size
     uint32_t                  max_blocks_fast; // fast kernel: persistent grid size
+    uint32_t                  nt_loads;        // fast kernel: non-temporal row loads
 };
 
 struct GnCountGeometry

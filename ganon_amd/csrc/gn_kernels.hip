@@ -964,7 +964,9 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
                 const uint64_t* ptr = p.rows + ((uint64_t)row[i] * p.W + wi);
                 if constexpr (LW == 2)
                 {
-                    const uint4 v = *reinterpret_cast<const uint4*>(ptr);
+                    typedef uint32_t gn_u32x4 __attribute__((ext_vector_type(4)));
+                    const gn_u32x4* p4 = reinterpret_cast<const gn_u32x4*>(ptr);
+                    const gn_u32x4  v  = p.nt_loads ? __builtin_nontemporal_load(p4) : *p4; // rows are read once: optional nt hint
                     R.m[i][0] = v.x;
                     R.m[i][1] = v.y;
                     R.m[i][2] = v.z;

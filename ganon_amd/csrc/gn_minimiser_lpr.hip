@@ -57,6 +57,8 @@ __device__ __forceinline__ unsigned long long gn_lpr_wave_sum(unsigned long long
     return v;
 }
 
+typedef uint32_t gn_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
 __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t gn_lpr_smem[];
@@ -100,32 +102,43 @@ __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams 
         const uint32_t Lmax = gn_lpr_wave_max(Leff);
         if (Lmax == 0)
             continue;
-        const uint8_t* seq = p.bases + (seg ? b2 : b1);
+        // Bases are fetched as 4-byte-aligned dwords, 16 bytes per load and two loads ahead of their use, so the
+        // HBM/L2 latency is not in the per-base dependency chain.  Base i is byte (o + i) of the dword stream.
+        const uintptr_t  sa  = reinterpret_cast<uintptr_t>(p.bases + (seg ? b2 : b1));
+        const uint32_t   o   = (uint32_t)(sa & 3u);
+        const uint32_t*  dws = reinterpret_cast<const uint32_t*>(sa & ~(uintptr_t)3);
+        const uint32_t   ndw = Leff ? (o + Leff + 3) / 4 : 0; // dwords this lane may touch
+        auto load4 = [&](uint32_t q) -> gn_u32x4u { // dwords q..q+3 (zeros past the lane's own range)
+            gn_u32x4u v = { 0u, 0u, 0u, 0u };
+            if (q < ndw)
+                v = *reinterpret_cast<const gn_u32x4u*>(dws + q);
+            return v;
+        };
+        gn_u32x4u cur4 = load4(0), nxt4 = load4(4);
 
         uint64_t f = 0, rc = 0;
-        uint32_t cur = 0;
         uint64_t pre_v = ~0ULL, Wprev = 0;
         uint32_t pre_p = 0, expiry = 0xFFFFFFFFu;
         uint32_t blk = 0, pin = 0; // collecting buffer, position inside the current block (both wave-uniform)
 
-        for (uint32_t i = 0; i < Lmax; ++i)
-        {
+        auto position = [&](uint32_t i, uint32_t c) {
             const bool on = i < Leff;
             uint64_t   v  = ~0ULL;
             if (on)
             {
-                const uintptr_t a = reinterpret_cast<uintptr_t>(seq + i);
-                if ((a & 3u) == 0 || i == 0)
-                    cur = *reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-                const uint32_t c = (cur >> (8u * (uint32_t)(a & 3u))) & 0xFFu;
-                const uint64_t b = GN_LPR_RANK_LUT.t[c];
+                // A C G T U (either case): rank = ((c>>1) ^ (c>>2)) & 3 without touching memory; anything else
+                // (IUPAC codes, garbage) takes the table -- a rare, wave-level branch
+                uint64_t       b      = ((c >> 1) ^ (c >> 2)) & 3u;
+                const bool     simple = ((0x0030008Au >> (c & 31u)) & 1u) && (c & 0xC0u) == 0x40u; // letters 1,3,7,20,21
+                if (!simple)
+                    b = GN_LPR_RANK_LUT.t[c];
                 f                = ((f << 2) | b) & mask;
                 rc               = (rc >> 2) | ((3ULL - b) << (2 * (k - 1)));
                 const uint64_t x = f ^ seed, y = rc ^ seed;
                 v                = x < y ? x : y;
             }
             if (i + 1 < k)
-                continue;
+                return;
             const uint32_t pk = i + 1 - k; // k-mer position (uniform)
             // collect the value, update the running prefix minimum of this block (rightmost on ties)
             bufV[((size_t)blk * K + pin) * GN_WAVE + lane] = v;
@@ -183,6 +196,27 @@ __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams 
             }
             else
                 ++pin;
+        };
+
+        // 16 bases per trip: group g of 4 bases reads bytes o..o+6 of the 64-bit window {D[g], D[g+1]}
+        for (uint32_t i0 = 0; i0 < Lmax; i0 += 16)
+        {
+            const gn_u32x4u nn4 = load4(i0 / 4 + 8); // consumed two trips from now
+            uint32_t        d[8] = { cur4.x, cur4.y, cur4.z, cur4.w, nxt4.x, nxt4.y, nxt4.z, nxt4.w };
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                const uint64_t win = ((uint64_t)d[u + 1] << 32) | d[u];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                {
+                    const uint32_t i = i0 + 4 * u + t;
+                    if (i < Lmax)
+                        position(i, (uint32_t)(win >> (8u * (o + t))) & 0xFFu);
+                }
+            }
+            cur4 = nxt4;
+            nxt4 = nn4;
         }
     }
     unsigned long long mine_total = 0;
