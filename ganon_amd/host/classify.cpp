@@ -16,6 +16,7 @@
 #include "lca.hpp"
 #include "seq_io.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>

@@ -5,8 +5,10 @@
 // an option is repeated, boolean switches with an optional "=true/false").
 #include "config.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 #include <sstream>
 #include <stdexcept>
 

@@ -148,13 +148,16 @@ bool SeqReader::next(std::string& id, std::string& seq)
                 throw ParseError(" unexpected end of FASTQ record");
             if (!s.line.empty() && s.line[0] == '+')
                 break;
-            for (char c : s.line)
-            {
-                if (!kLegal.ok[(unsigned char)c])
-                    throw ParseError(std::string(" Encountered an unexpected letter: char_is_valid_for<dna15> evaluated to false on '")
-                                     + c + "'");
-                seq.push_back(c);
-            }
+            // validate the whole line, then append it in one go
+            bool bad = false;
+            for (unsigned char c : s.line)
+                bad |= !kLegal.ok[c];
+            if (bad)
+                for (char c : s.line)
+                    if (!kLegal.ok[(unsigned char)c])
+                        throw ParseError(std::string(" Encountered an unexpected letter: char_is_valid_for<dna15> evaluated to false on '")
+                                         + c + "'");
+            seq.append(s.line);
         }
         size_t q = 0;
         while (q < seq.size())
