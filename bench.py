@@ -155,8 +155,10 @@ def main() -> int:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "algo_bytes_per_launch": int(tm["algo_bytes"]),
-            "avg_launch_ms": round(avg_count_ms, 4),
+            # the batch is pipelined in chunks (minimiser of chunk c+1 || count of chunk c): per-launch figures
+            "launches_per_step": int(tm["n_count_launches"]),
+            "algo_bytes_per_launch": int(tm["algo_bytes"] // max(1, tm["n_count_launches"])),
+            "avg_launch_ms": round(avg_count_ms / max(1, tm["n_count_launches"]), 4),
             "traffic": None,
         },
     }

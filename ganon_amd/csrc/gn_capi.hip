@@ -366,7 +366,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
         hipStreamSynchronize(s->st);
     void* ptrs[] = { s->d_bases,  s->d_off1,    s->d_off2,      s->d_slot_cnt,  s->d_slot_off, s->d_hashes, s->d_nh,
                      s->d_status, s->d_matches, s->d_sorted,    s->d_ctr,       s->d_seg_begin, s->d_seg_count,
-                     s->d_seg_off, s->d_deferred, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_keys[0], s->d_keys[1], s->d_vals[0],
+                     s->d_seg_off, s->d_deferred, s->d_mdeferred, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_keys[0], s->d_keys[1], s->d_vals[0],
                      s->d_vals[1], s->d_sort_tmp };
     for (void* p : ptrs)
         if (p)
@@ -376,6 +376,18 @@ extern "C" int gn_stream_destroy(gn_stream* s)
     for (auto& e : s->ev)
         if (e)
             hipEventDestroy(e);
+    for (auto& e : s->ev_chunk)
+        if (e)
+            hipEventDestroy(e);
+    if (s->ev_sync)
+        hipEventDestroy(s->ev_sync);
+    if (s->ev_count0)
+        hipEventDestroy(s->ev_count0);
+    if (s->st2)
+    {
+        hipStreamSynchronize(s->st2);
+        hipStreamDestroy(s->st2);
+    }
     if (s->st)
         hipStreamDestroy(s->st);
     delete s;
@@ -403,8 +415,13 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
             e = x;
     };
     ok(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    ok(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
     for (auto& ev : s->ev)
         ok(hipEventCreate(&ev));
+    ok(hipEventCreate(&s->ev_sync));
+    ok(hipEventCreate(&s->ev_count0));
+    for (auto& ev : s->ev_chunk)
+        ok(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     ok(gn_dmalloc(&s->d_bases, max_bases + 64));
     ok(gn_dmalloc(&s->d_off1, (size_t)max_reads + 1));
     ok(gn_dmalloc(&s->d_off2, (size_t)max_reads + 1));
@@ -420,6 +437,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
     ok(gn_dmalloc(&s->d_seg_count, nseg + 1));
     ok(gn_dmalloc(&s->d_seg_off, nseg + 1));
     ok(gn_dmalloc(&s->d_deferred, max_reads));
+    ok(gn_dmalloc(&s->d_mdeferred, max_reads));
     size_t tmp1 = 0, tmp2 = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, tmp1, s->d_slot_cnt, s->d_slot_off, (int)(max_reads + 1), s->st);
     hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st);
@@ -518,12 +536,10 @@ __global__ void gn_gather_kernel(const gn_match* __restrict__ in, gn_match* __re
 
 int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st); // gn_hibf.hip
 
-static int gn_run_count(gn_stream* s)
+// count + select over reads [lo, hi) on the stream's main HIP stream (the match cursor is NOT reset here)
+static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
 {
     gn_filter* f = s->f;
-    GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), s->st)); // cursor
-    if (f->is_hibf)
-        return gn_hibf_classify(s, f, s->st);
     GnCountParams p{};
     p.rows       = f->ibf.d_rows;
     p.S          = f->ibf.S;
@@ -540,7 +556,8 @@ static int gn_run_count(gn_stream* s)
     p.slot_off   = s->d_slot_off;
     p.n_hashes   = s->d_nh;
     p.status     = s->d_status;
-    p.n_reads    = s->n_reads;
+    p.n_reads    = hi;
+    p.read_begin = lo;
     p.rel_cutoff = s->rel_cutoff;
     p.wpr        = f->geom.wpr;
     p.gp_log2    = f->geom.gp_log2;
@@ -569,6 +586,15 @@ static int gn_run_count(gn_stream* s)
     return GN_OK;
 }
 
+// whole batch in one go (HIBF, and the re-run after a match-buffer overflow)
+static int gn_run_count(gn_stream* s)
+{
+    GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), s->st)); // cursor
+    if (s->f->is_hibf)
+        return gn_hibf_classify(s, s->f, s->st);
+    return gn_run_count_range(s, 0, s->n_reads);
+}
+
 static int gn_run_group(gn_stream* s)
 {
     // group matches by read on the device: exclusive scan of the segment sizes + gather
@@ -587,8 +613,7 @@ static int gn_run_group(gn_stream* s)
     return GN_OK;
 }
 
-// slot scan + minimiser kernels (shared by classify and the hash-only entry point)
-static int gn_run_minimisers(gn_stream* s, uint32_t k, uint32_t w)
+static int gn_check_shape(gn_stream* s, uint32_t k, uint32_t w)
 {
     if (!s->have_reads)
         return gn_fail(GN_EINVAL, "no reads uploaded on this stream");
@@ -596,24 +621,32 @@ static int gn_run_minimisers(gn_stream* s, uint32_t k, uint32_t w)
         return gn_fail(GN_EINVAL, "need 1 <= k <= 32 and w >= k (k=%u w=%u)", k, w);
     if (w - k + 1 > 448 || w > 4096)
         return gn_fail(GN_ERANGE, "window of %u k-mers exceeds the LDS sliding window (max 448)", w - k + 1);
-    gn_filter* f = s->f;
-    GN_HIP(hipSetDevice(f->device));
-    s->k = k;
-    s->w = w;
-    GN_HIP(hipEventRecord(s->ev[0], s->st));
-    GN_HIP(hipMemsetAsync(s->d_ctr, 0, GN_NCTR * sizeof(unsigned long long), s->st));
-    // hash slots: #windows per read, exclusive scan
-    hipLaunchKernelGGL(gn_slot_count_kernel, dim3((s->n_reads + 1 + 255) / 256), dim3(256), 0, s->st, s->d_off1,
+    return GN_OK;
+}
+
+// counters + hash slots (#windows per read, exclusive scan) on stream `st`
+static int gn_prepare_batch(gn_stream* s, uint32_t w, hipStream_t st)
+{
+    GN_HIP(hipMemsetAsync(s->d_ctr, 0, GN_NCTR * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(gn_slot_count_kernel, dim3((s->n_reads + 1 + 255) / 256), dim3(256), 0, st, s->d_off1,
                        s->paired ? s->d_off2 : nullptr, s->n_reads, w, s->d_slot_cnt);
     size_t tmp = s->scan_tmp_bytes;
-    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_slot_cnt, s->d_slot_off, (int)(s->n_reads + 1), s->st));
+    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_slot_cnt, s->d_slot_off, (int)(s->n_reads + 1), st));
+    return GN_OK;
+}
 
+// minimiser kernels over reads [lo, hi) on stream `st`
+static int gn_run_minimisers_range(gn_stream* s, uint32_t lo, uint32_t hi, hipStream_t st)
+{
+    gn_filter* f = s->f;
+    const uint32_t k = s->k, w = s->w;
     GnMinimiserParams mp{};
     mp.bases        = s->d_bases;
     mp.off1         = s->d_off1;
     mp.off2         = s->paired ? s->d_off2 : nullptr;
     mp.slot_off     = s->d_slot_off;
-    mp.n_reads      = s->n_reads;
+    mp.n_reads      = hi;
+    mp.read_begin   = lo;
     mp.k            = k;
     mp.w            = w;
     mp.hashes       = s->d_hashes;
@@ -624,18 +657,15 @@ static int gn_run_minimisers(gn_stream* s, uint32_t k, uint32_t w)
     if (w - k + 1 <= 65 && !mp.force_generic && !getenv("GANON_HIP_NO_LPR"))
     {
         // short reads: lane-per-read kernel; longer ones are deferred to the wave-per-read kernel below
+        GN_HIP(hipMemsetAsync(s->d_ctr + 5, 0, sizeof(unsigned long long), st));
         mp.lpr_max_len = 640;
-        mp.force_lds   = getenv("GANON_HIP_LPR_LDS") ? 1u : 0u;
-        mp.defer_list  = s->d_deferred;
+        mp.defer_list  = s->d_mdeferred;
         mp.defer_count = s->d_ctr + 5;
-        GN_HIP(gn_launch_minimiser_lpr(mp, s->st));
-        mp.work_list  = s->d_deferred;
+        GN_HIP(gn_launch_minimiser_lpr(mp, st));
+        mp.work_list  = s->d_mdeferred;
         mp.work_count = s->d_ctr + 5;
     }
-    GN_HIP(gn_launch_minimiser(mp, f->n_cu, s->st));
-    GN_HIP(hipEventRecord(s->ev[1], s->st));
-    s->hashed     = true;
-    s->classified = false;
+    GN_HIP(gn_launch_minimiser(mp, f->n_cu, st));
     return GN_OK;
 }
 
@@ -643,28 +673,91 @@ extern "C" int gn_stream_minimisers(gn_stream* s, uint32_t k, uint32_t w)
 {
     if (!s)
         return gn_fail(GN_EINVAL, "null stream");
-    return gn_run_minimisers(s, k, w);
+    int rc = gn_check_shape(s, k, w);
+    if (rc)
+        return rc;
+    GN_HIP(hipSetDevice(s->f->device));
+    s->k = k;
+    s->w = w;
+    GN_HIP(hipEventRecord(s->ev[0], s->st));
+    rc = gn_prepare_batch(s, w, s->st);
+    if (rc)
+        return rc;
+    rc = gn_run_minimisers_range(s, 0, s->n_reads, s->st);
+    if (rc)
+        return rc;
+    GN_HIP(hipEventRecord(s->ev[1], s->st));
+    s->hashed     = true;
+    s->classified = false;
+    return GN_OK;
 }
 
+// The minimiser kernels run on a side stream, the count kernels on the main stream.  With $GANON_HIP_CHUNK=<reads>
+// the batch is cut into chunks and software-pipelined (minimiser of chunk c+1 || count of chunk c).  Measured on
+// MI355X (10 M reads, 8 GiB filter): no gain -- 65.3 ms unchunked vs 65.7-66.7 ms pipelined, the persistent
+// HBM-bound count kernel slows down by as much as the hashing it overlaps -- so the default is ONE chunk.
 extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double rel_cutoff)
 {
     if (!s)
         return gn_fail(GN_EINVAL, "null stream");
     if (!(rel_cutoff >= 0.0 && rel_cutoff <= 1.0))
         return gn_fail(GN_EINVAL, "rel_cutoff must be within [0,1]");
+    int rc = gn_check_shape(s, k, w);
+    if (rc)
+        return rc;
+    gn_filter* f = s->f;
+    GN_HIP(hipSetDevice(f->device));
+    s->k          = k;
+    s->w          = w;
     s->rel_cutoff = rel_cutoff;
-    int rc        = gn_run_minimisers(s, k, w);
+    const uint32_t n = s->n_reads;
+
+    uint32_t chunk = getenv("GANON_HIP_CHUNK") ? (uint32_t)atoi(getenv("GANON_HIP_CHUNK")) : 0u;
+    if (chunk == 0 || f->is_hibf)
+        chunk = n ? n : 1;
+    const uint32_t n_chunks = n ? (n + chunk - 1) / chunk : 1;
+    if (n_chunks > GN_MAX_CHUNKS)
+        chunk = (n + GN_MAX_CHUNKS - 1) / GN_MAX_CHUNKS;
+    const uint32_t nc = n ? (n + chunk - 1) / chunk : 1;
+
+    // side stream starts after everything queued on the main stream (uploads, previous batch)
+    GN_HIP(hipEventRecord(s->ev_sync, s->st));
+    GN_HIP(hipStreamWaitEvent(s->st2, s->ev_sync, 0));
+    GN_HIP(hipEventRecord(s->ev[0], s->st2));
+    rc = gn_prepare_batch(s, w, s->st2);
     if (rc)
         return rc;
-    rc = gn_run_count(s);
-    if (rc)
-        return rc;
+    for (uint32_t c = 0; c < nc; ++c)
+    {
+        const uint32_t lo = c * chunk, hi = std::min<uint64_t>((uint64_t)lo + chunk, n);
+        rc = gn_run_minimisers_range(s, lo, hi, s->st2);
+        if (rc)
+            return rc;
+        GN_HIP(hipEventRecord(s->ev_chunk[c], s->st2));
+    }
+    GN_HIP(hipEventRecord(s->ev[1], s->st2));
+    s->hashed = true;
+
+    for (uint32_t c = 0; c < nc; ++c)
+    {
+        const uint32_t lo = c * chunk, hi = std::min<uint64_t>((uint64_t)lo + chunk, n);
+        GN_HIP(hipStreamWaitEvent(s->st, s->ev_chunk[c], 0));
+        if (c == 0)
+            GN_HIP(hipEventRecord(s->ev_count0, s->st)); // first count kernel can start here
+        if (f->is_hibf)
+            rc = gn_run_count(s);
+        else
+            rc = gn_run_count_range(s, lo, hi);
+        if (rc)
+            return rc;
+    }
     GN_HIP(hipEventRecord(s->ev[2], s->st));
     rc = gn_run_group(s);
     if (rc)
         return rc;
     GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
     GN_HIP(hipEventRecord(s->ev[3], s->st));
+    s->n_chunks   = nc;
     s->classified = true;
     return GN_OK;
 }
@@ -872,12 +965,13 @@ extern "C" int gn_stream_timings(gn_stream* s, gn_timings* t)
         return rc;
     gn_timings tm{};
     hipEventElapsedTime(&tm.ms_minimiser, s->ev[0], s->ev[1]);
-    hipEventElapsedTime(&tm.ms_count, s->ev[1], s->ev[2]);
+    hipEventElapsedTime(&tm.ms_count, s->ev_count0, s->ev[2]); // first count kernel start -> last count kernel end
     hipEventElapsedTime(&tm.ms_total, s->ev[0], s->ev[3]);
     tm.n_hashes = 0;
     for (int i = 8; i < GN_NCTR; ++i)
         tm.n_hashes += s->h_ctr[i];
     tm.n_matches = s->n_matches;
+    tm.n_count_launches = s->n_chunks;
     if (s->f->is_hibf)
         tm.algo_bytes = s->h_ctr[2];
     else

@@ -9,6 +9,7 @@
 
 #include "../../include/ganon_hip.h"
 
+#define GN_MAX_CHUNKS 64 // pipeline chunks per batch (minimiser on the side stream || count on the main stream)
 #define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
                    // [6] exact match total [8..71] total-hashes shards
 
@@ -19,7 +20,8 @@ struct GnMinimiserParams
     const uint64_t*     off1;      // n_reads+1
     const uint64_t*     off2;      // n_reads+1 or nullptr
     const uint64_t*     slot_off;  // n_reads+1: first hash slot of each read (upper bound = #windows)
-    uint32_t            n_reads;
+    uint32_t            n_reads;   // END of the read range (exclusive)
+    uint32_t            read_begin; // first read of the range this launch covers
     uint32_t            k, w;
     uint64_t*           hashes;    // slot_off[n_reads] slots
     uint32_t*           n_hashes;  // per read
@@ -57,7 +59,8 @@ struct GnCountParams
     const uint64_t* slot_off;
     const uint32_t* n_hashes;
     const uint8_t*  status;
-    uint32_t        n_reads;
+    uint32_t        n_reads;    // END of the read range (exclusive)
+    uint32_t        read_begin; // first read of the range this launch covers
     double          rel_cutoff;
     // geometry (host-chosen, see gn_count_geometry)
     uint32_t wpr;      // waves cooperating on one read (power of two)
@@ -162,8 +165,12 @@ struct gn_filter
 struct gn_stream
 {
     gn_filter*  f  = nullptr;
-    hipStream_t st = nullptr;
-    hipEvent_t  ev[4]{};
+    hipStream_t st = nullptr;   // main stream: uploads, count/select, grouping, downloads
+    hipStream_t st2 = nullptr;  // side stream: slot scan + minimiser kernels, one chunk ahead of the main stream
+    hipEvent_t  ev[4]{};        // [0] batch start (side) [1] last minimiser end (side) [2] last count end [3] batch end
+    hipEvent_t  ev_sync = nullptr, ev_count0 = nullptr;
+    hipEvent_t  ev_chunk[GN_MAX_CHUNKS]{};
+    uint32_t    n_chunks = 1;
     uint32_t    max_reads = 0;
     uint64_t    max_bases = 0;
     uint64_t    match_cap = 0;
@@ -183,6 +190,7 @@ struct gn_stream
     uint32_t*           d_seg_count = nullptr;
     uint64_t*           d_seg_off   = nullptr; // n*wpr+1 exclusive scan of seg_count
     uint32_t*           d_deferred  = nullptr; // reads the fast count kernel left to the generic one
+    uint32_t*           d_mdeferred = nullptr; // reads the lane-per-read minimiser kernel left to the wave-per-read one
     void*               d_scan_tmp  = nullptr;
     size_t              scan_tmp_bytes = 0;
     // hibf work queues + sort buffers

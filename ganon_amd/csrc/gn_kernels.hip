@@ -320,10 +320,10 @@ __global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
     const uint32_t waves_all = gridDim.x * (blockDim.x >> 6);
     unsigned long long my_total = 0;
 
-    const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads;
+    const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads - p.read_begin;
     for (uint32_t widx = blockIdx.x * (blockDim.x >> 6) + wave; widx < n_work; widx += waves_all)
     {
-        const uint32_t r    = p.work_list ? p.work_list[widx] : widx;
+        const uint32_t r    = p.work_list ? p.work_list[widx] : p.read_begin + widx;
         const uint64_t b1   = p.off1[r];
         const uint64_t len1 = p.off1[r + 1] - b1;
         uint64_t       b2 = 0, len2 = 0;
@@ -363,13 +363,13 @@ __global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
 
 hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t st)
 {
-    if (p.n_reads == 0)
+    if (p.n_reads <= p.read_begin)
         return hipSuccess;
     const uint32_t K        = p.w - p.k + 1;
     const bool     fastp    = K <= 65 && !p.force_generic;
     const uint32_t per_wave = fastp ? 128u * 8u : (GN_WAVE + K) * 8 + ((GN_WAVE + p.w + 15) & ~15u);
     const size_t   lds      = (size_t)per_wave * 4;
-    uint32_t       blocks   = (p.n_reads + 3) / 4;
+    uint32_t       blocks   = (p.n_reads - p.read_begin + 3) / 4;
     const uint32_t cap      = (uint32_t)n_cu * 16;
     if (blocks > cap)
         blocks = cap;
@@ -485,13 +485,13 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
 
     // Work items: either every read of the batch (work_list == nullptr) or the reads the fast kernel deferred.
     // Blocks stride over rounds of rpb reads; the trip count is block-uniform, so __syncthreads() is safe.
-    const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads;
+    const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads - p.read_begin;
     unsigned long long chunk_base = 0; // wave-private slice of the match buffer
     uint32_t           chunk_left = 0;
     for (uint32_t round0 = blockIdx.x * rpb; round0 < n_work; round0 += gridDim.x * rpb)
     {
     const uint32_t widx = round0 + rslot;
-    const uint32_t read = widx < n_work ? (p.work_list ? p.work_list[widx] : widx) : 0xFFFFFFFFu;
+    const uint32_t read = widx < n_work ? (p.work_list ? p.work_list[widx] : p.read_begin + widx) : 0xFFFFFFFFu;
     uint32_t       n    = 0;
     if (read < p.n_reads && p.status[read] == GN_READ_OK)
         n = p.n_hashes[read];
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
     // (status, n, hash slot) is loaded at the top of the current one and its hashes right after the current
     // main loop, so the chain status -> n -> slot -> hashes -> rows of dependent HBM latencies that a fresh
     // wave would pay before its first row load is hidden behind the previous read's work.
-    const uint64_t n_units = (uint64_t)p.n_reads * wpr;
+    const uint64_t n_units = (uint64_t)(p.n_reads - p.read_begin) * wpr;
     const uint64_t stride  = (uint64_t)gridDim.x * (blockDim.x >> 6);
     uint64_t       unit    = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (unit >= n_units)
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
     // hash q of a unit feeds row-table entries idx = lane and lane + 64 (idx = q*HF + i)
     const uint32_t q0 = (uint32_t)lane / HF, q1 = ((uint32_t)lane + GN_WAVE) / HF;
     auto load_meta = [&](uint64_t u, uint32_t& rd, uint32_t& nn, uint64_t& so) {
-        rd = (uint32_t)(u / wpr);
+        rd = p.read_begin + (uint32_t)(u / wpr);
         nn = p.status[rd] == GN_READ_OK ? p.n_hashes[rd] : 0u;
         so = p.slot_off[rd];
     };
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
 
     for (;;)
     {
-    const uint32_t slice = (uint32_t)(unit - (uint64_t)read * wpr);
+    const uint32_t slice = (uint32_t)(unit - (uint64_t)(read - p.read_begin) * wpr);
     // prefetch the next unit's metadata (consumed after the main loop)
     const uint64_t unit_n = unit + stride;
     const bool     more   = unit_n < n_units;
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(256) void gn_ibf_count_fast_kernel(GnCountParams p)
 template <int HF, int LW, int MAXT>
 static hipError_t gn_launch_count_one(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
 {
-    uint32_t blocks = (p.n_reads + g.rpb - 1) / g.rpb;
+    uint32_t blocks = (p.n_reads - p.read_begin + g.rpb - 1) / g.rpb;
     if (blocks > p.max_blocks)
         blocks = p.max_blocks;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_ibf_count_kernel<HF, LW, MAXT>),
@@ -1145,7 +1145,7 @@ static hipError_t gn_launch_count_one(const GnCountParams& p, const GnCountGeome
 template <int HF, int LW>
 static hipError_t gn_launch_fast_one(const GnCountParams& p, hipStream_t st)
 {
-    const uint64_t units  = (uint64_t)p.n_reads * p.wpr;
+    const uint64_t units  = (uint64_t)(p.n_reads - p.read_begin) * p.wpr;
     uint32_t       blocks = (uint32_t)((units + 3) / 4);
     if (blocks > p.max_blocks_fast)
         blocks = p.max_blocks_fast;
@@ -1156,7 +1156,7 @@ static hipError_t gn_launch_fast_one(const GnCountParams& p, hipStream_t st)
 
 hipError_t gn_launch_count_fast(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st)
 {
-    if (p.n_reads == 0)
+    if (p.n_reads <= p.read_begin)
         return hipSuccess;
     const bool two = g.lw == 2;
     switch (hash_funs)
@@ -1180,7 +1180,7 @@ static hipError_t gn_launch_count_hf(const GnCountParams& p, const GnCountGeomet
 
 hipError_t gn_launch_count(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st)
 {
-    if (p.n_reads == 0)
+    if (p.n_reads <= p.read_begin)
         return hipSuccess;
     switch (hash_funs)
     {

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams 
     const uint64_t seed = 0x8F3F73B5CF1C9ADEULL >> (64u - 2u * k);    // adjust_seed.hpp:33-37
     const uint64_t mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
 
-    const uint32_t r   = blockIdx.x * GN_WAVE + lane;
+    const uint32_t r   = p.read_begin + blockIdx.x * GN_WAVE + lane;
     const bool     inr = r < p.n_reads;
     uint64_t       b1 = 0, len1 = 0, b2 = 0, len2 = 0;
     if (inr)
@@ -236,12 +236,12 @@ __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams 
 
 hipError_t gn_launch_minimiser_lpr(const GnMinimiserParams& p, hipStream_t st)
 {
-    if (p.n_reads == 0)
+    if (p.n_reads <= p.read_begin)
         return hipSuccess;
     const uint32_t K   = p.w - p.k + 1;
     const size_t   lds = (size_t)2 * K * GN_WAVE * 9;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_minimiser_lpr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(gn_minimiser_lpr_kernel, dim3((p.n_reads + GN_WAVE - 1) / GN_WAVE), dim3(GN_WAVE), lds, st, p);
+    hipLaunchKernelGGL(gn_minimiser_lpr_kernel, dim3((p.n_reads - p.read_begin + GN_WAVE - 1) / GN_WAVE), dim3(GN_WAVE), lds, st, p);
     return hipGetLastError();
 }

@@ -33,7 +33,8 @@ class IbfDesc(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("ms_minimiser", C.c_float), ("ms_count", C.c_float), ("ms_total", C.c_float),
-                ("n_hashes", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_matches", C.c_uint64)]
+                ("n_hashes", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_matches", C.c_uint64),
+                ("n_count_launches", C.c_uint32)]
 
 
 _lib = None
@@ -230,7 +231,7 @@ class HipStream:
         t = Timings()
         _check(load_library().gn_stream_timings(self._h, C.byref(t)))
         return dict(ms_minimiser=t.ms_minimiser, ms_count=t.ms_count, ms_total=t.ms_total, n_hashes=t.n_hashes,
-                    algo_bytes=t.algo_bytes, n_matches=t.n_matches)
+                    algo_bytes=t.algo_bytes, n_matches=t.n_matches, n_count_launches=t.n_count_launches)
 
     def destroy(self) -> None:
         if self._h:

@@ -70,12 +70,13 @@ typedef struct
 /* device timings of the last gn_stream_classify, measured with hipEvents on the stream's HIP stream */
 typedef struct
 {
-    float    ms_minimiser; /* gn_minimiser_kernel */
-    float    ms_count;     /* IBF/HIBF count + select kernels */
+    float    ms_minimiser; /* slot scan + minimiser kernels (side stream; overlaps the count kernels of earlier chunks) */
+    float    ms_count;     /* first IBF/HIBF count+select kernel start -> last one's end (main stream) */
     float    ms_total;     /* first kernel start -> last kernel end */
     uint64_t n_hashes;     /* minimisers of the batch (sum over reads that were counted) */
     uint64_t algo_bytes;   /* algorithmic row bytes: sum n*h*W*8 over every IBF visited */
     uint64_t n_matches;
+    uint32_t n_count_launches; /* count/select launches of the batch (chunks of the minimiser||count pipeline); ms_count spans all */
 } gn_timings;
 
 int         gn_device_count(int* n);

@@ -21,4 +21,4 @@ for flags in [int(x) for x in os.environ.get("FLAGS", "0,1,2,6").split(",")]:
         st.classify(wl.k, wl.w, wl.rel_cutoff); st.sync()
         t = st.timings(); ms.append(t["ms_count"])
     gbs = t["algo_bytes"] / (min(ms[1:]) * 1e-3) / 1e9
-    print(f"flags {flags}: count ms {['%.2f' % m for m in ms]}  -> {gbs:.0f} GB/s algorithmic; minimiser {t['ms_minimiser']:.2f} ms", flush=True)
+    print(f"flags {flags}: count ms {['%.2f' % m for m in ms]}  -> {gbs:.0f} GB/s algorithmic; minimiser {t['ms_minimiser']:.2f} ms; total {t['ms_total']:.2f} ms", flush=True)
