@@ -234,3 +234,66 @@ def test_sim_hip_equals_oracle_backend_bytes(oracle_bin, sim_db, tmp_path, hibf)
     _check_sim_against_oracle_level(sim_db, a, hibf)
     for ext in (".all", ".one", ".unc", ".rep", ".sta"):
         assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[0]: 64-bin IBF (k=19, w=31, h=3), 10 k synthetic 150 bp reads -- the plumbing case
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config1(tmp_path_factory):
+    import struct
+
+    import numpy as np
+    import oracle
+    d = str(tmp_path_factory.mktemp("config1"))
+    rng = np.random.default_rng(2024)
+    genomes = ["".join("ACGT"[x] for x in rng.integers(0, 4, size=2000)) for _ in range(64)]
+    ibf = oracle.Ibf(64, 40009, 3)
+    hc = []
+    for b, g in enumerate(genomes):
+        hv = np.unique(oracle.minimiser_hash(oracle.to_ranks(g), 19, 31))
+        ibf.emplace_many(hv, b)
+        hc.append((f"G{b}", len(hv)))
+    built = gf.BuiltIbf()
+    built.ibf = ibf
+    built.config = dict(n_bins=64, max_hashes_bin=max(c for _, c in hc), hash_functions=3, kmer_size=19, window_size=31,
+                        bin_size_bits=40009, max_fp=0.05, true_max_fp=0.05, true_avg_fp=0.05)
+    built.hashes_count = hc
+    built.bin_map = [(b, f"G{b}") for b in range(64)]
+    gf.write_ibf(os.path.join(d, "c1.ibf"), built)
+    recs = []
+    for i in range(10000):
+        if i % 2:
+            g = genomes[i % 64]
+            p = int(rng.integers(0, 1850))
+            recs.append((f"r{i}", g[p:p + 150]))
+        else:
+            recs.append((f"r{i}", "".join("ACGT"[x] for x in rng.integers(0, 4, size=150))))
+    gf.write_fastq(os.path.join(d, "reads.fq"), recs)
+    return dict(dir=d, ibf=os.path.join(d, "c1.ibf"), fq=os.path.join(d, "reads.fq"), built=built, recs=recs)
+
+
+def _run_config1(binary, c1, out):
+    cu.run(binary, ["--ibf", c1["ibf"], "--single-reads", c1["fq"], "-o", out, "--output-all", "--output-unclassified",
+                    "--output-stats", "--quiet"])  # reference defaults: rel-cutoff 0.2, rel-filter 0, fpr-query 1
+    return out
+
+
+def test_config1_oracle_backend(oracle_bin, config1, tmp_path):
+    import oracle
+    p = _run_config1(oracle_bin, config1, str(tmp_path / "c1"))
+    res = cu.Res(p, lca_file=False)
+    res.sanity_check(output_lca=False)
+    assert res.total_classified + res.total_unclassified == 10000 and res.total_classified >= 5000
+    lvl = oracle.Level([config1["built"].as_filter(0.2)], 19, 31, rel_filter=0.0, fpr_query=1.0)
+    for rid, seq in config1["recs"][:400]:
+        rr = lvl.classify(oracle.to_ranks(seq))
+        assert res.all.get(rid, {}) == rr.kept, rid
+
+
+@pytest.mark.gpu
+def test_config1_hip_equals_oracle_backend(oracle_bin, config1, tmp_path):
+    a = _run_config1(cu.BIN_HIP, config1, str(tmp_path / "hip"))
+    b = _run_config1(oracle_bin, config1, str(tmp_path / "ora"))
+    for ext in (".all", ".unc", ".rep", ".sta"):
+        assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext

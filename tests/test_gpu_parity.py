@@ -305,3 +305,29 @@ def test_planted_matches_many_reads(hip, bins, rows, h, paired):
         tot += len(exp_m)
     assert tot >= n // 2 and tot == len(m)
     assert nh.max() > (30 if paired else 15)
+
+
+def test_chunked_pipeline_parity(hip, monkeypatch):
+    # $GANON_HIP_CHUNK cuts the batch into chunks pipelined over two HIP streams (minimiser || count); results must
+    # not depend on the chunking
+    k, w = 19, 31
+    bins, rows, h = 4096, 4099, 4
+    rng = np.random.default_rng(21)
+    ibf = gf.random_ibf(bins, rows, h, 0.3, seed=3)
+    genomes = [gu.random_seq(rng, 1000) for _ in range(32)]
+    for gi, g in enumerate(genomes):
+        ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), gi * 97 % bins)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h)
+    seqs = [genomes[i % 32][(i * 7) % 800:(i * 7) % 800 + 150] if i % 2 else gu.random_seq(rng, int(rng.integers(10, 900)))
+            for i in range(5000)]
+    outs = []
+    for chunk in ("0", "1", "333", "4096"):
+        monkeypatch.setenv("GANON_HIP_CHUNK", chunk)
+        st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, 0.6)
+        outs.append((nh.copy(), status.copy(), mo.copy(), m.copy(), st.timings()["n_count_launches"]))
+        st.destroy()
+    assert outs[0][4] == 1 and outs[1][4] == 64 and outs[2][4] == 16 and outs[3][4] == 2  # capped at 64 launches
+    for o in outs[1:]:
+        for a, b in zip(outs[0][:4], o[:4]):
+            assert np.array_equal(a, b)
+    assert len(outs[0][3]) > 2000
