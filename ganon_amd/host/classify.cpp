@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <ctime>
 #include <deque>
 #include <filesystem>
@@ -601,6 +602,7 @@ static bool ganon_classify(Config config)
     } joiner{ read_task, queue1 };
 
     std::vector<ReadBatch> carried; // unclassified reads kept for the next hierarchy level (:811-830)
+    double sec_device = 0, sec_post = 0; // where the host's classify time goes ($GANON_HOST_TIMING=1 prints it)
 
     size_t       hierarchy_id   = 0;
     const size_t hierarchy_size = parsed_hierarchy.size();
@@ -723,11 +725,14 @@ static bool ganon_classify(Config config)
         BatchResult             res;
 
         auto process_batch = [&](ReadBatch& rb) -> bool {
+            const auto t_dev0 = std::chrono::steady_clock::now();
             if (!backend->classify(rb, hierarchy_config.kmer_size, hierarchy_config.window_size, rel_cutoffs, res, err))
             {
                 std::cerr << "ERROR: " << err << std::endl;
                 return false;
             }
+            const auto t_dev1 = std::chrono::steady_clock::now();
+            sec_device += std::chrono::duration<double>(t_dev1 - t_dev0).count();
             Total&    total  = totals[rb.prefix];
             auto&     prep   = rep[rb.prefix];
             ReadBatch left;
@@ -898,6 +903,7 @@ static bool ganon_classify(Config config)
                 finalize_batch(left, left1, left2);
                 next_carried.push_back(std::move(left));
             }
+            sec_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev1).count();
             return true;
         };
 
@@ -976,6 +982,9 @@ static bool ganon_classify(Config config)
     if (config.output_stats)
         write_stats(config.output_prefix, stats, parsed_hierarchy);
     timeGanon.stop();
+    if (std::getenv("GANON_HOST_TIMING"))
+        std::cerr << "[host timing] backend (upload+kernels+fetch) " << sec_device << " s, post-processing+writing " << sec_post
+                  << " s, classify+print wall " << timeClassPrint.elapsed() << " s" << std::endl;
     if (!config.quiet)
     {
         if (config.verbose) // print_time :1041-1051

@@ -55,8 +55,9 @@ with open(f"{d}/reads.fq", "wb") as f:
 print(f"files written in {time.time()-t0:.1f}s: db.ibf {os.path.getsize(d+'/db.ibf')/2**30:.2f} GiB, reads.fq {os.path.getsize(d+'/reads.fq')/2**20:.0f} MiB", flush=True)
 t0 = time.time()
 p = subprocess.run([os.path.join(ROOT, "ganon_amd/host/ganon-classify"), "--ibf", f"{d}/db.ibf", "--single-reads", f"{d}/reads.fq",
-                    "-o", f"{d}/out", "--output-all", "--rel-cutoff", "0.75", "--verbose"], capture_output=True, text=True)
+                    "-o", f"{d}/out", "--output-all", "--rel-cutoff", "0.75", "--verbose"], capture_output=True, text=True,
+                   env=dict(os.environ, GANON_HOST_TIMING="1"))
 dt = time.time() - t0
 print("rc", p.returncode, f"wall {dt:.2f}s")
-print("\n".join(l for l in p.stderr.splitlines() if "elapsed" in l or "processed" in l or "classified" in l or "ERROR" in l))
+print("\n".join(l for l in p.stderr.splitlines() if "elapsed" in l or "host timing" in l or "processed" in l or "classified" in l or "ERROR" in l))
 print("all lines:", sum(1 for _ in open(f"{d}/out.all")), open(f"{d}/out.rep").read().splitlines()[-2:])

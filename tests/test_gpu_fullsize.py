@@ -100,3 +100,52 @@ def test_sample_against_oracle(full):
         exp = [(int(t), int(counts[t])) for t in np.nonzero(counts >= thr)[0]]
         got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[r]):int(mo[r + 1])]]
         assert nh[r] == len(hh) and got == exp, (r, got, exp)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2]: 2-level HIBF, 65 536 user bins (top IBF of 256 merged bins -> 256 children of 256 bins)
+# ---------------------------------------------------------------------------------------------------------------
+HIBF_READS = int(os.environ.get("GANON_FULLSIZE_HIBF_READS", 2_000_000))
+HIBF_ROWS = int(os.environ.get("GANON_FULLSIZE_HIBF_ROWS", 1 << 20))   # 257 IBFs x 2^20 rows x 32 B = 8 GiB
+
+
+@pytest.fixture(scope="module")
+def hibf_full():
+    import ganon_amd
+    wl = bw.make_hibf_workload(ganon_amd, "hibf64k", 65536, 256, HIBF_ROWS, HIBF_ROWS, 3, HIBF_READS, seed=99)
+    flt = ganon_amd.HipFilter.hibf(wl.ibfs, wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)
+    st = ganon_amd.HipStream(flt, HIBF_READS, wl.bases.size, HIBF_READS * 2)
+    st.upload(wl.bases, wl.off, None)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    out = st.fetch()
+    yield ganon_amd, wl, flt, st, out
+    st.destroy()
+    flt.free()
+
+
+def test_hibf_fullsize_structure_and_oracle_sample(hibf_full):
+    hip, wl, flt, st, (nh, status, mo, m) = hibf_full
+    info = flt.info()
+    assert info["is_hibf"] and info["n_ibf"] == 257 and info["n_targets"] == 65536
+    assert mo[-1] == len(m) and (np.diff(mo.astype(np.int64)) >= 0).all()
+    key = m["read"].astype(np.uint64) << np.uint64(32) | m["target"].astype(np.uint64)
+    assert (np.diff(key.astype(np.int64)) > 0).all()
+    assert (m["count"] <= nh[m["read"]]).all() and (m["target"] < 65536).all()
+    # every planted read (even index) is classified; algorithmic bytes >= the top-level visit of every read
+    n_pl = int(wl.n_reads * 0.5)
+    assert (np.diff(mo.astype(np.int64))[np.arange(n_pl) * 2] >= 1).all()
+    tm = st.timings()
+    assert tm["algo_bytes"] >= int(nh.sum(dtype=np.uint64)) * 3 * 32
+    # oracle HIBF on the same host arrays for a random sample
+    ibfs = [oracle.Ibf(b, s, h, r) for (r, b, s, h) in wl.ibfs]
+    hb = oracle.Hibf(ibfs, wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)
+    rng = np.random.default_rng(5)
+    algo = 0
+    for r in np.unique(rng.integers(0, wl.n_reads, size=600)).tolist():
+        seq = wl.bases[int(wl.off[r]):int(wl.off[r + 1])]
+        hh = oracle.minimiser_hash(oracle.to_ranks(seq), wl.k, wl.w)
+        thr = oracle.threshold_cutoff(len(hh), wl.rel_cutoff)
+        counts = hb.bulk_count(hh, thr)
+        exp = [(int(u), int(min(c, len(hh)))) for u, c in zip(np.nonzero(counts)[0], counts[np.nonzero(counts)[0]])]
+        got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[r]):int(mo[r + 1])]]
+        assert nh[r] == len(hh) and got == exp, (r, got, exp)
