@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <string_view>
 #include <vector>
 
 namespace gnhost
@@ -18,13 +19,15 @@ namespace gnhost
 // A batch of reads in the layout the C ABI takes: ASCII bases, mate-1 block then mate-2 block.
 struct ReadBatch
 {
-    bool                     paired = false;
-    std::string              prefix;
-    std::vector<std::string> ids;
-    std::vector<uint8_t>     bases;
-    std::vector<uint64_t>    off1; // n+1
-    std::vector<uint64_t>    off2; // n+1 when paired (offsets into `bases`)
-    size_t                   size() const { return ids.size(); }
+    bool                  paired = false;
+    std::string           prefix;
+    std::string           id_buf;      // all read ids back to back
+    std::vector<uint64_t> id_off{ 0 }; // n+1 offsets into id_buf
+    std::vector<uint8_t>  bases;       // mates 1 of all reads, then mates 2 of all reads
+    std::vector<uint64_t> off1;        // n+1
+    std::vector<uint64_t> off2;        // n+1 when paired (offsets into `bases`)
+    size_t                size() const { return id_off.size() - 1; }
+    std::string_view      id(size_t i) const { return { id_buf.data() + id_off[i], size_t(id_off[i + 1] - id_off[i]) }; }
     uint64_t len1(size_t i) const { return off1[i + 1] - off1[i]; }
     uint64_t len2(size_t i) const { return paired ? off2[i + 1] - off2[i] : 0; }
 };

@@ -17,6 +17,7 @@
 #include "seq_io.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -392,11 +393,14 @@ void write_stats(const std::string& output_prefix, Stats& stats, const std::map<
 }
 
 // ---- read side (:1220-1287): a producer thread turns files into large batches ------------------------------
-class BatchQueue
+// bounded producer/consumer queue; consumed items can be handed back so that their (already faulted-in) buffers
+// are reused by the producer
+template <typename T>
+class BoundedQueue
 {
 public:
-    explicit BatchQueue(size_t cap) : cap_(cap) {}
-    void push(ReadBatch&& b)
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T&& b)
     {
         std::unique_lock<std::mutex> lk(m_);
         not_full_.wait(lk, [&] { return q_.size() < cap_; });
@@ -409,7 +413,7 @@ public:
         done_ = true;
         not_empty_.notify_all();
     }
-    bool pop(ReadBatch& b)
+    bool pop(T& b)
     {
         std::unique_lock<std::mutex> lk(m_);
         not_empty_.wait(lk, [&] { return !q_.empty() || done_; });
@@ -420,52 +424,52 @@ public:
         not_full_.notify_one();
         return true;
     }
+    void recycle(T&& b)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (free_.size() < cap_ + 2)
+            free_.push_back(std::move(b));
+    }
+    bool take_free(T& b)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (free_.empty())
+            return false;
+        b = std::move(free_.back());
+        free_.pop_back();
+        return true;
+    }
 
 private:
     std::mutex              m_;
     std::condition_variable not_full_, not_empty_;
-    std::deque<ReadBatch>   q_;
+    std::deque<T>           q_;
+    std::vector<T>          free_;
     size_t                  cap_;
     bool                    done_ = false;
+};
+using BatchQueue = BoundedQueue<ReadBatch>;
+
+// a batch together with what the device said about it
+struct ClassifiedBatch
+{
+    ReadBatch   rb;
+    BatchResult res;
 };
 
 constexpr size_t kBatchReads = 1u << 20;   // reads per device batch
 constexpr size_t kBatchBases = 1ull << 28; // bases per device batch
 
-void finalize_batch(ReadBatch& rb, std::vector<std::string>& seqs1, std::vector<std::string>& seqs2)
+// appends the mates-2 region behind the mates-1 region and rebases its offsets
+void finalize_batch(ReadBatch& rb, std::vector<uint8_t>& bases2)
 {
-    const size_t n = rb.ids.size();
-    size_t       total = 0;
-    for (auto const& s : seqs1)
-        total += s.size();
-    for (auto const& s : seqs2)
-        total += s.size();
-    rb.bases.resize(total);
-    rb.off1.assign(n + 1, 0);
-    size_t p = 0;
-    for (size_t i = 0; i < n; ++i)
-    {
-        rb.off1[i] = p;
-        std::copy(seqs1[i].begin(), seqs1[i].end(), rb.bases.begin() + p);
-        p += seqs1[i].size();
-    }
-    rb.off1[n] = p;
-    if (rb.paired)
-    {
-        rb.off2.assign(n + 1, p);
-        for (size_t i = 0; i < n; ++i)
-        {
-            rb.off2[i] = p;
-            if (i < seqs2.size())
-            {
-                std::copy(seqs2[i].begin(), seqs2[i].end(), rb.bases.begin() + p);
-                p += seqs2[i].size();
-            }
-        }
-        rb.off2[n] = p;
-    }
-    seqs1.clear();
-    seqs2.clear();
+    if (!rb.paired)
+        return;
+    const uint64_t base = rb.bases.size();
+    for (auto& o : rb.off2)
+        o += base;
+    rb.bases.insert(rb.bases.end(), bases2.begin(), bases2.end());
+    bases2.clear();
 }
 
 void parse_reads(BatchQueue& queue, Stats& stats, std::mutex& stats_mutex, const TReadConfig& reads_config)
@@ -474,50 +478,64 @@ void parse_reads(BatchQueue& queue, Stats& stats, std::mutex& stats_mutex, const
     {
         for (auto const& [filename1, filename2] : files)
         {
-            const bool               paired = !filename2.empty();
-            ReadBatch                rb;
-            std::vector<std::string> s1, s2;
-            size_t                   bases = 0;
+            const bool           paired = !filename2.empty();
+            ReadBatch            rb;
+            std::vector<uint8_t> bases2; // mates 2 of the current batch
+            auto                 fresh = [&]() {
+                if (queue.take_free(rb))
+                {
+                    rb.id_buf.clear();
+                    rb.id_off.assign(1, 0);
+                    rb.bases.clear();
+                }
+                else
+                    rb = ReadBatch();
+                rb.paired = paired;
+                rb.prefix = prefix;
+                rb.off1.assign(1, 0);
+                if (paired)
+                    rb.off2.assign(1, 0);
+                else
+                    rb.off2.clear();
+            };
             auto flush = [&]() {
-                if (rb.ids.empty())
+                if (rb.size() == 0)
                     return;
                 {
                     std::lock_guard<std::mutex> lk(stats_mutex);
-                    stats.total[prefix].input_seqs += rb.ids.size(); // :1253,1272
+                    stats.total[prefix].input_seqs += rb.size(); // :1253,1272
                 }
-                finalize_batch(rb, s1, s2);
+                finalize_batch(rb, bases2);
                 queue.push(std::move(rb));
-                rb        = ReadBatch();
-                rb.paired = paired;
-                rb.prefix = prefix;
-                bases     = 0;
+                fresh();
             };
-            rb.paired = paired;
-            rb.prefix = prefix;
+            fresh();
             try
             {
                 SeqReader                  fin1(filename1);
                 std::unique_ptr<SeqReader> fin2;
                 if (paired)
                     fin2.reset(new SeqReader(filename2));
-                std::string id, seq, id2, seq2;
-                while (fin1.next(id, seq))
+                std::string id2; // ids come from file 1; file 2 only contributes sequences (:1243-1252)
+                while (fin1.next(rb.id_buf, rb.bases))
                 {
-                    bases += seq.size();
-                    rb.ids.push_back(id);
-                    s1.push_back(seq);
+                    rb.id_off.push_back(rb.id_buf.size());
+                    rb.off1.push_back(rb.bases.size());
                     if (paired)
                     {
-                        // ids come from file 1; file 2 only contributes sequences (:1243-1252)
-                        if (fin2->next(id2, seq2))
+                        id2.clear();
+                        try
                         {
-                            bases += seq2.size();
-                            s2.push_back(seq2);
+                            fin2->next(id2, bases2); // at EOF the mate stays empty
                         }
-                        else
-                            s2.emplace_back();
+                        catch (ParseError const&)
+                        {
+                            rb.off2.push_back(bases2.size());
+                            throw;
+                        }
+                        rb.off2.push_back(bases2.size());
                     }
-                    if (rb.ids.size() >= kBatchReads || bases >= kBatchBases)
+                    if (rb.size() >= kBatchReads || rb.bases.size() + bases2.size() >= kBatchBases)
                         flush();
                 }
                 flush();
@@ -706,7 +724,12 @@ static bool ganon_classify(Config config)
                 out_all[prefix].open(config.output_prefix + prefix + "." + hierarchy_config.output_file_all, file_mode);
 
         // per-level report: prefix -> node id -> Rep
-        std::map<std::string, std::unordered_map<uint32_t, Rep>> rep;
+        std::map<std::string, std::vector<Rep>> rep; // dense by node id, grown on demand
+        auto rep_at = [](std::vector<Rep>& v, uint32_t gid) -> Rep& {
+            if (gid >= v.size())
+                v.resize((size_t)gid + 1);
+            return v[gid];
+        };
         TTotal                                                   totals;
         std::vector<double>                                      rel_cutoffs;
         for (auto const& fc : hierarchy_config.filters)
@@ -722,23 +745,47 @@ static bool ganon_classify(Config config)
             double   fpr;
         };
         std::vector<MatchEntry> matches;
-        BatchResult             res;
-
-        auto process_batch = [&](ReadBatch& rb) -> bool {
-            const auto t_dev0 = std::chrono::steady_clock::now();
-            if (!backend->classify(rb, hierarchy_config.kmer_size, hierarchy_config.window_size, rel_cutoffs, res, err))
+        std::vector<uint32_t>    kept_gids;
+        std::vector<std::string> kept_targets;
+        std::string              buf_all, buf_lca, buf_unc; // one write per batch and file
+        auto append_num = [](std::string& dst, size_t v) {
+            char  tmp[24];
+            char* e = tmp + sizeof(tmp);
+            char* q = e;
+            do
             {
-                std::cerr << "ERROR: " << err << std::endl;
-                return false;
-            }
+                *--q = char('0' + v % 10);
+                v /= 10;
+            } while (v);
+            dst.append(q, e - q);
+        };
+
+        std::mutex dev_mutex; // sec_device / err are written by the device stage
+        auto device_stage = [&](const ReadBatch& rb, BatchResult& res) -> bool {
+            const auto  t_dev0 = std::chrono::steady_clock::now();
+            std::string e;
+            const bool  ok = backend->classify(rb, hierarchy_config.kmer_size, hierarchy_config.window_size, rel_cutoffs, res, e);
+            std::lock_guard<std::mutex> lk(dev_mutex);
+            sec_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev0).count();
+            if (!ok)
+                err = e;
+            return ok;
+        };
+
+        auto post_stage = [&](ReadBatch& rb, const BatchResult& res) -> bool {
             const auto t_dev1 = std::chrono::steady_clock::now();
-            sec_device += std::chrono::duration<double>(t_dev1 - t_dev0).count();
             Total&    total  = totals[rb.prefix];
             auto&     prep   = rep[rb.prefix];
+            buf_all.clear();
+            buf_lca.clear();
+            buf_unc.clear();
             ReadBatch left;
             left.paired = rb.paired;
             left.prefix = rb.prefix;
-            std::vector<std::string> left1, left2;
+            std::vector<uint8_t> left2;
+            left.off1.assign(1, 0);
+            if (left.paired)
+                left.off2.assign(1, 0);
             std::ofstream*           o_all = config.output_all ? &out_all[rb.prefix] : nullptr;
             std::ofstream*           o_lca = (config.output_lca && !config.skip_lca) ? &out_lca[rb.prefix] : nullptr;
             std::ofstream*           o_unc = config.output_unclassified ? &out_unc[rb.prefix] : nullptr;
@@ -806,12 +853,10 @@ static bool ganon_classify(Config config)
                     const size_t threshold_filter =
                         max_count_read - threshold_rel(max_count_read - min_count_read, hierarchy_config.rel_filter);
                     // filter_matches (:579-613)
-                    size_t   kept = 0;
-                    uint32_t first_kept = 0;
-                    std::vector<std::string> kept_targets;
-                    const size_t all_pos = 0;
-                    (void)all_pos;
-                    std::string all_lines;
+                    size_t       kept = 0;
+                    uint32_t     first_kept = 0;
+                    const size_t all_mark = buf_all.size(); // lines of a read that ends up unclassified are dropped
+                    kept_gids.clear();
                     for (auto const& me : matches)
                     {
                         if (me.count >= (double)threshold_filter)
@@ -823,28 +868,27 @@ static bool ganon_classify(Config config)
                                     q -= binom(n_hashes, i) * pow(me.fpr, i) * pow(1 - me.fpr, n_hashes - i);
                                 if (q > hierarchy_config.fpr_query)
                                 {
-                                    prep[me.gid].discarded_matches_fprquery++;
+                                    rep_at(prep, me.gid).discarded_matches_fprquery++;
                                     continue;
                                 }
                             }
-                            prep[me.gid].matches++;
+                            rep_at(prep, me.gid).matches++;
                             if (kept == 0)
                                 first_kept = me.gid;
                             ++kept;
-                            if (!config.skip_lca)
-                                kept_targets.push_back(node_names[me.gid]);
+                            kept_gids.push_back(me.gid);
                             if (o_all)
                             {
-                                all_lines += rb.ids[r];
-                                all_lines += '\t';
-                                all_lines += node_names[me.gid];
-                                all_lines += '\t';
-                                all_lines += std::to_string(me.count);
-                                all_lines += '\n';
+                                buf_all += rb.id(r);
+                                buf_all += '\t';
+                                buf_all += node_names[me.gid];
+                                buf_all += '\t';
+                                append_num(buf_all, me.count);
+                                buf_all += '\n';
                             }
                         }
                         else
-                            prep[me.gid].discarded_matches_filter++;
+                            rep_at(prep, me.gid).discarded_matches_filter++;
                     }
                     if (kept > 0)
                     {
@@ -856,7 +900,7 @@ static bool ganon_classify(Config config)
                         {
                             if (kept == 1) // :773-778
                             {
-                                prep[first_kept].seqs_unique++;
+                                rep_at(prep, first_kept).seqs_unique++;
                                 if (o_lca)
                                 {
                                     // read_out_lca = read_out: the single kept match with its own count
@@ -864,43 +908,73 @@ static bool ganon_classify(Config config)
                                     for (auto const& me : matches)
                                         if (me.gid == first_kept)
                                             c = me.count;
-                                    *o_lca << rb.ids[r] << '\t' << node_names[first_kept] << '\t' << c << '\n';
+                                    buf_lca += rb.id(r);
+                                    buf_lca += '\t';
+                                    buf_lca += node_names[first_kept];
+                                    buf_lca += '\t';
+                                    append_num(buf_lca, c);
+                                    buf_lca += '\n';
                                 }
                             }
                             else // lca_matches :615-627
                             {
+                                kept_targets.clear();
+                                for (uint32_t g : kept_gids)
+                                    kept_targets.push_back(node_names[g]);
                                 const std::string target_lca = lca.getLCA(kept_targets);
-                                prep[nid(target_lca)].seqs_lca++;
+                                rep_at(prep, nid(target_lca)).seqs_lca++;
                                 if (o_lca)
-                                    *o_lca << rb.ids[r] << '\t' << target_lca << '\t' << max_count_read << '\n';
+                                {
+                                    buf_lca += rb.id(r);
+                                    buf_lca += '\t';
+                                    buf_lca += target_lca;
+                                    buf_lca += '\t';
+                                    append_num(buf_lca, max_count_read);
+                                    buf_lca += '\n';
+                                }
                             }
                         }
                         else
                         {
                             if (kept == 1) // :790-793
-                                prep[first_kept].seqs_unique++;
+                                rep_at(prep, first_kept).seqs_unique++;
                             else           // :794-799
-                                prep[nid(config.tax_root_node)].seqs_lca++;
+                                rep_at(prep, nid(config.tax_root_node)).seqs_lca++;
                         }
-                        if (o_all)
-                            *o_all << all_lines;
                     }
+                    else
+                        buf_all.resize(all_mark);
                 }
                 if (classified)
                     continue;
                 if (!hierarchy_last) // :811-820
                 {
-                    left.ids.push_back(std::move(rb.ids[r]));
-                    left1.emplace_back(reinterpret_cast<const char*>(rb.bases.data()) + rb.off1[r], read1_len);
+                    const std::string_view id = rb.id(r);
+                    left.id_buf.append(id);
+                    left.id_off.push_back(left.id_buf.size());
+                    left.bases.insert(left.bases.end(), rb.bases.begin() + rb.off1[r], rb.bases.begin() + rb.off1[r] + read1_len);
+                    left.off1.push_back(left.bases.size());
                     if (rb.paired)
-                        left2.emplace_back(reinterpret_cast<const char*>(rb.bases.data()) + rb.off2[r], read2_len);
+                    {
+                        left2.insert(left2.end(), rb.bases.begin() + rb.off2[r], rb.bases.begin() + rb.off2[r] + read2_len);
+                        left.off2.push_back(left2.size());
+                    }
                 }
                 else if (o_unc) // :821-825
-                    *o_unc << rb.ids[r] << '\n';
+                {
+                    buf_unc += rb.id(r);
+                    buf_unc += '\n';
+                }
             }
-            if (!hierarchy_last && !left.ids.empty())
+            if (o_all)
+                o_all->write(buf_all.data(), (std::streamsize)buf_all.size());
+            if (o_lca)
+                o_lca->write(buf_lca.data(), (std::streamsize)buf_lca.size());
+            if (o_unc)
+                o_unc->write(buf_unc.data(), (std::streamsize)buf_unc.size());
+            if (!hierarchy_last && left.size() != 0)
             {
-                finalize_batch(left, left1, left2);
+                finalize_batch(left, left2);
                 next_carried.push_back(std::move(left));
             }
             sec_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev1).count();
@@ -909,32 +983,77 @@ static bool ganon_classify(Config config)
 
         if (hierarchy_first)
         {
-            ReadBatch rb;
-            while (queue1.pop(rb))
-                if (!process_batch(rb))
+            // three stages on three threads: parse_reads -> queue1 -> device stage -> queue2 -> post stage (here)
+            BoundedQueue<ClassifiedBatch> queue2(2);
+            std::atomic<bool>             device_failed{ false };
+            std::thread                   device_task([&] {
+                ClassifiedBatch cb;
+                while (queue2.take_free(cb), queue1.pop(cb.rb))
+                {
+                    if (!device_stage(cb.rb, cb.res))
+                    {
+                        device_failed = true;
+                        break;
+                    }
+                    queue2.push(std::move(cb));
+                }
+                queue2.done();
+            });
+            struct DeviceJoiner
+            {
+                std::thread&                   t;
+                BoundedQueue<ClassifiedBatch>& q;
+                BatchQueue&                    q_in;
+                ~DeviceJoiner()
+                {
+                    if (!t.joinable())
+                        return;
+                    ClassifiedBatch cb; // unblock the stage whichever queue it waits on, then join
+                    while (q.pop(cb)) {}
+                    t.join();
+                }
+            } device_joiner{ device_task, queue2, queue1 };
+            ClassifiedBatch cb;
+            while (queue2.pop(cb))
+            {
+                if (!post_stage(cb.rb, cb.res))
                     return false;
+                queue1.recycle(std::move(cb.rb));
+                cb.rb = ReadBatch();
+                queue2.recycle(std::move(cb));
+            }
+            device_task.join();
+            if (device_failed)
+            {
+                std::cerr << "ERROR: " << err << std::endl;
+                return false;
+            }
             read_task.join();
         }
         else
         {
+            BatchResult res;
             for (auto& rb : carried)
-                if (!process_batch(rb))
+            {
+                if (!device_stage(rb, res))
+                {
+                    std::cerr << "ERROR: " << err << std::endl;
                     return false;
+                }
+                if (!post_stage(rb, res))
+                    return false;
+            }
         }
         carried.swap(next_carried);
 
         // reports (:1609-1617)
         stats.add_totals(hierarchy_label, totals);
         for (auto const& [prefix, pr] : rep)
-            for (auto const& [gid, rp] : pr)
+            for (auto const& rp : pr)
                 stats.add_report(hierarchy_label, prefix, rp);
         for (auto& [prefix, pr] : rep) // write_report :834-853, rows in node order
         {
-            std::vector<uint32_t> gids;
-            for (auto const& [gid, rp] : pr)
-                gids.push_back(gid);
-            std::sort(gids.begin(), gids.end());
-            for (uint32_t gid : gids)
+            for (uint32_t gid = 0; gid < pr.size(); ++gid)
             {
                 const Rep& report = pr[gid];
                 if (report.matches || report.seqs_lca || report.seqs_unique)

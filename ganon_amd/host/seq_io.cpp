@@ -1,10 +1,12 @@
 // seq_io.cpp -- see seq_io.hpp
 #include "seq_io.hpp"
 
+#include <tmmintrin.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <cstring>
+#include <string_view>
 
 namespace gnhost
 {
@@ -32,62 +34,128 @@ struct LegalTable
     }
 };
 const LegalTable kLegal;
+
+bool all_legal_scalar(const char* p, size_t n)
+{
+    unsigned bad = 0;
+    for (size_t i = 0; i < n; ++i)
+        bad |= !kLegal.ok[(unsigned char)p[i]];
+    return !bad;
+}
+
+// 16 letters per step: a letter is legal iff its high nibble selects the A-O / P-Z half (either case) and its low
+// nibble is a member of that half's set -- two 16-entry byte shuffles and an AND.
+__attribute__((target("ssse3"))) bool all_legal_ssse3(const char* p, size_t n)
+{
+    // low-nibble classes: bit 0 = legal in A-O (A B C D G H K M N), bit 1 = legal in P-Z (R S T U V W Y)
+    const __m128i lo_tbl = _mm_setr_epi8(0, 1, 3, 3, 3, 2, 2, 3, 1, 2, 0, 1, 0, 1, 1, 0);
+    // high-nibble classes: 0x4_/0x6_ -> bit 0, 0x5_/0x7_ -> bit 1
+    const __m128i hi_tbl = _mm_setr_epi8(0, 0, 0, 0, 1, 2, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m128i nib    = _mm_set1_epi8(0x0F);
+    __m128i       ok_all = _mm_set1_epi8((char)0xFF);
+    size_t        i      = 0;
+    for (; i + 16 <= n; i += 16)
+    {
+        const __m128i v  = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i));
+        const __m128i lo = _mm_shuffle_epi8(lo_tbl, _mm_and_si128(v, nib));
+        const __m128i hi = _mm_shuffle_epi8(hi_tbl, _mm_and_si128(_mm_srli_epi16(v, 4), nib));
+        const __m128i ok = _mm_cmpgt_epi8(_mm_and_si128(lo, hi), _mm_setzero_si128());
+        ok_all           = _mm_and_si128(ok_all, ok);
+    }
+    if (_mm_movemask_epi8(ok_all) != 0xFFFF)
+        return false;
+    return all_legal_scalar(p + i, n - i);
+}
+
+bool all_legal(const char* p, size_t n)
+{
+    static const bool have_ssse3 = __builtin_cpu_supports("ssse3");
+    return have_ssse3 ? all_legal_ssse3(p, n) : all_legal_scalar(p, n);
+}
 } // namespace
 
 struct SeqReader::Impl
 {
-    gzFile      gz = nullptr;
-    std::string path;
-    bool        fastq = false;
+    gzFile            gz = nullptr;
+    std::string       path;
+    bool              fastq = false;
     std::vector<char> buf;
-    size_t      pos = 0, len = 0;
-    bool        eof = false;
-    std::string line;
-    bool        have_pending = false; // FASTA: header of the next record already read into `line`
+    size_t            pos = 0, len = 0;
+    bool              eof = false;
+    bool              have_pending = false; // FASTA: header of the next record already read
+    std::string       pending;
 
-    bool fill()
+    // moves the unread tail to the front and reads more; false when nothing could be added
+    bool refill()
     {
         if (eof)
             return false;
-        const int n = gzread(gz, buf.data(), (unsigned)buf.size());
+        if (pos > 0)
+        {
+            std::memmove(buf.data(), buf.data() + pos, len - pos);
+            len -= pos;
+            pos = 0;
+        }
+        if (len == buf.size())
+            buf.resize(buf.size() * 2); // a single line longer than the buffer
+        const int n = gzread(gz, buf.data() + len, (unsigned)std::min<size_t>(buf.size() - len, 1u << 30));
         if (n < 0)
         {
             int         err = 0;
             const char* msg = gzerror(gz, &err);
             throw ParseError(" " + std::string(msg ? msg : "decompression error"));
         }
-        pos = 0;
-        len = (size_t)n;
         if (n == 0)
+        {
             eof = true;
-        return n > 0;
+            return false;
+        }
+        len += (size_t)n;
+        return true;
     }
-    // reads one line (without '\n', trailing '\r' stripped); false at EOF with nothing read
-    bool getline(std::string& out)
+    // next line as a view into the buffer (no '\n', trailing '\r' stripped), valid until the next call;
+    // false at EOF with nothing read
+    bool line(std::string_view& out)
     {
-        out.clear();
-        bool any = false;
+        size_t scanned = 0; // bytes after pos already known to hold no newline
         while (true)
         {
-            if (pos == len && !fill())
-                break;
-            any              = true;
-            const char* b    = buf.data() + pos;
-            const char* nl   = static_cast<const char*>(std::memchr(b, '\n', len - pos));
+            const char* b  = buf.data() + pos;
+            const char* nl = static_cast<const char*>(std::memchr(b + scanned, '\n', len - pos - scanned));
             if (nl)
             {
-                out.append(b, nl - b);
-                pos += (size_t)(nl - b) + 1;
-                break;
+                size_t n = (size_t)(nl - b);
+                pos += n + 1;
+                if (n && b[n - 1] == '\r')
+                    --n;
+                out = std::string_view(b, n);
+                return true;
             }
-            out.append(b, len - pos);
-            pos = len;
+            scanned = len - pos;
+            if (!refill())
+            {
+                if (len == pos)
+                    return false;
+                size_t n = len - pos; // last line without a newline
+                b        = buf.data() + pos;
+                pos      = len;
+                if (n && b[n - 1] == '\r')
+                    --n;
+                out = std::string_view(b, n);
+                return true;
+            }
         }
-        if (!out.empty() && out.back() == '\r')
-            out.pop_back();
-        return any;
     }
 };
+
+[[noreturn]] void bad_letter(std::string_view l)
+{
+    for (char c : l)
+        if (!kLegal.ok[(unsigned char)c])
+            throw ParseError(std::string(" Encountered an unexpected letter: char_is_valid_for<dna15> evaluated to false on '") + c
+                             + "'");
+    throw ParseError(" Encountered an unexpected letter");
+}
 
 SeqReader::SeqReader(const std::string& path) : impl_(new Impl)
 {
@@ -117,7 +185,7 @@ SeqReader::SeqReader(const std::string& path) : impl_(new Impl)
     if (!impl_->gz)
         throw ParseError(" cannot open file");
     gzbuffer(impl_->gz, 1 << 20);
-    impl_->buf.resize(1 << 20);
+    impl_->buf.resize(4 << 20);
 }
 
 SeqReader::~SeqReader()
@@ -126,81 +194,86 @@ SeqReader::~SeqReader()
         gzclose(impl_->gz);
 }
 
-bool SeqReader::next(std::string& id, std::string& seq)
+bool SeqReader::next(std::string& ids, std::vector<uint8_t>& bases)
 {
-    Impl& s = *impl_;
-    id.clear();
-    seq.clear();
-    if (s.fastq)
+    Impl&            s = *impl_;
+    const size_t     ids0 = ids.size(), bases0 = bases.size();
+    std::string_view l;
+    try
     {
-        // @id / sequence line(s) / +[id] / quality line(s)
-        do
+        if (s.fastq)
         {
-            if (!s.getline(s.line))
-                return false;
-        } while (s.line.empty());
-        if (s.line[0] != '@')
-            throw ParseError(" FASTQ record does not start with '@'");
-        id = s.line.substr(1);
-        while (true)
+            // @id / sequence line(s) / +[id] / quality line(s)
+            do
+            {
+                if (!s.line(l))
+                    return false;
+            } while (l.empty());
+            if (l[0] != '@')
+                throw ParseError(" FASTQ record does not start with '@'");
+            ids.append(l.data() + 1, l.size() - 1);
+            while (true)
+            {
+                if (!s.line(l))
+                    throw ParseError(" unexpected end of FASTQ record");
+                if (!l.empty() && l[0] == '+')
+                    break;
+                if (!all_legal(l.data(), l.size()))
+                    bad_letter(l);
+                const size_t at = bases.size();
+                bases.resize(at + l.size());
+                std::memcpy(bases.data() + at, l.data(), l.size());
+            }
+            const size_t want = bases.size() - bases0;
+            size_t       q    = 0;
+            while (q < want)
+            {
+                if (!s.line(l))
+                    throw ParseError(" unexpected end of FASTQ qualities");
+                q += l.size();
+            }
+            if (q != want)
+                throw ParseError(" sequence and quality lengths differ");
+            return true;
+        }
+        // FASTA
+        if (s.have_pending)
+            l = s.pending;
+        else
+            do
+            {
+                if (!s.line(l))
+                    return false;
+            } while (l.empty());
+        s.have_pending = false;
+        if (l[0] != '>' && l[0] != ';')
+            throw ParseError(" FASTA record does not start with '>'");
+        ids.append(l.data() + 1, l.size() - 1);
+        while (s.line(l))
         {
-            if (!s.getline(s.line))
-                throw ParseError(" unexpected end of FASTQ record");
-            if (!s.line.empty() && s.line[0] == '+')
+            if (!l.empty() && (l[0] == '>' || l[0] == ';'))
+            {
+                s.pending.assign(l);
+                s.have_pending = true;
                 break;
-            // validate the whole line, then append it in one go
-            bool bad = false;
-            for (unsigned char c : s.line)
-                bad |= !kLegal.ok[c];
-            if (bad)
-                for (char c : s.line)
-                    if (!kLegal.ok[(unsigned char)c])
-                        throw ParseError(std::string(" Encountered an unexpected letter: char_is_valid_for<dna15> evaluated to false on '")
-                                         + c + "'");
-            seq.append(s.line);
+            }
+            for (char c : l)
+            {
+                if (std::isspace((unsigned char)c) || std::isdigit((unsigned char)c))
+                    continue;
+                if (!kLegal.ok[(unsigned char)c])
+                    bad_letter(std::string_view(&c, 1));
+                bases.push_back((uint8_t)c);
+            }
         }
-        size_t q = 0;
-        while (q < seq.size())
-        {
-            if (!s.getline(s.line))
-                throw ParseError(" unexpected end of FASTQ qualities");
-            q += s.line.size();
-        }
-        if (q != seq.size())
-            throw ParseError(" sequence and quality lengths differ");
         return true;
     }
-    // FASTA
-    if (!s.have_pending)
+    catch (ParseError const&)
     {
-        do
-        {
-            if (!s.getline(s.line))
-                return false;
-        } while (s.line.empty());
+        ids.resize(ids0); // the record that failed leaves nothing behind
+        bases.resize(bases0);
+        throw;
     }
-    s.have_pending = false;
-    if (s.line[0] != '>' && s.line[0] != ';')
-        throw ParseError(" FASTA record does not start with '>'");
-    id = s.line.substr(1);
-    while (s.getline(s.line))
-    {
-        if (!s.line.empty() && (s.line[0] == '>' || s.line[0] == ';'))
-        {
-            s.have_pending = true;
-            break;
-        }
-        for (char c : s.line)
-        {
-            if (std::isspace((unsigned char)c) || std::isdigit((unsigned char)c))
-                continue;
-            if (!kLegal.ok[(unsigned char)c])
-                throw ParseError(std::string(" Encountered an unexpected letter: char_is_valid_for<dna15> evaluated to false on '") + c
-                                 + "'");
-            seq.push_back(c);
-        }
-    }
-    return true;
 }
 
 } // namespace gnhost

@@ -28,8 +28,9 @@ class SeqReader
 public:
     explicit SeqReader(const std::string& path); // throws ParseError / runtime_error
     ~SeqReader();
-    // next record: id and ASCII sequence appended to `seq`; returns false at end of file
-    bool next(std::string& id, std::string& seq);
+    // next record: its id is appended to `ids` and its ASCII sequence to `bases` (the caller keeps the offsets);
+    // returns false at end of file.  A ParseError leaves both containers as they were before the call.
+    bool next(std::string& ids, std::vector<uint8_t>& bases);
 
 private:
     struct Impl;

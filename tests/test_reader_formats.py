@@ -1,0 +1,160 @@
+"""Input-format semantics of the host reader (seqan3::sequence_file_input as used at GanonClassify.cpp:1220-1287):
+the same reads written as FASTQ / FASTA, wrapped, CRLF, gzipped, without a final newline ... must give byte-identical
+outputs; a parse error keeps the records before it and moves on.  CPU: test-only oracle backend."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import cli_util as cu
+import ganon_fixtures as gf
+from test_cli_kat import _sim_reads, oracle_bin, sim_db  # noqa: F401  (fixtures)
+
+
+def _wrap(s, n):
+    return "\n".join(s[i:i + n] for i in range(0, len(s), n)) if s else ""
+
+
+def _write(path, text, nl="\n", gz=False):
+    data = text.replace("\n", nl).encode()
+    if gz:
+        with gzip.open(path, "wb") as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+
+
+def _fastq(recs, wrap=None):
+    out = []
+    for rid, s in recs:
+        q = "I" * len(s)
+        out.append(f"@{rid}\n{_wrap(s, wrap) if wrap else s}\n+\n{_wrap(q, wrap) if wrap else q}\n")
+    return "".join(out)
+
+
+def _fasta(recs, wrap=70, lower=False):
+    return "".join(f">{rid}\n{_wrap(s.lower() if lower else s, wrap)}\n" for rid, s in recs)
+
+
+def _run(binary, sim_db, reads_arg, prefix, check=True, cutoff="0.25"):
+    args = ["--ibf", sim_db["ibf"], "--tax", sim_db["tax"], "-o", prefix, "--output-all", "--output-lca",
+            "--output-unclassified", "--quiet", "--rel-cutoff", cutoff, "--rel-filter", "0.1"] + reads_arg
+    return cu.run(binary, args, check=check)
+
+
+def _outputs(prefix):
+    return {e: open(prefix + e, "rb").read() for e in (".rep", ".all", ".one", ".unc")}
+
+
+def _variants(d, r1):
+    v = {}
+    _write(os.path.join(d, "a.fq"), _fastq(r1)); v["plain"] = "a.fq"
+    _write(os.path.join(d, "b.fastq"), _fastq(r1).rstrip("\n"), nl="\r\n"); v["crlf_noeol"] = "b.fastq"
+    _write(os.path.join(d, "c.fq"), "\n\n" + _fastq(r1, wrap=60)); v["wrapped_fastq"] = "c.fq"
+    _write(os.path.join(d, "d.fa"), _fasta(r1, 70, lower=True)); v["fasta_lower"] = "d.fa"
+    _write(os.path.join(d, "e.fasta.gz"), _fasta(r1, 10_000), gz=True); v["fasta_gz"] = "e.fasta.gz"
+    spaced = "".join(f">{rid}\n{_wrap(s, 33).replace(chr(10), ' ' + chr(10))} \n" for rid, s in r1)  # blanks inside sequences
+    _write(os.path.join(d, "f.fna"), spaced, nl="\r\n"); v["fasta_crlf_spaces"] = "f.fna"
+    return v
+
+
+def _check_variants(binary, sim_db, tmp):
+    r1, r2 = _sim_reads()
+    r1 = r1[:40]
+    v = _variants(tmp, r1)
+    ref = None
+    for name, fn in v.items():
+        p = os.path.join(tmp, "o_" + name)
+        _run(binary, sim_db, ["--single-reads", os.path.join(tmp, fn)], p)
+        out = _outputs(p)
+        assert len(out[".all"]) > 100
+        if ref is None:
+            ref = out
+        assert out == ref, name
+
+
+def test_formats_equivalent_oracle_backend(oracle_bin, sim_db, tmp_path):
+    _check_variants(oracle_bin, sim_db, str(tmp_path))
+
+
+def _check_errors(binary, sim_db, tmp):
+    r1, r2 = _sim_reads()
+    r1, r2 = r1[:30], r2[:30]
+    good1, good2 = os.path.join(tmp, "g1.fq"), os.path.join(tmp, "g2.fq")
+    # reference run: first 10 pairs only
+    _write(good1, _fastq(r1[:10])); _write(good2, _fastq(r2[:10]))
+    p_ref = os.path.join(tmp, "ref")
+    _run(binary, sim_db, ["--paired-reads", good1 + "," + good2], p_ref)
+    # (1) illegal letter in record 11 of file 1 -> error reported, 10 records kept
+    bad = list(r1)
+    bad[10] = (bad[10][0], bad[10][1][:50] + "!" + bad[10][1][51:])
+    b1, b2 = os.path.join(tmp, "b1.fq"), os.path.join(tmp, "b2.fq")
+    _write(b1, _fastq(bad)); _write(b2, _fastq(r2))
+    p = os.path.join(tmp, "bad")
+    res = _run(binary, sim_db, ["--paired-reads", b1 + "," + b2], p)
+    assert "Error parsing file" in res.stderr and "'!'" in res.stderr
+    assert _outputs(p) == _outputs(p_ref)
+    # (2) truncated record (no quality line) at the end
+    t1 = os.path.join(tmp, "t1.fq")
+    _write(t1, _fastq(r1[:10]) + f"@{r1[10][0]}\n{r1[10][1]}\n+\n")
+    p = os.path.join(tmp, "trunc")
+    res = _run(binary, sim_db, ["--paired-reads", t1 + "," + good2], p)
+    assert "Error parsing file" in res.stderr
+    assert _outputs(p) == _outputs(p_ref)
+    # (3) the error only stops THAT file: a second, good pair of files is still processed
+    p = os.path.join(tmp, "two")
+    res = _run(binary, sim_db, ["--paired-reads", ",".join([b1, b2, good1, good2])], p)
+    assert "Error parsing file" in res.stderr
+    two = cu.Res(p)
+    one = cu.Res(p_ref)
+    assert two.total_classified + two.total_unclassified == 2 * (one.total_classified + one.total_unclassified)
+    # (4) mates file shorter than file 1: the missing mates count as empty
+    s2 = os.path.join(tmp, "s2.fq")
+    _write(s2, _fastq(r2[:5]))
+    p = os.path.join(tmp, "short")
+    _run(binary, sim_db, ["--paired-reads", good1 + "," + s2], p)
+    r = cu.Res(p)
+    assert r.total_classified + r.total_unclassified == 10
+    # (5) unknown extension
+    u = os.path.join(tmp, "reads.txt")
+    _write(u, _fastq(r1))
+    p = os.path.join(tmp, "unk")
+    res = _run(binary, sim_db, ["--single-reads", u], p, check=False)
+    assert "Error parsing file" in res.stderr
+
+
+def test_parse_errors_oracle_backend(oracle_bin, sim_db, tmp_path):
+    _check_errors(oracle_bin, sim_db, str(tmp_path))
+
+
+def _check_long_line(binary, sim_db, tmp):
+    """one 6 Mbp sequence on a single line (longer than the reader's buffer) == the same sequence wrapped"""
+    rng = np.random.default_rng(4)
+    tgt = list(sim_db["targets"].values())[3]
+    seq = "".join("ACGT"[x] for x in rng.integers(0, 4, size=6_000_000))
+    seq = seq[:3_000_000] + tgt + seq[3_000_000:]
+    a, b = os.path.join(tmp, "long1.fa"), os.path.join(tmp, "long2.fa")
+    mid = seq[:200_000] + tgt + seq[200_000:400_000]
+    _write(a, f">chr\n{seq}\n>mid\n{mid}\n>tail\n{tgt[:400]}")
+    _write(b, f">chr\n{_wrap(seq, 80)}\n>mid\n{_wrap(mid, 80)}\n>tail\n{_wrap(tgt[:400], 80)}\n")
+    outs = []
+    for fn in (a, b):
+        p = os.path.join(tmp, "o_" + os.path.basename(fn))
+        _run(binary, sim_db, ["--single-reads", fn], p, cutoff="0")
+        outs.append(_outputs(p))
+    assert outs[0] == outs[1]
+    # chr has more than 65535 minimisers -> skipped like the reference does (:674); the records after it are intact
+    assert outs[0][".unc"] == b"chr\n" and b"mid\tT3.1\t" in outs[0][".all"] and b"tail\tT3.1\t" in outs[0][".all"]
+
+
+def test_long_line_oracle_backend(oracle_bin, sim_db, tmp_path):
+    _check_long_line(oracle_bin, sim_db, str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_formats_errors_long_line_hip(sim_db, tmp_path):
+    _check_variants(cu.BIN_HIP, sim_db, str(tmp_path))
+    _check_errors(cu.BIN_HIP, sim_db, str(tmp_path))
+    _check_long_line(cu.BIN_HIP, sim_db, str(tmp_path))
