@@ -68,9 +68,12 @@ def main() -> int:
     if not torch.cuda.is_available():
         log("bench.py: no GPU visible -- the hot path has no CPU fallback")
         return 2
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # == local_rank on a real N-GPU node
+    torch.cuda.set_device(dev_index)
+    dist_backend = os.environ.get("GANON_BENCH_DIST", "nccl")   # nccl == RCCL; "gloo" only for 1-GPU dry runs
+    red_dev = "cuda" if dist_backend == "nccl" else "cpu"
     if world > 1:
-        gdist.init("nccl", torch.device("cuda", local_rank))
+        gdist.init(dist_backend, torch.device("cuda", dev_index))
 
     bins, rows, h, n_reads = WORKLOADS[args.workload]
     if args.reads:
@@ -81,7 +84,7 @@ def main() -> int:
         f"generated in {time.time() - t0:.1f}s")
 
     t0 = time.time()
-    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs, device=local_rank)
+    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs, device=dev_index)
     n_planted = bw.plant_genomes(flt, wl)
     log(f"[rank {rank}] filter uploaded + {n_planted} genome minimisers emplaced on device in {time.time() - t0:.1f}s")
 
@@ -110,8 +113,8 @@ def main() -> int:
         total_ms.append(tm["ms_total"])
     barrier()
     elapsed = time.perf_counter() - t_begin
-    elapsed = gdist.max_over_ranks(elapsed, device="cuda")       # slowest rank defines the step time
-    total_reads = gdist.sum_over_ranks(n_reads, device="cuda")    # whole-job reads per step
+    elapsed = gdist.max_over_ranks(elapsed, device=red_dev)       # slowest rank defines the step time
+    total_reads = gdist.sum_over_ranks(n_reads, device=red_dev)    # whole-job reads per step
 
     tm = st.timings()
     nh, status, mo, matches = st.fetch()
@@ -182,12 +185,13 @@ def main() -> int:
             if not ok:
                 log("bench.py: ORACLE SPOT CHECK FAILED:", detail)
                 result["value"] = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N=1 measurement
             try:
                 result["cpu_baseline"] = bench_cpu.cpu_baseline(wl, flt, args.cpu_sample)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
                 log("bench.py: cpu_baseline failed:", repr(e))
                 result["cpu_baseline"] = None
+        result.setdefault("cpu_baseline", None)
         print(json.dumps(result), flush=True)
     st.destroy()
     flt.free()
