@@ -162,6 +162,10 @@ def main() -> int:
             "launches_per_step": int(tm["n_count_launches"]),
             "algo_bytes_per_launch": int(tm["algo_bytes"] // max(1, tm["n_count_launches"])),
             "avg_launch_ms": round(avg_count_ms / max(1, tm["n_count_launches"]), 4),
+            # rows actually requested: reads that can no longer reach their cutoff stop fetching (exact early exit),
+            # so the kernel moves fewer bytes than the algorithmic n*h*W*8 it is credited with above
+            "fetched_bytes_per_launch": int(tm["fetched_bytes"] // max(1, tm["n_count_launches"])),
+            "fetched_gbs": round(tm["fetched_bytes"] / (avg_count_ms * 1e-3) / 1e9, 1) if count_ms else None,
             "traffic": None,
         },
     }

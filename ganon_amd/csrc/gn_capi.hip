@@ -569,8 +569,13 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.seg_count  = s->d_seg_count;
     p.dense      = nullptr;
     p.max_blocks = (uint32_t)f->n_cu * 16u;
-    p.max_blocks_fast = (uint32_t)f->n_cu * (getenv("GANON_HIP_FAST_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_FAST_BPC")) : 6u);
+    // persistent grid = a whole number of resident rounds: 8-byte-lane variant holds 4 blocks per CU, 16-byte one 3
+    p.max_blocks_fast = (uint32_t)f->n_cu * (getenv("GANON_HIP_FAST_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_FAST_BPC")) : (f->geom.lw == 1 ? 8u : 6u));
     p.nt_loads = getenv("GANON_HIP_NT") ? (uint32_t)atoi(getenv("GANON_HIP_NT")) : 0u;
+    p.early_exit = getenv("GANON_HIP_NO_EARLY_EXIT") ? 0u : (getenv("GANON_HIP_EE") ? (uint32_t)atoi(getenv("GANON_HIP_EE")) : 1u);
+    p.skip_ctr   = s->d_ctr + 7;
+    if (lo == 0) // (a re-run after a match-buffer regrow starts the tally again)
+        GN_HIP(hipMemsetAsync(s->d_ctr + 7, 0, sizeof(unsigned long long), s->st));
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
     if (fast)
     {
@@ -976,6 +981,7 @@ extern "C" int gn_stream_timings(gn_stream* s, gn_timings* t)
         tm.algo_bytes = s->h_ctr[2];
     else
         tm.algo_bytes = tm.n_hashes * (uint64_t)s->f->ibf.h * s->f->ibf.W * 8ull;
+    tm.fetched_bytes = tm.algo_bytes - (s->f->is_hibf ? 0ull : (uint64_t)s->h_ctr[7]);
     *t = tm;
     return GN_OK;
 }

@@ -83,6 +83,8 @@ struct GnCountParams
     uint32_t                  max_blocks; // generic kernel: persistent grid size
     uint32_t                  max_blocks_fast; // fast kernel: persistent grid size
     uint32_t                  nt_loads;        // fast kernel: non-temporal row loads
+    uint32_t                  early_exit;      // fast kernel: stop fetching rows of reads that cannot reach the cutoff
+    unsigned long long*       skip_ctr;        // row bytes not fetched thanks to early exits
 };
 
 struct GnCountGeometry

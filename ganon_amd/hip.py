@@ -8,7 +8,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "csrc", "libganon_hip.so")
+_LIB_PATH = os.environ.get("GANON_HIP_LIB") or os.path.join(_HERE, "csrc", "libganon_hip.so")  # override: A/B builds
 
 READ_OK, READ_SMALL, READ_BIG = 0, 1, 2
 MATCH_DTYPE = np.dtype([("read", "<u4"), ("target", "<u4"), ("count", "<u4")])
@@ -34,7 +34,7 @@ class IbfDesc(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("ms_minimiser", C.c_float), ("ms_count", C.c_float), ("ms_total", C.c_float),
                 ("n_hashes", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_matches", C.c_uint64),
-                ("n_count_launches", C.c_uint32)]
+                ("n_count_launches", C.c_uint32), ("fetched_bytes", C.c_uint64)]
 
 
 _lib = None
@@ -231,7 +231,8 @@ class HipStream:
         t = Timings()
         _check(load_library().gn_stream_timings(self._h, C.byref(t)))
         return dict(ms_minimiser=t.ms_minimiser, ms_count=t.ms_count, ms_total=t.ms_total, n_hashes=t.n_hashes,
-                    algo_bytes=t.algo_bytes, n_matches=t.n_matches, n_count_launches=t.n_count_launches)
+                    algo_bytes=t.algo_bytes, n_matches=t.n_matches, n_count_launches=t.n_count_launches,
+                    fetched_bytes=t.fetched_bytes)
 
     def destroy(self) -> None:
         if self._h:

@@ -77,6 +77,8 @@ typedef struct
     uint64_t algo_bytes;   /* algorithmic row bytes: sum n*h*W*8 over every IBF visited */
     uint64_t n_matches;
     uint32_t n_count_launches; /* count/select launches of the batch (chunks of the minimiser||count pipeline); ms_count spans all */
+    uint64_t fetched_bytes;    /* row bytes actually requested: algo_bytes minus the rows skipped by the exact early exit
+                                  of reads that can no longer reach their cutoff (flat IBF fast path) */
 } gn_timings;
 
 int         gn_device_count(int* n);

@@ -331,3 +331,57 @@ def test_chunked_pipeline_parity(hip, monkeypatch):
         for a, b in zip(outs[0][:4], o[:4]):
             assert np.array_equal(a, b)
     assert len(outs[0][3]) > 2000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bins,rows,h", [(4096, 5003, 4), (4096, 3001, 2), (8192, 2003, 3), (32768, 1201, 4), (4032, 2003, 5)])
+def test_early_exit_is_exact(hip, monkeypatch, bins, rows, h):
+    # Reads whose best count lands just below / at / above the cutoff (mutated copies of planted genomes), several
+    # cutoffs: the fast kernel's early exit (stop fetching rows once no bin can still reach the cutoff) must not
+    # change a single match -- against the oracle and against the same kernel with the exit disabled -- and must
+    # actually skip rows when the cutoff leaves room for it.
+    k, w = 19, 31
+    rng = np.random.default_rng(bins * 3 + h)
+    ibf = gf.random_ibf(bins, rows, h, 0.5, seed=bins + h)
+    genomes = [gu.random_seq(rng, 900) for _ in range(48)]
+    for gi, g in enumerate(genomes):
+        ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), (gi * 611 + 5) % bins)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h)
+    reads = []
+    for i in range(2400):
+        g = genomes[i % 48]
+        p = int(rng.integers(0, 700))
+        s = bytearray(g[p:p + 150])
+        for _ in range(i % 8):  # 0..7 substitutions: minimiser hits range from all to about a third
+            q = int(rng.integers(0, 150))
+            s[q] = b"ACGT"[(b"ACGT".index(s[q]) + 1 + int(rng.integers(0, 3))) % 4]
+        reads.append(bytes(s) if i % 5 else gu.random_seq(rng, 150))
+    b2t = np.arange(bins, dtype=np.uint32)
+    for cutoff in (0.0, 0.3, 0.55, 0.75, 0.9, 1.0):
+        monkeypatch.delenv("GANON_HIP_NO_EARLY_EXIT", raising=False)
+        st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
+        tm = st.timings()
+        ho, hs = st.fetch_hashes()
+        monkeypatch.setenv("GANON_HIP_NO_EARLY_EXIT", "1")
+        st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
+        tm2 = st2.timings()
+        assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
+        assert tm2["fetched_bytes"] == tm2["algo_bytes"] == tm["algo_bytes"]
+        assert tm["fetched_bytes"] <= tm["algo_bytes"]
+        if cutoff == 0.0:
+            assert tm["fetched_bytes"] == tm["algo_bytes"]     # T = 1: nothing can be ruled out early
+        if cutoff >= 0.75 and bins % 4096 == 0 and h >= 3:  # (h = 2 at 50 % fill: random bins stay in the race)
+            assert tm["fetched_bytes"] < tm["algo_bytes"]      # rows were skipped
+        near = 0
+        for i in range(0, len(reads), 3):
+            hh = hs[int(ho[i]):int(ho[i + 1])]
+            exp_m, _ = gu.oracle_matches(ibf, b2t, bins, hh, cutoff)
+            got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+            assert got == exp_m, (cutoff, i, got[:3], exp_m[:3])
+            thr = oracle.threshold_cutoff(len(hh), cutoff)
+            near += any(abs(c - thr) <= 1 for _, c in exp_m)
+        if 0.3 <= cutoff <= 0.9:
+            assert near > 10   # the boundary is exercised
+        st.destroy()
+        st2.destroy()
+    flt.free()
