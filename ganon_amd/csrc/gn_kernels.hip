@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     constexpr uint32_t NMAX = 127;
 
     const int      lane  = threadIdx.x & (GN_WAVE - 1);
-    const int      wave  = threadIdx.x >> 6;
+    const int      wave  = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform: unit, read, n, ... live in SGPRs
     const uint32_t wpr   = p.wpr;
     const uint32_t Gp    = 1u << p.gp_log2;
     const uint32_t H     = GN_WAVE >> p.gp_log2;
