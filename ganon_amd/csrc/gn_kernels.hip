@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t gn_smem[];
     const int      lane      = threadIdx.x & (GN_WAVE - 1);
-    const int      wave      = threadIdx.x >> 6;
+    const int      wave      = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform -> SGPRs
     const uint32_t K         = p.w - p.k + 1;
     const bool     fastp     = K <= 65 && !p.force_generic; // two-chunk LDS ring + bit-plane k-mers
     const uint32_t vv_bytes  = fastp ? 128u * 8u : (GN_WAVE + K) * 8;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
     constexpr int HFP = HF <= 4 ? 4 : 8; // padded row-table stride (u32)
 
     const int      lane   = threadIdx.x & (GN_WAVE - 1);
-    const int      wave   = threadIdx.x >> 6;
+    const int      wave   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform -> SGPRs
     const uint32_t nwaves = blockDim.x >> 6;
     const uint32_t wpr    = p.wpr;
     const uint32_t rpb    = nwaves / wpr;
