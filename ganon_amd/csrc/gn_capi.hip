@@ -206,6 +206,37 @@ extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const ui
             return gn_fail(GN_ENOMEM, "target map allocation failed");
         }
         hipMemcpy(f->d_tgt_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice);
+        // candidate-driven select of the generic kernel: bin -> target, and bins-per-target of every bin (one byte,
+        // capped at 255, 0 for bins of no target); the bytes of count dwords 2j and 2j+1 (gn_count_lds_index: u16 pairs
+        // at dword q*(Gp+1)+gl) share dword j*(Gp+1)+gl of a half-sized table
+        if (geom.nbtab_off != 0)
+        {
+            std::vector<uint32_t> bin_tgt(ibf->bins ? ibf->bins : 1, 0xFFFFFFFFu);
+            std::vector<uint32_t> nb2((size_t)geom.wpr * (geom.slice_dwords / 2), 0u);
+            const uint32_t        gp1 = (1u << geom.gp_log2) + 1u;
+            for (uint64_t b = 0; b < ibf->bins; ++b)
+            {
+                const uint32_t t = bin2target[b];
+                if (t == 0xFFFFFFFFu)
+                    continue;
+                bin_tgt[b]         = t;
+                const uint32_t len = off[t + 1] - off[t];
+                const uint32_t nbc = len > 255u ? 255u : len;
+                const uint32_t a    = gn_count_lds_index(geom, (uint32_t)b);
+                const uint32_t dw   = a >> 1, half = a & 1u; // count dword inside the read's area, u16 half
+                const uint32_t sl   = dw / geom.slice_dwords, in_sl = dw - sl * geom.slice_dwords;
+                const uint32_t q    = in_sl / gp1, g = in_sl - q * gp1;
+                nb2[(size_t)sl * (geom.slice_dwords / 2) + (q >> 1) * gp1 + g] |= nbc << (8 * (2 * (q & 1u) + half));
+            }
+            if (hipMalloc(reinterpret_cast<void**>(&f->d_bin_tgt), bin_tgt.size() * 4) != hipSuccess
+                || hipMalloc(reinterpret_cast<void**>(&f->d_bin_nb2), nb2.size() * 4) != hipSuccess)
+            {
+                gn_filter_free(f);
+                return gn_fail(GN_ENOMEM, "target map allocation failed");
+            }
+            hipMemcpy(f->d_bin_tgt, bin_tgt.data(), bin_tgt.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(f->d_bin_nb2, nb2.data(), nb2.size() * 4, hipMemcpyHostToDevice);
+        }
     }
     *out = f;
     return GN_OK;
@@ -266,6 +297,10 @@ extern "C" int gn_filter_free(gn_filter* f)
         hipFree(f->d_tgt_lds);
     if (f->d_tgt_rec)
         hipFree(f->d_tgt_rec);
+    if (f->d_bin_tgt)
+        hipFree(f->d_bin_tgt);
+    if (f->d_bin_nb2)
+        hipFree(f->d_bin_nb2);
     for (auto& i : f->ibfs)
         if (i.d_rows)
             hipFree(i.d_rows);
@@ -510,27 +545,33 @@ __global__ void gn_slot_count_kernel(const uint64_t* off1, const uint64_t* off2,
 }
 
 __global__ void gn_gather_kernel(const gn_match* __restrict__ in, gn_match* __restrict__ out, const uint64_t* __restrict__ seg_begin,
-                                 const uint32_t* __restrict__ seg_count, const uint64_t* __restrict__ seg_off, uint64_t nseg,
-                                 const unsigned long long* __restrict__ cursor, uint64_t cap)
+                                 const uint32_t* __restrict__ seg_count, const uint64_t* __restrict__ seg_off, uint64_t n_reads,
+                                 uint32_t wpr, const unsigned long long* __restrict__ cursor, uint64_t cap)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nseg || *cursor > cap) // overflowed batch: nothing was written, gn_finish() grows the buffers and re-runs
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || *cursor > cap) // overflowed batch: nothing was written, gn_finish() grows the buffers and re-runs
         return;
-    const uint32_t c = seg_count[i];
-    const uint64_t b = seg_begin[i], o = seg_off[i];
-    // copy with an insertion sort by target: the generic kernel emits ascending targets already (O(c)); the fast
-    // kernel emits ascending 64/128-bin column chunks with unordered bins inside a chunk, so an element moves
-    // left by at most one chunk's worth of matches
-    for (uint32_t j = 0; j < c; ++j)
+    // One thread per read: the segments of its column slices are copied behind each other with an insertion sort by
+    // target.  The kernels emit nearly sorted data (ascending column chunks / target ranges; the candidate-driven
+    // select emits a slice's few hits in no particular order), so an element moves left by a few places at most.
+    const uint64_t o = seg_off[r * wpr];
+    uint32_t       k_total = 0;
+    for (uint32_t sl = 0; sl < wpr; ++sl)
     {
-        const gn_match m = in[b + j];
-        uint32_t       k = j;
-        while (k > 0 && out[o + k - 1].target > m.target)
+        const uint32_t c = seg_count[r * wpr + sl];
+        const uint64_t b = seg_begin[r * wpr + sl];
+        for (uint32_t j = 0; j < c; ++j)
         {
-            out[o + k] = out[o + k - 1];
-            --k;
+            const gn_match m = in[b + j];
+            uint32_t       k = k_total;
+            while (k > 0 && out[o + k - 1].target > m.target)
+            {
+                out[o + k] = out[o + k - 1];
+                --k;
+            }
+            out[o + k] = m;
+            ++k_total;
         }
-        out[o + k] = m;
     }
 }
 
@@ -550,6 +591,9 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.tgt_bins   = f->d_tgt_bins;
     p.tgt_lds    = f->d_tgt_lds;
     p.tgt_rec    = f->d_tgt_rec;
+    p.bin_tgt    = f->d_bin_tgt;
+    p.bin_nb2    = getenv("GANON_HIP_NO_CAND_SELECT") ? nullptr : f->d_bin_nb2;
+    p.nbtab_off  = (uint32_t)f->geom.nbtab_off;
     p.tgt_ids    = nullptr;
     p.n_targets  = f->n_targets;
     p.hashes     = s->d_hashes;
@@ -610,8 +654,9 @@ static int gn_run_group(gn_stream* s)
     size_t tmp = s->scan_tmp_bytes;
     GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st));
     if (nseg)
-        hipLaunchKernelGGL(gn_gather_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, s->st, s->d_matches,
-                           s->d_sorted, s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)nseg, s->d_ctr, s->match_cap);
+        hipLaunchKernelGGL(gn_gather_kernel, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, s->st, s->d_matches,
+                           s->d_sorted, s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)s->n_reads,
+                           (uint32_t)s->f->geom.wpr, s->d_ctr, s->match_cap);
     GN_HIP(hipGetLastError());
     // exact number of matches = scan total (the cursor counts allocated space including chunk holes)
     GN_HIP(hipMemcpyAsync(s->d_ctr + 6, s->d_seg_off + nseg, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->st));

@@ -83,6 +83,11 @@ struct GnCountParams
     uint32_t                  max_blocks; // generic kernel: persistent grid size
     uint32_t                  max_blocks_fast; // fast kernel: persistent grid size
     uint32_t                  nt_loads;        // fast kernel: non-temporal row loads
+    // generic kernel, candidate-driven select (split bins): bin -> CSR target, and (bins of the bin's target, capped
+    // at 255) as u16 pairs in the layout of the LDS count area; nullptr = scan every target
+    const uint32_t*           bin_tgt;
+    const uint32_t*           bin_nb2;
+    uint32_t                  nbtab_off;       // dword offset of the LDS copy of bin_nb2
     uint32_t                  early_exit;      // fast kernel: stop fetching rows of reads that cannot reach the cutoff
     unsigned long long*       skip_ctr;        // row bytes not fetched thanks to early exits
 };
@@ -96,6 +101,7 @@ struct GnCountGeometry
     uint32_t rpb;      // reads per block
     uint32_t slice_dwords;
     size_t   lds_bytes;
+    size_t   nbtab_off;   // dword offset of the bins-per-target table inside the block's LDS (0 = it does not fit)
 };
 
 // returns false (and a message) when the IBF shape is outside what the kernel supports
@@ -152,6 +158,8 @@ struct gn_filter
     uint32_t*       d_tgt_bins = nullptr;
     uint32_t*       d_tgt_lds  = nullptr;
     uint4*          d_tgt_rec  = nullptr;
+    uint32_t*       d_bin_tgt  = nullptr; // bin -> CSR target (0xFFFFFFFF = none)
+    uint32_t*       d_bin_nb2  = nullptr; // see GnCountParams::bin_nb2
     uint32_t        n_targets  = 0;
     bool            identity   = false;
     GnCountGeometry geom{};

@@ -437,6 +437,15 @@ bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const
     const size_t tab = (size_t)(g->block / 64) * 64 * 8 * 4; // row table: 64 hashes x (up to 8 padded) u32
     const size_t stg = (size_t)(g->block / 64) * 2 * GN_STAGE_CAP * 4; // match staging
     g->lds_bytes     = cnt + tab + stg;
+    // bins-per-target table of the candidate-driven select (one byte per bin, half a read's count area), if there is
+    // room for it
+    const size_t nbt = (size_t)wpr2 * (g->slice_dwords / 2) * 4;
+    g->nbtab_off     = 0;
+    if (g->lds_bytes + nbt <= 64 * 1024)
+    {
+        g->nbtab_off = g->lds_bytes / 4;
+        g->lds_bytes += nbt;
+    }
     if (g->lds_bytes > 160 * 1024)
     {
         *why = "per-read count vector does not fit LDS";
@@ -489,6 +498,16 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
     uint32_t* cnt      = cnt_read + (size_t)slice * p.slice_dwords;     // my slice
     uint32_t* rowtab   = gn_lds + (size_t)rpb * wpr * p.slice_dwords + (size_t)wave * 64 * 8;
     uint32_t* stage    = gn_lds + (size_t)rpb * wpr * p.slice_dwords + (size_t)nwaves * 64 * 8 + (size_t)wave * 2 * GN_STAGE_CAP;
+
+    // candidate-driven select: bins-per-target table, block-resident for the whole (persistent) kernel
+    const bool      cand_ok = p.bin_nb2 != nullptr && p.nbtab_off != 0 && p.tgt_off != nullptr;
+    const uint32_t* nbt     = gn_lds + p.nbtab_off + (size_t)slice * (p.slice_dwords / 2); // my slice of it
+    if (cand_ok)
+    {
+        for (uint32_t i = threadIdx.x; i < wpr * (p.slice_dwords / 2); i += blockDim.x)
+            gn_lds[p.nbtab_off + i] = p.bin_nb2[i];
+        __syncthreads();
+    }
 
     // Work items: either every read of the batch (work_list == nullptr) or the reads the fast kernel deferred.
     // Blocks stride over rounds of rpb reads; the trip count is block-uniform, so __syncthreads() is safe.
@@ -708,12 +727,136 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
             return rec_count(p.tgt_rec[t]);
         };
 
-        // Single pass: hits are staged in a small per-wave LDS list (ascending target order) and copied to one
-        // reserved segment at the end; a read with more than GN_STAGE_CAP hits in this slice falls back to
-        // count-then-write (two passes).
+        // ---- candidate-driven select (split bins; T >= 2, n <= 255) ----
+        // A target reaches T only if one of its nb bins holds at least T/nb hits, i.e. count*nb >= T.  Every lane
+        // tests the bins it counted (its own LDS column; nb from the block-resident table, both as u16 pairs: packed
+        // multiply, packed saturating subtract), and only the few candidate bins go on to their target's record.
+        // A target is reported by the wave that owns its lowest candidate bin -- every wave evaluates that the
+        // same way, so nothing is reported twice -- with the exact sum over all its bins (any slice: the count
+        // area of the read is complete after the barrier above).  Replaces a scan over every target's 16-byte
+        // record per read (32 KB of L2 traffic per read at 2048 targets, 36 % of the kernel's time).
+        const bool use_cand = cand_ok && n != 0 && n <= 255 && T >= 2;
+        uint32_t   cand[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+            cand[d] = 0;
+        if (use_cand && col_act && hsub == 0) // one lane per LDS column
+        {
+            typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
+            const gn_u16x2 tm1 = __builtin_bit_cast(gn_u16x2, (T - 1) * 0x00010001u);
+            // count pair q = (16d + qq) sits at dword q*(Gp+1)+gl; the nb bytes of pairs 2j and 2j+1 share dword
+            // j*(Gp+1)+gl of the table
+            auto pair_ge = [&](uint32_t q, uint32_t nb4) -> uint32_t {
+                const gn_u16x2 c2  = __builtin_bit_cast(gn_u16x2, cnt[q * (Gp + 1) + gl]);
+                const uint32_t sel = (q & 1u) ? 0x0C030C02u : 0x0C010C00u; // two bytes -> two u16
+                const gn_u16x2 nb2 = __builtin_bit_cast(gn_u16x2, __builtin_amdgcn_perm(0u, nb4, sel));
+                return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(c2 * nb2, tm1)); // count*nb <= 255*255
+            };
+            uint32_t any_ge = 0; // first a cheap pass: almost every lane has no candidate at all
+            for (uint32_t j = 0; j < 8 * ND; ++j)
+            {
+                const uint32_t nb4 = nbt[j * (Gp + 1) + gl];
+                any_ge |= pair_ge(2 * j, nb4) | pair_ge(2 * j + 1, nb4);
+            }
+            if (any_ge)
+            {
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int qq = 0; qq < 16; ++qq)
+                    {
+                        const uint32_t q  = 16 * d + qq;
+                        const uint32_t ge = pair_ge(q, nbt[(q >> 1) * (Gp + 1) + gl]);
+                        m |= ((ge & 0xFFFFu) ? 1u : 0u) << (2 * qq);
+                        m |= ((ge >> 16) ? 1u : 0u) << (2 * qq + 1);
+                    }
+                    cand[d] = m;
+                }
+            }
+        }
+        // one candidate per lane and trip; `direct` = second pass of a read with more than GN_STAGE_CAP hits
+        auto cand_rounds = [&](bool direct, gn_match* out) -> uint32_t {
+            uint32_t c[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                c[d] = cand[d];
+            uint32_t tot = 0;
+            for (;;)
+            {
+                bool     have = false;
+                uint32_t tp   = 0;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    if (!have && c[d])
+                    {
+                        have = true;
+                        tp   = 32u * d + (uint32_t)__builtin_ctz(c[d]);
+                        c[d] &= c[d] - 1;
+                    }
+                if (__ballot(have) == 0)
+                    break;
+                bool     emit = false;
+                uint32_t tgt = 0, cv = 0;
+                if (have)
+                {
+                    const uint32_t b   = wi * 64 + tp;
+                    const uint32_t t   = p.bin_tgt[b];
+                    const uint4    rec = p.tgt_rec[t];
+                    const uint32_t nbc = rec.y > 255u ? 255u : rec.y;
+                    bool           lowest = true;
+                    for (uint32_t x = 0; x < rec.y; ++x) // bins of a target ascend in the CSR
+                    {
+                        if (p.tgt_bins[rec.x + x] >= b)
+                            break;
+                        const uint32_t cx = lds_count(x == 0 ? rec.z : (x == 1 ? rec.w : p.tgt_lds[rec.x + x]));
+                        if (cx * nbc >= T)
+                        {
+                            lowest = false;
+                            break;
+                        }
+                    }
+                    if (lowest)
+                    {
+                        cv   = rec_count(rec);
+                        emit = cv >= T;
+                        tgt  = p.tgt_ids ? p.tgt_ids[t] : t;
+                    }
+                }
+                const uint64_t bm = __ballot(emit);
+                if (emit)
+                {
+                    const uint32_t o = tot + __popcll(bm & ((1ULL << lane) - 1ULL));
+                    if (direct)
+                    {
+                        gn_match mt;
+                        mt.read   = read;
+                        mt.target = tgt;
+                        mt.count  = cv;
+                        out[o]    = mt;
+                    }
+                    else if (o < GN_STAGE_CAP)
+                    {
+                        stage[2 * o]     = tgt;
+                        stage[2 * o + 1] = cv;
+                    }
+                }
+                tot += (uint32_t)__popcll(bm);
+            }
+            return tot;
+        };
+
+        // Single pass: hits are staged in a small per-wave LDS list and copied to one reserved segment at the end; a
+        // read with more than GN_STAGE_CAP hits in this slice falls back to count-then-write (two passes).
         uint32_t total    = 0;
         bool     overflow = false;
-        if (n)
+        if (use_cand)
+        {
+            total    = cand_rounds(false, nullptr);
+            overflow = total > GN_STAGE_CAP;
+        }
+        else if (n && !(p.nt_loads & 4u)) // (bit 2: ablation -- skip the select scan)
             for (uint32_t t0 = t_lo; t0 < t_hi; t0 += 4 * GN_WAVE)
             {
                 // four 64-target chunks per trip: their records are fetched together so that the (L2-resident) table
@@ -792,6 +935,8 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
                     }
                     gn_wave_lds_sync();
                 }
+                else if (use_cand)
+                    (void)cand_rounds(true, p.matches + base);
                 else
                 {
                     uint32_t run = 0;

@@ -385,3 +385,71 @@ def test_early_exit_is_exact(hip, monkeypatch, bins, rows, h):
         st.destroy()
         st2.destroy()
     flt.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bins,rows,h,contiguous", [(4096, 4001, 4, True), (4096, 4001, 3, False), (1024, 9001, 4, False),
+                                                    (16384, 1501, 4, True), (16384, 1501, 2, False), (704, 9001, 5, False),
+                                                    (4096, 2001, 2, False)])
+def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, contiguous):
+    # Split-bin maps of every kind (targets of 1..300 bins, contiguous runs or scattered bins, bins of no target, rows
+    # of one to several column slices and rows narrower than a wave): the generic kernel's candidate-driven select
+    # (count*nb >= T prefilter, lowest-candidate-bin rule, staged and direct output) must give what the plain scan
+    # over every target gives, and what the oracle gives -- including reads with more hits than the staging list.
+    k, w = 19, 31
+    rng = np.random.default_rng(bins + 13 * h + contiguous)
+    sizes = []
+    left = bins - bins // 16          # a sixteenth of the bins belongs to no target
+    while left > 0:
+        s = int(rng.choice([1, 1, 2] if rows == 2001 else [1, 1, 1, 1, 2, 2, 2, 3, 4, 5, 9, 40, 300]))
+        s = min(s, left)
+        sizes.append(s)
+        left -= s
+    n_targets = len(sizes)
+    order = np.arange(bins) if contiguous else rng.permutation(bins)
+    b2t = np.full(bins, 0xFFFFFFFF, dtype=np.uint32)
+    pos = 0
+    tbins = []
+    for t, s in enumerate(sizes):
+        b2t[order[pos:pos + s]] = t
+        tbins.append(order[pos:pos + s])
+        pos += s
+    ibf = gf.random_ibf(bins, rows, h, 0.45, seed=bins + h)
+    genomes = []
+    for gi in range(60):
+        t = int(rng.integers(0, n_targets))
+        g = gu.random_seq(rng, 1500)
+        hs = np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w))
+        parts = np.array_split(hs, len(tbins[t])) if len(tbins[t]) <= 8 else np.array_split(hs, 8)
+        for pi, part in enumerate(parts):     # the genome's hashes are spread over the target's bins, like ganon-build
+            if len(part):
+                ibf.emplace_many(part, int(tbins[t][pi]))
+        genomes.append(g)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
+    reads = []
+    for i in range(1500):
+        g = genomes[i % 60]
+        p = int(rng.integers(0, 1300))
+        s = bytearray(g[p:p + 150])
+        for _ in range(i % 6):
+            q = int(rng.integers(0, 150))
+            s[q] = b"ACGT"[(b"ACGT".index(s[q]) + 1 + int(rng.integers(0, 3))) % 4]
+        reads.append(bytes(s) if i % 4 else gu.random_seq(rng, 150))
+    reads.append(g[:640])                      # a long read (n > 64: several row-table chunks)
+    for cutoff in (0.05, 0.1, 0.3, 0.75, 1.0):
+        monkeypatch.delenv("GANON_HIP_NO_CAND_SELECT", raising=False)
+        st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
+        ho, hs = st.fetch_hashes()
+        monkeypatch.setenv("GANON_HIP_NO_CAND_SELECT", "1")
+        st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
+        assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
+        per_read = np.diff(mo.astype(np.int64))
+        if cutoff == 0.1 and h == 2 and bins == 4096:
+            assert per_read.max() > 128        # the direct (count-then-write) pass of the candidate select ran
+        for i in range(0, len(reads), 4):
+            exp_m, _ = gu.oracle_matches(ibf, b2t, n_targets, hs[int(ho[i]):int(ho[i + 1])], cutoff)
+            got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+            assert got == exp_m, (cutoff, i, got[:3], exp_m[:3])
+        st.destroy()
+        st2.destroy()
+    flt.free()
