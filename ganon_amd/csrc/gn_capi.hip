@@ -206,14 +206,18 @@ extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const ui
             return gn_fail(GN_ENOMEM, "target map allocation failed");
         }
         hipMemcpy(f->d_tgt_rec, rec.data(), rec.size() * sizeof(uint4), hipMemcpyHostToDevice);
-        // candidate-driven select of the generic kernel: bin -> target, and bins-per-target of every bin (one byte,
-        // capped at 255, 0 for bins of no target); the bytes of count dwords 2j and 2j+1 (gn_count_lds_index: u16 pairs
-        // at dword q*(Gp+1)+gl) share dword j*(Gp+1)+gl of a half-sized table
-        if (geom.nbtab_off != 0)
+        // candidate-driven select of the generic kernel: bin -> target, and bins-per-target of every bin (one byte;
+        // 0 for bins of no target and of targets with more than GN_CAND_NBIG bins, which go to big_list); the bytes
+        // of count dwords 2j and 2j+1 (gn_count_lds_index: u16 pairs at dword q*(Gp+1)+gl) share dword
+        // j*(Gp+1)+gl of a half-sized table
         {
             std::vector<uint32_t> bin_tgt(ibf->bins ? ibf->bins : 1, 0xFFFFFFFFu);
             std::vector<uint32_t> nb2((size_t)geom.wpr * (geom.slice_dwords / 2), 0u);
+            std::vector<uint32_t> big;
             const uint32_t        gp1 = (1u << geom.gp_log2) + 1u;
+            for (uint32_t t = 0; t < n_targets; ++t)
+                if (off[t + 1] - off[t] > GN_CAND_NBIG)
+                    big.push_back(t);
             for (uint64_t b = 0; b < ibf->bins; ++b)
             {
                 const uint32_t t = bin2target[b];
@@ -221,21 +225,27 @@ extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const ui
                     continue;
                 bin_tgt[b]         = t;
                 const uint32_t len = off[t + 1] - off[t];
-                const uint32_t nbc = len > 255u ? 255u : len;
+                if (len > GN_CAND_NBIG)
+                    continue;
                 const uint32_t a    = gn_count_lds_index(geom, (uint32_t)b);
                 const uint32_t dw   = a >> 1, half = a & 1u; // count dword inside the read's area, u16 half
                 const uint32_t sl   = dw / geom.slice_dwords, in_sl = dw - sl * geom.slice_dwords;
                 const uint32_t q    = in_sl / gp1, g = in_sl - q * gp1;
-                nb2[(size_t)sl * (geom.slice_dwords / 2) + (q >> 1) * gp1 + g] |= nbc << (8 * (2 * (q & 1u) + half));
+                nb2[(size_t)sl * (geom.slice_dwords / 2) + (q >> 1) * gp1 + g] |= len << (8 * (2 * (q & 1u) + half));
             }
+            f->n_big = (uint32_t)big.size();
+            if (big.empty())
+                big.push_back(0);
             if (hipMalloc(reinterpret_cast<void**>(&f->d_bin_tgt), bin_tgt.size() * 4) != hipSuccess
-                || hipMalloc(reinterpret_cast<void**>(&f->d_bin_nb2), nb2.size() * 4) != hipSuccess)
+                || hipMalloc(reinterpret_cast<void**>(&f->d_bin_nb2), nb2.size() * 4) != hipSuccess
+                || hipMalloc(reinterpret_cast<void**>(&f->d_big_list), big.size() * 4) != hipSuccess)
             {
                 gn_filter_free(f);
                 return gn_fail(GN_ENOMEM, "target map allocation failed");
             }
             hipMemcpy(f->d_bin_tgt, bin_tgt.data(), bin_tgt.size() * 4, hipMemcpyHostToDevice);
             hipMemcpy(f->d_bin_nb2, nb2.data(), nb2.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(f->d_big_list, big.data(), big.size() * 4, hipMemcpyHostToDevice);
         }
     }
     *out = f;
@@ -301,6 +311,8 @@ extern "C" int gn_filter_free(gn_filter* f)
         hipFree(f->d_bin_tgt);
     if (f->d_bin_nb2)
         hipFree(f->d_bin_nb2);
+    if (f->d_big_list)
+        hipFree(f->d_big_list);
     for (auto& i : f->ibfs)
         if (i.d_rows)
             hipFree(i.d_rows);
@@ -594,6 +606,9 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.bin_tgt    = f->d_bin_tgt;
     p.bin_nb2    = getenv("GANON_HIP_NO_CAND_SELECT") ? nullptr : f->d_bin_nb2;
     p.nbtab_off  = (uint32_t)f->geom.nbtab_off;
+    p.candcnt_off = (uint32_t)f->geom.candcnt_off;
+    p.big_list   = f->d_big_list;
+    p.n_big      = f->n_big;
     p.tgt_ids    = nullptr;
     p.n_targets  = f->n_targets;
     p.hashes     = s->d_hashes;

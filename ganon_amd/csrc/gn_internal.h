@@ -10,6 +10,8 @@
 #include "../../include/ganon_hip.h"
 
 #define GN_MAX_CHUNKS 64 // pipeline chunks per batch (minimiser on the side stream || count on the main stream)
+// candidate-driven select of the generic count kernel: targets with more bins than this are scanned from a list
+#define GN_CAND_NBIG 4u
 #define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
                    // [6] exact match total [8..71] total-hashes shards
 
@@ -87,7 +89,10 @@ struct GnCountParams
     // at 255) as u16 pairs in the layout of the LDS count area; nullptr = scan every target
     const uint32_t*           bin_tgt;
     const uint32_t*           bin_nb2;
-    uint32_t                  nbtab_off;       // dword offset of the LDS copy of bin_nb2
+    uint32_t                  nbtab_off;       // dword offset of the LDS copy of bin_nb2 (0 = none)
+    uint32_t                  candcnt_off;     // dword offset of the per-wave candidate counters in LDS
+    const uint32_t*           big_list;        // targets with more than GN_CAND_NBIG bins
+    uint32_t                  n_big;
     uint32_t                  early_exit;      // fast kernel: stop fetching rows of reads that cannot reach the cutoff
     unsigned long long*       skip_ctr;        // row bytes not fetched thanks to early exits
 };
@@ -101,7 +106,8 @@ struct GnCountGeometry
     uint32_t rpb;      // reads per block
     uint32_t slice_dwords;
     size_t   lds_bytes;
-    size_t   nbtab_off;   // dword offset of the bins-per-target table inside the block's LDS (0 = it does not fit)
+    size_t   nbtab_off;   // dword offset of the bins-per-target table inside the block's LDS (0 = read it from global)
+    size_t   candcnt_off; // dword offset of the per-wave candidate counters
 };
 
 // returns false (and a message) when the IBF shape is outside what the kernel supports
@@ -160,6 +166,8 @@ struct gn_filter
     uint4*          d_tgt_rec  = nullptr;
     uint32_t*       d_bin_tgt  = nullptr; // bin -> CSR target (0xFFFFFFFF = none)
     uint32_t*       d_bin_nb2  = nullptr; // see GnCountParams::bin_nb2
+    uint32_t*       d_big_list = nullptr; // targets with more than GN_CAND_NBIG bins
+    uint32_t        n_big      = 0;
     uint32_t        n_targets  = 0;
     bool            identity   = false;
     GnCountGeometry geom{};

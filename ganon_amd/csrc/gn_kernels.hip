@@ -16,6 +16,9 @@
 #include <cstdlib>
 
 #define GN_WAVE 64
+// candidate-driven select of the generic kernel: reads with more candidate bins per wave than this keep the scan over
+// every target (GN_CAND_NBIG is in gn_internal.h)
+#define GN_CAND_LIMIT 128u
 #define GN_MATCH_CHUNK 256u
 #define GN_STAGE_CAP 128u // per-wave LDS staging of (target, count) hits in the generic select pass
 
@@ -437,15 +440,9 @@ bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const
     const size_t tab = (size_t)(g->block / 64) * 64 * 8 * 4; // row table: 64 hashes x (up to 8 padded) u32
     const size_t stg = (size_t)(g->block / 64) * 2 * GN_STAGE_CAP * 4; // match staging
     g->lds_bytes     = cnt + tab + stg;
-    // bins-per-target table of the candidate-driven select (one byte per bin, half a read's count area), if there is
-    // room for it
-    const size_t nbt = (size_t)wpr2 * (g->slice_dwords / 2) * 4;
-    g->nbtab_off     = 0;
-    if (g->lds_bytes + nbt <= 64 * 1024)
-    {
-        g->nbtab_off = g->lds_bytes / 4;
-        g->lds_bytes += nbt;
-    }
+    g->candcnt_off   = g->lds_bytes / 4; // one dword per wave: candidate bins found by the select's prefilter
+    g->lds_bytes += (size_t)(g->block / 64) * 4;
+    g->nbtab_off     = 0; // (the bins-per-target bytes live in registers)
     if (g->lds_bytes > 160 * 1024)
     {
         *why = "per-read count vector does not fit LDS";
@@ -476,7 +473,7 @@ struct GnRowRegs
 };
 
 template <int HF, int LW, int MAXT>
-__global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 256 ? 4 : (LW == 2 ? 2 : 3)))) void gn_ibf_count_kernel(GnCountParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_lds[];
     constexpr int ND  = 2 * LW;      // mask dwords per lane
@@ -499,15 +496,15 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
     uint32_t* rowtab   = gn_lds + (size_t)rpb * wpr * p.slice_dwords + (size_t)wave * 64 * 8;
     uint32_t* stage    = gn_lds + (size_t)rpb * wpr * p.slice_dwords + (size_t)nwaves * 64 * 8 + (size_t)wave * 2 * GN_STAGE_CAP;
 
-    // candidate-driven select: bins-per-target table, block-resident for the whole (persistent) kernel
-    const bool      cand_ok = p.bin_nb2 != nullptr && p.nbtab_off != 0 && p.tgt_off != nullptr;
-    const uint32_t* nbt     = gn_lds + p.nbtab_off + (size_t)slice * (p.slice_dwords / 2); // my slice of it
-    if (cand_ok)
-    {
-        for (uint32_t i = threadIdx.x; i < wpr * (p.slice_dwords / 2); i += blockDim.x)
-            gn_lds[p.nbtab_off + i] = p.bin_nb2[i];
-        __syncthreads();
-    }
+    // candidate-driven select: a persistent wave always works on the same column slice, so the bins-per-target bytes
+    // of the bins a lane counts are the same for every read -- they stay in 8*ND registers for the whole kernel
+    const bool      cand_ok = p.bin_nb2 != nullptr && p.tgt_off != nullptr;
+    const uint32_t* nbt_g   = p.bin_nb2 + (size_t)slice * (p.slice_dwords / 2);
+    uint32_t*       candcnt = gn_lds + p.candcnt_off;
+    uint32_t        nbreg[8 * ND];
+#pragma unroll
+    for (int j = 0; j < 8 * ND; ++j)
+        nbreg[j] = cand_ok ? nbt_g[j * (Gp + 1) + gl] : 0u;
 
     // Work items: either every read of the batch (work_list == nullptr) or the reads the fast kernel deferred.
     // Blocks stride over rounds of rpb reads; the trip count is block-uniform, so __syncthreads() is safe.
@@ -690,12 +687,78 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
     }
 
     // ---- select_matches: sum target bins, cap at n, cutoff, compact (GanonClassify.cpp:516-540) ----
+    // threshold_cutoff = max(1, ceil(n * rel_cutoff)) in IEEE double (:492-495,720-724)
+    uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
+    if (T == 0)
+        T = 1;
+
+    // Candidate-driven select (split-bin maps; T >= 2, n <= 255), step 1: prefilter.
+    // A target reaches T only if one of its nb bins holds at least T/nb hits, i.e. count*nb >= T.  Every lane tests
+    // the bins it counted (its own LDS column) against a bins-per-target byte table (0 for bins of no target and of
+    // targets with more than GN_CAND_NBIG bins, which are scanned from a list instead), both as u16 pairs: v_perm
+    // unpack, packed multiply, packed saturating subtract.  The candidates of all waves of the read are added up;
+    // a read with too many of them (tiny T, dense hits) keeps the plain scan over every target.
+    uint32_t cand[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+        cand[d] = 0;
+    bool use_cand = cand_ok && read < p.n_reads && n != 0 && n <= 255 && T >= 2;
+    if (cand_ok) // kernel-uniform: the barrier below is reached by every wave of the block
+    {
+        uint32_t mine = 0;
+        if (use_cand && col_act && hsub == 0 && !(p.nt_loads & 32u)) // one lane per LDS column
+        {
+            typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
+            const gn_u16x2 tm1 = __builtin_bit_cast(gn_u16x2, (T - 1) * 0x00010001u);
+            // count pair q = (16d + qq) sits at dword q*(Gp+1)+gl; the nb bytes of pairs 2j and 2j+1 share dword
+            // j*(Gp+1)+gl of the table
+            auto pair_ge = [&](uint32_t q, uint32_t nb4) -> uint32_t {
+                const gn_u16x2 c2  = __builtin_bit_cast(gn_u16x2, cnt[q * (Gp + 1) + gl]);
+                const uint32_t sel = (q & 1u) ? 0x0C030C02u : 0x0C010C00u; // two bytes -> two u16
+                const gn_u16x2 nb2 = __builtin_bit_cast(gn_u16x2, __builtin_amdgcn_perm(0u, nb4, sel));
+                return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(c2 * nb2, tm1)); // count*nb <= 255*255
+            };
+            uint32_t any_ge = 0; // first a cheap pass: almost every lane has no candidate at all
+#pragma unroll
+            for (int j = 0; j < 8 * ND; ++j)
+            {
+                any_ge |= pair_ge(2 * j, nbreg[j]) | pair_ge(2 * j + 1, nbreg[j]);
+            }
+            if (any_ge)
+            {
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                {
+                    // (taken by one lane of every read that has a true match: unrolled, everything from registers/LDS)
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int qq = 0; qq < 16; ++qq)
+                    {
+                        const uint32_t ge = pair_ge(16 * d + qq, nbreg[(16 * d + qq) >> 1]);
+                        m |= (((ge & 0xFFFFu) ? 1u : 0u) | ((ge >> 16) ? 2u : 0u)) << (2 * qq);
+                    }
+                    cand[d] = m;
+                    mine += (uint32_t)__popc(m);
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            mine += __shfl_xor(mine, off);
+        uint32_t c_read = mine;
+        if (wpr > 1) // the waves of a read must agree on which select runs
+        {
+            if (lane == 0)
+                candcnt[wave] = mine;
+            __syncthreads();
+            c_read = 0;
+            for (uint32_t sl = 0; sl < wpr; ++sl)
+                c_read += candcnt[rslot * wpr + sl];
+        }
+        use_cand = use_cand && (c_read <= GN_CAND_LIMIT * wpr || (p.nt_loads & 8u)); // (bit 3: ablation -- never fall back)
+    }
+
     if (read < p.n_reads)
     {
-        // threshold_cutoff = max(1, ceil(n * rel_cutoff)) in IEEE double (:492-495,720-724)
-        uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
-        if (T == 0)
-            T = 1;
         // targets of this wave: [t_lo, t_hi), chunk-major inside the wave so that LDS reads are conflict free
         const uint32_t per_wave = (p.n_targets + wpr - 1) / wpr;
         const uint32_t t_lo     = min(p.n_targets, slice * per_wave);
@@ -727,62 +790,59 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
             return rec_count(p.tgt_rec[t]);
         };
 
-        // ---- candidate-driven select (split bins; T >= 2, n <= 255) ----
-        // A target reaches T only if one of its nb bins holds at least T/nb hits, i.e. count*nb >= T.  Every lane
-        // tests the bins it counted (its own LDS column; nb from the block-resident table, both as u16 pairs: packed
-        // multiply, packed saturating subtract), and only the few candidate bins go on to their target's record.
-        // A target is reported by the wave that owns its lowest candidate bin -- every wave evaluates that the
-        // same way, so nothing is reported twice -- with the exact sum over all its bins (any slice: the count
-        // area of the read is complete after the barrier above).  Replaces a scan over every target's 16-byte
-        // record per read (32 KB of L2 traffic per read at 2048 targets, 36 % of the kernel's time).
-        const bool use_cand = cand_ok && n != 0 && n <= 255 && T >= 2;
-        uint32_t   cand[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-            cand[d] = 0;
-        if (use_cand && col_act && hsub == 0) // one lane per LDS column
-        {
-            typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
-            const gn_u16x2 tm1 = __builtin_bit_cast(gn_u16x2, (T - 1) * 0x00010001u);
-            // count pair q = (16d + qq) sits at dword q*(Gp+1)+gl; the nb bytes of pairs 2j and 2j+1 share dword
-            // j*(Gp+1)+gl of the table
-            auto pair_ge = [&](uint32_t q, uint32_t nb4) -> uint32_t {
-                const gn_u16x2 c2  = __builtin_bit_cast(gn_u16x2, cnt[q * (Gp + 1) + gl]);
-                const uint32_t sel = (q & 1u) ? 0x0C030C02u : 0x0C010C00u; // two bytes -> two u16
-                const gn_u16x2 nb2 = __builtin_bit_cast(gn_u16x2, __builtin_amdgcn_perm(0u, nb4, sel));
-                return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(c2 * nb2, tm1)); // count*nb <= 255*255
-            };
-            uint32_t any_ge = 0; // first a cheap pass: almost every lane has no candidate at all
-            for (uint32_t j = 0; j < 8 * ND; ++j)
+        // Candidate-driven select, step 2: only the candidate bins go on to bin -> target -> record.  A target is
+        // reported by the wave that owns its lowest candidate bin -- every wave evaluates that the same way, so
+        // nothing is reported twice -- with the exact sum over all its bins (any slice: the count area of the read
+        // is complete after the barrier above).  Replaces a scan over every target's 16-byte record per read (32 KB of
+        // L2 traffic per read at 2048 targets, 262 KB at 16384).
+        // one candidate per lane and trip; `direct` = second pass of a read with more than GN_STAGE_CAP hits
+        auto emit_hits = [&](bool emit, uint32_t tgt, uint32_t cv, uint32_t& tot, bool direct, gn_match* out) {
+            const uint64_t bm = __ballot(emit);
+            if (emit)
             {
-                const uint32_t nb4 = nbt[j * (Gp + 1) + gl];
-                any_ge |= pair_ge(2 * j, nb4) | pair_ge(2 * j + 1, nb4);
-            }
-            if (any_ge)
-            {
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
+                const uint32_t o = tot + __popcll(bm & ((1ULL << lane) - 1ULL));
+                if (direct)
                 {
-                    uint32_t m = 0;
-#pragma unroll
-                    for (int qq = 0; qq < 16; ++qq)
-                    {
-                        const uint32_t q  = 16 * d + qq;
-                        const uint32_t ge = pair_ge(q, nbt[(q >> 1) * (Gp + 1) + gl]);
-                        m |= ((ge & 0xFFFFu) ? 1u : 0u) << (2 * qq);
-                        m |= ((ge >> 16) ? 1u : 0u) << (2 * qq + 1);
-                    }
-                    cand[d] = m;
+                    gn_match mt;
+                    mt.read   = read;
+                    mt.target = tgt;
+                    mt.count  = cv;
+                    out[o]    = mt;
+                }
+                else if (o < GN_STAGE_CAP)
+                {
+                    stage[2 * o]     = tgt;
+                    stage[2 * o + 1] = cv;
                 }
             }
-        }
-        // one candidate per lane and trip; `direct` = second pass of a read with more than GN_STAGE_CAP hits
+            tot += (uint32_t)__popcll(bm);
+        };
         auto cand_rounds = [&](bool direct, gn_match* out) -> uint32_t {
             uint32_t c[ND];
 #pragma unroll
             for (int d = 0; d < ND; ++d)
                 c[d] = cand[d];
             uint32_t tot = 0;
+            // targets with more than GN_CAND_NBIG bins: their bins are no candidates (a big target collects random
+            // hits in most of its bins); this wave scans its share of the list of such targets instead
+            {
+                const uint32_t per = (p.n_big + wpr - 1) / wpr;
+                const uint32_t lo = min(p.n_big, slice * per), hi = min(p.n_big, lo + per);
+                for (uint32_t i0 = lo; i0 < hi; i0 += GN_WAVE)
+                {
+                    const uint32_t i = i0 + lane;
+                    bool           emit = false;
+                    uint32_t       tgt = 0, cv = 0;
+                    if (i < hi)
+                    {
+                        const uint32_t t = p.big_list[i];
+                        cv               = rec_count(p.tgt_rec[t]);
+                        emit             = cv >= T;
+                        tgt              = p.tgt_ids ? p.tgt_ids[t] : t;
+                    }
+                    emit_hits(emit, tgt, cv, tot, direct, out);
+                }
+            }
             for (;;)
             {
                 bool     have = false;
@@ -804,7 +864,7 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
                     const uint32_t b   = wi * 64 + tp;
                     const uint32_t t   = p.bin_tgt[b];
                     const uint4    rec = p.tgt_rec[t];
-                    const uint32_t nbc = rec.y > 255u ? 255u : rec.y;
+                    const uint32_t nbc = rec.y; // <= GN_CAND_NBIG: bins of bigger targets have a zero table entry
                     bool           lowest = true;
                     for (uint32_t x = 0; x < rec.y; ++x) // bins of a target ascend in the CSR
                     {
@@ -824,25 +884,7 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
                         tgt  = p.tgt_ids ? p.tgt_ids[t] : t;
                     }
                 }
-                const uint64_t bm = __ballot(emit);
-                if (emit)
-                {
-                    const uint32_t o = tot + __popcll(bm & ((1ULL << lane) - 1ULL));
-                    if (direct)
-                    {
-                        gn_match mt;
-                        mt.read   = read;
-                        mt.target = tgt;
-                        mt.count  = cv;
-                        out[o]    = mt;
-                    }
-                    else if (o < GN_STAGE_CAP)
-                    {
-                        stage[2 * o]     = tgt;
-                        stage[2 * o + 1] = cv;
-                    }
-                }
-                tot += (uint32_t)__popcll(bm);
+                emit_hits(emit, tgt, cv, tot, direct, out);
             }
             return tot;
         };
@@ -853,7 +895,7 @@ __global__ __launch_bounds__(MAXT) void gn_ibf_count_kernel(GnCountParams p)
         bool     overflow = false;
         if (use_cand)
         {
-            total    = cand_rounds(false, nullptr);
+            total    = (p.nt_loads & 16u) ? 0u : cand_rounds(false, nullptr);
             overflow = total > GN_STAGE_CAP;
         }
         else if (n && !(p.nt_loads & 4u)) // (bit 2: ablation -- skip the select scan)

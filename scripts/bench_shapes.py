@@ -39,3 +39,16 @@ if "split" in which:
     print(f"split (4096 bins -> 2048 targets, 1 GiB): count {t['ms_count']:.2f} ms, {t['algo_bytes']/t['ms_count']/1e6:.0f} GB/s "
           f"algorithmic, {n/t['ms_total']/1e3:.1f} Mreads/s, matches {t['n_matches']}", flush=True)
     st.destroy(); flt.free(); del wl
+if "split32k" in which:
+    # 32768 bins, every target owns 2 technical bins -> generic kernel with 4 column slices per read
+    n = 2_000_000
+    wl = bw.make_flat_workload("flat32k", 32768, 1 << 21, 4, n, seed=42)
+    b2t = (np.arange(wl.bins, dtype=np.uint32) // 2)
+    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs, b2t.tolist(), wl.bins // 2)
+    bw.plant_genomes(flt, wl)
+    st = ganon_amd.HipStream(flt, n, wl.bases.size, n * 2); st.upload(wl.bases, wl.off, None)
+    for i in range(3):
+        st.classify(wl.k, wl.w, wl.rel_cutoff); st.sync(); t = st.timings()
+    print(f"split32k (32768 bins -> 16384 targets, 8 GiB): count {t['ms_count']:.2f} ms, {t['algo_bytes']/t['ms_count']/1e6:.0f} GB/s "
+          f"algorithmic, {n/t['ms_total']/1e3:.1f} Mreads/s, matches {t['n_matches']}", flush=True)
+    st.destroy(); flt.free(); del wl
