@@ -19,6 +19,9 @@
 // candidate-driven select of the generic kernel: reads with more candidate bins per wave than this keep the scan over
 // every target (GN_CAND_NBIG is in gn_internal.h)
 #define GN_CAND_LIMIT 128u
+// fast kernel, early-exit instances: with at most this many bins left in the race the remaining hashes only fetch the
+// words that hold those bins
+#define GN_NARROW_MAX 4u
 #define GN_MATCH_CHUNK 256u
 #define GN_STAGE_CAP 128u // per-wave LDS staging of (target, count) hits in the generic select pass
 
@@ -1232,11 +1235,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
             acc_n = 0;
         }
     };
-    // true when no bin of this slice can still reach T (see above); spills the nibbles first so that the byte
-    // counters are complete.  Same cross-group sum and SWAR compare as the epilogue; the summed counts are parked in hash group 0.
-    auto cannot_match = [&](uint32_t done) -> bool {
-        const uint32_t m  = done * H < n ? done * H : n;
-        const uint32_t t  = T - (n - m); // >= 2 at every check point
+    // Survey at a check point (EE instances run with one hash group per wave, so `done` iterations = `done` hashes):
+    // which bins of this slice can still reach T?  A bin gains at most one per remaining hash, so only bins with
+    // count >= t = T - (n - done) are left in the race; their bits go to sm[] (bit = bin inside the lane's words)
+    // and their number is returned.  Same SWAR compare as the epilogue; spills the nibbles first.
+    uint32_t sm[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+        sm[d] = 0;
+    auto survey = [&](uint32_t done) -> uint32_t {
+        const uint32_t t  = T - (n - done); // >= 2 at every check point
         const uint32_t Kt = (0x80u - t) * 0x01010101u;
         if (acc_n)
         {
@@ -1247,27 +1255,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
 #pragma unroll
         for (int d = 0; d < ND; ++d)
         {
+            uint32_t m = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp)
                 {
-                    uint32_t x = byt[d][j][pp];
-                    for (uint32_t off = Gp; off < GN_WAVE; off <<= 1)
-                        x += __shfl_xor(x, (int)off);
-                    any_t |= (x + Kt) & 0x80808080u;
-                    byt[d][j][pp] = hsub == 0 ? x : 0u; // the total moves to hash group 0 (the epilogue adds the groups again)
+                    const uint32_t g = (byt[d][j][pp] + Kt) & 0x80808080u; // byte y <-> bit 8y + 4pp + j of dword d
+                    any_t |= g;
+                    m |= (g >> 7) << (4 * pp + j);
                 }
-            __builtin_amdgcn_sched_barrier(0); // eight shuffles in flight are enough; more only costs registers
+            sm[d] = m;
         }
-        return __ballot(any_t != 0) == 0;
+        if (__ballot(any_t != 0) == 0)
+            return 0u;
+        uint32_t c = 0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+            c += (uint32_t)__popc(sm[d]);
+        for (int off = 32; off > 0; off >>= 1)
+            c += __shfl_xor(c, off);
+        return c;
     };
-    bool     dead    = false;
-    uint32_t fetched = iters; // iterations whose rows were requested
+    bool     dead    = false; // no bin can reach T any more: nothing to report
+    bool     narrow  = false; // a handful of bins can: the remaining hashes only look at those (below)
+    uint32_t fetched = iters; // iterations whose full rows were requested
     {
-        // Two row-register sets in flight (A, Bq), two iterations per trip.  The early-exit check sits after the
-        // Bq half only (a second copy of it costs ~45 VGPRs and a wave of occupancy); when the first check point
-        // is odd the loop is entered at its Bq half, so that the check still falls on the right iteration.
+        // Two row-register sets in flight (A, Bq), two iterations per trip.  The check sits after the Bq half only (a
+        // second copy of it costs ~45 VGPRs and a wave of occupancy); when the first check point is odd the loop is
+        // entered at its Bq half, so that the check still falls on the right iteration.
         GnRowRegs<HF, LW> A, Bq;
         const bool odd = EE && chk1 != 0xFFFFFFFFu && (chk1 & 1u);
         int        it  = odd ? -1 : 0;
@@ -1279,9 +1295,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         {
             if (it >= 0)
             {
-                if (it + 1 < (int)iters)
+                if (it + 1 < (int)iters && !(EE && narrow))
                     issue((uint32_t)it + 1, Bq);
                 consume(A);
+                if (EE && narrow) // that was the iteration in flight when the survey decided to narrow
+                {
+                    fetched = (uint32_t)it + 1;
+                    break;
+                }
             }
             if (it + 1 < (int)iters)
             {
@@ -1289,20 +1310,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                     issue((uint32_t)it + 2, A);
                 consume(Bq);
                 const uint32_t done = (uint32_t)(it + 2);
-                if (EE && done >= chk1 && done <= chk2 && cannot_match(done))
+                if (EE && done >= chk1 && done <= chk2)
                 {
-                    dead    = true;
-                    fetched = done + 1; // the iteration in flight
-                    break;
+                    const uint32_t left = survey(done);
+                    if (left == 0)
+                    {
+                        dead    = true;
+                        fetched = done + 1; // the iteration in flight
+                        break;
+                    }
+                    if (left <= GN_NARROW_MAX && done + 2 <= iters)
+                    {
+                        narrow = true; // the next trip consumes the iteration in flight and leaves the loop
+                        continue;
+                    }
                 }
             }
         }
     }
-    if (dead && slice * 64 * LW < p.W)
+    // Narrow mode (exact): the bins that lost the race keep their stale counts (< t <= T, never reported); for each
+    // of the few that are left, the remaining hashes fetch only the 8-byte word that holds the bin -- lane l looks at
+    // (hash l / HF, row l % HF), a ballot collects the bits, the HF rows of a hash are AND-ed with shifts of the
+    // ballot -- and the hits are added to the owner lane's byte counter before the normal epilogue runs.
+    uint32_t narrow_loads = 0;
+    if (EE && narrow)
     {
-        const uint32_t got  = fetched * H < n ? fetched * H : n;
+        constexpr uint32_t QPC = GN_WAVE / HF; // hashes per pass
+        uint64_t           grp = 0;            // bit q*HF for q < QPC
+#pragma unroll
+        for (uint32_t q = 0; q < QPC; ++q)
+            grp |= 1ULL << (q * HF);
+        const uint32_t l_q = (uint32_t)lane / HF, l_i = (uint32_t)lane - l_q * HF;
+        uint32_t       any_sm = 0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+            any_sm |= sm[d];
+        uint64_t lm = __ballot(any_sm != 0);
+        while (lm)
+        {
+            const int L = __builtin_ctzll(lm);
+            lm &= lm - 1;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+            {
+                uint32_t mb = (uint32_t)__builtin_amdgcn_readlane((int)sm[d], L);
+                while (mb)
+                {
+                    const uint32_t bit = (uint32_t)__builtin_ctz(mb);
+                    mb &= mb - 1;
+                    const uint32_t tp   = 32u * d + bit;
+                    const uint32_t word = slice * 64 * LW + (uint32_t)L * LW + (tp >> 6);
+                    const uint32_t sh   = tp & 63u;
+                    uint32_t       add  = 0;
+                    for (uint32_t q0 = fetched; q0 < n; q0 += QPC)
+                    {
+                        const uint32_t q  = q0 + l_q;
+                        bool           on = false;
+                        if (l_q < QPC && q < n)
+                        {
+                            const uint32_t row = rowtab[q * HFP + l_i];
+                            on = (p.rows[(uint64_t)row * p.W + word] >> sh) & 1ULL;
+                        }
+                        const uint64_t bm  = __ballot(on);
+                        uint64_t       all = bm;
+#pragma unroll
+                        for (int i = 1; i < HF; ++i)
+                            all &= bm >> i;
+                        add += (uint32_t)__popcll(all & grp);
+                    }
+                    narrow_loads += (n - fetched) * HF;
+                    // into byte (bit >> 3) of byt[d][bit & 3][(bit >> 2) & 1] of lane L
+                    const uint32_t inc = add << (8u * (bit >> 3));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+                            if ((bit & 3u) == (uint32_t)j && ((bit >> 2) & 1u) == (uint32_t)pp && lane == L)
+                                byt[d][j][pp] += inc;
+                }
+            }
+        }
+    }
+    if ((dead || narrow) && slice * 64 * LW < p.W)
+    {
+        const uint32_t got  = fetched < n ? fetched : n;
         const uint32_t wcol = p.W - slice * 64 * LW < 64u * LW ? p.W - slice * 64 * LW : 64u * LW; // words of this slice
-        skipped_bytes += (uint64_t)(n - got) * HF * wcol * 8ull;
+        const uint64_t full = (uint64_t)(n - got) * HF * wcol * 8ull;
+        const uint64_t part = (uint64_t)narrow_loads * 64ull; // a narrow load costs a 64-byte memory access
+        skipped_bytes += full > part ? full - part : 0ull;
     }
 
     if (more) // next unit's hashes: the loads fly while this unit's epilogue runs
