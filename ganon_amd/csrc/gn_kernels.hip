@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         const uint32_t got  = fetched < n ? fetched : n;
         const uint32_t wcol = p.W - slice * 64 * LW < 64u * LW ? p.W - slice * 64 * LW : 64u * LW; // words of this slice
         const uint64_t full = (uint64_t)(n - got) * HF * wcol * 8ull;
-        const uint64_t part = (uint64_t)narrow_loads * 64ull; // a narrow load costs a 64-byte memory access
+        const uint64_t part = (uint64_t)narrow_loads * 128ull; // a narrow load fills a 128-byte L2 line (FETCH_SIZE agrees)
         skipped_bytes += full > part ? full - part : 0ull;
     }
 

@@ -17,8 +17,9 @@ KERNEL = "gn_ibf_count_fast_kernel"
 
 
 def find(sub, suffix):
-    hits = sorted(glob.glob(os.path.join(src, sub, "**", f"*{suffix}"), recursive=True))
-    return hits[0] if hits else None
+    # gpurun merges every call's files into the same local directory: take the newest one
+    hits = glob.glob(os.path.join(src, sub, "**", f"*{suffix}"), recursive=True)
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def counter_avg(path, counter):
