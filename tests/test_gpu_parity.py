@@ -270,6 +270,34 @@ def test_partition_slices_hip(hip):
         assert len(m_full) > 50 and np.array_equal(got, m_full), world
 
 
+def test_partition_exchange_over_rccl_world1(hip):
+    # The config-5 exchange step with device tensors over the nccl (= RCCL) backend.  One GPU means world size 1, so
+    # the all-to-all is degenerate, but it goes through the same RCCL calls, tensor placement and split bookkeeping
+    # that the N-GPU job uses (the N > 1 logic is covered by the gloo tests).
+    import socket
+    import torch
+    import torch.distributed as dist
+    import dist_worker as dw
+    from ganon_amd import partition as gp
+    ibf, b2t, n_targets, seqs = dw.make_case(seed=11)
+    bases, off1, _ = gu.pack_reads(seqs, None)
+    full = hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, n_targets)
+    st, nh, status, mo, m_full = _classify(hip, full, seqs, None, dw.K, dw.W, 0.25)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        part = gp.PartitionedIbf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, 0, 1, gp.hip_local_classify(0),
+                                 comm_device="cuda")
+        lo, hi, nh2, status2, mine = part.classify(bases, off1, None, dw.K, dw.W, 0.25)
+    finally:
+        dist.destroy_process_group()
+    assert (lo, hi) == (0, len(seqs)) and np.array_equal(nh2, nh)
+    assert len(m_full) > 50 and np.array_equal(mine, m_full)
+
+
 @pytest.mark.parametrize("bins,rows,h,paired", [(4096, 5003, 4, False), (4096, 5003, 4, True), (32768, 1201, 4, False),
                                                   (32768, 1201, 3, True), (8192, 2003, 5, False), (640, 3001, 2, True)])
 def test_planted_matches_many_reads(hip, bins, rows, h, paired):
