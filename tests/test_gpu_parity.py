@@ -362,7 +362,8 @@ def test_chunked_pipeline_parity(hip, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bins,rows,h", [(4096, 5003, 4), (4096, 3001, 2), (8192, 2003, 3), (32768, 1201, 4), (4032, 2003, 5)])
+@pytest.mark.parametrize("bins,rows,h", [(4096, 5003, 4), (4096, 3001, 2), (8192, 2003, 3), (32768, 1201, 4), (4032, 2003, 5),
+                                         (4096, 3001, 1), (16384, 1501, 5)])
 def test_early_exit_is_exact(hip, monkeypatch, bins, rows, h):
     # Reads whose best count lands just below / at / above the cutoff (mutated copies of planted genomes), several
     # cutoffs: the fast kernel's early exit (stop fetching rows once no bin can still reach the cutoff) must not
