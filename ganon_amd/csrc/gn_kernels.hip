@@ -476,7 +476,7 @@ struct GnRowRegs
 };
 
 template <int HF, int LW, int MAXT>
-__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 256 ? 4 : (LW == 2 ? 2 : 3)))) void gn_ibf_count_kernel(GnCountParams p)
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512 ? 4 : (LW == 2 || MAXT > 256 ? 2 : 3)))) void gn_ibf_count_kernel(GnCountParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_lds[];
     constexpr int ND  = 2 * LW;      // mask dwords per lane
@@ -1558,6 +1558,8 @@ static hipError_t gn_launch_count_hf(const GnCountParams& p, const GnCountGeomet
 {
     if (g.block <= 256)
         return g.lw == 2 ? gn_launch_count_one<HF, 2, 256>(p, g, st) : gn_launch_count_one<HF, 1, 256>(p, g, st);
+    if (g.block <= 512) // 8 waves per read: two waves per SIMD, the whole register file is available (no spills)
+        return g.lw == 2 ? gn_launch_count_one<HF, 2, 512>(p, g, st) : gn_launch_count_one<HF, 1, 512>(p, g, st);
     return g.lw == 2 ? gn_launch_count_one<HF, 2, 1024>(p, g, st) : gn_launch_count_one<HF, 1, 1024>(p, g, st);
 }
 

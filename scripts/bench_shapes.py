@@ -52,3 +52,25 @@ if "split32k" in which:
     print(f"split32k (32768 bins -> 16384 targets, 8 GiB): count {t['ms_count']:.2f} ms, {t['algo_bytes']/t['ms_count']/1e6:.0f} GB/s "
           f"algorithmic, {n/t['ms_total']/1e3:.1f} Mreads/s, matches {t['n_matches']}", flush=True)
     st.destroy(); flt.free(); del wl
+if "split40k" in which:
+    # 40960 bins (640 words per row: 5 column slices of a wave, 8 waves per read), 2 bins per target: the shape of a
+    # species-level RefSeq index
+    n = 1_000_000
+    wl = bw.make_flat_workload("flat40k", 40960, 1 << 20, 4, n, seed=42)   # 2^20 rows x 5 KiB = 5 GiB
+    b2t = (np.arange(wl.bins, dtype=np.uint32) // 2)
+    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs, b2t.tolist(), wl.bins // 2)
+    bw.plant_genomes(flt, wl)
+    st = ganon_amd.HipStream(flt, n, wl.bases.size, n * 2); st.upload(wl.bases, wl.off, None)
+    for i in range(3):
+        st.classify(wl.k, wl.w, wl.rel_cutoff); st.sync(); t = st.timings()
+    print(f"split40k (40960 bins -> 20480 targets, 5 GiB): count {t['ms_count']:.2f} ms, {t['algo_bytes']/t['ms_count']/1e6:.0f} GB/s "
+          f"algorithmic, {n/t['ms_total']/1e3:.1f} Mreads/s, matches {t['n_matches']}", flush=True)
+    st.destroy(); flt.free()
+    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs)
+    bw.plant_genomes(flt, wl)
+    st = ganon_amd.HipStream(flt, n, wl.bases.size, n * 2); st.upload(wl.bases, wl.off, None)
+    for i in range(3):
+        st.classify(wl.k, wl.w, wl.rel_cutoff); st.sync(); t = st.timings()
+    print(f"flat40k identity (fast kernel): count {t['ms_count']:.2f} ms, {t['algo_bytes']/t['ms_count']/1e6:.0f} GB/s "
+          f"algorithmic, fetched {t['fetched_bytes']/t['algo_bytes']:.3f}, {n/t['ms_total']/1e3:.1f} Mreads/s, matches {t['n_matches']}", flush=True)
+    st.destroy(); flt.free(); del wl

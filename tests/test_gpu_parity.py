@@ -419,7 +419,7 @@ def test_early_exit_is_exact(hip, monkeypatch, bins, rows, h):
 @pytest.mark.gpu
 @pytest.mark.parametrize("bins,rows,h,contiguous", [(4096, 4001, 4, True), (4096, 4001, 3, False), (1024, 9001, 4, False),
                                                     (16384, 1501, 4, True), (16384, 1501, 2, False), (704, 9001, 5, False),
-                                                    (4096, 2001, 2, False)])
+                                                    (4096, 2001, 2, False), (36864, 701, 4, True), (36864, 701, 3, False)])
 def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, contiguous):
     # Split-bin maps of every kind (targets of 1..300 bins, contiguous runs or scattered bins, bins of no target, rows
     # of one to several column slices and rows narrower than a wave): the generic kernel's candidate-driven select
