@@ -590,49 +590,42 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 
         const uint32_t iters = (mch + H - 1) / H;
 
+        // every lane issues its row loads unconditionally (see the fast kernel): lanes without a column or past the
+        // chunk's last hash read a valid word and are masked when the rows are consumed
+        const uint32_t wi_ld = col_act ? wi : 0u; // (word 0 exists in every row)
         auto issue = [&](uint32_t it, GnRowRegs<HF, LW>& R) {
-            const uint32_t q   = it * H + hsub;
-            const bool     act = col_act && q < mch;
-            if (act) // one exec-masked region: all HF row loads are issued back to back
+            uint32_t q = it * H + hsub;
+            q          = q < mch ? q : mch - 1;
+            uint32_t row[HF];
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+                row[i] = rowtab[q * HFP + i];
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
             {
-                uint32_t row[HF];
-#pragma unroll
-                for (int i = 0; i < HF; ++i)
-                    row[i] = rowtab[q * HFP + i];
-#pragma unroll
-                for (int i = 0; i < HF; ++i)
+                const uint64_t* ptr = p.rows + ((uint64_t)row[i] * p.W + wi_ld);
+                if constexpr (LW == 2)
                 {
-                    const uint64_t* ptr = p.rows + ((uint64_t)row[i] * p.W + wi);
-                    if constexpr (LW == 2)
-                    {
-                        const uint4 v = *reinterpret_cast<const uint4*>(ptr);
-                        R.m[i][0] = v.x;
-                        R.m[i][1] = v.y;
-                        R.m[i][2] = v.z;
-                        R.m[i][3] = v.w;
-                    }
-                    else
-                    {
-                        const uint2 v = *reinterpret_cast<const uint2*>(ptr);
-                        R.m[i][0] = v.x;
-                        R.m[i][1] = v.y;
-                    }
+                    const uint4 v = *reinterpret_cast<const uint4*>(ptr);
+                    R.m[i][0] = v.x;
+                    R.m[i][1] = v.y;
+                    R.m[i][2] = v.z;
+                    R.m[i][3] = v.w;
+                }
+                else
+                {
+                    const uint2 v = *reinterpret_cast<const uint2*>(ptr);
+                    R.m[i][0] = v.x;
+                    R.m[i][1] = v.y;
                 }
             }
-            else
-            {
-#pragma unroll
-                for (int i = 0; i < HF; ++i)
-#pragma unroll
-                    for (int d = 0; d < ND; ++d)
-                        R.m[i][d] = 0;
-            }
         };
-        auto consume = [&](const GnRowRegs<HF, LW>& R) {
+        auto consume = [&](const GnRowRegs<HF, LW>& R, uint32_t it) {
+            const uint32_t on = (col_act && it * H + hsub < mch) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
             for (int d = 0; d < ND; ++d)
             {
-                uint32_t a = R.m[0][d];
+                uint32_t a = R.m[0][d] & on;
 #pragma unroll
                 for (int i = 1; i < HF; ++i)
                     a &= R.m[i][d];
@@ -647,20 +640,23 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             }
         };
 
+        // straight-line double buffer: while one set is consumed the other set's loads stay in flight
         GnRowRegs<HF, LW> A, Bq;
+        uint32_t          it = 0;
         issue(0, A);
-        for (uint32_t it = 0; it < iters; it += 2)
+        for (; it + 2 < iters; it += 2)
         {
-            if (it + 1 < iters)
-                issue(it + 1, Bq);
-            consume(A);
-            if (it + 1 < iters)
-            {
-                if (it + 2 < iters)
-                    issue(it + 2, A);
-                consume(Bq);
-            }
+            issue(it + 1, Bq);
+            consume(A, it);
+            issue(it + 2, A);
+            consume(Bq, it + 1);
         }
+        const bool two = it + 1 < iters;
+        if (two)
+            issue(it + 1, Bq);
+        consume(A, it);
+        if (two)
+            consume(Bq, it + 1);
     }
     if (acc_n)
         flush_nibbles();
@@ -1177,51 +1173,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
             chk2 = p.early_exit >= 2 ? iters - 2 : c + 2;   // ... then every second iteration up to chk2
         }
     }
+    // Row loads are issued by every lane, unconditionally (lanes without a column or past the last hash read a valid
+    // word and are masked when the rows are consumed): with the loads inside an exec-masked region the compiler
+    // cannot know how many are outstanding behind the set it waits for and falls back to s_waitcnt vmcnt(0) -- which
+    // turned the double buffer into "issue two iterations, wait for both, consume both".
+    const uint32_t wi_ld = col_act ? wi : 0u; // a word that exists in every row
     auto issue = [&](uint32_t it, GnRowRegs<HF, LW>& R) {
-        const uint32_t q   = it * H + hsub;
-        const bool     act = col_act && q < n;
-        if (act)
+        uint32_t q = it * H + hsub;
+        q          = q < n ? q : n - 1;
+        uint32_t row[HF];
+#pragma unroll
+        for (int i = 0; i < HF; ++i)
+            row[i] = rowtab[q * HFP + i];
+#pragma unroll
+        for (int i = 0; i < HF; ++i)
         {
-            uint32_t row[HF];
-#pragma unroll
-            for (int i = 0; i < HF; ++i)
-                row[i] = rowtab[q * HFP + i];
-#pragma unroll
-            for (int i = 0; i < HF; ++i)
+            const uint64_t* ptr = p.rows + ((uint64_t)row[i] * p.W + wi_ld);
+            if constexpr (LW == 2)
             {
-                const uint64_t* ptr = p.rows + ((uint64_t)row[i] * p.W + wi);
-                if constexpr (LW == 2)
-                {
-                    typedef uint32_t gn_u32x4 __attribute__((ext_vector_type(4)));
-                    const gn_u32x4* p4 = reinterpret_cast<const gn_u32x4*>(ptr);
-                    const gn_u32x4  v  = p.nt_loads ? __builtin_nontemporal_load(p4) : *p4; // rows are read once: optional nt hint
-                    R.m[i][0] = v.x;
-                    R.m[i][1] = v.y;
-                    R.m[i][2] = v.z;
-                    R.m[i][3] = v.w;
-                }
-                else
-                {
-                    const uint2 v = *reinterpret_cast<const uint2*>(ptr);
-                    R.m[i][0] = v.x;
-                    R.m[i][1] = v.y;
-                }
+                typedef uint32_t gn_u32x4 __attribute__((ext_vector_type(4)));
+                const gn_u32x4* p4 = reinterpret_cast<const gn_u32x4*>(ptr);
+                const gn_u32x4  v  = p.nt_loads ? __builtin_nontemporal_load(p4) : *p4; // rows are read once: optional nt hint
+                R.m[i][0] = v.x;
+                R.m[i][1] = v.y;
+                R.m[i][2] = v.z;
+                R.m[i][3] = v.w;
+            }
+            else
+            {
+                const uint2 v = *reinterpret_cast<const uint2*>(ptr);
+                R.m[i][0] = v.x;
+                R.m[i][1] = v.y;
             }
         }
-        else
-        {
-#pragma unroll
-            for (int i = 0; i < HF; ++i)
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-                    R.m[i][d] = 0;
-        }
     };
-    auto consume = [&](const GnRowRegs<HF, LW>& R) {
+    auto consume = [&](const GnRowRegs<HF, LW>& R, uint32_t it) {
+        const uint32_t on = (col_act && it * H + hsub < n) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
         {
-            uint32_t a = R.m[0][d];
+            uint32_t a = R.m[0][d] & on;
 #pragma unroll
             for (int i = 1; i < HF; ++i)
                 a &= R.m[i][d];
@@ -1281,36 +1272,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     bool     narrow  = false; // a handful of bins can: the remaining hashes only look at those (below)
     uint32_t fetched = iters; // iterations whose full rows were requested
     {
-        // Two row-register sets in flight (A, Bq), two iterations per trip.  The check sits after the Bq half only (a
-        // second copy of it costs ~45 VGPRs and a wave of occupancy); when the first check point is odd the loop is
-        // entered at its Bq half, so that the check still falls on the right iteration.
+        // Two row-register sets (A, Bq), two iterations per trip, straight-line: while set X is consumed the other
+        // set's four loads stay in flight (s_waitcnt vmcnt(HF)).  Invariant at the top of a trip and after the loop:
+        // A holds iteration `it`, in flight.  The survey sits after the second half (check points are even when a
+        // wave is one hash group, and only those instances check).
         GnRowRegs<HF, LW> A, Bq;
-        const bool odd = EE && chk1 != 0xFFFFFFFFu && (chk1 & 1u);
-        int        it  = odd ? -1 : 0;
-        if (odd)
-            issue(0, Bq);
-        else
-            issue(0, A);
-        for (; it < (int)iters; it += 2)
+        uint32_t          it = 0;
+        issue(0, A);
+        for (; it + 2 < iters; it += 2)
         {
-            if (it >= 0)
+            if (EE && narrow)
+                break;
+            issue(it + 1, Bq);
+            consume(A, it);
+            issue(it + 2, A);
+            consume(Bq, it + 1);
+            if constexpr (EE)
             {
-                if (it + 1 < (int)iters && !(EE && narrow))
-                    issue((uint32_t)it + 1, Bq);
-                consume(A);
-                if (EE && narrow) // that was the iteration in flight when the survey decided to narrow
-                {
-                    fetched = (uint32_t)it + 1;
-                    break;
-                }
-            }
-            if (it + 1 < (int)iters)
-            {
-                if (it + 2 < (int)iters)
-                    issue((uint32_t)it + 2, A);
-                consume(Bq);
-                const uint32_t done = (uint32_t)(it + 2);
-                if (EE && done >= chk1 && done <= chk2)
+                const uint32_t done = it + 2;
+                if (done >= chk1 && done <= chk2)
                 {
                     const uint32_t left = survey(done);
                     if (left == 0)
@@ -1319,13 +1299,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                         fetched = done + 1; // the iteration in flight
                         break;
                     }
-                    if (left <= GN_NARROW_MAX && done + 2 <= iters)
-                    {
-                        narrow = true; // the next trip consumes the iteration in flight and leaves the loop
-                        continue;
-                    }
+                    if (left <= GN_NARROW_MAX)
+                        narrow = true; // A (iteration `done`) is consumed below, then the narrow pass takes over
                 }
             }
+        }
+        if (!dead)
+        {
+            const bool two = !(EE && narrow) && it + 1 < iters; // the last one or two iterations
+            if (two)
+                issue(it + 1, Bq);
+            consume(A, it);
+            if (two)
+                consume(Bq, it + 1);
+            if (EE && narrow)
+                fetched = it + 1;
         }
     }
     // Narrow mode (exact): the bins that lost the race keep their stale counts (< t <= T, never reported); for each
