@@ -108,11 +108,12 @@ __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams 
         const uint32_t   o   = (uint32_t)(sa & 3u);
         const uint32_t*  dws = reinterpret_cast<const uint32_t*>(sa & ~(uintptr_t)3);
         const uint32_t   ndw = Leff ? (o + Leff + 3) / 4 : 0; // dwords this lane may touch
-        auto load4 = [&](uint32_t q) -> gn_u32x4u { // dwords q..q+3 (zeros past the lane's own range)
-            gn_u32x4u v = { 0u, 0u, 0u, 0u };
-            if (q < ndw)
-                v = *reinterpret_cast<const gn_u32x4u*>(dws + q);
-            return v;
+        // dwords q..q+3, loaded unconditionally (a load inside an exec-masked region makes the compiler wait with
+        // vmcnt(0), i.e. for the prefetches too): past the lane's own range the index is clamped -- those bytes are never
+        // looked at, and the base buffer carries 64 bytes of padding for the last read
+        auto load4 = [&](uint32_t q) -> gn_u32x4u {
+            const uint32_t qc = q < ndw ? q : (ndw ? ndw - 1 : 0u);
+            return *reinterpret_cast<const gn_u32x4u*>(dws + qc);
         };
         gn_u32x4u cur4 = load4(0), nxt4 = load4(4);
 
