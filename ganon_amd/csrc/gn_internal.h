@@ -65,7 +65,7 @@ struct GnCountParams
     uint32_t        read_begin; // first read of the range this launch covers
     double          rel_cutoff;
     // geometry (host-chosen, see gn_count_geometry)
-    uint32_t wpr;      // waves cooperating on one read (power of two)
+    uint32_t wpr;      // waves cooperating on one read = column slices of a row (1..16)
     uint32_t gp_log2;  // lanes per hash group = 1 << gp_log2
     uint32_t slice_dwords; // LDS dwords of one wave's count slice = 32*LW*(Gp+1)
     // output

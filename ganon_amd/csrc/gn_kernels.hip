@@ -418,11 +418,11 @@ bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const
         if ((atoi(e) == 1) || (atoi(e) == 2 && W % 2 == 0))
             g->lw = (uint32_t)atoi(e);
     const uint64_t per_wv = 64ull * g->lw; // words per wave slice
-    uint64_t       wpr    = (W + per_wv - 1) / per_wv;
-    uint32_t       wpr2   = 1;
-    while (wpr2 < wpr)
-        wpr2 <<= 1;
-    if (wpr2 > 16)
+    // waves per read = column slices of the row, exactly (rounding up to a power of two left 3 of 8 waves -- and
+    // their LDS -- idle on a 640-word row)
+    const uint64_t wpr    = (W + per_wv - 1) / per_wv;
+    const uint32_t wpr2   = (uint32_t)wpr;
+    if (wpr > 16)
     {
         *why = "rows wider than 16 wave slices (bins > 131072 for even bin_words) are not supported by the flat "
                "count kernel yet; partition the filter by bin range";
@@ -436,8 +436,8 @@ bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const
     while ((1u << gp_log2) < lanes)
         ++gp_log2;
     g->gp_log2       = gp_log2;
-    g->block         = wpr2 * 64 > 256 ? wpr2 * 64 : 256;
-    g->rpb           = (g->block / 64) / wpr2;
+    g->rpb           = wpr2 >= 4 ? 1u : 4u / wpr2; // reads per block: about four waves, whole reads only
+    g->block         = g->rpb * wpr2 * 64;
     g->slice_dwords  = 32 * g->lw * ((1u << gp_log2) + 1);
     const size_t cnt = (size_t)g->rpb * wpr2 * g->slice_dwords * 4;
     const size_t tab = (size_t)(g->block / 64) * 64 * 8 * 4; // row table: 64 hashes x (up to 8 padded) u32

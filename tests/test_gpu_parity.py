@@ -299,7 +299,8 @@ def test_partition_exchange_over_rccl_world1(hip):
 
 
 @pytest.mark.parametrize("bins,rows,h,paired", [(4096, 5003, 4, False), (4096, 5003, 4, True), (32768, 1201, 4, False),
-                                                  (32768, 1201, 3, True), (8192, 2003, 5, False), (640, 3001, 2, True)])
+                                                  (32768, 1201, 3, True), (8192, 2003, 5, False), (640, 3001, 2, True),
+                                                  (20480, 1201, 4, False), (36864, 701, 3, True)])
 def test_planted_matches_many_reads(hip, bins, rows, h, paired):
     # thousands of reads per launch (persistent waves loop over many reads), true matches with counts up to n
     # (> 15: the 4-bit first-level counters must spill correctly), single and paired (n ~ 35) reads
@@ -363,7 +364,7 @@ def test_chunked_pipeline_parity(hip, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("bins,rows,h", [(4096, 5003, 4), (4096, 3001, 2), (8192, 2003, 3), (32768, 1201, 4), (4032, 2003, 5),
-                                         (4096, 3001, 1), (16384, 1501, 5)])
+                                         (4096, 3001, 1), (16384, 1501, 5), (20480, 1201, 4), (36864, 701, 4)])
 def test_early_exit_is_exact(hip, monkeypatch, bins, rows, h):
     # Reads whose best count lands just below / at / above the cutoff (mutated copies of planted genomes), several
     # cutoffs: the fast kernel's early exit (stop fetching rows once no bin can still reach the cutoff) must not
@@ -419,7 +420,8 @@ def test_early_exit_is_exact(hip, monkeypatch, bins, rows, h):
 @pytest.mark.gpu
 @pytest.mark.parametrize("bins,rows,h,contiguous", [(4096, 4001, 4, True), (4096, 4001, 3, False), (1024, 9001, 4, False),
                                                     (16384, 1501, 4, True), (16384, 1501, 2, False), (704, 9001, 5, False),
-                                                    (4096, 2001, 2, False), (36864, 701, 4, True), (36864, 701, 3, False)])
+                                                    (4096, 2001, 2, False), (36864, 701, 4, True), (36864, 701, 3, False),
+                                                    (20480, 1201, 4, False)])
 def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, contiguous):
     # Split-bin maps of every kind (targets of 1..300 bins, contiguous runs or scattered bins, bins of no target, rows
     # of one to several column slices and rows narrower than a wave): the generic kernel's candidate-driven select
