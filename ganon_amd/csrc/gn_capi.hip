@@ -246,6 +246,34 @@ extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const ui
             hipMemcpy(f->d_bin_tgt, bin_tgt.data(), bin_tgt.size() * 4, hipMemcpyHostToDevice);
             hipMemcpy(f->d_bin_nb2, nb2.data(), nb2.size() * 4, hipMemcpyHostToDevice);
             hipMemcpy(f->d_big_list, big.data(), big.size() * 4, hipMemcpyHostToDevice);
+            // split kernel (register counters + byte image): the same bytes in the layout of the byte counters --
+            // register r = (d*4+j)*2+pp of lane l at [(slice*8*nd + r)*64 + l], byte y <-> bit 8y + 4pp + j of dword d
+            const size_t split_lds = gn_split_lds_bytes(geom, ibf->hash_funs);
+            if (geom.gp_log2 == 6 && split_lds <= 160u * 1024u)
+            {
+                const uint32_t        lw = geom.lw, nd = 2u * lw;
+                std::vector<uint32_t> nbr((size_t)geom.wpr * 8u * nd * 64u, 0u);
+                for (uint64_t b = 0; b < ibf->bins; ++b)
+                {
+                    const uint32_t t = bin2target[b];
+                    if (t == 0xFFFFFFFFu)
+                        continue;
+                    const uint32_t len = off[t + 1] - off[t];
+                    if (len > GN_CAND_NBIG)
+                        continue;
+                    const uint32_t word = (uint32_t)(b >> 6), sl = word / (64u * lw), wrel = word - sl * 64u * lw, lane = wrel / lw;
+                    const uint32_t tp = (wrel - lane * lw) * 64u + (uint32_t)(b & 63u), d = tp >> 5, bit = tp & 31u;
+                    const uint32_t r  = (d * 4u + (bit & 3u)) * 2u + ((bit >> 2) & 1u);
+                    nbr[((size_t)sl * 8u * nd + r) * 64u + lane] |= len << (8u * (bit >> 3));
+                }
+                if (hipMalloc(reinterpret_cast<void**>(&f->d_sl_nbr), nbr.size() * 4) != hipSuccess)
+                {
+                    gn_filter_free(f);
+                    return gn_fail(GN_ENOMEM, "target map allocation failed");
+                }
+                hipMemcpy(f->d_sl_nbr, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice);
+                f->split_bpc = (uint32_t)((160u * 1024u) / split_lds);
+            }
         }
     }
     *out = f;
@@ -313,6 +341,8 @@ extern "C" int gn_filter_free(gn_filter* f)
         hipFree(f->d_bin_nb2);
     if (f->d_big_list)
         hipFree(f->d_big_list);
+    if (f->d_sl_nbr)
+        hipFree(f->d_sl_nbr);
     for (auto& i : f->ibfs)
         if (i.d_rows)
             hipFree(i.d_rows);
@@ -635,6 +665,21 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.skip_ctr   = s->d_ctr + 7;
     if (lo == 0) // (a re-run after a match-buffer regrow starts the tally again)
         GN_HIP(hipMemsetAsync(s->d_ctr + 7, 0, sizeof(unsigned long long), s->st));
+    p.sl_nbr = f->d_sl_nbr;
+    const bool split = !f->identity && f->d_sl_nbr != nullptr && !getenv("GANON_HIP_NO_SPLIT_KERNEL");
+    if (split)
+    {
+        // split-bin maps: register counters + byte image for reads with <= 127 minimisers, the rest lands in d_deferred
+        GN_HIP(hipMemsetAsync(s->d_ctr + 4, 0, sizeof(unsigned long long), s->st));
+        p.work_list_out  = s->d_deferred;
+        p.work_count_out = s->d_ctr + 4;
+        const uint32_t keep = p.max_blocks;
+        p.max_blocks        = (uint32_t)f->n_cu * (f->split_bpc ? f->split_bpc : 1u) * 2u;
+        GN_HIP(gn_launch_count_split(p, f->geom, f->ibf.h, s->st));
+        p.max_blocks = keep;
+        p.work_list  = s->d_deferred;
+        p.work_count = s->d_ctr + 4;
+    }
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
     if (fast)
     {

@@ -93,6 +93,7 @@ struct GnCountParams
     uint32_t                  candcnt_off;     // dword offset of the per-wave candidate counters in LDS
     const uint32_t*           big_list;        // targets with more than GN_CAND_NBIG bins
     uint32_t                  n_big;
+    const uint32_t*           sl_nbr;          // split kernel: bins-per-target bytes in the layout of the byte counters
     uint32_t                  early_exit;      // fast kernel: stop fetching rows of reads that cannot reach the cutoff
     unsigned long long*       skip_ctr;        // row bytes not fetched thanks to early exits
 };
@@ -118,6 +119,9 @@ uint32_t gn_count_lds_index(const GnCountGeometry& g, uint32_t b);
 hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t st);
 hipError_t gn_launch_count(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
 hipError_t gn_launch_count_fast(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
+// split-bin maps, reads with <= 127 minimisers, rows of at least one wave (gn_split.hip)
+hipError_t gn_launch_count_split(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
+size_t     gn_split_lds_bytes(const GnCountGeometry& g, uint32_t hash_funs);
 
 // ---- HIBF -----------------------------------------------------------------------------------
 struct GnHibfIbfDev
@@ -168,6 +172,8 @@ struct gn_filter
     uint32_t*       d_bin_nb2  = nullptr; // see GnCountParams::bin_nb2
     uint32_t*       d_big_list = nullptr; // targets with more than GN_CAND_NBIG bins
     uint32_t        n_big      = 0;
+    uint32_t*       d_sl_nbr   = nullptr; // split kernel (GnCountParams::sl_nbr); nullptr = not applicable
+    uint32_t        split_bpc  = 0;       // split kernel: resident blocks per CU
     uint32_t        n_targets  = 0;
     bool            identity   = false;
     GnCountGeometry geom{};

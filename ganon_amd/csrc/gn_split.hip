@@ -1,0 +1,486 @@
+// gn_split.hip -- count + select for split-bin maps (a target owns several technical bins, GanonClassify.cpp:516-540),
+// reads with at most 127 minimisers, rows of at least one full wave (one hash per wave iteration).
+//
+// The generic kernel (gn_kernels.hip) keeps the 16-bit counters of a whole read in LDS -- 2 bytes per bin, flushed
+// from the nibble registers with LDS atomics and zeroed for every read -- which on wide rows leaves room for one block
+// per CU.  Here the counters stay in registers exactly as in the fast kernel (4-bit SWAR, spilled into 8-bit SWAR),
+// and LDS only ever holds a byte image of them, written when the read has a candidate at all:
+//   1. prefilter in registers: a target with nb bins reaches T only through a bin with count*nb >= T; the bins-per-
+//      target bytes of the bins a lane counts are the same for every read of a persistent wave (8*ND registers, in the
+//      layout of the byte counters); targets with more than GN_CAND_NBIG bins have byte 0 and are scanned from a list
+//   2. the waves of a read add up their candidates (block barrier); no candidate and no big target -> done
+//   3. otherwise every wave of the read stores its byte image, and the candidate bins go on to
+//      bin -> target -> CSR of bins: a target is reported by the wave that owns its lowest candidate bin, with the exact
+//      sum over all its bins (any slice); reads with more candidates than the budget scan every target instead
+// Reads with more minimisers are handed to the generic kernel through the work list.
+#include "gn_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#define GN_WAVE 64
+#define GN_SPLIT_STAGE 128u
+#define GN_SPLIT_LIMIT 128u // candidates per wave beyond which the read scans every target
+#define GN_SPLIT_CHUNK 256u
+
+namespace
+{
+
+__device__ __forceinline__ void gn_sp_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint64_t gn_sp_readlane64(uint64_t v, uint32_t l)
+{
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// IBF row of hash v for hash function i (seqan3 hash_and_fit) -- same as gn_kernels.hip
+__device__ __forceinline__ uint32_t gn_sp_row(uint64_t v, uint32_t i, uint32_t shift, uint64_t S)
+{
+    constexpr uint64_t seeds[5] = { 13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL,
+                                    16499269484942379435ULL, 4893150838803335377ULL };
+    uint64_t x = v * seeds[i];
+    x ^= x >> shift;
+    x *= 11400714819323198485ULL;
+    return (uint32_t)__umul64hi(x, S);
+}
+
+template <int HF, int LW>
+struct GnSpRows
+{
+    uint32_t m[HF][2 * LW];
+};
+
+} // namespace
+
+template <int HF, int LW, int MAXT>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512 ? 4 : (LW == 2 || MAXT > 256 ? 2 : 3)))) void gn_ibf_count_split_kernel(GnCountParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t gn_sp_lds[];
+    constexpr int      ND   = 2 * LW;
+    constexpr int      HFP  = HF <= 4 ? 4 : 8;
+    constexpr uint32_t NMAX = 127;
+    constexpr uint32_t IMG  = 8 * ND * 64; // dwords of one wave's byte image
+
+    const int      lane   = threadIdx.x & (GN_WAVE - 1);
+    const int      wave   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint32_t wpr    = p.wpr;
+    const uint32_t rpb    = nwaves / wpr;
+    const uint32_t rslot  = wave / wpr;
+    const uint32_t slice  = wave % wpr;
+
+    uint32_t* img_read = gn_sp_lds + (size_t)rslot * wpr * IMG; // byte images of all slices of my read
+    uint32_t* img      = img_read + (size_t)slice * IMG;
+    uint32_t* rowtab   = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)wave * 128 * HFP;
+    uint32_t* stage    = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)nwaves * 128 * HFP + (size_t)wave * 2 * GN_SPLIT_STAGE;
+    uint32_t* candcnt  = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)nwaves * (128 * HFP + 2 * GN_SPLIT_STAGE);
+
+    const uint32_t wi      = slice * 64 * LW + lane * LW; // first word of this lane in the row
+    const bool     col_act = wi < p.W;
+    const uint32_t wi_ld   = col_act ? wi : 0u;
+
+    // bins-per-target bytes of my bins, in the layout of the byte counters (register r = (d*4+j)*2+pp, byte y <-> bit
+    // 8y + 4pp + j of dword d)
+    uint32_t nbreg[8 * ND];
+#pragma unroll
+    for (int r = 0; r < 8 * ND; ++r)
+        nbreg[r] = p.sl_nbr[((size_t)slice * 8 * ND + r) * 64 + lane];
+
+    const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads - p.read_begin;
+    unsigned long long chunk_base = 0;
+    uint32_t           chunk_left = 0;
+    for (uint32_t round0 = blockIdx.x * rpb; round0 < n_work; round0 += gridDim.x * rpb)
+    {
+        const uint32_t widx = round0 + rslot;
+        const uint32_t read = widx < n_work ? (p.work_list ? p.work_list[widx] : p.read_begin + widx) : 0xFFFFFFFFu;
+        uint32_t       n    = 0;
+        if (read < p.n_reads && p.status[read] == GN_READ_OK)
+            n = p.n_hashes[read];
+        if (n > NMAX) // the generic kernel takes it
+        {
+            if (slice == 0 && lane == 0)
+                p.work_list_out[atomicAdd(p.work_count_out, 1ULL)] = read;
+            n = 0;
+        }
+        const uint64_t* hs = p.hashes + (n ? p.slot_off[read] : 0);
+
+        // ---- row table of the read, then one hash per iteration ----
+        gn_sp_wave_sync();
+        for (uint32_t idx = lane; idx < n * HF; idx += GN_WAVE)
+        {
+            const uint32_t q = idx / HF, i = idx - q * HF;
+            rowtab[q * HFP + i] = gn_sp_row(hs[q], i, p.shift, p.S);
+        }
+        gn_sp_wave_sync();
+
+        uint32_t nib[ND][4];
+        uint32_t byt[ND][4][2];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                nib[d][j]    = 0;
+                byt[d][j][0] = 0;
+                byt[d][j][1] = 0;
+            }
+        uint32_t acc_n = 0;
+        auto spill_nibbles = [&]() {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    byt[d][j][0] += nib[d][j] & 0x0F0F0F0Fu;
+                    byt[d][j][1] += (nib[d][j] >> 4) & 0x0F0F0F0Fu;
+                    nib[d][j] = 0;
+                }
+        };
+        auto issue = [&](uint32_t q, GnSpRows<HF, LW>& R) { // unconditional loads (see the fast kernel)
+            q = q < n ? q : (n ? n - 1 : 0u);
+            uint32_t row[HF];
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+                row[i] = rowtab[q * HFP + i];
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+            {
+                const uint64_t* ptr = p.rows + ((uint64_t)row[i] * p.W + wi_ld);
+                if constexpr (LW == 2)
+                {
+                    const uint4 v = *reinterpret_cast<const uint4*>(ptr);
+                    R.m[i][0] = v.x;
+                    R.m[i][1] = v.y;
+                    R.m[i][2] = v.z;
+                    R.m[i][3] = v.w;
+                }
+                else
+                {
+                    const uint2 v = *reinterpret_cast<const uint2*>(ptr);
+                    R.m[i][0] = v.x;
+                    R.m[i][1] = v.y;
+                }
+            }
+        };
+        auto consume = [&](const GnSpRows<HF, LW>& R, uint32_t q) {
+            const uint32_t on = (col_act && q < n) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+            {
+                uint32_t a = R.m[0][d] & on;
+#pragma unroll
+                for (int i = 1; i < HF; ++i)
+                    a &= R.m[i][d];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    nib[d][j] += (a >> j) & 0x11111111u;
+            }
+            if (++acc_n == 15)
+            {
+                spill_nibbles();
+                acc_n = 0;
+            }
+        };
+        if (n) // wave-uniform
+        {
+            GnSpRows<HF, LW> A, Bq;
+            uint32_t         it = 0;
+            issue(0, A);
+            for (; it + 2 < n; it += 2)
+            {
+                issue(it + 1, Bq);
+                consume(A, it);
+                issue(it + 2, A);
+                consume(Bq, it + 1);
+            }
+            const bool two = it + 1 < n;
+            if (two)
+                issue(it + 1, Bq);
+            consume(A, it);
+            if (two)
+                consume(Bq, it + 1);
+            if (acc_n)
+                spill_nibbles();
+        }
+
+        // threshold_cutoff = max(1, ceil(n * rel_cutoff)) in IEEE double (:492-495,720-724)
+        uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
+        if (T == 0)
+            T = 1;
+
+        // ---- 1. prefilter in registers: bins with count * nb >= T ----
+        uint32_t sm[ND];
+        uint32_t mine = 0;
+        {
+            typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
+            const gn_u16x2 tm1 = __builtin_bit_cast(gn_u16x2, (T - 1) * 0x00010001u);
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+            {
+                uint32_t m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                    {
+                        const uint32_t x  = byt[d][j][pp];
+                        const uint32_t nb = nbreg[(d * 4 + j) * 2 + pp];
+                        // bytes (0,1) and (2,3) as u16 pairs: count * nb <= 127 * 255
+                        const gn_u16x2 lo = __builtin_bit_cast(gn_u16x2, __builtin_amdgcn_perm(0u, x, 0x0C010C00u))
+                                            * __builtin_bit_cast(gn_u16x2, __builtin_amdgcn_perm(0u, nb, 0x0C010C00u));
+                        const gn_u16x2 hi = __builtin_bit_cast(gn_u16x2, __builtin_amdgcn_perm(0u, x, 0x0C030C02u))
+                                            * __builtin_bit_cast(gn_u16x2, __builtin_amdgcn_perm(0u, nb, 0x0C030C02u));
+                        const uint32_t gl_ = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(lo, tm1));
+                        const uint32_t gh_ = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(hi, tm1));
+                        const uint32_t g   = ((gl_ & 0xFFFFu) ? 1u : 0u) | ((gl_ >> 16) ? 0x100u : 0u)
+                                           | ((gh_ & 0xFFFFu) ? 0x10000u : 0u) | ((gh_ >> 16) ? 0x1000000u : 0u); // bit 8y
+                        m |= g << (4 * pp + j);
+                    }
+                sm[d] = n ? m : 0u;
+                mine += (uint32_t)__popc(sm[d]);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            mine += __shfl_xor(mine, off);
+
+        // ---- 2. the waves of a read agree: anything to do, and which select ----
+        if (lane == 0)
+            candcnt[wave] = mine;
+        __syncthreads();
+        uint32_t c_read = 0;
+        for (uint32_t sl = 0; sl < wpr; ++sl)
+            c_read += candcnt[rslot * wpr + sl];
+        const bool work     = n != 0 && (c_read != 0 || p.n_big != 0);
+        const bool scan_all = c_read > GN_SPLIT_LIMIT * wpr;
+
+        // ---- 3. byte image, then the select ----
+        if (work)
+        {
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                        img[((d * 4 + j) * 2 + pp) * 64 + lane] = byt[d][j][pp];
+        }
+        __syncthreads();
+
+        uint32_t           total = 0;
+        unsigned long long base  = 0;
+        if (work)
+        {
+            auto cnt_of = [&](uint32_t bin) -> uint32_t {
+                const uint32_t word = bin >> 6, sl = word / (64 * LW), wrel = word - sl * 64 * LW, ln = wrel / LW;
+                const uint32_t tp = (wrel - ln * LW) * 64 + (bin & 63u), d = tp >> 5, bit = tp & 31u;
+                return (img_read[(size_t)sl * IMG + ((d * 4 + (bit & 3u)) * 2 + ((bit >> 2) & 1u)) * 64 + ln] >> (8u * (bit >> 3))) & 0xFFu;
+            };
+            auto target_sum = [&](const uint4& rec) -> uint32_t { // {first CSR entry, bins, ., .}
+                uint32_t s = 0;
+                for (uint32_t x = 0; x < rec.y; ++x)
+                    s += cnt_of(p.tgt_bins[rec.x + x]);
+                return s > n ? n : s; // :525-526
+            };
+            auto emit_hits = [&](bool emit, uint32_t tgt, uint32_t cv, uint32_t& tot, bool direct, gn_match* out) {
+                const uint64_t bm = __ballot(emit);
+                if (emit)
+                {
+                    const uint32_t o = tot + __popcll(bm & ((1ULL << lane) - 1ULL));
+                    if (direct)
+                    {
+                        gn_match mt;
+                        mt.read   = read;
+                        mt.target = tgt;
+                        mt.count  = cv;
+                        out[o]    = mt;
+                    }
+                    else if (o < GN_SPLIT_STAGE)
+                    {
+                        stage[2 * o]     = tgt;
+                        stage[2 * o + 1] = cv;
+                    }
+                }
+                tot += (uint32_t)__popcll(bm);
+            };
+            // `direct` = second pass of a (read, slice) with more hits than the staging list holds
+            auto select = [&](bool direct, gn_match* out) -> uint32_t {
+                uint32_t tot = 0;
+                if (scan_all)
+                {
+                    // too many candidates (tiny T, dense hits): every target, this wave takes its share
+                    const uint32_t per = (p.n_targets + wpr - 1) / wpr;
+                    const uint32_t lo = min(p.n_targets, slice * per), hi = min(p.n_targets, lo + per);
+                    for (uint32_t t0 = lo; t0 < hi; t0 += GN_WAVE)
+                    {
+                        const uint32_t t    = t0 + lane;
+                        bool           emit = false;
+                        uint32_t       cv   = 0;
+                        if (t < hi)
+                        {
+                            cv   = target_sum(p.tgt_rec[t]);
+                            emit = cv >= T;
+                        }
+                        emit_hits(emit, t, cv, tot, direct, out);
+                    }
+                    return tot;
+                }
+                // targets with more than GN_CAND_NBIG bins: this wave's share of the list
+                {
+                    const uint32_t per = (p.n_big + wpr - 1) / wpr;
+                    const uint32_t lo = min(p.n_big, slice * per), hi = min(p.n_big, lo + per);
+                    for (uint32_t i0 = lo; i0 < hi; i0 += GN_WAVE)
+                    {
+                        const uint32_t i    = i0 + lane;
+                        bool           emit = false;
+                        uint32_t       tgt = 0, cv = 0;
+                        if (i < hi)
+                        {
+                            tgt  = p.big_list[i];
+                            cv   = target_sum(p.tgt_rec[tgt]);
+                            emit = cv >= T;
+                        }
+                        emit_hits(emit, tgt, cv, tot, direct, out);
+                    }
+                }
+                // candidate bins, one per lane and trip; a target is reported by its lowest candidate bin
+                uint32_t c[ND];
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    c[d] = sm[d];
+                for (;;)
+                {
+                    bool     have = false;
+                    uint32_t tp   = 0;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        if (!have && c[d])
+                        {
+                            have = true;
+                            tp   = 32u * d + (uint32_t)__builtin_ctz(c[d]);
+                            c[d] &= c[d] - 1;
+                        }
+                    if (__ballot(have) == 0)
+                        break;
+                    bool     emit = false;
+                    uint32_t tgt = 0, cv = 0;
+                    if (have)
+                    {
+                        const uint32_t b   = wi * 64 + tp;
+                        const uint32_t t   = p.bin_tgt[b];
+                        const uint4    rec = p.tgt_rec[t];
+                        bool           lowest = true;
+                        for (uint32_t x = 0; x < rec.y; ++x) // bins of a target ascend in the CSR
+                        {
+                            const uint32_t bx = p.tgt_bins[rec.x + x];
+                            if (bx >= b)
+                                break;
+                            if (cnt_of(bx) * rec.y >= T)
+                            {
+                                lowest = false;
+                                break;
+                            }
+                        }
+                        if (lowest)
+                        {
+                            cv   = target_sum(rec);
+                            emit = cv >= T;
+                            tgt  = t;
+                        }
+                    }
+                    emit_hits(emit, tgt, cv, tot, direct, out);
+                }
+                return tot;
+            };
+
+            total = select(false, nullptr);
+            if (total)
+            {
+                if (total > chunk_left)
+                {
+                    const uint32_t need = total > GN_SPLIT_CHUNK ? total : GN_SPLIT_CHUNK;
+                    unsigned long long nb = 0;
+                    if (lane == 0)
+                        nb = atomicAdd(p.cursor, (unsigned long long)need);
+                    chunk_base = gn_sp_readlane64(nb, 0);
+                    chunk_left = need;
+                }
+                base = chunk_base;
+                chunk_base += total;
+                chunk_left -= total;
+                if (base + total <= p.match_cap)
+                {
+                    if (total <= GN_SPLIT_STAGE)
+                    {
+                        gn_sp_wave_sync();
+                        for (uint32_t o = lane; o < total; o += GN_WAVE)
+                        {
+                            gn_match mt;
+                            mt.read   = read;
+                            mt.target = stage[2 * o];
+                            mt.count  = stage[2 * o + 1];
+                            p.matches[base + o] = mt;
+                        }
+                    }
+                    else
+                        (void)select(true, p.matches + base);
+                }
+            }
+        }
+        if (read < p.n_reads && lane == 0)
+        {
+            p.seg_begin[(size_t)read * wpr + slice] = base;
+            p.seg_count[(size_t)read * wpr + slice] = total;
+        }
+        __syncthreads(); // the next round reuses the images, the hit lists and the candidate counters
+    }
+}
+
+size_t gn_split_lds_bytes(const GnCountGeometry& g, uint32_t hash_funs)
+{
+    const uint32_t nd = 2 * g.lw, hfp = hash_funs <= 4 ? 4 : 8, nwaves = g.block / 64;
+    return ((size_t)g.rpb * g.wpr * 8 * nd * 64 + (size_t)nwaves * (128 * hfp + 2 * GN_SPLIT_STAGE) + nwaves) * 4;
+}
+
+template <int HF, int LW, int MAXT>
+static hipError_t gn_launch_split_one(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
+{
+    uint32_t blocks = (p.n_reads - p.read_begin + g.rpb - 1) / g.rpb;
+    if (blocks > p.max_blocks)
+        blocks = p.max_blocks;
+    const size_t lds = gn_split_lds_bytes(g, HF);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_ibf_count_split_kernel<HF, LW, MAXT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gn_ibf_count_split_kernel<HF, LW, MAXT>), dim3(blocks), dim3(g.block), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int HF>
+static hipError_t gn_launch_split_hf(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
+{
+    if (g.block <= 256)
+        return g.lw == 2 ? gn_launch_split_one<HF, 2, 256>(p, g, st) : gn_launch_split_one<HF, 1, 256>(p, g, st);
+    if (g.block <= 512)
+        return g.lw == 2 ? gn_launch_split_one<HF, 2, 512>(p, g, st) : gn_launch_split_one<HF, 1, 512>(p, g, st);
+    return g.lw == 2 ? gn_launch_split_one<HF, 2, 1024>(p, g, st) : gn_launch_split_one<HF, 1, 1024>(p, g, st);
+}
+
+hipError_t gn_launch_count_split(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st)
+{
+    if (p.n_reads <= p.read_begin)
+        return hipSuccess;
+    switch (hash_funs)
+    {
+        case 1: return gn_launch_split_hf<1>(p, g, st);
+        case 2: return gn_launch_split_hf<2>(p, g, st);
+        case 3: return gn_launch_split_hf<3>(p, g, st);
+        case 4: return gn_launch_split_hf<4>(p, g, st);
+        case 5: return gn_launch_split_hf<5>(p, g, st);
+        default: return hipErrorInvalidValue;
+    }
+}

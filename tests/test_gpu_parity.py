@@ -471,8 +471,15 @@ def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, c
         monkeypatch.delenv("GANON_HIP_NO_CAND_SELECT", raising=False)
         st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
         ho, hs = st.fetch_hashes()
+        # default = split kernel (register counters, byte image) for reads of up to 127 minimisers; without it the
+        # generic kernel's candidate select; without that the plain scan over every target
+        monkeypatch.setenv("GANON_HIP_NO_SPLIT_KERNEL", "1")
+        st3, nh3, status3, mo3, m3 = _classify(hip, flt, reads, None, k, w, cutoff)
+        assert np.array_equal(mo, mo3) and np.array_equal(m, m3), cutoff
+        st3.destroy()
         monkeypatch.setenv("GANON_HIP_NO_CAND_SELECT", "1")
         st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
+        monkeypatch.delenv("GANON_HIP_NO_SPLIT_KERNEL", raising=False)
         assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
         per_read = np.diff(mo.astype(np.int64))
         if cutoff == 0.1 and h == 2 and bins == 4096:
