@@ -472,6 +472,88 @@ void finalize_batch(ReadBatch& rb, std::vector<uint8_t>& bases2)
     bases2.clear();
 }
 
+// Second file of a pair, parsed on its own thread (for gzip input the reader is inflate-bound: two files, two inflate
+// streams).  Only sequences are kept (ids come from file 1, :1243-1252); records arrive in blocks through a bounded
+// queue; a parse error is delivered in place, after the records that precede it.
+class MateStream
+{
+public:
+    // the file is opened here, on the caller's thread: a file that cannot be opened fails before any record is read
+    explicit MateStream(const std::string& path) : q_(8), in_(new SeqReader(path)), worker_([this] { run(); }) {}
+    ~MateStream()
+    {
+        stop_ = true;
+        Block b;
+        while (q_.pop(b)) {} // unblock the producer
+        worker_.join();
+    }
+    // appends the next mate to `bases`; false at end of file; throws the file's ParseError where it occurred
+    bool next(std::vector<uint8_t>& bases)
+    {
+        while (pos_ == cur_.off.size() - 1)
+        {
+            if (cur_.last)
+            {
+                if (!cur_.error.empty())
+                {
+                    std::string e;
+                    e.swap(cur_.error);
+                    throw ParseError(e);
+                }
+                return false;
+            }
+            if (!q_.pop(cur_))
+                return false;
+            pos_ = 0;
+        }
+        bases.insert(bases.end(), cur_.bases.begin() + cur_.off[pos_], cur_.bases.begin() + cur_.off[pos_ + 1]);
+        ++pos_;
+        return true;
+    }
+
+private:
+    struct Block
+    {
+        std::vector<uint8_t>  bases;
+        std::vector<uint64_t> off{ 0 };
+        bool                  last = false;
+        std::string           error; // with last: the ParseError that ended the file
+    };
+    void run()
+    {
+        Block b;
+        try
+        {
+            std::string id;
+            while (!stop_)
+            {
+                id.clear();
+                if (!in_->next(id, b.bases))
+                    break;
+                b.off.push_back(b.bases.size());
+                if (b.off.size() > 65536 || b.bases.size() >= (16u << 20))
+                {
+                    q_.push(std::move(b));
+                    b = Block();
+                }
+            }
+        }
+        catch (ParseError const& e)
+        {
+            b.error = e.what();
+        }
+        b.last = true;
+        q_.push(std::move(b));
+        q_.done();
+    }
+    BoundedQueue<Block>        q_;
+    std::atomic<bool>          stop_{ false };
+    Block                      cur_;
+    size_t                     pos_ = 0;
+    std::unique_ptr<SeqReader> in_;
+    std::thread                worker_; // last member: everything above exists when it starts
+};
+
 void parse_reads(BatchQueue& queue, Stats& stats, std::mutex& stats_mutex, const TReadConfig& reads_config)
 {
     for (auto const& [prefix, files] : reads_config)
@@ -512,21 +594,19 @@ void parse_reads(BatchQueue& queue, Stats& stats, std::mutex& stats_mutex, const
             fresh();
             try
             {
-                SeqReader                  fin1(filename1);
-                std::unique_ptr<SeqReader> fin2;
+                SeqReader                   fin1(filename1);
+                std::unique_ptr<MateStream> fin2;
                 if (paired)
-                    fin2.reset(new SeqReader(filename2));
-                std::string id2; // ids come from file 1; file 2 only contributes sequences (:1243-1252)
+                    fin2.reset(new MateStream(filename2));
                 while (fin1.next(rb.id_buf, rb.bases))
                 {
                     rb.id_off.push_back(rb.id_buf.size());
                     rb.off1.push_back(rb.bases.size());
                     if (paired)
                     {
-                        id2.clear();
                         try
                         {
-                            fin2->next(id2, bases2); // at EOF the mate stays empty
+                            fin2->next(bases2); // at EOF the mate stays empty
                         }
                         catch (ParseError const&)
                         {

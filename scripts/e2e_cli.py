@@ -61,3 +61,15 @@ dt = time.time() - t0
 print("rc", p.returncode, f"wall {dt:.2f}s")
 print("\n".join(l for l in p.stderr.splitlines() if "elapsed" in l or "host timing" in l or "processed" in l or "classified" in l or "ERROR" in l))
 print("all lines:", sum(1 for _ in open(f"{d}/out.all")), open(f"{d}/out.rep").read().splitlines()[-2:])
+
+# ---- gzip input: one file, and the same file as both mates (inflate-bound reader)
+if os.environ.get("E2E_GZ"):
+    subprocess.run(["gzip", "-1", "-k", "-f", f"{d}/reads.fq"], check=True)
+    for label, args in (("single gz", ["--single-reads", f"{d}/reads.fq.gz"]),
+                        ("paired gz", ["--paired-reads", f"{d}/reads.fq.gz,{d}/reads.fq.gz"])):
+        t0 = time.time()
+        p = subprocess.run([os.path.join(ROOT, "ganon_amd/host/ganon-classify"), "--ibf", f"{d}/db.ibf", *args, "-o", f"{d}/outz",
+                            "--output-all", "--rel-cutoff", "0.75", "--verbose"], capture_output=True, text=True,
+                           env=dict(os.environ, GANON_HOST_TIMING="1"))
+        print(label, "rc", p.returncode, f"wall {time.time()-t0:.2f}s")
+        print("\n".join(l for l in p.stderr.splitlines() if "host timing" in l or "processed" in l or "ERROR" in l))
