@@ -4,6 +4,14 @@
 #include <tmmintrin.h>
 #include <zlib.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <thread>
+
 #include <algorithm>
 #include <cstring>
 #include <string_view>
@@ -74,10 +82,208 @@ bool all_legal(const char* p, size_t n)
 }
 } // namespace
 
+// ---- BGZF (blocked gzip: bgzip, Illumina bcl2fastq/BCL Convert) ---------------------------------------------------
+// A BGZF file is a series of gzip members of at most 64 KiB, each with a 'BC' extra subfield that holds its compressed
+// size and a trailer that holds its inflated size -- so the members can be found without decoding and inflated
+// independently.  A producer thread reads a batch of members, helper threads inflate them straight into one output
+// buffer at the offsets the trailers give, and the parser consumes the buffers in order.  Plain gzip (one long
+// deflate stream) cannot be split this way and keeps going through gzread().
+class BgzfSource
+{
+public:
+    // nullptr when the file is not BGZF
+    static std::unique_ptr<BgzfSource> open(const std::string& path)
+    {
+        FILE* f = std::fopen(path.c_str(), "rb");
+        if (!f)
+            return nullptr;
+        unsigned char h[18];
+        const bool    ok = std::fread(h, 1, 18, f) == 18 && member_size(h) != 0;
+        if (!ok)
+        {
+            std::fclose(f);
+            return nullptr;
+        }
+        std::fseek(f, 0, SEEK_SET);
+        return std::unique_ptr<BgzfSource>(new BgzfSource(f));
+    }
+    ~BgzfSource()
+    {
+        stop_ = true;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            q_.clear();
+            cv_space_.notify_all();
+        }
+        producer_.join();
+        std::fclose(f_);
+    }
+    // up to n bytes; 0 at end of file; throws ParseError on a damaged file
+    size_t read(char* dst, size_t n)
+    {
+        size_t got = 0;
+        while (got < n)
+        {
+            if (pos_ == cur_.size())
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_data_.wait(lk, [&] { return !q_.empty() || done_; });
+                if (q_.empty())
+                {
+                    if (!error_.empty())
+                        throw ParseError(error_);
+                    break;
+                }
+                cur_ = std::move(q_.front());
+                q_.pop_front();
+                pos_ = 0;
+                cv_space_.notify_one();
+                continue;
+            }
+            const size_t k = std::min(n - got, cur_.size() - pos_);
+            std::memcpy(dst + got, cur_.data() + pos_, k);
+            got += k;
+            pos_ += k;
+        }
+        return got;
+    }
+
+private:
+    explicit BgzfSource(FILE* f) : f_(f), producer_([this] { produce(); }) {}
+
+    // total size of the gzip member whose first 18 bytes are h, 0 if it is not a BGZF member
+    static size_t member_size(const unsigned char* h)
+    {
+        if (h[0] != 0x1F || h[1] != 0x8B || h[2] != 8 || !(h[3] & 4))
+            return 0;
+        const unsigned xlen = h[10] | (h[11] << 8);
+        if (xlen < 6 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0)
+            return 0; // (bgzip always writes BC as the first and only subfield)
+        return (size_t)(h[16] | (h[17] << 8)) + 1;
+    }
+
+    void fail(const std::string& msg)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        error_ = msg;
+    }
+
+    void produce()
+    {
+        const unsigned T = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        struct Member
+        {
+            size_t in_off, in_len, out_off, out_len;
+        };
+        std::vector<unsigned char> in;
+        bool                       eof = false;
+        while (!stop_ && !eof)
+        {
+            // a batch: members until ~16 MiB of output
+            in.clear();
+            std::vector<Member> mem;
+            size_t              out_total = 0;
+            while (out_total < (16u << 20))
+            {
+                unsigned char h[18];
+                const size_t  r = std::fread(h, 1, 18, f_);
+                if (r == 0)
+                {
+                    eof = true;
+                    break;
+                }
+                const size_t sz = r == 18 ? member_size(h) : 0;
+                if (sz < 18 + 8)
+                {
+                    fail(" damaged BGZF member header");
+                    eof = true;
+                    break;
+                }
+                const size_t at = in.size();
+                in.resize(at + sz);
+                std::memcpy(in.data() + at, h, 18);
+                if (std::fread(in.data() + at + 18, 1, sz - 18, f_) != sz - 18)
+                {
+                    fail(" truncated BGZF member");
+                    in.resize(at);
+                    eof = true;
+                    break;
+                }
+                const unsigned char* t     = in.data() + at + sz - 4;
+                const size_t         isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+                mem.push_back(Member{ at, sz, out_total, isize });
+                out_total += isize;
+            }
+            if (mem.empty())
+                break;
+            std::vector<char> out(out_total);
+            std::atomic<size_t> next{ 0 };
+            std::atomic<bool>   bad{ false };
+            auto work = [&] {
+                z_stream z;
+                for (size_t i = next++; i < mem.size() && !bad; i = next++)
+                {
+                    const Member& m = mem[i];
+                    if (m.out_len == 0) // (the empty end-of-file member)
+                        continue;
+                    std::memset(&z, 0, sizeof(z));
+                    const unsigned xlen = in[m.in_off + 10] | (in[m.in_off + 11] << 8);
+                    const size_t   hdr  = 12 + xlen;
+                    if (hdr + 8 > m.in_len || inflateInit2(&z, -15) != Z_OK)
+                    {
+                        bad = true;
+                        break;
+                    }
+                    z.next_in   = in.data() + m.in_off + hdr;
+                    z.avail_in  = (uInt)(m.in_len - hdr - 8);
+                    z.next_out  = reinterpret_cast<Bytef*>(out.data() + m.out_off);
+                    z.avail_out = (uInt)m.out_len;
+                    const int rc = inflate(&z, Z_FINISH);
+                    if (rc != Z_STREAM_END || z.total_out != m.out_len)
+                        bad = true;
+                    inflateEnd(&z);
+                }
+            };
+            std::vector<std::thread> helpers;
+            for (unsigned t = 1; t < T && t < mem.size(); ++t)
+                helpers.emplace_back(work);
+            work();
+            for (auto& th : helpers)
+                th.join();
+            if (bad)
+            {
+                fail(" damaged BGZF member (inflate failed)");
+                break;
+            }
+            std::unique_lock<std::mutex> lk(m_);
+            cv_space_.wait(lk, [&] { return q_.size() < 4 || stop_; });
+            if (stop_)
+                break;
+            q_.push_back(std::move(out));
+            cv_data_.notify_one();
+        }
+        std::lock_guard<std::mutex> lk(m_);
+        done_ = true;
+        cv_data_.notify_all();
+    }
+
+    FILE*                         f_;
+    std::mutex                    m_;
+    std::condition_variable       cv_data_, cv_space_;
+    std::deque<std::vector<char>> q_;
+    bool                          done_ = false;
+    std::string                   error_;
+    std::atomic<bool>             stop_{ false };
+    std::vector<char>             cur_;
+    size_t                        pos_ = 0;
+    std::thread                   producer_; // last member
+};
+
 struct SeqReader::Impl
 {
-    gzFile            gz = nullptr;
-    std::string       path;
+    gzFile                      gz = nullptr;
+    std::unique_ptr<BgzfSource> bgzf; // set instead of gz for blocked gzip
+    std::string                 path;
     bool              fastq = false;
     std::vector<char> buf;
     size_t            pos = 0, len = 0;
@@ -98,7 +304,8 @@ struct SeqReader::Impl
         }
         if (len == buf.size())
             buf.resize(buf.size() * 2); // a single line longer than the buffer
-        const int n = gzread(gz, buf.data() + len, (unsigned)std::min<size_t>(buf.size() - len, 1u << 30));
+        const size_t want = std::min<size_t>(buf.size() - len, 1u << 30);
+        const int    n    = bgzf ? (int)bgzf->read(buf.data() + len, want) : gzread(gz, buf.data() + len, (unsigned)want);
         if (n < 0)
         {
             int         err = 0;
@@ -181,11 +388,15 @@ SeqReader::SeqReader(const std::string& path) : impl_(new Impl)
             known = true;
     if (!known)
         throw ParseError(" unknown sequence file extension (expected FASTA or FASTQ, optionally gzipped)");
+    impl_->buf.resize(4 << 20);
+    if (!std::getenv("GANON_HOST_NO_BGZF"))
+        impl_->bgzf = BgzfSource::open(path); // blocked gzip: members inflated in parallel
+    if (impl_->bgzf)
+        return;
     impl_->gz = gzopen(path.c_str(), "rb"); // transparently reads uncompressed files too
     if (!impl_->gz)
         throw ParseError(" cannot open file");
     gzbuffer(impl_->gz, 1 << 20);
-    impl_->buf.resize(4 << 20);
 }
 
 SeqReader::~SeqReader()

@@ -26,6 +26,21 @@ def _write(path, text, nl="\n", gz=False):
             f.write(data)
 
 
+def _write_bgzf(path, text, block=20000):
+    """blocked gzip as bgzip / Illumina converters write it: independent members with a 'BC' extra field, empty
+    end-of-file member"""
+    import struct, zlib
+    data = text.encode()
+    with open(path, "wb") as f:
+        for lo in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if lo is None else data[lo:lo + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = co.compress(chunk) + co.flush()
+            bsize = 12 + 6 + len(comp) + 8 - 1
+            f.write(struct.pack("<4BI2BH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6) + struct.pack("<2BHH", ord("B"), ord("C"), 2, bsize))
+            f.write(comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
 def _fastq(recs, wrap=None):
     out = []
     for rid, s in recs:
@@ -55,6 +70,8 @@ def _variants(d, r1):
     _write(os.path.join(d, "c.fq"), "\n\n" + _fastq(r1, wrap=60)); v["wrapped_fastq"] = "c.fq"
     _write(os.path.join(d, "d.fa"), _fasta(r1, 70, lower=True)); v["fasta_lower"] = "d.fa"
     _write(os.path.join(d, "e.fasta.gz"), _fasta(r1, 10_000), gz=True); v["fasta_gz"] = "e.fasta.gz"
+    _write_bgzf(os.path.join(d, "g.fq.gz"), _fastq(r1), block=1500); v["fastq_bgzf"] = "g.fq.gz"   # members inflated in parallel
+    _write_bgzf(os.path.join(d, "h.fastq.bgzf"), _fastq(r1, wrap=60), block=64000); v["fastq_bgzf_wrapped"] = "h.fastq.bgzf"
     spaced = "".join(f">{rid}\n{_wrap(s, 33).replace(chr(10), ' ' + chr(10))} \n" for rid, s in r1)  # blanks inside sequences
     _write(os.path.join(d, "f.fna"), spaced, nl="\r\n"); v["fasta_crlf_spaces"] = "f.fna"
     return v
@@ -117,6 +134,15 @@ def _check_errors(binary, sim_db, tmp):
     _run(binary, sim_db, ["--paired-reads", good1 + "," + s2], p)
     r = cu.Res(p)
     assert r.total_classified + r.total_unclassified == 10
+    # (4b) blocked gzip with a damaged member: error reported, nothing after the damage is used
+    bz = os.path.join(tmp, "dmg.fq.gz")
+    _write_bgzf(bz, _fastq(r1), block=700)
+    raw = bytearray(open(bz, "rb").read())
+    raw[len(raw) // 2] ^= 0xFF
+    open(bz, "wb").write(bytes(raw))
+    p = os.path.join(tmp, "dmg")
+    res = _run(binary, sim_db, ["--single-reads", bz], p)
+    assert "Error parsing file" in res.stderr
     # (5) unknown extension
     u = os.path.join(tmp, "reads.txt")
     _write(u, _fastq(r1))
