@@ -455,6 +455,9 @@ def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, c
         for pi, part in enumerate(parts):     # the genome's hashes are spread over the target's bins, like ganon-build
             if len(part):
                 ibf.emplace_many(part, int(tbins[t][pi]))
+        if gi % 5 == 0:                        # ... and some are in every bin of their target: one hash then hits several
+            for b in tbins[t][:8]:             # bins of the target, the sum passes n and is capped (:525-526)
+                ibf.emplace_many(hs, int(b))
         genomes.append(g)
     flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
     reads = []
@@ -482,6 +485,9 @@ def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, c
         monkeypatch.delenv("GANON_HIP_NO_SPLIT_KERNEL", raising=False)
         assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
         per_read = np.diff(mo.astype(np.int64))
+        assert (m["count"] <= nh[m["read"]]).all()
+        if cutoff == 1.0:
+            assert (m["count"] == nh[m["read"]]).all() and len(m) > 100   # capped sums are reported as n
         if cutoff == 0.1 and h == 2 and bins == 4096:
             assert per_read.max() > 128        # the direct (count-then-write) pass of the candidate select ran
         for i in range(0, len(reads), 4):
