@@ -683,7 +683,7 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
     if (fast)
     {
-        // register-resident fast path for reads with <= 30 minimisers; the rest lands in d_deferred
+        // register-resident fast path for reads with <= 127 minimisers; the rest lands in d_deferred
         GN_HIP(hipMemsetAsync(s->d_ctr + 4, 0, sizeof(unsigned long long), s->st));
         p.work_list_out  = s->d_deferred;
         p.work_count_out = s->d_ctr + 4;
