@@ -1169,8 +1169,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
             c = 1;
         if (c + 2 <= iters)
         {
-            chk1 = c;                                        // first check ...
-            chk2 = p.early_exit >= 2 ? iters - 2 : c + 2;   // ... then every second iteration up to chk2
+            chk1 = p.early_exit == 3 ? c : (c > 1 ? c - 1 : c); // first check (one hash before the half-way bound) ...
+            chk2 = p.early_exit >= 2 && p.early_exit != 3 ? iters - 2 : c + 2; // ... then every iteration up to chk2
         }
     }
     // Row loads are issued by every lane, unconditionally (lanes without a column or past the last hash read a valid
@@ -1277,7 +1277,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         // A holds iteration `it`, in flight.  The survey sits after the second half (check points are even when a
         // wave is one hash group, and only those instances check).
         GnRowRegs<HF, LW> A, Bq;
-        uint32_t          it = 0;
+        uint32_t          it      = 0;
+        bool              drained = false; // a check on an odd iteration consumed everything that was in flight
         issue(0, A);
         for (; it + 2 < iters; it += 2)
         {
@@ -1285,6 +1286,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                 break;
             issue(it + 1, Bq);
             consume(A, it);
+            if constexpr (EE)
+            {
+                const uint32_t done = it + 1; // odd check points: Bq (iteration `done`) is in flight
+                if (done >= chk1 && done <= chk2)
+                {
+                    const uint32_t left = survey(done);
+                    if (left == 0)
+                    {
+                        dead    = true;
+                        fetched = done + 1;
+                        break;
+                    }
+                    if (left <= GN_NARROW_MAX)
+                    {
+                        consume(Bq, it + 1);
+                        narrow  = true;
+                        fetched = it + 2;
+                        drained = true;
+                        break;
+                    }
+                }
+            }
             issue(it + 2, A);
             consume(Bq, it + 1);
             if constexpr (EE)
@@ -1304,7 +1327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                 }
             }
         }
-        if (!dead)
+        if (!dead && !drained)
         {
             const bool two = !(EE && narrow) && it + 1 < iters; // the last one or two iterations
             if (two)
