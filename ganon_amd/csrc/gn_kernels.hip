@@ -1298,8 +1298,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                         fetched = done + 1;
                         break;
                     }
-                    if (left <= GN_NARROW_MAX)
+                    if (left <= GN_NARROW_MAX && (done > chk1 || (p.early_exit & 4u)))
                     {
+                        // (not at the very first check: a stray bin that happens to be ahead there is cheaper to wait
+                        // out for one more iteration than to follow for the rest of the read)
                         consume(Bq, it + 1);
                         narrow  = true;
                         fetched = it + 2;
