@@ -1234,14 +1234,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
 #pragma unroll
     for (int d = 0; d < ND; ++d)
         sm[d] = 0;
-    auto survey = [&](uint32_t done) -> uint32_t {
-        const uint32_t t  = T - (n - done); // >= 2 at every check point
-        const uint32_t Kt = (0x80u - t) * 0x01010101u;
-        if (acc_n)
-        {
-            spill_nibbles();
-            acc_n = 0;
-        }
+    // bins with count >= tval (1 <= tval <= 127; the byte counters must be complete) -> sm[], their number is returned
+    auto survivors = [&](uint32_t tval) -> uint32_t {
+        const uint32_t Kt = (0x80u - tval) * 0x01010101u;
         uint32_t any_t = 0;
 #pragma unroll
         for (int d = 0; d < ND; ++d)
@@ -1267,6 +1262,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         for (int off = 32; off > 0; off >>= 1)
             c += __shfl_xor(c, off);
         return c;
+    };
+    auto survey = [&](uint32_t done) -> uint32_t {
+        if (acc_n)
+        {
+            spill_nibbles();
+            acc_n = 0;
+        }
+        return survivors(T - (n - done)); // >= 1 at every check point
     };
     bool     dead    = false; // no bin can reach T any more: nothing to report
     bool     narrow  = false; // a handful of bins can: the remaining hashes only look at those (below)
@@ -1298,10 +1301,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                         fetched = done + 1;
                         break;
                     }
-                    if (left <= GN_NARROW_MAX && (done > chk1 || (p.early_exit & 4u)))
+                    // At the very first check a stray bin that happens to be ahead is cheaper to wait out for one
+                    // more iteration than to follow for the rest of the read: narrow there only when every survivor
+                    // has been hit by (nearly) every hash so far, as a true match has.
+                    if (left <= GN_NARROW_MAX && (done > chk1 || (done > 2 && survivors(done - 1) == left)))
                     {
-                        // (not at the very first check: a stray bin that happens to be ahead there is cheaper to wait
-                        // out for one more iteration than to follow for the rest of the read)
                         consume(Bq, it + 1);
                         narrow  = true;
                         fetched = it + 2;
