@@ -21,7 +21,9 @@
 #define GN_CAND_LIMIT 128u
 // fast kernel, early-exit instances: with at most this many bins left in the race the remaining hashes only fetch the
 // words that hold those bins
+#ifndef GN_NARROW_MAX
 #define GN_NARROW_MAX 4u
+#endif
 #define GN_MATCH_CHUNK 256u
 #define GN_STAGE_CAP 128u // per-wave LDS staging of (target, count) hits in the generic select pass
 
