@@ -104,6 +104,7 @@ def _check_errors(binary, sim_db, tmp):
     _write(good1, _fastq(r1[:10])); _write(good2, _fastq(r2[:10]))
     p_ref = os.path.join(tmp, "ref")
     _run(binary, sim_db, ["--paired-reads", good1 + "," + good2], p_ref)
+    _write(os.path.join(tmp, "full1.fq"), _fastq(r1))
     # (1) illegal letter in record 11 of file 1 -> error reported, 10 records kept
     bad = list(r1)
     bad[10] = (bad[10][0], bad[10][1][:50] + "!" + bad[10][1][51:])
@@ -134,6 +135,17 @@ def _check_errors(binary, sim_db, tmp):
     _run(binary, sim_db, ["--paired-reads", good1 + "," + s2], p)
     r = cu.Res(p)
     assert r.total_classified + r.total_unclassified == 10
+    # (4a) illegal letter in record 11 of the MATES file (parsed on its own thread): the error arrives in place --
+    # ten complete pairs, the eleventh read keeps an empty mate, nothing after it
+    badm = list(r2)
+    badm[10] = (badm[10][0], badm[10][1][:20] + "?" + badm[10][1][21:])
+    bm = os.path.join(tmp, "bm2.fq")
+    _write(bm, _fastq(badm))
+    p = os.path.join(tmp, "badmate")
+    res = _run(binary, sim_db, ["--paired-reads", os.path.join(tmp, "full1.fq") + "," + bm], p)
+    assert "Error parsing file" in res.stderr and "'?'" in res.stderr
+    r = cu.Res(p)
+    assert r.total_classified + r.total_unclassified == 11
     # (4b) blocked gzip with a damaged member: error reported, nothing after the damage is used
     bz = os.path.join(tmp, "dmg.fq.gz")
     _write_bgzf(bz, _fastq(r1), block=700)
