@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- ganon read classification on MI355X: Mreads/s classified + IBF-lookup GB/s vs the HBM roofline.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload flat8g|flat1g|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (minimiser kernel -> IBF count+select kernel -> match grouping) over one
-batch of synthetic 150 bp reads that is already resident in HBM; the filter is resident too.  The default
-workload is BASELINE.json configs[1]: 8 GiB flat IBF, 4096 technical bins, h=4, 10 M reads (k=19, w=31).
-With N > 1 ranks the reads are sharded (each rank classifies its own 10 M reads against its own filter
-replica, no data-path collective) -> "scaling": "weak".
+A "step" is one pass of the hot path (minimiser kernels -> IBF/HIBF count+select kernels -> match grouping, plus
+the sparse-match exchange for a partitioned filter) over one batch of synthetic 150 bp reads that is already
+resident in HBM; the filter is resident too.  Workloads (BASELINE.json `configs`):
 
-Rank 0 prints ONE JSON line (driver contract) with two extra objects:
-  roofline     achieved = algorithmic row bytes (n_hashes * h * W * 8 per launch) / average count-kernel duration,
-               measured with hipEvents on the library's own HIP stream (gn_stream_timings); peak = 8000 GB/s
-  cpu_baseline the CPU oracle (kind "port": OpenMP restatement of the reference loop) on a bounded sample of the
-               same reads against the same filter bits, timed on this box's host cores
+  flat8g    configs[1]  8 GiB flat IBF, 4096 bins, h=4, 10 M reads                      <- the default / headline
+  hibf64k   configs[2]  2-level HIBF, 65 536 user bins (256 x 256), 10 M reads
+  flat128g  configs[3]  128 GiB flat IBF (32 768 bins, 4 KiB rows), 12.5 M pairs 2x150 = the per-GPU shard of the
+                        100 M-pair job; with N ranks every rank holds a replica and its own shard ("weak")
+  slice1t   configs[4]  one rank's 128 GiB column slice (32 768 of 262 144 bins) of a 1 TiB filter; every rank sees
+                        every pair, sparse matches go to the read's owner over RCCL (world 1 on one GPU)
+
+The 128 GiB filters are generated on the device (gn_filter_fill_random); nothing that large exists on the host.
+Rank 0 prints ONE JSON line (driver contract) with extra objects:
+  roofline         dominant kernel: `achieved` = HBM row bytes the kernel actually requested per launch / its average
+                   duration (hipEvents on the library's own stream); `frac` = achieved / 8000 GB/s.  The algorithmic
+                   rate (n*h*W*8 per read) is reported beside it as `effective_gbs`: the exact early
+                   exit makes the kernel fetch fewer rows than the algorithm names, so only `achieved` is physical.
+  variants         the same resident batch with the early exit disabled and at the binary's default --rel-cutoff 0.2
+  cpu_baseline     the CPU oracle (kind "port") on a bounded sample of the same reads against the same filter bits
+  other_workloads  (default N=1 run only) the other BASELINE configs, each run at full size in a child process
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,16 +44,40 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (bins, rows, h, n_reads)
-    "flat8g": (4096, 1 << 24, 4, 10_000_000),   # BASELINE.json configs[1]: 2^24 rows x 512 B = 8 GiB
-    "flat1g": (4096, 1 << 21, 4, 2_000_000),    # same shape, 1 GiB (quick runs; still >> 256 MiB Infinity Cache)
-    "tiny": (4096, 1 << 14, 4, 100_000),        # smoke-sized
-    "flat32k": (32768, 1 << 21, 4, 2_000_000),  # 4 KiB rows (the row shape of BASELINE.json configs[3]), 8 GiB
+    "flat8g": dict(kind="flat", bins=4096, rows=1 << 24, h=4, reads=10_000_000, paired=False, config=1),
+    "flat1g": dict(kind="flat", bins=4096, rows=1 << 21, h=4, reads=2_000_000, paired=False, config=None),
+    "tiny": dict(kind="flat", bins=4096, rows=1 << 14, h=4, reads=100_000, paired=False, config=None),
+    "flat32k": dict(kind="flat", bins=32768, rows=1 << 21, h=4, reads=2_000_000, paired=False, config=None),
+    "hibf64k": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, h=3, reads=10_000_000, paired=False, config=2),
+    "hibf_tiny": dict(kind="hibf", user_bins=4096, tmax=64, rows=1 << 12, h=3, reads=100_000, paired=False, config=None),
+    "flat128g": dict(kind="flat", bins=32768, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=3),
+    "slice1t": dict(kind="slice", bins=32768, slices=8, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=4),
+    "slice_tiny": dict(kind="slice", bins=4096, slices=8, rows=1 << 14, h=4, reads=100_000, paired=True, config=None),
 }
+EXTRA_WORKLOADS = ["hibf64k", "flat128g", "slice1t"]
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def run_extra(name: str, timeout: int):
+    """another BASELINE config at full size in a child process (a crash or a timeout there cannot lose the main line)"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-extra", "--no-variants"]
+    t0 = time.time()
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
+        line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and line:
+            r = json.loads(line[-1])
+            return {"workload": name, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                    "config": r["config"], "roofline": r["roofline"], "wall_s": round(time.time() - t0, 1)}
+        return {"workload": name, "error": f"rc {p.returncode}: " + p.stderr.decode(errors="replace")[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"workload": name, "error": f"timeout after {timeout}s"}
+    except Exception as e:  # noqa: BLE001 -- the extras never take the main line down
+        return {"workload": name, "error": repr(e)}
 
 
 def main() -> int:
@@ -52,8 +86,13 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("GANON_BENCH_WORKLOAD", "flat8g"), choices=sorted(WORKLOADS))
-    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU")
+    ap.add_argument("--reads", type=int, default=0, help="override reads (pairs) per GPU")
+    ap.add_argument("--rows", type=int, default=0, help="override filter rows (dry runs)")
+    ap.add_argument("--rel-cutoff", type=float, default=0.75, help="0.75 = `ganon classify` default (src/ganon/config.py:597)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="do not run the other BASELINE configs after the headline")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--extra-timeout", type=int, default=420)
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s)")
     ap.add_argument("--check", type=int, default=2000, help="reads re-checked against the oracle (rank 0)")
     args = ap.parse_args()
@@ -63,6 +102,7 @@ def main() -> int:
     import ganon_amd
     import bench_workload as bw
     from ganon_amd import dist as gdist
+    from ganon_amd import partition as gp
 
     rank, local_rank, world = gdist.env_rank_world()
     if not torch.cuda.is_available():
@@ -72,107 +112,157 @@ def main() -> int:
     torch.cuda.set_device(dev_index)
     dist_backend = os.environ.get("GANON_BENCH_DIST", "nccl")   # nccl == RCCL; "gloo" only for 1-GPU dry runs
     red_dev = "cuda" if dist_backend == "nccl" else "cpu"
-    if world > 1:
+    spec = dict(WORKLOADS[args.workload])
+    kind = spec["kind"]
+    if world > 1 or kind == "slice":  # the partitioned filter exchanges matches over RCCL even at world size 1
         gdist.init(dist_backend, torch.device("cuda", dev_index))
 
-    bins, rows, h, n_reads = WORKLOADS[args.workload]
-    if args.reads:
-        n_reads = args.reads
+    n_reads = args.reads or spec["reads"]
+    rows = args.rows or spec["rows"]
+    paired = spec["paired"]
     t0 = time.time()
-    wl = bw.make_flat_workload(args.workload, bins, rows, h, n_reads, seed=42, shard=rank)
-    log(f"[rank {rank}] workload {args.workload}: filter {wl.filter_bytes / 2**30:.2f} GiB, {n_reads} reads, "
-        f"generated in {time.time() - t0:.1f}s")
+    part = None
+    if kind == "hibf":
+        wl, flt = bw.make_hibf_device_workload(ganon_amd, args.workload, spec["user_bins"], spec["tmax"], rows, rows, spec["h"],
+                                               n_reads, rel_cutoff=args.rel_cutoff, seed=42, shard=rank, device=dev_index)
+        off2 = None
+        desc = (f"2-level HIBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU: top IBF {spec['tmax']} merged bins -> "
+                f"{spec['tmax']} child IBFs x {spec['user_bins'] // spec['tmax']} user bins = {spec['user_bins']} user bins, "
+                f"S={rows} rows each, h={spec['h']}")
+        kernel_name = "gn_hibf_level_kernel"
+        row_bytes = ((spec["tmax"] + 63) >> 6) * 8
+    else:
+        slices = spec.get("slices", 1)
+        W_local = (spec["bins"] + 63) >> 6
+        sl_idx = rank % slices if kind == "slice" else 0
+        wl = bw.make_device_flat_workload(args.workload, spec["bins"], rows, spec["h"], n_reads, paired, rel_cutoff=args.rel_cutoff,
+                                          seed=42, shard=0 if kind == "slice" else rank, word_lo=sl_idx * W_local,
+                                          row_words_total=W_local * slices)
+        flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index)
+        off2 = wl.off2
+        row_bytes = W_local * 8
+        if kind == "slice":
+            sl = gp.Slice(rank, sl_idx * W_local, (sl_idx + 1) * W_local, spec["bins"], np.arange(spec["bins"], dtype=np.uint32),
+                          (np.arange(spec["bins"], dtype=np.uint32) + np.uint32(sl_idx * spec["bins"])))
+            part = gp.PartitionedIbf(sl, rank, world, gp.HipLocalFilter(flt, dev_index), comm_device=red_dev)
+            desc = (f"column slice {sl_idx} of {slices} ({spec['bins']} of {spec['bins'] * slices} technical bins, "
+                    f"{wl.filter_bytes / 2**30:.2f} GiB of a {wl.filter_bytes * slices / 2**40:.2f} TiB flat IBF), W_local={W_local} "
+                    f"({row_bytes} B rows), S={rows} rows, h={spec['h']}; every rank sees every read, sparse matches go to the "
+                    f"read's owner with one all-to-all over RCCL")
+        else:
+            desc = (f"flat IBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {wl.bins} technical bins (W={W_local}, "
+                    f"{row_bytes} B rows), S={rows} rows, h={spec['h']}")
+        kernel_name = "gn_ibf_count_fast_kernel"
+    unit_name = "pairs (2x150 bp)" if paired else "reads (150 bp)"
+    log(f"[rank {rank}] workload {args.workload}: filter {wl.filter_bytes / 2**30:.2f} GiB filled on the device, {n_reads} "
+        f"{unit_name}, set up in {time.time() - t0:.1f}s")
 
-    t0 = time.time()
-    flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs, device=dev_index)
-    n_planted = bw.plant_genomes(flt, wl)
-    log(f"[rank {rank}] filter uploaded + {n_planted} genome minimisers emplaced on device in {time.time() - t0:.1f}s")
+    if part is None:
+        st = ganon_amd.HipStream(flt, n_reads, wl.bases.size, max_matches=n_reads * 2)
+        st.upload(wl.bases, wl.off, off2)
+        st.sync()
 
-    st = ganon_amd.HipStream(flt, n_reads, wl.bases.size, max_matches=n_reads * 2)
-    st.upload(wl.bases, wl.off, None)
-    st.sync()
+        def step(cutoff):
+            st.classify(wl.k, wl.w, cutoff)
+            st.sync()
+    else:
+        owned = {}
+
+        def step(cutoff):
+            owned["out"] = part.classify(wl.bases, wl.off, off2, wl.k, wl.w, cutoff)
+        step(args.rel_cutoff)  # creates the stream and uploads the batch (it stays resident)
+        st = part.local.st
 
     def barrier():
         torch.cuda.synchronize()
         gdist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        st.classify(wl.k, wl.w, wl.rel_cutoff)
-        st.sync()
+    def timed(cutoff, steps, warmup):
+        for _ in range(warmup):
+            step(cutoff)
+        cms, mms, tms = [], [], []
+        barrier()
+        t_begin = time.perf_counter()
+        for _ in range(steps):
+            step(cutoff)
+            tm = st.timings()           # hipEvent durations on the stream the kernels ran on
+            cms.append(tm["ms_count"])
+            mms.append(tm["ms_minimiser"])
+            tms.append(tm["ms_total"])
+        barrier()
+        return time.perf_counter() - t_begin, cms, mms, tms, st.timings()
 
-    count_ms, mini_ms, total_ms = [], [], []
-    barrier()
-    t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        st.classify(wl.k, wl.w, wl.rel_cutoff)
-        st.sync()
-        tm = st.timings()           # hipEvent durations on the stream the kernels ran on
-        count_ms.append(tm["ms_count"])
-        mini_ms.append(tm["ms_minimiser"])
-        total_ms.append(tm["ms_total"])
-    barrier()
-    elapsed = time.perf_counter() - t_begin
+    def roofline_of(tm, cms):
+        avg = float(np.mean(cms))
+        nl = max(1, tm["n_count_launches"])
+        fetched = tm["fetched_bytes"] / (avg * 1e-3) / 1e9
+        return {
+            "achieved": round(fetched, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fetched / HBM_PEAK_GBS, 4),
+            "effective_gbs": round(tm["algo_bytes"] / (avg * 1e-3) / 1e9, 1),
+            "avg_launch_ms": round(avg / nl, 4), "launches_per_step": int(nl),
+            "fetched_bytes_per_launch": int(tm["fetched_bytes"] // nl), "algo_bytes_per_launch": int(tm["algo_bytes"] // nl),
+        }
+
+    elapsed, count_ms, mini_ms, total_ms, tm = timed(args.rel_cutoff, args.steps, args.warmup)
     elapsed = gdist.max_over_ranks(elapsed, device=red_dev)       # slowest rank defines the step time
-    total_reads = gdist.sum_over_ranks(n_reads, device=red_dev)    # whole-job reads per step
-
-    tm = st.timings()
-    nh, status, mo, matches = st.fetch()
-    n_class = int(np.count_nonzero(np.diff(mo)))
+    if kind == "slice":
+        total_reads = n_reads                                      # every rank classifies the same reads against its columns
+    else:
+        total_reads = gdist.sum_over_ranks(n_reads, device=red_dev)    # whole-job reads per step
+    if part is None:
+        nh, status, mo, matches = st.fetch()
+    else:
+        lo, hi, nh, status, matches = owned["out"]
+        mo = np.searchsorted(matches["read"], np.arange(n_reads + 1)).astype(np.uint64)
+    n_class = int(np.count_nonzero(np.diff(mo.astype(np.int64))))
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    value = total_reads / (elapsed / max(1, args.steps)) / 1e6  # Mreads/s, whole job
-    avg_count_ms = float(np.mean(count_ms)) if count_ms else float("nan")
-    achieved = tm["algo_bytes"] / (avg_count_ms * 1e-3) / 1e9 if count_ms else float("nan")
+    value = total_reads / (elapsed / max(1, args.steps)) / 1e6  # Mreads/s (M pairs/s for paired workloads), whole job
 
-    kernel_name = "gn_ibf_count_fast_kernel"  # dominant kernel of this workload (identity bin->target map, n <= 30)
+    roof = {"bound": "hbm", "kernel": kernel_name}
+    roof.update(roofline_of(tm, count_ms))
+    roof["note"] = ("achieved/frac = HBM row bytes the kernel requested (gn_timings.fetched_bytes: algorithmic bytes minus the rows the "
+                    "exact early exit skips; the PMC FETCH_SIZE pass in `traffic` agrees within 3 %) / hipEvent kernel time / peak; "
+                    "effective_gbs = algorithmic bytes n*h*W*8 (SURVEY 8d) / the same time, which may exceed the peak because skipped "
+                    "rows cost nothing")
+    if row_bytes < 128:
+        # rows narrower than an L2 line: every row fetch still moves one 128-byte line (what FETCH_SIZE charges a narrow load)
+        lines = tm["algo_bytes"] // row_bytes
+        avg = float(np.mean(count_ms))
+        roof["transaction_bytes_per_launch"] = int(lines * 128 // max(1, tm["n_count_launches"]))
+        roof["transaction_gbs"] = round(lines * 128 / (avg * 1e-3) / 1e9, 1)
+        roof["transaction_frac"] = round(lines * 128 / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roof["note"] += (f"; rows are {row_bytes} B, so the transaction roofline counts one 128-byte line per row fetch "
+                         "(transaction_gbs / transaction_frac)")
+    roof["traffic"] = None
+
     result = {
         "metric": "Mreads/s classified (150 bp) + IBF-lookup GB/s vs HBM roofline",
         "value": round(value, 3),
-        "unit": "Mreads/s",
+        "unit": "Mpairs/s" if paired else "Mreads/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if kind == "slice" else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: flat IBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {wl.bins} technical "
-                        f"bins (W={wl.bin_words}, {wl.bin_words * 8} B rows), S={wl.rows} rows, h={wl.hash_funs}, "
-                        f"k={wl.k} w={wl.w}, {n_reads} synthetic {wl.read_len} bp reads per GPU ({wl.planted_fraction:.0%} "
-                        f"planted), rel_cutoff={wl.rel_cutoff}, Bernoulli(0.5) fill, seed {wl.seed}",
+            "workload": f"{args.workload} (BASELINE.json configs[{spec['config']}]): {desc}, k={wl.k} w={wl.w}, {n_reads} synthetic "
+                        f"{unit_name} per GPU (50% cut from {4096} planted genomes), rel_cutoff={args.rel_cutoff}, seeded "
+                        f"Bernoulli(0.5) fill generated on the device, seed 42",
             "reads_per_gpu": n_reads,
-            "parallelism": f"read-sharded x{world}, filter replicated",
+            "parallelism": (f"bin-range partitioned x{world} of {spec.get('slices')} slices" if kind == "slice"
+                            else f"read-sharded x{world}, filter replicated"),
             "mean_minimisers_per_read": round(tm["n_hashes"] / max(1, n_reads), 3),
             "classified_reads_rank0": n_class,
-            "matches_rank0": int(tm["n_matches"]),
-            "kernel_ms": {"minimiser": round(float(np.mean(mini_ms)), 3), "count_select": round(avg_count_ms, 3),
+            "matches_rank0": int(len(matches)),
+            "kernel_ms": {"minimiser": round(float(np.mean(mini_ms)), 3), "count_select": round(float(np.mean(count_ms)), 3),
                           "device_total": round(float(np.mean(total_ms)), 3)},
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": kernel_name,
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            # the batch is pipelined in chunks (minimiser of chunk c+1 || count of chunk c): per-launch figures
-            "launches_per_step": int(tm["n_count_launches"]),
-            "algo_bytes_per_launch": int(tm["algo_bytes"] // max(1, tm["n_count_launches"])),
-            "avg_launch_ms": round(avg_count_ms / max(1, tm["n_count_launches"]), 4),
-            # rows actually requested: reads that can no longer reach their cutoff stop fetching (exact early exit),
-            # so the kernel moves fewer bytes than the algorithmic n*h*W*8 it is credited with above
-            "fetched_bytes_per_launch": int(tm["fetched_bytes"] // max(1, tm["n_count_launches"])),
-            "fetched_gbs": round(tm["fetched_bytes"] / (avg_count_ms * 1e-3) / 1e9, 1) if count_ms else None,
-            "fetched_frac": round(tm["fetched_bytes"] / (avg_count_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if count_ms else None,
-            "note": "achieved/frac use the algorithmic bytes n*h*W*8 per read (SURVEY 8d) as the contract defines them; the "
-                    "kernel returns identical matches but requests only fetched_bytes_per_launch of them (exact early exit "
-                    "and narrowing, DESIGN 3.2), so frac can approach or pass 1 -- fetched_gbs/fetched_frac are the physical "
-                    "rate, traffic is the PMC measurement",
-            "traffic": None,
-        },
+        "roofline": roof,
     }
 
     # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass (counter collection
@@ -181,30 +271,54 @@ def main() -> int:
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            result["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = pmc["source"]
-        except Exception as e:
+            roof["traffic"] = pmc["hbm_bytes_per_launch"]
+            roof["traffic_source"] = pmc["source"]
+        except Exception as e:  # noqa: BLE001
             log("bench.py: could not read", pmc_path, repr(e))
+
+    # the same resident batch under the two conditions the headline does not show (not part of `value`)
+    if not args.no_variants and part is None and kind == "flat":
+        variants = {}
+        os.environ["GANON_HIP_NO_EARLY_EXIT"] = "1"   # read by the library at every launch
+        _, cms, _, tms, tmv = timed(args.rel_cutoff, 3, 1)
+        del os.environ["GANON_HIP_NO_EARLY_EXIT"]
+        variants["no_early_exit"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
+                                         mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2))
+        _, cms, _, tms, tmv = timed(0.2, 3, 1)        # ganon-classify's own default (Config.hpp:32): T ~ 4, nothing to exit from
+        variants["rel_cutoff_0.2"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
+                                          mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches=int(tmv["n_matches"]))
+        result["variants"] = variants
+        step(args.rel_cutoff)  # leave the headline batch in the stream for the checks below
 
     if rank == 0:
         import bench_cpu
         if args.check:
-            ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check)
+            if kind == "hibf":
+                ok, detail = bench_cpu.spot_check_hibf(wl, flt, nh, status, mo, matches, min(args.check, 600))
+            else:
+                ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check,
+                                                  target_offset=(sl_idx * spec["bins"] if kind == "slice" else 0))
             result["config"]["oracle_spot_check"] = detail
             if not ok:
                 log("bench.py: ORACLE SPOT CHECK FAILED:", detail)
                 result["value"] = None
-        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N=1 measurement
-            try:
+        if not args.no_cpu_baseline and world == 1 and kind == "flat" and wl.filter_bytes <= (16 << 30):
+            try:  # the CPU baseline is an N=1 measurement on a filter the host can hold
                 result["cpu_baseline"] = bench_cpu.cpu_baseline(wl, flt, args.cpu_sample)
-            except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
+            except Exception as e:  # noqa: BLE001 -- a reported extra; never lose the GPU line over it
                 log("bench.py: cpu_baseline failed:", repr(e))
                 result["cpu_baseline"] = None
         result.setdefault("cpu_baseline", None)
-        print(json.dumps(result), flush=True)
-    st.destroy()
+    if part is not None:
+        part.local.close()
+    else:
+        st.destroy()
     flt.free()
-    if world > 1:
+    if rank == 0:
+        if not args.no_extra and world == 1 and args.workload == "flat8g" and not args.reads and not args.rows:
+            result["other_workloads"] = [run_extra(w, args.extra_timeout) for w in EXTRA_WORKLOADS]
+        print(json.dumps(result), flush=True)
+    if world > 1 or kind == "slice":
         import torch.distributed as dist
         gdist.barrier()
         dist.destroy_process_group()

@@ -37,28 +37,47 @@ def _oracle_native():
     return "portable"
 
 
-def spot_check(wl, flt, nh, status, mo, matches, n_sample: int):
-    """GPU (read, target, count) lists of a random read sample == oracle select_matches on the device's bits."""
+def spot_check(wl, flt, nh, status, mo, matches, n_sample: int, target_offset: int = 0):
+    """GPU (read, target, count) lists of a random read sample == oracle select_matches on the device's bits.  Only
+    the rows the sample touches are fetched from the device (gn_filter_download_row_list), so this also works on the
+    128 GiB filters; `target_offset` = first global target of a column slice."""
     import bench_workload as bw
-    import oracle
 
-    bw.download_filter(flt, wl)
-    _, ibf = bw.oracle_filter(wl)
+    ibf = bw.sampled_oracle_ibf(flt, wl)
     rng = np.random.default_rng(123)
     n = wl.n_reads
     idx = np.unique(rng.integers(0, n, size=min(n_sample, n)))
     bad = 0
     checked_matches = 0
     for r in idx.tolist():
-        seq = wl.bases[int(wl.off[r]):int(wl.off[r + 1])]
-        hashes = oracle.minimiser_hash(oracle.to_ranks(seq), wl.k, wl.w)
-        counts = ibf.bulk_count(hashes).astype(np.int64)
-        thr = oracle.threshold_cutoff(len(hashes), wl.rel_cutoff)
-        capped = np.minimum(counts, len(hashes))
-        tg = np.nonzero(capped >= thr)[0]
-        exp = [(int(t), int(capped[t])) for t in tg]
+        n_h, exp = bw.oracle_read_matches(ibf, wl, r)
+        exp = [(t + target_offset, c) for t, c in exp]
         got = [(int(x["target"]), int(x["count"])) for x in matches[int(mo[r]):int(mo[r + 1])]]
-        if nh[r] != len(hashes) or status[r] != 0 or got != exp:
+        if nh[r] != n_h or status[r] != 0 or got != exp:
+            bad += 1
+        checked_matches += len(exp)
+    return bad == 0, {"reads_checked": int(len(idx)), "matches_checked": int(checked_matches), "mismatching_reads": int(bad)}
+
+
+def spot_check_hibf(wl, flt, nh, status, mo, matches, n_sample: int):
+    """same for an HIBF workload: the oracle's counting_agent_type::bulk_count on the downloaded IBFs"""
+    import bench_workload as bw
+    import oracle
+
+    bw.download_hibf(flt, wl)
+    hb = oracle.Hibf([oracle.Ibf(b, s, h, r) for (r, b, s, h) in wl.ibfs], wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)
+    rng = np.random.default_rng(123)
+    idx = np.unique(rng.integers(0, wl.n_reads, size=min(n_sample, wl.n_reads)))
+    bad = 0
+    checked_matches = 0
+    for r in idx.tolist():
+        seq = wl.bases[int(wl.off[r]):int(wl.off[r + 1])]
+        hh = oracle.minimiser_hash(oracle.to_ranks(seq), wl.k, wl.w)
+        counts = hb.bulk_count(hh, oracle.threshold_cutoff(len(hh), wl.rel_cutoff))
+        nz = np.nonzero(counts)[0]
+        exp = [(int(u), int(min(int(counts[u]), len(hh)))) for u in nz]
+        got = [(int(x["target"]), int(x["count"])) for x in matches[int(mo[r]):int(mo[r + 1])]]
+        if nh[r] != len(hh) or status[r] != 0 or got != exp:
             bad += 1
         checked_matches += len(exp)
     return bad == 0, {"reads_checked": int(len(idx)), "matches_checked": int(checked_matches), "mismatching_reads": int(bad)}
@@ -70,6 +89,9 @@ def cpu_baseline(wl, flt, n_sample: int = 0):
 
     build = _oracle_native()
     threads = os.cpu_count() or 1
+    if getattr(wl, "filter_rows", None) is None:  # device-generated filter: the oracle needs its bits on the host
+        wl.filter_rows = np.empty((wl.rows, wl.bin_words), dtype=np.uint64)
+        bw.download_filter(flt, wl)
     ofl, ibf = bw.oracle_filter(wl)
     ranks_all = None
 

@@ -133,6 +133,138 @@ def oracle_filter(wl: FlatWorkload):
                          rel_cutoff=wl.rel_cutoff), ibf
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Device-generated flat workloads (BASELINE.json configs[3] and [4]: 128 GiB filters never exist on the host).
+# The bit matrix is gn_filter_fill_random's seeded Bernoulli(0.5) (ganon_amd.fill_random_words is its numpy twin),
+# planted genomes are emplaced on the device, and the oracle side fetches only the rows a read sample touches.
+# ---------------------------------------------------------------------------------------------------------------
+_COMP = np.array([3, 2, 1, 0], dtype=np.uint8)  # complement of ranks A C G T
+_ACGT256 = np.tile(ACGT, 64)                    # random byte -> uniform random base
+
+
+@dataclass
+class DeviceFlatWorkload:
+    name: str
+    bins: int                 # bins of THIS filter (a column slice when row_words_total > bin_words)
+    rows: int
+    hash_funs: int
+    k: int
+    w: int
+    rel_cutoff: float
+    read_len: int
+    n_reads: int              # reads, or pairs when paired
+    paired: bool
+    planted_fraction: float
+    seed: int
+    word_lo: int              # first global word of this column slice
+    row_words_total: int      # words per row of the whole filter
+    bases: np.ndarray         # mate-1 block, then mate-2 block
+    off: np.ndarray           # off1
+    off2: Optional[np.ndarray]
+    genomes: np.ndarray       # ASCII [n_genomes, genome_len]
+    genome_bins: np.ndarray   # LOCAL bin of each genome
+    planted_genome: np.ndarray  # genome index of read i (-1: random read)
+    filter_rows: Optional[np.ndarray] = None  # host copy, only when a checker downloaded it (download_filter)
+
+    @property
+    def bin_words(self) -> int:
+        return (self.bins + 63) >> 6
+
+    @property
+    def filter_bytes(self) -> int:
+        return self.rows * self.bin_words * 8
+
+
+def make_device_flat_workload(name: str, bins: int, rows: int, hash_funs: int, n_reads: int, paired: bool = False,
+                              read_len: int = 150, k: int = 19, w: int = 31, rel_cutoff: float = 0.75,
+                              planted_fraction: float = 0.5, genome_len: int = 3000, n_genomes: int = 4096,
+                              fragment_len: int = 400, seed: int = 42, shard: int = 0, word_lo: int = 0,
+                              row_words_total: int = 0, threads: Optional[int] = None) -> DeviceFlatWorkload:
+    """Reads only (the filter is filled on the device by `device_filter`).  Every second read / pair is cut from
+    one of `n_genomes` random genomes; a pair is the two ends of a `fragment_len` fragment, mate 2 reverse-
+    complemented (canonical minimisers make it hit the genome's bin like mate 1).  Generated in parallel chunks with
+    their own PCG64 streams keyed by (seed, shard, chunk)."""
+    threads = threads or min(32, os.cpu_count() or 1)
+    W = (bins + 63) >> 6
+    rng = np.random.default_rng([seed, 1])
+    genomes = rng.integers(0, 4, size=(n_genomes, genome_len), dtype=np.uint8)
+    gbins = ((np.arange(n_genomes, dtype=np.uint64) * np.uint64(max(1, bins // n_genomes))) % np.uint64(bins)).astype(np.uint32)
+    n_mates = 2 if paired else 1
+    bases = np.empty(n_reads * read_len * n_mates, dtype=np.uint8)
+    m1 = bases[: n_reads * read_len].reshape(n_reads, read_len)
+    m2 = bases[n_reads * read_len:].reshape(n_reads, read_len) if paired else None
+    planted = np.full(n_reads, -1, dtype=np.int32)
+    span = fragment_len if paired else read_len
+    chunk = 1 << 19
+    spans = [(a, min(n_reads, a + chunk)) for a in range(0, n_reads, chunk)]
+
+    # genomes and their reverse complements as flat ASCII; a read is one row of a sliding-window view (a 150-byte copy)
+    from numpy.lib.stride_tricks import sliding_window_view
+    g_fw = np.ascontiguousarray(ACGT[genomes]).reshape(-1)
+    g_rc = np.ascontiguousarray(ACGT[_COMP[genomes[:, ::-1]]]).reshape(-1)
+    win_fw = sliding_window_view(g_fw, read_len)
+    win_rc = sliding_window_view(g_rc, read_len)
+
+    def work(idx_span):
+        idx, (a, b) = idx_span
+        r = np.random.default_rng([seed, 2, shard, idx])
+        n = b - a
+        pl = np.arange(a, b) % 2 == 0
+        if planted_fraction < 0.5:
+            pl &= r.random(n) < 2 * planted_fraction
+        if genome_len <= span:
+            pl[:] = False
+        half = planted_fraction >= 0.5 and genome_len > span  # planted = the even reads: strided views, no index arrays
+        rnd = slice(a + 1, b, 2) if half else a + np.nonzero(~pl)[0]
+        n_rnd = len(range(a + 1, b, 2)) if half else len(rnd)
+        for dst in ([m1, m2] if paired else [m1]):
+            dst[rnd] = np.take(_ACGT256, np.frombuffer(r.bytes(n_rnd * read_len), dtype=np.uint8)).reshape(n_rnd, read_len)
+        npl = int(pl.sum())
+        if npl:
+            which = r.integers(0, n_genomes, size=npl)
+            pos = r.integers(0, genome_len - span, size=npl)
+            sel = slice(a, b, 2) if half else a + np.nonzero(pl)[0]
+            m1[sel] = win_fw[which * genome_len + pos]
+            if paired:  # revcomp of G[e-read_len+1 .. e], e = pos+span-1  ==  rcG[L-1-e .. +read_len)
+                m2[sel] = win_rc[which * genome_len + (genome_len - span - pos)]
+            planted[sel] = which
+
+    with cf.ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        list(ex.map(work, enumerate(spans)))
+    off1 = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
+    off2 = off1 + np.uint64(n_reads * read_len) if paired else None
+    return DeviceFlatWorkload(name, bins, rows, hash_funs, k, w, rel_cutoff, read_len, n_reads, paired, planted_fraction,
+                              seed, word_lo, row_words_total or W, bases, off1, off2, ACGT[genomes], gbins, planted)
+
+
+def device_filter(hip, wl: DeviceFlatWorkload, device: int = 0, bin2target=None, n_targets=None):
+    """allocate the filter on the device, fill it there, emplace the planted genomes' minimisers"""
+    flt = hip.HipFilter.ibf(None, wl.bins, wl.rows, wl.hash_funs, bin2target, n_targets, device=device)
+    flt.fill_random(wl.seed, 1, wl.word_lo, wl.row_words_total)
+    n = plant_genomes(flt, wl)
+    return flt, n
+
+
+def sampled_oracle_ibf(flt, wl):
+    """oracle.SampledIbf whose rows come from the device filter (gn_filter_download_row_list)"""
+    import oracle
+    return oracle.SampledIbf(wl.bins, wl.rows, wl.hash_funs, lambda idx: flt.download_row_list(idx, wl.bin_words))
+
+
+def oracle_read_matches(ibf, wl, r: int):
+    """(n_hashes, [(bin, count)]) of read / pair r per GanonClassify.cpp:690-735 on an identity bin->target map"""
+    import oracle
+    s1 = wl.bases[int(wl.off[r]):int(wl.off[r + 1])]
+    hh = oracle.minimiser_hash(oracle.to_ranks(s1), wl.k, wl.w)
+    if getattr(wl, "off2", None) is not None:
+        s2 = wl.bases[int(wl.off2[r]):int(wl.off2[r + 1])]
+        if len(s2) >= wl.w:
+            hh = np.concatenate([hh, oracle.minimiser_hash(oracle.to_ranks(s2), wl.k, wl.w)])
+    counts = np.minimum(ibf.bulk_count(hh).astype(np.int64), len(hh))
+    thr = oracle.threshold_cutoff(len(hh), wl.rel_cutoff)
+    return len(hh), [(int(t), int(counts[t])) for t in np.nonzero(counts >= thr)[0]]
+
+
 def checksum_matches(matches: np.ndarray) -> int:
     """order-independent checksum of (read, target, count) records; same formula as gno_baseline_classify."""
     if len(matches) == 0:
@@ -247,3 +379,51 @@ def make_hibf_workload(hip, name: str, n_user_bins: int, tmax: int, rows_top: in
     fbytes = top.nbytes + sum(a.nbytes for a in children)
     return HibfWorkload(name, k, w, rel_cutoff, read_len, n_reads, ibfs, next_ids, b2u, n_user_bins, ACGT[reads].reshape(-1),
                         np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len), fbytes)
+
+
+def make_hibf_device_workload(hip, name: str, n_user_bins: int, tmax: int, rows_top: int, rows_child: int, hash_funs: int,
+                              n_reads: int, read_len: int = 150, k: int = 19, w: int = 31, rel_cutoff: float = 0.75,
+                              planted_fraction: float = 0.5, genome_len: int = 3000, n_genomes: int = 4096, seed: int = 42,
+                              shard: int = 0, device: int = 0):
+    """Same 2-level HIBF as make_hibf_workload, but built on the device: every IBF is allocated empty, filled by
+    gn_filter_fill_random (seed + ibf index) and the genomes' minimisers are emplaced with gn_filter_emplace_ibf.
+    Returns (workload, filter); workload.ibfs holds (None, bins, rows, h) until download_hibf() fetches the bits."""
+    per_child = n_user_bins // tmax
+    assert per_child * tmax == n_user_bins
+    rd = make_device_flat_workload(name, per_child, rows_child, hash_funs, n_reads, False, read_len, k, w, rel_cutoff,
+                                   planted_fraction, genome_len, n_genomes, seed=seed, shard=shard)
+    g_user = (np.arange(n_genomes, dtype=np.int64) * (n_user_bins // n_genomes)) % n_user_bins
+    ibfs = [(None, tmax, rows_top, hash_funs)] + [(None, per_child, rows_child, hash_funs) for _ in range(tmax)]
+    next_ids = [np.arange(1, tmax + 1, dtype=np.int64)] + [np.full(per_child, c + 1, dtype=np.int64) for c in range(tmax)]
+    b2u = [np.full(tmax, -1, dtype=np.int64)] + [np.arange(c * per_child, (c + 1) * per_child, dtype=np.int64) for c in range(tmax)]
+    flt = hip.HipFilter.hibf(ibfs, next_ids, b2u, n_user_bins, device=device)
+    for i in range(len(ibfs)):
+        flt.fill_random(seed + i, 1, ibf_idx=i)
+    st = hip.HipStream(flt, n_genomes, n_genomes * genome_len)
+    st.upload(rd.genomes.reshape(-1), np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(genome_len), None)
+    st.minimisers(k, w)
+    ho, hs = st.fetch_hashes()
+    st.destroy()
+    ub = np.repeat(g_user, np.diff(ho).astype(np.int64))
+    flt.emplace(hs, (ub // per_child).astype(np.uint32), ibf_idx=0)
+    order = np.argsort(ub // per_child, kind="stable")
+    hs_s, ub_s = hs[order], ub[order]
+    bounds = np.searchsorted(ub_s // per_child, np.arange(tmax + 1))
+    for c in range(tmax):
+        a, b = bounds[c], bounds[c + 1]
+        if b > a:
+            flt.emplace(hs_s[a:b], (ub_s[a:b] % per_child).astype(np.uint32), ibf_idx=c + 1)
+    fbytes = sum(r * ((b + 63) >> 6) * 8 for (_, b, r, _) in ibfs)
+    wl = HibfWorkload(name, k, w, rel_cutoff, read_len, n_reads, ibfs, next_ids, b2u, n_user_bins, rd.bases, rd.off, fbytes)
+    wl.planted_genome = rd.planted_genome
+    wl.genome_user_bin = g_user
+    return wl, flt
+
+
+def download_hibf(flt, wl: HibfWorkload) -> None:
+    """fetch every IBF's bits from the device into wl.ibfs (for the CPU oracle)"""
+    out = []
+    for i, (_, bins, rows, h) in enumerate(wl.ibfs):
+        W = (bins + 63) >> 6
+        out.append((flt.download_rows(0, rows, W, ibf_idx=i).reshape(-1), bins, rows, h))
+    wl.ibfs = out

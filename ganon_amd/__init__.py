@@ -6,7 +6,7 @@ Python package is only a thin ctypes mirror of the C ABI for tests and benchmark
 falls back to a CPU implementation -- if the HIP library is missing or no GPU is visible, calls raise.
 """
 from .hip import (GanonHipError, HipFilter, HipStream, MATCH_DTYPE, READ_BIG, READ_OK, READ_SMALL, device_count,
-                  library_path, load_library)
+                  fill_random_words, library_path, load_library)
 
 __all__ = ["GanonHipError", "HipFilter", "HipStream", "MATCH_DTYPE", "READ_OK", "READ_SMALL", "READ_BIG",
-           "device_count", "library_path", "load_library"]
+           "device_count", "fill_random_words", "library_path", "load_library"]

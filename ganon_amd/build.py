@@ -38,14 +38,32 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
-    if force or _stale(LIB, deps):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value",
-               "-o", LIB] + srcs
+    """one object per .hip source (compiled in parallel, only when stale), then one link"""
+    import concurrent.futures as cf
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = None
+    jobs, objs = [], []
+    for s in HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            hipcc = hipcc or _hipcc()
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
+                         "-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([hipcc or _hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs)
     return LIB
 
 

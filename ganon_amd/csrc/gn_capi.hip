@@ -350,6 +350,8 @@ extern "C" int gn_filter_free(gn_filter* f)
         hipFree(p);
     if (f->d_hibf)
         hipFree(f->d_hibf);
+    if (f->load_st)
+        hipStreamDestroy(f->load_st);
     delete f;
     return GN_OK;
 }
@@ -369,16 +371,42 @@ extern "C" int gn_filter_info(const gn_filter* f, int* is_hibf, uint32_t* n_ibf,
     return GN_OK;
 }
 
-extern "C" int gn_filter_emplace(gn_filter* f, const uint64_t* hashes, const uint32_t* bins, uint64_t n)
+// IBF `ibf_idx` of a filter (0 for a flat one); nullptr + error message when out of range
+static GnIbfHost* gn_filter_ibf(gn_filter* f, uint32_t ibf_idx)
 {
-    if (!f || f->is_hibf)
-        return gn_fail(GN_EINVAL, "gn_filter_emplace needs a flat IBF filter");
+    if (!f)
+    {
+        gn_fail(GN_EINVAL, "null filter");
+        return nullptr;
+    }
+    if (f->is_hibf)
+    {
+        if (ibf_idx >= f->ibfs.size())
+        {
+            gn_fail(GN_EINVAL, "ibf index %u out of range (%zu IBFs)", ibf_idx, f->ibfs.size());
+            return nullptr;
+        }
+        return &f->ibfs[ibf_idx];
+    }
+    if (ibf_idx != 0)
+    {
+        gn_fail(GN_EINVAL, "ibf index %u out of range (flat filter)", ibf_idx);
+        return nullptr;
+    }
+    return &f->ibf;
+}
+
+extern "C" int gn_filter_emplace_ibf(gn_filter* f, uint32_t ibf_idx, const uint64_t* hashes, const uint32_t* bins, uint64_t n)
+{
+    GnIbfHost* ib = gn_filter_ibf(f, ibf_idx);
+    if (!ib)
+        return GN_EINVAL;
     if (n == 0)
         return GN_OK;
     if (!hashes || !bins)
         return gn_fail(GN_EINVAL, "null argument");
     for (uint64_t i = 0; i < n; ++i)
-        if (bins[i] >= f->ibf.B)
+        if (bins[i] >= ib->B)
             return gn_fail(GN_EINVAL, "bin %u out of range", bins[i]);
     GN_HIP(hipSetDevice(f->device));
     uint64_t* dh = nullptr;
@@ -392,13 +420,20 @@ extern "C" int gn_filter_emplace(gn_filter* f, const uint64_t* hashes, const uin
     }
     hipMemcpy(dh, hashes, n * 8, hipMemcpyHostToDevice);
     hipMemcpy(db, bins, n * 4, hipMemcpyHostToDevice);
-    e = gn_launch_emplace(f->ibf.d_rows, f->ibf.S, (uint32_t)f->ibf.W, f->ibf.shift, f->ibf.h, dh, db, n, nullptr);
+    e = gn_launch_emplace(ib->d_rows, ib->S, (uint32_t)ib->W, ib->shift, ib->h, dh, db, n, nullptr);
     hipError_t e2 = hipDeviceSynchronize();
     hipFree(dh);
     hipFree(db);
     if (e != hipSuccess || e2 != hipSuccess)
         return gn_fail(GN_ENODEV, "emplace kernel failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return GN_OK;
+}
+
+extern "C" int gn_filter_emplace(gn_filter* f, const uint64_t* hashes, const uint32_t* bins, uint64_t n)
+{
+    if (!f || f->is_hibf)
+        return gn_fail(GN_EINVAL, "gn_filter_emplace needs a flat IBF filter");
+    return gn_filter_emplace_ibf(f, 0, hashes, bins, n);
 }
 
 extern "C" int gn_filter_download_rows(const gn_filter* f, uint32_t ibf_idx, uint64_t row_begin, uint64_t n_rows, uint64_t* out)
@@ -422,6 +457,205 @@ extern "C" int gn_filter_download_rows(const gn_filter* f, uint32_t ibf_idx, uin
         return gn_fail(GN_EINVAL, "row range out of bounds");
     GN_HIP(hipSetDevice(f->device));
     GN_HIP(hipMemcpy(out, ib->d_rows + row_begin * ib->W, n_rows * ib->W * 8, hipMemcpyDeviceToHost));
+    return GN_OK;
+}
+
+__global__ void gn_gather_rows_kernel(const uint64_t* __restrict__ rows, uint64_t W, const uint64_t* __restrict__ idx,
+                                      uint64_t* __restrict__ out)
+{
+    const uint64_t r = idx[blockIdx.x];
+    for (uint64_t j = threadIdx.x; j < W; j += blockDim.x)
+        out[(uint64_t)blockIdx.x * W + j] = rows[r * W + j];
+}
+
+extern "C" int gn_filter_download_row_list(const gn_filter* f, uint32_t ibf_idx, const uint64_t* row_idx, uint64_t n, uint64_t* out)
+{
+    const GnIbfHost* ib = gn_filter_ibf(const_cast<gn_filter*>(f), ibf_idx);
+    if (!ib)
+        return GN_EINVAL;
+    if (n == 0)
+        return GN_OK;
+    if (!row_idx || !out)
+        return gn_fail(GN_EINVAL, "null argument");
+    for (uint64_t i = 0; i < n; ++i)
+        if (row_idx[i] >= ib->S)
+            return gn_fail(GN_EINVAL, "row %llu out of range", (unsigned long long)row_idx[i]);
+    GN_HIP(hipSetDevice(f->device));
+    const uint64_t per = std::max<uint64_t>(1, (256ull << 20) / (ib->W * 8)); // rows per 256 MiB staging round
+    const uint64_t cap = std::min(per, n);
+    uint64_t *     d_idx = nullptr, *d_out = nullptr;
+    GN_HIP(hipMalloc(reinterpret_cast<void**>(&d_idx), cap * 8));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_out), cap * ib->W * 8);
+    if (e != hipSuccess)
+    {
+        hipFree(d_idx);
+        return gn_fail(GN_ENOMEM, "row gather staging allocation failed");
+    }
+    for (uint64_t o = 0; o < n && e == hipSuccess; o += cap)
+    {
+        const uint64_t m = std::min(cap, n - o);
+        e                = hipMemcpy(d_idx, row_idx + o, m * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            break;
+        hipLaunchKernelGGL(gn_gather_rows_kernel, dim3((unsigned)m), dim3(64), 0, nullptr, ib->d_rows, ib->W, d_idx, d_out);
+        e = hipMemcpy(out + o * ib->W, d_out, m * ib->W * 8, hipMemcpyDeviceToHost);
+    }
+    hipFree(d_idx);
+    hipFree(d_out);
+    if (e != hipSuccess)
+        return gn_fail(GN_ENODEV, "row gather failed: %s", hipGetErrorString(e));
+    return GN_OK;
+}
+
+// ---- streaming load ------------------------------------------------------------------------------
+extern "C" int gn_pinned_alloc(size_t bytes, void** out)
+{
+    if (!out || bytes == 0)
+        return gn_fail(GN_EINVAL, "gn_pinned_alloc: bad argument");
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+        return gn_fail(GN_ENODEV, "no HIP device available (libganon_hip has no CPU fallback)");
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+    if (e != hipSuccess)
+        return gn_fail(GN_ENOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return GN_OK;
+}
+
+extern "C" int gn_pinned_free(void* p)
+{
+    if (p)
+        hipHostFree(p);
+    return GN_OK;
+}
+
+static int gn_filter_load_stream(gn_filter* f)
+{
+    GN_HIP(hipSetDevice(f->device));
+    if (!f->load_st)
+        GN_HIP(hipStreamCreateWithFlags(&f->load_st, hipStreamNonBlocking));
+    return GN_OK;
+}
+
+extern "C" int gn_filter_write_rows(gn_filter* f, uint32_t ibf_idx, uint64_t row_begin, uint64_t n_rows, const uint64_t* src,
+                                    uint64_t src_row_words, uint64_t word_lo)
+{
+    GnIbfHost* ib = gn_filter_ibf(f, ibf_idx);
+    if (!ib)
+        return GN_EINVAL;
+    if (n_rows == 0)
+        return GN_OK;
+    if (!src)
+        return gn_fail(GN_EINVAL, "null argument");
+    if (row_begin + n_rows > ib->S || word_lo + ib->W > src_row_words)
+        return gn_fail(GN_EINVAL, "gn_filter_write_rows: rows [%llu,+%llu) x words [%llu,+%llu) outside the filter (%llu rows) / "
+                                  "the source rows (%llu words)",
+                       (unsigned long long)row_begin, (unsigned long long)n_rows, (unsigned long long)word_lo,
+                       (unsigned long long)ib->W, (unsigned long long)ib->S, (unsigned long long)src_row_words);
+    int rc = gn_filter_load_stream(f);
+    if (rc)
+        return rc;
+    uint64_t* dst = ib->d_rows + row_begin * ib->W;
+    if (src_row_words == ib->W)
+        GN_HIP(hipMemcpyAsync(dst, src, n_rows * ib->W * 8, hipMemcpyHostToDevice, f->load_st));
+    else
+        GN_HIP(hipMemcpy2DAsync(dst, ib->W * 8, src + word_lo, src_row_words * 8, ib->W * 8, n_rows, hipMemcpyHostToDevice,
+                                f->load_st));
+    return GN_OK;
+}
+
+extern "C" int gn_filter_write_sync(gn_filter* f)
+{
+    if (!f)
+        return gn_fail(GN_EINVAL, "null filter");
+    GN_HIP(hipSetDevice(f->device));
+    if (f->load_st)
+        GN_HIP(hipStreamSynchronize(f->load_st));
+    return GN_OK;
+}
+
+static int gn_clear_padding(gn_filter* f, GnIbfHost* ib, hipStream_t st)
+{
+    if (ib->B & 63)
+    {
+        hipLaunchKernelGGL(gn_clear_padding_kernel, dim3((unsigned)((ib->S + 255) / 256)), dim3(256), 0, st, ib->d_rows, ib->S,
+                           ib->W, (1ull << (ib->B & 63)) - 1ull);
+        GN_HIP(hipGetLastError());
+    }
+    return GN_OK;
+}
+
+extern "C" int gn_filter_finalize(gn_filter* f)
+{
+    if (!f)
+        return gn_fail(GN_EINVAL, "null filter");
+    int rc = gn_filter_load_stream(f);
+    if (rc)
+        return rc;
+    if (f->is_hibf)
+    {
+        for (auto& ib : f->ibfs)
+            if ((rc = gn_clear_padding(f, &ib, f->load_st)) != GN_OK)
+                return rc;
+    }
+    else if ((rc = gn_clear_padding(f, &f->ibf, f->load_st)) != GN_OK)
+        return rc;
+    GN_HIP(hipStreamSynchronize(f->load_st));
+    return GN_OK;
+}
+
+// ---- synthetic fill ------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t gn_mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void gn_fill_random_kernel(uint64_t* __restrict__ rows, uint64_t S, uint64_t W, uint64_t seed,
+                                                             uint32_t and_words, uint64_t word_lo, uint64_t row_words_total,
+                                                             uint64_t last_mask)
+{
+    const uint64_t total  = S * W;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t       keys[8];
+    for (uint32_t a = 0; a < and_words; ++a)
+        keys[a] = gn_mix64(seed + a);
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride)
+    {
+        const uint64_t r = idx / W, j = idx - r * W;
+        const uint64_t g = (r * row_words_total + word_lo + j) * 0x9E3779B97F4A7C15ULL;
+        uint64_t       v = ~0ULL;
+        for (uint32_t a = 0; a < and_words; ++a)
+            v &= gn_mix64(keys[a] + g);
+        if (j == W - 1)
+            v &= last_mask;
+        rows[idx] = v;
+    }
+}
+
+extern "C" int gn_filter_fill_random(gn_filter* f, uint32_t ibf_idx, uint64_t seed, uint32_t and_words, uint64_t word_lo,
+                                     uint64_t row_words_total)
+{
+    GnIbfHost* ib = gn_filter_ibf(f, ibf_idx);
+    if (!ib)
+        return GN_EINVAL;
+    if (and_words < 1 || and_words > 8)
+        return gn_fail(GN_EINVAL, "and_words must be 1..8");
+    if (row_words_total == 0)
+        row_words_total = ib->W;
+    if (word_lo + ib->W > row_words_total)
+        return gn_fail(GN_EINVAL, "column slice [%llu,+%llu) outside rows of %llu words", (unsigned long long)word_lo,
+                       (unsigned long long)ib->W, (unsigned long long)row_words_total);
+    GN_HIP(hipSetDevice(f->device));
+    const uint64_t total  = ib->S * ib->W;
+    const uint64_t want   = (total + 255) / 256;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(want, (uint64_t)f->n_cu * 32);
+    const uint64_t mask   = (ib->B & 63) ? (1ull << (ib->B & 63)) - 1ull : ~0ull;
+    hipLaunchKernelGGL(gn_fill_random_kernel, dim3(blocks), dim3(256), 0, nullptr, ib->d_rows, ib->S, ib->W, seed, and_words,
+                       word_lo, row_words_total, mask);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipDeviceSynchronize());
     return GN_OK;
 }
 
@@ -977,6 +1211,18 @@ extern "C" int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status,
             GN_HIP(hipMemcpyAsync(matches, s->d_sorted, s->n_matches * sizeof(gn_match), hipMemcpyDeviceToHost, s->st));
     }
     GN_HIP(hipStreamSynchronize(s->st));
+    return GN_OK;
+}
+
+extern "C" int gn_stream_device_matches(gn_stream* s, const gn_match** d_matches, uint64_t* n_matches)
+{
+    if (!s || !d_matches || !n_matches)
+        return gn_fail(GN_EINVAL, "null argument");
+    int rc = gn_finish(s);
+    if (rc)
+        return rc;
+    *d_matches = s->d_sorted;
+    *n_matches = s->n_matches;
     return GN_OK;
 }
 

@@ -162,6 +162,7 @@ struct gn_filter
     int      n_cu    = 256;
     bool     is_hibf = false;
     uint64_t device_bytes = 0;
+    hipStream_t load_st = nullptr; // streaming upload (gn_filter_write_rows), created on first use
     // flat
     GnIbfHost       ibf;
     uint32_t*       d_tgt_off  = nullptr;

@@ -15,8 +15,10 @@ MATCH_DTYPE = np.dtype([("read", "<u4"), ("target", "<u4"), ("count", "<u4")])
 
 # every symbol include/ganon_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_filter_upload_hibf", "gn_filter_emplace",
-               "gn_filter_download_rows", "gn_filter_info", "gn_filter_free", "gn_stream_create", "gn_stream_destroy",
-               "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch",
+               "gn_filter_emplace_ibf", "gn_filter_download_rows", "gn_filter_download_row_list", "gn_pinned_alloc",
+               "gn_pinned_free", "gn_filter_write_rows", "gn_filter_write_sync", "gn_filter_finalize",
+               "gn_filter_fill_random", "gn_filter_info", "gn_filter_free", "gn_stream_create", "gn_stream_destroy",
+               "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch", "gn_stream_device_matches",
                "gn_stream_fetch_hashes", "gn_stream_dense_counts", "gn_stream_timings"]
 
 
@@ -59,7 +61,15 @@ def load_library():
     L.gn_filter_upload_ibf.argtypes = [i32, C.POINTER(IbfDesc), vp, u32, C.POINTER(vp)]
     L.gn_filter_upload_hibf.argtypes = [i32, u32, C.POINTER(IbfDesc), C.POINTER(vp), C.POINTER(vp), u64, C.POINTER(vp)]
     L.gn_filter_emplace.argtypes = [vp, vp, vp, u64]
+    L.gn_filter_emplace_ibf.argtypes = [vp, u32, vp, vp, u64]
     L.gn_filter_download_rows.argtypes = [vp, u32, u64, u64, vp]
+    L.gn_filter_download_row_list.argtypes = [vp, u32, vp, u64, vp]
+    L.gn_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.gn_pinned_free.argtypes = [vp]
+    L.gn_filter_write_rows.argtypes = [vp, u32, u64, u64, vp, u64, u64]
+    L.gn_filter_write_sync.argtypes = [vp]
+    L.gn_filter_finalize.argtypes = [vp]
+    L.gn_filter_fill_random.argtypes = [vp, u32, u64, u32, u64, u64]
     L.gn_filter_info.argtypes = [vp, C.POINTER(i32), C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
     L.gn_filter_free.argtypes = [vp]
     L.gn_stream_create.argtypes = [vp, u32, u64, u64, C.POINTER(vp)]
@@ -70,6 +80,7 @@ def load_library():
     L.gn_submit_batch.argtypes = [vp, vp, u64, vp, vp, u32, u32, u32, C.c_double]
     L.gn_stream_sync.argtypes = [vp]
     L.gn_fetch_batch.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
+    L.gn_stream_device_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.gn_stream_fetch_hashes.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.gn_stream_dense_counts.argtypes = [vp, u32, u32, vp]
     L.gn_stream_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -101,6 +112,30 @@ def _desc(rows: Optional[np.ndarray], bins: int, bin_size: int, hash_funs: int) 
     if rows is not None:
         assert rows.dtype == np.uint64 and rows.size == bin_size * W and rows.flags["C_CONTIGUOUS"]
     return IbfDesc(rows.ctypes.data if rows is not None else None, bin_size, W, bins, hash_funs, shift)
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def fill_random_words(seed: int, rows: np.ndarray, n_words: int, and_words: int = 1, word_lo: int = 0,
+                      row_words_total: int = 0, bins: int = 0) -> np.ndarray:
+    """numpy statement of gn_filter_fill_random (include/ganon_hip.h): words [word_lo, word_lo+n_words) of the given
+    rows -> uint64 [len(rows), n_words].  `bins` (of this column slice) clears the padding bins of its last word."""
+    rows = np.asarray(rows, dtype=np.uint64).reshape(-1, 1)
+    total = np.uint64(row_words_total or n_words)
+    with np.errstate(over="ignore"):
+        g = (rows * total + np.uint64(word_lo) + np.arange(n_words, dtype=np.uint64)[None, :]) * np.uint64(0x9E3779B97F4A7C15)
+        v = np.full(g.shape, np.uint64(0xFFFFFFFFFFFFFFFF))
+        for a in range(and_words):
+            key = _mix64(np.array([(seed + a) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+            v &= _mix64(key + g)
+    if bins & 63:
+        v[:, -1] &= np.uint64((1 << (bins & 63)) - 1)
+    return v
 
 
 class HipFilter:
@@ -138,11 +173,33 @@ class HipFilter:
         _check(load_library().gn_filter_upload_hibf(device, n, descs, nxp, bup, n_user_bins, C.byref(h)))
         return cls(h, keep=(nx, bu))
 
-    def emplace(self, hashes: np.ndarray, bins: np.ndarray) -> None:
+    def emplace(self, hashes: np.ndarray, bins: np.ndarray, ibf_idx: int = 0) -> None:
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
         bins = np.ascontiguousarray(bins, dtype=np.uint32)
         assert len(hashes) == len(bins)
-        _check(load_library().gn_filter_emplace(self._h, _p(hashes), _p(bins), len(hashes)))
+        _check(load_library().gn_filter_emplace_ibf(self._h, ibf_idx, _p(hashes), _p(bins), len(hashes)))
+
+    def fill_random(self, seed: int, and_words: int = 1, word_lo: int = 0, row_words_total: int = 0, ibf_idx: int = 0) -> None:
+        """device-side seeded Bernoulli(2**-and_words) fill (gn_filter_fill_random); fill_random_words() is its numpy twin"""
+        _check(load_library().gn_filter_fill_random(self._h, ibf_idx, seed & 0xFFFFFFFFFFFFFFFF, and_words, word_lo,
+                                                    row_words_total))
+
+    def write_rows(self, row_begin: int, src: np.ndarray, word_lo: int = 0, ibf_idx: int = 0) -> None:
+        """streaming upload of rows [row_begin, row_begin+len(src)) from a host chunk [n_rows, src_row_words]"""
+        src = np.ascontiguousarray(src, dtype=np.uint64)
+        assert src.ndim == 2
+        L = load_library()
+        _check(L.gn_filter_write_rows(self._h, ibf_idx, row_begin, src.shape[0], _p(src), src.shape[1], word_lo))
+        _check(L.gn_filter_write_sync(self._h))
+
+    def finalize(self) -> None:
+        _check(load_library().gn_filter_finalize(self._h))
+
+    def download_row_list(self, row_idx: np.ndarray, words: int, ibf_idx: int = 0) -> np.ndarray:
+        row_idx = np.ascontiguousarray(row_idx, dtype=np.uint64)
+        out = np.empty((len(row_idx), words), dtype=np.uint64)
+        _check(load_library().gn_filter_download_row_list(self._h, ibf_idx, _p(row_idx), len(row_idx), _p(out)))
+        return out
 
     def download_rows(self, row_begin: int, n_rows: int, words: int, ibf_idx: int = 0) -> np.ndarray:
         out = np.empty((n_rows, words), dtype=np.uint64)
@@ -210,6 +267,29 @@ class HipStream:
         m = np.zeros(max(int(need.value), 1), dtype=MATCH_DTYPE)
         _check(L.gn_fetch_batch(self._h, None, None, None, _p(m), len(m), C.byref(need)))
         return nh, st, mo, m[: int(need.value)]
+
+    def fetch_read_info(self):
+        """-> (n_hashes u32[n], status u8[n]) only"""
+        n = self.n_reads
+        nh = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8)
+        need = C.c_uint64(0)
+        _check(load_library().gn_fetch_batch(self._h, _p(nh), _p(st), None, None, 0, C.byref(need)))
+        return nh, st
+
+    def device_records(self, device_index: int = 0):
+        """the batch's matches as an int32 torch tensor [m, 3] (read, target, count) that ALIASES the library's device
+        buffer (gn_stream_device_matches); valid until the next submit on this stream"""
+        import torch
+        ptr, n = C.c_void_p(), C.c_uint64(0)
+        _check(load_library().gn_stream_device_matches(self._h, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return torch.empty((0, 3), dtype=torch.int32, device=f"cuda:{device_index}")
+
+        class _Dev:  # __cuda_array_interface__ v2: torch wraps the pointer without copying
+            __cuda_array_interface__ = {"data": (int(ptr.value), False), "shape": (int(n.value), 3), "typestr": "<i4",
+                                        "version": 2}
+        return torch.as_tensor(_Dev(), device=f"cuda:{device_index}")
 
     def fetch_hashes(self):
         """-> (hash_off u64[n+1], hashes u64[total]) in emission order (parity tap)."""

@@ -102,8 +102,37 @@ int gn_filter_upload_hibf(int device, uint32_t n_ibf, const gn_ibf_desc* ibfs, c
  * call site src/ganon-build/GanonBuild.cpp:694).  n (hash, bin) pairs in host memory. */
 int gn_filter_emplace(gn_filter* f, const uint64_t* hashes, const uint32_t* bins, uint64_t n);
 
+/* Same for IBF `ibf_idx` of an HIBF (ibf_idx = 0 for a flat filter). */
+int gn_filter_emplace_ibf(gn_filter* f, uint32_t ibf_idx, const uint64_t* hashes, const uint32_t* bins, uint64_t n);
+
 /* copy rows [row_begin, row_begin+n_rows) of IBF `ibf_idx` back to the host (tests / sampling parity) */
 int gn_filter_download_rows(const gn_filter* f, uint32_t ibf_idx, uint64_t row_begin, uint64_t n_rows, uint64_t* out);
+/* gather rows row_idx[0..n) of IBF `ibf_idx` (bin_words words each) into out[n*bin_words]: the sampling parity
+ * checks on filters too large to download (BASELINE configs 4/5) fetch only the rows their sample touches */
+int gn_filter_download_row_list(const gn_filter* f, uint32_t ibf_idx, const uint64_t* row_idx, uint64_t n, uint64_t* out);
+
+/* ---- streaming load (filter loaders, /root/reference/src/ganon-classify/GanonClassify.cpp:949-986 load_filter:
+ * the reference deserialises the whole sdsl bit_vector into host memory; here the payload goes to HBM chunk by chunk).
+ * gn_filter_upload_ibf/hibf with rows == NULL allocate a zero-filled matrix; gn_filter_write_rows then copies
+ * rows [row_begin, row_begin+n_rows) of IBF `ibf_idx` from a host chunk whose rows are src_row_words wide, keeping
+ * words [word_lo, word_lo + bin_words) of every row (word_lo > 0 / src_row_words > bin_words = one column slice of
+ * a bin-range partitioned filter).  With `src` from gn_pinned_alloc the copy is asynchronous on the
+ * filter's load stream: the caller may refill the OTHER staging buffer meanwhile and must call
+ * gn_filter_write_sync before reusing `src`.  gn_filter_finalize clears the padding bins and waits. */
+int gn_pinned_alloc(size_t bytes, void** out);
+int gn_pinned_free(void* p);
+int gn_filter_write_rows(gn_filter* f, uint32_t ibf_idx, uint64_t row_begin, uint64_t n_rows, const uint64_t* src,
+                         uint64_t src_row_words, uint64_t word_lo);
+int gn_filter_write_sync(gn_filter* f);
+int gn_filter_finalize(gn_filter* f);
+
+/* Synthetic content for benchmarks / full-size parity tests (SURVEY 8d "generated on device for >= 8 GiB"):
+ *   word(r, j) = AND_{a < and_words} mix64(mix64(seed + a) + (r * row_words_total + word_lo + j) * 0x9E3779B97F4A7C15)
+ * with mix64 = the splitmix64 finaliser, i.e. iid Bernoulli(2^-and_words) bits that depend only on the GLOBAL word
+ * position -- a column slice (word_lo, row_words_total of the whole filter) holds exactly the bits the unsliced
+ * filter has there.  Padding bins are cleared.  Not part of the reference's interface. */
+int gn_filter_fill_random(gn_filter* f, uint32_t ibf_idx, uint64_t seed, uint32_t and_words, uint64_t word_lo,
+                          uint64_t row_words_total);
 
 int gn_filter_info(const gn_filter* f, int* is_hibf, uint32_t* n_ibf, uint64_t* n_targets, uint64_t* device_bytes);
 int gn_filter_free(gn_filter* f);
@@ -139,6 +168,12 @@ int gn_stream_sync(gn_stream* s);
  * target).  Returns GN_EOVERFLOW with *n_matches = required capacity if cap is too small. */
 int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status, uint64_t* match_off, gn_match* matches,
                    uint64_t cap, uint64_t* n_matches);
+
+/* Device-resident view of the same result for callers that forward it without a host round trip (the sparse-match
+ * exchange of a bin-range partitioned filter sends it over RCCL straight from HBM): waits for the batch,
+ * then *d_matches points to n_matches records in DEVICE memory, grouped by read (ascending read, then target).
+ * The memory belongs to the stream and is valid until its next submit/classify/destroy. */
+int gn_stream_device_matches(gn_stream* s, const gn_match** d_matches, uint64_t* n_matches);
 
 /* Parity / debugging taps (tests only): minimiser hashes of the resident batch in emission order
  * (hash_off[n_reads+1]; hashes[cap]) and dense per-bin counts of reads [read_begin, read_end)

@@ -75,6 +75,8 @@ def lib():
         L.gno_ibf_emplace_many.argtypes = [C.POINTER(_IbfS), C.c_void_p, C.c_void_p, C.c_size_t]
         L.gno_ibf_bulk_count.restype = None
         L.gno_ibf_bulk_count.argtypes = [C.POINTER(_IbfS), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gno_ibf_bulk_count_gathered.restype = None
+        L.gno_ibf_bulk_count_gathered.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
         L.gno_hibf_bulk_count.restype = None
         L.gno_hibf_bulk_count.argtypes = [C.POINTER(_HibfS), C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
         L.gno_hibf_visited_bytes.restype = C.c_uint64
@@ -198,6 +200,33 @@ class Ibf:
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
         counts = np.zeros(max(self.bins, 1), dtype=np.uint16)
         lib().gno_ibf_bulk_count(C.byref(self._s), _ptr(hashes), len(hashes), _ptr(counts))
+        return counts[: self.bins]
+
+
+class SampledIbf:
+    """A flat IBF too large for the host: rows are fetched on demand through `fetch_rows(row_idx uint64[m]) ->
+    uint64[m, W]` (the device's gn_filter_download_row_list in the full-size tests).  Row selection is gno_ibf_row,
+    counting is gno_ibf_bulk_count_gathered -- the same statements as Ibf.bulk_count."""
+
+    def __init__(self, bins: int, bin_size: int, hash_funs: int, fetch_rows):
+        self.bins, self.bin_size, self.hash_funs = int(bins), int(bin_size), int(hash_funs)
+        self.bin_words = (self.bins + 63) >> 6
+        self.hash_shift = int(lib().gno_ibf_hash_shift(self.bin_size))
+        self._s = _IbfS(None, self.bins, self.bin_size, self.bin_words, self.hash_shift, self.hash_funs)
+        self._fetch = fetch_rows
+
+    def rows_of(self, hashes: np.ndarray) -> np.ndarray:
+        L = lib()
+        return np.array([L.gno_ibf_row(C.byref(self._s), int(v), i) for v in hashes for i in range(self.hash_funs)],
+                        dtype=np.uint64)
+
+    def bulk_count(self, hashes: np.ndarray) -> np.ndarray:
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        counts = np.zeros(max(self.bins, 1), dtype=np.uint16)
+        if len(hashes):
+            g = np.ascontiguousarray(self._fetch(self.rows_of(hashes)), dtype=np.uint64)
+            assert g.shape == (len(hashes) * self.hash_funs, self.bin_words)
+            lib().gno_ibf_bulk_count_gathered(_ptr(g), len(hashes), self.hash_funs, self.bin_words, self.bins, _ptr(counts))
         return counts[: self.bins]
 
 

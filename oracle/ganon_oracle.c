@@ -209,6 +209,32 @@ void gno_ibf_bulk_count(const gno_ibf* f, const uint64_t* hashes, size_t n, uint
     }
 }
 
+/* The same loop over PRE-GATHERED rows: gathered[(q*h + i)*W .. +W) is the row gno_ibf_row(f, hashes[q], i) of a
+ * filter that is too large to hold on the host (the sampling parity checks of BASELINE configs 4/5 fetch exactly
+ * the rows their reads touch from the device).  Row selection stays with gno_ibf_row; AND + count as above. */
+void gno_ibf_bulk_count_gathered(const uint64_t* gathered, size_t n, uint32_t hash_funs, uint64_t bin_words, uint64_t bins,
+                                 uint16_t* counts)
+{
+    memset(counts, 0, bins * sizeof(uint16_t));
+    for (size_t q = 0; q < n; ++q)
+    {
+        const uint64_t* base = gathered + q * hash_funs * bin_words;
+        for (uint64_t wd = 0; wd < bin_words; ++wd)
+        {
+            uint64_t t = ~0ULL;
+            for (uint32_t i = 0; i < hash_funs; ++i)
+                t &= base[i * bin_words + wd];
+            while (t)
+            {
+                const uint64_t bin = wd * 64 + (uint64_t)__builtin_ctzll(t);
+                t &= t - 1;
+                if (bin < bins)
+                    ++counts[bin];
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * a-7  HIBF counting agent
  * hierarchical_interleaved_bloom_filter.hpp:432-460 (bulk_count_impl), :506-523 (bulk_count)

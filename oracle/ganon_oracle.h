@@ -64,6 +64,9 @@ void     gno_ibf_emplace(gno_ibf* f, uint64_t v, uint64_t bin);
 void     gno_ibf_emplace_many(gno_ibf* f, const uint64_t* v, const uint32_t* bins, size_t n);
 /* counts[0..B) u16, zeroed then += bulk_contains(v) for each hash (GanonClassify.cpp:514) */
 void gno_ibf_bulk_count(const gno_ibf* f, const uint64_t* hashes, size_t n, uint16_t* counts);
+/* same, over rows gathered elsewhere: gathered[(q*h + i)*W ..) = row gno_ibf_row(f, hashes[q], i) */
+void gno_ibf_bulk_count_gathered(const uint64_t* gathered, size_t n, uint32_t hash_funs, uint64_t bin_words, uint64_t bins,
+                                 uint16_t* counts);
 
 /* ---- a-7 HIBF (src/ganon-classify/include/ganon-classify/hierarchical_interleaved_bloom_filter.hpp:432-460,506-523) */
 typedef struct

@@ -68,6 +68,16 @@ def oracle_local_classify(rows, bins, bin_size, hash_funs, bin2target, n_targets
     return nh, st, mo, np.array(recs, dtype=gp.MATCH_DTYPE) if recs else np.zeros(0, gp.MATCH_DTYPE)
 
 
+class OracleLocal(gp.LocalFilter):
+    """a rank's column slice with the oracle as the local hot path (CPU tests of the distributed logic)"""
+
+    def __init__(self, rows, bins, bin_size, hash_funs, bin2target, n_targets):
+        self.args = (rows, bins, bin_size, hash_funs, bin2target, n_targets)
+
+    def classify(self, bases, off1, off2, k, w, rel_cutoff):
+        return oracle_local_classify(*self.args, bases, off1, off2, k, w, rel_cutoff)
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     rank, _, world = gdist.env_rank_world()
@@ -75,7 +85,7 @@ def main():
     ibf, b2t, n_targets, seqs = make_case()
     bases, off1, _ = gu.pack_reads(seqs, None)
     if mode == "partition":
-        part = gp.PartitionedIbf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, rank, world, oracle_local_classify)
+        part = gp.PartitionedIbf.from_host_rows(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, rank, world, OracleLocal)
         lo, hi, nh, st, mine = part.classify(bases, off1, None, K, W, 0.25)
         np.save(f"{out}.{rank}.npy", mine)
         np.save(f"{out}.{rank}.range.npy", np.array([lo, hi, part.slice.word_lo, part.slice.word_hi]))

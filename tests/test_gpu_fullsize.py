@@ -105,15 +105,15 @@ def test_sample_against_oracle(full):
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[2]: 2-level HIBF, 65 536 user bins (top IBF of 256 merged bins -> 256 children of 256 bins)
 # ---------------------------------------------------------------------------------------------------------------
-HIBF_READS = int(os.environ.get("GANON_FULLSIZE_HIBF_READS", 2_000_000))
+HIBF_READS = int(os.environ.get("GANON_FULLSIZE_HIBF_READS", 10_000_000))  # BASELINE states 10 M
 HIBF_ROWS = int(os.environ.get("GANON_FULLSIZE_HIBF_ROWS", 1 << 20))   # 257 IBFs x 2^20 rows x 32 B = 8 GiB
 
 
 @pytest.fixture(scope="module")
 def hibf_full():
     import ganon_amd
-    wl = bw.make_hibf_workload(ganon_amd, "hibf64k", 65536, 256, HIBF_ROWS, HIBF_ROWS, 3, HIBF_READS, seed=99)
-    flt = ganon_amd.HipFilter.hibf(wl.ibfs, wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)
+    # built on the device: every IBF allocated empty, seeded fill, genomes emplaced per IBF (gn_filter_emplace_ibf)
+    wl, flt = bw.make_hibf_device_workload(ganon_amd, "hibf64k", 65536, 256, HIBF_ROWS, HIBF_ROWS, 3, HIBF_READS, seed=99)
     st = ganon_amd.HipStream(flt, HIBF_READS, wl.bases.size, HIBF_READS * 2)
     st.upload(wl.bases, wl.off, None)
     st.classify(wl.k, wl.w, wl.rel_cutoff)
@@ -131,12 +131,24 @@ def test_hibf_fullsize_structure_and_oracle_sample(hibf_full):
     key = m["read"].astype(np.uint64) << np.uint64(32) | m["target"].astype(np.uint64)
     assert (np.diff(key.astype(np.int64)) > 0).all()
     assert (m["count"] <= nh[m["read"]]).all() and (m["target"] < 65536).all()
-    # every planted read (even index) is classified; algorithmic bytes >= the top-level visit of every read
-    n_pl = int(wl.n_reads * 0.5)
-    assert (np.diff(mo.astype(np.int64))[np.arange(n_pl) * 2] >= 1).all()
+    # every planted read reports its genome's user bin with the full count; algorithmic bytes >= the top-level visit
+    pl = np.nonzero(wl.planted_genome >= 0)[0]
+    assert len(pl) == (wl.n_reads + 1) // 2 and (np.diff(mo.astype(np.int64))[pl] >= 1).all()
+    want = wl.genome_user_bin[wl.planted_genome[pl]]
+    found = np.zeros(len(pl), dtype=bool)
+    first, cnt = mo[pl].astype(np.int64), np.diff(mo.astype(np.int64))[pl]
+    for off in range(int(min(cnt.max(), 6))):
+        idx = np.minimum(first + off, len(m) - 1)
+        found |= (off < cnt) & (m["target"][idx] == want) & (m["count"][idx] == nh[pl])
+    assert found.mean() > 0.9999, found.mean()
     tm = st.timings()
     assert tm["algo_bytes"] >= int(nh.sum(dtype=np.uint64)) * 3 * 32
-    # oracle HIBF on the same host arrays for a random sample
+    # idempotent
+    ck = bw.checksum_matches(m)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    assert bw.checksum_matches(st.fetch()[3]) == ck
+    # oracle HIBF on the device's own bits for a random sample
+    bw.download_hibf(flt, wl)
     ibfs = [oracle.Ibf(b, s, h, r) for (r, b, s, h) in wl.ibfs]
     hb = oracle.Hibf(ibfs, wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)
     rng = np.random.default_rng(5)

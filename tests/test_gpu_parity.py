@@ -253,13 +253,17 @@ def test_partition_slices_hip(hip):
     bases, off1, _ = gu.pack_reads(seqs, None)
     full = hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, n_targets)
     st, nh, status, mo, m_full = _classify(hip, full, seqs, None, dw.K, dw.W, 0.25)
-    run = gp.hip_local_classify(0)
     for world in (2, 4):
         parts = []
         for sl in gp.plan_partition(b2t, ibf.bins, world):
             rows = gp.slice_rows(ibf.data, ibf.bin_words, sl)
-            nh2, st2, mo2, m = run(rows, sl.bins_local, ibf.bin_size, ibf.hash_funs, sl.bin2target_local,
-                                   max(1, len(sl.targets_global)), bases, off1, None, dw.K, dw.W, 0.25)
+            loc = gp.HipLocalFilter.from_rows(rows, sl.bins_local, ibf.bin_size, ibf.hash_funs, sl.bin2target_local,
+                                              max(1, len(sl.targets_global)))
+            nh2, st2, mo2, m = loc.classify(bases, off1, None, dw.K, dw.W, 0.25).fetch()
+            # the device-resident view of the same matches (what the RCCL exchange sends)
+            rec = loc.device_records().cpu().numpy()
+            assert np.array_equal(rec.view(np.uint32).reshape(-1, 3).view(hip.MATCH_DTYPE).reshape(-1), m)
+            loc.close()
             assert np.array_equal(nh2, nh)
             g = np.zeros(len(m), dtype=hip.MATCH_DTYPE)
             g["read"], g["count"] = m["read"], m["count"]
@@ -289,9 +293,13 @@ def test_partition_exchange_over_rccl_world1(hip):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
-        part = gp.PartitionedIbf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, 0, 1, gp.hip_local_classify(0),
-                                 comm_device="cuda")
-        lo, hi, nh2, status2, mine = part.classify(bases, off1, None, dw.K, dw.W, 0.25)
+        part = gp.PartitionedIbf.from_host_rows(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, 0, 1,
+                                                gp.HipLocalFilter.from_rows, comm_device="cuda")
+        lo, hi, nh2, status2, mine = part.classify(bases, off1, None, dw.K, dw.W, 0.25)  # device-resident exchange
+        part.local.device_records = lambda: None  # same collective, records staged through host memory
+        lo3, hi3, nh3, status3, mine3 = part.classify(bases, off1, None, dw.K, dw.W, 0.25)
+        assert np.array_equal(mine3, mine)
+        part.local.close()
     finally:
         dist.destroy_process_group()
     assert (lo, hi) == (0, len(seqs)) and np.array_equal(nh2, nh)
@@ -497,3 +505,67 @@ def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, c
         st.destroy()
         st2.destroy()
     flt.free()
+
+
+# --------------------------------------------------------------------------------------------- device fill / streaming load
+@pytest.mark.gpu
+def test_fill_random_is_position_keyed_and_matches_numpy_twin(hip):
+    # gn_filter_fill_random == ganon_amd.fill_random_words bit for bit; a column slice holds the unsliced filter's bits
+    S, bins_total, h = 777, 1000, 3
+    Wt = (bins_total + 63) >> 6
+    full = hip.HipFilter.ibf(None, bins_total, S, h)
+    full.fill_random(99, 1)
+    got = full.download_rows(0, S, Wt)
+    twin = hip.fill_random_words(99, np.arange(S), Wt, 1, 0, Wt, bins=bins_total)
+    assert np.array_equal(got, twin)
+    assert abs(np.unpackbits(got[:, :-1].view(np.uint8)).mean() - 0.5) < 0.01 and (got[:, -1] >> np.uint64(bins_total & 63) == 0).all()
+    for word_lo, bins_local in ((0, 320), (5, 384), (10, 1000 - 640)):
+        Wl = (bins_local + 63) >> 6
+        sl = hip.HipFilter.ibf(None, bins_local, S, h)
+        sl.fill_random(99, 1, word_lo, Wt)
+        exp = got[:, word_lo:word_lo + Wl].copy()
+        if bins_local & 63:
+            exp[:, -1] &= np.uint64((1 << (bins_local & 63)) - 1)
+        assert np.array_equal(sl.download_rows(0, S, Wl), exp)
+        # row gather agrees with the range download
+        pick = np.array([0, 5, 776, 5, 300], dtype=np.uint64)
+        assert np.array_equal(sl.download_row_list(pick, Wl), exp[pick.astype(np.int64)])
+        sl.free()
+    quarter = hip.HipFilter.ibf(None, bins_total, S, h)
+    quarter.fill_random(7, 2)
+    q = quarter.download_rows(0, S, Wt)
+    assert np.array_equal(q, hip.fill_random_words(7, np.arange(S), Wt, 2, 0, Wt, bins=bins_total))
+    assert abs(np.unpackbits(q[:, :-1].view(np.uint8)).mean() - 0.25) < 0.01
+    quarter.free()
+    full.free()
+
+
+@pytest.mark.gpu
+def test_streaming_write_rows_equals_one_shot_upload(hip):
+    # gn_filter_write_rows in chunks (whole rows, and one column slice out of wider source rows) == gn_filter_upload_ibf
+    rng = np.random.default_rng(5)
+    S, bins, h = 3001, 700, 3
+    ibf = gf.random_ibf(bins, S, h, 0.3, seed=3)
+    seqs = [gu.random_seq(rng, 150) for _ in range(300)]
+    for gi in range(20):
+        ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(seqs[gi]), 19, 31)), gi * 31 % bins)
+    ref = hip.HipFilter.ibf(ibf.data, bins, S, h)
+    _, nh, status, mo, m = _classify(hip, ref, seqs, None, 19, 31, 0.3)
+    streamed = hip.HipFilter.ibf(None, bins, S, h)
+    for r0 in range(0, S, 500):
+        streamed.write_rows(r0, ibf.data[r0:r0 + 500])
+    streamed.finalize()
+    assert np.array_equal(streamed.download_rows(0, S, ibf.bin_words), ref.download_rows(0, S, ibf.bin_words))
+    _, nh2, status2, mo2, m2 = _classify(hip, streamed, seqs, None, 19, 31, 0.3)
+    assert len(m) > 15 and np.array_equal(m, m2) and np.array_equal(nh, nh2)
+    # column slice: words [3, 8) of every 11-word source row, local bins 5*64 - 20 (padding cleared by finalize)
+    lo, Wl, bl = 3, 5, 300
+    sl = hip.HipFilter.ibf(None, bl, S, h)
+    for r0 in range(0, S, 777):
+        sl.write_rows(r0, ibf.data[r0:r0 + 777], word_lo=lo)
+    sl.finalize()
+    exp = ibf.data[:, lo:lo + Wl].copy()
+    exp[:, -1] &= np.uint64((1 << (bl & 63)) - 1)
+    assert np.array_equal(sl.download_rows(0, S, Wl), exp)
+    for f in (ref, streamed, sl):
+        f.free()
