@@ -4,12 +4,25 @@
 //   /root/reference/src/ganon-classify/include/ganon-classify/hierarchical_interleaved_bloom_filter.hpp:432-460 (bulk_count_impl)
 //   :506-523 (bulk_count) and select_matches(Filter<THIBF>) at /root/reference/src/ganon-classify/GanonClassify.cpp:543-577.
 //
-// The data-dependent recursion becomes a breadth-first work queue: level 0 = (read, ibf 0) for every counted
-// read; a level kernel gives one wavefront to each (read, ibf) item, counts all of the read's minimisers in that
-// IBF (h row words per hash fetched from HBM, AND-ed, set bits accumulated in LDS), evaluates the IBF's bin
-// RUNS (a merged bin is a run of its own; a split user bin is a run of equal filename index -- exactly where the
-// reference resets its running uint16 `sum`), and for runs with sum >= T either appends (read, child ibf) to
-// the next level's queue or emits (read, user bin, sum).  Matches are finally radix-sorted by (read, user bin).
+// The data-dependent recursion becomes a breadth-first work queue: level 0 = (read, ibf 0) for every counted read;
+// a level kernel counts all of the read's minimisers in the item's IBF, evaluates the IBF's bin RUNS (a merged bin is a
+// run of its own; a split user bin is a run of equal filename index -- exactly where the reference resets its running
+// uint16 `sum`), and for runs with sum >= T either appends (read, child ibf) to the next level's queue or emits
+// (read, user bin, sum).  Matches are finally radix-sorted by (read, user bin).
+//
+// The levels are launched back to back WITHOUT a host round trip: a level's kernels read their queue length from
+// device memory, the tree depth (known at upload) bounds the number of levels, and the host synchronises once per
+// batch -- to learn the match count for the sort and to check that no queue overflowed.
+//
+// Two kernels per level:
+//   gn_hibf_reg_kernel<HF>   IBFs of at most 64 words (4096 technical bins; raptor's t_max IBFs are 64..1024 bins) and
+//                            reads of at most 127 minimisers: the fast flat kernel's scheme on (read, ibf) items --
+//                            8-byte lanes, Gp = pow2 >= W lanes per row, 64/Gp hashes per wave iteration (16 for the
+//                            32-byte rows of a 256-bin IBF), h coalesced row requests per hash, bit-sliced SWAR
+//                            counters in registers, groups added with lane-xor shuffles, SWAR compare with the cutoff.
+//                            Single-bin runs (all of them unless a user bin is split) go bin -> table -> queue/match;
+//                            multi-bin runs are summed from a 4 KB LDS image of the counters.
+//   gn_hibf_level_kernel     everything else (wider IBFs, longer reads): LDS counters, one wave per item.
 #include "gn_internal.h"
 
 #include <hipcub/hipcub.hpp>
@@ -37,29 +50,444 @@ __device__ __forceinline__ void gn_hibf_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ unsigned long long gn_hibf_bcast64(unsigned long long v)
+{
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+
 struct GnHibfLevelParams
 {
-    const GnHibfIbfDev* ibfs;
-    const uint64_t*     hashes;
-    const uint64_t*     slot_off;
-    const uint32_t*     n_hashes;
-    double              rel_cutoff;
-    const uint2*        work_in;
-    uint32_t            n_work;
-    uint2*              work_out;
-    uint32_t            work_cap;
-    unsigned long long* ctr;       // [0] match cursor, [2] algo bytes, [3] next-level work count
-    uint64_t*           keys;      // (read << 32) | user_bin
-    uint32_t*           vals;      // raw uint16 sum
-    uint64_t            match_cap;
-    uint32_t            lds_bins;  // LDS counters per wave
+    const GnHibfIbfDev*       ibfs;
+    const uint64_t*           hashes;
+    const uint64_t*           slot_off;
+    const uint32_t*           n_hashes;
+    double                    rel_cutoff;
+    const uint2*              work_in;
+    const unsigned long long* count_in;  // items in work_in (device resident; clamped to work_cap)
+    uint2*                    work_out;
+    unsigned long long*       count_out; // next level's queue length (allocated slots, holes included)
+    uint2*                    defer_out; // reg kernel: items it leaves to the LDS kernel of the same level
+    unsigned long long*       defer_count;
+    uint32_t                  work_cap;
+    unsigned long long*       ctr;       // [0] match cursor, [2] algo bytes, [6] exact match count
+    uint64_t*                 keys;      // (read << ub_bits) | user_bin
+    uint32_t*                 vals;      // raw uint16 sum
+    uint64_t                  match_cap;
+    uint32_t                  ub_bits;
+    uint32_t                  lds_bins;  // LDS kernel: counters per wave
 };
 
 #define GN_HIBF_CHUNK 64u // wave-private slices of the work queue / match buffer (one global atomic per slice)
 
-// Persistent: waves stride over the (read, ibf) items of this level.  Queue appends and matches go to wave-private
-// chunks (a single counter address only sustains ~90 atomics/us); unused chunk tails hold sentinels
-// (read = 0xFFFFFFFF / key = ~0) that the next level and the final sort ignore.
+// Wave-private chunked append to the next level's queue and to the match buffer (a single counter address sustains only
+// ~90 atomics/us).  A chunk is filled front to back by successive appends; what is left of it when the wave moves on
+// (or ends) is filled with sentinels -- (read = 0xFFFFFFFF) / key = ~0 -- that the next level and the final sort ignore.
+// Sentinels only ever go to slots no entry was written to, so no store order between lanes is relied on.
+struct GnHibfAppender
+{
+    unsigned long long wq_base = 0, mq_base = 0;
+    uint32_t           wq_left = 0, mq_left = 0;
+    unsigned long long n_matches = 0;
+
+    __device__ __forceinline__ void close_work(const GnHibfLevelParams& p, int lane)
+    {
+        for (uint32_t i = lane; i < wq_left; i += GN_WAVE)
+            if (wq_base + i < p.work_cap)
+                p.work_out[wq_base + i] = make_uint2(0xFFFFFFFFu, 0u);
+        wq_left = 0;
+    }
+    __device__ __forceinline__ void close_matches(const GnHibfLevelParams& p, int lane)
+    {
+        for (uint32_t i = lane; i < mq_left; i += GN_WAVE)
+            if (mq_base + i < p.match_cap)
+                p.keys[mq_base + i] = ~0ULL;
+        mq_left = 0;
+    }
+    // every lane calls; `merged` / `leaf` are this lane's hits of the current trip
+    __device__ __forceinline__ void push(const GnHibfLevelParams& p, int lane, bool merged, bool leaf, uint32_t read, uint32_t tgt,
+                                         uint32_t sum)
+    {
+        const uint64_t mm = __ballot(merged);
+        if (mm)
+        {
+            const uint32_t need = (uint32_t)__popcll(mm);
+            if (need > wq_left)
+            {
+                close_work(p, lane);
+                const uint32_t     take = need > GN_HIBF_CHUNK ? need : GN_HIBF_CHUNK;
+                unsigned long long nb   = 0;
+                if (lane == 0)
+                    nb = atomicAdd(p.count_out, (unsigned long long)take);
+                wq_base = gn_hibf_bcast64(nb);
+                wq_left = take;
+            }
+            if (merged)
+            {
+                const unsigned long long o = wq_base + __popcll(mm & ((1ULL << lane) - 1ULL));
+                if (o < p.work_cap)
+                    p.work_out[o] = make_uint2(read, tgt);
+            }
+            wq_base += need;
+            wq_left -= need;
+        }
+        const uint64_t lm = __ballot(leaf);
+        if (lm)
+        {
+            const uint32_t need = (uint32_t)__popcll(lm);
+            if (need > mq_left)
+            {
+                close_matches(p, lane);
+                const uint32_t     take = need > GN_HIBF_CHUNK ? need : GN_HIBF_CHUNK;
+                unsigned long long nb   = 0;
+                if (lane == 0)
+                    nb = atomicAdd(&p.ctr[0], (unsigned long long)take);
+                mq_base = gn_hibf_bcast64(nb);
+                mq_left = take;
+            }
+            if (leaf)
+            {
+                const unsigned long long o = mq_base + __popcll(lm & ((1ULL << lane) - 1ULL));
+                if (o < p.match_cap)
+                {
+                    p.keys[o] = ((uint64_t)read << p.ub_bits) | tgt;
+                    p.vals[o] = sum;
+                }
+            }
+            mq_base += need;
+            mq_left -= need;
+            n_matches += need;
+        }
+    }
+    __device__ __forceinline__ void finish(const GnHibfLevelParams& p, int lane)
+    {
+        close_work(p, lane);
+        close_matches(p, lane);
+        if (lane == 0 && n_matches)
+            atomicAdd(&p.ctr[6], n_matches);
+    }
+};
+
+// ================================================================================================
+// register-counter level kernel
+// ================================================================================================
+#define GN_HIBF_REG_NMAX 127u
+#define GN_HIBF_REG_WMAX 64u
+
+template <int HF>
+__global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
+{
+    __shared__ uint32_t gn_img[4][GN_WAVE * 16]; // per wave: the byte counters of the owner lanes (multi-bin runs only)
+    const int      lane   = threadIdx.x & (GN_WAVE - 1);
+    const int      wave   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    uint32_t*      img    = gn_img[wave];
+
+    unsigned long long nw64 = *p.count_in;
+    const uint32_t     n_work = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
+
+    GnHibfAppender     app;
+    unsigned long long my_bytes = 0;
+
+    // Software pipeline over a wave's items (stride nwaves): the queue entry is fetched two items ahead, the read's
+    // metadata and the IBF descriptor one item ahead, its first hashes behind the current item's row loop -- so the
+    // chain entry -> n/slot -> hashes -> rows of dependent HBM latencies is hidden behind the previous item's work.
+    uint32_t item = (uint32_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
+    if (item >= n_work)
+        return;
+    auto load_entry = [&](uint32_t it) -> uint2 { return it < n_work ? p.work_in[it] : make_uint2(0xFFFFFFFFu, 0u); };
+    struct Meta
+    {
+        uint32_t read, ibf, n, W, shift, n_mruns, gp_log2;
+        uint64_t slot, S;
+        const uint64_t* rows;
+        const uint32_t* bin_tab;
+        const uint4*    mruns;
+        bool            valid, reg_ok;
+    };
+    auto load_meta = [&](uint2 wk) -> Meta {
+        Meta m{};
+        m.read  = (uint32_t)__builtin_amdgcn_readfirstlane((int)wk.x);
+        m.ibf   = (uint32_t)__builtin_amdgcn_readfirstlane((int)wk.y);
+        m.valid = m.read != 0xFFFFFFFFu; // hole left by a chunked append of the previous level
+        if (m.valid)
+        {
+            const GnHibfIbfDev* f = p.ibfs + m.ibf;
+            m.n       = p.n_hashes[m.read];
+            m.slot    = p.slot_off[m.read];
+            m.W       = f->W;
+            m.S       = f->S;
+            m.shift   = f->shift;
+            m.rows    = f->rows;
+            m.bin_tab = f->bin_tab;
+            m.mruns   = f->mruns;
+            m.n_mruns = f->n_mruns;
+            uint32_t g = 0;
+            while ((1u << g) < m.W && g < 6)
+                ++g;
+            m.gp_log2 = g;
+            m.reg_ok  = m.W <= GN_HIBF_REG_WMAX && m.n <= GN_HIBF_REG_NMAX && m.n >= 1;
+        }
+        return m;
+    };
+    // the first two iterations' hashes of an item (q = hsub, H + hsub)
+    auto load_hashes = [&](const Meta& m, uint64_t& h0, uint64_t& h1) {
+        h0 = h1 = 0;
+        if (m.valid && m.reg_ok)
+        {
+            const uint32_t H = GN_WAVE >> m.gp_log2, hs = (uint32_t)lane >> m.gp_log2;
+            const uint32_t q0 = hs < m.n ? hs : m.n - 1, q1 = H + hs < m.n ? H + hs : m.n - 1;
+            h0 = p.hashes[m.slot + q0];
+            h1 = p.hashes[m.slot + q1];
+        }
+    };
+
+    uint2 wk_next = load_entry(item + nwaves);
+    Meta  cur     = load_meta(load_entry(item));
+    uint64_t hA, hB;
+    load_hashes(cur, hA, hB);
+
+    for (;;)
+    {
+        const uint32_t item_n  = item + nwaves;
+        const bool     more    = item_n < n_work;
+        const uint2    wk_nn   = load_entry(item_n + nwaves);  // two ahead
+        Meta           nxt     = load_meta(wk_next);           // one ahead (wk_next arrived during the previous item)
+        uint64_t       hA_n = 0, hB_n = 0;
+        bool           prefetched = false;
+
+        if (cur.valid && !cur.reg_ok)
+        {
+            if (cur.n >= 1 && lane == 0) // n == 0 cannot be queued (status OK reads have n >= 1), be safe anyway
+            {
+                const unsigned long long o = atomicAdd(p.defer_count, 1ULL);
+                if (o < p.work_cap)
+                    p.defer_out[o] = make_uint2(cur.read, cur.ibf);
+            }
+        }
+        else if (cur.valid)
+        {
+            const uint32_t n    = cur.n;
+            const uint32_t W    = cur.W;
+            const uint32_t Gp   = 1u << cur.gp_log2;
+            const uint32_t H    = GN_WAVE >> cur.gp_log2;
+            const uint32_t gl   = (uint32_t)lane & (Gp - 1);
+            const uint32_t hsub = (uint32_t)lane >> cur.gp_log2;
+            const bool     col_act = gl < W;
+            const uint32_t gl_ld   = col_act ? gl : 0u; // lanes without a column load a word that exists and are masked below
+            const uint64_t* hs     = p.hashes + cur.slot;
+
+            uint32_t nib[2][4], byt[2][4][2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    nib[d][j]    = 0;
+                    byt[d][j][0] = 0;
+                    byt[d][j][1] = 0;
+                }
+            uint32_t acc_n = 0;
+            auto spill = [&]() {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                    {
+                        byt[d][j][0] += nib[d][j] & 0x0F0F0F0Fu;
+                        byt[d][j][1] += (nib[d][j] >> 4) & 0x0F0F0F0Fu;
+                        nib[d][j] = 0;
+                    }
+            };
+            struct Rows
+            {
+                uint2 m[HF];
+            };
+            // h row requests of hash value v; issued by every lane unconditionally (see gn_ibf_count_fast_kernel)
+            auto issue = [&](uint64_t v, Rows& R) {
+#pragma unroll
+                for (int i = 0; i < HF; ++i)
+                {
+                    const uint32_t row = gn_hibf_row(v, (uint32_t)i, cur.shift, cur.S);
+                    R.m[i]             = *reinterpret_cast<const uint2*>(cur.rows + ((uint64_t)row * W + gl_ld));
+                }
+            };
+            auto consume = [&](const Rows& R, uint32_t it) {
+                const uint32_t on = (col_act && it * H + hsub < n) ? 0xFFFFFFFFu : 0u;
+                uint32_t       a0 = R.m[0].x & on, a1 = R.m[0].y & on;
+#pragma unroll
+                for (int i = 1; i < HF; ++i)
+                {
+                    a0 &= R.m[i].x;
+                    a1 &= R.m[i].y;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    nib[0][j] += (a0 >> j) & 0x11111111u;
+                    nib[1][j] += (a1 >> j) & 0x11111111u;
+                }
+                if (++acc_n == 15)
+                {
+                    spill();
+                    acc_n = 0;
+                }
+            };
+            auto hash_of = [&](uint32_t it) -> uint64_t {
+                if (it == 0)
+                    return hA;
+                if (it == 1)
+                    return hB;
+                const uint32_t q = it * H + hsub;
+                return hs[q < n ? q : n - 1];
+            };
+
+            const uint32_t iters = (n + H - 1) / H;
+            Rows           A, B;
+            issue(hash_of(0), A);
+            uint32_t it = 0;
+            for (; it + 2 < iters; it += 2)
+            {
+                issue(hash_of(it + 1), B);
+                consume(A, it);
+                issue(hash_of(it + 2), A);
+                consume(B, it + 1);
+            }
+            const bool two = it + 1 < iters;
+            if (two)
+                issue(hash_of(it + 1), B);
+            if (more)
+            {
+                load_hashes(nxt, hA_n, hB_n); // fly behind the last row loads and the epilogue
+                prefetched = true;
+            }
+            consume(A, it);
+            if (two)
+                consume(B, it + 1);
+            if (acc_n)
+                spill();
+            my_bytes += (unsigned long long)n * HF * W * 8ull; // algorithmic bytes of this visit
+
+            // ---- epilogue: add the H hash groups, SWAR compare with the cutoff ----
+            // threshold_cutoff = max(1, ceil(n * rel_cutoff))  (GanonClassify.cpp:492-495,720-724); passed to bulk_count (:553)
+            uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
+            if (T == 0)
+                T = 1;
+            const uint32_t Kc  = (0x80u - T) * 0x01010101u; // counts <= n <= 127, 1 <= T <= 127: no carries between bytes
+            uint32_t       any = 0;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                    {
+                        uint32_t x = byt[d][j][pp];
+                        for (uint32_t off = Gp; off < GN_WAVE; off <<= 1)
+                            x += __shfl_xor(x, (int)off);
+                        byt[d][j][pp] = x;
+                        any |= (x + Kc) & 0x80808080u;
+                    }
+            const bool owner = hsub == 0 && col_act;
+            // single-bin runs: every bin with count >= T is a hit (sum of one bin; :445-458 with a run of length one)
+            uint32_t c0 = 0, c1 = 0; // candidate bits of the lane's two dwords
+            if (owner && any)
+            {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                    {
+                        c0 |= (((byt[0][j][pp] + Kc) & 0x80808080u) >> 7) << (4 * pp + j);
+                        c1 |= (((byt[1][j][pp] + Kc) & 0x80808080u) >> 7) << (4 * pp + j);
+                    }
+            }
+            while (__ballot((c0 | c1) != 0))
+            {
+                bool     merged = false, leaf = false;
+                uint32_t tgt = 0, sum = 0;
+                if (c0 | c1)
+                {
+                    const uint32_t d = c0 ? 0u : 1u;
+                    uint32_t&      c = c0 ? c0 : c1;
+                    const uint32_t t = (uint32_t)__builtin_ctz(c);
+                    c &= c - 1;
+                    const uint32_t y = t >> 3, pp = (t >> 2) & 1u, j = t & 3u;
+                    uint32_t       reg = 0;
+#pragma unroll
+                    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq)
+                                if ((uint32_t)dd == d && (uint32_t)jj == j && (uint32_t)qq == pp)
+                                    reg = byt[dd][jj][qq];
+                    sum                = (reg >> (8 * y)) & 0xFFu;
+                    const uint32_t tab = cur.bin_tab[gl * 64 + 32 * d + t];
+                    if (tab != 0xFFFFFFFFu)
+                    {
+                        merged = (tab & 0x80000000u) != 0;
+                        leaf   = !merged;
+                        tgt    = tab & 0x7FFFFFFFu;
+                    }
+                }
+                app.push(p, lane, merged, leaf, cur.read, tgt, sum);
+            }
+            // multi-bin runs (split user bins): sums from an image of the owner lanes' byte counters
+            if (cur.n_mruns)
+            {
+                gn_hibf_wave_sync();
+                if (owner)
+                {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int pp = 0; pp < 2; ++pp)
+                                img[gl * 16 + (d * 4 + j) * 2 + pp] = byt[d][j][pp];
+                }
+                gn_hibf_wave_sync();
+                for (uint32_t r0 = 0; r0 < cur.n_mruns; r0 += GN_WAVE)
+                {
+                    const uint32_t r = r0 + (uint32_t)lane;
+                    bool           merged = false, leaf = false;
+                    uint32_t       tgt = 0, sum = 0;
+                    if (r < cur.n_mruns)
+                    {
+                        const uint4 run = cur.mruns[r]; // first bin, n bins, user bin, -
+                        for (uint32_t b = run.x; b < run.x + run.y; ++b)
+                        {
+                            const uint32_t t = b & 63u, d = t >> 5, tt = t & 31u;
+                            const uint32_t v = img[(b >> 6) * 16 + (d * 4 + (tt & 3u)) * 2 + ((tt >> 2) & 1u)];
+                            sum              = (sum + ((v >> (8 * (tt >> 3))) & 0xFFu)) & 0xFFFFu; // value_t = uint16_t wraps (hibf.hpp:438,442)
+                        }
+                        leaf = sum >= T; // :455
+                        tgt  = run.z;
+                    }
+                    app.push(p, lane, merged, leaf, cur.read, tgt, sum);
+                }
+            }
+        }
+        if (more && !prefetched) // (holes and deferred items: nothing to hide the loads behind)
+            load_hashes(nxt, hA_n, hB_n);
+
+        if (!more)
+            break;
+        item    = item_n;
+        cur     = nxt;
+        hA      = hA_n;
+        hB      = hB_n;
+        wk_next = wk_nn;
+    }
+    app.finish(p, lane);
+    if (lane == 0 && my_bytes)
+        atomicAdd(&p.ctr[2], my_bytes);
+}
+
+// ================================================================================================
+// LDS-counter level kernel (IBFs wider than 64 words, reads with more than 127 minimisers)
+// ================================================================================================
 __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_hl[];
@@ -68,11 +496,13 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     uint32_t*      cnt    = gn_hl + (size_t)wave * p.lds_bins;
 
-    unsigned long long my_bytes = 0, my_matches = 0;
-    unsigned long long wq_base = 0, mq_base = 0; // current chunk cursors (wave-uniform)
-    uint32_t           wq_left = 0, mq_left = 0;
+    unsigned long long nw64   = *p.count_in;
+    const uint32_t     n_work = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
 
-    for (uint32_t item = blockIdx.x * (blockDim.x >> 6) + wave; item < p.n_work; item += nwaves)
+    GnHibfAppender     app;
+    unsigned long long my_bytes = 0;
+
+    for (uint32_t item = blockIdx.x * (blockDim.x >> 6) + wave; item < n_work; item += nwaves)
     {
         const uint2    wk   = p.work_in[item];
         const uint32_t read = wk.x;
@@ -146,76 +576,13 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
                 tgt    = merged ? (int32_t)run.w : (int32_t)run.z;
                 hit    = sum >= T; // :447 / :455
             }
-            // merged bins -> next level queue
-            const uint64_t mm = __ballot(hit && merged);
-            if (mm)
-            {
-                const uint32_t need = (uint32_t)__popcll(mm);
-                if (need > wq_left)
-                {
-                    const uint32_t     take = need > GN_HIBF_CHUNK ? need : GN_HIBF_CHUNK;
-                    unsigned long long nb   = 0;
-                    if (lane == 0)
-                        nb = atomicAdd(&p.ctr[3], (unsigned long long)take);
-                    nb = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(nb >> 32)) << 32) |
-                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
-                    for (uint32_t i = lane; i < take; i += GN_WAVE) // sentinels first; real entries overwrite them
-                        if (nb + i < p.work_cap)
-                            p.work_out[nb + i] = make_uint2(0xFFFFFFFFu, 0u);
-                    wq_base = nb;
-                    wq_left = take;
-                }
-                if (hit && merged)
-                {
-                    const unsigned long long o = wq_base + __popcll(mm & ((1ULL << lane) - 1ULL));
-                    if (o < p.work_cap)
-                        p.work_out[o] = make_uint2(read, (uint32_t)tgt);
-                }
-                wq_base += need;
-                wq_left -= need;
-            }
-            // leaf runs -> matches
-            const uint64_t lm = __ballot(hit && !merged);
-            if (lm)
-            {
-                const uint32_t need = (uint32_t)__popcll(lm);
-                if (need > mq_left)
-                {
-                    const uint32_t     take = need > GN_HIBF_CHUNK ? need : GN_HIBF_CHUNK;
-                    unsigned long long nb   = 0;
-                    if (lane == 0)
-                        nb = atomicAdd(&p.ctr[0], (unsigned long long)take);
-                    nb = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(nb >> 32)) << 32) |
-                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nb);
-                    for (uint32_t i = lane; i < take; i += GN_WAVE)
-                        if (nb + i < p.match_cap)
-                            p.keys[nb + i] = ~0ULL; // sentinel: sorts last
-                    mq_base = nb;
-                    mq_left = take;
-                }
-                if (hit && !merged)
-                {
-                    const unsigned long long o = mq_base + __popcll(lm & ((1ULL << lane) - 1ULL));
-                    if (o < p.match_cap)
-                    {
-                        p.keys[o] = ((uint64_t)read << 32) | (uint32_t)tgt;
-                        p.vals[o] = sum;
-                    }
-                }
-                mq_base += need;
-                mq_left -= need;
-                my_matches += need;
-            }
+            app.push(p, lane, hit && merged, hit && !merged, read, (uint32_t)tgt, sum);
         }
         my_bytes += (unsigned long long)n * f.h * f.W * 8ull; // algorithmic bytes of this visit
     }
-    if (lane == 0)
-    {
-        if (my_bytes)
-            atomicAdd(&p.ctr[2], my_bytes);
-        if (my_matches)
-            atomicAdd(&p.ctr[6], my_matches);
-    }
+    app.finish(p, lane);
+    if (lane == 0 && my_bytes)
+        atomicAdd(&p.ctr[2], my_bytes);
 }
 
 __global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t n_reads, unsigned long long* count)
@@ -227,14 +594,13 @@ __global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t
     unsigned long long base = 0;
     if (lane == 0 && bm)
         base = atomicAdd(count, (unsigned long long)__popcll(bm));
-    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    base = gn_hibf_bcast64(base);
     if (ok)
         work[base + __popcll(bm & ((1ULL << lane) - 1ULL))] = make_uint2(r, 0u);
 }
 
 // sorted (key, raw sum) -> gn_match with the cap of select_matches (GanonClassify.cpp:561-564) + per-read histogram
-__global__ void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, const uint32_t* n_hashes,
+__global__ void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, uint32_t ub_bits, const uint32_t* n_hashes,
                                       gn_match* out, uint32_t* seg_count)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,11 +608,11 @@ __global__ void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals
         return;
     if (keys[i] == ~0ULL) // chunk hole (sorted to the end)
         return;
-    const uint32_t read = (uint32_t)(keys[i] >> 32);
+    const uint32_t read = (uint32_t)(keys[i] >> ub_bits);
     const uint32_t nh   = n_hashes[read];
     gn_match m;
     m.read   = read;
-    m.target = (uint32_t)keys[i];
+    m.target = (uint32_t)(keys[i] & ((1ULL << ub_bits) - 1ULL));
     m.count  = vals[i] > nh ? nh : vals[i];
     out[i]   = m;
     atomicAdd(&seg_count[read], 1u);
@@ -255,15 +621,27 @@ __global__ void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+static uint32_t gn_bits_for(uint64_t v) // smallest b with v < 2^b
+{
+    uint32_t b = 0;
+    while (b < 64 && (v >> b))
+        ++b;
+    return b;
+}
+
 int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const int64_t* const* next_ibf_id,
                   const int64_t* const* bin2userbin, uint64_t n_user_bins)
 {
-    std::vector<GnHibfIbfDev> dev(n_ibf);
-    uint32_t                  max_tb = 0;
+    if (n_user_bins >= (1ull << 31))
+        return gn_fail(GN_ERANGE, "more than 2^31 user bins");
+    std::vector<GnHibfIbfDev>          dev(n_ibf);
+    std::vector<std::vector<uint32_t>> children(n_ibf);
+    uint32_t                           max_tb = 0;
     for (uint32_t i = 0; i < n_ibf; ++i)
     {
         const uint64_t B = ibfs[i].bins;
-        std::vector<uint4> runs;
+        std::vector<uint4>    runs, mruns;
+        std::vector<uint32_t> tab((size_t)f->ibfs[i].W * 64, 0xFFFFFFFFu);
         uint64_t b = 0;
         while (b < B)
         {
@@ -277,6 +655,8 @@ int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const i
                     return gn_fail(GN_EINVAL, "ibf %u bin %llu: merged bin without a valid child ibf (%lld)", i,
                                    (unsigned long long)b, (long long)c);
                 runs.push_back(make_uint4((uint32_t)b, 1u, 0xFFFFFFFFu, (uint32_t)c));
+                tab[b] = 0x80000000u | (uint32_t)c;
+                children[i].push_back((uint32_t)c);
                 ++b;
             }
             else
@@ -285,26 +665,68 @@ int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const i
                 while (e < B && bin2userbin[i][e] == u)
                     ++e;
                 runs.push_back(make_uint4((uint32_t)b, (uint32_t)(e - b), (uint32_t)u, 0u));
+                if (e - b == 1)
+                    tab[b] = (uint32_t)u;
+                else
+                    mruns.push_back(runs.back());
                 b = e;
             }
         }
-        uint4* d_runs = nullptr;
+        uint4*    d_runs  = nullptr;
+        uint4*    d_mruns = nullptr;
+        uint32_t* d_tab   = nullptr;
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&d_runs), std::max<size_t>(1, runs.size()) * sizeof(uint4)));
         f->hibf_allocs.push_back(d_runs);
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&d_mruns), std::max<size_t>(1, mruns.size()) * sizeof(uint4)));
+        f->hibf_allocs.push_back(d_mruns);
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&d_tab), tab.size() * sizeof(uint32_t)));
+        f->hibf_allocs.push_back(d_tab);
         if (!runs.empty())
             GN_HIP(hipMemcpy(d_runs, runs.data(), runs.size() * sizeof(uint4), hipMemcpyHostToDevice));
-        dev[i].rows   = f->ibfs[i].d_rows;
-        dev[i].S      = f->ibfs[i].S;
-        dev[i].W      = (uint32_t)f->ibfs[i].W;
-        dev[i].B      = (uint32_t)f->ibfs[i].B;
-        dev[i].shift  = f->ibfs[i].shift;
-        dev[i].h      = f->ibfs[i].h;
-        dev[i].runs   = d_runs;
-        dev[i].n_runs = (uint32_t)runs.size();
-        max_tb        = std::max(max_tb, dev[i].W * 64u);
+        if (!mruns.empty())
+            GN_HIP(hipMemcpy(d_mruns, mruns.data(), mruns.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        GN_HIP(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        dev[i].rows    = f->ibfs[i].d_rows;
+        dev[i].S       = f->ibfs[i].S;
+        dev[i].W       = (uint32_t)f->ibfs[i].W;
+        dev[i].B       = (uint32_t)f->ibfs[i].B;
+        dev[i].shift   = f->ibfs[i].shift;
+        dev[i].h       = f->ibfs[i].h;
+        dev[i].runs    = d_runs;
+        dev[i].n_runs  = (uint32_t)runs.size();
+        dev[i].bin_tab = d_tab;
+        dev[i].mruns   = d_mruns;
+        dev[i].n_mruns = (uint32_t)mruns.size();
+        max_tb         = std::max(max_tb, dev[i].W * 64u);
+        if (dev[i].h != dev[0].h)
+            return gn_fail(GN_ERANGE, "IBFs of one HIBF with different numbers of hash functions (%u vs %u)", dev[i].h, dev[0].h);
     }
     if ((size_t)max_tb * 4 > 144 * 1024)
         return gn_fail(GN_ERANGE, "an IBF of the HIBF has %u technical bins; the level kernel supports up to 36864", max_tb);
+    // depth of the tree below IBF 0 = number of levels a batch can take (the level kernels are launched that many times)
+    {
+        std::vector<uint32_t> depth(n_ibf, 0);
+        std::vector<uint32_t> stack{ 0u };
+        depth[0]        = 1;
+        uint32_t deepest = 1;
+        while (!stack.empty())
+        {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            for (uint32_t c : children[i])
+            {
+                if (depth[i] + 1 > GN_HIBF_MAXDEPTH)
+                    return gn_fail(GN_EINVAL, "HIBF deeper than %d levels (cycle in next_ibf_id?)", GN_HIBF_MAXDEPTH);
+                if (depth[c] < depth[i] + 1)
+                {
+                    depth[c] = depth[i] + 1;
+                    deepest  = std::max(deepest, depth[c]);
+                    stack.push_back(c);
+                }
+            }
+        }
+        f->max_depth = deepest;
+    }
     GN_HIP(hipMalloc(reinterpret_cast<void**>(&f->d_hibf), n_ibf * sizeof(GnHibfIbfDev)));
     GN_HIP(hipMemcpy(f->d_hibf, dev.data(), n_ibf * sizeof(GnHibfIbfDev), hipMemcpyHostToDevice));
     f->n_user_bins = n_user_bins;
@@ -339,72 +761,107 @@ static int gn_hibf_ensure_sort_buffers(gn_stream* s)
     return GN_OK;
 }
 
-// Runs all levels, then sorts/group matches.  Synchronises the stream once per level (queue sizes are
-// data dependent) -- HIBFs are a handful of levels deep.
+// persistent grid = what is resident at once (the register budget decides: ~5 waves per SIMD)
+template <int HF>
+static void gn_hibf_launch_reg(const GnHibfLevelParams& p, uint32_t n_cu, uint32_t bpc, hipStream_t st)
+{
+    if (bpc == 0)
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_hibf_reg_kernel<HF>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        bpc = (uint32_t)per_cu;
+    }
+    hipLaunchKernelGGL((gn_hibf_reg_kernel<HF>), dim3(n_cu * bpc), dim3(256), 0, st, p);
+}
+
+// Runs all levels back to back (queue lengths stay on the device), synchronises ONCE, then sorts/groups the matches.
 int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
 {
     int rc = gn_hibf_ensure_sort_buffers(s);
     if (rc)
         return rc;
-    const uint32_t n = s->n_reads;
-    GN_HIP(hipMemsetAsync(s->d_ctr + 2, 0, 2 * sizeof(unsigned long long), st)); // algo bytes, work count
+    const uint32_t n      = s->n_reads;
+    const uint32_t depth  = f->max_depth ? f->max_depth : 1;
+    const uint32_t NL     = GN_HIBF_MAXDEPTH + 1;
+    const uint32_t ub_bits = std::max(1u, gn_bits_for(f->n_user_bins ? f->n_user_bins - 1 : 0));
+    const uint32_t rd_bits = std::max(1u, gn_bits_for(n)); // a read index is < n <= 2^rd_bits - 1: below the all-ones sentinel
+    if (ub_bits + rd_bits > 64)
+        return gn_fail(GN_ERANGE, "read index and user bin do not fit one 64-bit sort key");
+    GN_HIP(hipMemsetAsync(s->d_ctr + 2, 0, 2 * sizeof(unsigned long long), st)); // algo bytes, (unused)
     GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
+    GN_HIP(hipMemsetAsync(s->d_hctr, 0, 2 * NL * sizeof(unsigned long long), st));
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
     if (n)
-        hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n,
-                           s->d_ctr + 3);
-    int      cur   = 0;
-    uint32_t depth = 0;
-    while (true)
+        hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n, s->d_hctr);
+
+    const uint32_t h     = f->ibfs[0].h;
+    const bool     no_reg = getenv("GANON_HIP_HIBF_NO_REG") != nullptr; // tests / A-B: everything through the LDS kernel
+    const uint32_t reg_bpc = getenv("GANON_HIP_HIBF_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_HIBF_BPC")) : 0u; // 0 = occupancy
+    for (uint32_t lvl = 0; lvl < depth && n; ++lvl)
     {
-        GN_HIP(hipStreamSynchronize(st));
-        GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        uint64_t n_work = s->h_ctr[3];
-        if (n_work == 0)
-            break;
-        if (n_work > s->work_cap)
-        {
-            // the queue overflowed: grow both queues and restart the whole batch
-            for (int i = 0; i < 2; ++i)
-            {
-                hipFree(s->d_work[i]);
-                s->d_work[i] = nullptr;
-            }
-            s->work_cap = (uint32_t)std::min<uint64_t>(n_work + n_work / 4 + 1024, 0xFFFFFFF0ull);
-            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[0]), (size_t)s->work_cap * sizeof(uint2)));
-            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[1]), (size_t)s->work_cap * sizeof(uint2)));
-            GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
-            return gn_hibf_classify(s, f, st);
-        }
-        if (++depth > 64)
-            return gn_fail(GN_EINVAL, "HIBF deeper than 64 levels (cycle in next_ibf_id?)");
-        GN_HIP(hipMemsetAsync(s->d_ctr + 3, 0, sizeof(unsigned long long), st));
         GnHibfLevelParams p{};
-        p.ibfs       = f->d_hibf;
-        p.hashes     = s->d_hashes;
-        p.slot_off   = s->d_slot_off;
-        p.n_hashes   = s->d_nh;
-        p.rel_cutoff = s->rel_cutoff;
-        p.work_in    = s->d_work[cur];
-        p.n_work     = (uint32_t)n_work;
-        p.work_out   = s->d_work[cur ^ 1];
-        p.work_cap   = s->work_cap;
-        p.ctr        = s->d_ctr;
-        p.keys       = s->d_keys[0];
-        p.vals       = s->d_vals[0];
-        p.match_cap  = s->match_cap;
-        p.lds_bins   = f->max_bins;
+        p.ibfs        = f->d_hibf;
+        p.hashes      = s->d_hashes;
+        p.slot_off    = s->d_slot_off;
+        p.n_hashes    = s->d_nh;
+        p.rel_cutoff  = s->rel_cutoff;
+        p.work_in     = s->d_work[lvl & 1];
+        p.count_in    = s->d_hctr + lvl;
+        p.work_out    = s->d_work[(lvl + 1) & 1];
+        p.count_out   = s->d_hctr + lvl + 1;
+        p.defer_out   = s->d_hdefer;
+        p.defer_count = s->d_hctr + NL + lvl;
+        p.work_cap    = s->work_cap;
+        p.ctr         = s->d_ctr;
+        p.keys        = s->d_keys[0];
+        p.vals        = s->d_vals[0];
+        p.match_cap   = s->match_cap;
+        p.ub_bits     = ub_bits;
+        p.lds_bins    = f->max_bins;
+        if (!no_reg)
+        {
+            switch (h)
+            {
+                case 1: gn_hibf_launch_reg<1>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 2: gn_hibf_launch_reg<2>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 3: gn_hibf_launch_reg<3>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 4: gn_hibf_launch_reg<4>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
+                default: gn_hibf_launch_reg<5>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
+            }
+            GN_HIP(hipGetLastError());
+            p.work_in  = s->d_hdefer;
+            p.count_in = s->d_hctr + NL + lvl;
+        }
+        // LDS-counter kernel: the deferred items (or, with the switch above, the whole level)
         const uint32_t wpb = (size_t)f->max_bins * 4 * 4 <= 64 * 1024 ? 4 : 1; // waves per block by LDS need
         const size_t   lds = (size_t)f->max_bins * 4 * wpb;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_hibf_level_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        uint32_t blocks = (p.n_work + wpb - 1) / wpb;
-        const uint32_t max_blocks = (uint32_t)f->n_cu * (wpb == 4 ? 8u : 16u);
-        if (blocks > max_blocks)
-            blocks = max_blocks;
-        hipLaunchKernelGGL(gn_hibf_level_kernel, dim3(blocks), dim3(wpb * 64), lds, st, p);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_hibf_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        hipLaunchKernelGGL(gn_hibf_level_kernel, dim3((uint32_t)f->n_cu * (wpb == 4 ? 8u : 16u)), dim3(wpb * 64), lds, st, p);
         GN_HIP(hipGetLastError());
-        cur ^= 1;
+    }
+    // the one synchronisation of the batch: queue lengths (overflow check) and the match cursor (sort size)
+    GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, 2 * NL * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipStreamSynchronize(st));
+    uint64_t worst = 0;
+    for (uint32_t i = 0; i < 2 * NL; ++i)
+        worst = std::max<uint64_t>(worst, s->h_hctr[i]);
+    if (worst > s->work_cap)
+    {
+        // a queue overflowed (entries past the capacity were dropped): grow the queues and run the batch again
+        for (uint2** q : { &s->d_work[0], &s->d_work[1], &s->d_hdefer })
+        {
+            hipFree(*q);
+            *q = nullptr;
+        }
+        s->work_cap = (uint32_t)std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFF0ull);
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[0]), (size_t)s->work_cap * sizeof(uint2)));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[1]), (size_t)s->work_cap * sizeof(uint2)));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_hdefer), (size_t)s->work_cap * sizeof(uint2)));
+        GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
+        return gn_hibf_classify(s, f, st);
     }
     // group: radix sort by (read, user bin), cap counts, histogram per read, exclusive scan
     const uint64_t nm = s->h_ctr[0];
@@ -416,9 +873,9 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
             return gn_fail(GN_ERANGE, "more than 2^31 matches in one batch");
         size_t tmp = s->sort_tmp_bytes;
         GN_HIP(hipcub::DeviceRadixSort::SortPairs(s->d_sort_tmp, tmp, s->d_keys[0], s->d_keys[1], s->d_vals[0], s->d_vals[1],
-                                                  (int)nm, 0, 64, st));
+                                                  (int)nm, 0, (int)(ub_bits + rd_bits), st));
         hipLaunchKernelGGL(gn_hibf_finish_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, s->d_keys[1],
-                           s->d_vals[1], nm, s->d_nh, s->d_sorted, s->d_seg_count);
+                           s->d_vals[1], nm, ub_bits, s->d_nh, s->d_sorted, s->d_seg_count);
     }
     size_t tmp = s->scan_tmp_bytes;
     GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(n + 1), st));
@@ -430,6 +887,7 @@ int gn_hibf_dense(gn_stream* s, uint32_t rb, uint32_t re, uint16_t* counts)
 {
     gn_filter*            f  = s->f;
     const uint64_t        nm = s->n_matches;
+    const uint32_t        ub_bits = std::max(1u, gn_bits_for(f->n_user_bins ? f->n_user_bins - 1 : 0));
     std::vector<uint64_t> keys(nm ? nm : 1);
     std::vector<uint32_t> vals(nm ? nm : 1);
     if (nm)
@@ -440,9 +898,9 @@ int gn_hibf_dense(gn_stream* s, uint32_t rb, uint32_t re, uint16_t* counts)
     std::fill(counts, counts + (size_t)(re - rb) * f->n_user_bins, (uint16_t)0);
     for (uint64_t i = 0; i < nm; ++i)
     {
-        const uint32_t r = (uint32_t)(keys[i] >> 32);
+        const uint32_t r = (uint32_t)(keys[i] >> ub_bits);
         if (r >= rb && r < re)
-            counts[(size_t)(r - rb) * f->n_user_bins + (uint32_t)keys[i]] = (uint16_t)vals[i];
+            counts[(size_t)(r - rb) * f->n_user_bins + (uint32_t)(keys[i] & ((1ULL << ub_bits) - 1ULL))] = (uint16_t)vals[i];
     }
     return GN_OK;
 }

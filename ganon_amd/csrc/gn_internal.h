@@ -12,6 +12,7 @@
 #define GN_MAX_CHUNKS 64 // pipeline chunks per batch (minimiser on the side stream || count on the main stream)
 // candidate-driven select of the generic count kernel: targets with more bins than this are scanned from a list
 #define GN_CAND_NBIG 4u
+#define GN_HIBF_MAXDEPTH 64
 #define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
                    // [6] exact match total [8..71] total-hashes shards
 
@@ -131,6 +132,12 @@ struct GnHibfIbfDev
     uint32_t        W, B, shift, h;
     const uint4*    runs;   // per run: first bin, n bins, user bin (0xFFFFFFFF = merged), child ibf
     uint32_t        n_runs;
+    // register-counter level kernel (W <= 64): per technical bin (64*W entries) what a single-bin run leads to --
+    // 0x80000000 | child ibf (merged bin), user bin (leaf), 0xFFFFFFFF (bin of a multi-bin run, or padding) -- and the
+    // runs of more than one bin (split user bins), which are summed from an LDS image of the counters
+    const uint32_t* bin_tab;
+    const uint4*    mruns;
+    uint32_t        n_mruns;
 };
 
 // ---- misc kernels ---------------------------------------------------------------------------
@@ -220,6 +227,9 @@ struct gn_stream
     size_t              scan_tmp_bytes = 0;
     // hibf work queues + sort buffers
     uint2*        d_work[2]{ nullptr, nullptr };
+    uint2*        d_hdefer = nullptr;  // (read, ibf) items the register-counter kernel leaves to the LDS-counter kernel
+    unsigned long long* d_hctr = nullptr; // per level: [l] queue length of level l, [GN_HIBF_MAXDEPTH+1+l] deferred items
+    unsigned long long* h_hctr = nullptr; // pinned copy
     uint32_t      work_cap = 0;
     uint64_t*     d_keys[2]{ nullptr, nullptr };
     uint32_t*     d_vals[2]{ nullptr, nullptr };

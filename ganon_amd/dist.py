@@ -18,8 +18,17 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def init(backend: str, device=None) -> None:
+    import socket
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        # stand-alone process (no launcher): a world of one on a free port -- the collectives still go through RCCL
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     os.environ.setdefault("MASTER_PORT", "29500")
     if not dist.is_initialized():
         kw = {}

@@ -244,6 +244,50 @@ def test_hibf_parity(hip, n_ub, tmax, depth, rel_cutoff):
     assert st.timings()["algo_bytes"] == algo
 
 
+@pytest.mark.parametrize("n_ub,tmax,depth,h,rel_cutoff", [(300, 64, 2, 2, 0.3), (700, 128, 3, 4, 0.6), (400, 320, 2, 5, 0.2),
+                                                           (6000, 4480, 2, 3, 0.5), (150, 64, 2, 1, 0.9)])
+def test_hibf_register_kernel_vs_lds_kernel_vs_oracle(hip, monkeypatch, n_ub, tmax, depth, h, rel_cutoff):
+    # gn_hibf_reg_kernel (W <= 64 words, n <= 127) against gn_hibf_level_kernel (everything; forced with the switch) and
+    # the oracle: short, medium (n ~ 70) and long reads (n > 127: deferred to the LDS kernel inside a level), 1..5 hash
+    # functions, an IBF wider than 64 words (tmax 4480 -> W = 70: deferred), split user bins, holes in the queues
+    k, w = 19, 31
+    rng = np.random.default_rng(n_ub * 7 + h)
+    genomes = {ub: gu.random_seq(rng, 3000) for ub in range(0, n_ub, 5)}
+    uh = {ub: np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)) for ub, g in genomes.items()}
+    hb = gf.random_hibf(n_ub, tmax, depth, seed=n_ub + h, density=0.3, hash_funs=h, user_hashes=uh)
+    flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+    keys = sorted(genomes)
+    seqs = []
+    for i in range(400):
+        L = (150, 150, 600, 2200)[i % 4] if i % 16 else 90
+        if i % 2:
+            g = genomes[keys[i % len(keys)]]
+            p = int(rng.integers(0, 3000 - L))
+            seqs.append(g[p:p + L])
+        else:
+            seqs.append(gu.random_seq(rng, L))
+    st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
+    assert nh.max() > 127 and (nh[nh > 0] <= 127).any()
+    tm = st.timings()
+    monkeypatch.setenv("GANON_HIP_HIBF_NO_REG", "1")
+    st2, nh2, status2, mo2, m2 = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
+    monkeypatch.delenv("GANON_HIP_HIBF_NO_REG")
+    assert np.array_equal(nh, nh2) and np.array_equal(mo, mo2) and np.array_equal(m, m2)
+    assert st2.timings()["algo_bytes"] == tm["algo_bytes"]
+    ho, hs = st.fetch_hashes()
+    n_true, algo = 0, 0
+    for i in range(len(seqs)):
+        hh = hs[int(ho[i]):int(ho[i + 1])]
+        thr = oracle.threshold_cutoff(len(hh), rel_cutoff)
+        exp_counts = hb.bulk_count(hh, thr)
+        exp = [(int(u), int(min(c, len(hh)))) for u, c in enumerate(exp_counts) if c > 0]
+        got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+        assert got == exp, (i, len(hh), got[:5], exp[:5])
+        n_true += len(exp)
+        algo += hb.visited_bytes(hh, thr)
+    assert n_true > 50 and tm["algo_bytes"] == algo
+
+
 # --------------------------------------------------------------------------------------------- bin-range partition
 def test_partition_slices_hip(hip):
     # config-5 style column slices on ONE GPU: the union of the per-slice results == the unpartitioned filter
