@@ -68,7 +68,7 @@ def run_extra(name: str, timeout: int):
     t0 = time.time()
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
-        line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{\"metric\"")]
         if p.returncode == 0 and line:
             r = json.loads(line[-1])
             return {"workload": name, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
@@ -317,11 +317,19 @@ def main() -> int:
     if rank == 0:
         if not args.no_extra and world == 1 and args.workload == "flat8g" and not args.reads and not args.rows:
             result["other_workloads"] = [run_extra(w, args.extra_timeout) for w in EXTRA_WORKLOADS]
-        print(json.dumps(result), flush=True)
     if world > 1 or kind == "slice":
         import torch.distributed as dist
         gdist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio (buffered until exit when stdout is a pipe): push it out first so that
+        # the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(json.dumps(result), flush=True)
     return 0
 
 

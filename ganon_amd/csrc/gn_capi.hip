@@ -742,7 +742,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
     ok(gn_dmalloc(&s->d_slot_off, (size_t)max_reads + 1));
     ok(gn_dmalloc(&s->d_hashes, max_bases)); // #windows <= #bases
     ok(gn_dmalloc(&s->d_nh, max_reads));
-    ok(gn_dmalloc(&s->d_status, max_reads));
+    ok(gn_dmalloc(&s->d_status, (size_t)max_reads + 8)); // (+8: the HIBF level-0 kernel reads status bytes as aligned dwords)
     ok(gn_dmalloc(&s->d_matches, s->match_cap));
     ok(gn_dmalloc(&s->d_sorted, s->match_cap));
     ok(gn_dmalloc(&s->d_ctr, GN_NCTR));

@@ -56,6 +56,23 @@ __device__ __forceinline__ unsigned long long gn_hibf_bcast64(unsigned long long
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
+// Wave-uniform loads through the scalar cache (s_load into SGPRs): the data is read-only for the whole launch, the
+// address is the same in every lane.  They use their own counter (lgkmcnt), so waiting for row loads (vmcnt) never waits
+// for them and vice versa, and they need no VGPRs.  The compiler only emits them for the constant address space.
+template <typename T>
+__device__ __forceinline__ T gn_sload(const T* ptr)
+{
+    typedef const __attribute__((address_space(4))) T* cptr;
+    return *(cptr)(uintptr_t)ptr;
+}
+// A pointer that was itself loaded from memory is "flat" to the compiler (flat_load counts on both wait counters and
+// forces conservative waits); filter rows and tables live in global memory.
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* gn_global(const T* ptr)
+{
+    return (const __attribute__((address_space(1))) T*)(uintptr_t)ptr;
+}
+
 struct GnHibfLevelParams
 {
     const GnHibfIbfDev*       ibfs;
@@ -76,6 +93,8 @@ struct GnHibfLevelParams
     uint64_t                  match_cap;
     uint32_t                  ub_bits;
     uint32_t                  lds_bins;  // LDS kernel: counters per wave
+    uint32_t                  n_reads;   // level 0 of the register-counter kernel: the reads are the items
+    const uint8_t*            status;
 };
 
 #define GN_HIBF_CHUNK 64u // wave-private slices of the work queue / match buffer (one global atomic per slice)
@@ -174,144 +193,167 @@ struct GnHibfAppender
 #define GN_HIBF_REG_NMAX 127u
 #define GN_HIBF_REG_WMAX 64u
 
-template <int HF>
+// x + (x rotated right by N lanes inside its row of 16 lanes): one DPP-modified add, no LDS crossbar
+template <int N>
+__device__ __forceinline__ uint32_t gn_hibf_add_ror(uint32_t x)
+{
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x120 + N, 0xF, 0xF, false);
+}
+
+// LEVEL0: the items are the reads of the batch themselves (read i against IBF 0, if its status is OK) -- no queue, no
+// seeding pass.  Deeper levels read (read, ibf) entries that the previous level appended.
+template <int HF, bool LEVEL0>
 __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
 {
     __shared__ uint32_t gn_img[4][GN_WAVE * 16]; // per wave: the byte counters of the owner lanes (multi-bin runs only)
     const int      lane   = threadIdx.x & (GN_WAVE - 1);
     const int      wave   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t stride = gridDim.x * (blockDim.x >> 6);
     uint32_t*      img    = gn_img[wave];
 
-    unsigned long long nw64 = *p.count_in;
-    const uint32_t     n_work = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
+    uint32_t n_work;
+    if constexpr (LEVEL0)
+        n_work = p.n_reads;
+    else
+    {
+        const unsigned long long nw64 = *p.count_in;
+        n_work                        = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
+    }
+    uint32_t item = (uint32_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
+    if (item >= n_work)
+        return;
 
     GnHibfAppender     app;
     unsigned long long my_bytes = 0;
 
-    // Software pipeline over a wave's items (stride nwaves): the queue entry is fetched two items ahead, the read's
-    // metadata and the IBF descriptor one item ahead, its first hashes behind the current item's row loop -- so the
-    // chain entry -> n/slot -> hashes -> rows of dependent HBM latencies is hidden behind the previous item's work.
-    uint32_t item = (uint32_t)blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
-    if (item >= n_work)
-        return;
-    auto load_entry = [&](uint32_t it) -> uint2 { return it < n_work ? p.work_in[it] : make_uint2(0xFFFFFFFFu, 0u); };
+    // ---- software pipeline over a wave's items (item, item + stride, ...) ------------------------------------------
+    // Everything an item needs arrives before the item is reached: its queue entry is fetched four items ahead, its
+    // metadata (n, hash slot, IBF shape; wave-uniform -> scalar loads into SGPRs) three ahead, its first hashes two
+    // ahead, and its first two row sets are requested one item ahead -- while the previous item's counters are being
+    // reduced and thresholded.  Nothing is waited for at the point where it is requested.
     struct Meta
     {
-        uint32_t read, ibf, n, W, shift, n_mruns, gp_log2;
-        uint64_t slot, S;
+        uint32_t        read, ibf, n, W, shift, n_mruns, S;
+        uint64_t        slot;
         const uint64_t* rows;
-        const uint32_t* bin_tab;
-        const uint4*    mruns;
-        bool            valid, reg_ok;
+        bool            valid;
+    };
+    // (item indices are wave-uniform: block index and an SGPR wave index)
+    auto load_entry = [&](uint32_t it) -> uint2 {
+        if (it >= n_work)
+            return make_uint2(0xFFFFFFFFu, 0u);
+        if constexpr (LEVEL0)
+        {
+            const uint32_t four = gn_sload(reinterpret_cast<const uint32_t*>(p.status) + (it >> 2)); // status bytes it&~3 ..
+            return make_uint2(((four >> (8u * (it & 3u))) & 0xFFu) == GN_READ_OK ? it : 0xFFFFFFFFu, 0u);
+        }
+        else
+        {
+            const uint64_t e = gn_sload(reinterpret_cast<const uint64_t*>(p.work_in) + it);
+            return make_uint2((uint32_t)e, (uint32_t)(e >> 32));
+        }
     };
     auto load_meta = [&](uint2 wk) -> Meta {
         Meta m{};
-        m.read  = (uint32_t)__builtin_amdgcn_readfirstlane((int)wk.x);
-        m.ibf   = (uint32_t)__builtin_amdgcn_readfirstlane((int)wk.y);
-        m.valid = m.read != 0xFFFFFFFFu; // hole left by a chunked append of the previous level
+        m.read  = wk.x;
+        m.ibf   = wk.y;
+        m.valid = m.read != 0xFFFFFFFFu; // hole left by a chunked append of the previous level / read that is not counted
         if (m.valid)
         {
             const GnHibfIbfDev* f = p.ibfs + m.ibf;
-            m.n       = p.n_hashes[m.read];
-            m.slot    = p.slot_off[m.read];
-            m.W       = f->W;
-            m.S       = f->S;
-            m.shift   = f->shift;
-            m.rows    = f->rows;
-            m.bin_tab = f->bin_tab;
-            m.mruns   = f->mruns;
-            m.n_mruns = f->n_mruns;
-            uint32_t g = 0;
-            while ((1u << g) < m.W && g < 6)
-                ++g;
-            m.gp_log2 = g;
-            m.reg_ok  = m.W <= GN_HIBF_REG_WMAX && m.n <= GN_HIBF_REG_NMAX && m.n >= 1;
+            m.n       = gn_sload(p.n_hashes + m.read);
+            m.slot    = gn_sload(p.slot_off + m.read);
+            m.W       = gn_sload(&f->W);
+            m.S       = (uint32_t)gn_sload(&f->S); // (bin_size < 2^32 is checked at upload)
+            m.shift   = gn_sload(&f->shift);
+            m.rows    = gn_sload(&f->rows);
+            m.n_mruns = gn_sload(&f->n_mruns);
         }
         return m;
     };
-    // the first two iterations' hashes of an item (q = hsub, H + hsub)
+    auto gp_of = [](uint32_t W) -> uint32_t { // lanes per row = 1 << gp
+        uint32_t g = W <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(W - 1);
+        return g < 6 ? g : 6u;
+    };
+    // items this kernel counts itself: rows of at most one wave, counters that fit (4-bit per lane in the loop: at most
+    // 15 iterations; 8-bit after the groups are added: at most 127 minimisers)
+    auto reg_ok = [&](const Meta& m) -> bool {
+        return m.valid && m.W <= GN_HIBF_REG_WMAX && m.n >= 1 && m.n <= GN_HIBF_REG_NMAX && m.n <= 15u * (GN_WAVE >> gp_of(m.W));
+    };
+    // the hashes of the first two iterations of an item (q = hsub, H + hsub)
     auto load_hashes = [&](const Meta& m, uint64_t& h0, uint64_t& h1) {
         h0 = h1 = 0;
-        if (m.valid && m.reg_ok)
+        if (reg_ok(m))
         {
-            const uint32_t H = GN_WAVE >> m.gp_log2, hs = (uint32_t)lane >> m.gp_log2;
+            const uint32_t g = gp_of(m.W), H = GN_WAVE >> g, hs = (uint32_t)lane >> g;
             const uint32_t q0 = hs < m.n ? hs : m.n - 1, q1 = H + hs < m.n ? H + hs : m.n - 1;
             h0 = p.hashes[m.slot + q0];
             h1 = p.hashes[m.slot + q1];
         }
     };
+    struct Rows
+    {
+        uint2 m[HF];
+    };
+    // h row requests of hash value v for item m; issued by every lane unconditionally (lanes without a column read
+    // word 0 of the row and are masked when the rows are consumed, see gn_ibf_count_fast_kernel)
+    auto issue = [&](const Meta& m, uint64_t v, Rows& R) {
+        const uint32_t g = gp_of(m.W), gl = (uint32_t)lane & ((1u << g) - 1u);
+        const uint32_t gl_ld = gl < m.W ? gl : 0u;
+#pragma unroll
+        for (int i = 0; i < HF; ++i)
+        {
+            const uint32_t row = gn_hibf_row(v, (uint32_t)i, m.shift, (uint64_t)m.S);
+            const auto* src    = gn_global(m.rows) + ((uint64_t)row * m.W + gl_ld);
+            R.m[i]             = make_uint2((uint32_t)*src, (uint32_t)(*src >> 32));
+        }
+    };
 
-    uint2 wk_next = load_entry(item + nwaves);
-    Meta  cur     = load_meta(load_entry(item));
-    uint64_t hA, hB;
-    load_hashes(cur, hA, hB);
+    Meta  m0 = load_meta(load_entry(item)), m1 = load_meta(load_entry(item + stride)), m2 = load_meta(load_entry(item + 2 * stride));
+    uint2 wk3 = load_entry(item + 3 * stride);
+    uint64_t hA, hB, h1A, h1B;
+    Rows     RA{}, RB{};
+    load_hashes(m0, hA, hB);
+    load_hashes(m1, h1A, h1B);
+    if (reg_ok(m0))
+    {
+        issue(m0, hA, RA);
+        issue(m0, hB, RB);
+    }
 
     for (;;)
     {
-        const uint32_t item_n  = item + nwaves;
-        const bool     more    = item_n < n_work;
-        const uint2    wk_nn   = load_entry(item_n + nwaves);  // two ahead
-        Meta           nxt     = load_meta(wk_next);           // one ahead (wk_next arrived during the previous item)
-        uint64_t       hA_n = 0, hB_n = 0;
-        bool           prefetched = false;
+        const bool more = item + stride < n_work;
+        Meta       m3   = load_meta(wk3);                       // three ahead (its entry arrived during the previous item)
+        wk3             = load_entry(item + 4 * stride);        // four ahead
+        uint64_t h2A = 0, h2B = 0;
 
-        if (cur.valid && !cur.reg_ok)
+        const bool     mine = reg_ok(m0);
+        uint32_t       nib[2][4];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                nib[d][j] = 0;
+        const uint32_t gpl  = gp_of(m0.W);
+        const uint32_t Gp   = 1u << gpl;
+        const uint32_t H    = GN_WAVE >> gpl;
+        const uint32_t gl   = (uint32_t)lane & (Gp - 1);
+        const uint32_t hsub = (uint32_t)lane >> gpl;
+        const bool     col_act = gl < m0.W;
+        const uint32_t n    = m0.n;
+
+        if (m0.valid && !mine)
         {
-            if (cur.n >= 1 && lane == 0) // n == 0 cannot be queued (status OK reads have n >= 1), be safe anyway
+            if (n >= 1 && lane == 0) // left to the LDS-counter kernel of this level
             {
                 const unsigned long long o = atomicAdd(p.defer_count, 1ULL);
                 if (o < p.work_cap)
-                    p.defer_out[o] = make_uint2(cur.read, cur.ibf);
+                    p.defer_out[o] = make_uint2(m0.read, m0.ibf);
             }
         }
-        else if (cur.valid)
+        else if (mine)
         {
-            const uint32_t n    = cur.n;
-            const uint32_t W    = cur.W;
-            const uint32_t Gp   = 1u << cur.gp_log2;
-            const uint32_t H    = GN_WAVE >> cur.gp_log2;
-            const uint32_t gl   = (uint32_t)lane & (Gp - 1);
-            const uint32_t hsub = (uint32_t)lane >> cur.gp_log2;
-            const bool     col_act = gl < W;
-            const uint32_t gl_ld   = col_act ? gl : 0u; // lanes without a column load a word that exists and are masked below
-            const uint64_t* hs     = p.hashes + cur.slot;
-
-            uint32_t nib[2][4], byt[2][4][2];
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                {
-                    nib[d][j]    = 0;
-                    byt[d][j][0] = 0;
-                    byt[d][j][1] = 0;
-                }
-            uint32_t acc_n = 0;
-            auto spill = [&]() {
-#pragma unroll
-                for (int d = 0; d < 2; ++d)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                    {
-                        byt[d][j][0] += nib[d][j] & 0x0F0F0F0Fu;
-                        byt[d][j][1] += (nib[d][j] >> 4) & 0x0F0F0F0Fu;
-                        nib[d][j] = 0;
-                    }
-            };
-            struct Rows
-            {
-                uint2 m[HF];
-            };
-            // h row requests of hash value v; issued by every lane unconditionally (see gn_ibf_count_fast_kernel)
-            auto issue = [&](uint64_t v, Rows& R) {
-#pragma unroll
-                for (int i = 0; i < HF; ++i)
-                {
-                    const uint32_t row = gn_hibf_row(v, (uint32_t)i, cur.shift, cur.S);
-                    R.m[i]             = *reinterpret_cast<const uint2*>(cur.rows + ((uint64_t)row * W + gl_ld));
-                }
-            };
             auto consume = [&](const Rows& R, uint32_t it) {
                 const uint32_t on = (col_act && it * H + hsub < n) ? 0xFFFFFFFFu : 0u;
                 uint32_t       a0 = R.m[0].x & on, a1 = R.m[0].y & on;
@@ -327,53 +369,44 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
                     nib[0][j] += (a0 >> j) & 0x11111111u;
                     nib[1][j] += (a1 >> j) & 0x11111111u;
                 }
-                if (++acc_n == 15)
-                {
-                    spill();
-                    acc_n = 0;
-                }
             };
+            const uint32_t  iters = (n + H - 1) / H; // <= 15
+            const uint64_t* hs    = p.hashes + m0.slot;
             auto hash_of = [&](uint32_t it) -> uint64_t {
-                if (it == 0)
-                    return hA;
-                if (it == 1)
-                    return hB;
                 const uint32_t q = it * H + hsub;
                 return hs[q < n ? q : n - 1];
             };
-
-            const uint32_t iters = (n + H - 1) / H;
-            Rows           A, B;
-            issue(hash_of(0), A);
-            uint32_t it = 0;
-            for (; it + 2 < iters; it += 2)
+            // RA / RB hold iterations 0 / 1 (requested while the previous item was finished)
+            for (uint32_t it = 0; it < iters; it += 2)
             {
-                issue(hash_of(it + 1), B);
-                consume(A, it);
-                issue(hash_of(it + 2), A);
-                consume(B, it + 1);
+                consume(RA, it);
+                if (it + 2 < iters)
+                    issue(m0, hash_of(it + 2), RA);
+                if (it + 1 < iters)
+                    consume(RB, it + 1);
+                if (it + 3 < iters)
+                    issue(m0, hash_of(it + 3), RB);
             }
-            const bool two = it + 1 < iters;
-            if (two)
-                issue(hash_of(it + 1), B);
-            if (more)
-            {
-                load_hashes(nxt, hA_n, hB_n); // fly behind the last row loads and the epilogue
-                prefetched = true;
-            }
-            consume(A, it);
-            if (two)
-                consume(B, it + 1);
-            if (acc_n)
-                spill();
-            my_bytes += (unsigned long long)n * HF * W * 8ull; // algorithmic bytes of this visit
+            my_bytes += (unsigned long long)n * HF * m0.W * 8ull; // algorithmic bytes of this visit
+        }
+        // the row registers are free: request the next item's first two row sets, then the hashes of the one after
+        if (more && reg_ok(m1))
+        {
+            issue(m1, h1A, RA);
+            issue(m1, h1B, RB);
+        }
+        if (more)
+            load_hashes(m2, h2A, h2B);
 
+        if (mine)
+        {
             // ---- epilogue: add the H hash groups, SWAR compare with the cutoff ----
             // threshold_cutoff = max(1, ceil(n * rel_cutoff))  (GanonClassify.cpp:492-495,720-724); passed to bulk_count (:553)
             uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
             if (T == 0)
                 T = 1;
             const uint32_t Kc  = (0x80u - T) * 0x01010101u; // counts <= n <= 127, 1 <= T <= 127: no carries between bytes
+            uint32_t       byt[2][4][2];
             uint32_t       any = 0;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
@@ -382,9 +415,20 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp)
                     {
-                        uint32_t x = byt[d][j][pp];
-                        for (uint32_t off = Gp; off < GN_WAVE; off <<= 1)
-                            x += __shfl_xor(x, (int)off);
+                        uint32_t x = (nib[d][j] >> (4 * pp)) & 0x0F0F0F0Fu;
+                        // groups inside a row of 16 lanes: DPP rotations; across rows: the LDS crossbar
+                        if (Gp <= 1)
+                            x = gn_hibf_add_ror<1>(x);
+                        if (Gp <= 2)
+                            x = gn_hibf_add_ror<2>(x);
+                        if (Gp <= 4)
+                            x = gn_hibf_add_ror<4>(x);
+                        if (Gp <= 8)
+                            x = gn_hibf_add_ror<8>(x);
+                        if (Gp <= 16)
+                            x += __shfl_xor(x, 16);
+                        if (Gp <= 32)
+                            x += __shfl_xor(x, 32);
                         byt[d][j][pp] = x;
                         any |= (x + Kc) & 0x80808080u;
                     }
@@ -402,40 +446,45 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
                         c1 |= (((byt[1][j][pp] + Kc) & 0x80808080u) >> 7) << (4 * pp + j);
                     }
             }
-            while (__ballot((c0 | c1) != 0))
+            if (__ballot((c0 | c1) != 0))
             {
-                bool     merged = false, leaf = false;
-                uint32_t tgt = 0, sum = 0;
-                if (c0 | c1)
+                const auto* bin_tab = gn_global(gn_sload(&p.ibfs[m0.ibf].bin_tab));
+                do
                 {
-                    const uint32_t d = c0 ? 0u : 1u;
-                    uint32_t&      c = c0 ? c0 : c1;
-                    const uint32_t t = (uint32_t)__builtin_ctz(c);
-                    c &= c - 1;
-                    const uint32_t y = t >> 3, pp = (t >> 2) & 1u, j = t & 3u;
-                    uint32_t       reg = 0;
-#pragma unroll
-                    for (int dd = 0; dd < 2; ++dd)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                            for (int qq = 0; qq < 2; ++qq)
-                                if ((uint32_t)dd == d && (uint32_t)jj == j && (uint32_t)qq == pp)
-                                    reg = byt[dd][jj][qq];
-                    sum                = (reg >> (8 * y)) & 0xFFu;
-                    const uint32_t tab = cur.bin_tab[gl * 64 + 32 * d + t];
-                    if (tab != 0xFFFFFFFFu)
+                    bool     merged = false, leaf = false;
+                    uint32_t tgt = 0, sum = 0;
+                    if (c0 | c1)
                     {
-                        merged = (tab & 0x80000000u) != 0;
-                        leaf   = !merged;
-                        tgt    = tab & 0x7FFFFFFFu;
+                        const uint32_t d = c0 ? 0u : 1u;
+                        uint32_t&      c = c0 ? c0 : c1;
+                        const uint32_t t = (uint32_t)__builtin_ctz(c);
+                        c &= c - 1;
+                        const uint32_t y = t >> 3, pp = (t >> 2) & 1u, j = t & 3u;
+                        uint32_t       reg = 0;
+#pragma unroll
+                        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                                for (int qq = 0; qq < 2; ++qq)
+                                    if ((uint32_t)dd == d && (uint32_t)jj == j && (uint32_t)qq == pp)
+                                        reg = byt[dd][jj][qq];
+                        sum                = (reg >> (8 * y)) & 0xFFu;
+                        const uint32_t tab = bin_tab[gl * 64 + 32 * d + t];
+                        if (tab != 0xFFFFFFFFu)
+                        {
+                            merged = (tab & 0x80000000u) != 0;
+                            leaf   = !merged;
+                            tgt    = tab & 0x7FFFFFFFu;
+                        }
                     }
-                }
-                app.push(p, lane, merged, leaf, cur.read, tgt, sum);
+                    app.push(p, lane, merged, leaf, m0.read, tgt, sum);
+                } while (__ballot((c0 | c1) != 0));
             }
             // multi-bin runs (split user bins): sums from an image of the owner lanes' byte counters
-            if (cur.n_mruns)
+            if (m0.n_mruns)
             {
+                const auto* mruns = gn_global(gn_sload(&p.ibfs[m0.ibf].mruns));
                 gn_hibf_wave_sync();
                 if (owner)
                 {
@@ -448,14 +497,14 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
                                 img[gl * 16 + (d * 4 + j) * 2 + pp] = byt[d][j][pp];
                 }
                 gn_hibf_wave_sync();
-                for (uint32_t r0 = 0; r0 < cur.n_mruns; r0 += GN_WAVE)
+                for (uint32_t r0 = 0; r0 < m0.n_mruns; r0 += GN_WAVE)
                 {
                     const uint32_t r = r0 + (uint32_t)lane;
-                    bool           merged = false, leaf = false;
+                    bool           leaf = false;
                     uint32_t       tgt = 0, sum = 0;
-                    if (r < cur.n_mruns)
+                    if (r < m0.n_mruns)
                     {
-                        const uint4 run = cur.mruns[r]; // first bin, n bins, user bin, -
+                        const uint4 run = *reinterpret_cast<const uint4*>((uintptr_t)(mruns + r)); // first bin, n bins, user bin, -
                         for (uint32_t b = run.x; b < run.x + run.y; ++b)
                         {
                             const uint32_t t = b & 63u, d = t >> 5, tt = t & 31u;
@@ -465,20 +514,19 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
                         leaf = sum >= T; // :455
                         tgt  = run.z;
                     }
-                    app.push(p, lane, merged, leaf, cur.read, tgt, sum);
+                    app.push(p, lane, false, leaf, m0.read, tgt, sum);
                 }
             }
         }
-        if (more && !prefetched) // (holes and deferred items: nothing to hide the loads behind)
-            load_hashes(nxt, hA_n, hB_n);
 
         if (!more)
             break;
-        item    = item_n;
-        cur     = nxt;
-        hA      = hA_n;
-        hB      = hB_n;
-        wk_next = wk_nn;
+        item += stride;
+        m0  = m1;
+        m1  = m2;
+        m2  = m3;
+        h1A = h2A;
+        h1B = h2B;
     }
     app.finish(p, lane);
     if (lane == 0 && my_bytes)
@@ -761,18 +809,26 @@ static int gn_hibf_ensure_sort_buffers(gn_stream* s)
     return GN_OK;
 }
 
-// persistent grid = what is resident at once (the register budget decides: ~5 waves per SIMD)
-template <int HF>
-static void gn_hibf_launch_reg(const GnHibfLevelParams& p, uint32_t n_cu, uint32_t bpc, hipStream_t st)
+// persistent grid = what is resident at once (the register budget decides)
+template <int HF, bool LEVEL0>
+static void gn_hibf_launch_reg2(const GnHibfLevelParams& p, uint32_t n_cu, uint32_t bpc, hipStream_t st)
 {
     if (bpc == 0)
     {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_hibf_reg_kernel<HF>, 256, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_hibf_reg_kernel<HF, LEVEL0>, 256, 0) != hipSuccess || per_cu < 1)
             per_cu = 4;
         bpc = (uint32_t)per_cu;
     }
-    hipLaunchKernelGGL((gn_hibf_reg_kernel<HF>), dim3(n_cu * bpc), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gn_hibf_reg_kernel<HF, LEVEL0>), dim3(n_cu * bpc), dim3(256), 0, st, p);
+}
+template <int HF>
+static void gn_hibf_launch_reg(const GnHibfLevelParams& p, bool level0, uint32_t n_cu, uint32_t bpc, hipStream_t st)
+{
+    if (level0)
+        gn_hibf_launch_reg2<HF, true>(p, n_cu, bpc, st);
+    else
+        gn_hibf_launch_reg2<HF, false>(p, n_cu, bpc, st);
 }
 
 // Runs all levels back to back (queue lengths stay on the device), synchronises ONCE, then sorts/groups the matches.
@@ -792,11 +848,10 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
     GN_HIP(hipMemsetAsync(s->d_hctr, 0, 2 * NL * sizeof(unsigned long long), st));
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
-    if (n)
-        hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n, s->d_hctr);
-
     const uint32_t h     = f->ibfs[0].h;
     const bool     no_reg = getenv("GANON_HIP_HIBF_NO_REG") != nullptr; // tests / A-B: everything through the LDS kernel
+    if (n && no_reg) // (the register-counter kernel takes level 0 straight from the batch)
+        hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n, s->d_hctr);
     const uint32_t reg_bpc = getenv("GANON_HIP_HIBF_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_HIBF_BPC")) : 0u; // 0 = occupancy
     for (uint32_t lvl = 0; lvl < depth && n; ++lvl)
     {
@@ -819,15 +874,18 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         p.match_cap   = s->match_cap;
         p.ub_bits     = ub_bits;
         p.lds_bins    = f->max_bins;
+        p.n_reads     = n;
+        p.status      = s->d_status;
         if (!no_reg)
         {
+            const bool l0 = lvl == 0;
             switch (h)
             {
-                case 1: gn_hibf_launch_reg<1>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 2: gn_hibf_launch_reg<2>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 3: gn_hibf_launch_reg<3>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 4: gn_hibf_launch_reg<4>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
-                default: gn_hibf_launch_reg<5>(p, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 1: gn_hibf_launch_reg<1>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 2: gn_hibf_launch_reg<2>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 3: gn_hibf_launch_reg<3>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 4: gn_hibf_launch_reg<4>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                default: gn_hibf_launch_reg<5>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
             }
             GN_HIP(hipGetLastError());
             p.work_in  = s->d_hdefer;

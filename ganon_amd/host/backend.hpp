@@ -1,8 +1,14 @@
-// backend.hpp -- the seam between the host pipeline and the device hot path.  The host hands a batch of reads and
-// gets, per filter, the sparse result of select_matches (GanonClassify.cpp:504-577): for every read the targets whose
-// summed, capped count reached the read's cutoff.  The product binary links exactly one implementation,
-// backend_hip.cpp (libganon_hip.so through include/ganon_hip.h); there is no CPU implementation in ganon_amd/.
-// (tests/host_oracle/ links a checker backend built on the CPU oracle to exercise the host logic without a GPU.)
+// backend.hpp -- the seam between the host pipeline and the device hot path.
+//
+// Loading: a filter file is parsed into its metadata (FilterMeta) and its bit matrices are STREAMED, chunk by chunk,
+// into a FilterSink -- for the product that is HBM (gn_filter_write_rows from pinned staging, backend_hip.cpp), on
+// every selected GPU at once; the host never holds a whole matrix (the reference deserialises the complete sdsl
+// bit_vector into RAM first, GanonClassify.cpp:949-986).
+// Classifying: the host hands a batch of reads to a Backend and gets, per filter, the sparse result of select_matches
+// (GanonClassify.cpp:504-577): for every read the targets whose summed, capped count reached the read's cutoff.
+// The product binary links exactly one implementation, backend_hip.cpp (libganon_hip.so through include/ganon_hip.h);
+// there is no CPU implementation in ganon_amd/.  (tests/host_oracle/ links a checker backend built on the CPU oracle
+// to exercise the host logic without a GPU.)
 #pragma once
 
 #include "filter_io.hpp"
@@ -20,6 +26,7 @@ namespace gnhost
 struct ReadBatch
 {
     bool                  paired = false;
+    uint64_t              seq    = 0;  // position in the input stream (outputs are written in this order)
     std::string           prefix;
     std::string           id_buf;      // all read ids back to back
     std::vector<uint64_t> id_off{ 0 }; // n+1 offsets into id_buf
@@ -34,7 +41,7 @@ struct ReadBatch
 
 struct Match
 {
-    uint32_t read, target, count; // target = index into LoadedFilter::targets
+    uint32_t read, target, count; // target = index into FilterMeta::targets
 };
 
 struct FilterResult
@@ -50,19 +57,58 @@ struct BatchResult
     std::vector<FilterResult> per_filter;
 };
 
-class Backend
+// One device (or the test checker): receives filters, classifies batches.  Not thread-safe; one host thread each.
+class Backend : public FilterSink
 {
 public:
-    virtual ~Backend() = default;
-    // takes over the filter's bit matrices (they are released after the upload); returns false + message on error
-    virtual bool add_filter(LoadedFilter& f, std::string& err) = 0;
-    virtual void clear_filters()                               = 0;
-    // classify `batch` against every added filter with minimiser shape (k, w); rel_cutoff[i] belongs to filter i
+    virtual void clear_filters() = 0;
+    // classify `batch` against every loaded filter with minimiser shape (k, w); rel_cutoff[i] belongs to filter i
     virtual bool classify(const ReadBatch& batch, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff,
                           BatchResult& out, std::string& err) = 0;
-    virtual std::string describe() const                      = 0;
+    virtual std::string describe() const = 0;
 };
 
-std::unique_ptr<Backend> make_backend(int device, std::string& err); // backend_hip.cpp (or the test checker)
+// devices: indices, or empty = every visible device ("all").  backend_hip.cpp (or the test checker).
+std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devices, std::string& err);
+
+// Forwards one filter stream to several backends (the filter is replicated into every GPU's HBM); the staging
+// buffers of the first backend are shared (pinned host memory is visible to every device).
+class ReplicatingSink final : public FilterSink
+{
+public:
+    explicit ReplicatingSink(std::vector<std::unique_ptr<Backend>>& backends) : b_(backends) {}
+    bool begin(const FilterMeta& meta, std::string& err) override
+    {
+        for (auto& b : b_)
+            if (!b->begin(meta, err))
+                return false;
+        return true;
+    }
+    uint64_t* staging(int which, size_t bytes) override { return b_.front()->staging(which, bytes); }
+    bool      rows(uint32_t ibf, uint64_t row_begin, uint64_t n_rows, const uint64_t* src, std::string& err) override
+    {
+        for (auto& b : b_)
+            if (!b->rows(ibf, row_begin, n_rows, src, err))
+                return false;
+        return true;
+    }
+    bool drain(std::string& err) override
+    {
+        for (auto& b : b_)
+            if (!b->drain(err))
+                return false;
+        return true;
+    }
+    bool end(std::string& err) override
+    {
+        for (auto& b : b_)
+            if (!b->end(err))
+                return false;
+        return true;
+    }
+
+private:
+    std::vector<std::unique_ptr<Backend>>& b_;
+};
 
 } // namespace gnhost
