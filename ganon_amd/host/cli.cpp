@@ -18,7 +18,7 @@ namespace gnhost
 namespace
 {
 
-enum class Kind { VecStr, VecDouble, Str, Bool, U16, Size, Int, Help, Version };
+enum class Kind { VecStr, VecDouble, Str, Bool, U16, Size, Devices, Help, Version };
 
 struct Opt
 {
@@ -29,8 +29,8 @@ struct Opt
 };
 
 const Opt kOpts[] = {
-    { 'r', "single-reads", Kind::VecStr, "single-end reads file[s] (comma-separated, flat or gzipped)" },
-    { 'p', "paired-reads", Kind::VecStr, "paired-end reads file[s] (comma-separated, flat or gzipped)" },
+    { 'r', "single-reads", Kind::VecStr, "single-end reads file[s] (comma-separated, flat or gzipped; bzip2 is not supported by this build)" },
+    { 'p', "paired-reads", Kind::VecStr, "paired-end reads file[s] (comma-separated, flat or gzipped; bzip2 is not supported by this build)" },
     { 'b', "batch-reads", Kind::VecStr,
       "file describing several files of single- or paired-end reads to be processed in one run: prefix <tab> file1 "
       "[<tab> file2]. Prefixes can be repeated for multiple files." },
@@ -63,7 +63,9 @@ const Opt kOpts[] = {
     { 0, "n-reads", Kind::Size, "Number of reads for each batch. Default: 400" },
     { 0, "verbose", Kind::Bool, "Verbose output mode" },
     { 0, "quiet", Kind::Bool, "Quiet output mode (only outputs errors and warnings to the STDERR)" },
-    { 0, "device", Kind::Int, "MI355X device index (extension; default $GANON_DEVICE or 0)" },
+    { 0, "device", Kind::Devices,
+      "MI355X device(s): one index, a comma-separated list or 'all' -- the filters are replicated into every listed GPU and "
+      "the read batches are shared out among them (extension; default $GANON_DEVICE or 0)" },
     { 'h', "help", Kind::Help, "Print help" },
     { 'v', "version", Kind::Version, "Show version" },
 };
@@ -118,6 +120,25 @@ void print_help()
     std::cerr << std::endl;
 }
 
+// "all" -> empty list (= every visible device); otherwise non-negative indices
+std::vector<int> parse_devices(const std::string& v)
+{
+    std::vector<int> out;
+    if (v == "all")
+        return out;
+    for (auto const& s : split_commas(v))
+    {
+        size_t pos = 0;
+        int    d   = std::stoi(s, &pos);
+        if (pos != s.size() || d < 0)
+            throw std::invalid_argument("Argument '" + s + "' failed to parse");
+        out.push_back(d);
+    }
+    if (out.empty())
+        throw std::invalid_argument("Argument '" + v + "' failed to parse");
+    return out;
+}
+
 bool parse_bool(const std::string& v)
 {
     if (v == "1" || v == "true" || v == "True" || v == "t" || v == "T")
@@ -139,11 +160,11 @@ std::optional<Config> parse_command_line(int argc, char** argv, int& exit_code)
         return std::nullopt;
     }
     Config cfg;
-    if (const char* d = std::getenv("GANON_DEVICE"))
-        cfg.device = std::atoi(d);
     bool want_help = false, want_version = false;
     try
     {
+        if (const char* d = std::getenv("GANON_DEVICE"))
+            cfg.devices = parse_devices(d);
         for (int i = 1; i < argc; ++i)
         {
             std::string arg = argv[i];
@@ -266,7 +287,7 @@ std::optional<Config> parse_command_line(int argc, char** argv, int& exit_code)
                         cfg.n_reads = (size_t)x;
                     break;
                 }
-                case Kind::Int: cfg.device = std::stoi(value); break;
+                case Kind::Devices: cfg.devices = parse_devices(value); break;
             }
         }
     }

@@ -41,7 +41,7 @@ struct Config
     size_t   n_batches = 1000; // accepted for compatibility
     size_t   n_reads   = 400;  // accepted for compatibility
     bool     verbose = false, quiet = false;
-    int      device  = 0; // extension: --device N (default $GANON_DEVICE or 0)
+    std::vector<int> devices{ 0 }; // extension: --device 0,1,.. | all (default $GANON_DEVICE or 0); empty = every visible GPU
 
     // checks + broadcasting; prints the reference's message to stderr and returns false on the first violation
     bool validate();

@@ -4,33 +4,23 @@
 #include "filter_io.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
+
+#include <fcntl.h>
+#include <unistd.h>
 
 namespace gnhost
 {
-
-IbfMatrix& IbfMatrix::operator=(IbfMatrix&& o) noexcept
-{
-    if (this != &o)
-    {
-        std::free(rows);
-        bins = o.bins; technical_bins = o.technical_bins; bin_size = o.bin_size; hash_shift = o.hash_shift;
-        bin_words = o.bin_words; hash_funs = o.hash_funs; rows = o.rows;
-        o.rows = nullptr;
-    }
-    return *this;
-}
-IbfMatrix::~IbfMatrix()
-{
-    std::free(rows);
-}
 
 namespace
 {
@@ -56,6 +46,20 @@ struct Reader
         if (!is)
             throw std::runtime_error(path + ": read error at offset " + std::to_string(pos));
         pos += n;
+    }
+    void skip(uint64_t n)
+    {
+        if (pos + n > size)
+            throw std::runtime_error(path + ": truncated (payload of " + std::to_string(n) + " bytes at offset "
+                                     + std::to_string(pos) + ", file has " + std::to_string(size) + ")");
+        pos += n;
+        is.seekg((std::streamoff)pos);
+    }
+    void seek(uint64_t to)
+    {
+        pos = to;
+        is.clear();
+        is.seekg((std::streamoff)pos);
     }
     template <typename T>
     T get()
@@ -86,8 +90,8 @@ struct Reader
 };
 
 // seqan3::interleaved_bloom_filter<uncompressed>: bins, technical_bins, bin_size_, hash_shift, bin_words, hash_funs
-// (all size_t), then sdsl::bit_vector: u8 width (=1), f32 growth_factor, u64 size in bits, raw words.
-void read_ibf(Reader& r, IbfMatrix& m)
+// (all size_t), then the sdsl::bit_vector `data`.
+void read_ibf_fields(Reader& r, IbfShape& m)
 {
     m.bins           = r.get<uint64_t>();
     m.technical_bins = r.get<uint64_t>();
@@ -108,23 +112,46 @@ void read_ibf(Reader& r, IbfMatrix& m)
         why << "hash_funs " << m.hash_funs << " outside 1..5";
     if (!why.str().empty())
         throw std::runtime_error(r.path + ": not a SeqAn3 IBF at offset " + std::to_string(r.pos) + ": " + why.str());
+}
 
-    const uint8_t width  = r.get<uint8_t>();
-    const float   growth = r.get<float>();
-    const uint64_t bits  = r.get<uint64_t>();
-    (void)growth;
-    if (width != 1 || bits != m.technical_bins * m.bin_size)
-        throw std::runtime_error(r.path + ": unexpected sdsl bit_vector header (width " + std::to_string(width) + ", size "
-                                 + std::to_string(bits) + " bits, expected " + std::to_string(m.technical_bins * m.bin_size)
-                                 + ")");
-    const uint64_t bytes = bits / 8;
-    void*          p     = nullptr;
-    if (posix_memalign(&p, 64, bytes ? bytes : 64) != 0)
-        throw std::runtime_error("out of memory loading " + r.path + " (" + std::to_string(bytes) + " bytes)");
-    m.rows = static_cast<uint64_t*>(p);
-    const uint64_t chunk = 1ull << 28;
-    for (uint64_t o = 0; o < bytes; o += chunk)
-        r.raw(reinterpret_cast<char*>(m.rows) + o, std::min(chunk, bytes - o));
+// The header sdsl-lite writes in front of a bit_vector's words.  Recalled layout (sdsl-lite v3 cereal support): the
+// width as a one-byte size tag (1), the growth factor (float), the size in BITS (u64), then ceil(bits/64) words.  No
+// real file pins that in the reference tree, so the variants that differ in exactly the parts a version could change
+// are accepted too -- without the width byte and/or the growth factor, and with the size counted in 64-bit words --
+// each still has to agree with technical_bins * bin_size, and for a flat .ibf (payload last in the file) the header
+// length is additionally dictated by the file size.
+// Returns with r positioned at the first payload byte.  `exact_len` = -1 when the file size cannot decide.
+void read_bitvector_header(Reader& r, const IbfShape& m, int64_t exact_len)
+{
+    const uint64_t bits  = m.technical_bins * m.bin_size;
+    const uint64_t start = r.pos;
+    struct Variant
+    {
+        bool width, growth;
+    };
+    static const Variant variants[] = { { true, true }, { false, false }, { true, false }, { false, true } };
+    std::string          seen;
+    for (const auto& v : variants)
+    {
+        const int64_t len = (v.width ? 1 : 0) + (v.growth ? 4 : 0) + 8;
+        if (exact_len >= 0 && len != exact_len)
+            continue;
+        if (start + (uint64_t)len > r.size)
+            continue;
+        r.seek(start);
+        uint8_t width = 1;
+        if (v.width)
+            width = r.get<uint8_t>();
+        if (v.growth)
+            (void)r.get<float>();
+        const uint64_t size = r.get<uint64_t>();
+        if (width == 1 && (size == bits || size * 64 == bits))
+            return;
+        seen += " [width " + std::to_string(width) + ", size " + std::to_string(size) + "]";
+    }
+    r.seek(start);
+    throw std::runtime_error(r.path + ": unexpected sdsl bit_vector header at offset " + std::to_string(start) + " (expected "
+                             + std::to_string(bits) + " bits; candidates read:" + seen + ")");
 }
 
 void replace_all(std::string& str, const std::string& from, const std::string& to)
@@ -137,14 +164,88 @@ void replace_all(std::string& str, const std::string& from, const std::string& t
     }
 }
 
-} // namespace
-
-double false_positive(uint64_t bin_size_bits, uint8_t hash_functions, uint64_t n_hashes)
+// ---- streaming the payload -----------------------------------------------------------------------------------
+// pread with a few threads: the page cache / a tmpfs copies at 3-6 GB/s per thread, one thread would be the limit
+void parallel_pread(int fd, uint8_t* dst, uint64_t bytes, uint64_t offset, const std::string& path)
 {
-    return std::pow(1 - std::exp(-hash_functions / (bin_size_bits / static_cast<double>(n_hashes))), hash_functions);
+    const unsigned    hw     = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned    nth    = (unsigned)std::min<uint64_t>(std::min(16u, hw), std::max<uint64_t>(1, bytes >> 23)); // >= 8 MiB each
+    std::atomic<bool> failed{ false };
+    auto              work = [&](uint64_t lo, uint64_t hi) {
+        while (lo < hi && !failed)
+        {
+            const ssize_t got = ::pread(fd, dst + lo, (size_t)std::min<uint64_t>(hi - lo, 1ull << 30), (off_t)(offset + lo));
+            if (got <= 0)
+            {
+                failed = true;
+                return;
+            }
+            lo += (uint64_t)got;
+        }
+    };
+    if (nth <= 1)
+        work(0, bytes);
+    else
+    {
+        std::vector<std::thread> pool;
+        const uint64_t           per = ((bytes + nth - 1) / nth + 4095) & ~4095ull;
+        for (unsigned t = 0; t < nth; ++t)
+        {
+            const uint64_t lo = std::min<uint64_t>(bytes, (uint64_t)t * per), hi = std::min<uint64_t>(bytes, lo + per);
+            if (lo < hi)
+                pool.emplace_back(work, lo, hi);
+        }
+        for (auto& t : pool)
+            t.join();
+    }
+    if (failed)
+        throw std::runtime_error(path + ": read error / unexpected end of file in the filter payload");
 }
 
-void load_ibf_file(const std::string& path, LoadedFilter& out)
+struct Fd
+{
+    int fd = -1;
+    explicit Fd(const std::string& p) : fd(::open(p.c_str(), O_RDONLY)) {}
+    ~Fd()
+    {
+        if (fd >= 0)
+            ::close(fd);
+    }
+};
+
+// rows of IBF `ibf` from file offset `offset` into the sink: fill one staging buffer while the previous one is copied
+void stream_matrix(const std::string& path, int fd, uint64_t offset, const IbfShape& m, uint32_t ibf, FilterSink& sink)
+{
+    const uint64_t row_bytes = m.bin_words * 8;
+    const uint64_t total     = m.payload_bytes();
+    const uint64_t want      = std::min<uint64_t>(total, 256ull << 20);
+    const uint64_t per       = std::max<uint64_t>(1, want / row_bytes); // rows per chunk
+    const uint64_t cap       = per * row_bytes;
+    uint64_t*      stage[2]  = { sink.staging(0, cap), sink.staging(1, cap) };
+    std::unique_ptr<uint64_t[]> own[2];
+    for (int i = 0; i < 2; ++i)
+        if (!stage[i])
+        {
+            own[i].reset(new uint64_t[cap / 8]);
+            stage[i] = own[i].get();
+        }
+    std::string err;
+    uint64_t    chunk = 0;
+    for (uint64_t row = 0; row < m.bin_size; row += per, ++chunk)
+    {
+        const uint64_t n   = std::min(per, m.bin_size - row);
+        uint64_t*      buf = stage[chunk & 1];
+        parallel_pread(fd, reinterpret_cast<uint8_t*>(buf), n * row_bytes, offset + row * row_bytes, path);
+        // the copy of the previous chunk ran while this one was read; it used the OTHER buffer, but the buffer filled
+        // next is that one again, so it has to be finished before the next round
+        if (!sink.drain(err) || !sink.rows(ibf, row, n, buf, err))
+            throw std::runtime_error(path + ": " + err);
+    }
+    if (!sink.drain(err))
+        throw std::runtime_error(path + ": " + err);
+}
+
+void load_ibf(const std::string& path, FilterMeta& out, FilterSink& sink)
 {
     Reader r(path);
     out.is_hibf = false;
@@ -177,10 +278,16 @@ void load_ibf_file(const std::string& path, LoadedFilter& out)
         std::string t = r.str();
         bin_map.emplace_back(b, std::move(t));
     }
-    read_ibf(r, out.ibf);
-    if (r.pos != r.size)
-        throw std::runtime_error(path + ": " + std::to_string(r.size - r.pos) + " trailing bytes after the IBF payload");
-    if (out.ibf.bins != c.n_bins || out.ibf.bin_size != c.bin_size_bits || out.ibf.hash_funs != c.hash_functions)
+    IbfShape m;
+    read_ibf_fields(r, m);
+    // the payload is the last thing in the file: whatever precedes it is the bit_vector header
+    const uint64_t payload = m.payload_bytes();
+    if (r.size < r.pos + 8 + payload)
+        throw std::runtime_error(path + ": truncated (the IBF payload needs " + std::to_string(payload) + " bytes, the file has "
+                                 + std::to_string(r.size - r.pos) + " left)");
+    read_bitvector_header(r, m, (int64_t)(r.size - r.pos - payload));
+    const uint64_t payload_at = r.pos;
+    if (m.bins != c.n_bins || m.bin_size != c.bin_size_bits || m.hash_funs != c.hash_functions)
         throw std::runtime_error(path + ": IBFConfig (n_bins/bin_size_bits/hash_functions) disagrees with the stored IBF");
     if (c.kmer_size == 0 || c.kmer_size > 32 || c.window_size < c.kmer_size)
         throw std::runtime_error(path + ": invalid k/w in IBFConfig");
@@ -191,7 +298,7 @@ void load_ibf_file(const std::string& path, LoadedFilter& out)
     std::map<std::string, size_t> idx;
     for (auto const& [binno, target] : bin_map)
     {
-        if (binno >= out.ibf.bins)
+        if (binno >= m.bins)
             throw std::runtime_error(path + ": bin_map references bin " + std::to_string(binno) + " >= bins");
         auto it = idx.find(target);
         if (it == idx.end())
@@ -217,10 +324,21 @@ void load_ibf_file(const std::string& path, LoadedFilter& out)
         if (it != fpr.end())
             out.target_fpr[t] = it->second; // operator[] default (0.0) otherwise, like target_fpr[target] at :533
     }
-    out.bin_count = out.ibf.bins;
+    out.bin_count = m.bins;
+    out.shapes.assign(1, m);
+
+    std::string err;
+    if (!sink.begin(out, err))
+        throw std::runtime_error(path + ": " + err);
+    Fd fd(path);
+    if (fd.fd < 0)
+        throw std::runtime_error("cannot open filter file " + path);
+    stream_matrix(path, fd.fd, payload_at, m, 0, sink);
+    if (!sink.end(err))
+        throw std::runtime_error(path + ": " + err);
 }
 
-void load_hibf_file(const std::string& path, LoadedFilter& out)
+void load_hibf(const std::string& path, FilterMeta& out, FilterSink& sink)
 {
     Reader r(path);
     out.is_hibf = true;
@@ -243,13 +361,20 @@ void load_hibf_file(const std::string& path, LoadedFilter& out)
     }
     const double fpr = r.get<double>();
     (void)r.get<uint8_t>(); // is_hibf
-    // hierarchical_interleaved_bloom_filter: ibf_vector, next_ibf_id, user_bins{user_bin_filenames, ibf_bin_to_filename_position}
+    // hierarchical_interleaved_bloom_filter: ibf_vector, next_ibf_id, user_bins{user_bin_filenames, ibf_bin_to_filename_position}.
+    // The tables FOLLOW the matrices: first pass over the IBF headers only (payloads skipped), matrices in a second pass.
     const uint64_t nibf = r.count(48);
     if (nibf == 0)
         throw std::runtime_error(path + ": HIBF without IBFs");
-    out.ibfs.resize(nibf);
-    for (auto& m : out.ibfs)
-        read_ibf(r, m);
+    out.shapes.resize(nibf);
+    std::vector<uint64_t> payload_at(nibf);
+    for (uint64_t i = 0; i < nibf; ++i)
+    {
+        read_ibf_fields(r, out.shapes[i]);
+        read_bitvector_header(r, out.shapes[i], -1);
+        payload_at[i] = r.pos;
+        r.skip(out.shapes[i].payload_bytes());
+    }
     auto read_vv = [&](std::vector<std::vector<int64_t>>& vv) {
         const uint64_t n = r.count(8);
         vv.resize(n);
@@ -272,7 +397,7 @@ void load_hibf_file(const std::string& path, LoadedFilter& out)
     if (out.next_ibf_id.size() != nibf || out.bin_to_user.size() != nibf)
         throw std::runtime_error(path + ": next_ibf_id / ibf_bin_to_filename_position do not cover every IBF");
     for (uint64_t i = 0; i < nibf; ++i)
-        if (out.next_ibf_id[i].size() < out.ibfs[i].bins || out.bin_to_user[i].size() < out.ibfs[i].bins)
+        if (out.next_ibf_id[i].size() < out.shapes[i].bins || out.bin_to_user[i].size() < out.shapes[i].bins)
             throw std::runtime_error(path + ": per-bin tables shorter than the IBF's bin count");
     out.n_user_bins = nub;
 
@@ -312,6 +437,33 @@ void load_hibf_file(const std::string& path, LoadedFilter& out)
         if (b[0] >= nub)
             throw std::runtime_error(path + ": bin_path has more entries than user bins");
     out.bin_count = nub;
+
+    std::string err;
+    if (!sink.begin(out, err))
+        throw std::runtime_error(path + ": " + err);
+    Fd fd(path);
+    if (fd.fd < 0)
+        throw std::runtime_error("cannot open filter file " + path);
+    for (uint64_t i = 0; i < nibf; ++i)
+        stream_matrix(path, fd.fd, payload_at[i], out.shapes[i], (uint32_t)i, sink);
+    if (!sink.end(err))
+        throw std::runtime_error(path + ": " + err);
+}
+
+} // namespace
+
+double false_positive(uint64_t bin_size_bits, uint8_t hash_functions, uint64_t n_hashes)
+{
+    return std::pow(1 - std::exp(-hash_functions / (bin_size_bits / static_cast<double>(n_hashes))), hash_functions);
+}
+
+void load_filter_file(const std::string& path, bool hibf, FilterMeta& meta, FilterSink& sink)
+{
+    meta = FilterMeta();
+    if (hibf)
+        load_hibf(path, meta, sink);
+    else
+        load_ibf(path, meta, sink);
 }
 
 std::map<std::string, TaxNode> load_tax(const std::string& path)

@@ -33,6 +33,7 @@ public:
         auto it = ids_.find(root_node);
         if (it == ids_.end())
             return;
+        root_ = it->second;
         std::vector<std::pair<int, size_t>> stack;
         stack.emplace_back(it->second, 0);
         first_[it->second] = 0;
@@ -44,8 +45,9 @@ public:
             if (idx < children_[u].size())
             {
                 const int c = children_[u][idx++];
-                if (first_[c] == -1)
-                    first_[c] = (int)euler_.size();
+                if (first_[c] != -1) // a node that is its own ancestor (e.g. a "1 <tab> 1" row) or has two parents:
+                    continue;        // visit it once, or the walk would never end
+                first_[c] = (int)euler_.size();
                 euler_.push_back(c);
                 depth_.push_back((int)stack.size());
                 stack.emplace_back(c, 0);
@@ -78,11 +80,13 @@ public:
     }
 
     // LCA.hpp:165-174 (taxIds.size() > 1)
+    // A node that the walk did not reach (a subtree that is not connected to the root) has no position in the tour:
+    // the only ancestor it can share with anything is taken to be the root.
     std::string getLCA(const std::vector<std::string>& taxIds) const
     {
-        int lca = pair(ids_.at(taxIds[0]), ids_.at(taxIds[1]));
+        int lca = pair(id_of(taxIds[0]), id_of(taxIds[1]));
         for (size_t i = 2; i < taxIds.size(); ++i)
-            lca = pair(lca, ids_.at(taxIds[i]));
+            lca = pair(lca, id_of(taxIds[i]));
         return decode_.at(lca);
     }
 
@@ -97,11 +101,18 @@ private:
         decode_.push_back(s);
         return id;
     }
+    int id_of(const std::string& s) const
+    {
+        auto it = ids_.find(s);
+        return it == ids_.end() ? root_ : it->second;
+    }
     int pair(int u, int v) const
     {
         if (u == v)
             return u;
         int i = first_[u], j = first_[v];
+        if (i < 0 || j < 0)
+            return root_;
         if (i > j)
             std::swap(i, j);
         int k = 0;
@@ -116,7 +127,7 @@ private:
     std::vector<std::string>             decode_;
     std::vector<std::vector<int>>        children_;
     std::vector<int>                     euler_, depth_, first_, table_;
-    int                                  log_ = 1;
+    int                                  log_ = 1, root_ = 0;
 };
 
 } // namespace gnhost

@@ -236,16 +236,24 @@ def _w_str(s: str) -> bytes:
     return struct.pack("<Q", len(b)) + b
 
 
-def ibf_cereal_bytes(ibf: oracle.Ibf) -> bytes:
+def ibf_cereal_bytes(ibf: oracle.Ibf, bv_header: str = "wgb") -> bytes:
     """seqan3::interleaved_bloom_filter<uncompressed> cereal layout (SURVEY App. A.3 item 5):
-    6 x u64 members, then sdsl bit_vector = u8 width(1), f32 growth_factor(1.5), u64 size_in_bits, payload."""
+    6 x u64 members, then sdsl bit_vector = u8 width(1), f32 growth_factor(1.5), u64 size_in_bits, payload.
+    `bv_header` spells the variants of the (unpinned) bit_vector header the loader accepts: w = width byte, g = growth
+    factor, b / q = size in bits / in 64-bit words."""
     head = struct.pack("<6Q", ibf.bins, ibf.technical_bins, ibf.bin_size, ibf.hash_shift, ibf.bin_words,
                        ibf.hash_funs)
     bits = ibf.technical_bins * ibf.bin_size
-    return head + struct.pack("<BfQ", 1, 1.5, bits) + np.ascontiguousarray(ibf.data, dtype="<u8").tobytes()
+    bv = b""
+    if "w" in bv_header:
+        bv += struct.pack("<B", 1)
+    if "g" in bv_header:
+        bv += struct.pack("<f", 1.5)
+    bv += struct.pack("<Q", bits // 64 if "q" in bv_header else bits)
+    return head + bv + np.ascontiguousarray(ibf.data, dtype="<u8").tobytes()
 
 
-def write_ibf(path: str, built: BuiltIbf, version=(2, 1, 1)) -> None:
+def write_ibf(path: str, built: BuiltIbf, version=(2, 1, 1), bv_header: str = "wgb") -> None:
     """save_filter (GanonBuild.cpp:251-288; reader GanonClassify.cpp:955-965)."""
     c = built.config
     with open(path, "wb") as f:
@@ -258,11 +266,11 @@ def write_ibf(path: str, built: BuiltIbf, version=(2, 1, 1)) -> None:
         f.write(struct.pack("<Q", len(built.bin_map)))
         for b, t in built.bin_map:
             f.write(struct.pack("<Q", b) + _w_str(t))
-        f.write(ibf_cereal_bytes(built.ibf))
+        f.write(ibf_cereal_bytes(built.ibf, bv_header))
 
 
 def write_hibf(path: str, hibf: oracle.Hibf, bin_path: Sequence[Sequence[str]], k: int, w: int, fpr: float,
-               user_bin_filenames: Optional[Sequence[str]] = None, version: int = 1) -> None:
+               user_bin_filenames: Optional[Sequence[str]] = None, version: int = 1, bv_header: str = "wgb") -> None:
     """raptor 3.0.1 index as read at GanonClassify.cpp:884-901 + hibf.hpp:163-169,293-298."""
     if user_bin_filenames is None:
         user_bin_filenames = [p[0] for p in bin_path]
@@ -282,7 +290,7 @@ def write_hibf(path: str, hibf: oracle.Hibf, bin_path: Sequence[Sequence[str]], 
         f.write(struct.pack("<B", 1))               # is_hibf
         f.write(struct.pack("<Q", len(hibf.ibfs)))  # ibf_vector
         for ibf in hibf.ibfs:
-            f.write(ibf_cereal_bytes(ibf))
+            f.write(ibf_cereal_bytes(ibf, bv_header))
         f.write(struct.pack("<Q", len(hibf.next_ibf_id)))
         for a in hibf.next_ibf_id:
             f.write(struct.pack("<Q", len(a)) + np.ascontiguousarray(a, dtype="<i8").tobytes())

@@ -14,24 +14,22 @@ namespace
 class OracleBackend final : public Backend
 {
 public:
-    bool add_filter(LoadedFilter& f, std::string&) override
+    // FilterSink: the matrices are assembled in host memory, chunk by chunk
+    bool begin(const FilterMeta& f, std::string&) override
     {
         Held h;
         h.is_hibf = f.is_hibf;
-        if (!f.is_hibf)
+        for (auto const& m : f.shapes)
         {
-            h.mats.push_back(std::move(f.ibf));
+            h.mats.emplace_back((size_t)(m.bin_size * m.bin_words), 0ull);
+            h.shapes.push_back(m);
         }
-        else
+        if (f.is_hibf)
         {
-            for (auto& m : f.ibfs)
-                h.mats.push_back(std::move(m));
             h.next = f.next_ibf_id;
             h.b2u  = f.bin_to_user;
             h.n_user_bins = f.n_user_bins;
         }
-        for (auto& m : h.mats)
-            h.ibfs.push_back(gno_ibf{ m.rows, m.bins, m.bin_size, m.bin_words, m.hash_shift, (uint32_t)m.hash_funs });
         h.off.push_back(0);
         for (auto const& b : f.target_bins)
         {
@@ -41,6 +39,27 @@ public:
         }
         h.n_targets = (uint32_t)f.targets.size();
         held_.push_back(std::move(h));
+        return true;
+    }
+    uint64_t* staging(int, size_t) override { return nullptr; }
+    bool      rows(uint32_t ibf, uint64_t row_begin, uint64_t n_rows, const uint64_t* src, std::string&) override
+    {
+        Held& h = held_.back();
+        std::copy(src, src + n_rows * h.shapes[ibf].bin_words, h.mats[ibf].begin() + row_begin * h.shapes[ibf].bin_words);
+        return true;
+    }
+    bool drain(std::string&) override { return true; }
+    bool end(std::string&) override
+    {
+        Held& h = held_.back();
+        for (size_t i = 0; i < h.mats.size(); ++i)
+        {
+            const IbfShape& m = h.shapes[i];
+            if (m.bins & 63) // padding bins are never reported (counting_vector has `bins` entries)
+                for (uint64_t r = 0; r < m.bin_size; ++r)
+                    h.mats[i][r * m.bin_words + m.bin_words - 1] &= (1ull << (m.bins & 63)) - 1ull;
+            h.ibfs.push_back(gno_ibf{ h.mats[i].data(), m.bins, m.bin_size, m.bin_words, m.hash_shift, (uint32_t)m.hash_funs });
+        }
         return true;
     }
     void clear_filters() override { held_.clear(); }
@@ -138,7 +157,8 @@ private:
     struct Held
     {
         bool                              is_hibf = false;
-        std::vector<IbfMatrix>            mats;
+        std::vector<std::vector<uint64_t>> mats;
+        std::vector<IbfShape>             shapes;
         std::vector<gno_ibf>              ibfs;
         std::vector<std::vector<int64_t>> next, b2u;
         uint64_t                          n_user_bins = 0;
@@ -149,8 +169,12 @@ private:
 };
 } // namespace
 
-std::unique_ptr<Backend> make_backend(int, std::string&)
+// one checker instance per requested "device" (the multi-worker pipeline is exercised with --device 0,0,..)
+std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devices, std::string&)
 {
-    return std::unique_ptr<Backend>(new OracleBackend());
+    std::vector<std::unique_ptr<Backend>> out;
+    for (size_t i = 0; i < std::max<size_t>(devices.size(), 1); ++i)
+        out.emplace_back(new OracleBackend());
+    return out;
 }
 } // namespace gnhost

@@ -3,6 +3,7 @@ post-processing -> writers) on the reference's scenarios.  On CPU the test-only 
 path; the gpu-marked twins run the product binary (libganon_hip.so through the C ABI)."""
 import os
 import shutil
+import subprocess
 
 import pytest
 
@@ -297,3 +298,94 @@ def test_config1_hip_equals_oracle_backend(oracle_bin, config1, tmp_path):
     b = _run_config1(oracle_bin, config1, str(tmp_path / "ora"))
     for ext in (".all", ".unc", ".rep", ".sta"):
         assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multi-worker pipeline: one classify worker per listed device, results consumed in input order
+# ---------------------------------------------------------------------------------------------------------------
+def _run_workers(binary, c1, out, devices, batch_reads="500"):
+    env = dict(os.environ, GANON_HOST_BATCH_READS=batch_reads)
+    p = subprocess.run([binary, "--ibf", c1["ibf"], "--single-reads", c1["fq"], "-o", out, "--output-all", "--output-unclassified",
+                        "--output-stats", "--quiet", "--device", devices], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr
+    return out
+
+
+def test_multi_worker_outputs_equal_single_worker_oracle_backend(oracle_bin, config1, tmp_path):
+    # 10 000 reads in 20 batches over 1, 2 and 5 workers: every output file byte-identical (GanonClassify.cpp:1579-1614:
+    # the reference's workers share one reader and their counters are summed; here the order is kept as well)
+    one = _run_workers(oracle_bin, config1, str(tmp_path / "w1"), "0")
+    big = _run_config1(oracle_bin, config1, str(tmp_path / "big"))  # one batch
+    for devs in ("0,0", "0,0,0,0,0"):
+        many = _run_workers(oracle_bin, config1, str(tmp_path / ("w" + str(len(devs)))), devs)
+        for ext in (".all", ".unc", ".rep", ".sta"):
+            assert open(many + ext, "rb").read() == open(one + ext, "rb").read() == open(big + ext, "rb").read(), (devs, ext)
+
+
+@pytest.mark.gpu
+def test_multi_worker_outputs_equal_single_worker_hip(oracle_bin, config1, tmp_path):
+    # the same with HIP backends: --device 0,0 = two workers, two replicas of the filter on one GPU
+    ref = _run_workers(oracle_bin, config1, str(tmp_path / "ora"), "0")
+    for devs in ("0", "0,0", "all"):
+        got = _run_workers(cu.BIN_HIP, config1, str(tmp_path / ("hip" + devs.replace(",", "_"))), devs)
+        for ext in (".all", ".unc", ".rep", ".sta"):
+            assert open(got + ext, "rb").read() == open(ref + ext, "rb").read(), (devs, ext)
+
+
+def test_device_argument_errors(oracle_bin, config1, tmp_path):
+    for bad in ("x", "0,,1", "-1"):
+        p = subprocess.run([oracle_bin, "--ibf", config1["ibf"], "--single-reads", config1["fq"], "-o", str(tmp_path / "e"), "--device", bad],
+                           capture_output=True, text=True)
+        assert p.returncode == 1 and "ERROR" in p.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# .ibf loader: the sdsl bit_vector header is not pinned by any reference fixture -> plausible variants are accepted,
+# anything else is refused; the payload is streamed in chunks
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bv_header", ["wgb", "b", "wb", "gb", "wgq", "q"])
+def test_ibf_loader_accepts_bit_vector_header_variants(oracle_bin, config1, tmp_path, bv_header):
+    ref = _run_config1(oracle_bin, config1, str(tmp_path / "ref"))
+    path = str(tmp_path / f"v_{bv_header}.ibf")
+    gf.write_ibf(path, config1["built"], bv_header=bv_header)
+    c = dict(config1, ibf=path)
+    got = _run_config1(oracle_bin, c, str(tmp_path / "got"))
+    for ext in (".all", ".rep"):
+        assert open(got + ext, "rb").read() == open(ref + ext, "rb").read()
+
+
+def test_ibf_loader_refuses_damaged_files(oracle_bin, config1, tmp_path):
+    raw = open(config1["ibf"], "rb").read()
+    payload = 40009 * 8
+    cases = {"truncated": raw[:-4096], "trailing": raw + b"\0" * 16, "bad_size": raw[:-payload - 8] + struct_pack_q(12345) + raw[-payload:],
+             "bad_width": raw[:-payload - 13] + b"\x02" + raw[-payload - 12:]}
+    for name, blob in cases.items():
+        path = str(tmp_path / f"{name}.ibf")
+        open(path, "wb").write(blob)
+        p = cu.run(oracle_bin, ["--ibf", path, "--single-reads", config1["fq"], "-o", str(tmp_path / name), "--quiet"], check=False)
+        assert p.returncode == 1 and "ERROR: loading ibf or tax files" in p.stderr, (name, p.stderr)
+
+
+def struct_pack_q(v):
+    import struct
+    return struct.pack("<Q", v)
+
+
+def test_host_lca_on_reference_vectors(tmp_path):
+    # /root/reference/tests/utils/LCA.test.cpp:17-107 against the PRODUCT's ganon_amd/host/lca.hpp (tests/test_oracle_kat.py
+    # runs the same vectors against the oracle's LCA)
+    subprocess.check_call(["make", "-C", os.path.join(cu.ROOT, "tests", "host_oracle"), "-s", "lca_check"])
+    exe = os.path.join(cu.ROOT, "tests", "host_oracle", "lca_check")
+    gold = os.path.join(cu.ROOT, "tests", "golden")
+    tree = [("D0", "E0,E1"), ("C3", "C3,F4"), ("A0", "G0,C3,D5"), ("1", "G0,G5"), ("B1", "B1,C2"), ("B1", "C2,B1"), ("B0", "C0,E1,F2"),
+            ("B0", "F2,E1,C0"), ("B0", "E1,C0,F2")]
+    ncbi = [("1224", "366602,470"), ("2", "366602,470,1406"), ("2290931", "2223,51589"), ("10239", "2025595,491893"),
+            ("1", "366602,470,1406,2223,51589,2025595,491893")]
+    for fn, cases in (("lca_tree.tax", tree), ("lca_ncbi.tax", ncbi)):
+        out = subprocess.run([exe, os.path.join(gold, fn), "1"] + [q for _, q in cases], capture_output=True, text=True, check=True)
+        assert out.stdout.split() == [w for w, _ in cases]
+    # robustness: a self-parent row cannot hang the walk; a node outside the rooted tree resolves to the root
+    bad = tmp_path / "bad.tax"
+    bad.write_text("1\t1\tno rank\troot\nA\t1\tx\tA\nB\tA\tx\tB\nC\tA\tx\tC\nZ\tY\tx\tdetached\n")
+    out = subprocess.run([exe, str(bad), "1", "B,C", "B,Z", "B,unknown"], capture_output=True, text=True, check=True, timeout=20)
+    assert out.stdout.split() == ["A", "1", "1"]
