@@ -677,7 +677,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
         hipStreamSynchronize(s->st);
     void* ptrs[] = { s->d_bases,  s->d_off1,    s->d_off2,      s->d_slot_cnt,  s->d_slot_off, s->d_hashes, s->d_nh,
                      s->d_status, s->d_matches, s->d_sorted,    s->d_ctr,       s->d_seg_begin, s->d_seg_count,
-                     s->d_seg_off, s->d_deferred, s->d_mdeferred, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_hdefer, s->d_hctr, s->d_keys[0], s->d_keys[1], s->d_vals[0],
+                     s->d_seg_off, s->d_deferred, s->d_mdeferred, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_hdefer, s->d_hdefer2, s->d_hctr, s->d_keys[0], s->d_keys[1], s->d_vals[0],
                      s->d_vals[1], s->d_sort_tmp };
     for (void* p : ptrs)
         if (p)
@@ -762,8 +762,9 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
         ok(gn_dmalloc(&s->d_work[0], s->work_cap));
         ok(gn_dmalloc(&s->d_work[1], s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer, s->work_cap));
-        ok(gn_dmalloc(&s->d_hctr, 2 * (GN_HIBF_MAXDEPTH + 1)));
-        ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), 2 * (GN_HIBF_MAXDEPTH + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+        ok(gn_dmalloc(&s->d_hdefer2, s->work_cap));
+        ok(gn_dmalloc(&s->d_hctr, 3 * (GN_HIBF_MAXDEPTH + 1)));
+        ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), 3 * (GN_HIBF_MAXDEPTH + 1) * sizeof(unsigned long long), hipHostMallocDefault));
     }
     ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), GN_NCTR * sizeof(unsigned long long), hipHostMallocDefault));
     if (e != hipSuccess)

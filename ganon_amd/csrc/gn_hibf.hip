@@ -93,8 +93,9 @@ struct GnHibfLevelParams
     uint64_t                  match_cap;
     uint32_t                  ub_bits;
     uint32_t                  lds_bins;  // LDS kernel: counters per wave
-    uint32_t                  n_reads;   // level 0 of the register-counter kernel: the reads are the items
+    uint32_t                  n_reads;   // level 0 of the register-counter kernels: the reads are the items
     const uint8_t*            status;
+    uint32_t                  pack_gp;   // packed kernel: log2 of the lanes per row every item of the launch must have
 };
 
 #define GN_HIBF_CHUNK 64u // wave-private slices of the work queue / match buffer (one global atomic per slice)
@@ -186,6 +187,294 @@ struct GnHibfAppender
             atomicAdd(&p.ctr[6], n_matches);
     }
 };
+
+// ================================================================================================
+// packed register-counter level kernel: 64/Gp ITEMS per wave side by side
+// ================================================================================================
+// For the narrow IBFs an HIBF is made of (a 256-bin IBF has 32-byte rows = 4 lanes) the per-item kernel below spends
+// most of its instructions adding up the 16 hash groups of a wave and hashing redundantly.  This kernel turns the
+// layout around: a group of Gp lanes owns one (read, ibf) ITEM and walks that item's minimisers one per iteration,
+// so a wave works on 64/Gp items at once, every lane accumulates exactly the 64 bins it will threshold itself --
+// no cross-lane sums at all -- and the lanes of a group share the h row hashes (lane i of the group computes
+// function i, the others fetch it with a lane permute).  Per iteration a wave still issues h coalesced requests that
+// touch 64/Gp different rows, so the memory system sees the same parallelism.
+// All items of a launch must use the same Gp (p.pack_gp: the most common lane width of the level's IBFs); items whose
+// IBF differs, has multi-bin runs, or whose read has more than 127 minimisers go to the per-item kernel's list.
+__device__ __forceinline__ uint32_t gn_hibf_row_seed(uint64_t v, uint64_t seed, uint32_t shift, uint32_t S)
+{
+    uint64_t x = v * seed;
+    x ^= x >> shift;
+    x *= 11400714819323198485ULL;
+    return (uint32_t)__umul64hi(x, (uint64_t)S);
+}
+
+template <int HF, bool LEVEL0>
+__global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
+{
+    const uint32_t lane   = threadIdx.x & (GN_WAVE - 1);
+    const uint32_t wave   = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t gpl    = p.pack_gp;
+    const uint32_t Gp     = 1u << gpl;
+    const uint32_t H      = GN_WAVE >> gpl;          // items per wave
+    const uint32_t gl     = lane & (Gp - 1);         // my word of the row
+    const uint32_t grp    = lane >> gpl;             // my item of the batch
+    const uint32_t gbase  = lane & ~(Gp - 1);        // first lane of my group
+    const bool     share  = Gp >= (uint32_t)HF;      // lane i of a group hashes function i for the whole group
+    const uint64_t my_seed = GN_HIBF_SEEDS[gl < (uint32_t)HF ? gl : 0u];
+
+    uint32_t n_work;
+    if constexpr (LEVEL0)
+        n_work = p.n_reads;
+    else
+    {
+        const unsigned long long nw64 = *p.count_in;
+        n_work                        = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
+    }
+    const uint32_t n_batches = (n_work + H - 1) / H;
+    const uint32_t stride    = gridDim.x * (blockDim.x >> 6);
+    uint32_t       batch     = (uint32_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (batch >= n_batches)
+        return;
+
+    GnHibfAppender     app;
+    unsigned long long my_bytes = 0;
+
+    // per-lane view of an item (the Gp lanes of a group hold identical copies)
+    struct Item
+    {
+        uint32_t read, ibf, n, W, shift, S;
+        uint64_t slot;
+        const __attribute__((address_space(1))) uint64_t* rows;
+        bool     ok;    // counted here
+        bool     defer; // valid, but left to the per-item kernel
+    };
+    auto load_item = [&](uint32_t b) -> Item {
+        Item           m{};
+        const uint32_t idx = b * H + grp;
+        uint32_t       read = 0xFFFFFFFFu, ibf = 0;
+        if (b < n_batches && idx < n_work)
+        {
+            if constexpr (LEVEL0)
+                read = p.status[idx] == GN_READ_OK ? idx : 0xFFFFFFFFu;
+            else
+            {
+                const uint2 e = p.work_in[idx];
+                read = e.x;
+                ibf  = e.y;
+            }
+        }
+        m.read = read;
+        m.ibf  = ibf;
+        if (read != 0xFFFFFFFFu)
+        {
+            const GnHibfIbfDev* f = p.ibfs + ibf;
+            m.n     = p.n_hashes[read];
+            m.slot  = p.slot_off[read];
+            m.W     = f->W;
+            m.S     = (uint32_t)f->S;
+            m.shift = f->shift;
+            m.rows  = gn_global(f->rows);
+            uint32_t g = m.W <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(m.W - 1);
+            m.ok    = m.W <= GN_WAVE && g == gpl && f->n_mruns == 0 && m.n >= 1 && m.n <= 127u;
+            m.defer = !m.ok && m.n >= 1;
+        }
+        return m;
+    };
+
+    Item cur = load_item(batch);
+    for (;;)
+    {
+        const Item nxt = load_item(batch + stride); // its loads fly behind this batch's row loop
+
+        // items this kernel does not count: one entry per group (lane gl == 0) on the per-item kernel's list
+        {
+            const uint64_t dm = __ballot(cur.defer && gl == 0);
+            if (dm)
+            {
+                unsigned long long base = 0;
+                if (lane == 0)
+                    base = atomicAdd(p.defer_count, (unsigned long long)__popcll(dm));
+                base = gn_hibf_bcast64(base);
+                if (cur.defer && gl == 0)
+                {
+                    const unsigned long long o = base + __popcll(dm & ((1ULL << lane) - 1ULL));
+                    if (o < p.work_cap)
+                        p.defer_out[o] = make_uint2(cur.read, cur.ibf);
+                }
+            }
+        }
+
+        const uint32_t n     = cur.ok ? cur.n : 0u;
+        const bool     col   = gl < cur.W;
+        const uint32_t gl_ld = col ? gl : 0u;
+        uint32_t       nib[2][4], byt[2][4][2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                nib[d][j]    = 0;
+                byt[d][j][0] = 0;
+                byt[d][j][1] = 0;
+            }
+        // longest item of the batch (wave-uniform trip count)
+        uint32_t n_max = n;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+        {
+            const uint32_t o = (uint32_t)__shfl_xor((int)n_max, off);
+            n_max            = o > n_max ? o : n_max;
+        }
+        n_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_max);
+
+        struct Rows
+        {
+            uint64_t m[HF];
+        };
+        const uint64_t hs_at = cur.slot; // (index into p.hashes)
+        auto issue = [&](uint32_t it, Rows& R) {
+            // every lane issues its loads unconditionally: finished / invalid items re-read their last (or any) row
+            const uint32_t q = n ? (it < n ? it : n - 1) : 0u;
+            const uint64_t v = p.hashes[n ? hs_at + q : 0ull]; // (unconditional: element 0 always exists)
+            uint32_t       row[HF];
+            if (share)
+            {
+                const uint32_t mine = gn_hibf_row_seed(v, my_seed, cur.shift, cur.S ? cur.S : 1u);
+#pragma unroll
+                for (int i = 0; i < HF; ++i)
+                    row[i] = (uint32_t)__shfl((int)mine, (int)(gbase + (uint32_t)i));
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < HF; ++i)
+                    row[i] = gn_hibf_row_seed(v, GN_HIBF_SEEDS[i], cur.shift, cur.S ? cur.S : 1u);
+            }
+            const auto* base = n ? cur.rows : gn_global(p.hashes); // items that are not counted: a readable address (element 0)
+            const uint32_t Wl = n ? cur.W : 0u;
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+                R.m[i] = base[(uint64_t)(n ? row[i] : 0u) * Wl + (n ? gl_ld : 0u)];
+        };
+        uint32_t acc_n = 0;
+        auto consume = [&](const Rows& R, uint32_t it) {
+            uint64_t a = R.m[0];
+#pragma unroll
+            for (int i = 1; i < HF; ++i)
+                a &= R.m[i];
+            if (!(col && it < n))
+                a = 0;
+            const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                nib[0][j] += (a0 >> j) & 0x11111111u;
+                nib[1][j] += (a1 >> j) & 0x11111111u;
+            }
+            if (++acc_n == 15)
+            {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                    {
+                        byt[d][j][0] += nib[d][j] & 0x0F0F0F0Fu;
+                        byt[d][j][1] += (nib[d][j] >> 4) & 0x0F0F0F0Fu;
+                        nib[d][j] = 0;
+                    }
+                acc_n = 0;
+            }
+        };
+        if (n_max)
+        {
+            Rows A, B;
+            issue(0, A);
+            uint32_t it = 0;
+            for (; it + 2 < n_max; it += 2)
+            {
+                issue(it + 1, B);
+                consume(A, it);
+                issue(it + 2, A);
+                consume(B, it + 1);
+            }
+            const bool two = it + 1 < n_max;
+            if (two)
+                issue(it + 1, B);
+            consume(A, it);
+            if (two)
+                consume(B, it + 1);
+        }
+        if (n && gl == 0)
+            my_bytes += (unsigned long long)n * HF * cur.W * 8ull; // algorithmic bytes of this visit (once per item)
+
+        // ---- threshold my own 64 bins; every bin of these IBFs is a run of its own (:445-458 with a run of length one) ----
+        // threshold_cutoff = max(1, ceil(n * rel_cutoff))  (GanonClassify.cpp:492-495,720-724); passed to bulk_count (:553)
+        uint32_t T = (uint32_t)(uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff));
+        if (T == 0)
+            T = 1;
+        const uint32_t Kc = (0x80u - T) * 0x01010101u; // counts <= n <= 127, 1 <= T <= 127: no carries between bytes
+        uint32_t       c0 = 0, c1 = 0;                 // candidate bits of my two dwords
+        if (n && col)
+        {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+                {
+                    byt[0][j][pp] += (nib[0][j] >> (4 * pp)) & 0x0F0F0F0Fu;
+                    byt[1][j][pp] += (nib[1][j] >> (4 * pp)) & 0x0F0F0F0Fu;
+                    c0 |= (((byt[0][j][pp] + Kc) & 0x80808080u) >> 7) << (4 * pp + j);
+                    c1 |= (((byt[1][j][pp] + Kc) & 0x80808080u) >> 7) << (4 * pp + j);
+                }
+        }
+        if (__ballot((c0 | c1) != 0))
+        {
+            const auto* bin_tab = (c0 | c1) ? gn_global(p.ibfs[cur.ibf].bin_tab) : gn_global((const uint32_t*)nullptr);
+            do
+            {
+                bool     merged = false, leaf = false;
+                uint32_t tgt = 0, sum = 0;
+                if (c0 | c1)
+                {
+                    const uint32_t d = c0 ? 0u : 1u;
+                    uint32_t&      c = c0 ? c0 : c1;
+                    const uint32_t t = (uint32_t)__builtin_ctz(c);
+                    c &= c - 1;
+                    const uint32_t y = t >> 3, pp = (t >> 2) & 1u, j = t & 3u;
+                    uint32_t       reg = 0;
+#pragma unroll
+                    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq)
+                                if ((uint32_t)dd == d && (uint32_t)jj == j && (uint32_t)qq == pp)
+                                    reg = byt[dd][jj][qq];
+                    sum                = (reg >> (8 * y)) & 0xFFu;
+                    const uint32_t tab = bin_tab[gl * 64 + 32 * d + t];
+                    if (tab != 0xFFFFFFFFu)
+                    {
+                        merged = (tab & 0x80000000u) != 0;
+                        leaf   = !merged;
+                        tgt    = tab & 0x7FFFFFFFu;
+                    }
+                }
+                app.push(p, (int)lane, merged, leaf, cur.read, tgt, sum);
+            } while (__ballot((c0 | c1) != 0));
+        }
+
+        batch += stride;
+        if (batch >= n_batches)
+            break;
+        cur = nxt;
+    }
+    app.finish(p, (int)lane);
+    // one atomic per wave
+    for (int off = 32; off >= 1; off >>= 1)
+        my_bytes += __shfl_xor(my_bytes, off);
+    if (lane == 0 && my_bytes)
+        atomicAdd(&p.ctr[2], my_bytes);
+}
 
 // ================================================================================================
 // register-counter level kernel
@@ -774,6 +1063,19 @@ int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const i
             }
         }
         f->max_depth = deepest;
+        // lanes per row that most IBFs of a level have: what the packed kernel of that level is launched for
+        f->level_gp.assign(deepest, 0u);
+        std::vector<std::vector<uint32_t>> votes(deepest, std::vector<uint32_t>(7, 0u));
+        for (uint32_t i = 0; i < n_ibf; ++i)
+            if (depth[i] >= 1)
+            {
+                uint32_t g = 0;
+                while ((1u << g) < dev[i].W && g < 6)
+                    ++g;
+                votes[depth[i] - 1][g]++;
+            }
+        for (uint32_t l = 0; l < deepest; ++l)
+            f->level_gp[l] = (uint32_t)(std::max_element(votes[l].begin(), votes[l].end()) - votes[l].begin());
     }
     GN_HIP(hipMalloc(reinterpret_cast<void**>(&f->d_hibf), n_ibf * sizeof(GnHibfIbfDev)));
     GN_HIP(hipMemcpy(f->d_hibf, dev.data(), n_ibf * sizeof(GnHibfIbfDev), hipMemcpyHostToDevice));
@@ -831,6 +1133,27 @@ static void gn_hibf_launch_reg(const GnHibfLevelParams& p, bool level0, uint32_t
         gn_hibf_launch_reg2<HF, false>(p, n_cu, bpc, st);
 }
 
+template <int HF, bool LEVEL0>
+static void gn_hibf_launch_pack2(const GnHibfLevelParams& p, uint32_t n_cu, uint32_t bpc, hipStream_t st)
+{
+    if (bpc == 0)
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_hibf_pack_kernel<HF, LEVEL0>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        bpc = (uint32_t)per_cu;
+    }
+    hipLaunchKernelGGL((gn_hibf_pack_kernel<HF, LEVEL0>), dim3(n_cu * bpc), dim3(256), 0, st, p);
+}
+template <int HF>
+static void gn_hibf_launch_pack(const GnHibfLevelParams& p, bool level0, uint32_t n_cu, uint32_t bpc, hipStream_t st)
+{
+    if (level0)
+        gn_hibf_launch_pack2<HF, true>(p, n_cu, bpc, st);
+    else
+        gn_hibf_launch_pack2<HF, false>(p, n_cu, bpc, st);
+}
+
 // Runs all levels back to back (queue lengths stay on the device), synchronises ONCE, then sorts/groups the matches.
 int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
 {
@@ -846,11 +1169,13 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         return gn_fail(GN_ERANGE, "read index and user bin do not fit one 64-bit sort key");
     GN_HIP(hipMemsetAsync(s->d_ctr + 2, 0, 2 * sizeof(unsigned long long), st)); // algo bytes, (unused)
     GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
-    GN_HIP(hipMemsetAsync(s->d_hctr, 0, 2 * NL * sizeof(unsigned long long), st));
+    GN_HIP(hipMemsetAsync(s->d_hctr, 0, 3 * NL * sizeof(unsigned long long), st));
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
-    const uint32_t h     = f->ibfs[0].h;
-    const bool     no_reg = getenv("GANON_HIP_HIBF_NO_REG") != nullptr; // tests / A-B: everything through the LDS kernel
-    if (n && no_reg) // (the register-counter kernel takes level 0 straight from the batch)
+    const uint32_t h      = f->ibfs[0].h;
+    // tests / A-B: skip the packed kernel (the per-item register kernel takes whole levels), or both (LDS kernel only)
+    const bool     no_reg  = getenv("GANON_HIP_HIBF_NO_REG") != nullptr;
+    const bool     no_pack = no_reg || getenv("GANON_HIP_HIBF_NO_PACK") != nullptr;
+    if (n && no_reg) // (the register-counter kernels take level 0 straight from the batch)
         hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n, s->d_hctr);
     const uint32_t reg_bpc = getenv("GANON_HIP_HIBF_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_HIBF_BPC")) : 0u; // 0 = occupancy
     for (uint32_t lvl = 0; lvl < depth && n; ++lvl)
@@ -865,8 +1190,6 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         p.count_in    = s->d_hctr + lvl;
         p.work_out    = s->d_work[(lvl + 1) & 1];
         p.count_out   = s->d_hctr + lvl + 1;
-        p.defer_out   = s->d_hdefer;
-        p.defer_count = s->d_hctr + NL + lvl;
         p.work_cap    = s->work_cap;
         p.ctr         = s->d_ctr;
         p.keys        = s->d_keys[0];
@@ -876,22 +1199,42 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         p.lds_bins    = f->max_bins;
         p.n_reads     = n;
         p.status      = s->d_status;
-        if (!no_reg)
+        p.pack_gp     = lvl < f->level_gp.size() ? f->level_gp[lvl] : 0u;
+        bool level0   = lvl == 0; // the first register kernel of level 0 takes the reads themselves as its items
+        if (!no_pack)
         {
-            const bool l0 = lvl == 0;
+            p.defer_out   = s->d_hdefer;
+            p.defer_count = s->d_hctr + NL + lvl;
             switch (h)
             {
-                case 1: gn_hibf_launch_reg<1>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 2: gn_hibf_launch_reg<2>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 3: gn_hibf_launch_reg<3>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 4: gn_hibf_launch_reg<4>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                default: gn_hibf_launch_reg<5>(p, l0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 1: gn_hibf_launch_pack<1>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 2: gn_hibf_launch_pack<2>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 3: gn_hibf_launch_pack<3>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 4: gn_hibf_launch_pack<4>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                default: gn_hibf_launch_pack<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
             }
             GN_HIP(hipGetLastError());
             p.work_in  = s->d_hdefer;
             p.count_in = s->d_hctr + NL + lvl;
+            level0     = false;
         }
-        // LDS-counter kernel: the deferred items (or, with the switch above, the whole level)
+        if (!no_reg)
+        {
+            p.defer_out   = s->d_hdefer2;
+            p.defer_count = s->d_hctr + 2 * NL + lvl;
+            switch (h)
+            {
+                case 1: gn_hibf_launch_reg<1>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 2: gn_hibf_launch_reg<2>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 3: gn_hibf_launch_reg<3>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                case 4: gn_hibf_launch_reg<4>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                default: gn_hibf_launch_reg<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+            }
+            GN_HIP(hipGetLastError());
+            p.work_in  = s->d_hdefer2;
+            p.count_in = s->d_hctr + 2 * NL + lvl;
+        }
+        // LDS-counter kernel: what the register kernels left (or, with the switch above, the whole level)
         const uint32_t wpb = (size_t)f->max_bins * 4 * 4 <= 64 * 1024 ? 4 : 1; // waves per block by LDS need
         const size_t   lds = (size_t)f->max_bins * 4 * wpb;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_hibf_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -900,16 +1243,16 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         GN_HIP(hipGetLastError());
     }
     // the one synchronisation of the batch: queue lengths (overflow check) and the match cursor (sort size)
-    GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, 2 * NL * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, 3 * NL * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
     uint64_t worst = 0;
-    for (uint32_t i = 0; i < 2 * NL; ++i)
+    for (uint32_t i = 0; i < 3 * NL; ++i)
         worst = std::max<uint64_t>(worst, s->h_hctr[i]);
     if (worst > s->work_cap)
     {
         // a queue overflowed (entries past the capacity were dropped): grow the queues and run the batch again
-        for (uint2** q : { &s->d_work[0], &s->d_work[1], &s->d_hdefer })
+        for (uint2** q : { &s->d_work[0], &s->d_work[1], &s->d_hdefer, &s->d_hdefer2 })
         {
             hipFree(*q);
             *q = nullptr;
@@ -918,6 +1261,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[0]), (size_t)s->work_cap * sizeof(uint2)));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[1]), (size_t)s->work_cap * sizeof(uint2)));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_hdefer), (size_t)s->work_cap * sizeof(uint2)));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_hdefer2), (size_t)s->work_cap * sizeof(uint2)));
         GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
         return gn_hibf_classify(s, f, st);
     }

@@ -192,6 +192,7 @@ struct gn_filter
     uint64_t               n_user_bins = 0;
     uint32_t               max_bins = 0;
     uint32_t               max_depth = 0;
+    std::vector<uint32_t>  level_gp;  // per tree level: log2(lanes per row) most of its IBFs have (packed kernel)
 };
 
 struct gn_stream
@@ -227,8 +228,9 @@ struct gn_stream
     size_t              scan_tmp_bytes = 0;
     // hibf work queues + sort buffers
     uint2*        d_work[2]{ nullptr, nullptr };
-    uint2*        d_hdefer = nullptr;  // (read, ibf) items the register-counter kernel leaves to the LDS-counter kernel
-    unsigned long long* d_hctr = nullptr; // per level: [l] queue length of level l, [GN_HIBF_MAXDEPTH+1+l] deferred items
+    uint2*        d_hdefer = nullptr;  // (read, ibf) items the packed kernel leaves to the per-item register-counter kernel
+    uint2*        d_hdefer2 = nullptr; // ... and those that one leaves to the LDS-counter kernel
+    unsigned long long* d_hctr = nullptr; // NL = GN_HIBF_MAXDEPTH+1 per row: [l] queue length of level l, [NL+l] / [2NL+l] deferred items
     unsigned long long* h_hctr = nullptr; // pinned copy
     uint32_t      work_cap = 0;
     uint64_t*     d_keys[2]{ nullptr, nullptr };

@@ -247,7 +247,8 @@ def test_hibf_parity(hip, n_ub, tmax, depth, rel_cutoff):
 @pytest.mark.parametrize("n_ub,tmax,depth,h,rel_cutoff", [(300, 64, 2, 2, 0.3), (700, 128, 3, 4, 0.6), (400, 320, 2, 5, 0.2),
                                                            (6000, 4480, 2, 3, 0.5), (150, 64, 2, 1, 0.9)])
 def test_hibf_register_kernel_vs_lds_kernel_vs_oracle(hip, monkeypatch, n_ub, tmax, depth, h, rel_cutoff):
-    # gn_hibf_reg_kernel (W <= 64 words, n <= 127) against gn_hibf_level_kernel (everything; forced with the switch) and
+    # gn_hibf_pack_kernel (64/Gp items per wave; IBFs of the level's common lane width, single-bin runs) -> gn_hibf_reg_kernel
+    # (one item per wave: other widths, split user bins) -> gn_hibf_level_kernel (everything; forced with the switches) and
     # the oracle: short, medium (n ~ 70) and long reads (n > 127: deferred to the LDS kernel inside a level), 1..5 hash
     # functions, an IBF wider than 64 words (tmax 4480 -> W = 70: deferred), split user bins, holes in the queues
     k, w = 19, 31
@@ -269,11 +270,12 @@ def test_hibf_register_kernel_vs_lds_kernel_vs_oracle(hip, monkeypatch, n_ub, tm
     st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
     assert nh.max() > 127 and (nh[nh > 0] <= 127).any()
     tm = st.timings()
-    monkeypatch.setenv("GANON_HIP_HIBF_NO_REG", "1")
-    st2, nh2, status2, mo2, m2 = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
-    monkeypatch.delenv("GANON_HIP_HIBF_NO_REG")
-    assert np.array_equal(nh, nh2) and np.array_equal(mo, mo2) and np.array_equal(m, m2)
-    assert st2.timings()["algo_bytes"] == tm["algo_bytes"]
+    for switch in ("GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG"):  # per-item register kernel first / LDS kernel only
+        monkeypatch.setenv(switch, "1")
+        st2, nh2, status2, mo2, m2 = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
+        monkeypatch.delenv(switch)
+        assert np.array_equal(nh, nh2) and np.array_equal(mo, mo2) and np.array_equal(m, m2), switch
+        assert st2.timings()["algo_bytes"] == tm["algo_bytes"], switch
     ho, hs = st.fetch_hashes()
     n_true, algo = 0, 0
     for i in range(len(seqs)):
