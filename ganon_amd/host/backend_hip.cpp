@@ -13,6 +13,14 @@ namespace gnhost
 namespace
 {
 
+// Rows wider than this many 64-bin words are cut into column parts, each a flat IBF of its own on the device (the flat
+// count kernels give a row at most 16 wave slices; the reference has no such limit, and ganon-build databases with more
+// than 131 072 technical bins exist).  A part is what ganon_amd/partition.py gives one GPU of a bin-range partitioned
+// filter, only that all parts live in the same HBM: cut at 64-bin word boundaries between targets, rows re-laid-out per
+// part by the strided copy of gn_filter_write_rows, per-target cutoff applied inside the part (a target's bins never
+// straddle a cut), matches concatenated per read in part order.
+constexpr uint64_t kPartWords = 1024; // 65 536 bins: eight wave slices of 16-byte lanes
+
 class HipBackend final : public Backend
 {
 public:
@@ -28,18 +36,89 @@ public:
     // ---- FilterSink: the filter is created empty on the device, its rows arrive in chunks ----------------------
     bool begin(const FilterMeta& f, std::string& err) override
     {
-        gn_filter* h  = nullptr;
-        int        rc = 0;
+        Logical lf;
+        lf.row_words.clear();
+        for (auto const& m : f.shapes)
+            lf.row_words.push_back(m.bin_words);
         if (!f.is_hibf)
         {
-            const IbfShape& m = f.shapes.at(0);
-            gn_ibf_desc     d{ nullptr, m.bin_size, m.bin_words, m.bins, (uint32_t)m.hash_funs, (uint32_t)m.hash_shift };
+            const IbfShape&       m = f.shapes.at(0);
             std::vector<uint32_t> bin2target(m.bins, 0xFFFFFFFFu);
             for (size_t t = 0; t < f.targets.size(); ++t)
                 for (uint64_t b : f.target_bins[t])
                     bin2target[b] = (uint32_t)t;
-            rc = gn_filter_upload_ibf(device_, &d, bin2target.data(), (uint32_t)f.targets.size(), &h);
-            userbin_to_target_.emplace_back();
+            // column parts: [word_lo, word_hi) with cuts moved left to the nearest boundary between two targets
+            std::vector<uint64_t> cuts{ 0 };
+            while (m.bin_words - cuts.back() > kPartWords)
+            {
+                uint64_t c = cuts.back() + kPartWords;
+                while (c > cuts.back() + 1)
+                {
+                    const uint32_t left = bin2target[c * 64 - 1], right = bin2target[c * 64];
+                    if (left != right || left == 0xFFFFFFFFu)
+                        break;
+                    --c;
+                }
+                if (c == cuts.back() + 1 && bin2target[c * 64 - 1] == bin2target[c * 64] && bin2target[c * 64] != 0xFFFFFFFFu)
+                {
+                    err = "a target owns more than " + std::to_string(kPartWords * 64) + " consecutive technical bins: the filter cannot be cut into column parts";
+                    return false;
+                }
+                cuts.push_back(c);
+            }
+            cuts.push_back(m.bin_words);
+            for (size_t g = 0; g + 1 < cuts.size(); ++g)
+            {
+                Part part;
+                part.word_lo = cuts[g];
+                part.words   = cuts[g + 1] - cuts[g];
+                const uint64_t bin_lo = part.word_lo * 64, bins = std::min<uint64_t>(m.bins, cuts[g + 1] * 64) - bin_lo;
+                std::vector<uint32_t> local(bins, 0xFFFFFFFFu);
+                if (cuts.size() == 2)
+                    local = bin2target; // the whole filter: target ids are the caller's
+                else
+                {
+                    // local target ids in order of appearance (targets ascend with bins, filter_io.cpp)
+                    for (uint64_t b = 0; b < bins; ++b)
+                    {
+                        const uint32_t t = bin2target[bin_lo + b];
+                        if (t == 0xFFFFFFFFu)
+                            continue;
+                        if (part.to_target.empty() || part.to_target.back() != t)
+                        {
+                            // (a target seen before can only come back if its bins are not contiguous)
+                            auto it = std::find(part.to_target.begin(), part.to_target.end(), t);
+                            if (it != part.to_target.end())
+                            {
+                                local[b] = (uint32_t)(it - part.to_target.begin());
+                                continue;
+                            }
+                            part.to_target.push_back(t);
+                        }
+                        local[b] = (uint32_t)part.to_target.size() - 1;
+                    }
+                    for (uint32_t t : part.to_target) // every bin of an owned target must be inside the part
+                        for (uint64_t b : f.target_bins[t])
+                            if (b < bin_lo || b >= bin_lo + bins)
+                            {
+                                err = "target '" + f.targets[t] + "' has technical bins on both sides of a column cut (its bins are not "
+                                      "contiguous): this filter is too wide for one row group";
+                                for (auto& q : lf.parts)
+                                    gn_filter_free(q.f);
+                                return false;
+                            }
+                }
+                gn_ibf_desc d{ nullptr, m.bin_size, part.words, bins, (uint32_t)m.hash_funs, (uint32_t)m.hash_shift };
+                const uint32_t nt = cuts.size() == 2 ? (uint32_t)f.targets.size() : (uint32_t)std::max<size_t>(part.to_target.size(), 1);
+                if (gn_filter_upload_ibf(device_, &d, local.data(), nt, &part.f) != GN_OK)
+                {
+                    err = gn_last_error();
+                    for (auto& q : lf.parts)
+                        gn_filter_free(q.f);
+                    return false;
+                }
+                lf.parts.push_back(std::move(part));
+            }
         }
         else
         {
@@ -52,26 +131,20 @@ public:
                 nx.push_back(f.next_ibf_id[i].data());
                 bu.push_back(f.bin_to_user[i].data());
             }
-            rc = gn_filter_upload_hibf(device_, (uint32_t)descs.size(), descs.data(), nx.data(), bu.data(), f.n_user_bins, &h);
+            Part part;
+            if (gn_filter_upload_hibf(device_, (uint32_t)descs.size(), descs.data(), nx.data(), bu.data(), f.n_user_bins, &part.f) != GN_OK)
+            {
+                err = gn_last_error();
+                return false;
+            }
             // user bin -> target index (select_matches(THIBF) reads counts[bins[0]], GanonClassify.cpp:556-558)
-            std::vector<uint32_t> ub2t(f.n_user_bins, 0xFFFFFFFFu);
+            part.to_target.assign(f.n_user_bins, 0xFFFFFFFFu);
             for (size_t t = 0; t < f.targets.size(); ++t)
-                ub2t[f.target_bins[t][0]] = (uint32_t)t;
-            userbin_to_target_.push_back(std::move(ub2t));
+                part.to_target[f.target_bins[t][0]] = (uint32_t)t;
+            lf.is_hibf = true;
+            lf.parts.push_back(std::move(part));
         }
-        if (rc != GN_OK)
-        {
-            err = gn_last_error();
-            userbin_to_target_.pop_back();
-            return false;
-        }
-        loading_words_.clear();
-        for (auto const& m : f.shapes)
-            loading_words_.push_back(m.bin_words);
-        filters_.push_back(h);
-        streams_.push_back(nullptr);
-        stream_reads_.push_back(0);
-        stream_bases_.push_back(0);
+        filters_.push_back(std::move(lf));
         return true;
     }
 
@@ -95,52 +168,56 @@ public:
 
     bool rows(uint32_t ibf, uint64_t row_begin, uint64_t n_rows, const uint64_t* src, std::string& err) override
     {
-        // asynchronous on the filter's load stream when src is pinned (gn_filter_write_rows); src holds whole rows
-        if (ibf >= loading_words_.size())
+        // asynchronous on the filter's load stream when src is pinned (gn_filter_write_rows); src holds whole rows, every
+        // column part takes its words of them
+        Logical& lf = filters_.back();
+        if (ibf >= lf.row_words.size())
         {
             err = "rows for an IBF the filter does not have";
             return false;
         }
-        if (gn_filter_write_rows(filters_.back(), ibf, row_begin, n_rows, src, loading_words_[ibf], 0) != GN_OK)
-        {
-            err = gn_last_error();
-            return false;
-        }
+        for (auto& part : lf.parts)
+            if (gn_filter_write_rows(part.f, lf.is_hibf ? ibf : 0, row_begin, n_rows, src, lf.row_words[ibf], part.word_lo) != GN_OK)
+            {
+                err = gn_last_error();
+                return false;
+            }
         return true;
     }
 
     bool drain(std::string& err) override
     {
-        if (!filters_.empty() && gn_filter_write_sync(filters_.back()) != GN_OK)
-        {
-            err = gn_last_error();
-            return false;
-        }
+        if (!filters_.empty())
+            for (auto& part : filters_.back().parts)
+                if (gn_filter_write_sync(part.f) != GN_OK)
+                {
+                    err = gn_last_error();
+                    return false;
+                }
         return true;
     }
 
     bool end(std::string& err) override
     {
-        if (gn_filter_finalize(filters_.back()) != GN_OK)
-        {
-            err = gn_last_error();
-            return false;
-        }
+        for (auto& part : filters_.back().parts)
+            if (gn_filter_finalize(part.f) != GN_OK)
+            {
+                err = gn_last_error();
+                return false;
+            }
         return true;
     }
 
     void clear_filters() override
     {
-        for (auto* s : streams_)
-            if (s)
-                gn_stream_destroy(s);
-        for (auto* f : filters_)
-            gn_filter_free(f);
-        streams_.clear();
+        for (auto& lf : filters_)
+            for (auto& part : lf.parts)
+            {
+                if (part.s)
+                    gn_stream_destroy(part.s);
+                gn_filter_free(part.f);
+            }
         filters_.clear();
-        stream_reads_.clear();
-        stream_bases_.clear();
-        userbin_to_target_.clear();
     }
 
     bool classify(const ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
@@ -150,80 +227,67 @@ public:
         out.n_hashes.assign(n, 0);
         out.status.assign(n, 0);
         out.per_filter.resize(filters_.size());
-        // submit to every filter's stream first (asynchronous), then fetch
+        // submit to every stream first (asynchronous), then fetch
+        const uint64_t nb = std::max<uint64_t>(b.bases.size(), 1);
         for (size_t i = 0; i < filters_.size(); ++i)
-        {
-            const uint64_t nb = std::max<uint64_t>(b.bases.size(), 1);
-            if (!streams_[i] || stream_reads_[i] < n || stream_bases_[i] < nb)
+            for (auto& part : filters_[i].parts)
             {
-                if (streams_[i])
-                    gn_stream_destroy(streams_[i]);
-                streams_[i]       = nullptr;
-                const uint32_t cr = std::max<uint32_t>(n, 1u << 16);
-                const uint64_t cb = std::max<uint64_t>(nb, 1ull << 24);
-                if (gn_stream_create(filters_[i], cr, cb, 0, &streams_[i]) != GN_OK)
+                if (!part.s || part.stream_reads < n || part.stream_bases < nb)
+                {
+                    if (part.s)
+                        gn_stream_destroy(part.s);
+                    part.s            = nullptr;
+                    const uint32_t cr = std::max<uint32_t>(n, 1u << 16);
+                    const uint64_t cb = std::max<uint64_t>(nb, 1ull << 24);
+                    if (gn_stream_create(part.f, cr, cb, 0, &part.s) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
+                    part.stream_reads = cr;
+                    part.stream_bases = cb;
+                }
+                if (gn_submit_batch(part.s, b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr, n, k, w,
+                                    rel_cutoff[i])
+                    != GN_OK)
                 {
                     err = gn_last_error();
                     return false;
                 }
-                stream_reads_[i] = cr;
-                stream_bases_[i] = cb;
             }
-            if (gn_submit_batch(streams_[i], b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr, n,
-                                k, w, rel_cutoff[i])
-                != GN_OK)
-            {
-                err = gn_last_error();
-                return false;
-            }
-        }
         for (size_t i = 0; i < filters_.size(); ++i)
         {
+            Logical&      lf = filters_[i];
             FilterResult& fr = out.per_filter[i];
             fr.match_off.assign((size_t)n + 1, 0);
-            uint64_t need = 0;
-            if (gn_fetch_batch(streams_[i], out.n_hashes.data(), out.status.data(), fr.match_off.data(), nullptr, 0, &need) != GN_OK)
+            fr.matches.clear();
+            if (lf.parts.size() == 1)
             {
-                err = gn_last_error();
-                return false;
+                if (!fetch_part(lf.parts[0], n, out, fr.match_off, fr.matches, err))
+                    return false;
+                continue;
             }
-            tmp_.resize(need ? need : 1);
-            if (gn_fetch_batch(streams_[i], nullptr, nullptr, nullptr, tmp_.data(), tmp_.size(), &need) != GN_OK)
+            // several column parts: the matches of a read are its parts' matches behind each other (targets ascend with
+            // the bins, so the concatenation is already in target order)
+            std::vector<std::vector<uint64_t>> offs(lf.parts.size());
+            std::vector<std::vector<Match>>    ms(lf.parts.size());
+            for (size_t g = 0; g < lf.parts.size(); ++g)
             {
-                err = gn_last_error();
-                return false;
+                offs[g].assign((size_t)n + 1, 0);
+                if (!fetch_part(lf.parts[g], n, out, offs[g], ms[g], err))
+                    return false;
+                for (uint32_t r = 0; r < n; ++r)
+                    fr.match_off[r + 1] += offs[g][r + 1] - offs[g][r];
             }
-            fr.matches.resize(need);
-            const auto& ub2t = userbin_to_target_[i];
-            for (uint64_t j = 0; j < need; ++j)
+            for (uint32_t r = 0; r < n; ++r)
+                fr.match_off[r + 1] += fr.match_off[r];
+            fr.matches.resize(fr.match_off[n]);
+            for (uint32_t r = 0; r < n; ++r)
             {
-                uint32_t t = tmp_[j].target;
-                if (!ub2t.empty())
-                    t = ub2t[t]; // HIBF reports user bins
-                fr.matches[j] = Match{ tmp_[j].read, t, tmp_[j].count };
-            }
-            if (!ub2t.empty())
-            {
-                // user bins that belong to no target (cannot happen with raptor indices) are dropped
-                bool drop = false;
-                for (auto const& m : fr.matches)
-                    if (m.target == 0xFFFFFFFFu)
-                        drop = true;
-                if (drop)
-                {
-                    std::vector<Match>    keep;
-                    std::vector<uint64_t> off((size_t)n + 1, 0);
-                    for (auto const& m : fr.matches)
-                        if (m.target != 0xFFFFFFFFu)
-                        {
-                            keep.push_back(m);
-                            off[m.read + 1]++;
-                        }
-                    for (uint32_t r = 0; r < n; ++r)
-                        off[r + 1] += off[r];
-                    fr.matches.swap(keep);
-                    fr.match_off.swap(off);
-                }
+                uint64_t o = fr.match_off[r];
+                for (size_t g = 0; g < lf.parts.size(); ++g)
+                    for (uint64_t x = offs[g][r]; x < offs[g][r + 1]; ++x)
+                        fr.matches[o++] = ms[g][x];
             }
         }
         return true;
@@ -242,15 +306,73 @@ private:
         void*  ptr   = nullptr;
         size_t bytes = 0;
     };
-    int                                device_;
-    Stage                              stage_[2];
-    std::vector<gn_filter*>            filters_;
-    std::vector<gn_stream*>            streams_;
-    std::vector<uint32_t>              stream_reads_;
-    std::vector<uint64_t>              stream_bases_;
-    std::vector<std::vector<uint32_t>> userbin_to_target_;
-    std::vector<gn_match>              tmp_;
-    std::vector<uint64_t>              loading_words_; // bin_words of every IBF of the filter being loaded
+    struct Part
+    {
+        gn_filter*            f = nullptr;
+        gn_stream*            s = nullptr;
+        uint32_t              stream_reads = 0;
+        uint64_t              stream_bases = 0;
+        uint64_t              word_lo = 0, words = 0;
+        std::vector<uint32_t> to_target; // device target id -> index into FilterMeta::targets (empty: the same)
+    };
+    struct Logical
+    {
+        bool                  is_hibf = false;
+        std::vector<Part>     parts;     // one, or the column parts of a wide flat filter
+        std::vector<uint64_t> row_words; // bin_words of every IBF as stored in the file
+    };
+
+    // n_hashes / status (the same for every part), match offsets and matches of one device filter, target ids translated
+    bool fetch_part(Part& part, uint32_t n, BatchResult& out, std::vector<uint64_t>& match_off, std::vector<Match>& matches,
+                    std::string& err)
+    {
+        uint64_t need = 0;
+        if (gn_fetch_batch(part.s, out.n_hashes.data(), out.status.data(), match_off.data(), nullptr, 0, &need) != GN_OK)
+        {
+            err = gn_last_error();
+            return false;
+        }
+        tmp_.resize(need ? need : 1);
+        if (gn_fetch_batch(part.s, nullptr, nullptr, nullptr, tmp_.data(), tmp_.size(), &need) != GN_OK)
+        {
+            err = gn_last_error();
+            return false;
+        }
+        matches.resize(need);
+        bool drop = false;
+        for (uint64_t j = 0; j < need; ++j)
+        {
+            uint32_t t = tmp_[j].target;
+            if (!part.to_target.empty())
+            {
+                t = part.to_target[t]; // HIBF: user bin -> target; column part: local -> global target
+                drop |= t == 0xFFFFFFFFu;
+            }
+            matches[j] = Match{ tmp_[j].read, t, tmp_[j].count };
+        }
+        if (drop)
+        {
+            // user bins that belong to no target (cannot happen with raptor indices) are dropped
+            std::vector<Match>    keep;
+            std::vector<uint64_t> off((size_t)n + 1, 0);
+            for (auto const& m : matches)
+                if (m.target != 0xFFFFFFFFu)
+                {
+                    keep.push_back(m);
+                    off[m.read + 1]++;
+                }
+            for (uint32_t r = 0; r < n; ++r)
+                off[r + 1] += off[r];
+            matches.swap(keep);
+            match_off.swap(off);
+        }
+        return true;
+    }
+
+    int                   device_;
+    Stage                 stage_[2];
+    std::vector<Logical>  filters_;
+    std::vector<gn_match> tmp_;
 };
 
 } // namespace

@@ -389,3 +389,74 @@ def test_host_lca_on_reference_vectors(tmp_path):
     bad.write_text("1\t1\tno rank\troot\nA\t1\tx\tA\nB\tA\tx\tB\nC\tA\tx\tC\nZ\tY\tx\tdetached\n")
     out = subprocess.run([exe, str(bad), "1", "B,C", "B,Z", "B,unknown"], capture_output=True, text=True, check=True, timeout=20)
     assert out.stdout.split() == ["A", "1", "1"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# filters wider than one row group of the flat kernels (> 65 536 technical bins): the binary cuts them into column parts
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def wide_db(tmp_path_factory):
+    import numpy as np
+    import oracle
+    d = str(tmp_path_factory.mktemp("wide"))
+    rng = np.random.default_rng(77)
+    bins, rows, h = 150_000, 311, 3        # W = 2344 words -> three column parts (cuts moved to target boundaries)
+    ibf = gf.random_ibf(bins, rows, h, 0.05, seed=9)
+    bin_map, hc = [], []
+    b, t = 0, 0
+    while b < bins:                        # targets own 1..3 consecutive bins
+        run = int(rng.choice([1, 1, 1, 2, 3]))
+        run = min(run, bins - b)
+        for x in range(run):
+            bin_map.append((b + x, f"t{t}"))
+        hc.append((f"t{t}", 10 * run))
+        b += run
+        t += 1
+    genomes = {}
+    for gi in range(60):
+        tb = int(rng.integers(0, bins))
+        name = bin_map[tb][1]
+        g = "".join("ACGT"[x] for x in rng.integers(0, 4, size=1200))
+        genomes[name] = g
+        ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), 19, 31)), tb)
+    built = gf.BuiltIbf()
+    built.ibf = ibf
+    built.config = dict(n_bins=bins, max_hashes_bin=10, hash_functions=h, kmer_size=19, window_size=31, bin_size_bits=rows,
+                        max_fp=0.05, true_max_fp=0.05, true_avg_fp=0.05)
+    built.hashes_count = hc
+    built.bin_map = bin_map
+    path = os.path.join(d, "wide.ibf")
+    gf.write_ibf(path, built)
+    recs = []
+    names = sorted(genomes)
+    for i in range(300):
+        if i % 3:
+            g = genomes[names[i % len(names)]]
+            p = int(rng.integers(0, 1000))
+            recs.append((f"r{i}", g[p:p + 150]))
+        else:
+            recs.append((f"r{i}", "".join("ACGT"[x] for x in rng.integers(0, 4, size=150))))
+    fq = os.path.join(d, "reads.fq")
+    gf.write_fastq(fq, recs)
+    return dict(ibf=path, fq=fq, n_targets=t)
+
+
+def _run_wide(binary, db, out):
+    cu.run(binary, ["--ibf", db["ibf"], "--single-reads", db["fq"], "-o", out, "--output-all", "--output-unclassified", "--rel-cutoff",
+                    "0.5", "--quiet"])
+    return out
+
+
+def test_wide_filter_oracle_backend(oracle_bin, wide_db, tmp_path):
+    res = cu.Res(_run_wide(oracle_bin, wide_db, str(tmp_path / "w")), lca_file=False)
+    res.sanity_check(output_lca=False)
+    assert res.total_classified >= 190 and res.total_classified + res.total_unclassified == 300
+
+
+@pytest.mark.gpu
+def test_wide_filter_hip_column_parts_equal_oracle_backend(oracle_bin, wide_db, tmp_path):
+    # 150 000 technical bins = 2344 words per row: three device filters behind one --ibf
+    a = _run_wide(cu.BIN_HIP, wide_db, str(tmp_path / "hip"))
+    b = _run_wide(oracle_bin, wide_db, str(tmp_path / "ora"))
+    for ext in (".all", ".unc", ".rep"):
+        assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext
