@@ -19,7 +19,7 @@ namespace
 // filter, only that all parts live in the same HBM: cut at 64-bin word boundaries between targets, rows re-laid-out per
 // part by the strided copy of gn_filter_write_rows, per-target cutoff applied inside the part (a target's bins never
 // straddle a cut), matches concatenated per read in part order.
-constexpr uint64_t kPartWords = 1024; // 65 536 bins: eight wave slices of 16-byte lanes
+constexpr uint64_t kPartWords = 512; // 32 768 bins: four wave slices of 16-byte lanes (the row shape of BASELINE config 4)
 
 class HipBackend final : public Backend
 {
@@ -51,15 +51,21 @@ public:
             std::vector<uint64_t> cuts{ 0 };
             while (m.bin_words - cuts.back() > kPartWords)
             {
-                uint64_t c = cuts.back() + kPartWords;
-                while (c > cuts.back() + 1)
-                {
+                // the nearest legal cut at or below the full part width; an even number of words is preferred (16-byte lanes)
+                auto legal = [&](uint64_t c) {
                     const uint32_t left = bin2target[c * 64 - 1], right = bin2target[c * 64];
-                    if (left != right || left == 0xFFFFFFFFu)
-                        break;
+                    return left != right || left == 0xFFFFFFFFu;
+                };
+                uint64_t c = cuts.back() + kPartWords, odd = 0;
+                while (c > cuts.back() + 1 && !(legal(c) && ((c - cuts.back()) & 1u) == 0))
+                {
+                    if (!odd && legal(c))
+                        odd = c;
                     --c;
                 }
-                if (c == cuts.back() + 1 && bin2target[c * 64 - 1] == bin2target[c * 64] && bin2target[c * 64] != 0xFFFFFFFFu)
+                if (!(legal(c) && ((c - cuts.back()) & 1u) == 0) && odd)
+                    c = odd;
+                if (!legal(c))
                 {
                     err = "a target owns more than " + std::to_string(kPartWords * 64) + " consecutive technical bins: the filter cannot be cut into column parts";
                     return false;

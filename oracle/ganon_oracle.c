@@ -615,6 +615,20 @@ uint64_t gno_baseline_classify(const gno_filter* flt, const uint8_t* bases, cons
                 if (n <= 65535)
                 {
                     const uint64_t thr = gno_threshold_cutoff(n, flt->rel_cutoff);
+                    /* software prefetch of every row the read will touch (h rows per minimiser, random over the whole
+                     * filter): without it a thread waits out one DRAM/TLB miss after the other.  Same rows, same
+                     * counting as gno_ibf_bulk_count below -- only the order in which the cache lines are requested. */
+                    {
+                        const gno_ibf* f   = flt->ibf;
+                        const size_t   rb  = (size_t)f->bin_words * 8;
+                        for (size_t q = 0; q < n; ++q)
+                            for (uint32_t i = 0; i < f->hash_funs; ++i)
+                            {
+                                const char* row = (const char*)(f->data + gno_ibf_row(f, hashes[q], i) * f->bin_words);
+                                for (size_t o = 0; o < rb; o += 64)
+                                    __builtin_prefetch(row + o, 0, 0);
+                            }
+                    }
                     gno_ibf_bulk_count(flt->ibf, hashes, n, counts);
                     for (uint32_t t = 0; t < flt->n_targets; ++t)
                     {
