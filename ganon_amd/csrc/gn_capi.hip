@@ -1009,6 +1009,7 @@ static int gn_run_minimisers_range(gn_stream* s, uint32_t lo, uint32_t hi, hipSt
         // short reads: lane-per-read kernel; longer ones are deferred to the wave-per-read kernel below
         GN_HIP(hipMemsetAsync(s->d_ctr + 5, 0, sizeof(unsigned long long), st));
         mp.lpr_max_len = 640;
+        mp.force_lds   = getenv("GANON_HIP_MINIMISER_LDS") ? 1u : 0u; // A/B: the LDS-window variant for every width
         mp.defer_list  = s->d_mdeferred;
         mp.defer_count = s->d_ctr + 5;
         GN_HIP(gn_launch_minimiser_lpr(mp, st));

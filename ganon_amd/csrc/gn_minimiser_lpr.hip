@@ -235,11 +235,238 @@ __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams 
         atomicAdd(p.total_hashes + (blockIdx.x & 63u), mine_total);
 }
 
+// ================================================================================================
+// Register-resident variant for compile-time window widths (KW = w-k+1 k-mers, 1..16) and k <= 24.
+// ================================================================================================
+// Same lane-per-read organisation and the same block decomposition, but
+//   * a k-mer travels as ONE 64-bit key (value << 16 | 0xFFFF - position): the smaller key is the smaller value and, among
+//     equal values, the one further right -- so "rightmost minimum" is a plain unsigned minimum, its position comes out of
+//     the key, and no separate argmin is carried around (2k + 16 <= 64);
+//   * the block of KW keys being collected and the suffix minima of the previous block live in REGISTERS: the block loop
+//     is unrolled by KW, every index is a compile-time constant, the once-per-block backward scan is KW-1 register minima
+//     -- the sliding window needs no LDS at all;
+//   * bases are fetched one block ahead as aligned dwords and cut out with byte-align instructions;
+//   * emitted minimisers are staged in LDS ([slot][lane], padded) and written out per read in one coalesced burst per
+//     mate, instead of one scattered 8-byte store per emission (the scattered stores cost 3.6 x the written bytes in HBM
+//     traffic, r01 WRITE_SIZE).
+#define GN_LPRK_STAGE 24u // staged emissions per mate and lane; further ones of a mate go straight to memory
+
+template <int KW>
+__global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams p)
+{
+    __shared__ uint64_t stage[GN_LPRK_STAGE * (GN_WAVE + 1)];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k    = p.k;
+    const uint64_t seed = 0x8F3F73B5CF1C9ADEULL >> (64u - 2u * k);    // adjust_seed.hpp:33-37
+    const uint64_t mask = (1ULL << (2 * k)) - 1ULL;                   // k <= 24
+    const uint32_t w    = k + KW - 1;
+
+    const uint32_t r   = p.read_begin + blockIdx.x * GN_WAVE + lane;
+    const bool     inr = r < p.n_reads;
+    uint64_t       b1 = 0, len1 = 0, b2 = 0, len2 = 0;
+    if (inr)
+    {
+        b1   = p.off1[r];
+        len1 = p.off1[r + 1] - b1;
+        if (p.off2)
+        {
+            b2   = p.off2[r];
+            len2 = p.off2[r + 1] - b2;
+        }
+    }
+    const bool too_long = len1 > p.lpr_max_len || len2 > p.lpr_max_len;
+    const bool mine     = inr && !too_long;
+    if (inr && too_long)
+        p.defer_list[atomicAdd(p.defer_count, 1ULL)] = r;
+
+    uint8_t  st = GN_READ_OK;
+    uint32_t n  = 0;
+    if (mine && len1 < w) // GanonClassify.cpp:690,743-747
+        st = GN_READ_SMALL;
+    const uint64_t out_base = mine ? p.slot_off[r] : 0;
+
+    for (uint32_t seg = 0; seg < 2; ++seg)
+    {
+        const uint64_t L64  = seg ? len2 : len1;
+        const bool     act  = mine && st == GN_READ_OK && L64 >= w; // :690 / :695
+        const uint32_t Leff = act ? (uint32_t)L64 : 0u;
+        const uint32_t Lmax = gn_lpr_wave_max(Leff);
+        if (Lmax == 0)
+            continue;
+        const uint32_t n_seg0 = n; // emissions of this mate are staged from here
+        const uintptr_t sa  = reinterpret_cast<uintptr_t>(p.bases + (seg ? b2 : b1));
+        const uint32_t  o   = (uint32_t)(sa & 3u);
+        const uint32_t* dws = reinterpret_cast<const uint32_t*>(sa & ~(uintptr_t)3);
+        const uint32_t  ndw = Leff ? (o + Leff + 3) / 4 : 0; // dwords this lane may touch
+        auto dword_at = [&](uint32_t q) -> uint32_t { // clamped: bytes past the lane's range are never looked at
+            const uint32_t qc = q < ndw ? q : (ndw ? ndw - 1 : 0u);
+            return dws[qc];
+        };
+
+        uint64_t f = 0, rc = 0;
+        auto roll = [&](uint32_t c) -> uint64_t { // append base c, return the canonical value of the k-mer ending here
+            // A C G T U (either case): rank = ((c>>1) ^ (c>>2)) & 3 without touching memory; anything else (IUPAC codes)
+            // takes the table -- a rare, wave-level branch
+            uint64_t   b      = ((c >> 1) ^ (c >> 2)) & 3u;
+            const bool simple = ((0x0030008Au >> (c & 31u)) & 1u) && (c & 0xC0u) == 0x40u; // letters 1,3,7,20,21
+            if (!simple)
+                b = GN_LPR_RANK_LUT.t[c];
+            f                = ((f << 2) | b) & mask;
+            rc               = (rc >> 2) | ((3ULL - b) << (2 * (k - 1)));
+            const uint64_t x = f ^ seed, y = rc ^ seed;
+            return x < y ? x : y;
+        };
+        // warm-up: the first k-1 bases complete no k-mer
+        for (uint32_t i = 0; i + 1 < k; ++i)
+        {
+            const uint32_t by = o + i;
+            const uint32_t c  = (dword_at(by >> 2) >> (8u * (by & 3u))) & 0xFFu;
+            if (i < Leff)
+                (void)roll(c);
+        }
+
+        uint64_t V[KW], S[KW];
+#pragma unroll
+        for (int t = 0; t < KW; ++t)
+            V[t] = S[t] = ~0ULL;
+        uint64_t pre = ~0ULL, Wprev = 0;
+        uint32_t expiry = 0xFFFFFFFFu;
+        const uint32_t M = Lmax - k + 1; // k-mers of the longest read of the wave
+
+        // bytes [o + k-1 + blk*KW, +KW) of the dword stream = 5 aligned dwords (KW <= 16), fetched one block ahead
+        constexpr int NDW = (KW + 3) / 4 + 1;
+        uint32_t      cur[NDW], nxt[NDW];
+        auto fetch = [&](uint32_t blk, uint32_t* dst) {
+            const uint32_t q = (o + k - 1 + blk * KW) >> 2;
+#pragma unroll
+            for (int d = 0; d < NDW; ++d)
+                dst[d] = dword_at(q + d);
+        };
+        fetch(0, cur);
+        for (uint32_t blk = 0; blk * KW < M; ++blk)
+        {
+            fetch(blk + 1, nxt);
+            const uint32_t sh = (o + k - 1 + blk * KW) & 3u; // byte offset inside cur[0]
+            uint32_t       by[NDW - 1];
+#pragma unroll
+            for (int d = 0; d + 1 < NDW; ++d)
+                by[d] = __builtin_amdgcn_alignbyte(cur[d + 1], cur[d], sh);
+#pragma unroll
+            for (int pin = 0; pin < KW; ++pin)
+            {
+                const uint32_t pk = blk * KW + pin;     // k-mer position (wave-uniform)
+                const uint32_t i  = pk + k - 1;         // base index
+                const bool     on = i < Leff;           // (past the longest read of the wave nothing is on: the tail of the
+                                                        //  last block runs empty instead of leaving the unrolled loop)
+                const uint32_t c  = (by[pin >> 2] >> (8 * (pin & 3))) & 0xFFu;
+                uint64_t       key = ~0ULL;
+                if (on)
+                    key = (roll(c) << 16) | (uint64_t)(0xFFFFu - pk);
+                V[pin] = key;
+                pre    = pin == 0 ? key : (key < pre ? key : pre);
+                if (pk + 1 >= KW)
+                {
+                    const uint32_t j = pk + 1 - KW; // window index (uniform); valid for this lane iff `on`
+                    uint64_t       W = pre;
+                    if (pin != KW - 1)              // window starts inside the previous block: its suffix from slot pin+1
+                        W = S[(pin + 1) % KW] < pre ? S[(pin + 1) % KW] : pre;
+                    if (on)
+                    {
+                        // first window / the remembered minimiser leaves / a strictly smaller VALUE enters
+                        const bool emit = j == 0 || j == expiry || (key | 0xFFFFull) < (Wprev & ~0xFFFFull);
+                        if (emit)
+                        {
+                            const uint32_t e = n - n_seg0;
+                            if (e < GN_LPRK_STAGE)
+                                stage[e * (GN_WAVE + 1) + lane] = W >> 16;
+                            else
+                                p.hashes[out_base + n] = W >> 16;
+                            ++n;
+                            expiry = (0xFFFFu - (uint32_t)(W & 0xFFFFu)) + 1u;
+                        }
+                        Wprev = W;
+                    }
+                }
+            }
+            // block complete: its keys become suffix minima (register to register)
+            S[KW - 1] = V[KW - 1];
+#pragma unroll
+            for (int t = KW - 2; t >= 0; --t)
+                S[t] = V[t] < S[t + 1] ? V[t] : S[t + 1];
+#pragma unroll
+            for (int d = 0; d < NDW; ++d)
+                cur[d] = nxt[d];
+        }
+        // flush this mate's staged emissions: read after read, one coalesced store of up to GN_LPRK_STAGE hashes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t cnt_mine = act ? (n - n_seg0 < GN_LPRK_STAGE ? n - n_seg0 : GN_LPRK_STAGE) : 0u;
+        uint64_t       todo     = __ballot(cnt_mine != 0);
+        while (todo)
+        {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt_mine, l);
+            const uint64_t dst0 = out_base + n_seg0;
+            const uint64_t dst  = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(dst0 >> 32), l) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)dst0, l);
+            if (lane < cnt)
+                p.hashes[dst + lane] = stage[lane * (GN_WAVE + 1) + (uint32_t)l];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    unsigned long long mine_total = 0;
+    if (mine)
+    {
+        if (n > 65535u) // :674,706
+            st = GN_READ_BIG;
+        else if (st == GN_READ_OK)
+            mine_total = n;
+        p.n_hashes[r] = n;
+        p.status[r]   = st;
+    }
+    mine_total = gn_lpr_wave_sum(mine_total);
+    if (lane == 0 && mine_total)
+        atomicAdd(p.total_hashes + (blockIdx.x & 63u), mine_total);
+}
+
+template <int KW>
+static void gn_launch_lprk(const GnMinimiserParams& p, hipStream_t st)
+{
+    hipLaunchKernelGGL((gn_minimiser_lprk_kernel<KW>), dim3((p.n_reads - p.read_begin + GN_WAVE - 1) / GN_WAVE), dim3(GN_WAVE), 0, st, p);
+}
+
 hipError_t gn_launch_minimiser_lpr(const GnMinimiserParams& p, hipStream_t st)
 {
     if (p.n_reads <= p.read_begin)
         return hipSuccess;
     const uint32_t K   = p.w - p.k + 1;
+    if (K <= 16 && p.k <= 24 && !p.force_lds)
+    {
+        switch (K)
+        {
+            case 1: gn_launch_lprk<1>(p, st); break;
+            case 2: gn_launch_lprk<2>(p, st); break;
+            case 3: gn_launch_lprk<3>(p, st); break;
+            case 4: gn_launch_lprk<4>(p, st); break;
+            case 5: gn_launch_lprk<5>(p, st); break;
+            case 6: gn_launch_lprk<6>(p, st); break;
+            case 7: gn_launch_lprk<7>(p, st); break;
+            case 8: gn_launch_lprk<8>(p, st); break;
+            case 9: gn_launch_lprk<9>(p, st); break;
+            case 10: gn_launch_lprk<10>(p, st); break;
+            case 11: gn_launch_lprk<11>(p, st); break;
+            case 12: gn_launch_lprk<12>(p, st); break;
+            case 13: gn_launch_lprk<13>(p, st); break;
+            case 14: gn_launch_lprk<14>(p, st); break;
+            case 15: gn_launch_lprk<15>(p, st); break;
+            default: gn_launch_lprk<16>(p, st); break;
+        }
+        return hipGetLastError();
+    }
     const size_t   lds = (size_t)2 * K * GN_WAVE * 9;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_minimiser_lpr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
