@@ -48,6 +48,8 @@ WORKLOADS = {
     "flat1g": dict(kind="flat", bins=4096, rows=1 << 21, h=4, reads=2_000_000, paired=False, config=None),
     "tiny": dict(kind="flat", bins=4096, rows=1 << 14, h=4, reads=100_000, paired=False, config=None),
     "flat32k": dict(kind="flat", bins=32768, rows=1 << 21, h=4, reads=2_000_000, paired=False, config=None),
+    # split-bin map (what ganon-build makes of targets larger than max_hashes_bin): two technical bins per target
+    "split32k": dict(kind="flat", bins=32768, rows=1 << 21, h=4, reads=2_000_000, paired=False, config=None, bins_per_target=2),
     "hibf64k": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, h=3, reads=10_000_000, paired=False, config=2),
     "hibf_tiny": dict(kind="hibf", user_bins=4096, tmax=64, rows=1 << 12, h=3, reads=100_000, paired=False, config=None),
     "flat128g": dict(kind="flat", bins=32768, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=3),
@@ -129,7 +131,7 @@ def main() -> int:
         desc = (f"2-level HIBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU: top IBF {spec['tmax']} merged bins -> "
                 f"{spec['tmax']} child IBFs x {spec['user_bins'] // spec['tmax']} user bins = {spec['user_bins']} user bins, "
                 f"S={rows} rows each, h={spec['h']}")
-        kernel_name = "gn_hibf_level_kernel"
+        kernel_name = "gn_hibf_pack_kernel"
         row_bytes = ((spec["tmax"] + 63) >> 6) * 8
     else:
         slices = spec.get("slices", 1)
@@ -138,7 +140,12 @@ def main() -> int:
         wl = bw.make_device_flat_workload(args.workload, spec["bins"], rows, spec["h"], n_reads, paired, rel_cutoff=args.rel_cutoff,
                                           seed=42, shard=0 if kind == "slice" else rank, word_lo=sl_idx * W_local,
                                           row_words_total=W_local * slices)
-        flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index)
+        bpt = spec.get("bins_per_target", 1)
+        if bpt > 1:
+            flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index, (np.arange(spec["bins"], dtype=np.uint32) // bpt).astype(np.uint32),
+                                              spec["bins"] // bpt)
+        else:
+            flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index)
         off2 = wl.off2
         row_bytes = W_local * 8
         if kind == "slice":
@@ -151,8 +158,8 @@ def main() -> int:
                     f"read's owner with one all-to-all over RCCL")
         else:
             desc = (f"flat IBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {wl.bins} technical bins (W={W_local}, "
-                    f"{row_bytes} B rows), S={rows} rows, h={spec['h']}")
-        kernel_name = "gn_ibf_count_fast_kernel"
+                    f"{row_bytes} B rows), S={rows} rows, h={spec['h']}" + (f", {bpt} bins per target" if bpt > 1 else ""))
+        kernel_name = "gn_ibf_count_split_kernel" if bpt > 1 else "gn_ibf_count_fast_kernel"
     unit_name = "pairs (2x150 bp)" if paired else "reads (150 bp)"
     log(f"[rank {rank}] workload {args.workload}: filter {wl.filter_bytes / 2**30:.2f} GiB filled on the device, {n_reads} "
         f"{unit_name}, set up in {time.time() - t0:.1f}s")
@@ -277,7 +284,7 @@ def main() -> int:
             log("bench.py: could not read", pmc_path, repr(e))
 
     # the same resident batch under the two conditions the headline does not show (not part of `value`)
-    if not args.no_variants and part is None and kind == "flat":
+    if not args.no_variants and part is None and kind == "flat" and spec.get("bins_per_target", 1) == 1:
         variants = {}
         os.environ["GANON_HIP_NO_EARLY_EXIT"] = "1"   # read by the library at every launch
         _, cms, _, tms, tmv = timed(args.rel_cutoff, 3, 1)
@@ -297,12 +304,13 @@ def main() -> int:
                 ok, detail = bench_cpu.spot_check_hibf(wl, flt, nh, status, mo, matches, min(args.check, 600))
             else:
                 ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check,
-                                                  target_offset=(sl_idx * spec["bins"] if kind == "slice" else 0))
+                                                  target_offset=(sl_idx * spec["bins"] if kind == "slice" else 0),
+                                                  bins_per_target=spec.get("bins_per_target", 1))
             result["config"]["oracle_spot_check"] = detail
             if not ok:
                 log("bench.py: ORACLE SPOT CHECK FAILED:", detail)
                 result["value"] = None
-        if not args.no_cpu_baseline and world == 1 and kind == "flat" and wl.filter_bytes <= (16 << 30):
+        if not args.no_cpu_baseline and world == 1 and kind == "flat" and wl.filter_bytes <= (16 << 30) and spec.get("bins_per_target", 1) == 1:
             try:  # the CPU baseline is an N=1 measurement on a filter the host can hold
                 result["cpu_baseline"] = bench_cpu.cpu_baseline(wl, flt, args.cpu_sample)
             except Exception as e:  # noqa: BLE001 -- a reported extra; never lose the GPU line over it

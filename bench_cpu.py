@@ -37,7 +37,7 @@ def _oracle_native():
     return "portable"
 
 
-def spot_check(wl, flt, nh, status, mo, matches, n_sample: int, target_offset: int = 0):
+def spot_check(wl, flt, nh, status, mo, matches, n_sample: int, target_offset: int = 0, bins_per_target: int = 1):
     """GPU (read, target, count) lists of a random read sample == oracle select_matches on the device's bits.  Only
     the rows the sample touches are fetched from the device (gn_filter_download_row_list), so this also works on the
     128 GiB filters; `target_offset` = first global target of a column slice."""
@@ -50,7 +50,7 @@ def spot_check(wl, flt, nh, status, mo, matches, n_sample: int, target_offset: i
     bad = 0
     checked_matches = 0
     for r in idx.tolist():
-        n_h, exp = bw.oracle_read_matches(ibf, wl, r)
+        n_h, exp = bw.oracle_read_matches(ibf, wl, r, bins_per_target)
         exp = [(t + target_offset, c) for t, c in exp]
         got = [(int(x["target"]), int(x["count"])) for x in matches[int(mo[r]):int(mo[r + 1])]]
         if nh[r] != n_h or status[r] != 0 or got != exp:

@@ -251,8 +251,9 @@ def sampled_oracle_ibf(flt, wl):
     return oracle.SampledIbf(wl.bins, wl.rows, wl.hash_funs, lambda idx: flt.download_row_list(idx, wl.bin_words))
 
 
-def oracle_read_matches(ibf, wl, r: int):
-    """(n_hashes, [(bin, count)]) of read / pair r per GanonClassify.cpp:690-735 on an identity bin->target map"""
+def oracle_read_matches(ibf, wl, r: int, bins_per_target: int = 1):
+    """(n_hashes, [(target, count)]) of read / pair r per GanonClassify.cpp:690-735; target t owns bins
+    [t*bins_per_target, (t+1)*bins_per_target) (1 = identity map)"""
     import oracle
     s1 = wl.bases[int(wl.off[r]):int(wl.off[r + 1])]
     hh = oracle.minimiser_hash(oracle.to_ranks(s1), wl.k, wl.w)
@@ -260,7 +261,10 @@ def oracle_read_matches(ibf, wl, r: int):
         s2 = wl.bases[int(wl.off2[r]):int(wl.off2[r + 1])]
         if len(s2) >= wl.w:
             hh = np.concatenate([hh, oracle.minimiser_hash(oracle.to_ranks(s2), wl.k, wl.w)])
-    counts = np.minimum(ibf.bulk_count(hh).astype(np.int64), len(hh))
+    counts = ibf.bulk_count(hh).astype(np.int64)
+    if bins_per_target > 1:
+        counts = counts.reshape(-1, bins_per_target).sum(axis=1)  # :516-523
+    counts = np.minimum(counts, len(hh))                           # :525-526
     thr = oracle.threshold_cutoff(len(hh), wl.rel_cutoff)
     return len(hh), [(int(t), int(counts[t])) for t in np.nonzero(counts >= thr)[0]]
 

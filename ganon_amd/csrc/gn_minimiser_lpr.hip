@@ -305,24 +305,29 @@ __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams
 
         uint64_t f = 0, rc = 0;
         auto roll = [&](uint32_t c) -> uint64_t { // append base c, return the canonical value of the k-mer ending here
-            // A C G T U (either case): rank = ((c>>1) ^ (c>>2)) & 3 without touching memory; anything else (IUPAC codes)
-            // takes the table -- a rare, wave-level branch
-            uint64_t   b      = ((c >> 1) ^ (c >> 2)) & 3u;
-            const bool simple = ((0x0030008Au >> (c & 31u)) & 1u) && (c & 0xC0u) == 0x40u; // letters 1,3,7,20,21
-            if (!simple)
-                b = GN_LPR_RANK_LUT.t[c];
+            // dna4 rank of any byte without a table and without a branch: letters (either case) index two 32-bit masks
+            // with c & 31 -- low rank bit set for C Y S B T U, high rank bit for G K T U; every other byte is rank 0
+            // (seqan3::dna4 char_to_rank; the same values as GN_LPR_RANK_LUT)
+            const uint32_t idx    = c & 31u;
+            uint32_t       b32    = ((0x0238000Cu >> idx) & 1u) | (((0x00300880u >> idx) & 1u) << 1);
+            b32                   = (c & 0xC0u) == 0x40u ? b32 : 0u;
+            const uint64_t b      = b32;
             f                = ((f << 2) | b) & mask;
             rc               = (rc >> 2) | ((3ULL - b) << (2 * (k - 1)));
             const uint64_t x = f ^ seed, y = rc ^ seed;
             return x < y ? x : y;
         };
-        // warm-up: the first k-1 bases complete no k-mer
-        for (uint32_t i = 0; i + 1 < k; ++i)
+        // warm-up: the first k-1 bases complete no k-mer (one aligned dword per four bases)
+        for (uint32_t q = 0; q * 4 < o + k - 1; ++q)
         {
-            const uint32_t by = o + i;
-            const uint32_t c  = (dword_at(by >> 2) >> (8u * (by & 3u))) & 0xFFu;
-            if (i < Leff)
-                (void)roll(c);
+            const uint32_t dw = dword_at(q);
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t)
+            {
+                const uint32_t by = q * 4 + t;
+                if (by >= o && by - o + 1 < k)  // (lane-dependent start offset o; lanes past their read: harmless)
+                    (void)roll((dw >> (8u * t)) & 0xFFu);
+            }
         }
 
         uint64_t V[KW], S[KW];
@@ -359,9 +364,9 @@ __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams
                 const bool     on = i < Leff;           // (past the longest read of the wave nothing is on: the tail of the
                                                         //  last block runs empty instead of leaving the unrolled loop)
                 const uint32_t c  = (by[pin >> 2] >> (8 * (pin & 3))) & 0xFFu;
-                uint64_t       key = ~0ULL;
-                if (on)
-                    key = (roll(c) << 16) | (uint64_t)(0xFFFFu - pk);
+                // (rolled by every lane: lanes past their read only waste the arithmetic, their key is discarded)
+                const uint64_t kv  = (roll(c) << 16) | (uint64_t)(0xFFFFu - pk);
+                const uint64_t key = on ? kv : ~0ULL;
                 V[pin] = key;
                 pre    = pin == 0 ? key : (key < pre ? key : pre);
                 if (pk + 1 >= KW)

@@ -1,19 +1,25 @@
-"""Copies the rocprofv3 summaries of one profiling round (scripts/profile_round.sh) from gpurun_out/ into profiles/
-and derives the per-launch HBM traffic that bench.py attaches to its `roofline.traffic`.
+"""Copies the rocprofv3 summaries of one profiling round (scripts/profile_round.sh <tag> <workload>) from gpurun_out/ into
+profiles/ and derives the per-step HBM traffic that bench.py attaches to its `roofline.traffic`.
 
 FETCH_SIZE is in KiB.  The guide (MI355X_MICROARCH.md, HBM section) says gfx950 tallies 128-byte requests of wide
-coalesced reads at 64 bytes (-> x2) and that other access widths must be calibrated on a known byte count.  The
-kernel's row loads are 8 B/lane (512 contiguous bytes per wave instruction), so the x2 is checked on the same bench
-with the early exit disabled, where the dominant kernel requests exactly the algorithmic n*h*W*8 row bytes (plus
-< 0.5 % hashes/metadata): FETCH_SIZE * 1024 * 2 / algorithmic is reported as `calibration_check` (1.0 = exact).
+coalesced reads at 64 bytes (-> x2) and that other access widths must be calibrated on a known byte count.  The flat
+kernels' row loads are 8 or 16 B/lane over rows of 512 B .. 4 KiB, so the x2 is checked on the same bench with the early
+exit disabled, where the dominant kernel requests exactly the algorithmic n*h*W*8 row bytes (plus < 0.5 % hashes /
+metadata): FETCH_SIZE * 1024 * 2 / algorithmic is reported as `calibration_check` (1.0 = exact).  The HIBF kernels fetch
+32-byte rows (8 B/lane, four lanes per row): no run with a known byte count exists for that pattern, so both readings are
+given -- x1 (64-byte requests counted in full) and x2 -- next to the algorithmic bytes and the one-128-byte-line-per-row
+transaction count.
 """
 import csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+wl = sys.argv[2] if len(sys.argv) > 2 else "flat8g"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
 dst = os.path.join(ROOT, "profiles")
-KERNEL = "gn_ibf_count_fast_kernel"
+# kernels whose launches make up one "count/select" step of the workload
+KERNELS = {"hibf64k": ["gn_hibf_pack_kernel", "gn_hibf_reg_kernel", "gn_hibf_level_kernel"], "split32k": ["gn_ibf_count_split_kernel"]}.get(
+    wl, ["gn_ibf_count_fast_kernel"])
 
 
 def find(sub, suffix):
@@ -22,16 +28,16 @@ def find(sub, suffix):
     return max(hits, key=os.path.getmtime) if hits else None
 
 
-def counter_avg(path, counter):
-    path = path if os.path.exists(path) else path
-    vals = {}
+def counter_per_step(path, counter, steps):
+    """sum of `counter` over every launch of the workload's count kernels, divided by the steps of the run"""
+    tot, n, names = 0.0, 0, set()
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
-            if KERNEL in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                vals.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
-    name = max(vals, key=lambda k: len(vals[k]))
-    v = vals[name]
-    return name, sum(v) / len(v), len(v)
+            if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in KERNELS):
+                tot += float(row["Counter_Value"])
+                n += 1
+                names.add(row["Kernel_Name"].split("(")[0])
+    return tot / steps, n, sorted(names)
 
 
 def copy(sub, suffix, name, only_ours=False):
@@ -54,8 +60,8 @@ def copy(sub, suffix, name, only_ours=False):
     return p
 
 
-bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-wl = bench["config"]["workload"].split(":")[0]
+line = [ln for ln in open(os.path.join(src, "bench.json")).read().splitlines() if ln.startswith('{"metric"')][-1]
+bench = json.loads(line)
 with open(os.path.join(dst, f"{tag}_bench_{wl}.json"), "w") as f:
     json.dump(bench, f, indent=1)
 copy("trace", "kernel_stats.csv", f"{tag}_{wl}_kernel_stats.csv")
@@ -66,31 +72,44 @@ p_n = copy("pmc_fetch_noee", "counter_collection.csv", f"{tag}_{wl}_pmc_FETCH_SI
 p_w = copy("pmc_write", "counter_collection.csv", f"{tag}_{wl}_pmc_WRITE_SIZE.csv", only_ours=True)
 copy("pmc_sq", "counter_collection.csv", f"{tag}_{wl}_pmc_SQ.csv", only_ours=True)
 
+STEPS = 6  # the counter passes run `bench.py --steps 5 --warmup 1`
 rf = bench["roofline"]
-algo = rf["algo_bytes_per_launch"]
-fetched = rf.get("fetched_bytes_per_launch", algo)
-out = {"workload": wl, "tag": tag, "algo_bytes_per_launch": algo, "kernel_fetched_bytes_per_launch": fetched}
-if p_f and p_n:
-    name, raw, n = counter_avg(p_f, "FETCH_SIZE")
-    _, raw_cal, n_cal = counter_avg(p_n, "FETCH_SIZE")
-    factor = 2.0
-    out.update({
-        "kernel": name,
-        "FETCH_SIZE_KB_raw": raw, "launches_averaged": n,
-        "FETCH_SIZE_KB_raw_no_early_exit": raw_cal,
-        "calibration_check": round(raw_cal * 1024.0 * factor / algo, 4),
-        "hbm_bytes_per_launch": int(raw * 1024.0 * factor),
-        "hbm_over_kernel_fetched": round(raw * 1024.0 * factor / fetched, 4),
-        "hbm_over_algorithmic": round(raw * 1024.0 * factor / algo, 4),
-        "source": f"profiles/{tag}_{wl}_pmc_FETCH_SIZE.csv (normal run) calibrated with "
-                  f"profiles/{tag}_{wl}_pmc_FETCH_SIZE_no_early_exit.csv: separate `rocprofv3 --pmc FETCH_SIZE` passes over "
-                  "bench.py; FETCH_SIZE is in KiB and, on gfx950, tallies the 128-byte requests of coalesced reads at 64 bytes "
-                  "(MI355X_MICROARCH.md HBM section) -> bytes = value * 1024 * 2; the x2 is checked on the run whose kernel "
-                  "requests exactly the algorithmic rows (calibration_check)",
-    })
+algo = rf["algo_bytes_per_launch"] * rf.get("launches_per_step", 1)
+fetched = rf.get("fetched_bytes_per_launch", rf["algo_bytes_per_launch"]) * rf.get("launches_per_step", 1)
+out = {"workload": wl, "tag": tag, "algo_bytes_per_step": algo, "kernel_fetched_bytes_per_step": fetched,
+       "count_ms_bench": bench["config"]["kernel_ms"]["count_select"]}
+if p_f:
+    raw, n, names = counter_per_step(p_f, "FETCH_SIZE", STEPS)
+    out.update({"kernels": names, "launches_seen": n, "FETCH_SIZE_KB_per_step": raw})
+    if p_n:
+        raw_cal, _, _ = counter_per_step(p_n, "FETCH_SIZE", STEPS)
+        out.update({
+            "FETCH_SIZE_KB_per_step_no_early_exit": raw_cal,
+            "calibration_check": round(raw_cal * 1024.0 * 2.0 / algo, 4),
+            "hbm_bytes_per_launch": int(raw * 1024.0 * 2.0),
+            "hbm_over_kernel_fetched": round(raw * 1024.0 * 2.0 / fetched, 4),
+            "hbm_over_algorithmic": round(raw * 1024.0 * 2.0 / algo, 4),
+            "source": f"profiles/{tag}_{wl}_pmc_FETCH_SIZE.csv (normal run) calibrated with "
+                      f"profiles/{tag}_{wl}_pmc_FETCH_SIZE_no_early_exit.csv: separate `rocprofv3 --pmc FETCH_SIZE` passes over "
+                      "bench.py; FETCH_SIZE is in KiB and, on gfx950, tallies the 128-byte requests of coalesced reads at 64 bytes "
+                      "(MI355X_MICROARCH.md HBM section) -> bytes = value * 1024 * 2; the x2 is checked on the run whose kernel "
+                      "requests exactly the algorithmic rows (calibration_check)",
+        })
+    else:
+        x1 = raw * 1024.0
+        out.update({
+            "hbm_bytes_per_launch": int(x1 * 2.0) if wl == "split32k" else int(x1),
+            "hbm_bytes_if_x1": int(x1), "hbm_bytes_if_x2": int(x1 * 2.0),
+            "transaction_bytes_per_step": rf.get("transaction_bytes_per_launch"),
+            "source": f"profiles/{tag}_{wl}_pmc_FETCH_SIZE.csv: separate `rocprofv3 --pmc FETCH_SIZE` pass over bench.py, KiB summed over "
+                      f"the launches of {names} per step; " + (
+                          "512 B .. 4 KiB coalesced rows like the fast kernel's: x2 (calibrated on flat8g in the same round)"
+                          if wl == "split32k" else
+                          "32-byte rows, 8 B per lane: counter uncalibrated for this pattern, x1 reading reported as traffic, x2 beside it"),
+        })
 if p_w:
-    _, w_raw, _ = counter_avg(p_w, "WRITE_SIZE")
-    out["WRITE_SIZE_KB_raw"] = w_raw
+    w_raw, _, _ = counter_per_step(p_w, "WRITE_SIZE", STEPS)
+    out["WRITE_SIZE_KB_per_step"] = w_raw
 with open(os.path.join(dst, f"pmc_fetch_{wl}.json"), "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))

@@ -82,7 +82,7 @@ def test_device_build_save_and_classify_with_the_binary(tmp_path):
     from ganon_amd import ibf_file
     rng = np.random.default_rng(8)
     genomes = {f"G{i}": [gu.random_seq(rng, 2500), gu.random_seq(rng, 800)] for i in range(12)}
-    flt, kw = ibf_file.build_ibf(genomes, 19, 31, max_fp=0.01, hash_funs=3, max_hashes_bin=700)  # forces split bins
+    flt, kw = ibf_file.build_ibf(genomes, 19, 31, max_fp=0.01, hash_funs=3, max_hashes_bin=150)  # forces split bins
     path = str(tmp_path / "dev.ibf")
     ibf_file.save_ibf(path, flt, **kw)
     m = ibf_file.read_ibf_meta(path)
