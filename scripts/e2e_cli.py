@@ -1,89 +1,81 @@
-"""End-to-end timing of the ganon-classify binary (FASTQ parse -> GPU -> .all/.rep written) on a synthetic 1 GiB filter,
-and device-only timing of paired reads on the same filter.  Exploration script (numbers quoted in DESIGN.md)."""
-import os, struct, subprocess, sys, time
+"""End-to-end timing of the product binary on self-hosted files: a device-generated filter is saved as a ganon-build .ibf
+(ganon_amd.ibf_file), synthetic reads are written as FASTQ, then `ganon-classify` runs start to finish (streaming filter
+load -> FASTQ parse -> GPU -> .all/.rep written) on one device and with two workers (`--device 0,0`; on a multi-GPU node
+use `--device all`).  Prints one JSON object.   usage: e2e_cli.py [n_reads=16000000] [rows_log2=21] [dir=/dev/shm]"""
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
-import numpy as np
-import ganon_amd, bench_workload as bw
+import numpy as np  # noqa: E402
 
-n = int(os.environ.get("N_READS", 2_000_000))
-wl = bw.make_flat_workload("e2e", 4096, 1 << 21, 4, n, seed=42)
-flt = ganon_amd.HipFilter.ibf(wl.filter_rows.reshape(-1), wl.bins, wl.rows, wl.hash_funs)
-bw.plant_genomes(flt, wl)
-bw.download_filter(flt, wl)
+import bench_workload as bw  # noqa: E402
+import ganon_amd  # noqa: E402
+from ganon_amd import ibf_file  # noqa: E402
 
-# ---- paired reads, device only
-half = n // 2
-off1 = wl.off[: half + 1]
-off2 = wl.off[half: 2 * half + 1]
-st = ganon_amd.HipStream(flt, half, wl.bases.size, half * 2)
-st.upload(wl.bases, off1, off2)
-for i in range(3):
-    st.classify(wl.k, wl.w, wl.rel_cutoff); st.sync(); t = st.timings()
-print(f"paired 2x150 ({half} pairs): count {t['ms_count']:.2f} ms, minimiser {t['ms_minimiser']:.2f} ms, "
-      f"{t['algo_bytes']/t['ms_count']/1e6:.0f} GB/s algorithmic, {half/t['ms_total']/1e3:.1f} Mpairs/s, "
-      f"{t['n_hashes']/half:.1f} minimisers/pair", flush=True)
-st.destroy(); flt.free()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
+rows = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 21)
+d = sys.argv[3] if len(sys.argv) > 3 else "/dev/shm"
+bins = 4096
+out = {"reads": n, "filter_gib": rows * 512 / 2**30}
 
-# ---- files
-d = "/tmp/e2e"; os.makedirs(d, exist_ok=True)
-def wstr(s):
-    b = s.encode(); return struct.pack("<Q", len(b)) + b
-t0 = time.time()
-with open(f"{d}/db.ibf", "wb") as f:
-    f.write(struct.pack("<3i", 2, 1, 1))
-    f.write(struct.pack("<QQBBHQddd", wl.bins, 500, wl.hash_funs, wl.k, wl.w, wl.rows, 0.05, 0.05, 0.05))
-    f.write(struct.pack("<Q", wl.bins))
-    for i in range(wl.bins):
-        f.write(wstr(f"T{i}") + struct.pack("<Q", 400))
-    f.write(struct.pack("<Q", wl.bins))
-    for i in range(wl.bins):
-        f.write(struct.pack("<Q", i) + wstr(f"T{i}"))
-    W = wl.bin_words
-    f.write(struct.pack("<6Q", wl.bins, W * 64, wl.rows, 64 - int(wl.rows).bit_length(), W, wl.hash_funs))
-    f.write(struct.pack("<BfQ", 1, 1.5, W * 64 * wl.rows))
-    f.write(wl.filter_rows.tobytes())
-reads = wl.bases.reshape(n, wl.read_len)
-with open(f"{d}/reads.fq", "wb") as f:
-    qual = b"I" * wl.read_len
-    chunk = []
-    for i in range(n):
-        chunk.append(b"@r%d\n%s\n+\n%s\n" % (i, reads[i].tobytes(), qual))
-        if len(chunk) == 100000:
-            f.write(b"".join(chunk)); chunk = []
-    f.write(b"".join(chunk))
-print(f"files written in {time.time()-t0:.1f}s: db.ibf {os.path.getsize(d+'/db.ibf')/2**30:.2f} GiB, reads.fq {os.path.getsize(d+'/reads.fq')/2**20:.0f} MiB", flush=True)
-t0 = time.time()
-p = subprocess.run([os.path.join(ROOT, "ganon_amd/host/ganon-classify"), "--ibf", f"{d}/db.ibf", "--single-reads", f"{d}/reads.fq",
-                    "-o", f"{d}/out", "--output-all", "--rel-cutoff", "0.75", "--verbose"], capture_output=True, text=True,
-                   env=dict(os.environ, GANON_HOST_TIMING="1"))
-dt = time.time() - t0
-print("rc", p.returncode, f"wall {dt:.2f}s")
-print("\n".join(l for l in p.stderr.splitlines() if "elapsed" in l or "host timing" in l or "processed" in l or "classified" in l or "ERROR" in l))
-print("all lines:", sum(1 for _ in open(f"{d}/out.all")), open(f"{d}/out.rep").read().splitlines()[-2:])
+wl = bw.make_device_flat_workload("e2e", bins, rows, 4, n, seed=42)
+flt, _ = bw.device_filter(ganon_amd, wl)
+ibf = os.path.join(d, "ganon_e2e.ibf")
+cfg = dict(n_bins=bins, max_hashes_bin=500, hash_functions=4, kmer_size=wl.k, window_size=wl.w, bin_size_bits=rows, max_fp=0.05,
+           true_max_fp=0.05, true_avg_fp=0.05)
+ibf_file.save_ibf(ibf, flt, cfg, [(f"T{b}", 400) for b in range(bins)], [(b, f"T{b}") for b in range(bins)], bins, rows, 4)
+flt.free()
 
-# ---- gzip input: one file, and the same file as both mates (inflate-bound reader)
-if os.environ.get("E2E_GZ"):
-    subprocess.run(["gzip", "-1", "-k", "-f", f"{d}/reads.fq"], check=True)
-    import zlib
+# FASTQ with fixed-width ids, assembled as one byte matrix
+L = wl.read_len
+rec = np.empty((n, 2 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+rec[:, 0], rec[:, 1] = ord("@"), ord("r")
+idx = np.arange(n, dtype=np.int64)
+for p in range(9):
+    rec[:, 2 + p] = (idx // 10 ** (8 - p)) % 10 + ord("0")
+rec[:, 11] = ord("\n")
+rec[:, 12:12 + L] = wl.bases.reshape(n, L)
+rec[:, 12 + L:15 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+rec[:, 15 + L:15 + 2 * L] = ord("I")
+rec[:, -1] = ord("\n")
+fq = os.path.join(d, "ganon_e2e.fq")
+rec.tofile(fq)
+out["fastq_gib"] = round(os.path.getsize(fq) / 2**30, 2)
+del rec
+
+exe = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
+for label, dev in (("one_worker", "0"), ("two_workers_one_gpu", "0,0")):
+    prefix = os.path.join(d, "ganon_e2e_out_" + label)
     t0 = time.time()
-    with open(f"{d}/reads.fq", "rb") as fi, open(f"{d}/readsb.fq.gz", "wb") as fo:   # blocked gzip (bgzip / Illumina style)
-        while True:
-            chunk = fi.read(65280)
-            co = zlib.compressobj(1, zlib.DEFLATED, -15)
-            comp = co.compress(chunk) + co.flush()
-            fo.write(struct.pack("<4BI2BH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6) + struct.pack("<2BHH", 66, 67, 2, 12 + 6 + len(comp) + 8 - 1))
-            fo.write(comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
-            if not chunk:
-                break
-    print(f"bgzf written in {time.time()-t0:.1f}s")
-    for label, args in (("single gz", ["--single-reads", f"{d}/reads.fq.gz"]),
-                        ("paired gz", ["--paired-reads", f"{d}/reads.fq.gz,{d}/reads.fq.gz"]),
-                        ("single bgzf", ["--single-reads", f"{d}/readsb.fq.gz"]),
-                        ("paired bgzf", ["--paired-reads", f"{d}/readsb.fq.gz,{d}/readsb.fq.gz"])):
-        t0 = time.time()
-        p = subprocess.run([os.path.join(ROOT, "ganon_amd/host/ganon-classify"), "--ibf", f"{d}/db.ibf", *args, "-o", f"{d}/outz",
-                            "--output-all", "--rel-cutoff", "0.75", "--verbose"], capture_output=True, text=True,
-                           env=dict(os.environ, GANON_HOST_TIMING="1"))
-        print(label, "rc", p.returncode, f"wall {time.time()-t0:.2f}s")
-        print("\n".join(l for l in p.stderr.splitlines() if "host timing" in l or "processed" in l or "ERROR" in l))
+    p = subprocess.run([exe, "--ibf", ibf, "--single-reads", fq, "-o", prefix, "--output-all", "--rel-cutoff", "0.75", "--verbose",
+                        "--device", dev], capture_output=True, text=True, env=dict(os.environ, GANON_HOST_TIMING="1"))
+    r = {"rc": p.returncode, "wall_s": round(time.time() - t0, 2)}
+    for key, pat in (("load_s", r"loading filter\(s\)\s+elapsed \(s\): ([0-9.eE+-]+)"),
+                     ("classify_print_s", r"classifying\+printing elapsed \(s\): ([0-9.eE+-]+)"),
+                     ("total_s", r"total\s+elapsed \(s\): ([0-9.eE+-]+)")):
+        m = re.search(pat, p.stderr)
+        if m:
+            r[key] = float(m.group(1))
+    m = re.search(r"\[host timing\] (.*)", p.stderr)
+    if m:
+        r["host_timing"] = m.group(1)
+    if "classify_print_s" in r:
+        r["mreads_per_s_classify_print"] = round(n / r["classify_print_s"] / 1e6, 2)
+    if p.returncode == 0:
+        r["all_lines"] = sum(1 for _ in open(prefix + ".all"))
+        r["rep_tail"] = open(prefix + ".rep").read().splitlines()[-2:]
+    else:
+        r["stderr"] = p.stderr[-400:]
+    out[label] = r
+if out["one_worker"].get("rc") == 0 and out["two_workers_one_gpu"].get("rc") == 0:
+    a, b = (os.path.join(d, "ganon_e2e_out_" + x) for x in ("one_worker", "two_workers_one_gpu"))
+    out["outputs_identical"] = all(open(a + e, "rb").read() == open(b + e, "rb").read() for e in (".all", ".rep"))
+for f in os.listdir(d):
+    if f.startswith("ganon_e2e"):
+        os.remove(os.path.join(d, f))
+print(json.dumps(out))
