@@ -83,6 +83,25 @@ def spot_check_hibf(wl, flt, nh, status, mo, matches, n_sample: int):
     return bad == 0, {"reads_checked": int(len(idx)), "matches_checked": int(checked_matches), "mismatching_reads": int(bad)}
 
 
+def usable_cores() -> int:
+    """cores this process may really use: the affinity mask, capped by the cgroup CPU quota (cpu.max) -- the GPU boxes
+    show 256 logical CPUs but grant a quota of 16; 256 OpenMP threads on 16 cores cost 25 x per read (r01's 650 us)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:  # noqa: BLE001
+            pass
+    return n
+
+
 def _host_filter_buffer(n_words: int):
     """Host memory for the CPU baseline's copy of the filter: anonymous mapping with transparent huge pages requested
     and, while it is first touched, pages interleaved over the NUMA nodes (set_mempolicy) -- on 4 KiB pages bound to one
@@ -128,7 +147,7 @@ def cpu_baseline(wl, flt, n_sample: int = 0):
     import oracle
 
     build = _oracle_native()
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     mem_note = "numpy pages"
     if getattr(wl, "filter_rows", None) is None:  # device-generated filter: the oracle needs its bits on the host
         arr, keep, mem_note = _host_filter_buffer(wl.rows * wl.bin_words)
@@ -160,7 +179,8 @@ def cpu_baseline(wl, flt, n_sample: int = 0):
         "cores": threads,
         "kind": "port",
         "us_per_read_per_thread": round(dt * threads / n * 1e6, 1),
-        "sample": f"first {n} reads of the same workload against the same filter bits, {threads} OpenMP threads, "
+        "sample": f"first {n} reads of the same workload against the same filter bits, {threads} OpenMP threads (= usable cores: "
+                  f"affinity {len(os.sched_getaffinity(0))}, cgroup quota applied), "
                   f"{dt:.1f} s, oracle build: {build}, filter memory: {mem_note}, rows software-prefetched per read; "
                   f"minimiser + bulk_count + select per read (GanonClassify.cpp:676-735), {total} matches",
     }

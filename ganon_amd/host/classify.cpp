@@ -211,7 +211,10 @@ class MateStream
 {
 public:
     // the file is opened here, on the caller's thread: a file that cannot be opened fails before any record is read
-    explicit MateStream(const std::string& path) : q_(8), in_(new SeqReader(path)), worker_([this] { run(); }) {}
+    explicit MateStream(const std::string& path, uint64_t start_offset = 0)
+      : q_(8), in_(new SeqReader(path, start_offset)), worker_([this] { run(); })
+    {
+    }
     ~MateStream()
     {
         stop_ = true;
@@ -286,10 +289,23 @@ private:
     std::thread                worker_; // last member: everything above exists when it starts
 };
 
-// the reader thread (:1220-1287): files -> large batches, numbered in input order
+size_t env_size(const char* name, size_t dflt)
+{
+    const char* v = std::getenv(name);
+    return v ? (size_t)std::max(0LL, std::atoll(v)) : dflt;
+}
+
+// the reader thread (:1220-1287): files -> large batches, numbered in input order.
+// Uncompressed four-line FASTQ is parsed by several threads (ParallelFastq, seq_io.hpp): for single-end files a parsed
+// slab IS the batch (no copy); for pairs the slabs of file 1 become batches and the mates are copied next to them from
+// the slabs of file 2.  Everything else -- compressed input, FASTA, wrapped records, and whatever follows the first
+// record the parallel parser does not take -- goes through the sequential reader, from the byte where the slabs stopped.
 void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan)
 {
-    uint64_t seq = 0;
+    uint64_t       seq = 0;
+    const unsigned par_threads = (unsigned)env_size("GANON_HOST_PARSE_THREADS", 6);
+    const size_t   slab_bytes  = env_size("GANON_HOST_SLAB_BYTES", 48u << 20);
+    const size_t   par_min     = env_size("GANON_HOST_PARALLEL_MIN", 32u << 20);
     for (auto const& [prefix, files] : plan)
     {
         for (auto const& pair : files)
@@ -326,13 +342,170 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                 queue.push(std::move(rb));
                 fresh();
             };
+            auto report_error = [&](const std::string& what) { // :1278-1283: report, keep what was read, go on with the next file
+                std::cerr << "Error parsing file(s) [" << pair.mate1 << ", " << pair.mate2 << "]" << what << std::endl;
+            };
             fresh();
+
+            // ---- parallel slabs ----------------------------------------------------------------------------------
+            uint64_t resume1 = 0, resume2 = 0; // where the sequential reader takes over (0 = from the start)
+            bool     file_done = false, fallback = false;
+            {
+                auto pf1 = ParallelFastq::open(pair.mate1, paired ? std::max(1u, par_threads / 2) : par_threads, slab_bytes, par_min);
+                auto pf2 = paired && pf1 ? ParallelFastq::open(pair.mate2, std::max(1u, par_threads / 2), slab_bytes, 0) : nullptr;
+                if (paired && !pf2)
+                    pf1.reset();
+                ParallelFastq::Slab a, b;
+                size_t              bpos = 0;       // next unread mate of slab b
+                bool                b_open = true;  // file 2 may still deliver slabs
+                bool                b_end = false;  // file 2 is exhausted (mates stay empty, like the sequential reader at EOF)
+                std::string         b_error;        // file 2's ParseError, raised when the mate at bpos is asked for
+                bool                b_irregular = false;
+                // makes sure slab b has an unread mate; false when file 2 cannot deliver one (end / error / irregular)
+                auto mate_ready = [&]() -> bool {
+                    while (bpos >= b.size())
+                    {
+                        if (!b.error.empty())
+                        {
+                            b_error = b.error;
+                            return false;
+                        }
+                        if (b.irregular)
+                        {
+                            b_irregular = true;
+                            return false;
+                        }
+                        if (!b_open || !pf2->next(b))
+                        {
+                            b_open = false;
+                            b_end  = true;
+                            return false;
+                        }
+                        bpos = 0;
+                    }
+                    return true;
+                };
+                while (pf1 && pf1->next(a))
+                {
+                    // records of slab a, cut into batches of at most kBatchReads
+                    size_t r0 = 0;
+                    bool   stop_file = false;
+                    while (r0 < a.size() && !stop_file)
+                    {
+                        const size_t r1 = std::min(a.size(), r0 + kBatchReads);
+                        size_t       taken = r1 - r0;
+                        if (r0 == 0 && r1 == a.size())
+                        {
+                            rb.id_buf.swap(a.ids); // the slab is the batch
+                            rb.id_off.swap(a.id_off);
+                            rb.bases.swap(a.bases);
+                            rb.off1.swap(a.off);
+                        }
+                        else
+                        {
+                            rb.id_buf.assign(a.ids, a.id_off[r0], a.id_off[r1] - a.id_off[r0]);
+                            rb.id_off.resize(taken + 1);
+                            rb.off1.resize(taken + 1);
+                            for (size_t i = 0; i <= taken; ++i)
+                            {
+                                rb.id_off[i] = a.id_off[r0 + i] - a.id_off[r0];
+                                rb.off1[i]   = a.off[r0 + i] - a.off[r0];
+                            }
+                            rb.bases.assign(a.bases.begin() + a.off[r0], a.bases.begin() + a.off[r1]);
+                        }
+                        if (paired)
+                        {
+                            rb.off2.assign(1, 0);
+                            for (size_t i = 0; i < taken; ++i)
+                            {
+                                if (b_end || mate_ready())
+                                {
+                                    if (!b_end)
+                                    {
+                                        bases2.insert(bases2.end(), b.bases.begin() + b.off[bpos], b.bases.begin() + b.off[bpos + 1]);
+                                        ++bpos;
+                                    }
+                                    rb.off2.push_back(bases2.size());
+                                    continue;
+                                }
+                                if (b_end) // (set by mate_ready just now: this and all later mates are empty)
+                                {
+                                    rb.off2.push_back(bases2.size());
+                                    continue;
+                                }
+                                // file 2 stopped at this mate: keep the records before it
+                                if (!b_error.empty())
+                                    rb.off2.push_back(bases2.size()); // the sequential reader keeps this read with an empty mate
+                                const size_t keep = rb.off2.size() - 1;
+                                rb.id_buf.resize(rb.id_off[keep]);
+                                rb.id_off.resize(keep + 1);
+                                rb.bases.resize(rb.off1[keep]);
+                                rb.off1.resize(keep + 1);
+                                if (b_irregular)
+                                {
+                                    resume1  = a.rec_at[r0 + keep];
+                                    resume2  = b.resume_at;
+                                    fallback = true;
+                                }
+                                taken     = keep;
+                                stop_file = true;
+                                break;
+                            }
+                        }
+                        flush();
+                        r0 += taken;
+                    }
+                    if (stop_file)
+                    {
+                        if (!b_error.empty())
+                        {
+                            report_error(b_error);
+                            file_done = true;
+                        }
+                        break;
+                    }
+                    if (!a.error.empty())
+                    {
+                        report_error(a.error);
+                        file_done = true;
+                        break;
+                    }
+                    if (a.irregular)
+                    {
+                        resume1  = a.resume_at;
+                        fallback = true;
+                        if (paired)
+                        {
+                            // the mate of the first unparsed record of file 1: the next unread record of file 2
+                            if (bpos < b.size() || mate_ready())
+                                resume2 = b.rec_at[bpos];
+                            else if (b_irregular)
+                                resume2 = b.resume_at;
+                            else if (!b_error.empty())
+                            {
+                                report_error(b_error); // (file 2 fails before file 1 continues)
+                                file_done = true;
+                            }
+                            else
+                                resume2 = UINT64_MAX; // file 2 is exhausted
+                        }
+                        break;
+                    }
+                    a = ParallelFastq::Slab();
+                }
+                if (pf1 && !fallback)
+                    file_done = true; // the slabs covered the whole file (or ended it with a parse error)
+            }
+            if (file_done)
+                continue;
+
+            // ---- sequential reader (whole file, or the rest of it) -------------------------------------------------
             try
             {
-                SeqReader                   fin1(pair.mate1);
+                SeqReader                   fin1(pair.mate1, resume1);
                 std::unique_ptr<MateStream> fin2;
-                if (paired)
-                    fin2.reset(new MateStream(pair.mate2));
+                if (paired && resume2 != UINT64_MAX)
+                    fin2.reset(new MateStream(pair.mate2, resume2));
                 while (fin1.next(rb.id_buf, rb.bases))
                 {
                     rb.id_off.push_back(rb.id_buf.size());
@@ -341,7 +514,8 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     {
                         try
                         {
-                            fin2->next(bases2); // at EOF the mate stays empty
+                            if (fin2)
+                                fin2->next(bases2); // at EOF the mate stays empty
                         }
                         catch (ParseError const&)
                         {
@@ -355,10 +529,10 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                 }
                 flush();
             }
-            catch (ParseError const& ext) // :1278-1283: report, keep what was read, go on with the next file
+            catch (ParseError const& ext)
             {
                 flush();
-                std::cerr << "Error parsing file(s) [" << pair.mate1 << ", " << pair.mate2 << "]" << ext.what() << std::endl;
+                report_error(ext.what());
                 continue;
             }
         }

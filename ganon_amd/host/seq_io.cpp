@@ -14,7 +14,13 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <string_view>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace gnhost
 {
@@ -364,7 +370,7 @@ struct SeqReader::Impl
     throw ParseError(" Encountered an unexpected letter");
 }
 
-SeqReader::SeqReader(const std::string& path) : impl_(new Impl)
+SeqReader::SeqReader(const std::string& path, uint64_t start_offset) : impl_(new Impl)
 {
     impl_->path = path;
     std::string base = path;
@@ -389,7 +395,7 @@ SeqReader::SeqReader(const std::string& path) : impl_(new Impl)
     if (!known)
         throw ParseError(" unknown sequence file extension (expected FASTA or FASTQ, optionally gzipped)");
     impl_->buf.resize(4 << 20);
-    if (!std::getenv("GANON_HOST_NO_BGZF"))
+    if (!std::getenv("GANON_HOST_NO_BGZF") && start_offset == 0)
         impl_->bgzf = BgzfSource::open(path); // blocked gzip: members inflated in parallel
     if (impl_->bgzf)
         return;
@@ -397,6 +403,8 @@ SeqReader::SeqReader(const std::string& path) : impl_(new Impl)
     if (!impl_->gz)
         throw ParseError(" cannot open file");
     gzbuffer(impl_->gz, 1 << 20);
+    if (start_offset && gzseek(impl_->gz, (z_off_t)start_offset, SEEK_SET) < 0)
+        throw ParseError(" cannot seek in file");
 }
 
 SeqReader::~SeqReader()
@@ -485,6 +493,202 @@ bool SeqReader::next(std::string& ids, std::vector<uint8_t>& bases)
         bases.resize(bases0);
         throw;
     }
+}
+
+// ---- ParallelFastq ----------------------------------------------------------------------------------------------------
+struct ParallelFastq::Impl
+{
+    const char* data = nullptr;
+    size_t      size = 0;
+    int         fd   = -1;
+    size_t      slab_bytes = 0, n_slabs = 0;
+    std::vector<std::thread> workers;
+    std::mutex               m;
+    std::condition_variable  cv;
+    std::map<size_t, Slab>   ready;
+    size_t                   next_to_parse = 0, next_to_take = 0, window = 0;
+    bool                     stop = false, ended = false;
+
+    // first byte of the first record at or after p (== size when there is none)
+    size_t record_at_or_after(size_t p) const
+    {
+        if (p == 0)
+            return 0;
+        const char* e = data + size;
+        const char* q = static_cast<const char*>(std::memchr(data + p - 1, '\n', size - (p - 1))); // a record may start exactly at p
+        while (q)
+        {
+            const char* l0 = q + 1;
+            if (l0 >= e)
+                return size;
+            if (*l0 == '@')
+            {
+                const char* n1 = static_cast<const char*>(std::memchr(l0, '\n', (size_t)(e - l0)));
+                const char* n2 = n1 && n1 + 1 < e ? static_cast<const char*>(std::memchr(n1 + 1, '\n', (size_t)(e - n1 - 1))) : nullptr;
+                if (n2 && n2 + 1 < e && n2[1] == '+')
+                    return (size_t)(l0 - data);
+            }
+            q = static_cast<const char*>(std::memchr(l0, '\n', (size_t)(e - l0)));
+        }
+        return size;
+    }
+
+    void parse(size_t begin, size_t end, Slab& out) const
+    {
+        const char* p = data + begin;
+        const char* e = data + end;
+        const char* file_end = data + size;
+        out.ids.reserve((end - begin) / 8);
+        out.bases.reserve((end - begin) / 2);
+        auto line = [&](const char*& cur, std::string_view& l) -> bool { // a line inside the FILE (a record may not be cut by `e`)
+            if (cur >= file_end)
+                return false;
+            const char* nl = static_cast<const char*>(std::memchr(cur, '\n', (size_t)(file_end - cur)));
+            const char* le = nl ? nl : file_end;
+            size_t      n  = (size_t)(le - cur);
+            if (n && cur[n - 1] == '\r')
+                --n;
+            l   = std::string_view(cur, n);
+            cur = nl ? nl + 1 : file_end;
+            return true;
+        };
+        out.rec_at.reserve((end - begin) / 256);
+        while (p < e)
+        {
+            const char*      rec = p;
+            out.rec_at.push_back((uint64_t)(rec - data));
+            std::string_view id, seq, plus, qual;
+            const char*      cur = p;
+            if (!line(cur, id) || id.empty() || id[0] != '@' || !line(cur, seq) || !line(cur, plus) || plus.empty() || plus[0] != '+'
+                || !line(cur, qual) || (!seq.empty() && seq[0] == '+'))
+            {
+                out.irregular = true; // blank line, wrapped record, truncated tail, ...: the sequential parser decides
+                out.resume_at = (uint64_t)(rec - data);
+                return;
+            }
+            if (!all_legal(seq.data(), seq.size()))
+            {
+                try
+                {
+                    bad_letter(seq);
+                }
+                catch (ParseError const& x)
+                {
+                    out.error = x.what();
+                }
+                return;
+            }
+            if (qual.size() != seq.size())
+            {
+                // (could be a wrapped record whose first quality line is shorter: let the sequential parser look at it)
+                out.irregular = true;
+                out.resume_at = (uint64_t)(rec - data);
+                return;
+            }
+            out.ids.append(id.data() + 1, id.size() - 1);
+            out.id_off.push_back(out.ids.size());
+            const size_t at = out.bases.size();
+            out.bases.resize(at + seq.size());
+            std::memcpy(out.bases.data() + at, seq.data(), seq.size());
+            out.off.push_back(out.bases.size());
+            p = cur;
+        }
+        out.rec_at.push_back((uint64_t)(p - data));
+    }
+
+    void work()
+    {
+        for (;;)
+        {
+            size_t i;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || next_to_parse >= n_slabs || next_to_parse < next_to_take + window; });
+                if (stop || next_to_parse >= n_slabs)
+                    return;
+                i = next_to_parse++;
+            }
+            Slab         s;
+            const size_t b = record_at_or_after(i * slab_bytes);
+            const size_t e = i + 1 == n_slabs ? size : record_at_or_after((i + 1) * slab_bytes);
+            if (b < e)
+                parse(b, e, s);
+            std::lock_guard<std::mutex> lk(m);
+            ready.emplace(i, std::move(s));
+            cv.notify_all();
+        }
+    }
+};
+
+ParallelFastq::ParallelFastq(Impl* i) : impl_(i) {}
+
+std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes)
+{
+    if (!(ends_with(path, ".fq") || ends_with(path, ".fastq")) || threads == 0)
+        return nullptr;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0)
+        return nullptr;
+    struct stat st;
+    unsigned char magic[2] = { 0, 0 };
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < std::max<size_t>(min_bytes, 2) || pread(fd, magic, 2, 0) != 2
+        || (magic[0] == 0x1F && magic[1] == 0x8B))
+    {
+        ::close(fd);
+        return nullptr;
+    }
+    void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED)
+    {
+        ::close(fd);
+        return nullptr;
+    }
+    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
+    Impl* im       = new Impl;
+    im->data       = static_cast<const char*>(map);
+    im->size       = (size_t)st.st_size;
+    im->fd         = fd;
+    im->slab_bytes = std::max<size_t>(slab_bytes, 1 << 16);
+    im->n_slabs    = (im->size + im->slab_bytes - 1) / im->slab_bytes;
+    im->window     = 2 * threads + 2;
+    std::unique_ptr<ParallelFastq> pf(new ParallelFastq(im));
+    for (unsigned t = 0; t < threads; ++t)
+        im->workers.emplace_back([im] { im->work(); });
+    return pf;
+}
+
+ParallelFastq::~ParallelFastq()
+{
+    Impl& s = *impl_;
+    {
+        std::lock_guard<std::mutex> lk(s.m);
+        s.stop = true;
+        s.cv.notify_all();
+    }
+    for (auto& t : s.workers)
+        t.join();
+    munmap(const_cast<char*>(s.data), s.size);
+    ::close(s.fd);
+}
+
+bool ParallelFastq::next(Slab& out)
+{
+    Impl&                        s = *impl_;
+    std::unique_lock<std::mutex> lk(s.m);
+    if (s.ended || s.next_to_take >= s.n_slabs)
+        return false;
+    s.cv.wait(lk, [&] { return s.ready.count(s.next_to_take) != 0; });
+    auto it = s.ready.find(s.next_to_take);
+    out     = std::move(it->second);
+    s.ready.erase(it);
+    ++s.next_to_take;
+    if (!out.error.empty() || out.irregular)
+    {
+        s.ended = true; // what the other workers parsed beyond this point is dropped
+        s.stop  = true;
+    }
+    s.cv.notify_all();
+    return true;
 }
 
 } // namespace gnhost

@@ -26,7 +26,8 @@ struct ParseError : std::runtime_error
 class SeqReader
 {
 public:
-    explicit SeqReader(const std::string& path); // throws ParseError / runtime_error
+    // start_offset: begin at this byte of an UNCOMPRESSED file (must be the first byte of a record)
+    explicit SeqReader(const std::string& path, uint64_t start_offset = 0); // throws ParseError / runtime_error
     ~SeqReader();
     // next record: its id is appended to `ids` and its ASCII sequence to `bases` (the caller keeps the offsets);
     // returns false at end of file.  A ParseError leaves both containers as they were before the call.
@@ -35,6 +36,39 @@ public:
 private:
     struct Impl;
     std::unique_ptr<Impl> impl_;
+};
+
+// Parallel parser for uncompressed FASTQ files whose records have the common four-line form (@id / bases / + / qualities):
+// the file is mapped, cut into byte slabs, and a few threads parse slabs ahead of the consumer, which receives them in
+// file order.  A slab starts at the first record boundary at or after its first byte; a line starts a record iff it begins
+// with '@' and the line after the next begins with '+' (a quality line may begin with '@', but then the line after the
+// next is a base line, and '+' is no legal base).  The records of a slab are validated strictly; anything the four-line
+// form does not cover (wrapped sequences, blank lines) ends the slab as `irregular` at that record, and the caller
+// continues there with the sequential SeqReader -- so the result is the sequential parser's, record for record.
+class ParallelFastq
+{
+public:
+    struct Slab
+    {
+        std::string           ids;         // ids back to back
+        std::vector<uint64_t> id_off{ 0 }; // n+1
+        std::vector<uint8_t>  bases;       // ASCII, back to back
+        std::vector<uint64_t> off{ 0 };    // n+1
+        std::vector<uint64_t> rec_at;      // n+1: byte offset of every record in the file (last = end of the parsed part)
+        std::string           error;       // a ParseError ended the file after the records above
+        bool                  irregular = false;
+        uint64_t              resume_at = 0; // irregular: byte offset of the first record that was not parsed here
+        size_t                size() const { return off.size() - 1; }
+    };
+    // nullptr when the file is not eligible (compressed, not FASTQ by extension, smaller than min_bytes, cannot be mapped)
+    static std::unique_ptr<ParallelFastq> open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes);
+    ~ParallelFastq();
+    bool next(Slab& out); // slabs in file order; false at the end of the file (or after an error / irregular slab)
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+    explicit ParallelFastq(Impl* i);
 };
 
 } // namespace gnhost

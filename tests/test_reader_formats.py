@@ -3,6 +3,7 @@ the same reads written as FASTQ / FASTA, wrapped, CRLF, gzipped, without a final
 outputs; a parse error keeps the records before it and moves on.  CPU: test-only oracle backend."""
 import gzip
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -196,3 +197,68 @@ def test_formats_errors_long_line_hip(sim_db, tmp_path):
     _check_variants(cu.BIN_HIP, sim_db, str(tmp_path))
     _check_errors(cu.BIN_HIP, sim_db, str(tmp_path))
     _check_long_line(cu.BIN_HIP, sim_db, str(tmp_path))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parallel FASTQ slabs (ganon_amd/host/seq_io.cpp ParallelFastq): same batches' content, same outputs as the sequential reader
+# ---------------------------------------------------------------------------------------------------------------
+def _fastq_text(recs, wrap=0, crlf=False, blank_after=None):
+    nl = "\r\n" if crlf else "\n"
+    out = []
+    for i, (rid, s) in enumerate(recs):
+        q = "".join("I@+#"[(i + j) % 4] for j in range(len(s)))  # quality lines that start with '@' and '+'
+        if wrap and len(s) > wrap and i % 5 == 0:
+            body = nl.join(s[a:a + wrap] for a in range(0, len(s), wrap))
+            qual = nl.join(q[a:a + wrap] for a in range(0, len(q), wrap))
+        else:
+            body, qual = s, q
+        out.append(f"@{rid}{nl}{body}{nl}+{nl}{qual}{nl}")
+        if blank_after is not None and i == blank_after:
+            out.append(nl)
+    return "".join(out)
+
+
+def _run_reader_case(binary, ibf, files, out, paired, env):
+    args = ["--ibf", ibf, "-o", out, "--output-all", "--output-unclassified", "--rel-cutoff", "0.3", "--quiet"]
+    args += ["--paired-reads", ",".join(files)] if paired else ["--single-reads", files[0]]
+    p = subprocess.run([binary] + args, capture_output=True, text=True, env=dict(os.environ, **env))
+    assert p.returncode == 0, p.stderr
+    return p.stderr, {e: open(out + e, "rb").read() for e in (".all", ".unc", ".rep")}
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("variant", ["plain", "crlf", "wrapped", "blank_line", "bad_letter", "mate_short", "mate_bad"])
+def test_parallel_fastq_equals_sequential_reader(oracle_bin, sim_db, tmp_path, paired, variant):
+    import numpy as np
+    rng = np.random.default_rng(17)
+    n = 1500
+    g = list(sim_db["targets"].values())
+    db = sim_db
+    recs1, recs2 = [], []
+    for i in range(n):
+        src = g[i % len(g)] if i % 3 else "".join("ACGT"[x] for x in rng.integers(0, 4, size=400))
+        p = int(rng.integers(0, len(src) - 310))
+        L = int(rng.integers(40, 152))
+        recs1.append((f"read{i} extra words", src[p:p + L]))
+        recs2.append((f"read{i}/2", src[p + 150:p + 150 + L][::-1].translate(str.maketrans("ACGT", "TGCA"))))
+    if variant == "bad_letter":
+        recs1[n // 2] = (recs1[n // 2][0], recs1[n // 2][1][:20] + "!" + recs1[n // 2][1][21:])
+    if variant == "mate_short":
+        recs2 = recs2[: n // 3]
+    if variant == "mate_bad":
+        recs2[2 * n // 3] = (recs2[2 * n // 3][0], "ACGT*ACGT" * 8)
+    kw = dict(crlf=variant == "crlf", wrap=40 if variant == "wrapped" else 0, blank_after=n // 4 if variant == "blank_line" else None)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    open(f1, "w", newline="").write(_fastq_text(recs1, **kw))
+    open(f2, "w", newline="").write(_fastq_text(recs2, **(kw if variant in ("crlf",) else {})))
+    files = [f1, f2] if paired else [f1]
+    if not paired and variant.startswith("mate"):
+        pytest.skip("paired-only case")
+    seq_err, seq_out = _run_reader_case(oracle_bin, db["ibf"], files, str(tmp_path / "seq"), paired, {"GANON_HOST_PARSE_THREADS": "0"})
+    for slab in ("65536", "200000"):
+        par_err, par_out = _run_reader_case(oracle_bin, db["ibf"], files, str(tmp_path / ("par" + slab)), paired,
+                                            {"GANON_HOST_PARSE_THREADS": "4", "GANON_HOST_SLAB_BYTES": slab, "GANON_HOST_PARALLEL_MIN": "0",
+                                             "GANON_HOST_BATCH_READS": "333"})
+        assert par_out == seq_out, (variant, slab)
+        assert ("Error parsing" in par_err) == ("Error parsing" in seq_err) == (variant in ("bad_letter", "mate_bad"))
+    assert seq_out[".all"].count(b"\n") > 100
