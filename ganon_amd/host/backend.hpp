@@ -12,6 +12,7 @@
 #pragma once
 
 #include "filter_io.hpp"
+#include "hostmem.hpp"
 
 #include <cstdint>
 #include <memory>
@@ -30,7 +31,7 @@ struct ReadBatch
     std::string           prefix;
     std::string           id_buf;      // all read ids back to back
     std::vector<uint64_t> id_off{ 0 }; // n+1 offsets into id_buf
-    std::vector<uint8_t>  bases;       // mates 1 of all reads, then mates 2 of all reads
+    ByteBuf               bases;       // mates 1 of all reads, then mates 2 of all reads (page-locked under the HIP backend)
     std::vector<uint64_t> off1;        // n+1
     std::vector<uint64_t> off2;        // n+1 when paired (offsets into `bases`)
     size_t                size() const { return id_off.size() - 1; }

@@ -5,6 +5,7 @@
 #include <ganon_hip.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <sstream>
 
 namespace gnhost
@@ -404,6 +405,15 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
         }
     for (int d : use)
         out.emplace_back(new HipBackend(d));
+    // device-bound host buffers (read batches) come from page-locked memory from now on (hostmem.hpp)
+    if (!std::getenv("GANON_HOST_PAGEABLE"))
+    {
+        g_host_arena.alloc = [](size_t n) -> void* {
+            void* p = nullptr;
+            return gn_pinned_alloc(n ? n : 1, &p) == GN_OK ? p : nullptr;
+        };
+        g_host_arena.release = [](void* p) { gn_pinned_free(p); };
+    }
     return out;
 }
 

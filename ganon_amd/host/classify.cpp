@@ -193,7 +193,7 @@ const size_t     kBatchReads = std::getenv("GANON_HOST_BATCH_READS") ? std::max(
 constexpr size_t kBatchBases = 1ull << 28;
 
 // appends the mates-2 region behind the mates-1 region and rebases its offsets
-void finalize_batch(ReadBatch& rb, std::vector<uint8_t>& bases2)
+void finalize_batch(ReadBatch& rb, ByteBuf& bases2)
 {
     if (!rb.paired)
         return;
@@ -223,7 +223,7 @@ public:
         worker_.join();
     }
     // appends the next mate to `bases`; false at end of file; throws the file's ParseError where it occurred
-    bool next(std::vector<uint8_t>& bases)
+    bool next(ByteBuf& bases)
     {
         while (pos_ == cur_.off.size() - 1)
         {
@@ -249,7 +249,7 @@ public:
 private:
     struct Block
     {
-        std::vector<uint8_t>  bases;
+        ByteBuf               bases;
         std::vector<uint64_t> off{ 0 };
         bool                  last = false;
         std::string           error; // with last: the ParseError that ended the file
@@ -312,7 +312,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
         {
             const bool           paired = pair.paired();
             ReadBatch            rb;
-            std::vector<uint8_t> bases2; // mates 2 of the current batch
+            ByteBuf              bases2; // mates 2 of the current batch
             auto                 fresh = [&]() {
                 if (queue.take_free(rb))
                 {
@@ -491,6 +491,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                         }
                         break;
                     }
+                    pf1->recycle(std::move(a));
                     a = ParallelFastq::Slab();
                 }
                 if (pf1 && !fallback)
@@ -776,7 +777,7 @@ static bool ganon_classify(Config config)
             ReadBatch left;
             left.paired = rb.paired;
             left.prefix = rb.prefix;
-            std::vector<uint8_t> left2;
+            ByteBuf left2;
             left.off1.assign(1, 0);
             if (left.paired)
                 left.off2.assign(1, 0);

@@ -413,7 +413,7 @@ SeqReader::~SeqReader()
         gzclose(impl_->gz);
 }
 
-bool SeqReader::next(std::string& ids, std::vector<uint8_t>& bases)
+bool SeqReader::next(std::string& ids, ByteBuf& bases)
 {
     Impl&            s = *impl_;
     const size_t     ids0 = ids.size(), bases0 = bases.size();
@@ -506,6 +506,7 @@ struct ParallelFastq::Impl
     std::mutex               m;
     std::condition_variable  cv;
     std::map<size_t, Slab>   ready;
+    std::vector<Slab>        free_slabs;
     size_t                   next_to_parse = 0, next_to_take = 0, window = 0;
     bool                     stop = false, ended = false;
 
@@ -608,7 +609,22 @@ struct ParallelFastq::Impl
                     return;
                 i = next_to_parse++;
             }
-            Slab         s;
+            Slab s;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (!free_slabs.empty())
+                {
+                    s = std::move(free_slabs.back());
+                    free_slabs.pop_back();
+                }
+            }
+            s.ids.clear();
+            s.id_off.assign(1, 0);
+            s.bases.clear();
+            s.off.assign(1, 0);
+            s.rec_at.clear();
+            s.error.clear();
+            s.irregular = false;
             const size_t b = record_at_or_after(i * slab_bytes);
             const size_t e = i + 1 == n_slabs ? size : record_at_or_after((i + 1) * slab_bytes);
             if (b < e)
@@ -669,6 +685,13 @@ ParallelFastq::~ParallelFastq()
         t.join();
     munmap(const_cast<char*>(s.data), s.size);
     ::close(s.fd);
+}
+
+void ParallelFastq::recycle(Slab&& used)
+{
+    std::lock_guard<std::mutex> lk(impl_->m);
+    if (impl_->free_slabs.size() < impl_->window + 2)
+        impl_->free_slabs.push_back(std::move(used));
 }
 
 bool ParallelFastq::next(Slab& out)

@@ -9,6 +9,8 @@
 //   * FASTA: whitespace and digits inside sequences are ignored; FASTQ: qualities are read and dropped
 #pragma once
 
+#include "hostmem.hpp"
+
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -31,7 +33,7 @@ public:
     ~SeqReader();
     // next record: its id is appended to `ids` and its ASCII sequence to `bases` (the caller keeps the offsets);
     // returns false at end of file.  A ParseError leaves both containers as they were before the call.
-    bool next(std::string& ids, std::vector<uint8_t>& bases);
+    bool next(std::string& ids, ByteBuf& bases);
 
 private:
     struct Impl;
@@ -52,7 +54,7 @@ public:
     {
         std::string           ids;         // ids back to back
         std::vector<uint64_t> id_off{ 0 }; // n+1
-        std::vector<uint8_t>  bases;       // ASCII, back to back
+        ByteBuf               bases;       // ASCII, back to back (device-bound: page-locked under the HIP backend)
         std::vector<uint64_t> off{ 0 };    // n+1
         std::vector<uint64_t> rec_at;      // n+1: byte offset of every record in the file (last = end of the parsed part)
         std::string           error;       // a ParseError ended the file after the records above
@@ -64,6 +66,7 @@ public:
     static std::unique_ptr<ParallelFastq> open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes);
     ~ParallelFastq();
     bool next(Slab& out); // slabs in file order; false at the end of the file (or after an error / irregular slab)
+    void recycle(Slab&& used); // hands a consumed slab's buffers back to the parser threads
 
 private:
     struct Impl;
