@@ -325,18 +325,20 @@ def main() -> int:
     if rank == 0:
         if not args.no_extra and world == 1 and args.workload == "flat8g" and not args.reads and not args.rows:
             result["other_workloads"] = [run_extra(w, args.extra_timeout) for w in EXTRA_WORKLOADS]
+    # RCCL writes a version banner through C stdio (buffered until exit when stdout is a pipe).  Every rank pushes its
+    # buffered C output out BEFORE the last barrier, rank 0 prints the JSON line after it: the JSON is the last line of
+    # the job's stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
     if world > 1 or kind == "slice":
         import torch.distributed as dist
         gdist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL writes a version banner through C stdio (buffered until exit when stdout is a pipe): push it out first so that
-        # the JSON line is the LAST line of stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:  # noqa: BLE001
-            pass
         print(json.dumps(result), flush=True)
     return 0
 
