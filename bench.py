@@ -305,7 +305,9 @@ def main() -> int:
             else:
                 ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check,
                                                   target_offset=(sl_idx * spec["bins"] if kind == "slice" else 0),
-                                                  bins_per_target=spec.get("bins_per_target", 1))
+                                                  bins_per_target=spec.get("bins_per_target", 1),
+                                                  read_range=(lo, hi) if kind == "slice" else None,
+                                                  own_targets_only=kind == "slice" and world > 1)
             result["config"]["oracle_spot_check"] = detail
             if not ok:
                 log("bench.py: ORACLE SPOT CHECK FAILED:", detail)

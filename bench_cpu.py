@@ -37,7 +37,8 @@ def _oracle_native():
     return "portable"
 
 
-def spot_check(wl, flt, nh, status, mo, matches, n_sample: int, target_offset: int = 0, bins_per_target: int = 1):
+def spot_check(wl, flt, nh, status, mo, matches, n_sample: int, target_offset: int = 0, bins_per_target: int = 1,
+               read_range=None, own_targets_only: bool = False):
     """GPU (read, target, count) lists of a random read sample == oracle select_matches on the device's bits.  Only
     the rows the sample touches are fetched from the device (gn_filter_download_row_list), so this also works on the
     128 GiB filters; `target_offset` = first global target of a column slice."""
@@ -46,13 +47,17 @@ def spot_check(wl, flt, nh, status, mo, matches, n_sample: int, target_offset: i
     ibf = bw.sampled_oracle_ibf(flt, wl)
     rng = np.random.default_rng(123)
     n = wl.n_reads
-    idx = np.unique(rng.integers(0, n, size=min(n_sample, n)))
+    lo, hi = read_range if read_range is not None else (0, n)   # partitioned filter, N > 1: this rank holds the matches of [lo, hi)
+    idx = np.unique(rng.integers(lo, hi, size=min(n_sample, hi - lo)))
     bad = 0
     checked_matches = 0
+    t_lo, t_hi = target_offset, target_offset + wl.bins // bins_per_target
     for r in idx.tolist():
         n_h, exp = bw.oracle_read_matches(ibf, wl, r, bins_per_target)
         exp = [(t + target_offset, c) for t, c in exp]
         got = [(int(x["target"]), int(x["count"])) for x in matches[int(mo[r]):int(mo[r + 1])]]
+        if own_targets_only:  # the other ranks' targets arrive through the exchange; this rank can only re-derive its own
+            got = [g for g in got if t_lo <= g[0] < t_hi]
         if nh[r] != n_h or status[r] != 0 or got != exp:
             bad += 1
         checked_matches += len(exp)

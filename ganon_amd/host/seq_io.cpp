@@ -496,9 +496,101 @@ bool SeqReader::next(std::string& ids, ByteBuf& bases)
 }
 
 // ---- ParallelFastq ----------------------------------------------------------------------------------------------------
+namespace
+{
+// Lines of a byte range of a file, read with pread into a private buffer (no shared page tables, no page faults: the
+// mapping-based first version did not scale past a few threads on mmap_lock).
+class RangeLines
+{
+public:
+    RangeLines(int fd, uint64_t file_size) : fd_(fd), size_(file_size), buf_(4u << 20) {}
+    void seek(uint64_t off)
+    {
+        if (off >= base_ && off <= base_ + len_)
+            pos_ = (size_t)(off - base_);
+        else
+        {
+            base_ = off;
+            len_ = pos_ = 0;
+        }
+    }
+    uint64_t tell() const { return base_ + pos_; }
+    // next line (no '\n', trailing '\r' stripped), valid until the next call; false at the end of the file
+    bool line(std::string_view& out)
+    {
+        size_t scanned = 0;
+        for (;;)
+        {
+            const char* b  = buf_.data() + pos_;
+            const char* nl = static_cast<const char*>(std::memchr(b + scanned, '\n', len_ - pos_ - scanned));
+            if (nl)
+            {
+                size_t n = (size_t)(nl - b);
+                pos_ += n + 1;
+                if (n && b[n - 1] == '\r')
+                    --n;
+                out = std::string_view(b, n);
+                return true;
+            }
+            scanned = len_ - pos_;
+            if (!refill())
+            {
+                if (len_ == pos_)
+                    return false;
+                size_t n = len_ - pos_; // last line without a newline
+                b        = buf_.data() + pos_;
+                pos_     = len_;
+                if (n && b[n - 1] == '\r')
+                    --n;
+                out = std::string_view(b, n);
+                return true;
+            }
+        }
+    }
+    // n bytes followed by '\n' right here?  (the quality line of a four-line record: no search needed)
+    bool skip_exact_line(size_t n, std::string_view& out)
+    {
+        while (len_ - pos_ < n + 1)
+            if (!refill())
+                return false;
+        const char* b = buf_.data() + pos_;
+        if (b[n] != '\n' || (n && std::memchr(b, '\n', n)))
+            return false;
+        out = std::string_view(b, n);
+        pos_ += n + 1;
+        return true;
+    }
+
+private:
+    bool refill()
+    {
+        if (base_ + len_ >= size_)
+            return false;
+        if (pos_ > 0)
+        {
+            std::memmove(buf_.data(), buf_.data() + pos_, len_ - pos_);
+            base_ += pos_;
+            len_ -= pos_;
+            pos_ = 0;
+        }
+        if (len_ == buf_.size())
+            buf_.resize(buf_.size() * 2); // a single line longer than the buffer
+        const size_t  want = (size_t)std::min<uint64_t>(buf_.size() - len_, size_ - (base_ + len_));
+        const ssize_t got  = ::pread(fd_, buf_.data() + len_, want, (off_t)(base_ + len_));
+        if (got <= 0)
+            return false;
+        len_ += (size_t)got;
+        return true;
+    }
+    int               fd_;
+    uint64_t          size_, base_ = 0;
+    std::vector<char> buf_;
+    size_t            pos_ = 0, len_ = 0;
+};
+} // namespace
+
 struct ParallelFastq::Impl
 {
-    const char* data = nullptr;
     size_t      size = 0;
     int         fd   = -1;
     size_t      slab_bytes = 0, n_slabs = 0;
@@ -510,108 +602,110 @@ struct ParallelFastq::Impl
     size_t                   next_to_parse = 0, next_to_take = 0, window = 0;
     bool                     stop = false, ended = false;
 
-    // first byte of the first record at or after p (== size when there is none)
-    size_t record_at_or_after(size_t p) const
+    // first byte of the first record at or after p (== size when there is none): a line that begins with '@' and whose
+    // next-but-one line begins with '+'
+    size_t record_at_or_after(RangeLines& in, size_t p) const
     {
         if (p == 0)
             return 0;
-        const char* e = data + size;
-        const char* q = static_cast<const char*>(std::memchr(data + p - 1, '\n', size - (p - 1))); // a record may start exactly at p
-        while (q)
+        if (p >= size)
+            return size;
+        std::string_view l;
+        in.seek(p - 1);
+        if (!in.line(l)) // the rest of the line that holds byte p-1 (empty when a line starts exactly at p)
+            return size;
+        for (;;)
         {
-            const char* l0 = q + 1;
-            if (l0 >= e)
+            const uint64_t o0 = in.tell();
+            if (!in.line(l))
                 return size;
-            if (*l0 == '@')
-            {
-                const char* n1 = static_cast<const char*>(std::memchr(l0, '\n', (size_t)(e - l0)));
-                const char* n2 = n1 && n1 + 1 < e ? static_cast<const char*>(std::memchr(n1 + 1, '\n', (size_t)(e - n1 - 1))) : nullptr;
-                if (n2 && n2 + 1 < e && n2[1] == '+')
-                    return (size_t)(l0 - data);
-            }
-            q = static_cast<const char*>(std::memchr(l0, '\n', (size_t)(e - l0)));
+            if (l.empty() || l[0] != '@')
+                continue;
+            const uint64_t o1 = in.tell();
+            std::string_view l1, l2;
+            if (!in.line(l1) || !in.line(l2))
+                return size;
+            if (!l2.empty() && l2[0] == '+')
+                return (size_t)o0;
+            in.seek(o1); // not a record start: go on with the line after it
         }
-        return size;
     }
 
-    void parse(size_t begin, size_t end, Slab& out) const
+    void parse(RangeLines& in, size_t begin, size_t end, Slab& out) const
     {
-        const char* p = data + begin;
-        const char* e = data + end;
-        const char* file_end = data + size;
         out.ids.reserve((end - begin) / 8);
         out.bases.reserve((end - begin) / 2);
-        auto line = [&](const char*& cur, std::string_view& l) -> bool { // a line inside the FILE (a record may not be cut by `e`)
-            if (cur >= file_end)
-                return false;
-            const char* nl = static_cast<const char*>(std::memchr(cur, '\n', (size_t)(file_end - cur)));
-            const char* le = nl ? nl : file_end;
-            size_t      n  = (size_t)(le - cur);
-            if (n && cur[n - 1] == '\r')
-                --n;
-            l   = std::string_view(cur, n);
-            cur = nl ? nl + 1 : file_end;
-            return true;
-        };
         out.rec_at.reserve((end - begin) / 256);
-        while (p < e)
+        in.seek(begin);
+        while (in.tell() < end)
         {
-            const char*      rec = p;
-            out.rec_at.push_back((uint64_t)(rec - data));
+            const uint64_t rec = in.tell();
+            out.rec_at.push_back(rec);
             std::string_view id, seq, plus, qual;
-            const char*      cur = p;
-            if (!line(cur, id) || id.empty() || id[0] != '@' || !line(cur, seq) || !line(cur, plus) || plus.empty() || plus[0] != '+'
-                || !line(cur, qual) || (!seq.empty() && seq[0] == '+'))
+            // (a line view is valid until the next call: id and sequence are stored before the next line is read)
+            bool ok = in.line(id) && !id.empty() && id[0] == '@';
+            if (ok)
             {
-                out.irregular = true; // blank line, wrapped record, truncated tail, ...: the sequential parser decides
-                out.resume_at = (uint64_t)(rec - data);
-                return;
+                out.ids.append(id.data() + 1, id.size() - 1);
+                ok = in.line(seq);
             }
-            if (!all_legal(seq.data(), seq.size()))
+            size_t seq_len = 0;
+            if (ok)
             {
-                try
+                seq_len = seq.size();
+                if (seq_len && seq[0] == '+')
+                    ok = false;
+                else if (!all_legal(seq.data(), seq_len))
                 {
-                    bad_letter(seq);
+                    out.ids.resize(out.id_off.back());
+                    try
+                    {
+                        bad_letter(seq);
+                    }
+                    catch (ParseError const& x)
+                    {
+                        out.error = x.what();
+                    }
+                    return;
                 }
-                catch (ParseError const& x)
+                else
                 {
-                    out.error = x.what();
+                    const size_t at = out.bases.size();
+                    out.bases.resize(at + seq_len);
+                    std::memcpy(out.bases.data() + at, seq.data(), seq_len);
                 }
-                return;
             }
-            if (qual.size() != seq.size())
+            if (ok)
+                ok = in.line(plus) && !plus.empty() && plus[0] == '+';
+            if (ok && !in.skip_exact_line(seq_len, qual))
+                ok = false; // shorter / longer / wrapped quality, or the end of the file: the sequential parser decides
+            if (!ok)
             {
-                // (could be a wrapped record whose first quality line is shorter: let the sequential parser look at it)
-                out.irregular = true;
-                out.resume_at = (uint64_t)(rec - data);
+                out.ids.resize(out.id_off.back());
+                out.bases.resize(out.off.back());
+                out.irregular = true; // blank line, wrapped record, truncated tail, ...
+                out.resume_at = rec;
                 return;
             }
-            out.ids.append(id.data() + 1, id.size() - 1);
             out.id_off.push_back(out.ids.size());
-            const size_t at = out.bases.size();
-            out.bases.resize(at + seq.size());
-            std::memcpy(out.bases.data() + at, seq.data(), seq.size());
             out.off.push_back(out.bases.size());
-            p = cur;
         }
-        out.rec_at.push_back((uint64_t)(p - data));
+        out.rec_at.push_back(in.tell());
     }
 
     void work()
     {
+        RangeLines in(fd, size);
         for (;;)
         {
             size_t i;
+            Slab   s;
             {
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return stop || next_to_parse >= n_slabs || next_to_parse < next_to_take + window; });
                 if (stop || next_to_parse >= n_slabs)
                     return;
                 i = next_to_parse++;
-            }
-            Slab s;
-            {
-                std::lock_guard<std::mutex> lk(m);
                 if (!free_slabs.empty())
                 {
                     s = std::move(free_slabs.back());
@@ -625,10 +719,12 @@ struct ParallelFastq::Impl
             s.rec_at.clear();
             s.error.clear();
             s.irregular = false;
-            const size_t b = record_at_or_after(i * slab_bytes);
-            const size_t e = i + 1 == n_slabs ? size : record_at_or_after((i + 1) * slab_bytes);
+            const size_t b = record_at_or_after(in, i * slab_bytes);
+            const size_t e = i + 1 == n_slabs ? size : record_at_or_after(in, (i + 1) * slab_bytes);
             if (b < e)
-                parse(b, e, s);
+                parse(in, b, e, s);
+            else
+                s.rec_at.assign(1, b);
             std::lock_guard<std::mutex> lk(m);
             ready.emplace(i, std::move(s));
             cv.notify_all();
@@ -653,15 +749,7 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
         ::close(fd);
         return nullptr;
     }
-    void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    if (map == MAP_FAILED)
-    {
-        ::close(fd);
-        return nullptr;
-    }
-    madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
     Impl* im       = new Impl;
-    im->data       = static_cast<const char*>(map);
     im->size       = (size_t)st.st_size;
     im->fd         = fd;
     im->slab_bytes = std::max<size_t>(slab_bytes, 1 << 16);
@@ -683,7 +771,6 @@ ParallelFastq::~ParallelFastq()
     }
     for (auto& t : s.workers)
         t.join();
-    munmap(const_cast<char*>(s.data), s.size);
     ::close(s.fd);
 }
 
