@@ -303,18 +303,22 @@ __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams
             return dws[qc];
         };
 
-        uint64_t f = 0, rc = 0;
+        // f = forward hash; rcx = reverse-complement hash XOR (4^k - 1): complementing turns the digit (3 - b) that enters
+        // at the top into b itself, so both updates are shift + or, and the complement is folded into the seed once
+        uint64_t       f = 0, rcx = mask;
+        const uint64_t seed_rc = seed ^ mask;
+        const uint32_t top     = 2 * (k - 1);
         auto roll = [&](uint32_t c) -> uint64_t { // append base c, return the canonical value of the k-mer ending here
             // dna4 rank of any byte without a table and without a branch: letters (either case) index two 32-bit masks
             // with c & 31 -- low rank bit set for C Y S B T U, high rank bit for G K T U; every other byte is rank 0
             // (seqan3::dna4 char_to_rank; the same values as GN_LPR_RANK_LUT)
-            const uint32_t idx    = c & 31u;
-            uint32_t       b32    = ((0x0238000Cu >> idx) & 1u) | (((0x00300880u >> idx) & 1u) << 1);
-            b32                   = (c & 0xC0u) == 0x40u ? b32 : 0u;
-            const uint64_t b      = b32;
-            f                = ((f << 2) | b) & mask;
-            rc               = (rc >> 2) | ((3ULL - b) << (2 * (k - 1)));
-            const uint64_t x = f ^ seed, y = rc ^ seed;
+            const uint32_t idx = c & 31u;
+            uint32_t       b32 = ((0x0238000Cu >> idx) & 1u) | (((0x00300880u >> idx) & 1u) << 1);
+            b32                = (c & 0xC0u) == 0x40u ? b32 : 0u;
+            const uint64_t b   = b32;
+            f                  = ((f << 2) | b) & mask;
+            rcx                = (rcx >> 2) | (b << top);
+            const uint64_t x = f ^ seed, y = rcx ^ seed_rc;
             return x < y ? x : y;
         };
         // warm-up: the first k-1 bases complete no k-mer (one aligned dword per four bases)
