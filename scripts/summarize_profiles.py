@@ -112,4 +112,11 @@ if p_w:
     out["WRITE_SIZE_KB_per_step"] = w_raw
 with open(os.path.join(dst, f"pmc_fetch_{wl}.json"), "w") as f:
     json.dump(out, f, indent=1)
+# the bench line of this round was taken BEFORE the counter passes: stamp the traffic of the same round into its copy so
+# that profiles/<tag>_bench_<workload>.json and pmc_fetch_<workload>.json agree
+if "hbm_bytes_per_launch" in out:
+    bench["roofline"]["traffic"] = out["hbm_bytes_per_launch"]
+    bench["roofline"]["traffic_source"] = out.get("source")
+    with open(os.path.join(dst, f"{tag}_bench_{wl}.json"), "w") as f:
+        json.dump(bench, f, indent=1)
 print(json.dumps(out, indent=1))
