@@ -69,3 +69,64 @@ def test_split_bins_one_million_reads(monkeypatch):
         assert got == exp, (r, got, exp)
     st.destroy()
     flt.free()
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_hibf_randomised_layouts(seed, monkeypatch):
+    # random raptor-style layouts (1-3 levels, 64..640 technical bins per IBF, 1-5 hash functions, split user bins, mixed
+    # lane widths inside one level), random cutoffs, reads of 40..2500 bp, pairs: the three HIBF kernel paths agree with
+    # each other and with the oracle's counting_agent_type::bulk_count
+    import ganon_amd as hip
+    import ganon_fixtures as gf
+    import gpu_util as gu
+    rng = np.random.default_rng(seed)
+    for cfg in range(8):
+        n_ub = int(rng.integers(30, 2500))
+        tmax = int(rng.choice([64, 64, 128, 192, 256, 640]))
+        depth = int(rng.integers(1, 4))
+        h = int(rng.integers(1, 6))
+        cutoff = float(rng.choice([0.0, 0.1, 0.25, 0.5, 0.75, 1.0]))
+        k = int(rng.choice([19, 21, 15]))
+        w = k + int(rng.integers(0, 14))
+        genomes = {ub: gu.random_seq(rng, 2600) for ub in range(0, n_ub, max(1, n_ub // 60))}
+        uh = {ub: np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)) for ub, g in genomes.items()}
+        hb = gf.random_hibf(n_ub, tmax, depth, seed=seed * 100 + cfg, density=float(rng.uniform(0.1, 0.45)), hash_funs=h, user_hashes=uh)
+        flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+        keys = sorted(genomes)
+        s1, s2 = [], []
+        for i in range(300):
+            L = int(rng.choice([40, 100, 150, 150, 250, 900, 2500]))
+            g = genomes[keys[i % len(keys)]]
+            p = int(rng.integers(0, max(1, len(g) - L)))
+            a = bytearray(g[p:p + L]) if i % 3 else bytearray(gu.random_seq(rng, L))
+            for _ in range(int(rng.integers(0, 6))):
+                a[int(rng.integers(0, len(a)))] = b"ACGTN"[int(rng.integers(0, 5))]
+            s1.append(bytes(a))
+            s2.append(g[max(0, p - 50):max(0, p - 50) + 150])
+        paired = bool(cfg % 2)
+        bases, off1, off2 = gu.pack_reads(s1, s2 if paired else None)
+        outs = []
+        for sw in (None, "GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG"):
+            if sw:
+                monkeypatch.setenv(sw, "1")
+            st = hip.HipStream(flt, len(s1), max(bases.size, 1))
+            st.submit(bases, off1, off2, k, w, cutoff)
+            nh, status, mo, m = st.fetch()
+            ho, hs = st.fetch_hashes()
+            outs.append((mo.copy(), m.copy(), st.timings()["algo_bytes"]))
+            st.destroy()
+            if sw:
+                monkeypatch.delenv(sw)
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) and outs[0][2] == o[2], (seed, cfg)
+        mo, m, _ = outs[0]
+        for i in range(0, len(s1), 3):
+            hh = hs[int(ho[i]):int(ho[i + 1])]
+            if status[i] != 0:
+                continue
+            thr = oracle.threshold_cutoff(len(hh), cutoff)
+            ec = hb.bulk_count(hh, thr)
+            exp = [(int(u), int(min(c, len(hh)))) for u, c in enumerate(ec) if c > 0]
+            got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+            assert got == exp, (seed, cfg, i, got[:4], exp[:4])
+        flt.free()
