@@ -19,7 +19,7 @@ HOST = os.path.join(HERE, "host")
 LIB = os.path.join(CSRC, "libganon_hip.so")
 BIN = os.path.join(HOST, "ganon-classify")
 
-HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_capi.hip"]
+HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_capi.hip"]
 HIP_HEADERS = ["gn_internal.h", os.path.join(ROOT, "include", "ganon_hip.h")]
 
 

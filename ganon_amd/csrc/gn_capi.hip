@@ -672,7 +672,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
 {
     if (!s)
         return GN_OK;
-    hipSetDevice(s->f->device);
+    hipSetDevice(s->device); // (not s->f->device: a caller may have freed the filter first)
     if (s->st)
         hipStreamSynchronize(s->st);
     void* ptrs[] = { s->d_bases,  s->d_off1,    s->d_off2,      s->d_slot_cnt,  s->d_slot_off, s->d_hashes, s->d_nh,
@@ -682,6 +682,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
     for (void* p : ptrs)
         if (p)
             hipFree(p);
+    gn_postfilter_release(s);
     if (s->h_ctr)
         hipHostFree(s->h_ctr);
     if (s->h_hctr)
@@ -717,6 +718,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
     if (!s)
         return gn_fail(GN_ENOMEM, "out of host memory");
     s->f         = f;
+    s->device    = f->device;
     s->max_reads = max_reads;
     s->max_bases = max_bases;
     s->match_cap = max_matches ? max_matches : (uint64_t)max_reads * 4;
@@ -826,33 +828,111 @@ __global__ void gn_slot_count_kernel(const uint64_t* off1, const uint64_t* off2,
     cnt[r] = c;
 }
 
+// Group the matches by read: read r's segments (one per column slice, written by the count kernels into wave-private
+// chunks of d_matches) are copied behind each other to out[seg_off[r*wpr] ...), ascending target inside a read.
+//   * reads with at most GN_GATHER_SMALL matches (the usual case: 0-2 per read) are handled one per lane, with an
+//     insertion sort by target (the candidate-driven select emits a slice's few hits in no particular order);
+//   * reads with more (low cutoffs: ~100 chance matches per read at --rel-cutoff 0.2 on a 4096-bin filter) are handled
+//     by the whole wave one after the other: coalesced 12-byte copies, with an order check on the way; the count kernels
+//     emit ascending targets, so the rank sort behind the check is a rarely taken fallback (O(c^2/64)).
+#define GN_GATHER_SMALL 6u
 __global__ void gn_gather_kernel(const gn_match* __restrict__ in, gn_match* __restrict__ out, const uint64_t* __restrict__ seg_begin,
                                  const uint32_t* __restrict__ seg_count, const uint64_t* __restrict__ seg_off, uint64_t n_reads,
                                  uint32_t wpr, const unsigned long long* __restrict__ cursor, uint64_t cap)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads || *cursor > cap) // overflowed batch: nothing was written, gn_finish() grows the buffers and re-runs
+    if (*cursor > cap) // overflowed batch: nothing was written, gn_finish() grows the buffers and re-runs
         return;
-    // One thread per read: the segments of its column slices are copied behind each other with an insertion sort by
-    // target.  The kernels emit nearly sorted data (ascending column chunks / target ranges; the candidate-driven
-    // select emits a slice's few hits in no particular order), so an element moves left by a few places at most.
-    const uint64_t o = seg_off[r * wpr];
-    uint32_t       k_total = 0;
-    for (uint32_t sl = 0; sl < wpr; ++sl)
+    const uint64_t r     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane  = threadIdx.x & 63u;
+    const bool     valid = r < n_reads;
+    uint64_t       o     = 0;
+    uint32_t       c     = 0;
+    if (valid)
     {
-        const uint32_t c = seg_count[r * wpr + sl];
-        const uint64_t b = seg_begin[r * wpr + sl];
-        for (uint32_t j = 0; j < c; ++j)
+        o = seg_off[r * wpr];
+        c = (uint32_t)(seg_off[(r + 1) * wpr] - o);
+    }
+    if (valid && c != 0 && c <= GN_GATHER_SMALL)
+    {
+        uint32_t k_total = 0;
+        for (uint32_t sl = 0; sl < wpr; ++sl)
         {
-            const gn_match m = in[b + j];
-            uint32_t       k = k_total;
-            while (k > 0 && out[o + k - 1].target > m.target)
+            const uint32_t cs = seg_count[r * wpr + sl];
+            const uint64_t b  = seg_begin[r * wpr + sl];
+            for (uint32_t j = 0; j < cs; ++j)
             {
-                out[o + k] = out[o + k - 1];
-                --k;
+                const gn_match m = in[b + j];
+                uint32_t       k = k_total;
+                while (k > 0 && out[o + k - 1].target > m.target)
+                {
+                    out[o + k] = out[o + k - 1];
+                    --k;
+                }
+                out[o + k] = m;
+                ++k_total;
             }
-            out[o + k] = m;
-            ++k_total;
+        }
+    }
+    uint64_t heavy = __ballot(valid && c > GN_GATHER_SMALL);
+    while (heavy)
+    {
+        const uint32_t L = (uint32_t)__builtin_ctzll(heavy);
+        heavy &= heavy - 1;
+        const uint64_t rr = r - lane + L;
+        const uint64_t oo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), (int)L) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o, (int)L);
+        uint32_t done = 0, prev_last = 0;
+        bool     have_prev = false, disorder = false;
+        for (uint32_t sl = 0; sl < wpr; ++sl)
+        {
+            const uint32_t cs = seg_count[rr * wpr + sl];
+            const uint64_t b  = seg_begin[rr * wpr + sl];
+            for (uint32_t j0 = 0; j0 < cs; j0 += 64)
+            {
+                const uint32_t j   = j0 + lane;
+                const bool     act = j < cs;
+                gn_match       m{};
+                if (act)
+                    m = in[b + j];
+                const uint32_t t  = act ? m.target : 0xFFFFFFFFu;
+                uint32_t       tp = (uint32_t)__shfl_up((int)t, 1);
+                if (lane == 0)
+                    tp = have_prev ? prev_last : 0u;
+                disorder = disorder || __ballot(act && tp > t) != 0;
+                if (act)
+                    out[oo + done + j] = m;
+                const uint32_t nact = cs - j0 < 64u ? cs - j0 : 64u;
+                prev_last = (uint32_t)__builtin_amdgcn_readlane((int)t, (int)(nact - 1));
+                have_prev = true;
+            }
+            done += cs;
+        }
+        if (disorder)
+        {
+            // rank of every element among the read's matches (a target occurs once per read), straight from `in`
+            for (uint32_t sl = 0; sl < wpr; ++sl)
+            {
+                const uint32_t cs = seg_count[rr * wpr + sl];
+                const uint64_t b  = seg_begin[rr * wpr + sl];
+                for (uint32_t j0 = 0; j0 < cs; j0 += 64)
+                {
+                    const uint32_t j   = j0 + lane;
+                    const bool     act = j < cs;
+                    gn_match       m{};
+                    if (act)
+                        m = in[b + j];
+                    uint32_t rank = 0;
+                    for (uint32_t s2 = 0; s2 < wpr; ++s2)
+                    {
+                        const uint32_t c2 = seg_count[rr * wpr + s2];
+                        const uint64_t b2 = seg_begin[rr * wpr + s2];
+                        for (uint32_t e = 0; e < c2; ++e)
+                            rank += in[b2 + e].target < m.target ? 1u : 0u;
+                    }
+                    if (act)
+                        out[oo + rank] = m;
+                }
+            }
         }
     }
 }
@@ -1106,6 +1186,9 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     rc = gn_run_group(s);
     if (rc)
         return rc;
+    rc = gn_run_postfilter(s);
+    if (rc)
+        return rc;
     GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
     GN_HIP(hipEventRecord(s->ev[3], s->st));
     s->n_chunks   = nc;
@@ -1140,6 +1223,11 @@ static int gn_finish(gn_stream* s)
         if (need <= s->match_cap)
         {
             s->n_matches = s->h_ctr[6]; // exact (the cursor `need` counts allocated space including chunk holes)
+            if (s->pf_on) // the batch's result is what the device-side filter_matches pre-pass left
+            {
+                GN_HIP(hipMemcpy(s->h_pf_ctr, s->d_pf_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                s->n_matches = s->h_pf_ctr[2];
+            }
             return GN_OK;
         }
         const uint64_t ncap = need + need / 8 + 1024;
@@ -1153,6 +1241,9 @@ static int gn_finish(gn_stream* s)
         if (rc)
             return rc;
         rc = gn_run_group(s);
+        if (rc)
+            return rc;
+        rc = gn_run_postfilter(s);
         if (rc)
             return rc;
         GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
@@ -1196,7 +1287,9 @@ extern "C" int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status,
     if (match_off)
     {
         const uint32_t wpr = s->f->is_hibf ? 1 : s->f->geom.wpr;
-        if (wpr == 1)
+        if (s->pf_on)
+            GN_HIP(hipMemcpyAsync(match_off, s->d_slot_cnt, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s->st));
+        else if (wpr == 1)
             GN_HIP(hipMemcpyAsync(match_off, s->d_seg_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s->st));
         else
         {
@@ -1215,9 +1308,28 @@ extern "C" int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status,
                            (unsigned long long)cap);
         }
         if (s->n_matches)
-            GN_HIP(hipMemcpyAsync(matches, s->d_sorted, s->n_matches * sizeof(gn_match), hipMemcpyDeviceToHost, s->st));
+            GN_HIP(hipMemcpyAsync(matches, s->pf_on ? s->d_matches : s->d_sorted, s->n_matches * sizeof(gn_match), hipMemcpyDeviceToHost,
+                                  s->st));
     }
     GN_HIP(hipStreamSynchronize(s->st));
+    return GN_OK;
+}
+
+extern "C" int gn_fetch_postfilter(gn_stream* s, uint32_t* max_count, uint64_t* dropped_rel_filter, uint64_t* dropped_fpr_query)
+{
+    if (!s)
+        return gn_fail(GN_EINVAL, "null stream");
+    if (!s->pf_on)
+        return gn_fail(GN_EINVAL, "no post-filter set on this stream");
+    int rc = gn_finish(s);
+    if (rc)
+        return rc;
+    if (max_count && s->n_reads)
+        GN_HIP(hipMemcpy(max_count, s->d_pf_max, (size_t)s->n_reads * 4, hipMemcpyDeviceToHost));
+    if (dropped_rel_filter)
+        *dropped_rel_filter = s->h_pf_ctr[0];
+    if (dropped_fpr_query)
+        *dropped_fpr_query = s->h_pf_ctr[1];
     return GN_OK;
 }
 
@@ -1228,7 +1340,7 @@ extern "C" int gn_stream_device_matches(gn_stream* s, const gn_match** d_matches
     int rc = gn_finish(s);
     if (rc)
         return rc;
-    *d_matches = s->d_sorted;
+    *d_matches = s->pf_on ? s->d_matches : s->d_sorted;
     *n_matches = s->n_matches;
     return GN_OK;
 }

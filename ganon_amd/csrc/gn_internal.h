@@ -141,6 +141,8 @@ struct GnHibfIbfDev
 };
 
 // ---- misc kernels ---------------------------------------------------------------------------
+int  gn_run_postfilter(gn_stream* s);     // gn_postfilter.hip
+void gn_postfilter_release(gn_stream* s);
 hipError_t gn_launch_emplace(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h, const uint64_t* hashes,
                              const uint32_t* bins, uint64_t n, hipStream_t st);
 
@@ -198,6 +200,7 @@ struct gn_filter
 struct gn_stream
 {
     gn_filter*  f  = nullptr;
+    int         device = 0;     // f->device, kept here so that destroying a stream never touches the filter
     hipStream_t st = nullptr;   // main stream: uploads, count/select, grouping, downloads
     hipStream_t st2 = nullptr;  // side stream: slot scan + minimiser kernels, one chunk ahead of the main stream
     hipEvent_t  ev[4]{};        // [0] batch start (side) [1] last minimiser end (side) [2] last count end [3] batch end
@@ -238,6 +241,16 @@ struct gn_stream
     void*         d_sort_tmp = nullptr;
     size_t        sort_tmp_bytes = 0;
     uint64_t      hibf_cap = 0;
+    // device-side pre-pass of filter_matches (gn_postfilter.hip); off unless gn_stream_set_postfilter enabled it
+    bool                pf_on = false;
+    double              pf_rel_filter = 0, pf_fpr_query = 1;
+    uint32_t*           d_pf_keep = nullptr; // survivors per read
+    uint32_t*           d_pf_max  = nullptr; // max count per read before filtering
+    double*             d_pf_fpr  = nullptr; // per target
+    unsigned long long* d_pf_ctr  = nullptr; // [0] dropped rel_filter [1] dropped fpr_query [2] survivors
+    unsigned long long* h_pf_ctr  = nullptr; // pinned copy
+    void*               d_pf_scan = nullptr;
+    size_t              pf_scan_bytes = 0;
     // pinned host
     unsigned long long* h_ctr = nullptr;
     // state

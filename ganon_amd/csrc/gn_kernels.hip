@@ -1449,29 +1449,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     unsigned long long base = 0;
     if (hm)
     {
-        // matches of this lane (counts are capped at n by construction: a bin is hit at most once per hash)
+        // matches of this lane (counts are capped at n by construction: a bin is hit at most once per hash) as one bit
+        // per bin: byte y of byt[d][j][pp] is bin 8y + 4pp + j of dword d, so its flag bits 7/15/23/31 shift into place
+        uint32_t hit[ND];
         uint32_t mine = 0;
-        if (owner && any)
-        {
 #pragma unroll
-            for (int d = 0; d < ND; ++d)
+        for (int d = 0; d < ND; ++d)
+        {
+            hit[d] = 0;
+            if (owner && any)
+            {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int pp = 0; pp < 2; ++pp)
-                        mine += __popc((byt[d][j][pp] + Kc) & 0x80808080u);
+                        hit[d] |= ((((byt[d][j][pp] + Kc) & 0x80808080u) >> 7) << (4 * pp + j));
+            }
+            mine += __popc(hit[d]);
         }
-        // exclusive prefix over the few lanes that have matches (scalar loop over the ballot)
+        // exclusive prefix over the lanes that have matches: a scalar loop over the ballot while they are few (high
+        // cutoffs: one or two lanes), a shuffle scan otherwise (low cutoffs: chance matches in most lanes)
         uint32_t my_off = 0;
-        uint64_t rem    = hm;
-        while (rem)
+        if (__popcll(hm) <= 6)
         {
-            const uint32_t L = (uint32_t)__builtin_ctzll(rem);
-            rem &= rem - 1;
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)L);
-            if ((uint32_t)lane == L)
-                my_off = total;
-            total += c;
+            uint64_t rem = hm;
+            while (rem)
+            {
+                const uint32_t L = (uint32_t)__builtin_ctzll(rem);
+                rem &= rem - 1;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)L);
+                if ((uint32_t)lane == L)
+                    my_off = total;
+                total += c;
+            }
+        }
+        else
+        {
+            uint32_t x = mine;
+#pragma unroll
+            for (int off = 1; off < GN_WAVE; off <<= 1)
+            {
+                const uint32_t y = (uint32_t)__shfl_up((int)x, off);
+                if (lane >= off)
+                    x += y;
+            }
+            my_off = x - mine;
+            total  = (uint32_t)__builtin_amdgcn_readlane((int)x, GN_WAVE - 1);
         }
         // padding bins (>= B) of the last word never count: real filters keep them zero; be exact anyway
         // Output space comes from a wave-private chunk: one returning atomic on the global cursor per
@@ -1491,10 +1514,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         chunk_left -= total;
         if (base + total <= p.match_cap && owner && any)
         {
+            // every match goes to its rank among the lane's hit bits, so a read's segment leaves in ascending target
+            // order (the gather pass then only copies)
             gn_match* out = p.matches + base + my_off;
-            uint32_t  k   = 0;
+            uint32_t  before = 0; // hits in the lane's lower dwords
 #pragma unroll
             for (int d = 0; d < ND; ++d)
+            {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1505,13 +1531,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                         {
                             const uint32_t y = (uint32_t)__builtin_ctz(hbits) >> 3;
                             hbits &= hbits - 1;
+                            const uint32_t bitpos = 8 * y + 4 * pp + j; // bit t = 4*(2y+pp) + j of dword d
                             gn_match mt;
                             mt.read   = read;
-                            mt.target = wi * 64 + 32 * d + 8 * y + 4 * pp + j; // bit t = 4*(2y+pp) + j of dword d
+                            mt.target = wi * 64 + 32 * d + bitpos;
                             mt.count  = (byt[d][j][pp] >> (8 * y)) & 0xFFu;
-                            out[k++]  = mt;
+                            out[before + __popc(hit[d] & ((1u << bitpos) - 1u))] = mt;
                         }
                     }
+                before += __popc(hit[d]);
+            }
         }
     }
     if (lane == 0)

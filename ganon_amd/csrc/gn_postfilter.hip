@@ -1,0 +1,313 @@
+// gn_postfilter.hip -- device-side pre-pass of filter_matches (/root/reference/src/ganon-classify/GanonClassify.cpp:579-613
+// with the threshold of :755-761), run on the matches of a batch after they were grouped by read.
+//
+// Why it exists: at the binary's default thresholds (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5) a read has ~100
+// chance matches on a 4096-bin filter (T = 4 of ~18 minimisers), and nearly all of them die in filter_matches.  Shipping
+// them over PCIe and walking them on one host thread made the end-to-end rate 2 Mreads/s; dropping them here, in HBM,
+// leaves the host the survivors only.
+//
+// What it computes, per read with matches (count_i, target_i), n = number of minimisers:
+//   max = max_i count_i, min = min(n, min_i count_i)                         (:704 and select_matches' tracking)
+//   threshold_filter = max - ceil((max - min) * rel_filter)                   (:757-758; IEEE double multiply + ceil)
+//   count_i < threshold_filter                      -> dropped (--rel-filter), counted
+//   fpr_query < 1 and q_i SURELY > fpr_query        -> dropped (--fpr-query), counted
+//   everything else                                 -> kept, original order
+// The --rel-filter rule is exact integer/double arithmetic and is applied completely.  The --fpr-query rule
+// (q = 1 - sum_{i<=count} C(n,i) p^i (1-p)^(n-i), libm lgamma/exp/pow on the host) is applied CONSERVATIVELY: the device
+// evaluates q with a multiplicative recurrence and drops a match only if q > fpr_query*1.001 + 1e-9, a margin far above
+// both evaluations' error (<= ~1e-11 for n <= 4096, the only range the device decides; longer reads, degenerate p and
+// underflowing terms are left alone).  The host applies the reference's own expression to every survivor, so the final
+// result is the one the reference computes; the device only removes matches whose fate is not in doubt.
+//
+// Valid only where one filter (one gn_filter) sees all matches of a read: a hierarchy level with several filters merges
+// their matches before thresholding (:716-735), and a filter cut into column parts spreads a read over several streams;
+// the host enables this pass only otherwise (backend_hip.cpp).
+#include "gn_internal.h"
+#include <hipcub/hipcub.hpp>
+
+#define GN_PF_SMALL 6u
+
+struct GnPostfilterParams
+{
+    gn_match*           m;          // grouped matches, filtered in place (survivors move to the front of the read's range)
+    const uint64_t*     off;        // read r owns [off[r*stride], off[(r+1)*stride])
+    uint32_t            stride;
+    uint32_t            n_reads;
+    const uint32_t*     nh;         // minimisers per read
+    double              rel_filter;
+    double              fpr_query;  // >= 1: rule off
+    const double*       tfpr;       // per target
+    uint32_t*           keep;       // [n_reads+1] survivors per read (keep[n_reads] = 0)
+    uint32_t*           maxc;       // [n_reads] max count before filtering (0 = no match)
+    unsigned long long* ctr;        // [0] dropped by rel_filter [1] dropped by fpr_query
+    const unsigned long long* cursor; // match cursor and capacity: an overflowed batch holds no matches yet (gn_finish re-runs)
+    uint64_t            cap;
+    uint64_t            n_targets;
+};
+
+__device__ __forceinline__ bool gn_fpr_surely_above(uint32_t n, uint32_t count, double p, double fq)
+{
+    if (!(p > 0.0) || !(p < 1.0) || n > 4096u || count > 1024u)
+        return false; // the host decides
+    double term = exp((double)n * log1p(-p)); // i = 0
+    if (!(term > 1e-200))
+        return false;
+    const double ratio = p / (1.0 - p);
+    double       sum   = term;
+    for (uint32_t i = 1; i <= count; ++i)
+    {
+        term *= (double)(n - i + 1) / (double)i * ratio;
+        sum += term;
+    }
+    return 1.0 - sum > fq * 1.001 + 1e-9;
+}
+
+__device__ __forceinline__ uint32_t gn_pf_threshold(uint32_t mx, uint32_t mn, double rel_filter)
+{
+    // size_t threshold_filter = max - size_t(std::ceil((max - min) * rel_filter))
+    return mx - (uint32_t)(unsigned long long)ceil(__dmul_rn((double)(mx - mn), rel_filter));
+}
+
+__global__ void gn_postfilter_kernel(GnPostfilterParams p)
+{
+    if (*p.cursor > p.cap)
+        return;
+    const uint64_t r     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane  = threadIdx.x & 63u;
+    const bool     valid = r < p.n_reads;
+    const bool     fpr_on = p.fpr_query < 1.0;
+    uint64_t       o = 0;
+    uint32_t       c = 0, n = 0;
+    uint32_t       n_fil = 0, n_fpr = 0;
+    if (valid)
+    {
+        o = p.off[r * p.stride];
+        c = (uint32_t)(p.off[(r + 1) * p.stride] - o);
+        n = p.nh[r];
+    }
+    if (valid && c <= GN_PF_SMALL)
+    {
+        uint32_t mx = 0, mn = n;
+        for (uint32_t j = 0; j < c; ++j)
+        {
+            const uint32_t ct = p.m[o + j].count;
+            mx = ct > mx ? ct : mx;
+            mn = ct < mn ? ct : mn;
+        }
+        uint32_t kept = 0;
+        if (c)
+        {
+            const uint32_t thr = gn_pf_threshold(mx, mn, p.rel_filter);
+            for (uint32_t j = 0; j < c; ++j)
+            {
+                const gn_match m = p.m[o + j];
+                if (m.count < thr)
+                    ++n_fil;
+                else if (fpr_on && gn_fpr_surely_above(n, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query))
+                    ++n_fpr;
+                else
+                    p.m[o + kept++] = m;
+            }
+        }
+        p.keep[r] = kept;
+        p.maxc[r] = mx;
+    }
+    if (r == p.n_reads)
+        p.keep[r] = 0;
+    uint64_t heavy = __ballot(valid && c > GN_PF_SMALL);
+    while (heavy)
+    {
+        const uint32_t L = (uint32_t)__builtin_ctzll(heavy);
+        heavy &= heavy - 1;
+        const uint64_t rr = r - lane + L;
+        const uint64_t oo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), (int)L) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o, (int)L);
+        const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)L);
+        const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)L);
+        uint32_t mx = 0, mn = nn;
+        for (uint32_t j = lane; j < cc; j += 64)
+        {
+            const uint32_t ct = p.m[oo + j].count;
+            mx = ct > mx ? ct : mx;
+            mn = ct < mn ? ct : mn;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+        {
+            const uint32_t a = (uint32_t)__shfl_xor((int)mx, off), b = (uint32_t)__shfl_xor((int)mn, off);
+            mx = a > mx ? a : mx;
+            mn = b < mn ? b : mn;
+        }
+        const uint32_t thr  = gn_pf_threshold(mx, mn, p.rel_filter);
+        uint32_t       kept = 0;
+        for (uint32_t j0 = 0; j0 < cc; j0 += 64)
+        {
+            const uint32_t j   = j0 + lane;
+            const bool     act = j < cc;
+            gn_match       m{};
+            if (act)
+                m = p.m[oo + j];
+            bool k = false;
+            if (act)
+            {
+                if (m.count < thr)
+                    ++n_fil;
+                else if (fpr_on && gn_fpr_surely_above(nn, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query))
+                    ++n_fpr;
+                else
+                    k = true;
+            }
+            const uint64_t km = __ballot(k);
+            if (k) // all loads of this chunk are done (the store data depends on them) and kept <= j0: in place is safe
+                p.m[oo + kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = m;
+            kept += (uint32_t)__popcll(km);
+        }
+        if (lane == 0)
+        {
+            p.keep[rr] = kept;
+            p.maxc[rr] = mx;
+        }
+    }
+    // batch totals: one atomic per wave and counter
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        n_fil += (uint32_t)__shfl_xor((int)n_fil, off);
+        n_fpr += (uint32_t)__shfl_xor((int)n_fpr, off);
+    }
+    if (lane == 0)
+    {
+        if (n_fil)
+            atomicAdd(&p.ctr[0], (unsigned long long)n_fil);
+        if (n_fpr)
+            atomicAdd(&p.ctr[1], (unsigned long long)n_fpr);
+    }
+}
+
+// survivors of read r: in[off[r*stride] + i], i < keep[r]  ->  out[new_off[r] + i]
+__global__ void gn_postfilter_compact_kernel(const gn_match* __restrict__ in, gn_match* __restrict__ out, const uint64_t* __restrict__ off,
+                                             uint32_t stride, const uint32_t* __restrict__ keep, const uint64_t* __restrict__ new_off,
+                                             uint32_t n_reads, const unsigned long long* __restrict__ cursor, uint64_t cap)
+{
+    if (*cursor > cap)
+        return;
+    const uint64_t r     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane  = threadIdx.x & 63u;
+    const bool     valid = r < n_reads;
+    uint64_t       o = 0, no = 0;
+    uint32_t       c = 0;
+    if (valid)
+    {
+        o  = off[r * stride];
+        no = new_off[r];
+        c  = keep[r];
+    }
+    if (valid && c <= GN_PF_SMALL)
+        for (uint32_t j = 0; j < c; ++j)
+            out[no + j] = in[o + j];
+    uint64_t heavy = __ballot(valid && c > GN_PF_SMALL);
+    while (heavy)
+    {
+        const uint32_t L = (uint32_t)__builtin_ctzll(heavy);
+        heavy &= heavy - 1;
+        const uint64_t oo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o >> 32), (int)L) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o, (int)L);
+        const uint64_t nn = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(no >> 32), (int)L) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)no, (int)L);
+        const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)L);
+        for (uint32_t j = lane; j < cc; j += 64)
+            out[nn + j] = in[oo + j];
+    }
+}
+
+// queued on the stream right after the grouping pass; results: s->d_matches (compacted survivors), s->d_slot_cnt (n+1
+// offsets), s->d_pf_max, s->d_pf_ctr [0] dropped rel_filter [1] dropped fpr_query [2] survivors
+int gn_run_postfilter(gn_stream* s)
+{
+    if (!s->pf_on)
+        return GN_OK;
+    const uint32_t n      = s->n_reads;
+    const uint32_t stride = s->f->is_hibf ? 1u : (uint32_t)s->f->geom.wpr;
+    GN_HIP(hipMemsetAsync(s->d_pf_ctr, 0, 4 * sizeof(unsigned long long), s->st));
+    GnPostfilterParams p{};
+    p.m          = s->d_sorted;
+    p.off        = s->d_seg_off;
+    p.stride     = stride;
+    p.n_reads    = n;
+    p.nh         = s->d_nh;
+    p.rel_filter = s->pf_rel_filter;
+    p.fpr_query  = s->pf_fpr_query;
+    p.tfpr       = s->d_pf_fpr;
+    p.keep       = s->d_pf_keep;
+    p.maxc       = s->d_pf_max;
+    p.ctr        = s->d_pf_ctr;
+    p.cursor     = s->d_ctr;
+    p.cap        = s->match_cap;
+    p.n_targets  = s->f->is_hibf ? s->f->n_user_bins : s->f->n_targets;
+    const unsigned blocks = (unsigned)(((uint64_t)n + 1 + 255) / 256);
+    hipLaunchKernelGGL(gn_postfilter_kernel, dim3(blocks), dim3(256), 0, s->st, p);
+    GN_HIP(hipGetLastError());
+    size_t tmp = s->pf_scan_bytes;
+    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_pf_scan, tmp, s->d_pf_keep, s->d_slot_cnt, (int)(n + 1), s->st));
+    hipLaunchKernelGGL(gn_postfilter_compact_kernel, dim3(blocks), dim3(256), 0, s->st, s->d_sorted, s->d_matches, s->d_seg_off, stride,
+                       s->d_pf_keep, s->d_slot_cnt, n, s->d_ctr, s->match_cap);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipMemcpyAsync(s->d_pf_ctr + 2, s->d_slot_cnt + n, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->st));
+    GN_HIP(hipMemcpyAsync(s->h_pf_ctr, s->d_pf_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
+    return GN_OK;
+}
+
+extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
+{
+    if (!s)
+        return gn_fail(GN_EINVAL, "null stream");
+    if (!pf)
+    {
+        s->pf_on = false;
+        return GN_OK;
+    }
+    if (!(pf->rel_filter >= 0.0 && pf->rel_filter <= 1.0))
+        return gn_fail(GN_EINVAL, "rel_filter must be within [0,1]");
+    if (!(pf->fpr_query >= 0.0))
+        return gn_fail(GN_EINVAL, "fpr_query must not be negative");
+    const uint64_t nt = s->f->is_hibf ? s->f->n_user_bins : s->f->n_targets;
+    if (pf->fpr_query < 1.0 && !pf->target_fpr)
+        return gn_fail(GN_EINVAL, "target_fpr is required when fpr_query < 1");
+    GN_HIP(hipSetDevice(s->f->device));
+    if (!s->d_pf_keep)
+    {
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_keep), ((size_t)s->max_reads + 1) * 4));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_max), ((size_t)s->max_reads + 1) * 4));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_ctr), 4 * sizeof(unsigned long long)));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_fpr), (nt ? nt : 1) * sizeof(double)));
+        GN_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_pf_ctr), 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        size_t tmp = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, s->d_pf_keep, s->d_slot_cnt, (int)(s->max_reads + 1), s->st);
+        GN_HIP(hipMalloc(&s->d_pf_scan, tmp ? tmp : 1));
+        s->pf_scan_bytes = tmp;
+    }
+    GN_HIP(hipStreamSynchronize(s->st)); // (a batch in flight still reads the previous table)
+    if (pf->target_fpr && nt)
+        GN_HIP(hipMemcpy(s->d_pf_fpr, pf->target_fpr, nt * sizeof(double), hipMemcpyHostToDevice));
+    else if (nt)
+        GN_HIP(hipMemset(s->d_pf_fpr, 0, nt * sizeof(double)));
+    s->pf_rel_filter = pf->rel_filter;
+    s->pf_fpr_query  = pf->fpr_query;
+    s->pf_on         = true;
+    return GN_OK;
+}
+
+void gn_postfilter_release(gn_stream* s)
+{
+    void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan };
+    for (void* q : ptrs)
+        if (q)
+            hipFree(q);
+    if (s->h_pf_ctr)
+        hipHostFree(s->h_pf_ctr);
+    s->d_pf_keep = s->d_pf_max = nullptr;
+    s->d_pf_ctr  = nullptr;
+    s->d_pf_fpr  = nullptr;
+    s->d_pf_scan = nullptr;
+    s->h_pf_ctr  = nullptr;
+}

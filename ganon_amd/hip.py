@@ -18,8 +18,13 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_filter_emplace_ibf", "gn_filter_download_rows", "gn_filter_download_row_list", "gn_pinned_alloc",
                "gn_pinned_free", "gn_filter_write_rows", "gn_filter_write_sync", "gn_filter_finalize",
                "gn_filter_fill_random", "gn_filter_info", "gn_filter_free", "gn_stream_create", "gn_stream_destroy",
-               "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch", "gn_stream_device_matches",
+               "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch", "gn_stream_set_postfilter",
+               "gn_fetch_postfilter", "gn_stream_device_matches",
                "gn_stream_fetch_hashes", "gn_stream_dense_counts", "gn_stream_timings"]
+
+
+class PostFilter(C.Structure):  # gn_postfilter
+    _fields_ = [("rel_filter", C.c_double), ("fpr_query", C.c_double), ("target_fpr", C.c_void_p)]
 
 
 class GanonHipError(RuntimeError):
@@ -81,6 +86,8 @@ def load_library():
     L.gn_stream_sync.argtypes = [vp]
     L.gn_fetch_batch.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
     L.gn_stream_device_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.gn_stream_set_postfilter.argtypes = [vp, vp]
+    L.gn_fetch_postfilter.argtypes = [vp, vp, C.POINTER(u64), C.POINTER(u64)]
     L.gn_stream_fetch_hashes.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.gn_stream_dense_counts.argtypes = [vp, u32, u32, vp]
     L.gn_stream_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -267,6 +274,23 @@ class HipStream:
         m = np.zeros(max(int(need.value), 1), dtype=MATCH_DTYPE)
         _check(L.gn_fetch_batch(self._h, None, None, None, _p(m), len(m), C.byref(need)))
         return nh, st, mo, m[: int(need.value)]
+
+    def set_postfilter(self, rel_filter: Optional[float] = None, fpr_query: float = 1.0, target_fpr=None) -> None:
+        """device-side pre-pass of filter_matches on the following batches (gn_stream_set_postfilter); rel_filter=None: off"""
+        L = load_library()
+        if rel_filter is None:
+            _check(L.gn_stream_set_postfilter(self._h, None))
+            return
+        tf = None if target_fpr is None else np.ascontiguousarray(target_fpr, dtype=np.float64)
+        pf = PostFilter(float(rel_filter), float(fpr_query), None if tf is None else tf.ctypes.data_as(C.c_void_p))
+        _check(L.gn_stream_set_postfilter(self._h, C.byref(pf)))
+
+    def fetch_postfilter(self):
+        """-> (max_count u32[n] before filtering, dropped by --rel-filter, dropped by --fpr-query) of the last batch"""
+        mx = np.zeros(self.n_reads, dtype=np.uint32)
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(load_library().gn_fetch_postfilter(self._h, _p(mx), C.byref(a), C.byref(b)))
+        return mx, int(a.value), int(b.value)
 
     def fetch_read_info(self):
         """-> (n_hashes u32[n], status u8[n]) only"""

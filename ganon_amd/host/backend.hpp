@@ -56,6 +56,19 @@ struct BatchResult
     std::vector<uint32_t>     n_hashes; // per read
     std::vector<uint8_t>      status;   // 0 ok, 1 small, 2 big (GN_READ_*)
     std::vector<FilterResult> per_filter;
+    // set when the backend already applied the pre-pass of filter_matches (see Backend::set_postfilter): the matches are
+    // the survivors, max_count is every read's largest match count BEFORE filtering, the two totals are what was dropped
+    bool                  prefiltered = false;
+    std::vector<uint32_t> max_count;
+    uint64_t              dropped_rel_filter = 0, dropped_fpr_query = 0;
+};
+
+// filter_matches parameters of a hierarchy level with ONE filter (GanonClassify.cpp:579-613,755-761)
+struct PostFilterSpec
+{
+    double              rel_filter = 0.0;
+    double              fpr_query  = 1.0;
+    std::vector<double> target_fpr; // per FilterMeta target of that filter
 };
 
 // One device (or the test checker): receives filters, classifies batches.  Not thread-safe; one host thread each.
@@ -67,6 +80,12 @@ public:
     virtual bool classify(const ReadBatch& batch, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff,
                           BatchResult& out, std::string& err) = 0;
     virtual std::string describe() const = 0;
+    // Optional.  Ask for the --rel-filter rule (exactly) and the --fpr-query rule (conservatively: only matches that are
+    // above the limit by a safe margin) to be applied where the matches are produced, so that only survivors travel to the
+    // host, which then applies the exact --fpr-query rule to them.  nullptr switches it off.  Returns whether the backend
+    // will do it for the filters it currently holds (one filter that sees whole reads); BatchResult::prefiltered says
+    // so per batch.  The default does nothing: the host then runs filter_matches on everything.
+    virtual bool set_postfilter(const PostFilterSpec* /*spec*/) { return false; }
 };
 
 // devices: indices, or empty = every visible device ("all").  backend_hip.cpp (or the test checker).

@@ -234,6 +234,9 @@ public:
         out.n_hashes.assign(n, 0);
         out.status.assign(n, 0);
         out.per_filter.resize(filters_.size());
+        out.prefiltered = false;
+        out.max_count.clear();
+        out.dropped_rel_filter = out.dropped_fpr_query = 0;
         // submit to every stream first (asynchronous), then fetch
         const uint64_t nb = std::max<uint64_t>(b.bases.size(), 1);
         for (size_t i = 0; i < filters_.size(); ++i)
@@ -253,6 +256,17 @@ public:
                     }
                     part.stream_reads = cr;
                     part.stream_bases = cb;
+                    part.pf_generation = 0;
+                }
+                if (part.pf_generation != pf_generation_)
+                {
+                    gn_postfilter pf{ pf_spec_.rel_filter, pf_spec_.fpr_query, pf_spec_.target_fpr.data() };
+                    if (gn_stream_set_postfilter(part.s, pf_active_ ? &pf : nullptr) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
+                    part.pf_generation = pf_generation_;
                 }
                 if (gn_submit_batch(part.s, b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr, n, k, w,
                                     rel_cutoff[i])
@@ -272,6 +286,19 @@ public:
             {
                 if (!fetch_part(lf.parts[0], n, out, fr.match_off, fr.matches, err))
                     return false;
+                if (pf_active_)
+                {
+                    out.max_count.assign(n, 0);
+                    uint64_t a = 0, b2 = 0;
+                    if (gn_fetch_postfilter(lf.parts[0].s, out.max_count.data(), &a, &b2) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
+                    out.prefiltered        = true;
+                    out.dropped_rel_filter = a;
+                    out.dropped_fpr_query  = b2;
+                }
                 continue;
             }
             // several column parts: the matches of a read are its parts' matches behind each other (targets ascend with
@@ -307,6 +334,36 @@ public:
         return os.str();
     }
 
+    bool set_postfilter(const PostFilterSpec* spec) override
+    {
+        pf_active_ = false;
+        ++pf_generation_;
+        if (!spec || filters_.size() != 1 || filters_[0].parts.size() != 1)
+            return false;
+        const Part&         part = filters_[0].parts[0];
+        std::vector<double> dev_fpr;
+        if (part.to_target.empty())
+            dev_fpr = spec->target_fpr;
+        else
+        {
+            // device target ids must map one-to-one onto the filter's targets, or a read's matches are not what the host sees
+            std::vector<uint8_t> seen(spec->target_fpr.size(), 0);
+            dev_fpr.resize(part.to_target.size(), 0.0);
+            for (size_t d = 0; d < part.to_target.size(); ++d)
+            {
+                const uint32_t t = part.to_target[d];
+                if (t >= seen.size() || seen[t])
+                    return false;
+                seen[t]    = 1;
+                dev_fpr[d] = spec->target_fpr[t];
+            }
+        }
+        pf_spec_            = *spec;
+        pf_spec_.target_fpr = std::move(dev_fpr);
+        pf_active_          = true;
+        return true;
+    }
+
 private:
     struct Stage
     {
@@ -319,6 +376,7 @@ private:
         gn_stream*            s = nullptr;
         uint32_t              stream_reads = 0;
         uint64_t              stream_bases = 0;
+        uint64_t              pf_generation = 0; // Backend::set_postfilter call this stream was last configured for
         uint64_t              word_lo = 0, words = 0;
         std::vector<uint32_t> to_target; // device target id -> index into FilterMeta::targets (empty: the same)
     };
@@ -380,6 +438,9 @@ private:
     Stage                 stage_[2];
     std::vector<Logical>  filters_;
     std::vector<gn_match> tmp_;
+    PostFilterSpec        pf_spec_;
+    bool                  pf_active_ = false;
+    uint64_t              pf_generation_ = 1;
 };
 
 } // namespace

@@ -742,6 +742,18 @@ static bool ganon_classify(Config config)
         for (auto const& fc : level.filters)
             rel_cutoffs.push_back(fc.rel_cutoff);
 
+        // a level with one filter: the backends drop what filter_matches would drop where the matches are produced
+        {
+            PostFilterSpec spec;
+            spec.rel_filter = level.rel_filter;
+            spec.fpr_query  = level.fpr_query;
+            if (filters.size() == 1)
+                spec.target_fpr = filters[0].target_fpr;
+            const bool want = filters.size() == 1 && !getenv("GANON_HOST_NO_PREFILTER");
+            for (auto& be : backends)
+                be->set_postfilter(want ? &spec : nullptr);
+        }
+
         std::vector<ReadBatch> next_carried;
         classifying.start();
 
@@ -859,10 +871,13 @@ static bool ganon_classify(Config config)
                     }
                 }
 
+                if (res.prefiltered) // `matches` are the survivors of the --rel-filter rule; the read's maximum comes with them
+                    max_count_read = res.max_count[r];
                 bool classified = false;
                 if (max_count_read > 0) // :753-808
                 {
-                    const size_t threshold_filter = max_count_read - ceil_share(max_count_read - min_count_read, level.rel_filter);
+                    const size_t threshold_filter =
+                        res.prefiltered ? 0 : max_count_read - ceil_share(max_count_read - min_count_read, level.rel_filter);
                     // filter_matches (:579-613)
                     size_t       kept = 0;
                     uint32_t     first_kept = 0;
@@ -947,6 +962,8 @@ static bool ganon_classify(Config config)
                     buf_unc += '\n';
                 }
             }
+            total.dropped_by_rel_filter += res.dropped_rel_filter;
+            total.dropped_by_fpr_query += res.dropped_fpr_query;
             if (o_all)
                 o_all->write(buf_all.data(), (std::streamsize)buf_all.size());
             if (o_lca)

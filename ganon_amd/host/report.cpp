@@ -46,6 +46,9 @@ void ReadSetTally::absorb_reads(const ReadSetTally& o)
     reads_classified += o.reads_classified;
     best_match_minimisers += o.best_match_minimisers;
     minimisers_of_classified += o.minimisers_of_classified;
+    // (matches a backend dropped before they reached the host's per-target tallies)
+    dropped_by_rel_filter += o.dropped_by_rel_filter;
+    dropped_by_fpr_query += o.dropped_by_fpr_query;
 }
 
 void ReadSetTally::absorb_targets(const TargetTally& t)

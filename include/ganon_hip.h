@@ -169,6 +169,25 @@ int gn_stream_sync(gn_stream* s);
 int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status, uint64_t* match_off, gn_match* matches,
                    uint64_t cap, uint64_t* n_matches);
 
+/* Optional device-side pre-pass of filter_matches (/root/reference/src/ganon-classify/GanonClassify.cpp:579-613 with the
+ * threshold of :755-761) on every following batch of this stream: with max/min = the read's largest/smallest match count
+ * (min starts at n_hashes, :704), matches below max - ceil((max-min)*rel_filter) are dropped (exact), and, if fpr_query < 1,
+ * matches whose q = 1 - BinomCDF(count; n_hashes, target_fpr[target]) is above fpr_query BY A SAFE MARGIN are dropped too
+ * (q > fpr_query*1.001 + 1e-9; the caller applies the exact rule to what is left, so the final result is the reference's).
+ * gn_fetch_batch / gn_stream_device_matches then return the survivors only.  Use it only where this filter sees all of a
+ * read's matches (one filter per hierarchy level, filter not cut into column parts).  target_fpr: n_targets doubles
+ * (flat IBF) / n_user_bins doubles (HIBF); may be NULL when fpr_query >= 1.  pf == NULL switches the pass off. */
+typedef struct gn_postfilter
+{
+    double        rel_filter;
+    double        fpr_query;
+    const double* target_fpr;
+} gn_postfilter;
+int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf);
+/* after a batch with the pass on: per read the largest match count BEFORE filtering (0 = the read had no match; the
+ * reference's max_count_read, :753,776,806), and how many matches each rule dropped in this batch */
+int gn_fetch_postfilter(gn_stream* s, uint32_t* max_count, uint64_t* dropped_rel_filter, uint64_t* dropped_fpr_query);
+
 /* Device-resident view of the same result for callers that forward it without a host round trip (the sparse-match
  * exchange of a bin-range partitioned filter sends it over RCCL straight from HBM): waits for the batch,
  * then *d_matches points to n_matches records in DEVICE memory, grouped by read (ascending read, then target).

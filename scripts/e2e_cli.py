@@ -21,14 +21,21 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
 rows = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 21)
 d = sys.argv[3] if len(sys.argv) > 3 else "/dev/shm"
 bins = 4096
-out = {"reads": n, "filter_gib": rows * 512 / 2**30}
+# classification thresholds: E2E_ARGS="" runs the binary's own defaults (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5)
+EXTRA = os.environ.get("E2E_ARGS", "--rel-cutoff 0.75").split()
+out = {"reads": n, "filter_gib": rows * 512 / 2**30, "args": " ".join(EXTRA)}
 
 wl = bw.make_device_flat_workload("e2e", bins, rows, 4, n, seed=42)
 flt, _ = bw.device_filter(ganon_amd, wl)
 ibf = os.path.join(d, "ganon_e2e.ibf")
-cfg = dict(n_bins=bins, max_hashes_bin=500, hash_functions=4, kmer_size=wl.k, window_size=wl.w, bin_size_bits=rows, max_fp=0.05,
-           true_max_fp=0.05, true_avg_fp=0.05)
-ibf_file.save_ibf(ibf, flt, cfg, [(f"T{b}", 400) for b in range(bins)], [(b, f"T{b}") for b in range(bins)], bins, rows, 4)
+# the filter's rows are Bernoulli(0.5) bits, i.e. every bin is a Bloom filter at its optimal load for h = 4: per-hash false
+# positive rate 0.5^4 = 0.0625 (a database built with --max-fp 0.0625; ganon-build's default is 0.05).  The header
+# declares the number of minimisers per bin that gives exactly that rate (n = S ln2 / h), so that classify's per-target
+# fpr (GanonClassify.cpp:940-947,968-982) -- what --fpr-query works with -- describes the bits that are really there.
+per_bin = int(rows * 0.6931471805599453 / 4)
+cfg = dict(n_bins=bins, max_hashes_bin=per_bin, hash_functions=4, kmer_size=wl.k, window_size=wl.w, bin_size_bits=rows, max_fp=0.0625,
+           true_max_fp=0.0625, true_avg_fp=0.0625)
+ibf_file.save_ibf(ibf, flt, cfg, [(f"T{b}", per_bin) for b in range(bins)], [(b, f"T{b}") for b in range(bins)], bins, rows, 4)
 flt.free()
 
 # FASTQ with fixed-width ids, assembled as one byte matrix
@@ -52,8 +59,8 @@ exe = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
 for label, dev in (("one_worker", "0"), ("two_workers_one_gpu", "0,0")):
     prefix = os.path.join(d, "ganon_e2e_out_" + label)
     t0 = time.time()
-    p = subprocess.run([exe, "--ibf", ibf, "--single-reads", fq, "-o", prefix, "--output-all", "--rel-cutoff", "0.75", "--verbose",
-                        "--device", dev], capture_output=True, text=True, env=dict(os.environ, GANON_HOST_TIMING="1"))
+    p = subprocess.run([exe, "--ibf", ibf, "--single-reads", fq, "-o", prefix, "--output-all", "--verbose", "--device", dev] + EXTRA,
+                       capture_output=True, text=True, env=dict(os.environ, GANON_HOST_TIMING="1"))
     r = {"rc": p.returncode, "wall_s": round(time.time() - t0, 2)}
     for key, pat in (("load_s", r"loading filter\(s\)\s+elapsed \(s\): ([0-9.eE+-]+)"),
                      ("classify_print_s", r"classifying\+printing elapsed \(s\): ([0-9.eE+-]+)"),

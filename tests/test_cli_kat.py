@@ -185,11 +185,11 @@ def sim_db(tmp_path_factory):
                 fq1=os.path.join(here, "sim.1.fq.gz"), fq2=os.path.join(here, "sim.2.fq.gz"))
 
 
-def _run_sim(binary, sim_db, tmp, hibf=False, extra=()):
+def _run_sim(binary, sim_db, tmp, hibf=False, extra=(), thresholds=("--rel-cutoff", "0.25", "--rel-filter", "0.1")):
     p = os.path.join(tmp, "hibf" if hibf else "ibf")
     args = ["--ibf", sim_db["hibf"] if hibf else sim_db["ibf"], "--tax", sim_db["tax"], "--paired-reads",
             sim_db["fq1"] + "," + sim_db["fq2"], "-o", p, "--output-all", "--output-lca", "--output-unclassified",
-            "--output-stats", "--quiet", "--rel-cutoff", "0.25", "--rel-filter", "0.1"] + (["--hibf"] if hibf else []) + list(extra)
+            "--output-stats", "--quiet"] + list(thresholds) + (["--hibf"] if hibf else []) + list(extra)
     cu.run(binary, args)
     return p
 
@@ -235,6 +235,26 @@ def test_sim_hip_equals_oracle_backend_bytes(oracle_bin, sim_db, tmp_path, hibf)
     _check_sim_against_oracle_level(sim_db, a, hibf)
     for ext in (".all", ".one", ".unc", ".rep", ".sta"):
         assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hibf", [False, True])
+@pytest.mark.parametrize("thresholds", [[], ["--rel-cutoff", "0.05", "--rel-filter", "0.3", "--fpr-query", "0.2"],
+                                        ["--rel-cutoff", "0", "--rel-filter", "1", "--fpr-query", "1e-3"],
+                                        ["--rel-cutoff", "0.1", "--rel-filter", "0", "--fpr-query", "1"]])
+def test_device_prefilter_changes_no_output_byte(sim_db, tmp_path, monkeypatch, hibf, thresholds):
+    # the device-side pre-pass of filter_matches (one-filter levels) vs the host doing all of it: identical files,
+    # including the discarded-match totals of the .sta; [] = the thresholds `ganon classify` passes by default
+    # (src/ganon/config.py: --rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5; the C++ binary's own are 0.2 / 0 / 1)
+    extra = thresholds if thresholds else ["--rel-cutoff", "0.2", "--rel-filter", "0.1", "--fpr-query", "1e-5"]
+    os.makedirs(tmp_path / "pre")
+    os.makedirs(tmp_path / "host")
+    a = _run_sim(cu.BIN_HIP, sim_db, str(tmp_path / "pre"), hibf=hibf, thresholds=extra)
+    monkeypatch.setenv("GANON_HOST_NO_PREFILTER", "1")
+    b = _run_sim(cu.BIN_HIP, sim_db, str(tmp_path / "host"), hibf=hibf, thresholds=extra)
+    for ext in (".all", ".one", ".unc", ".rep", ".sta"):
+        assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext
+    assert os.path.getsize(a + ".all") > 0
 
 
 # ---------------------------------------------------------------------------------------------------------------

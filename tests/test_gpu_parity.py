@@ -596,14 +596,16 @@ def test_streaming_write_rows_equals_one_shot_upload(hip):
     for gi in range(20):
         ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(seqs[gi]), 19, 31)), gi * 31 % bins)
     ref = hip.HipFilter.ibf(ibf.data, bins, S, h)
-    _, nh, status, mo, m = _classify(hip, ref, seqs, None, 19, 31, 0.3)
+    st1, nh, status, mo, m = _classify(hip, ref, seqs, None, 19, 31, 0.3)
     streamed = hip.HipFilter.ibf(None, bins, S, h)
     for r0 in range(0, S, 500):
         streamed.write_rows(r0, ibf.data[r0:r0 + 500])
     streamed.finalize()
     assert np.array_equal(streamed.download_rows(0, S, ibf.bin_words), ref.download_rows(0, S, ibf.bin_words))
-    _, nh2, status2, mo2, m2 = _classify(hip, streamed, seqs, None, 19, 31, 0.3)
+    st2, nh2, status2, mo2, m2 = _classify(hip, streamed, seqs, None, 19, 31, 0.3)
     assert len(m) > 15 and np.array_equal(m, m2) and np.array_equal(nh, nh2)
+    st1.destroy()
+    st2.destroy()
     # column slice: words [3, 8) of every 11-word source row, local bins 5*64 - 20 (padding cleared by finalize)
     lo, Wl, bl = 3, 5, 300
     sl = hip.HipFilter.ibf(None, bl, S, h)
@@ -615,3 +617,93 @@ def test_streaming_write_rows_equals_one_shot_upload(hip):
     assert np.array_equal(sl.download_rows(0, S, Wl), exp)
     for f in (ref, streamed, sl):
         f.free()
+
+
+def _exact_filter_matches(m_read, n_hashes, rel_filter, fpr_query, tfpr):
+    """filter_matches (GanonClassify.cpp:579-613, threshold :755-761) on one read's (target, count) list through the oracle;
+    -> (kept list, n dropped by rel_filter, n dropped by fpr_query, max_count)"""
+    import ctypes as C
+    import math
+    if len(m_read) == 0:
+        return [], 0, 0, 0
+    counts = np.array([c for _, c in m_read], dtype=np.uint64)
+    fprs = np.array([tfpr[t] for t, _ in m_read], dtype=np.float64)
+    mx, mn = int(counts.max()), min(int(n_hashes), int(counts.min()))
+    thr = mx - int(math.ceil(float(mx - mn) * rel_filter))
+    keep = np.zeros(len(m_read), dtype=np.uint8)
+    L = oracle.lib()
+    L.gno_filter_matches.restype = C.c_size_t
+    L.gno_filter_matches(counts.ctypes.data_as(C.c_void_p), fprs.ctypes.data_as(C.c_void_p), C.c_size_t(len(m_read)),
+                         C.c_uint64(int(n_hashes)), C.c_uint64(thr), C.c_double(fpr_query), keep.ctypes.data_as(C.c_void_p))
+    kept = [m_read[i] for i in range(len(m_read)) if keep[i] == 1]
+    return kept, int((keep == 2).sum()), int((keep == 3).sum()), mx
+
+
+@pytest.mark.parametrize("shape", ["identity4096", "split1000", "hibf"])
+@pytest.mark.parametrize("rel_filter,fpr_query", [(0.1, 1e-5), (0.0, 1.0), (1.0, 0.01), (0.5, 1.0), (0.25, 1e-9)])
+def test_device_postfilter_is_a_safe_prepass_of_filter_matches(hip, shape, rel_filter, fpr_query):
+    # gn_stream_set_postfilter: the --rel-filter rule is applied exactly, the --fpr-query rule conservatively; applying the
+    # exact rule to the survivors gives exactly what filter_matches gives on the unfiltered matches
+    k, w = 19, 31
+    rng = np.random.default_rng(77)
+    genomes = [gu.random_seq(rng, 3000) for _ in range(24)]
+    if shape == "hibf":
+        uh = {ub * 9: np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)) for ub, g in enumerate(genomes)}
+        hb = gf.random_hibf(600, 128, 2, seed=31, density=0.42, hash_funs=3, user_hashes=uh)
+        flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+        n_targets = 600
+    else:
+        bins, rows, h = (4096, 1531, 4) if shape == "identity4096" else (1000, 3001, 3)
+        ibf = gf.random_ibf(bins, rows, h, 0.42, seed=5)
+        n_targets = bins if shape == "identity4096" else 300
+        b2t = None if shape == "identity4096" else rng.integers(0, n_targets, size=bins).astype(np.uint32)
+        for gi, g in enumerate(genomes):
+            for hv in np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)):
+                ibf.emplace(int(hv), gi * 41 % bins)
+        flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
+    tfpr = rng.choice([1e-4, 0.003, 0.02, 0.05, 0.11, 0.3], size=n_targets)
+    seqs = []
+    for i in range(600):
+        L = int(rng.choice([100, 150, 150, 250, 600]))
+        if i % 3:
+            g = genomes[i % 24]
+            p = int(rng.integers(0, 3000 - L))
+            seqs.append(g[p:p + L])
+        else:
+            seqs.append(gu.random_seq(rng, L))
+    bases, off1, off2 = gu.pack_reads(seqs, None)
+    st = hip.HipStream(flt, len(seqs), bases.size)
+    st.submit(bases, off1, off2, k, w, 0.15)
+    nh, status, mo, m = st.fetch()
+    raw = [[(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]] for i in range(len(seqs))]
+    assert max(len(r) for r in raw) > 40  # the cooperative path is exercised
+    st.set_postfilter(rel_filter, fpr_query, tfpr)
+    st.submit(bases, off1, off2, k, w, 0.15)
+    nh2, status2, mo2, m2 = st.fetch()
+    mx, d_fil, d_fpr = st.fetch_postfilter()
+    assert np.array_equal(nh, nh2) and np.array_equal(status, status2)
+    e_fil = e_fpr = on_device = 0
+    for i in range(len(seqs)):
+        kept, nf, nq, emx = _exact_filter_matches(raw[i], nh[i], rel_filter, fpr_query, tfpr)
+        got = [(int(x["target"]), int(x["count"])) for x in m2[int(mo2[i]):int(mo2[i + 1])]]
+        assert all(int(x["read"]) == i for x in m2[int(mo2[i]):int(mo2[i + 1])])
+        assert int(mx[i]) == emx
+        assert set(kept) <= set(got) <= set(raw[i]), i
+        assert got == [x for x in raw[i] if x in set(got)]  # original order
+        # the host applies the exact --fpr-query rule to the survivors: what it keeps is what filter_matches keeps
+        exact_drop = set(raw[i]) - set(kept)
+        assert [x for x in got if x not in exact_drop] == kept, i
+        assert len(raw[i]) - len(got) >= nf
+        e_fil += nf
+        e_fpr += nq
+        on_device += len(raw[i]) - len(got) - nf
+    assert d_fil == e_fil
+    assert d_fpr == on_device and d_fpr <= e_fpr
+    if fpr_query < 1.0 and e_fpr > 50:
+        assert d_fpr >= 0.9 * e_fpr  # the margin leaves only borderline cases to the host
+    st.set_postfilter(None)
+    st.submit(bases, off1, off2, k, w, 0.15)
+    _, _, mo3, m3 = st.fetch()
+    assert np.array_equal(mo3, mo) and np.array_equal(m3, m)
+    st.destroy()
+    flt.free()
