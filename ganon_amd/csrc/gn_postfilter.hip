@@ -11,11 +11,12 @@
 //   threshold_filter = max - ceil((max - min) * rel_filter)                   (:757-758; IEEE double multiply + ceil)
 //   count_i < threshold_filter                      -> dropped (--rel-filter), counted
 //   fpr_query < 1 and q_i SURELY > fpr_query        -> dropped (--fpr-query), counted
-//   everything else                                 -> kept, original order
+//   everything else                                 -> kept, original order; if q_i is SURELY <= fpr_query the match is
+//                                                      marked (GN_MATCH_FPR_OK in its count) and the host skips its own check
 // The --rel-filter rule is exact integer/double arithmetic and is applied completely.  The --fpr-query rule
 // (q = 1 - sum_{i<=count} C(n,i) p^i (1-p)^(n-i), libm lgamma/exp/pow on the host) is applied CONSERVATIVELY: the device
-// evaluates q with a multiplicative recurrence and drops a match only if q > fpr_query*1.001 + 1e-9, a margin far above
-// both evaluations' error (<= ~1e-11 for n <= 4096, the only range the device decides; longer reads, degenerate p and
+// evaluates q with a multiplicative recurrence and drops a match only if q > fpr_query*1.001 + 1e-9 (and marks it as
+// passed only if q < fpr_query*0.999 - 1e-9), a margin far above both evaluations' error (<= ~1e-11 for n <= 4096, the only range the device decides; longer reads, degenerate p and
 // underflowing terms are left alone).  The host applies the reference's own expression to every survivor, so the final
 // result is the one the reference computes; the device only removes matches whose fate is not in doubt.
 //
@@ -45,13 +46,14 @@ struct GnPostfilterParams
     uint64_t            n_targets;
 };
 
-__device__ __forceinline__ bool gn_fpr_surely_above(uint32_t n, uint32_t count, double p, double fq)
+// 0 = the host decides, 1 = q is surely above fpr_query (drop), 2 = q is surely not above it (keep, no host check needed)
+__device__ __forceinline__ uint32_t gn_fpr_verdict(uint32_t n, uint32_t count, double p, double fq)
 {
     if (!(p > 0.0) || !(p < 1.0) || n > 4096u || count > 1024u)
-        return false; // the host decides
+        return 0;
     double term = exp((double)n * log1p(-p)); // i = 0
     if (!(term > 1e-200))
-        return false;
+        return 0;
     const double ratio = p / (1.0 - p);
     double       sum   = term;
     for (uint32_t i = 1; i <= count; ++i)
@@ -59,7 +61,12 @@ __device__ __forceinline__ bool gn_fpr_surely_above(uint32_t n, uint32_t count, 
         term *= (double)(n - i + 1) / (double)i * ratio;
         sum += term;
     }
-    return 1.0 - sum > fq * 1.001 + 1e-9;
+    const double q = 1.0 - sum;
+    if (q > fq * 1.001 + 1e-9)
+        return 1;
+    if (q < fq * 0.999 - 1e-9)
+        return 2;
+    return 0;
 }
 
 __device__ __forceinline__ uint32_t gn_pf_threshold(uint32_t mx, uint32_t mn, double rel_filter)
@@ -100,13 +107,19 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
             const uint32_t thr = gn_pf_threshold(mx, mn, p.rel_filter);
             for (uint32_t j = 0; j < c; ++j)
             {
-                const gn_match m = p.m[o + j];
+                gn_match       m = p.m[o + j];
+                const uint32_t v = m.count >= thr && fpr_on
+                                       ? gn_fpr_verdict(n, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query)
+                                       : 0u;
                 if (m.count < thr)
                     ++n_fil;
-                else if (fpr_on && gn_fpr_surely_above(n, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query))
+                else if (v == 1)
                     ++n_fpr;
                 else
+                {
+                    m.count |= v == 2 ? GN_MATCH_FPR_OK : 0u;
                     p.m[o + kept++] = m;
+                }
             }
         }
         p.keep[r] = kept;
@@ -150,12 +163,18 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
             bool k = false;
             if (act)
             {
+                const uint32_t v = m.count >= thr && fpr_on
+                                       ? gn_fpr_verdict(nn, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query)
+                                       : 0u;
                 if (m.count < thr)
                     ++n_fil;
-                else if (fpr_on && gn_fpr_surely_above(nn, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query))
+                else if (v == 1)
                     ++n_fpr;
                 else
+                {
                     k = true;
+                    m.count |= v == 2 ? GN_MATCH_FPR_OK : 0u;
+                }
             }
             const uint64_t km = __ballot(k);
             if (k) // all loads of this chunk are done (the store data depends on them) and kept <= j0: in place is safe

@@ -49,6 +49,7 @@ struct FilterResult
 {
     std::vector<uint64_t> match_off; // n+1
     std::vector<Match>    matches;   // grouped by read, ascending target
+    std::vector<uint8_t>  fpr_ok;    // empty, or per match: 1 = the backend already verified q <= fpr_query (see set_postfilter)
 };
 
 struct BatchResult
@@ -82,7 +83,8 @@ public:
     virtual std::string describe() const = 0;
     // Optional.  Ask for the --rel-filter rule (exactly) and the --fpr-query rule (conservatively: only matches that are
     // above the limit by a safe margin) to be applied where the matches are produced, so that only survivors travel to the
-    // host, which then applies the exact --fpr-query rule to them.  nullptr switches it off.  Returns whether the backend
+    // host, which then applies the exact --fpr-query rule to them (except to those the backend marks as surely passing,
+    // FilterResult::fpr_ok).  nullptr switches it off.  Returns whether the backend
     // will do it for the filters it currently holds (one filter that sees whole reads); BatchResult::prefiltered says
     // so per batch.  The default does nothing: the host then runs filter_matches on everything.
     virtual bool set_postfilter(const PostFilterSpec* /*spec*/) { return false; }

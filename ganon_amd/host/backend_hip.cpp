@@ -284,7 +284,8 @@ public:
             fr.matches.clear();
             if (lf.parts.size() == 1)
             {
-                if (!fetch_part(lf.parts[0], n, out, fr.match_off, fr.matches, err))
+                fr.fpr_ok.clear();
+                if (!fetch_part(lf.parts[0], n, out, fr.match_off, fr.matches, err, pf_active_ ? &fr.fpr_ok : nullptr))
                     return false;
                 if (pf_active_)
                 {
@@ -389,7 +390,7 @@ private:
 
     // n_hashes / status (the same for every part), match offsets and matches of one device filter, target ids translated
     bool fetch_part(Part& part, uint32_t n, BatchResult& out, std::vector<uint64_t>& match_off, std::vector<Match>& matches,
-                    std::string& err)
+                    std::string& err, std::vector<uint8_t>* fpr_ok = nullptr)
     {
         uint64_t need = 0;
         if (gn_fetch_batch(part.s, out.n_hashes.data(), out.status.data(), match_off.data(), nullptr, 0, &need) != GN_OK)
@@ -413,7 +414,13 @@ private:
                 t = part.to_target[t]; // HIBF: user bin -> target; column part: local -> global target
                 drop |= t == 0xFFFFFFFFu;
             }
-            matches[j] = Match{ tmp_[j].read, t, tmp_[j].count };
+            matches[j] = Match{ tmp_[j].read, t, tmp_[j].count & ~GN_MATCH_FPR_OK };
+        }
+        if (fpr_ok)
+        {
+            fpr_ok->resize(need);
+            for (uint64_t j = 0; j < need; ++j)
+                (*fpr_ok)[j] = (tmp_[j].count & GN_MATCH_FPR_OK) ? 1 : 0;
         }
         if (drop)
         {

@@ -762,6 +762,7 @@ static bool ganon_classify(Config config)
             uint32_t gid;
             size_t   count;
             double   fpr;
+            bool     fpr_ok; // the backend already verified the --fpr-query rule for this match
         };
         std::vector<MatchEntry>  matches;
         // several filters of a level can report the same target: its slot in `matches`, valid while the stamp is the read's
@@ -834,6 +835,7 @@ static bool ganon_classify(Config config)
                         {
                             const Match&   m   = fr.matches[x];
                             const uint32_t gid = target_gid[i][m.target];
+                            const bool     ok  = !fr.fpr_ok.empty() && fr.fpr_ok[x] != 0;
                             MatchEntry*    e   = nullptr;
                             if (!one_filter) // (one filter reports a target once)
                             {
@@ -850,8 +852,9 @@ static bool ganon_classify(Config config)
                             {
                                 if (e)
                                 {
-                                    e->count = m.count;
-                                    e->fpr   = filters[i].target_fpr[m.target];
+                                    e->count  = m.count;
+                                    e->fpr    = filters[i].target_fpr[m.target];
+                                    e->fpr_ok = ok;
                                 }
                                 else
                                 {
@@ -860,7 +863,7 @@ static bool ganon_classify(Config config)
                                         stamp_of[gid] = stamp;
                                         slot_of[gid]  = (uint32_t)matches.size();
                                     }
-                                    matches.push_back(MatchEntry{ gid, m.count, filters[i].target_fpr[m.target] });
+                                    matches.push_back(MatchEntry{ gid, m.count, filters[i].target_fpr[m.target], ok });
                                 }
                                 if (m.count > max_count_read)
                                     max_count_read = m.count;
@@ -888,7 +891,7 @@ static bool ganon_classify(Config config)
                     {
                         if (me.count >= (double)threshold_filter)
                         {
-                            if (level.fpr_query < 1.0)
+                            if (level.fpr_query < 1.0 && !me.fpr_ok)
                             {
                                 double q = 1;
                                 for (size_t i = 0; i <= me.count; i++)

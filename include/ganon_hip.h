@@ -174,9 +174,12 @@ int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status, uint64_t* 
  * (min starts at n_hashes, :704), matches below max - ceil((max-min)*rel_filter) are dropped (exact), and, if fpr_query < 1,
  * matches whose q = 1 - BinomCDF(count; n_hashes, target_fpr[target]) is above fpr_query BY A SAFE MARGIN are dropped too
  * (q > fpr_query*1.001 + 1e-9; the caller applies the exact rule to what is left, so the final result is the reference's).
+ * A surviving match whose q is below fpr_query by the same margin (q < fpr_query*0.999 - 1e-9) comes back with
+ * GN_MATCH_FPR_OK set in its count: the caller may skip its own evaluation for it (mask the bit off to get the count).
  * gn_fetch_batch / gn_stream_device_matches then return the survivors only.  Use it only where this filter sees all of a
  * read's matches (one filter per hierarchy level, filter not cut into column parts).  target_fpr: n_targets doubles
  * (flat IBF) / n_user_bins doubles (HIBF); may be NULL when fpr_query >= 1.  pf == NULL switches the pass off. */
+#define GN_MATCH_FPR_OK 0x80000000u
 typedef struct gn_postfilter
 {
     double        rel_filter;

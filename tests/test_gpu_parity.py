@@ -682,10 +682,14 @@ def test_device_postfilter_is_a_safe_prepass_of_filter_matches(hip, shape, rel_f
     nh2, status2, mo2, m2 = st.fetch()
     mx, d_fil, d_fpr = st.fetch_postfilter()
     assert np.array_equal(nh, nh2) and np.array_equal(status, status2)
-    e_fil = e_fpr = on_device = 0
+    e_fil = e_fpr = on_device = n_marked = n_kept = 0
     for i in range(len(seqs)):
         kept, nf, nq, emx = _exact_filter_matches(raw[i], nh[i], rel_filter, fpr_query, tfpr)
-        got = [(int(x["target"]), int(x["count"])) for x in m2[int(mo2[i]):int(mo2[i + 1])]]
+        got = [(int(x["target"]), int(x["count"]) & 0x7FFFFFFF) for x in m2[int(mo2[i]):int(mo2[i + 1])]]
+        marked = [(int(x["target"]), int(x["count"]) & 0x7FFFFFFF) for x in m2[int(mo2[i]):int(mo2[i + 1])] if int(x["count"]) >> 31]
+        assert set(marked) <= set(kept)  # GN_MATCH_FPR_OK only on matches the exact rule keeps
+        n_marked += len(marked)
+        n_kept += len(kept)
         assert all(int(x["read"]) == i for x in m2[int(mo2[i]):int(mo2[i + 1])])
         assert int(mx[i]) == emx
         assert set(kept) <= set(got) <= set(raw[i]), i
@@ -701,6 +705,10 @@ def test_device_postfilter_is_a_safe_prepass_of_filter_matches(hip, shape, rel_f
     assert d_fpr == on_device and d_fpr <= e_fpr
     if fpr_query < 1.0 and e_fpr > 50:
         assert d_fpr >= 0.9 * e_fpr  # the margin leaves only borderline cases to the host
+    if fpr_query >= 1.0:
+        assert n_marked == 0
+    elif fpr_query > 1e-8 and n_kept > 50:
+        assert n_marked >= 0.9 * n_kept
     st.set_postfilter(None)
     st.submit(bases, off1, off2, k, w, 0.15)
     _, _, mo3, m3 = st.fetch()
