@@ -24,7 +24,8 @@
 #ifndef GN_NARROW_MAX
 #define GN_NARROW_MAX 4u
 #endif
-#define GN_MATCH_CHUNK 256u
+#define GN_MATCH_CHUNK 256u      // first wave-private chunk of the match buffer ...
+#define GN_MATCH_CHUNK_MAX 8192u // ... doubling with every further request of the wave (see the fast kernel's epilogue)
 #define GN_STAGE_CAP 128u // per-wave LDS staging of (target, count) hits in the generic select pass
 
 // ------------------------------------------------------------------------------------------------
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
     // Blocks stride over rounds of rpb reads; the trip count is block-uniform, so __syncthreads() is safe.
     const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads - p.read_begin;
     unsigned long long chunk_base = 0; // wave-private slice of the match buffer
-    uint32_t           chunk_left = 0;
+    uint32_t           chunk_left = 0, chunk_size = GN_MATCH_CHUNK;
     for (uint32_t round0 = blockIdx.x * rpb; round0 < n_work; round0 += gridDim.x * rpb)
     {
     const uint32_t widx = round0 + rslot;
@@ -953,7 +954,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             // wave-private chunk of the match buffer (see the fast kernel): one global atomic per GN_MATCH_CHUNK
             if (total > chunk_left)
             {
-                const uint32_t need = total > GN_MATCH_CHUNK ? total : GN_MATCH_CHUNK;
+                const uint32_t need = total > chunk_size ? total : chunk_size;
+                chunk_size = chunk_size < GN_MATCH_CHUNK_MAX ? chunk_size * 2u : chunk_size;
                 unsigned long long nb = 0;
                 if (lane == 0)
                     nb = atomicAdd(p.cursor, (unsigned long long)need);
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         }
     };
     unsigned long long chunk_base = 0; // wave-private slice of the match buffer
-    uint32_t           chunk_left = 0;
+    uint32_t           chunk_left = 0, chunk_size = GN_MATCH_CHUNK;
     uint64_t           skipped_bytes = 0; // row bytes this lane's column group did not fetch thanks to early exits
     uint32_t read, n;
     uint64_t slot, hA, hB;
@@ -1497,12 +1499,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
             total  = (uint32_t)__builtin_amdgcn_readlane((int)x, GN_WAVE - 1);
         }
         // padding bins (>= B) of the last word never count: real filters keep them zero; be exact anyway
-        // Output space comes from a wave-private chunk: one returning atomic on the global cursor per
-        // GN_MATCH_CHUNK matches instead of one per read (a single address sustains only ~90 atomics/us, which
-        // would cap the kernel at a few M reads/ms).  Unused chunk tails are holes; the gather pass compacts.
+        // Output space comes from a wave-private chunk: one returning atomic on the global cursor per chunk instead of
+        // one per read (a single address sustains only ~90 atomics/us, which would cap the kernel at a few M reads/ms).
+        // A wave's chunks double from GN_MATCH_CHUNK to GN_MATCH_CHUNK_MAX: at low cutoffs (~100 chance matches per
+        // read) fixed 256-match chunks meant 4 M atomics per 10 M reads -- 20 ms of the kernel.  Unused chunk tails are
+        // holes; the gather pass compacts.
         if (total > chunk_left)
         {
-            const uint32_t need = total > GN_MATCH_CHUNK ? total : GN_MATCH_CHUNK;
+            const uint32_t need = total > chunk_size ? total : chunk_size;
+                chunk_size = chunk_size < GN_MATCH_CHUNK_MAX ? chunk_size * 2u : chunk_size;
             unsigned long long nb = 0;
             if (lane == 0)
                 nb = atomicAdd(p.cursor, (unsigned long long)need);
@@ -1512,7 +1517,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         base = chunk_base;
         chunk_base += total;
         chunk_left -= total;
-        if (base + total <= p.match_cap && owner && any)
+        const bool fits = base + total <= p.match_cap;
+        if (__popcll(hm) > 6)
+        {
+            // many lanes report (low cutoffs): the lane's count bytes go through the wave's row table, which is idle during
+            // the epilogue, 32 bins (8 dwords) at a time, and the hit bits are walked in ascending order -- one short loop
+            // per dword instead of sixteen nested ones, and the count of a bin is one ds_read_u8
+            gn_match*      out = p.matches + base + my_off;
+            uint32_t       k   = 0;
+            const uint8_t* tabb = reinterpret_cast<const uint8_t*>(rowtab);
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+            {
+                gn_wave_lds_sync();
+                if (owner && any)
+                {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+                            rowtab[(uint32_t)lane * 8u + (uint32_t)(j * 2 + pp)] = byt[d][j][pp];
+                }
+                gn_wave_lds_sync();
+                uint32_t mbits = (fits && owner && any) ? hit[d] : 0u;
+                while (mbits)
+                {
+                    const uint32_t b = (uint32_t)__builtin_ctz(mbits);
+                    mbits &= mbits - 1;
+                    gn_match mt;
+                    mt.read   = read;
+                    mt.target = wi * 64 + 32 * d + b; // bit b = 8y + 4pp + j of dword d is byte y of byt[d][j][pp]
+                    mt.count  = tabb[(uint32_t)lane * 32u + (((b & 3u) << 1) + ((b >> 2) & 1u)) * 4u + (b >> 3)];
+                    out[k++]  = mt;
+                }
+            }
+            gn_wave_lds_sync(); // the next unit refills the row table
+        }
+        else if (fits && owner && any)
         {
             // every match goes to its rank among the lane's hit bits, so a read's segment leaves in ascending target
             // order (the gather pass then only copies)

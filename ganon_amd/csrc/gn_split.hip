@@ -21,6 +21,7 @@
 #define GN_SPLIT_STAGE 128u
 #define GN_SPLIT_LIMIT 128u // candidates per wave beyond which the read scans every target
 #define GN_SPLIT_CHUNK 256u
+#define GN_SPLIT_CHUNK_MAX 8192u
 
 namespace
 {
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 
     const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads - p.read_begin;
     unsigned long long chunk_base = 0;
-    uint32_t           chunk_left = 0;
+    uint32_t           chunk_left = 0, chunk_size = GN_SPLIT_CHUNK; // (doubles per request up to GN_SPLIT_CHUNK_MAX, see gn_kernels.hip)
     for (uint32_t round0 = blockIdx.x * rpb; round0 < n_work; round0 += gridDim.x * rpb)
     {
         const uint32_t widx = round0 + rslot;
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             {
                 if (total > chunk_left)
                 {
-                    const uint32_t need = total > GN_SPLIT_CHUNK ? total : GN_SPLIT_CHUNK;
+                    const uint32_t need = total > chunk_size ? total : chunk_size;
+                    chunk_size = chunk_size < GN_SPLIT_CHUNK_MAX ? chunk_size * 2u : chunk_size;
                     unsigned long long nb = 0;
                     if (lane == 0)
                         nb = atomicAdd(p.cursor, (unsigned long long)need);
