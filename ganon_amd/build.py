@@ -18,8 +18,10 @@ CSRC = os.path.join(HERE, "csrc")
 HOST = os.path.join(HERE, "host")
 LIB = os.path.join(CSRC, "libganon_hip.so")
 BIN = os.path.join(HOST, "ganon-classify")
+BIN_BUILD = os.path.join(HOST, "ganon-build")
+BUILD_ONLY = ("build.cpp", "build_params.cpp")  # sources of ganon-build that ganon-classify does not link
 
-HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_capi.hip"]
+HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_build.hip", "gn_capi.hip"]
 HIP_HEADERS = ["gn_internal.h", os.path.join(ROOT, "include", "ganon_hip.h")]
 
 
@@ -68,17 +70,22 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:
-    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cpp")) if os.path.isdir(HOST) else []
-    if not srcs:
+    """ganon-classify (every host source but the builder's) and ganon-build (its own sources + the sequence reader)"""
+    if not os.path.isdir(HOST):
         return ""
+    every = sorted(f for f in os.listdir(HOST) if f.endswith(".cpp"))
     hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "ganon_hip.h")]
     build_hip(force=False, verbose=verbose)
-    if force or _stale(BIN, srcs + hdrs + [LIB]):
-        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", BIN] + srcs + \
-              ["-L", CSRC, "-lganon_hip", "-lz", "-Wl,-rpath,$ORIGIN/../csrc"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+    for binary, names in ((BIN, [f for f in every if f not in BUILD_ONLY]), (BIN_BUILD, [f for f in every if f in BUILD_ONLY] + ["seq_io.cpp"])):
+        srcs = [os.path.join(HOST, f) for f in names]
+        if not srcs:
+            continue
+        if force or _stale(binary, srcs + hdrs + [LIB]):
+            cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", binary] + srcs + \
+                  ["-L", CSRC, "-lganon_hip", "-lz", "-Wl,-rpath,$ORIGIN/../csrc"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
     return BIN
 
 

@@ -350,6 +350,8 @@ extern "C" int gn_filter_free(gn_filter* f)
         hipFree(p);
     if (f->d_hibf)
         hipFree(f->d_hibf);
+    if (f->d_emplace_stage)
+        hipFree(f->d_emplace_stage);
     if (f->load_st)
         hipStreamDestroy(f->load_st);
     delete f;
@@ -683,6 +685,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
         if (p)
             hipFree(p);
     gn_postfilter_release(s);
+    gn_build_release(s);
     if (s->h_ctr)
         hipHostFree(s->h_ctr);
     if (s->h_hctr)

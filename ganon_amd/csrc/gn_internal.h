@@ -143,6 +143,7 @@ struct GnHibfIbfDev
 // ---- misc kernels ---------------------------------------------------------------------------
 int  gn_run_postfilter(gn_stream* s);     // gn_postfilter.hip
 void gn_postfilter_release(gn_stream* s);
+void gn_build_release(gn_stream* s);       // gn_build.hip
 hipError_t gn_launch_emplace(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h, const uint64_t* hashes,
                              const uint32_t* bins, uint64_t n, hipStream_t st);
 
@@ -172,6 +173,7 @@ struct gn_filter
     bool     is_hibf = false;
     uint64_t device_bytes = 0;
     hipStream_t load_st = nullptr; // streaming upload (gn_filter_write_rows), created on first use
+    uint64_t*   d_emplace_stage = nullptr; // gn_filter_emplace_split's staging buffer
     // flat
     GnIbfHost       ibf;
     uint32_t*       d_tgt_off  = nullptr;
@@ -241,6 +243,12 @@ struct gn_stream
     void*         d_sort_tmp = nullptr;
     size_t        sort_tmp_bytes = 0;
     uint64_t      hibf_cap = 0;
+    // build side (gn_build.hip): pack / sort / unique buffers, allocated by the first gn_stream_distinct_hashes
+    uint64_t*           d_build[2]{ nullptr, nullptr };
+    void*               d_build_tmp = nullptr;
+    size_t              build_tmp_bytes = 0;
+    unsigned long long* d_build_ctr = nullptr; // [0] packed hashes [1] distinct hashes
+    uint64_t            build_cap = 0;
     // device-side pre-pass of filter_matches (gn_postfilter.hip); off unless gn_stream_set_postfilter enabled it
     bool                pf_on = false;
     double              pf_rel_filter = 0, pf_fpr_query = 1;

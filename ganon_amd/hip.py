@@ -20,7 +20,8 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_filter_fill_random", "gn_filter_info", "gn_filter_free", "gn_stream_create", "gn_stream_destroy",
                "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch", "gn_stream_set_postfilter",
                "gn_fetch_postfilter", "gn_stream_device_matches",
-               "gn_stream_fetch_hashes", "gn_stream_dense_counts", "gn_stream_timings"]
+               "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
+               "gn_stream_timings"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -89,6 +90,8 @@ def load_library():
     L.gn_stream_set_postfilter.argtypes = [vp, vp]
     L.gn_fetch_postfilter.argtypes = [vp, vp, C.POINTER(u64), C.POINTER(u64)]
     L.gn_stream_fetch_hashes.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+    L.gn_stream_distinct_hashes.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.gn_filter_emplace_split.argtypes = [vp, vp, u64, u32, u64]
     L.gn_stream_dense_counts.argtypes = [vp, u32, u32, vp]
     L.gn_stream_timings.argtypes = [vp, C.POINTER(Timings)]
     for name in ABI_SYMBOLS:
@@ -291,6 +294,15 @@ class HipStream:
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(load_library().gn_fetch_postfilter(self._h, _p(mx), C.byref(a), C.byref(b)))
         return mx, int(a.value), int(b.value)
+
+    def distinct_hashes(self) -> np.ndarray:
+        """sorted distinct minimiser hashes of the resident sequences (gn_stream_distinct_hashes)"""
+        L = load_library()
+        n = C.c_uint64(0)
+        _check(L.gn_stream_distinct_hashes(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(int(n.value), 1), dtype=np.uint64)
+        _check(L.gn_stream_distinct_hashes(self._h, _p(out), len(out), C.byref(n)))
+        return out[: int(n.value)]
 
     def fetch_read_info(self):
         """-> (n_hashes u32[n], status u8[n]) only"""

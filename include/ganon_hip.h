@@ -197,6 +197,17 @@ int gn_fetch_postfilter(gn_stream* s, uint32_t* max_count, uint64_t* dropped_rel
  * The memory belongs to the stream and is valid until its next submit/classify/destroy. */
 int gn_stream_device_matches(gn_stream* s, const gn_match** d_matches, uint64_t* n_matches);
 
+/* Build side (/root/reference/src/ganon-build/GanonBuild.cpp).
+ * gn_stream_distinct_hashes: after gn_stream_minimisers, the SET of minimiser hashes of all sequences resident in the
+ * stream, ascending -- what count_hashes collects per file in a robin_hood::unordered_set (:184-249; the set's own iteration
+ * order is not reproducible here, ascending order is this library's definition).  out may be NULL to query *n_distinct.
+ * A long sequence is passed as overlapping pieces (consecutive pieces share window_size-1 bases): every window lies in one
+ * piece, so the set is the sequence's (emission order and duplicates differ, the set does not).
+ * gn_filter_emplace_split: hash i of `hashes` is inserted into technical bin first_bin + i / hashes_per_bin -- a target's
+ * run of bins with equal shares, create_bin_map_hash (:619-653) + build (:655-698). */
+int gn_stream_distinct_hashes(gn_stream* s, uint64_t* out, uint64_t cap, uint64_t* n_distinct);
+int gn_filter_emplace_split(gn_filter* f, const uint64_t* hashes, uint64_t n, uint32_t first_bin, uint64_t hashes_per_bin);
+
 /* Parity / debugging taps (tests only): minimiser hashes of the resident batch in emission order
  * (hash_off[n_reads+1]; hashes[cap]) and dense per-bin counts of reads [read_begin, read_end)
  * (flat IBF: uint16[bins] per read == counting_agent::bulk_count; HIBF: uint16[n_user_bins] per read

@@ -87,6 +87,10 @@ def false_positive(bin_size_bits: int, hash_functions: int, n_hashes: int) -> fl
 def true_false_positive(counts: Sequence[int], max_hashes_bin: int, bin_size_bits: int, hash_functions: int) -> Tuple[float, float]:
     highest, average = 0.0, 0.0
     for c in counts:
+        if c == 0:
+            # a target without minimisers: the reference divides 0/0 here and (on x86-64, where NaN converts to 2^63) ends
+            # up with 1 - pow(0, 0) = 0; it still counts in the average's denominator
+            continue
         n_bins_target = _u64(math.ceil(c / float(max_hashes_bin)))
         n_hashes_bin = _u64(math.ceil(c / float(n_bins_target)))
         real_fp = 1.0 - math.pow(1.0 - false_positive(bin_size_bits, hash_functions, n_hashes_bin), n_bins_target)
