@@ -94,12 +94,25 @@ extern "C" int gn_stream_distinct_hashes(gn_stream* s, uint64_t* out, uint64_t c
     const uint32_t n = s->n_reads;
     if (n == 0)
         return GN_OK;
+    if (s->build_distinct != ~0ull) // asked before for these hashes (size query, then fetch): the sorted set is still there
+    {
+        *n_distinct = s->build_distinct;
+        if (!out || s->build_distinct == 0)
+            return GN_OK;
+        if (cap < s->build_distinct)
+            return gn_fail(GN_EOVERFLOW, "hash buffer too small: need %llu", (unsigned long long)s->build_distinct);
+        GN_HIP(hipMemcpy(out, s->d_build[0], s->build_distinct * 8, hipMemcpyDeviceToHost));
+        return GN_OK;
+    }
     // every read's count is at most its window count, so the slot total bounds the packed size
     uint64_t slots = 0;
     GN_HIP(hipMemcpyAsync(&slots, s->d_slot_off + n, 8, hipMemcpyDeviceToHost, s->st));
     GN_HIP(hipStreamSynchronize(s->st));
     if (slots == 0)
+    {
+        s->build_distinct = 0;
         return GN_OK;
+    }
     if (slots > 0x7FFFFFF0ull)
         return gn_fail(GN_ERANGE, "more than 2^31 minimiser windows in one batch");
     int rc = gn_build_reserve(s, slots);
@@ -113,7 +126,10 @@ extern "C" int gn_stream_distinct_hashes(gn_stream* s, uint64_t* out, uint64_t c
     GN_HIP(hipMemcpyAsync(&total, s->d_build_ctr, 8, hipMemcpyDeviceToHost, s->st));
     GN_HIP(hipStreamSynchronize(s->st));
     if (total == 0)
+    {
+        s->build_distinct = 0;
         return GN_OK;
+    }
     size_t    tmp      = s->build_tmp_bytes;
     const int end_bit  = (int)(2 * s->k > 64 ? 64 : 2 * s->k); // values are below 4^k
     GN_HIP(hipcub::DeviceRadixSort::SortKeys(s->d_build_tmp, tmp, s->d_build[0], s->d_build[1], (int)total, 0, end_bit, s->st));
@@ -122,7 +138,8 @@ extern "C" int gn_stream_distinct_hashes(gn_stream* s, uint64_t* out, uint64_t c
     unsigned long long nd = 0;
     GN_HIP(hipMemcpyAsync(&nd, s->d_build_ctr + 1, 8, hipMemcpyDeviceToHost, s->st));
     GN_HIP(hipStreamSynchronize(s->st));
-    *n_distinct = nd;
+    *n_distinct       = nd;
+    s->build_distinct = nd;
     if (!out)
         return GN_OK;
     if (cap < nd)

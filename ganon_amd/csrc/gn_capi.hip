@@ -128,12 +128,31 @@ static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* by
 extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const uint32_t* bin2target, uint32_t n_targets,
                                     gn_filter** out)
 {
-    if (!out || !ibf || !bin2target)
+    if (!out || !ibf)
         return gn_fail(GN_EINVAL, "gn_filter_upload_ibf: null argument");
     *out = nullptr;
     int rc = gn_set_device(device);
     if (rc)
         return rc;
+    if (!bin2target)
+    {
+        // storage-only filter (the builder's): bits can be written, inserted and read back, reads cannot be classified
+        // against it -- so the shape limits of the count kernels do not apply (a database may have more bins than one
+        // classify-side filter takes; ganon-classify cuts such a file into column parts when it loads it)
+        gn_filter* f = new (std::nothrow) gn_filter();
+        if (!f)
+            return gn_fail(GN_ENOMEM, "out of host memory");
+        f->device       = device;
+        f->storage_only = true;
+        rc              = gn_upload_ibf_rows(ibf, &f->ibf, &f->device_bytes);
+        if (rc)
+        {
+            delete f;
+            return rc;
+        }
+        *out = f;
+        return GN_OK;
+    }
     GnCountGeometry geom{};
     const char*     why = "";
     if (!gn_count_geometry(ibf->bin_words, ibf->hash_funs, &geom, &why))
@@ -715,6 +734,8 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
 {
     if (!f || !out || max_reads == 0 || max_bases == 0)
         return gn_fail(GN_EINVAL, "gn_stream_create: bad argument");
+    if (f->storage_only)
+        return gn_fail(GN_EINVAL, "gn_stream_create: the filter was created without a bin map (storage only)");
     *out = nullptr;
     GN_HIP(hipSetDevice(f->device));
     gn_stream* s = new (std::nothrow) gn_stream();
@@ -804,6 +825,7 @@ extern "C" int gn_stream_upload_reads(gn_stream* s, const uint8_t* bases, uint64
     s->have_reads = true;
     s->classified = false;
     s->hashed     = false;
+    s->build_distinct = ~0ull;
     return GN_OK;
 }
 
@@ -1122,6 +1144,7 @@ extern "C" int gn_stream_minimisers(gn_stream* s, uint32_t k, uint32_t w)
         return rc;
     GN_HIP(hipEventRecord(s->ev[1], s->st));
     s->hashed     = true;
+    s->build_distinct = ~0ull;
     s->classified = false;
     return GN_OK;
 }
@@ -1171,6 +1194,7 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     }
     GN_HIP(hipEventRecord(s->ev[1], s->st2));
     s->hashed = true;
+    s->build_distinct = ~0ull;
 
     for (uint32_t c = 0; c < nc; ++c)
     {

@@ -171,6 +171,7 @@ struct gn_filter
     int      device  = 0;
     int      n_cu    = 256;
     bool     is_hibf = false;
+    bool     storage_only = false; // flat, created without a bin map: no streams (gn_filter_upload_ibf)
     uint64_t device_bytes = 0;
     hipStream_t load_st = nullptr; // streaming upload (gn_filter_write_rows), created on first use
     uint64_t*   d_emplace_stage = nullptr; // gn_filter_emplace_split's staging buffer
@@ -249,6 +250,7 @@ struct gn_stream
     size_t              build_tmp_bytes = 0;
     unsigned long long* d_build_ctr = nullptr; // [0] packed hashes [1] distinct hashes
     uint64_t            build_cap = 0;
+    uint64_t            build_distinct = ~0ull; // result of the last gn_stream_distinct_hashes on the resident hashes (~0: none)
     // device-side pre-pass of filter_matches (gn_postfilter.hip); off unless gn_stream_set_postfilter enabled it
     bool                pf_on = false;
     double              pf_rel_filter = 0, pf_fpr_query = 1;

@@ -339,8 +339,11 @@ public:
         // pieces of `stride_` window starts; short enough for the lane-per-read minimiser kernel where it applies
         stride_ = w <= 128 ? 512 : 4096;
         gn_ibf_desc d{};
-        d.bins = 64, d.bin_size = 64, d.hash_funs = 1, d.rows = nullptr;
-        if (gn_filter_upload_ibf(device, &d, nullptr, 0, &flt_) != GN_OK)
+        d.bins = 64, d.bin_words = 1, d.bin_size = 64, d.hash_shift = 57, d.hash_funs = 1, d.rows = nullptr;
+        std::vector<uint32_t> identity(64);
+        for (uint32_t b = 0; b < 64; ++b)
+            identity[b] = b;
+        if (gn_filter_upload_ibf(device, &d, identity.data(), 64, &flt_) != GN_OK)
             throw std::runtime_error(hip_error());
         if (gn_stream_create(flt_, kMaxPieces, kMaxBases, 1, &st_) != GN_OK)
             throw std::runtime_error(hip_error());
@@ -371,7 +374,7 @@ public:
             short_[(uint32_t)len].append(reinterpret_cast<const char*>(seq), len);
             return;
         }
-        for (uint64_t at = 0; len - at >= w_; at += stride_)
+        for (uint64_t at = 0; at + w_ <= len; at += stride_)
         {
             const uint64_t n = std::min<uint64_t>(len - at, (uint64_t)stride_ + w_ - 1);
             if (fill_ + n > kMaxBases || off_.size() > kMaxPieces)
@@ -749,8 +752,9 @@ bool run(Config c)
     filling.start();
     gn_filter*  flt = nullptr;
     gn_ibf_desc d{};
-    d.bins = p.n_bins, d.bin_size = p.bin_size_bits, d.hash_funs = p.hash_functions, d.rows = nullptr;
-    if (gn_filter_upload_ibf(c.device, &d, nullptr, 0, &flt) != GN_OK)
+    d.bins = p.n_bins, d.bin_words = (p.n_bins + 63) >> 6, d.bin_size = p.bin_size_bits, d.hash_funs = p.hash_functions, d.rows = nullptr;
+    d.hash_shift = (uint32_t)__builtin_clzll(p.bin_size_bits);
+    if (gn_filter_upload_ibf(c.device, &d, nullptr, 0, &flt) != GN_OK) // storage only: no bin map
     {
         std::cerr << gn_last_error() << std::endl;
         return false;

@@ -88,7 +88,9 @@ const char* gn_last_error(void);
 
 /* Flat IBF.  bin2target[b] (b < bins) = caller's target id of technical bin b, or 0xFFFFFFFF for
  * bins that belong to no target (replaces Filter::map, GanonClassify.cpp:279-287,1021-1025);
- * target ids must be < n_targets.  A target may own any set of bins (split bins, :516-523). */
+ * target ids must be < n_targets.  A target may own any set of bins (split bins, :516-523).
+ * bin2target == NULL makes a STORAGE-ONLY filter (the builder's use): rows can be written, hashes inserted, rows read
+ * back, but no stream can be created on it -- and the bin-count limit of the classify kernels does not apply. */
 int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const uint32_t* bin2target, uint32_t n_targets,
                          gn_filter** out);
 

@@ -32,7 +32,9 @@ SEQS2 = [s[:n] for s, n in zip(SEQS, (80, 75, 70, 65, 60, 55, 50, 45, 40, 35))]
 @pytest.fixture(scope="module")
 def hip():
     import ganon_amd
-    ganon_amd.build.build_all()
+    ganon_amd.load_library()
+    assert ganon_amd.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    assert os.path.exists(BIN_BUILD), "ganon-build is built by __graft_entry__.build()"
     return ganon_amd
 
 
@@ -122,7 +124,10 @@ def check_filter(hip, path, seqs, names, k, w, h_req, max_fp, filter_size, mode=
     dense = st.dense_counts(0, len(ok), m.bins)
     for i, (s, t) in enumerate(ok):
         assert status[i] == 0 and nh[i] == len(hashes_of(s, k, w))
-        assert int(dense[i][tb[t]].astype(np.int64).sum()) & 0xFFFF == nh[i]
+        found = int(dense[i][tb[t]].astype(np.int64).sum())
+        # one bin: exactly its minimisers (:80-82); a target split over several bins can see a hash again in a sibling bin as
+        # a false positive (the reference only runs this check on one-bin targets)
+        assert found == nh[i] if len(tb[t]) == 1 else nh[i] <= found <= nh[i] * len(tb[t])
     st.destroy()
     flt.free()
     return m
