@@ -5,6 +5,7 @@
 #include <ganon_hip.h>
 
 #include <algorithm>
+#include <map>
 #include <cstdlib>
 #include <sstream>
 
@@ -25,7 +26,9 @@ constexpr uint64_t kPartWords = 512; // 32 768 bins: four wave slices of 16-byte
 class HipBackend final : public Backend
 {
 public:
-    explicit HipBackend(int device) : device_(device) {}
+    // primary != nullptr: a further worker on the same device.  It classifies against the primary's filters (one copy of the
+    // bits in that GPU's HBM, read-only while batches run) with streams of its own.
+    explicit HipBackend(int device, HipBackend* primary = nullptr) : device_(device), primary_(primary) {}
     ~HipBackend() override
     {
         clear_filters();
@@ -37,6 +40,8 @@ public:
     // ---- FilterSink: the filter is created empty on the device, its rows arrive in chunks ----------------------
     bool begin(const FilterMeta& f, std::string& err) override
     {
+        if (primary_)
+            return true; // (the primary, earlier in the sink's list, receives the filter)
         Logical lf;
         lf.row_words.clear();
         for (auto const& m : f.shapes)
@@ -157,6 +162,8 @@ public:
 
     uint64_t* staging(int which, size_t bytes) override
     {
+        if (primary_)
+            return primary_->staging(which, bytes);
         Stage& s = stage_[which & 1];
         if (s.bytes < bytes)
         {
@@ -177,6 +184,8 @@ public:
     {
         // asynchronous on the filter's load stream when src is pinned (gn_filter_write_rows); src holds whole rows, every
         // column part takes its words of them
+        if (primary_)
+            return true;
         Logical& lf = filters_.back();
         if (ibf >= lf.row_words.size())
         {
@@ -194,7 +203,7 @@ public:
 
     bool drain(std::string& err) override
     {
-        if (!filters_.empty())
+        if (!primary_ && !filters_.empty())
             for (auto& part : filters_.back().parts)
                 if (gn_filter_write_sync(part.f) != GN_OK)
                 {
@@ -206,6 +215,20 @@ public:
 
     bool end(std::string& err) override
     {
+        if (primary_)
+        {
+            // the primary has just finished this filter: take its device filters, without streams
+            Logical lf = primary_->filters_.at(filters_.size());
+            for (auto& part : lf.parts)
+            {
+                part.s             = nullptr;
+                part.stream_reads  = 0;
+                part.stream_bases  = 0;
+                part.pf_generation = 0;
+            }
+            filters_.push_back(std::move(lf));
+            return true;
+        }
         for (auto& part : filters_.back().parts)
             if (gn_filter_finalize(part.f) != GN_OK)
             {
@@ -222,7 +245,8 @@ public:
             {
                 if (part.s)
                     gn_stream_destroy(part.s);
-                gn_filter_free(part.f);
+                if (!primary_) // (a further worker's streams do not need the filter to go away: gn_stream_destroy never touches it)
+                    gn_filter_free(part.f);
             }
         filters_.clear();
     }
@@ -442,6 +466,7 @@ private:
     }
 
     int                   device_;
+    HipBackend*           primary_ = nullptr;
     Stage                 stage_[2];
     std::vector<Logical>  filters_;
     std::vector<gn_match> tmp_;
@@ -471,8 +496,16 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
             err = "device index " + std::to_string(d) + " out of range (" + std::to_string(n) + " device(s) visible)";
             return out;
         }
+    // one backend per listed device; a device listed again gets a further worker that shares the first one's filters
+    std::map<int, HipBackend*> first;
     for (int d : use)
-        out.emplace_back(new HipBackend(d));
+    {
+        auto it = first.find(d);
+        auto* b = new HipBackend(d, it == first.end() ? nullptr : it->second);
+        if (it == first.end())
+            first[d] = b;
+        out.emplace_back(b);
+    }
     // device-bound host buffers (read batches) come from page-locked memory from now on (hostmem.hpp)
     if (!std::getenv("GANON_HOST_PAGEABLE"))
     {

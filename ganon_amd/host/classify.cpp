@@ -63,10 +63,15 @@ public:
     void push(T&& b)
     {
         std::unique_lock<std::mutex> lk(m_);
+        const auto t0 = std::chrono::steady_clock::now();
         not_full_.wait(lk, [&] { return q_.size() < cap_; });
+        blocked_push_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         q_.push_back(std::move(b));
         not_empty_.notify_one();
     }
+    // seconds producers spent waiting for room / consumers waiting for an item ($GANON_HOST_TIMING)
+    double blocked_push() const { return blocked_push_; }
+    double blocked_pop() const { return blocked_pop_; }
     void done()
     {
         std::lock_guard<std::mutex> lk(m_);
@@ -76,7 +81,9 @@ public:
     bool pop(T& b)
     {
         std::unique_lock<std::mutex> lk(m_);
+        const auto t0 = std::chrono::steady_clock::now();
         not_empty_.wait(lk, [&] { return !q_.empty() || done_; });
+        blocked_pop_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (q_.empty())
             return false;
         b = std::move(q_.front());
@@ -107,6 +114,7 @@ private:
     std::vector<T>          free_;
     size_t                  cap_;
     bool                    done_ = false;
+    double                  blocked_push_ = 0, blocked_pop_ = 0;
 };
 using BatchQueue = BoundedQueue<ReadBatch>;
 
@@ -126,8 +134,12 @@ public:
     void wait_turn(uint64_t seq) // before a worker starts on batch `seq`
     {
         std::unique_lock<std::mutex> lk(m_);
+        const auto t0 = std::chrono::steady_clock::now();
         cv_.wait(lk, [&] { return seq < next_ + window_ || aborted_; });
+        blocked_turn_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    double blocked_turn() const { return blocked_turn_; }
+    double blocked_take() const { return blocked_take_; }
     void put(uint64_t seq, ClassifiedBatch&& cb)
     {
         std::lock_guard<std::mutex> lk(m_);
@@ -150,7 +162,9 @@ public:
     bool take(ClassifiedBatch& cb, size_t n_workers)
     {
         std::unique_lock<std::mutex> lk(m_);
+        const auto t0 = std::chrono::steady_clock::now();
         cv_.wait(lk, [&] { return aborted_ || ready_.count(next_) || (finished_ == n_workers && ready_.empty()); });
+        blocked_take_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (aborted_)
             return false;
         auto it = ready_.find(next_);
@@ -186,6 +200,7 @@ private:
     uint64_t                            next_ = 0;
     size_t                              window_, finished_ = 0;
     bool                                aborted_ = false;
+    double                              blocked_turn_ = 0, blocked_take_ = 0;
 };
 
 // reads / bases per device batch ($GANON_HOST_BATCH_READS: smaller batches for tests of the multi-worker pipeline)
@@ -1049,6 +1064,11 @@ static bool ganon_classify(Config config)
             }
             if (first_level)
                 read_task.join();
+            if (std::getenv("GANON_HOST_TIMING"))
+                std::cerr << "[host stalls] level " << level.label << ": reader blocked on a full batch queue " << queue1.blocked_push()
+                          << " s, workers waiting for a batch " << queue1.blocked_pop() << " s (summed), workers waiting for their turn "
+                          << ordered.blocked_turn() << " s (summed), post stage waiting for a result " << ordered.blocked_take() << " s"
+                          << std::endl;
         }
         carried.swap(next_carried);
 

@@ -56,11 +56,17 @@ out["fastq_gib"] = round(os.path.getsize(fq) / 2**30, 2)
 del rec
 
 exe = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
-for label, dev in (("one_worker", "0"), ("two_workers_one_gpu", "0,0")):
+runs = [("one_worker", "0", None), ("two_workers_one_gpu", "0,0", None), ("three_workers_one_gpu", "0,0,0", None), ("default_no_device_flag", None, None)]
+if os.environ.get("E2E_SWEEP"):  # parser threads x device workers, to see which stage limits the pipeline on this host
+    runs += [(f"sweep_parse{pt}_workers{len(dev.split(','))}", dev, pt) for pt in (4, 6, 8, 10, 12) for dev in ("0", "0,0", "0,0,0")]
+for label, dev, parse_threads in runs:
     prefix = os.path.join(d, "ganon_e2e_out_" + label)
     t0 = time.time()
-    p = subprocess.run([exe, "--ibf", ibf, "--single-reads", fq, "-o", prefix, "--output-all", "--verbose", "--device", dev] + EXTRA,
-                       capture_output=True, text=True, env=dict(os.environ, GANON_HOST_TIMING="1"))
+    env = dict(os.environ, GANON_HOST_TIMING="1")
+    if parse_threads:
+        env["GANON_HOST_PARSE_THREADS"] = str(parse_threads)
+    p = subprocess.run([exe, "--ibf", ibf, "--single-reads", fq, "-o", prefix, "--output-all", "--verbose"] + (["--device", dev] if dev else []) + EXTRA,
+                       capture_output=True, text=True, env=env)
     r = {"rc": p.returncode, "wall_s": round(time.time() - t0, 2)}
     for key, pat in (("load_s", r"loading filter\(s\)\s+elapsed \(s\): ([0-9.eE+-]+)"),
                      ("classify_print_s", r"classifying\+printing elapsed \(s\): ([0-9.eE+-]+)"),
@@ -71,17 +77,29 @@ for label, dev in (("one_worker", "0"), ("two_workers_one_gpu", "0,0")):
     m = re.search(r"\[host timing\] (.*)", p.stderr)
     if m:
         r["host_timing"] = m.group(1)
+    bt = re.findall(r"\[backend timing\] (.*)", p.stderr)
+    if bt:
+        r["backend_timing"] = bt
+    m = re.search(r"\[host stalls\] (.*)", p.stderr)
+    if m:
+        r["host_stalls"] = m.group(1)
     if "classify_print_s" in r:
         r["mreads_per_s_classify_print"] = round(n / r["classify_print_s"] / 1e6, 2)
-    if p.returncode == 0:
+    if p.returncode == 0 and parse_threads is None:
         r["all_lines"] = sum(1 for _ in open(prefix + ".all"))
         r["rep_tail"] = open(prefix + ".rep").read().splitlines()[-2:]
+    elif p.returncode == 0:
+        os.remove(prefix + ".all")
     else:
         r["stderr"] = p.stderr[-400:]
     out[label] = r
-if out["one_worker"].get("rc") == 0 and out["two_workers_one_gpu"].get("rc") == 0:
-    a, b = (os.path.join(d, "ganon_e2e_out_" + x) for x in ("one_worker", "two_workers_one_gpu"))
-    out["outputs_identical"] = all(open(a + e, "rb").read() == open(b + e, "rb").read() for e in (".all", ".rep"))
+if all(out[x].get("rc") == 0 for x in ("one_worker", "two_workers_one_gpu", "three_workers_one_gpu", "default_no_device_flag")):
+    a = os.path.join(d, "ganon_e2e_out_one_worker")
+    out["outputs_identical"] = all(open(a + e, "rb").read() == open(os.path.join(d, "ganon_e2e_out_" + x) + e, "rb").read()
+                                   for e in (".all", ".rep") for x in ("two_workers_one_gpu", "three_workers_one_gpu", "default_no_device_flag"))
+if os.environ.get("E2E_KEEP"):  # leave filter and reads behind for follow-up runs (A/B scripts)
+    os.rename(ibf, os.path.join(d, os.environ["E2E_KEEP"] + ".ibf"))
+    os.rename(fq, os.path.join(d, os.environ["E2E_KEEP"] + ".fq"))
 for f in os.listdir(d):
     if f.startswith("ganon_e2e"):
         os.remove(os.path.join(d, f))
