@@ -359,3 +359,56 @@ def test_built_filter_classifies_with_the_binary(hip, tmp_path):
             best[rid] = (t, int(c))
     assert len(best) == 2000
     assert all(best[r][0] == truth[r] for r in truth)
+
+
+def test_nothing_to_build_and_all_short(hip, tmp_path):
+    # every sequence below --min-length / below one k-mer: "No valid sequences to build", exit code 1, no file (:804-808)
+    inp, _, _ = write_inputs(str(tmp_path), [s[:15] for s in SEQS[:3]])
+    out, p = run_build(str(tmp_path), inp, expect=1)
+    assert not os.path.exists(out)
+    p = subprocess.run([BIN_BUILD, "-i", inp, "-o", out, "-k", "19", "-w", "32"], capture_output=True, text=True)
+    assert p.returncode == 1 and "No valid sequences to build" in p.stderr
+    inp, _, _ = write_inputs(str(tmp_path), SEQS)
+    out, p = run_build(str(tmp_path), inp, extra=["--min-length", "1000"], expect=1)
+    assert not os.path.exists(out)
+    # an input file that lists nothing usable
+    empty = tmp_path / "none.tsv"
+    empty.write_text(f"{tmp_path}/does_not_exist.fasta\tT\n")
+    p = subprocess.run([BIN_BUILD, "-i", str(empty), "-o", out], capture_output=True, text=True)
+    assert p.returncode == 1 and "No valid input files" in p.stderr
+
+
+def test_more_bins_than_one_classify_filter_takes(hip, tmp_path):
+    # 33 000 one-bin targets: the builder's filter is storage-only (no bin-count limit); ganon-classify loads the file as
+    # column parts and finds every target's own sequence
+    rng = np.random.default_rng(12)
+    n = 33000
+    d = str(tmp_path)
+    seqs = rng.integers(0, 4, size=(n, 120), dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(os.path.join(d, "in.tsv"), "w") as tsv:
+        for i in range(n):
+            f = os.path.join(d, f"t{i}.fa")
+            with open(f, "wb") as o:
+                o.write(b">s\n" + lut[seqs[i]].tobytes() + b"\n")
+            tsv.write(f"{f}\tT{i}\n")
+    out = os.path.join(d, "wide.ibf")
+    p = subprocess.run([BIN_BUILD, "-i", os.path.join(d, "in.tsv"), "-o", out, "-t", "16", "--quiet", "-p", "0.001", "-s", "3"], capture_output=True,
+                       text=True)
+    assert p.returncode == 0, p.stderr
+    from ganon_amd import ibf_file
+    m = ibf_file.read_ibf_meta(out)
+    assert m.bins == n and m.bin_words == (n + 63) // 64
+    import cli_util as cu
+    fq = os.path.join(d, "r.fq")
+    pick = rng.integers(0, n, size=500)
+    with open(fq, "w") as o:
+        for j, i in enumerate(pick):
+            o.write(f"@r{j}\n{lut[seqs[i]].tobytes().decode()}\n+\n{'I' * 120}\n")
+    prefix = os.path.join(d, "res")
+    cu.run(cu.BIN_HIP, ["--ibf", out, "--single-reads", fq, "-o", prefix, "--output-all", "--quiet", "--rel-cutoff", "1", "--skip-lca"])
+    hits = {}
+    for line in open(prefix + ".all"):
+        rid, t, c = line.rstrip("\n").split("\t")
+        hits.setdefault(rid, set()).add(t)
+    assert all(f"T{i}" in hits.get(f"r{j}", ()) for j, i in enumerate(pick))

@@ -715,3 +715,36 @@ def test_device_postfilter_is_a_safe_prepass_of_filter_matches(hip, shape, rel_f
     assert np.array_equal(mo3, mo) and np.array_equal(m3, m)
     st.destroy()
     flt.free()
+
+
+def test_postfilter_survives_match_buffer_regrow_and_empty_batches(hip):
+    # a match buffer far too small for the unfiltered matches: the batch is re-run after the buffer grew, the pre-pass with it
+    k, w = 19, 31
+    rng = np.random.default_rng(123)
+    ibf = gf.random_ibf(2048, 1201, 3, 0.45, seed=8)
+    flt = hip.HipFilter.ibf(ibf.data, 2048, 1201, 3)
+    seqs = [gu.random_seq(rng, 150) for _ in range(400)]
+    bases, off1, off2 = gu.pack_reads(seqs, None)
+    tfpr = np.full(2048, 0.09)
+    ref = hip.HipStream(flt, len(seqs), bases.size)
+    ref.set_postfilter(0.2, 1e-3, tfpr)
+    ref.submit(bases, off1, off2, k, w, 0.1)
+    nh, status, mo, m = ref.fetch()
+    mx, a, b = ref.fetch_postfilter()
+    assert a + b > 20000 and len(m) > 0
+    small = hip.HipStream(flt, len(seqs), bases.size, max_matches=64)
+    small.set_postfilter(0.2, 1e-3, tfpr)
+    for _ in range(2):  # (the second batch finds the buffer already grown)
+        small.submit(bases, off1, off2, k, w, 0.1)
+        nh2, status2, mo2, m2 = small.fetch()
+        mx2, a2, b2 = small.fetch_postfilter()
+        assert np.array_equal(mo, mo2) and np.array_equal(m, m2) and np.array_equal(mx, mx2) and (a, b) == (a2, b2)
+    # reads too short for a window / no reads at all
+    e_bases, e_off, _ = gu.pack_reads([b"ACGT", b""], None)
+    small.submit(e_bases, e_off, None, k, w, 0.1)
+    nh3, status3, mo3, m3 = small.fetch()
+    mx3, a3, b3 = small.fetch_postfilter()
+    assert list(status3) == [1, 1] and len(m3) == 0 and list(mo3) == [0, 0, 0] and list(mx3) == [0, 0] and (a3, b3) == (0, 0)
+    for s in (ref, small):
+        s.destroy()
+    flt.free()
