@@ -15,6 +15,7 @@
 // Reads longer than lpr_max_len (or windows wider than 65 k-mers) are appended to a deferred list that the
 // wave-per-read kernel (gn_kernels.hip) processes.
 #include "gn_internal.h"
+#include <type_traits>
 
 #define GN_WAVE 64
 
@@ -251,11 +252,43 @@ __global__ __launch_bounds__(64) void gn_minimiser_lpr_kernel(GnMinimiserParams 
 //     traffic, r01 WRITE_SIZE).
 #define GN_LPRK_STAGE 24u // staged emissions per mate and lane; further ones of a mate go straight to memory
 
-template <int KW>
+// min of two 64-bit keys.  FMIN: both are below 2^56 or the all-ones sentinel, so read as IEEE doubles they are non-negative
+// finite numbers (denormals included: f64 denormals are never flushed on gfx9) or a quiet NaN, whose order is the order of
+// the integers and for which v_min_f64 returns the other operand -- one VALU instruction instead of compare + two selects
+// (the inline asm keeps the compiler from adding canonicalising operations around it).  The selected operand comes back
+// bit for bit; NaN against NaN gives a NaN, which is still above every key.
+template <bool FMIN>
+__device__ __forceinline__ uint64_t gn_key_min(uint64_t a, uint64_t b)
+{
+    if constexpr (FMIN)
+    {
+        uint64_t r;
+        asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    else
+        return a < b ? a : b;
+}
+
+template <int KW, bool FMIN>
 __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams p)
 {
     __shared__ uint64_t stage[GN_LPRK_STAGE * (GN_WAVE + 1)];
     const uint32_t lane = threadIdx.x;
+    // dna4 rank of every byte value (seqan3::dna4 char_to_rank; the same values as GN_LPR_RANK_LUT):
+    // letters of either case index two 32-bit masks with c & 31 -- low rank bit set for C Y S B T U, high rank bit for
+    // G K T U; every other byte is rank 0
+    __shared__ uint8_t rank_lut[256];
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t)
+    {
+        const uint32_t c   = lane * 4 + t, idx = c & 31u;
+        uint32_t       b32 = ((0x0238000Cu >> idx) & 1u) | (((0x00300880u >> idx) & 1u) << 1);
+        rank_lut[c]        = (uint8_t)((c & 0xC0u) == 0x40u ? b32 : 0u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t k    = p.k;
     const uint64_t seed = 0x8F3F73B5CF1C9ADEULL >> (64u - 2u * k);    // adjust_seed.hpp:33-37
     const uint64_t mask = (1ULL << (2 * k)) - 1ULL;                   // k <= 24
@@ -293,6 +326,7 @@ __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams
         const uint32_t Lmax = gn_lpr_wave_max(Leff);
         if (Lmax == 0)
             continue;
+        const uint32_t Lmin = ~gn_lpr_wave_max(~Leff); // 0 as soon as one lane sits this mate out
         const uint32_t n_seg0 = n; // emissions of this mate are staged from here
         const uintptr_t sa  = reinterpret_cast<uintptr_t>(p.bases + (seg ? b2 : b1));
         const uint32_t  o   = (uint32_t)(sa & 3u);
@@ -309,17 +343,14 @@ __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams
         const uint64_t seed_rc = seed ^ mask;
         const uint32_t top     = 2 * (k - 1);
         auto roll = [&](uint32_t c) -> uint64_t { // append base c, return the canonical value of the k-mer ending here
-            // dna4 rank of any byte without a table and without a branch: letters (either case) index two 32-bit masks
-            // with c & 31 -- low rank bit set for C Y S B T U, high rank bit for G K T U; every other byte is rank 0
-            // (seqan3::dna4 char_to_rank; the same values as GN_LPR_RANK_LUT)
-            const uint32_t idx = c & 31u;
-            uint32_t       b32 = ((0x0238000Cu >> idx) & 1u) | (((0x00300880u >> idx) & 1u) << 1);
-            b32                = (c & 0xC0u) == 0x40u ? b32 : 0u;
-            const uint64_t b   = b32;
+            // dna4 rank of any byte: a 256-byte table in LDS (filled at kernel start, see there), one ds_read_u8 -- the
+            // LDS port is idle in this VALU-bound loop, the ~9 VALU operations of the bit-mask form were not free
+            // (2.82 -> 2.69 ms per 10 M reads)
+            const uint64_t b = rank_lut[c];
             f                  = ((f << 2) | b) & mask;
             rcx                = (rcx >> 2) | (b << top);
             const uint64_t x = f ^ seed, y = rcx ^ seed_rc;
-            return x < y ? x : y;
+            return gn_key_min<FMIN>(x, y);
         };
         // warm-up: the first k-1 bases complete no k-mer (one aligned dword per four bases)
         for (uint32_t q = 0; q * 4 < o + k - 1; ++q)
@@ -360,25 +391,29 @@ __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams
 #pragma unroll
             for (int d = 0; d + 1 < NDW; ++d)
                 by[d] = __builtin_amdgcn_alignbyte(cur[d + 1], cur[d], sh);
+            // a block that lies inside EVERY lane's read (the usual case: 64 reads of one length) needs no per-lane
+            // predicate; the general form handles the blocks around the ends of shorter reads
+            auto block = [&](auto all_on_tag) {
+            constexpr bool ALL_ON = decltype(all_on_tag)::value;
 #pragma unroll
             for (int pin = 0; pin < KW; ++pin)
             {
                 const uint32_t pk = blk * KW + pin;     // k-mer position (wave-uniform)
                 const uint32_t i  = pk + k - 1;         // base index
-                const bool     on = i < Leff;           // (past the longest read of the wave nothing is on: the tail of the
+                const bool     on = ALL_ON || i < Leff; // (past the longest read of the wave nothing is on: the tail of the
                                                         //  last block runs empty instead of leaving the unrolled loop)
                 const uint32_t c  = (by[pin >> 2] >> (8 * (pin & 3))) & 0xFFu;
                 // (rolled by every lane: lanes past their read only waste the arithmetic, their key is discarded)
                 const uint64_t kv  = (roll(c) << 16) | (uint64_t)(0xFFFFu - pk);
                 const uint64_t key = on ? kv : ~0ULL;
                 V[pin] = key;
-                pre    = pin == 0 ? key : (key < pre ? key : pre);
+                pre    = pin == 0 ? key : gn_key_min<FMIN>(key, pre);
                 if (pk + 1 >= KW)
                 {
                     const uint32_t j = pk + 1 - KW; // window index (uniform); valid for this lane iff `on`
                     uint64_t       W = pre;
                     if (pin != KW - 1)              // window starts inside the previous block: its suffix from slot pin+1
-                        W = S[(pin + 1) % KW] < pre ? S[(pin + 1) % KW] : pre;
+                        W = gn_key_min<FMIN>(S[(pin + 1) % KW], pre);
                     if (on)
                     {
                         // first window / the remembered minimiser leaves / a strictly smaller VALUE enters
@@ -397,11 +432,16 @@ __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams
                     }
                 }
             }
+            };
+            if ((blk + 1) * KW + k - 1 <= Lmin)
+                block(std::true_type{});
+            else
+                block(std::false_type{});
             // block complete: its keys become suffix minima (register to register)
             S[KW - 1] = V[KW - 1];
 #pragma unroll
             for (int t = KW - 2; t >= 0; --t)
-                S[t] = V[t] < S[t + 1] ? V[t] : S[t + 1];
+                S[t] = gn_key_min<FMIN>(V[t], S[t + 1]);
 #pragma unroll
             for (int d = 0; d < NDW; ++d)
                 cur[d] = nxt[d];
@@ -445,7 +485,12 @@ __global__ __launch_bounds__(64) void gn_minimiser_lprk_kernel(GnMinimiserParams
 template <int KW>
 static void gn_launch_lprk(const GnMinimiserParams& p, hipStream_t st)
 {
-    hipLaunchKernelGGL((gn_minimiser_lprk_kernel<KW>), dim3((p.n_reads - p.read_begin + GN_WAVE - 1) / GN_WAVE), dim3(GN_WAVE), 0, st, p);
+    const dim3 grid((p.n_reads - p.read_begin + GN_WAVE - 1) / GN_WAVE);
+    // keys are (value << 16) | position with value < 4^k: below 2^56 -- the range gn_key_min's float form needs -- up to k = 20
+    if (p.k <= 20 && !getenv("GANON_HIP_MINIMISER_INTMIN"))
+        hipLaunchKernelGGL((gn_minimiser_lprk_kernel<KW, true>), grid, dim3(GN_WAVE), 0, st, p);
+    else
+        hipLaunchKernelGGL((gn_minimiser_lprk_kernel<KW, false>), grid, dim3(GN_WAVE), 0, st, p);
 }
 
 hipError_t gn_launch_minimiser_lpr(const GnMinimiserParams& p, hipStream_t st)
