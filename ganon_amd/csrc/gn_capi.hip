@@ -705,6 +705,9 @@ extern "C" int gn_stream_destroy(gn_stream* s)
             hipFree(p);
     gn_postfilter_release(s);
     gn_build_release(s);
+    for (void* q : { (void*)s->d_long_list, (void*)s->d_long_count, (void*)s->d_long_scratch })
+        if (q)
+            hipFree(q);
     if (s->h_ctr)
         hipHostFree(s->h_ctr);
     if (s->h_hctr)
@@ -1037,6 +1040,12 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
         p.work_count = s->d_ctr + 4;
     }
     GN_HIP(gn_launch_count(p, f->geom, f->ibf.h, s->st));
+    if (s->long_reads) // reads the kernels above skipped as GN_READ_BIG: 32-bit counters, one workgroup each
+    {
+        GN_HIP(hipMemsetAsync(s->d_long_count, 0, sizeof(unsigned long long), s->st));
+        p.work_list = nullptr;
+        GN_HIP(gn_launch_count_long(p, f->ibf.h, s->d_long_list, s->d_long_count, s->d_long_scratch, GN_LONG_BLOCKS, s->st));
+    }
     return GN_OK;
 }
 
@@ -1339,6 +1348,32 @@ extern "C" int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status,
                                   s->st));
     }
     GN_HIP(hipStreamSynchronize(s->st));
+    if (status && s->long_reads) // the long kernel classified them (the device keeps GN_READ_BIG: a re-run after a
+        for (uint32_t r = 0; r < n; ++r) // match-buffer regrow has to find them again)
+            if (status[r] == GN_READ_BIG)
+                status[r] = GN_READ_OK;
+    return GN_OK;
+}
+
+extern "C" int gn_stream_set_long_reads(gn_stream* s, int on)
+{
+    if (!s)
+        return gn_fail(GN_EINVAL, "null stream");
+    if (!on)
+    {
+        s->long_reads = false;
+        return GN_OK;
+    }
+    if (s->f->is_hibf)
+        return gn_fail(GN_ERANGE, "long reads (more than 65535 minimisers) are supported for flat IBF filters only");
+    GN_HIP(hipSetDevice(s->device));
+    if (!s->d_long_list)
+    {
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_long_list), ((size_t)s->max_reads + 1) * 4));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_long_count), sizeof(unsigned long long)));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_long_scratch), (size_t)GN_LONG_BLOCKS * ((size_t)s->f->ibf.B + 64) * 4));
+    }
+    s->long_reads = true;
     return GN_OK;
 }
 

@@ -13,6 +13,7 @@
 // candidate-driven select of the generic count kernel: targets with more bins than this are scanned from a list
 #define GN_CAND_NBIG 4u
 #define GN_HIBF_MAXDEPTH 64
+#define GN_LONG_BLOCKS 128u // workgroups (and uint32 count slabs) of the long-read kernel
 #define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
                    // [6] exact match total [8..71] total-hashes shards
 
@@ -121,6 +122,8 @@ hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t
 hipError_t gn_launch_count(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
 hipError_t gn_launch_count_fast(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
 // split-bin maps, reads with <= 127 minimisers, rows of at least one wave (gn_split.hip)
+hipError_t gn_launch_count_long(const GnCountParams& p, uint32_t hash_funs, uint32_t* list, unsigned long long* count, uint32_t* scratch,
+                                uint32_t blocks, hipStream_t st);
 hipError_t gn_launch_count_split(const GnCountParams& p, const GnCountGeometry& g, uint32_t hash_funs, hipStream_t st);
 size_t     gn_split_lds_bytes(const GnCountGeometry& g, uint32_t hash_funs);
 
@@ -244,6 +247,11 @@ struct gn_stream
     void*         d_sort_tmp = nullptr;
     size_t        sort_tmp_bytes = 0;
     uint64_t      hibf_cap = 0;
+    // reads with more than 65 535 minimisers (gn_stream_set_long_reads): list, counter, uint32 count slabs of the long kernel
+    bool                long_reads = false;
+    uint32_t*           d_long_list = nullptr;
+    unsigned long long* d_long_count = nullptr;
+    uint32_t*           d_long_scratch = nullptr;
     // build side (gn_build.hip): pack / sort / unique buffers, allocated by the first gn_stream_distinct_hashes
     uint64_t*           d_build[2]{ nullptr, nullptr };
     void*               d_build_tmp = nullptr;

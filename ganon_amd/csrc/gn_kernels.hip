@@ -1668,6 +1668,135 @@ hipError_t gn_launch_count(const GnCountParams& p, const GnCountGeometry& g, uin
 }
 
 // ================================================================================================
+// reads with more than 65 535 minimisers -- what the reference classifies only when built with -DLONGREADS
+// (TIntCount = uint32_t, GanonClassify.cpp:45-49; hashes_limit :674).  Rare and long (a 65 536-minimiser read is ~0.5 Mbp),
+// so: one workgroup per read, uint32 counters in a global scratch slab (L2-resident), every thread owns the row words
+// j = tid, tid + 256, ... and with them their bins' counters (no atomics); then the select of :516-540 over contiguous
+// target ranges per thread (ascending output), 64-bit sums capped at n.
+// ================================================================================================
+__global__ void gn_long_list_kernel(const uint8_t* __restrict__ status, uint32_t read_begin, uint32_t n_reads,
+                                    uint32_t* __restrict__ list, unsigned long long* __restrict__ count)
+{
+    const uint32_t r = read_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads && status[r] == GN_READ_BIG)
+        list[atomicAdd(count, 1ULL)] = r;
+}
+
+__global__ __launch_bounds__(256) void gn_ibf_count_long_kernel(GnCountParams p, uint32_t* __restrict__ scratch)
+{
+    __shared__ uint32_t           part[256];
+    __shared__ unsigned long long base_sh;
+    __shared__ uint32_t           total_sh;
+    const uint32_t tid   = threadIdx.x;
+    uint32_t*      cnt   = scratch + (size_t)blockIdx.x * ((size_t)p.B + 64);
+    const uint32_t n_work = (uint32_t)*p.work_count;
+    const uint32_t hf    = p.early_exit; // (the launcher passes the number of hash functions here)
+    for (uint32_t widx = blockIdx.x; widx < n_work; widx += gridDim.x)
+    {
+        const uint32_t read = p.work_list[widx];
+        const uint32_t n    = p.n_hashes[read];
+        for (uint32_t i = tid; i < p.B; i += 256)
+            cnt[i] = 0;
+        __syncthreads();
+        const uint64_t* hs = p.hashes + p.slot_off[read];
+        for (uint32_t q = 0; q < n; ++q)
+        {
+            const uint64_t v = hs[q];
+            uint32_t       row[5];
+            for (uint32_t i = 0; i < hf; ++i)
+                row[i] = gn_ibf_row(v, i, p.shift, p.S);
+            for (uint32_t j = tid; j < p.W; j += 256)
+            {
+                uint64_t m = p.rows[(uint64_t)row[0] * p.W + j];
+                for (uint32_t i = 1; i < hf; ++i)
+                    m &= p.rows[(uint64_t)row[i] * p.W + j];
+                while (m)
+                {
+                    const uint32_t b = j * 64u + (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    if (b < p.B)
+                        cnt[b]++;
+                }
+            }
+        }
+        __syncthreads();
+        uint64_t T = (uint64_t)ceil(__dmul_rn((double)n, p.rel_cutoff)); // GanonClassify.cpp:492-495,720-724
+        if (T == 0)
+            T = 1;
+        // targets [lo, hi) of this thread: contiguous, so the read's matches come out in ascending target order
+        const uint32_t per = (p.n_targets + 255u) / 256u;
+        const uint32_t lo  = tid * per < p.n_targets ? tid * per : p.n_targets;
+        const uint32_t hi  = lo + per < p.n_targets ? lo + per : p.n_targets;
+        auto           summed = [&](uint32_t t) -> uint64_t {
+            uint64_t c = 0;
+            if (!p.tgt_off)
+                c = cnt[t];
+            else
+                for (uint32_t e = p.tgt_off[t]; e < p.tgt_off[t + 1]; ++e)
+                    c += cnt[p.tgt_bins[e]];
+            return c > n ? (uint64_t)n : c; // :525-526
+        };
+        uint32_t mine = 0;
+        for (uint32_t t = lo; t < hi; ++t)
+            mine += summed(t) >= T ? 1u : 0u;
+        part[tid] = mine;
+        __syncthreads();
+        if (tid == 0)
+        {
+            uint32_t run = 0;
+            for (uint32_t i = 0; i < 256; ++i)
+            {
+                const uint32_t c = part[i];
+                part[i]          = run;
+                run += c;
+            }
+            base_sh = run ? atomicAdd(p.cursor, (unsigned long long)run) : 0ull;
+            for (uint32_t sl = 0; sl < p.wpr; ++sl)
+            {
+                p.seg_begin[(size_t)read * p.wpr + sl] = sl == 0 ? base_sh : 0ull;
+                p.seg_count[(size_t)read * p.wpr + sl] = sl == 0 ? run : 0u;
+            }
+            total_sh = run;
+        }
+        __syncthreads();
+        const uint32_t           total = total_sh;
+        const unsigned long long base  = base_sh;
+        if (base + total <= p.match_cap)
+        {
+            uint32_t k = part[tid];
+            for (uint32_t t = lo; t < hi; ++t)
+            {
+                const uint64_t c = summed(t);
+                if (c >= T)
+                {
+                    gn_match mt;
+                    mt.read   = read;
+                    mt.target = p.tgt_ids ? p.tgt_ids[t] : t;
+                    mt.count  = (uint32_t)c;
+                    p.matches[base + k++] = mt;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t gn_launch_count_long(const GnCountParams& p, uint32_t hash_funs, uint32_t* list, unsigned long long* count, uint32_t* scratch,
+                                uint32_t blocks, hipStream_t st)
+{
+    const uint32_t n = p.n_reads - p.read_begin;
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(gn_long_list_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.status, p.read_begin, p.n_reads, list, count);
+    GnCountParams q = p;
+    q.work_list  = list;
+    q.work_count = count;
+    q.early_exit = hash_funs;
+    hipLaunchKernelGGL(gn_ibf_count_long_kernel, dim3(blocks), dim3(256), 0, st, q, scratch);
+    return hipGetLastError();
+}
+
+// ================================================================================================
 // emplace (GPU side of the fixture/bench filter builder): set bit (row_i(v), bin) for i < h
 // ================================================================================================
 __global__ void gn_emplace_kernel(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h,

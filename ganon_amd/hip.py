@@ -19,7 +19,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_pinned_free", "gn_filter_write_rows", "gn_filter_write_sync", "gn_filter_finalize",
                "gn_filter_fill_random", "gn_filter_info", "gn_filter_free", "gn_stream_create", "gn_stream_destroy",
                "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch", "gn_stream_set_postfilter",
-               "gn_fetch_postfilter", "gn_stream_device_matches",
+               "gn_fetch_postfilter", "gn_stream_set_long_reads", "gn_stream_device_matches",
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
                "gn_stream_timings"]
 
@@ -89,6 +89,7 @@ def load_library():
     L.gn_stream_device_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.gn_stream_set_postfilter.argtypes = [vp, vp]
     L.gn_fetch_postfilter.argtypes = [vp, vp, C.POINTER(u64), C.POINTER(u64)]
+    L.gn_stream_set_long_reads.argtypes = [vp, i32]
     L.gn_stream_fetch_hashes.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.gn_stream_distinct_hashes.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.gn_filter_emplace_split.argtypes = [vp, vp, u64, u32, u64]
@@ -287,6 +288,10 @@ class HipStream:
         tf = None if target_fpr is None else np.ascontiguousarray(target_fpr, dtype=np.float64)
         pf = PostFilter(float(rel_filter), float(fpr_query), None if tf is None else tf.ctypes.data_as(C.c_void_p))
         _check(L.gn_stream_set_postfilter(self._h, C.byref(pf)))
+
+    def set_long_reads(self, on: bool = True) -> None:
+        """classify reads with more than 65535 minimisers too (the reference's -DLONGREADS build); flat IBF only"""
+        _check(load_library().gn_stream_set_long_reads(self._h, 1 if on else 0))
 
     def fetch_postfilter(self):
         """-> (max_count u32[n] before filtering, dropped by --rel-filter, dropped by --fpr-query) of the last batch"""

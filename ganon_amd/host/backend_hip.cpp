@@ -281,6 +281,11 @@ public:
                     part.stream_reads = cr;
                     part.stream_bases = cb;
                     part.pf_generation = 0;
+                    if (long_reads_ && !filters_[i].is_hibf && gn_stream_set_long_reads(part.s, 1) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
                 }
                 if (part.pf_generation != pf_generation_)
                 {
@@ -357,6 +362,16 @@ public:
         std::ostringstream os;
         os << "HIP device " << device_ << " (libganon_hip, gfx950)";
         return os.str();
+    }
+
+    bool set_long_reads(bool on) override
+    {
+        long_reads_ = on;
+        for (auto& lf : filters_) // (streams that exist already; new ones get it when they are created)
+            for (auto& part : lf.parts)
+                if (part.s && !lf.is_hibf)
+                    gn_stream_set_long_reads(part.s, on ? 1 : 0);
+        return true;
     }
 
     bool set_postfilter(const PostFilterSpec* spec) override
@@ -467,6 +482,7 @@ private:
 
     int                   device_;
     HipBackend*           primary_ = nullptr;
+    bool                  long_reads_ = false;
     Stage                 stage_[2];
     std::vector<Logical>  filters_;
     std::vector<gn_match> tmp_;

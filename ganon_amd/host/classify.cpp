@@ -613,6 +613,17 @@ static bool ganon_classify(Config config)
         std::cerr << "ERROR: " << err << std::endl;
         return false;
     }
+    if (config.long_reads)
+    {
+        if (config.hibf && !config.quiet)
+            std::cerr << "WARNING: --long-reads has no effect on HIBF filters (reads with more than 65535 minimisers stay skipped)" << std::endl;
+        for (auto& b : backends)
+            if (!b->set_long_reads(true))
+            {
+                std::cerr << "ERROR: --long-reads is not supported by this backend" << std::endl;
+                return false;
+            }
+    }
     const size_t n_workers = backends.size();
     if (config.verbose)
         for (auto& b : backends)

@@ -171,6 +171,12 @@ int gn_stream_sync(gn_stream* s);
 int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status, uint64_t* match_off, gn_match* matches,
                    uint64_t cap, uint64_t* n_matches);
 
+/* Reads with more than 65535 minimisers.  By default they come back with status GN_READ_BIG and no matches, like the
+ * reference's default build (TIntCount = uint16_t, GanonClassify.cpp:45-49,674).  on != 0 gives what the reference does when
+ * compiled with -DLONGREADS (uint32 counters): such reads are counted with 32-bit counters by a kernel of their own, come
+ * back with status GN_READ_OK, and their match counts may exceed 65535.  Flat IBF filters only (GN_ERANGE for an HIBF). */
+int gn_stream_set_long_reads(gn_stream* s, int on);
+
 /* Optional device-side pre-pass of filter_matches (/root/reference/src/ganon-classify/GanonClassify.cpp:579-613 with the
  * threshold of :755-761) on every following batch of this stream: with max/min = the read's largest/smallest match count
  * (min starts at n_hashes, :704), matches below max - ceil((max-min)*rel_filter) are dropped (exact), and, if fpr_query < 1,

@@ -480,3 +480,30 @@ def test_wide_filter_hip_column_parts_equal_oracle_backend(oracle_bin, wide_db, 
     b = _run_wide(oracle_bin, wide_db, str(tmp_path / "ora"))
     for ext in (".all", ".unc", ".rep"):
         assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext
+
+
+@pytest.mark.gpu
+def test_long_reads_flag(tmp_path):
+    # a read with more than 65535 minimisers: skipped by default (the reference's default build, GanonClassify.cpp:45-49,674),
+    # classified with --long-reads (its -DLONGREADS=ON build) with a count no 16-bit counter holds
+    import numpy as np
+    rng = np.random.default_rng(8)
+    genome = "".join("ACGT"[x] for x in rng.integers(0, 4, size=640_000))
+    other = "".join("ACGT"[x] for x in rng.integers(0, 4, size=30_000))
+    built = gf.build_ibf({"BIG.1": genome, "OTHER.1": other}, 19, 31, max_fp=0.01, hash_functions=3)
+    ibf = str(tmp_path / "long.ibf")
+    gf.write_ibf(ibf, built)
+    fa = str(tmp_path / "reads.fa")
+    gf.write_fasta(fa, [("long_read", genome[2000:632_000]), ("short_read", genome[100:250]), ("other_read", other[500:700])])
+    outs = {}
+    for tag, extra in (("default", []), ("long", ["--long-reads"])):
+        prefix = str(tmp_path / tag)
+        cu.run(cu.BIN_HIP, ["--ibf", ibf, "--single-reads", fa, "-o", prefix, "--output-all", "--output-unclassified", "--skip-lca",
+                            "--rel-cutoff", "0.5", "--quiet"] + extra)
+        rows = [line.rstrip("\n").split("\t") for line in open(prefix + ".all")]
+        outs[tag] = ({r[0]: (r[1], int(r[2])) for r in rows}, open(prefix + ".unc").read().split())
+    assert set(outs["default"][0]) == {"short_read", "other_read"} and outs["default"][1] == ["long_read"]
+    assert set(outs["long"][0]) == {"long_read", "short_read", "other_read"} and outs["long"][1] == []
+    assert outs["long"][0]["long_read"][0] == "BIG.1" and outs["long"][0]["long_read"][1] > 65535
+    for r in ("short_read", "other_read"):
+        assert outs["long"][0][r] == outs["default"][0][r]

@@ -748,3 +748,76 @@ def test_postfilter_survives_match_buffer_regrow_and_empty_batches(hip):
     for s in (ref, small):
         s.destroy()
     flt.free()
+
+
+@pytest.mark.parametrize("split_map", [False, True])
+def test_long_reads_option_classifies_what_the_default_skips(hip, split_map):
+    # reads with more than 65535 minimisers: GN_READ_BIG by default (TIntCount = uint16_t, GanonClassify.cpp:45-49,674);
+    # with gn_stream_set_long_reads they are counted with 32-bit counters like the reference's -DLONGREADS build
+    k, w = 19, 31
+    rng = np.random.default_rng(31)
+    bins, rows, h = 300, 40009, 3
+    ibf = gf.random_ibf(bins, rows, h, 0.2, seed=4)
+    genome = gu.random_seq(rng, 620_000)
+    gh = np.unique(oracle.minimiser_hash(oracle.to_ranks(genome), k, w))
+    ibf.emplace_many(gh[: len(gh) // 2], 17)
+    ibf.emplace_many(gh[len(gh) // 2:], 18)
+    n_targets = 120 if split_map else bins
+    b2t = None
+    if split_map:
+        b2t = rng.integers(0, n_targets, size=bins).astype(np.uint32)
+        b2t[17] = b2t[18] = 5  # the genome's two bins belong to one target
+        b2t[rng.integers(0, bins, size=10)] = 0xFFFFFFFF
+        b2t[17] = b2t[18] = 5
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
+    s1 = [genome[1000:601_000], gu.random_seq(rng, 560_000), genome[:300_000], gu.random_seq(rng, 150), genome[5000:5150]]
+    s2 = [b"", b"", genome[300_000:600_000], b"", b""]
+    for paired in (False, True):
+        bases, off1, off2 = gu.pack_reads(s1, s2 if paired else None)
+        st = hip.HipStream(flt, len(s1), bases.size)
+        for cutoff in (0.0, 0.3, 0.9):
+            st.set_long_reads(False)
+            st.submit(bases, off1, off2, k, w, cutoff)
+            nh0, status0, mo0, m0 = st.fetch()
+            st.set_long_reads(True)
+            st.submit(bases, off1, off2, k, w, cutoff)
+            nh, status, mo, m = st.fetch()
+            assert np.array_equal(nh, nh0)
+            big = [i for i in range(len(s1)) if nh[i] > 65535]
+            assert big == ([0, 1, 2] if paired else [0, 1])
+            for i in range(len(s1)):
+                got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+                if i not in big:  # untouched by the option
+                    assert status[i] == status0[i]
+                    assert got == [(int(x["target"]), int(x["count"])) for x in m0[int(mo0[i]):int(mo0[i + 1])]]
+                    continue
+                assert status0[i] == 2 and mo0[i] == mo0[i + 1] and status[i] == 0
+                hh = oracle.minimiser_hash(oracle.to_ranks(s1[i]), k, w)
+                if paired and len(s2[i]) >= w:
+                    hh = np.concatenate([hh, oracle.minimiser_hash(oracle.to_ranks(s2[i]), k, w)])
+                assert len(hh) == nh[i]
+                counts = np.zeros(bins, dtype=np.uint64)
+                for a in range(0, len(hh), 60000):  # uint16 counters cannot wrap within 60000 hashes
+                    counts += ibf.bulk_count(hh[a:a + 60000]).astype(np.uint64)
+                T = max(1, oracle.threshold_rel(len(hh), cutoff))
+                exp = []
+                for t in range(n_targets):
+                    c = int(counts[t]) if b2t is None else int(counts[b2t == t].sum())
+                    c = min(c, len(hh))
+                    if c >= T:
+                        exp.append((t, c))
+                assert got == exp, (paired, cutoff, i, got[:4], exp[:4])
+                if i != 1:
+                    assert any(c > 65535 for _, c in got)  # the planted genome: a count no uint16 holds
+        st.destroy()
+    flt.free()
+
+
+def test_long_reads_option_is_refused_for_hibf(hip):
+    hb = gf.random_hibf(50, 64, 1, seed=2, density=0.2, hash_funs=2)
+    flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+    st = hip.HipStream(flt, 4, 1000)
+    with pytest.raises(hip.GanonHipError):
+        st.set_long_reads(True)
+    st.destroy()
+    flt.free()
