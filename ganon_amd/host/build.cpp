@@ -420,8 +420,10 @@ public:
     }
 
 private:
-    static constexpr uint64_t kMaxBases  = 256ull << 20;
-    static constexpr uint32_t kMaxPieces = 1u << 20;
+    // one device batch: enough for a bacterial genome in one go; every parser thread has its own (page-locked) copy, so the
+    // size is also what start-up pays per thread
+    static constexpr uint64_t kMaxBases  = 64ull << 20;
+    static constexpr uint32_t kMaxPieces = 1u << 18;
 
     void run(uint32_t w, std::vector<uint64_t>& out)
     {

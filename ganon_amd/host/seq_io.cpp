@@ -476,6 +476,13 @@ bool SeqReader::next(std::string& ids, ByteBuf& bases)
                 s.have_pending = true;
                 break;
             }
+            // a line of nothing but legal letters (every line of an ordinary genome file) is appended in one piece;
+            // whitespace, digits and illegal letters take the character-wise path (a legal letter is neither)
+            if (all_legal(l.data(), l.size()))
+            {
+                bases.insert(bases.end(), reinterpret_cast<const uint8_t*>(l.data()), reinterpret_cast<const uint8_t*>(l.data()) + l.size());
+                continue;
+            }
             for (char c : l)
             {
                 if (std::isspace((unsigned char)c) || std::isdigit((unsigned char)c))
