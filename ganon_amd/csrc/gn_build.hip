@@ -176,10 +176,18 @@ extern "C" int gn_filter_emplace_split(gn_filter* f, const uint64_t* hashes, uin
     GN_HIP(hipSetDevice(f->device));
     if (!f->load_st)
         GN_HIP(hipStreamCreateWithFlags(&f->load_st, hipStreamNonBlocking));
-    // staged through a device buffer that stays with the filter, 32 M hashes at a time
-    const uint64_t step = 32ull << 20;
-    if (!f->d_emplace_stage)
+    // staged through a device buffer that stays with the filter (grown to the largest request so far), at most 32 M hashes
+    // at a time
+    const uint64_t step = n < (32ull << 20) ? n : (32ull << 20);
+    if (f->emplace_stage_cap < step)
+    {
+        if (f->d_emplace_stage)
+            hipFree(f->d_emplace_stage);
+        f->d_emplace_stage   = nullptr;
+        f->emplace_stage_cap = 0;
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&f->d_emplace_stage), step * 8));
+        f->emplace_stage_cap = step;
+    }
     for (uint64_t done = 0; done < n; done += step)
     {
         const uint64_t c = n - done < step ? n - done : step;

@@ -178,6 +178,7 @@ struct gn_filter
     uint64_t device_bytes = 0;
     hipStream_t load_st = nullptr; // streaming upload (gn_filter_write_rows), created on first use
     uint64_t*   d_emplace_stage = nullptr; // gn_filter_emplace_split's staging buffer
+    uint64_t    emplace_stage_cap = 0;     // ... and its capacity in hashes
     // flat
     GnIbfHost       ibf;
     uint32_t*       d_tgt_off  = nullptr;

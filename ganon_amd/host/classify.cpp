@@ -310,6 +310,95 @@ size_t env_size(const char* name, size_t dflt)
     return v ? (size_t)std::max(0LL, std::atoll(v)) : dflt;
 }
 
+// Second mates of a batch of pairs: the reader thread only notes which records of file 2's slabs belong to the batch; a few
+// threads of this pool append them behind the first mates (one copy, straight into the batch's page-locked buffer), fill in
+// the mate offsets and hand the batch to the device workers.  Batches carry their input-order number, so they may reach
+// the queue in any order.
+class MateCopier
+{
+public:
+    struct Part
+    {
+        std::shared_ptr<ParallelFastq::Slab> slab;
+        size_t                               first, count;
+    };
+    MateCopier(BatchQueue& out, unsigned threads) : out_(out)
+    {
+        for (unsigned t = 0; t < threads; ++t)
+            th_.emplace_back([this] { run(); });
+    }
+    ~MateCopier()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_)
+            t.join();
+    }
+    void submit(ReadBatch&& rb, std::vector<Part>&& parts)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return q_.size() + busy_ < 2 * th_.size() + 2; });
+        q_.emplace_back(std::move(rb), std::move(parts));
+        cv_.notify_all();
+    }
+    void drain() // every submitted batch is in the queue
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return q_.empty() && busy_ == 0; });
+    }
+    // appends the parts' bases behind dst and their end offsets (absolute positions in dst) to off2
+    static void materialise(const std::vector<Part>& parts, ByteBuf& dst, std::vector<uint64_t>& off2)
+    {
+        for (const Part& p : parts)
+        {
+            const auto&    sl   = *p.slab;
+            const uint64_t from = sl.off[p.first], at = dst.size();
+            dst.insert(dst.end(), sl.bases.begin() + from, sl.bases.begin() + sl.off[p.first + p.count]);
+            for (size_t j = 1; j <= p.count; ++j)
+                off2.push_back(at + (sl.off[p.first + j] - from));
+        }
+    }
+
+private:
+    void run()
+    {
+        for (;;)
+        {
+            std::pair<ReadBatch, std::vector<Part>> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !q_.empty() || stop_; });
+                if (q_.empty())
+                    return;
+                job = std::move(q_.front());
+                q_.pop_front();
+                ++busy_;
+            }
+            ReadBatch& rb = job.first;
+            rb.off2.assign(1, rb.bases.size()); // mates follow the first mates in the same buffer (finalize_batch's layout)
+            rb.off2.reserve(rb.size() + 1);
+            materialise(job.second, rb.bases, rb.off2);
+            job.second.clear(); // (releases the slabs: the last user hands a slab back to its parser)
+            out_.push(std::move(rb));
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                --busy_;
+            }
+            cv_.notify_all();
+        }
+    }
+    BatchQueue&                                         out_;
+    std::mutex                                          m_;
+    std::condition_variable                             cv_;
+    std::deque<std::pair<ReadBatch, std::vector<Part>>> q_;
+    size_t                                              busy_ = 0;
+    bool                                                stop_ = false;
+    std::vector<std::thread>                            th_;
+};
+
 // the reader thread (:1220-1287): files -> large batches, numbered in input order.
 // Uncompressed four-line FASTQ is parsed by several threads (ParallelFastq, seq_io.hpp): for single-end files a parsed
 // slab IS the batch (no copy); for pairs the slabs of file 1 become batches and the mates are copied next to them from
@@ -318,6 +407,7 @@ size_t env_size(const char* name, size_t dflt)
 void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan)
 {
     uint64_t       seq = 0;
+    MateCopier     copier(queue, (unsigned)env_size("GANON_HOST_MATE_THREADS", 3));
     const unsigned par_threads = (unsigned)env_size("GANON_HOST_PARSE_THREADS", 6);
     const size_t   slab_bytes  = env_size("GANON_HOST_SLAB_BYTES", 48u << 20);
     const size_t   par_min     = env_size("GANON_HOST_PARALLEL_MIN", 32u << 20);
@@ -366,11 +456,24 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             uint64_t resume1 = 0, resume2 = 0; // where the sequential reader takes over (0 = from the start)
             bool     file_done = false, fallback = false;
             {
-                auto pf1 = ParallelFastq::open(pair.mate1, paired ? std::max(1u, par_threads / 2) : par_threads, slab_bytes, par_min);
-                auto pf2 = paired && pf1 ? ParallelFastq::open(pair.mate2, std::max(1u, par_threads / 2), slab_bytes, 0) : nullptr;
+                auto pf1 = ParallelFastq::open(pair.mate1, paired ? std::max(1u, par_threads / 2) : par_threads, slab_bytes, par_min, paired);
+                std::shared_ptr<ParallelFastq> pf2(paired && pf1 ? ParallelFastq::open(pair.mate2, std::max(1u, par_threads / 2), slab_bytes, 0)
+                                                                 : nullptr);
                 if (paired && !pf2)
                     pf1.reset();
-                ParallelFastq::Slab a, b;
+                // file 2's slabs are shared with the mate copier; whoever lets go of one last hands it back to its parser
+                auto new_b = [&]() {
+                    return pf2 ? std::shared_ptr<ParallelFastq::Slab>(new ParallelFastq::Slab(),
+                                                                      [pf2](ParallelFastq::Slab* p) {
+                                                                          pf2->recycle(std::move(*p));
+                                                                          delete p;
+                                                                      })
+                               : std::make_shared<ParallelFastq::Slab>();
+                };
+                ParallelFastq::Slab                  a;
+                std::shared_ptr<ParallelFastq::Slab> bcur = new_b();
+                ParallelFastq::Slab*                 bp   = bcur.get();
+                std::vector<MateCopier::Part>        parts; // mates of the current batch that the copier will fetch
                 size_t              bpos = 0;       // next unread mate of slab b
                 bool                b_open = true;  // file 2 may still deliver slabs
                 bool                b_end = false;  // file 2 is exhausted (mates stay empty, like the sequential reader at EOF)
@@ -378,24 +481,27 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                 bool                b_irregular = false;
                 // makes sure slab b has an unread mate; false when file 2 cannot deliver one (end / error / irregular)
                 auto mate_ready = [&]() -> bool {
-                    while (bpos >= b.size())
+                    while (bpos >= bp->size())
                     {
-                        if (!b.error.empty())
+                        if (!bp->error.empty())
                         {
-                            b_error = b.error;
+                            b_error = bp->error;
                             return false;
                         }
-                        if (b.irregular)
+                        if (bp->irregular)
                         {
                             b_irregular = true;
                             return false;
                         }
-                        if (!b_open || !pf2->next(b))
+                        auto nb = new_b();
+                        if (!b_open || !pf2->next(*nb))
                         {
                             b_open = false;
                             b_end  = true;
                             return false;
                         }
+                        bcur = std::move(nb);
+                        bp   = bcur.get();
                         bpos = 0;
                     }
                     return true;
@@ -431,13 +537,42 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                         if (paired)
                         {
                             rb.off2.assign(1, 0);
-                            for (size_t i = 0; i < taken; ++i)
+                            rb.off2.reserve(taken + 1);
+                            size_t i = 0;
+                            // mates of a run of records that file 2's current slab holds: one copy, offsets rebased in a
+                            // loop of additions (the record-by-record code below takes over where file 2 ends, fails or
+                            // turns irregular)
+                            parts.clear();
+                            while (i < taken && !b_end && (bpos < bp->size() || mate_ready()))
+                            {
+                                const size_t run = std::min(taken - i, bp->size() - bpos);
+                                parts.push_back(MateCopier::Part{ bcur, bpos, run });
+                                bpos += run;
+                                i += run;
+                            }
+                            if (i == taken && !parts.empty())
+                            {
+                                // the usual case: every mate is there.  The copier threads do the copying.
+                                {
+                                    std::lock_guard<std::mutex> lk(report_mutex);
+                                    report.count_input(prefix, rb.size()); // :1253,1272
+                                }
+                                rb.seq = seq++;
+                                copier.submit(std::move(rb), std::move(parts));
+                                parts.clear();
+                                fresh();
+                                r0 += taken;
+                                continue;
+                            }
+                            MateCopier::materialise(parts, bases2, rb.off2); // file 2 ended / failed: finish here, record by record
+                            parts.clear();
+                            for (; i < taken; ++i)
                             {
                                 if (b_end || mate_ready())
                                 {
                                     if (!b_end)
                                     {
-                                        bases2.insert(bases2.end(), b.bases.begin() + b.off[bpos], b.bases.begin() + b.off[bpos + 1]);
+                                        bases2.insert(bases2.end(), bp->bases.begin() + bp->off[bpos], bp->bases.begin() + bp->off[bpos + 1]);
                                         ++bpos;
                                     }
                                     rb.off2.push_back(bases2.size());
@@ -459,7 +594,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                                 if (b_irregular)
                                 {
                                     resume1  = a.rec_at[r0 + keep];
-                                    resume2  = b.resume_at;
+                                    resume2  = bp->resume_at;
                                     fallback = true;
                                 }
                                 taken     = keep;
@@ -492,10 +627,10 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                         if (paired)
                         {
                             // the mate of the first unparsed record of file 1: the next unread record of file 2
-                            if (bpos < b.size() || mate_ready())
-                                resume2 = b.rec_at[bpos];
+                            if (bpos < bp->size() || mate_ready())
+                                resume2 = bp->rec_at[bpos];
                             else if (b_irregular)
-                                resume2 = b.resume_at;
+                                resume2 = bp->resume_at;
                             else if (!b_error.empty())
                             {
                                 report_error(b_error); // (file 2 fails before file 1 continues)
@@ -553,6 +688,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             }
         }
     }
+    copier.drain();
     queue.done();
 }
 

@@ -608,6 +608,7 @@ struct ParallelFastq::Impl
     std::vector<Slab>        free_slabs;
     size_t                   next_to_parse = 0, next_to_take = 0, window = 0;
     bool                     stop = false, ended = false;
+    bool                     mate_room = false;
 
     // first byte of the first record at or after p (== size when there is none): a line that begins with '@' and whose
     // next-but-one line begins with '+'
@@ -641,7 +642,7 @@ struct ParallelFastq::Impl
     void parse(RangeLines& in, size_t begin, size_t end, Slab& out) const
     {
         out.ids.reserve((end - begin) / 8);
-        out.bases.reserve((end - begin) / 2);
+        out.bases.reserve(mate_room ? (end - begin) + (end - begin) / 16 : (end - begin) / 2);
         out.rec_at.reserve((end - begin) / 256);
         in.seek(begin);
         while (in.tell() < end)
@@ -741,7 +742,8 @@ struct ParallelFastq::Impl
 
 ParallelFastq::ParallelFastq(Impl* i) : impl_(i) {}
 
-std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes)
+std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
+                                                   bool mate_room)
 {
     if (!(ends_with(path, ".fq") || ends_with(path, ".fastq")) || threads == 0)
         return nullptr;
@@ -762,6 +764,7 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     im->slab_bytes = std::max<size_t>(slab_bytes, 1 << 16);
     im->n_slabs    = (im->size + im->slab_bytes - 1) / im->slab_bytes;
     im->window     = 2 * threads + 2;
+    im->mate_room  = mate_room;
     std::unique_ptr<ParallelFastq> pf(new ParallelFastq(im));
     for (unsigned t = 0; t < threads; ++t)
         im->workers.emplace_back([im] { im->work(); });

@@ -63,7 +63,10 @@ public:
         size_t                size() const { return off.size() - 1; }
     };
     // nullptr when the file is not eligible (compressed, not FASTQ by extension, smaller than min_bytes, cannot be mapped)
-    static std::unique_ptr<ParallelFastq> open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes);
+    // mate_room: the slabs' base buffers are reserved with room for as many bases again (the first file of a pair: the
+    // mates are appended behind them when the slab becomes a batch -- without the room that append re-locks pages)
+    static std::unique_ptr<ParallelFastq> open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
+                                               bool mate_room = false);
     ~ParallelFastq();
     bool next(Slab& out); // slabs in file order; false at the end of the file (or after an error / irregular slab)
     void recycle(Slab&& used); // hands a consumed slab's buffers back to the parser threads

@@ -53,6 +53,13 @@ rec[:, -1] = ord("\n")
 fq = os.path.join(d, "ganon_e2e.fq")
 rec.tofile(fq)
 out["fastq_gib"] = round(os.path.getsize(fq) / 2**30, 2)
+READS = ["--single-reads", fq]
+if os.environ.get("E2E_PAIRED"):  # a mate file: the same records, bases of the neighbouring read (content does not matter here)
+    rec[:, 12:12 + L] = np.roll(wl.bases.reshape(n, L), 1, axis=0)
+    fq2 = os.path.join(d, "ganon_e2e.2.fq")
+    rec.tofile(fq2)
+    READS = ["--paired-reads", fq + "," + fq2]
+    out["paired"] = True
 del rec
 
 exe = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
@@ -65,7 +72,7 @@ for label, dev, parse_threads in runs:
     env = dict(os.environ, GANON_HOST_TIMING="1")
     if parse_threads:
         env["GANON_HOST_PARSE_THREADS"] = str(parse_threads)
-    p = subprocess.run([exe, "--ibf", ibf, "--single-reads", fq, "-o", prefix, "--output-all", "--verbose"] + (["--device", dev] if dev else []) + EXTRA,
+    p = subprocess.run([exe, "--ibf", ibf] + READS + ["-o", prefix, "--output-all", "--verbose"] + (["--device", dev] if dev else []) + EXTRA,
                        capture_output=True, text=True, env=env)
     r = {"rc": p.returncode, "wall_s": round(time.time() - t0, 2)}
     for key, pat in (("load_s", r"loading filter\(s\)\s+elapsed \(s\): ([0-9.eE+-]+)"),
