@@ -312,8 +312,8 @@ size_t env_size(const char* name, size_t dflt)
 
 // Second mates of a batch of pairs: the reader thread only notes which records of file 2's slabs belong to the batch; a few
 // threads of this pool append them behind the first mates (one copy, straight into the batch's page-locked buffer), fill in
-// the mate offsets and hand the batch to the device workers.  Batches carry their input-order number, so they may reach
-// the queue in any order.
+// the mate offsets and hand the batch to the device workers.  Batches carry their input-order number and reach
+// the queue through deliver(), which keeps that order.
 class MateCopier
 {
 public:
@@ -349,6 +349,20 @@ public:
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return q_.empty() && busy_ == 0; });
     }
+    // Batches enter the queue in input order, whichever thread finished them (the reader's own batches come through here
+    // too): a device worker that held batch k+5 while batch k was still being copied would wait for its turn for ever.
+    void deliver(ReadBatch&& rb)
+    {
+        std::lock_guard<std::mutex> lk(order_m_);
+        const uint64_t seq = rb.seq;
+        held_.emplace(seq, std::move(rb));
+        for (auto it = held_.find(next_seq_); it != held_.end(); it = held_.find(next_seq_))
+        {
+            out_.push(std::move(it->second));
+            held_.erase(it);
+            ++next_seq_;
+        }
+    }
     // appends the parts' bases behind dst and their end offsets (absolute positions in dst) to off2
     static void materialise(const std::vector<Part>& parts, ByteBuf& dst, std::vector<uint64_t>& off2)
     {
@@ -382,7 +396,7 @@ private:
             rb.off2.reserve(rb.size() + 1);
             materialise(job.second, rb.bases, rb.off2);
             job.second.clear(); // (releases the slabs: the last user hands a slab back to its parser)
-            out_.push(std::move(rb));
+            deliver(std::move(rb));
             {
                 std::lock_guard<std::mutex> lk(m_);
                 --busy_;
@@ -391,6 +405,9 @@ private:
         }
     }
     BatchQueue&                                         out_;
+    std::mutex                                          order_m_;
+    std::map<uint64_t, ReadBatch>                       held_;
+    uint64_t                                            next_seq_ = 0;
     std::mutex                                          m_;
     std::condition_variable                             cv_;
     std::deque<std::pair<ReadBatch, std::vector<Part>>> q_;
@@ -444,7 +461,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                 }
                 finalize_batch(rb, bases2);
                 rb.seq = seq++;
-                queue.push(std::move(rb));
+                copier.deliver(std::move(rb));
                 fresh();
             };
             auto report_error = [&](const std::string& what) { // :1278-1283: report, keep what was read, go on with the next file

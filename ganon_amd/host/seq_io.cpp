@@ -609,6 +609,7 @@ struct ParallelFastq::Impl
     size_t                   next_to_parse = 0, next_to_take = 0, window = 0;
     bool                     stop = false, ended = false;
     bool                     mate_room = false;
+    bool                     fasta = false; // records start at lines that begin with '>' (no sequence line can: '>' is no legal letter)
 
     // first byte of the first record at or after p (== size when there is none): a line that begins with '@' and whose
     // next-but-one line begins with '+'
@@ -627,6 +628,12 @@ struct ParallelFastq::Impl
             const uint64_t o0 = in.tell();
             if (!in.line(l))
                 return size;
+            if (fasta)
+            {
+                if (!l.empty() && l[0] == '>')
+                    return (size_t)o0;
+                continue;
+            }
             if (l.empty() || l[0] != '@')
                 continue;
             const uint64_t o1 = in.tell();
@@ -639,11 +646,86 @@ struct ParallelFastq::Impl
         }
     }
 
+    // FASTA records of [begin, end): header line, then sequence lines up to the next header (a record that starts before
+    // `end` is read to its end).  Same letters, same skipping of white space and digits, same errors as the sequential
+    // reader; a ';' header or a first line that is no header hands over to it.
+    void parse_fasta(RangeLines& in, size_t begin, size_t end, Slab& out) const
+    {
+        in.seek(begin);
+        std::string_view l;
+        while (in.tell() < end)
+        {
+            const uint64_t rec = in.tell();
+            out.rec_at.push_back(rec);
+            if (!in.line(l) || l.empty() || l[0] != '>')
+            {
+                out.irregular = true;
+                out.resume_at = rec;
+                return;
+            }
+            out.ids.append(l.data() + 1, l.size() - 1);
+            for (;;)
+            {
+                const uint64_t at_line = in.tell();
+                if (!in.line(l))
+                    break; // end of the file
+                if (!l.empty() && l[0] == '>')
+                {
+                    in.seek(at_line); // the next record's header
+                    break;
+                }
+                if (!l.empty() && l[0] == ';')
+                {
+                    out.ids.resize(out.id_off.back());
+                    out.bases.resize(out.off.back());
+                    out.irregular = true;
+                    out.resume_at = rec;
+                    return;
+                }
+                if (all_legal(l.data(), l.size()))
+                {
+                    out.bases.insert(out.bases.end(), reinterpret_cast<const uint8_t*>(l.data()),
+                                     reinterpret_cast<const uint8_t*>(l.data()) + l.size());
+                    continue;
+                }
+                for (char c : l)
+                {
+                    if (std::isspace((unsigned char)c) || std::isdigit((unsigned char)c))
+                        continue;
+                    if (!kLegal.ok[(unsigned char)c])
+                    {
+                        out.ids.resize(out.id_off.back());
+                        out.bases.resize(out.off.back());
+                        try
+                        {
+                            bad_letter(std::string_view(&c, 1));
+                        }
+                        catch (ParseError const& x)
+                        {
+                            out.error = x.what();
+                        }
+                        return;
+                    }
+                    out.bases.push_back((uint8_t)c);
+                }
+            }
+            out.id_off.push_back(out.ids.size());
+            out.off.push_back(out.bases.size());
+        }
+        out.rec_at.push_back(in.tell());
+    }
+
     void parse(RangeLines& in, size_t begin, size_t end, Slab& out) const
     {
         out.ids.reserve((end - begin) / 8);
-        out.bases.reserve(mate_room ? (end - begin) + (end - begin) / 16 : (end - begin) / 2);
+        const size_t expect = fasta ? (end - begin) + 4096 : (end - begin) / 2; // bases of this slab, roughly
+        out.bases.reserve(mate_room ? 2 * expect + expect / 8 : expect);
         out.rec_at.reserve((end - begin) / 256);
+        if (fasta)
+        {
+            parse_fasta(in, begin, end, out);
+            return;
+        }
         in.seek(begin);
         while (in.tell() < end)
         {
@@ -745,7 +827,10 @@ ParallelFastq::ParallelFastq(Impl* i) : impl_(i) {}
 std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
                                                    bool mate_room)
 {
-    if (!(ends_with(path, ".fq") || ends_with(path, ".fastq")) || threads == 0)
+    bool fasta = false;
+    for (const char* e : { ".fa", ".fasta", ".fna", ".ffn", ".faa", ".frn", ".fas" })
+        fasta = fasta || ends_with(path, e);
+    if (!(fasta || ends_with(path, ".fq") || ends_with(path, ".fastq")) || threads == 0)
         return nullptr;
     const int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0)
@@ -765,6 +850,7 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     im->n_slabs    = (im->size + im->slab_bytes - 1) / im->slab_bytes;
     im->window     = 2 * threads + 2;
     im->mate_room  = mate_room;
+    im->fasta      = fasta;
     std::unique_ptr<ParallelFastq> pf(new ParallelFastq(im));
     for (unsigned t = 0; t < threads; ++t)
         im->workers.emplace_back([im] { im->work(); });

@@ -54,6 +54,14 @@ fq = os.path.join(d, "ganon_e2e.fq")
 rec.tofile(fq)
 out["fastq_gib"] = round(os.path.getsize(fq) / 2**30, 2)
 READS = ["--single-reads", fq]
+if os.environ.get("E2E_FASTA"):  # the same reads as a FASTA file (sequential reader: no four-line structure to cut slabs at)
+    fa = os.path.join(d, "ganon_e2e.fa")
+    rec2 = rec[:, :12 + L + 1].copy()
+    rec2[:, 0] = ord(">")
+    rec2.tofile(fa)
+    READS = ["--single-reads", fa]
+    out["fasta"] = True
+    del rec2
 if os.environ.get("E2E_PAIRED"):  # a mate file: the same records, bases of the neighbouring read (content does not matter here)
     rec[:, 12:12 + L] = np.roll(wl.bases.reshape(n, L), 1, axis=0)
     fq2 = os.path.join(d, "ganon_e2e.2.fq")

@@ -262,3 +262,62 @@ def test_parallel_fastq_equals_sequential_reader(oracle_bin, sim_db, tmp_path, p
         assert par_out == seq_out, (variant, slab)
         assert ("Error parsing" in par_err) == ("Error parsing" in seq_err) == (variant in ("bad_letter", "mate_bad"))
     assert seq_out[".all"].count(b"\n") > 100
+
+
+def _fasta_text(recs, variant):
+    nl = "\r\n" if variant == "crlf" else "\n"
+    out = []
+    for i, (rid, seq) in enumerate(recs):
+        if variant == "lower_iupac" and i % 4 == 0:
+            seq = seq.lower().replace("a", "r", 1).replace("c", "y", 1)
+        if variant == "spaces_digits" and i % 3 == 0:
+            seq = " ".join(seq[a:a + 10] for a in range(0, len(seq), 10)) + " 60"
+        width = 60 if variant in ("wrapped", "crlf", "blank_lines") else 10 ** 9
+        lines = [seq[a:a + width] for a in range(0, len(seq), width)] or [""]
+        if variant == "blank_lines" and i % 7 == 0:
+            lines.insert(1, "")
+        out.append(f">{rid}{nl}" + nl.join(lines) + nl)
+        if variant == "blank_lines" and i % 11 == 0:
+            out.append(nl)
+        if variant == "semicolon" and i == len(recs) // 2:
+            out.append(f";old-style header{nl}ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT{nl}")
+    return "".join(out)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("variant", ["plain", "wrapped", "crlf", "blank_lines", "lower_iupac", "spaces_digits", "semicolon", "bad_letter",
+                                     "empty_records", "leading_blank"])
+def test_parallel_fasta_equals_sequential_reader(oracle_bin, sim_db, tmp_path, paired, variant):
+    # uncompressed FASTA goes through the same slab parser as FASTQ (records start at '>' lines); whatever it does not take
+    # (a ';' header, a file that does not begin with a header) continues in the sequential reader at that byte
+    import numpy as np
+    rng = np.random.default_rng(23)
+    n = 1200
+    g = list(sim_db["targets"].values())
+    recs1, recs2 = [], []
+    for i in range(n):
+        src = g[i % len(g)] if i % 3 else "".join("ACGT"[x] for x in rng.integers(0, 4, size=900))
+        L = int(rng.choice([40, 100, 150, 320]))
+        p = int(rng.integers(0, len(src) - 2 * L))
+        recs1.append((f"read{i} some words", src[p:p + L]))
+        recs2.append((f"read{i}/2", src[p + L:p + 2 * L]))
+    if variant == "bad_letter":
+        recs1[n // 2] = (recs1[n // 2][0], recs1[n // 2][1][:30] + "!" + recs1[n // 2][1][31:])
+    if variant == "empty_records":
+        for i in range(0, n, 97):
+            recs1[i] = (recs1[i][0], "")
+    f1, f2 = str(tmp_path / "r1.fasta"), str(tmp_path / "r2.fa")
+    text1 = _fasta_text(recs1, variant)
+    if variant == "leading_blank":
+        text1 = "\n\n" + text1
+    open(f1, "w", newline="").write(text1)
+    open(f2, "w", newline="").write(_fasta_text(recs2, "crlf" if variant == "crlf" else "plain"))
+    files = [f1, f2] if paired else [f1]
+    seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], files, str(tmp_path / "seq"), paired, {"GANON_HOST_PARSE_THREADS": "0"})
+    for slab in ("40000", "250000"):
+        par_err, par_out = _run_reader_case(oracle_bin, sim_db["ibf"], files, str(tmp_path / ("par" + slab)), paired,
+                                            {"GANON_HOST_PARSE_THREADS": "4", "GANON_HOST_SLAB_BYTES": slab, "GANON_HOST_PARALLEL_MIN": "0",
+                                             "GANON_HOST_BATCH_READS": "277"})
+        assert par_out == seq_out, (variant, slab)
+        assert ("Error parsing" in par_err) == ("Error parsing" in seq_err) == (variant == "bad_letter")
+    assert seq_out[".all"].count(b"\n") > 100
