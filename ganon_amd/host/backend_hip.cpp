@@ -5,6 +5,8 @@
 #include <ganon_hip.h>
 
 #include <algorithm>
+#include <chrono>
+#include <iostream>
 #include <map>
 #include <cstdlib>
 #include <sstream>
@@ -31,6 +33,9 @@ public:
     explicit HipBackend(int device, HipBackend* primary = nullptr) : device_(device), primary_(primary) {}
     ~HipBackend() override
     {
+        if (std::getenv("GANON_HOST_TIMING") && n_create_)
+            std::cerr << "[backend timing] device " << device_ << ": stream (re)creation " << sec_create_ << " s (" << n_create_
+                      << "x), submit calls " << sec_submit_ << " s, waiting for + fetching the results " << sec_fetch_ << " s" << std::endl;
         clear_filters();
         for (auto& s : stage_)
             if (s.ptr)
@@ -255,6 +260,12 @@ public:
                   std::string& err) override
     {
         const uint32_t n = (uint32_t)b.size();
+        auto           t = std::chrono::steady_clock::now();
+        auto           lap = [&](double& acc) {
+            const auto now = std::chrono::steady_clock::now();
+            acc += std::chrono::duration<double>(now - t).count();
+            t = now;
+        };
         out.n_hashes.assign(n, 0);
         out.status.assign(n, 0);
         out.per_filter.resize(filters_.size());
@@ -281,6 +292,8 @@ public:
                     part.stream_reads = cr;
                     part.stream_bases = cb;
                     part.pf_generation = 0;
+                    lap(sec_create_);
+                    ++n_create_;
                     if (long_reads_ && !filters_[i].is_hibf && gn_stream_set_long_reads(part.s, 1) != GN_OK)
                     {
                         err = gn_last_error();
@@ -305,6 +318,7 @@ public:
                     return false;
                 }
             }
+        lap(sec_submit_);
         for (size_t i = 0; i < filters_.size(); ++i)
         {
             Logical&      lf = filters_[i];
@@ -354,6 +368,7 @@ public:
                         fr.matches[o++] = ms[g][x];
             }
         }
+        lap(sec_fetch_);
         return true;
     }
 
@@ -482,6 +497,8 @@ private:
 
     int                   device_;
     HipBackend*           primary_ = nullptr;
+    double                sec_create_ = 0, sec_submit_ = 0, sec_fetch_ = 0; // $GANON_HOST_TIMING: where classify() spends its time
+    unsigned              n_create_ = 0;
     bool                  long_reads_ = false;
     Stage                 stage_[2];
     std::vector<Logical>  filters_;

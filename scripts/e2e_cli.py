@@ -115,6 +115,8 @@ if all(out[x].get("rc") == 0 for x in ("one_worker", "two_workers_one_gpu", "thr
 if os.environ.get("E2E_KEEP"):  # leave filter and reads behind for follow-up runs (A/B scripts)
     os.rename(ibf, os.path.join(d, os.environ["E2E_KEEP"] + ".ibf"))
     os.rename(fq, os.path.join(d, os.environ["E2E_KEEP"] + ".fq"))
+    if os.environ.get("E2E_PAIRED"):
+        os.rename(fq2, os.path.join(d, "ganon_keep2.fq"))
 for f in os.listdir(d):
     if f.startswith("ganon_e2e"):
         os.remove(os.path.join(d, f))
