@@ -119,10 +119,21 @@ private:
 using BatchQueue = BoundedQueue<ReadBatch>;
 
 // a batch together with what the device said about it
+// what the post stage makes of one batch; merged into the level's tallies and files in input order
+struct PostOutput
+{
+    std::string              all, lca, unc; // text for the .all / .one / .unc files
+    ReadSetTally             reads;         // this batch's share of the per-prefix read tally
+    std::vector<TargetTally> targets;       // ... and of the per-target tallies (dense by node id)
+    ReadBatch                left;          // reads that stay unclassified on a level that is not the last
+    bool                     has_left = false;
+};
+
 struct ClassifiedBatch
 {
     ReadBatch   rb;
     BatchResult res;
+    PostOutput  post;
 };
 
 // Results of several device workers, handed to the post stage in input order.  A worker may not run ahead of the
@@ -759,8 +770,14 @@ static bool ganon_classify(Config config)
         list_outputs(std::cerr, config, levels, reads);
     }
 
+    // One worker (a thread with its own device streams) per --device entry; entries naming the same GPU share one copy of
+    // the filters.  Without --device the reference's own knob decides: --threads classify workers (:1579-1597), here on
+    // GPU 0 -- at least two, so that one batch's upload and fetch overlap another batch's kernels, at most four.
+    std::vector<int> devices = config.devices;
+    if (!config.devices_given)
+        devices.assign(std::min<size_t>(4, std::max<size_t>(2, config.threads)), 0);
     std::string err;
-    auto        backends = make_backends(config.devices, err);
+    auto        backends = make_backends(devices, err);
     if (backends.empty())
     {
         std::cerr << "ERROR: " << err << std::endl;
@@ -901,6 +918,16 @@ static bool ganon_classify(Config config)
             lca.doEulerWalk(config.tax_root_node);
         }
 
+        // every node an LCA or the root fallback can name gets its id now: the post stage runs on several threads and only
+        // looks ids up (`.rep` rows come in id order: targets in filter order, then the remaining tax nodes by name)
+        for (auto const& [target, node] : tax)
+        {
+            nid(target);
+            nid(node.parent);
+        }
+        nid(config.tax_root_node);
+        auto known_nid = [&](const std::string& s) -> uint32_t { return node_ids.at(s); };
+
         const auto file_mode = first_level || !config.output_single ? std::ofstream::out : std::ofstream::app; // :1542
         if (config.output_lca && !config.skip_lca)
             for (auto& [prefix, files] : reads)
@@ -943,13 +970,16 @@ static bool ganon_classify(Config config)
             double   fpr;
             bool     fpr_ok; // the backend already verified the --fpr-query rule for this match
         };
-        std::vector<MatchEntry>  matches;
-        // several filters of a level can report the same target: its slot in `matches`, valid while the stamp is the read's
-        std::vector<uint32_t>    slot_of, stamp_of;
-        uint32_t                 stamp = 0;
-        std::vector<uint32_t>    kept_gids;
-        std::vector<std::string> kept_targets;
-        std::string              buf_all, buf_lca, buf_unc; // one write per batch and file
+        // the post stage runs on a small pool of threads, one batch each; this is what a thread keeps between batches
+        struct PostScratch
+        {
+            std::vector<MatchEntry>  matches;
+            // several filters of a level can report the same target: its slot in `matches`, valid while the stamp is the read's
+            std::vector<uint32_t>    slot_of, stamp_of;
+            uint32_t                 stamp = 0;
+            std::vector<uint32_t>    kept_gids;
+            std::vector<std::string> kept_targets;
+        };
 
         auto device_stage = [&](Backend& be, const ReadBatch& rb, BatchResult& res, std::string& e) -> bool {
             const auto t0 = std::chrono::steady_clock::now();
@@ -959,10 +989,21 @@ static bool ganon_classify(Config config)
             return ok;
         };
 
-        auto post_stage = [&](ReadBatch& rb, const BatchResult& res) {
+        // one batch's reads -> text, tallies, carried reads.  Touches nothing shared but read-only tables (filters, node names
+        // and ids -- all registered before the first batch --, the LCA structure), so several threads run it at once.
+        auto post_stage = [&](ReadBatch& rb, const BatchResult& res, PostScratch& sc, PostOutput& po) {
             const auto    t0    = std::chrono::steady_clock::now();
-            ReadSetTally& total = read_tallies[rb.prefix];
-            auto&         per_target = target_tallies[rb.prefix];
+            po.reads = ReadSetTally();
+            po.targets.clear();
+            po.has_left = false;
+            ReadSetTally& total = po.reads;
+            auto&         per_target = po.targets;
+            std::string & buf_all = po.all, &buf_lca = po.lca, &buf_unc = po.unc;
+            auto&         matches = sc.matches;
+            auto &        slot_of = sc.slot_of, &stamp_of = sc.stamp_of;
+            uint32_t&     stamp = sc.stamp;
+            auto&         kept_gids = sc.kept_gids;
+            auto&         kept_targets = sc.kept_targets;
             buf_all.clear();
             buf_lca.clear();
             buf_unc.clear();
@@ -1113,12 +1154,12 @@ static bool ganon_classify(Config config)
                             for (uint32_t g : kept_gids)
                                 kept_targets.push_back(node_names[g]);
                             const std::string target_lca = lca.getLCA(kept_targets);
-                            tally_at(per_target, nid(target_lca)).lca_reads++;
+                            tally_at(per_target, known_nid(target_lca)).lca_reads++;
                             if (o_lca)
                                 append_line(buf_lca, rb.id(r), target_lca, max_count_read);
                         }
                         else // :794-799
-                            tally_at(per_target, nid(config.tax_root_node)).lca_reads++;
+                            tally_at(per_target, known_nid(config.tax_root_node)).lca_reads++;
                     }
                     else
                         buf_all.resize(all_mark);
@@ -1146,24 +1187,45 @@ static bool ganon_classify(Config config)
             }
             total.dropped_by_rel_filter += res.dropped_rel_filter;
             total.dropped_by_fpr_query += res.dropped_fpr_query;
-            if (o_all)
-                o_all->write(buf_all.data(), (std::streamsize)buf_all.size());
-            if (o_lca)
-                o_lca->write(buf_lca.data(), (std::streamsize)buf_lca.size());
-            if (o_unc)
-                o_unc->write(buf_unc.data(), (std::streamsize)buf_unc.size());
             if (!last_level && left.size() != 0)
             {
                 finalize_batch(left, left2);
-                left.seq = next_carried.size();
-                next_carried.push_back(std::move(left));
+                po.left     = std::move(left);
+                po.has_left = true;
             }
+            std::lock_guard<std::mutex> lk(timing_mutex);
             sec_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        };
+        // a batch's share goes into the level's tallies and files; called in input order on this thread
+        auto merge_stage = [&](ClassifiedBatch& cb) {
+            PostOutput& po = cb.post;
+            read_tallies[cb.rb.prefix].add(po.reads);
+            auto& rows = target_tallies[cb.rb.prefix];
+            if (rows.size() < po.targets.size())
+                rows.resize(po.targets.size());
+            for (size_t g = 0; g < po.targets.size(); ++g)
+                rows[g].add(po.targets[g]);
+            if (config.output_all)
+                out_all[cb.rb.prefix].write(po.all.data(), (std::streamsize)po.all.size());
+            if (config.output_lca && !config.skip_lca)
+                out_lca[cb.rb.prefix].write(po.lca.data(), (std::streamsize)po.lca.size());
+            if (config.output_unclassified)
+                out_unc[cb.rb.prefix].write(po.unc.data(), (std::streamsize)po.unc.size());
+            if (po.has_left)
+            {
+                po.left.seq = next_carried.size();
+                next_carried.push_back(std::move(po.left));
+                po.left     = ReadBatch();
+                po.has_left = false;
+            }
         };
 
         // ---- reader -> [one device worker per GPU] -> post stage (this thread), results consumed in input order
         {
-            InOrder                  ordered(2 * n_workers + 2);
+            const size_t             n_post = (size_t)env_size("GANON_HOST_POST_THREADS", 3);
+            InOrder                  ordered(2 * n_workers + n_post + 2);
+            BoundedQueue<ClassifiedBatch> classified(n_post + 1);
+            std::atomic<size_t>      workers_left{ n_workers };
             std::atomic<bool>        failed{ false };
             std::mutex               err_mutex, carried_mutex;
             size_t                   carried_next = 0;
@@ -1198,6 +1260,21 @@ static bool ganon_classify(Config config)
                             ordered.abort();
                             break;
                         }
+                        classified.push(std::move(cb));
+                        cb = ClassifiedBatch();
+                    }
+                    if (workers_left.fetch_sub(1) == 1)
+                        classified.done(); // the last device worker out closes the post pool's queue
+                });
+            // post pool: batches in any order, results into `ordered`
+            std::vector<std::thread> posters;
+            for (size_t pi = 0; pi < n_post; ++pi)
+                posters.emplace_back([&] {
+                    PostScratch     scratch;
+                    ClassifiedBatch cb;
+                    while (classified.pop(cb))
+                    {
+                        post_stage(cb.rb, cb.res, scratch, cb.post);
                         const uint64_t seq = cb.rb.seq;
                         ordered.put(seq, std::move(cb));
                         cb = ClassifiedBatch();
@@ -1205,9 +1282,9 @@ static bool ganon_classify(Config config)
                     ordered.producer_done();
                 });
             ClassifiedBatch cb;
-            while (ordered.take(cb, n_workers))
+            while (ordered.take(cb, n_post))
             {
-                post_stage(cb.rb, cb.res);
+                merge_stage(cb);
                 if (first_level)
                     queue1.recycle(std::move(cb.rb));
                 cb.rb = ReadBatch();
@@ -1221,6 +1298,8 @@ static bool ganon_classify(Config config)
             }
             for (auto& w : workers)
                 w.join();
+            for (auto& t : posters)
+                t.join();
             if (failed)
             {
                 std::cerr << "ERROR: " << err << std::endl;

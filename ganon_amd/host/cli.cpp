@@ -165,7 +165,10 @@ std::optional<Config> parse_command_line(int argc, char** argv, int& exit_code)
     try
     {
         if (const char* d = std::getenv("GANON_DEVICE"))
-            cfg.devices = parse_devices(d);
+        {
+            cfg.devices       = parse_devices(d);
+            cfg.devices_given = true;
+        }
         for (int i = 1; i < argc; ++i)
         {
             std::string arg = argv[i];
@@ -289,7 +292,10 @@ std::optional<Config> parse_command_line(int argc, char** argv, int& exit_code)
                         cfg.n_reads = (size_t)x;
                     break;
                 }
-                case Kind::Devices: cfg.devices = parse_devices(value); break;
+                case Kind::Devices:
+                    cfg.devices       = parse_devices(value);
+                    cfg.devices_given = true;
+                    break;
             }
         }
     }

@@ -38,11 +38,12 @@ struct Config
     bool        skip_lca      = false;
     std::string tax_root_node = "1";
     // execution
-    uint16_t threads   = 1;    // accepted for compatibility; batches are sized for the GPU
+    uint16_t threads   = 1;    // classify workers (:1579-1597) when --device is not given: 2..4 of them on GPU 0, sharing the filters
     size_t   n_batches = 1000; // accepted for compatibility
     size_t   n_reads   = 400;  // accepted for compatibility
     bool     verbose = false, quiet = false;
     std::vector<int> devices{ 0 }; // extension: --device 0,1,.. | all (default $GANON_DEVICE or 0); empty = every visible GPU
+    bool             devices_given = false; // --device / $GANON_DEVICE was used (else --threads decides the workers on GPU 0)
 
     // checks + broadcasting; prints the reference's message to stderr and returns false on the first violation
     bool validate();

@@ -51,6 +51,17 @@ void ReadSetTally::absorb_reads(const ReadSetTally& o)
     dropped_by_fpr_query += o.dropped_by_fpr_query;
 }
 
+void ReadSetTally::add(const ReadSetTally& o)
+{
+    reads_in += o.reads_in;
+    reads_seen += o.reads_seen, bases_seen += o.bases_seen, minimisers_seen += o.minimisers_seen;
+    too_short += o.too_short, too_many_minimisers += o.too_many_minimisers;
+    reads_classified += o.reads_classified, best_match_minimisers += o.best_match_minimisers;
+    minimisers_of_classified += o.minimisers_of_classified;
+    matches += o.matches, unique_reads += o.unique_reads;
+    dropped_by_rel_filter += o.dropped_by_rel_filter, dropped_by_fpr_query += o.dropped_by_fpr_query;
+}
+
 void ReadSetTally::absorb_targets(const TargetTally& t)
 {
     matches += t.matches;

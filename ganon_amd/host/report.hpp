@@ -41,6 +41,11 @@ struct TargetTally
 {
     size_t matches = 0, lca_reads = 0, unique_reads = 0, dropped_by_rel_filter = 0, dropped_by_fpr_query = 0;
     bool   reported() const { return matches || lca_reads || unique_reads; }
+    void   add(const TargetTally& o)
+    {
+        matches += o.matches, lca_reads += o.lca_reads, unique_reads += o.unique_reads;
+        dropped_by_rel_filter += o.dropped_by_rel_filter, dropped_by_fpr_query += o.dropped_by_fpr_query;
+    }
 };
 
 // Per (hierarchy level, read-set prefix).
@@ -52,6 +57,7 @@ struct ReadSetTally
     size_t reads_classified = 0, best_match_minimisers = 0, minimisers_of_classified = 0;
     size_t matches = 0, unique_reads = 0, dropped_by_rel_filter = 0, dropped_by_fpr_query = 0;
 
+    void add(const ReadSetTally& o);            // every field (two partial tallies of the same level and prefix)
     void absorb_reads(const ReadSetTally& o);   // everything a level counts per read
     void absorb_targets(const TargetTally& t);  // what a level's `.rep` rows add up to
 };
