@@ -34,6 +34,7 @@
 #include <iostream>
 #include <map>
 #include <mutex>
+#include <sched.h>
 #include <thread>
 #include <unordered_map>
 
@@ -315,6 +316,26 @@ private:
     std::thread                worker_; // last member: everything above exists when it starts
 };
 
+// cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (a container that shows 256 CPUs
+// and grants 16 runs 16 threads' worth of work, however many threads there are)
+unsigned usable_cores()
+{
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0)
+        n = (unsigned)CPU_COUNT(&set);
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string   quota;
+    double        period = 0;
+    if (f >> quota >> period && quota != "max" && period > 0)
+    {
+        const double q = std::atof(quota.c_str()) / period;
+        if (q >= 1 && q < n)
+            n = (unsigned)q;
+    }
+    return n ? n : 1;
+}
+
 size_t env_size(const char* name, size_t dflt)
 {
     const char* v = std::getenv(name);
@@ -436,7 +457,9 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
 {
     uint64_t       seq = 0;
     MateCopier     copier(queue, (unsigned)env_size("GANON_HOST_MATE_THREADS", 3));
-    const unsigned par_threads = (unsigned)env_size("GANON_HOST_PARSE_THREADS", 6);
+    // slab parsers: half of the cores this process may use, between 4 and 12 (the other half: reader, mate copier, device
+    // workers, post pool); 8 on the 16-core quota of the boxes the numbers in DESIGN.md come from
+    const unsigned par_threads = (unsigned)env_size("GANON_HOST_PARSE_THREADS", std::min(12u, std::max(4u, usable_cores() / 2)));
     const size_t   slab_bytes  = env_size("GANON_HOST_SLAB_BYTES", 48u << 20);
     const size_t   par_min     = env_size("GANON_HOST_PARALLEL_MIN", 32u << 20);
     for (auto const& [prefix, files] : plan)
