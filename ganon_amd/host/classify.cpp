@@ -50,7 +50,9 @@ inline size_t ceil_share(size_t n, double p) // ceil(n * p) in double, as thresh
 }
 inline double binomial_coefficient(double n, double k) noexcept // :498-501
 {
-    return std::exp(std::lgamma(n + 1) - std::lgamma(n - k + 1) - std::lgamma(k + 1));
+    // lgamma_r: the values of std::lgamma without its write to the global `signgam` (the post stage runs on several threads)
+    int sign = 0;
+    return std::exp(lgamma_r(n + 1, &sign) - lgamma_r(n - k + 1, &sign) - lgamma_r(k + 1, &sign));
 }
 
 // ---- queues --------------------------------------------------------------------------------------------------
