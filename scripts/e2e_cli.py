@@ -70,6 +70,15 @@ if os.environ.get("E2E_PAIRED"):  # a mate file: the same records, bases of the 
     out["paired"] = True
 del rec
 
+if os.environ.get("E2E_HIBF"):  # a two-level raptor-style HIBF (4096 user bins) written by the tests' fixture writer instead of the flat filter
+    import ganon_fixtures as gf
+    t0 = time.time()
+    hb = gf.random_hibf(4096, 64, 2, seed=5, density=0.3, hash_funs=3, rows=(60000, 65537))
+    os.remove(ibf)
+    ibf = os.path.join(d, "ganon_e2e.hibf")
+    gf.write_hibf(ibf, hb, [[f"/x/U{u}.minimiser"] for u in range(4096)], wl.k, wl.w, 0.05)
+    EXTRA = EXTRA + ["--hibf"]
+    out["hibf"] = {"user_bins": 4096, "file_mib": round(os.path.getsize(ibf) / 2**20, 1), "built_s": round(time.time() - t0, 1)}
 exe = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
 runs = [("one_worker", "0", None), ("two_workers_one_gpu", "0,0", None), ("three_workers_one_gpu", "0,0,0", None), ("default_no_device_flag", None, None)]
 if os.environ.get("E2E_SWEEP"):  # parser threads x device workers, to see which stage limits the pipeline on this host
