@@ -7,7 +7,12 @@
 #include <algorithm>
 #include <chrono>
 #include <iostream>
+#include <atomic>
 #include <map>
+#include <vector>
+#include <unordered_map>
+#include <thread>
+#include <mutex>
 #include <cstdlib>
 #include <sstream>
 
@@ -25,6 +30,89 @@ namespace
 // straddle a cut), matches concatenated per read in part order.
 constexpr uint64_t kPartWords = 512; // 32 768 bins: four wave slices of 16-byte lanes (the row shape of BASELINE config 4)
 
+
+// Page-locked blocks for the read batches, kept for the life of the process.  Locking pages costs ~0.26 s per GiB
+// (profiles/r02_pinned_probe.json) and a pipeline's worth of batch buffers is half a GiB or more, so (a) a block, once
+// locked, is handed out again instead of being unlocked, and (b) a thread starts locking the first blocks while the filters
+// are still being loaded.  Sizes are rounded up to a power of two (>= 1 MiB) so that freed blocks fit later requests.
+class PinnedPool
+{
+public:
+    static PinnedPool& get()
+    {
+        static PinnedPool* p = new PinnedPool(); // (never destroyed: blocks may be released during static teardown)
+        return *p;
+    }
+    void* take(size_t n)
+    {
+        const size_t cls = size_class(n);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            auto& fl = free_[cls];
+            if (!fl.empty())
+            {
+                void* p = fl.back();
+                fl.pop_back();
+                return p;
+            }
+        }
+        void* p = nullptr;
+        if (gn_pinned_alloc(cls, &p) != GN_OK)
+            return nullptr;
+        std::lock_guard<std::mutex> lk(m_);
+        size_of_[p] = cls;
+        return p;
+    }
+    void give(void* p)
+    {
+        if (!p)
+            return;
+        std::lock_guard<std::mutex> lk(m_);
+        auto it = size_of_.find(p);
+        if (it != size_of_.end())
+            free_[it->second].push_back(p);
+    }
+    // blocks for the first slabs of the reader (32 MiB holds the bases of a 48 MiB FASTQ slab), locked in the background
+    void warm_up()
+    {
+        const char* e = std::getenv("GANON_HOST_PRELOCK_MIB");
+        const size_t total = (e ? (size_t)std::atol(e) : 512) << 20, block = 32u << 20;
+        if (total == 0)
+            return;
+        warm_ = std::thread([this, total, block] {
+            for (size_t done = 0; done < total && !stop_; done += block)
+            {
+                void* p = nullptr;
+                if (gn_pinned_alloc(block, &p) != GN_OK)
+                    return;
+                std::lock_guard<std::mutex> lk(m_);
+                size_of_[p] = block;
+                free_[block].push_back(p);
+            }
+        });
+    }
+    void settle() // before the process lets go of the device: the warm-up thread is not in the middle of a call
+    {
+        stop_ = true;
+        if (warm_.joinable())
+            warm_.join();
+    }
+
+private:
+    static size_t size_class(size_t n)
+    {
+        size_t c = 1u << 20;
+        while (c < n)
+            c <<= 1;
+        return c;
+    }
+    std::mutex                            m_;
+    std::map<size_t, std::vector<void*>>  free_;
+    std::unordered_map<void*, size_t>     size_of_;
+    std::thread                           warm_;
+    std::atomic<bool>                     stop_{ false };
+};
+
 class HipBackend final : public Backend
 {
 public:
@@ -33,6 +121,7 @@ public:
     explicit HipBackend(int device, HipBackend* primary = nullptr) : device_(device), primary_(primary) {}
     ~HipBackend() override
     {
+        PinnedPool::get().settle();
         if (std::getenv("GANON_HOST_TIMING") && n_create_)
             std::cerr << "[backend timing] device " << device_ << ": stream (re)creation " << sec_create_ << " s (" << n_create_
                       << "x), submit calls " << sec_submit_ << " s, waiting for + fetching the results " << sec_fetch_ << " s" << std::endl;
@@ -542,11 +631,9 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
     // device-bound host buffers (read batches) come from page-locked memory from now on (hostmem.hpp)
     if (!std::getenv("GANON_HOST_PAGEABLE"))
     {
-        g_host_arena.alloc = [](size_t n) -> void* {
-            void* p = nullptr;
-            return gn_pinned_alloc(n ? n : 1, &p) == GN_OK ? p : nullptr;
-        };
-        g_host_arena.release = [](void* p) { gn_pinned_free(p); };
+        g_host_arena.alloc   = [](size_t n) -> void* { return PinnedPool::get().take(n); };
+        g_host_arena.release = [](void* p) { PinnedPool::get().give(p); };
+        PinnedPool::get().warm_up();
     }
     return out;
 }
