@@ -821,3 +821,65 @@ def test_long_reads_option_is_refused_for_hibf(hip):
         st.set_long_reads(True)
     st.destroy()
     flt.free()
+
+
+@pytest.mark.parametrize("shape", ["identity", "split", "hibf"])
+def test_matches_against_an_oracle_that_never_sees_device_hashes(hip, shape):
+    # the whole path on both sides: oracle minimisers -> oracle counts -> oracle selection, nothing taken from the device
+    # (most other match tests hand the device's hashes to the oracle's counting, which test_minimiser_parity justifies)
+    k, w = 19, 31
+    rng = np.random.default_rng(404)
+    genomes = [gu.random_seq(rng, 5000) for _ in range(40)]
+    if shape == "hibf":
+        uh = {ub * 13: np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)) for ub, g in enumerate(genomes)}
+        hb = gf.random_hibf(700, 128, 2, seed=77, density=0.3, hash_funs=3, user_hashes=uh)
+        flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+    else:
+        bins, rows, h = (4096, 3001, 4) if shape == "identity" else (1500, 4099, 3)
+        ibf = gf.random_ibf(bins, rows, h, 0.3, seed=6)
+        n_targets = bins if shape == "identity" else 400
+        b2t = None if shape == "identity" else rng.integers(0, n_targets, size=bins).astype(np.uint32)
+        for gi, g in enumerate(genomes):
+            ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), gi * 37 % bins)
+        flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
+    iupac = b"ACGTNRYKMSWBDHVacgtn"
+    s1, s2 = [], []
+    for i in range(4000):
+        L = int(rng.choice([25, 31, 75, 100, 150, 150, 151, 250, 400]))
+        if i % 3:
+            g = genomes[i % len(genomes)]
+            p = int(rng.integers(0, len(g) - 2 * L))
+            a, b = bytearray(g[p:p + L]), bytearray(g[p + L:p + 2 * L])
+        else:
+            a, b = bytearray(gu.random_seq(rng, L)), bytearray(gu.random_seq(rng, int(rng.choice([10, L]))))
+        for _ in range(int(rng.integers(0, 4))):
+            a[int(rng.integers(0, len(a)))] = iupac[int(rng.integers(0, len(iupac)))]
+        s1.append(bytes(a))
+        s2.append(bytes(b))
+    for paired in (False, True):
+        for cutoff in (0.1, 0.6):
+            bases, off1, off2 = gu.pack_reads(s1, s2 if paired else None)
+            st = hip.HipStream(flt, len(s1), bases.size)
+            st.submit(bases, off1, off2, k, w, cutoff)
+            nh, status, mo, m = st.fetch()
+            n_match = 0
+            for i in range(len(s1)):
+                if len(s1[i]) < w:
+                    assert status[i] == 1 and mo[i] == mo[i + 1]
+                    continue
+                hh = oracle.minimiser_hash(oracle.to_ranks(s1[i]), k, w)
+                if paired and len(s2[i]) >= w:
+                    hh = np.concatenate([hh, oracle.minimiser_hash(oracle.to_ranks(s2[i]), k, w)])
+                assert status[i] == 0 and nh[i] == len(hh), i
+                thr = oracle.threshold_cutoff(len(hh), cutoff)
+                if shape == "hibf":
+                    ec = hb.bulk_count(hh, thr)
+                    exp = [(int(u), int(min(c, len(hh)))) for u, c in enumerate(ec) if c > 0]
+                else:
+                    exp, _ = gu.oracle_matches(ibf, b2t if b2t is not None else np.arange(bins, dtype=np.uint32), n_targets, hh, cutoff)
+                got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+                assert got == exp, (shape, paired, cutoff, i, got[:3], exp[:3])
+                n_match += len(exp)
+            assert n_match > 1000
+            st.destroy()
+    flt.free()
