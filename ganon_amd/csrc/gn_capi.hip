@@ -1287,6 +1287,11 @@ static int gn_finish(gn_stream* s)
     return gn_fail(GN_ENODEV, "match buffer kept overflowing");
 }
 
+int gn_finish_batch(gn_stream* s) // (for gn_postfilter.hip)
+{
+    return gn_finish(s);
+}
+
 extern "C" int gn_stream_sync(gn_stream* s)
 {
     if (!s)

@@ -13,6 +13,7 @@
 // candidate-driven select of the generic count kernel: targets with more bins than this are scanned from a list
 #define GN_CAND_NBIG 4u
 #define GN_HIBF_MAXDEPTH 64
+#define GN_PF_MAX_JOINT 16   // filters of one hierarchy level in a joint filter_matches pre-pass
 #define GN_LONG_BLOCKS 128u // workgroups (and uint32 count slabs) of the long-read kernel
 #define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
                    // [6] exact match total [8..71] total-hashes shards
@@ -265,6 +266,10 @@ struct gn_stream
     double              pf_rel_filter = 0, pf_fpr_query = 1;
     uint32_t*           d_pf_keep = nullptr; // survivors per read
     uint32_t*           d_pf_max  = nullptr; // max count per read before filtering
+    uint32_t*           d_pf_min  = nullptr; // joint pass: min count per read (this stream's filter)
+    uint32_t*           d_pf_gmax = nullptr; // joint pass: the level's max / min per read (filled on the first stream)
+    uint32_t*           d_pf_gmin = nullptr;
+    bool                pf_joint  = false;   // the pass is run by gn_streams_postfilter_joint, not with the batch
     double*             d_pf_fpr  = nullptr; // per target
     unsigned long long* d_pf_ctr  = nullptr; // [0] dropped rel_filter [1] dropped fpr_query [2] survivors
     unsigned long long* h_pf_ctr  = nullptr; // pinned copy

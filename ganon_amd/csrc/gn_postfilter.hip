@@ -40,6 +40,9 @@ struct GnPostfilterParams
     const double*       tfpr;       // per target
     uint32_t*           keep;       // [n_reads+1] survivors per read (keep[n_reads] = 0)
     uint32_t*           maxc;       // [n_reads] max count before filtering (0 = no match)
+    uint32_t*           minc;       // [n_reads] STATS mode: min count (starts at the read's minimiser count, :704)
+    const uint32_t*     gmax;       // APPLY mode: the level's max / min per read (several filters, see gn_streams_postfilter_joint)
+    const uint32_t*     gmin;
     unsigned long long* ctr;        // [0] dropped by rel_filter [1] dropped by fpr_query
     const unsigned long long* cursor; // match cursor and capacity: an overflowed batch holds no matches yet (gn_finish re-runs)
     uint64_t            cap;
@@ -75,6 +78,10 @@ __device__ __forceinline__ uint32_t gn_pf_threshold(uint32_t mx, uint32_t mn, do
     return mx - (uint32_t)(unsigned long long)ceil(__dmul_rn((double)(mx - mn), rel_filter));
 }
 
+// MODE 0: max/min of the read's own matches, then the rules (one filter per level)
+// MODE 1: max/min only (-> maxc, minc): the first half of the joint pass over a level's filters
+// MODE 2: the rules with the level's max/min given (gmax, gmin): its second half
+template <int MODE>
 __global__ void gn_postfilter_kernel(GnPostfilterParams p)
 {
     if (*p.cursor > p.cap)
@@ -95,37 +102,51 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
     if (valid && c <= GN_PF_SMALL)
     {
         uint32_t mx = 0, mn = n;
-        for (uint32_t j = 0; j < c; ++j)
+        if constexpr (MODE == 2)
         {
-            const uint32_t ct = p.m[o + j].count;
-            mx = ct > mx ? ct : mx;
-            mn = ct < mn ? ct : mn;
+            mx = p.gmax[r];
+            mn = p.gmin[r];
         }
-        uint32_t kept = 0;
-        if (c)
-        {
-            const uint32_t thr = gn_pf_threshold(mx, mn, p.rel_filter);
+        else
             for (uint32_t j = 0; j < c; ++j)
             {
-                gn_match       m = p.m[o + j];
-                const uint32_t v = m.count >= thr && fpr_on
-                                       ? gn_fpr_verdict(n, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query)
-                                       : 0u;
-                if (m.count < thr)
-                    ++n_fil;
-                else if (v == 1)
-                    ++n_fpr;
-                else
+                const uint32_t ct = p.m[o + j].count;
+                mx = ct > mx ? ct : mx;
+                mn = ct < mn ? ct : mn;
+            }
+        if constexpr (MODE == 1)
+        {
+            p.maxc[r] = mx;
+            p.minc[r] = mn;
+        }
+        else
+        {
+            uint32_t kept = 0;
+            if (c)
+            {
+                const uint32_t thr = gn_pf_threshold(mx, mn, p.rel_filter);
+                for (uint32_t j = 0; j < c; ++j)
                 {
-                    m.count |= v == 2 ? GN_MATCH_FPR_OK : 0u;
-                    p.m[o + kept++] = m;
+                    gn_match       m = p.m[o + j];
+                    const uint32_t v = m.count >= thr && fpr_on
+                                           ? gn_fpr_verdict(n, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query)
+                                           : 0u;
+                    if (m.count < thr)
+                        ++n_fil;
+                    else if (v == 1)
+                        ++n_fpr;
+                    else
+                    {
+                        m.count |= v == 2 ? GN_MATCH_FPR_OK : 0u;
+                        p.m[o + kept++] = m;
+                    }
                 }
             }
+            p.keep[r] = kept;
+            p.maxc[r] = mx;
         }
-        p.keep[r] = kept;
-        p.maxc[r] = mx;
     }
-    if (r == p.n_reads)
+    if (MODE != 1 && r == p.n_reads)
         p.keep[r] = 0;
     uint64_t heavy = __ballot(valid && c > GN_PF_SMALL);
     while (heavy)
@@ -138,18 +159,35 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
         const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)L);
         const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)L);
         uint32_t mx = 0, mn = nn;
-        for (uint32_t j = lane; j < cc; j += 64)
+        if constexpr (MODE == 2)
         {
-            const uint32_t ct = p.m[oo + j].count;
-            mx = ct > mx ? ct : mx;
-            mn = ct < mn ? ct : mn;
+            mx = p.gmax[rr];
+            mn = p.gmin[rr];
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
+        else
         {
-            const uint32_t a = (uint32_t)__shfl_xor((int)mx, off), b = (uint32_t)__shfl_xor((int)mn, off);
-            mx = a > mx ? a : mx;
-            mn = b < mn ? b : mn;
+            for (uint32_t j = lane; j < cc; j += 64)
+            {
+                const uint32_t ct = p.m[oo + j].count;
+                mx = ct > mx ? ct : mx;
+                mn = ct < mn ? ct : mn;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+            {
+                const uint32_t a = (uint32_t)__shfl_xor((int)mx, off), b = (uint32_t)__shfl_xor((int)mn, off);
+                mx = a > mx ? a : mx;
+                mn = b < mn ? b : mn;
+            }
+        }
+        if constexpr (MODE == 1)
+        {
+            if (lane == 0)
+            {
+                p.maxc[rr] = mx;
+                p.minc[rr] = mn;
+            }
+            continue;
         }
         const uint32_t thr  = gn_pf_threshold(mx, mn, p.rel_filter);
         uint32_t       kept = 0;
@@ -241,38 +279,134 @@ __global__ void gn_postfilter_compact_kernel(const gn_match* __restrict__ in, gn
 
 // queued on the stream right after the grouping pass; results: s->d_matches (compacted survivors), s->d_slot_cnt (n+1
 // offsets), s->d_pf_max, s->d_pf_ctr [0] dropped rel_filter [1] dropped fpr_query [2] survivors
-int gn_run_postfilter(gn_stream* s)
+static GnPostfilterParams gn_pf_params(gn_stream* s)
 {
-    if (!s->pf_on)
-        return GN_OK;
-    const uint32_t n      = s->n_reads;
-    const uint32_t stride = s->f->is_hibf ? 1u : (uint32_t)s->f->geom.wpr;
-    GN_HIP(hipMemsetAsync(s->d_pf_ctr, 0, 4 * sizeof(unsigned long long), s->st));
     GnPostfilterParams p{};
     p.m          = s->d_sorted;
     p.off        = s->d_seg_off;
-    p.stride     = stride;
-    p.n_reads    = n;
+    p.stride     = s->f->is_hibf ? 1u : (uint32_t)s->f->geom.wpr;
+    p.n_reads    = s->n_reads;
     p.nh         = s->d_nh;
     p.rel_filter = s->pf_rel_filter;
     p.fpr_query  = s->pf_fpr_query;
     p.tfpr       = s->d_pf_fpr;
     p.keep       = s->d_pf_keep;
     p.maxc       = s->d_pf_max;
+    p.minc       = s->d_pf_min;
     p.ctr        = s->d_pf_ctr;
     p.cursor     = s->d_ctr;
     p.cap        = s->match_cap;
     p.n_targets  = s->f->is_hibf ? s->f->n_user_bins : s->f->n_targets;
+    return p;
+}
+
+// survivors' offsets (scan of keep[]) and their compaction into d_matches; totals to the pinned copy
+static int gn_pf_finish(gn_stream* s, const GnPostfilterParams& p)
+{
+    const uint32_t n      = s->n_reads;
     const unsigned blocks = (unsigned)(((uint64_t)n + 1 + 255) / 256);
-    hipLaunchKernelGGL(gn_postfilter_kernel, dim3(blocks), dim3(256), 0, s->st, p);
-    GN_HIP(hipGetLastError());
-    size_t tmp = s->pf_scan_bytes;
+    size_t         tmp    = s->pf_scan_bytes;
     GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_pf_scan, tmp, s->d_pf_keep, s->d_slot_cnt, (int)(n + 1), s->st));
-    hipLaunchKernelGGL(gn_postfilter_compact_kernel, dim3(blocks), dim3(256), 0, s->st, s->d_sorted, s->d_matches, s->d_seg_off, stride,
+    hipLaunchKernelGGL(gn_postfilter_compact_kernel, dim3(blocks), dim3(256), 0, s->st, s->d_sorted, s->d_matches, s->d_seg_off, p.stride,
                        s->d_pf_keep, s->d_slot_cnt, n, s->d_ctr, s->match_cap);
     GN_HIP(hipGetLastError());
     GN_HIP(hipMemcpyAsync(s->d_pf_ctr + 2, s->d_slot_cnt + n, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->st));
     GN_HIP(hipMemcpyAsync(s->h_pf_ctr, s->d_pf_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
+    return GN_OK;
+}
+
+// queued on the stream right after the grouping pass; results: s->d_matches (compacted survivors), s->d_slot_cnt (n+1
+// offsets), s->d_pf_max, s->d_pf_ctr [0] dropped rel_filter [1] dropped fpr_query [2] survivors
+int gn_run_postfilter(gn_stream* s)
+{
+    if (!s->pf_on || s->pf_joint) // (a joint pass is run by gn_streams_postfilter_joint, after every stream of the level)
+        return GN_OK;
+    GN_HIP(hipMemsetAsync(s->d_pf_ctr, 0, 4 * sizeof(unsigned long long), s->st));
+    const GnPostfilterParams p = gn_pf_params(s);
+    const unsigned blocks = (unsigned)(((uint64_t)s->n_reads + 1 + 255) / 256);
+    hipLaunchKernelGGL(gn_postfilter_kernel<0>, dim3(blocks), dim3(256), 0, s->st, p);
+    GN_HIP(hipGetLastError());
+    return gn_pf_finish(s, p);
+}
+
+struct GnPfLists
+{
+    const uint32_t* mx[GN_PF_MAX_JOINT];
+    const uint32_t* mn[GN_PF_MAX_JOINT];
+    uint32_t        k;
+};
+__global__ void gn_pf_combine_kernel(GnPfLists l, uint32_t n, uint32_t* __restrict__ gmax, uint32_t* __restrict__ gmin)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n)
+        return;
+    uint32_t a = l.mx[0][r], b = l.mn[0][r];
+    for (uint32_t i = 1; i < l.k; ++i)
+    {
+        const uint32_t x = l.mx[i][r], y = l.mn[i][r];
+        a = x > a ? x : a;
+        b = y < b ? y : b;
+    }
+    gmax[r] = a;
+    gmin[r] = b;
+}
+
+int gn_finish_batch(gn_stream* s); // gn_capi.hip: waits for the batch, re-runs it after a match-buffer overflow
+
+// Several filters of one hierarchy level, the same batch classified against each (one stream per filter, one device):
+// the reference merges their matches before it thresholds (GanonClassify.cpp:716-735,755-761), so max/min are the level's.
+// With DISJOINT targets across the filters (no target is reported twice) the merge is a union and the rules can run per
+// filter once every stream knows the level's max/min per read: max/min per stream -> combined -> rules per stream.
+extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n_streams)
+{
+    if (!streams || n_streams == 0 || n_streams > GN_PF_MAX_JOINT)
+        return gn_fail(GN_EINVAL, "gn_streams_postfilter_joint: 1..%u streams", (unsigned)GN_PF_MAX_JOINT);
+    gn_stream* s0 = streams[0];
+    for (uint32_t i = 0; i < n_streams; ++i)
+    {
+        gn_stream* s = streams[i];
+        if (!s || !s->pf_on || !s->pf_joint)
+            return gn_fail(GN_EINVAL, "stream %u has no joint post-filter set", i);
+        if (s->device != s0->device || s->n_reads != s0->n_reads)
+            return gn_fail(GN_EINVAL, "streams of a joint pass must hold the same batch on one device");
+    }
+    GN_HIP(hipSetDevice(s0->device));
+    const uint32_t n      = s0->n_reads;
+    const unsigned blocks = (unsigned)(((uint64_t)n + 1 + 255) / 256);
+    GnPfLists      lists{};
+    lists.k = n_streams;
+    for (uint32_t i = 0; i < n_streams; ++i)
+    {
+        gn_stream* s  = streams[i];
+        int        rc = gn_finish_batch(s); // (a match buffer that overflowed is grown and the batch re-run first)
+        if (rc)
+            return rc;
+        GN_HIP(hipMemsetAsync(s->d_pf_ctr, 0, 4 * sizeof(unsigned long long), s->st));
+        hipLaunchKernelGGL(gn_postfilter_kernel<1>, dim3(blocks), dim3(256), 0, s->st, gn_pf_params(s));
+        GN_HIP(hipGetLastError());
+        lists.mx[i] = s->d_pf_max;
+        lists.mn[i] = s->d_pf_min;
+    }
+    for (uint32_t i = 0; i < n_streams; ++i)
+        GN_HIP(hipStreamSynchronize(streams[i]->st));
+    if (n)
+        hipLaunchKernelGGL(gn_pf_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, s0->st, lists, n, s0->d_pf_gmax, s0->d_pf_gmin);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipStreamSynchronize(s0->st));
+    for (uint32_t i = 0; i < n_streams; ++i)
+    {
+        gn_stream*         s = streams[i];
+        GnPostfilterParams p = gn_pf_params(s);
+        p.gmax = s0->d_pf_gmax;
+        p.gmin = s0->d_pf_gmin;
+        hipLaunchKernelGGL(gn_postfilter_kernel<2>, dim3(blocks), dim3(256), 0, s->st, p);
+        GN_HIP(hipGetLastError());
+        int rc = gn_pf_finish(s, p);
+        if (rc)
+            return rc;
+    }
+    // (stream 0's gmax/gmin are read by the other streams' kernels: nothing reuses them before every stream is fetched,
+    //  and a fetch waits for its stream)
     return GN_OK;
 }
 
@@ -297,6 +431,9 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
     {
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_keep), ((size_t)s->max_reads + 1) * 4));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_max), ((size_t)s->max_reads + 1) * 4));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_min), ((size_t)s->max_reads + 1) * 4));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_gmax), ((size_t)s->max_reads + 1) * 4));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_gmin), ((size_t)s->max_reads + 1) * 4));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_ctr), 4 * sizeof(unsigned long long)));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_fpr), (nt ? nt : 1) * sizeof(double)));
         GN_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_pf_ctr), 4 * sizeof(unsigned long long), hipHostMallocDefault));
@@ -312,19 +449,20 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
         GN_HIP(hipMemset(s->d_pf_fpr, 0, nt * sizeof(double)));
     s->pf_rel_filter = pf->rel_filter;
     s->pf_fpr_query  = pf->fpr_query;
+    s->pf_joint      = pf->joint != 0;
     s->pf_on         = true;
     return GN_OK;
 }
 
 void gn_postfilter_release(gn_stream* s)
 {
-    void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan };
+    void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_min, s->d_pf_gmax, s->d_pf_gmin, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan };
     for (void* q : ptrs)
         if (q)
             hipFree(q);
     if (s->h_pf_ctr)
         hipHostFree(s->h_pf_ctr);
-    s->d_pf_keep = s->d_pf_max = nullptr;
+    s->d_pf_keep = s->d_pf_max = s->d_pf_min = s->d_pf_gmax = s->d_pf_gmin = nullptr;
     s->d_pf_ctr  = nullptr;
     s->d_pf_fpr  = nullptr;
     s->d_pf_scan = nullptr;

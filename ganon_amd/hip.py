@@ -19,13 +19,13 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_pinned_free", "gn_filter_write_rows", "gn_filter_write_sync", "gn_filter_finalize",
                "gn_filter_fill_random", "gn_filter_info", "gn_filter_free", "gn_stream_create", "gn_stream_destroy",
                "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch", "gn_stream_set_postfilter",
-               "gn_fetch_postfilter", "gn_stream_set_long_reads", "gn_stream_device_matches",
+               "gn_fetch_postfilter", "gn_streams_postfilter_joint", "gn_stream_set_long_reads", "gn_stream_device_matches",
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
                "gn_stream_timings"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
-    _fields_ = [("rel_filter", C.c_double), ("fpr_query", C.c_double), ("target_fpr", C.c_void_p)]
+    _fields_ = [("rel_filter", C.c_double), ("fpr_query", C.c_double), ("target_fpr", C.c_void_p), ("joint", C.c_int)]
 
 
 class GanonHipError(RuntimeError):
@@ -90,6 +90,7 @@ def load_library():
     L.gn_stream_set_postfilter.argtypes = [vp, vp]
     L.gn_fetch_postfilter.argtypes = [vp, vp, C.POINTER(u64), C.POINTER(u64)]
     L.gn_stream_set_long_reads.argtypes = [vp, i32]
+    L.gn_streams_postfilter_joint.argtypes = [vp, u32]
     L.gn_stream_fetch_hashes.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.gn_stream_distinct_hashes.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.gn_filter_emplace_split.argtypes = [vp, vp, u64, u32, u64]
@@ -279,19 +280,25 @@ class HipStream:
         _check(L.gn_fetch_batch(self._h, None, None, None, _p(m), len(m), C.byref(need)))
         return nh, st, mo, m[: int(need.value)]
 
-    def set_postfilter(self, rel_filter: Optional[float] = None, fpr_query: float = 1.0, target_fpr=None) -> None:
+    def set_postfilter(self, rel_filter: Optional[float] = None, fpr_query: float = 1.0, target_fpr=None, joint: bool = False) -> None:
         """device-side pre-pass of filter_matches on the following batches (gn_stream_set_postfilter); rel_filter=None: off"""
         L = load_library()
         if rel_filter is None:
             _check(L.gn_stream_set_postfilter(self._h, None))
             return
         tf = None if target_fpr is None else np.ascontiguousarray(target_fpr, dtype=np.float64)
-        pf = PostFilter(float(rel_filter), float(fpr_query), None if tf is None else tf.ctypes.data_as(C.c_void_p))
+        pf = PostFilter(float(rel_filter), float(fpr_query), None if tf is None else tf.ctypes.data_as(C.c_void_p), 1 if joint else 0)
         _check(L.gn_stream_set_postfilter(self._h, C.byref(pf)))
 
     def set_long_reads(self, on: bool = True) -> None:
         """classify reads with more than 65535 minimisers too (the reference's -DLONGREADS build); flat IBF only"""
         _check(load_library().gn_stream_set_long_reads(self._h, 1 if on else 0))
+
+    @staticmethod
+    def postfilter_joint(streams) -> None:
+        """gn_streams_postfilter_joint: the pre-pass over the streams of one hierarchy level (same batch, disjoint targets)"""
+        arr = (C.c_void_p * len(streams))(*[st._h for st in streams])
+        _check(load_library().gn_streams_postfilter_joint(arr, len(streams)))
 
     def fetch_postfilter(self):
         """-> (max_count u32[n] before filtering, dropped by --rel-filter, dropped by --fpr-query) of the last batch"""

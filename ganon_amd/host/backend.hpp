@@ -64,12 +64,15 @@ struct BatchResult
     uint64_t              dropped_rel_filter = 0, dropped_fpr_query = 0;
 };
 
-// filter_matches parameters of a hierarchy level with ONE filter (GanonClassify.cpp:579-613,755-761)
+// filter_matches parameters of a hierarchy level (GanonClassify.cpp:579-613,755-761)
 struct PostFilterSpec
 {
-    double              rel_filter = 0.0;
-    double              fpr_query  = 1.0;
-    std::vector<double> target_fpr; // per FilterMeta target of that filter
+    double                           rel_filter = 0.0;
+    double                           fpr_query  = 1.0;
+    std::vector<std::vector<double>> target_fpr; // per filter of the level: per FilterMeta target of that filter
+    // several filters: no target name occurs in two of them (then the level's merge of matches is a plain union and the
+    // rules can be applied per filter with the level's max/min; otherwise the backend must leave everything to the host)
+    bool disjoint_targets = true;
 };
 
 // One device (or the test checker): receives filters, classifies batches.  Not thread-safe; one host thread each.
@@ -85,8 +88,8 @@ public:
     // above the limit by a safe margin) to be applied where the matches are produced, so that only survivors travel to the
     // host, which then applies the exact --fpr-query rule to them (except to those the backend marks as surely passing,
     // FilterResult::fpr_ok).  nullptr switches it off.  Returns whether the backend
-    // will do it for the filters it currently holds (one filter that sees whole reads); BatchResult::prefiltered says
-    // so per batch.  The default does nothing: the host then runs filter_matches on everything.
+    // will do it for the filters it currently holds (filters that see whole reads and report disjoint targets);
+    // BatchResult::prefiltered says so per batch.  The default does nothing: the host then runs filter_matches on everything.
     virtual bool set_postfilter(const PostFilterSpec* /*spec*/) { return false; }
     // Optional.  Reads with more than 65535 minimisers: classified like every other read (the reference's -DLONGREADS build)
     // instead of coming back with status 2.  Returns whether the backend can do that; flat IBF filters only.

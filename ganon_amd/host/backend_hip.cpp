@@ -391,7 +391,8 @@ public:
                 }
                 if (part.pf_generation != pf_generation_)
                 {
-                    gn_postfilter pf{ pf_spec_.rel_filter, pf_spec_.fpr_query, pf_spec_.target_fpr.data() };
+                    gn_postfilter pf{ pf_spec_.rel_filter, pf_spec_.fpr_query, pf_active_ ? pf_spec_.target_fpr[i].data() : nullptr,
+                                      filters_.size() > 1 ? 1 : 0 };
                     if (gn_stream_set_postfilter(part.s, pf_active_ ? &pf : nullptr) != GN_OK)
                     {
                         err = gn_last_error();
@@ -408,6 +409,17 @@ public:
                 }
             }
         lap(sec_submit_);
+        if (pf_active_ && filters_.size() > 1) // several filters: the rules need the level's max/min per read
+        {
+            std::vector<gn_stream*> level;
+            for (auto& lf : filters_)
+                level.push_back(lf.parts[0].s);
+            if (gn_streams_postfilter_joint(level.data(), (uint32_t)level.size()) != GN_OK)
+            {
+                err = gn_last_error();
+                return false;
+            }
+        }
         for (size_t i = 0; i < filters_.size(); ++i)
         {
             Logical&      lf = filters_[i];
@@ -421,16 +433,18 @@ public:
                     return false;
                 if (pf_active_)
                 {
-                    out.max_count.assign(n, 0);
+                    if (i == 0)
+                        out.max_count.assign(n, 0);
                     uint64_t a = 0, b2 = 0;
-                    if (gn_fetch_postfilter(lf.parts[0].s, out.max_count.data(), &a, &b2) != GN_OK)
+                    // (with several filters every stream holds the level's maximum: the first one's copy is taken)
+                    if (gn_fetch_postfilter(lf.parts[0].s, i == 0 ? out.max_count.data() : nullptr, &a, &b2) != GN_OK)
                     {
                         err = gn_last_error();
                         return false;
                     }
-                    out.prefiltered        = true;
-                    out.dropped_rel_filter = a;
-                    out.dropped_fpr_query  = b2;
+                    out.prefiltered = true;
+                    out.dropped_rel_filter += a;
+                    out.dropped_fpr_query += b2;
                 }
                 continue;
             }
@@ -482,24 +496,32 @@ public:
     {
         pf_active_ = false;
         ++pf_generation_;
-        if (!spec || filters_.size() != 1 || filters_[0].parts.size() != 1)
+        if (!spec || filters_.empty() || filters_.size() > 16 || spec->target_fpr.size() != filters_.size())
             return false;
-        const Part&         part = filters_[0].parts[0];
-        std::vector<double> dev_fpr;
-        if (part.to_target.empty())
-            dev_fpr = spec->target_fpr;
-        else
+        if (filters_.size() > 1 && !spec->disjoint_targets)
+            return false;
+        std::vector<std::vector<double>> dev_fpr(filters_.size());
+        for (size_t i = 0; i < filters_.size(); ++i)
         {
+            if (filters_[i].parts.size() != 1) // (a filter cut into column parts spreads a read over several streams)
+                return false;
+            const Part&                part = filters_[i].parts[0];
+            const std::vector<double>& fpr  = spec->target_fpr[i];
+            if (part.to_target.empty())
+            {
+                dev_fpr[i] = fpr;
+                continue;
+            }
             // device target ids must map one-to-one onto the filter's targets, or a read's matches are not what the host sees
-            std::vector<uint8_t> seen(spec->target_fpr.size(), 0);
-            dev_fpr.resize(part.to_target.size(), 0.0);
+            std::vector<uint8_t> seen(fpr.size(), 0);
+            dev_fpr[i].resize(part.to_target.size(), 0.0);
             for (size_t d = 0; d < part.to_target.size(); ++d)
             {
                 const uint32_t t = part.to_target[d];
                 if (t >= seen.size() || seen[t])
                     return false;
-                seen[t]    = 1;
-                dev_fpr[d] = spec->target_fpr[t];
+                seen[t]       = 1;
+                dev_fpr[i][d] = fpr[t];
             }
         }
         pf_spec_            = *spec;

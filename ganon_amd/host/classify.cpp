@@ -973,16 +973,28 @@ static bool ganon_classify(Config config)
         for (auto const& fc : level.filters)
             rel_cutoffs.push_back(fc.rel_cutoff);
 
-        // a level with one filter: the backends drop what filter_matches would drop where the matches are produced
+        // the backends drop what filter_matches would drop where the matches are produced: always possible with one filter,
+        // with several only if no target name occurs in two of them (else the level's merge keeps the larger count, :531-537)
         {
             PostFilterSpec spec;
             spec.rel_filter = level.rel_filter;
             spec.fpr_query  = level.fpr_query;
-            if (filters.size() == 1)
-                spec.target_fpr = filters[0].target_fpr;
-            const bool want = filters.size() == 1 && !getenv("GANON_HOST_NO_PREFILTER");
+            std::unordered_map<std::string, int> owner;
+            for (size_t i = 0; i < filters.size(); ++i)
+            {
+                spec.target_fpr.push_back(filters[i].target_fpr);
+                for (auto const& t : filters[i].targets)
+                    if (!owner.emplace(t, (int)i).second)
+                        spec.disjoint_targets = false;
+            }
+            const bool want = !getenv("GANON_HOST_NO_PREFILTER");
+            bool       on   = true;
             for (auto& be : backends)
-                be->set_postfilter(want ? &spec : nullptr);
+                on = be->set_postfilter(want ? &spec : nullptr) && on;
+            if (std::getenv("GANON_HOST_TIMING"))
+                std::cerr << "[prefilter] level " << level.label << ": filter_matches pre-pass on the device "
+                          << (on ? "on" : "off") << " (" << filters.size() << " filter(s), targets "
+                          << (spec.disjoint_targets ? "disjoint" : "shared between filters") << ")" << std::endl;
         }
 
         std::vector<ReadBatch> next_carried;

@@ -193,8 +193,16 @@ typedef struct gn_postfilter
     double        rel_filter;
     double        fpr_query;
     const double* target_fpr;
+    int           joint; /* 0: the pass runs with every batch.  1: one of several filters of a hierarchy level (see below) */
 } gn_postfilter;
 int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf);
+/* A hierarchy level with several filters: the reference merges their matches before it thresholds (:716-735,755-761), so a
+ * read's max/min are the level's.  If the filters' targets are DISJOINT (no target can be reported by two of them) the
+ * pre-pass still works per filter: submit the same batch to one stream per filter (same device, post-filters set with
+ * joint = 1), then call this once: it finds every stream's max/min per read, combines them, and applies the rules to every
+ * stream with the level's values.  Afterwards gn_fetch_batch / gn_fetch_postfilter work per stream as above (max_count is the
+ * level's maximum on every stream). */
+int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n_streams);
 /* after a batch with the pass on: per read the largest match count BEFORE filtering (0 = the read had no match; the
  * reference's max_count_read, :753,776,806), and how many matches each rule dropped in this batch */
 int gn_fetch_postfilter(gn_stream* s, uint32_t* max_count, uint64_t* dropped_rel_filter, uint64_t* dropped_fpr_query);

@@ -45,6 +45,20 @@ def world(tmp_path_factory):
         p = os.path.join(d, f"h{i}.hibf")
         gf.write_hibf(p, hb, [[f"/x/{n}.minimiser"] for n in sub], K, W, [0.05, 0.2][i])
         hibfs.append(p)
+    # ... and filters with DISJOINT targets (the joint device pre-pass of filter_matches runs on levels made of these)
+    d_ibfs, d_hibfs = [], []
+    thirds = [names[0::3], names[1::3], names[2::3]]
+    for i, sub in enumerate(thirds):
+        built = gf.build_ibf({n: genomes[n] for n in sub}, K, W, max_fp=[0.05, 0.1, 0.02][i], hash_functions=[3, 0, 4][i])
+        p = os.path.join(d, f"d{i}.ibf")
+        gf.write_ibf(p, built)
+        d_ibfs.append(p)
+    for i, sub in enumerate([names[0::2], names[1::2]]):
+        uh = {j: np.unique(oracle.minimiser_hash(oracle.to_ranks(genomes[n].encode()), K, W)) for j, n in enumerate(sub)}
+        hb = gf.random_hibf(len(sub), 64, 2, seed=60 + i, density=0.03, hash_funs=3, rows=(9000, 16000), user_hashes=uh)
+        p = os.path.join(d, f"dh{i}.hibf")
+        gf.write_hibf(p, hb, [[f"/x/{n}.minimiser"] for n in sub], K, W, [0.05, 0.1][i])
+        d_hibfs.append(p)
     tax = {n: f"G{i % 6}" for i, n in enumerate(names)}
     tax.update({f"G{i}": f"F{i % 2}" for i in range(6)})
     tax.update({"F0": "1", "F1": "1"})
@@ -72,17 +86,20 @@ def world(tmp_path_factory):
     gf.write_fastq(fq1, r1)
     gf.write_fastq(fq2, r2)
     gf.write_fasta(fa, r1[:300])
-    return dict(dir=d, ibfs=ibfs, hibfs=hibfs, tax=tax_path, fq1=fq1, fq2=fq2, fa=fa)
+    return dict(dir=d, ibfs=ibfs, hibfs=hibfs, d_ibfs=d_ibfs, d_hibfs=d_hibfs, tax=tax_path, fq1=fq1, fq2=fq2, fa=fa)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(20))
 def test_random_hierarchies_hip_equals_oracle_backend(oracle_bin, world, tmp_path, monkeypatch, seed):
     rng = np.random.default_rng(1000 + seed)
     hibf = bool(seed % 3 == 2)
-    pool = world["hibfs"] if hibf else world["ibfs"]
-    n_f = int(rng.integers(1, len(pool) + 1))
+    disjoint = seed >= 12 or seed % 4 == 1  # filters with disjoint targets: several per level still get the device pre-pass
+    pool = world[("d_" if disjoint else "") + ("hibfs" if hibf else "ibfs")]
+    n_f = len(pool) if seed >= 12 else int(rng.integers(1, len(pool) + 1))
     files = [pool[int(x)] for x in rng.permutation(len(pool))[:n_f]]
     labels = sorted(str(int(x)) for x in rng.integers(1, 3, size=n_f))  # one or two levels, possibly several filters each
+    if seed >= 16:
+        labels = ["1"] * n_f  # every filter on one level
     levels = sorted(set(labels))
     args = ["--ibf", ",".join(files), "--hierarchy-labels", ",".join(labels)]  # (vectors are comma-separated, as with cxxopts)
     args += ["--rel-cutoff", ",".join(repr(float(rng.choice([0.0, 0.05, 0.2, 0.5, 0.8]))) for _ in files)]
@@ -111,7 +128,12 @@ def test_random_hierarchies_hip_equals_oracle_backend(oracle_bin, world, tmp_pat
             monkeypatch.setenv("GANON_HOST_NO_PREFILTER", env)
         else:
             monkeypatch.delenv("GANON_HOST_NO_PREFILTER", raising=False)
-        cu.run(binary, args + ["-o", str(d / "o")])
+        if tag == "hip":
+            monkeypatch.setenv("GANON_HOST_TIMING", "1")
+        p = cu.run(binary, args + ["-o", str(d / "o")])
+        monkeypatch.delenv("GANON_HOST_TIMING", raising=False)
+        if tag == "hip" and seed >= 16:  # every filter on one level, disjoint targets: the joint device pre-pass must be what ran
+            assert f"pre-pass on the device on ({n_f} filter(s), targets disjoint)" in p.stderr, p.stderr[-500:]
         outs[tag] = {f: open(d / f, "rb").read() for f in sorted(os.listdir(d))}
     assert list(outs["hip"]) == list(outs["oracle"]) == list(outs["host_only"]) and len(outs["hip"]) >= 2
     for f in outs["hip"]:

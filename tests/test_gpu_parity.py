@@ -883,3 +883,78 @@ def test_matches_against_an_oracle_that_never_sees_device_hashes(hip, shape):
             assert n_match > 1000
             st.destroy()
     flt.free()
+
+
+@pytest.mark.parametrize("rel_filter,fpr_query", [(0.1, 1e-5), (0.0, 1.0), (0.5, 1e-2), (1.0, 1.0)])
+def test_joint_postfilter_over_the_filters_of_a_level(hip, rel_filter, fpr_query):
+    # three filters with disjoint targets classify the same batch; the pre-pass uses the LEVEL's max/min per read
+    # (GanonClassify.cpp:716-735,755-761), so its survivors are those of filter_matches on the union of the matches
+    k, w = 19, 31
+    rng = np.random.default_rng(99)
+    genomes = [gu.random_seq(rng, 3000) for _ in range(30)]
+    shapes = [("flat", 2048, 2003, 4), ("flat", 700, 3001, 3), ("hibf", 300, None, 3)]
+    flts, n_targets, tfprs = [], [], []
+    for fi, (kind, bins, rows, h) in enumerate(shapes):
+        mine = [g for gi, g in enumerate(genomes) if gi % 3 == fi]
+        if kind == "hibf":
+            uh = {ub * 7: np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)) for ub, g in enumerate(mine)}
+            hb = gf.random_hibf(bins, 64, 2, seed=11, density=0.4, hash_funs=h, user_hashes=uh)
+            flts.append(hip.HipFilter.hibf(*gf.hibf_upload_args(hb)))
+        else:
+            ibf = gf.random_ibf(bins, rows, h, 0.4, seed=20 + fi)
+            for gi, g in enumerate(mine):
+                ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), gi * 17 % bins)
+            flts.append(hip.HipFilter.ibf(ibf.data, bins, rows, h))
+        n_targets.append(bins)
+        tfprs.append(rng.choice([1e-4, 0.01, 0.05, 0.2], size=bins))
+    seqs = []
+    for i in range(500):
+        L = int(rng.choice([100, 150, 250]))
+        if i % 4:
+            g = genomes[i % 30]
+            p = int(rng.integers(0, 3000 - L))
+            seqs.append(g[p:p + L])
+        else:
+            seqs.append(gu.random_seq(rng, L))
+    bases, off1, off2 = gu.pack_reads(seqs, None)
+    sts = [hip.HipStream(f, len(seqs), bases.size) for f in flts]
+    raw = []
+    for st in sts:  # unfiltered matches of every filter
+        st.submit(bases, off1, off2, k, w, 0.15)
+        nh, status, mo, m = st.fetch()
+        raw.append([[(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]] for i in range(len(seqs))])
+    for st, tf in zip(sts, tfprs):
+        st.set_postfilter(rel_filter, fpr_query, tf, joint=True)
+        st.submit(bases, off1, off2, k, w, 0.15)
+    hip.HipStream.postfilter_joint(sts)
+    got, mxs, drops = [], [], []
+    for st in sts:
+        nh2, _, mo2, m2 = st.fetch()
+        mx, a, b = st.fetch_postfilter()
+        got.append([[(int(x["target"]), int(x["count"]) & 0x7FFFFFFF, int(x["count"]) >> 31) for x in m2[int(mo2[i]):int(mo2[i + 1])]]
+                    for i in range(len(seqs))])
+        mxs.append(mx)
+        drops.append((a, b))
+    base = np.concatenate([[0], np.cumsum(n_targets)])
+    all_fpr = np.concatenate(tfprs)
+    e_fil = e_fpr = dev_fpr = 0
+    for i in range(len(seqs)):
+        union = [(int(base[f]) + t, c) for f in range(3) for t, c in raw[f][i]]
+        kept, nf, nq, emx = _exact_filter_matches(union, nh[i], rel_filter, fpr_query, all_fpr)
+        kept = set(kept)
+        for f in range(3):
+            assert int(mxs[f][i]) == emx, (i, f)
+            g = [(int(base[f]) + t, c) for t, c, _ in got[f][i]]
+            mine = {u for u in union if base[f] <= u[0] < base[f + 1]}
+            assert kept & mine <= set(g) <= mine
+            assert {(int(base[f]) + t, c) for t, c, ok in got[f][i] if ok} <= kept
+            dev_fpr += len([u for u in mine if u not in set(g)])
+        e_fil += nf
+        e_fpr += nq
+    assert sum(a for a, _ in drops) == e_fil
+    assert sum(b for _, b in drops) == dev_fpr - e_fil <= e_fpr
+    assert any(max(len(r) for r in raw[f]) > 20 for f in range(3))
+    for st in sts:
+        st.destroy()
+    for f in flts:
+        f.free()
