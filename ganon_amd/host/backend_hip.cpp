@@ -364,8 +364,9 @@ public:
         // submit to every stream first (asynchronous), then fetch
         const uint64_t nb = std::max<uint64_t>(b.bases.size(), 1);
         for (size_t i = 0; i < filters_.size(); ++i)
-            for (auto& part : filters_[i].parts)
+            for (size_t g = 0; g < filters_[i].parts.size(); ++g)
             {
+                Part& part = filters_[i].parts[g];
                 if (!part.s || part.stream_reads < n || part.stream_bases < nb)
                 {
                     if (part.s)
@@ -391,8 +392,7 @@ public:
                 }
                 if (part.pf_generation != pf_generation_)
                 {
-                    gn_postfilter pf{ pf_spec_.rel_filter, pf_spec_.fpr_query, pf_active_ ? pf_spec_.target_fpr[i].data() : nullptr,
-                                      filters_.size() > 1 ? 1 : 0 };
+                    gn_postfilter pf{ pf_spec_.rel_filter, pf_spec_.fpr_query, pf_active_ ? pf_fpr_[i][g].data() : nullptr, pf_joint_ ? 1 : 0 };
                     if (gn_stream_set_postfilter(part.s, pf_active_ ? &pf : nullptr) != GN_OK)
                     {
                         err = gn_last_error();
@@ -409,11 +409,12 @@ public:
                 }
             }
         lap(sec_submit_);
-        if (pf_active_ && filters_.size() > 1) // several filters: the rules need the level's max/min per read
+        if (pf_active_ && pf_joint_) // several device filters: the rules need the level's max/min per read
         {
             std::vector<gn_stream*> level;
             for (auto& lf : filters_)
-                level.push_back(lf.parts[0].s);
+                for (auto& part : lf.parts)
+                    level.push_back(part.s);
             if (gn_streams_postfilter_joint(level.data(), (uint32_t)level.size()) != GN_OK)
             {
                 err = gn_last_error();
@@ -433,11 +434,12 @@ public:
                     return false;
                 if (pf_active_)
                 {
-                    if (i == 0)
+                    const bool first = out.max_count.empty();
+                    if (first)
                         out.max_count.assign(n, 0);
                     uint64_t a = 0, b2 = 0;
-                    // (with several filters every stream holds the level's maximum: the first one's copy is taken)
-                    if (gn_fetch_postfilter(lf.parts[0].s, i == 0 ? out.max_count.data() : nullptr, &a, &b2) != GN_OK)
+                    // (in a joint pass every stream holds the level's maximum: the first one's copy is taken)
+                    if (gn_fetch_postfilter(lf.parts[0].s, first ? out.max_count.data() : nullptr, &a, &b2) != GN_OK)
                     {
                         err = gn_last_error();
                         return false;
@@ -452,23 +454,46 @@ public:
             // the bins, so the concatenation is already in target order)
             std::vector<std::vector<uint64_t>> offs(lf.parts.size());
             std::vector<std::vector<Match>>    ms(lf.parts.size());
+            std::vector<std::vector<uint8_t>>  oks(lf.parts.size());
             for (size_t g = 0; g < lf.parts.size(); ++g)
             {
                 offs[g].assign((size_t)n + 1, 0);
-                if (!fetch_part(lf.parts[g], n, out, offs[g], ms[g], err))
+                if (!fetch_part(lf.parts[g], n, out, offs[g], ms[g], err, pf_active_ ? &oks[g] : nullptr))
                     return false;
+                if (pf_active_)
+                {
+                    const bool first = out.max_count.empty();
+                    if (first)
+                        out.max_count.assign(n, 0);
+                    uint64_t a = 0, b2 = 0;
+                    if (gn_fetch_postfilter(lf.parts[g].s, first ? out.max_count.data() : nullptr, &a, &b2) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
+                    out.prefiltered = true;
+                    out.dropped_rel_filter += a;
+                    out.dropped_fpr_query += b2;
+                }
                 for (uint32_t r = 0; r < n; ++r)
                     fr.match_off[r + 1] += offs[g][r + 1] - offs[g][r];
             }
             for (uint32_t r = 0; r < n; ++r)
                 fr.match_off[r + 1] += fr.match_off[r];
             fr.matches.resize(fr.match_off[n]);
+            fr.fpr_ok.clear();
+            if (pf_active_)
+                fr.fpr_ok.resize(fr.match_off[n]);
             for (uint32_t r = 0; r < n; ++r)
             {
                 uint64_t o = fr.match_off[r];
                 for (size_t g = 0; g < lf.parts.size(); ++g)
                     for (uint64_t x = offs[g][r]; x < offs[g][r + 1]; ++x)
+                    {
+                        if (pf_active_)
+                            fr.fpr_ok[o] = oks[g][x];
                         fr.matches[o++] = ms[g][x];
+                    }
             }
         }
         lap(sec_fetch_);
@@ -496,37 +521,48 @@ public:
     {
         pf_active_ = false;
         ++pf_generation_;
-        if (!spec || filters_.empty() || filters_.size() > 16 || spec->target_fpr.size() != filters_.size())
+        if (!spec || filters_.empty() || spec->target_fpr.size() != filters_.size())
             return false;
         if (filters_.size() > 1 && !spec->disjoint_targets)
             return false;
-        std::vector<std::vector<double>> dev_fpr(filters_.size());
+        // one device filter (a whole filter, or a column part of a wide one) per stream; their targets are disjoint -- parts
+        // are cut at target boundaries -- so all of a level's streams take part in one joint pass
+        size_t n_streams = 0;
+        for (auto const& lf : filters_)
+            n_streams += lf.parts.size();
+        if (n_streams > 16) // GN_PF_MAX_JOINT
+            return false;
+        pf_fpr_.assign(filters_.size(), {});
         for (size_t i = 0; i < filters_.size(); ++i)
         {
-            if (filters_[i].parts.size() != 1) // (a filter cut into column parts spreads a read over several streams)
-                return false;
-            const Part&                part = filters_[i].parts[0];
-            const std::vector<double>& fpr  = spec->target_fpr[i];
-            if (part.to_target.empty())
+            const std::vector<double>& fpr = spec->target_fpr[i];
+            std::vector<uint8_t>       seen(fpr.size(), 0);
+            pf_fpr_[i].resize(filters_[i].parts.size());
+            for (size_t g = 0; g < filters_[i].parts.size(); ++g)
             {
-                dev_fpr[i] = fpr;
-                continue;
-            }
-            // device target ids must map one-to-one onto the filter's targets, or a read's matches are not what the host sees
-            std::vector<uint8_t> seen(fpr.size(), 0);
-            dev_fpr[i].resize(part.to_target.size(), 0.0);
-            for (size_t d = 0; d < part.to_target.size(); ++d)
-            {
-                const uint32_t t = part.to_target[d];
-                if (t >= seen.size() || seen[t])
-                    return false;
-                seen[t]       = 1;
-                dev_fpr[i][d] = fpr[t];
+                const Part& part = filters_[i].parts[g];
+                if (part.to_target.empty())
+                {
+                    if (filters_[i].parts.size() != 1)
+                        return false;
+                    pf_fpr_[i][g] = fpr;
+                    continue;
+                }
+                // device target ids must map one-to-one onto the filter's targets, or a read's matches are not what the host sees
+                pf_fpr_[i][g].resize(part.to_target.size(), 0.0);
+                for (size_t d = 0; d < part.to_target.size(); ++d)
+                {
+                    const uint32_t t = part.to_target[d];
+                    if (t >= seen.size() || seen[t])
+                        return false;
+                    seen[t]          = 1;
+                    pf_fpr_[i][g][d] = fpr[t];
+                }
             }
         }
-        pf_spec_            = *spec;
-        pf_spec_.target_fpr = std::move(dev_fpr);
-        pf_active_          = true;
+        pf_spec_   = *spec;
+        pf_joint_  = n_streams > 1;
+        pf_active_ = true;
         return true;
     }
 
@@ -615,6 +651,8 @@ private:
     std::vector<Logical>  filters_;
     std::vector<gn_match> tmp_;
     PostFilterSpec        pf_spec_;
+    std::vector<std::vector<std::vector<double>>> pf_fpr_; // [filter][part]: per device target of that part
+    bool                  pf_joint_ = false;
     bool                  pf_active_ = false;
     uint64_t              pf_generation_ = 1;
 };

@@ -461,9 +461,10 @@ def wide_db(tmp_path_factory):
     return dict(ibf=path, fq=fq, n_targets=t)
 
 
-def _run_wide(binary, db, out):
-    cu.run(binary, ["--ibf", db["ibf"], "--single-reads", db["fq"], "-o", out, "--output-all", "--output-unclassified", "--rel-cutoff",
-                    "0.5", "--quiet"])
+def _run_wide(binary, db, out, extra=()):
+    p = cu.run(binary, ["--ibf", db["ibf"], "--single-reads", db["fq"], "-o", out, "--output-all", "--output-unclassified", "--rel-cutoff",
+                        "0.5", "--quiet"] + list(extra))
+    _run_wide.last_stderr = p.stderr
     return out
 
 
@@ -474,12 +475,22 @@ def test_wide_filter_oracle_backend(oracle_bin, wide_db, tmp_path):
 
 
 @pytest.mark.gpu
-def test_wide_filter_hip_column_parts_equal_oracle_backend(oracle_bin, wide_db, tmp_path):
+def test_wide_filter_hip_column_parts_equal_oracle_backend(oracle_bin, wide_db, tmp_path, monkeypatch):
     # 150 000 technical bins = 2344 words per row: three device filters behind one --ibf
     a = _run_wide(cu.BIN_HIP, wide_db, str(tmp_path / "hip"))
     b = _run_wide(oracle_bin, wide_db, str(tmp_path / "ora"))
     for ext in (".all", ".unc", ".rep"):
         assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), ext
+    # with thresholds that make filter_matches drop things: the column parts take part in ONE joint device pre-pass
+    # (their targets are disjoint: parts are cut at target boundaries), and nothing changes in the output
+    thr = ["--rel-filter", "0.3", "--fpr-query", "1e-3", "--output-stats"]
+    monkeypatch.setenv("GANON_HOST_TIMING", "1")
+    c = _run_wide(cu.BIN_HIP, wide_db, str(tmp_path / "hip_thr"), thr)
+    assert "pre-pass on the device on (1 filter(s)" in _run_wide.last_stderr
+    monkeypatch.delenv("GANON_HOST_TIMING")
+    d = _run_wide(oracle_bin, wide_db, str(tmp_path / "ora_thr"), thr)
+    for ext in (".all", ".unc", ".rep", ".sta"):
+        assert open(c + ext, "rb").read() == open(d + ext, "rb").read(), ext
 
 
 @pytest.mark.gpu
