@@ -58,7 +58,7 @@ public:
         }
         void* p = nullptr;
         if (gn_pinned_alloc(cls, &p) != GN_OK)
-            return nullptr;
+            return std::malloc(n ? n : 1); // (no more lockable memory: an ordinary buffer still works, its copies are just staged)
         std::lock_guard<std::mutex> lk(m_);
         size_of_[p] = cls;
         return p;
@@ -67,10 +67,16 @@ public:
     {
         if (!p)
             return;
-        std::lock_guard<std::mutex> lk(m_);
-        auto it = size_of_.find(p);
-        if (it != size_of_.end())
-            free_[it->second].push_back(p);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            auto it = size_of_.find(p);
+            if (it != size_of_.end())
+            {
+                free_[it->second].push_back(p);
+                return;
+            }
+        }
+        std::free(p); // (the malloc fallback of take())
     }
     // blocks for the first slabs of the reader (32 MiB holds the bases of a 48 MiB FASTQ slab), locked in the background
     void warm_up()
