@@ -89,7 +89,7 @@ def world(tmp_path_factory):
     return dict(dir=d, ibfs=ibfs, hibfs=hibfs, d_ibfs=d_ibfs, d_hibfs=d_hibfs, tax=tax_path, fq1=fq1, fq2=fq2, fa=fa)
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GANON_FUZZ_SEEDS", "20"))))  # (soak runs: GANON_FUZZ_SEEDS=100)
 def test_random_hierarchies_hip_equals_oracle_backend(oracle_bin, world, tmp_path, monkeypatch, seed):
     rng = np.random.default_rng(1000 + seed)
     hibf = bool(seed % 3 == 2)
