@@ -65,8 +65,9 @@ const Opt kOpts[] = {
     { 0, "verbose", Kind::Bool, "Verbose output mode" },
     { 0, "quiet", Kind::Bool, "Quiet output mode (only outputs errors and warnings to the STDERR)" },
     { 0, "device", Kind::Devices,
-      "MI355X device(s): one index, a comma-separated list or 'all' -- the filters are replicated into every listed GPU and "
-      "the read batches are shared out among them (extension; default $GANON_DEVICE or 0)" },
+      "MI355X device(s): one index, a comma-separated list or 'all' -- one classify worker per entry, one copy of the filters "
+      "per GPU (an index listed twice: two workers sharing it), read batches shared out among the workers (extension; default "
+      "$GANON_DEVICE, else GPU 0 with --threads workers, at least 2, at most 4)" },
     { 'h', "help", Kind::Help, "Print help" },
     { 'v', "version", Kind::Version, "Show version" },
 };
