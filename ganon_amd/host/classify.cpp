@@ -1155,7 +1155,7 @@ static bool ganon_classify(Config config)
                                     q -= binomial_coefficient(n_hashes, i) * pow(me.fpr, i) * pow(1 - me.fpr, n_hashes - i);
                                 if (q > level.fpr_query)
                                 {
-                                    tally_at(per_target, me.gid).dropped_by_fpr_query++;
+                                    total.dropped_by_fpr_query++; // (only the level's total is ever reported: no per-target row to touch)
                                     continue;
                                 }
                             }
@@ -1171,7 +1171,7 @@ static bool ganon_classify(Config config)
                                 append_line(buf_all, rb.id(r), node_names[me.gid], me.count);
                         }
                         else
-                            tally_at(per_target, me.gid).dropped_by_rel_filter++;
+                            total.dropped_by_rel_filter++;
                     }
                     if (kept > 0)
                     {

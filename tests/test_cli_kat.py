@@ -206,16 +206,25 @@ def _check_sim_against_oracle_level(sim_db, prefix, hibf):
     r1, r2 = _sim_reads()
     res = cu.Res(prefix)
     res.sanity_check(has_tax=True)
-    n_class = 0
+    n_class = n_matches = dis_filter = dis_fpr = 0
     for (rid, s1), (_, s2) in zip(r1, r2):
         rr = lvl.classify(oracle.to_ranks(s1), oracle.to_ranks(s2))
+        dis_filter += len(rr.discarded_filter)
+        dis_fpr += len(rr.discarded_fpr)
         if rr.kept:
             n_class += 1
+            n_matches += len(rr.kept)
             assert res.all.get(rid) == rr.kept, (rid, res.all.get(rid), rr.kept)
         else:
             assert rid not in res.all and rid in res.unc
     assert res.total_classified == n_class and n_class > 20
     assert res.total_classified + res.total_unclassified == len(r1)
+    # the .sta row (write_stats :1167-1218): classified reads, matches and the two discarded-match totals are the oracle's
+    head, row = [line.rstrip("\n").split("\t") for line in open(prefix + ".sta")][:2]
+    sta = dict(zip(head, row))
+    assert (int(sta["seq_classified"]), int(sta["matches"])) == (n_class, n_matches)
+    assert (int(sta["dis_matches_rel_filter"]), int(sta["dis_matches_fpr_query"])) == (dis_filter, dis_fpr)
+    assert hibf or dis_filter > 0
 
 
 def test_sim_fastq_gz_ibf_oracle_backend(oracle_bin, sim_db, tmp_path):
