@@ -270,6 +270,8 @@ struct gn_stream
     uint32_t*           d_pf_gmax = nullptr; // joint pass: the level's max / min per read (filled on the first stream)
     uint32_t*           d_pf_gmin = nullptr;
     bool                pf_joint  = false;   // the pass is run by gn_streams_postfilter_joint, not with the batch
+    bool                pf_merge  = false;   // ... in its merging form (filters of the level share targets)
+    uint32_t*           d_pf_gid  = nullptr; // merging form: device target -> level-wide target id
     double*             d_pf_fpr  = nullptr; // per target
     unsigned long long* d_pf_ctr  = nullptr; // [0] dropped rel_filter [1] dropped fpr_query [2] survivors
     unsigned long long* h_pf_ctr  = nullptr; // pinned copy

@@ -27,6 +27,8 @@
 #include <hipcub/hipcub.hpp>
 
 #define GN_PF_SMALL 6u
+#define GN_PF_MERGE_CAP 512u
+#define GN_MATCH_REMOVED 0x40000000u // (internal: entry dropped by the level merge; compacted away before anything is fetched)
 
 struct GnPostfilterParams
 {
@@ -81,6 +83,7 @@ __device__ __forceinline__ uint32_t gn_pf_threshold(uint32_t mx, uint32_t mn, do
 // MODE 0: max/min of the read's own matches, then the rules (one filter per level)
 // MODE 1: max/min only (-> maxc, minc): the first half of the joint pass over a level's filters
 // MODE 2: the rules with the level's max/min given (gmax, gmin): its second half
+// MODE 3: sweep after gn_pf_merge_kernel (levels whose filters share targets): entries marked GN_MATCH_REMOVED go
 template <int MODE>
 __global__ void gn_postfilter_kernel(GnPostfilterParams p)
 {
@@ -107,7 +110,7 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
             mx = p.gmax[r];
             mn = p.gmin[r];
         }
-        else
+        else if constexpr (MODE != 3)
             for (uint32_t j = 0; j < c; ++j)
             {
                 const uint32_t ct = p.m[o + j].count;
@@ -118,6 +121,17 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
         {
             p.maxc[r] = mx;
             p.minc[r] = mn;
+        }
+        else if constexpr (MODE == 3) // the level merge marked what goes: sweep
+        {
+            uint32_t kept = 0;
+            for (uint32_t j = 0; j < c; ++j)
+            {
+                const gn_match m = p.m[o + j];
+                if (!(m.count & GN_MATCH_REMOVED))
+                    p.m[o + kept++] = m;
+            }
+            p.keep[r] = kept;
         }
         else
         {
@@ -159,7 +173,27 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
         const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)L);
         const uint32_t nn = (uint32_t)__builtin_amdgcn_readlane((int)n, (int)L);
         uint32_t mx = 0, mn = nn;
-        if constexpr (MODE == 2)
+        if constexpr (MODE == 3)
+        {
+            uint32_t kept = 0;
+            for (uint32_t j0 = 0; j0 < cc; j0 += 64)
+            {
+                const uint32_t j   = j0 + lane;
+                const bool     act = j < cc;
+                gn_match       m{};
+                if (act)
+                    m = p.m[oo + j];
+                const bool     k  = act && !(m.count & GN_MATCH_REMOVED);
+                const uint64_t km = __ballot(k);
+                if (k)
+                    p.m[oo + kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = m;
+                kept += (uint32_t)__popcll(km);
+            }
+            if (lane == 0)
+                p.keep[rr] = kept;
+            continue;
+        }
+        else if constexpr (MODE == 2)
         {
             mx = p.gmax[rr];
             mn = p.gmin[rr];
@@ -351,6 +385,170 @@ __global__ void gn_pf_combine_kernel(GnPfLists l, uint32_t n, uint32_t* __restri
     gmin[r] = b;
 }
 
+// ---- levels whose filters SHARE targets ----------------------------------------------------------------------------------
+// The reference merges a read's matches filter after filter (GanonClassify.cpp:531-537): an entry replaces the target's entry
+// only if its count is larger, and max_count_read / min_count_read are updated only by entries that got in.  Replayed here per
+// read: the matches of all streams, keyed by (level-wide target id, filter order), are ranked in LDS; within a target's group
+//   inserted(e) = count(e) > max(count of the earlier filters' entries),   winner = the largest count, earliest filter on ties
+// max = max over all counts, min = min(n_hashes, counts of inserted entries); the rules of filter_matches then apply to the
+// winners (one per target -- what the merged map holds), everything else is removed.  A read with more than GN_PF_MERGE_CAP
+// matches over all filters is left untouched and flagged (bit 31 of its max_count): the host does that read itself.
+
+struct GnPfMergeParams
+{
+    gn_match*       m[GN_PF_MAX_JOINT];
+    const uint64_t* off[GN_PF_MAX_JOINT];
+    uint32_t        stride[GN_PF_MAX_JOINT];
+    const uint32_t* gid[GN_PF_MAX_JOINT];  // device target -> level-wide target id
+    const double*   fpr[GN_PF_MAX_JOINT];
+    uint64_t        n_targets[GN_PF_MAX_JOINT];
+    uint32_t*       maxc[GN_PF_MAX_JOINT];
+    uint32_t        k;
+    uint32_t        n_reads;
+    const uint32_t* nh;
+    double          rel_filter, fpr_query;
+    unsigned long long* ctr; // stream 0's: [0] dropped rel_filter [1] dropped fpr_query
+};
+
+__global__ __launch_bounds__(256) void gn_pf_merge_kernel(GnPfMergeParams p)
+{
+    __shared__ uint32_t key[4][GN_PF_MERGE_CAP], cnt[4][GN_PF_MERGE_CAP], skey[4][GN_PF_MERGE_CAP], scnt[4][GN_PF_MERGE_CAP];
+    __shared__ uint16_t sidx[4][GN_PF_MERGE_CAP];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const bool     fpr_on = p.fpr_query < 1.0;
+    uint32_t       n_fil = 0, n_fpr = 0;
+    for (uint32_t r = blockIdx.x * 4 + wv; r < p.n_reads; r += gridDim.x * 4)
+    {
+        // entries of the read: filter f's segment is [o_f, o_f + c_f)
+        uint64_t o[GN_PF_MAX_JOINT];
+        uint32_t c[GN_PF_MAX_JOINT], total = 0;
+        for (uint32_t f = 0; f < p.k; ++f)
+        {
+            o[f] = p.off[f][(uint64_t)r * p.stride[f]];
+            c[f] = (uint32_t)(p.off[f][(uint64_t)(r + 1) * p.stride[f]] - o[f]);
+            total += c[f];
+        }
+        const uint32_t n = p.nh[r];
+        if (total == 0)
+        {
+            if (lane == 0)
+                for (uint32_t f = 0; f < p.k; ++f)
+                    p.maxc[f][r] = 0;
+            continue;
+        }
+        if (total > GN_PF_MERGE_CAP)
+        {
+            if (lane == 0) // the host takes this read as it is
+                for (uint32_t f = 0; f < p.k; ++f)
+                    p.maxc[f][r] = 0x80000000u;
+            continue;
+        }
+        // load: key = gid * 16 + filter (unique), count, index inside the filter's segment
+        uint32_t base = 0;
+        for (uint32_t f = 0; f < p.k; ++f)
+        {
+            for (uint32_t j = lane; j < c[f]; j += 64)
+            {
+                const gn_match mt = p.m[f][o[f] + j];
+                key[wv][base + j] = p.gid[f][mt.target] * 16u + f;
+                cnt[wv][base + j] = mt.count;
+            }
+            base += c[f];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // rank by counting (keys are unique when every filter's gid table is injective) -> sorted copies
+        for (uint32_t e = lane; e < total; e += 64)
+        {
+            const uint32_t ke = key[wv][e];
+            uint32_t       rank = 0;
+            for (uint32_t x = 0; x < total; ++x)
+                rank += (key[wv][x] < ke || (key[wv][x] == ke && x < e)) ? 1u : 0u; // (ties only if a gid table repeats an id)
+            skey[wv][rank] = ke;
+            scnt[wv][rank] = cnt[wv][e];
+            sidx[wv][rank] = (uint16_t)e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // per entry: inserted? winner of its target?
+        uint32_t mx = 0, mn = n;
+        for (uint32_t e = lane; e < total; e += 64)
+        {
+            const uint32_t g = skey[wv][e] >> 4, ce = scnt[wv][e];
+            uint32_t       before = 0;
+            for (uint32_t x = e; x > 0 && (skey[wv][x - 1] >> 4) == g; --x)
+                before = scnt[wv][x - 1] > before ? scnt[wv][x - 1] : before;
+            mx = ce > mx ? ce : mx;
+            if (ce > before)
+                mn = ce < mn ? ce : mn;
+        }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1)
+        {
+            const uint32_t a = (uint32_t)__shfl_xor((int)mx, sh), b = (uint32_t)__shfl_xor((int)mn, sh);
+            mx = a > mx ? a : mx;
+            mn = b < mn ? b : mn;
+        }
+        const uint32_t thr = gn_pf_threshold(mx, mn, p.rel_filter);
+        for (uint32_t e = lane; e < total; e += 64)
+        {
+            const uint32_t g = skey[wv][e] >> 4, f = skey[wv][e] & 15u, ce = scnt[wv][e];
+            bool           winner = true; // largest count of the group; the earliest filter on ties
+            for (uint32_t x = e; x > 0 && (skey[wv][x - 1] >> 4) == g; --x)
+                winner = winner && scnt[wv][x - 1] < ce;
+            for (uint32_t x = e + 1; x < total && (skey[wv][x] >> 4) == g; ++x)
+                winner = winner && scnt[wv][x] <= ce;
+            // position of the entry in its filter's segment
+            uint32_t pos = sidx[wv][e];
+            for (uint32_t ff = 0; ff < f; ++ff)
+                pos -= c[ff];
+            gn_match* rec = p.m[f] + o[f] + pos;
+            uint32_t  out = ce;
+            if (!winner)
+                out |= GN_MATCH_REMOVED;
+            else if (ce < thr)
+            {
+                out |= GN_MATCH_REMOVED;
+                ++n_fil;
+            }
+            else if (fpr_on)
+            {
+                const uint32_t t = rec->target;
+                const uint32_t v = gn_fpr_verdict(n, ce, t < p.n_targets[f] ? p.fpr[f][t] : 0.0, p.fpr_query);
+                if (v == 1)
+                {
+                    out |= GN_MATCH_REMOVED;
+                    ++n_fpr;
+                }
+                else if (v == 2)
+                    out |= GN_MATCH_FPR_OK;
+            }
+            rec->count = out;
+        }
+        if (lane == 0)
+            for (uint32_t f = 0; f < p.k; ++f)
+                p.maxc[f][r] = mx;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1)
+    {
+        n_fil += (uint32_t)__shfl_xor((int)n_fil, sh);
+        n_fpr += (uint32_t)__shfl_xor((int)n_fpr, sh);
+    }
+    if (lane == 0)
+    {
+        if (n_fil)
+            atomicAdd(&p.ctr[0], (unsigned long long)n_fil);
+        if (n_fpr)
+            atomicAdd(&p.ctr[1], (unsigned long long)n_fpr);
+    }
+}
+
 int gn_finish_batch(gn_stream* s); // gn_capi.hip: waits for the batch, re-runs it after a match-buffer overflow
 
 // Several filters of one hierarchy level, the same batch classified against each (one stream per filter, one device):
@@ -373,6 +571,60 @@ extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n
     GN_HIP(hipSetDevice(s0->device));
     const uint32_t n      = s0->n_reads;
     const unsigned blocks = (unsigned)(((uint64_t)n + 1 + 255) / 256);
+    bool           merge  = false;
+    for (uint32_t i = 0; i < n_streams; ++i)
+        merge = merge || streams[i]->pf_merge;
+    if (merge)
+    {
+        // filters that share targets: one kernel replays the level's merge per read over all streams, then every stream
+        // sweeps what was marked
+        GnPfMergeParams mp{};
+        mp.k = n_streams;
+        for (uint32_t i = 0; i < n_streams; ++i)
+        {
+            gn_stream* s = streams[i];
+            if (!s->pf_merge || !s->d_pf_gid)
+                return gn_fail(GN_EINVAL, "stream %u of a merging joint pass has no target_gid table", i);
+            int rc = gn_finish_batch(s);
+            if (rc)
+                return rc;
+            GN_HIP(hipMemsetAsync(s->d_pf_ctr, 0, 4 * sizeof(unsigned long long), s->st));
+            mp.m[i]         = s->d_sorted;
+            mp.off[i]       = s->d_seg_off;
+            mp.stride[i]    = s->f->is_hibf ? 1u : (uint32_t)s->f->geom.wpr;
+            mp.gid[i]       = s->d_pf_gid;
+            mp.fpr[i]       = s->d_pf_fpr;
+            mp.n_targets[i] = s->f->is_hibf ? s->f->n_user_bins : s->f->n_targets;
+            mp.maxc[i]      = s->d_pf_max;
+        }
+        mp.n_reads    = n;
+        mp.nh         = s0->d_nh;
+        mp.rel_filter = s0->pf_rel_filter;
+        mp.fpr_query  = s0->pf_fpr_query;
+        mp.ctr        = s0->d_pf_ctr;
+        for (uint32_t i = 0; i < n_streams; ++i)
+            GN_HIP(hipStreamSynchronize(streams[i]->st));
+        if (n)
+        {
+            unsigned mb = (n + 3) / 4;
+            if (mb > 8192u)
+                mb = 8192u;
+            hipLaunchKernelGGL(gn_pf_merge_kernel, dim3(mb), dim3(256), 0, s0->st, mp);
+        }
+        GN_HIP(hipGetLastError());
+        GN_HIP(hipStreamSynchronize(s0->st));
+        for (uint32_t i = 0; i < n_streams; ++i)
+        {
+            gn_stream*               s = streams[i];
+            const GnPostfilterParams p = gn_pf_params(s);
+            hipLaunchKernelGGL(gn_postfilter_kernel<3>, dim3(blocks), dim3(256), 0, s->st, p);
+            GN_HIP(hipGetLastError());
+            int rc = gn_pf_finish(s, p);
+            if (rc)
+                return rc;
+        }
+        return GN_OK;
+    }
     GnPfLists      lists{};
     lists.k = n_streams;
     for (uint32_t i = 0; i < n_streams; ++i)
@@ -450,19 +702,32 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
     s->pf_rel_filter = pf->rel_filter;
     s->pf_fpr_query  = pf->fpr_query;
     s->pf_joint      = pf->joint != 0;
+    s->pf_merge      = pf->joint == 2;
+    if (s->pf_merge)
+    {
+        if (!pf->target_gid)
+            return gn_fail(GN_EINVAL, "joint = 2 needs target_gid");
+        if (!s->d_pf_gid)
+            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_gid), (nt ? nt : 1) * sizeof(uint32_t)));
+        for (uint64_t t = 0; t < nt; ++t)
+            if (pf->target_gid[t] >= (1u << 28))
+                return gn_fail(GN_ERANGE, "level-wide target ids must be below 2^28");
+        if (nt)
+            GN_HIP(hipMemcpy(s->d_pf_gid, pf->target_gid, nt * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     s->pf_on         = true;
     return GN_OK;
 }
 
 void gn_postfilter_release(gn_stream* s)
 {
-    void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_min, s->d_pf_gmax, s->d_pf_gmin, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan };
+    void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_min, s->d_pf_gmax, s->d_pf_gmin, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan, s->d_pf_gid };
     for (void* q : ptrs)
         if (q)
             hipFree(q);
     if (s->h_pf_ctr)
         hipHostFree(s->h_pf_ctr);
-    s->d_pf_keep = s->d_pf_max = s->d_pf_min = s->d_pf_gmax = s->d_pf_gmin = nullptr;
+    s->d_pf_keep = s->d_pf_max = s->d_pf_min = s->d_pf_gmax = s->d_pf_gmin = s->d_pf_gid = nullptr;
     s->d_pf_ctr  = nullptr;
     s->d_pf_fpr  = nullptr;
     s->d_pf_scan = nullptr;

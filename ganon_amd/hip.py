@@ -25,7 +25,8 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
 
 
 class PostFilter(C.Structure):  # gn_postfilter
-    _fields_ = [("rel_filter", C.c_double), ("fpr_query", C.c_double), ("target_fpr", C.c_void_p), ("joint", C.c_int)]
+    _fields_ = [("rel_filter", C.c_double), ("fpr_query", C.c_double), ("target_fpr", C.c_void_p), ("joint", C.c_int),
+                ("target_gid", C.c_void_p)]
 
 
 class GanonHipError(RuntimeError):
@@ -280,14 +281,16 @@ class HipStream:
         _check(L.gn_fetch_batch(self._h, None, None, None, _p(m), len(m), C.byref(need)))
         return nh, st, mo, m[: int(need.value)]
 
-    def set_postfilter(self, rel_filter: Optional[float] = None, fpr_query: float = 1.0, target_fpr=None, joint: bool = False) -> None:
+    def set_postfilter(self, rel_filter: Optional[float] = None, fpr_query: float = 1.0, target_fpr=None, joint=False, target_gid=None) -> None:
         """device-side pre-pass of filter_matches on the following batches (gn_stream_set_postfilter); rel_filter=None: off"""
         L = load_library()
         if rel_filter is None:
             _check(L.gn_stream_set_postfilter(self._h, None))
             return
         tf = None if target_fpr is None else np.ascontiguousarray(target_fpr, dtype=np.float64)
-        pf = PostFilter(float(rel_filter), float(fpr_query), None if tf is None else tf.ctypes.data_as(C.c_void_p), 1 if joint else 0)
+        tg = None if target_gid is None else np.ascontiguousarray(target_gid, dtype=np.uint32)
+        pf = PostFilter(float(rel_filter), float(fpr_query), None if tf is None else tf.ctypes.data_as(C.c_void_p),
+                        2 if tg is not None else (1 if joint else 0), None if tg is None else tg.ctypes.data_as(C.c_void_p))
         _check(L.gn_stream_set_postfilter(self._h, C.byref(pf)))
 
     def set_long_reads(self, on: bool = True) -> None:

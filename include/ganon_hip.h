@@ -193,7 +193,8 @@ typedef struct gn_postfilter
     double        rel_filter;
     double        fpr_query;
     const double* target_fpr;
-    int           joint; /* 0: the pass runs with every batch.  1: one of several filters of a hierarchy level (see below) */
+    int           joint; /* 0: the pass runs with every batch.  1 / 2: one of several filters of a hierarchy level (see below) */
+    const uint32_t* target_gid; /* joint == 2: level-wide id (< 2^28) of every target of this filter (same size as target_fpr) */
 } gn_postfilter;
 int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf);
 /* A hierarchy level with several filters: the reference merges their matches before it thresholds (:716-735,755-761), so a

@@ -958,3 +958,106 @@ def test_joint_postfilter_over_the_filters_of_a_level(hip, rel_filter, fpr_query
         st.destroy()
     for f in flts:
         f.free()
+
+
+@pytest.mark.parametrize("rel_filter,fpr_query", [(0.1, 1e-5), (0.0, 1.0), (0.5, 1e-2), (1.0, 1.0)])
+def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr_query):
+    # three filters report overlapping sets of level-wide targets; the device replays the reference's merge per read
+    # (GanonClassify.cpp:531-537: larger count wins, max/min follow the entries that got in) and applies filter_matches to the
+    # winners -- checked against a replay of the same rule on the unfiltered matches and the oracle's filter_matches
+    import ctypes as C
+    import math
+    k, w = 19, 31
+    rng = np.random.default_rng(7)
+    genomes = [gu.random_seq(rng, 3000) for _ in range(30)]
+    n_gid = 900
+    shapes = [(512, 2003, 4), (700, 3001, 3), (300, 1201, 2)]
+    flts, gids, tfprs, ibfs = [], [], [], []
+    for fi, (bins, rows, h) in enumerate(shapes):
+        ibf = gf.random_ibf(bins, rows, h, 0.45, seed=40 + fi)
+        for gi, g in enumerate(genomes):
+            if (gi + fi) % 2 == 0:  # every genome sits in two of the three filters
+                ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), gi)
+        gid = (30 + rng.permutation(n_gid)[:bins]).astype(np.uint32)  # (a filter names every target once)
+        gid[:30] = np.arange(30)  # bin gi of every filter is the level's target gi: shared
+        flts.append(hip.HipFilter.ibf(ibf.data, bins, rows, h))
+        gids.append(gid)
+        tfprs.append(rng.choice([1e-4, 0.01, 0.05, 0.2], size=bins))
+    seqs = []
+    for i in range(400):
+        L = int(rng.choice([100, 150, 250]))
+        if i % 4:
+            g = genomes[i % 30]
+            p = int(rng.integers(0, 3000 - L))
+            seqs.append(g[p:p + L])
+        else:
+            seqs.append(gu.random_seq(rng, L))
+    bases, off1, off2 = gu.pack_reads(seqs, None)
+    sts = [hip.HipStream(f, len(seqs), bases.size) for f in flts]
+    raw = []
+    for st in sts:
+        st.submit(bases, off1, off2, k, w, 0.12)
+        nh, status, mo, m = st.fetch()
+        raw.append([[(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]] for i in range(len(seqs))])
+    for st, tf, gid in zip(sts, tfprs, gids):
+        st.set_postfilter(rel_filter, fpr_query, tf, target_gid=gid)
+        st.submit(bases, off1, off2, k, w, 0.12)
+    hip.HipStream.postfilter_joint(sts)
+    got, mxs, drops = [], [], []
+    for st in sts:
+        _, _, mo2, m2 = st.fetch()
+        mx, a, b = st.fetch_postfilter()
+        got.append([{int(x["target"]): (int(x["count"]) & 0x3FFFFFFF, int(x["count"]) >> 31) for x in m2[int(mo2[i]):int(mo2[i + 1])]}
+                    for i in range(len(seqs))])
+        mxs.append(mx)
+        drops.append((a, b))
+    L_ = oracle.lib()
+    L_.gno_filter_matches.restype = C.c_size_t
+    e_fil = e_fpr = d_fpr = n_big = n_shared = 0
+    for i in range(len(seqs)):
+        n = int(nh[i])
+        merged, mxc, mnc = {}, 0, n
+        for f in range(3):  # the reference's loop over the filters of the level
+            for t, c in raw[f][i]:
+                g = int(gids[f][t])
+                if c > merged.get(g, (0,))[0]:
+                    n_shared += g in merged
+                    merged[g] = (c, f, t)
+                    mxc, mnc = max(mxc, c), min(mnc, c)
+        total = sum(len(raw[f][i]) for f in range(3))
+        if total > 512:  # left to the caller
+            n_big += 1
+            assert all(int(mxs[f][i]) == 0x80000000 for f in range(3))
+            assert all(got[f][i] == {t: (c, 0) for t, c in raw[f][i]} for f in range(3))
+            continue
+        assert all(int(mxs[f][i]) == mxc for f in range(3)), i
+        if not merged:
+            assert all(not got[f][i] for f in range(3))
+            continue
+        thr = mxc - int(math.ceil(float(mxc - mnc) * rel_filter))
+        items = sorted(merged.items())
+        counts = np.array([v[0] for _, v in items], dtype=np.uint64)
+        fprs = np.array([tfprs[v[1]][v[2]] for _, v in items], dtype=np.float64)
+        keep = np.zeros(len(items), dtype=np.uint8)
+        L_.gno_filter_matches(counts.ctypes.data_as(C.c_void_p), fprs.ctypes.data_as(C.c_void_p), C.c_size_t(len(items)), C.c_uint64(n),
+                              C.c_uint64(thr), C.c_double(fpr_query), keep.ctypes.data_as(C.c_void_p))
+        e_fil += int((keep == 2).sum())
+        e_fpr += int((keep == 3).sum())
+        for (g, (c, f, t)), kflag in zip(items, keep):
+            present = t in got[f][i]
+            if kflag == 1:
+                assert present and got[f][i][t][0] == c, (i, g)
+            elif kflag == 2:
+                assert not present
+            else:
+                d_fpr += not present  # dropped on the device, or left for the caller's exact check
+            if present and got[f][i][t][1]:
+                assert kflag == 1  # marked GN_MATCH_FPR_OK only if the exact rule keeps it
+        winners = {(f, t) for _, (c, f, t) in items}
+        for f in range(3):  # nothing but winners survives
+            assert all((f, t) in winners for t in got[f][i])
+    assert n_shared > 100 and sum(a for a, _ in drops) == e_fil and sum(b for _, b in drops) == d_fpr <= e_fpr
+    for st in sts:
+        st.destroy()
+    for f in flts:
+        f.free()
