@@ -71,8 +71,13 @@ struct PostFilterSpec
     double                           fpr_query  = 1.0;
     std::vector<std::vector<double>> target_fpr; // per filter of the level: per FilterMeta target of that filter
     // several filters: no target name occurs in two of them (then the level's merge of matches is a plain union and the
-    // rules can be applied per filter with the level's max/min; otherwise the backend must leave everything to the host)
+    // rules can be applied per filter with the level's max/min)
     bool disjoint_targets = true;
+    // per filter: target -> id of its name in the level (the same name in two filters has the same id).  Needed when the
+    // targets are not disjoint: the backend then replays the level's merge (a target keeps its largest count, the earliest
+    // filter's on ties, GanonClassify.cpp:531-537) and hands over the winners only.  A read it cannot do that for comes
+    // back with all its matches and bit 31 of BatchResult::max_count set: the host runs merge and rules on it.
+    std::vector<std::vector<uint32_t>> target_gid;
 };
 
 // One device (or the test checker): receives filters, classifies batches.  Not thread-safe; one host thread each.

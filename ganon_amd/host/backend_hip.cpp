@@ -398,7 +398,8 @@ public:
                 }
                 if (part.pf_generation != pf_generation_)
                 {
-                    gn_postfilter pf{ pf_spec_.rel_filter, pf_spec_.fpr_query, pf_active_ ? pf_fpr_[i][g].data() : nullptr, pf_joint_ ? 1 : 0 };
+                    gn_postfilter pf{ pf_spec_.rel_filter, pf_spec_.fpr_query, pf_active_ ? pf_fpr_[i][g].data() : nullptr,
+                                      pf_merge_ ? 2 : (pf_joint_ ? 1 : 0), pf_active_ && pf_merge_ ? pf_gid_[i][g].data() : nullptr };
                     if (gn_stream_set_postfilter(part.s, pf_active_ ? &pf : nullptr) != GN_OK)
                     {
                         err = gn_last_error();
@@ -529,21 +530,37 @@ public:
         ++pf_generation_;
         if (!spec || filters_.empty() || spec->target_fpr.size() != filters_.size())
             return false;
-        if (filters_.size() > 1 && !spec->disjoint_targets)
-            return false;
-        // one device filter (a whole filter, or a column part of a wide one) per stream; their targets are disjoint -- parts
-        // are cut at target boundaries -- so all of a level's streams take part in one joint pass
+        // filters that share target names: the device replays the level's merge, which needs every name's level-wide id
+        const bool merge = filters_.size() > 1 && !spec->disjoint_targets;
+        if (merge)
+        {
+            if (spec->target_gid.size() != filters_.size())
+                return false;
+            for (size_t i = 0; i < filters_.size(); ++i)
+            {
+                if (spec->target_gid[i].size() != spec->target_fpr[i].size())
+                    return false;
+                std::vector<uint32_t> ids = spec->target_gid[i]; // (a filter must name a target once, or there is no merge rule)
+                std::sort(ids.begin(), ids.end());
+                if (std::adjacent_find(ids.begin(), ids.end()) != ids.end() || (!ids.empty() && ids.back() >= (1u << 28)))
+                    return false;
+            }
+        }
+        // one device filter (a whole filter, or a column part of a wide one) per stream; column parts are cut at target
+        // boundaries, so their targets are disjoint; all of a level's streams take part in one joint pass
         size_t n_streams = 0;
         for (auto const& lf : filters_)
             n_streams += lf.parts.size();
         if (n_streams > 16) // GN_PF_MAX_JOINT
             return false;
         pf_fpr_.assign(filters_.size(), {});
+        pf_gid_.assign(filters_.size(), {});
         for (size_t i = 0; i < filters_.size(); ++i)
         {
             const std::vector<double>& fpr = spec->target_fpr[i];
             std::vector<uint8_t>       seen(fpr.size(), 0);
             pf_fpr_[i].resize(filters_[i].parts.size());
+            pf_gid_[i].resize(filters_[i].parts.size());
             for (size_t g = 0; g < filters_[i].parts.size(); ++g)
             {
                 const Part& part = filters_[i].parts[g];
@@ -552,10 +569,14 @@ public:
                     if (filters_[i].parts.size() != 1)
                         return false;
                     pf_fpr_[i][g] = fpr;
+                    if (merge)
+                        pf_gid_[i][g] = spec->target_gid[i];
                     continue;
                 }
                 // device target ids must map one-to-one onto the filter's targets, or a read's matches are not what the host sees
                 pf_fpr_[i][g].resize(part.to_target.size(), 0.0);
+                if (merge)
+                    pf_gid_[i][g].resize(part.to_target.size(), 0u);
                 for (size_t d = 0; d < part.to_target.size(); ++d)
                 {
                     const uint32_t t = part.to_target[d];
@@ -563,11 +584,14 @@ public:
                         return false;
                     seen[t]          = 1;
                     pf_fpr_[i][g][d] = fpr[t];
+                    if (merge)
+                        pf_gid_[i][g][d] = spec->target_gid[i][t];
                 }
             }
         }
         pf_spec_   = *spec;
         pf_joint_  = n_streams > 1;
+        pf_merge_  = merge;
         pf_active_ = true;
         return true;
     }
@@ -659,6 +683,8 @@ private:
     PostFilterSpec        pf_spec_;
     std::vector<std::vector<std::vector<double>>> pf_fpr_; // [filter][part]: per device target of that part
     bool                  pf_joint_ = false;
+    bool                  pf_merge_ = false; // the level's filters share targets: the joint pass merges (gn_postfilter.joint = 2)
+    std::vector<std::vector<std::vector<uint32_t>>> pf_gid_; // [filter][part][device target] -> level-wide target id
     bool                  pf_active_ = false;
     uint64_t              pf_generation_ = 1;
 };

@@ -973,8 +973,9 @@ static bool ganon_classify(Config config)
         for (auto const& fc : level.filters)
             rel_cutoffs.push_back(fc.rel_cutoff);
 
-        // the backends drop what filter_matches would drop where the matches are produced: always possible with one filter,
-        // with several only if no target name occurs in two of them (else the level's merge keeps the larger count, :531-537)
+        // the backends drop what filter_matches would drop where the matches are produced; with several filters that share
+        // target names they also replay the level's merge (the larger count wins, :531-537) and hand over the winners
+        bool shared_targets = false;
         {
             PostFilterSpec spec;
             spec.rel_filter = level.rel_filter;
@@ -987,6 +988,8 @@ static bool ganon_classify(Config config)
                     if (!owner.emplace(t, (int)i).second)
                         spec.disjoint_targets = false;
             }
+            spec.target_gid = target_gid;
+            shared_targets  = !spec.disjoint_targets;
             const bool want = !getenv("GANON_HOST_NO_PREFILTER");
             bool       on   = true;
             for (auto& be : backends)
@@ -1131,13 +1134,18 @@ static bool ganon_classify(Config config)
                     }
                 }
 
-                if (res.prefiltered) // `matches` are the survivors of the --rel-filter rule; the read's maximum comes with them
+                // `matches` are the survivors of the --rel-filter rule and the read's maximum comes with them -- unless the
+                // backend left this read alone (bit 31: more matches over the level's filters than its merge takes)
+                const bool prefiltered = res.prefiltered && !(res.max_count[r] & 0x80000000u);
+                if (prefiltered)
                     max_count_read = res.max_count[r];
+                if (shared_targets && matches.size() > 1) // one order whoever did the merge: by the target's id in the level
+                    std::sort(matches.begin(), matches.end(), [](const MatchEntry& a, const MatchEntry& b) { return a.gid < b.gid; });
                 bool classified = false;
                 if (max_count_read > 0) // :753-808
                 {
                     const size_t threshold_filter =
-                        res.prefiltered ? 0 : max_count_read - ceil_share(max_count_read - min_count_read, level.rel_filter);
+                        prefiltered ? 0 : max_count_read - ceil_share(max_count_read - min_count_read, level.rel_filter);
                     // filter_matches (:579-613)
                     size_t       kept = 0;
                     uint32_t     first_kept = 0;

@@ -202,7 +202,14 @@ int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf);
  * pre-pass still works per filter: submit the same batch to one stream per filter (same device, post-filters set with
  * joint = 1), then call this once: it finds every stream's max/min per read, combines them, and applies the rules to every
  * stream with the level's values.  Afterwards gn_fetch_batch / gn_fetch_postfilter work per stream as above (max_count is the
- * level's maximum on every stream). */
+ * level's maximum on every stream).
+ * If the filters SHARE targets, set joint = 2 and target_gid on every stream (an id per target name, the same id for the same
+ * name in every filter; a filter names a target once): the call then replays the reference's merge per read (:531-537: a
+ * target keeps its largest count, the entry of the earliest stream in `streams` on ties; max/min follow the entries that got
+ * in), keeps only the winning entry of every target -- on the stream of the filter that reported it -- and applies the rules
+ * to the winners.  Reads with more than 512 matches over all streams are left untouched and come back with bit 31 of
+ * max_count set on every stream: the caller merges and thresholds those itself.  The dropped-match totals of a merging pass
+ * are reported on streams[0]. */
 int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n_streams);
 /* after a batch with the pass on: per read the largest match count BEFORE filtering (0 = the read had no match; the
  * reference's max_count_read, :753,776,806), and how many matches each rule dropped in this batch */

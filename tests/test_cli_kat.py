@@ -527,3 +527,46 @@ def test_long_reads_flag(tmp_path):
     assert outs["long"][0]["long_read"][0] == "BIG.1" and outs["long"][0]["long_read"][1] > 65535
     for r in ("short_read", "other_read"):
         assert outs["long"][0][r] == outs["default"][0][r]
+
+
+@pytest.mark.gpu
+def test_shared_targets_with_more_matches_than_the_device_merges(oracle_bin, tmp_path, monkeypatch):
+    # two dense filters that share half of their target names on one level: the device replays the level's merge per read, but
+    # only up to 512 matches over the level's filters -- longer reads here match nearly every bin of both filters and come back
+    # untouched (bit 31 of the read's max_count), so the host runs merge and rules on them; short reads take the device path
+    import numpy as np
+    rng = np.random.default_rng(5)
+    paths = []
+    for fi, (lo, rows, h) in enumerate([(0, 4099, 2), (200, 6007, 3)]):
+        bins = 400
+        ibf = gf.random_ibf(bins, rows, h, [0.55, 0.65][fi], seed=20 + fi)
+        built = gf.BuiltIbf()
+        built.ibf = ibf
+        built.config = dict(n_bins=bins, max_hashes_bin=50, hash_functions=h, kmer_size=19, window_size=31, bin_size_bits=rows,
+                            max_fp=0.3, true_max_fp=0.3, true_avg_fp=0.3)
+        built.hashes_count = [(f"t{lo + b}", 50) for b in range(bins)]
+        built.bin_map = [(b, f"t{lo + b}") for b in range(bins)]
+        p = str(tmp_path / f"dense{fi}.ibf")
+        gf.write_ibf(p, built)
+        paths.append(p)
+    recs = [(f"r{i}", "".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.choice([31, 33, 40, 150, 250])))))
+            for i in range(400)]
+    fq = str(tmp_path / "reads.fq")
+    gf.write_fastq(fq, recs)
+    outs = {}
+    for tag, binary in (("hip", cu.BIN_HIP), ("oracle", oracle_bin)):
+        prefix = str(tmp_path / tag)
+        if tag == "hip":
+            monkeypatch.setenv("GANON_HOST_TIMING", "1")
+        p = cu.run(binary, ["--ibf", ",".join(paths), "--single-reads", fq, "-o", prefix, "--output-all", "--output-unclassified",
+                            "--output-stats", "--skip-lca", "--rel-cutoff", "0.3,0.3", "--rel-filter", "0.4", "--fpr-query", "0.6", "--quiet"])
+        monkeypatch.delenv("GANON_HOST_TIMING", raising=False)
+        if tag == "hip":
+            assert "pre-pass on the device on (2 filter(s), targets shared between filters)" in p.stderr, p.stderr[-400:]
+        outs[tag] = {ext: open(prefix + ext, "rb").read() for ext in (".all", ".unc", ".rep", ".sta")}
+    assert outs["hip"] == outs["oracle"]
+    per_read = {}
+    for line in outs["hip"][".all"].decode().splitlines():
+        per_read[line.split("\t")[0]] = per_read.get(line.split("\t")[0], 0) + 1
+    # both kinds of reads are there: some with more surviving targets than the device's merge takes, some with few
+    assert max(per_read.values()) > 300 and min(per_read.values()) < 100, (max(per_read.values()), min(per_read.values()))
