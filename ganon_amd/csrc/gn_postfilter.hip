@@ -27,7 +27,8 @@
 #include <hipcub/hipcub.hpp>
 
 #define GN_PF_SMALL 6u
-#define GN_PF_MERGE_CAP 512u
+#define GN_PF_MERGE_WAVE 512u  // matches of a read over a level's filters that one wave merges (LDS table of 1024 slots)
+#define GN_PF_MERGE_CAP 4096u  // ... that a block merges (8192 slots); beyond that the caller does the read
 #define GN_MATCH_REMOVED 0x40000000u // (internal: entry dropped by the level merge; compacted away before anything is fetched)
 
 struct GnPostfilterParams
@@ -388,7 +389,7 @@ __global__ void gn_pf_combine_kernel(GnPfLists l, uint32_t n, uint32_t* __restri
 // ---- levels whose filters SHARE targets ----------------------------------------------------------------------------------
 // The reference merges a read's matches filter after filter (GanonClassify.cpp:531-537): an entry replaces the target's entry
 // only if its count is larger, and max_count_read / min_count_read are updated only by entries that got in.  Replayed here per
-// read: the matches of all streams, keyed by (level-wide target id, filter order), are ranked in LDS; within a target's group
+// read (gn_pf_merge_kernel below): in the end
 //   inserted(e) = count(e) > max(count of the earlier filters' entries),   winner = the largest count, earliest filter on ties
 // max = max over all counts, min = min(n_hashes, counts of inserted entries); the rules of filter_matches then apply to the
 // winners (one per target -- what the merged map holds), everything else is removed.  A read with more than GN_PF_MERGE_CAP
@@ -407,18 +408,39 @@ struct GnPfMergeParams
     uint32_t        n_reads;
     const uint32_t* nh;
     double          rel_filter, fpr_query;
-    unsigned long long* ctr; // stream 0's: [0] dropped rel_filter [1] dropped fpr_query
+    unsigned long long* ctr; // stream 0's: [0] dropped rel_filter [1] dropped fpr_query [3] length of `big`
+    uint32_t*           big; // reads with more matches than a wave's table takes: done by the block-per-read launch
 };
 
+// The merged map of the reference is an open-addressing table in LDS, keyed by level-wide target id: filter after filter
+// (barrier in between) every entry looks its target up, gets in if its count beats what is there (count, entry index), and
+// min follows the entries that got in; what the table holds in the end are the winners.  BLOCK = false: a wave per read, 1024
+// slots, reads up to GN_PF_MERGE_WAVE matches; larger ones are listed for the BLOCK = true launch (a block per read, 8192
+// slots, up to GN_PF_MERGE_CAP matches).
+template <bool BLOCK>
 __global__ __launch_bounds__(256) void gn_pf_merge_kernel(GnPfMergeParams p)
 {
-    __shared__ uint32_t key[4][GN_PF_MERGE_CAP], cnt[4][GN_PF_MERGE_CAP], skey[4][GN_PF_MERGE_CAP], scnt[4][GN_PF_MERGE_CAP];
-    __shared__ uint16_t sidx[4][GN_PF_MERGE_CAP];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    constexpr uint32_t SLOTS = BLOCK ? 2u * GN_PF_MERGE_CAP : 2u * GN_PF_MERGE_WAVE, G = BLOCK ? 256u : 64u, NG = BLOCK ? 1u : 4u;
+    __shared__ uint32_t           tkey[NG][SLOTS];
+    __shared__ unsigned long long tval[NG][SLOTS];
+    __shared__ uint32_t           red[2][4];
+    const uint32_t lane = BLOCK ? threadIdx.x : (threadIdx.x & 63u), grp = BLOCK ? 0u : (threadIdx.x >> 6);
     const bool     fpr_on = p.fpr_query < 1.0;
     uint32_t       n_fil = 0, n_fpr = 0;
-    for (uint32_t r = blockIdx.x * 4 + wv; r < p.n_reads; r += gridDim.x * 4)
+    auto           sync = [&]() {
+        if constexpr (BLOCK)
+            __syncthreads();
+        else
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+    const uint32_t n_items = BLOCK ? (uint32_t)p.ctr[3] : p.n_reads;
+    for (uint32_t it = BLOCK ? blockIdx.x : blockIdx.x * 4 + grp; it < n_items; it += BLOCK ? gridDim.x : gridDim.x * 4)
     {
+        const uint32_t r = BLOCK ? p.big[it] : it;
         // entries of the read: filter f's segment is [o_f, o_f + c_f)
         uint64_t o[GN_PF_MAX_JOINT];
         uint32_t c[GN_PF_MAX_JOINT], total = 0;
@@ -436,53 +458,54 @@ __global__ __launch_bounds__(256) void gn_pf_merge_kernel(GnPfMergeParams p)
                     p.maxc[f][r] = 0;
             continue;
         }
-        if (total > GN_PF_MERGE_CAP)
+        if (total > SLOTS / 2)
         {
-            if (lane == 0) // the host takes this read as it is
+            if (!BLOCK && lane == 0) // flagged for the caller unless the block-per-read launch takes it
+            {
                 for (uint32_t f = 0; f < p.k; ++f)
                     p.maxc[f][r] = 0x80000000u;
+                p.big[atomicAdd(&p.ctr[3], 1ull)] = r;
+            }
             continue;
         }
-        // load: key = gid * 16 + filter (unique), count, index inside the filter's segment
-        uint32_t base = 0;
+        uint32_t used = 64, shift = 26;
+        while (used < 2 * total)
+        {
+            used <<= 1;
+            --shift;
+        }
+        for (uint32_t x = lane; x < used; x += G)
+            tkey[grp][x] = 0;
+        sync();
+        uint32_t mx = 0, mn = n, base = 0;
         for (uint32_t f = 0; f < p.k; ++f)
         {
-            for (uint32_t j = lane; j < c[f]; j += 64)
+            for (uint32_t j = lane; j < c[f]; j += G)
             {
                 const gn_match mt = p.m[f][o[f] + j];
-                key[wv][base + j] = p.gid[f][mt.target] * 16u + f;
-                cnt[wv][base + j] = mt.count;
+                const uint32_t g1 = p.gid[f][mt.target] + 1u;
+                uint32_t       h = (g1 * 0x9E3779B1u) >> shift, existing = 0;
+                for (uint32_t step = 0; step < used; ++step)
+                {
+                    const uint32_t prev = atomicCAS(&tkey[grp][h], 0u, g1);
+                    if (prev == 0)
+                        break;
+                    if (prev == g1) // (an earlier filter's entry: a filter names a target once)
+                    {
+                        existing = (uint32_t)(tval[grp][h] >> 32);
+                        break;
+                    }
+                    h = (h + 1) & (used - 1);
+                }
+                mx = mt.count > mx ? mt.count : mx;
+                if (mt.count > existing)
+                {
+                    tval[grp][h] = ((unsigned long long)mt.count << 32) | (base + j);
+                    mn           = mt.count < mn ? mt.count : mn;
+                }
             }
             base += c[f];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // rank by counting (keys are unique when every filter's gid table is injective) -> sorted copies
-        for (uint32_t e = lane; e < total; e += 64)
-        {
-            const uint32_t ke = key[wv][e];
-            uint32_t       rank = 0;
-            for (uint32_t x = 0; x < total; ++x)
-                rank += (key[wv][x] < ke || (key[wv][x] == ke && x < e)) ? 1u : 0u; // (ties only if a gid table repeats an id)
-            skey[wv][rank] = ke;
-            scnt[wv][rank] = cnt[wv][e];
-            sidx[wv][rank] = (uint16_t)e;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // per entry: inserted? winner of its target?
-        uint32_t mx = 0, mn = n;
-        for (uint32_t e = lane; e < total; e += 64)
-        {
-            const uint32_t g = skey[wv][e] >> 4, ce = scnt[wv][e];
-            uint32_t       before = 0;
-            for (uint32_t x = e; x > 0 && (skey[wv][x - 1] >> 4) == g; --x)
-                before = scnt[wv][x - 1] > before ? scnt[wv][x - 1] : before;
-            mx = ce > mx ? ce : mx;
-            if (ce > before)
-                mn = ce < mn ? ce : mn;
+            sync();
         }
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1)
@@ -491,48 +514,60 @@ __global__ __launch_bounds__(256) void gn_pf_merge_kernel(GnPfMergeParams p)
             mx = a > mx ? a : mx;
             mn = b < mn ? b : mn;
         }
-        const uint32_t thr = gn_pf_threshold(mx, mn, p.rel_filter);
-        for (uint32_t e = lane; e < total; e += 64)
+        if constexpr (BLOCK)
         {
-            const uint32_t g = skey[wv][e] >> 4, f = skey[wv][e] & 15u, ce = scnt[wv][e];
-            bool           winner = true; // largest count of the group; the earliest filter on ties
-            for (uint32_t x = e; x > 0 && (skey[wv][x - 1] >> 4) == g; --x)
-                winner = winner && scnt[wv][x - 1] < ce;
-            for (uint32_t x = e + 1; x < total && (skey[wv][x] >> 4) == g; ++x)
-                winner = winner && scnt[wv][x] <= ce;
-            // position of the entry in its filter's segment
-            uint32_t pos = sidx[wv][e];
-            for (uint32_t ff = 0; ff < f; ++ff)
-                pos -= c[ff];
-            gn_match* rec = p.m[f] + o[f] + pos;
-            uint32_t  out = ce;
-            if (!winner)
-                out |= GN_MATCH_REMOVED;
-            else if (ce < thr)
+            if ((threadIdx.x & 63u) == 0)
             {
-                out |= GN_MATCH_REMOVED;
-                ++n_fil;
+                red[0][threadIdx.x >> 6] = mx;
+                red[1][threadIdx.x >> 6] = mn;
             }
-            else if (fpr_on)
+            __syncthreads();
+            for (uint32_t x = 0; x < 4; ++x)
             {
-                const uint32_t t = rec->target;
-                const uint32_t v = gn_fpr_verdict(n, ce, t < p.n_targets[f] ? p.fpr[f][t] : 0.0, p.fpr_query);
-                if (v == 1)
+                mx = red[0][x] > mx ? red[0][x] : mx;
+                mn = red[1][x] < mn ? red[1][x] : mn;
+            }
+        }
+        const uint32_t thr = gn_pf_threshold(mx, mn, p.rel_filter);
+        base = 0;
+        for (uint32_t f = 0; f < p.k; ++f)
+        {
+            for (uint32_t j = lane; j < c[f]; j += G)
+            {
+                gn_match*      rec = p.m[f] + o[f] + j;
+                const gn_match mt = *rec;
+                const uint32_t g1 = p.gid[f][mt.target] + 1u;
+                uint32_t       h = (g1 * 0x9E3779B1u) >> shift;
+                for (uint32_t step = 0; step < used && tkey[grp][h] != g1; ++step)
+                    h = (h + 1) & (used - 1);
+                const bool winner = (uint32_t)tval[grp][h] == base + j; // what the merged map holds for this target
+                uint32_t   out = mt.count;
+                if (!winner)
+                    out |= GN_MATCH_REMOVED;
+                else if (mt.count < thr)
                 {
                     out |= GN_MATCH_REMOVED;
-                    ++n_fpr;
+                    ++n_fil;
                 }
-                else if (v == 2)
-                    out |= GN_MATCH_FPR_OK;
+                else if (fpr_on)
+                {
+                    const uint32_t v = gn_fpr_verdict(n, mt.count, mt.target < p.n_targets[f] ? p.fpr[f][mt.target] : 0.0, p.fpr_query);
+                    if (v == 1)
+                    {
+                        out |= GN_MATCH_REMOVED;
+                        ++n_fpr;
+                    }
+                    else if (v == 2)
+                        out |= GN_MATCH_FPR_OK;
+                }
+                rec->count = out;
             }
-            rec->count = out;
+            base += c[f];
         }
         if (lane == 0)
             for (uint32_t f = 0; f < p.k; ++f)
                 p.maxc[f][r] = mx;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        sync(); // (the table is cleared for the next read)
     }
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1)
@@ -540,7 +575,7 @@ __global__ __launch_bounds__(256) void gn_pf_merge_kernel(GnPfMergeParams p)
         n_fil += (uint32_t)__shfl_xor((int)n_fil, sh);
         n_fpr += (uint32_t)__shfl_xor((int)n_fpr, sh);
     }
-    if (lane == 0)
+    if ((threadIdx.x & 63u) == 0)
     {
         if (n_fil)
             atomicAdd(&p.ctr[0], (unsigned long long)n_fil);
@@ -602,6 +637,7 @@ extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n
         mp.rel_filter = s0->pf_rel_filter;
         mp.fpr_query  = s0->pf_fpr_query;
         mp.ctr        = s0->d_pf_ctr;
+        mp.big        = s0->d_pf_min; // (a merging pass has no use for the per-stream minima: the buffer holds the list)
         for (uint32_t i = 0; i < n_streams; ++i)
             GN_HIP(hipStreamSynchronize(streams[i]->st));
         if (n)
@@ -609,7 +645,8 @@ extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n
             unsigned mb = (n + 3) / 4;
             if (mb > 8192u)
                 mb = 8192u;
-            hipLaunchKernelGGL(gn_pf_merge_kernel, dim3(mb), dim3(256), 0, s0->st, mp);
+            hipLaunchKernelGGL(gn_pf_merge_kernel<false>, dim3(mb), dim3(256), 0, s0->st, mp);
+            hipLaunchKernelGGL(gn_pf_merge_kernel<true>, dim3(n < 2048u ? n : 2048u), dim3(256), 0, s0->st, mp);
         }
         GN_HIP(hipGetLastError());
         GN_HIP(hipStreamSynchronize(s0->st));

@@ -976,6 +976,7 @@ static bool ganon_classify(Config config)
         // the backends drop what filter_matches would drop where the matches are produced; with several filters that share
         // target names they also replay the level's merge (the larger count wins, :531-537) and hand over the winners
         bool shared_targets = false;
+        std::atomic<uint64_t> diag_unmerged{ 0 }, diag_fpr_evals{ 0 }; // (GANON_HOST_TIMING: what was left to the host)
         {
             PostFilterSpec spec;
             spec.rel_filter = level.rel_filter;
@@ -1058,6 +1059,7 @@ static bool ganon_classify(Config config)
             std::ofstream* o_lca = (config.output_lca && !config.skip_lca) ? &out_lca[rb.prefix] : nullptr;
             std::ofstream* o_unc = config.output_unclassified ? &out_unc[rb.prefix] : nullptr;
             const bool     one_filter = filters.size() == 1;
+            uint64_t       n_unmerged = 0, n_fpr_evals = 0;
 
             for (size_t r = 0; r < rb.size(); ++r)
             {
@@ -1139,6 +1141,8 @@ static bool ganon_classify(Config config)
                 const bool prefiltered = res.prefiltered && !(res.max_count[r] & 0x80000000u);
                 if (prefiltered)
                     max_count_read = res.max_count[r];
+                else if (res.prefiltered)
+                    ++n_unmerged;
                 if (shared_targets && matches.size() > 1) // one order whoever did the merge: by the target's id in the level
                     std::sort(matches.begin(), matches.end(), [](const MatchEntry& a, const MatchEntry& b) { return a.gid < b.gid; });
                 bool classified = false;
@@ -1159,6 +1163,7 @@ static bool ganon_classify(Config config)
                             if (level.fpr_query < 1.0 && !me.fpr_ok)
                             {
                                 double q = 1;
+                                ++n_fpr_evals;
                                 for (size_t i = 0; i <= me.count; i++)
                                     q -= binomial_coefficient(n_hashes, i) * pow(me.fpr, i) * pow(1 - me.fpr, n_hashes - i);
                                 if (q > level.fpr_query)
@@ -1232,6 +1237,8 @@ static bool ganon_classify(Config config)
             }
             total.dropped_by_rel_filter += res.dropped_rel_filter;
             total.dropped_by_fpr_query += res.dropped_fpr_query;
+            diag_unmerged.fetch_add(n_unmerged, std::memory_order_relaxed);
+            diag_fpr_evals.fetch_add(n_fpr_evals, std::memory_order_relaxed);
             if (!last_level && left.size() != 0)
             {
                 finalize_batch(left, left2);
@@ -1356,7 +1363,8 @@ static bool ganon_classify(Config config)
                 std::cerr << "[host stalls] level " << level.label << ": reader blocked on a full batch queue " << queue1.blocked_push()
                           << " s, workers waiting for a batch " << queue1.blocked_pop() << " s (summed), workers waiting for their turn "
                           << ordered.blocked_turn() << " s (summed), post stage waiting for a result " << ordered.blocked_take() << " s"
-                          << std::endl;
+                          << "; reads the pre-pass handed back whole " << diag_unmerged.load() << ", --fpr-query evaluations on the host "
+                          << diag_fpr_evals.load() << std::endl;
         }
         carried.swap(next_carried);
 

@@ -207,7 +207,7 @@ int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf);
  * name in every filter; a filter names a target once): the call then replays the reference's merge per read (:531-537: a
  * target keeps its largest count, the entry of the earliest stream in `streams` on ties; max/min follow the entries that got
  * in), keeps only the winning entry of every target -- on the stream of the filter that reported it -- and applies the rules
- * to the winners.  Reads with more than 512 matches over all streams are left untouched and come back with bit 31 of
+ * to the winners.  Reads with more than 4096 matches over all streams are left untouched and come back with bit 31 of
  * max_count set on every stream: the caller merges and thresholds those itself.  The dropped-match totals of a merging pass
  * are reported on streams[0]. */
 int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n_streams);

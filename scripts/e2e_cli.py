@@ -37,6 +37,17 @@ cfg = dict(n_bins=bins, max_hashes_bin=per_bin, hash_functions=4, kmer_size=wl.k
            true_max_fp=0.0625, true_avg_fp=0.0625)
 ibf_file.save_ibf(ibf, flt, cfg, [(f"T{b}", per_bin) for b in range(bins)], [(b, f"T{b}") for b in range(bins)], bins, rows, 4)
 flt.free()
+IBFS = ibf
+if os.environ.get("E2E_SHARED"):  # a second filter on the same level that shares half of its target names with the first
+    wl2 = bw.make_device_flat_workload("e2e_b", bins, rows, 4, 1024, seed=43)
+    flt2, _ = bw.device_filter(ganon_amd, wl2)
+    ibf2 = os.path.join(d, "ganon_e2e_b.ibf")
+    ibf_file.save_ibf(ibf2, flt2, cfg, [(f"T{b + bins // 2}", per_bin) for b in range(bins)], [(b, f"T{b + bins // 2}") for b in range(bins)],
+                      bins, rows, 4)
+    flt2.free()
+    del wl2
+    IBFS = ibf + "," + ibf2
+    out["shared_targets"] = "two filters on one level, 2048 of 4096 target names in both"
 
 # FASTQ with fixed-width ids, assembled as one byte matrix
 L = wl.read_len
@@ -89,7 +100,7 @@ for label, dev, parse_threads in runs:
     env = dict(os.environ, GANON_HOST_TIMING="1")
     if parse_threads:
         env["GANON_HOST_PARSE_THREADS"] = str(parse_threads)
-    p = subprocess.run([exe, "--ibf", ibf] + READS + ["-o", prefix, "--output-all", "--verbose"] + (["--device", dev] if dev else []) + EXTRA,
+    p = subprocess.run([exe, "--ibf", IBFS if not os.environ.get("E2E_HIBF") else ibf] + READS + ["-o", prefix, "--output-all", "--verbose"] + (["--device", dev] if dev else []) + EXTRA,
                        capture_output=True, text=True, env=env)
     r = {"rc": p.returncode, "wall_s": round(time.time() - t0, 2)}
     for key, pat in (("load_s", r"loading filter\(s\)\s+elapsed \(s\): ([0-9.eE+-]+)"),
@@ -104,6 +115,9 @@ for label, dev, parse_threads in runs:
     bt = re.findall(r"\[backend timing\] (.*)", p.stderr)
     if bt:
         r["backend_timing"] = bt
+    m = re.search(r"\[prefilter\] (.*)", p.stderr)
+    if m:
+        r["prefilter"] = m.group(1)
     m = re.search(r"\[host stalls\] (.*)", p.stderr)
     if m:
         r["host_stalls"] = m.group(1)

@@ -960,8 +960,9 @@ def test_joint_postfilter_over_the_filters_of_a_level(hip, rel_filter, fpr_query
         f.free()
 
 
+@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("rel_filter,fpr_query", [(0.1, 1e-5), (0.0, 1.0), (0.5, 1e-2), (1.0, 1.0)])
-def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr_query):
+def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr_query, dense):
     # three filters report overlapping sets of level-wide targets; the device replays the reference's merge per read
     # (GanonClassify.cpp:531-537: larger count wins, max/min follow the entries that got in) and applies filter_matches to the
     # winners -- checked against a replay of the same rule on the unfiltered matches and the oracle's filter_matches
@@ -971,10 +972,13 @@ def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr
     rng = np.random.default_rng(7)
     genomes = [gu.random_seq(rng, 3000) for _ in range(30)]
     n_gid = 900
-    shapes = [(512, 2003, 4), (700, 3001, 3), (300, 1201, 2)]
+    # sparse filters: a read has a handful of matches (a wave merges it); dense ones: a read matches most bins of every filter,
+    # 1000-4600 matches over the level (a block merges it, or -- past 4096 -- it is left to the caller)
+    shapes = [(2100, 2003, 2), (2200, 3001, 2), (300, 1201, 2)] if dense else [(512, 2003, 4), (700, 3001, 3), (300, 1201, 2)]
     flts, gids, tfprs, ibfs = [], [], [], []
+    n_gid = 5000 if dense else n_gid
     for fi, (bins, rows, h) in enumerate(shapes):
-        ibf = gf.random_ibf(bins, rows, h, 0.45, seed=40 + fi)
+        ibf = gf.random_ibf(bins, rows, h, 0.5 if dense else 0.45, seed=40 + fi)
         for gi, g in enumerate(genomes):
             if (gi + fi) % 2 == 0:  # every genome sits in two of the three filters
                 ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), gi)
@@ -1013,7 +1017,7 @@ def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr
         drops.append((a, b))
     L_ = oracle.lib()
     L_.gno_filter_matches.restype = C.c_size_t
-    e_fil = e_fpr = d_fpr = n_big = n_shared = 0
+    e_fil = e_fpr = d_fpr = n_big = n_block = n_shared = 0
     for i in range(len(seqs)):
         n = int(nh[i])
         merged, mxc, mnc = {}, 0, n
@@ -1025,7 +1029,8 @@ def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr
                     merged[g] = (c, f, t)
                     mxc, mnc = max(mxc, c), min(mnc, c)
         total = sum(len(raw[f][i]) for f in range(3))
-        if total > 512:  # left to the caller
+        n_block += 512 < total <= 4096
+        if total > 4096:  # left to the caller
             n_big += 1
             assert all(int(mxs[f][i]) == 0x80000000 for f in range(3))
             assert all(got[f][i] == {t: (c, 0) for t, c in raw[f][i]} for f in range(3))
@@ -1056,6 +1061,7 @@ def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr
         winners = {(f, t) for _, (c, f, t) in items}
         for f in range(3):  # nothing but winners survives
             assert all((f, t) in winners for t in got[f][i])
+    assert (n_big > 20 and n_block > 20) if dense else n_big == 0, (n_big, n_block)
     assert n_shared > 100 and sum(a for a, _ in drops) == e_fil and sum(b for _, b in drops) == d_fpr <= e_fpr
     for st in sts:
         st.destroy()
