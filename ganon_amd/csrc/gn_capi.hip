@@ -1029,6 +1029,22 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
         p.work_count = s->d_ctr + 4;
     }
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
+    // with a filter_matches pre-pass on the stream the fast kernel does not write matches the --rel-filter rule is bound to
+    // drop (not for a merging level: there the minimum follows the entries that got in, which only the merge knows)
+    const bool predrop = fast && s->pf_on && !s->pf_merge && s->d_pf_segmin && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
+                         (uint64_t)hi * f->geom.wpr <= s->pf_segmin_cap && !getenv("GANON_HIP_NO_PREDROP");
+    if (lo == 0)
+        s->pf_predrop = predrop;
+    if (predrop)
+    {
+        if (lo == 0)
+            GN_HIP(hipMemsetAsync(s->d_pf_pre, 0, sizeof(unsigned long long), s->st));
+        GN_HIP(hipMemsetAsync(s->d_pf_segmin + (size_t)lo * f->geom.wpr, 0xFF, (size_t)(hi - lo) * f->geom.wpr * 4, s->st));
+        p.pre_mode = s->pf_joint ? 2u : 1u;
+        p.pre_rel  = s->pf_rel_filter;
+        p.seg_min  = s->d_pf_segmin;
+        p.pre_ctr  = s->d_pf_pre;
+    }
     if (fast)
     {
         // register-resident fast path for reads with <= 127 minimisers; the rest lands in d_deferred

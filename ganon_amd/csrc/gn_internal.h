@@ -99,7 +99,21 @@ struct GnCountParams
     const uint32_t*           sl_nbr;          // split kernel: bins-per-target bytes in the layout of the byte counters
     uint32_t                  early_exit;      // fast kernel: stop fetching rows of reads that cannot reach the cutoff
     unsigned long long*       skip_ctr;        // row bytes not fetched thanks to early exits
+    // fast kernel, with a filter_matches pre-pass set on the stream: matches that the --rel-filter rule is bound to drop are
+    // not written at all (see the epilogue).  0 off, 1: the read's minimum is at least its cutoff count T (this filter sees all
+    // of the read's matches), 2: nothing known about the minimum (other filters of the level may report smaller counts)
+    uint32_t            pre_mode;
+    double              pre_rel;
+    uint32_t*           seg_min; // n_reads*wpr: smallest count among a unit's unwritten matches (0xFFFFFFFF: none)
+    unsigned long long* pre_ctr; // matches not written
 };
+
+// size_t threshold_filter = max - size_t(std::ceil((max - min) * rel_filter))   (GanonClassify.cpp:755-757)
+// non-decreasing in max and in min for 0 <= rel_filter < 1 (one more in max raises the ceil by at most one)
+__device__ __forceinline__ uint32_t gn_pf_threshold(uint32_t mx, uint32_t mn, double rel_filter)
+{
+    return mx - (uint32_t)(unsigned long long)ceil(__dmul_rn((double)(mx - mn), rel_filter));
+}
 
 struct GnCountGeometry
 {
@@ -270,9 +284,13 @@ struct gn_stream
     uint32_t*           d_pf_gmax = nullptr; // joint pass: the level's max / min per read (filled on the first stream)
     uint32_t*           d_pf_gmin = nullptr;
     bool                pf_joint  = false;   // the pass is run by gn_streams_postfilter_joint, not with the batch
+    bool                pf_predrop = false;  // this batch's count kernel left surely-dropped matches unwritten (seg_min, d_pf_pre valid)
     bool                pf_merge  = false;   // ... in its merging form (filters of the level share targets)
     uint32_t*           d_pf_gid  = nullptr; // merging form: device target -> level-wide target id
     double*             d_pf_fpr  = nullptr; // per target
+    uint32_t*           d_pf_segmin = nullptr; // per (read, column slice): see GnCountParams::seg_min
+    uint64_t            pf_segmin_cap = 0;
+    unsigned long long* d_pf_pre  = nullptr; // matches the count kernel did not write (they count as dropped by rel_filter)
     unsigned long long* d_pf_ctr  = nullptr; // [0] dropped rel_filter [1] dropped fpr_query [2] survivors
     unsigned long long* h_pf_ctr  = nullptr; // pinned copy
     void*               d_pf_scan = nullptr;

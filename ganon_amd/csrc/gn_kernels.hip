@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     unsigned long long chunk_base = 0; // wave-private slice of the match buffer
     uint32_t           chunk_left = 0, chunk_size = GN_MATCH_CHUNK;
     uint64_t           skipped_bytes = 0; // row bytes this lane's column group did not fetch thanks to early exits
+    uint32_t           n_pre = 0;         // matches of this lane left unwritten for the filter_matches pre-pass (pre_mode)
     uint32_t read, n;
     uint64_t slot, hA, hB;
     load_meta(unit, read, n, slot);
@@ -1425,8 +1426,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         load_hashes(n_n, slot_n, hA_n, hB_n);
 
     // ---- epilogue: bytes, cross-group sum, SWAR threshold ----
-    const uint32_t Kc = (0x80u - T) * 0x01010101u; // 1 <= T <= n <= 127 and counts <= 127: no carry between bytes
-    uint32_t       any = 0;
+    uint32_t Kc  = (0x80u - T) * 0x01010101u; // 1 <= T <= n <= 127 and counts <= 127: no carry between bytes
+    uint32_t any = 0;
     if (!dead)
     {
         if (acc_n)
@@ -1445,8 +1446,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                     any |= (x + Kc) & 0x80808080u;
                 }
     }
-    const bool     owner = hsub == 0 && col_act; // one lane per column chunk reports
-    const uint64_t hm    = dead ? 0ull : __ballot(owner && any != 0);
+    const bool owner = hsub == 0 && col_act; // one lane per column chunk reports
+    uint64_t   hm    = dead ? 0ull : __ballot(owner && any != 0);
+    if (p.pre_mode && __popcll(hm) > 6)
+    {
+        // A filter_matches pre-pass follows (gn_postfilter.hip) and many bins passed the cutoff (chance matches at a low
+        // --rel-cutoff): with the largest count of THIS unit and a lower bound of the read's minimum, the --rel-filter threshold
+        // of the read can only be higher than t2 below (gn_pf_threshold is non-decreasing in both), so bins under t2 are not
+        // written at all.  What the pre-pass still needs of them is their number and their smallest count (the read's minimum
+        // is taken over ALL bins that passed the cutoff).  Largest / smallest count by binary search with SWAR compares.
+        auto any_ge = [&](uint32_t v) -> bool { // a bin with count >= v  (1 <= v <= 127)
+            const uint32_t K = (0x80u - v) * 0x01010101u;
+            uint32_t       a = 0;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                        a |= byt[d][j][pp] + K;
+            return __ballot(owner && (a & 0x80808080u) != 0) != 0;
+        };
+        uint32_t lo = T, hi = n;
+        while (lo < hi)
+        {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (any_ge(mid))
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const uint32_t t2 = gn_pf_threshold(lo, p.pre_mode == 1 ? T : 0u, p.pre_rel);
+        if (t2 > T && t2 <= lo)
+        {
+            const uint32_t K2 = (0x80u - t2) * 0x01010101u;
+            auto in_range = [&](uint32_t v, bool count) -> uint32_t { // bins with T <= count <= v  (v < t2): any / how many (this lane)
+                const uint32_t K1 = (0x80u - (v + 1u)) * 0x01010101u;
+                uint32_t       a = 0;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+                        {
+                            const uint32_t e = ((byt[d][j][pp] + Kc) & ~(byt[d][j][pp] + K1)) & 0x80808080u;
+                            a = count ? a + (uint32_t)__popc(e) : (a | e);
+                        }
+                return a;
+            };
+            const uint32_t below = owner ? in_range(t2 - 1u, true) : 0u;
+            if (__ballot(below != 0))
+            {
+                uint32_t a = T, b = t2 - 1u; // the smallest count among them
+                while (a < b)
+                {
+                    const uint32_t mid = (a + b) >> 1;
+                    if (__ballot(owner && in_range(mid, false) != 0))
+                        b = mid;
+                    else
+                        a = mid + 1u;
+                }
+                if (lane == 0)
+                    p.seg_min[(size_t)read * wpr + slice] = a;
+                n_pre += below;
+                Kc  = K2;
+                any = 0;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+                            any |= (byt[d][j][pp] + Kc) & 0x80808080u;
+                hm = __ballot(owner && any != 0);
+            }
+        }
+    }
     uint32_t       total = 0;
     unsigned long long base = 0;
     if (hm)
@@ -1595,6 +1671,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     } // persistent loop
     if (lane == 0 && skipped_bytes) // wave-uniform amount, one atomic per wave
         atomicAdd(p.skip_ctr, (unsigned long long)skipped_bytes);
+    if (p.pre_mode)
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            n_pre += (uint32_t)__shfl_xor((int)n_pre, off);
+        if (lane == 0 && n_pre)
+            atomicAdd(p.pre_ctr, (unsigned long long)n_pre);
+    }
 }
 
 template <int HF, int LW, int MAXT>

@@ -50,6 +50,8 @@ struct GnPostfilterParams
     const unsigned long long* cursor; // match cursor and capacity: an overflowed batch holds no matches yet (gn_finish re-runs)
     uint64_t            cap;
     uint64_t            n_targets;
+    const uint32_t*     seg_min;    // per (read, column slice): smallest count the count kernel left unwritten (nullptr: none did)
+    const unsigned long long* pre_ctr; // how many it left unwritten: they count as dropped by rel_filter
 };
 
 // 0 = the host decides, 1 = q is surely above fpr_query (drop), 2 = q is surely not above it (keep, no host check needed)
@@ -75,19 +77,22 @@ __device__ __forceinline__ uint32_t gn_fpr_verdict(uint32_t n, uint32_t count, d
     return 0;
 }
 
-__device__ __forceinline__ uint32_t gn_pf_threshold(uint32_t mx, uint32_t mn, double rel_filter)
-{
-    // size_t threshold_filter = max - size_t(std::ceil((max - min) * rel_filter))
-    return mx - (uint32_t)(unsigned long long)ceil(__dmul_rn((double)(mx - mn), rel_filter));
-}
-
 // MODE 0: max/min of the read's own matches, then the rules (one filter per level)
 // MODE 1: max/min only (-> maxc, minc): the first half of the joint pass over a level's filters
 // MODE 2: the rules with the level's max/min given (gmax, gmin): its second half
 // MODE 3: sweep after gn_pf_merge_kernel (levels whose filters share targets): entries marked GN_MATCH_REMOVED go
-template <int MODE>
-__global__ void gn_postfilter_kernel(GnPostfilterParams p)
+__device__ __forceinline__ void gn_wave_sync_lds()
 {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_postfilter_kernel(GnPostfilterParams p)
+{
+    __shared__ gn_match stage[4][128]; // per wave: entries of a heavy read waiting for their --fpr-query verdict
+    const uint32_t      wv = threadIdx.x >> 6;
     if (*p.cursor > p.cap)
         return;
     const uint64_t r     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,12 +117,20 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
             mn = p.gmin[r];
         }
         else if constexpr (MODE != 3)
+        {
             for (uint32_t j = 0; j < c; ++j)
             {
                 const uint32_t ct = p.m[o + j].count;
                 mx = ct > mx ? ct : mx;
                 mn = ct < mn ? ct : mn;
             }
+            if (p.seg_min)
+                for (uint32_t x = 0; x < p.stride; ++x)
+                {
+                    const uint32_t sm = p.seg_min[r * p.stride + x];
+                    mn = sm < mn ? sm : mn;
+                }
+        }
         if constexpr (MODE == 1)
         {
             p.maxc[r] = mx;
@@ -162,7 +175,11 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
         }
     }
     if (MODE != 1 && r == p.n_reads)
+    {
         p.keep[r] = 0;
+        if (MODE != 3 && p.pre_ctr && *p.pre_ctr)
+            atomicAdd(&p.ctr[0], *p.pre_ctr);
+    }
     uint64_t heavy = __ballot(valid && c > GN_PF_SMALL);
     while (heavy)
     {
@@ -207,6 +224,12 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
                 mx = ct > mx ? ct : mx;
                 mn = ct < mn ? ct : mn;
             }
+            if (p.seg_min)
+                for (uint32_t x = lane; x < p.stride; x += 64)
+                {
+                    const uint32_t sm = p.seg_min[rr * p.stride + x];
+                    mn = sm < mn ? sm : mn;
+                }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1)
             {
@@ -226,34 +249,73 @@ __global__ void gn_postfilter_kernel(GnPostfilterParams p)
         }
         const uint32_t thr  = gn_pf_threshold(mx, mn, p.rel_filter);
         uint32_t       kept = 0;
-        for (uint32_t j0 = 0; j0 < cc; j0 += 64)
+        if (fpr_on)
         {
-            const uint32_t j   = j0 + lane;
-            const bool     act = j < cc;
-            gn_match       m{};
-            if (act)
-                m = p.m[oo + j];
-            bool k = false;
-            if (act)
-            {
-                const uint32_t v = m.count >= thr && fpr_on
-                                       ? gn_fpr_verdict(nn, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query)
-                                       : 0u;
-                if (m.count < thr)
-                    ++n_fil;
-                else if (v == 1)
-                    ++n_fpr;
-                else
+            // the --fpr-query verdict is a loop of `count` steps: entries that pass the --rel-filter rule (a few of many) are
+            // first gathered in LDS, then judged 64 at a time with every lane busy
+            uint32_t ns = 0;
+            auto     judge = [&](uint32_t take) {
+                gn_wave_sync_lds();
+                gn_match m{};
+                bool     k = false;
+                if (lane < take)
                 {
-                    k = true;
-                    m.count |= v == 2 ? GN_MATCH_FPR_OK : 0u;
+                    m = stage[wv][lane];
+                    const uint32_t v = gn_fpr_verdict(nn, m.count, m.target < p.n_targets ? p.tfpr[m.target] : 0.0, p.fpr_query);
+                    if (v == 1)
+                        ++n_fpr;
+                    else
+                    {
+                        k = true;
+                        m.count |= v == 2 ? GN_MATCH_FPR_OK : 0u;
+                    }
                 }
+                gn_match rest{};
+                if (take + lane < ns)
+                    rest = stage[wv][take + lane];
+                gn_wave_sync_lds();
+                if (take + lane < ns)
+                    stage[wv][lane] = rest;
+                ns -= take;
+                const uint64_t km = __ballot(k);
+                if (k) // (kept never passes the number of entries loaded so far: in place is safe)
+                    p.m[oo + kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = m;
+                kept += (uint32_t)__popcll(km);
+            };
+            for (uint32_t j0 = 0; j0 < cc; j0 += 64)
+            {
+                const uint32_t j   = j0 + lane;
+                const bool     act = j < cc;
+                gn_match       m{};
+                if (act)
+                    m = p.m[oo + j];
+                const bool pass = act && m.count >= thr;
+                n_fil += act && !pass;
+                const uint64_t pm = __ballot(pass);
+                if (pass)
+                    stage[wv][ns + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = m;
+                ns += (uint32_t)__popcll(pm);
+                if (ns >= 64)
+                    judge(64);
             }
-            const uint64_t km = __ballot(k);
-            if (k) // all loads of this chunk are done (the store data depends on them) and kept <= j0: in place is safe
-                p.m[oo + kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = m;
-            kept += (uint32_t)__popcll(km);
+            if (ns)
+                judge(ns);
         }
+        else
+            for (uint32_t j0 = 0; j0 < cc; j0 += 64)
+            {
+                const uint32_t j   = j0 + lane;
+                const bool     act = j < cc;
+                gn_match       m{};
+                if (act)
+                    m = p.m[oo + j];
+                const bool k = act && m.count >= thr;
+                n_fil += act && !k;
+                const uint64_t km = __ballot(k);
+                if (k) // all loads of this chunk are done (the store data depends on them) and kept <= j0: in place is safe
+                    p.m[oo + kept + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = m;
+                kept += (uint32_t)__popcll(km);
+            }
         if (lane == 0)
         {
             p.keep[rr] = kept;
@@ -332,6 +394,8 @@ static GnPostfilterParams gn_pf_params(gn_stream* s)
     p.cursor     = s->d_ctr;
     p.cap        = s->match_cap;
     p.n_targets  = s->f->is_hibf ? s->f->n_user_bins : s->f->n_targets;
+    p.seg_min    = s->pf_predrop ? s->d_pf_segmin : nullptr;
+    p.pre_ctr    = s->pf_predrop ? s->d_pf_pre : nullptr;
     return p;
 }
 
@@ -724,6 +788,12 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_gmax), ((size_t)s->max_reads + 1) * 4));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_gmin), ((size_t)s->max_reads + 1) * 4));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_ctr), 4 * sizeof(unsigned long long)));
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_pre), sizeof(unsigned long long)));
+        if (!s->f->is_hibf)
+        {
+            s->pf_segmin_cap = ((uint64_t)s->max_reads + 1) * s->f->geom.wpr;
+            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_segmin), s->pf_segmin_cap * 4));
+        }
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_fpr), (nt ? nt : 1) * sizeof(double)));
         GN_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_pf_ctr), 4 * sizeof(unsigned long long), hipHostMallocDefault));
         size_t tmp = 0;
@@ -758,7 +828,8 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
 
 void gn_postfilter_release(gn_stream* s)
 {
-    void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_min, s->d_pf_gmax, s->d_pf_gmin, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan, s->d_pf_gid };
+    void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_min, s->d_pf_gmax, s->d_pf_gmin, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan, s->d_pf_gid,
+                     s->d_pf_segmin, s->d_pf_pre };
     for (void* q : ptrs)
         if (q)
             hipFree(q);
@@ -766,6 +837,10 @@ void gn_postfilter_release(gn_stream* s)
         hipHostFree(s->h_pf_ctr);
     s->d_pf_keep = s->d_pf_max = s->d_pf_min = s->d_pf_gmax = s->d_pf_gmin = s->d_pf_gid = nullptr;
     s->d_pf_ctr  = nullptr;
+    s->d_pf_segmin = nullptr;
+    s->pf_segmin_cap = 0;
+    s->d_pf_pre  = nullptr;
+    s->pf_predrop = false;
     s->d_pf_fpr  = nullptr;
     s->d_pf_scan = nullptr;
     s->h_pf_ctr  = nullptr;

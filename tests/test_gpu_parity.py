@@ -1067,3 +1067,60 @@ def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr
         st.destroy()
     for f in flts:
         f.free()
+
+
+@pytest.mark.parametrize("bins,joint", [(4096, False), (9000, False), (4096, True)])
+def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, monkeypatch, bins, joint):
+    # with a filter_matches pre-pass on the stream the fast kernel does not write bins that the --rel-filter rule is bound to
+    # drop (threshold from the unit's own maximum and a lower bound of the read's minimum); switching that off
+    # (GANON_HIP_NO_PREDROP) must change nothing: survivors, their order and marks, every read's maximum, both totals.
+    # 9000 bins = three column slices per read: a slice only knows its own maximum.  joint: the minimum bound is 0.
+    k, w = 19, 31
+    rng = np.random.default_rng(123)
+    genomes = [gu.random_seq(rng, 2500) for _ in range(16)]
+    ibf = gf.random_ibf(bins, 1531, 3, 0.5, seed=15)  # every minimiser hits an eighth of the bins by chance
+    for gi, g in enumerate(genomes):
+        ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), (gi * 577) % bins)
+    flt = hip.HipFilter.ibf(ibf.data, bins, 1531, 3)
+    tfpr = rng.choice([1e-4, 0.02, 0.11, 0.3], size=bins)
+    seqs = []
+    for i in range(500):
+        L = int(rng.choice([60, 100, 150, 250]))
+        g = genomes[i % 16]
+        p = int(rng.integers(0, 2500 - L))
+        seqs.append(g[p:p + L] if i % 4 else gu.random_seq(rng, L))
+    bases, off1, off2 = gu.pack_reads(seqs, None)
+    st = hip.HipStream(flt, len(seqs), bases.size)
+    st.submit(bases, off1, off2, k, w, 0.1)
+    nh, _, mo, m = st.fetch()
+    assert int(mo[-1]) > 200 * len(seqs)  # hundreds of chance matches per read
+    res = {}
+    for rel_filter, fpr_query in ((0.1, 1e-5), (0.5, 1.0), (0.0, 1.0), (0.99, 0.5)):
+        for tag in ("predrop", "plain"):
+            if tag == "plain":
+                monkeypatch.setenv("GANON_HIP_NO_PREDROP", "1")
+            else:
+                monkeypatch.delenv("GANON_HIP_NO_PREDROP", raising=False)
+            st.set_postfilter(rel_filter, fpr_query, tfpr, joint=joint)
+            st.submit(bases, off1, off2, k, w, 0.1)
+            if joint:
+                hip.HipStream.postfilter_joint([st])
+            _, _, mo2, m2 = st.fetch()
+            mx, a, b = st.fetch_postfilter()
+            res[tag] = (mo2.copy(), m2.copy(), mx.copy(), a, b)
+        monkeypatch.delenv("GANON_HIP_NO_PREDROP", raising=False)
+        assert np.array_equal(res["predrop"][0], res["plain"][0]) and np.array_equal(res["predrop"][1], res["plain"][1])
+        assert np.array_equal(res["predrop"][2], res["plain"][2]) and res["predrop"][3:] == res["plain"][3:]
+        # ... and it is the reference's rule: every read against _exact_filter_matches on the unfiltered matches
+        tot = 0
+        for i in range(0, len(seqs), 7):
+            raw = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+            kept, nf, nq, emx = _exact_filter_matches(raw, nh[i], rel_filter, 1.0, tfpr)
+            got = [(int(x["target"]), int(x["count"]) & 0x7FFFFFFF) for x in res["predrop"][1][int(res["predrop"][0][i]):int(res["predrop"][0][i + 1])]]
+            assert int(res["predrop"][2][i]) == emx and set(got) <= set(kept), i
+            if fpr_query >= 1.0:
+                assert got == kept, i
+            tot += nf
+        assert tot > 0 or rel_filter in (0.0, 0.99)
+    st.destroy()
+    flt.free()
