@@ -284,20 +284,30 @@ def main() -> int:
             log("bench.py: could not read", pmc_path, repr(e))
 
     # the same resident batch under the two conditions the headline does not show (not part of `value`)
-    if not args.no_variants and part is None and kind == "flat" and spec.get("bins_per_target", 1) == 1:
+    if not args.no_variants and part is None and kind == "flat":
         variants = {}
-        os.environ["GANON_HIP_NO_EARLY_EXIT"] = "1"   # read by the library at every launch
-        _, cms, _, tms, tmv = timed(args.rel_cutoff, 3, 1)
-        del os.environ["GANON_HIP_NO_EARLY_EXIT"]
-        variants["no_early_exit"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
-                                         mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2))
+        bpt = spec.get("bins_per_target", 1)
+        if bpt == 1:  # (the split-bin kernel has no early exit)
+            os.environ["GANON_HIP_NO_EARLY_EXIT"] = "1"   # read by the library at every launch
+            _, cms, _, tms, tmv = timed(args.rel_cutoff, 3, 1)
+            del os.environ["GANON_HIP_NO_EARLY_EXIT"]
+            variants["no_early_exit"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
+                                             mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2))
         _, cms, _, tms, tmv = timed(0.2, 3, 1)        # ganon-classify's own default (Config.hpp:32): T ~ 4, nothing to exit from
         variants["rel_cutoff_0.2"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
                                           mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches=int(tmv["n_matches"]))
         # ... and with the thresholds `ganon classify` passes by default (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5,
         # /root/reference/src/ganon/config.py), the pre-pass of filter_matches running on the device (gn_stream_set_postfilter);
         # per-target fpr 0.5^h = what the Bernoulli(0.5) bits are
-        st.set_postfilter(0.1, 1e-5, np.full(wl.bins, 0.5 ** spec["h"], dtype=np.float64))
+        st.set_postfilter(0.1, 1e-5, np.full(wl.bins // bpt, 1.0 - (1.0 - 0.5 ** spec["h"]) ** bpt, dtype=np.float64))
+        if os.environ.get("GANON_BENCH_AB_PREDROP"):  # A/B: every match written, then judged
+            os.environ["GANON_HIP_NO_PREDROP"] = "1"
+            _, cms, _, tms, tmv = timed(0.2, 3, 1)
+            del os.environ["GANON_HIP_NO_PREDROP"]
+            _, d_fil, d_fpr = st.fetch_postfilter()
+            variants["wrapper_defaults_every_match_written"] = dict(ms_per_step=round(float(np.mean(tms)), 3),
+                                                                    count_select_ms=round(float(np.mean(cms)), 3), dropped_rel_filter=d_fil,
+                                                                    dropped_fpr_query=d_fpr, matches_after=int(st.fetch()[2][-1]))
         _, cms, _, tms, tmv = timed(0.2, 3, 1)
         _, d_fil, d_fpr = st.fetch_postfilter()
         variants["wrapper_defaults_device_filter_matches"] = dict(

@@ -3,6 +3,7 @@
 #include "gn_internal.h"
 
 #include <hipcub/hipcub.hpp>
+#include "gn_scan.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -782,7 +783,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
     ok(gn_dmalloc(&s->d_mdeferred, max_reads));
     size_t tmp1 = 0, tmp2 = 0;
     hipcub::DeviceScan::ExclusiveSum(nullptr, tmp1, s->d_slot_cnt, s->d_slot_off, (int)(max_reads + 1), s->st);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st);
+    gn_scan_counts(nullptr, tmp2, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st);
     s->scan_tmp_bytes = std::max(tmp1, tmp2) + 256;
     ok(hipMalloc(&s->d_scan_tmp, s->scan_tmp_bytes));
     if (f->is_hibf)
@@ -1015,23 +1016,10 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
         GN_HIP(hipMemsetAsync(s->d_ctr + 7, 0, sizeof(unsigned long long), s->st));
     p.sl_nbr = f->d_sl_nbr;
     const bool split = !f->identity && f->d_sl_nbr != nullptr && !getenv("GANON_HIP_NO_SPLIT_KERNEL");
-    if (split)
-    {
-        // split-bin maps: register counters + byte image for reads with <= 127 minimisers, the rest lands in d_deferred
-        GN_HIP(hipMemsetAsync(s->d_ctr + 4, 0, sizeof(unsigned long long), s->st));
-        p.work_list_out  = s->d_deferred;
-        p.work_count_out = s->d_ctr + 4;
-        const uint32_t keep = p.max_blocks;
-        p.max_blocks        = (uint32_t)f->n_cu * (f->split_bpc ? f->split_bpc : 1u) * 2u;
-        GN_HIP(gn_launch_count_split(p, f->geom, f->ibf.h, s->st));
-        p.max_blocks = keep;
-        p.work_list  = s->d_deferred;
-        p.work_count = s->d_ctr + 4;
-    }
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
-    // with a filter_matches pre-pass on the stream the fast kernel does not write matches the --rel-filter rule is bound to
+    // with a filter_matches pre-pass on the stream the fast and the split-bin kernel do not write matches the --rel-filter rule is bound to
     // drop (not for a merging level: there the minimum follows the entries that got in, which only the merge knows)
-    const bool predrop = fast && s->pf_on && !s->pf_merge && s->d_pf_segmin && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
+    const bool predrop = (fast || split) && s->pf_on && !s->pf_merge && s->d_pf_segmin && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
                          (uint64_t)hi * f->geom.wpr <= s->pf_segmin_cap && !getenv("GANON_HIP_NO_PREDROP");
     if (lo == 0)
         s->pf_predrop = predrop;
@@ -1044,6 +1032,19 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
         p.pre_rel  = s->pf_rel_filter;
         p.seg_min  = s->d_pf_segmin;
         p.pre_ctr  = s->d_pf_pre;
+    }
+    if (split)
+    {
+        // split-bin maps: register counters + byte image for reads with <= 127 minimisers, the rest lands in d_deferred
+        GN_HIP(hipMemsetAsync(s->d_ctr + 4, 0, sizeof(unsigned long long), s->st));
+        p.work_list_out  = s->d_deferred;
+        p.work_count_out = s->d_ctr + 4;
+        const uint32_t keep = p.max_blocks;
+        p.max_blocks        = (uint32_t)f->n_cu * (f->split_bpc ? f->split_bpc : 1u) * 2u;
+        GN_HIP(gn_launch_count_split(p, f->geom, f->ibf.h, s->st));
+        p.max_blocks = keep;
+        p.work_list  = s->d_deferred;
+        p.work_count = s->d_ctr + 4;
     }
     if (fast)
     {
@@ -1082,7 +1083,7 @@ static int gn_run_group(gn_stream* s)
     const size_t nseg = (size_t)s->n_reads * s->f->geom.wpr;
     GN_HIP(hipMemsetAsync(s->d_seg_count + nseg, 0, 4, s->st));
     size_t tmp = s->scan_tmp_bytes;
-    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st));
+    GN_HIP(gn_scan_counts(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st));
     if (nseg)
         hipLaunchKernelGGL(gn_gather_kernel, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, s->st, s->d_matches,
                            s->d_sorted, s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)s->n_reads,

@@ -26,6 +26,7 @@
 #include "gn_internal.h"
 
 #include <hipcub/hipcub.hpp>
+#include "gn_scan.h"
 
 #include <algorithm>
 #include <vector>
@@ -1280,7 +1281,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                            s->d_vals[1], nm, ub_bits, s->d_nh, s->d_sorted, s->d_seg_count);
     }
     size_t tmp = s->scan_tmp_bytes;
-    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(n + 1), st));
+    GN_HIP(gn_scan_counts(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(n + 1), st));
     return GN_OK;
 }
 

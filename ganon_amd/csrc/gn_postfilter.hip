@@ -25,6 +25,7 @@
 // the host enables this pass only otherwise (backend_hip.cpp).
 #include "gn_internal.h"
 #include <hipcub/hipcub.hpp>
+#include "gn_scan.h"
 
 #define GN_PF_SMALL 6u
 #define GN_PF_MERGE_WAVE 512u  // matches of a read over a level's filters that one wave merges (LDS table of 1024 slots)
@@ -405,7 +406,7 @@ static int gn_pf_finish(gn_stream* s, const GnPostfilterParams& p)
     const uint32_t n      = s->n_reads;
     const unsigned blocks = (unsigned)(((uint64_t)n + 1 + 255) / 256);
     size_t         tmp    = s->pf_scan_bytes;
-    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_pf_scan, tmp, s->d_pf_keep, s->d_slot_cnt, (int)(n + 1), s->st));
+    GN_HIP(gn_scan_counts(s->d_pf_scan, tmp, s->d_pf_keep, s->d_slot_cnt, (int)(n + 1), s->st));
     hipLaunchKernelGGL(gn_postfilter_compact_kernel, dim3(blocks), dim3(256), 0, s->st, s->d_sorted, s->d_matches, s->d_seg_off, p.stride,
                        s->d_pf_keep, s->d_slot_cnt, n, s->d_ctr, s->match_cap);
     GN_HIP(hipGetLastError());
@@ -797,7 +798,7 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_fpr), (nt ? nt : 1) * sizeof(double)));
         GN_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_pf_ctr), 4 * sizeof(unsigned long long), hipHostMallocDefault));
         size_t tmp = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, s->d_pf_keep, s->d_slot_cnt, (int)(s->max_reads + 1), s->st);
+        gn_scan_counts(nullptr, tmp, s->d_pf_keep, s->d_slot_cnt, (int)(s->max_reads + 1), s->st);
         GN_HIP(hipMalloc(&s->d_pf_scan, tmp ? tmp : 1));
         s->pf_scan_bytes = tmp;
     }

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
     uint32_t* rowtab   = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)wave * 128 * HFP;
     uint32_t* stage    = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)nwaves * 128 * HFP + (size_t)wave * 2 * GN_SPLIT_STAGE;
     uint32_t* candcnt  = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)nwaves * (128 * HFP + 2 * GN_SPLIT_STAGE);
+    uint32_t* premax   = candcnt + nwaves; // largest count each wave reported (pre_mode)
 
     const uint32_t wi      = slice * 64 * LW + lane * LW; // first word of this lane in the row
     const bool     col_act = wi < p.W;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
     const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads - p.read_begin;
     unsigned long long chunk_base = 0;
     uint32_t           chunk_left = 0, chunk_size = GN_SPLIT_CHUNK; // (doubles per request up to GN_SPLIT_CHUNK_MAX, see gn_kernels.hip)
+    unsigned long long n_pre = 0; // (lane 0) matches left unwritten for the filter_matches pre-pass, see below
     for (uint32_t round0 = blockIdx.x * rpb; round0 < n_work; round0 += gridDim.x * rpb)
     {
         const uint32_t widx = round0 + rslot;
@@ -273,9 +275,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
         }
         __syncthreads();
 
-        uint32_t           total = 0;
+        uint32_t           total = 0, mxl = 0, mnl = 0xFFFFFFFFu, Tsel = T; // Tsel: what a target's sum must reach to be reported
         unsigned long long base  = 0;
-        if (work)
         {
             auto cnt_of = [&](uint32_t bin) -> uint32_t {
                 const uint32_t word = bin >> 6, sl = word / (64 * LW), wrel = word - sl * 64 * LW, ln = wrel / LW;
@@ -292,6 +293,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                 const uint64_t bm = __ballot(emit);
                 if (emit)
                 {
+                    mxl = cv > mxl ? cv : mxl;
+                    mnl = cv < mnl ? cv : mnl;
                     const uint32_t o = tot + __popcll(bm & ((1ULL << lane) - 1ULL));
                     if (direct)
                     {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         if (t < hi)
                         {
                             cv   = target_sum(p.tgt_rec[t]);
-                            emit = cv >= T;
+                            emit = cv >= Tsel;
                         }
                         emit_hits(emit, t, cv, tot, direct, out);
                     }
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         {
                             tgt  = p.big_list[i];
                             cv   = target_sum(p.tgt_rec[tgt]);
-                            emit = cv >= T;
+                            emit = cv >= Tsel;
                         }
                         emit_hits(emit, tgt, cv, tot, direct, out);
                     }
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         if (lowest)
                         {
                             cv   = target_sum(rec);
-                            emit = cv >= T;
+                            emit = cv >= Tsel;
                             tgt  = t;
                         }
                     }
@@ -399,7 +402,75 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                 return tot;
             };
 
-            total = select(false, nullptr);
+            if (work)
+                total = select(false, nullptr);
+            if (p.pre_mode)
+            {
+                // A filter_matches pre-pass follows (gn_postfilter.hip): the waves of the read share the largest count any of
+                // them found, and targets under t2 -- which the --rel-filter threshold of the read cannot be below, see the
+                // fast kernel's epilogue in gn_kernels.hip -- leave the staging list again: counted, their smallest count kept
+                // for the read's minimum, not written.
+                for (int off = 32; off > 0; off >>= 1)
+                {
+                    const uint32_t y = (uint32_t)__shfl_xor((int)mxl, off);
+                    mxl = y > mxl ? y : mxl;
+                }
+                if (lane == 0)
+                    premax[wave] = mxl;
+                __syncthreads();
+                uint32_t mx_r = 0;
+                for (uint32_t sl = 0; sl < wpr; ++sl)
+                    mx_r = premax[rslot * wpr + sl] > mx_r ? premax[rslot * wpr + sl] : mx_r;
+                const uint32_t t2 = gn_pf_threshold(mx_r, p.pre_mode == 1 ? T : 0u, p.pre_rel);
+                for (int off = 32; off > 0; off >>= 1)
+                {
+                    const uint32_t y = (uint32_t)__shfl_xor((int)mnl, off);
+                    mnl = y < mnl ? y : mnl;
+                }
+                if (total && t2 > T && t2 <= mx_r && mnl < t2) // (the unit's smallest count goes first: it is the smallest unwritten one)
+                {
+                    uint32_t kept = 0;
+                    if (total <= GN_SPLIT_STAGE)
+                    {
+                        gn_sp_wave_sync();
+                        for (uint32_t o0 = 0; o0 < total; o0 += GN_WAVE)
+                        {
+                            const uint32_t o   = o0 + lane;
+                            const bool     act = o < total;
+                            uint32_t       tg = 0, cv = 0;
+                            if (act)
+                            {
+                                tg = stage[2 * o];
+                                cv = stage[2 * o + 1];
+                            }
+                            const bool     keep = act && cv >= t2;
+                            const uint64_t bm   = __ballot(keep);
+                            gn_sp_wave_sync(); // (every lane has read its entry: compaction in place)
+                            if (keep)
+                            {
+                                const uint32_t q = kept + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL));
+                                stage[2 * q]     = tg;
+                                stage[2 * q + 1] = cv;
+                            }
+                            kept += (uint32_t)__popcll(bm);
+                        }
+                    }
+                    else // more hits than the list holds: counted again with the higher bar (and staged, if they fit now)
+                    {
+                        Tsel = t2;
+                        const uint32_t keep_mx = mxl, keep_mn = mnl;
+                        kept = select(false, nullptr);
+                        mxl = keep_mx;
+                        mnl = keep_mn;
+                    }
+                    if (lane == 0)
+                    {
+                        p.seg_min[(size_t)read * wpr + slice] = mnl;
+                        n_pre += total - kept;
+                    }
+                    total = kept;
+                }
+            }
             if (total)
             {
                 if (total > chunk_left)
@@ -441,12 +512,14 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
         }
         __syncthreads(); // the next round reuses the images, the hit lists and the candidate counters
     }
+    if (p.pre_mode && lane == 0 && n_pre)
+        atomicAdd(p.pre_ctr, n_pre);
 }
 
 size_t gn_split_lds_bytes(const GnCountGeometry& g, uint32_t hash_funs)
 {
     const uint32_t nd = 2 * g.lw, hfp = hash_funs <= 4 ? 4 : 8, nwaves = g.block / 64;
-    return ((size_t)g.rpb * g.wpr * 8 * nd * 64 + (size_t)nwaves * (128 * hfp + 2 * GN_SPLIT_STAGE) + nwaves) * 4;
+    return ((size_t)g.rpb * g.wpr * 8 * nd * 64 + (size_t)nwaves * (128 * hfp + 2 * GN_SPLIT_STAGE) + 2 * nwaves) * 4;
 }
 
 template <int HF, int LW, int MAXT>

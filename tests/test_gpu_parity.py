@@ -1069,20 +1069,27 @@ def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr
         f.free()
 
 
-@pytest.mark.parametrize("bins,joint", [(4096, False), (9000, False), (4096, True)])
-def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, monkeypatch, bins, joint):
+@pytest.mark.parametrize("bins,joint,split", [(4096, False, False), (9000, False, False), (4096, True, False), (4096, False, True),
+                                              (9000, True, True), (32768, False, True)])
+def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, monkeypatch, bins, joint, split):
     # with a filter_matches pre-pass on the stream the fast kernel does not write bins that the --rel-filter rule is bound to
     # drop (threshold from the unit's own maximum and a lower bound of the read's minimum); switching that off
     # (GANON_HIP_NO_PREDROP) must change nothing: survivors, their order and marks, every read's maximum, both totals.
     # 9000 bins = three column slices per read: a slice only knows its own maximum.  joint: the minimum bound is 0.
+    # split: targets own one to four bins (the split-bin kernel: the waves of a read share their maxima).
     k, w = 19, 31
     rng = np.random.default_rng(123)
     genomes = [gu.random_seq(rng, 2500) for _ in range(16)]
     ibf = gf.random_ibf(bins, 1531, 3, 0.5, seed=15)  # every minimiser hits an eighth of the bins by chance
     for gi, g in enumerate(genomes):
         ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)), (gi * 577) % bins)
-    flt = hip.HipFilter.ibf(ibf.data, bins, 1531, 3)
-    tfpr = rng.choice([1e-4, 0.02, 0.11, 0.3], size=bins)
+    n_targets, b2t = bins, None
+    if split:
+        b2t = np.cumsum(rng.random(bins) < 0.45).astype(np.uint32)  # consecutive bins share a target now and then
+        b2t -= b2t[0]
+        n_targets = int(b2t[-1]) + 1
+    flt = hip.HipFilter.ibf(ibf.data, bins, 1531, 3, b2t, n_targets)
+    tfpr = rng.choice([1e-4, 0.02, 0.11, 0.3], size=n_targets)
     seqs = []
     for i in range(500):
         L = int(rng.choice([60, 100, 150, 250]))
