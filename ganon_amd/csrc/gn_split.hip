@@ -253,12 +253,52 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             mine += __shfl_xor(mine, off);
 
         // ---- 2. the waves of a read agree: anything to do, and which select ----
+        // (pre_mode, see step 3) the largest count of a single bin, by binary search with SWAR compares: a lower bound of the
+        // read's largest target sum that is known before any target is summed
+        uint32_t binmax = 0;
+        if (p.pre_mode && n)
+        {
+            uint32_t lo = 0, hi = n;
+            while (lo < hi)
+            {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                const uint32_t K   = (0x80u - mid) * 0x01010101u; // counts <= n <= 127: no carry between bytes
+                uint32_t       a   = 0;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp)
+                            a |= byt[d][j][pp] + K;
+                if (__ballot((a & 0x80808080u) != 0))
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            binmax = lo;
+        }
         if (lane == 0)
+        {
             candcnt[wave] = mine;
+            premax[wave]  = binmax;
+        }
         __syncthreads();
-        uint32_t c_read = 0;
+        uint32_t c_read = 0, Tpre = T;
         for (uint32_t sl = 0; sl < wpr; ++sl)
             c_read += candcnt[rslot * wpr + sl];
+        if (p.pre_mode)
+        {
+            uint32_t mb = 0;
+            for (uint32_t sl = 0; sl < wpr; ++sl)
+                mb = premax[rslot * wpr + sl] > mb ? premax[rslot * wpr + sl] : mb;
+            const uint32_t lb = p.pre_mode == 1 ? T : 0u;
+            if (mb > lb)
+            {
+                const uint32_t t = gn_pf_threshold(mb, lb, p.pre_rel);
+                Tpre = t > T ? t : T;
+            }
+        }
         const bool work     = n != 0 && (c_read != 0 || p.n_big != 0);
         const bool scan_all = c_read > GN_SPLIT_LIMIT * wpr;
 
@@ -275,7 +315,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
         }
         __syncthreads();
 
-        uint32_t           total = 0, mxl = 0, mnl = 0xFFFFFFFFu, Tsel = T; // Tsel: what a target's sum must reach to be reported
+        // Tsel: what a target's sum must reach to be reported (>= T; above it with a pre-pass to follow: targets in [T, Tsel) are
+        // counted in drop1, their smallest sum kept in mnd, while `counting`); mxl / mne: largest / smallest sum reported
+        uint32_t total = 0, mxl = 0, mne = 0xFFFFFFFFu, mnd = 0xFFFFFFFFu, drop1 = 0, Tsel = Tpre;
+        bool     counting = true;
         unsigned long long base  = 0;
         {
             auto cnt_of = [&](uint32_t bin) -> uint32_t {
@@ -289,12 +332,22 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     s += cnt_of(p.tgt_bins[rec.x + x]);
                 return s > n ? n : s; // :525-526
             };
+            auto judge = [&](uint32_t cv) -> bool {
+                if (cv >= Tsel)
+                    return true;
+                if (counting && cv >= T)
+                {
+                    ++drop1;
+                    mnd = cv < mnd ? cv : mnd;
+                }
+                return false;
+            };
             auto emit_hits = [&](bool emit, uint32_t tgt, uint32_t cv, uint32_t& tot, bool direct, gn_match* out) {
                 const uint64_t bm = __ballot(emit);
                 if (emit)
                 {
                     mxl = cv > mxl ? cv : mxl;
-                    mnl = cv < mnl ? cv : mnl;
+                    mne = cv < mne ? cv : mne;
                     const uint32_t o = tot + __popcll(bm & ((1ULL << lane) - 1ULL));
                     if (direct)
                     {
@@ -320,17 +373,75 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     // too many candidates (tiny T, dense hits): every target, this wave takes its share
                     const uint32_t per = (p.n_targets + wpr - 1) / wpr;
                     const uint32_t lo = min(p.n_targets, slice * per), hi = min(p.n_targets, lo + per);
-                    for (uint32_t t0 = lo; t0 < hi; t0 += GN_WAVE)
+                    if (p.csr_identity)
                     {
-                        const uint32_t t    = t0 + lane;
-                        bool           emit = false;
-                        uint32_t       cv   = 0;
-                        if (t < hi)
+                        // targets own consecutive bins in target order (what ganon-build writes): the bins of target t are
+                        // [tgt_off[t], tgt_off[t+1]) -- two coalesced loads, no record, no bin list
+                        for (uint32_t t0 = lo; t0 < hi; t0 += 4 * GN_WAVE)
                         {
-                            cv   = target_sum(p.tgt_rec[t]);
-                            emit = cv >= Tsel;
+                            uint32_t o0[4], o1[4], cv[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                            {
+                                const uint32_t t = t0 + 64u * (uint32_t)u + lane;
+                                o0[u] = t < hi ? p.tgt_off[t] : 0u;
+                                o1[u] = t < hi ? p.tgt_off[t + 1] : 0u;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                            {
+                                uint32_t sum = 0;
+                                for (uint32_t b = o0[u]; b < o1[u]; ++b)
+                                    sum += cnt_of(b);
+                                cv[u] = sum > n ? n : sum; // :525-526
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                            {
+                                const uint32_t t = t0 + 64u * (uint32_t)u + lane;
+                                if (t0 + 64u * (uint32_t)u < hi) // (wave-uniform: emit_hits holds a ballot)
+                                    emit_hits(t < hi && judge(cv[u]), t, cv[u], tot, direct, out);
+                            }
                         }
-                        emit_hits(emit, t, cv, tot, direct, out);
+                        return tot;
+                    }
+                    // four targets per lane and trip: their records, then their first two bins, are loaded side by side (the chain
+                    // record -> bin list -> byte image is all latency; one target at a time it was most of the kernel at low cutoffs)
+                    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * GN_WAVE)
+                    {
+                        uint4    rec[4];
+                        uint32_t b0[4], b1[4], cv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                        {
+                            const uint32_t t = t0 + 64u * (uint32_t)u + lane;
+                            rec[u] = t < hi ? p.tgt_rec[t] : make_uint4(0u, 0u, 0u, 0u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                        {
+                            b0[u] = rec[u].y >= 1 ? p.tgt_bins[rec[u].x] : 0u;
+                            b1[u] = rec[u].y >= 2 ? p.tgt_bins[rec[u].x + 1] : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                        {
+                            uint32_t sum = 0;
+                            if (rec[u].y >= 1)
+                                sum = cnt_of(b0[u]);
+                            if (rec[u].y >= 2)
+                                sum += cnt_of(b1[u]);
+                            for (uint32_t x = 2; x < rec[u].y; ++x)
+                                sum += cnt_of(p.tgt_bins[rec[u].x + x]);
+                            cv[u] = sum > n ? n : sum; // :525-526
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                        {
+                            const uint32_t t = t0 + 64u * (uint32_t)u + lane;
+                            if (t0 + 64u * (uint32_t)u < hi) // (wave-uniform: emit_hits holds a ballot)
+                                emit_hits(t < hi && judge(cv[u]), t, cv[u], tot, direct, out);
+                        }
                     }
                     return tot;
                 }
@@ -347,7 +458,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         {
                             tgt  = p.big_list[i];
                             cv   = target_sum(p.tgt_rec[tgt]);
-                            emit = cv >= Tsel;
+                            emit = judge(cv);
                         }
                         emit_hits(emit, tgt, cv, tot, direct, out);
                     }
@@ -393,7 +504,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         if (lowest)
                         {
                             cv   = target_sum(rec);
-                            emit = cv >= Tsel;
+                            emit = judge(cv);
                             tgt  = t;
                         }
                     }
@@ -406,10 +517,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                 total = select(false, nullptr);
             if (p.pre_mode)
             {
-                // A filter_matches pre-pass follows (gn_postfilter.hip): the waves of the read share the largest count any of
-                // them found, and targets under t2 -- which the --rel-filter threshold of the read cannot be below, see the
-                // fast kernel's epilogue in gn_kernels.hip -- leave the staging list again: counted, their smallest count kept
-                // for the read's minimum, not written.
+                // A filter_matches pre-pass follows (gn_postfilter.hip).  The select above already left out targets under Tsel, the
+                // bar that the largest single-bin count of the read allows (the --rel-filter threshold of the read cannot be
+                // lower, see the fast kernel's epilogue in gn_kernels.hip).  Now the waves of the read share the largest sum any of
+                // them reported -- the read's true maximum -- and what is under the bar t2 it allows leaves the staging list again.
+                // Everything left out is counted and its smallest sum kept (the read's minimum is over all targets that reached T).
                 for (int off = 32; off > 0; off >>= 1)
                 {
                     const uint32_t y = (uint32_t)__shfl_xor((int)mxl, off);
@@ -421,13 +533,18 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                 uint32_t mx_r = 0;
                 for (uint32_t sl = 0; sl < wpr; ++sl)
                     mx_r = premax[rslot * wpr + sl] > mx_r ? premax[rslot * wpr + sl] : mx_r;
-                const uint32_t t2 = gn_pf_threshold(mx_r, p.pre_mode == 1 ? T : 0u, p.pre_rel);
+                counting = false;
                 for (int off = 32; off > 0; off >>= 1)
                 {
-                    const uint32_t y = (uint32_t)__shfl_xor((int)mnl, off);
-                    mnl = y < mnl ? y : mnl;
+                    const uint32_t y = (uint32_t)__shfl_xor((int)mne, off), z = (uint32_t)__shfl_xor((int)mnd, off);
+                    mne = y < mne ? y : mne;
+                    mnd = z < mnd ? z : mnd;
+                    drop1 += (uint32_t)__shfl_xor((int)drop1, off);
                 }
-                if (total && t2 > T && t2 <= mx_r && mnl < t2) // (the unit's smallest count goes first: it is the smallest unwritten one)
+                const uint32_t mn_all = mne < mnd ? mne : mnd; // smallest sum >= T of the unit, written or not
+                uint32_t       dropped = drop1;
+                const uint32_t t2 = mx_r ? gn_pf_threshold(mx_r, p.pre_mode == 1 ? T : 0u, p.pre_rel) : 0u;
+                if (total && t2 > Tsel && t2 <= mx_r && mne < t2) // the true maximum raises the bar further
                 {
                     uint32_t kept = 0;
                     if (total <= GN_SPLIT_STAGE)
@@ -458,17 +575,15 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     else // more hits than the list holds: counted again with the higher bar (and staged, if they fit now)
                     {
                         Tsel = t2;
-                        const uint32_t keep_mx = mxl, keep_mn = mnl;
                         kept = select(false, nullptr);
-                        mxl = keep_mx;
-                        mnl = keep_mn;
                     }
-                    if (lane == 0)
-                    {
-                        p.seg_min[(size_t)read * wpr + slice] = mnl;
-                        n_pre += total - kept;
-                    }
+                    dropped += total - kept;
                     total = kept;
+                }
+                if (dropped && lane == 0)
+                {
+                    p.seg_min[(size_t)read * wpr + slice] = mn_all;
+                    n_pre += dropped;
                 }
             }
             if (total)

@@ -1103,11 +1103,15 @@ def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, mon
     assert int(mo[-1]) > 200 * len(seqs)  # hundreds of chance matches per read
     res = {}
     for rel_filter, fpr_query in ((0.1, 1e-5), (0.5, 1.0), (0.0, 1.0), (0.99, 0.5)):
-        for tag in ("predrop", "plain"):
+        for tag in ("predrop", "plain", "bin_lists"):
             if tag == "plain":
                 monkeypatch.setenv("GANON_HIP_NO_PREDROP", "1")
             else:
                 monkeypatch.delenv("GANON_HIP_NO_PREDROP", raising=False)
+            if tag == "bin_lists":  # split maps whose targets own consecutive bins: without the shortcut that needs no bin lists
+                monkeypatch.setenv("GANON_HIP_NO_CSR_IDENTITY", "1")
+            else:
+                monkeypatch.delenv("GANON_HIP_NO_CSR_IDENTITY", raising=False)
             st.set_postfilter(rel_filter, fpr_query, tfpr, joint=joint)
             st.submit(bases, off1, off2, k, w, 0.1)
             if joint:
@@ -1116,6 +1120,8 @@ def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, mon
             mx, a, b = st.fetch_postfilter()
             res[tag] = (mo2.copy(), m2.copy(), mx.copy(), a, b)
         monkeypatch.delenv("GANON_HIP_NO_PREDROP", raising=False)
+        monkeypatch.delenv("GANON_HIP_NO_CSR_IDENTITY", raising=False)
+        assert np.array_equal(res["predrop"][0], res["bin_lists"][0]) and np.array_equal(res["predrop"][1], res["bin_lists"][1])
         assert np.array_equal(res["predrop"][0], res["plain"][0]) and np.array_equal(res["predrop"][1], res["plain"][1])
         assert np.array_equal(res["predrop"][2], res["plain"][2]) and res["predrop"][3:] == res["plain"][3:]
         # ... and it is the reference's rule: every read against _exact_filter_matches on the unfiltered matches
