@@ -1287,12 +1287,27 @@ static int gn_finish(gn_stream* s)
             }
             return GN_OK;
         }
-        const uint64_t ncap = need + need / 8 + 1024;
+        const uint64_t ncap = need + need / 8 + 1024, ocap = s->match_cap;
         hipFree(s->d_matches);
         hipFree(s->d_sorted);
         s->d_matches = s->d_sorted = nullptr;
-        GN_HIP(gn_dmalloc(&s->d_matches, ncap));
-        GN_HIP(gn_dmalloc(&s->d_sorted, ncap));
+        if (gn_dmalloc(&s->d_matches, ncap) != hipSuccess || gn_dmalloc(&s->d_sorted, ncap) != hipSuccess)
+        {
+            // no room for this batch's matches: the stream goes back to the buffers it had (so that a smaller batch can follow)
+            (void)hipGetLastError();
+            if (s->d_matches)
+                hipFree(s->d_matches);
+            if (s->d_sorted)
+                hipFree(s->d_sorted);
+            s->d_matches = s->d_sorted = nullptr;
+            s->match_cap  = 0;
+            s->classified = false;
+            if (gn_dmalloc(&s->d_matches, ocap) == hipSuccess && gn_dmalloc(&s->d_sorted, ocap) == hipSuccess)
+                s->match_cap = ocap;
+            return gn_fail(GN_ENOMEM, "the batch has %llu matches: 2 x %.1f GB of match records do not fit into device memory next to the filter -- "
+                                      "submit fewer reads per batch (or raise the cutoff)",
+                           (unsigned long long)need, (double)ncap * sizeof(gn_match) / 1e9);
+        }
         s->match_cap = ncap;
         int rc       = gn_run_count(s);
         if (rc)
