@@ -296,7 +296,7 @@ def main() -> int:
         _, cms, _, tms, tmv = timed(0.2, 3, 1)        # ganon-classify's own default (Config.hpp:32): T ~ 4, nothing to exit from
         variants["rel_cutoff_0.2"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
                                           mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches=int(tmv["n_matches"]))
-        # ... and with the thresholds `ganon classify` passes by default (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5,
+        # ... and with the binary's low cutoff under the filter rules `ganon classify` passes by default (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5,
         # /root/reference/src/ganon/config.py), the pre-pass of filter_matches running on the device (gn_stream_set_postfilter);
         # per-target fpr 0.5^h = what the Bernoulli(0.5) bits are
         st.set_postfilter(0.1, 1e-5, np.full(wl.bins // bpt, 1.0 - (1.0 - 0.5 ** spec["h"]) ** bpt, dtype=np.float64))
@@ -311,6 +311,7 @@ def main() -> int:
         _, cms, _, tms, tmv = timed(0.2, 3, 1)
         _, d_fil, d_fpr = st.fetch_postfilter()
         variants["wrapper_defaults_device_filter_matches"] = dict(
+            thresholds="--rel-cutoff 0.2 (the binary's default) --rel-filter 0.1 --fpr-query 1e-5 (what `ganon classify` passes)",
             ms_per_step=round(float(np.mean(tms)), 3), count_select_ms=round(float(np.mean(cms)), 3),
             mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches_before=int(variants["rel_cutoff_0.2"]["matches"]),
             dropped_rel_filter=d_fil, dropped_fpr_query=d_fpr, matches_after=int(st.fetch()[2][-1]))

@@ -21,7 +21,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
 rows = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 21)
 d = sys.argv[3] if len(sys.argv) > 3 else "/dev/shm"
 bins = 4096
-# classification thresholds: E2E_ARGS="" runs the binary's own defaults (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5)
+# classification thresholds: E2E_ARGS="" runs the binary's own defaults (--rel-cutoff 0.2 --rel-filter 0 --fpr-query 1); what `ganon classify`
+# passes is E2E_ARGS="--rel-cutoff 0.75 --rel-filter 0.1 --fpr-query 1e-5"; the demanding mix for filter_matches is
+# E2E_ARGS="--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5"
 EXTRA = os.environ.get("E2E_ARGS", "--rel-cutoff 0.75").split()
 out = {"reads": n, "filter_gib": rows * 512 / 2**30, "args": " ".join(EXTRA)}
 
