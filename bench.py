@@ -319,6 +319,25 @@ def main() -> int:
         result["variants"] = variants
         step(args.rel_cutoff)  # leave the headline batch in the stream for the checks below
 
+    if not args.no_variants and kind == "hibf" and os.environ.get("GANON_BENCH_HIBF_LOW_CUTOFF"):
+        # A/B on request (needs --reads <= 500000: 3 000 chance matches per read at this cutoff): --rel-cutoff 0.2 plain, with the
+        # filter_matches pre-pass judging every pair after the sort, and with the pairs it is bound to drop left out of the sort
+        variants = {}
+        _, cms, _, tms, tmv = timed(0.2, 3, 1)
+        variants["rel_cutoff_0.2"] = dict(ms_per_step=round(float(np.mean(tms)), 3), matches=int(tmv["n_matches"]))
+        st.set_postfilter(0.1, 1e-5, np.full(spec["user_bins"], 0.05, dtype=np.float64))
+        for tag, env in (("every_pair_sorted", "1"), ("device_filter_matches", None)):
+            if env:
+                os.environ["GANON_HIP_NO_PREDROP"] = env
+            _, cms, _, tms, tmv = timed(0.2, 3, 1)
+            os.environ.pop("GANON_HIP_NO_PREDROP", None)
+            _, d_fil, d_fpr = st.fetch_postfilter()
+            variants["low_cutoff_" + tag] = dict(ms_per_step=round(float(np.mean(tms)), 3), dropped_rel_filter=d_fil, dropped_fpr_query=d_fpr,
+                                                 matches_after=int(st.fetch()[2][-1]))
+        st.set_postfilter(None)
+        result["variants"] = variants
+        step(args.rel_cutoff)
+
     if rank == 0:
         import bench_cpu
         if args.check:

@@ -956,6 +956,110 @@ __global__ void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals
     atomicAdd(&seg_count[read], 1u);
 }
 
+// ---- matches that a filter_matches pre-pass is bound to drop never reach the sort --------------------------------------------
+// With gn_stream_set_postfilter on the stream (gn_postfilter.hip) most of what the level kernels append at a low --rel-cutoff
+// goes again a moment later, after a radix sort over all of it.  The rule is the fast kernel's (gn_kernels.hip, epilogue):
+// the read's --rel-filter threshold cannot be below t2 = threshold(largest count of the read, lower bound of its minimum), so
+// pairs under t2 are counted, their smallest count is kept per read (seg_min: the read's minimum is over everything that passed
+// the cutoff) and only the rest is copied -- in wave-private chunks, holes = all-ones keys like the appender's -- to the buffer
+// the sort then reads.  Here the maximum is the read's true one: a first pass over the raw pairs collects it.
+__global__ void gn_hibf_premax_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n, uint32_t ub_bits,
+                                      const uint32_t* __restrict__ n_hashes, uint32_t* rmax)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t k = keys[i];
+        if (k == ~0ULL)
+            continue;
+        const uint32_t read = (uint32_t)(k >> ub_bits), nh = n_hashes[read];
+        const uint32_t cv   = vals[i] > nh ? nh : vals[i];
+        if (cv > rmax[read]) // (a stale value only costs an atomic too many: the maximum never goes down)
+            atomicMax(&rmax[read], cv);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_hibf_predrop_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n,
+                                                              uint32_t ub_bits, const uint32_t* __restrict__ n_hashes,
+                                                              const uint32_t* __restrict__ rmax, double rel_cutoff, uint32_t pre_mode,
+                                                              double pre_rel, uint64_t* __restrict__ keys_out,
+                                                              uint32_t* __restrict__ vals_out, uint64_t cap, unsigned long long* cursor,
+                                                              uint32_t* seg_min, unsigned long long* pre_ctr)
+{
+    const uint32_t     lane = threadIdx.x & 63u;
+    const uint64_t     wid  = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long cbase = 0;
+    uint32_t           cleft = 0, n_drop = 0;
+    auto               close = [&]() {
+        for (uint32_t x = lane; x < cleft; x += 64)
+            if (cbase + x < cap)
+                keys_out[cbase + x] = ~0ULL;
+        cleft = 0;
+    };
+    for (uint64_t b = wid * 64; b < n; b += nw * 64) // (wave-uniform trip count)
+    {
+        const uint64_t i = b + lane;
+        uint64_t       k = ~0ULL;
+        uint32_t       v = 0;
+        if (i < n)
+        {
+            k = keys[i];
+            v = vals[i];
+        }
+        bool keep = false;
+        if (k != ~0ULL)
+        {
+            const uint32_t read = (uint32_t)(k >> ub_bits), nh = n_hashes[read];
+            const uint32_t cv   = v > nh ? nh : v;
+            uint32_t       lb   = 0;
+            if (pre_mode == 1) // this filter sees all of the read's matches: none is below the cutoff count
+            {
+                lb = (uint32_t)(uint64_t)ceil(__dmul_rn((double)nh, rel_cutoff));
+                lb = lb ? lb : 1u;
+            }
+            const uint32_t mx = rmax[read];
+            const uint32_t t2 = mx >= lb ? gn_pf_threshold(mx, lb, pre_rel) : 0u;
+            keep = cv >= t2;
+            if (!keep)
+            {
+                ++n_drop;
+                if (cv < seg_min[read])
+                    atomicMin(&seg_min[read], cv);
+            }
+        }
+        const uint64_t km = __ballot(keep);
+        if (km)
+        {
+            const uint32_t need = (uint32_t)__popcll(km);
+            if (need > cleft)
+            {
+                close();
+                unsigned long long nb = 0;
+                if (lane == 0)
+                    nb = atomicAdd(cursor, (unsigned long long)GN_HIBF_CHUNK);
+                cbase = gn_hibf_bcast64(nb);
+                cleft = GN_HIBF_CHUNK;
+            }
+            if (keep)
+            {
+                const unsigned long long o = cbase + __popcll(km & ((1ULL << lane) - 1ULL));
+                if (o < cap)
+                {
+                    keys_out[o] = k;
+                    vals_out[o] = v;
+                }
+            }
+            cbase += need;
+            cleft -= need;
+        }
+    }
+    close();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        n_drop += (uint32_t)__shfl_xor((int)n_drop, off);
+    if (lane == 0 && n_drop)
+        atomicAdd(pre_ctr, (unsigned long long)n_drop);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1270,15 +1374,47 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     const uint64_t nm = s->h_ctr[0];
     if (nm > s->match_cap)
         return GN_OK; // gn_finish() sees the overflow, grows the buffers and re-runs
-    if (nm)
+    // with a filter_matches pre-pass on the stream, what it is bound to drop does not reach the sort (kernels above)
+    uint64_t ns = nm; // pairs to sort
+    int      src = 0;
+    s->pf_predrop = false;
+    if (s->pf_on && !s->pf_merge && s->d_pf_segmin && s->d_pf_rmax && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
+        (uint64_t)n + 1 <= s->pf_segmin_cap && nm > 8ull * n && !getenv("GANON_HIP_NO_PREDROP"))
     {
-        if (nm > 0x7FFFFFFFull)
+        GN_HIP(hipMemsetAsync(s->d_pf_rmax, 0, ((size_t)n + 1) * 4, st));
+        GN_HIP(hipMemsetAsync(s->d_pf_segmin, 0xFF, ((size_t)n + 1) * 4, st));
+        GN_HIP(hipMemsetAsync(s->d_pf_pre, 0, 2 * sizeof(unsigned long long), st)); // [0] pairs left out [1] output cursor
+        const unsigned blocks = (unsigned)std::min<uint64_t>((nm + 255) / 256, (uint64_t)f->n_cu * 8);
+        hipLaunchKernelGGL(gn_hibf_premax_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->d_nh,
+                           s->d_pf_rmax);
+        hipLaunchKernelGGL(gn_hibf_predrop_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->d_nh,
+                           s->d_pf_rmax, s->rel_cutoff, s->pf_joint ? 2u : 1u, s->pf_rel_filter, s->d_keys[1], s->d_vals[1], s->match_cap,
+                           s->d_pf_pre + 1, s->d_pf_segmin, s->d_pf_pre);
+        GN_HIP(hipGetLastError());
+        unsigned long long out_n = 0;
+        GN_HIP(hipMemcpyAsync(&out_n, s->d_pf_pre + 1, sizeof(out_n), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipStreamSynchronize(st));
+        if (out_n <= s->match_cap) // (else: chunk holes pushed it past the buffer -- the raw pairs are sorted as they are)
+        {
+            ns            = out_n;
+            src           = 1;
+            s->pf_predrop = true;
+        }
+    }
+    if (ns)
+    {
+        if (ns > 0x7FFFFFFFull)
             return gn_fail(GN_ERANGE, "more than 2^31 matches in one batch");
         size_t tmp = s->sort_tmp_bytes;
-        GN_HIP(hipcub::DeviceRadixSort::SortPairs(s->d_sort_tmp, tmp, s->d_keys[0], s->d_keys[1], s->d_vals[0], s->d_vals[1],
-                                                  (int)nm, 0, (int)(ub_bits + rd_bits), st));
-        hipLaunchKernelGGL(gn_hibf_finish_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, s->d_keys[1],
-                           s->d_vals[1], nm, ub_bits, s->d_nh, s->d_sorted, s->d_seg_count);
+        GN_HIP(hipcub::DeviceRadixSort::SortPairs(s->d_sort_tmp, tmp, s->d_keys[src], s->d_keys[1 - src], s->d_vals[src], s->d_vals[1 - src],
+                                                  (int)ns, 0, (int)(ub_bits + rd_bits), st));
+        if (src == 1) // (the sorted pairs are expected in buffer 1)
+        {
+            std::swap(s->d_keys[0], s->d_keys[1]);
+            std::swap(s->d_vals[0], s->d_vals[1]);
+        }
+        hipLaunchKernelGGL(gn_hibf_finish_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, s->d_keys[1],
+                           s->d_vals[1], ns, ub_bits, s->d_nh, s->d_sorted, s->d_seg_count);
     }
     size_t tmp = s->scan_tmp_bytes;
     GN_HIP(gn_scan_counts(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(n + 1), st));

@@ -292,7 +292,8 @@ struct gn_stream
     double*             d_pf_fpr  = nullptr; // per target
     uint32_t*           d_pf_segmin = nullptr; // per (read, column slice): see GnCountParams::seg_min
     uint64_t            pf_segmin_cap = 0;
-    unsigned long long* d_pf_pre  = nullptr; // matches the count kernel did not write (they count as dropped by rel_filter)
+    unsigned long long* d_pf_pre  = nullptr; // [0] matches the count kernel did not write (they count as dropped by rel_filter) [1] HIBF: cursor
+    uint32_t*           d_pf_rmax = nullptr; // HIBF: largest count per read over the raw pairs (gn_hibf_premax_kernel)
     unsigned long long* d_pf_ctr  = nullptr; // [0] dropped rel_filter [1] dropped fpr_query [2] survivors
     unsigned long long* h_pf_ctr  = nullptr; // pinned copy
     void*               d_pf_scan = nullptr;

@@ -789,12 +789,11 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_gmax), ((size_t)s->max_reads + 1) * 4));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_gmin), ((size_t)s->max_reads + 1) * 4));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_ctr), 4 * sizeof(unsigned long long)));
-        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_pre), sizeof(unsigned long long)));
-        if (!s->f->is_hibf)
-        {
-            s->pf_segmin_cap = ((uint64_t)s->max_reads + 1) * s->f->geom.wpr;
-            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_segmin), s->pf_segmin_cap * 4));
-        }
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_pre), 2 * sizeof(unsigned long long)));
+        s->pf_segmin_cap = ((uint64_t)s->max_reads + 1) * (s->f->is_hibf ? 1u : s->f->geom.wpr);
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_segmin), s->pf_segmin_cap * 4));
+        if (s->f->is_hibf)
+            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_rmax), ((size_t)s->max_reads + 1) * 4));
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_pf_fpr), (nt ? nt : 1) * sizeof(double)));
         GN_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_pf_ctr), 4 * sizeof(unsigned long long), hipHostMallocDefault));
         size_t tmp = 0;
@@ -830,7 +829,7 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
 void gn_postfilter_release(gn_stream* s)
 {
     void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_min, s->d_pf_gmax, s->d_pf_gmin, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan, s->d_pf_gid,
-                     s->d_pf_segmin, s->d_pf_pre };
+                     s->d_pf_segmin, s->d_pf_pre, s->d_pf_rmax };
     for (void* q : ptrs)
         if (q)
             hipFree(q);
@@ -841,6 +840,7 @@ void gn_postfilter_release(gn_stream* s)
     s->d_pf_segmin = nullptr;
     s->pf_segmin_cap = 0;
     s->d_pf_pre  = nullptr;
+    s->d_pf_rmax = nullptr;
     s->pf_predrop = false;
     s->d_pf_fpr  = nullptr;
     s->d_pf_scan = nullptr;
