@@ -100,6 +100,7 @@ struct GnHibfLevelParams
 };
 
 #define GN_HIBF_CHUNK 64u // wave-private slices of the work queue / match buffer (one global atomic per slice)
+#define GN_HIBF_CHUNK_MAX 4096u
 
 // Wave-private chunked append to the next level's queue and to the match buffer (a single counter address sustains only
 // ~90 atomics/us).  A chunk is filled front to back by successive appends; what is left of it when the wave moves on
@@ -109,6 +110,9 @@ struct GnHibfAppender
 {
     unsigned long long wq_base = 0, mq_base = 0;
     uint32_t           wq_left = 0, mq_left = 0;
+    uint32_t           mq_chunk = GN_HIBF_CHUNK; // doubles with every chunk a wave asks for, up to GN_HIBF_CHUNK_MAX: at low cutoffs
+                                                  // (thousands of chance matches per read) fixed 64-pair chunks meant 21 M atomics on
+                                                  // one address per 1.35 G pairs -- most of the leaf level's time
     unsigned long long n_matches = 0;
 
     __device__ __forceinline__ void close_work(const GnHibfLevelParams& p, int lane)
@@ -159,7 +163,8 @@ struct GnHibfAppender
             if (need > mq_left)
             {
                 close_matches(p, lane);
-                const uint32_t     take = need > GN_HIBF_CHUNK ? need : GN_HIBF_CHUNK;
+                const uint32_t     take = need > mq_chunk ? need : mq_chunk;
+                mq_chunk                = mq_chunk < GN_HIBF_CHUNK_MAX ? mq_chunk * 2u : mq_chunk;
                 unsigned long long nb   = 0;
                 if (lane == 0)
                     nb = atomicAdd(&p.ctr[0], (unsigned long long)take);
@@ -938,22 +943,34 @@ __global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t
 }
 
 // sorted (key, raw sum) -> gn_match with the cap of select_matches (GanonClassify.cpp:561-564) + per-read histogram
-__global__ void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, uint32_t ub_bits, const uint32_t* n_hashes,
-                                      gn_match* out, uint32_t* seg_count)
+__global__ __launch_bounds__(256) void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, uint32_t ub_bits,
+                                                             const uint32_t* n_hashes, gn_match* out, uint32_t* seg_count)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    if (keys[i] == ~0ULL) // chunk hole (sorted to the end)
-        return;
-    const uint32_t read = (uint32_t)(keys[i] >> ub_bits);
-    const uint32_t nh   = n_hashes[read];
-    gn_match m;
-    m.read   = read;
-    m.target = (uint32_t)(keys[i] & ((1ULL << ub_bits) - 1ULL));
-    m.count  = vals[i] > nh ? nh : vals[i];
-    out[i]   = m;
-    atomicAdd(&seg_count[read], 1u);
+    const uint64_t i    = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t key  = i < n ? keys[i] : ~0ULL;
+    const bool     valid = key != ~0ULL; // (chunk holes are sorted to the end: the valid pairs of a wave are its first lanes)
+    const uint32_t read = valid ? (uint32_t)(key >> ub_bits) : 0xFFFFFFFFu;
+    if (valid)
+    {
+        const uint32_t nh = n_hashes[read];
+        gn_match       m;
+        m.read   = read;
+        m.target = (uint32_t)(key & ((1ULL << ub_bits) - 1ULL));
+        m.count  = vals[i] > nh ? nh : vals[i];
+        out[i]   = m;
+    }
+    // histogram per read: the pairs are sorted, so a wave adds one number per run of equal reads instead of one per pair
+    // (thousands of pairs per read at low cutoffs: the per-pair atomics on one address were 35 % of such a batch)
+    const uint32_t prev  = (uint32_t)__shfl_up((int)read, 1);
+    const bool     start = valid && (lane == 0 || prev != read);
+    const uint64_t sm = __ballot(start), vm = __ballot(valid);
+    if (start)
+    {
+        const uint64_t above = lane == 63 ? 0ULL : (sm & ~((2ULL << lane) - 1ULL));
+        const uint32_t end   = above ? (uint32_t)__builtin_ctzll(above) : (uint32_t)__popcll(vm);
+        atomicAdd(&seg_count[read], end - lane);
+    }
 }
 
 // ---- matches that a filter_matches pre-pass is bound to drop never reach the sort --------------------------------------------
