@@ -377,16 +377,21 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     {
                         // targets own consecutive bins in target order (what ganon-build writes): the bins of target t are
                         // [tgt_off[t], tgt_off[t+1]) -- two coalesced loads, no record, no bin list
-                        for (uint32_t t0 = lo; t0 < hi; t0 += 4 * GN_WAVE)
-                        {
-                            uint32_t o0[4], o1[4], cv[4];
+                        uint32_t o0[4], o1[4];
+                        auto     load_off = [&](uint32_t tb, uint32_t (&a)[4], uint32_t (&b)[4]) {
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
                             {
-                                const uint32_t t = t0 + 64u * (uint32_t)u + lane;
-                                o0[u] = t < hi ? p.tgt_off[t] : 0u;
-                                o1[u] = t < hi ? p.tgt_off[t + 1] : 0u;
+                                const uint32_t t = tb + 64u * (uint32_t)u + lane;
+                                a[u] = t < hi ? p.tgt_off[t] : 0u;
+                                b[u] = t < hi ? p.tgt_off[t + 1] : 0u;
                             }
+                        };
+                        load_off(lo, o0, o1);
+                        for (uint32_t t0 = lo; t0 < hi; t0 += 4 * GN_WAVE)
+                        {
+                            uint32_t n0[4], n1[4], cv[4];
+                            load_off(t0 + 4 * GN_WAVE, n0, n1); // the next trip's offsets fly while this trip's bins are summed
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
                             {
@@ -401,6 +406,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                                 const uint32_t t = t0 + 64u * (uint32_t)u + lane;
                                 if (t0 + 64u * (uint32_t)u < hi) // (wave-uniform: emit_hits holds a ballot)
                                     emit_hits(t < hi && judge(cv[u]), t, cv[u], tot, direct, out);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                            {
+                                o0[u] = n0[u];
+                                o1[u] = n1[u];
                             }
                         }
                         return tot;
