@@ -16,10 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("script,seed,n_cfg", [("fuzz_early_exit.py", 11, 12), ("fuzz_early_exit.py", 12, 8), ("fuzz_split.py", 21, 12),
-                                               ("fuzz_split.py", 22, 8)])
+                                               ("fuzz_split.py", 22, 8), ("fuzz_predrop.py", 31, 16)])
 def test_randomised_cross_checks(script, seed, n_cfg):
     env = dict(os.environ, SEED=str(seed), N_CFG=str(n_cfg))
-    for k in ("GANON_HIP_NO_EARLY_EXIT", "GANON_HIP_NO_SPLIT_KERNEL", "GANON_HIP_NO_CAND_SELECT"):
+    for k in ("GANON_HIP_NO_EARLY_EXIT", "GANON_HIP_NO_SPLIT_KERNEL", "GANON_HIP_NO_CAND_SELECT", "GANON_HIP_NO_PREDROP"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "BAD 0" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
