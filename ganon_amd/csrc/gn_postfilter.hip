@@ -1,7 +1,7 @@
 // gn_postfilter.hip -- device-side pre-pass of filter_matches (/root/reference/src/ganon-classify/GanonClassify.cpp:579-613
 // with the threshold of :755-761), run on the matches of a batch after they were grouped by read.
 //
-// Why it exists: at the binary's default thresholds (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5) a read has ~100
+// Why it exists: at a low cutoff (--rel-cutoff 0.2, the binary's default, with --rel-filter 0.1 --fpr-query 1e-5) a read has ~100
 // chance matches on a 4096-bin filter (T = 4 of ~18 minimisers), and nearly all of them die in filter_matches.  Shipping
 // them over PCIe and walking them on one host thread made the end-to-end rate 2 Mreads/s; dropping them here, in HBM,
 // leaves the host the survivors only.
@@ -20,9 +20,12 @@
 // underflowing terms are left alone).  The host applies the reference's own expression to every survivor, so the final
 // result is the one the reference computes; the device only removes matches whose fate is not in doubt.
 //
-// Valid only where one filter (one gn_filter) sees all matches of a read: a hierarchy level with several filters merges
-// their matches before thresholding (:716-735), and a filter cut into column parts spreads a read over several streams;
-// the host enables this pass only otherwise (backend_hip.cpp).
+// One stream's pass (MODE 0) is valid only where one filter (one gn_filter) sees all matches of a read.  A hierarchy level
+// with several filters merges their matches before thresholding (:716-735), and a filter cut into column parts spreads a
+// read over several streams: gn_streams_postfilter_joint below runs the rule over all the streams of a level -- max/min
+// per stream, combined, applied (filters with disjoint targets, column parts), or the reference's merge replayed per read
+// (filters that share targets).  The count kernels take part too: what the --rel-filter rule is bound to drop they do not
+// write in the first place (GnCountParams::pre_mode; seg_min / pre_ctr carry what this pass still needs of it).
 #include "gn_internal.h"
 #include <hipcub/hipcub.hpp>
 #include "gn_scan.h"

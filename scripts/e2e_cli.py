@@ -140,6 +140,8 @@ if all(out[x].get("rc") == 0 for x in ("one_worker", "two_workers_one_gpu", "thr
 if os.environ.get("E2E_KEEP"):  # leave filter and reads behind for follow-up runs (A/B scripts)
     os.rename(ibf, os.path.join(d, os.environ["E2E_KEEP"] + ".ibf"))
     os.rename(fq, os.path.join(d, os.environ["E2E_KEEP"] + ".fq"))
+    if os.environ.get("E2E_SHARED"):
+        os.rename(ibf2, os.path.join(d, os.environ["E2E_KEEP"] + "_b.ibf"))
     if os.environ.get("E2E_PAIRED"):
         os.rename(fq2, os.path.join(d, "ganon_keep2.fq"))
 for f in os.listdir(d):
