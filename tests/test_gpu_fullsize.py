@@ -102,6 +102,52 @@ def test_sample_against_oracle(full):
         assert nh[r] == len(hh) and got == exp, (r, got, exp)
 
 
+def test_filter_matches_prepass_at_full_size(full, monkeypatch):
+    # the device pre-pass of filter_matches at a low cutoff (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5: ~100 chance matches
+    # per read) on all 10 M reads: nothing is lost or invented (dropped + survivors = matches of the plain run), the count kernel's
+    # pre-drop changes no survivor, mark, maximum or total, and on a sample of reads the survivors are what the oracle's
+    # filter_matches leaves of the unfiltered matches
+    from test_gpu_parity import _exact_filter_matches
+    hip, wl, flt, st, _ = full
+    tfpr = np.full(wl.bins, 0.5 ** wl.hash_funs)
+    res = {}
+    for tag in ("predrop", "plain"):
+        if tag == "plain":
+            monkeypatch.setenv("GANON_HIP_NO_PREDROP", "1")
+        st.set_postfilter(0.1, 1e-5, tfpr)
+        st.classify(wl.k, wl.w, 0.2)
+        nh, status, mo, m = st.fetch()
+        mx, d_fil, d_fpr = st.fetch_postfilter()
+        res[tag] = (mo, m, mx, d_fil, d_fpr)
+        monkeypatch.delenv("GANON_HIP_NO_PREDROP", raising=False)
+    mo, m, mx, d_fil, d_fpr = res["predrop"]
+    assert np.array_equal(mo, res["plain"][0]) and np.array_equal(m, res["plain"][1]) and np.array_equal(mx, res["plain"][2])
+    assert (d_fil, d_fpr) == res["plain"][3:]
+    st.set_postfilter(None)
+    st.classify(wl.k, wl.w, 0.2)
+    st.sync()
+    raw_n = st.timings()["n_matches"]
+    assert raw_n > 50 * wl.n_reads * (READS >= 1_000_000) and d_fil + d_fpr + len(m) == raw_n
+    # a sub-batch through a second stream without the pass gives the unfiltered matches of its reads
+    rng = np.random.default_rng(5)
+    pick = rng.choice(wl.n_reads, size=min(50_000, wl.n_reads), replace=False)
+    reads = wl.bases.reshape(wl.n_reads, wl.read_len)[pick]
+    st2 = hip.HipStream(flt, len(pick), reads.size)
+    st2.submit(reads.reshape(-1), np.arange(len(pick) + 1, dtype=np.uint64) * np.uint64(wl.read_len), None, wl.k, wl.w, 0.2)
+    nh3, _, mo3, m3 = st2.fetch()
+    for x in rng.integers(0, len(pick), size=1500).tolist():
+        r = int(pick[x])
+        raw = [(int(e["target"]), int(e["count"])) for e in m3[int(mo3[x]):int(mo3[x + 1])]]
+        kept, nf, nq, emx = _exact_filter_matches(raw, nh3[x], 0.1, 1e-5, tfpr)
+        got = [(int(e["target"]), int(e["count"]) & 0x7FFFFFFF) for e in m[int(mo[r]):int(mo[r + 1])]]
+        assert int(mx[r]) == emx and set(kept) <= set(got) <= set(raw), r
+        exact_drop = set(raw) - set(kept)
+        assert [e for e in got if e not in exact_drop] == kept, r  # (the host's exact --fpr-query check on the survivors ends there)
+    st2.destroy()
+    st.classify(wl.k, wl.w, wl.rel_cutoff)  # (the fixture's batch again)
+    st.sync()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[2]: 2-level HIBF, 65 536 user bins (top IBF of 256 merged bins -> 256 children of 256 bins)
 # ---------------------------------------------------------------------------------------------------------------
