@@ -1405,9 +1405,12 @@ extern "C" int gn_stream_set_long_reads(gn_stream* s, int on)
         s->long_reads = false;
         return GN_OK;
     }
-    if (s->f->is_hibf)
-        return gn_fail(GN_ERANGE, "long reads (more than 65535 minimisers) are supported for flat IBF filters only");
     GN_HIP(hipSetDevice(s->device));
+    if (s->f->is_hibf) // (the level kernels take the flag: 32-bit sums, GN_READ_BIG reads through the LDS-counter kernel)
+    {
+        s->long_reads = true;
+        return GN_OK;
+    }
     if (!s->d_long_list)
     {
         GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_long_list), ((size_t)s->max_reads + 1) * 4));

@@ -97,6 +97,8 @@ struct GnHibfLevelParams
     uint32_t                  n_reads;   // level 0 of the register-counter kernels: the reads are the items
     const uint8_t*            status;
     uint32_t                  pack_gp;   // packed kernel: log2 of the lanes per row every item of the launch must have
+    uint32_t                  wide;      // the reference's -DLONGREADS build (value_t = uint32_t): sums do not wrap at 2^16 and reads
+                                         // of more than 65535 minimisers (GN_READ_BIG) are counted like the others
 };
 
 #define GN_HIBF_CHUNK 64u // wave-private slices of the work queue / match buffer (one global atomic per slice)
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
         if (b < n_batches && idx < n_work)
         {
             if constexpr (LEVEL0)
-                read = p.status[idx] == GN_READ_OK ? idx : 0xFFFFFFFFu;
+                read = (p.status[idx] == GN_READ_OK || (p.wide && p.status[idx] == GN_READ_BIG)) ? idx : 0xFFFFFFFFu;
             else
             {
                 const uint2 e = p.work_in[idx];
@@ -540,7 +542,8 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
         if constexpr (LEVEL0)
         {
             const uint32_t four = gn_sload(reinterpret_cast<const uint32_t*>(p.status) + (it >> 2)); // status bytes it&~3 ..
-            return make_uint2(((four >> (8u * (it & 3u))) & 0xFFu) == GN_READ_OK ? it : 0xFFFFFFFFu, 0u);
+            const uint32_t st1  = (four >> (8u * (it & 3u))) & 0xFFu;
+            return make_uint2((st1 == GN_READ_OK || (p.wide && st1 == GN_READ_BIG)) ? it : 0xFFFFFFFFu, 0u);
         }
         else
         {
@@ -804,7 +807,8 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
                         {
                             const uint32_t t = b & 63u, d = t >> 5, tt = t & 31u;
                             const uint32_t v = img[(b >> 6) * 16 + (d * 4 + (tt & 3u)) * 2 + ((tt >> 2) & 1u)];
-                            sum              = (sum + ((v >> (8 * (tt >> 3))) & 0xFFu)) & 0xFFFFu; // value_t = uint16_t wraps (hibf.hpp:438,442)
+                            sum              = sum + ((v >> (8 * (tt >> 3))) & 0xFFu);
+                            sum              = p.wide ? sum : (sum & 0xFFFFu); // value_t = uint16_t wraps (hibf.hpp:438,442)
                         }
                         leaf = sum >= T; // :455
                         tgt  = run.z;
@@ -914,7 +918,7 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
             {
                 const uint4 run = f.runs[r]; // first bin, n bins, user bin (-1 merged), child ibf
                 for (uint32_t b = 0; b < run.y; ++b)
-                    sum = (sum + cnt[run.x + b]) & 0xFFFFu; // value_t = uint16_t wraps (hibf.hpp:438,442)
+                    sum = p.wide ? sum + cnt[run.x + b] : ((sum + cnt[run.x + b]) & 0xFFFFu); // value_t = uint16_t wraps (hibf.hpp:438,442)
                 merged = (int32_t)run.z < 0;
                 tgt    = merged ? (int32_t)run.w : (int32_t)run.z;
                 hit    = sum >= T; // :447 / :455
@@ -928,10 +932,10 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
         atomicAdd(&p.ctr[2], my_bytes);
 }
 
-__global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t n_reads, unsigned long long* count)
+__global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t n_reads, unsigned long long* count, uint32_t wide)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool     ok = r < n_reads && status[r] == GN_READ_OK;
+    const bool     ok = r < n_reads && (status[r] == GN_READ_OK || (wide && status[r] == GN_READ_BIG));
     const uint64_t bm = __ballot(ok);
     const int      lane = threadIdx.x & 63;
     unsigned long long base = 0;
@@ -1298,7 +1302,8 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     const bool     no_reg  = getenv("GANON_HIP_HIBF_NO_REG") != nullptr;
     const bool     no_pack = no_reg || getenv("GANON_HIP_HIBF_NO_PACK") != nullptr;
     if (n && no_reg) // (the register-counter kernels take level 0 straight from the batch)
-        hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n, s->d_hctr);
+        hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n, s->d_hctr,
+                           s->long_reads ? 1u : 0u);
     const uint32_t reg_bpc = getenv("GANON_HIP_HIBF_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_HIBF_BPC")) : 0u; // 0 = occupancy
     for (uint32_t lvl = 0; lvl < depth && n; ++lvl)
     {
@@ -1308,6 +1313,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         p.slot_off    = s->d_slot_off;
         p.n_hashes    = s->d_nh;
         p.rel_cutoff  = s->rel_cutoff;
+        p.wide        = s->long_reads ? 1u : 0u;
         p.work_in     = s->d_work[lvl & 1];
         p.count_in    = s->d_hctr + lvl;
         p.work_out    = s->d_work[(lvl + 1) & 1];

@@ -97,7 +97,7 @@ public:
     // BatchResult::prefiltered says so per batch.  The default does nothing: the host then runs filter_matches on everything.
     virtual bool set_postfilter(const PostFilterSpec* /*spec*/) { return false; }
     // Optional.  Reads with more than 65535 minimisers: classified like every other read (the reference's -DLONGREADS build)
-    // instead of coming back with status 2.  Returns whether the backend can do that; flat IBF filters only.
+    // instead of coming back with status 2.  Returns whether the backend can do that.
     virtual bool set_long_reads(bool /*on*/) { return false; }
 };
 

@@ -390,7 +390,7 @@ public:
                     part.pf_generation = 0;
                     lap(sec_create_);
                     ++n_create_;
-                    if (long_reads_ && !filters_[i].is_hibf && gn_stream_set_long_reads(part.s, 1) != GN_OK)
+                    if (long_reads_ && gn_stream_set_long_reads(part.s, 1) != GN_OK)
                     {
                         err = gn_last_error();
                         return false;
@@ -519,7 +519,7 @@ public:
         long_reads_ = on;
         for (auto& lf : filters_) // (streams that exist already; new ones get it when they are created)
             for (auto& part : lf.parts)
-                if (part.s && !lf.is_hibf)
+                if (part.s)
                     gn_stream_set_long_reads(part.s, on ? 1 : 0);
         return true;
     }

@@ -810,8 +810,6 @@ static bool ganon_classify(Config config)
     }
     if (config.long_reads)
     {
-        if (config.hibf && !config.quiet)
-            std::cerr << "WARNING: --long-reads has no effect on HIBF filters (reads with more than 65535 minimisers stay skipped)" << std::endl;
         for (auto& b : backends)
             if (!b->set_long_reads(true))
             {

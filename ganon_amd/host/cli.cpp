@@ -56,7 +56,7 @@ const Opt kOpts[] = {
     { 'z', "output-stats", Kind::Bool, "Outputs classification statistics (prefix.sta)" },
     { 's', "output-single", Kind::Bool, "Do not split output files (one and all) with multi-level --hierarchy-labels" },
     { 0, "hibf", Kind::Bool, "Input is an Hierarchical IBF (.hibf) generated from raptor." },
-    { 0, "long-reads", Kind::Bool, "Classify reads with more than 65535 minimisers too (what the reference does when it is built with -DLONGREADS=ON). Flat IBF filters only." },
+    { 0, "long-reads", Kind::Bool, "Classify reads with more than 65535 minimisers too (what the reference does when it is built with -DLONGREADS=ON)." },
     { 0, "skip-lca", Kind::Bool, "Skip LCA step." },
     { 0, "tax-root-node", Kind::Str, "Define alternative root node for LCA. Default: 1" },
     { 't', "threads", Kind::U16, "Number of threads" },

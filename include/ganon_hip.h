@@ -173,8 +173,10 @@ int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status, uint64_t* 
 
 /* Reads with more than 65535 minimisers.  By default they come back with status GN_READ_BIG and no matches, like the
  * reference's default build (TIntCount = uint16_t, GanonClassify.cpp:45-49,674).  on != 0 gives what the reference does when
- * compiled with -DLONGREADS (uint32 counters): such reads are counted with 32-bit counters by a kernel of their own, come
- * back with status GN_READ_OK, and their match counts may exceed 65535.  Flat IBF filters only (GN_ERANGE for an HIBF). */
+ * compiled with -DLONGREADS (uint32 counters): such reads are counted with 32-bit counters (flat IBF: by a kernel of their
+ * own; HIBF: by the LDS-counter level kernel), come back with status GN_READ_OK, and their match counts may exceed 65535.
+ * For an HIBF the option also switches the 16-bit wrap of the per-user-bin sums off for every read, as the uint32 build does
+ * (hibf.hpp:438,442: value_t). */
 int gn_stream_set_long_reads(gn_stream* s, int on);
 
 /* Optional device-side pre-pass of filter_matches (/root/reference/src/ganon-classify/GanonClassify.cpp:579-613 with the

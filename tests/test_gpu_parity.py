@@ -813,12 +813,65 @@ def test_long_reads_option_classifies_what_the_default_skips(hip, split_map):
     flt.free()
 
 
-def test_long_reads_option_is_refused_for_hibf(hip):
-    hb = gf.random_hibf(50, 64, 1, seed=2, density=0.2, hash_funs=2)
+def _hibf_bulk_count_wide(hb, hashes, threshold):
+    """hierarchical_interleaved_bloom_filter.hpp:432-460 with value_t = uint32_t (the reference's -DLONGREADS build): the recursion
+    of bulk_count_impl with sums that do not wrap; per-bin counts from the oracle's 16-bit bulk_count in chunks that cannot wrap"""
+    out = {}
+
+    def visit(i):
+        f = hb.ibfs[i]
+        counts = np.zeros(f.bins, dtype=np.uint64)
+        for a in range(0, len(hashes), 60000):
+            counts += f.bulk_count(hashes[a:a + 60000]).astype(np.uint64)
+        total = 0
+        for b in range(f.bins):
+            total += int(counts[b])
+            u = hb.bin_to_user[i][b]
+            if u < 0:
+                if total >= threshold:
+                    visit(hb.next_ibf_id[i][b])
+                total = 0
+            elif b + 1 == f.bins or u != hb.bin_to_user[i][b + 1]:
+                if total >= threshold:
+                    out[int(u)] = total
+                total = 0
+
+    visit(0)
+    return out
+
+
+def test_long_reads_option_for_an_hibf(hip):
+    # an HIBF with gn_stream_set_long_reads: reads of more than 65535 minimisers are counted (through the LDS-counter level
+    # kernel) instead of skipped, and no per-user-bin sum wraps at 2^16 -- for ANY read, like the reference's uint32 build
+    k, w = 19, 31
+    rng = np.random.default_rng(9)
+    genome = gu.random_seq(rng, 640_000)
+    other = gu.random_seq(rng, 40_000)
+    uh = {7: np.unique(oracle.minimiser_hash(oracle.to_ranks(genome), k, w)), 33: np.unique(oracle.minimiser_hash(oracle.to_ranks(other), k, w))}
+    hb = gf.random_hibf(90, 32, 2, seed=12, density=0.15, hash_funs=2, rows=(60000, 90000), user_hashes=uh)
     flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
-    st = hip.HipStream(flt, 4, 1000)
-    with pytest.raises(hip.GanonHipError):
+    seqs = [genome[1000:631_000], other[100:39_000], genome[200_000:200_150], gu.random_seq(rng, 600_000), other[5000:5250]]
+    bases, off1, off2 = gu.pack_reads(seqs, None)
+    st = hip.HipStream(flt, len(seqs), bases.size)
+    for cutoff in (0.1, 0.6):
+        st.set_long_reads(False)
+        st.submit(bases, off1, off2, k, w, cutoff)
+        nh0, status0, mo0, m0 = st.fetch()
         st.set_long_reads(True)
+        st.submit(bases, off1, off2, k, w, cutoff)
+        nh, status, mo, m = st.fetch()
+        assert np.array_equal(nh, nh0) and [int(x) for x in status0] == [2, 0, 0, 2, 0] and (status == 0).all()
+        for i, sq in enumerate(seqs):
+            hh = oracle.minimiser_hash(oracle.to_ranks(sq), k, w)
+            assert len(hh) == nh[i]
+            T = max(1, oracle.threshold_rel(len(hh), cutoff))
+            exp = sorted((u, min(c, len(hh))) for u, c in _hibf_bulk_count_wide(hb, hh, T).items())
+            got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+            assert got == exp, (cutoff, i, got[:4], exp[:4])
+            if status0[i] == 2:
+                assert mo0[i] == mo0[i + 1]
+        got0 = [(int(x["target"]), int(x["count"])) for x in m[int(mo[0]):int(mo[1])]]
+        assert any(u == 7 and c > 65535 for u, c in got0)  # the planted genome: a count no uint16 holds
     st.destroy()
     flt.free()
 
