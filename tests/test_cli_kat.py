@@ -570,3 +570,33 @@ def test_shared_targets_with_more_matches_than_the_device_merges(oracle_bin, tmp
         outs[tag] = {ext: open(prefix + ext, "rb").read() for ext in (".all", ".unc", ".rep", ".sta")}
     assert outs["hip"] == outs["oracle"]
     assert outs["hip"][".all"].count(b"\n") > 10000
+
+
+@pytest.mark.gpu
+def test_long_reads_flag_with_an_hibf(tmp_path):
+    # the same switch for an HIBF (the level kernels take it: sums do not wrap, reads over 65535 minimisers are counted)
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(18)
+    genome = "".join("ACGT"[x] for x in rng.integers(0, 4, size=640_000))
+    other = "".join("ACGT"[x] for x in rng.integers(0, 4, size=30_000))
+    names = [f"U{u}" for u in range(40)]
+    uh = {5: np.unique(oracle.minimiser_hash(oracle.to_ranks(genome.encode()), 19, 31)),
+          21: np.unique(oracle.minimiser_hash(oracle.to_ranks(other.encode()), 19, 31))}
+    hb = gf.random_hibf(40, 16, 2, seed=3, density=0.1, hash_funs=2, rows=(70000, 90000), user_hashes=uh)
+    path = str(tmp_path / "long.hibf")
+    gf.write_hibf(path, hb, [[f"/x/{n}.minimiser"] for n in names], 19, 31, 0.05)
+    fa = str(tmp_path / "reads.fa")
+    gf.write_fasta(fa, [("long_read", genome[2000:632_000]), ("short_read", genome[100:250]), ("other_read", other[500:700])])
+    outs = {}
+    for tag, extra in (("default", []), ("long", ["--long-reads"])):
+        prefix = str(tmp_path / tag)
+        cu.run(cu.BIN_HIP, ["--ibf", path, "--hibf", "--single-reads", fa, "-o", prefix, "--output-all", "--output-unclassified", "--skip-lca",
+                            "--rel-cutoff", "0.5", "--quiet"] + extra)
+        rows = [line.rstrip("\n").split("\t") for line in open(prefix + ".all")]
+        outs[tag] = ({(r[0], r[1]): int(r[2]) for r in rows}, open(prefix + ".unc").read().split())
+    assert outs["default"][1] == ["long_read"] and outs["long"][1] == []
+    assert {k for k in outs["default"][0]} == {k for k in outs["long"][0] if k[0] != "long_read"}
+    assert outs["long"][0][("long_read", "U5")] > 65535
+    for key, c in outs["default"][0].items():
+        assert outs["long"][0][key] == c
