@@ -876,6 +876,56 @@ def test_long_reads_option_for_an_hibf(hip):
     flt.free()
 
 
+def test_hibf_sums_wrap_at_16_bits_in_the_default_build_only(hip):
+    # a user bin split over several technical bins that ALL hold a read's minimisers: the per-user-bin sum passes 65535 although
+    # the read has fewer minimisers than that.  Default build: value_t = uint16_t wraps (hibf.hpp:438,442) -- the oracle's C
+    # restatement does the same; with the long-reads switch (uint32 build) the sum is exact and then capped at the read's
+    # minimiser count (GanonClassify.cpp:561-564)
+    k, w = 19, 31
+    rng = np.random.default_rng(2)
+    hb = gf.random_hibf(60, 32, 2, seed=21, density=0.05, hash_funs=2, rows=(60000, 90000))
+    where = {}
+    for i, b2u in enumerate(hb.bin_to_user):
+        for b, u in enumerate(b2u):
+            if u >= 0:
+                where.setdefault(int(u), []).append((i, b))
+    ub, cells = max(where.items(), key=lambda kv: len(kv[1]))
+    assert len(cells) >= 2
+    genome = gu.random_seq(rng, 330_000)
+    hh = oracle.minimiser_hash(oracle.to_ranks(genome), k, w)
+    assert 32768 < len(hh) <= 65535
+    uniq = np.unique(hh)
+    for i, b in cells:  # every technical bin of the user bin, and the merged bins on the way down to it
+        hb.ibfs[i].emplace_many(uniq, b)
+    leaf = cells[0][0]
+    while leaf != 0:
+        pi, pb = next((pi, pb) for pi, nx in enumerate(hb.next_ibf_id) for pb, c in enumerate(nx) if c == leaf and hb.bin_to_user[pi][pb] < 0)
+        hb.ibfs[pi].emplace_many(uniq, pb)
+        leaf = pi
+    hb = oracle.Hibf(hb.ibfs, hb.next_ibf_id, hb.bin_to_user, hb.n_user_bins)  # (the C view of the changed matrices)
+    flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+    bases, off1, off2 = gu.pack_reads([genome], None)
+    st = hip.HipStream(flt, 1, bases.size)
+    T = max(1, oracle.threshold_rel(len(hh), 0.25))
+    raw = len(cells) * len(hh)
+    assert raw > 65535
+    for wide in (False, True):
+        st.set_long_reads(wide)
+        st.submit(bases, off1, off2, k, w, 0.25)
+        nh, status, mo, m = st.fetch()
+        got = {int(x["target"]): int(x["count"]) for x in m}
+        if wide:
+            exp = {u: min(c, len(hh)) for u, c in _hibf_bulk_count_wide(hb, hh, T).items()}
+            assert exp[ub] == len(hh)
+        else:
+            cnt = hb.bulk_count(hh, T)
+            exp = {int(u): min(int(cnt[u]), len(hh)) for u in np.nonzero(cnt)[0]}
+            assert exp.get(ub, 0) == ((raw & 0xFFFF) if (raw & 0xFFFF) >= T else 0) or len(cells) > 2
+        assert nh[0] == len(hh) and status[0] == 0 and got == exp, (wide, got, exp)
+    st.destroy()
+    flt.free()
+
+
 @pytest.mark.parametrize("shape", ["identity", "split", "hibf"])
 def test_matches_against_an_oracle_that_never_sees_device_hashes(hip, shape):
     # the whole path on both sides: oracle minimisers -> oracle counts -> oracle selection, nothing taken from the device
