@@ -82,7 +82,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
             continue
         if force or _stale(binary, srcs + hdrs + [LIB]):
             cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", binary] + srcs + \
-                  ["-L", CSRC, "-lganon_hip", "-lz", "-Wl,-rpath,$ORIGIN/../csrc"]
+                  ["-L", CSRC, "-lganon_hip", "-lz", "-ldl", "-Wl,-rpath,$ORIGIN/../csrc"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)

@@ -29,8 +29,8 @@ struct Opt
 };
 
 const Opt kOpts[] = {
-    { 'r', "single-reads", Kind::VecStr, "single-end reads file[s] (comma-separated, flat or gzipped; bzip2 is not supported by this build)" },
-    { 'p', "paired-reads", Kind::VecStr, "paired-end reads file[s] (comma-separated, flat or gzipped; bzip2 is not supported by this build)" },
+    { 'r', "single-reads", Kind::VecStr, "single-end reads file[s] (comma-separated; flat, gzipped or bzip2-compressed)" },
+    { 'p', "paired-reads", Kind::VecStr, "paired-end reads file[s] (comma-separated; flat, gzipped or bzip2-compressed)" },
     { 'b', "batch-reads", Kind::VecStr,
       "file describing several files of single- or paired-end reads to be processed in one run: prefix <tab> file1 "
       "[<tab> file2]. Prefixes can be repeated for multiple files." },

@@ -3,6 +3,7 @@
 
 #include <tmmintrin.h>
 #include <zlib.h>
+#include <dlfcn.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -285,10 +286,127 @@ private:
     std::thread                   producer_; // last member
 };
 
+// bzip2 input (the reference reads it through seqan3 when it is built with bzip2).  The image has libbz2's shared object but
+// not its header, so the library is opened at run time and the few entry points of its stable low-level interface
+// (bzlib.h of bzip2 1.0: bz_stream, BZ2_bzDecompressInit / BZ2_bzDecompress / BZ2_bzDecompressEnd) are declared here.
+// Concatenated streams (pbzip2 output) are read one after the other.
+struct Bz2Source
+{
+    struct Stream // bz_stream
+    {
+        char*        next_in;
+        unsigned int avail_in, total_in_lo32, total_in_hi32;
+        char*        next_out;
+        unsigned int avail_out, total_out_lo32, total_out_hi32;
+        void*        state;
+        void* (*bzalloc)(void*, int, int);
+        void (*bzfree)(void*, void*);
+        void* opaque;
+    };
+    using InitFn = int (*)(Stream*, int, int);
+    using RunFn  = int (*)(Stream*);
+    void*             lib = nullptr;
+    InitFn            init = nullptr;
+    RunFn             run = nullptr, end = nullptr;
+    FILE*             fp = nullptr;
+    Stream            st{};
+    bool              open_stream = false, file_eof = false;
+    std::vector<char> in;
+
+    static std::unique_ptr<Bz2Source> open(const std::string& path, std::string& why)
+    {
+        std::unique_ptr<Bz2Source> b(new Bz2Source);
+        for (const char* name : { "libbz2.so.1.0", "libbz2.so.1", "libbz2.so" })
+            if ((b->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
+                break;
+        if (!b->lib)
+        {
+            why = " bzip2 input needs libbz2 (libbz2.so.1.0 could not be loaded)";
+            return nullptr;
+        }
+        b->init = reinterpret_cast<InitFn>(dlsym(b->lib, "BZ2_bzDecompressInit"));
+        b->run  = reinterpret_cast<RunFn>(dlsym(b->lib, "BZ2_bzDecompress"));
+        b->end  = reinterpret_cast<RunFn>(dlsym(b->lib, "BZ2_bzDecompressEnd"));
+        if (!b->init || !b->run || !b->end)
+        {
+            why = " libbz2 lacks the decompression entry points";
+            return nullptr;
+        }
+        b->fp = std::fopen(path.c_str(), "rb");
+        if (!b->fp)
+        {
+            why = " cannot open file";
+            return nullptr;
+        }
+        b->in.resize(1 << 20);
+        return b;
+    }
+    ~Bz2Source()
+    {
+        if (open_stream)
+            end(&st);
+        if (fp)
+            std::fclose(fp);
+        if (lib)
+            dlclose(lib);
+    }
+    // up to `want` decompressed bytes; 0 at the end of the file; -1 on a damaged stream
+    long read(char* out, size_t want)
+    {
+        size_t done = 0;
+        while (done < want)
+        {
+            if (st.avail_in == 0 && !file_eof)
+            {
+                const size_t n = std::fread(in.data(), 1, in.size(), fp);
+                if (n == 0)
+                    file_eof = true;
+                st.next_in  = in.data();
+                st.avail_in = (unsigned int)n;
+            }
+            if (!open_stream)
+            {
+                if (st.avail_in == 0) // nothing after the last stream
+                    break;
+                char*              keep_in = st.next_in;
+                const unsigned int keep_n  = st.avail_in;
+                st = Stream{};
+                if (init(&st, 0, 0) != 0)
+                    return -1;
+                st.next_in  = keep_in;
+                st.avail_in = keep_n;
+                open_stream = true;
+            }
+            st.next_out  = out + done;
+            st.avail_out = (unsigned int)std::min<size_t>(want - done, 1u << 30);
+            const unsigned int before = st.avail_out;
+            const int          rc     = run(&st);
+            done += before - st.avail_out;
+            if (rc == 4) // BZ_STREAM_END: another stream may follow
+            {
+                char*              keep_in = st.next_in;
+                const unsigned int keep_n  = st.avail_in;
+                end(&st);
+                open_stream = false;
+                st          = Stream{};
+                st.next_in  = keep_in;
+                st.avail_in = keep_n;
+                continue;
+            }
+            if (rc != 0) // BZ_OK
+                return -1;
+            if (st.avail_in == 0 && file_eof) // the stream wants more than the file holds
+                return before == st.avail_out ? -1 : (long)done;
+        }
+        return (long)done;
+    }
+};
+
 struct SeqReader::Impl
 {
     gzFile                      gz = nullptr;
     std::unique_ptr<BgzfSource> bgzf; // set instead of gz for blocked gzip
+    std::unique_ptr<Bz2Source>  bz2;  // set instead of gz for bzip2
     std::string                 path;
     bool              fastq = false;
     std::vector<char> buf;
@@ -311,7 +429,10 @@ struct SeqReader::Impl
         if (len == buf.size())
             buf.resize(buf.size() * 2); // a single line longer than the buffer
         const size_t want = std::min<size_t>(buf.size() - len, 1u << 30);
-        const int    n    = bgzf ? (int)bgzf->read(buf.data() + len, want) : gzread(gz, buf.data() + len, (unsigned)want);
+        const int    n    = bz2 ? (int)bz2->read(buf.data() + len, want)
+                                : bgzf ? (int)bgzf->read(buf.data() + len, want) : gzread(gz, buf.data() + len, (unsigned)want);
+        if (n < 0 && bz2)
+            throw ParseError(" damaged bzip2 stream");
         if (n < 0)
         {
             int         err = 0;
@@ -380,8 +501,9 @@ SeqReader::SeqReader(const std::string& path, uint64_t start_offset) : impl_(new
             base = base.substr(0, base.size() - std::strlen(z));
             break;
         }
-    if (ends_with(base, ".bz2"))
-        throw ParseError(" bzip2 input is not supported by this build (no bzlib in the image)");
+    const bool is_bz2 = ends_with(base, ".bz2");
+    if (is_bz2)
+        base = base.substr(0, base.size() - 4);
     bool known = false;
     for (const char* e : { ".fq", ".fastq" })
         if (ends_with(base, e))
@@ -395,6 +517,16 @@ SeqReader::SeqReader(const std::string& path, uint64_t start_offset) : impl_(new
     if (!known)
         throw ParseError(" unknown sequence file extension (expected FASTA or FASTQ, optionally gzipped)");
     impl_->buf.resize(4 << 20);
+    if (is_bz2)
+    {
+        if (start_offset)
+            throw ParseError(" cannot seek in a bzip2 file");
+        std::string why;
+        impl_->bz2 = Bz2Source::open(path, why);
+        if (!impl_->bz2)
+            throw ParseError(why);
+        return;
+    }
     if (!std::getenv("GANON_HOST_NO_BGZF") && start_offset == 0)
         impl_->bgzf = BgzfSource::open(path); // blocked gzip: members inflated in parallel
     if (impl_->bgzf)

@@ -75,6 +75,13 @@ def _variants(d, r1):
     _write_bgzf(os.path.join(d, "h.fastq.bgzf"), _fastq(r1, wrap=60), block=64000); v["fastq_bgzf_wrapped"] = "h.fastq.bgzf"
     spaced = "".join(f">{rid}\n{_wrap(s, 33).replace(chr(10), ' ' + chr(10))} \n" for rid, s in r1)  # blanks inside sequences
     _write(os.path.join(d, "f.fna"), spaced, nl="\r\n"); v["fasta_crlf_spaces"] = "f.fna"
+    import bz2  # bzip2: one stream, and several streams behind each other (what pbzip2 writes)
+    fq = _fastq(r1).encode()
+    open(os.path.join(d, "i.fq.bz2"), "wb").write(bz2.compress(fq)); v["fastq_bz2"] = "i.fq.bz2"
+    cut = [0, len(fq) // 3, len(fq) // 3 + 17, len(fq)]
+    open(os.path.join(d, "j.fastq.bz2"), "wb").write(b"".join(bz2.compress(fq[a:b], 1) for a, b in zip(cut, cut[1:])))
+    v["fastq_bz2_three_streams"] = "j.fastq.bz2"
+    open(os.path.join(d, "k.fa.bz2"), "wb").write(bz2.compress(_fasta(r1, 70).encode())); v["fasta_bz2"] = "k.fa.bz2"
     return v
 
 
@@ -155,6 +162,15 @@ def _check_errors(binary, sim_db, tmp):
     open(bz, "wb").write(bytes(raw))
     p = os.path.join(tmp, "dmg")
     res = _run(binary, sim_db, ["--single-reads", bz], p)
+    assert "Error parsing file" in res.stderr
+    # (4c) bzip2 with a damaged block: error reported
+    import bz2
+    bzf = os.path.join(tmp, "dmg.fq.bz2")
+    rawb = bytearray(bz2.compress(_fastq(r1).encode()))
+    rawb[len(rawb) // 2] ^= 0xFF
+    open(bzf, "wb").write(bytes(rawb))
+    p = os.path.join(tmp, "dmgbz")
+    res = _run(binary, sim_db, ["--single-reads", bzf], p, check=False)
     assert "Error parsing file" in res.stderr
     # (5) unknown extension
     u = os.path.join(tmp, "reads.txt")
