@@ -248,7 +248,7 @@ def test_min_length(hip, tmp_path):
 def test_long_multi_record_and_short_sequences(hip, tmp_path):
     # what the reference's tests do not reach: sequences far longer than a device piece (every window must still be seen
     # exactly as in the unsplit sequence), several records and several files per target (per-file sets are concatenated,
-    # :236-238), gzip, IUPAC letters, sequences shorter than the window, an unreadable file and a missing one
+    # :236-238), gzip, bzip2, IUPAC letters, sequences shorter than the window, an unreadable file and a missing one
     rng = np.random.default_rng(3)
     k, w = 19, 31
     d = str(tmp_path)
@@ -259,17 +259,20 @@ def test_long_multi_record_and_short_sequences(hip, tmp_path):
     big = rnd(300_000)
     shared = rnd(5000)
     files = {"g1.fasta": [("a", big[:150_000] + "NNNNRYKM" + big[150_000:])], "g2.fa.gz": [("b1", rnd(20_000)), ("b2", shared), ("b3", rnd(25))],
-             "g3.fasta": [("c1", shared), ("c2", rnd(30)), ("c3", rnd(18))], "g4.fasta": [("d", rnd(2000))]}
+             "g3.fasta.bz2": [("c1", shared), ("c2", rnd(30)), ("c3", rnd(18))], "g4.fasta": [("d", rnd(2000))]}
     for name, recs in files.items():
         text = "".join(f">{i}\n" + "\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + "\n" for i, s in recs)
         if name.endswith(".gz"):
             gzip.open(os.path.join(d, name), "wt").write(text)
+        elif name.endswith(".bz2"):
+            import bz2
+            bz2.open(os.path.join(d, name), "wt").write(text)
         else:
             open(os.path.join(d, name), "w").write(text)
     open(os.path.join(d, "bad.fasta"), "w").write(">x\nACGTACGTACGT!!ACGT\n")
     inp = os.path.join(d, "in.tsv")
     with open(inp, "w") as o:
-        o.write(f"{d}/g1.fasta\tBIG\n{d}/g2.fa.gz\tMIX\n{d}/g3.fasta\tMIX\n{d}/missing.fasta\tGONE\n{d}/bad.fasta\tBAD\n{d}/g4.fasta\n")
+        o.write(f"{d}/g1.fasta\tBIG\n{d}/g2.fa.gz\tMIX\n{d}/g3.fasta.bz2\tMIX\n{d}/missing.fasta\tGONE\n{d}/bad.fasta\tBAD\n{d}/g4.fasta\n")
     out = os.path.join(d, "x.ibf")
     p = subprocess.run([BIN_BUILD, "-i", inp, "-o", out, "-k", str(k), "-w", str(w), "-s", "3", "-p", "0.01", "-t", "3"], capture_output=True,
                        text=True)
@@ -278,7 +281,7 @@ def test_long_multi_record_and_short_sequences(hip, tmp_path):
     assert " sequences / 6 files (" in p.stderr and " - 1 invalid files skipped" in p.stderr
     from ganon_amd import ibf_file
     m = ibf_file.read_ibf_meta(out)
-    exp = {"BIG": [files["g1.fasta"]], "MIX": [files["g2.fa.gz"], files["g3.fasta"]], "BAD": [], "g4.fasta": [files["g4.fasta"]]}
+    exp = {"BIG": [files["g1.fasta"]], "MIX": [files["g2.fa.gz"], files["g3.fasta.bz2"]], "BAD": [], "g4.fasta": [files["g4.fasta"]]}
     got = dict(m.hashes_count)
     assert list(got) == ["BIG", "MIX", "BAD", "g4.fasta"]
     sets = {}
