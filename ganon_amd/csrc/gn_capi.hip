@@ -1250,6 +1250,7 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     GN_HIP(hipEventRecord(s->ev[3], s->st));
     s->n_chunks   = nc;
     s->classified = true;
+    s->pf_joint_done = false;
     return GN_OK;
 }
 
@@ -1280,7 +1281,7 @@ static int gn_finish(gn_stream* s)
         if (need <= s->match_cap)
         {
             s->n_matches = s->h_ctr[6]; // exact (the cursor `need` counts allocated space including chunk holes)
-            if (s->pf_on) // the batch's result is what the device-side filter_matches pre-pass left
+            if (s->pf_on && (!s->pf_joint || s->pf_joint_done)) // the batch's result is what the device-side filter_matches pre-pass left
             {
                 GN_HIP(hipMemcpy(s->h_pf_ctr, s->d_pf_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
                 s->n_matches = s->h_pf_ctr[2];

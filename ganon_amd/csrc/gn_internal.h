@@ -13,7 +13,8 @@
 // candidate-driven select of the generic count kernel: targets with more bins than this are scanned from a list
 #define GN_CAND_NBIG 4u
 #define GN_HIBF_MAXDEPTH 64
-#define GN_PF_MAX_JOINT 16   // filters of one hierarchy level in a joint filter_matches pre-pass
+#define GN_PF_MAX_JOINT 16   // filters of one hierarchy level in a joint filter_matches pre-pass, per device
+#define GN_PF_MAX_DEVICES 16 // devices a joint pass spans (column parts of a bin-range partitioned filter)
 #define GN_LONG_BLOCKS 128u // workgroups (and uint32 count slabs) of the long-read kernel
 #define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
                    // [6] exact match total [8..71] total-hashes shards
@@ -163,6 +164,7 @@ struct GnHibfIbfDev
 int  gn_run_postfilter(gn_stream* s);     // gn_postfilter.hip
 void gn_postfilter_release(gn_stream* s);
 void gn_build_release(gn_stream* s);       // gn_build.hip
+void gn_peer_enable(int dst, int src);     // gn_gather.hip: direct device-to-device copies between the two (best effort)
 hipError_t gn_launch_emplace(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h, const uint64_t* hashes,
                              const uint32_t* bins, uint64_t n, hipStream_t st);
 
@@ -286,6 +288,9 @@ struct gn_stream
     uint32_t*           d_pf_gmax = nullptr; // joint pass: the level's max / min per read (filled on the first stream)
     uint32_t*           d_pf_gmin = nullptr;
     bool                pf_joint  = false;   // the pass is run by gn_streams_postfilter_joint, not with the batch
+    bool                pf_joint_done = false; // ... and has run for the batch this stream holds
+    uint32_t*           d_pf_peer = nullptr; // joint pass over several devices: [this device's max | min] then one such pair per other device
+    uint64_t            pf_peer_cap = 0;     // ... in uint32 entries
     bool                pf_predrop = false;  // this batch's count kernel left surely-dropped matches unwritten (seg_min, d_pf_pre valid)
     bool                pf_merge  = false;   // ... in its merging form (filters of the level share targets)
     uint32_t*           d_pf_gid  = nullptr; // merging form: device target -> level-wide target id

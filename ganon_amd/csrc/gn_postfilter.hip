@@ -660,18 +660,19 @@ int gn_finish_batch(gn_stream* s); // gn_capi.hip: waits for the batch, re-runs 
 // filter once every stream knows the level's max/min per read: max/min per stream -> combined -> rules per stream.
 extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n_streams)
 {
-    if (!streams || n_streams == 0 || n_streams > GN_PF_MAX_JOINT)
-        return gn_fail(GN_EINVAL, "gn_streams_postfilter_joint: 1..%u streams", (unsigned)GN_PF_MAX_JOINT);
+    if (!streams || n_streams == 0 || n_streams > GN_PF_MAX_JOINT * GN_PF_MAX_DEVICES)
+        return gn_fail(GN_EINVAL, "gn_streams_postfilter_joint: 1..%u streams", (unsigned)(GN_PF_MAX_JOINT * GN_PF_MAX_DEVICES));
     gn_stream* s0 = streams[0];
+    bool       one_device = true;
     for (uint32_t i = 0; i < n_streams; ++i)
     {
         gn_stream* s = streams[i];
         if (!s || !s->pf_on || !s->pf_joint)
             return gn_fail(GN_EINVAL, "stream %u has no joint post-filter set", i);
-        if (s->device != s0->device || s->n_reads != s0->n_reads)
-            return gn_fail(GN_EINVAL, "streams of a joint pass must hold the same batch on one device");
+        if (s->n_reads != s0->n_reads)
+            return gn_fail(GN_EINVAL, "streams of a joint pass must hold the same batch");
+        one_device = one_device && s->device == s0->device;
     }
-    GN_HIP(hipSetDevice(s0->device));
     const uint32_t n      = s0->n_reads;
     const unsigned blocks = (unsigned)(((uint64_t)n + 1 + 255) / 256);
     bool           merge  = false;
@@ -681,6 +682,9 @@ extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n
     {
         // filters that share targets: one kernel replays the level's merge per read over all streams, then every stream
         // sweeps what was marked
+        if (!one_device || n_streams > GN_PF_MAX_JOINT)
+            return gn_fail(GN_EINVAL, "a merging joint pass (filters that share targets) takes up to %u streams on one device", (unsigned)GN_PF_MAX_JOINT);
+        GN_HIP(hipSetDevice(s0->device));
         GnPfMergeParams mp{};
         mp.k = n_streams;
         for (uint32_t i = 0; i < n_streams; ++i)
@@ -727,43 +731,140 @@ extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n
             int rc = gn_pf_finish(s, p);
             if (rc)
                 return rc;
+            s->pf_joint_done = true;
         }
         return GN_OK;
     }
-    GnPfLists      lists{};
-    lists.k = n_streams;
+    // Disjoint targets.  The streams may sit on several devices (the column parts of a bin-range partitioned filter,
+    // SURVEY 8e): max/min per stream -> combined per device on that device's first stream (its leader) -> every leader
+    // gets every other leader's pair of arrays, device to device (8 bytes per read and pair of devices over xGMI) ->
+    // combined again -> rules per stream with the level's values.
+    struct Group
+    {
+        gn_stream*            leader;
+        std::vector<uint32_t> idx;
+    };
+    std::vector<Group> groups;
+    const bool apart = getenv("GANON_HIP_JOINT_APART") != nullptr; // tests on one GPU: every stream is treated as a device of its own
+    for (uint32_t i = 0; i < n_streams; ++i)
+    {
+        size_t g = 0;
+        while (g < groups.size() && (apart || groups[g].leader->device != streams[i]->device))
+            ++g;
+        if (g == groups.size())
+            groups.push_back(Group{ streams[i], {} });
+        groups[g].idx.push_back(i);
+    }
+    if (groups.size() > GN_PF_MAX_DEVICES)
+        return gn_fail(GN_EINVAL, "a joint pass spans at most %u devices", (unsigned)GN_PF_MAX_DEVICES);
+    for (auto const& g : groups)
+        if (g.idx.size() > GN_PF_MAX_JOINT)
+            return gn_fail(GN_EINVAL, "a joint pass takes at most %u streams per device", (unsigned)GN_PF_MAX_JOINT);
     for (uint32_t i = 0; i < n_streams; ++i)
     {
         gn_stream* s  = streams[i];
         int        rc = gn_finish_batch(s); // (a match buffer that overflowed is grown and the batch re-run first)
         if (rc)
             return rc;
+        GN_HIP(hipSetDevice(s->device));
         GN_HIP(hipMemsetAsync(s->d_pf_ctr, 0, 4 * sizeof(unsigned long long), s->st));
         hipLaunchKernelGGL(gn_postfilter_kernel<1>, dim3(blocks), dim3(256), 0, s->st, gn_pf_params(s));
         GN_HIP(hipGetLastError());
-        lists.mx[i] = s->d_pf_max;
-        lists.mn[i] = s->d_pf_min;
     }
-    for (uint32_t i = 0; i < n_streams; ++i)
-        GN_HIP(hipStreamSynchronize(streams[i]->st));
-    if (n)
-        hipLaunchKernelGGL(gn_pf_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, s0->st, lists, n, s0->d_pf_gmax, s0->d_pf_gmin);
-    GN_HIP(hipGetLastError());
-    GN_HIP(hipStreamSynchronize(s0->st));
     for (uint32_t i = 0; i < n_streams; ++i)
     {
-        gn_stream*         s = streams[i];
-        GnPostfilterParams p = gn_pf_params(s);
-        p.gmax = s0->d_pf_gmax;
-        p.gmin = s0->d_pf_gmin;
-        hipLaunchKernelGGL(gn_postfilter_kernel<2>, dim3(blocks), dim3(256), 0, s->st, p);
-        GN_HIP(hipGetLastError());
-        int rc = gn_pf_finish(s, p);
-        if (rc)
-            return rc;
+        GN_HIP(hipSetDevice(streams[i]->device));
+        GN_HIP(hipStreamSynchronize(streams[i]->st));
     }
-    // (stream 0's gmax/gmin are read by the other streams' kernels: nothing reuses them before every stream is fetched,
-    //  and a fetch waits for its stream)
+    const size_t   ng   = groups.size();
+    const uint64_t slot = (uint64_t)n; // entries of one array
+    for (auto& g : groups)
+    {
+        gn_stream* L = g.leader;
+        GN_HIP(hipSetDevice(L->device));
+        uint32_t *lmax = L->d_pf_gmax, *lmin = L->d_pf_gmin;
+        if (ng > 1)
+        {
+            const uint64_t need = 2ull * ((uint64_t)L->max_reads + 1) * ng;
+            if (L->pf_peer_cap < need)
+            {
+                if (L->d_pf_peer)
+                    GN_HIP(hipFree(L->d_pf_peer));
+                L->d_pf_peer   = nullptr;
+                L->pf_peer_cap = 0;
+                GN_HIP(hipMalloc(reinterpret_cast<void**>(&L->d_pf_peer), need * 4));
+                L->pf_peer_cap = need;
+            }
+            lmax = L->d_pf_peer;
+            lmin = L->d_pf_peer + slot;
+        }
+        GnPfLists lists{};
+        lists.k = (uint32_t)g.idx.size();
+        for (size_t j = 0; j < g.idx.size(); ++j)
+        {
+            lists.mx[j] = streams[g.idx[j]]->d_pf_max;
+            lists.mn[j] = streams[g.idx[j]]->d_pf_min;
+        }
+        if (n)
+            hipLaunchKernelGGL(gn_pf_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, L->st, lists, n, lmax, lmin);
+        GN_HIP(hipGetLastError());
+    }
+    for (auto& g : groups)
+    {
+        GN_HIP(hipSetDevice(g.leader->device));
+        GN_HIP(hipStreamSynchronize(g.leader->st));
+    }
+    if (ng > 1)
+    {
+        for (size_t a = 0; a < ng; ++a)
+        {
+            gn_stream* L = groups[a].leader;
+            GN_HIP(hipSetDevice(L->device));
+            GnPfLists lists{};
+            lists.k     = (uint32_t)ng;
+            lists.mx[0] = L->d_pf_peer;
+            lists.mn[0] = L->d_pf_peer + slot;
+            size_t k    = 1;
+            for (size_t b = 0; b < ng; ++b)
+            {
+                if (b == a)
+                    continue;
+                gn_stream* R   = groups[b].leader;
+                uint32_t*  dst = L->d_pf_peer + 2 * slot * k;
+                gn_peer_enable(L->device, R->device);
+                if (n) // [max | min] of the other device in one copy
+                    GN_HIP(hipMemcpyPeerAsync(dst, L->device, R->d_pf_peer, R->device, 2 * slot * 4, L->st));
+                lists.mx[k] = dst;
+                lists.mn[k] = dst + slot;
+                ++k;
+            }
+            if (n)
+                hipLaunchKernelGGL(gn_pf_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, L->st, lists, n, L->d_pf_gmax, L->d_pf_gmin);
+            GN_HIP(hipGetLastError());
+        }
+        for (auto& g : groups)
+        {
+            GN_HIP(hipSetDevice(g.leader->device));
+            GN_HIP(hipStreamSynchronize(g.leader->st));
+        }
+    }
+    for (auto& g : groups)
+        for (uint32_t i : g.idx)
+        {
+            gn_stream* s = streams[i];
+            GN_HIP(hipSetDevice(s->device));
+            GnPostfilterParams p = gn_pf_params(s);
+            p.gmax = g.leader->d_pf_gmax;
+            p.gmin = g.leader->d_pf_gmin;
+            hipLaunchKernelGGL(gn_postfilter_kernel<2>, dim3(blocks), dim3(256), 0, s->st, p);
+            GN_HIP(hipGetLastError());
+            int rc = gn_pf_finish(s, p);
+            if (rc)
+                return rc;
+            s->pf_joint_done = true;
+        }
+    // (a leader's gmax/gmin are read by the other streams' kernels on its device: nothing reuses them before every stream
+    //  is fetched, and a fetch waits for its stream)
     return GN_OK;
 }
 
@@ -832,7 +933,7 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
 void gn_postfilter_release(gn_stream* s)
 {
     void* ptrs[] = { s->d_pf_keep, s->d_pf_max, s->d_pf_min, s->d_pf_gmax, s->d_pf_gmin, s->d_pf_ctr, s->d_pf_fpr, s->d_pf_scan, s->d_pf_gid,
-                     s->d_pf_segmin, s->d_pf_pre, s->d_pf_rmax };
+                     s->d_pf_segmin, s->d_pf_pre, s->d_pf_rmax, s->d_pf_peer };
     for (void* q : ptrs)
         if (q)
             hipFree(q);
@@ -844,6 +945,8 @@ void gn_postfilter_release(gn_stream* s)
     s->pf_segmin_cap = 0;
     s->d_pf_pre  = nullptr;
     s->d_pf_rmax = nullptr;
+    s->d_pf_peer = nullptr;
+    s->pf_peer_cap = 0;
     s->pf_predrop = false;
     s->d_pf_fpr  = nullptr;
     s->d_pf_scan = nullptr;

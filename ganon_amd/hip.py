@@ -21,7 +21,8 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_stream_upload_reads", "gn_stream_minimisers", "gn_stream_classify", "gn_submit_batch", "gn_stream_sync", "gn_fetch_batch", "gn_stream_set_postfilter",
                "gn_fetch_postfilter", "gn_streams_postfilter_joint", "gn_stream_set_long_reads", "gn_stream_device_matches",
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
-               "gn_stream_timings"]
+               "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
+               "gn_gather_destroy", "gn_device_memory"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -97,6 +98,12 @@ def load_library():
     L.gn_filter_emplace_split.argtypes = [vp, vp, u64, u32, u64]
     L.gn_stream_dense_counts.argtypes = [vp, u32, u32, vp]
     L.gn_stream_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.gn_gather_create.argtypes = [i32, u32, C.POINTER(vp), vp, C.POINTER(vp)]
+    L.gn_gather_run.argtypes = [vp, C.POINTER(vp), u32]
+    L.gn_gather_fetch.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+    L.gn_gather_device_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.gn_gather_destroy.argtypes = [vp]
+    L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
     for name in ABI_SYMBOLS:
         if name != "gn_last_error":
             getattr(L, name).restype = i32
@@ -149,6 +156,58 @@ def fill_random_words(seed: int, rows: np.ndarray, n_words: int, and_words: int 
     if bins & 63:
         v[:, -1] &= np.uint64((1 << (bins & 63)) - 1)
     return v
+
+
+def device_memory(device: int = 0) -> Tuple[int, int]:
+    """(free, total) bytes of a device (gn_device_memory)"""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    _check(load_library().gn_device_memory(device, C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
+
+class HipGather:
+    """gn_gather: the column parts of a bin-range partitioned flat IBF put back together on the batch's owner device."""
+
+    def __init__(self, device: int, target_maps: Sequence[Optional[np.ndarray]]):
+        self._maps = [None if m is None else np.ascontiguousarray(m, dtype=np.uint32) for m in target_maps]
+        n = len(self._maps)
+        ptrs = (C.c_void_p * n)(*[None if m is None else m.ctypes.data for m in self._maps])
+        sizes = np.array([0 if m is None else len(m) for m in self._maps], dtype=np.uint32)
+        self._h = C.c_void_p()
+        self.n_reads = 0
+        _check(load_library().gn_gather_create(device, n, ptrs, _p(sizes), C.byref(self._h)))
+
+    def run(self, streams: Sequence["HipStream"]) -> None:
+        arr = (C.c_void_p * len(streams))(*[st._h for st in streams])
+        self.n_reads = streams[0].n_reads
+        _check(load_library().gn_gather_run(self._h, arr, len(streams)))
+
+    def fetch(self):
+        """-> (match_off u64[n+1], matches MATCH_DTYPE[m]) grouped by read, ascending target"""
+        L = load_library()
+        mo = np.zeros(self.n_reads + 1, dtype=np.uint64)
+        need = C.c_uint64(0)
+        _check(L.gn_gather_fetch(self._h, _p(mo), None, 0, C.byref(need)))
+        m = np.zeros(max(int(need.value), 1), dtype=MATCH_DTYPE)
+        _check(L.gn_gather_fetch(self._h, None, _p(m), len(m), C.byref(need)))
+        return mo, m[: int(need.value)]
+
+    def peer_bytes(self) -> int:
+        """bytes the last run() copied between devices"""
+        b = C.c_uint64(0)
+        _check(load_library().gn_gather_device_matches(self._h, None, None, None, C.byref(b)))
+        return int(b.value)
+
+    def destroy(self) -> None:
+        if self._h:
+            load_library().gn_gather_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 class HipFilter:

@@ -99,6 +99,11 @@ public:
     // Optional.  Reads with more than 65535 minimisers: classified like every other read (the reference's -DLONGREADS build)
     // instead of coming back with status 2.  Returns whether the backend can do that.
     virtual bool set_long_reads(bool /*on*/) { return false; }
+    // Optional.  After a level's filters are loaded: does this worker take batches on this level?  (A level with a filter
+    // that is partitioned over the devices keeps all of them busy with every batch: only a few workers run then.)
+    virtual bool active() const { return true; }
+    // Optional.  Where the level's filters were put (replicated / partitioned, which columns on which device), for --verbose.
+    virtual std::string placement() const { return std::string(); }
 };
 
 // devices: indices, or empty = every visible device ("all").  backend_hip.cpp (or the test checker).

@@ -9,6 +9,7 @@
 #include <iostream>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <vector>
 #include <unordered_map>
 #include <thread>
@@ -119,151 +120,341 @@ private:
     std::atomic<bool>                     stop_{ false };
 };
 
-class HipBackend final : public Backend
+// ---- where the filters of a hierarchy level live -------------------------------------------------------------------
+// One DeviceSet per run, shared by all workers.  It receives every filter of the level once (FilterSink) and decides per
+// filter, from the filter's size and what the devices have left:
+//   * REPLICATED: a copy on every GPU in use (read-sharded classification, SURVEY 8e first bullet) -- entries of --device
+//     that name the same GPU share its copy;
+//   * PARTITIONED (flat IBF only): the reference loads a filter of any size (GanonClassify.cpp:949-986,1007-1039); one that
+//     does not fit beside what a device already holds is cut by technical-bin range at target boundaries and its column
+//     parts are placed on different devices (SURVEY 8e second bullet, BASELINE config 5).  Every part is at most kPartWords
+//     wide, so a device may hold several.
+// A "device" for placement is a GPU with the memory it has free at the start of the run (minus a reserve for the batch
+// buffers), or -- with $GANON_DEVICE_BUDGET=<bytes, K/M/G/T suffix allowed> -- every --device ENTRY with that budget, so
+// that `--device 0,0,0` with a small budget exercises the partitioned path on one GPU (tests).
+struct DevPart
+{
+    gn_filter*            f      = nullptr;
+    int                   device = 0;
+    int                   vdev   = 0;
+    uint64_t              word_lo = 0, words = 0;
+    std::vector<uint32_t> to_target; // device target id -> index into FilterMeta::targets (empty: the same)
+};
+
+struct SharedFilter
+{
+    bool                              is_hibf = false;
+    bool                              spread  = false; // partitioned over the placement devices
+    std::vector<uint64_t>             row_words;       // bin_words of every IBF as stored in the file
+    // replicated: copies[u] = the filter's parts on unique device u; partitioned: copies[0] = all parts, in column order
+    std::vector<std::vector<DevPart>> copies;
+};
+
+uint64_t parse_bytes(const char* v)
+{
+    char*  end = nullptr;
+    double x   = std::strtod(v, &end);
+    if (end)
+        switch (*end)
+        {
+            case 'k': case 'K': x *= 1024.0; break;
+            case 'm': case 'M': x *= 1024.0 * 1024.0; break;
+            case 'g': case 'G': x *= 1024.0 * 1024.0 * 1024.0; break;
+            case 't': case 'T': x *= 1024.0 * 1024.0 * 1024.0 * 1024.0; break;
+            default: break;
+        }
+    return x > 0 ? (uint64_t)x : 0;
+}
+
+class DeviceSet
 {
 public:
-    // primary != nullptr: a further worker on the same device.  It classifies against the primary's filters (one copy of the
-    // bits in that GPU's HBM, read-only while batches run) with streams of its own.
-    explicit HipBackend(int device, HipBackend* primary = nullptr) : device_(device), primary_(primary) {}
-    ~HipBackend() override
+    explicit DeviceSet(const std::vector<int>& entries) : entries_(entries)
     {
-        PinnedPool::get().settle();
-        if (std::getenv("GANON_HOST_TIMING") && n_create_)
-            std::cerr << "[backend timing] device " << device_ << ": stream (re)creation " << sec_create_ << " s (" << n_create_
-                      << "x), submit calls " << sec_submit_ << " s, waiting for + fetching the results " << sec_fetch_ << " s" << std::endl;
-        clear_filters();
+        for (int d : entries)
+            if (std::find(uniq_.begin(), uniq_.end(), d) == uniq_.end())
+                uniq_.push_back(d);
+        const char* e = std::getenv("GANON_DEVICE_BUDGET");
+        if (e && *e)
+        {
+            const uint64_t b = parse_bytes(e);
+            for (int d : entries)
+                vdev_.push_back(VDev{ d, b, 0 });
+            virtual_ = true;
+        }
+        else
+            for (int d : uniq_)
+            {
+                uint64_t fr = 0, tot = 0;
+                if (gn_device_memory(d, &fr, &tot) != GN_OK)
+                    fr = 0;
+                // what the batch buffers of the workers need stays out of the filters' budget
+                const uint64_t reserve = std::max<uint64_t>(fr / 8, std::min<uint64_t>(fr / 2, 16ull << 30));
+                vdev_.push_back(VDev{ d, fr > reserve ? fr - reserve : 0, 0 });
+            }
+    }
+    ~DeviceSet()
+    {
+        clear();
         for (auto& s : stage_)
             if (s.ptr)
                 gn_pinned_free(s.ptr);
     }
 
-    // ---- FilterSink: the filter is created empty on the device, its rows arrive in chunks ----------------------
-    bool begin(const FilterMeta& f, std::string& err) override
+    const std::vector<int>& entries() const { return entries_; }
+    const std::vector<SharedFilter>& filters() const { return filters_; }
+    bool any_spread() const
     {
-        if (primary_)
-            return true; // (the primary, earlier in the sink's list, receives the filter)
-        Logical lf;
-        lf.row_words.clear();
+        for (auto const& f : filters_)
+            if (f.spread)
+                return true;
+        return false;
+    }
+    size_t unique_index(int device) const { return (size_t)(std::find(uniq_.begin(), uniq_.end(), device) - uniq_.begin()); }
+
+    void clear()
+    {
+        for (auto& sf : filters_)
+            for (auto& copy : sf.copies)
+                for (auto& part : copy)
+                    if (part.f)
+                        gn_filter_free(part.f);
+        filters_.clear();
+        for (auto& v : vdev_)
+            v.used = 0;
+        log_.clear();
+    }
+
+    std::string placement() const { return log_; }
+
+    bool begin(const FilterMeta& f, std::string& err)
+    {
+        SharedFilter sf;
         for (auto const& m : f.shapes)
-            lf.row_words.push_back(m.bin_words);
-        if (!f.is_hibf)
+            sf.row_words.push_back(m.bin_words);
+        uint64_t bytes = 0;
+        for (auto const& m : f.shapes)
+            bytes += m.payload_bytes();
+        bool fits = true;
+        for (auto const& v : vdev_)
+            fits = fits && v.used + bytes <= v.budget;
+        std::ostringstream note;
+        note << "filter " << filters_.size() << " (" << (f.is_hibf ? "HIBF, " : "IBF, ") << bytes / double(1ull << 30) << " GiB): ";
+        if (f.is_hibf)
+        {
+            if (!fits)
+            {
+                err = "the HIBF (" + std::to_string(bytes >> 20) + " MiB) does not fit into the memory of one device beside the filters "
+                      "loaded before it; an HIBF cannot be partitioned by bin range (its levels are data dependent)";
+                return false;
+            }
+            sf.is_hibf = true;
+            for (int d : uniq_)
+            {
+                std::vector<gn_ibf_desc>    descs;
+                std::vector<const int64_t*> nx, bu;
+                for (size_t i = 0; i < f.shapes.size(); ++i)
+                {
+                    auto& m = f.shapes[i];
+                    descs.push_back(gn_ibf_desc{ nullptr, m.bin_size, m.bin_words, m.bins, (uint32_t)m.hash_funs, (uint32_t)m.hash_shift });
+                    nx.push_back(f.next_ibf_id[i].data());
+                    bu.push_back(f.bin_to_user[i].data());
+                }
+                DevPart part;
+                part.device = d;
+                if (gn_filter_upload_hibf(d, (uint32_t)descs.size(), descs.data(), nx.data(), bu.data(), f.n_user_bins, &part.f) != GN_OK)
+                {
+                    err = gn_last_error();
+                    free_parts(sf);
+                    return false;
+                }
+                // user bin -> target index (select_matches(THIBF) reads counts[bins[0]], GanonClassify.cpp:556-558)
+                part.to_target.assign(f.n_user_bins, 0xFFFFFFFFu);
+                for (size_t t = 0; t < f.targets.size(); ++t)
+                    part.to_target[f.target_bins[t][0]] = (uint32_t)t;
+                sf.copies.push_back({});
+                sf.copies.back().push_back(std::move(part));
+            }
+            for (auto& v : vdev_)
+                v.used += bytes;
+            note << "replicated on " << uniq_.size() << " device(s)";
+        }
+        else
         {
             const IbfShape&       m = f.shapes.at(0);
             std::vector<uint32_t> bin2target(m.bins, 0xFFFFFFFFu);
             for (size_t t = 0; t < f.targets.size(); ++t)
                 for (uint64_t b : f.target_bins[t])
                     bin2target[b] = (uint32_t)t;
-            // column parts: [word_lo, word_hi) with cuts moved left to the nearest boundary between two targets
-            std::vector<uint64_t> cuts{ 0 };
-            while (m.bin_words - cuts.back() > kPartWords)
-            {
-                // the nearest legal cut at or below the full part width; an even number of words is preferred (16-byte lanes)
-                auto legal = [&](uint64_t c) {
-                    const uint32_t left = bin2target[c * 64 - 1], right = bin2target[c * 64];
-                    return left != right || left == 0xFFFFFFFFu;
-                };
-                uint64_t c = cuts.back() + kPartWords, odd = 0;
-                while (c > cuts.back() + 1 && !(legal(c) && ((c - cuts.back()) & 1u) == 0))
+            // a cut between words c-1 and c is legal where no target has bins on both sides
+            auto legal = [&](uint64_t c) {
+                const uint32_t left = bin2target[c * 64 - 1], right = bin2target[c * 64];
+                return left != right || left == 0xFFFFFFFFu;
+            };
+            // the largest legal cut in (from, limit]; an even number of words is preferred (16-byte lanes); 0 = none
+            auto next_cut = [&](uint64_t from, uint64_t limit) -> uint64_t {
+                if (limit >= m.bin_words)
+                    return m.bin_words;
+                uint64_t c = limit, odd = 0;
+                while (c > from + 1 && !(legal(c) && ((c - from) & 1u) == 0))
                 {
                     if (!odd && legal(c))
                         odd = c;
                     --c;
                 }
-                if (!(legal(c) && ((c - cuts.back()) & 1u) == 0) && odd)
+                if (!(legal(c) && ((c - from) & 1u) == 0) && odd)
                     c = odd;
-                if (!legal(c))
+                return c > from && legal(c) ? c : 0;
+            };
+            // [word_lo, word_hi) per placement device
+            struct Range
+            {
+                size_t   vdev;
+                uint64_t lo, hi;
+            };
+            std::vector<Range> ranges;
+            if (fits)
+                ranges.push_back(Range{ 0, 0, m.bin_words }); // (replicated: the same cuts on every device)
+            else
+            {
+                sf.spread = true;
+                const uint64_t row_group_bytes = m.bin_size * 8; // one 64-bin word of every row
+                uint64_t       at = 0;
+                for (size_t v = 0; v < vdev_.size() && at < m.bin_words; ++v)
                 {
-                    err = "a target owns more than " + std::to_string(kPartWords * 64) + " consecutive technical bins: the filter cannot be cut into column parts";
+                    const uint64_t room  = vdev_[v].budget > vdev_[v].used ? (vdev_[v].budget - vdev_[v].used) / row_group_bytes : 0;
+                    const uint64_t left  = m.bin_words - at, devs = vdev_.size() - v;
+                    const uint64_t share = std::min<uint64_t>(room, (left + devs - 1) / devs);
+                    if (share == 0)
+                        continue;
+                    const uint64_t c = next_cut(at, at + share);
+                    if (c == 0)
+                        continue; // (no boundary between targets inside this device's share: the next one may have more room)
+                    ranges.push_back(Range{ v, at, c });
+                    at = c;
+                }
+                if (at < m.bin_words)
+                {
+                    err = "the filter (" + std::to_string(bytes >> 20) + " MiB) does not fit into the " + std::to_string(vdev_.size())
+                          + " device(s) given (" + std::to_string(budget_left() >> 20) + " MiB left for filters in total" +
+                          (virtual_ ? ", $GANON_DEVICE_BUDGET" : "") + ")";
                     return false;
                 }
-                cuts.push_back(c);
             }
-            cuts.push_back(m.bin_words);
-            for (size_t g = 0; g + 1 < cuts.size(); ++g)
-            {
-                Part part;
-                part.word_lo = cuts[g];
-                part.words   = cuts[g + 1] - cuts[g];
-                const uint64_t bin_lo = part.word_lo * 64, bins = std::min<uint64_t>(m.bins, cuts[g + 1] * 64) - bin_lo;
-                std::vector<uint32_t> local(bins, 0xFFFFFFFFu);
-                if (cuts.size() == 2)
-                    local = bin2target; // the whole filter: target ids are the caller's
-                else
+            auto make_parts = [&](const Range& rg, int device, int vdev, std::vector<DevPart>& out) -> bool {
+                std::vector<uint64_t> cuts{ rg.lo };
+                while (rg.hi - cuts.back() > kPartWords)
                 {
-                    // local target ids in order of appearance (targets ascend with bins, filter_io.cpp)
-                    for (uint64_t b = 0; b < bins; ++b)
+                    const uint64_t c = next_cut(cuts.back(), cuts.back() + kPartWords);
+                    if (c == 0)
                     {
-                        const uint32_t t = bin2target[bin_lo + b];
-                        if (t == 0xFFFFFFFFu)
-                            continue;
-                        if (part.to_target.empty() || part.to_target.back() != t)
-                        {
-                            // (a target seen before can only come back if its bins are not contiguous)
-                            auto it = std::find(part.to_target.begin(), part.to_target.end(), t);
-                            if (it != part.to_target.end())
-                            {
-                                local[b] = (uint32_t)(it - part.to_target.begin());
-                                continue;
-                            }
-                            part.to_target.push_back(t);
-                        }
-                        local[b] = (uint32_t)part.to_target.size() - 1;
+                        err = "a target owns more than " + std::to_string(kPartWords * 64) + " consecutive technical bins: the filter cannot be cut into column parts";
+                        return false;
                     }
-                    for (uint32_t t : part.to_target) // every bin of an owned target must be inside the part
-                        for (uint64_t b : f.target_bins[t])
-                            if (b < bin_lo || b >= bin_lo + bins)
-                            {
-                                err = "target '" + f.targets[t] + "' has technical bins on both sides of a column cut (its bins are not "
-                                      "contiguous): this filter is too wide for one row group";
-                                for (auto& q : lf.parts)
-                                    gn_filter_free(q.f);
-                                return false;
-                            }
+                    cuts.push_back(c);
                 }
-                gn_ibf_desc d{ nullptr, m.bin_size, part.words, bins, (uint32_t)m.hash_funs, (uint32_t)m.hash_shift };
-                const uint32_t nt = cuts.size() == 2 ? (uint32_t)f.targets.size() : (uint32_t)std::max<size_t>(part.to_target.size(), 1);
-                if (gn_filter_upload_ibf(device_, &d, local.data(), nt, &part.f) != GN_OK)
+                cuts.push_back(rg.hi);
+                const bool whole = rg.lo == 0 && rg.hi == m.bin_words && cuts.size() == 2;
+                for (size_t g = 0; g + 1 < cuts.size(); ++g)
                 {
-                    err = gn_last_error();
-                    for (auto& q : lf.parts)
-                        gn_filter_free(q.f);
+                    DevPart part;
+                    part.device  = device;
+                    part.vdev    = vdev;
+                    part.word_lo = cuts[g];
+                    part.words   = cuts[g + 1] - cuts[g];
+                    const uint64_t bin_lo = part.word_lo * 64, bins = std::min<uint64_t>(m.bins, cuts[g + 1] * 64) - bin_lo;
+                    std::vector<uint32_t> local(bins, 0xFFFFFFFFu);
+                    if (whole)
+                        local = bin2target; // the whole filter: target ids are the caller's
+                    else
+                    {
+                        // local target ids in order of appearance (targets ascend with bins, filter_io.cpp)
+                        for (uint64_t b = 0; b < bins; ++b)
+                        {
+                            const uint32_t t = bin2target[bin_lo + b];
+                            if (t == 0xFFFFFFFFu)
+                                continue;
+                            if (part.to_target.empty() || part.to_target.back() != t)
+                            {
+                                // (a target seen before can only come back if its bins are not contiguous)
+                                auto it = std::find(part.to_target.begin(), part.to_target.end(), t);
+                                if (it != part.to_target.end())
+                                {
+                                    local[b] = (uint32_t)(it - part.to_target.begin());
+                                    continue;
+                                }
+                                part.to_target.push_back(t);
+                            }
+                            local[b] = (uint32_t)part.to_target.size() - 1;
+                        }
+                        for (uint32_t t : part.to_target) // every bin of an owned target must be inside the part
+                            for (uint64_t b : f.target_bins[t])
+                                if (b < bin_lo || b >= bin_lo + bins)
+                                {
+                                    err = "target '" + f.targets[t] + "' has technical bins on both sides of a column cut (its bins are not "
+                                          "contiguous): this filter is too wide for one row group";
+                                    return false;
+                                }
+                    }
+                    gn_ibf_desc d{ nullptr, m.bin_size, part.words, bins, (uint32_t)m.hash_funs, (uint32_t)m.hash_shift };
+                    const uint32_t nt = whole ? (uint32_t)f.targets.size() : (uint32_t)std::max<size_t>(part.to_target.size(), 1);
+                    if (gn_filter_upload_ibf(device, &d, local.data(), nt, &part.f) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
+                    out.push_back(std::move(part));
+                }
+                return true;
+            };
+            if (!sf.spread)
+            {
+                for (int d : uniq_)
+                {
+                    sf.copies.push_back({});
+                    if (!make_parts(ranges[0], d, -1, sf.copies.back()))
+                    {
+                        free_parts(sf);
+                        return false;
+                    }
+                }
+                for (auto& v : vdev_)
+                    v.used += bytes;
+                note << "replicated on " << uniq_.size() << " device(s)";
+                if (sf.copies[0].size() > 1)
+                    note << ", " << sf.copies[0].size() << " column parts each";
+            }
+            else
+            {
+                sf.copies.push_back({});
+                note << "partitioned by bin range:";
+                for (auto const& rg : ranges)
+                {
+                    const size_t before = sf.copies[0].size();
+                    if (!make_parts(rg, vdev_[rg.vdev].device, (int)rg.vdev, sf.copies[0]))
+                    {
+                        free_parts(sf);
+                        return false;
+                    }
+                    vdev_[rg.vdev].used += (rg.hi - rg.lo) * m.bin_size * 8;
+                    note << " [words " << rg.lo << "-" << rg.hi << " -> device " << vdev_[rg.vdev].device << ", "
+                         << sf.copies[0].size() - before << " part(s)]";
+                }
+                if (sf.copies[0].size() > 64) // GN_GATHER_MAX_PARTS
+                {
+                    err = "the filter would be cut into " + std::to_string(sf.copies[0].size()) + " column parts (at most 64)";
+                    free_parts(sf);
                     return false;
                 }
-                lf.parts.push_back(std::move(part));
             }
         }
-        else
-        {
-            std::vector<gn_ibf_desc>    descs;
-            std::vector<const int64_t*> nx, bu;
-            for (size_t i = 0; i < f.shapes.size(); ++i)
-            {
-                auto& m = f.shapes[i];
-                descs.push_back(gn_ibf_desc{ nullptr, m.bin_size, m.bin_words, m.bins, (uint32_t)m.hash_funs, (uint32_t)m.hash_shift });
-                nx.push_back(f.next_ibf_id[i].data());
-                bu.push_back(f.bin_to_user[i].data());
-            }
-            Part part;
-            if (gn_filter_upload_hibf(device_, (uint32_t)descs.size(), descs.data(), nx.data(), bu.data(), f.n_user_bins, &part.f) != GN_OK)
-            {
-                err = gn_last_error();
-                return false;
-            }
-            // user bin -> target index (select_matches(THIBF) reads counts[bins[0]], GanonClassify.cpp:556-558)
-            part.to_target.assign(f.n_user_bins, 0xFFFFFFFFu);
-            for (size_t t = 0; t < f.targets.size(); ++t)
-                part.to_target[f.target_bins[t][0]] = (uint32_t)t;
-            lf.is_hibf = true;
-            lf.parts.push_back(std::move(part));
-        }
-        filters_.push_back(std::move(lf));
+        log_ += note.str() + "\n";
+        filters_.push_back(std::move(sf));
         return true;
     }
 
-    uint64_t* staging(int which, size_t bytes) override
+    uint64_t* staging(int which, size_t bytes)
     {
-        if (primary_)
-            return primary_->staging(which, bytes);
         Stage& s = stage_[which & 1];
         if (s.bytes < bytes)
         {
@@ -280,32 +471,19 @@ public:
         return static_cast<uint64_t*>(s.ptr);
     }
 
-    bool rows(uint32_t ibf, uint64_t row_begin, uint64_t n_rows, const uint64_t* src, std::string& err) override
+    // asynchronous on every device filter's load stream when src is pinned (gn_filter_write_rows); src holds whole rows,
+    // every column part -- on whichever device -- takes its words of them
+    bool rows(uint32_t ibf, uint64_t row_begin, uint64_t n_rows, const uint64_t* src, std::string& err)
     {
-        // asynchronous on the filter's load stream when src is pinned (gn_filter_write_rows); src holds whole rows, every
-        // column part takes its words of them
-        if (primary_)
-            return true;
-        Logical& lf = filters_.back();
-        if (ibf >= lf.row_words.size())
+        SharedFilter& sf = filters_.back();
+        if (ibf >= sf.row_words.size())
         {
             err = "rows for an IBF the filter does not have";
             return false;
         }
-        for (auto& part : lf.parts)
-            if (gn_filter_write_rows(part.f, lf.is_hibf ? ibf : 0, row_begin, n_rows, src, lf.row_words[ibf], part.word_lo) != GN_OK)
-            {
-                err = gn_last_error();
-                return false;
-            }
-        return true;
-    }
-
-    bool drain(std::string& err) override
-    {
-        if (!primary_ && !filters_.empty())
-            for (auto& part : filters_.back().parts)
-                if (gn_filter_write_sync(part.f) != GN_OK)
+        for (auto& copy : sf.copies)
+            for (auto& part : copy)
+                if (gn_filter_write_rows(part.f, sf.is_hibf ? ibf : 0, row_begin, n_rows, src, sf.row_words[ibf], part.word_lo) != GN_OK)
                 {
                     err = gn_last_error();
                     return false;
@@ -313,47 +491,118 @@ public:
         return true;
     }
 
-    bool end(std::string& err) override
+    bool drain(std::string& err)
     {
-        if (primary_)
-        {
-            // the primary has just finished this filter: take its device filters, without streams
-            Logical lf = primary_->filters_.at(filters_.size());
-            for (auto& part : lf.parts)
-            {
-                part.s             = nullptr;
-                part.stream_reads  = 0;
-                part.stream_bases  = 0;
-                part.pf_generation = 0;
-            }
-            filters_.push_back(std::move(lf));
-            return true;
-        }
-        for (auto& part : filters_.back().parts)
-            if (gn_filter_finalize(part.f) != GN_OK)
-            {
-                err = gn_last_error();
-                return false;
-            }
+        if (!filters_.empty())
+            for (auto& copy : filters_.back().copies)
+                for (auto& part : copy)
+                    if (gn_filter_write_sync(part.f) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
         return true;
     }
 
+    bool end(std::string& err)
+    {
+        for (auto& copy : filters_.back().copies)
+            for (auto& part : copy)
+                if (gn_filter_finalize(part.f) != GN_OK)
+                {
+                    err = gn_last_error();
+                    return false;
+                }
+        return true;
+    }
+
+private:
+    struct VDev
+    {
+        int      device;
+        uint64_t budget, used;
+    };
+    struct Stage
+    {
+        void*  ptr   = nullptr;
+        size_t bytes = 0;
+    };
+    uint64_t budget_left() const
+    {
+        uint64_t x = 0;
+        for (auto const& v : vdev_)
+            x += v.budget > v.used ? v.budget - v.used : 0;
+        return x;
+    }
+    static void free_parts(SharedFilter& sf)
+    {
+        for (auto& copy : sf.copies)
+            for (auto& part : copy)
+                if (part.f)
+                    gn_filter_free(part.f);
+        sf.copies.clear();
+    }
+
+    std::vector<int>          entries_, uniq_;
+    std::vector<VDev>         vdev_;
+    bool                      virtual_ = false;
+    std::vector<SharedFilter> filters_;
+    Stage                     stage_[2];
+    std::string               log_;
+};
+
+// One worker: a host thread's streams on the filters of the DeviceSet.  Replicated filters are classified on the worker's
+// home device; the parts of a partitioned filter on whichever devices hold them, all against the same batch, and put back
+// together on the home device (gn_gather).
+class HipBackend final : public Backend
+{
+public:
+    HipBackend(std::shared_ptr<DeviceSet> set, size_t index) : set_(std::move(set)), index_(index), device_(set_->entries()[index]) {}
+    ~HipBackend() override
+    {
+        PinnedPool::get().settle();
+        if (std::getenv("GANON_HOST_TIMING") && n_create_)
+            std::cerr << "[backend timing] device " << device_ << ": stream (re)creation " << sec_create_ << " s (" << n_create_
+                      << "x), submit calls " << sec_submit_ << " s, waiting for + fetching the results " << sec_fetch_ << " s"
+                      << (gathered_bytes_ ? ", moved between devices " + std::to_string(gathered_bytes_ >> 20) + " MiB" : std::string()) << std::endl;
+        clear_filters();
+    }
+
+    // ---- FilterSink: the first worker hands the filter to the DeviceSet; the others find it there ---------------
+    bool begin(const FilterMeta& f, std::string& err) override { return index_ ? true : set_->begin(f, err); }
+    uint64_t* staging(int which, size_t bytes) override { return set_->staging(which, bytes); }
+    bool rows(uint32_t ibf, uint64_t row_begin, uint64_t n_rows, const uint64_t* src, std::string& err) override
+    {
+        return index_ ? true : set_->rows(ibf, row_begin, n_rows, src, err);
+    }
+    bool drain(std::string& err) override { return index_ ? true : set_->drain(err); }
+    bool end(std::string& err) override { return index_ ? true : set_->end(err); }
+
     void clear_filters() override
     {
-        for (auto& lf : filters_)
-            for (auto& part : lf.parts)
-            {
-                if (part.s)
-                    gn_stream_destroy(part.s);
-                if (!primary_) // (a further worker's streams do not need the filter to go away: gn_stream_destroy never touches it)
-                    gn_filter_free(part.f);
-            }
-        filters_.clear();
+        drop_streams();
+        if (index_ == 0)
+            set_->clear();
     }
+
+    // A level with a partitioned filter keeps every device busy with every batch: a few workers (upload and fetch of one
+    // batch behind the kernels of another) are all it can use.
+    bool active() const override
+    {
+        if (!set_->any_spread())
+            return true;
+        const char*  e = std::getenv("GANON_PARTITION_WORKERS");
+        const size_t k = e ? (size_t)std::max(1L, std::atol(e)) : 2;
+        return index_ < k;
+    }
+
+    std::string placement() const override { return index_ ? std::string() : set_->placement(); }
 
     bool classify(const ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
                   std::string& err) override
     {
+        if (!resolve(err))
+            return false;
         const uint32_t n = (uint32_t)b.size();
         auto           t = std::chrono::steady_clock::now();
         auto           lap = [&](double& acc) {
@@ -380,7 +629,7 @@ public:
                     part.s            = nullptr;
                     const uint32_t cr = std::max<uint32_t>(n, 1u << 16);
                     const uint64_t cb = std::max<uint64_t>(nb, 1ull << 24);
-                    if (gn_stream_create(part.f, cr, cb, 0, &part.s) != GN_OK)
+                    if (gn_stream_create(part.dp->f, cr, cb, 0, &part.s) != GN_OK)
                     {
                         err = gn_last_error();
                         return false;
@@ -428,25 +677,79 @@ public:
                 return false;
             }
         }
+        bool have_reads = false; // n_hashes / status are the same on every stream: taken once
         for (size_t i = 0; i < filters_.size(); ++i)
         {
             Logical&      lf = filters_[i];
             FilterResult& fr = out.per_filter[i];
             fr.match_off.assign((size_t)n + 1, 0);
             fr.matches.clear();
+            fr.fpr_ok.clear();
             if (lf.parts.size() == 1)
             {
-                fr.fpr_ok.clear();
-                if (!fetch_part(lf.parts[0], n, out, fr.match_off, fr.matches, err, pf_active_ ? &fr.fpr_ok : nullptr))
+                if (!fetch_part(lf.parts[0], n, out, !have_reads, fr.match_off, fr.matches, err, pf_active_ ? &fr.fpr_ok : nullptr))
                     return false;
-                if (pf_active_)
+                have_reads = true;
+            }
+            else
+            {
+                // several column parts, on this device or on others: the matches of a read are its parts' matches behind each
+                // other (targets ascend with the bins, so the concatenation is in target order); put together on the device
+                if (!lf.gather)
+                {
+                    std::vector<const uint32_t*> maps;
+                    std::vector<uint32_t>        sizes;
+                    for (auto& part : lf.parts)
+                    {
+                        maps.push_back(part.dp->to_target.empty() ? nullptr : part.dp->to_target.data());
+                        sizes.push_back((uint32_t)part.dp->to_target.size());
+                    }
+                    if (gn_gather_create(device_, (uint32_t)lf.parts.size(), maps.data(), sizes.data(), &lf.gather) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
+                }
+                std::vector<gn_stream*> ss;
+                for (auto& part : lf.parts)
+                    ss.push_back(part.s);
+                uint64_t need = 0;
+                if (gn_gather_run(lf.gather, ss.data(), (uint32_t)ss.size()) != GN_OK
+                    || gn_gather_fetch(lf.gather, fr.match_off.data(), nullptr, 0, &need) != GN_OK)
+                {
+                    err = gn_last_error();
+                    return false;
+                }
+                tmp_.resize(need ? need : 1);
+                if (gn_gather_fetch(lf.gather, nullptr, tmp_.data(), tmp_.size(), &need) != GN_OK)
+                {
+                    err = gn_last_error();
+                    return false;
+                }
+                uint64_t moved = 0;
+                if (gn_gather_device_matches(lf.gather, nullptr, nullptr, nullptr, &moved) == GN_OK)
+                    gathered_bytes_ += moved;
+                unpack(need, nullptr, fr.matches, pf_active_ ? &fr.fpr_ok : nullptr);
+                if (!have_reads)
+                {
+                    Part& home = lf.parts[lf.home];
+                    if (gn_fetch_batch(home.s, out.n_hashes.data(), out.status.data(), nullptr, nullptr, 0, &need) != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
+                    have_reads = true;
+                }
+            }
+            if (pf_active_)
+                for (auto& part : lf.parts)
                 {
                     const bool first = out.max_count.empty();
                     if (first)
                         out.max_count.assign(n, 0);
                     uint64_t a = 0, b2 = 0;
                     // (in a joint pass every stream holds the level's maximum: the first one's copy is taken)
-                    if (gn_fetch_postfilter(lf.parts[0].s, first ? out.max_count.data() : nullptr, &a, &b2) != GN_OK)
+                    if (gn_fetch_postfilter(part.s, first ? out.max_count.data() : nullptr, &a, &b2) != GN_OK)
                     {
                         err = gn_last_error();
                         return false;
@@ -455,53 +758,6 @@ public:
                     out.dropped_rel_filter += a;
                     out.dropped_fpr_query += b2;
                 }
-                continue;
-            }
-            // several column parts: the matches of a read are its parts' matches behind each other (targets ascend with
-            // the bins, so the concatenation is already in target order)
-            std::vector<std::vector<uint64_t>> offs(lf.parts.size());
-            std::vector<std::vector<Match>>    ms(lf.parts.size());
-            std::vector<std::vector<uint8_t>>  oks(lf.parts.size());
-            for (size_t g = 0; g < lf.parts.size(); ++g)
-            {
-                offs[g].assign((size_t)n + 1, 0);
-                if (!fetch_part(lf.parts[g], n, out, offs[g], ms[g], err, pf_active_ ? &oks[g] : nullptr))
-                    return false;
-                if (pf_active_)
-                {
-                    const bool first = out.max_count.empty();
-                    if (first)
-                        out.max_count.assign(n, 0);
-                    uint64_t a = 0, b2 = 0;
-                    if (gn_fetch_postfilter(lf.parts[g].s, first ? out.max_count.data() : nullptr, &a, &b2) != GN_OK)
-                    {
-                        err = gn_last_error();
-                        return false;
-                    }
-                    out.prefiltered = true;
-                    out.dropped_rel_filter += a;
-                    out.dropped_fpr_query += b2;
-                }
-                for (uint32_t r = 0; r < n; ++r)
-                    fr.match_off[r + 1] += offs[g][r + 1] - offs[g][r];
-            }
-            for (uint32_t r = 0; r < n; ++r)
-                fr.match_off[r + 1] += fr.match_off[r];
-            fr.matches.resize(fr.match_off[n]);
-            fr.fpr_ok.clear();
-            if (pf_active_)
-                fr.fpr_ok.resize(fr.match_off[n]);
-            for (uint32_t r = 0; r < n; ++r)
-            {
-                uint64_t o = fr.match_off[r];
-                for (size_t g = 0; g < lf.parts.size(); ++g)
-                    for (uint64_t x = offs[g][r]; x < offs[g][r + 1]; ++x)
-                    {
-                        if (pf_active_)
-                            fr.fpr_ok[o] = oks[g][x];
-                        fr.matches[o++] = ms[g][x];
-                    }
-            }
         }
         lap(sec_fetch_);
         return true;
@@ -528,7 +784,8 @@ public:
     {
         pf_active_ = false;
         ++pf_generation_;
-        if (!spec || filters_.empty() || spec->target_fpr.size() != filters_.size())
+        std::string err;
+        if (!spec || !resolve(err) || filters_.empty() || spec->target_fpr.size() != filters_.size())
             return false;
         // filters that share target names: the device replays the level's merge, which needs every name's level-wide id
         const bool merge = filters_.size() > 1 && !spec->disjoint_targets;
@@ -547,11 +804,20 @@ public:
             }
         }
         // one device filter (a whole filter, or a column part of a wide one) per stream; column parts are cut at target
-        // boundaries, so their targets are disjoint; all of a level's streams take part in one joint pass
-        size_t n_streams = 0;
+        // boundaries, so their targets are disjoint; all of a level's streams take part in one joint pass, which spans the
+        // devices of a partitioned filter (up to 16 streams per device, 16 devices); a merging pass stays on one device
+        std::map<int, size_t> per_device;
+        size_t                n_streams = 0;
         for (auto const& lf : filters_)
-            n_streams += lf.parts.size();
-        if (n_streams > 16) // GN_PF_MAX_JOINT
+            for (auto const& part : lf.parts)
+            {
+                ++per_device[part.dp->device];
+                ++n_streams;
+            }
+        for (auto const& [dev, cnt] : per_device)
+            if (cnt > 16) // GN_PF_MAX_JOINT
+                return false;
+        if (per_device.size() > 16 || (merge && (per_device.size() > 1 || n_streams > 16)))
             return false;
         pf_fpr_.assign(filters_.size(), {});
         pf_gid_.assign(filters_.size(), {});
@@ -563,7 +829,7 @@ public:
             pf_gid_[i].resize(filters_[i].parts.size());
             for (size_t g = 0; g < filters_[i].parts.size(); ++g)
             {
-                const Part& part = filters_[i].parts[g];
+                const DevPart& part = *filters_[i].parts[g].dp;
                 if (part.to_target.empty())
                 {
                     if (filters_[i].parts.size() != 1)
@@ -597,52 +863,80 @@ public:
     }
 
 private:
-    struct Stage
-    {
-        void*  ptr   = nullptr;
-        size_t bytes = 0;
-    };
     struct Part
     {
-        gn_filter*            f = nullptr;
-        gn_stream*            s = nullptr;
-        uint32_t              stream_reads = 0;
-        uint64_t              stream_bases = 0;
-        uint64_t              pf_generation = 0; // Backend::set_postfilter call this stream was last configured for
-        uint64_t              word_lo = 0, words = 0;
-        std::vector<uint32_t> to_target; // device target id -> index into FilterMeta::targets (empty: the same)
+        const DevPart* dp = nullptr;
+        gn_stream*     s  = nullptr;
+        uint32_t       stream_reads = 0;
+        uint64_t       stream_bases = 0;
+        uint64_t       pf_generation = 0; // Backend::set_postfilter call this stream was last configured for
     };
     struct Logical
     {
-        bool                  is_hibf = false;
-        std::vector<Part>     parts;     // one, or the column parts of a wide flat filter
-        std::vector<uint64_t> row_words; // bin_words of every IBF as stored in the file
+        bool              is_hibf = false;
+        std::vector<Part> parts;  // one, or the column parts of a wide / partitioned flat filter
+        size_t            home = 0; // a part on this worker's device (n_hashes / status are fetched from its stream)
+        gn_gather*        gather = nullptr;
     };
 
-    // n_hashes / status (the same for every part), match offsets and matches of one device filter, target ids translated
-    bool fetch_part(Part& part, uint32_t n, BatchResult& out, std::vector<uint64_t>& match_off, std::vector<Match>& matches,
-                    std::string& err, std::vector<uint8_t>* fpr_ok = nullptr)
+    // this worker's view of the level's filters (after the DeviceSet has received them all)
+    bool resolve(std::string& err)
     {
-        uint64_t need = 0;
-        if (gn_fetch_batch(part.s, out.n_hashes.data(), out.status.data(), match_off.data(), nullptr, 0, &need) != GN_OK)
+        auto const& shared = set_->filters();
+        if (filters_.size() == shared.size())
+            return true;
+        drop_streams();
+        for (auto const& sf : shared)
         {
-            err = gn_last_error();
-            return false;
+            Logical lf;
+            lf.is_hibf = sf.is_hibf;
+            auto const& copy = sf.spread ? sf.copies.at(0) : sf.copies.at(set_->unique_index(device_));
+            for (size_t g = 0; g < copy.size(); ++g)
+            {
+                Part part;
+                part.dp = &copy[g];
+                lf.parts.push_back(part);
+            }
+            for (size_t g = 0; g < lf.parts.size(); ++g)
+                if (lf.parts[g].dp->device == device_)
+                {
+                    lf.home = g;
+                    break;
+                }
+            if (lf.parts.empty())
+            {
+                err = "a filter without device parts";
+                return false;
+            }
+            filters_.push_back(std::move(lf));
         }
-        tmp_.resize(need ? need : 1);
-        if (gn_fetch_batch(part.s, nullptr, nullptr, nullptr, tmp_.data(), tmp_.size(), &need) != GN_OK)
+        return true;
+    }
+
+    void drop_streams()
+    {
+        for (auto& lf : filters_)
         {
-            err = gn_last_error();
-            return false;
+            for (auto& part : lf.parts)
+                if (part.s)
+                    gn_stream_destroy(part.s); // (never touches the filter)
+            if (lf.gather)
+                gn_gather_destroy(lf.gather);
         }
+        filters_.clear();
+    }
+
+    // tmp_[0..need) -> matches (+ the pre-pass's "surely passes --fpr-query" flags), target ids translated
+    bool unpack(uint64_t need, const std::vector<uint32_t>* to_target, std::vector<Match>& matches, std::vector<uint8_t>* fpr_ok)
+    {
         matches.resize(need);
         bool drop = false;
         for (uint64_t j = 0; j < need; ++j)
         {
             uint32_t t = tmp_[j].target;
-            if (!part.to_target.empty())
+            if (to_target)
             {
-                t = part.to_target[t]; // HIBF: user bin -> target; column part: local -> global target
+                t = (*to_target)[t]; // HIBF: user bin -> target
                 drop |= t == 0xFFFFFFFFu;
             }
             matches[j] = Match{ tmp_[j].read, t, tmp_[j].count & ~GN_MATCH_FPR_OK };
@@ -653,31 +947,58 @@ private:
             for (uint64_t j = 0; j < need; ++j)
                 (*fpr_ok)[j] = (tmp_[j].count & GN_MATCH_FPR_OK) ? 1 : 0;
         }
-        if (drop)
+        return drop;
+    }
+
+    // match offsets and matches of one device filter (and, if wanted, n_hashes / status of the batch), target ids translated
+    bool fetch_part(Part& part, uint32_t n, BatchResult& out, bool with_reads, std::vector<uint64_t>& match_off, std::vector<Match>& matches,
+                    std::string& err, std::vector<uint8_t>* fpr_ok = nullptr)
+    {
+        uint64_t need = 0;
+        if (gn_fetch_batch(part.s, with_reads ? out.n_hashes.data() : nullptr, with_reads ? out.status.data() : nullptr, match_off.data(),
+                           nullptr, 0, &need)
+            != GN_OK)
         {
-            // user bins that belong to no target (cannot happen with raptor indices) are dropped
+            err = gn_last_error();
+            return false;
+        }
+        tmp_.resize(need ? need : 1);
+        if (gn_fetch_batch(part.s, nullptr, nullptr, nullptr, tmp_.data(), tmp_.size(), &need) != GN_OK)
+        {
+            err = gn_last_error();
+            return false;
+        }
+        if (unpack(need, part.dp->to_target.empty() ? nullptr : &part.dp->to_target, matches, fpr_ok))
+        {
+            // user bins that belong to no target (cannot happen with raptor indices) are dropped, and their flags with them
             std::vector<Match>    keep;
+            std::vector<uint8_t>  keep_ok;
             std::vector<uint64_t> off((size_t)n + 1, 0);
-            for (auto const& m : matches)
-                if (m.target != 0xFFFFFFFFu)
+            for (size_t j = 0; j < matches.size(); ++j)
+                if (matches[j].target != 0xFFFFFFFFu)
                 {
-                    keep.push_back(m);
-                    off[m.read + 1]++;
+                    keep.push_back(matches[j]);
+                    if (fpr_ok)
+                        keep_ok.push_back((*fpr_ok)[j]);
+                    off[matches[j].read + 1]++;
                 }
             for (uint32_t r = 0; r < n; ++r)
                 off[r + 1] += off[r];
             matches.swap(keep);
             match_off.swap(off);
+            if (fpr_ok)
+                fpr_ok->swap(keep_ok);
         }
         return true;
     }
 
+    std::shared_ptr<DeviceSet> set_;
+    size_t                index_;
     int                   device_;
-    HipBackend*           primary_ = nullptr;
     double                sec_create_ = 0, sec_submit_ = 0, sec_fetch_ = 0; // $GANON_HOST_TIMING: where classify() spends its time
     unsigned              n_create_ = 0;
+    uint64_t              gathered_bytes_ = 0;
     bool                  long_reads_ = false;
-    Stage                 stage_[2];
     std::vector<Logical>  filters_;
     std::vector<gn_match> tmp_;
     PostFilterSpec        pf_spec_;
@@ -710,16 +1031,11 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
             err = "device index " + std::to_string(d) + " out of range (" + std::to_string(n) + " device(s) visible)";
             return out;
         }
-    // one backend per listed device; a device listed again gets a further worker that shares the first one's filters
-    std::map<int, HipBackend*> first;
-    for (int d : use)
-    {
-        auto it = first.find(d);
-        auto* b = new HipBackend(d, it == first.end() ? nullptr : it->second);
-        if (it == first.end())
-            first[d] = b;
-        out.emplace_back(b);
-    }
+    // one worker per listed device; the filters live in the DeviceSet they share (a device listed again gets a further
+    // worker on the same copy)
+    auto set = std::make_shared<DeviceSet>(use);
+    for (size_t i = 0; i < use.size(); ++i)
+        out.emplace_back(new HipBackend(set, i));
     // device-bound host buffers (read batches) come from page-locked memory from now on (hostmem.hpp)
     if (!std::getenv("GANON_HOST_PAGEABLE"))
     {

@@ -884,6 +884,13 @@ static bool ganon_classify(Config config)
             }
         }
         loading.stop();
+        if (config.verbose || std::getenv("GANON_HOST_TIMING"))
+            for (auto& b : backends)
+            {
+                const std::string where = b->placement();
+                if (!where.empty())
+                    std::cerr << "[placement] level " << level.label << ": " << where;
+            }
 
         level.kmer_size   = filters[0].ibf_config.kmer_size;
         level.window_size = filters[0].ibf_config.window_size;
@@ -1295,7 +1302,7 @@ static bool ganon_classify(Config config)
             for (size_t wi = 0; wi < n_workers; ++wi)
                 workers.emplace_back([&, wi] {
                     ClassifiedBatch cb;
-                    for (;;)
+                    while (backends[wi]->active()) // (a level with a partitioned filter runs on a few of the workers)
                     {
                         ordered.take_free(cb);
                         if (failed || !next_batch(cb.rb))

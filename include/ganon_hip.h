@@ -213,6 +213,10 @@ int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf);
  * max_count set on every stream: the caller merges and thresholds those itself.  The dropped-match totals of a merging pass
  * are reported on streams[0]. */
 int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n_streams);
+/* The streams of a joint pass over DISJOINT targets may sit on several devices -- the column parts of a bin-range
+ * partitioned filter (below): every device combines its streams' max/min per read, the devices exchange those two arrays
+ * (8 bytes per read and pair of devices, hipMemcpyPeerAsync over xGMI), and every stream applies the rules with the level's
+ * values.  Up to 16 streams per device and 16 devices.  A merging pass (joint = 2) needs all its streams on one device. */
 /* after a batch with the pass on: per read the largest match count BEFORE filtering (0 = the read had no match; the
  * reference's max_count_read, :753,776,806), and how many matches each rule dropped in this batch */
 int gn_fetch_postfilter(gn_stream* s, uint32_t* max_count, uint64_t* dropped_rel_filter, uint64_t* dropped_fpr_query);
@@ -222,6 +226,32 @@ int gn_fetch_postfilter(gn_stream* s, uint32_t* max_count, uint64_t* dropped_rel
  * then *d_matches points to n_matches records in DEVICE memory, grouped by read (ascending read, then target).
  * The memory belongs to the stream and is valid until its next submit/classify/destroy. */
 int gn_stream_device_matches(gn_stream* s, const gn_match** d_matches, uint64_t* n_matches);
+
+/* ---- bin-range partitioned flat IBF (BASELINE config 5) ------------------------------------------------
+ * The reference loads a filter of any size into host memory (/root/reference/src/ganon-classify/GanonClassify.cpp:949-986,
+ * 1007-1039) and one bulk_count sees all of its bins (:514).  A filter larger than one GPU's HBM is cut by technical-bin
+ * range, at boundaries between targets, into column parts: part g is a flat IBF of its own (gn_filter_upload_ibf with the
+ * part's bins and a part-local target numbering, rows streamed with gn_filter_write_rows(word_lo = the part's first word)),
+ * created on whichever device has room.  Every part classifies every batch (one gn_stream per part, same reads); the cutoff
+ * and the per-target sum of :516-527 are complete inside a part because a target's bins never straddle a cut.
+ * gn_gather puts a read's matches back together on the batch's OWNER device: the parts' grouped matches and per-read
+ * offsets are copied device to device (hipMemcpyPeerAsync: xGMI, not the host) and one kernel concatenates them per read in
+ * part order -- ascending target, since targets ascend with the bins -- translating part-local target ids through
+ * target_map[i] (n_map[i] entries; NULL = ids are the caller's already).  Parts that live on the owner device are read in
+ * place.  With a filter_matches pre-pass set on the parts' streams (joint = 1), call gn_streams_postfilter_joint over them
+ * first: then only survivors travel.  The result is what gn_fetch_batch would return for the unpartitioned filter. */
+typedef struct gn_gather gn_gather;
+int gn_gather_create(int device, uint32_t n_parts, const uint32_t* const* target_map, const uint32_t* n_map, gn_gather** out);
+/* streams[i] = part i's stream, all holding the same submitted batch (gn_submit_batch / gn_stream_classify) */
+int gn_gather_run(gn_gather* g, gn_stream* const* streams, uint32_t n_streams);
+/* match_off[n_reads+1], matches[cap] grouped by read (ascending read, then ascending target); either may be NULL */
+int gn_gather_fetch(gn_gather* g, uint64_t* match_off, gn_match* matches, uint64_t cap, uint64_t* n_matches);
+/* device-resident view (valid until the next gn_gather_run) and the bytes the last run moved between devices */
+int gn_gather_device_matches(gn_gather* g, const gn_match** d_matches, const uint64_t** d_match_off, uint64_t* n_matches,
+                             uint64_t* peer_bytes);
+int gn_gather_destroy(gn_gather* g);
+/* free / total memory of a device: the host decides with it whether a filter is replicated or partitioned */
+int gn_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* Build side (/root/reference/src/ganon-build/GanonBuild.cpp).
  * gn_stream_distinct_hashes: after gn_stream_minimisers, the SET of minimiser hashes of all sequences resident in the
