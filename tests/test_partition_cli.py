@@ -22,8 +22,9 @@ EXTS = (".all", ".unc", ".rep")
 def _run(binary, db, out, extra=(), env=None, check=True):
     e = dict(os.environ)
     e.update(env or {})
+    cutoff = [] if "--rel-cutoff" in extra else ["--rel-cutoff", "0.5"]
     p = subprocess.run([binary, "--ibf", db["ibf"], "--single-reads", db["fq"], "-o", out, "--output-all", "--output-unclassified",
-                        "--rel-cutoff", "0.5", "--quiet"] + list(extra), capture_output=True, text=True, env=e)
+                        "--quiet"] + cutoff + list(extra), capture_output=True, text=True, env=e)
     if check:
         assert p.returncode == 0, p.stderr
     return p
