@@ -169,3 +169,44 @@ def test_config4_column_slice_through_partition_and_rccl(flat128g):
     finally:
         dist.destroy_process_group()
         flt.free()
+
+
+# ------------------------------------------------------------------- configs[3]'s filter as two bin-range parts
+def test_config3_filter_as_two_64g_parts_gathered_equals_the_whole(flat128g, monkeypatch):
+    """The 128 GiB filter of configs[3] cut at bin 16 384 into two 64 GiB column parts -- what ganon-classify places on two
+    devices when the filter exceeds one (host/backend_hip.cpp) -- each classifying all 12.5 M pairs; the parts' matches,
+    copied device to device and concatenated per pair by gn_gather, must be the whole filter's matches record for record."""
+    import copy
+    hip, wl0, flt0, st0, (nh, status, mo, m) = flat128g
+    st0.destroy()
+    flt0.free()                              # (idempotent: the slice test above may have released them already)
+    W = BINS // 64
+    parts, streams = [], []
+    for g in range(2):
+        wl = copy.copy(wl0)
+        wl.bins = BINS // 2
+        wl.word_lo, wl.row_words_total = g * (W // 2), W
+        mine = (wl0.genome_bins // (BINS // 2)) == g
+        wl.genomes = wl0.genomes[mine]
+        wl.genome_bins = (wl0.genome_bins[mine] - g * (BINS // 2)).astype(np.uint32)
+        flt, n_planted = bw.device_filter(hip, wl)
+        assert flt.info()["device_bytes"] == ROWS * 2048 and n_planted > 0
+        parts.append(flt)
+    for flt in parts:
+        st = hip.HipStream(flt, PAIRS, wl0.bases.size, PAIRS)
+        st.upload(wl0.bases, wl0.off, wl0.off2)
+        st.classify(wl0.k, wl0.w, wl0.rel_cutoff)
+        streams.append(st)
+    monkeypatch.setenv("GANON_HIP_GATHER_COPY", "1")   # one GPU: take the device-to-device copy path all the same
+    g = hip.HipGather(0, [None, np.arange(BINS // 2, dtype=np.uint32) + np.uint32(BINS // 2)])
+    g.run(streams)
+    mo2, m2 = g.fetch()
+    assert g.peer_bytes() == 2 * (PAIRS + 1) * 8 + 12 * len(m)
+    assert np.array_equal(mo2, mo) and np.array_equal(m2, m)
+    nh2, status2 = streams[1].fetch_read_info()
+    assert np.array_equal(nh2, nh) and np.array_equal(status2, status)
+    g.destroy()
+    for st in streams:
+        st.destroy()
+    for flt in parts:
+        flt.free()

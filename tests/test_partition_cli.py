@@ -77,7 +77,7 @@ def test_partitioned_filter_with_the_filter_matches_prepass(oracle_bin, wide_db,
 def test_level_with_a_replicated_and_a_partitioned_filter(oracle_bin, wide_db, config1, tmp_path):
     # two filters on one hierarchy level (disjoint target names): the small one fits everywhere and is replicated, the wide
     # one is spread over what the devices have left
-    args = lambda out: ["--ibf", config1["ibf"], wide_db["ibf"], "--single-reads", wide_db["fq"], config1["fq"], "-o", out,  # noqa: E731
+    args = lambda out: ["--ibf", config1["ibf"] + "," + wide_db["ibf"], "--single-reads", wide_db["fq"] + "," + config1["fq"], "-o", out,  # noqa: E731
                         "--output-all", "--output-unclassified", "--output-stats", "--rel-cutoff", "0.4", "--rel-filter", "0.2", "--quiet"]
     ora, got = str(tmp_path / "ora"), str(tmp_path / "got")
     cu.run(oracle_bin, args(ora))
