@@ -24,7 +24,11 @@ Rank 0 prints ONE JSON line (driver contract) with extra objects:
                    exit makes the kernel fetch fewer rows than the algorithm names, so only `achieved` is physical.
   variants         the same resident batch with the early exit disabled and at the binary's default --rel-cutoff 0.2
   cpu_baseline     the CPU oracle (kind "port") on a bounded sample of the same reads against the same filter bits
-  other_workloads  (default N=1 run only) the other BASELINE configs, each run at full size in a child process
+  other_workloads  the other BASELINE configs at full size: at N=1 each in a child process (hibf64k, its variant with an
+                   HBM-resident top level, flat128g, slice1t); at N>1 in this job, one after the other: flat128g (configs[3]:
+                   12.5 M pairs PER RANK against a replica, weak) and slice1t (configs[4]: rank r holds column slice r, every
+                   rank classifies all pairs, sparse matches go to the pair's owner over RCCL) -- so a scaling run yields the
+                   points BASELINE.json quotes its scaling target on
 """
 from __future__ import annotations
 
@@ -51,12 +55,28 @@ WORKLOADS = {
     # split-bin map (what ganon-build makes of targets larger than max_hashes_bin): two technical bins per target
     "split32k": dict(kind="flat", bins=32768, rows=1 << 21, h=4, reads=2_000_000, paired=False, config=None, bins_per_target=2),
     "hibf64k": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, h=3, reads=10_000_000, paired=False, config=2),
+    # the same tree with a top-level IBF of 1 GiB (2^25 rows of 32 bytes): level 0 no longer fits the 256 MiB Infinity Cache
+    "hibf64k_top1g": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, rows_top=1 << 25, h=3, reads=10_000_000, paired=False, config=2),
     "hibf_tiny": dict(kind="hibf", user_bins=4096, tmax=64, rows=1 << 12, h=3, reads=100_000, paired=False, config=None),
     "flat128g": dict(kind="flat", bins=32768, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=3),
     "slice1t": dict(kind="slice", bins=32768, slices=8, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=4),
     "slice_tiny": dict(kind="slice", bins=4096, slices=8, rows=1 << 14, h=4, reads=100_000, paired=True, config=None),
 }
-EXTRA_WORKLOADS = ["hibf64k", "flat128g", "slice1t"]
+EXTRA_WORKLOADS = ["hibf64k", "hibf64k_top1g", "flat128g", "slice1t"]   # N = 1: child processes
+EXTRA_WORKLOADS_MULTI = ["flat128g", "slice1t"]                           # N > 1: in this job (BASELINE's scaling configs)
+
+# What a random gather of 128-byte lines reaches on MI355X by residency of the table (scripts/calib_gather.hip, measured:
+# profiles/r03_calib_gather.json): every row narrower than a line still moves the whole line (TCC_EA0_RDREQ = 1 per row
+# request for 32-, 64- and 128-byte rows alike; FETCH_SIZE tallies a line at 64 B, i.e. the guide's x2 holds here too).
+GATHER_ROOF_GBS = [(64 << 20, 8394.0, "infinity cache (table <= 64 MiB)"), (256 << 20, 7267.0, "infinity cache (table <= 256 MiB)"),
+                   (2 << 30, 7158.0, "HBM behind a partly caching MALL (table <= 2 GiB)"), (1 << 62, 6407.0, "HBM")]
+
+
+def gather_roof(table_bytes: int):
+    for lim, gbs, where in GATHER_ROOF_GBS:
+        if table_bytes <= lim:
+            return gbs, where
+    return GATHER_ROOF_GBS[-1][1:]
 
 
 def log(*a):
@@ -73,13 +93,18 @@ def run_extra(name: str, timeout: int):
         line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{\"metric\"")]
         if p.returncode == 0 and line:
             r = json.loads(line[-1])
-            return {"workload": name, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
-                    "config": r["config"], "roofline": r["roofline"], "wall_s": round(time.time() - t0, 1)}
+            return slim(name, r, time.time() - t0)
         return {"workload": name, "error": f"rc {p.returncode}: " + p.stderr.decode(errors="replace")[-400:]}
     except subprocess.TimeoutExpired:
         return {"workload": name, "error": f"timeout after {timeout}s"}
     except Exception as e:  # noqa: BLE001 -- the extras never take the main line down
         return {"workload": name, "error": repr(e)}
+
+
+def slim(name: str, r: dict, wall: float) -> dict:
+    return {"workload": name, "value": r["value"], "unit": r["unit"], "n_gpus": r["n_gpus"], "scaling": r["scaling"],
+            "ms_per_step": r["ms_per_step"], "steps": r["steps"], "config": r["config"], "roofline": r["roofline"],
+            "wall_s": round(wall, 1)}
 
 
 def main() -> int:
@@ -114,260 +139,300 @@ def main() -> int:
     torch.cuda.set_device(dev_index)
     dist_backend = os.environ.get("GANON_BENCH_DIST", "nccl")   # nccl == RCCL; "gloo" only for 1-GPU dry runs
     red_dev = "cuda" if dist_backend == "nccl" else "cpu"
-    spec = dict(WORKLOADS[args.workload])
-    kind = spec["kind"]
-    if world > 1 or kind == "slice":  # the partitioned filter exchanges matches over RCCL even at world size 1
+    if world > 1:
         gdist.init(dist_backend, torch.device("cuda", dev_index))
 
-    n_reads = args.reads or spec["reads"]
-    rows = args.rows or spec["rows"]
-    paired = spec["paired"]
-    t0 = time.time()
-    part = None
-    if kind == "hibf":
-        wl, flt = bw.make_hibf_device_workload(ganon_amd, args.workload, spec["user_bins"], spec["tmax"], rows, rows, spec["h"],
-                                               n_reads, rel_cutoff=args.rel_cutoff, seed=42, shard=rank, device=dev_index)
-        off2 = None
-        desc = (f"2-level HIBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU: top IBF {spec['tmax']} merged bins -> "
-                f"{spec['tmax']} child IBFs x {spec['user_bins'] // spec['tmax']} user bins = {spec['user_bins']} user bins, "
-                f"S={rows} rows each, h={spec['h']}")
-        kernel_name = "gn_hibf_pack_kernel"
-        row_bytes = ((spec["tmax"] + 63) >> 6) * 8
-    else:
-        slices = spec.get("slices", 1)
-        W_local = (spec["bins"] + 63) >> 6
-        sl_idx = rank % slices if kind == "slice" else 0
-        wl = bw.make_device_flat_workload(args.workload, spec["bins"], rows, spec["h"], n_reads, paired, rel_cutoff=args.rel_cutoff,
-                                          seed=42, shard=0 if kind == "slice" else rank, word_lo=sl_idx * W_local,
-                                          row_words_total=W_local * slices)
-        bpt = spec.get("bins_per_target", 1)
-        if bpt > 1:
-            flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index, (np.arange(spec["bins"], dtype=np.uint32) // bpt).astype(np.uint32),
-                                              spec["bins"] // bpt)
-        else:
-            flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index)
-        off2 = wl.off2
-        row_bytes = W_local * 8
-        if kind == "slice":
-            sl = gp.Slice(rank, sl_idx * W_local, (sl_idx + 1) * W_local, spec["bins"], np.arange(spec["bins"], dtype=np.uint32),
-                          (np.arange(spec["bins"], dtype=np.uint32) + np.uint32(sl_idx * spec["bins"])))
-            part = gp.PartitionedIbf(sl, rank, world, gp.HipLocalFilter(flt, dev_index), comm_device=red_dev)
-            desc = (f"column slice {sl_idx} of {slices} ({spec['bins']} of {spec['bins'] * slices} technical bins, "
-                    f"{wl.filter_bytes / 2**30:.2f} GiB of a {wl.filter_bytes * slices / 2**40:.2f} TiB flat IBF), W_local={W_local} "
-                    f"({row_bytes} B rows), S={rows} rows, h={spec['h']}; every rank sees every read, sparse matches go to the "
-                    f"read's owner with one all-to-all over RCCL")
-        else:
-            desc = (f"flat IBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {wl.bins} technical bins (W={W_local}, "
-                    f"{row_bytes} B rows), S={rows} rows, h={spec['h']}" + (f", {bpt} bins per target" if bpt > 1 else ""))
-        kernel_name = "gn_ibf_count_split_kernel" if bpt > 1 else "gn_ibf_count_fast_kernel"
-    unit_name = "pairs (2x150 bp)" if paired else "reads (150 bp)"
-    log(f"[rank {rank}] workload {args.workload}: filter {wl.filter_bytes / 2**30:.2f} GiB filled on the device, {n_reads} "
-        f"{unit_name}, set up in {time.time() - t0:.1f}s")
+    def run_one(name: str, headline: bool) -> dict:
+        spec = dict(WORKLOADS[name])
+        kind = spec["kind"]
+        steps, warmup = (args.steps, args.warmup) if headline else (3, 1)
+        if kind == "slice":  # the partitioned filter exchanges matches over RCCL even at world size 1
+            gdist.init(dist_backend, torch.device("cuda", dev_index))
 
-    if part is None:
-        st = ganon_amd.HipStream(flt, n_reads, wl.bases.size, max_matches=n_reads * 2)
-        st.upload(wl.bases, wl.off, off2)
-        st.sync()
+        n_reads = (args.reads if headline else 0) or spec["reads"]
+        rows = (args.rows if headline else 0) or spec["rows"]
+        paired = spec["paired"]
+        t0 = time.time()
+        part = None
+        if kind == "hibf":
+            rows_top = spec.get("rows_top", rows) if not (headline and args.rows) else rows
+            wl, flt = bw.make_hibf_device_workload(ganon_amd, name, spec["user_bins"], spec["tmax"], rows_top, rows, spec["h"],
+                                                   n_reads, rel_cutoff=args.rel_cutoff, seed=42, shard=rank, device=dev_index)
+            off2 = None
+            desc = (f"2-level HIBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU: top IBF {spec['tmax']} merged bins -> "
+                    f"{spec['tmax']} child IBFs x {spec['user_bins'] // spec['tmax']} user bins = {spec['user_bins']} user bins, "
+                    f"S={rows_top} rows (top, {rows_top * 32 / 2**20:.0f} MiB) / {rows} rows (children), h={spec['h']}")
+            kernel_name = "gn_hibf_pack_kernel"
+            row_bytes = ((spec["tmax"] + 63) >> 6) * 8
+        else:
+            slices = spec.get("slices", 1)
+            W_local = (spec["bins"] + 63) >> 6
+            sl_idx = rank % slices if kind == "slice" else 0
+            wl = bw.make_device_flat_workload(name, spec["bins"], rows, spec["h"], n_reads, paired, rel_cutoff=args.rel_cutoff,
+                                              seed=42, shard=0 if kind == "slice" else rank, word_lo=sl_idx * W_local,
+                                              row_words_total=W_local * slices)
+            bpt = spec.get("bins_per_target", 1)
+            if bpt > 1:
+                flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index, (np.arange(spec["bins"], dtype=np.uint32) // bpt).astype(np.uint32),
+                                                  spec["bins"] // bpt)
+            else:
+                flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index)
+            off2 = wl.off2
+            row_bytes = W_local * 8
+            if kind == "slice":
+                sl = gp.Slice(rank, sl_idx * W_local, (sl_idx + 1) * W_local, spec["bins"], np.arange(spec["bins"], dtype=np.uint32),
+                              (np.arange(spec["bins"], dtype=np.uint32) + np.uint32(sl_idx * spec["bins"])))
+                part = gp.PartitionedIbf(sl, rank, world, gp.HipLocalFilter(flt, dev_index), comm_device=red_dev)
+                desc = (f"column slice {sl_idx} of {slices} ({spec['bins']} of {spec['bins'] * slices} technical bins, "
+                        f"{wl.filter_bytes / 2**30:.2f} GiB of a {wl.filter_bytes * slices / 2**40:.2f} TiB flat IBF), W_local={W_local} "
+                        f"({row_bytes} B rows), S={rows} rows, h={spec['h']}; every rank sees every read, sparse matches go to the "
+                        f"read's owner with one all-to-all over RCCL")
+            else:
+                desc = (f"flat IBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {wl.bins} technical bins (W={W_local}, "
+                        f"{row_bytes} B rows), S={rows} rows, h={spec['h']}" + (f", {bpt} bins per target" if bpt > 1 else ""))
+            kernel_name = "gn_ibf_count_split_kernel" if bpt > 1 else "gn_ibf_count_fast_kernel"
+        unit_name = "pairs (2x150 bp)" if paired else "reads (150 bp)"
+        log(f"[rank {rank}] workload {name}: filter {wl.filter_bytes / 2**30:.2f} GiB filled on the device, {n_reads} "
+            f"{unit_name}, set up in {time.time() - t0:.1f}s")
 
-        def step(cutoff):
-            st.classify(wl.k, wl.w, cutoff)
+        if part is None:
+            st = ganon_amd.HipStream(flt, n_reads, wl.bases.size, max_matches=n_reads * 2)
+            st.upload(wl.bases, wl.off, off2)
             st.sync()
-    else:
-        owned = {}
 
-        def step(cutoff):
-            owned["out"] = part.classify(wl.bases, wl.off, off2, wl.k, wl.w, cutoff)
-        step(args.rel_cutoff)  # creates the stream and uploads the batch (it stays resident)
-        st = part.local.st
+            def step(cutoff):
+                st.classify(wl.k, wl.w, cutoff)
+                st.sync()
+        else:
+            owned = {}
 
-    def barrier():
-        torch.cuda.synchronize()
-        gdist.barrier()
-        torch.cuda.synchronize()
+            def step(cutoff):  # classify against the slice, exchange, merge on the owner; the result stays in HBM
+                owned["out"] = part.classify(wl.bases, wl.off, off2, wl.k, wl.w, cutoff, fetch=False)
+            step(args.rel_cutoff)  # creates the stream and uploads the batch (it stays resident)
+            st = part.local.st
 
-    def timed(cutoff, steps, warmup):
-        for _ in range(warmup):
-            step(cutoff)
-        cms, mms, tms = [], [], []
-        barrier()
-        t_begin = time.perf_counter()
-        for _ in range(steps):
-            step(cutoff)
-            tm = st.timings()           # hipEvent durations on the stream the kernels ran on
-            cms.append(tm["ms_count"])
-            mms.append(tm["ms_minimiser"])
-            tms.append(tm["ms_total"])
-        barrier()
-        return time.perf_counter() - t_begin, cms, mms, tms, st.timings()
+        def barrier():
+            torch.cuda.synchronize()
+            gdist.barrier()
+            torch.cuda.synchronize()
 
-    def roofline_of(tm, cms):
-        avg = float(np.mean(cms))
-        nl = max(1, tm["n_count_launches"])
-        fetched = tm["fetched_bytes"] / (avg * 1e-3) / 1e9
-        return {
-            "achieved": round(fetched, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fetched / HBM_PEAK_GBS, 4),
-            "effective_gbs": round(tm["algo_bytes"] / (avg * 1e-3) / 1e9, 1),
-            "avg_launch_ms": round(avg / nl, 4), "launches_per_step": int(nl),
-            "fetched_bytes_per_launch": int(tm["fetched_bytes"] // nl), "algo_bytes_per_launch": int(tm["algo_bytes"] // nl),
+        def timed(cutoff, steps, warmup):
+            for _ in range(warmup):
+                step(cutoff)
+            cms, mms, tms = [], [], []
+            barrier()
+            t_begin = time.perf_counter()
+            for _ in range(steps):
+                step(cutoff)
+                tm = st.timings()           # hipEvent durations on the stream the kernels ran on
+                cms.append(tm["ms_count"])
+                mms.append(tm["ms_minimiser"])
+                tms.append(tm["ms_total"])
+            barrier()
+            return time.perf_counter() - t_begin, cms, mms, tms, st.timings()
+
+        def roofline_of(tm, cms):
+            avg = float(np.mean(cms))
+            nl = max(1, tm["n_count_launches"])
+            fetched = tm["fetched_bytes"] / (avg * 1e-3) / 1e9
+            return {
+                "achieved": round(fetched, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fetched / HBM_PEAK_GBS, 4),
+                "effective_gbs": round(tm["algo_bytes"] / (avg * 1e-3) / 1e9, 1),
+                "avg_launch_ms": round(avg / nl, 4), "launches_per_step": int(nl),
+                "fetched_bytes_per_launch": int(tm["fetched_bytes"] // nl), "algo_bytes_per_launch": int(tm["algo_bytes"] // nl),
+            }
+
+        elapsed, count_ms, mini_ms, total_ms, tm = timed(args.rel_cutoff, steps, warmup)
+        elapsed = gdist.max_over_ranks(elapsed, device=red_dev)       # slowest rank defines the step time
+        if kind == "slice":
+            total_reads = n_reads                                      # every rank classifies the same reads against its columns
+        else:
+            total_reads = gdist.sum_over_ranks(n_reads, device=red_dev)    # whole-job reads per step
+        if part is None:
+            nh, status, mo, matches = st.fetch()
+        else:
+            lo, hi = owned["out"][:2]
+            nh, status = st.fetch_read_info()
+            matches = part.fetch_owned()
+            mo = np.searchsorted(matches["read"], np.arange(n_reads + 1)).astype(np.uint64)
+        n_class = int(np.count_nonzero(np.diff(mo.astype(np.int64))))
+        ms_per_step = elapsed * 1e3 / max(1, steps)
+        value = total_reads / (elapsed / max(1, steps)) / 1e6  # Mreads/s (M pairs/s for paired workloads), whole job
+
+        roof = {"bound": "hbm", "kernel": kernel_name}
+        roof.update(roofline_of(tm, count_ms))
+        roof["note"] = ("achieved/frac = HBM row bytes the kernel requested (gn_timings.fetched_bytes: algorithmic bytes minus the rows the "
+                        "exact early exit skips; the PMC FETCH_SIZE pass in `traffic` agrees within 3 %) / hipEvent kernel time / peak; "
+                        "effective_gbs = algorithmic bytes n*h*W*8 (SURVEY 8d) / the same time, which may exceed the peak because skipped "
+                        "rows cost nothing")
+        if kind == "hibf":
+            # The roofline per tree level: a level's rows are gathered from the IBFs at that depth, and whether those sit in
+            # the 256 MiB Infinity Cache or in HBM decides the roof.  A row narrower than a 128-byte line still moves the line
+            # (calibrated: one fabric request per row request for 32-, 64- and 128-byte rows), so the physical rate is the
+            # LINE rate; the roof is what a bare random gather of lines reaches at that residency (scripts/calib_gather.hip).
+            levels = []
+            for li, lv in enumerate(st.hibf_levels()):
+                rb = max(1, lv["row_bytes"])
+                line = lv["algo_bytes"] // rb * max(128, rb)
+                roof_gbs, where = gather_roof(lv["table_bytes"])
+                sec = max(lv["ms"], 1e-6) * 1e-3
+                levels.append({"level": li, "ms": round(lv["ms"], 4), "row_bytes": rb, "table_bytes": lv["table_bytes"], "resident_in": where,
+                               "algorithmic_bytes": lv["algo_bytes"], "line_bytes": int(line),
+                               "algorithmic_gbs": round(lv["algo_bytes"] / sec / 1e9, 1), "line_gbs": round(line / sec / 1e9, 1),
+                               "gather_roof_gbs": roof_gbs, "frac_of_gather_roof": round(line / sec / 1e9 / roof_gbs, 4),
+                               "line_frac_of_hbm_peak": round(line / sec / 1e9 / HBM_PEAK_GBS, 4)})
+            roof["levels"] = levels
+            roof["note"] += ("; HIBF rows are 32 B (256-bin IBFs): `levels` gives, per tree level of the last step, the rate in 128-byte lines "
+                             "against the measured gather roof for a table of that size (profiles/r03_calib_gather.json) -- level 0's tables "
+                             "fit the Infinity Cache unless the workload says otherwise, so HBM is not its roof")
+        roof["traffic"] = None
+
+        result = {
+            "metric": "Mreads/s classified (150 bp) + IBF-lookup GB/s vs HBM roofline",
+            "value": round(value, 3),
+            "unit": "Mpairs/s" if paired else "Mreads/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong" if kind == "slice" else "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{name} (BASELINE.json configs[{spec['config']}]): {desc}, k={wl.k} w={wl.w}, {n_reads} synthetic "
+                            f"{unit_name} per GPU (50% cut from {4096} planted genomes), rel_cutoff={args.rel_cutoff}, seeded "
+                            f"Bernoulli(0.5) fill generated on the device, seed 42",
+                "reads_per_gpu": n_reads,
+                "parallelism": (f"bin-range partitioned x{world} of {spec.get('slices')} slices" if kind == "slice"
+                                else f"read-sharded x{world}, filter replicated"),
+                "mean_minimisers_per_read": round(tm["n_hashes"] / max(1, n_reads), 3),
+                "classified_reads_rank0": n_class,
+                "matches_rank0": int(len(matches)),
+                "kernel_ms": {"minimiser": round(float(np.mean(mini_ms)), 3), "count_select": round(float(np.mean(count_ms)), 3),
+                              "device_total": round(float(np.mean(total_ms)), 3)},
+            },
+            "roofline": roof,
         }
 
-    elapsed, count_ms, mini_ms, total_ms, tm = timed(args.rel_cutoff, args.steps, args.warmup)
-    elapsed = gdist.max_over_ranks(elapsed, device=red_dev)       # slowest rank defines the step time
-    if kind == "slice":
-        total_reads = n_reads                                      # every rank classifies the same reads against its columns
-    else:
-        total_reads = gdist.sum_over_ranks(n_reads, device=red_dev)    # whole-job reads per step
-    if part is None:
-        nh, status, mo, matches = st.fetch()
-    else:
-        lo, hi, nh, status, matches = owned["out"]
-        mo = np.searchsorted(matches["read"], np.arange(n_reads + 1)).astype(np.uint64)
-    n_class = int(np.count_nonzero(np.diff(mo.astype(np.int64))))
-    ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    value = total_reads / (elapsed / max(1, args.steps)) / 1e6  # Mreads/s (M pairs/s for paired workloads), whole job
+        # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass (counter collection
+        # cannot share a run with timing); its committed summary is attached when it was taken on this workload.
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_fetch_{name}.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                roof["traffic_source"] = pmc["source"]
+            except Exception as e:  # noqa: BLE001
+                log("bench.py: could not read", pmc_path, repr(e))
 
-    roof = {"bound": "hbm", "kernel": kernel_name}
-    roof.update(roofline_of(tm, count_ms))
-    roof["note"] = ("achieved/frac = HBM row bytes the kernel requested (gn_timings.fetched_bytes: algorithmic bytes minus the rows the "
-                    "exact early exit skips; the PMC FETCH_SIZE pass in `traffic` agrees within 3 %) / hipEvent kernel time / peak; "
-                    "effective_gbs = algorithmic bytes n*h*W*8 (SURVEY 8d) / the same time, which may exceed the peak because skipped "
-                    "rows cost nothing")
-    if row_bytes < 128:
-        # rows narrower than an L2 line: every row fetch still moves one 128-byte line (what FETCH_SIZE charges a narrow load)
-        lines = tm["algo_bytes"] // row_bytes
-        avg = float(np.mean(count_ms))
-        roof["transaction_bytes_per_launch"] = int(lines * 128 // max(1, tm["n_count_launches"]))
-        roof["transaction_gbs"] = round(lines * 128 / (avg * 1e-3) / 1e9, 1)
-        roof["transaction_frac"] = round(lines * 128 / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        roof["note"] += (f"; rows are {row_bytes} B, so the transaction roofline counts one 128-byte line per row fetch "
-                         "(transaction_gbs / transaction_frac)")
-    roof["traffic"] = None
-
-    result = {
-        "metric": "Mreads/s classified (150 bp) + IBF-lookup GB/s vs HBM roofline",
-        "value": round(value, 3),
-        "unit": "Mpairs/s" if paired else "Mreads/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True,
-        "scaling": "strong" if kind == "slice" else "weak",
-        "vs_baseline": None,
-        "dtype": "u64",
-        "data": "synthetic",
-        "config": {
-            "workload": f"{args.workload} (BASELINE.json configs[{spec['config']}]): {desc}, k={wl.k} w={wl.w}, {n_reads} synthetic "
-                        f"{unit_name} per GPU (50% cut from {4096} planted genomes), rel_cutoff={args.rel_cutoff}, seeded "
-                        f"Bernoulli(0.5) fill generated on the device, seed 42",
-            "reads_per_gpu": n_reads,
-            "parallelism": (f"bin-range partitioned x{world} of {spec.get('slices')} slices" if kind == "slice"
-                            else f"read-sharded x{world}, filter replicated"),
-            "mean_minimisers_per_read": round(tm["n_hashes"] / max(1, n_reads), 3),
-            "classified_reads_rank0": n_class,
-            "matches_rank0": int(len(matches)),
-            "kernel_ms": {"minimiser": round(float(np.mean(mini_ms)), 3), "count_select": round(float(np.mean(count_ms)), 3),
-                          "device_total": round(float(np.mean(total_ms)), 3)},
-        },
-        "roofline": roof,
-    }
-
-    # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass (counter collection
-    # cannot share a run with timing); its committed summary is attached when it was taken on this workload.
-    pmc_path = os.path.join(ROOT, "profiles", f"pmc_fetch_{args.workload}.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-            roof["traffic"] = pmc["hbm_bytes_per_launch"]
-            roof["traffic_source"] = pmc["source"]
-        except Exception as e:  # noqa: BLE001
-            log("bench.py: could not read", pmc_path, repr(e))
-
-    # the same resident batch under the two conditions the headline does not show (not part of `value`)
-    if not args.no_variants and part is None and kind == "flat":
-        variants = {}
-        bpt = spec.get("bins_per_target", 1)
-        if bpt == 1:  # (the split-bin kernel has no early exit)
-            os.environ["GANON_HIP_NO_EARLY_EXIT"] = "1"   # read by the library at every launch
-            _, cms, _, tms, tmv = timed(args.rel_cutoff, 3, 1)
-            del os.environ["GANON_HIP_NO_EARLY_EXIT"]
-            variants["no_early_exit"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
-                                             mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2))
-        _, cms, _, tms, tmv = timed(0.2, 3, 1)        # ganon-classify's own default (Config.hpp:32): T ~ 4, nothing to exit from
-        variants["rel_cutoff_0.2"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
-                                          mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches=int(tmv["n_matches"]))
-        # ... and with the binary's low cutoff under the filter rules `ganon classify` passes by default (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5,
-        # /root/reference/src/ganon/config.py), the pre-pass of filter_matches running on the device (gn_stream_set_postfilter);
-        # per-target fpr 0.5^h = what the Bernoulli(0.5) bits are
-        st.set_postfilter(0.1, 1e-5, np.full(wl.bins // bpt, 1.0 - (1.0 - 0.5 ** spec["h"]) ** bpt, dtype=np.float64))
-        if os.environ.get("GANON_BENCH_AB_PREDROP"):  # A/B: every match written, then judged
-            os.environ["GANON_HIP_NO_PREDROP"] = "1"
+        # the same resident batch under the two conditions the headline does not show (not part of `value`)
+        if headline and not args.no_variants and part is None and kind == "flat":
+            variants = {}
+            bpt = spec.get("bins_per_target", 1)
+            if bpt == 1:  # (the split-bin kernel has no early exit)
+                os.environ["GANON_HIP_NO_EARLY_EXIT"] = "1"   # read by the library at every launch
+                _, cms, _, tms, tmv = timed(args.rel_cutoff, 3, 1)
+                del os.environ["GANON_HIP_NO_EARLY_EXIT"]
+                variants["no_early_exit"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
+                                                 mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2))
+            _, cms, _, tms, tmv = timed(0.2, 3, 1)        # ganon-classify's own default (Config.hpp:32): T ~ 4, nothing to exit from
+            variants["rel_cutoff_0.2"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
+                                              mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches=int(tmv["n_matches"]))
+            # ... and with the binary's low cutoff under the filter rules `ganon classify` passes by default (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5,
+            # /root/reference/src/ganon/config.py), the pre-pass of filter_matches running on the device (gn_stream_set_postfilter);
+            # per-target fpr 0.5^h = what the Bernoulli(0.5) bits are
+            st.set_postfilter(0.1, 1e-5, np.full(wl.bins // bpt, 1.0 - (1.0 - 0.5 ** spec["h"]) ** bpt, dtype=np.float64))
+            if os.environ.get("GANON_BENCH_AB_PREDROP"):  # A/B: every match written, then judged
+                os.environ["GANON_HIP_NO_PREDROP"] = "1"
+                _, cms, _, tms, tmv = timed(0.2, 3, 1)
+                del os.environ["GANON_HIP_NO_PREDROP"]
+                _, d_fil, d_fpr = st.fetch_postfilter()
+                variants["wrapper_defaults_every_match_written"] = dict(ms_per_step=round(float(np.mean(tms)), 3),
+                                                                        count_select_ms=round(float(np.mean(cms)), 3), dropped_rel_filter=d_fil,
+                                                                        dropped_fpr_query=d_fpr, matches_after=int(st.fetch()[2][-1]))
             _, cms, _, tms, tmv = timed(0.2, 3, 1)
-            del os.environ["GANON_HIP_NO_PREDROP"]
             _, d_fil, d_fpr = st.fetch_postfilter()
-            variants["wrapper_defaults_every_match_written"] = dict(ms_per_step=round(float(np.mean(tms)), 3),
-                                                                    count_select_ms=round(float(np.mean(cms)), 3), dropped_rel_filter=d_fil,
-                                                                    dropped_fpr_query=d_fpr, matches_after=int(st.fetch()[2][-1]))
-        _, cms, _, tms, tmv = timed(0.2, 3, 1)
-        _, d_fil, d_fpr = st.fetch_postfilter()
-        variants["wrapper_defaults_device_filter_matches"] = dict(
-            thresholds="--rel-cutoff 0.2 (the binary's default) --rel-filter 0.1 --fpr-query 1e-5 (what `ganon classify` passes)",
-            ms_per_step=round(float(np.mean(tms)), 3), count_select_ms=round(float(np.mean(cms)), 3),
-            mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches_before=int(variants["rel_cutoff_0.2"]["matches"]),
-            dropped_rel_filter=d_fil, dropped_fpr_query=d_fpr, matches_after=int(st.fetch()[2][-1]))
-        st.set_postfilter(None)
-        result["variants"] = variants
-        step(args.rel_cutoff)  # leave the headline batch in the stream for the checks below
+            variants["wrapper_defaults_device_filter_matches"] = dict(
+                thresholds="--rel-cutoff 0.2 (the binary's default) --rel-filter 0.1 --fpr-query 1e-5 (what `ganon classify` passes)",
+                ms_per_step=round(float(np.mean(tms)), 3), count_select_ms=round(float(np.mean(cms)), 3),
+                mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches_before=int(variants["rel_cutoff_0.2"]["matches"]),
+                dropped_rel_filter=d_fil, dropped_fpr_query=d_fpr, matches_after=int(st.fetch()[2][-1]))
+            st.set_postfilter(None)
+            result["variants"] = variants
+            step(args.rel_cutoff)  # leave the headline batch in the stream for the checks below
 
-    if not args.no_variants and kind == "hibf" and os.environ.get("GANON_BENCH_HIBF_LOW_CUTOFF"):
-        # A/B on request (needs --reads <= 500000: 3 000 chance matches per read at this cutoff): --rel-cutoff 0.2 plain, with the
-        # filter_matches pre-pass judging every pair after the sort, and with the pairs it is bound to drop left out of the sort
-        variants = {}
-        _, cms, _, tms, tmv = timed(0.2, 3, 1)
-        variants["rel_cutoff_0.2"] = dict(ms_per_step=round(float(np.mean(tms)), 3), matches=int(tmv["n_matches"]))
-        st.set_postfilter(0.1, 1e-5, np.full(spec["user_bins"], 0.05, dtype=np.float64))
-        for tag, env in (("every_pair_sorted", "1"), ("device_filter_matches", None)):
-            if env:
-                os.environ["GANON_HIP_NO_PREDROP"] = env
+        if headline and not args.no_variants and kind == "hibf" and os.environ.get("GANON_BENCH_HIBF_LOW_CUTOFF"):
+            # A/B on request (needs --reads <= 500000: 3 000 chance matches per read at this cutoff): --rel-cutoff 0.2 plain, with the
+            # filter_matches pre-pass judging every pair after the sort, and with the pairs it is bound to drop left out of the sort
+            variants = {}
             _, cms, _, tms, tmv = timed(0.2, 3, 1)
-            os.environ.pop("GANON_HIP_NO_PREDROP", None)
-            _, d_fil, d_fpr = st.fetch_postfilter()
-            variants["low_cutoff_" + tag] = dict(ms_per_step=round(float(np.mean(tms)), 3), dropped_rel_filter=d_fil, dropped_fpr_query=d_fpr,
-                                                 matches_after=int(st.fetch()[2][-1]))
-        st.set_postfilter(None)
-        result["variants"] = variants
-        step(args.rel_cutoff)
+            variants["rel_cutoff_0.2"] = dict(ms_per_step=round(float(np.mean(tms)), 3), matches=int(tmv["n_matches"]))
+            st.set_postfilter(0.1, 1e-5, np.full(spec["user_bins"], 0.05, dtype=np.float64))
+            for tag, env in (("every_pair_sorted", "1"), ("device_filter_matches", None)):
+                if env:
+                    os.environ["GANON_HIP_NO_PREDROP"] = env
+                _, cms, _, tms, tmv = timed(0.2, 3, 1)
+                os.environ.pop("GANON_HIP_NO_PREDROP", None)
+                _, d_fil, d_fpr = st.fetch_postfilter()
+                variants["low_cutoff_" + tag] = dict(ms_per_step=round(float(np.mean(tms)), 3), dropped_rel_filter=d_fil, dropped_fpr_query=d_fpr,
+                                                     matches_after=int(st.fetch()[2][-1]))
+            st.set_postfilter(None)
+            result["variants"] = variants
+            step(args.rel_cutoff)
 
-    if rank == 0:
-        import bench_cpu
-        if args.check:
-            if kind == "hibf":
-                ok, detail = bench_cpu.spot_check_hibf(wl, flt, nh, status, mo, matches, min(args.check, 600))
-            else:
-                ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check,
-                                                  target_offset=(sl_idx * spec["bins"] if kind == "slice" else 0),
-                                                  bins_per_target=spec.get("bins_per_target", 1),
-                                                  read_range=(lo, hi) if kind == "slice" else None,
-                                                  own_targets_only=kind == "slice" and world > 1)
-            result["config"]["oracle_spot_check"] = detail
-            if not ok:
-                log("bench.py: ORACLE SPOT CHECK FAILED:", detail)
-                result["value"] = None
-        if not args.no_cpu_baseline and world == 1 and kind == "flat" and wl.filter_bytes <= (16 << 30) and spec.get("bins_per_target", 1) == 1:
-            try:  # the CPU baseline is an N=1 measurement on a filter the host can hold
-                result["cpu_baseline"] = bench_cpu.cpu_baseline(wl, flt, args.cpu_sample)
-            except Exception as e:  # noqa: BLE001 -- a reported extra; never lose the GPU line over it
-                log("bench.py: cpu_baseline failed:", repr(e))
-                result["cpu_baseline"] = None
-        result.setdefault("cpu_baseline", None)
-    if part is not None:
-        part.local.close()
-    else:
-        st.destroy()
-    flt.free()
-    if rank == 0:
-        if not args.no_extra and world == 1 and args.workload == "flat8g" and not args.reads and not args.rows:
-            result["other_workloads"] = [run_extra(w, args.extra_timeout) for w in EXTRA_WORKLOADS]
+        if rank == 0:
+            import bench_cpu
+            if args.check:
+                if kind == "hibf":
+                    ok, detail = bench_cpu.spot_check_hibf(wl, flt, nh, status, mo, matches, min(args.check, 600))
+                else:
+                    ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check,
+                                                      target_offset=(sl_idx * spec["bins"] if kind == "slice" else 0),
+                                                      bins_per_target=spec.get("bins_per_target", 1),
+                                                      read_range=(lo, hi) if kind == "slice" else None,
+                                                      own_targets_only=kind == "slice" and world > 1)
+                result["config"]["oracle_spot_check"] = detail
+                if not ok:
+                    log("bench.py: ORACLE SPOT CHECK FAILED:", detail)
+                    result["value"] = None
+            if headline and not args.no_cpu_baseline and world == 1 and kind == "flat" and wl.filter_bytes <= (16 << 30) and spec.get("bins_per_target", 1) == 1:
+                try:  # the CPU baseline is an N=1 measurement on a filter the host can hold
+                    result["cpu_baseline"] = bench_cpu.cpu_baseline(wl, flt, args.cpu_sample)
+                except Exception as e:  # noqa: BLE001 -- a reported extra; never lose the GPU line over it
+                    log("bench.py: cpu_baseline failed:", repr(e))
+                    result["cpu_baseline"] = None
+            if headline:
+                result.setdefault("cpu_baseline", None)
+        if part is not None:
+            part.close()
+        else:
+            st.destroy()
+        flt.free()
+        return result
+
+    result = run_one(args.workload, True)
+    default_run = not args.no_extra and args.workload == "flat8g" and not args.reads and not args.rows
+    extras_multi = EXTRA_WORKLOADS_MULTI
+    if os.environ.get("GANON_BENCH_EXTRAS"):   # dry runs: small stand-ins for the extras, e.g. "tiny,slice_tiny"
+        extras_multi = [w for w in os.environ["GANON_BENCH_EXTRAS"].split(",") if w in WORKLOADS]
+        default_run = not args.no_extra
+    if default_run and world == 1 and rank == 0:
+        result["other_workloads"] = [run_extra(w, args.extra_timeout) for w in EXTRA_WORKLOADS]
+    elif default_run and world > 1:
+        # the configs BASELINE.json quotes its scaling target on, with the real world size (every rank takes part)
+        others = []
+        for w in extras_multi:
+            t0 = time.time()
+            try:
+                r = run_one(w, False)
+                others.append(slim(w, r, time.time() - t0))
+            except Exception as e:  # noqa: BLE001 -- the headline line is never lost over an extra
+                log(f"[rank {rank}] bench.py: workload {w} failed:", repr(e))
+                others.append({"workload": w, "error": repr(e)[:400]})
+                break   # (the ranks may be out of step now: no further collective work)
+        result["other_workloads"] = others
     # RCCL writes a version banner through C stdio (buffered until exit when stdout is a pipe).  Every rank pushes its
     # buffered C output out BEFORE the last barrier, rank 0 prints the JSON line after it: the JSON is the last line of
     # the job's stdout.
@@ -377,8 +442,8 @@ def main() -> int:
     except Exception:  # noqa: BLE001
         pass
     sys.stdout.flush()
-    if world > 1 or kind == "slice":
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         gdist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -722,6 +722,9 @@ extern "C" int gn_stream_destroy(gn_stream* s)
     for (auto& e : s->ev_chunk)
         if (e)
             hipEventDestroy(e);
+    for (auto& e : s->ev_lvl)
+        if (e)
+            hipEventDestroy(e);
     if (s->ev_sync)
         hipEventDestroy(s->ev_sync);
     if (s->ev_count0)
@@ -796,8 +799,8 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
         ok(gn_dmalloc(&s->d_work[1], s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer, s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer2, s->work_cap));
-        ok(gn_dmalloc(&s->d_hctr, 3 * (GN_HIBF_MAXDEPTH + 1)));
-        ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), 3 * (GN_HIBF_MAXDEPTH + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+        ok(gn_dmalloc(&s->d_hctr, 4 * (GN_HIBF_MAXDEPTH + 1)));
+        ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), 4 * (GN_HIBF_MAXDEPTH + 1) * sizeof(unsigned long long), hipHostMallocDefault));
     }
     ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), GN_NCTR * sizeof(unsigned long long), hipHostMallocDefault));
     if (e != hipSuccess)

@@ -63,7 +63,8 @@ struct GnGatherParams
 };
 
 // read r of the result = its segment of part 0, then of part 1, ...; moff[r] = sum of the parts' offsets (a sum of
-// exclusive prefix sums is the exclusive prefix sum of the sums: no scan is needed)
+// exclusive prefix sums is the exclusive prefix sum of the sums: no scan is needed).  Part i's read r is
+// in[i][off[i][r] - off[i][0] .. off[i][r+1] - off[i][0]).
 __global__ __launch_bounds__(256) void gn_gather_parts_kernel(GnGatherParams p)
 {
     const uint64_t r     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void gn_gather_parts_kernel(GnGatherParams p)
     if (r <= p.n_reads)
     {
         for (uint32_t i = 0; i < p.k; ++i)
-            o += p.off[i][r];
+            o += p.off[i][r] - p.off[i][0]; // (a part's offsets may start anywhere: a slice of a longer offset array)
         p.moff[r] = o;
     }
     if (valid)
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void gn_gather_parts_kernel(GnGatherParams p)
         uint64_t w = o;
         for (uint32_t i = 0; i < p.k; ++i)
         {
-            const uint64_t b = p.off[i][r], e = p.off[i][r + 1];
+            const uint64_t base = p.off[i][0], b = p.off[i][r] - base, e = p.off[i][r + 1] - base;
             for (uint64_t j = b; j < e; ++j)
             {
                 gn_match m = p.in[i][j];
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256) void gn_gather_parts_kernel(GnGatherParams p)
                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o, (int)L);
         for (uint32_t i = 0; i < p.k; ++i)
         {
-            const uint64_t  b   = p.off[i][rr];
-            const uint32_t  cs  = (uint32_t)(p.off[i][rr + 1] - b);
+            const uint64_t  b   = p.off[i][rr] - p.off[i][0];
+            const uint32_t  cs  = (uint32_t)(p.off[i][rr + 1] - p.off[i][rr]);
             const uint32_t* map = p.map[i];
             for (uint32_t j = lane; j < cs; j += 64)
             {
@@ -345,6 +346,71 @@ extern "C" int gn_gather_run(gn_gather* g, gn_stream* const* streams, uint32_t n
     g->n_reads   = n;
     g->n_matches = total;
     g->ran       = true;
+    return GN_OK;
+}
+
+// The same concatenation over parts that are plain device buffers on the gather's device -- the receive buffers of the
+// multi-process exchange (ganon_amd/partition.py: one process per GPU, the parts' records arrive through RCCL's
+// all-to-all): d_off[i] = n_reads+1 offsets of part i (any origin: read r = d_matches[i][d_off[i][r]-d_off[i][0] ...)).
+// The caller makes sure the buffers are complete (its own stream is synchronised) before the call.
+extern "C" int gn_gather_run_buffers(gn_gather* g, const uint64_t* const* d_off, const gn_match* const* d_matches, const uint64_t* n_matches,
+                                     uint32_t n_parts, uint32_t n_reads)
+{
+    if (!g || !d_off || !d_matches || !n_matches || n_parts != g->n_parts)
+        return gn_fail(GN_EINVAL, "gn_gather_run_buffers: the gather was created for %u parts", g ? g->n_parts : 0u);
+    g->ran = false;
+    GN_HIP(hipSetDevice(g->device));
+    GnGatherParams p{};
+    p.k       = n_parts;
+    p.n_reads = n_reads;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_parts; ++i)
+    {
+        if (!d_off[i] || (!d_matches[i] && n_matches[i]))
+            return gn_fail(GN_EINVAL, "gn_gather_run_buffers: part %u has no buffers", i);
+        p.off[i] = d_off[i];
+        p.in[i]  = d_matches[i];
+        p.map[i] = g->d_map[i];
+        total += n_matches[i];
+    }
+    int rc = gn_gather_reserve(&g->d_moff, &g->moff_cap, (uint64_t)n_reads + 1);
+    if (rc)
+        return rc;
+    rc = gn_gather_reserve(&g->d_out, &g->out_cap, total);
+    if (rc)
+        return rc;
+    p.moff = g->d_moff;
+    p.out  = g->d_out;
+    hipLaunchKernelGGL(gn_gather_parts_kernel, dim3((unsigned)(((uint64_t)n_reads + 1 + 255) / 256)), dim3(256), 0, g->st, p);
+    GN_HIP(hipGetLastError());
+    g->n_reads    = n_reads;
+    g->n_matches  = total;
+    g->peer_bytes = 0;
+    g->ran        = true;
+    return GN_OK;
+}
+
+// per-read offsets (n_reads+1) of the stream's grouped matches, in device memory: what gn_stream_device_matches leaves out
+extern "C" int gn_stream_device_offsets(gn_stream* s, const uint64_t** d_match_off)
+{
+    if (!s || !d_match_off)
+        return gn_fail(GN_EINVAL, "null argument");
+    int rc = gn_finish_batch(s);
+    if (rc)
+        return rc;
+    GN_HIP(hipSetDevice(s->device));
+    const uint32_t wpr = s->f->is_hibf ? 1u : (uint32_t)s->f->geom.wpr, n = s->n_reads;
+    if (s->pf_on && (!s->pf_joint || s->pf_joint_done))
+        *d_match_off = s->d_slot_cnt;
+    else if (wpr == 1)
+        *d_match_off = s->d_seg_off;
+    else
+    {
+        hipLaunchKernelGGL(gn_gather_pick_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, s->st, s->d_seg_off, wpr, n, s->d_slot_cnt);
+        GN_HIP(hipGetLastError());
+        GN_HIP(hipStreamSynchronize(s->st));
+        *d_match_off = s->d_slot_cnt;
+    }
     return GN_OK;
 }
 

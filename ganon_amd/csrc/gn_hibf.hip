@@ -1202,6 +1202,13 @@ int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const i
             }
         for (uint32_t l = 0; l < deepest; ++l)
             f->level_gp[l] = (uint32_t)(std::max_element(votes[l].begin(), votes[l].end()) - votes[l].begin());
+        f->level_bytes.assign(deepest, 0ull);
+        f->level_row_bytes.assign(deepest, 0u);
+        for (uint32_t i = 0; i < n_ibf; ++i)
+            if (depth[i] >= 1)
+                f->level_bytes[depth[i] - 1] += dev[i].S * (uint64_t)dev[i].W * 8ull;
+        for (uint32_t l = 0; l < deepest; ++l)
+            f->level_row_bytes[l] = 8u << f->level_gp[l];
     }
     GN_HIP(hipMalloc(reinterpret_cast<void**>(&f->d_hibf), n_ibf * sizeof(GnHibfIbfDev)));
     GN_HIP(hipMemcpy(f->d_hibf, dev.data(), n_ibf * sizeof(GnHibfIbfDev), hipMemcpyHostToDevice));
@@ -1281,6 +1288,8 @@ static void gn_hibf_launch_pack(const GnHibfLevelParams& p, bool level0, uint32_
 }
 
 // Runs all levels back to back (queue lengths stay on the device), synchronises ONCE, then sorts/groups the matches.
+int gn_finish_batch(gn_stream* s); // gn_capi.hip
+
 int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
 {
     int rc = gn_hibf_ensure_sort_buffers(s);
@@ -1295,7 +1304,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         return gn_fail(GN_ERANGE, "read index and user bin do not fit one 64-bit sort key");
     GN_HIP(hipMemsetAsync(s->d_ctr + 2, 0, 2 * sizeof(unsigned long long), st)); // algo bytes, (unused)
     GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
-    GN_HIP(hipMemsetAsync(s->d_hctr, 0, 3 * NL * sizeof(unsigned long long), st));
+    GN_HIP(hipMemsetAsync(s->d_hctr, 0, 4 * NL * sizeof(unsigned long long), st));
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
     const uint32_t h      = f->ibfs[0].h;
     // tests / A-B: skip the packed kernel (the per-item register kernel takes whole levels), or both (LDS kernel only)
@@ -1305,8 +1314,17 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n, s->d_hctr,
                            s->long_reads ? 1u : 0u);
     const uint32_t reg_bpc = getenv("GANON_HIP_HIBF_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_HIBF_BPC")) : 0u; // 0 = occupancy
+    s->hibf_levels_run = 0;
     for (uint32_t lvl = 0; lvl < depth && n; ++lvl)
     {
+        if (lvl < GN_HIBF_TIMED_LEVELS)
+        {
+            if (!s->ev_lvl[lvl])
+                GN_HIP(hipEventCreate(&s->ev_lvl[lvl]));
+            GN_HIP(hipEventRecord(s->ev_lvl[lvl], st));
+        }
+        if (lvl > 0) // algorithmic bytes so far (cumulative), for the per-level figures
+            GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (lvl - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         GnHibfLevelParams p{};
         p.ibfs        = f->d_hibf;
         p.hashes      = s->d_hashes;
@@ -1370,12 +1388,21 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         hipLaunchKernelGGL(gn_hibf_level_kernel, dim3((uint32_t)f->n_cu * (wpb == 4 ? 8u : 16u)), dim3(wpb * 64), lds, st, p);
         GN_HIP(hipGetLastError());
     }
+    if (n)
+    {
+        const uint32_t last = depth < GN_HIBF_TIMED_LEVELS ? depth : GN_HIBF_TIMED_LEVELS;
+        if (!s->ev_lvl[last])
+            GN_HIP(hipEventCreate(&s->ev_lvl[last]));
+        GN_HIP(hipEventRecord(s->ev_lvl[last], st));
+        GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (depth - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+        s->hibf_levels_run = depth;
+    }
     // the one synchronisation of the batch: queue lengths (overflow check) and the match cursor (sort size)
-    GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, 3 * NL * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, 4 * NL * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     GN_HIP(hipStreamSynchronize(st));
     uint64_t worst = 0;
-    for (uint32_t i = 0; i < 3 * NL; ++i)
+    for (uint32_t i = 0; i < 3 * NL; ++i) // (the fourth row holds byte counts, not queue lengths)
         worst = std::max<uint64_t>(worst, s->h_hctr[i]);
     if (worst > s->work_cap)
     {
@@ -1463,6 +1490,46 @@ int gn_hibf_dense(gn_stream* s, uint32_t rb, uint32_t re, uint16_t* counts)
         const uint32_t r = (uint32_t)(keys[i] >> ub_bits);
         if (r >= rb && r < re)
             counts[(size_t)(r - rb) * f->n_user_bins + (uint32_t)(keys[i] & ((1ULL << ub_bits) - 1ULL))] = (uint16_t)vals[i];
+    }
+    return GN_OK;
+}
+
+// Per tree level of the last HIBF batch: time of the level's kernels (hipEvents on the stream), algorithmic row bytes
+// n*h*W*8 summed over the items of the level, the bytes of the IBFs at that depth (a level whose tables fit the 256 MiB
+// Infinity Cache is not HBM bound) and their usual row width.  Levels beyond GN_HIBF_TIMED_LEVELS share the last stamp.
+extern "C" int gn_stream_hibf_levels(gn_stream* s, uint32_t* n_levels, float* ms, uint64_t* algo_bytes, uint64_t* table_bytes,
+                                     uint32_t* row_bytes, uint32_t cap)
+{
+    if (!s || !n_levels)
+        return gn_fail(GN_EINVAL, "null argument");
+    if (!s->f->is_hibf)
+        return gn_fail(GN_EINVAL, "gn_stream_hibf_levels: the stream's filter is not an HIBF");
+    int rc = gn_finish_batch(s);
+    if (rc)
+        return rc;
+    const uint32_t NL = GN_HIBF_MAXDEPTH + 1;
+    const uint32_t timed = s->hibf_levels_run < GN_HIBF_TIMED_LEVELS ? s->hibf_levels_run : GN_HIBF_TIMED_LEVELS;
+    *n_levels = timed;
+    uint64_t prev = 0;
+    for (uint32_t l = 0; l < timed && l < cap; ++l)
+    {
+        const bool last = l + 1 == timed;
+        if (ms)
+        {
+            ms[l] = 0.f;
+            hipEventElapsedTime(&ms[l], s->ev_lvl[l], s->ev_lvl[l + 1]);
+        }
+        const uint64_t cum = s->h_hctr[3 * NL + (last ? s->hibf_levels_run - 1 : l)];
+        if (algo_bytes)
+            algo_bytes[l] = cum - prev;
+        prev = cum;
+        uint64_t tb = 0;
+        for (uint32_t x = l; x < (last ? (uint32_t)s->f->level_bytes.size() : l + 1); ++x)
+            tb += s->f->level_bytes[x];
+        if (table_bytes)
+            table_bytes[l] = tb;
+        if (row_bytes)
+            row_bytes[l] = s->f->level_row_bytes[l];
     }
     return GN_OK;
 }

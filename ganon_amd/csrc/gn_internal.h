@@ -13,6 +13,7 @@
 // candidate-driven select of the generic count kernel: targets with more bins than this are scanned from a list
 #define GN_CAND_NBIG 4u
 #define GN_HIBF_MAXDEPTH 64
+#define GN_HIBF_TIMED_LEVELS 8 // tree levels with a time stamp of their own (gn_stream_hibf_levels)
 #define GN_PF_MAX_JOINT 16   // filters of one hierarchy level in a joint filter_matches pre-pass, per device
 #define GN_PF_MAX_DEVICES 16 // devices a joint pass spans (column parts of a bin-range partitioned filter)
 #define GN_LONG_BLOCKS 128u // workgroups (and uint32 count slabs) of the long-read kernel
@@ -221,6 +222,8 @@ struct gn_filter
     uint32_t               max_bins = 0;
     uint32_t               max_depth = 0;
     std::vector<uint32_t>  level_gp;  // per tree level: log2(lanes per row) most of its IBFs have (packed kernel)
+    std::vector<uint64_t>  level_bytes; // per tree level: bytes of the IBFs at that depth (is the level's table cache resident?)
+    std::vector<uint32_t>  level_row_bytes; // per tree level: row bytes most of its IBFs have
 };
 
 struct gn_stream
@@ -267,6 +270,8 @@ struct gn_stream
     void*         d_sort_tmp = nullptr;
     size_t        sort_tmp_bytes = 0;
     uint64_t      hibf_cap = 0;
+    hipEvent_t    ev_lvl[GN_HIBF_TIMED_LEVELS + 1]{}; // HIBF: start of every tree level's kernels (and the end of the last)
+    uint32_t      hibf_levels_run = 0;
     // reads with more than 65 535 minimisers (gn_stream_set_long_reads): list, counter, uint32 count slabs of the long kernel
     bool                long_reads = false;
     uint32_t*           d_long_list = nullptr;

@@ -22,7 +22,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_fetch_postfilter", "gn_streams_postfilter_joint", "gn_stream_set_long_reads", "gn_stream_device_matches",
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
-               "gn_gather_destroy", "gn_device_memory"]
+               "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -103,6 +103,9 @@ def load_library():
     L.gn_gather_fetch.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.gn_gather_device_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.gn_gather_destroy.argtypes = [vp]
+    L.gn_gather_run_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp, u32, u32]
+    L.gn_stream_device_offsets.argtypes = [vp, C.POINTER(vp)]
+    L.gn_stream_hibf_levels.argtypes = [vp, C.POINTER(u32), vp, vp, vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
     for name in ABI_SYMBOLS:
         if name != "gn_last_error":
@@ -181,6 +184,15 @@ class HipGather:
         arr = (C.c_void_p * len(streams))(*[st._h for st in streams])
         self.n_reads = streams[0].n_reads
         _check(load_library().gn_gather_run(self._h, arr, len(streams)))
+
+    def run_buffers(self, off_ptrs: Sequence[int], match_ptrs: Sequence[int], n_matches: Sequence[int], n_reads: int) -> None:
+        """gn_gather_run_buffers: parts given as raw device pointers (offsets, records) on the gather's device"""
+        k = len(off_ptrs)
+        a = (C.c_void_p * k)(*[int(x) for x in off_ptrs])
+        b = (C.c_void_p * k)(*[int(x) if x else None for x in match_ptrs])
+        nm = np.asarray(n_matches, dtype=np.uint64)
+        self.n_reads = int(n_reads)
+        _check(load_library().gn_gather_run_buffers(self._h, a, b, _p(nm), k, int(n_reads)))
 
     def fetch(self):
         """-> (match_off u64[n+1], matches MATCH_DTYPE[m]) grouped by read, ascending target"""
@@ -401,6 +413,16 @@ class HipStream:
                                         "version": 2}
         return torch.as_tensor(_Dev(), device=f"cuda:{device_index}")
 
+    def device_offsets(self, device_index: int = 0):
+        """the n_reads+1 per-read offsets that go with device_records(), as an int64 torch tensor ALIASING the library's buffer"""
+        import torch
+        ptr = C.c_void_p()
+        _check(load_library().gn_stream_device_offsets(self._h, C.byref(ptr)))
+
+        class _Dev:
+            __cuda_array_interface__ = {"data": (int(ptr.value), False), "shape": (self.n_reads + 1,), "typestr": "<i8", "version": 2}
+        return torch.as_tensor(_Dev(), device=f"cuda:{device_index}")
+
     def fetch_hashes(self):
         """-> (hash_off u64[n+1], hashes u64[total]) in emission order (parity tap)."""
         L = load_library()
@@ -423,6 +445,17 @@ class HipStream:
         return dict(ms_minimiser=t.ms_minimiser, ms_count=t.ms_count, ms_total=t.ms_total, n_hashes=t.n_hashes,
                     algo_bytes=t.algo_bytes, n_matches=t.n_matches, n_count_launches=t.n_count_launches,
                     fetched_bytes=t.fetched_bytes)
+
+    def hibf_levels(self):
+        """per tree level of the last HIBF batch: [dict(ms, algo_bytes, table_bytes, row_bytes)] (gn_stream_hibf_levels)"""
+        cap = 8
+        n = C.c_uint32(0)
+        ms = np.zeros(cap, dtype=np.float32)
+        ab = np.zeros(cap, dtype=np.uint64)
+        tb = np.zeros(cap, dtype=np.uint64)
+        rb = np.zeros(cap, dtype=np.uint32)
+        _check(load_library().gn_stream_hibf_levels(self._h, C.byref(n), _p(ms), _p(ab), _p(tb), _p(rb), cap))
+        return [dict(ms=float(ms[i]), algo_bytes=int(ab[i]), table_bytes=int(tb[i]), row_bytes=int(rb[i])) for i in range(min(cap, n.value))]
 
     def destroy(self) -> None:
         if self._h:

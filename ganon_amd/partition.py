@@ -7,9 +7,14 @@ own columns and applies the per-read cutoff locally -- valid because a target's 
 the cutoff of select_matches is per target (/root/reference/src/ganon-classify/GanonClassify.cpp:516-527).
 The only exchange step is one variable-size all-to-all of sparse (read, target, count) records (12 bytes each) to
 the rank that owns the read (contiguous read ranges), over RCCL/xGMI with the `nccl` backend (gloo in the CPU
-tests).  With a HIP local filter the records never visit the host on the way: the library's device match buffer
-is wrapped as a tensor, target ids are made global and the per-owner split points are found on the device, RCCL
-sends straight from HBM, and the owner sorts what it received on the device.
+tests), next to a fixed-size all-to-all of the owners' per-read offsets.  With a HIP local filter the records never
+visit the host: RCCL sends straight from the library's device match buffer (wrapped as a tensor, no copy), the
+per-owner split points are read off the library's device offsets, and the owner concatenates what it received per
+read, source rank after source rank -- ascending target, because slices ascend with the rank -- with the same kernel
+the single-process product uses (gn_gather_run_buffers), which also rewrites part-local target ids.  One host
+synchronisation per batch: the world x world count matrix (torch wants split sizes as Python ints).
+This module is the ONE-PROCESS-PER-GPU form of the partition (bench.py under torchrun); `ganon-classify` does the same
+inside one process with hipMemcpyPeerAsync between its devices (host/backend_hip.cpp, gn_gather_run).
 A boundary word shared by two ranks is simply held by both (8 bytes per row); the foreign bins in it are mapped to
 "no target" locally.  HIBFs cannot be column-sliced this way: replicas only.
 
@@ -100,57 +105,66 @@ def read_owner_ranges(n_reads: int, world: int) -> np.ndarray:
     return np.array([(n_reads * g) // world for g in range(world + 1)], dtype=np.int64)
 
 
-def _all_to_all_records(send, send_counts, world: int, group):
-    """send: int32 tensor [m, 3] ordered by destination rank; send_counts: int64 tensor [world] on the comm device"""
+def merge_parts_numpy(offs, recs, maps, read_base: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """numpy statement of gn_gather (csrc/gn_gather.hip): part i holds, for every owned read r, the records
+    recs[i][offs[i][r]-offs[i][0] : offs[i][r+1]-offs[i][0]] (grouped by read, ascending target, part-local target ids);
+    the result is read after read the parts' segments behind each other, target ids mapped through maps[i].
+    -> (match_off u64[n+1], records MATCH_DTYPE)"""
+    n = len(offs[0]) - 1
+    moff = np.zeros(n + 1, dtype=np.uint64)
+    chunks = []
+    for o, r, mp in zip(offs, recs, maps):
+        o = np.asarray(o, dtype=np.int64) - int(o[0])
+        moff += o.astype(np.uint64)
+        g = np.zeros(len(r), dtype=MATCH_DTYPE)
+        if len(r):
+            g["read"], g["count"] = r["read"], r["count"]
+            g["target"] = r["target"] if mp is None else np.asarray(mp, dtype=np.uint32)[r["target"]]
+        chunks.append(g)
+    allr = np.concatenate(chunks) if chunks else np.zeros(0, MATCH_DTYPE)
+    order = np.argsort(allr["read"], kind="stable")  # (parts were appended in order: a stable sort keeps part order per read)
+    return moff, allr[order]
+
+
+def exchange_grouped(off, rec, n_reads: int, rank: int, world: int, group=None):
+    """The exchange step.  off: int64 tensor [n_reads+1], rec: int32 tensor [m, 3] = this rank's matches of ALL reads grouped
+    by read (part-local target ids), both on the communication device.  Every record goes to the rank that owns its read
+    (contiguous read ranges); the owner gets, per source rank, the records and the per-read offsets of its reads.
+      1. counts: one all-gather of the world x world matrix "records from rank s for the reads of rank d" -- its copy to
+         the host is the ONLY host synchronisation of the step (torch's all-to-all takes its split sizes as Python ints);
+      2. offsets: all-to-all of off[lo_d .. hi_d] per owner d (sizes follow from the read ranges alone);
+      3. records: all-to-all straight from the caller's buffer (records are ordered by read, hence by owner).
+    -> (parts_off [world tensors of n_own+1], parts_rec [world tensors of c_s x 3])"""
     import torch
     import torch.distributed as dist
 
-    rc = torch.empty(world, dtype=torch.int64, device=send.device)
-    dist.all_to_all_single(rc, send_counts.to(send.device), group=group)
-    recv_counts = [int(x) for x in rc.cpu().tolist()]
-    recv = torch.empty((sum(recv_counts), 3), dtype=torch.int32, device=send.device)
-    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts,
-                           input_split_sizes=[int(x) for x in send_counts.cpu().tolist()], group=group)
-    return recv
-
-
-def _sorted_records(recv) -> np.ndarray:
-    """int32 [m, 3] tensor -> MATCH_DTYPE records sorted by (read, target); the sort runs where the tensor lives"""
-    import torch
-
-    if recv.shape[0]:
-        key = (recv[:, 0].to(torch.int64) & 0xFFFFFFFF) << 32 | (recv[:, 1].to(torch.int64) & 0xFFFFFFFF)
-        recv = recv[torch.argsort(key)]
-    got = np.ascontiguousarray(recv.cpu().numpy())
-    return got.view(np.uint32).reshape(-1, 3).view(MATCH_DTYPE).reshape(-1).copy()
-
-
-def exchange_matches(local: np.ndarray, n_reads: int, rank: int, world: int, device: str = "cpu", group=None) -> np.ndarray:
-    """local: MATCH_DTYPE records with GLOBAL target ids, grouped by read (ascending).  One variable-size
-    all-to-all sends every record (12 bytes, as three int32) to the owner of its read; returns the records of the
-    reads this rank owns, sorted by (read, target)."""
-    import torch
-
     ranges = read_owner_ranges(n_reads, world)
-    reads = local["read"].astype(np.int64)
-    bounds = np.searchsorted(reads, ranges, side="left")  # records are already ordered by read
-    send_counts = torch.from_numpy(np.diff(bounds).astype(np.int64))
-    flat = np.ascontiguousarray(local).view(np.uint32).reshape(-1, 3).view(np.int32)
-    send = torch.from_numpy(flat).to(device)
-    return _sorted_records(_all_to_all_records(send, send_counts, world, group))
-
-
-def exchange_matches_device(records, targets_global, n_reads: int, rank: int, world: int, group=None) -> np.ndarray:
-    """records: int32 DEVICE tensor [m, 3] (read, LOCAL target, count) ordered by read -- the library's own match
-    buffer; targets_global: int32 device tensor (local target -> global).  Remap, split and exchange on the device."""
-    import torch
-
-    rec = records.clone()
-    if rec.shape[0]:
-        rec[:, 1] = targets_global[rec[:, 1].to(torch.int64)]
-    ranges = torch.from_numpy(read_owner_ranges(n_reads, world)).to(rec.device)
-    bounds = torch.searchsorted(rec[:, 0].contiguous().to(torch.int64), ranges)
-    return _sorted_records(_all_to_all_records(rec, bounds[1:] - bounds[:-1], world, group))
+    dev = off.device
+    bounds = off[torch.from_numpy(ranges).to(dev)]
+    cnt = (bounds[1:] - bounds[:-1]).contiguous()
+    if world > 1:
+        rows = [torch.empty_like(cnt) for _ in range(world)]
+        dist.all_gather(rows, cnt, group=group)
+        mat = torch.stack(rows).cpu().numpy()          # [source][owner]
+    else:
+        mat = cnt.cpu().numpy().reshape(1, 1)
+    send_counts = [int(x) for x in mat[rank]]
+    recv_counts = [int(x) for x in mat[:, rank]]
+    n_own = int(ranges[rank + 1] - ranges[rank])
+    send_off = torch.cat([off[int(ranges[d]):int(ranges[d + 1]) + 1] for d in range(world)]).contiguous()
+    recv_off = torch.empty(world * (n_own + 1), dtype=off.dtype, device=dev)
+    recv = torch.empty((sum(recv_counts), 3), dtype=rec.dtype, device=dev)
+    if dist.is_initialized():  # (a world of one still goes through the collective: same calls, same buffers)
+        dist.all_to_all_single(recv_off, send_off, output_split_sizes=[n_own + 1] * world,
+                               input_split_sizes=[int(ranges[d + 1] - ranges[d]) + 1 for d in range(world)], group=group)
+        dist.all_to_all_single(recv, rec.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+    else:
+        recv_off.copy_(send_off)
+        recv.copy_(rec)
+    parts_off = [recv_off[s * (n_own + 1):(s + 1) * (n_own + 1)] for s in range(world)]
+    starts = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+    parts_rec = [recv[int(starts[s]):int(starts[s + 1])] for s in range(world)]
+    return parts_off, parts_rec
 
 
 class LocalFilter:
@@ -201,6 +215,9 @@ class HipLocalFilter(LocalFilter):
     def device_records(self):
         return self.st.device_records(self.dev)
 
+    def device_offsets(self):
+        return self.st.device_offsets(self.dev)
+
     def close(self):
         if self.st is not None:
             self.st.destroy()
@@ -221,7 +238,9 @@ class PartitionedIbf:
         self.local = local
         self.comm_device = comm_device
         self.group = group
-        self._tg_dev = None
+        self._maps = None     # every rank's local -> global target table (exchanged once)
+        self._gather = None   # device merge (gn_gather) of what the exchange delivered
+        self._last = None
 
     @classmethod
     def from_host_rows(cls, rows: np.ndarray, bins: int, bin_size: int, hash_funs: int, bin2target: np.ndarray, rank: int,
@@ -232,25 +251,67 @@ class PartitionedIbf:
         local = make_local(rows_local, sl.bins_local, bin_size, hash_funs, sl.bin2target_local, max(1, len(sl.targets_global)))
         return cls(sl, rank, world, local, comm_device, group)
 
-    def classify(self, bases: np.ndarray, off1: np.ndarray, off2: Optional[np.ndarray], k: int, w: int, rel_cutoff: float):
-        """-> (read_lo, read_hi, n_hashes[all reads], status[all reads], matches of the owned reads)"""
-        sl = self.slice
+    def _target_maps(self):
+        """the owner rewrites part-local target ids while it merges (gn_gather's target_map): it needs every rank's table"""
+        if self._maps is None:
+            import torch.distributed as dist
+            mine = np.ascontiguousarray(self.slice.targets_global, dtype=np.uint32)
+            if self.world > 1:
+                tables = [None] * self.world
+                dist.all_gather_object(tables, mine, group=self.group)
+                self._maps = [np.asarray(t, dtype=np.uint32) for t in tables]
+            else:
+                self._maps = [mine]
+        return self._maps
+
+    def classify(self, bases: np.ndarray, off1: np.ndarray, off2: Optional[np.ndarray], k: int, w: int, rel_cutoff: float,
+                 fetch: bool = True):
+        """-> (read_lo, read_hi, n_hashes[all reads], status[all reads], matches of the owned reads).  With fetch=False the
+        last three are None and the owned matches stay in device memory (fetch_owned() copies them out later)."""
+        import torch
         n_reads = len(off1) - 1
         out = self.local.classify(bases, off1, off2, k, w, rel_cutoff)
         ranges = read_owner_ranges(n_reads, self.world)
+        lo, hi = int(ranges[self.rank]), int(ranges[self.rank + 1])
+        maps = self._target_maps()
         rec = self.local.device_records() if self.comm_device != "cpu" else None
         if rec is not None:
-            import torch
-            if self._tg_dev is None:
-                tg = sl.targets_global if len(sl.targets_global) else np.zeros(1, np.uint32)
-                self._tg_dev = torch.from_numpy(tg.view(np.int32).copy()).to(rec.device)
-            mine = exchange_matches_device(rec, self._tg_dev, n_reads, self.rank, self.world, self.group)
+            # device-resident: the library's own match buffer and offsets are what RCCL sends; what arrives is merged per
+            # read by gn_gather_run_buffers on this rank's GPU
+            off = self.local.device_offsets()
+            parts_off, parts_rec = exchange_grouped(off, rec, n_reads, self.rank, self.world, self.group)
+            torch.cuda.current_stream().synchronize()   # the receive buffers are complete before the library reads them
+            if self._gather is None:
+                from . import HipGather
+                self._gather = HipGather(rec.device.index or 0, [m if len(m) else None for m in maps])
+            self._keep = (parts_off, parts_rec)
+            self._gather.run_buffers([t.data_ptr() for t in parts_off], [t.data_ptr() if t.numel() else 0 for t in parts_rec],
+                                     [t.shape[0] for t in parts_rec], hi - lo)
+            self._last = ("device", out)
+            if not fetch:
+                return lo, hi, None, None, None
             nh, status = out.fetch_read_info()
-        else:
-            nh, status, mo, m = out.fetch() if hasattr(out, "fetch") else out
-            glob = np.zeros(len(m), dtype=MATCH_DTYPE)
-            if len(m):
-                glob["read"], glob["count"] = m["read"], m["count"]
-                glob["target"] = sl.targets_global[m["target"]]
-            mine = exchange_matches(glob, n_reads, self.rank, self.world, self.comm_device, self.group)
-        return int(ranges[self.rank]), int(ranges[self.rank + 1]), nh, status, mine
+            return lo, hi, nh, status, self.fetch_owned()
+        nh, status, mo, m = out.fetch() if hasattr(out, "fetch") else out
+        off = torch.from_numpy(np.ascontiguousarray(mo).astype(np.int64)).to(self.comm_device)
+        flat = np.ascontiguousarray(m).view(np.uint32).reshape(-1, 3).view(np.int32)
+        parts_off, parts_rec = exchange_grouped(off, torch.from_numpy(flat).to(self.comm_device), n_reads, self.rank, self.world, self.group)
+        offs = [t.cpu().numpy() for t in parts_off]
+        recs = [np.ascontiguousarray(t.cpu().numpy()).view(np.uint32).reshape(-1, 3).view(MATCH_DTYPE).reshape(-1) for t in parts_rec]
+        _, mine = merge_parts_numpy(offs, recs, [mp if len(mp) else None for mp in maps])
+        self._last = ("host", mine)
+        return lo, hi, nh, status, mine
+
+    def fetch_owned(self) -> np.ndarray:
+        """the owned reads' matches of the last classify() (global read indices, global target ids)"""
+        kind, what = self._last
+        if kind == "host":
+            return what
+        _, m = self._gather.fetch()
+        return m.copy()
+
+    def close(self):
+        if self._gather is not None:
+            self._gather.destroy()
+            self._gather = None
+        self.local.close()

@@ -244,6 +244,14 @@ typedef struct gn_gather gn_gather;
 int gn_gather_create(int device, uint32_t n_parts, const uint32_t* const* target_map, const uint32_t* n_map, gn_gather** out);
 /* streams[i] = part i's stream, all holding the same submitted batch (gn_submit_batch / gn_stream_classify) */
 int gn_gather_run(gn_gather* g, gn_stream* const* streams, uint32_t n_streams);
+/* The same over parts that are plain DEVICE buffers on the gather's device -- the receive buffers of a multi-process job
+ * (one process per GPU, the parts' records arrive over RCCL: ganon_amd/partition.py).  d_off[i]: n_reads+1 offsets of part
+ * i, of any origin (read r of part i = d_matches[i][d_off[i][r] - d_off[i][0] .. d_off[i][r+1] - d_off[i][0])), n_matches[i]
+ * its record count.  The caller's own stream must be done with the buffers. */
+int gn_gather_run_buffers(gn_gather* g, const uint64_t* const* d_off, const gn_match* const* d_matches, const uint64_t* n_matches,
+                          uint32_t n_parts, uint32_t n_reads);
+/* per-read offsets (n_reads+1, device memory) that go with gn_stream_device_matches; valid as long as those */
+int gn_stream_device_offsets(gn_stream* s, const uint64_t** d_match_off);
 /* match_off[n_reads+1], matches[cap] grouped by read (ascending read, then ascending target); either may be NULL */
 int gn_gather_fetch(gn_gather* g, uint64_t* match_off, gn_match* matches, uint64_t cap, uint64_t* n_matches);
 /* device-resident view (valid until the next gn_gather_run) and the bytes the last run moved between devices */
@@ -272,6 +280,12 @@ int gn_stream_fetch_hashes(gn_stream* s, uint64_t* hash_off, uint64_t* hashes, u
 int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_t read_end, uint16_t* counts);
 
 int gn_stream_timings(gn_stream* s, gn_timings* t);
+/* HIBF only: the last batch per tree level (level 0 = the top IBF) -- duration of the level's kernels, algorithmic row
+ * bytes of the level (they add up to gn_timings.algo_bytes), bytes of the IBFs at that depth and their usual row width.
+ * A level whose tables fit the 256 MiB Infinity Cache is not bound by HBM; the roofline is stated per level for that
+ * reason.  Arrays of `cap` entries; *n_levels = levels of the filter's tree (at most 8 are timed separately). */
+int gn_stream_hibf_levels(gn_stream* s, uint32_t* n_levels, float* ms, uint64_t* algo_bytes, uint64_t* table_bytes,
+                          uint32_t* row_bytes, uint32_t cap);
 
 #ifdef __cplusplus
 }

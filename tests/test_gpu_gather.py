@@ -199,3 +199,42 @@ def test_gather_refuses_what_it_cannot_do(hip):
         s.destroy()
     for f, _ in parts:
         f.free()
+
+
+def test_gather_of_raw_device_buffers_with_offsets_of_any_origin(hip):
+    # gn_gather_run_buffers: what the one-process-per-GPU exchange hands over -- per source rank a slice of a longer offset
+    # array (its origin is not 0) and the records of the owner's reads only
+    import torch
+    ibf, b2t, n_targets, seqs = _case(seed=13)
+    bases, off1, _ = gu.pack_reads(seqs, None)
+    full = hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs, b2t, n_targets)
+    st = hip.HipStream(full, len(seqs), bases.size)
+    st.submit(bases, off1, None, K, W, 0.2)
+    nh, status, mo, m_full = st.fetch()
+    parts = _parts(hip, ibf, b2t, 3)
+    res = []
+    for f, sl in parts:
+        s = hip.HipStream(f, len(seqs), bases.size)
+        s.submit(bases, off1, None, K, W, 0.2)
+        res.append(s.fetch())
+        # the device views the exchange sends from: offsets and records as tensors aliasing the library's buffers
+        d_off, d_rec = s.device_offsets(0), s.device_records(0)
+        assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), res[-1][2])
+        assert np.array_equal(d_rec.cpu().numpy().view(np.uint32).reshape(-1, 3).view(hip.MATCH_DTYPE).reshape(-1), res[-1][3])
+        s.destroy()
+    g = hip.HipGather(0, [sl.targets_global for _, sl in parts])
+    for lo, hi in ((0, len(seqs)), (len(seqs) // 3, 2 * len(seqs) // 3), (len(seqs) - 5, len(seqs)), (7, 7)):
+        offs, recs = [], []
+        for _, _, mo_p, m_p in res:
+            offs.append(torch.from_numpy(mo_p[lo:hi + 1].astype(np.int64)).cuda())
+            chunk = np.ascontiguousarray(m_p[int(mo_p[lo]):int(mo_p[hi])]).view(np.uint32).reshape(-1, 3).view(np.int32)
+            recs.append(torch.from_numpy(chunk.copy()).cuda())
+        torch.cuda.synchronize()
+        g.run_buffers([t.data_ptr() for t in offs], [t.data_ptr() if t.numel() else 0 for t in recs], [t.shape[0] for t in recs], hi - lo)
+        mo2, m2 = g.fetch()
+        assert np.array_equal(mo2, mo[lo:hi + 1] - mo[lo]) and np.array_equal(m2, m_full[int(mo[lo]):int(mo[hi])]), (lo, hi)
+    g.destroy()
+    st.destroy()
+    full.free()
+    for f, _ in parts:
+        f.free()
