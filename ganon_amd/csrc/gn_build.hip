@@ -113,8 +113,8 @@ extern "C" int gn_stream_distinct_hashes(gn_stream* s, uint64_t* out, uint64_t c
         s->build_distinct = 0;
         return GN_OK;
     }
-    if (slots > 0x7FFFFFF0ull)
-        return gn_fail(GN_ERANGE, "more than 2^31 minimiser windows in one batch");
+    if (slots + slots / 8 + 1024 > 0x7FFFFFFFull) // (the sort / unique calls take their item count -- the reserved capacity -- as an int)
+        return gn_fail(GN_ERANGE, "more than 1.9 * 10^9 minimiser windows in one batch");
     int rc = gn_build_reserve(s, slots);
     if (rc)
         return rc;

@@ -165,6 +165,12 @@ int parse_args(int argc, char** argv, Config& c)
     {
         std::string a = argv[i], v;
         bool        has = false;
+        if (a.size() > 2 && a[0] == '-' && a[1] != '-') // attached short form, -k19 (what cxxopts takes as well)
+        {
+            v   = a.substr(a[2] == '=' ? 3 : 2);
+            a   = a.substr(0, 2);
+            has = true;
+        }
         if (a.rfind("--", 0) == 0)
         {
             const size_t eq = a.find('=');
@@ -682,7 +688,9 @@ bool run(Config c)
 
     counting.start();
     {
-        const unsigned           nt = std::max<unsigned>(1, std::min<unsigned>(c.threads, (unsigned)targets.size()));
+        // every hasher page-locks 64 MiB and owns a device stream with GBs of hash and sort buffers: --threads (the wrapper
+        // forwards 64 or 128 gladly) buys parser threads only up to what eight such streams keep busy
+        const unsigned           nt = std::max<unsigned>(1, std::min<unsigned>(std::min<unsigned>(c.threads, 8u), (unsigned)targets.size()));
         std::vector<Totals>      per(nt);
         std::vector<std::thread> th;
         std::atomic<size_t>      next{ 0 };
@@ -751,6 +759,13 @@ bool run(Config c)
         return false;
     }
 
+    if (p.bin_size_bits == 0 || p.hash_functions < 1 || p.hash_functions > 5)
+    {
+        // (the reference fails in the seqan3 IBF constructor: "The size of a bin must be > 0" / "hash functions must be > 0 and <= 5")
+        std::cerr << "ERROR: the parameters leave a filter of " << p.bin_size_bits << " bits per bin with " << (unsigned)p.hash_functions
+                  << " hash function(s): --filter-size / --max-fp do not fit " << targets.size() << " target(s)" << std::endl;
+        return false;
+    }
     filling.start();
     gn_filter*  flt = nullptr;
     gn_ibf_desc d{};

@@ -311,6 +311,8 @@ struct Bz2Source
     FILE*             fp = nullptr;
     Stream            st{};
     bool              open_stream = false, file_eof = false;
+    bool              broken = false; // an error is due with the next call (what was decoded before it has been delivered)
+    unsigned          streams_done = 0;
     std::vector<char> in;
 
     static std::unique_ptr<Bz2Source> open(const std::string& path, std::string& why)
@@ -354,6 +356,8 @@ struct Bz2Source
     long read(char* out, size_t want)
     {
         size_t done = 0;
+        if (broken)
+            return -1;
         while (done < want)
         {
             if (st.avail_in == 0 && !file_eof)
@@ -382,8 +386,19 @@ struct Bz2Source
             const unsigned int before = st.avail_out;
             const int          rc     = run(&st);
             done += before - st.avail_out;
+            if (rc == -5 && streams_done > 0) // BZ_DATA_ERROR_MAGIC
+            {
+                // what follows the last complete stream does not begin like a bzip2 stream (padding, garbage): the bzip2 tool
+                // warns and stops there ("trailing garbage after EOF ignored"); so does this reader
+                end(&st);
+                open_stream = false;
+                st          = Stream{};
+                file_eof    = true;
+                break;
+            }
             if (rc == 4) // BZ_STREAM_END: another stream may follow
             {
+                ++streams_done;
                 char*              keep_in = st.next_in;
                 const unsigned int keep_n  = st.avail_in;
                 end(&st);
@@ -394,7 +409,14 @@ struct Bz2Source
                 continue;
             }
             if (rc != 0) // BZ_OK
+            {
+                if (done) // what was decoded before the damage is delivered first; the error comes with the next call
+                {
+                    broken = true;
+                    return (long)done;
+                }
                 return -1;
+            }
             if (st.avail_in == 0 && file_eof) // the stream wants more than the file holds
                 return before == st.avail_out ? -1 : (long)done;
         }

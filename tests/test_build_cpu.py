@@ -158,13 +158,15 @@ def test_reference_properties_hold_for_the_sizing(mode_counts):
     (["-i", "INPUT", "-o", "x.ibf", "-k", "35", "-w", "42"], "--kmer-size has to be <= 32"),
     (["-i", "INPUT", "-o", "x.ibf", "--frobnicate", "1"], "Option '--frobnicate' does not exist"),
     (["-i", "INPUT", "-o", "x.ibf", "-k"], "is missing an argument"),
+    (["-iINPUT", "-ox.ibf", "-k35", "-w42"], "--kmer-size has to be <= 32"),          # attached short forms, as cxxopts takes them
+    (["-i=INPUT", "-ox.ibf", "-s6"], "--hash-functions must be <=5"),
 ])
 def test_command_line_validation(build_bin, tmp_path, args, msg):
     # Config.hpp:29-107 / GanonBuild.test.cpp "invalid" SECTIONs: rejected before anything is read or any device is used
     inp = tmp_path / "input.tsv"
     inp.write_text("a.fasta\tT1\n")
     (tmp_path / "empty.tsv").write_text("")
-    args = [str(inp) if a == "INPUT" else str(tmp_path / "empty.tsv") if a == "EMPTY" else a for a in args]
+    args = [a.replace("INPUT", str(inp)) if "INPUT" in a else str(tmp_path / "empty.tsv") if a == "EMPTY" else a for a in args]
     p = subprocess.run([build_bin] + args, capture_output=True, text=True, cwd=tmp_path)
     assert p.returncode == 1
     assert msg in p.stderr

@@ -177,6 +177,16 @@ def test_max_fp_and_filter_size(hip, tmp_path):
     assert sizes["fs0.1"] < sizes["fs1"]  # :287
 
 
+def test_filter_size_too_small_for_the_targets_fails_cleanly(hip, tmp_path):
+    # a --filter-size that leaves no bit per bin: the reference dies in the seqan3 IBF constructor, this build says why
+    d = tmp_path / "tiny"
+    d.mkdir()
+    inp, _, names = write_inputs(str(d), SEQS)
+    p = subprocess.run([BIN_BUILD, "-i", inp, "-o", str(d / "x.ibf"), "--filter-size", "1e-9", "--max-fp", "0"], capture_output=True, text=True)
+    assert p.returncode == 1 and ("bits per bin" in p.stderr or "filter" in p.stderr.lower()), p.stderr
+    assert not (d / "x.ibf").exists()
+
+
 def test_modes_on_the_reference_data_set(hip, tmp_path):
     # :290-352 with the reference's own mode_input.tsv and 25 gzipped genomes
     from ganon_amd import ibf_file

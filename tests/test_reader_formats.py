@@ -82,6 +82,8 @@ def _variants(d, r1):
     open(os.path.join(d, "j.fastq.bz2"), "wb").write(b"".join(bz2.compress(fq[a:b], 1) for a, b in zip(cut, cut[1:])))
     v["fastq_bz2_three_streams"] = "j.fastq.bz2"
     open(os.path.join(d, "k.fa.bz2"), "wb").write(bz2.compress(_fasta(r1, 70).encode())); v["fasta_bz2"] = "k.fa.bz2"
+    # padding / garbage behind the last stream: the bzip2 tool warns and ignores it, and so does the reader
+    open(os.path.join(d, "l.fq.bz2"), "wb").write(bz2.compress(fq) + b"\0" * 513 + b"not a stream"); v["fastq_bz2_trailing_garbage"] = "l.fq.bz2"
     return v
 
 
@@ -172,6 +174,19 @@ def _check_errors(binary, sim_db, tmp):
     p = os.path.join(tmp, "dmgbz")
     res = _run(binary, sim_db, ["--single-reads", bzf], p, check=False)
     assert "Error parsing file" in res.stderr
+    # (4d) two bzip2 streams, the second one damaged: the first stream's records are all delivered, then the error
+    two = bytearray(bz2.compress(_fastq(r1[:10]).encode()) + bz2.compress(_fastq(r1[10:]).encode()))
+    two[len(two) - 40] ^= 0xFF
+    bz2f = os.path.join(tmp, "dmg2.fq.bz2")
+    open(bz2f, "wb").write(bytes(two))
+    p = os.path.join(tmp, "dmgbz2")
+    res = _run(binary, sim_db, ["--single-reads", bz2f], p, check=False)
+    assert "Error parsing file" in res.stderr
+    _write(os.path.join(tmp, "first10.fq"), _fastq(r1[:10]))
+    p10 = os.path.join(tmp, "first10")
+    _run(binary, sim_db, ["--single-reads", os.path.join(tmp, "first10.fq")], p10)
+    got, want = _outputs(p), _outputs(p10)
+    assert got[".all"].startswith(want[".all"]) and len(got[".all"]) >= len(want[".all"])
     # (5) unknown extension
     u = os.path.join(tmp, "reads.txt")
     _write(u, _fastq(r1))
