@@ -79,6 +79,8 @@ def lib():
         L.gno_ibf_bulk_count_gathered.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
         L.gno_hibf_bulk_count.restype = None
         L.gno_hibf_bulk_count.argtypes = [C.POINTER(_HibfS), C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
+        L.gno_hibf_bulk_count_longreads.restype = None
+        L.gno_hibf_bulk_count_longreads.argtypes = [C.POINTER(_HibfS), C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
         L.gno_hibf_visited_bytes.restype = C.c_uint64
         L.gno_hibf_visited_bytes.argtypes = [C.POINTER(_HibfS), C.c_void_p, C.c_size_t, C.c_uint64]
         L.gno_binom.restype = C.c_double
@@ -253,6 +255,13 @@ class Hibf:
         hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
         res = np.zeros(max(self.n_user_bins, 1), dtype=np.uint16)
         lib().gno_hibf_bulk_count(C.byref(self._s), _ptr(hashes), len(hashes), int(threshold), _ptr(res))
+        return res[: self.n_user_bins]
+
+    def bulk_count_longreads(self, hashes: np.ndarray, threshold: int) -> np.ndarray:
+        """the agent of the reference's -DLONGREADS build: uint32 counts and sums (no wrap at 2^16)"""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        res = np.zeros(max(self.n_user_bins, 1), dtype=np.uint32)
+        lib().gno_hibf_bulk_count_longreads(C.byref(self._s), _ptr(hashes), len(hashes), int(threshold), _ptr(res))
         return res[: self.n_user_bins]
 
     def visited_bytes(self, hashes: np.ndarray, threshold: int) -> int:

@@ -274,6 +274,65 @@ void gno_hibf_bulk_count(const gno_hibf* h, const uint64_t* hashes, size_t n, ui
     hibf_impl(h, hashes, n, 0, threshold, result, NULL);  /* :520 */
 }
 
+/* The same agent as the reference's -DLONGREADS build instantiates it (GanonClassify.cpp:45-49: TIntCount = uint32_t, so
+ * value_t of counting_agent_type and `sum` at hibf.hpp:438 are 32 bits wide): per-bin counts and per-user-bin sums do not
+ * wrap at 2^16.  Per-bin counts: the uint32 counting_agent (A.2 bulk_count with uint32 counters). */
+static void ibf_bulk_count_u32(const gno_ibf* f, const uint64_t* hashes, size_t n, uint32_t* counts)
+{
+    memset(counts, 0, (f->bins ? f->bins : 1) * sizeof(uint32_t));
+    const uint64_t* rows[5];
+    for (size_t q = 0; q < n; ++q)
+    {
+        for (uint32_t i = 0; i < f->hash_funs; ++i)
+            rows[i] = f->data + gno_ibf_row(f, hashes[q], i) * f->bin_words;
+        for (uint64_t wd = 0; wd < f->bin_words; ++wd)
+        {
+            uint64_t t = ~0ULL;
+            for (uint32_t i = 0; i < f->hash_funs; ++i)
+                t &= rows[i][wd];
+            while (t)
+            {
+                const uint64_t bin = wd * 64 + (uint64_t)__builtin_ctzll(t);
+                t &= t - 1;
+                if (bin < f->bins)
+                    ++counts[bin];
+            }
+        }
+    }
+}
+
+static void hibf_impl_u32(const gno_hibf* h, const uint64_t* hashes, size_t n, int64_t ibf_idx, uint64_t threshold, uint32_t* result)
+{
+    const gno_ibf* f      = &h->ibfs[ibf_idx];
+    uint32_t*      counts = (uint32_t*)malloc((f->bins ? f->bins : 1) * sizeof(uint32_t));
+    ibf_bulk_count_u32(f, hashes, n, counts); /* :435-436 */
+    uint32_t sum = 0;                         /* value_t = uint32_t (:438) */
+    for (uint64_t bin = 0; bin < f->bins; ++bin)
+    {
+        sum += counts[bin];
+        const int64_t fidx = h->bin_to_user[ibf_idx][bin];
+        if (fidx < 0) /* merged bin :445-450 */
+        {
+            if ((uint64_t)sum >= threshold)
+                hibf_impl_u32(h, hashes, n, h->next_ibf_id[ibf_idx][bin], threshold, result);
+            sum = 0;
+        }
+        else if (bin + 1 == f->bins || fidx != h->bin_to_user[ibf_idx][bin + 1]) /* :451-458 */
+        {
+            if ((uint64_t)sum >= threshold)
+                result[fidx] = sum;
+            sum = 0;
+        }
+    }
+    free(counts);
+}
+
+void gno_hibf_bulk_count_longreads(const gno_hibf* h, const uint64_t* hashes, size_t n, uint64_t threshold, uint32_t* result)
+{
+    memset(result, 0, h->n_user_bins * sizeof(uint32_t)); /* :518 */
+    hibf_impl_u32(h, hashes, n, 0, threshold, result);    /* :520 */
+}
+
 uint64_t gno_hibf_visited_bytes(const gno_hibf* h, const uint64_t* hashes, size_t n, uint64_t threshold)
 {
     uint64_t bytes = 0;

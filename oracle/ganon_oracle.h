@@ -80,6 +80,8 @@ typedef struct
 /* result[0..n_user_bins) zeroed, then filled as counting_agent_type::bulk_count(values, threshold) */
 void gno_hibf_bulk_count(const gno_hibf* h, const uint64_t* hashes, size_t n, uint64_t threshold, uint16_t* result);
 /* sum over all visited IBFs of n*h*W*8 (algorithmic bytes) for the last call chain */
+/* value_t = uint32_t: what the reference's -DLONGREADS build instantiates (GanonClassify.cpp:45-49, hibf.hpp:438) */
+void gno_hibf_bulk_count_longreads(const gno_hibf* h, const uint64_t* hashes, size_t n, uint64_t threshold, uint32_t* result);
 uint64_t gno_hibf_visited_bytes(const gno_hibf* h, const uint64_t* hashes, size_t n, uint64_t threshold);
 
 /* ---- a-6 select_matches (GanonClassify.cpp:504-541 IBF, :543-577 HIBF) over ONE filter.

@@ -814,30 +814,10 @@ def test_long_reads_option_classifies_what_the_default_skips(hip, split_map):
 
 
 def _hibf_bulk_count_wide(hb, hashes, threshold):
-    """hierarchical_interleaved_bloom_filter.hpp:432-460 with value_t = uint32_t (the reference's -DLONGREADS build): the recursion
-    of bulk_count_impl with sums that do not wrap; per-bin counts from the oracle's 16-bit bulk_count in chunks that cannot wrap"""
-    out = {}
-
-    def visit(i):
-        f = hb.ibfs[i]
-        counts = np.zeros(f.bins, dtype=np.uint64)
-        for a in range(0, len(hashes), 60000):
-            counts += f.bulk_count(hashes[a:a + 60000]).astype(np.uint64)
-        total = 0
-        for b in range(f.bins):
-            total += int(counts[b])
-            u = hb.bin_to_user[i][b]
-            if u < 0:
-                if total >= threshold:
-                    visit(hb.next_ibf_id[i][b])
-                total = 0
-            elif b + 1 == f.bins or u != hb.bin_to_user[i][b + 1]:
-                if total >= threshold:
-                    out[int(u)] = total
-                total = 0
-
-    visit(0)
-    return out
+    """the C oracle's agent with value_t = uint32_t (hierarchical_interleaved_bloom_filter.hpp:432-460 as the reference's
+    -DLONGREADS build instantiates it): {user bin: sum} of the sums that reached the threshold"""
+    counts = hb.bulk_count_longreads(hashes, threshold)
+    return {int(u): int(counts[u]) for u in np.nonzero(counts)[0]}
 
 
 def test_long_reads_option_for_an_hibf(hip):

@@ -144,3 +144,26 @@ def test_lca_reference_vectors():
                         #  seven-node query survives and is the one actually REQUIRE'd)
                         ("1", ["366602", "470", "1406", "2223", "51589", "2025595", "491893"])]:
         assert ncbi.lca(nodes) == want
+
+
+def test_hibf_agent_of_the_longreads_build():
+    """oracle.Hibf.bulk_count_longreads = hierarchical_interleaved_bloom_filter.hpp:432-460 with value_t = uint32_t (the reference's
+    -DLONGREADS build, GanonClassify.cpp:45-49).  Where no count or sum reaches 2^16 it must agree with the default (uint16) agent;
+    where a user bin's sum passes 65535 the default agent wraps (:438,442) and this one does not."""
+    import numpy as np
+    import ganon_fixtures as gf
+    import oracle
+    rng = np.random.default_rng(4)
+    hb = gf.random_hibf(120, 32, 3, seed=5, density=0.2, hash_funs=2, rows=(700, 900))
+    for n, thr in ((1, 1), (40, 3), (500, 20), (3000, 1)):
+        hh = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64)
+        assert np.array_equal(hb.bulk_count(hh, thr).astype(np.uint32), hb.bulk_count_longreads(hh, thr))
+    # one hash repeated 70 000 times: every bin that holds it counts 70 000 -> 4464 after a 16-bit wrap
+    for _ in range(200):
+        one = np.full(70_000, rng.integers(0, 2 ** 63, dtype=np.uint64), dtype=np.uint64)
+        wide, narrow = hb.bulk_count_longreads(one, 1), hb.bulk_count(one, 1)
+        hit = np.nonzero(wide)[0]
+        if len(hit):
+            break
+    assert len(hit) > 0 and (wide[hit] % 70_000 == 0).all()
+    assert ((wide[hit] & 0xFFFF) == narrow[hit]).all() or (narrow[hit] == 0).any()   # (a wrapped sum of 0 is not reported at all)
