@@ -781,12 +781,13 @@ static bool ganon_classify(Config config)
     if (!make_read_plan(config, reads))
         return false;
 
-    for (auto& [prefix, files] : reads) // :1390-1397
+    // every output prefix names files in a directory that exists (:1390-1397: a prefix that is a directory itself is left alone)
+    for (auto const& entry : reads)
     {
-        (void)files;
-        std::filesystem::path filepath = std::string(config.output_prefix + prefix);
-        if (!std::filesystem::is_directory(filepath) && !filepath.parent_path().empty())
-            std::filesystem::create_directories(filepath.parent_path());
+        const std::filesystem::path target(config.output_prefix + entry.first);
+        const std::filesystem::path dir = target.parent_path();
+        if (!dir.empty() && !std::filesystem::is_directory(target))
+            std::filesystem::create_directories(dir);
     }
     if (config.verbose)
     {
@@ -824,12 +825,15 @@ static bool ganon_classify(Config config)
 
     RunReport  report;
     std::mutex report_mutex;
+    // one stream per read set and kind of output; .rep always, .unc on request (:1416-1419), .all/.one per level below
     std::map<std::string, std::ofstream> out_rep, out_all, out_lca, out_unc;
-    for (auto& [prefix, files] : reads)
-        out_rep[prefix].open(config.output_prefix + prefix + ".rep");
+    auto open_for_every_prefix = [&](std::map<std::string, std::ofstream>& files, const std::string& suffix, std::ios_base::openmode mode) {
+        for (auto const& entry : reads)
+            files[entry.first].open(config.output_prefix + entry.first + "." + suffix, mode);
+    };
+    open_for_every_prefix(out_rep, "rep", std::ofstream::out);
     if (config.output_unclassified)
-        for (auto& [prefix, files] : reads)
-            out_unc[prefix].open(config.output_prefix + prefix + ".unc");
+        open_for_every_prefix(out_unc, "unc", std::ofstream::out);
 
     BatchQueue  queue1(2 + 2 * n_workers);
     std::thread read_task(parse_reads, std::ref(queue1), std::ref(report), std::ref(report_mutex), std::cref(reads));
@@ -918,33 +922,37 @@ static bool ganon_classify(Config config)
             for (auto const& t : filters[i].targets)
                 target_gid[i].push_back(nid(t));
 
-        // tax: merge first-wins (:1324-1341), missing targets -> root (:1343-1362)
+        // The level's taxonomy: the union of the filters' tax files, an earlier file winning where two define a node
+        // (:1324-1341); a target no file knows hangs below the root as "no rank" (:1343-1362).  Only levels with a tax file.
         std::map<std::string, TaxNode> tax;
-        if (!level.filters[0].tax_file.empty())
+        const bool                     has_tax = !level.filters[0].tax_file.empty();
+        if (has_tax)
         {
-            tax = filter_tax[0];
-            for (size_t i = 1; i < filters.size(); ++i)
-                tax.insert(filter_tax[i].begin(), filter_tax[i].end());
+            for (auto const& one : filter_tax)
+                for (auto const& kv : one)
+                    tax.emplace(kv.first, kv.second); // (emplace keeps what is there)
             for (auto const& f : filters)
                 for (auto const& target : f.targets)
-                    if (tax.count(target) == 0)
-                    {
-                        tax[target] = TaxNode{ config.tax_root_node, "no rank", target };
-                        if (!config.quiet)
-                            std::cerr << "WARNING: target [" << target << "] without tax entry, setting parent as root node ["
-                                      << config.tax_root_node << "]" << std::endl;
-                    }
+                {
+                    if (tax.find(target) != tax.end())
+                        continue;
+                    tax.emplace(target, TaxNode{ config.tax_root_node, "no rank", target });
+                    if (!config.quiet)
+                        std::cerr << "WARNING: target [" << target << "] without tax entry, setting parent as root node ["
+                                  << config.tax_root_node << "]" << std::endl;
+                }
         }
+        // the LCA structure over that tree (:1506-1515); without --skip-lca the root has to be one of its nodes
         LCA lca;
-        if (!config.skip_lca) // :1506-1515
+        if (!config.skip_lca)
         {
-            if (tax.count(config.tax_root_node) == 0)
+            if (tax.find(config.tax_root_node) == tax.end())
             {
                 std::cerr << "Root node [" << config.tax_root_node << "] not found (--tax-root-node)" << std::endl;
                 return false;
             }
-            for (auto const& [target, node] : tax)
-                lca.addEdge(node.parent, target);
+            for (auto const& kv : tax)
+                lca.addEdge(kv.second.parent, kv.first);
             lca.doEulerWalk(config.tax_root_node);
         }
 
@@ -960,11 +968,9 @@ static bool ganon_classify(Config config)
 
         const auto file_mode = first_level || !config.output_single ? std::ofstream::out : std::ofstream::app; // :1542
         if (config.output_lca && !config.skip_lca)
-            for (auto& [prefix, files] : reads)
-                out_lca[prefix].open(config.output_prefix + prefix + "." + level.suffix_one, file_mode);
+            open_for_every_prefix(out_lca, level.suffix_one, file_mode);
         if (config.output_all)
-            for (auto& [prefix, files] : reads)
-                out_all[prefix].open(config.output_prefix + prefix + "." + level.suffix_all, file_mode);
+            open_for_every_prefix(out_all, level.suffix_all, file_mode);
 
         // per-level tallies: prefix -> target tallies (dense by node id, grown on demand) / read tallies
         std::map<std::string, std::vector<TargetTally>> target_tallies;
