@@ -15,6 +15,7 @@
 //     target index, .rep rows in target order (the reference iterates robin_hood maps and, with --threads > 1,
 //     interleaves reads arbitrarily; its own tests compare order-insensitively, tests/aux/Aux.hpp:56-68)
 #include "backend.hpp"
+#include "robin_order.hpp"
 #include "config.hpp"
 #include "filter_io.hpp"
 #include "lca.hpp"
@@ -130,6 +131,7 @@ struct PostOutput
     std::vector<TargetTally> targets;       // ... and of the per-target tallies (dense by node id)
     ReadBatch                left;          // reads that stay unclassified on a level that is not the last
     bool                     has_left = false;
+    std::vector<uint32_t>    touched;       // --reference-order: node ids in the order this batch first touched their report rows
 };
 
 struct ClassifiedBatch
@@ -966,6 +968,34 @@ static bool ganon_classify(Config config)
         nid(config.tax_root_node);
         auto known_nid = [&](const std::string& s) -> uint32_t { return node_ids.at(s); };
 
+        // --reference-order: what the reference's robin_hood maps need to be replayed (robin_order.hpp) -- the hash of every
+        // node name (TMatches is keyed by the target string, :53) and, per filter, the rank of every target in the iteration
+        // order of the filter's TMap (:55; filled from the bin map in file order, :1021-1025), which is the order
+        // select_matches offers targets to the read's map (:516,556)
+        std::vector<uint64_t>              name_hash;
+        std::vector<std::vector<uint32_t>> map_rank(filters.size());
+        if (config.reference_order)
+        {
+            name_hash.resize(node_names.size());
+            for (size_t g = 0; g < node_names.size(); ++g)
+                name_hash[g] = rh_hash(node_names[g]);
+            RobinSlots            tmap;
+            std::vector<uint32_t> order;
+            for (size_t i = 0; i < filters.size(); ++i)
+            {
+                tmap.clear();
+                for (size_t t = 0; t < filters[i].targets.size(); ++t)
+                    tmap.insert((uint32_t)t, rh_hash(filters[i].targets[t]));
+                tmap.order(order);
+                map_rank[i].assign(filters[i].targets.size(), 0u);
+                for (size_t k = 0; k < order.size(); ++k)
+                    map_rank[i][order[k]] = (uint32_t)k;
+            }
+        }
+        // report rows in the order they were first touched, over all read sets (TRep is ONE map keyed by (prefix, target), :180)
+        std::vector<std::pair<std::string, uint32_t>>            touched_rows;
+        std::map<std::string, std::vector<uint8_t>>              touched_seen;
+
         const auto file_mode = first_level || !config.output_single ? std::ofstream::out : std::ofstream::app; // :1542
         if (config.output_lca && !config.skip_lca)
             open_for_every_prefix(out_lca, level.suffix_one, file_mode);
@@ -1002,7 +1032,8 @@ static bool ganon_classify(Config config)
             }
             spec.target_gid = target_gid;
             shared_targets  = !spec.disjoint_targets;
-            const bool want = !getenv("GANON_HOST_NO_PREFILTER");
+            // (--reference-order replays the read's whole map of matches: nothing may be dropped before the host sees it)
+            const bool want = !getenv("GANON_HOST_NO_PREFILTER") && !config.reference_order;
             bool       on   = true;
             for (auto& be : backends)
                 on = be->set_postfilter(want ? &spec : nullptr) && on;
@@ -1021,6 +1052,7 @@ static bool ganon_classify(Config config)
             size_t   count;
             double   fpr;
             bool     fpr_ok; // the backend already verified the --fpr-query rule for this match
+            uint64_t ins;    // --reference-order: (filter, rank in the filter's TMap order) of the insertion into the read's map
         };
         // the post stage runs on a small pool of threads, one batch each; this is what a thread keeps between batches
         struct PostScratch
@@ -1031,6 +1063,11 @@ static bool ganon_classify(Config config)
             uint32_t                 stamp = 0;
             std::vector<uint32_t>    kept_gids;
             std::vector<std::string> kept_targets;
+            // --reference-order
+            RobinSlots               slots;
+            std::vector<uint32_t>    slot_order, pos_of, touch_stamp;
+            std::vector<MatchEntry>  reordered;
+            uint32_t                 touch_epoch = 0;
         };
 
         auto device_stage = [&](Backend& be, const ReadBatch& rb, BatchResult& res, std::string& e) -> bool {
@@ -1071,6 +1108,24 @@ static bool ganon_classify(Config config)
             std::ofstream* o_unc = config.output_unclassified ? &out_unc[rb.prefix] : nullptr;
             const bool     one_filter = filters.size() == 1;
             uint64_t       n_unmerged = 0, n_fpr_evals = 0;
+            po.touched.clear();
+            if (config.reference_order)
+            {
+                if (sc.touch_stamp.size() < node_names.size())
+                    sc.touch_stamp.resize(node_names.size(), 0u);
+                if (++sc.touch_epoch == 0)
+                {
+                    std::fill(sc.touch_stamp.begin(), sc.touch_stamp.end(), 0u);
+                    sc.touch_epoch = 1;
+                }
+            }
+            auto touch = [&](uint32_t gid) { // rep[{prefix, target}] of the reference: the row exists from here on
+                if (config.reference_order && sc.touch_stamp[gid] != sc.touch_epoch)
+                {
+                    sc.touch_stamp[gid] = sc.touch_epoch;
+                    po.touched.push_back(gid);
+                }
+            };
 
             for (size_t r = 0; r < rb.size(); ++r)
             {
@@ -1136,7 +1191,8 @@ static bool ganon_classify(Config config)
                                         stamp_of[gid] = stamp;
                                         slot_of[gid]  = (uint32_t)matches.size();
                                     }
-                                    matches.push_back(MatchEntry{ gid, m.count, filters[i].target_fpr[m.target], ok });
+                                    matches.push_back(MatchEntry{ gid, m.count, filters[i].target_fpr[m.target], ok,
+                                                                  config.reference_order ? ((uint64_t)i << 40) | map_rank[i][m.target] : 0ull });
                                 }
                                 if (m.count > max_count_read)
                                     max_count_read = m.count;
@@ -1154,7 +1210,29 @@ static bool ganon_classify(Config config)
                     max_count_read = res.max_count[r];
                 else if (res.prefiltered)
                     ++n_unmerged;
-                if (shared_targets && matches.size() > 1) // one order whoever did the merge: by the target's id in the level
+                if (config.reference_order && !matches.empty())
+                {
+                    // the read's TMatches: keys arrive filter after filter in each filter's TMap order; what filter_matches
+                    // walks is the map's slot order (:583)
+                    if (matches.size() > 1)
+                    {
+                        std::sort(matches.begin(), matches.end(), [](const MatchEntry& a, const MatchEntry& b) { return a.ins < b.ins; });
+                        sc.slots.clear();
+                        if (sc.pos_of.size() < node_names.size())
+                            sc.pos_of.resize(node_names.size());
+                        for (size_t x = 0; x < matches.size(); ++x)
+                        {
+                            sc.slots.insert(matches[x].gid, name_hash[matches[x].gid]);
+                            sc.pos_of[matches[x].gid] = (uint32_t)x;
+                        }
+                        sc.slots.order(sc.slot_order);
+                        sc.reordered.clear();
+                        for (uint32_t g : sc.slot_order)
+                            sc.reordered.push_back(matches[sc.pos_of[g]]);
+                        matches.swap(sc.reordered);
+                    }
+                }
+                else if (shared_targets && matches.size() > 1) // one order whoever did the merge: by the target's id in the level
                     std::sort(matches.begin(), matches.end(), [](const MatchEntry& a, const MatchEntry& b) { return a.gid < b.gid; });
                 bool classified = false;
                 if (max_count_read > 0) // :753-808
@@ -1169,6 +1247,7 @@ static bool ganon_classify(Config config)
                     kept_gids.clear();
                     for (auto const& me : matches)
                     {
+                        touch(me.gid);
                         if (me.count >= (double)threshold_filter)
                         {
                             if (level.fpr_query < 1.0 && !me.fpr_ok)
@@ -1215,12 +1294,16 @@ static bool ganon_classify(Config config)
                             for (uint32_t g : kept_gids)
                                 kept_targets.push_back(node_names[g]);
                             const std::string target_lca = lca.getLCA(kept_targets);
+                            touch(known_nid(target_lca));
                             tally_at(per_target, known_nid(target_lca)).lca_reads++;
                             if (o_lca)
                                 append_line(buf_lca, rb.id(r), target_lca, max_count_read);
                         }
                         else // :794-799
+                        {
+                            touch(known_nid(config.tax_root_node));
                             tally_at(per_target, known_nid(config.tax_root_node)).lca_reads++;
+                        }
                     }
                     else
                         buf_all.resize(all_mark);
@@ -1268,6 +1351,18 @@ static bool ganon_classify(Config config)
                 rows.resize(po.targets.size());
             for (size_t g = 0; g < po.targets.size(); ++g)
                 rows[g].add(po.targets[g]);
+            if (config.reference_order)
+            {
+                auto& seen = touched_seen[cb.rb.prefix];
+                if (seen.size() < node_names.size())
+                    seen.resize(node_names.size(), 0);
+                for (uint32_t g : po.touched)
+                    if (!seen[g])
+                    {
+                        seen[g] = 1;
+                        touched_rows.emplace_back(cb.rb.prefix, g);
+                    }
+            }
             if (config.output_all)
                 out_all[cb.rb.prefix].write(po.all.data(), (std::streamsize)po.all.size());
             if (config.output_lca && !config.skip_lca)
@@ -1381,28 +1476,55 @@ static bool ganon_classify(Config config)
 
         // reports (:1609-1617): `.rep` rows in node order (write_report :834-853)
         report.add_level(level.label, read_tallies, target_tallies);
-        for (auto& [prefix, rows] : target_tallies)
-        {
+        auto write_row = [&](const std::string& prefix, uint32_t gid) -> bool {
+            auto it = target_tallies.find(prefix);
+            if (it == target_tallies.end() || gid >= it->second.size())
+                return true;
+            const TargetTally& row = it->second[gid];
+            if (!row.reported())
+                return true;
             std::ofstream& rep = out_rep[prefix];
-            for (uint32_t gid = 0; gid < rows.size(); ++gid)
+            rep << level.label << '\t' << node_names[gid] << '\t' << row.matches << '\t' << row.unique_reads << '\t' << row.lca_reads;
+            if (!tax.empty())
             {
-                const TargetTally& row = rows[gid];
-                if (!row.reported())
-                    continue;
-                rep << level.label << '\t' << node_names[gid] << '\t' << row.matches << '\t' << row.unique_reads << '\t' << row.lca_reads;
-                if (!tax.empty())
+                auto node = tax.find(node_names[gid]);
+                if (node == tax.end())
                 {
-                    auto it = tax.find(node_names[gid]);
-                    if (it == tax.end())
-                    {
-                        std::cerr << "ERROR: node [" << node_names[gid] << "] not found in tax" << std::endl;
-                        return false;
-                    }
-                    rep << '\t' << it->second.rank << '\t' << it->second.name;
+                    std::cerr << "ERROR: node [" << node_names[gid] << "] not found in tax" << std::endl;
+                    return false;
                 }
-                rep << '\n';
+                rep << '\t' << node->second.rank << '\t' << node->second.name;
             }
+            rep << '\n';
+            return true;
+        };
+        if (config.reference_order)
+        {
+            // the one classify thread's TRep in first-touch order, then sum_reports' copy of it (:475-490: a fresh map filled
+            // in the first one's iteration order), whose iteration order write_report follows (:836)
+            RobinSlots            thread_rep, summed;
+            std::vector<uint32_t> order;
+            std::vector<uint64_t> key_hash(touched_rows.size());
+            thread_rep.clear();
+            for (size_t x = 0; x < touched_rows.size(); ++x)
+            {
+                key_hash[x] = pair_hash(touched_rows[x].first, node_names[touched_rows[x].second]);
+                thread_rep.insert((uint32_t)x, key_hash[x]);
+            }
+            thread_rep.order(order);
+            summed.clear();
+            for (uint32_t x : order)
+                summed.insert(x, key_hash[x]);
+            summed.order(order);
+            for (uint32_t x : order)
+                if (!write_row(touched_rows[x].first, touched_rows[x].second))
+                    return false;
         }
+        else
+            for (auto& [prefix, rows] : target_tallies)
+                for (uint32_t gid = 0; gid < rows.size(); ++gid)
+                    if (!write_row(prefix, gid))
+                        return false;
         classifying.stop();
         if (config.output_lca)
             for (auto& [prefix, file] : out_lca)

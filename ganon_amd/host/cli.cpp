@@ -57,6 +57,10 @@ const Opt kOpts[] = {
     { 's', "output-single", Kind::Bool, "Do not split output files (one and all) with multi-level --hierarchy-labels" },
     { 0, "hibf", Kind::Bool, "Input is an Hierarchical IBF (.hibf) generated from raptor." },
     { 0, "long-reads", Kind::Bool, "Classify reads with more than 65535 minimisers too (what the reference does when it is built with -DLONGREADS=ON)." },
+    { 0, "reference-order", Kind::Bool,
+      "Write .all lines and .rep rows in the order the reference's robin_hood hash maps iterate, instead of ascending target (needs "
+      "--threads 1, where the reference's own order is deterministic). Restated from robin_hood 3.11 and libstdc++; UNVERIFIED against a "
+      "run of the reference." },
     { 0, "skip-lca", Kind::Bool, "Skip LCA step." },
     { 0, "tax-root-node", Kind::Str, "Define alternative root node for LCA. Default: 1" },
     { 't', "threads", Kind::U16, "Number of threads" },
@@ -271,6 +275,7 @@ std::optional<Config> parse_command_line(int argc, char** argv, int& exit_code)
                     else if (n == "output-single") cfg.output_single = b;
                     else if (n == "hibf") cfg.hibf = b;
                     else if (n == "long-reads") cfg.long_reads = b;
+                    else if (n == "reference-order") cfg.reference_order = b;
                     else if (n == "skip-lca") cfg.skip_lca = b;
                     else if (n == "verbose") cfg.verbose = b;
                     else if (n == "quiet") cfg.quiet = b;

@@ -97,6 +97,8 @@ bool Config::validate()
 
     if (tax.empty()) // no taxonomy -> no LCA (:168-170)
         skip_lca = true;
+    if (reference_order && threads != 1)
+        return complain("--reference-order needs --threads 1 (with more threads the reference's own line order is not deterministic)");
     return true;
 }
 

@@ -34,6 +34,7 @@ struct Config
     DoubleList rel_filter{ 0.0 };
     DoubleList fpr_query{ 1.0 };
     bool        hibf          = false;
+    bool        reference_order = false; // extension: .all / .rep in the reference's robin_hood iteration order (robin_order.hpp)
     bool        long_reads    = false; // extension: the reference's compile-time -DLONGREADS (GanonClassify.cpp:45-49) as a flag
     bool        skip_lca      = false;
     std::string tax_root_node = "1";
