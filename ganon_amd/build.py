@@ -76,7 +76,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     every = sorted(f for f in os.listdir(HOST) if f.endswith(".cpp"))
     hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "ganon_hip.h")]
     build_hip(force=False, verbose=verbose)
-    for binary, names in ((BIN, [f for f in every if f not in BUILD_ONLY]), (BIN_BUILD, [f for f in every if f in BUILD_ONLY] + ["seq_io.cpp"])):
+    for binary, names in ((BIN, [f for f in every if f not in BUILD_ONLY]), (BIN_BUILD, [f for f in every if f in BUILD_ONLY] + ["seq_io.cpp", "pgzip.cpp"])):
         srcs = [os.path.join(HOST, f) for f in names]
         if not srcs:
             continue

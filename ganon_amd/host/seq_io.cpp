@@ -1,5 +1,6 @@
 // seq_io.cpp -- see seq_io.hpp
 #include "seq_io.hpp"
+#include "pgzip.hpp"
 
 #include <tmmintrin.h>
 #include <zlib.h>
@@ -664,7 +665,9 @@ namespace
 class RangeLines
 {
 public:
-    RangeLines(int fd, uint64_t file_size) : fd_(fd), size_(file_size), buf_(4u << 20) {}
+    // an uncompressed file (pread), or the decompressed stream of a gzip file (ParallelGzip::pread; its size is known only at its
+    // end; a damaged stream makes refill throw)
+    RangeLines(int fd, uint64_t file_size, ParallelGzip* gz = nullptr) : fd_(fd), gz_(gz), size_(file_size), buf_(4u << 20) {}
     void seek(uint64_t off)
     {
         if (off >= base_ && off <= base_ + len_)
@@ -737,13 +740,15 @@ private:
         if (len_ == buf_.size())
             buf_.resize(buf_.size() * 2); // a single line longer than the buffer
         const size_t  want = (size_t)std::min<uint64_t>(buf_.size() - len_, size_ - (base_ + len_));
-        const ssize_t got  = ::pread(fd_, buf_.data() + len_, want, (off_t)(base_ + len_));
+        const ssize_t got  = gz_ ? (ssize_t)gz_->pread(buf_.data() + len_, want, base_ + len_)
+                                 : ::pread(fd_, buf_.data() + len_, want, (off_t)(base_ + len_));
         if (got <= 0)
             return false;
         len_ += (size_t)got;
         return true;
     }
     int               fd_;
+    ParallelGzip*     gz_;
     uint64_t          size_, base_ = 0;
     std::vector<char> buf_;
     size_t            pos_ = 0, len_ = 0;
@@ -752,8 +757,10 @@ private:
 
 struct ParallelFastq::Impl
 {
-    size_t      size = 0;
+    size_t      size = 0;   // bytes of the (decompressed) input; for a gzip stream unknown until its end has been read
     int         fd   = -1;
+    std::unique_ptr<ParallelGzip> gz; // the input is the decompressed stream of a plain gzip file
+    size_t      end_size() const { return gz ? (size_t)gz->known_size() : size; }
     size_t      slab_bytes = 0, n_slabs = 0;
     std::vector<std::thread> workers;
     std::mutex               m;
@@ -771,17 +778,17 @@ struct ParallelFastq::Impl
     {
         if (p == 0)
             return 0;
-        if (p >= size)
-            return size;
+        if (p >= end_size())
+            return end_size();
         std::string_view l;
         in.seek(p - 1);
         if (!in.line(l)) // the rest of the line that holds byte p-1 (empty when a line starts exactly at p)
-            return size;
+            return end_size();
         for (;;)
         {
             const uint64_t o0 = in.tell();
             if (!in.line(l))
-                return size;
+                return end_size();
             if (fasta)
             {
                 if (!l.empty() && l[0] == '>')
@@ -793,7 +800,7 @@ struct ParallelFastq::Impl
             const uint64_t o1 = in.tell();
             std::string_view l1, l2;
             if (!in.line(l1) || !in.line(l2))
-                return size;
+                return end_size();
             if (!l2.empty() && l2[0] == '+')
                 return (size_t)o0;
             in.seek(o1); // not a record start: go on with the line after it
@@ -939,7 +946,7 @@ struct ParallelFastq::Impl
 
     void work()
     {
-        RangeLines in(fd, size);
+        RangeLines in(fd, gz ? ~0ull : size, gz.get());
         for (;;)
         {
             size_t i;
@@ -963,13 +970,37 @@ struct ParallelFastq::Impl
             s.rec_at.clear();
             s.error.clear();
             s.irregular = false;
-            const size_t b = record_at_or_after(in, i * slab_bytes);
-            const size_t e = i + 1 == n_slabs ? size : record_at_or_after(in, (i + 1) * slab_bytes);
-            if (b < e)
-                parse(in, b, e, s);
-            else
-                s.rec_at.assign(1, b);
+            size_t b = 0;
+            bool   have_b = false, last = false;
+            try
+            {
+                b      = record_at_or_after(in, i * slab_bytes);
+                have_b = true;
+                // (a gzip stream's size turns up when a search runs into its end: no record starts at or after this slab's
+                //  first byte, so this slab is the last, and empty)
+                last = gz && b >= end_size();
+                const size_t e = (!gz && i + 1 == n_slabs) || last ? end_size() : record_at_or_after(in, (i + 1) * slab_bytes);
+                if (b < e)
+                    parse(in, b, e, s);
+                else
+                    s.rec_at.assign(1, b);
+            }
+            catch (std::exception const&)
+            {
+                // the gzip stream is damaged somewhere in this slab's reach: nothing of the slab is kept; the sequential
+                // reader (zlib) takes over at the slab's first record and produces records and message its own way.  (The
+                // first slab in file order that fails has found its first record: that search is the previous slab's end.)
+                s.ids.clear();
+                s.id_off.assign(1, 0);
+                s.bases.clear();
+                s.off.assign(1, 0);
+                s.rec_at.clear();
+                s.irregular = true;
+                s.resume_at = have_b ? b : 0;
+            }
             std::lock_guard<std::mutex> lk(m);
+            if (last && i + 1 < n_slabs)
+                n_slabs = i + 1;
             ready.emplace(i, std::move(s));
             cv.notify_all();
         }
@@ -981,30 +1012,69 @@ ParallelFastq::ParallelFastq(Impl* i) : impl_(i) {}
 std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
                                                    bool mate_room)
 {
+    std::string base = path;
+    bool        gz_name = false;
+    for (const char* z : { ".gz" })
+        if (ends_with(base, z))
+        {
+            base    = base.substr(0, base.size() - std::strlen(z));
+            gz_name = true;
+        }
     bool fasta = false;
     for (const char* e : { ".fa", ".fasta", ".fna", ".ffn", ".faa", ".frn", ".fas" })
-        fasta = fasta || ends_with(path, e);
-    if (!(fasta || ends_with(path, ".fq") || ends_with(path, ".fastq")) || threads == 0)
+        fasta = fasta || ends_with(base, e);
+    if (!(fasta || ends_with(base, ".fq") || ends_with(base, ".fastq")) || threads == 0)
         return nullptr;
     const int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0)
         return nullptr;
     struct stat st;
     unsigned char magic[2] = { 0, 0 };
-    if (fstat(fd, &st) != 0 || (size_t)st.st_size < std::max<size_t>(min_bytes, 2) || pread(fd, magic, 2, 0) != 2
-        || (magic[0] == 0x1F && magic[1] == 0x8B))
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < std::max<size_t>(min_bytes, 2) || pread(fd, magic, 2, 0) != 2)
     {
         ::close(fd);
         return nullptr;
+    }
+    const bool is_gzip = magic[0] == 0x1F && magic[1] == 0x8B;
+    std::unique_ptr<ParallelGzip> gz;
+    if (is_gzip)
+    {
+        // An ordinary gzip file (blocked gzip has a reader of its own, BgzfSource): inflated by several threads (pgzip.hpp),
+        // and the slab parsers work on the decompressed stream as on a file.  The name must say .gz: the sequential reader that
+        // takes over at irregular records opens the file by name.
+        if (!gz_name || std::getenv("GANON_HOST_NO_PGZIP") || BgzfSource::open(path))
+        {
+            ::close(fd);
+            return nullptr;
+        }
+        const char*    e  = std::getenv("GANON_HOST_INFLATE_THREADS");
+        const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+        unsigned       it = e ? (unsigned)std::max(1, std::atoi(e)) : std::min(hw, 64u);
+        // (hardware_concurrency ignores a cgroup quota; the affinity mask and cpu.max are what classify.cpp's usable_cores reads --
+        //  here: a fixed share of what the caller gave its parsers, which is derived from that)
+        if (!e)
+            it = std::max(2u, threads + threads / 2);
+        const char* cb = std::getenv("GANON_HOST_INFLATE_CHUNK");
+        gz = ParallelGzip::open(path, it, 0, cb ? (size_t)std::atoll(cb) : 0);
+        if (!gz)
+        {
+            ::close(fd);
+            return nullptr;
+        }
     }
     Impl* im       = new Impl;
     im->size       = (size_t)st.st_size;
     im->fd         = fd;
     im->slab_bytes = std::max<size_t>(slab_bytes, 1 << 16);
-    im->n_slabs    = (im->size + im->slab_bytes - 1) / im->slab_bytes;
+    im->n_slabs    = gz ? ~(size_t)0 : (im->size + im->slab_bytes - 1) / im->slab_bytes;
     im->window     = 2 * threads + 2;
     im->mate_room  = mate_room;
     im->fasta      = fasta;
+    if (gz)
+    {
+        gz->set_retain_limit((uint64_t)(im->window + 3) * im->slab_bytes);
+        im->gz = std::move(gz);
+    }
     std::unique_ptr<ParallelFastq> pf(new ParallelFastq(im));
     for (unsigned t = 0; t < threads; ++t)
         im->workers.emplace_back([im] { im->work(); });
@@ -1037,7 +1107,9 @@ bool ParallelFastq::next(Slab& out)
     std::unique_lock<std::mutex> lk(s.m);
     if (s.ended || s.next_to_take >= s.n_slabs)
         return false;
-    s.cv.wait(lk, [&] { return s.ready.count(s.next_to_take) != 0; });
+    s.cv.wait(lk, [&] { return s.ready.count(s.next_to_take) != 0 || s.next_to_take >= s.n_slabs; });
+    if (s.next_to_take >= s.n_slabs) // (a gzip stream ended before this slab)
+        return false;
     auto it = s.ready.find(s.next_to_take);
     out     = std::move(it->second);
     s.ready.erase(it);
@@ -1047,6 +1119,8 @@ bool ParallelFastq::next(Slab& out)
         s.ended = true; // what the other workers parsed beyond this point is dropped
         s.stop  = true;
     }
+    if (s.gz && s.next_to_take * s.slab_bytes > 0) // the slabs still in work begin their search one byte before their range
+        s.gz->release_below((uint64_t)s.next_to_take * s.slab_bytes - 1);
     s.cv.notify_all();
     return true;
 }

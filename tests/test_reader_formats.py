@@ -352,3 +352,82 @@ def test_parallel_fasta_equals_sequential_reader(oracle_bin, sim_db, tmp_path, p
         assert par_out == seq_out, (variant, slab)
         assert ("Error parsing" in par_err) == ("Error parsing" in seq_err) == (variant == "bad_letter")
     assert seq_out[".all"].count(b"\n") > 100
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ordinary gzip input, inflated by several threads (host/pgzip.cpp): the sequential zlib reader's records, byte for byte
+# ---------------------------------------------------------------------------------------------------------------
+def _gz_variants(raw: bytes, variant: str) -> bytes:
+    import gzip
+    import zlib
+    if variant in ("level1", "level6", "level9"):
+        return gzip.compress(raw, int(variant[-1]))
+    if variant == "multi_member":          # what `cat a.gz b.gz c.gz` gives; members end in the middle of records
+        cut = [0, len(raw) // 3 + 7, len(raw) // 3 + 1000, 2 * len(raw) // 3, len(raw)]
+        return b"".join(gzip.compress(raw[a:b], 6) for a, b in zip(cut, cut[1:]))
+    if variant == "flush_points":          # sync / full flushes: empty stored blocks between the others
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        parts = []
+        for i in range(0, len(raw), 50_000):
+            parts += [co.compress(raw[i:i + 50_000]), co.flush(zlib.Z_FULL_FLUSH if (i // 50_000) % 2 else zlib.Z_SYNC_FLUSH)]
+        return b"".join(parts) + co.flush()
+    if variant == "fixed_codes":
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+        return co.compress(raw) + co.flush()
+    if variant == "stored":
+        co = zlib.compressobj(0, zlib.DEFLATED, 31)
+        return co.compress(raw) + co.flush()
+    if variant == "trailing_garbage":
+        return gzip.compress(raw, 6) + b"\0" * 100 + b"garbage"
+    if variant == "truncated":
+        z = gzip.compress(raw, 6)
+        return z[: 2 * len(z) // 3]
+    if variant == "corrupt":
+        z = bytearray(gzip.compress(raw, 6))
+        z[len(z) // 2] ^= 0x55
+        return bytes(z)
+    if variant == "bad_crc":
+        z = bytearray(gzip.compress(raw, 6))
+        z[-6] ^= 0xFF
+        return bytes(z)
+    raise ValueError(variant)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("variant", ["level1", "level6", "level9", "multi_member", "flush_points", "fixed_codes", "stored", "trailing_garbage",
+                                     "truncated", "corrupt", "bad_crc", "wrapped_records", "fasta"])
+def test_parallel_gzip_equals_sequential_reader(oracle_bin, sim_db, tmp_path, paired, variant):
+    import numpy as np
+    rng = np.random.default_rng(29)
+    n = 6000
+    g = list(sim_db["targets"].values())
+    recs1, recs2 = [], []
+    for i in range(n):
+        src = g[i % len(g)] if i % 3 else "".join("ACGT"[x] for x in rng.integers(0, 4, size=400))
+        p = int(rng.integers(0, len(src) - 310))
+        L = int(rng.integers(60, 152))
+        recs1.append((f"SRR000001.{i} {i} length={L}", src[p:p + L]))
+        recs2.append((f"SRR000001.{i}/2", src[p + 150:p + 150 + L][::-1].translate(str.maketrans("ACGT", "TGCA"))))
+    ext = ".fa.gz" if variant == "fasta" else ".fq.gz"
+    if variant == "fasta":
+        t1, t2 = _fasta_text(recs1, "wrapped"), _fasta_text(recs2, "plain")
+    else:
+        t1, t2 = _fastq_text(recs1, wrap=50 if variant == "wrapped_records" else 0), _fastq_text(recs2)
+    gzv = variant if variant not in ("wrapped_records", "fasta") else "level6"
+    f1, f2 = str(tmp_path / ("r1" + ext)), str(tmp_path / ("r2" + ext))
+    open(f1, "wb").write(_gz_variants(t1.encode(), gzv))
+    open(f2, "wb").write(_gz_variants(t2.encode(), gzv if variant in ("level1", "level9", "multi_member") else "level6"))
+    files = [f1, f2] if paired else [f1]
+    seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], files, str(tmp_path / "seq"), paired, {"GANON_HOST_PARSE_THREADS": "0"})
+    broken = variant in ("truncated", "corrupt", "bad_crc")
+    assert ("Error parsing" in seq_err) == broken
+    for chunk, slab in (("4096", "65536"), ("70000", "300000")):
+        env = {"GANON_HOST_PARSE_THREADS": "3", "GANON_HOST_SLAB_BYTES": slab, "GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_BATCH_READS": "777",
+               "GANON_HOST_INFLATE_CHUNK": chunk, "GANON_HOST_INFLATE_THREADS": "3", "GANON_HOST_TIMING": "1"}
+        par_err, par_out = _run_reader_case(oracle_bin, sim_db["ibf"], files, str(tmp_path / ("par" + chunk)), paired, env)
+        assert par_out == seq_out, (variant, chunk)
+        assert ("Error parsing" in par_err) == broken
+        off_err, off_out = _run_reader_case(oracle_bin, sim_db["ibf"], files, str(tmp_path / ("off" + chunk)), paired,
+                                            dict(env, GANON_HOST_NO_PGZIP="1"))
+        assert off_out == seq_out
+    assert broken or seq_out[".all"].count(b"\n") > 300   # (zlib hands out nothing of the buffer an error turns up in)
