@@ -62,11 +62,19 @@ rec[:, 11] = ord("\n")
 rec[:, 12:12 + L] = wl.bases.reshape(n, L)
 rec[:, 12 + L:15 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
 rec[:, 15 + L:15 + 2 * L] = ord("I")
+if os.environ.get("E2E_GZ"):  # binned qualities as sequencers write them (a constant line would inflate unrealistically fast)
+    qs = np.frombuffer(b"FFFFFFFFFFFF:FFF,FFFF#", dtype=np.uint8)
+    rec[:, 15 + L:15 + 2 * L] = qs[np.random.default_rng(7).integers(0, len(qs), size=(n, L), dtype=np.uint8)]
 rec[:, -1] = ord("\n")
 fq = os.path.join(d, "ganon_e2e.fq")
 rec.tofile(fq)
 out["fastq_gib"] = round(os.path.getsize(fq) / 2**30, 2)
 READS = ["--single-reads", fq]
+if os.environ.get("E2E_GZ"):  # the same file as ordinary gzip (one member, level 6): what read sets usually look like
+    t0 = time.time()
+    subprocess.check_call(["gzip", "-6", "-k", "-f", fq])
+    READS = ["--single-reads", fq + ".gz"]
+    out["gzip"] = {"file_gib": round(os.path.getsize(fq + ".gz") / 2**30, 2), "compress_s": round(time.time() - t0, 1)}
 if os.environ.get("E2E_FASTA"):  # the same reads as a FASTA file (sequential reader: no four-line structure to cut slabs at)
     fa = os.path.join(d, "ganon_e2e.fa")
     rec2 = rec[:, :12 + L + 1].copy()
@@ -94,13 +102,19 @@ if os.environ.get("E2E_HIBF"):  # a two-level raptor-style HIBF (4096 user bins)
     out["hibf"] = {"user_bins": 4096, "file_mib": round(os.path.getsize(ibf) / 2**20, 1), "built_s": round(time.time() - t0, 1)}
 exe = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
 runs = [("one_worker", "0", None), ("two_workers_one_gpu", "0,0", None), ("three_workers_one_gpu", "0,0,0", None), ("default_no_device_flag", None, None)]
+if os.environ.get("E2E_GZ"):  # ... and with the parallel inflate switched off (one zlib stream, as before) / other thread counts
+    runs += [("gz_sequential_inflate", "0,0", "seq"), ("gz_inflate_8", "0,0", "i8"), ("gz_inflate_16", "0,0", "i16")]
 if os.environ.get("E2E_SWEEP"):  # parser threads x device workers, to see which stage limits the pipeline on this host
     runs += [(f"sweep_parse{pt}_workers{len(dev.split(','))}", dev, pt) for pt in (4, 6, 8, 10, 12) for dev in ("0", "0,0", "0,0,0")]
 for label, dev, parse_threads in runs:
     prefix = os.path.join(d, "ganon_e2e_out_" + label)
     t0 = time.time()
     env = dict(os.environ, GANON_HOST_TIMING="1")
-    if parse_threads:
+    if parse_threads == "seq":
+        env["GANON_HOST_NO_PGZIP"] = "1"
+    elif isinstance(parse_threads, str) and parse_threads.startswith("i"):
+        env["GANON_HOST_INFLATE_THREADS"] = parse_threads[1:]
+    elif parse_threads:
         env["GANON_HOST_PARSE_THREADS"] = str(parse_threads)
     p = subprocess.run([exe, "--ibf", IBFS if not os.environ.get("E2E_HIBF") else ibf] + READS + ["-o", prefix, "--output-all", "--verbose"] + (["--device", dev] if dev else []) + EXTRA,
                        capture_output=True, text=True, env=env)
