@@ -6,7 +6,7 @@
 # the kernel trace), in the order: timing (bench line) -> kernel trace/stats -> FETCH_SIZE -> FETCH_SIZE without the early
 # exit (calibration of the counter on this access pattern) -> WRITE_SIZE -> SQ counters.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-flat8g}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_${TAG}_$WL

@@ -6,9 +6,10 @@ coalesced reads at 64 bytes (-> x2) and that other access widths must be calibra
 kernels' row loads are 8 or 16 B/lane over rows of 512 B .. 4 KiB, so the x2 is checked on the same bench with the early
 exit disabled, where the dominant kernel requests exactly the algorithmic n*h*W*8 row bytes (plus < 0.5 % hashes /
 metadata): FETCH_SIZE * 1024 * 2 / algorithmic is reported as `calibration_check` (1.0 = exact).  The HIBF kernels fetch
-32-byte rows (8 B/lane, four lanes per row): no run with a known byte count exists for that pattern, so both readings are
-given -- x1 (64-byte requests counted in full) and x2 -- next to the algorithmic bytes and the one-128-byte-line-per-row
-transaction count.
+32-byte rows (8 B/lane, four lanes per row).  That pattern was calibrated in round 3 (scripts/calib_gather.hip ->
+profiles/r03_calib_gather.json: a bare gather with a KNOWN number of row requests): the L2 issues exactly one fabric request
+per row request for 32-, 64- and 128-byte rows alike (TCC_EA0_RDREQ = TCC_MISS = requests), each a 128-byte line tallied
+at 64 bytes -- so the x2 of the guide holds for it too, and every 32-byte row costs a whole line: traffic = 4 x algorithmic.
 """
 import csv, glob, json, os, shutil, sys
 
@@ -18,8 +19,8 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "flat8g"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
 dst = os.path.join(ROOT, "profiles")
 # kernels whose launches make up one "count/select" step of the workload
-KERNELS = {"hibf64k": ["gn_hibf_pack_kernel", "gn_hibf_reg_kernel", "gn_hibf_level_kernel"], "split32k": ["gn_ibf_count_split_kernel"]}.get(
-    wl, ["gn_ibf_count_fast_kernel"])
+HIBF = ["gn_hibf_pack_kernel", "gn_hibf_reg_kernel", "gn_hibf_level_kernel"]
+KERNELS = {"hibf64k": HIBF, "hibf64k_top1g": HIBF, "split32k": ["gn_ibf_count_split_kernel"]}.get(wl, ["gn_ibf_count_fast_kernel"])
 
 
 def find(sub, suffix):
@@ -97,15 +98,19 @@ if p_f:
         })
     else:
         x1 = raw * 1024.0
+        lines = sum(lv["line_bytes"] for lv in rf.get("levels", [])) or None
         out.update({
-            "hbm_bytes_per_launch": int(x1 * 2.0) if wl == "split32k" else int(x1),
+            "hbm_bytes_per_launch": int(x1 * 2.0),
             "hbm_bytes_if_x1": int(x1), "hbm_bytes_if_x2": int(x1 * 2.0),
-            "transaction_bytes_per_step": rf.get("transaction_bytes_per_launch"),
+            "line_bytes_per_step": lines,
+            "fabric_over_line_bytes": round(x1 * 2.0 / lines, 4) if lines else None,
+            "fabric_over_algorithmic": round(x1 * 2.0 / algo, 4),
             "source": f"profiles/{tag}_{wl}_pmc_FETCH_SIZE.csv: separate `rocprofv3 --pmc FETCH_SIZE` pass over bench.py, KiB summed over "
                       f"the launches of {names} per step; " + (
                           "512 B .. 4 KiB coalesced rows like the fast kernel's: x2 (calibrated on flat8g in the same round)"
                           if wl == "split32k" else
-                          "32-byte rows, 8 B per lane: counter uncalibrated for this pattern, x1 reading reported as traffic, x2 beside it"),
+                          "32-byte rows, 8 B per lane: x2 as calibrated on a bare gather of such rows (profiles/r03_calib_gather.json): one "
+                          "128-byte line per row request, tallied at 64 bytes; lines served by the Infinity Cache are counted too"),
         })
 if p_w:
     w_raw, _, _ = counter_per_step(p_w, "WRITE_SIZE", STEPS)
