@@ -77,7 +77,6 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
     const uint32_t slice  = wave % wpr;
 
     uint32_t* img_read = gn_sp_lds + (size_t)rslot * wpr * IMG; // byte images of all slices of my read
-    uint32_t* img      = img_read + (size_t)slice * IMG;
     uint32_t* rowtab   = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)wave * 128 * HFP;
     uint32_t* stage    = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)nwaves * 128 * HFP + (size_t)wave * 2 * GN_SPLIT_STAGE;
     uint32_t* candcnt  = gn_sp_lds + (size_t)rpb * wpr * IMG + (size_t)nwaves * (128 * HFP + 2 * GN_SPLIT_STAGE);
@@ -305,13 +304,28 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
         // ---- 3. byte image, then the select ----
         if (work)
         {
+            // The image is in BIN ORDER: byte b of the read's image = count of bin b.  (Round 2 stored the registers as they
+            // were -- register-major, lane-minor: neighbouring bins lay 256 or 512 bytes apart, i.e. in the SAME bank, and a
+            // wave summing the bins of 64 neighbouring targets took 32-64 bank conflicts per read instruction; that, not
+            // the arithmetic, was the 110 ms the select cost at low cutoffs.)  Byte y of register (d, j, pp) counts bin
+            // 32d + 8y + 4pp + j of the lane: dword k of group d takes byte y = k/2 of the four registers (d, 0..3, k%2).
+            uint32_t* nat = img_read + (size_t)wi * 16; // 16 dwords per 64-bin word
 #pragma unroll
             for (int d = 0; d < ND; ++d)
+            {
+                uint32_t o[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int pp = 0; pp < 2; ++pp)
-                        img[((d * 4 + j) * 2 + pp) * 64 + lane] = byt[d][j][pp];
+                for (int k = 0; k < 8; ++k)
+                {
+                    const uint32_t y = (uint32_t)k >> 1, pp = (uint32_t)k & 1u;
+                    const uint32_t sel = 0x0C0C0000u | ((4u + y) << 8) | y; // {lo.byte y, hi.byte y, 0, 0}
+                    const uint32_t t01 = __builtin_amdgcn_perm(byt[d][1][pp], byt[d][0][pp], sel);
+                    const uint32_t t23 = __builtin_amdgcn_perm(byt[d][3][pp], byt[d][2][pp], sel);
+                    o[k] = t01 | (t23 << 16);
+                }
+                *reinterpret_cast<uint4*>(nat + 8 * d)     = make_uint4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<uint4*>(nat + 8 * d + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+            }
         }
         __syncthreads();
 
@@ -321,11 +335,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
         bool     counting = true;
         unsigned long long base  = 0;
         {
-            auto cnt_of = [&](uint32_t bin) -> uint32_t {
-                const uint32_t word = bin >> 6, sl = word / (64 * LW), wrel = word - sl * 64 * LW, ln = wrel / LW;
-                const uint32_t tp = (wrel - ln * LW) * 64 + (bin & 63u), d = tp >> 5, bit = tp & 31u;
-                return (img_read[(size_t)sl * IMG + ((d * 4 + (bit & 3u)) * 2 + ((bit >> 2) & 1u)) * 64 + ln] >> (8u * (bit >> 3))) & 0xFFu;
-            };
+            const uint8_t* img_bytes = reinterpret_cast<const uint8_t*>(img_read);
+            auto cnt_of = [&](uint32_t bin) -> uint32_t { return img_bytes[bin]; };
             auto target_sum = [&](const uint4& rec) -> uint32_t { // {first CSR entry, bins, ., .}
                 uint32_t s = 0;
                 for (uint32_t x = 0; x < rec.y; ++x)
