@@ -336,6 +336,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
         unsigned long long base  = 0;
         {
             const uint8_t* img_bytes = reinterpret_cast<const uint8_t*>(img_read);
+            const uint32_t img_dwords = wpr * IMG; // dwords of the read's image
             auto cnt_of = [&](uint32_t bin) -> uint32_t { return img_bytes[bin]; };
             auto target_sum = [&](const uint4& rec) -> uint32_t { // {first CSR entry, bins, ., .}
                 uint32_t s = 0;
@@ -403,11 +404,26 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         {
                             uint32_t n0[4], n1[4], cv[4];
                             load_off(t0 + 4 * GN_WAVE, n0, n1); // the next trip's offsets fly while this trip's bins are summed
+                            // a target of up to four bins is one pair of dwords of the bin-ordered image, shifted to its first
+                            // bin and masked to its width: no loop whose trip count depends on the data, so the four targets of
+                            // a lane are in flight together (targets with more bins: the loop below, rarely taken)
+                            uint32_t x[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u)
                             {
-                                uint32_t sum = 0;
-                                for (uint32_t b = o0[u]; b < o1[u]; ++b)
+                                const uint32_t w0 = o0[u] >> 2;
+                                const uint32_t lo_dw = img_read[w0], hi_dw = img_read[w0 + 1 < img_dwords ? w0 + 1 : w0];
+                                x[u] = __builtin_amdgcn_alignbyte(hi_dw, lo_dw, o0[u] & 3u);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                            {
+                                const uint32_t nb = o1[u] - o0[u];
+                                const uint32_t m  = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+                                const uint32_t y  = x[u] & m;
+                                uint32_t       sum = (y & 0x00FF00FFu) + ((y >> 8) & 0x00FF00FFu);
+                                sum = (sum & 0xFFFFu) + (sum >> 16);
+                                for (uint32_t b = o0[u] + 4u; b < o1[u]; ++b)
                                     sum += cnt_of(b);
                                 cv[u] = sum > n ? n : sum; // :525-526
                             }
