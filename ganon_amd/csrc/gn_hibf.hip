@@ -94,7 +94,8 @@ struct GnHibfLevelParams
     uint64_t                  match_cap;
     uint32_t                  ub_bits;
     uint32_t                  lds_bins;  // LDS kernel: counters per wave
-    uint32_t                  n_reads;   // level 0 of the register-counter kernels: the reads are the items
+    uint32_t                  n_reads;   // level 0 of the register-counter kernels: the reads are the items ...
+    uint32_t                  read_base; // ... reads [read_base, read_base + n_reads) of the batch (a batch may be run in read ranges)
     const uint8_t*            status;
     uint32_t                  pack_gp;   // packed kernel: log2 of the lanes per row every item of the launch must have
     uint32_t                  wide;      // the reference's -DLONGREADS build (value_t = uint32_t): sums do not wrap at 2^16 and reads
@@ -263,7 +264,9 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
         if (b < n_batches && idx < n_work)
         {
             if constexpr (LEVEL0)
-                read = (p.status[idx] == GN_READ_OK || (p.wide && p.status[idx] == GN_READ_BIG)) ? idx : 0xFFFFFFFFu;
+                read = (p.status[idx + p.read_base] == GN_READ_OK || (p.wide && p.status[idx + p.read_base] == GN_READ_BIG))
+                           ? idx + p.read_base
+                           : 0xFFFFFFFFu;
             else
             {
                 const uint2 e = p.work_in[idx];
@@ -541,9 +544,10 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
             return make_uint2(0xFFFFFFFFu, 0u);
         if constexpr (LEVEL0)
         {
-            const uint32_t four = gn_sload(reinterpret_cast<const uint32_t*>(p.status) + (it >> 2)); // status bytes it&~3 ..
-            const uint32_t st1  = (four >> (8u * (it & 3u))) & 0xFFu;
-            return make_uint2((st1 == GN_READ_OK || (p.wide && st1 == GN_READ_BIG)) ? it : 0xFFFFFFFFu, 0u);
+            const uint32_t rd   = it + p.read_base;
+            const uint32_t four = gn_sload(reinterpret_cast<const uint32_t*>(p.status) + (rd >> 2)); // status bytes rd&~3 ..
+            const uint32_t st1  = (four >> (8u * (rd & 3u))) & 0xFFu;
+            return make_uint2((st1 == GN_READ_OK || (p.wide && st1 == GN_READ_BIG)) ? rd : 0xFFFFFFFFu, 0u);
         }
         else
         {
@@ -932,10 +936,12 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
         atomicAdd(&p.ctr[2], my_bytes);
 }
 
-__global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t n_reads, unsigned long long* count, uint32_t wide)
+__global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t read_base, uint32_t n_reads, unsigned long long* count,
+                                    uint32_t wide)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool     ok = r < n_reads && (status[r] == GN_READ_OK || (wide && status[r] == GN_READ_BIG));
+    const uint32_t i  = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r  = read_base + i;
+    const bool     ok = i < n_reads && (status[r] == GN_READ_OK || (wide && status[r] == GN_READ_BIG));
     const uint64_t bm = __ballot(ok);
     const int      lane = threadIdx.x & 63;
     unsigned long long base = 0;
@@ -947,9 +953,14 @@ __global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t
 }
 
 // sorted (key, raw sum) -> gn_match with the cap of select_matches (GanonClassify.cpp:561-564) + per-read histogram
+// (out_base: matches of the read ranges before this one; the valid pairs of a sorted range are its first entries)
 __global__ __launch_bounds__(256) void gn_hibf_finish_kernel(const uint64_t* keys, const uint32_t* vals, uint64_t n, uint32_t ub_bits,
-                                                             const uint32_t* n_hashes, gn_match* out, uint32_t* seg_count)
+                                                             const uint32_t* n_hashes, gn_match* out_all, uint32_t* seg_count,
+                                                             const unsigned long long* out_base, uint64_t out_cap)
 {
+    gn_match* out = out_all + *out_base;
+    if (*out_base + n > out_cap) // (the host sees the same and has the batch run again with more room)
+        return;
     const uint64_t i    = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t key  = i < n ? keys[i] : ~0ULL;
@@ -975,6 +986,21 @@ __global__ __launch_bounds__(256) void gn_hibf_finish_kernel(const uint64_t* key
         const uint32_t end   = above ? (uint32_t)__builtin_ctzll(above) : (uint32_t)__popcll(vm);
         atomicAdd(&seg_count[read], end - lane);
     }
+}
+
+// after a range's finish: the next range's matches begin behind this one's valid pairs (holes are sorted to the end)
+__global__ void gn_hibf_advance_kernel(const uint64_t* keys, uint64_t n, unsigned long long* out_base)
+{
+    uint64_t lo = 0, hi = n; // first index whose key is the all-ones sentinel
+    while (lo < hi)
+    {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] == ~0ULL)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    *out_base += lo;
 }
 
 // ---- matches that a filter_matches pre-pass is bound to drop never reach the sort --------------------------------------------
@@ -1290,6 +1316,12 @@ static void gn_hibf_launch_pack(const GnHibfLevelParams& p, bool level0, uint32_
 // Runs all levels back to back (queue lengths stay on the device), synchronises ONCE, then sorts/groups the matches.
 int gn_finish_batch(gn_stream* s); // gn_capi.hip
 
+// One HIBF batch.  The raw (read, user bin) pairs of a batch must fit the pair buffers before they are pre-dropped and sorted,
+// and the radix sort counts its items in an int: at low cutoffs (thousands of chance pairs per read: 27 G pairs for 10 M reads
+// against 65 536 user bins at --rel-cutoff 0.2) a batch holds more than either allows.  Such a batch is run in READ RANGES:
+// every range goes through the levels, the pre-drop, the sort and the finish on its own, appending its matches behind the
+// previous range's (ranges ascend, so the result is grouped by read as ever).  A range whose pairs exceed what memory or the
+// sort can take is halved; one that merely exceeds the current buffers makes the caller grow them (gn_finish) as before.
 int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
 {
     int rc = gn_hibf_ensure_sort_buffers(s);
@@ -1304,167 +1336,261 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         return gn_fail(GN_ERANGE, "read index and user bin do not fit one 64-bit sort key");
     GN_HIP(hipMemsetAsync(s->d_ctr + 2, 0, 2 * sizeof(unsigned long long), st)); // algo bytes, (unused)
     GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
-    GN_HIP(hipMemsetAsync(s->d_hctr, 0, 4 * NL * sizeof(unsigned long long), st));
+    GN_HIP(hipMemsetAsync(s->d_hctr, 0, (4 * NL + 2) * sizeof(unsigned long long), st)); // queues, per-level bytes, [4NL] output base
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
+    unsigned long long* d_out_base = s->d_hctr + 4 * NL;
     const uint32_t h      = f->ibfs[0].h;
     // tests / A-B: skip the packed kernel (the per-item register kernel takes whole levels), or both (LDS kernel only)
     const bool     no_reg  = getenv("GANON_HIP_HIBF_NO_REG") != nullptr;
     const bool     no_pack = no_reg || getenv("GANON_HIP_HIBF_NO_PACK") != nullptr;
-    if (n && no_reg) // (the register-counter kernels take level 0 straight from the batch)
-        hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, n, s->d_hctr,
-                           s->long_reads ? 1u : 0u);
     const uint32_t reg_bpc = getenv("GANON_HIP_HIBF_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_HIBF_BPC")) : 0u; // 0 = occupancy
-    s->hibf_levels_run = 0;
-    for (uint32_t lvl = 0; lvl < depth && n; ++lvl)
-    {
-        if (lvl < GN_HIBF_TIMED_LEVELS)
-        {
-            if (!s->ev_lvl[lvl])
-                GN_HIP(hipEventCreate(&s->ev_lvl[lvl]));
-            GN_HIP(hipEventRecord(s->ev_lvl[lvl], st));
-        }
-        if (lvl > 0) // algorithmic bytes so far (cumulative), for the per-level figures
-            GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (lvl - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
-        GnHibfLevelParams p{};
-        p.ibfs        = f->d_hibf;
-        p.hashes      = s->d_hashes;
-        p.slot_off    = s->d_slot_off;
-        p.n_hashes    = s->d_nh;
-        p.rel_cutoff  = s->rel_cutoff;
-        p.wide        = s->long_reads ? 1u : 0u;
-        p.work_in     = s->d_work[lvl & 1];
-        p.count_in    = s->d_hctr + lvl;
-        p.work_out    = s->d_work[(lvl + 1) & 1];
-        p.count_out   = s->d_hctr + lvl + 1;
-        p.work_cap    = s->work_cap;
-        p.ctr         = s->d_ctr;
-        p.keys        = s->d_keys[0];
-        p.vals        = s->d_vals[0];
-        p.match_cap   = s->match_cap;
-        p.ub_bits     = ub_bits;
-        p.lds_bins    = f->max_bins;
-        p.n_reads     = n;
-        p.status      = s->d_status;
-        p.pack_gp     = lvl < f->level_gp.size() ? f->level_gp[lvl] : 0u;
-        bool level0   = lvl == 0; // the first register kernel of level 0 takes the reads themselves as its items
-        if (!no_pack)
-        {
-            p.defer_out   = s->d_hdefer;
-            p.defer_count = s->d_hctr + NL + lvl;
-            switch (h)
-            {
-                case 1: gn_hibf_launch_pack<1>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 2: gn_hibf_launch_pack<2>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 3: gn_hibf_launch_pack<3>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 4: gn_hibf_launch_pack<4>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                default: gn_hibf_launch_pack<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-            }
-            GN_HIP(hipGetLastError());
-            p.work_in  = s->d_hdefer;
-            p.count_in = s->d_hctr + NL + lvl;
-            level0     = false;
-        }
-        if (!no_reg)
-        {
-            p.defer_out   = s->d_hdefer2;
-            p.defer_count = s->d_hctr + 2 * NL + lvl;
-            switch (h)
-            {
-                case 1: gn_hibf_launch_reg<1>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 2: gn_hibf_launch_reg<2>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 3: gn_hibf_launch_reg<3>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                case 4: gn_hibf_launch_reg<4>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-                default: gn_hibf_launch_reg<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
-            }
-            GN_HIP(hipGetLastError());
-            p.work_in  = s->d_hdefer2;
-            p.count_in = s->d_hctr + 2 * NL + lvl;
-        }
-        // LDS-counter kernel: what the register kernels left (or, with the switch above, the whole level)
-        const uint32_t wpb = (size_t)f->max_bins * 4 * 4 <= 64 * 1024 ? 4 : 1; // waves per block by LDS need
-        const size_t   lds = (size_t)f->max_bins * 4 * wpb;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_hibf_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        hipLaunchKernelGGL(gn_hibf_level_kernel, dim3((uint32_t)f->n_cu * (wpb == 4 ? 8u : 16u)), dim3(wpb * 64), lds, st, p);
-        GN_HIP(hipGetLastError());
-    }
-    if (n)
-    {
-        const uint32_t last = depth < GN_HIBF_TIMED_LEVELS ? depth : GN_HIBF_TIMED_LEVELS;
-        if (!s->ev_lvl[last])
-            GN_HIP(hipEventCreate(&s->ev_lvl[last]));
-        GN_HIP(hipEventRecord(s->ev_lvl[last], st));
-        GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (depth - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
-        s->hibf_levels_run = depth;
-    }
-    // the one synchronisation of the batch: queue lengths (overflow check) and the match cursor (sort size)
-    GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, 4 * NL * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    GN_HIP(hipStreamSynchronize(st));
-    uint64_t worst = 0;
-    for (uint32_t i = 0; i < 3 * NL; ++i) // (the fourth row holds byte counts, not queue lengths)
-        worst = std::max<uint64_t>(worst, s->h_hctr[i]);
-    if (worst > s->work_cap)
-    {
-        // a queue overflowed (entries past the capacity were dropped): grow the queues and run the batch again
-        for (uint2** q : { &s->d_work[0], &s->d_work[1], &s->d_hdefer, &s->d_hdefer2 })
-        {
-            hipFree(*q);
-            *q = nullptr;
-        }
-        s->work_cap = (uint32_t)std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFF0ull);
-        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[0]), (size_t)s->work_cap * sizeof(uint2)));
-        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[1]), (size_t)s->work_cap * sizeof(uint2)));
-        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_hdefer), (size_t)s->work_cap * sizeof(uint2)));
-        GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_hdefer2), (size_t)s->work_cap * sizeof(uint2)));
-        GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
-        return gn_hibf_classify(s, f, st);
-    }
-    // group: radix sort by (read, user bin), cap counts, histogram per read, exclusive scan
-    const uint64_t nm = s->h_ctr[0];
-    if (nm > s->match_cap)
-        return GN_OK; // gn_finish() sees the overflow, grows the buffers and re-runs
-    // with a filter_matches pre-pass on the stream, what it is bound to drop does not reach the sort (kernels above)
-    uint64_t ns = nm; // pairs to sort
-    int      src = 0;
+    // with a filter_matches pre-pass on the stream, what it is bound to drop does not reach the sort
+    const bool may_predrop = s->pf_on && !s->pf_merge && s->d_pf_segmin && s->d_pf_rmax && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
+                             (uint64_t)n + 1 <= s->pf_segmin_cap && !getenv("GANON_HIP_NO_PREDROP");
     s->pf_predrop = false;
-    if (s->pf_on && !s->pf_merge && s->d_pf_segmin && s->d_pf_rmax && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
-        (uint64_t)n + 1 <= s->pf_segmin_cap && nm > 8ull * n && !getenv("GANON_HIP_NO_PREDROP"))
+    if (may_predrop)
     {
         GN_HIP(hipMemsetAsync(s->d_pf_rmax, 0, ((size_t)n + 1) * 4, st));
         GN_HIP(hipMemsetAsync(s->d_pf_segmin, 0xFF, ((size_t)n + 1) * 4, st));
         GN_HIP(hipMemsetAsync(s->d_pf_pre, 0, 2 * sizeof(unsigned long long), st)); // [0] pairs left out [1] output cursor
-        const unsigned blocks = (unsigned)std::min<uint64_t>((nm + 255) / 256, (uint64_t)f->n_cu * 8);
-        hipLaunchKernelGGL(gn_hibf_premax_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->d_nh,
-                           s->d_pf_rmax);
-        hipLaunchKernelGGL(gn_hibf_predrop_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->d_nh,
-                           s->d_pf_rmax, s->rel_cutoff, s->pf_joint ? 2u : 1u, s->pf_rel_filter, s->d_keys[1], s->d_vals[1], s->match_cap,
-                           s->d_pf_pre + 1, s->d_pf_segmin, s->d_pf_pre);
-        GN_HIP(hipGetLastError());
-        unsigned long long out_n = 0;
-        GN_HIP(hipMemcpyAsync(&out_n, s->d_pf_pre + 1, sizeof(out_n), hipMemcpyDeviceToHost, st));
-        GN_HIP(hipStreamSynchronize(st));
-        if (out_n <= s->match_cap) // (else: chunk holes pushed it past the buffer -- the raw pairs are sorted as they are)
-        {
-            ns            = out_n;
-            src           = 1;
-            s->pf_predrop = true;
-        }
     }
-    if (ns)
+    // pairs one range may have: the sort's int, and what the device could hold if the buffers were grown for it (two pair
+    // buffers, two match buffers, the sort's scratch: ~64 bytes a pair) -- $GANON_HIP_HIBF_PAIR_LIMIT for tests
+    uint64_t pair_limit = 0x7FFFFFF0ull;
     {
-        if (ns > 0x7FFFFFFFull)
-            return gn_fail(GN_ERANGE, "more than 2^31 matches in one batch");
-        size_t tmp = s->sort_tmp_bytes;
-        GN_HIP(hipcub::DeviceRadixSort::SortPairs(s->d_sort_tmp, tmp, s->d_keys[src], s->d_keys[1 - src], s->d_vals[src], s->d_vals[1 - src],
-                                                  (int)ns, 0, (int)(ub_bits + rd_bits), st));
-        if (src == 1) // (the sorted pairs are expected in buffer 1)
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess)
+            pair_limit = std::min<uint64_t>(pair_limit, std::max<uint64_t>(1u << 20, ((uint64_t)fr + s->match_cap * 64ull) / 80ull));
+        if (getenv("GANON_HIP_HIBF_PAIR_LIMIT"))
+            pair_limit = std::max<uint64_t>(64, strtoull(getenv("GANON_HIP_HIBF_PAIR_LIMIT"), nullptr, 10));
+    }
+
+    // the levels of reads [lo, lo + cnt): queue lengths and the match cursor come back to the host (one sync)
+    auto run_levels = [&](uint32_t lo, uint32_t cnt, bool stamp) -> int {
+        GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
+        GN_HIP(hipMemsetAsync(s->d_hctr, 0, 3 * NL * sizeof(unsigned long long), st));
+        if (cnt && no_reg) // (the register-counter kernels take level 0 straight from the batch)
+            hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, lo, cnt, s->d_hctr,
+                               s->long_reads ? 1u : 0u);
+        for (uint32_t lvl = 0; lvl < depth && cnt; ++lvl)
         {
-            std::swap(s->d_keys[0], s->d_keys[1]);
-            std::swap(s->d_vals[0], s->d_vals[1]);
+            if (stamp && lvl < GN_HIBF_TIMED_LEVELS)
+            {
+                if (!s->ev_lvl[lvl])
+                    GN_HIP(hipEventCreate(&s->ev_lvl[lvl]));
+                GN_HIP(hipEventRecord(s->ev_lvl[lvl], st));
+            }
+            if (lvl > 0) // algorithmic bytes so far (cumulative), for the per-level figures
+                GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (lvl - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+            GnHibfLevelParams p{};
+            p.ibfs        = f->d_hibf;
+            p.hashes      = s->d_hashes;
+            p.slot_off    = s->d_slot_off;
+            p.n_hashes    = s->d_nh;
+            p.rel_cutoff  = s->rel_cutoff;
+            p.wide        = s->long_reads ? 1u : 0u;
+            p.work_in     = s->d_work[lvl & 1];
+            p.count_in    = s->d_hctr + lvl;
+            p.work_out    = s->d_work[(lvl + 1) & 1];
+            p.count_out   = s->d_hctr + lvl + 1;
+            p.work_cap    = s->work_cap;
+            p.ctr         = s->d_ctr;
+            p.keys        = s->d_keys[0];
+            p.vals        = s->d_vals[0];
+            p.match_cap   = s->match_cap;
+            p.ub_bits     = ub_bits;
+            p.lds_bins    = f->max_bins;
+            p.n_reads     = cnt;
+            p.read_base   = lo;
+            p.status      = s->d_status;
+            p.pack_gp     = lvl < f->level_gp.size() ? f->level_gp[lvl] : 0u;
+            bool level0   = lvl == 0; // the first register kernel of level 0 takes the reads themselves as its items
+            if (!no_pack)
+            {
+                p.defer_out   = s->d_hdefer;
+                p.defer_count = s->d_hctr + NL + lvl;
+                switch (h)
+                {
+                    case 1: gn_hibf_launch_pack<1>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                    case 2: gn_hibf_launch_pack<2>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                    case 3: gn_hibf_launch_pack<3>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                    case 4: gn_hibf_launch_pack<4>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                    default: gn_hibf_launch_pack<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                }
+                GN_HIP(hipGetLastError());
+                p.work_in  = s->d_hdefer;
+                p.count_in = s->d_hctr + NL + lvl;
+                level0     = false;
+            }
+            if (!no_reg)
+            {
+                p.defer_out   = s->d_hdefer2;
+                p.defer_count = s->d_hctr + 2 * NL + lvl;
+                switch (h)
+                {
+                    case 1: gn_hibf_launch_reg<1>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                    case 2: gn_hibf_launch_reg<2>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                    case 3: gn_hibf_launch_reg<3>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                    case 4: gn_hibf_launch_reg<4>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                    default: gn_hibf_launch_reg<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
+                }
+                GN_HIP(hipGetLastError());
+                p.work_in  = s->d_hdefer2;
+                p.count_in = s->d_hctr + 2 * NL + lvl;
+            }
+            // LDS-counter kernel: what the register kernels left (or, with the switch above, the whole level)
+            const uint32_t wpb = (size_t)f->max_bins * 4 * 4 <= 64 * 1024 ? 4 : 1; // waves per block by LDS need
+            const size_t   lds = (size_t)f->max_bins * 4 * wpb;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_hibf_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            hipLaunchKernelGGL(gn_hibf_level_kernel, dim3((uint32_t)f->n_cu * (wpb == 4 ? 8u : 16u)), dim3(wpb * 64), lds, st, p);
+            GN_HIP(hipGetLastError());
         }
-        hipLaunchKernelGGL(gn_hibf_finish_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, s->d_keys[1],
-                           s->d_vals[1], ns, ub_bits, s->d_nh, s->d_sorted, s->d_seg_count);
+        if (cnt && stamp)
+        {
+            const uint32_t last = depth < GN_HIBF_TIMED_LEVELS ? depth : GN_HIBF_TIMED_LEVELS;
+            if (!s->ev_lvl[last])
+                GN_HIP(hipEventCreate(&s->ev_lvl[last]));
+            GN_HIP(hipEventRecord(s->ev_lvl[last], st));
+            GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (depth - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+        }
+        GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, 4 * NL * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipStreamSynchronize(st));
+        return GN_OK;
+    };
+
+    s->hibf_levels_run = 0;
+    uint64_t need_cap = 0;       // capacity the caller has to provide if this run does not fit (-> d_ctr[0], see gn_finish)
+    uint64_t out_upper = 0;      // matches appended so far, holes of the sorted ranges included (an upper bound of *d_out_base)
+    uint64_t done_bytes = 0, done_exact = 0; // ctr[2] / ctr[6] after the ranges that are through (a range that is run again starts from them)
+    uint32_t n_ranges = 0;
+    uint32_t step = s->hibf_range_reads && s->hibf_range_reads < n ? s->hibf_range_reads : n; // (what fitted the last batch)
+    uint32_t lo = 0;
+    while (lo < n || (n == 0 && n_ranges == 0))
+    {
+        const uint32_t cnt = n ? std::min<uint32_t>(step, n - lo) : 0;
+        rc = run_levels(lo, cnt, lo == 0 && cnt == n);
+        if (rc)
+            return rc;
+        uint64_t worst = 0;
+        for (uint32_t i = 0; i < 3 * NL; ++i) // (the fourth row holds byte counts, not queue lengths)
+            worst = std::max<uint64_t>(worst, s->h_hctr[i]);
+        const uint64_t nm = s->h_ctr[0];
+        auto restore = [&]() -> int { // the range is run again: what it added to the batch totals goes
+            GN_HIP(hipMemcpyAsync(s->d_ctr + 2, &done_bytes, 8, hipMemcpyHostToDevice, st));
+            GN_HIP(hipMemcpyAsync(s->d_ctr + 6, &done_exact, 8, hipMemcpyHostToDevice, st));
+            GN_HIP(hipStreamSynchronize(st));
+            return GN_OK;
+        };
+        if (worst > s->work_cap)
+        {
+            // a queue overflowed (entries past the capacity were dropped): grow the queues and run the range again
+            for (uint2** q : { &s->d_work[0], &s->d_work[1], &s->d_hdefer, &s->d_hdefer2 })
+            {
+                hipFree(*q);
+                *q = nullptr;
+            }
+            s->work_cap = (uint32_t)std::min<uint64_t>(worst + worst / 4 + 1024, 0xFFFFFFF0ull);
+            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[0]), (size_t)s->work_cap * sizeof(uint2)));
+            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work[1]), (size_t)s->work_cap * sizeof(uint2)));
+            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_hdefer), (size_t)s->work_cap * sizeof(uint2)));
+            GN_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_hdefer2), (size_t)s->work_cap * sizeof(uint2)));
+            if ((rc = restore()))
+                return rc;
+            continue;
+        }
+        if (nm > s->match_cap || nm > pair_limit)
+        {
+            if (nm > pair_limit && cnt > 1)
+            {
+                // more pairs than one sort (or the device) takes: this range in two halves
+                step = (cnt + 1) / 2;
+                if ((rc = restore()))
+                    return rc;
+                continue;
+            }
+            if (nm > pair_limit)
+                return gn_fail(GN_ERANGE, "one read has %llu HIBF matches: more than one batch can hold", (unsigned long long)nm);
+            need_cap = std::max(need_cap, nm); // fits after the caller has grown the buffers: nothing more to do in this run
+            break;
+        }
+        // ---- pre-drop, sort, finish of this range ----
+        uint64_t ns  = nm; // pairs to sort
+        int      src = 0;
+        if (may_predrop && nm > 8ull * cnt)
+        {
+            GN_HIP(hipMemsetAsync(s->d_pf_pre + 1, 0, sizeof(unsigned long long), st));
+            const unsigned blocks = (unsigned)std::min<uint64_t>((nm + 255) / 256, (uint64_t)f->n_cu * 8);
+            hipLaunchKernelGGL(gn_hibf_premax_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->d_nh,
+                               s->d_pf_rmax);
+            hipLaunchKernelGGL(gn_hibf_predrop_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->d_nh,
+                               s->d_pf_rmax, s->rel_cutoff, s->pf_joint ? 2u : 1u, s->pf_rel_filter, s->d_keys[1], s->d_vals[1], s->match_cap,
+                               s->d_pf_pre + 1, s->d_pf_segmin, s->d_pf_pre);
+            GN_HIP(hipGetLastError());
+            unsigned long long out_n = 0;
+            GN_HIP(hipMemcpyAsync(&out_n, s->d_pf_pre + 1, sizeof(out_n), hipMemcpyDeviceToHost, st));
+            GN_HIP(hipStreamSynchronize(st));
+            if (out_n <= s->match_cap) // (else: chunk holes pushed it past the buffer -- the raw pairs are sorted as they are)
+            {
+                ns            = out_n;
+                src           = 1;
+                s->pf_predrop = true;
+            }
+            else
+            {
+                // chunk holes pushed the survivors past the buffer: the batch is run again with more room (everything the
+                // pre-drop has noted so far is reset at the start of that run)
+                need_cap = std::max<uint64_t>(need_cap, out_n);
+                break;
+            }
+        }
+        if (out_upper + ns > s->match_cap)
+        {
+            need_cap = std::max(need_cap, out_upper + ns + ((uint64_t)(n - lo - cnt) / std::max<uint32_t>(cnt, 1u)) * ns);
+            break;
+        }
+        if (ns)
+        {
+            size_t tmp = s->sort_tmp_bytes;
+            GN_HIP(hipcub::DeviceRadixSort::SortPairs(s->d_sort_tmp, tmp, s->d_keys[src], s->d_keys[1 - src], s->d_vals[src], s->d_vals[1 - src],
+                                                      (int)ns, 0, (int)(ub_bits + rd_bits), st));
+            if (src == 1) // (the sorted pairs are expected in buffer 1)
+            {
+                std::swap(s->d_keys[0], s->d_keys[1]);
+                std::swap(s->d_vals[0], s->d_vals[1]);
+            }
+            hipLaunchKernelGGL(gn_hibf_finish_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, s->d_keys[1], s->d_vals[1], ns,
+                               ub_bits, s->d_nh, s->d_sorted, s->d_seg_count, d_out_base, s->match_cap);
+            hipLaunchKernelGGL(gn_hibf_advance_kernel, dim3(1), dim3(1), 0, st, s->d_keys[1], ns, d_out_base);
+            GN_HIP(hipGetLastError());
+            out_upper += ns;
+        }
+        done_bytes = s->h_ctr[2];
+        done_exact = s->h_ctr[6];
+        ++n_ranges;
+        if (n_ranges == 1 && cnt == n)
+            s->hibf_levels_run = depth;
+        lo += cnt;
+        if (n == 0)
+            break;
+    }
+    s->hibf_ranges = n_ranges;
+    if (n_ranges > 1 || step < n)
+        s->hibf_range_reads = step; // the next batch starts with ranges of the size that went through
+    if (need_cap)
+    {
+        // gn_finish() reads the cursor, sees that it exceeds the capacity, grows the buffers and runs the batch again
+        const unsigned long long v = need_cap;
+        GN_HIP(hipMemcpyAsync(s->d_ctr, &v, sizeof(v), hipMemcpyHostToDevice, st));
+        GN_HIP(hipStreamSynchronize(st));
+        return GN_OK;
+    }
+    {
+        // the cursor of a batch that went through: within the capacity (the gather / pre-pass kernels look at it)
+        const unsigned long long v = out_upper;
+        GN_HIP(hipMemcpyAsync(s->d_ctr, &v, sizeof(v), hipMemcpyHostToDevice, st));
+        GN_HIP(hipStreamSynchronize(st));
     }
     size_t tmp = s->scan_tmp_bytes;
     GN_HIP(gn_scan_counts(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(n + 1), st));
@@ -1477,6 +1603,8 @@ int gn_hibf_dense(gn_stream* s, uint32_t rb, uint32_t re, uint16_t* counts)
     gn_filter*            f  = s->f;
     const uint64_t        nm = s->n_matches;
     const uint32_t        ub_bits = std::max(1u, gn_bits_for(f->n_user_bins ? f->n_user_bins - 1 : 0));
+    if (s->hibf_ranges > 1)
+        return gn_fail(GN_ERANGE, "dense counts: the batch was run in %u read ranges (the tap reads one sorted pair buffer)", s->hibf_ranges);
     std::vector<uint64_t> keys(nm ? nm : 1);
     std::vector<uint32_t> vals(nm ? nm : 1);
     if (nm)

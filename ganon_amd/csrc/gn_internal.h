@@ -272,6 +272,8 @@ struct gn_stream
     uint64_t      hibf_cap = 0;
     hipEvent_t    ev_lvl[GN_HIBF_TIMED_LEVELS + 1]{}; // HIBF: start of every tree level's kernels (and the end of the last)
     uint32_t      hibf_levels_run = 0;
+    uint32_t      hibf_ranges = 0;       // read ranges the last HIBF batch was run in (1 = the usual case)
+    uint32_t      hibf_range_reads = 0;  // reads per range that went through last time (0: whole batches)
     // reads with more than 65 535 minimisers (gn_stream_set_long_reads): list, counter, uint32 count slabs of the long kernel
     bool                long_reads = false;
     uint32_t*           d_long_list = nullptr;

@@ -1220,3 +1220,65 @@ def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, mon
         assert tot > 0 or rel_filter in (0.0, 0.99)
     st.destroy()
     flt.free()
+
+
+@pytest.mark.parametrize("prepass", [False, True])
+@pytest.mark.parametrize("limit", [200, 3000, 40000])
+def test_hibf_batch_in_read_ranges_equals_one_pass(hip, monkeypatch, limit, prepass):
+    # A batch with more raw (read, user bin) pairs than one radix sort (2^31 items) or the device takes is run in read ranges,
+    # each with its own levels / pre-drop / sort / finish, appended in read order.  $GANON_HIP_HIBF_PAIR_LIMIT makes that happen
+    # at toy size: the result must be the one-pass result record for record -- and the oracle's.
+    k, w = 19, 31
+    rng = np.random.default_rng(41)
+    genomes = [gu.random_seq(rng, 4000) for _ in range(50)]
+    uh = {ub * 5: np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w)) for ub, g in enumerate(genomes)}
+    hb = gf.random_hibf(400, 64, 2, seed=31, density=0.35, hash_funs=3, user_hashes=uh)
+    flt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+    seqs = []
+    for i in range(700):
+        L = int(rng.choice([60, 150, 250]))
+        if i % 3:
+            g = genomes[i % 50]
+            p = int(rng.integers(0, 4000 - L))
+            seqs.append(g[p:p + L])
+        else:
+            seqs.append(gu.random_seq(rng, L))
+    seqs[5] = b"ACGT"
+    bases, off1, off2 = gu.pack_reads(seqs, None)
+    tfpr = rng.choice([1e-4, 0.01, 0.05, 0.2], size=400)
+
+    def run():
+        st = hip.HipStream(flt, len(seqs), bases.size, max_matches=64)   # tiny buffers: the regrow path is part of it
+        if prepass:
+            st.set_postfilter(0.1, 1e-3, tfpr)
+        out = []
+        for cutoff in (0.1, 0.5):
+            st.submit(bases, off1, off2, k, w, cutoff)
+            nh, status, mo, m = st.fetch()
+            extra = st.fetch_postfilter() if prepass else None
+            out.append((nh.copy(), status.copy(), mo.copy(), m.copy(), extra))
+            # a second batch on the same stream (the range size of the last batch is remembered)
+            st.submit(bases, off1, off2, k, w, cutoff)
+            nh2, status2, mo2, m2 = st.fetch()
+            assert np.array_equal(mo2, mo) and np.array_equal(m2, m)
+        st.destroy()
+        return out
+
+    whole = run()
+    monkeypatch.setenv("GANON_HIP_HIBF_PAIR_LIMIT", str(limit))
+    split = run()
+    for (nh, status, mo, m, ex), (nh2, status2, mo2, m2, ex2) in zip(whole, split):
+        assert np.array_equal(nh, nh2) and np.array_equal(status, status2) and np.array_equal(mo, mo2) and np.array_equal(m, m2)
+        if prepass:
+            assert np.array_equal(ex[0], ex2[0]) and ex[1:] == ex2[1:]
+    if not prepass:
+        nh, status, mo, m, _ = whole[0]
+        for r, sq in enumerate(seqs):
+            if len(sq) < w:
+                continue
+            hh = oracle.minimiser_hash(oracle.to_ranks(sq), k, w)
+            counts = hb.bulk_count(hh, oracle.threshold_cutoff(len(hh), 0.1))
+            exp = [(int(u), int(min(int(counts[u]), len(hh)))) for u in np.nonzero(counts)[0]]
+            assert [(int(x["target"]), int(x["count"])) for x in m[int(mo[r]):int(mo[r + 1])]] == exp, r
+    assert len(whole[0][3]) > 2000
+    flt.free()
