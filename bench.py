@@ -367,17 +367,21 @@ def main() -> int:
             # A/B on request (needs --reads <= 500000: 3 000 chance matches per read at this cutoff): --rel-cutoff 0.2 plain, with the
             # filter_matches pre-pass judging every pair after the sort, and with the pairs it is bound to drop left out of the sort
             variants = {}
-            _, cms, _, tms, tmv = timed(0.2, 3, 1)
-            variants["rel_cutoff_0.2"] = dict(ms_per_step=round(float(np.mean(tms)), 3), matches=int(tmv["n_matches"]))
+            small = n_reads <= 500_000   # (without the pre-pass the RESULT of 10 M reads is 27 G matches = 330 GB: only the pre-pass run fits)
+            if small:
+                _, cms, _, tms, tmv = timed(0.2, 3, 1)
+                variants["rel_cutoff_0.2"] = dict(ms_per_step=round(float(np.mean(tms)), 3), matches=int(tmv["n_matches"]))
             st.set_postfilter(0.1, 1e-5, np.full(spec["user_bins"], 0.05, dtype=np.float64))
-            for tag, env in (("every_pair_sorted", "1"), ("device_filter_matches", None)):
+            for tag, env in ((("every_pair_sorted", "1"),) if small else ()) + (("device_filter_matches", None),):
                 if env:
                     os.environ["GANON_HIP_NO_PREDROP"] = env
-                _, cms, _, tms, tmv = timed(0.2, 3, 1)
+                _, cms, _, tms, tmv = timed(0.2, 3 if small else 2, 1)
                 os.environ.pop("GANON_HIP_NO_PREDROP", None)
                 _, d_fil, d_fpr = st.fetch_postfilter()
-                variants["low_cutoff_" + tag] = dict(ms_per_step=round(float(np.mean(tms)), 3), dropped_rel_filter=d_fil, dropped_fpr_query=d_fpr,
-                                                     matches_after=int(st.fetch()[2][-1]))
+                variants["low_cutoff_" + tag] = dict(thresholds="--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5", ms_per_step=round(float(np.mean(tms)), 3),
+                                                     mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), dropped_rel_filter=d_fil,
+                                                     dropped_fpr_query=d_fpr, matches_after=int(st.fetch()[2][-1]),
+                                                     raw_pairs=int(d_fil + d_fpr + int(st.fetch()[2][-1])))
             st.set_postfilter(None)
             result["variants"] = variants
             step(args.rel_cutoff)

@@ -1500,18 +1500,18 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                 return rc;
             continue;
         }
-        if (nm > s->match_cap || nm > pair_limit)
+        if (nm > pair_limit && cnt > 1)
         {
-            if (nm > pair_limit && cnt > 1)
-            {
-                // more pairs than one sort (or the device) takes: this range in two halves
-                step = (cnt + 1) / 2;
-                if ((rc = restore()))
-                    return rc;
-                continue;
-            }
-            if (nm > pair_limit)
-                return gn_fail(GN_ERANGE, "one read has %llu HIBF matches: more than one batch can hold", (unsigned long long)nm);
+            // more pairs than one sort (or the device) takes: this range in two halves
+            step = (cnt + 1) / 2;
+            if ((rc = restore()))
+                return rc;
+            continue;
+        }
+        if (nm > 0x7FFFFFF0ull)
+            return gn_fail(GN_ERANGE, "one read has %llu HIBF matches: more than one sort takes", (unsigned long long)nm);
+        if (nm > s->match_cap)
+        {
             need_cap = std::max(need_cap, nm); // fits after the caller has grown the buffers: nothing more to do in this run
             break;
         }

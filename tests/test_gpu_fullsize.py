@@ -207,3 +207,42 @@ def test_hibf_fullsize_structure_and_oracle_sample(hibf_full):
         exp = [(int(u), int(min(c, len(hh)))) for u, c in zip(np.nonzero(counts)[0], counts[np.nonzero(counts)[0]])]
         got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[r]):int(mo[r + 1])]]
         assert nh[r] == len(hh) and got == exp, (r, got, exp)
+
+
+def test_hibf_low_cutoff_at_full_size_runs_in_read_ranges(hibf_full, monkeypatch):
+    """configs[2] at the binary's own --rel-cutoff 0.2 with the pre-pass `ganon classify` sets (--rel-filter 0.1 --fpr-query 1e-5):
+    ~2700 chance pairs per read, 27 G raw pairs for the 10 M reads -- more than one radix sort counts and more than the device
+    holds.  The batch is run in read ranges (gn_hibf.hip); whatever the range size, survivors and dropped totals are the same,
+    and a sample of reads agrees with the oracle's counting agent + filter_matches."""
+    import oracle
+    hip, wl, flt, st, _ = hibf_full
+    tfpr = np.full(65536, 0.05)
+    runs = []
+    for limit in (None, "600000000"):
+        if limit:
+            monkeypatch.setenv("GANON_HIP_HIBF_PAIR_LIMIT", limit)
+        st.set_postfilter(0.1, 1e-5, tfpr)
+        st.classify(wl.k, wl.w, 0.2)
+        nh, status, mo, m = st.fetch()
+        mx, d_fil, d_fpr = st.fetch_postfilter()
+        runs.append((mo.copy(), bw.checksum_matches(m), len(m), d_fil, d_fpr, mx.copy(), m if limit is None else None))
+    st.set_postfilter(None)
+    a, b = runs
+    assert np.array_equal(a[0], b[0]) and a[1:5] == b[1:5] and np.array_equal(a[5], b[5])
+    raw_pairs = a[2] + a[3] + a[4]
+    assert raw_pairs > 2_000 * (HIBF_READS // 1000) and raw_pairs > 2**31 or HIBF_READS < 10_000_000
+    # oracle on a few reads: every pair that passed the cutoff, then filter_matches' two rules
+    bw.download_hibf(flt, wl)
+    hb = oracle.Hibf([oracle.Ibf(bn, s_, h, r) for (r, bn, s_, h) in wl.ibfs], wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)
+    rng = np.random.default_rng(8)
+    mo, m = a[0], a[6]
+    for r in rng.integers(0, wl.n_reads, size=12).tolist():
+        hh = oracle.minimiser_hash(oracle.to_ranks(wl.bases[int(wl.off[r]):int(wl.off[r + 1])]), wl.k, wl.w)
+        counts = np.minimum(hb.bulk_count(hh, oracle.threshold_cutoff(len(hh), 0.2)).astype(np.int64), len(hh))
+        nz = np.nonzero(counts)[0]
+        mx_, mn_ = int(counts[nz].max()), int(min(len(hh), counts[nz].min()))
+        thr = mx_ - int(np.ceil((mx_ - mn_) * 0.1))
+        keep = {int(u) for u in nz if counts[u] >= thr}
+        got = {int(x["target"]): int(x["count"]) & 0x7FFFFFFF for x in m[int(mo[r]):int(mo[r + 1])]}
+        assert set(got) <= keep and all(got[u] == counts[u] for u in got), r      # survivors of --rel-filter, minus what --fpr-query took
+        assert int(a[5][r]) == mx_
