@@ -425,8 +425,24 @@ def main() -> int:
     if default_run and world == 1 and rank == 0:
         result["other_workloads"] = [run_extra(w, args.extra_timeout) for w in EXTRA_WORKLOADS]
     elif default_run and world > 1:
-        # the configs BASELINE.json quotes its scaling target on, with the real world size (every rank takes part)
+        # the configs BASELINE.json quotes its scaling target on, with the real world size (every rank takes part).
+        # They run behind a watchdog: if a rank fails inside a collective the others would wait for ever, and the headline
+        # measured above must not be lost over an extra -- after --extra-timeout seconds rank 0 prints the line it has and
+        # every rank leaves.
+        import threading
         others = []
+
+        def give_up():
+            log(f"[rank {rank}] bench.py: the in-job extras did not finish within {args.extra_timeout} s -- leaving without them")
+            if rank == 0:
+                result["other_workloads"] = others + [{"workload": "(in-job extras)", "error": f"timeout after {args.extra_timeout}s"}]
+                sys.stdout.write(json.dumps(result) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(args.extra_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         for w in extras_multi:
             t0 = time.time()
             try:
@@ -437,6 +453,7 @@ def main() -> int:
                 others.append({"workload": w, "error": repr(e)[:400]})
                 break   # (the ranks may be out of step now: no further collective work)
         result["other_workloads"] = others
+        watchdog.cancel()
     # RCCL writes a version banner through C stdio (buffered until exit when stdout is a pipe).  Every rank pushes its
     # buffered C output out BEFORE the last barrier, rank 0 prints the JSON line after it: the JSON is the last line of
     # the job's stdout.
@@ -448,6 +465,12 @@ def main() -> int:
     sys.stdout.flush()
     import torch.distributed as dist
     if dist.is_initialized():
+        out_of_step = any("error" in o for o in result.get("other_workloads", [])) if world > 1 else False
+        if out_of_step:   # (an extra failed on some rank: a barrier could wait for ever)
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
         gdist.barrier()
         dist.destroy_process_group()
     if rank == 0:
