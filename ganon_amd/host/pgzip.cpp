@@ -27,6 +27,7 @@ namespace
 
 constexpr uint64_t kNone   = ~0ull;
 constexpr uint32_t kWindow = 32768;
+constexpr size_t   kMaxChunkSymbols = 96u << 20; // symbols one decode keeps (192 MiB): bounds memory on data that inflates 100-fold
 
 // ---- bits, least significant first --------------------------------------------------------------------------------
 struct Bits
@@ -442,6 +443,8 @@ void decode_range(const uint8_t* data, size_t size, uint64_t start_bit, bool at_
     for (;;)
     {
         if (!(at_header && in.pos() == pos) && in.pos() >= stop_bit) // (a block boundary at or past the next chunk's start)
+            break;
+        if (r.out.n >= kMaxChunkSymbols) // extremely compressible data: hand over at this block boundary (the stitcher goes on from here)
             break;
         in.refill();
         const unsigned bfinal = in.get(1), btype = in.get(2);
