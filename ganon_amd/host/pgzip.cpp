@@ -747,6 +747,16 @@ struct ParallelGzip::Impl
         {
             // settle as many chunks as are decoded
             bool progressed = false;
+            if (k == n_chunks && !ended && pos < (uint64_t)size * 8)
+            {
+                // every chunk is settled but the stream is not at its end: the last decode handed over early (the cap on the
+                // symbols one decode keeps).  One more chunk, behind the file's last, that continues from `pos`.
+                std::lock_guard<std::mutex> lk(m);
+                chunks.emplace_back();
+                chunks.back().decoded = true; // (no speculative decode: the "does not begin at pos" path below decodes it)
+                ++n_chunks;
+                next_decode = n_chunks;
+            }
             if (k < n_chunks)
             {
                 Chunk* c = &chunks[k];

@@ -106,3 +106,18 @@ def test_damaged_streams_are_reported(check, fastq, tmp_path):
     p = str(tmp_path / "plain.txt")
     open(p, "wb").write(fastq[:100_000])
     assert check(p, 2, 20_000) == "NOTGZIP"
+
+
+def test_data_that_inflates_a_hundredfold(check, tmp_path):
+    # one chunk of compressed bytes may hold hundreds of MB of text: a decode keeps at most 96 M symbols and hands over at a
+    # block boundary; the stitcher continues from there (also behind the file's last chunk)
+    rec = b"@r\n" + b"ACGT" * 37 + b"AC\n+\n" + b"I" * 150 + b"\n"
+    data = rec * 420_000
+    p = str(tmp_path / "const.fq.gz")
+    open(p, "wb").write(gzip.compress(data, 6))
+    assert os.path.getsize(p) < 2_000_000
+    for chunk in (1 << 21, 200_000):
+        n, st = _stats(check(p, 3, chunk, 1 << 22))
+        assert n == len(data)
+    n, st = _stats(check(p, 3, 1 << 21, 1 << 22))
+    assert st["redone"] >= 1     # the continuation behind the only chunk
