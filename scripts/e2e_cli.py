@@ -103,7 +103,7 @@ if os.environ.get("E2E_HIBF"):  # a two-level raptor-style HIBF (4096 user bins)
 exe = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
 runs = [("one_worker", "0", None), ("two_workers_one_gpu", "0,0", None), ("three_workers_one_gpu", "0,0,0", None), ("default_no_device_flag", None, None)]
 if os.environ.get("E2E_GZ"):  # ... and with the parallel inflate switched off (one zlib stream, as before) / other thread counts
-    runs += [("gz_sequential_inflate", "0,0", "seq"), ("gz_inflate_8", "0,0", "i8"), ("gz_inflate_16", "0,0", "i16")]
+    runs += [("gz_sequential_inflate", "0,0", "seq"), ("gz_inflate_8", "0,0", "i8"), ("gz_inflate_12", "0,0", "i12"), ("gz_inflate_24", "0,0", "i24")]
 if os.environ.get("E2E_SWEEP"):  # parser threads x device workers, to see which stage limits the pipeline on this host
     runs += [(f"sweep_parse{pt}_workers{len(dev.split(','))}", dev, pt) for pt in (4, 6, 8, 10, 12) for dev in ("0", "0,0", "0,0,0")]
 for label, dev, parse_threads in runs:
