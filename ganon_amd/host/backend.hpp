@@ -102,6 +102,9 @@ public:
     // Optional.  After a level's filters are loaded: does this worker take batches on this level?  (A level with a filter
     // that is partitioned over the devices keeps all of them busy with every batch: only a few workers run then.)
     virtual bool active() const { return true; }
+    // Optional.  Called by a worker before its first batch of a level: batches will hold at most this many reads / bases.
+    // (Device streams are created here, while the reader is still parsing its first slabs, instead of with the first batch.)
+    virtual void prepare(size_t /*max_reads*/, size_t /*max_bases*/) {}
     // Optional.  Where the level's filters were put (replicated / partitioned, which columns on which device), for --verbose.
     virtual std::string placement() const { return std::string(); }
 };

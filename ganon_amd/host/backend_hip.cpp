@@ -624,26 +624,9 @@ public:
                 Part& part = filters_[i].parts[g];
                 if (!part.s || part.stream_reads < n || part.stream_bases < nb)
                 {
-                    if (part.s)
-                        gn_stream_destroy(part.s);
-                    part.s            = nullptr;
-                    const uint32_t cr = std::max<uint32_t>(n, 1u << 16);
-                    const uint64_t cb = std::max<uint64_t>(nb, 1ull << 24);
-                    if (gn_stream_create(part.dp->f, cr, cb, 0, &part.s) != GN_OK)
-                    {
-                        err = gn_last_error();
+                    if (!make_stream(part, std::max<uint64_t>(n, hint_reads_), std::max<uint64_t>(nb, hint_bases_), err))
                         return false;
-                    }
-                    part.stream_reads = cr;
-                    part.stream_bases = cb;
-                    part.pf_generation = 0;
                     lap(sec_create_);
-                    ++n_create_;
-                    if (long_reads_ && gn_stream_set_long_reads(part.s, 1) != GN_OK)
-                    {
-                        err = gn_last_error();
-                        return false;
-                    }
                 }
                 if (part.pf_generation != pf_generation_)
                 {
@@ -763,6 +746,23 @@ public:
         return true;
     }
 
+    void prepare(size_t max_reads, size_t max_bases) override
+    {
+        // streams sized for the largest batch the reader makes, created before the first batch arrives (a stream is ~30 device
+        // buffers: tens of milliseconds, and every later re-creation frees memory, which stalls the whole device)
+        hint_reads_ = max_reads;
+        hint_bases_ = max_bases;
+        std::string err;
+        if (!resolve(err))
+            return;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (auto& lf : filters_)
+            for (auto& part : lf.parts)
+                if (!part.s && !make_stream(part, max_reads, max_bases, err))
+                    return; // (the first batch will report what is wrong)
+        sec_create_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+
     std::string describe() const override
     {
         std::ostringstream os;
@@ -878,6 +878,30 @@ private:
         size_t            home = 0; // a part on this worker's device (n_hashes / status are fetched from its stream)
         gn_gather*        gather = nullptr;
     };
+
+    bool make_stream(Part& part, uint64_t reads, uint64_t bases, std::string& err)
+    {
+        if (part.s)
+            gn_stream_destroy(part.s);
+        part.s            = nullptr;
+        const uint32_t cr = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(reads, 1u << 16), 0xFFFFFFF0ull);
+        const uint64_t cb = std::max<uint64_t>(bases, 1ull << 24);
+        if (gn_stream_create(part.dp->f, cr, cb, 0, &part.s) != GN_OK)
+        {
+            err = gn_last_error();
+            return false;
+        }
+        part.stream_reads  = cr;
+        part.stream_bases  = cb;
+        part.pf_generation = 0;
+        ++n_create_;
+        if (long_reads_ && gn_stream_set_long_reads(part.s, 1) != GN_OK)
+        {
+            err = gn_last_error();
+            return false;
+        }
+        return true;
+    }
 
     // this worker's view of the level's filters (after the DeviceSet has received them all)
     bool resolve(std::string& err)
@@ -998,6 +1022,7 @@ private:
     double                sec_create_ = 0, sec_submit_ = 0, sec_fetch_ = 0; // $GANON_HOST_TIMING: where classify() spends its time
     unsigned              n_create_ = 0;
     uint64_t              gathered_bytes_ = 0;
+    uint64_t              hint_reads_ = 0, hint_bases_ = 0; // largest batch the reader makes (prepare())
     bool                  long_reads_ = false;
     std::vector<Logical>  filters_;
     std::vector<gn_match> tmp_;

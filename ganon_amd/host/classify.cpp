@@ -1403,6 +1403,9 @@ static bool ganon_classify(Config config)
             for (size_t wi = 0; wi < n_workers; ++wi)
                 workers.emplace_back([&, wi] {
                     ClassifiedBatch cb;
+                    if (backends[wi]->active()) // (streams for the largest batch, while the reader is busy with its first slabs)
+                        backends[wi]->prepare(std::min<size_t>(kBatchReads, 1u << 20),
+                                              std::min<size_t>(kBatchBases, env_size("GANON_HOST_SLAB_BYTES", 48u << 20)));
                     while (backends[wi]->active()) // (a level with a partitioned filter runs on a few of the workers)
                     {
                         ordered.take_free(cb);
