@@ -32,12 +32,32 @@ extern "C" const char* gn_last_error(void)
     return g_err;
 }
 
+// How host threads wait for the device.  HIP's default spins: a worker thread that waits for its batch burns a core, and the
+// host pipeline (parsers, post pool) has a use for that core ($GANON_HIP_SYNC=spin|yield|block; set before anything touches a device).
+static void gn_apply_sync_mode(int n_devices)
+{
+    static bool done = false;
+    if (done)
+        return;
+    done = true;
+    const char* m = getenv("GANON_HIP_SYNC");
+    if (!m || !*m)
+        return;
+    const unsigned flag = !strcmp(m, "block") ? hipDeviceScheduleBlockingSync : !strcmp(m, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleSpin;
+    for (int d = 0; d < n_devices; ++d)
+        if (hipSetDevice(d) == hipSuccess)
+            (void)hipSetDeviceFlags(flag);
+    (void)hipGetLastError();
+}
+
 extern "C" int gn_device_count(int* n)
 {
     if (!n)
         return gn_fail(GN_EINVAL, "gn_device_count: null argument");
     int        c = 0;
     hipError_t e = hipGetDeviceCount(&c);
+    if (e == hipSuccess)
+        gn_apply_sync_mode(c);
     if (e != hipSuccess)
     {
         *n = 0;

@@ -1041,6 +1041,9 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
 {
     std::vector<std::unique_ptr<Backend>> out;
     int                                   n = 0;
+    // worker threads BLOCK while they wait for the device instead of spinning (HIP's default): the cores are needed by the
+    // parsers and the post pool (2-4 device workers on a 16-core quota: +2 .. +17 % end to end, profiles/r03_e2e_ab_sync.txt)
+    setenv("GANON_HIP_SYNC", "block", 0);
     if (gn_device_count(&n) != GN_OK || n <= 0)
     {
         err = std::string("no usable MI355X/HIP device (") + gn_last_error() + "); ganon-classify has no CPU fallback";

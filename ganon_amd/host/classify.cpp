@@ -800,10 +800,10 @@ static bool ganon_classify(Config config)
 
     // One worker (a thread with its own device streams) per --device entry; entries naming the same GPU share one copy of
     // the filters.  Without --device the reference's own knob decides: --threads classify workers (:1579-1597), here on
-    // GPU 0 -- at least two, so that one batch's upload and fetch overlap another batch's kernels, at most four.
+    // GPU 0 -- at least three, so that one batch's upload and another's fetch overlap a third one's kernels, at most four.
     std::vector<int> devices = config.devices;
     if (!config.devices_given)
-        devices.assign(std::min<size_t>(4, std::max<size_t>(2, config.threads)), 0);
+        devices.assign(std::min<size_t>(4, std::max<size_t>(3, config.threads)), 0);
     std::string err;
     auto        backends = make_backends(devices, err);
     if (backends.empty())

@@ -15,7 +15,7 @@ struct Bufs { uint8_t* bases; uint64_t* off; uint32_t* nh; uint8_t* st; uint64_t
 static void* alloc(bool pinned, size_t n) { void* p = nullptr; if (pinned) { CK(gn_pinned_alloc(n, &p)); } else p = malloc(n); memset(p, 0, n); return p; }
 int main(int argc, char** argv)
 {
-    const uint32_t n = 1u << 20, L = 150; const uint64_t rows = 1ull << 21; const int batches = argc > 1 ? atoi(argv[1]) : 24;
+    const uint32_t n = argc > 2 ? (uint32_t)atoi(argv[2]) : 1u << 20, L = 150; const uint64_t rows = 1ull << 21; const int batches = argc > 1 ? atoi(argv[1]) : 24;
     gn_ibf_desc d{ nullptr, rows, 64, 4096, 4, (uint32_t)__builtin_clzll(rows) };
     std::vector<uint32_t> b2t(4096); for (uint32_t i = 0; i < 4096; ++i) b2t[i] = i;
     gn_filter* f; CK(gn_filter_upload_ibf(0, &d, b2t.data(), 4096, &f)); CK(gn_filter_fill_random(f, 0, 42, 1, 0, 64)); CK(gn_filter_finalize(f));
@@ -48,8 +48,8 @@ int main(int argc, char** argv)
             for (auto& t : th) t.join();
         }
         const double wall = now() - t0;
-        printf("{\"per_read_arrays\": \"%s\", \"streams\": %d, \"batches\": %d, \"ms_per_batch\": %.2f, \"mreads_per_s\": %.1f, \"submit_ms\": %.2f, \"fetch_ms\": %.2f}\n",
-               pin_small ? "page-locked" : "pageable", n_streams, batches, wall / batches * 1e3, (double)n * batches / wall / 1e6, t_sub / batches * 1e3, t_fetch / batches * 1e3);
+        printf("{\"reads_per_batch\": %u, \"per_read_arrays\": \"%s\", \"streams\": %d, \"batches\": %d, \"ms_per_batch\": %.2f, \"mreads_per_s\": %.1f, \"submit_ms\": %.2f, \"fetch_ms\": %.2f}\n",
+               n, pin_small ? "page-locked" : "pageable", n_streams, batches, wall / batches * 1e3, (double)n * batches / wall / 1e6, t_sub / batches * 1e3, t_fetch / batches * 1e3);
         for (int i = 0; i < n_streams; ++i) gn_stream_destroy(s[i]);
     }
     gn_filter_free(f);

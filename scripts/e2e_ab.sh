@@ -15,9 +15,11 @@ run() { # label, env..., -- args
   echo "$label: classify+print $t s = $(python -c "print(round($N/$t/1e6,1))") Mreads/s"
   echo "$out" | grep -E "host stalls|backend timing" | sed 's/^/      /' | cut -c1-330
 }
-for slab in 50331648 100663296 201326592 402653184; do
-  run "2 workers, slab $slab" GANON_HOST_SLAB_BYTES=$slab -- --device 0,0
-  run "3 workers, slab $slab" GANON_HOST_SLAB_BYTES=$slab -- --device 0,0,0
+for mode in spin block yield; do
+  run "2 workers, sync $mode" GANON_HIP_SYNC=$mode -- --device 0,0
+  run "3 workers, sync $mode" GANON_HIP_SYNC=$mode -- --device 0,0,0
+  run "4 workers, sync $mode" GANON_HIP_SYNC=$mode -- --device 0,0,0,0
 done
-run "3 workers, slab 192M, 12 parsers" GANON_HOST_SLAB_BYTES=201326592 GANON_HOST_PARSE_THREADS=12 -- --device 0,0,0
+run "3 workers, sync block, 10 parsers" GANON_HIP_SYNC=block GANON_HOST_PARSE_THREADS=10 -- --device 0,0,0
+run "4 workers, sync block, 10 parsers, 4 post" GANON_HIP_SYNC=block GANON_HOST_PARSE_THREADS=10 GANON_HOST_POST_THREADS=4 -- --device 0,0,0,0
 rm -f $D/keep.ibf $D/keep.fq $D/ab_out.*
