@@ -828,6 +828,10 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
         gn_stream_destroy(s);
         return gn_fail(e == hipErrorOutOfMemory ? GN_ENOMEM : GN_ENODEV, "gn_stream_create: %s", hipGetErrorString(e));
     }
+    s->v_hashes   = s->d_hashes;
+    s->v_slot_off = s->d_slot_off;
+    s->v_nh       = s->d_nh;
+    s->v_status   = s->d_status;
     *out = s;
     return GN_OK;
 }
@@ -849,6 +853,11 @@ extern "C" int gn_stream_upload_reads(gn_stream* s, const uint8_t* bases, uint64
     GN_HIP(hipMemcpyAsync(s->d_off1, off1, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s->st));
     if (off2)
         GN_HIP(hipMemcpyAsync(s->d_off2, off2, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s->st));
+    s->v_hashes   = s->d_hashes; // (a batch of its own again)
+    s->v_slot_off = s->d_slot_off;
+    s->v_nh       = s->d_nh;
+    s->v_status   = s->d_status;
+    s->src        = nullptr;
     s->n_reads    = n_reads;
     s->n_bases    = n_bases;
     s->paired     = off2 != nullptr;
@@ -1016,10 +1025,10 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.n_big      = f->n_big;
     p.tgt_ids    = nullptr;
     p.n_targets  = f->n_targets;
-    p.hashes     = s->d_hashes;
-    p.slot_off   = s->d_slot_off;
-    p.n_hashes   = s->d_nh;
-    p.status     = s->d_status;
+    p.hashes     = s->v_hashes;
+    p.slot_off   = s->v_slot_off;
+    p.n_hashes   = s->v_nh;
+    p.status     = s->v_status;
     p.n_reads    = hi;
     p.read_begin = lo;
     p.rel_cutoff = s->rel_cutoff;
@@ -1286,6 +1295,65 @@ extern "C" int gn_submit_batch(gn_stream* s, const uint8_t* bases, uint64_t n_ba
     return gn_stream_classify(s, k, w, rel_cutoff);
 }
 
+// The batch resident in `source` (uploaded and hashed there: gn_submit_batch / gn_stream_classify / gn_stream_minimisers) counted
+// against THIS stream's filter as well: several filters of a hierarchy level, or the column parts of a wide filter, on one
+// device see the same reads with the same (k, w) -- one upload and one pass of the minimiser kernels serve them all.
+extern "C" int gn_stream_classify_shared(gn_stream* s, gn_stream* source, double rel_cutoff)
+{
+    if (!s || !source || s == source)
+        return gn_fail(GN_EINVAL, "gn_stream_classify_shared: two different streams are needed");
+    if (!(rel_cutoff >= 0.0 && rel_cutoff <= 1.0))
+        return gn_fail(GN_EINVAL, "rel_cutoff must be within [0,1]");
+    if (s->device != source->device)
+        return gn_fail(GN_EINVAL, "gn_stream_classify_shared: the streams are on different devices");
+    if (!source->hashed || source->src)
+        return gn_fail(GN_EINVAL, "gn_stream_classify_shared: the source stream holds no hashed batch of its own");
+    if (source->n_reads > s->max_reads)
+        return gn_fail(GN_EINVAL, "batch (%u reads) exceeds the stream capacity (%u)", source->n_reads, s->max_reads);
+    gn_filter* f = s->f;
+    GN_HIP(hipSetDevice(f->device));
+    GN_HIP(hipStreamSynchronize(s->st)); // this stream's previous batch is done with its buffers
+    s->src        = source;
+    s->v_hashes   = source->d_hashes;
+    s->v_slot_off = source->d_slot_off;
+    s->v_nh       = source->d_nh;
+    s->v_status   = source->d_status;
+    s->n_reads    = source->n_reads;
+    s->n_bases    = source->n_bases;
+    s->paired     = source->paired;
+    s->have_reads = true;
+    s->hashed     = false; // (no hashes of its own: gn_stream_fetch_hashes belongs to the source)
+    s->k          = source->k;
+    s->w          = source->w;
+    s->rel_cutoff = rel_cutoff;
+    s->build_distinct = ~0ull;
+    // behind the source's minimiser kernels (its side stream), or behind its main stream when it hashed there
+    GN_HIP(hipEventRecord(s->ev_sync, source->st2));
+    GN_HIP(hipStreamWaitEvent(s->st, s->ev_sync, 0));
+    GN_HIP(hipEventRecord(s->ev_sync, source->st));
+    GN_HIP(hipStreamWaitEvent(s->st, s->ev_sync, 0));
+    GN_HIP(hipMemsetAsync(s->d_ctr, 0, GN_NCTR * sizeof(unsigned long long), s->st));
+    GN_HIP(hipEventRecord(s->ev[0], s->st));
+    GN_HIP(hipEventRecord(s->ev[1], s->st));
+    GN_HIP(hipEventRecord(s->ev_count0, s->st));
+    int rc = f->is_hibf ? gn_run_count(s) : gn_run_count_range(s, 0, s->n_reads);
+    if (rc)
+        return rc;
+    GN_HIP(hipEventRecord(s->ev[2], s->st));
+    rc = gn_run_group(s);
+    if (rc)
+        return rc;
+    rc = gn_run_postfilter(s);
+    if (rc)
+        return rc;
+    GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
+    GN_HIP(hipEventRecord(s->ev[3], s->st));
+    s->n_chunks      = 1;
+    s->classified    = true;
+    s->pf_joint_done = false;
+    return GN_OK;
+}
+
 // Waits for the batch; if the device match buffer overflowed, grows it and re-runs count+group.
 static int gn_finish(gn_stream* s)
 {
@@ -1382,9 +1450,9 @@ extern "C" int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status,
         *n_matches = s->n_matches;
     const uint32_t n = s->n_reads;
     if (n_hashes && n)
-        GN_HIP(hipMemcpyAsync(n_hashes, s->d_nh, (size_t)n * 4, hipMemcpyDeviceToHost, s->st));
+        GN_HIP(hipMemcpyAsync(n_hashes, s->v_nh, (size_t)n * 4, hipMemcpyDeviceToHost, s->st));
     if (status && n)
-        GN_HIP(hipMemcpyAsync(status, s->d_status, (size_t)n, hipMemcpyDeviceToHost, s->st));
+        GN_HIP(hipMemcpyAsync(status, s->v_status, (size_t)n, hipMemcpyDeviceToHost, s->st));
     if (match_off)
     {
         const uint32_t wpr = s->f->is_hibf ? 1 : s->f->geom.wpr;
@@ -1486,9 +1554,9 @@ extern "C" int gn_stream_fetch_hashes(gn_stream* s, uint64_t* hash_off, uint64_t
     const uint32_t        n = s->n_reads;
     std::vector<uint64_t> slot(n + 1);
     std::vector<uint32_t> nh(n);
-    GN_HIP(hipMemcpy(slot.data(), s->d_slot_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+    GN_HIP(hipMemcpy(slot.data(), s->v_slot_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
     if (n)
-        GN_HIP(hipMemcpy(nh.data(), s->d_nh, (size_t)n * 4, hipMemcpyDeviceToHost));
+        GN_HIP(hipMemcpy(nh.data(), s->v_nh, (size_t)n * 4, hipMemcpyDeviceToHost));
     uint64_t total = 0;
     for (uint32_t r = 0; r < n; ++r)
     {
@@ -1504,7 +1572,7 @@ extern "C" int gn_stream_fetch_hashes(gn_stream* s, uint64_t* hash_off, uint64_t
         return gn_fail(GN_EOVERFLOW, "hash buffer too small: need %llu", (unsigned long long)total);
     std::vector<uint64_t> all(slot[n] ? slot[n] : 1);
     if (slot[n])
-        GN_HIP(hipMemcpy(all.data(), s->d_hashes, slot[n] * 8, hipMemcpyDeviceToHost));
+        GN_HIP(hipMemcpy(all.data(), s->v_hashes, slot[n] * 8, hipMemcpyDeviceToHost));
     for (uint32_t r = 0; r < n; ++r)
         if (nh[r])
             memcpy(hashes + hash_off[r], all.data() + slot[r], (size_t)nh[r] * 8);
@@ -1536,7 +1604,7 @@ extern "C" int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_
     GnCountParams p{};
     p.rows = f->ibf.d_rows; p.S = f->ibf.S; p.W = (uint32_t)f->ibf.W; p.B = (uint32_t)f->ibf.B; p.shift = f->ibf.shift;
     p.tgt_off = f->identity ? nullptr : f->d_tgt_off; p.tgt_bins = f->d_tgt_bins; p.tgt_lds = f->d_tgt_lds; p.tgt_rec = f->d_tgt_rec; p.n_targets = f->n_targets;
-    p.hashes = s->d_hashes; p.slot_off = s->d_slot_off; p.n_hashes = s->d_nh; p.status = s->d_status;
+    p.hashes = s->v_hashes; p.slot_off = s->v_slot_off; p.n_hashes = s->v_nh; p.status = s->v_status;
     p.n_reads = s->n_reads; p.rel_cutoff = s->rel_cutoff; p.wpr = f->geom.wpr; p.gp_log2 = f->geom.gp_log2;
     p.slice_dwords = f->geom.slice_dwords;
     p.matches = s->d_matches; p.match_cap = 0; // no writes
@@ -1573,8 +1641,8 @@ extern "C" int gn_stream_timings(gn_stream* s, gn_timings* t)
     hipEventElapsedTime(&tm.ms_count, s->ev_count0, s->ev[2]); // first count kernel start -> last count kernel end
     hipEventElapsedTime(&tm.ms_total, s->ev[0], s->ev[3]);
     tm.n_hashes = 0;
-    for (int i = 8; i < GN_NCTR; ++i)
-        tm.n_hashes += s->h_ctr[i];
+    for (int i = 8; i < GN_NCTR; ++i) // (the minimiser kernels of the batch ran on the stream the reads were uploaded to)
+        tm.n_hashes += (s->src ? s->src : s)->h_ctr[i];
     tm.n_matches = s->n_matches;
     tm.n_count_launches = s->n_chunks;
     if (s->f->is_hibf)

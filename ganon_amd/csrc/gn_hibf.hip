@@ -1370,7 +1370,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
         GN_HIP(hipMemsetAsync(s->d_hctr, 0, 3 * NL * sizeof(unsigned long long), st));
         if (cnt && no_reg) // (the register-counter kernels take level 0 straight from the batch)
-            hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, s->d_work[0], s->d_status, lo, cnt, s->d_hctr,
+            hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, s->d_work[0], s->v_status, lo, cnt, s->d_hctr,
                                s->long_reads ? 1u : 0u);
         for (uint32_t lvl = 0; lvl < depth && cnt; ++lvl)
         {
@@ -1384,9 +1384,9 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                 GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (lvl - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
             GnHibfLevelParams p{};
             p.ibfs        = f->d_hibf;
-            p.hashes      = s->d_hashes;
-            p.slot_off    = s->d_slot_off;
-            p.n_hashes    = s->d_nh;
+            p.hashes      = s->v_hashes;
+            p.slot_off    = s->v_slot_off;
+            p.n_hashes    = s->v_nh;
             p.rel_cutoff  = s->rel_cutoff;
             p.wide        = s->long_reads ? 1u : 0u;
             p.work_in     = s->d_work[lvl & 1];
@@ -1402,7 +1402,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
             p.lds_bins    = f->max_bins;
             p.n_reads     = cnt;
             p.read_base   = lo;
-            p.status      = s->d_status;
+            p.status      = s->v_status;
             p.pack_gp     = lvl < f->level_gp.size() ? f->level_gp[lvl] : 0u;
             bool level0   = lvl == 0; // the first register kernel of level 0 takes the reads themselves as its items
             if (!no_pack)
@@ -1522,9 +1522,9 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         {
             GN_HIP(hipMemsetAsync(s->d_pf_pre + 1, 0, sizeof(unsigned long long), st));
             const unsigned blocks = (unsigned)std::min<uint64_t>((nm + 255) / 256, (uint64_t)f->n_cu * 8);
-            hipLaunchKernelGGL(gn_hibf_premax_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->d_nh,
+            hipLaunchKernelGGL(gn_hibf_premax_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->v_nh,
                                s->d_pf_rmax);
-            hipLaunchKernelGGL(gn_hibf_predrop_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->d_nh,
+            hipLaunchKernelGGL(gn_hibf_predrop_kernel, dim3(blocks), dim3(256), 0, st, s->d_keys[0], s->d_vals[0], nm, ub_bits, s->v_nh,
                                s->d_pf_rmax, s->rel_cutoff, s->pf_joint ? 2u : 1u, s->pf_rel_filter, s->d_keys[1], s->d_vals[1], s->match_cap,
                                s->d_pf_pre + 1, s->d_pf_segmin, s->d_pf_pre);
             GN_HIP(hipGetLastError());
@@ -1561,7 +1561,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                 std::swap(s->d_vals[0], s->d_vals[1]);
             }
             hipLaunchKernelGGL(gn_hibf_finish_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, s->d_keys[1], s->d_vals[1], ns,
-                               ub_bits, s->d_nh, s->d_sorted, s->d_seg_count, d_out_base, s->match_cap);
+                               ub_bits, s->v_nh, s->d_sorted, s->d_seg_count, d_out_base, s->match_cap);
             hipLaunchKernelGGL(gn_hibf_advance_kernel, dim3(1), dim3(1), 0, st, s->d_keys[1], ns, d_out_base);
             GN_HIP(hipGetLastError());
             out_upper += ns;

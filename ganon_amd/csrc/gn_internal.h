@@ -248,6 +248,13 @@ struct gn_stream
     uint64_t*           d_hashes   = nullptr;
     uint32_t*           d_nh       = nullptr;
     uint8_t*            d_status   = nullptr;
+    // what the count / select / fetch side READS: this stream's own buffers above, or -- after gn_stream_classify_shared -- those of
+    // the stream whose resident batch it shares (same device, same reads, hashed once)
+    const uint64_t*     v_hashes   = nullptr;
+    const uint64_t*     v_slot_off = nullptr;
+    const uint32_t*     v_nh       = nullptr;
+    const uint8_t*      v_status   = nullptr;
+    gn_stream*          src        = nullptr; // the stream shared from (nullptr: own batch)
     gn_match*           d_matches  = nullptr; // unordered (reservation order)
     gn_match*           d_sorted   = nullptr; // grouped by read
     unsigned long long* d_ctr      = nullptr; // [0] cursor [1] total_hashes [2] algo_bytes [3] work count

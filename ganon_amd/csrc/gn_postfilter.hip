@@ -387,7 +387,7 @@ static GnPostfilterParams gn_pf_params(gn_stream* s)
     p.off        = s->d_seg_off;
     p.stride     = s->f->is_hibf ? 1u : (uint32_t)s->f->geom.wpr;
     p.n_reads    = s->n_reads;
-    p.nh         = s->d_nh;
+    p.nh         = s->v_nh;
     p.rel_filter = s->pf_rel_filter;
     p.fpr_query  = s->pf_fpr_query;
     p.tfpr       = s->d_pf_fpr;
@@ -705,7 +705,7 @@ extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n
             mp.maxc[i]      = s->d_pf_max;
         }
         mp.n_reads    = n;
-        mp.nh         = s0->d_nh;
+        mp.nh         = s0->v_nh;
         mp.rel_filter = s0->pf_rel_filter;
         mp.fpr_query  = s0->pf_fpr_query;
         mp.ctr        = s0->d_pf_ctr;

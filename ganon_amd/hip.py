@@ -22,7 +22,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_fetch_postfilter", "gn_streams_postfilter_joint", "gn_stream_set_long_reads", "gn_stream_device_matches",
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
-               "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels"]
+               "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_classify_shared"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -87,6 +87,7 @@ def load_library():
     L.gn_stream_classify.argtypes = [vp, u32, u32, C.c_double]
     L.gn_submit_batch.argtypes = [vp, vp, u64, vp, vp, u32, u32, u32, C.c_double]
     L.gn_stream_sync.argtypes = [vp]
+    L.gn_stream_classify_shared.argtypes = [vp, vp, C.c_double]
     L.gn_fetch_batch.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
     L.gn_stream_device_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.gn_stream_set_postfilter.argtypes = [vp, vp]
@@ -331,6 +332,11 @@ class HipStream:
 
     def classify(self, k: int, w: int, rel_cutoff: float) -> None:
         _check(load_library().gn_stream_classify(self._h, k, w, float(rel_cutoff)))
+
+    def classify_shared(self, source: "HipStream", rel_cutoff: float) -> None:
+        """count the batch resident (and hashed) in `source` against this stream's filter too (gn_stream_classify_shared)"""
+        self.n_reads = source.n_reads
+        _check(load_library().gn_stream_classify_shared(self._h, source._h, float(rel_cutoff)))
 
     def submit(self, bases, off1, off2, k: int, w: int, rel_cutoff: float) -> None:
         self.upload(bases, off1, off2)

@@ -618,6 +618,8 @@ public:
         out.dropped_rel_filter = out.dropped_fpr_query = 0;
         // submit to every stream first (asynchronous), then fetch
         const uint64_t nb = std::max<uint64_t>(b.bases.size(), 1);
+        std::map<int, gn_stream*> source_of; // device -> the stream that holds this batch there
+        const bool                share_hashes = !std::getenv("GANON_HOST_NO_SHARED_HASHES");
         for (size_t i = 0; i < filters_.size(); ++i)
             for (size_t g = 0; g < filters_[i].parts.size(); ++g)
             {
@@ -639,13 +641,20 @@ public:
                     }
                     part.pf_generation = pf_generation_;
                 }
-                if (gn_submit_batch(part.s, b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr, n, k, w,
-                                    rel_cutoff[i])
-                    != GN_OK)
+                // the first stream of a device takes the batch (upload + minimisers); the level's other streams on that device --
+                // further filters, column parts -- count the same hashes (gn_stream_classify_shared)
+                auto src = share_hashes ? source_of.find(part.dp->device) : source_of.end();
+                const int rc = src == source_of.end()
+                                   ? gn_submit_batch(part.s, b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr,
+                                                     n, k, w, rel_cutoff[i])
+                                   : gn_stream_classify_shared(part.s, src->second, rel_cutoff[i]);
+                if (rc != GN_OK)
                 {
                     err = gn_last_error();
                     return false;
                 }
+                if (src == source_of.end())
+                    source_of[part.dp->device] = part.s;
             }
         lap(sec_submit_);
         if (pf_active_ && pf_joint_) // several device filters: the rules need the level's max/min per read

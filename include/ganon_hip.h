@@ -163,6 +163,13 @@ int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double rel_cutoff);
 /* upload + classify (asynchronous) -- the call the reference's loop body maps to */
 int gn_submit_batch(gn_stream* s, const uint8_t* bases, uint64_t n_bases, const uint64_t* off1, const uint64_t* off2,
                     uint32_t n_reads, uint32_t k, uint32_t w, double rel_cutoff);
+/* Several filters on ONE device see the same batch -- the filters of a hierarchy level (same k, w: GanonClassify.cpp:1479-1494), or
+ * the column parts of a wide / partitioned filter: the reference hashes a read once and hands the hashes to every filter's agent
+ * (:693-735).  gn_stream_classify_shared counts the batch that is resident in `source` (uploaded and hashed there by
+ * gn_submit_batch / gn_stream_classify / gn_stream_minimisers) against the filter of `s` as well, without uploading or hashing
+ * again (asynchronous; k, w are the source's).  Everything that follows -- gn_fetch_batch, the pre-pass, gn_gather -- works on `s`
+ * as after gn_stream_classify.  The caller fetches (or syncs) every sharing stream before it puts the next batch into `source`. */
+int gn_stream_classify_shared(gn_stream* s, gn_stream* source, double rel_cutoff);
 int gn_stream_sync(gn_stream* s);
 
 /* Wait for the batch and copy results out.  n_hashes[n_reads], status[n_reads], match_off[n_reads+1]

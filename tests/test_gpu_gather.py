@@ -238,3 +238,66 @@ def test_gather_of_raw_device_buffers_with_offsets_of_any_origin(hip):
     full.free()
     for f, _ in parts:
         f.free()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_streams_that_share_one_hashed_batch(hip, paired):
+    # gn_stream_classify_shared: the batch is uploaded and hashed on ONE stream; the other filters of the device count the same
+    # hashes (the reference hashes a read once and hands the hashes to every filter's agent, GanonClassify.cpp:693-735)
+    ibf, b2t, n_targets, seqs = _case(seed=21)
+    mates = [s[::-1] for s in seqs] if paired else None
+    bases, off1, off2 = gu.pack_reads(seqs, mates)
+    parts = _parts(hip, ibf, b2t, 3)
+    hb = gf.random_hibf(60, 32, 2, seed=4, density=0.3, hash_funs=3)
+    hflt = hip.HipFilter.hibf(*gf.hibf_upload_args(hb))
+    filters = [f for f, _ in parts] + [hflt]
+    own = []
+    for f in filters:                       # every filter with an upload of its own
+        st = hip.HipStream(f, len(seqs), bases.size)
+        st.submit(bases, off1, off2, K, W, 0.2)
+        own.append(st.fetch())
+        st.destroy()
+    sts = [hip.HipStream(f, len(seqs), bases.size) for f in filters]
+    for rep in range(2):                    # twice: the second batch is a shorter one
+        n = len(seqs) if rep == 0 else len(seqs) // 3
+        b2, o1, o2 = gu.pack_reads(seqs[:n], mates[:n] if paired else None)
+        sts[0].submit(b2, o1, o2, K, W, 0.2)
+        for st in sts[1:]:
+            st.classify_shared(sts[0], 0.2)
+        for st, (nh, status, mo, m) in zip(sts, own):
+            nh2, status2, mo2, m2 = st.fetch()
+            assert np.array_equal(nh2, nh[:n]) and np.array_equal(status2, status[:n])
+            assert np.array_equal(mo2, mo[:n + 1]) and np.array_equal(m2, m[:int(mo[n])])
+        assert sts[1].timings()["n_hashes"] == sts[0].timings()["n_hashes"] > 0
+    # the source is what holds the hashes; a sharing stream is no source, and an upload makes a stream its own again
+    with pytest.raises(hip.GanonHipError):
+        sts[2].classify_shared(sts[1], 0.2)
+    with pytest.raises(hip.GanonHipError):
+        sts[1].fetch_hashes()
+    sts[1].submit(bases, off1, off2, K, W, 0.2)
+    assert np.array_equal(sts[1].fetch()[3], own[1][3])
+    sts[2].classify_shared(sts[1], 0.2)
+    assert np.array_equal(sts[2].fetch()[3], own[2][3])
+    # with the joint pre-pass and the gather on top: the same result as with separate uploads
+    tfpr = np.full(n_targets, 0.05)
+    res = []
+    for shared in (False, True):
+        ps = [hip.HipStream(f, len(seqs), bases.size) for f, _ in parts]
+        for i, (st, (_, sl)) in enumerate(zip(ps, parts)):
+            st.set_postfilter(0.2, 1e-3, tfpr[sl.targets_global] if len(sl.targets_global) else np.zeros(1), joint=True)
+            if shared and i:
+                st.classify_shared(ps[0], 0.2)
+            else:
+                st.submit(bases, off1, off2, K, W, 0.2)
+        hip.HipStream.postfilter_joint(ps)
+        g = hip.HipGather(0, [sl.targets_global for _, sl in parts])
+        g.run(ps)
+        res.append(g.fetch())
+        g.destroy()
+        for st in ps:
+            st.destroy()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and len(res[0][1]) > 20
+    for st in sts:
+        st.destroy()
+    for f in filters:
+        f.free()
