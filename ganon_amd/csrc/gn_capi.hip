@@ -223,6 +223,15 @@ extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const ui
         f->csr_identity = off[n_targets] == ibf->bins;
         for (size_t x = 0; x < bins.size() && f->csr_identity; ++x)
             f->csr_identity = bins[x] == (uint32_t)x;
+        f->uniform_nb = 0;
+        if (f->csr_identity && n_targets)
+        {
+            const uint32_t nb = off[1] - off[0];
+            bool           same = nb == 2 || nb == 4;
+            for (uint32_t t = 0; t < n_targets && same; ++t)
+                same = off[t + 1] - off[t] == nb;
+            f->uniform_nb = same ? nb : 0u;
+        }
         std::vector<uint32_t> lds_idx(bins.size());
         for (size_t x = 0; x < bins.size(); ++x)
             lds_idx[x] = gn_count_lds_index(geom, bins[x]);
@@ -1051,6 +1060,7 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
         GN_HIP(hipMemsetAsync(s->d_ctr + 7, 0, sizeof(unsigned long long), s->st));
     p.sl_nbr = f->d_sl_nbr;
     p.csr_identity = f->csr_identity && !getenv("GANON_HIP_NO_CSR_IDENTITY") ? 1u : 0u;
+    p.uniform_nb   = p.csr_identity && !getenv("GANON_HIP_NO_UNIFORM_SELECT") ? f->uniform_nb : 0u;
     const bool split = !f->identity && f->d_sl_nbr != nullptr && !getenv("GANON_HIP_NO_SPLIT_KERNEL");
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
     // with a filter_matches pre-pass on the stream the fast and the split-bin kernel do not write matches the --rel-filter rule is bound to

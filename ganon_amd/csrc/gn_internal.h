@@ -104,6 +104,7 @@ struct GnCountParams
     // fast kernel, with a filter_matches pre-pass set on the stream: matches that the --rel-filter rule is bound to drop are
     // not written at all (see the epilogue).  0 off, 1: the read's minimum is at least its cutoff count T (this filter sees all
     // of the read's matches), 2: nothing known about the minimum (other filters of the level may report smaller counts)
+    uint32_t            uniform_nb;   // csr_identity and every target owns exactly this many bins (2 or 4): packed select of the split kernel; else 0
     uint32_t            csr_identity; // tgt_bins[i] == i: target t owns the bins [tgt_off[t], tgt_off[t+1]) (what ganon-build writes)
     uint32_t            pre_mode;
     double              pre_rel;
@@ -212,6 +213,7 @@ struct gn_filter
     uint32_t        split_bpc  = 0;       // split kernel: resident blocks per CU
     uint32_t        n_targets  = 0;
     bool            identity   = false;
+    uint32_t        uniform_nb = 0;       // see GnCountParams::uniform_nb
     bool            csr_identity = false; // bins of the targets, target after target, are 0, 1, 2, ... (GnCountParams::csr_identity)
     GnCountGeometry geom{};
     // hibf

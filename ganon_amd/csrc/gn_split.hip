@@ -380,6 +380,99 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             // `direct` = second pass of a (read, slice) with more hits than the staging list holds
             auto select = [&](bool direct, gn_match* out) -> uint32_t {
                 uint32_t tot = 0;
+                if (scan_all && p.uniform_nb)
+                {
+                    // Every target owns the same power-of-two number of consecutive bins (2 or 4) in target order: a target is
+                    // half a dword (or a dword) of the lane's own bin-ordered counters, so the lane judges its 64*LW/nb targets
+                    // with packed 16-bit arithmetic -- sum, cap at n, the two compares, the tallies of what stays under the bar
+                    // -- ~5 instructions a target instead of ~60 (the scan below), and only targets at or above the bar are
+                    // looked at one by one.  Each wave takes the targets of its own column slice.
+                    typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
+                    typedef short          gn_i16x2 __attribute__((ext_vector_type(2)));
+                    const bool     two  = p.uniform_nb == 2;
+                    const uint32_t tb   = (wi * 64u) >> (two ? 1 : 2); // first target of this lane
+                    const gn_u16x2 nv   = __builtin_bit_cast(gn_u16x2, n * 0x00010001u);
+                    const gn_u16x2 selv = __builtin_bit_cast(gn_u16x2, (Tsel > 0xFFFFu ? 0xFFFFu : Tsel) * 0x00010001u);
+                    const gn_u16x2 tv   = __builtin_bit_cast(gn_u16x2, T * 0x00010001u);
+                    gn_u16x2       mnd2 = __builtin_bit_cast(gn_u16x2, 0xFFFFFFFFu);
+                    uint32_t       hit[ND];
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                    {
+                        uint32_t hm = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                        {
+                            const uint32_t y = (uint32_t)k >> 1, pp = (uint32_t)k & 1u;
+                            const uint32_t sel = 0x0C0C0000u | ((4u + y) << 8) | y;
+                            const uint32_t x   = __builtin_amdgcn_perm(byt[d][1][pp], byt[d][0][pp], sel)
+                                               | (__builtin_amdgcn_perm(byt[d][3][pp], byt[d][2][pp], sel) << 16); // bins 4k .. 4k+3
+                            uint32_t s2 = (x & 0x00FF00FFu) + ((x >> 8) & 0x00FF00FFu); // {bins 4k + 4k+1, bins 4k+2 + 4k+3}
+                            if (!two)
+                                s2 = (s2 & 0xFFFFu) + (s2 >> 16); // one target per dword (upper half: 0, never reaches T >= 1)
+                            const gn_u16x2 sv  = __builtin_elementwise_min(__builtin_bit_cast(gn_u16x2, s2), nv); // :525-526
+                            const gn_i16x2 pm  = sv >= selv;
+                            const gn_i16x2 mid = counting ? (gn_i16x2)((sv >= tv) & ~pm) : (gn_i16x2)(0);
+                            const uint32_t pmb = __builtin_bit_cast(uint32_t, pm), midb = __builtin_bit_cast(uint32_t, mid);
+                            drop1 += (uint32_t)__popc(midb) >> 4;
+                            mnd2 = __builtin_elementwise_min(mnd2, __builtin_bit_cast(gn_u16x2, (__builtin_bit_cast(uint32_t, sv) & midb) | ~midb));
+                            hm |= ((pmb & 1u) | ((pmb >> 15) & 2u)) << (2 * k);
+                        }
+                        hit[d] = col_act ? hm : 0u;
+                    }
+                    {
+                        const uint32_t m2 = __builtin_bit_cast(uint32_t, mnd2), lo16 = m2 & 0xFFFFu, hi16 = m2 >> 16;
+                        const uint32_t mm = lo16 < hi16 ? lo16 : hi16;
+                        if (mm != 0xFFFFu)
+                            mnd = mm < mnd ? mm : mnd;
+                    }
+                    // emission in target order: lane after lane (a lane's targets are consecutive), each lane at the offset the
+                    // wave's prefix sum of hit counts gives it -- the grouping pass (gn_gather_kernel) wants ascending targets
+                    uint32_t mine_hits = 0;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        mine_hits += (uint32_t)__popc(hit[d]);
+                    uint32_t inc = mine_hits;
+#pragma unroll
+                    for (int off = 1; off < GN_WAVE; off <<= 1)
+                    {
+                        const uint32_t y = (uint32_t)__shfl_up((int)inc, off);
+                        inc += lane >= off ? y : 0u;
+                    }
+                    uint32_t       o      = inc - mine_hits;
+                    const uint32_t in_all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        while (hit[d])
+                        {
+                            const uint32_t tp = 16u * d + (uint32_t)__builtin_ctz(hit[d]); // half-dword index inside the lane
+                            hit[d] &= hit[d] - 1;
+                            const uint32_t b0 = wi * 64u + 2u * tp;
+                            uint32_t       cv = cnt_of(b0) + cnt_of(b0 + 1);
+                            if (!two)
+                                cv += cnt_of(b0 + 2) + cnt_of(b0 + 3);
+                            cv = cv > n ? n : cv;
+                            const uint32_t tgt = tb + (two ? tp : tp >> 1);
+                            mxl = cv > mxl ? cv : mxl;
+                            mne = cv < mne ? cv : mne;
+                            if (direct)
+                            {
+                                gn_match mt;
+                                mt.read   = read;
+                                mt.target = tgt;
+                                mt.count  = cv;
+                                out[o]    = mt;
+                            }
+                            else if (o < GN_SPLIT_STAGE)
+                            {
+                                stage[2 * o]     = tgt;
+                                stage[2 * o + 1] = cv;
+                            }
+                            ++o;
+                        }
+                    tot += in_all;
+                    return tot;
+                }
                 if (scan_all)
                 {
                     // too many candidates (tiny T, dense hits): every target, this wave takes its share
