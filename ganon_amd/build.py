@@ -21,7 +21,7 @@ BIN = os.path.join(HOST, "ganon-classify")
 BIN_BUILD = os.path.join(HOST, "ganon-build")
 BUILD_ONLY = ("build.cpp", "build_params.cpp")  # sources of ganon-build that ganon-classify does not link
 
-HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_build.hip", "gn_gather.hip", "gn_capi.hip"]
+HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_build.hip", "gn_gather.hip", "gn_fastq.hip", "gn_capi.hip"]
 HIP_HEADERS = ["gn_internal.h", "gn_scan.h", os.path.join(ROOT, "include", "ganon_hip.h")]
 
 

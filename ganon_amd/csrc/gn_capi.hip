@@ -738,6 +738,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
             hipFree(p);
     gn_postfilter_release(s);
     gn_build_release(s);
+    gn_fastq_release(s);
     for (void* q : { (void*)s->d_long_list, (void*)s->d_long_count, (void*)s->d_long_scratch })
         if (q)
             hipFree(q);

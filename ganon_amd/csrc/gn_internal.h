@@ -166,6 +166,7 @@ struct GnHibfIbfDev
 int  gn_run_postfilter(gn_stream* s);     // gn_postfilter.hip
 void gn_postfilter_release(gn_stream* s);
 void gn_build_release(gn_stream* s);       // gn_build.hip
+void gn_fastq_release(gn_stream* s);       // gn_fastq.hip
 void gn_peer_enable(int dst, int src);     // gn_gather.hip: direct device-to-device copies between the two (best effort)
 hipError_t gn_launch_emplace(uint64_t* rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h, const uint64_t* hashes,
                              const uint32_t* bins, uint64_t n, hipStream_t st);
@@ -319,6 +320,20 @@ struct gn_stream
     unsigned long long* h_pf_ctr  = nullptr; // pinned copy
     void*               d_pf_scan = nullptr;
     size_t              pf_scan_bytes = 0;
+    // FASTQ text tokenised on the device (gn_fastq.hip); allocated by the first gn_stream_upload_fastq
+    uint8_t*            d_text    = nullptr;
+    uint32_t*           d_fq_tile = nullptr; // newline count per 4 KiB tile, then its exclusive scan
+    uint32_t*           d_fq_nl   = nullptr; // position of every newline (up to four per read the stream holds)
+    uint32_t*           d_fq_rec  = nullptr; // per record: first byte / first letter / number of letters
+    uint32_t*           d_fq_seq  = nullptr;
+    uint32_t*           d_fq_len  = nullptr;
+    unsigned long long* d_fq      = nullptr; // see gn_fq_records_kernel
+    unsigned long long* h_fq      = nullptr; // pinned copy
+    void*               d_fq_scan = nullptr;
+    size_t              fq_scan_bytes = 0;
+    uint64_t            fq_text_cap = 0, fq_bytes = 0;
+    uint32_t            fq_tiles_cap = 0, fq_nl_cap = 0, fq_reads = 0;
+    bool                fq_pending = false;  // text uploaded, gn_stream_fastq_index not yet called
     // pinned host
     unsigned long long* h_ctr = nullptr;
     // state

@@ -22,7 +22,8 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_fetch_postfilter", "gn_streams_postfilter_joint", "gn_stream_set_long_reads", "gn_stream_device_matches",
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
-               "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_classify_shared"]
+               "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_classify_shared",
+               "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -88,6 +89,10 @@ def load_library():
     L.gn_submit_batch.argtypes = [vp, vp, u64, vp, vp, u32, u32, u32, C.c_double]
     L.gn_stream_sync.argtypes = [vp]
     L.gn_stream_classify_shared.argtypes = [vp, vp, C.c_double]
+    L.gn_stream_upload_fastq.argtypes = [vp, vp, u64]
+    L.gn_stream_fastq_index.argtypes = [vp, C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+    L.gn_stream_fastq_keep.argtypes = [vp, u32]
+    L.gn_stream_fastq_records.argtypes = [vp, vp, vp, vp]
     L.gn_fetch_batch.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
     L.gn_stream_device_matches.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.gn_stream_set_postfilter.argtypes = [vp, vp]
@@ -341,6 +346,28 @@ class HipStream:
     def submit(self, bases, off1, off2, k: int, w: int, rel_cutoff: float) -> None:
         self.upload(bases, off1, off2)
         self.classify(k, w, rel_cutoff)
+
+    def upload_fastq(self, text) -> Tuple[int, int, int]:
+        """four-line FASTQ text, tokenised on the device (gn_stream_upload_fastq + gn_stream_fastq_index):
+        -> (reads, bases, parsed_bytes); the stream then holds the reads like after upload()"""
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text, dtype=np.uint8)
+        self._keep = (text,)
+        L = load_library()
+        _check(L.gn_stream_upload_fastq(self._h, _p(text), text.size))
+        n, nb, pb = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(L.gn_stream_fastq_index(self._h, C.byref(n), C.byref(nb), C.byref(pb)))
+        self.n_reads = n.value
+        return n.value, nb.value, pb.value
+
+    def fastq_keep(self, n_reads: int) -> None:
+        _check(load_library().gn_stream_fastq_keep(self._h, n_reads))
+        self.n_reads = n_reads
+
+    def fastq_records(self):
+        """(rec_at, seq_at, seq_len): uint32 per read, offsets into the uploaded text"""
+        out = [np.empty(self.n_reads, dtype=np.uint32) for _ in range(3)]
+        _check(load_library().gn_stream_fastq_records(self._h, _p(out[0]), _p(out[1]), _p(out[2])))
+        return tuple(out)
 
     def sync(self) -> None:
         _check(load_library().gn_stream_sync(self._h))

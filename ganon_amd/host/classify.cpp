@@ -15,6 +15,7 @@
 //     target index, .rep rows in target order (the reference iterates robin_hood maps and, with --threads > 1,
 //     interleaves reads arbitrarily; its own tests compare order-insensitively, tests/aux/Aux.hpp:56-68)
 #include "backend.hpp"
+#include "cpu_tally.hpp"
 #include "robin_order.hpp"
 #include "config.hpp"
 #include "filter_io.hpp"
@@ -422,7 +423,10 @@ private:
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return !q_.empty() || stop_; });
                 if (q_.empty())
+                {
+                    g_cpu.mate.add_this_thread();
                     return;
+                }
                 job = std::move(q_.front());
                 q_.pop_front();
                 ++busy_;
@@ -745,6 +749,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
     }
     copier.drain();
     queue.done();
+    g_cpu.reader.add_this_thread();
 }
 
 void append_number(std::string& dst, size_t v)
@@ -1424,6 +1429,7 @@ static bool ganon_classify(Config config)
                         classified.push(std::move(cb));
                         cb = ClassifiedBatch();
                     }
+                    g_cpu.worker.add_this_thread();
                     if (workers_left.fetch_sub(1) == 1)
                         classified.done(); // the last device worker out closes the post pool's queue
                 });
@@ -1440,6 +1446,7 @@ static bool ganon_classify(Config config)
                         ordered.put(seq, std::move(cb));
                         cb = ClassifiedBatch();
                     }
+                    g_cpu.post.add_this_thread();
                     ordered.producer_done();
                 });
             ClassifiedBatch cb;
@@ -1560,6 +1567,19 @@ static bool ganon_classify(Config config)
         std::cerr << "[host timing] backend (upload+kernels+fetch, summed over " << n_workers << " worker(s)) " << sec_device
                   << " s, post-processing+writing " << sec_post << " s, loading filters " << loading.seconds()
                   << " s, classify+print wall " << classifying.seconds() << " s" << std::endl;
+    if (std::getenv("GANON_HOST_TIMING"))
+    {
+        rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        std::cerr << "[host cpu] seconds user + system: ";
+        g_cpu.parse.print(std::cerr, "slab parsers");
+        g_cpu.reader.print(std::cerr, ", reader");
+        g_cpu.mate.print(std::cerr, ", mate copiers");
+        g_cpu.worker.print(std::cerr, ", device workers");
+        g_cpu.post.print(std::cerr, ", post pool");
+        std::cerr << "; whole process " << ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6 << " + " << ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6
+                  << " on " << usable_cores() << " usable cores" << std::endl;
+    }
     if (!config.quiet)
     {
         if (config.verbose)

@@ -1,0 +1,40 @@
+// cpu_tally.hpp -- CPU seconds per group of threads (parsers, device workers, post pool, ...), for $GANON_HOST_TIMING.
+// On a host with fewer cores than threads the sum of these, divided by the cores, is the floor of the run's wall time:
+// which stage to make cheaper is read off this table, not off the stages' wall times.
+#pragma once
+
+#include <sys/resource.h>
+
+#include <atomic>
+#include <cstdint>
+#include <ostream>
+
+namespace gnhost
+{
+
+struct CpuTally
+{
+    std::atomic<uint64_t> user_us{ 0 }, sys_us{ 0 };
+    // adds what the calling thread has used so far (call once, when the thread is about to end)
+    void add_this_thread()
+    {
+        rusage r;
+        if (getrusage(RUSAGE_THREAD, &r) == 0)
+        {
+            user_us += (uint64_t)r.ru_utime.tv_sec * 1000000u + (uint64_t)r.ru_utime.tv_usec;
+            sys_us += (uint64_t)r.ru_stime.tv_sec * 1000000u + (uint64_t)r.ru_stime.tv_usec;
+        }
+    }
+    void print(std::ostream& os, const char* name) const
+    {
+        os << name << ' ' << user_us.load() * 1e-6 << " + " << sys_us.load() * 1e-6;
+    }
+};
+
+struct CpuTallies
+{
+    CpuTally parse, inflate, reader, mate, worker, post;
+};
+inline CpuTallies g_cpu;
+
+} // namespace gnhost

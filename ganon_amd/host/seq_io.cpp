@@ -1,6 +1,7 @@
 // seq_io.cpp -- see seq_io.hpp
 #include "seq_io.hpp"
 #include "pgzip.hpp"
+#include "cpu_tally.hpp"
 
 #include <tmmintrin.h>
 #include <zlib.h>
@@ -667,7 +668,9 @@ class RangeLines
 public:
     // an uncompressed file (pread), or the decompressed stream of a gzip file (ParallelGzip::pread; its size is known only at its
     // end; a damaged stream makes refill throw)
-    RangeLines(int fd, uint64_t file_size, ParallelGzip* gz = nullptr) : fd_(fd), gz_(gz), size_(file_size), buf_(4u << 20) {}
+    RangeLines(int fd, uint64_t file_size, ParallelGzip* gz = nullptr) : fd_(fd), gz_(gz), size_(file_size), buf_(4u << 20) { data_ = buf_.data(); }
+    // the whole file mapped into memory: lines are views of the mapping, nothing is copied
+    RangeLines(const char* map, uint64_t file_size) : fd_(-1), gz_(nullptr), size_(file_size), data_(map), len_((size_t)file_size), mapped_(true) {}
     void seek(uint64_t off)
     {
         if (off >= base_ && off <= base_ + len_)
@@ -685,7 +688,7 @@ public:
         size_t scanned = 0;
         for (;;)
         {
-            const char* b  = buf_.data() + pos_;
+            const char* b  = data_ + pos_;
             const char* nl = static_cast<const char*>(std::memchr(b + scanned, '\n', len_ - pos_ - scanned));
             if (nl)
             {
@@ -702,7 +705,7 @@ public:
                 if (len_ == pos_)
                     return false;
                 size_t n = len_ - pos_; // last line without a newline
-                b        = buf_.data() + pos_;
+                b        = data_ + pos_;
                 pos_     = len_;
                 if (n && b[n - 1] == '\r')
                     --n;
@@ -717,7 +720,7 @@ public:
         while (len_ - pos_ < n + 1)
             if (!refill())
                 return false;
-        const char* b = buf_.data() + pos_;
+        const char* b = data_ + pos_;
         if (b[n] != '\n' || (n && std::memchr(b, '\n', n)))
             return false;
         out = std::string_view(b, n);
@@ -728,7 +731,7 @@ public:
 private:
     bool refill()
     {
-        if (base_ + len_ >= size_)
+        if (mapped_ || base_ + len_ >= size_)
             return false;
         if (pos_ > 0)
         {
@@ -739,6 +742,7 @@ private:
         }
         if (len_ == buf_.size())
             buf_.resize(buf_.size() * 2); // a single line longer than the buffer
+        data_ = buf_.data();
         const size_t  want = (size_t)std::min<uint64_t>(buf_.size() - len_, size_ - (base_ + len_));
         const ssize_t got  = gz_ ? (ssize_t)gz_->pread(buf_.data() + len_, want, base_ + len_)
                                  : ::pread(fd_, buf_.data() + len_, want, (off_t)(base_ + len_));
@@ -751,7 +755,9 @@ private:
     ParallelGzip*     gz_;
     uint64_t          size_, base_ = 0;
     std::vector<char> buf_;
+    const char*       data_ = nullptr;
     size_t            pos_ = 0, len_ = 0;
+    bool              mapped_ = false;
 };
 } // namespace
 
@@ -759,6 +765,7 @@ struct ParallelFastq::Impl
 {
     size_t      size = 0;   // bytes of the (decompressed) input; for a gzip stream unknown until its end has been read
     int         fd   = -1;
+    const char* map  = nullptr; // the file mapped read-only (uncompressed input): the parsers read the page cache in place
     std::unique_ptr<ParallelGzip> gz; // the input is the decompressed stream of a plain gzip file
     size_t      end_size() const { return gz ? (size_t)gz->known_size() : size; }
     size_t      slab_bytes = 0, n_slabs = 0;
@@ -946,7 +953,7 @@ struct ParallelFastq::Impl
 
     void work()
     {
-        RangeLines in(fd, gz ? ~0ull : size, gz.get());
+        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get());
         for (;;)
         {
             size_t i;
@@ -955,7 +962,10 @@ struct ParallelFastq::Impl
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return stop || next_to_parse >= n_slabs || next_to_parse < next_to_take + window; });
                 if (stop || next_to_parse >= n_slabs)
+                {
+                    g_cpu.parse.add_this_thread();
                     return;
+                }
                 i = next_to_parse++;
                 if (!free_slabs.empty())
                 {
@@ -1075,6 +1085,16 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
         gz->set_retain_limit((uint64_t)(im->window + 3) * im->slab_bytes);
         im->gz = std::move(gz);
     }
+    else if (const char* how = std::getenv("GANON_HOST_READ"); how && std::string(how) == "mmap")
+    {
+        // the parsers scan the page cache in place instead of copying it into their buffers first (pread)
+        void* m = ::mmap(nullptr, im->size, PROT_READ, MAP_SHARED, fd, 0);
+        if (m != MAP_FAILED)
+        {
+            ::madvise(m, im->size, MADV_SEQUENTIAL);
+            im->map = static_cast<const char*>(m);
+        }
+    }
     std::unique_ptr<ParallelFastq> pf(new ParallelFastq(im));
     for (unsigned t = 0; t < threads; ++t)
         im->workers.emplace_back([im] { im->work(); });
@@ -1091,6 +1111,8 @@ ParallelFastq::~ParallelFastq()
     }
     for (auto& t : s.workers)
         t.join();
+    if (s.map)
+        ::munmap(const_cast<char*>(s.map), s.size);
     ::close(s.fd);
 }
 

@@ -170,6 +170,24 @@ int gn_submit_batch(gn_stream* s, const uint8_t* bases, uint64_t n_bases, const 
  * again (asynchronous; k, w are the source's).  Everything that follows -- gn_fetch_batch, the pre-pass, gn_gather -- works on `s`
  * as after gn_stream_classify.  The caller fetches (or syncs) every sharing stream before it puts the next batch into `source`. */
 int gn_stream_classify_shared(gn_stream* s, gn_stream* source, double rel_cutoff);
+
+/* Reads as they lie in the file: uncompressed four-line FASTQ text instead of packed bases.  Replaces, for such input, the record
+ * parsing of the reference's input side (seqan3::sequence_file_input in parse_reads, GanonClassify.cpp:1220-1287) together with
+ * gn_stream_upload_reads: `text` (n_bytes <= the stream's max_bases, first byte = first byte of a record) is copied to the device
+ * and the records are found there.  A record is taken when its four lines are  @id / letters / +... / quality  with as many
+ * quality characters as letters and dna15 letters only (a '\r' before the '\n' of the letters line does not count); the first
+ * record that is not -- or the end of the text inside a record, or the stream's max_reads -- ends the batch.  Asynchronous.
+ *   gn_stream_fastq_index   waits for the tokeniser: the batch's reads (records before the first one not taken), their bases,
+ *                           and parsed_bytes = offset of the first byte that is not part of them (== n_bytes: all of the text).
+ *                           From here on the stream holds the batch as after gn_stream_upload_reads (single-end):
+ *                           gn_stream_classify / gn_stream_minimisers / gn_fetch_batch apply, read i = record i.
+ *   gn_stream_fastq_keep    the caller takes fewer records than were found (before gn_stream_classify)
+ *   gn_stream_fastq_records per read: offset of its record ('@'), of its first letter, and its number of letters, in `text`
+ *                           (any may be NULL; waits for the stream) -- ids and letters stay where they are, in the caller's text */
+int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_t n_bytes);
+int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* n_bases, uint64_t* parsed_bytes);
+int gn_stream_fastq_keep(gn_stream* s, uint32_t n_reads);
+int gn_stream_fastq_records(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len);
 int gn_stream_sync(gn_stream* s);
 
 /* Wait for the batch and copy results out.  n_hashes[n_reads], status[n_reads], match_off[n_reads+1]
