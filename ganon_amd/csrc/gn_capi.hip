@@ -759,7 +759,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
         hipEventDestroy(s->ev_sync);
     if (s->ev_count0)
         hipEventDestroy(s->ev_count0);
-    if (s->st2)
+    if (s->st2 && s->st2 != s->st)
     {
         hipStreamSynchronize(s->st2);
         hipStreamDestroy(s->st2);
@@ -794,7 +794,14 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
             e = x;
     };
     ok(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-    ok(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+    // The minimiser kernels may run on a side stream, one chunk ahead of the count kernels ($GANON_HIP_CHUNK, $GANON_HIP_SIDE_STREAM=1).
+    // With one chunk per batch -- the default: chunking gained nothing, see gn_stream_classify -- a second stream per batch context
+    // only costs: the runtime maps all streams of a process onto a few hardware queues (4 by default), and streams that share a
+    // queue wait for each other's copies and kernels.  One stream per context keeps a worker's batches independent of the others'.
+    if (getenv("GANON_HIP_SIDE_STREAM") || getenv("GANON_HIP_CHUNK"))
+        ok(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+    else
+        s->st2 = s->st;
     for (auto& ev : s->ev)
         ok(hipEventCreate(&ev));
     ok(hipEventCreate(&s->ev_sync));

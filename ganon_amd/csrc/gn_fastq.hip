@@ -21,6 +21,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+
 #define GN_FQ_TILE 4096u // bytes per block of the newline kernels: 256 threads x 16 bytes
 
 // 0x80 in every byte of x that is '\n' (exact: no borrow between bytes)
@@ -190,6 +193,9 @@ __global__ void gn_fq_finish_kernel(const uint32_t* __restrict__ nl, const uint6
 
 void gn_fastq_release(gn_stream* s)
 {
+    if (s->fq_probe[3] > 0)
+        fprintf(stderr, "[hip call timing] gn_stream_upload_fastq x%.0f: initial sync %.3f ms, copy call %.3f ms, other calls %.3f ms per batch\n", s->fq_probe[3],
+                s->fq_probe[0] / s->fq_probe[3] * 1e3, s->fq_probe[1] / s->fq_probe[3] * 1e3, s->fq_probe[2] / s->fq_probe[3] * 1e3);
     for (void* p : { (void*)s->d_text, (void*)s->d_fq_tile, (void*)s->d_fq_nl, (void*)s->d_fq_rec, (void*)s->d_fq_seq, (void*)s->d_fq_len, (void*)s->d_fq,
                      (void*)s->d_fq_scan })
         if (p)
@@ -238,10 +244,15 @@ extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_
     int rc = gn_fastq_prepare(s);
     if (rc)
         return rc;
+    static const bool probe = getenv("GANON_HIP_CALL_TIMING") != nullptr;
+    auto              now   = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double      p0    = probe ? now() : 0;
     GN_HIP(hipStreamSynchronize(s->st)); // previous batch must be done before its inputs are overwritten
+    const double p1 = probe ? now() : 0;
     hipStream_t st = s->st;
     if (n_bytes)
         GN_HIP(hipMemcpyAsync(s->d_text, text, n_bytes, hipMemcpyHostToDevice, st));
+    const double p2 = probe ? now() : 0;
     const uint32_t tiles = (uint32_t)((n_bytes + GN_FQ_TILE - 1) / GN_FQ_TILE);
     uint32_t*      cnt   = s->d_fq_tile;
     uint32_t*      toff  = s->d_fq_tile + s->fq_tiles_cap + 1;
@@ -266,6 +277,14 @@ extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_
     hipLaunchKernelGGL(gn_fq_finish_kernel, dim3(1), dim3(1), 0, st, s->d_fq_nl, s->d_off1, s->max_reads, n_bytes, s->d_fq);
     GN_HIP(hipMemcpyAsync(s->h_fq, s->d_fq, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     GN_HIP(hipGetLastError());
+    if (probe)
+    {
+        const double p3 = now();
+        s->fq_probe[0] += p1 - p0;
+        s->fq_probe[1] += p2 - p1;
+        s->fq_probe[2] += p3 - p2;
+        s->fq_probe[3] += 1;
+    }
     s->fq_pending = true;
     s->fq_bytes   = n_bytes;
     s->have_reads = false;

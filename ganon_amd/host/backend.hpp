@@ -14,14 +14,80 @@
 #include "filter_io.hpp"
 #include "hostmem.hpp"
 
+#include <condition_variable>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <string_view>
 #include <vector>
 
 namespace gnhost
 {
+
+// Uncompressed FASTQ whose records the BACKEND finds (raw batches, below): the pieces of one file are validated in file
+// order although several workers hold them at once.  A piece whose text is not four-line records from its first to its last
+// byte stops the file there: pieces behind it are void, and the reader hands the rest of the file to its sequential parser.
+class RawFileTracker
+{
+public:
+    // piece `idx` was tokenised: all of it is records (complete), or the first byte that is not part of one is resume_at
+    void publish(size_t idx, bool complete, uint64_t resume_at)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (state_.size() <= idx)
+            state_.resize(idx + 1, 0);
+        if (state_[idx])
+            return;
+        state_[idx] = complete ? 1 : 2;
+        ++published_;
+        while (known_below_ < state_.size() && state_[known_below_])
+            ++known_below_;
+        if (!complete && idx < first_stop_)
+        {
+            first_stop_ = idx;
+            resume_at_  = resume_at;
+        }
+        cv_.notify_all();
+    }
+    // waits until every piece before idx is known; true when all of them were complete (this piece counts)
+    bool wait_prefix(size_t idx)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return first_stop_ < idx || known_below_ >= idx; });
+        return first_stop_ >= idx;
+    }
+    // the reader, after the file's last piece: waits for all `count` pieces; false when one stopped the file (then resume_at)
+    bool wait_all(size_t count, uint64_t& resume_at)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return published_ >= count; });
+        resume_at = resume_at_;
+        return first_stop_ == SIZE_MAX;
+    }
+
+private:
+    std::mutex              m_;
+    std::condition_variable cv_;
+    std::vector<uint8_t>    state_;
+    size_t                  published_ = 0, first_stop_ = SIZE_MAX, known_below_ = 0; // (every piece below known_below_ has been published)
+    uint64_t                resume_at_ = 0;
+};
+
+// a raw batch's place in its file; a batch that is dropped before anyone tokenised it stops the file (nobody waits for ever)
+struct RawTicket
+{
+    std::shared_ptr<RawFileTracker> tracker;
+    size_t                          idx  = 0;
+    bool                            done = false;
+    void publish(bool complete, uint64_t resume_at)
+    {
+        if (tracker && !done)
+            tracker->publish(idx, complete, resume_at);
+        done = true;
+    }
+    ~RawTicket() { publish(false, UINT64_MAX); }
+};
 
 // A batch of reads in the layout the C ABI takes: ASCII bases, mate-1 block then mate-2 block.
 struct ReadBatch
@@ -34,10 +100,30 @@ struct ReadBatch
     ByteBuf               bases;       // mates 1 of all reads, then mates 2 of all reads (page-locked under the HIP backend)
     std::vector<uint64_t> off1;        // n+1
     std::vector<uint64_t> off2;        // n+1 when paired (offsets into `bases`)
-    size_t                size() const { return id_off.size() - 1; }
-    std::string_view      id(size_t i) const { return { id_buf.data() + id_off[i], size_t(id_off[i + 1] - id_off[i]) }; }
-    uint64_t len1(size_t i) const { return off1[i + 1] - off1[i]; }
-    uint64_t len2(size_t i) const { return paired ? off2[i + 1] - off2[i] : 0; }
+    // Raw form (single-end uncompressed FASTQ under a backend that tokenises, Backend::tokenises_fastq): `text` is a piece of
+    // the file that begins with a record; Backend::tokenise finds the records, Backend::classify fills rec_at / seq_at / seq_len
+    // for the `raw_keep` records the batch consists of.  Ids and letters are read where they lie in `text`.
+    bool                       raw = false;
+    ByteBuf                    text;
+    uint64_t                   text_at = 0;  // offset of text[0] in the file
+    uint32_t                   raw_keep = 0; // records of the batch (set by the pipeline between tokenise and classify)
+    U32Buf                     rec_at, seq_at, seq_len;
+    std::unique_ptr<RawTicket> ticket;
+    size_t size() const { return raw ? rec_at.size() : id_off.size() - 1; }
+    std::string_view id(size_t i) const
+    {
+        if (!raw)
+            return { id_buf.data() + id_off[i], size_t(id_off[i + 1] - id_off[i]) };
+        const char* b = reinterpret_cast<const char*>(text.data()) + rec_at[i] + 1; // behind the '@'
+        size_t      n = seq_at[i] - rec_at[i] - 2;                                   // up to the '\n' before the letters
+        if (n && b[n - 1] == '\r')
+            --n;
+        return { b, n };
+    }
+    uint64_t       len1(size_t i) const { return raw ? seq_len[i] : off1[i + 1] - off1[i]; }
+    uint64_t       len2(size_t i) const { return paired ? off2[i + 1] - off2[i] : 0; }
+    const uint8_t* seq1(size_t i) const { return raw ? text.data() + seq_at[i] : bases.data() + off1[i]; }
+    const uint8_t* seq2(size_t i) const { return bases.data() + off2[i]; }
 };
 
 struct Match
@@ -47,20 +133,20 @@ struct Match
 
 struct FilterResult
 {
-    std::vector<uint64_t> match_off; // n+1
+    U64Buf                match_off; // n+1 (the per-read arrays are written by the device: page-locked under the HIP backend)
     std::vector<Match>    matches;   // grouped by read, ascending target
     std::vector<uint8_t>  fpr_ok;    // empty, or per match: 1 = the backend already verified q <= fpr_query (see set_postfilter)
 };
 
 struct BatchResult
 {
-    std::vector<uint32_t>     n_hashes; // per read
-    std::vector<uint8_t>      status;   // 0 ok, 1 small, 2 big (GN_READ_*)
+    U32Buf                    n_hashes; // per read
+    ByteBuf                   status;   // 0 ok, 1 small, 2 big (GN_READ_*)
     std::vector<FilterResult> per_filter;
     // set when the backend already applied the pre-pass of filter_matches (see Backend::set_postfilter): the matches are
     // the survivors, max_count is every read's largest match count BEFORE filtering, the two totals are what was dropped
     bool                  prefiltered = false;
-    std::vector<uint32_t> max_count;
+    U32Buf                max_count;
     uint64_t              dropped_rel_filter = 0, dropped_fpr_query = 0;
 };
 
@@ -86,9 +172,36 @@ class Backend : public FilterSink
 public:
     virtual void clear_filters() = 0;
     // classify `batch` against every loaded filter with minimiser shape (k, w); rel_cutoff[i] belongs to filter i
-    virtual bool classify(const ReadBatch& batch, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff,
-                          BatchResult& out, std::string& err) = 0;
+    // (a raw batch -- ReadBatch::raw -- has been through tokenise(); its first raw_keep records are classified and described)
+    virtual bool classify(ReadBatch& batch, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
+                          std::string& err) = 0;
+    // Optional.  Does this backend find the records of uncompressed four-line FASTQ itself?  Then the reader hands such files
+    // over as raw batches (pieces of the file in page-locked memory) instead of parsing them.
+    virtual bool tokenises_fastq() const { return false; }
+    // Raw batches: takes batch.text, finds the records.  n_reads = records before the first that is not a plain four-line
+    // record (or the end of the text inside one); parsed_bytes = where that one begins (== text.size(): all of it is records).
+    virtual bool tokenise(ReadBatch& /*batch*/, uint32_t& /*n_reads*/, uint64_t& /*parsed_bytes*/, std::string& err)
+    {
+        err = "this backend does not tokenise";
+        return false;
+    }
     virtual std::string describe() const = 0;
+    // Optional.  The two calls above in halves, for a caller that keeps two backends busy from one thread (it starts a batch on one
+    // while the other one's kernels run): *_begin queues the work and returns, *_end waits for it and delivers.  The defaults do
+    // everything in *_end.
+    virtual bool tokenise_begin(ReadBatch& /*batch*/, std::string& /*err*/) { return true; }
+    virtual bool tokenise_end(ReadBatch& batch, uint32_t& n_reads, uint64_t& parsed_bytes, std::string& err)
+    {
+        return tokenise(batch, n_reads, parsed_bytes, err);
+    }
+    virtual bool classify_begin(ReadBatch& /*batch*/, uint32_t /*k*/, uint32_t /*w*/, const std::vector<double>& /*rel_cutoff*/, std::string& /*err*/)
+    {
+        return true;
+    }
+    virtual bool classify_end(ReadBatch& batch, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out, std::string& err)
+    {
+        return classify(batch, k, w, rel_cutoff, out, err);
+    }
     // Optional.  Ask for the --rel-filter rule (exactly) and the --fpr-query rule (conservatively: only matches that are
     // above the limit by a safe margin) to be applied where the matches are produced, so that only survivors travel to the
     // host, which then applies the exact --fpr-query rule to them (except to those the backend marks as surely passing,
@@ -105,6 +218,13 @@ public:
     // Optional.  Called by a worker before its first batch of a level: batches will hold at most this many reads / bases.
     // (Device streams are created here, while the reader is still parsing its first slabs, instead of with the first batch.)
     virtual void prepare(size_t /*max_reads*/, size_t /*max_bases*/) {}
+    // Optional.  After prepare(): run something small through the whole path so that one-time costs (code loading, first-use
+    // allocations) are paid before the first real batch.  Results are discarded.
+    virtual void warm_up(uint32_t /*k*/, uint32_t /*w*/, const std::vector<double>& /*rel_cutoff*/) {}
+    // Optional.  A second worker context on the same device and the same filters (own streams, nothing loaded twice), for a
+    // caller that keeps two batches in flight from one thread.  It takes clear_filters / set_postfilter / set_long_reads /
+    // prepare / tokenise / classify like the backend it comes from, never filter data.  nullptr: there is none.
+    virtual std::unique_ptr<Backend> twin() { return nullptr; }
     // Optional.  Where the level's filters were put (replicated / partitioned, which columns on which device), for --verbose.
     virtual std::string placement() const { return std::string(); }
 };

@@ -35,7 +35,7 @@ constexpr uint64_t kPartWords = 512; // 32 768 bins: four wave slices of 16-byte
 // Page-locked blocks for the read batches, kept for the life of the process.  Locking pages costs ~0.26 s per GiB
 // (profiles/r02_pinned_probe.json) and a pipeline's worth of batch buffers is half a GiB or more, so (a) a block, once
 // locked, is handed out again instead of being unlocked, and (b) a thread starts locking the first blocks while the filters
-// are still being loaded.  Sizes are rounded up to a power of two (>= 1 MiB) so that freed blocks fit later requests.
+// are still being loaded.  Sizes are rounded up (size_class) so that freed blocks fit later requests.
 class PinnedPool
 {
 public:
@@ -57,12 +57,24 @@ public:
                 return p;
             }
         }
-        void* p = nullptr;
+        void*      p  = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         if (gn_pinned_alloc(cls, &p) != GN_OK)
             return std::malloc(n ? n : 1); // (no more lockable memory: an ordinary buffer still works, its copies are just staged)
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::lock_guard<std::mutex> lk(m_);
         size_of_[p] = cls;
+        (running_ ? late_ : early_).add(cls, sec);
         return p;
+    }
+    // from here on batches are on the device: a block locked now stalls them ($GANON_HOST_TIMING reports how many were)
+    void mark_running() { running_ = true; }
+    std::string tally() const
+    {
+        std::ostringstream os;
+        os << "page-locked on demand before the first batch: " << early_.n << " blocks, " << (early_.bytes >> 20) << " MiB, " << early_.sec
+           << " s; after it: " << late_.n << " blocks, " << (late_.bytes >> 20) << " MiB, " << late_.sec << " s";
+        return os.str();
     }
     void give(void* p)
     {
@@ -98,6 +110,20 @@ public:
             }
         });
     }
+    // `count` more blocks that hold n bytes each go into the pool (locked now, handed out later)
+    void reserve(size_t n, size_t count)
+    {
+        const size_t cls = size_class(n);
+        for (size_t i = 0; i < count; ++i)
+        {
+            void* p = nullptr;
+            if (gn_pinned_alloc(cls, &p) != GN_OK)
+                return;
+            std::lock_guard<std::mutex> lk(m_);
+            size_of_[p] = cls;
+            free_[cls].push_back(p);
+        }
+    }
     void settle() // before the process lets go of the device: the warm-up thread is not in the middle of a call
     {
         stop_ = true;
@@ -106,13 +132,29 @@ public:
     }
 
 private:
+    // powers of two up to 8 MiB, multiples of 8 MiB above (a 51 MiB piece of FASTQ text takes 56 MiB, not 64: locking is what costs)
     static size_t size_class(size_t n)
     {
         size_t c = 1u << 20;
-        while (c < n)
+        while (c < n && c < (8u << 20))
             c <<= 1;
-        return c;
+        if (c >= n)
+            return c;
+        return (n + (8u << 20) - 1) / (8u << 20) * (8u << 20);
     }
+    struct Tally
+    {
+        size_t n = 0, bytes = 0;
+        double sec = 0;
+        void   add(size_t b, double s)
+        {
+            ++n;
+            bytes += b;
+            sec += s;
+        }
+    };
+    Tally                                 early_, late_;
+    std::atomic<bool>                     running_{ false };
     std::mutex                            m_;
     std::map<size_t, std::vector<void*>>  free_;
     std::unordered_map<void*, size_t>     size_of_;
@@ -210,6 +252,7 @@ public:
                 return true;
         return false;
     }
+    size_t n_devices() const { return uniq_.size(); }
     size_t unique_index(int device) const { return (size_t)(std::find(uniq_.begin(), uniq_.end(), device) - uniq_.begin()); }
 
     void clear()
@@ -561,9 +604,12 @@ public:
     ~HipBackend() override
     {
         PinnedPool::get().settle();
+        if (std::getenv("GANON_HOST_TIMING") && index_ == 0 && !twin_)
+            std::cerr << "[pinned pool] " << PinnedPool::get().tally() << std::endl;
         if (std::getenv("GANON_HOST_TIMING") && n_create_)
             std::cerr << "[backend timing] device " << device_ << ": stream (re)creation " << sec_create_ << " s (" << n_create_
-                      << "x), submit calls " << sec_submit_ << " s, waiting for + fetching the results " << sec_fetch_ << " s"
+                      << "x), submit calls " << sec_submit_ << " s, waiting for + fetching the results " << sec_fetch_ << " s, FASTQ text: upload calls "
+                      << sec_tok_enqueue_ << " s + waiting for the records " << sec_tok_wait_ << " s"
                       << (gathered_bytes_ ? ", moved between devices " + std::to_string(gathered_bytes_ >> 20) + " MiB" : std::string()) << std::endl;
         clear_filters();
     }
@@ -581,8 +627,15 @@ public:
     void clear_filters() override
     {
         drop_streams();
-        if (index_ == 0)
+        if (index_ == 0 && !twin_)
             set_->clear();
+    }
+
+    std::unique_ptr<Backend> twin() override
+    {
+        auto t   = std::make_unique<HipBackend>(set_, index_);
+        t->twin_ = true;
+        return t;
     }
 
     // A level with a partitioned filter keeps every device busy with every batch: a few workers (upload and fetch of one
@@ -598,24 +651,112 @@ public:
 
     std::string placement() const override { return index_ ? std::string() : set_->placement(); }
 
-    bool classify(const ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
-                  std::string& err) override
+    // Uncompressed FASTQ as text, records found on the device (csrc/gn_fastq.hip)?  It takes the parse -- the largest share of the
+    // host's CPU seconds -- off the host and costs 2.1x the bytes over the link.  Measured on one MI355X behind a 16-core host
+    // (DESIGN 7-5): the link-bound device side delivers 151-157 Mreads/s on its own, the whole binary 85-100 against 97-117 with
+    // the host's slab parser -- one GPU is better off with the parser.  Several GPUs have a link each but share the host's cores:
+    // there the text goes to the devices.  $GANON_HOST_DEVICE_FASTQ=1 / 0 decides by hand.
+    bool tokenises_fastq() const override
+    {
+        if (const char* e = std::getenv("GANON_HOST_DEVICE_FASTQ"))
+            return e[0] == '1';
+        return set_->n_devices() >= 2;
+    }
+
+    // Raw batch: the text goes to the first stream of every device the level's filters live on (the stream that takes a parsed
+    // batch's upload, see classify()); the records are found there (csrc/gn_fastq.hip).  Every device finds the same ones.
+    bool tokenise(ReadBatch& b, uint32_t& n_reads, uint64_t& parsed_bytes, std::string& err) override
+    {
+        return tokenise_begin(b, err) && tokenise_end(b, n_reads, parsed_bytes, err);
+    }
+
+    bool tokenise_begin(ReadBatch& b, std::string& err) override
     {
         if (!resolve(err))
             return false;
-        const uint32_t n = (uint32_t)b.size();
+        auto t = std::chrono::steady_clock::now();
+        const uint64_t nb    = b.text.size();
+        const uint64_t reads = std::max<uint64_t>(hint_reads_, nb / 40); // (records shorter than 40 bytes on average: the rest goes the slow way)
+        // (prepare() sized the streams by the same rule: no re-creation unless a piece is larger than the reader said)
+        std::vector<gn_stream*>& sources = tok_sources_;
+        sources.clear();
+        std::map<int, bool>     seen;
+        for (auto& lf : filters_)
+            for (auto& part : lf.parts)
+            {
+                if (seen.count(part.dp->device))
+                    continue;
+                seen[part.dp->device] = true;
+                if (!part.s || part.stream_reads < reads || part.stream_bases < nb + 64)
+                {
+                    if (!make_stream(part, reads, std::max<uint64_t>(nb + nb / 16 + 65536, hint_bases_), err))
+                        return false;
+                    const auto now = std::chrono::steady_clock::now();
+                    sec_create_ += std::chrono::duration<double>(now - t).count();
+                    t = now;
+                }
+                if (gn_stream_upload_fastq(part.s, b.text.data(), nb) != GN_OK)
+                {
+                    err = gn_last_error();
+                    return false;
+                }
+                sources.push_back(part.s);
+            }
+        sec_tok_enqueue_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+        return !sources.empty();
+    }
+
+    bool tokenise_end(ReadBatch&, uint32_t& n_reads, uint64_t& parsed_bytes, std::string& err) override
+    {
+        auto                     t       = std::chrono::steady_clock::now();
+        std::vector<gn_stream*>& sources = tok_sources_;
+        for (size_t i = 0; i < sources.size(); ++i)
+        {
+            uint32_t n  = 0;
+            uint64_t pb = 0;
+            if (gn_stream_fastq_index(sources[i], &n, nullptr, &pb) != GN_OK)
+            {
+                err = gn_last_error();
+                return false;
+            }
+            if (i == 0)
+            {
+                n_reads      = n;
+                parsed_bytes = pb;
+            }
+            else if (n != n_reads || pb != parsed_bytes)
+            {
+                err = "devices disagree about the records of a FASTQ piece";
+                return false;
+            }
+        }
+        sec_tok_wait_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+        return !sources.empty();
+    }
+
+    bool classify(ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
+                  std::string& err) override
+    {
+        return classify_begin(b, k, w, rel_cutoff, err) && classify_end(b, k, w, rel_cutoff, out, err);
+    }
+
+    // queues upload (a parsed batch), kernels and the pre-pass of every filter
+    bool classify_begin(ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, std::string& err) override
+    {
+        if (!resolve(err))
+            return false;
+        if (warmed_)
+            PinnedPool::get().mark_running();
+        const uint32_t n = b.raw ? b.raw_keep : (uint32_t)b.size();
+        if (b.raw && n == 0)
+            return true;
         auto           t = std::chrono::steady_clock::now();
         auto           lap = [&](double& acc) {
             const auto now = std::chrono::steady_clock::now();
             acc += std::chrono::duration<double>(now - t).count();
             t = now;
         };
-        out.n_hashes.assign(n, 0);
-        out.status.assign(n, 0);
-        out.per_filter.resize(filters_.size());
-        out.prefiltered = false;
-        out.max_count.clear();
-        out.dropped_rel_filter = out.dropped_fpr_query = 0;
+
         // submit to every stream first (asynchronous), then fetch
         const uint64_t nb = std::max<uint64_t>(b.bases.size(), 1);
         std::map<int, gn_stream*> source_of; // device -> the stream that holds this batch there
@@ -626,6 +767,11 @@ public:
                 Part& part = filters_[i].parts[g];
                 if (!part.s || part.stream_reads < n || part.stream_bases < nb)
                 {
+                    if (b.raw && !source_of.count(part.dp->device))
+                    {
+                        err = "the stream that holds a tokenised batch is too small for it"; // (cannot happen: tokenise() sized it)
+                        return false;
+                    }
                     if (!make_stream(part, std::max<uint64_t>(n, hint_reads_), std::max<uint64_t>(nb, hint_bases_), err))
                         return false;
                     lap(sec_create_);
@@ -643,11 +789,19 @@ public:
                 }
                 // the first stream of a device takes the batch (upload + minimisers); the level's other streams on that device --
                 // further filters, column parts -- count the same hashes (gn_stream_classify_shared)
-                auto src = share_hashes ? source_of.find(part.dp->device) : source_of.end();
-                const int rc = src == source_of.end()
-                                   ? gn_submit_batch(part.s, b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr,
-                                                     n, k, w, rel_cutoff[i])
-                                   : gn_stream_classify_shared(part.s, src->second, rel_cutoff[i]);
+                auto src = share_hashes || b.raw ? source_of.find(part.dp->device) : source_of.end(); // (a raw batch lives in one stream per device)
+                int rc;
+                if (src != source_of.end())
+                    rc = gn_stream_classify_shared(part.s, src->second, rel_cutoff[i]);
+                else if (b.raw) // the batch is resident already (tokenise())
+                {
+                    rc = gn_stream_fastq_keep(part.s, n);
+                    if (rc == GN_OK)
+                        rc = gn_stream_classify(part.s, k, w, rel_cutoff[i]);
+                }
+                else
+                    rc = gn_submit_batch(part.s, b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr, n, k, w,
+                                         rel_cutoff[i]);
                 if (rc != GN_OK)
                 {
                     err = gn_last_error();
@@ -657,6 +811,50 @@ public:
                     source_of[part.dp->device] = part.s;
             }
         lap(sec_submit_);
+        return true;
+    }
+
+    // waits for the batch and fetches: per filter the matches grouped by read, the reads' hash counts, the pre-pass's tallies
+    bool classify_end(ReadBatch& b, uint32_t, uint32_t, const std::vector<double>&, BatchResult& out, std::string& err) override
+    {
+        const uint32_t n = b.raw ? b.raw_keep : (uint32_t)b.size();
+        auto           t = std::chrono::steady_clock::now();
+        auto           lap = [&](double& acc) {
+            const auto now = std::chrono::steady_clock::now();
+            acc += std::chrono::duration<double>(now - t).count();
+            t = now;
+        };
+        if (warmed_ && !sets_reserved_ && n)
+        {
+            // the first real batch says how large the per-read arrays are: blocks for the result sets that will be in flight between
+            // this context, the post pool and the writer are locked now, in one go, instead of one by one under the next batches
+            sets_reserved_ = true;
+            const size_t m = (size_t)n + n / 8;
+            for (size_t bytes : { m * 4, m * 4, m * 8 + 8, m * 12, m * 4, m * 4, m * 4, m })
+                PinnedPool::get().reserve(bytes, 3);
+        }
+        out.n_hashes.assign(n, 0);
+        out.status.assign(n, 0);
+        out.per_filter.resize(filters_.size());
+        out.prefiltered = false;
+        out.max_count.clear();
+        out.dropped_rel_filter = out.dropped_fpr_query = 0;
+        if (b.raw)
+        {
+            b.rec_at.resize(n);
+            b.seq_at.resize(n);
+            b.seq_len.resize(n);
+            if (n == 0) // a piece behind the one that stopped its file: nothing of it is input
+            {
+                for (auto& fr : out.per_filter)
+                {
+                    fr.match_off.assign(1, 0);
+                    fr.matches.clear();
+                    fr.fpr_ok.clear();
+                }
+                return true;
+            }
+        }
         if (pf_active_ && pf_joint_) // several device filters: the rules need the level's max/min per read
         {
             std::vector<gn_stream*> level;
@@ -751,6 +949,15 @@ public:
                     out.dropped_fpr_query += b2;
                 }
         }
+        if (b.raw) // where the records lie in the batch's text (ids and letters are read there)
+        {
+            gn_stream* first = filters_.front().parts.front().s;
+            if (gn_stream_fastq_records(first, b.rec_at.data(), b.seq_at.data(), b.seq_len.data()) != GN_OK)
+            {
+                err = gn_last_error();
+                return false;
+            }
+        }
         lap(sec_fetch_);
         return true;
     }
@@ -759,17 +966,63 @@ public:
     {
         // streams sized for the largest batch the reader makes, created before the first batch arrives (a stream is ~30 device
         // buffers: tens of milliseconds, and every later re-creation frees memory, which stalls the whole device)
-        hint_reads_ = max_reads;
-        hint_bases_ = max_bases;
+        hint_bases_ = max_bases + max_bases / 16 + 65536; // (a piece of FASTQ text ends at a record's end, a little behind the slab's)
+        hint_reads_ = tokenises_fastq() ? std::max<size_t>(max_reads, hint_bases_ / 40) : max_reads;
         std::string err;
         if (!resolve(err))
             return;
         const auto t0 = std::chrono::steady_clock::now();
         for (auto& lf : filters_)
             for (auto& part : lf.parts)
-                if (!part.s && !make_stream(part, max_reads, max_bases, err))
+                if (!part.s && !make_stream(part, hint_reads_, hint_bases_, err))
                     return; // (the first batch will report what is wrong)
         sec_create_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    void warm_up(uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff) override
+    {
+        if (std::getenv("GANON_HOST_NO_WARM_UP"))
+            return;
+        // eight reads of 2 w letters, as a parsed batch or as text -- whichever way the run's batches will come
+        ReadBatch   b;
+        BatchResult out;
+        std::string err, text;
+        const std::string letters(std::max<size_t>(2 * w, 8), 'A');
+        b.off1.assign(1, 0);
+        for (int i = 0; i < 8; ++i)
+        {
+            text += "@w\n" + letters + "\n+\n" + std::string(letters.size(), 'I') + "\n";
+            b.id_buf += "w";
+            b.id_off.push_back(b.id_buf.size());
+            b.bases.insert(b.bases.end(), letters.begin(), letters.end());
+            b.off1.push_back(b.bases.size());
+        }
+        if (tokenises_fastq())
+        {
+            ReadBatch r;
+            r.raw = true;
+            r.text.assign(text.begin(), text.end());
+            uint32_t n = 0;
+            uint64_t parsed = 0;
+            if (tokenise(r, n, parsed, err))
+            {
+                r.raw_keep = n;
+                classify(r, k, w, rel_cutoff, out, err);
+            }
+        }
+        classify(b, k, w, rel_cutoff, out, err); // (errors: the first real batch will report them)
+        // page-locked blocks for the batches' text / bases
+        {
+            // ... and for the batches' text / bases: the reader fills its own window and the batch queue while the filters load; what
+            // is in flight behind the queue (device contexts, post pool, writer) needs blocks of its own.  Locking a block while
+            // batches are on the device stalls ALL device work for its duration (50 ms holes in the device timeline of the first
+            // hundred milliseconds, profiles/r03_e2e_timeline.txt): every block is locked before the first batch.
+            PinnedPool::get().reserve(tokenises_fastq() ? hint_bases_ : hint_bases_ / 2 + (1u << 20), 5);
+        }
+        // (the per-read arrays of the results are sized by the first real batch: classify_end)
+        warmed_ = true;
+        sec_create_ += sec_submit_ + sec_fetch_ + sec_tok_enqueue_ + sec_tok_wait_;
+        sec_submit_ = sec_fetch_ = sec_tok_enqueue_ = sec_tok_wait_ = 0;
     }
 
     std::string describe() const override
@@ -984,7 +1237,7 @@ private:
     }
 
     // match offsets and matches of one device filter (and, if wanted, n_hashes / status of the batch), target ids translated
-    bool fetch_part(Part& part, uint32_t n, BatchResult& out, bool with_reads, std::vector<uint64_t>& match_off, std::vector<Match>& matches,
+    bool fetch_part(Part& part, uint32_t n, BatchResult& out, bool with_reads, U64Buf& match_off, std::vector<Match>& matches,
                     std::string& err, std::vector<uint8_t>* fpr_ok = nullptr)
     {
         uint64_t need = 0;
@@ -1006,7 +1259,7 @@ private:
             // user bins that belong to no target (cannot happen with raptor indices) are dropped, and their flags with them
             std::vector<Match>    keep;
             std::vector<uint8_t>  keep_ok;
-            std::vector<uint64_t> off((size_t)n + 1, 0);
+            U64Buf                off((size_t)n + 1, 0);
             for (size_t j = 0; j < matches.size(); ++j)
                 if (matches[j].target != 0xFFFFFFFFu)
                 {
@@ -1027,14 +1280,18 @@ private:
 
     std::shared_ptr<DeviceSet> set_;
     size_t                index_;
+    bool                  sets_reserved_ = false;
+    bool                  warmed_ = false; // warm_up() has run: the next batch is a real one
+    bool                  twin_ = false; // a second set of streams beside the worker with the same index (never receives filters)
     int                   device_;
-    double                sec_create_ = 0, sec_submit_ = 0, sec_fetch_ = 0; // $GANON_HOST_TIMING: where classify() spends its time
+    double                sec_create_ = 0, sec_submit_ = 0, sec_fetch_ = 0, sec_tok_enqueue_ = 0, sec_tok_wait_ = 0; // $GANON_HOST_TIMING: where classify() spends its time
     unsigned              n_create_ = 0;
     uint64_t              gathered_bytes_ = 0;
     uint64_t              hint_reads_ = 0, hint_bases_ = 0; // largest batch the reader makes (prepare())
     bool                  long_reads_ = false;
     std::vector<Logical>  filters_;
-    std::vector<gn_match> tmp_;
+    std::vector<gn_match, ArenaAllocator<gn_match>> tmp_; // (page-locked: the device writes it)
+    std::vector<gn_stream*> tok_sources_; // streams that hold the FASTQ text of the batch being tokenised (one per device)
     PostFilterSpec        pf_spec_;
     std::vector<std::vector<std::vector<double>>> pf_fpr_; // [filter][part]: per device target of that part
     bool                  pf_joint_ = false;

@@ -96,6 +96,17 @@ public:
         not_full_.notify_one();
         return true;
     }
+    // 1 = got one, 0 = nothing there right now, -1 = the producer is done and nothing is left
+    int try_pop(T& b)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (q_.empty())
+            return done_ ? -1 : 0;
+        b = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return 1;
+    }
     void recycle(T&& b)
     {
         std::lock_guard<std::mutex> lk(m_);
@@ -154,6 +165,11 @@ public:
         const auto t0 = std::chrono::steady_clock::now();
         cv_.wait(lk, [&] { return seq < next_ + window_ || aborted_; });
         blocked_turn_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    bool try_turn(uint64_t seq) // the same without waiting
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        return seq < next_ + window_ || aborted_;
     }
     double blocked_turn() const { return blocked_turn_; }
     double blocked_take() const { return blocked_take_; }
@@ -461,7 +477,7 @@ private:
 // slab IS the batch (no copy); for pairs the slabs of file 1 become batches and the mates are copied next to them from
 // the slabs of file 2.  Everything else -- compressed input, FASTA, wrapped records, and whatever follows the first
 // record the parallel parser does not take -- goes through the sequential reader, from the byte where the slabs stopped.
-void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan)
+void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq)
 {
     uint64_t       seq = 0;
     MateCopier     copier(queue, (unsigned)env_size("GANON_HOST_MATE_THREADS", 3));
@@ -483,6 +499,12 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     rb.id_buf.clear();
                     rb.id_off.assign(1, 0);
                     rb.bases.clear();
+                    rb.raw = false;
+                    rb.text.clear();
+                    rb.rec_at.clear();
+                    rb.seq_at.clear();
+                    rb.seq_len.clear();
+                    rb.ticket.reset();
                 }
                 else
                     rb = ReadBatch();
@@ -514,6 +536,43 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             // ---- parallel slabs ----------------------------------------------------------------------------------
             uint64_t resume1 = 0, resume2 = 0; // where the sequential reader takes over (0 = from the start)
             bool     file_done = false, fallback = false;
+            // ---- raw pieces: the backend finds the records (single-end, uncompressed four-line FASTQ) ------------------------
+            if (raw_fastq && !paired)
+            {
+                if (auto pfr = ParallelFastq::open(pair.mate1, std::min(par_threads, 6u), slab_bytes, par_min, false, true)) // (six readers copy faster than the link takes)
+                {
+                    auto                tracker = std::make_shared<RawFileTracker>();
+                    size_t              pieces  = 0;
+                    ParallelFastq::Slab a;
+                    while (pfr->next(a))
+                    {
+                        if (!a.text.empty())
+                        {
+                            rb.raw = true;
+                            rb.text.swap(a.text); // (a recycled batch's buffer goes back to the slab readers)
+                            rb.text_at  = a.text_at;
+                            rb.raw_keep = 0;
+                            rb.ticket.reset(new RawTicket{ tracker, pieces++ });
+                            rb.seq = seq++;
+                            copier.deliver(std::move(rb)); // (input is counted by the worker, once the records are known)
+                            fresh();
+                        }
+                        pfr->recycle(std::move(a));
+                        a = ParallelFastq::Slab();
+                    }
+                    // every piece is records from end to end: done.  Otherwise the sequential reader goes on at the first byte that is
+                    // not (a wrapped or damaged record, a last line without its newline, ...) -- pieces behind it were dropped.
+                    uint64_t at = 0;
+                    if (tracker->wait_all(pieces, at) || at == UINT64_MAX) // (UINT64_MAX: the pipeline is going down)
+                        file_done = true;
+                    else
+                    {
+                        resume1  = at;
+                        fallback = true;
+                    }
+                }
+            }
+            if (!file_done && !fallback)
             {
                 auto pf1 = ParallelFastq::open(pair.mate1, paired ? std::max(1u, par_threads / 2) : par_threads, slab_bytes, par_min, paired);
                 std::shared_ptr<ParallelFastq> pf2(paired && pf1 ? ParallelFastq::open(pair.mate2, std::max(1u, par_threads / 2), slab_bytes, 0)
@@ -826,6 +885,23 @@ static bool ganon_classify(Config config)
             }
     }
     const size_t n_workers = backends.size();
+    // every worker thread drives two sets of device streams in turn (see the worker loop); $GANON_HOST_LANES=1: one
+    std::vector<std::vector<std::unique_ptr<Backend>>> twins(n_workers);
+    for (size_t i = 0; i < n_workers; ++i)
+        for (size_t l = 1; l < env_size("GANON_HOST_LANES", 2); ++l)
+        {
+            auto t = backends[i]->twin();
+            if (!t)
+                break;
+            if (config.long_reads)
+                t->set_long_reads(true);
+            twins[i].push_back(std::move(t));
+        }
+    auto each_twin = [&](auto&& f) {
+        for (auto& v : twins)
+            for (auto& t : v)
+                f(*t);
+    };
     if (config.verbose)
         for (auto& b : backends)
             std::cerr << "Backend: " << b->describe() << "\n";
@@ -843,7 +919,9 @@ static bool ganon_classify(Config config)
         open_for_every_prefix(out_unc, "unc", std::ofstream::out);
 
     BatchQueue  queue1(2 + 2 * n_workers);
-    std::thread read_task(parse_reads, std::ref(queue1), std::ref(report), std::ref(report_mutex), std::cref(reads));
+    // uncompressed single-end FASTQ goes to the workers as it lies in the file when the backend finds the records itself
+    const bool  raw_fastq = backends.front()->tokenises_fastq();
+    std::thread read_task(parse_reads, std::ref(queue1), std::ref(report), std::ref(report_mutex), std::cref(reads), raw_fastq);
     struct Joiner
     {
         std::thread& t;
@@ -877,6 +955,7 @@ static bool ganon_classify(Config config)
         loading.start();
         std::vector<FilterMeta>                     filters(level.filters.size());
         std::vector<std::map<std::string, TaxNode>> filter_tax(filters.size());
+        each_twin([](Backend& b) { b.clear_filters(); });
         for (auto& b : backends)
             b->clear_filters();
         ReplicatingSink sink(backends);
@@ -1023,6 +1102,7 @@ static bool ganon_classify(Config config)
         // target names they also replay the level's merge (the larger count wins, :531-537) and hand over the winners
         bool shared_targets = false;
         std::atomic<uint64_t> diag_unmerged{ 0 }, diag_fpr_evals{ 0 }; // (GANON_HOST_TIMING: what was left to the host)
+        std::atomic<uint64_t> diag_raw_pieces{ 0 }, diag_raw_reads{ 0 }, diag_raw_void{ 0 };
         {
             PostFilterSpec spec;
             spec.rel_filter = level.rel_filter;
@@ -1042,14 +1122,36 @@ static bool ganon_classify(Config config)
             bool       on   = true;
             for (auto& be : backends)
                 on = be->set_postfilter(want ? &spec : nullptr) && on;
+            each_twin([&](Backend& be) { on = be.set_postfilter(want ? &spec : nullptr) && on; });
             if (std::getenv("GANON_HOST_TIMING"))
                 std::cerr << "[prefilter] level " << level.label << ": filter_matches pre-pass on the device "
                           << (on ? "on" : "off") << " (" << filters.size() << " filter(s), targets "
                           << (spec.disjoint_targets ? "disjoint" : "shared between filters") << ")" << std::endl;
         }
 
+        loading.start(); // (device-side setup belongs to loading: the reference's agents exist once its filters are read)
+        // device streams for the largest batch, and one tiny batch through every worker context: buffers are allocated and the
+        // kernels' code is loaded here, not with the first reads (the reader is parsing its first slabs meanwhile)
+        {
+            std::vector<std::thread> setup;
+            auto warm = [&](Backend* be) {
+                if (!be->active())
+                    return;
+                be->prepare(std::min<size_t>(kBatchReads, 1u << 20), std::min<size_t>(kBatchBases, env_size("GANON_HOST_SLAB_BYTES", 48u << 20)));
+                be->warm_up(level.kmer_size, level.window_size, std::vector<double>(filters.size(), 1.0));
+            };
+            for (auto& b : backends)
+                setup.emplace_back(warm, b.get());
+            each_twin([&](Backend& b) { setup.emplace_back(warm, &b); });
+            for (auto& t : setup)
+                t.join();
+        }
+        loading.stop();
         std::vector<ReadBatch> next_carried;
         classifying.start();
+        const auto level_t0 = std::chrono::steady_clock::now();
+        auto       since    = [level_t0] { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - level_t0).count(); };
+        EventSpan  ev_taken, ev_begun, ev_fetched, ev_posted, ev_merged; // ($GANON_HOST_TIMING: ramp-up and tail of the pipeline)
 
         struct MatchEntry
         {
@@ -1073,14 +1175,6 @@ static bool ganon_classify(Config config)
             std::vector<uint32_t>    slot_order, pos_of, touch_stamp;
             std::vector<MatchEntry>  reordered;
             uint32_t                 touch_epoch = 0;
-        };
-
-        auto device_stage = [&](Backend& be, const ReadBatch& rb, BatchResult& res, std::string& e) -> bool {
-            const auto t0 = std::chrono::steady_clock::now();
-            const bool ok = be.classify(rb, level.kmer_size, level.window_size, rel_cutoffs, res, e);
-            std::lock_guard<std::mutex> lk(timing_mutex);
-            sec_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            return ok;
         };
 
         // one batch's reads -> text, tallies, carried reads.  Touches nothing shared but read-only tables (filters, node names
@@ -1320,11 +1414,11 @@ static bool ganon_classify(Config config)
                     const std::string_view id = rb.id(r);
                     left.id_buf.append(id);
                     left.id_off.push_back(left.id_buf.size());
-                    left.bases.insert(left.bases.end(), rb.bases.begin() + rb.off1[r], rb.bases.begin() + rb.off1[r] + read1_len);
+                    left.bases.insert(left.bases.end(), rb.seq1(r), rb.seq1(r) + read1_len);
                     left.off1.push_back(left.bases.size());
                     if (rb.paired)
                     {
-                        left2.insert(left2.end(), rb.bases.begin() + rb.off2[r], rb.bases.begin() + rb.off2[r] + read2_len);
+                        left2.insert(left2.end(), rb.seq2(r), rb.seq2(r) + read2_len);
                         left.off2.push_back(left2.size());
                     }
                 }
@@ -1386,7 +1480,8 @@ static bool ganon_classify(Config config)
         // ---- reader -> [one device worker per GPU] -> post stage (this thread), results consumed in input order
         {
             const size_t             n_post = (size_t)env_size("GANON_HOST_POST_THREADS", 3);
-            InOrder                  ordered(2 * n_workers + n_post + 2);
+            // (what may pile up in front of the writer while one batch is late: every batch held there is page-locked memory that is missing elsewhere)
+            InOrder                  ordered(env_size("GANON_HOST_LANES", 2) * n_workers + n_post + 2); // (more than what workers, post pool and queues hold at once)
             BoundedQueue<ClassifiedBatch> classified(n_post + 1);
             std::atomic<size_t>      workers_left{ n_workers };
             std::atomic<bool>        failed{ false };
@@ -1407,27 +1502,174 @@ static bool ganon_classify(Config config)
             std::vector<std::thread> workers;
             for (size_t wi = 0; wi < n_workers; ++wi)
                 workers.emplace_back([&, wi] {
-                    ClassifiedBatch cb;
-                    if (backends[wi]->active()) // (streams for the largest batch, while the reader is busy with its first slabs)
-                        backends[wi]->prepare(std::min<size_t>(kBatchReads, 1u << 20),
-                                              std::min<size_t>(kBatchBases, env_size("GANON_HOST_SLAB_BYTES", 48u << 20)));
-                    while (backends[wi]->active()) // (a level with a partitioned filter runs on a few of the workers)
+                    // One thread, several lanes (the worker's backend and its twins: own device streams, same filters), each holding
+                    // one batch: IDLE -> UPLOADED (raw text on its way, records not yet known) -> QUEUED (kernels queued) -> IDLE.
+                    // Per round the thread queues the kernels of the batch it uploaded last round, starts the next upload, and
+                    // then waits for its oldest batch -- so the link, the compute units and the host side of a worker overlap.
+                    enum class St { idle, uploaded, queued };
+                    struct Lane
                     {
-                        ordered.take_free(cb);
-                        if (failed || !next_batch(cb.rb))
-                            break;
-                        ordered.wait_turn(cb.rb.seq);
+                        Backend*        be = nullptr;
+                        ClassifiedBatch cb;
+                        St              st = St::idle;
+                        uint64_t        age = 0;
+                    };
+                    std::vector<Lane> lanes;
+                    if (backends[wi]->active()) // (a level with a partitioned filter runs on a few of the workers)
+                    {
+                        lanes.emplace_back();
+                        lanes.back().be = backends[wi].get();
+                        for (auto& t : twins[wi])
+                            if (t->active())
+                            {
+                                lanes.emplace_back();
+                                lanes.back().be = t.get();
+                            }
+                    }
+                    auto fail = [&](const std::string& e) {
+                        std::lock_guard<std::mutex> lk(err_mutex);
+                        if (!failed.exchange(true))
+                            err = e;
+                        ordered.abort();
+                        return false;
+                    };
+                    auto timed = [&](auto&& f) {
+                        const auto t0 = std::chrono::steady_clock::now();
+                        const bool ok = f();
+                        std::lock_guard<std::mutex> lk(timing_mutex);
+                        sec_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                        return ok;
+                    };
+                    // UPLOADED -> QUEUED: the records (a file's pieces are accepted in file order), then the kernels
+                    auto queue_kernels = [&](Lane& x) -> bool {
                         std::string e;
-                        if (!device_stage(*backends[wi], cb.rb, cb.res, e))
+                        ReadBatch&  rb = x.cb.rb;
+                        if (rb.raw && rb.ticket)
                         {
-                            std::lock_guard<std::mutex> lk(err_mutex);
-                            if (!failed.exchange(true))
-                                err = e;
-                            ordered.abort();
-                            break;
+                            uint32_t n = 0;
+                            uint64_t parsed = 0;
+                            if (!timed([&] { return x.be->tokenise_end(rb, n, parsed, e); }))
+                                return fail(e);
+                            // the piece says what it is right away; whether the pieces before it were all records is asked when its
+                            // results arrive (they always are, unless the file is damaged: then this batch's results are dropped there)
+                            rb.ticket->publish(parsed == rb.text.size(), rb.text_at + parsed);
+                            rb.raw_keep = n;
                         }
-                        classified.push(std::move(cb));
-                        cb = ClassifiedBatch();
+                        if (!timed([&] { return x.be->classify_begin(rb, level.kmer_size, level.window_size, rel_cutoffs, e); }))
+                            return fail(e);
+                        x.st = St::queued;
+                        ev_begun.mark(since());
+                        return true;
+                    };
+                    // QUEUED -> IDLE: wait, fetch, hand over to the post pool
+                    auto finish = [&](Lane& x) -> bool {
+                        std::string e;
+                        if (!timed([&] { return x.be->classify_end(x.cb.rb, level.kmer_size, level.window_size, rel_cutoffs, x.cb.res, e); }))
+                            return fail(e);
+                        ReadBatch& rb = x.cb.rb;
+                        if (rb.raw && rb.ticket)
+                        {
+                            const uint32_t n = rb.raw_keep;
+                            if (!rb.ticket->tracker->wait_prefix(rb.ticket->idx)) // a piece before this one stopped the file: none of this is input
+                            {
+                                rb.raw_keep = 0;
+                                rb.rec_at.clear();
+                                rb.seq_at.clear();
+                                rb.seq_len.clear();
+                                x.cb.res.n_hashes.clear();
+                                x.cb.res.status.clear();
+                                x.cb.res.max_count.clear();
+                                x.cb.res.prefiltered = false;
+                                x.cb.res.dropped_rel_filter = x.cb.res.dropped_fpr_query = 0;
+                                for (auto& fr : x.cb.res.per_filter)
+                                {
+                                    fr.match_off.assign(1, 0);
+                                    fr.matches.clear();
+                                    fr.fpr_ok.clear();
+                                }
+                            }
+                            diag_raw_pieces++;
+                            diag_raw_reads += rb.raw_keep;
+                            diag_raw_void += rb.raw_keep == n ? 0 : 1;
+                            if (rb.raw_keep)
+                            {
+                                std::lock_guard<std::mutex> lk(report_mutex);
+                                report.count_input(rb.prefix, rb.raw_keep); // :1253,1272
+                            }
+                        }
+                        x.st = St::idle;
+                        ev_fetched.mark(since());
+                        classified.push(std::move(x.cb));
+                        x.cb = ClassifiedBatch();
+                        return true;
+                    };
+                    auto pick = [&](St st) -> Lane* { // the oldest lane in that state
+                        Lane* best = nullptr;
+                        for (auto& ln : lanes)
+                            if (ln.st == st && (!best || ln.age < best->age))
+                                best = &ln;
+                        return best;
+                    };
+                    uint64_t age = 0;
+                    bool     good = !lanes.empty(), more = true;
+                    while (good)
+                    {
+                        if (Lane* u = pick(St::uploaded)) // last round's upload: its kernels
+                            if (!(good = queue_kernels(*u)))
+                                break;
+                        bool  took = false;
+                        Lane* x    = more && !failed ? pick(St::idle) : nullptr;
+                        if (x)
+                        {
+                            ordered.take_free(x->cb);
+                            const bool in_flight = pick(St::queued) != nullptr;
+                            int        got;
+                            if (!first_level || !in_flight) // (nothing to do meanwhile: wait for the reader)
+                                got = next_batch(x->cb.rb) ? 1 : -1;
+                            else
+                                got = queue1.try_pop(x->cb.rb);
+                            if (got < 0)
+                                more = false;
+                            took = got > 0;
+                        }
+                        if (took)
+                        {
+                            // (too far ahead of the writer?  Never wait for it while holding results it may be waiting for: deliver first)
+                            while (good && !ordered.try_turn(x->cb.rb.seq))
+                            {
+                                if (Lane* mine = pick(St::queued))
+                                    good = finish(*mine);
+                                else
+                                {
+                                    ordered.wait_turn(x->cb.rb.seq);
+                                    break;
+                                }
+                            }
+                            if (!good)
+                                break;
+                            ev_taken.mark(since());
+                            x->age = age++;
+                            std::string e;
+                            if (x->cb.rb.raw && x->cb.rb.ticket)
+                            {
+                                if (!timed([&] { return x->be->tokenise_begin(x->cb.rb, e); })) // the text is on its way
+                                {
+                                    good = fail(e);
+                                    break;
+                                }
+                                x->st = St::uploaded;
+                            }
+                            else if (!(good = queue_kernels(*x))) // (a parsed batch: upload and kernels in one go)
+                                break;
+                        }
+                        Lane* q = pick(St::queued);
+                        if (q && (!took || !pick(St::idle))) // every lane holds a batch, or there is nothing new to start: the oldest one's results
+                        {
+                            if (!(good = finish(*q)))
+                                break;
+                        }
+                        else if (!took && !pick(St::uploaded) && !q && !more)
+                            break; // everything delivered
                     }
                     g_cpu.worker.add_this_thread();
                     if (workers_left.fetch_sub(1) == 1)
@@ -1442,6 +1684,7 @@ static bool ganon_classify(Config config)
                     while (classified.pop(cb))
                     {
                         post_stage(cb.rb, cb.res, scratch, cb.post);
+                        ev_posted.mark(since());
                         const uint64_t seq = cb.rb.seq;
                         ordered.put(seq, std::move(cb));
                         cb = ClassifiedBatch();
@@ -1453,6 +1696,11 @@ static bool ganon_classify(Config config)
             while (ordered.take(cb, n_post))
             {
                 merge_stage(cb);
+                ev_merged.mark(since());
+                { // (a raw batch's text goes back to the allocator's pool right away, where the slab readers find it; the free lists would sit on it)
+                    ByteBuf none;
+                    none.swap(cb.rb.text);
+                }
                 if (first_level)
                     queue1.recycle(std::move(cb.rb));
                 cb.rb = ReadBatch();
@@ -1481,6 +1729,19 @@ static bool ganon_classify(Config config)
                           << ordered.blocked_turn() << " s (summed), post stage waiting for a result " << ordered.blocked_take() << " s"
                           << "; reads the pre-pass handed back whole " << diag_unmerged.load() << ", --fpr-query evaluations on the host "
                           << diag_fpr_evals.load() << std::endl;
+            if (std::getenv("GANON_HOST_TIMING"))
+            {
+                std::cerr << "[host pipeline] level " << level.label << ", seconds since the level's start, first .. last: ";
+                ev_taken.print(std::cerr, "batch taken by a worker");
+                ev_begun.print(std::cerr, ", kernels queued");
+                ev_fetched.print(std::cerr, ", results fetched");
+                ev_posted.print(std::cerr, ", post-processed");
+                ev_merged.print(std::cerr, ", merged + written");
+                std::cerr << "; workers done at " << since() * 1e-6 << std::endl;
+            }
+            if (std::getenv("GANON_HOST_TIMING") && diag_raw_pieces.load())
+                std::cerr << "[host input] level " << level.label << ": " << diag_raw_pieces.load() << " pieces of FASTQ text tokenised on the device ("
+                          << diag_raw_reads.load() << " reads), " << diag_raw_void.load() << " dropped behind a piece that stopped its file" << std::endl;
         }
         carried.swap(next_carried);
 
@@ -1543,6 +1804,7 @@ static bool ganon_classify(Config config)
             for (auto& [prefix, file] : out_all)
                 file.close();
     }
+    each_twin([](Backend& b) { b.clear_filters(); });
     for (auto& b : backends)
         b->clear_filters();
 

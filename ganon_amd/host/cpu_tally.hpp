@@ -31,6 +31,31 @@ struct CpuTally
     }
 };
 
+// first and last time something happened, in seconds since a common start (the pipeline's ramp-up and tail, $GANON_HOST_TIMING)
+struct EventSpan
+{
+    std::atomic<int64_t> first_us{ -1 }, last_us{ -1 };
+    std::atomic<uint64_t> count{ 0 };
+    void mark(int64_t us)
+    {
+        int64_t expect = -1;
+        first_us.compare_exchange_strong(expect, us);
+        int64_t prev = last_us.load();
+        while (prev < us && !last_us.compare_exchange_weak(prev, us)) {}
+        ++count;
+    }
+    void reset()
+    {
+        first_us = -1;
+        last_us  = -1;
+        count    = 0;
+    }
+    void print(std::ostream& os, const char* name) const
+    {
+        os << name << ' ' << count.load() << "x " << first_us.load() * 1e-6 << " .. " << last_us.load() * 1e-6;
+    }
+};
+
 struct CpuTallies
 {
     CpuTally parse, inflate, reader, mate, worker, post;

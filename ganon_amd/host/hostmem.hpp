@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <new>
+#include <utility>
 #include <vector>
 
 namespace gnhost
@@ -39,6 +40,15 @@ struct ArenaAllocator
         return static_cast<T*>(p);
     }
     void deallocate(T* p, size_t) noexcept { g_host_arena.release(p); }
+    // resize() leaves new elements as they are (these buffers are filled by pread / memcpy / the device right after)
+    template <typename U, typename... Args>
+    void construct(U* p, Args&&... args)
+    {
+        if constexpr (sizeof...(Args) == 0)
+            ::new (static_cast<void*>(p)) U;
+        else
+            ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
     template <typename U>
     bool operator==(const ArenaAllocator<U>&) const noexcept
     {
@@ -52,5 +62,7 @@ struct ArenaAllocator
 };
 
 using ByteBuf = std::vector<uint8_t, ArenaAllocator<uint8_t>>;
+using U32Buf  = std::vector<uint32_t, ArenaAllocator<uint32_t>>;
+using U64Buf  = std::vector<uint64_t, ArenaAllocator<uint64_t>>; // per-read arrays the device writes (page-locked under the HIP backend)
 
 } // namespace gnhost

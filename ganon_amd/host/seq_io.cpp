@@ -668,7 +668,10 @@ class RangeLines
 public:
     // an uncompressed file (pread), or the decompressed stream of a gzip file (ParallelGzip::pread; its size is known only at its
     // end; a damaged stream makes refill throw)
-    RangeLines(int fd, uint64_t file_size, ParallelGzip* gz = nullptr) : fd_(fd), gz_(gz), size_(file_size), buf_(4u << 20) { data_ = buf_.data(); }
+    RangeLines(int fd, uint64_t file_size, ParallelGzip* gz = nullptr, size_t buffer = 4u << 20) : fd_(fd), gz_(gz), size_(file_size), buf_(buffer)
+    {
+        data_ = buf_.data();
+    }
     // the whole file mapped into memory: lines are views of the mapping, nothing is copied
     RangeLines(const char* map, uint64_t file_size) : fd_(-1), gz_(nullptr), size_(file_size), data_(map), len_((size_t)file_size), mapped_(true) {}
     void seek(uint64_t off)
@@ -778,6 +781,7 @@ struct ParallelFastq::Impl
     bool                     stop = false, ended = false;
     bool                     mate_room = false;
     bool                     fasta = false; // records start at lines that begin with '>' (no sequence line can: '>' is no legal letter)
+    bool                     raw = false;   // slabs are delivered as text (Slab::text)
 
     // first byte of the first record at or after p (== size when there is none): a line that begins with '@' and whose
     // next-but-one line begins with '+'
@@ -951,9 +955,26 @@ struct ParallelFastq::Impl
         out.rec_at.push_back(in.tell());
     }
 
+    // raw mode: bytes [begin, end) of the file into the slab's (page-locked) text buffer
+    void read_text(size_t begin, size_t end, Slab& out) const
+    {
+        out.text_at = begin;
+        out.text.resize(end - begin);
+        size_t got = 0;
+        while (got < end - begin)
+        {
+            const ssize_t k = ::pread(fd, out.text.data() + got, end - begin - got, (off_t)(begin + got));
+            if (k <= 0)
+                break; // (the file shrank under us: what is there is delivered; the records end where the text ends)
+            got += (size_t)k;
+        }
+        out.text.resize(got);
+    }
+
     void work()
     {
-        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get());
+        // (raw slabs: the lines read here are the few around a slab's borders)
+        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get(), raw ? (64u << 10) : (4u << 20));
         for (;;)
         {
             size_t i;
@@ -980,6 +1001,8 @@ struct ParallelFastq::Impl
             s.rec_at.clear();
             s.error.clear();
             s.irregular = false;
+            s.text.clear();
+            s.text_at = 0;
             size_t b = 0;
             bool   have_b = false, last = false;
             try
@@ -990,7 +1013,9 @@ struct ParallelFastq::Impl
                 //  first byte, so this slab is the last, and empty)
                 last = gz && b >= end_size();
                 const size_t e = (!gz && i + 1 == n_slabs) || last ? end_size() : record_at_or_after(in, (i + 1) * slab_bytes);
-                if (b < e)
+                if (b < e && raw)
+                    read_text(b, e, s);
+                else if (b < e)
                     parse(in, b, e, s);
                 else
                     s.rec_at.assign(1, b);
@@ -1020,7 +1045,7 @@ struct ParallelFastq::Impl
 ParallelFastq::ParallelFastq(Impl* i) : impl_(i) {}
 
 std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
-                                                   bool mate_room)
+                                                   bool mate_room, bool raw)
 {
     std::string base = path;
     bool        gz_name = false;
@@ -1047,6 +1072,11 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     }
     const bool is_gzip = magic[0] == 0x1F && magic[1] == 0x8B;
     std::unique_ptr<ParallelGzip> gz;
+    if (raw && (is_gzip || fasta))
+    {
+        ::close(fd);
+        return nullptr;
+    }
     if (is_gzip)
     {
         // An ordinary gzip file (blocked gzip has a reader of its own, BgzfSource): inflated by several threads (pgzip.hpp),
@@ -1077,9 +1107,10 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     im->fd         = fd;
     im->slab_bytes = std::max<size_t>(slab_bytes, 1 << 16);
     im->n_slabs    = gz ? ~(size_t)0 : (im->size + im->slab_bytes - 1) / im->slab_bytes;
-    im->window     = 2 * threads + 2;
+    im->window     = raw ? threads + 2 : 2 * threads + 2; // (a raw slab is one pread: the readers need little lead, and every slab in flight is page-locked memory)
     im->mate_room  = mate_room;
     im->fasta      = fasta;
+    im->raw        = raw;
     if (gz)
     {
         gz->set_retain_limit((uint64_t)(im->window + 3) * im->slab_bytes);

@@ -57,6 +57,10 @@ public:
         ByteBuf               bases;       // ASCII, back to back (device-bound: page-locked under the HIP backend)
         std::vector<uint64_t> off{ 0 };    // n+1
         std::vector<uint64_t> rec_at;      // n+1: byte offset of every record in the file (last = end of the parsed part)
+        // raw mode (open(..., raw = true)): the bytes of the slab's records as they lie in the file, nothing parsed -- whoever
+        // takes the slab finds the records itself (the HIP backend does, on the device: csrc/gn_fastq.hip)
+        ByteBuf               text;
+        uint64_t              text_at = 0; // offset of text[0] in the file (the first byte of a record, by the slab rule below)
         std::string           error;       // a ParseError ended the file after the records above
         bool                  irregular = false;
         uint64_t              resume_at = 0; // irregular: byte offset of the first record that was not parsed here
@@ -65,8 +69,9 @@ public:
     // nullptr when the file is not eligible (compressed, not FASTQ by extension, smaller than min_bytes, cannot be mapped)
     // mate_room: the slabs' base buffers are reserved with room for as many bases again (the first file of a pair: the
     // mates are appended behind them when the slab becomes a batch -- without the room that append re-locks pages)
+    // raw: uncompressed FASTQ only -- the slabs are cut by the same rule but delivered as text (Slab::text), unparsed
     static std::unique_ptr<ParallelFastq> open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
-                                               bool mate_room = false);
+                                               bool mate_room = false, bool raw = false);
     ~ParallelFastq();
     bool next(Slab& out); // slabs in file order; false at the end of the file (or after an error / irregular slab)
     void recycle(Slab&& used); // hands a consumed slab's buffers back to the parser threads

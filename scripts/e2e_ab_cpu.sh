@@ -10,7 +10,7 @@ run() { # label, env..., -- args
   label=$1; shift
   envs=()
   while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  out=$( env GANON_HOST_TIMING=1 "${envs[@]}" $EXE --ibf $D/keep.ibf --single-reads $D/keep.fq -o $D/ab_out --output-all --rel-cutoff 0.75 --verbose "$@" 2>&1 )
+  out=$( env GANON_HOST_TIMING=1 "${envs[@]}" timeout 120 $EXE --ibf $D/keep.ibf --single-reads $D/keep.fq -o $D/ab_out --output-all --rel-cutoff 0.75 --verbose "$@" 2>&1 )
   t=$(echo "$out" | grep -o "classifying+printing elapsed (s): [0-9.e+-]*" | grep -o "[0-9.e+-]*$")
   echo "$label: classify+print $t s = $(python -c "print(round($N/$t/1e6,1))") Mreads/s"
   echo "$out" | grep -E "host stalls|backend timing|host cpu|host timing" | sed 's/^/      /' | cut -c1-400

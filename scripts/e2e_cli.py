@@ -28,7 +28,12 @@ EXTRA = os.environ.get("E2E_ARGS", "--rel-cutoff 0.75").split()
 out = {"reads": n, "filter_gib": rows * 512 / 2**30, "args": " ".join(EXTRA)}
 
 wl = bw.make_device_flat_workload("e2e", bins, rows, 4, n, seed=42)
-flt, _ = bw.device_filter(ganon_amd, wl)
+if os.environ.get("E2E_NO_PLANT"):  # the filter holds none of the genomes the reads were cut from: chance matches only
+    flt = ganon_amd.HipFilter.ibf(None, wl.bins, wl.rows, wl.hash_funs, None, None, device=0)
+    flt.fill_random(wl.seed, 1, wl.word_lo, wl.row_words_total)
+    out["planted"] = False
+else:
+    flt, _ = bw.device_filter(ganon_amd, wl)
 ibf = os.path.join(d, "ganon_e2e.ibf")
 # the filter's rows are Bernoulli(0.5) bits, i.e. every bin is a Bloom filter at its optimal load for h = 4: per-hash false
 # positive rate 0.5^4 = 0.0625 (a database built with --max-fp 0.0625; ganon-build's default is 0.05).  The header
@@ -117,7 +122,7 @@ for label, dev, parse_threads in runs:
     elif parse_threads:
         env["GANON_HOST_PARSE_THREADS"] = str(parse_threads)
     p = subprocess.run([exe, "--ibf", IBFS if not os.environ.get("E2E_HIBF") else ibf] + READS + ["-o", prefix, "--output-all", "--verbose"] + (["--device", dev] if dev else []) + EXTRA,
-                       capture_output=True, text=True, env=env)
+                       capture_output=True, text=True, env=env, timeout=900)
     r = {"rc": p.returncode, "wall_s": round(time.time() - t0, 2)}
     for key, pat in (("load_s", r"loading filter\(s\)\s+elapsed \(s\): ([0-9.eE+-]+)"),
                      ("classify_print_s", r"classifying\+printing elapsed \(s\): ([0-9.eE+-]+)"),

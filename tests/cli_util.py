@@ -19,7 +19,7 @@ def build_oracle_binary() -> str:
 
 
 def run(binary: str, args: List[str], check: bool = True):
-    p = subprocess.run([binary] + args, capture_output=True, text=True)
+    p = subprocess.run([binary] + args, capture_output=True, text=True, timeout=600)  # (a hang fails the test)
     if check and p.returncode != 0:
         raise AssertionError(f"{binary} {' '.join(args)} -> rc {p.returncode}\n{p.stderr}")
     return p

@@ -6,6 +6,8 @@
 #include "../../oracle/ganon_oracle.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace gnhost
 {
@@ -62,11 +64,82 @@ public:
         }
         return true;
     }
-    void clear_filters() override { held_.clear(); }
+    void clear_filters() override
+    {
+        if (!origin_)
+            held_.clear();
+    }
 
-    bool classify(const ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
+    // The checker can stand in for the product backend's optional features, so that the host pipeline's code for them (raw FASTQ
+    // pieces accepted in file order, several batch contexts per worker thread) runs in the CPU tests too:
+    //   $GANON_HOST_DEVICE_FASTQ=1   raw pieces, records found here by the slab parser's rule (scalar restatement)
+    //   twin()                        a second context on the same filters
+    bool tokenises_fastq() const override
+    {
+        const char* e = std::getenv("GANON_HOST_DEVICE_FASTQ");
+        return e && e[0] == '1';
+    }
+    std::unique_ptr<Backend> twin() override
+    {
+        auto t     = std::make_unique<OracleBackend>();
+        t->origin_ = origin_ ? origin_ : this;
+        return t;
+    }
+    bool tokenise(ReadBatch& b, uint32_t& n_reads, uint64_t& parsed_bytes, std::string&) override
+    {
+        static const LegalLetters legal;
+        tok_rec_.clear();
+        tok_seq_.clear();
+        tok_len_.clear();
+        const uint8_t* t = b.text.data();
+        const size_t   n = b.text.size();
+        size_t         pos = 0;
+        auto line_end = [&](size_t p) -> size_t { // index of the '\n' that ends the line at p, or n
+            const void* q = p < n ? std::memchr(t + p, '\n', n - p) : nullptr;
+            return q ? (size_t)((const uint8_t*)q - t) : n;
+        };
+        while (pos < n)
+        {
+            const size_t a = line_end(pos);
+            if (a == n || a == pos || t[pos] != '@')
+                break;
+            const size_t bnl = line_end(a + 1);
+            if (bnl == n)
+                break;
+            size_t len = bnl - a - 1;
+            if (len && t[bnl - 1] == '\r')
+                --len;
+            bool ok = true;
+            for (size_t i = 0; i < len && ok; ++i)
+                ok = legal.ok[t[a + 1 + i]];
+            if (!ok)
+                break;
+            const size_t c = line_end(bnl + 1);
+            if (c == n || c == bnl + 1 || t[bnl + 1] != '+')
+                break;
+            const size_t d = line_end(c + 1);
+            if (d == n || d - c - 1 != len)
+                break;
+            tok_rec_.push_back((uint32_t)pos);
+            tok_seq_.push_back((uint32_t)(a + 1));
+            tok_len_.push_back((uint32_t)len);
+            pos = d + 1;
+        }
+        n_reads      = (uint32_t)tok_rec_.size();
+        parsed_bytes = pos;
+        return true;
+    }
+
+    bool classify(ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
                   std::string&) override
     {
+        std::vector<Held>& held_ = origin_ ? origin_->held_ : this->held_;
+        if (b.raw) // the first raw_keep records found by tokenise(): described for the pipeline, then classified like parsed reads
+        {
+            b.rec_at.assign(tok_rec_.begin(), tok_rec_.begin() + b.raw_keep);
+            b.seq_at.assign(tok_seq_.begin(), tok_seq_.begin() + b.raw_keep);
+            b.seq_len.assign(tok_len_.begin(), tok_len_.begin() + b.raw_keep);
+        }
         const size_t n = b.size();
         out.n_hashes.assign(n, 0);
         out.status.assign(n, 0);
@@ -78,14 +151,14 @@ public:
         std::vector<uint16_t> counts;
         for (size_t r = 0; r < n; ++r)
         {
-            auto ranks = [&](uint64_t o, uint64_t len, std::vector<uint8_t>& dst) {
+            auto ranks = [&](const uint8_t* src, uint64_t len, std::vector<uint8_t>& dst) {
                 dst.resize(len);
                 for (uint64_t i = 0; i < len; ++i)
-                    dst[i] = gno_char_to_rank(b.bases[o + i], nullptr);
+                    dst[i] = gno_char_to_rank(src[i], nullptr);
             };
-            ranks(b.off1[r], b.len1(r), r1);
+            ranks(b.seq1(r), b.len1(r), r1);
             if (b.paired)
-                ranks(b.off2[r], b.len2(r), r2);
+                ranks(b.seq2(r), b.len2(r), r2);
             else
                 r2.clear();
             size_t nh = 0;
@@ -165,7 +238,19 @@ private:
         std::vector<uint32_t>             off, bins;
         uint32_t                          n_targets = 0;
     };
-    std::vector<Held> held_;
+    struct LegalLetters // dna15, either case (host/seq_io.cpp LegalTable)
+    {
+        bool ok[256];
+        LegalLetters()
+        {
+            std::fill(ok, ok + 256, false);
+            for (const char* p = "ACGTURYSWKMBDHVNacgturyswkmbdhvn"; *p; ++p)
+                ok[(unsigned char)*p] = true;
+        }
+    };
+    std::vector<Held>     held_;
+    OracleBackend*        origin_ = nullptr; // a twin classifies against its origin's filters
+    std::vector<uint32_t> tok_rec_, tok_seq_, tok_len_;
 };
 } // namespace
 

@@ -335,7 +335,7 @@ def test_config1_hip_equals_oracle_backend(oracle_bin, config1, tmp_path):
 def _run_workers(binary, c1, out, devices, batch_reads="500"):
     env = dict(os.environ, GANON_HOST_BATCH_READS=batch_reads)
     p = subprocess.run([binary, "--ibf", c1["ibf"], "--single-reads", c1["fq"], "-o", out, "--output-all", "--output-unclassified",
-                        "--output-stats", "--quiet", "--device", devices], capture_output=True, text=True, env=env)
+                        "--output-stats", "--quiet", "--device", devices], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr
     return out
 
@@ -364,7 +364,7 @@ def test_multi_worker_outputs_equal_single_worker_hip(oracle_bin, config1, tmp_p
 def test_device_argument_errors(oracle_bin, config1, tmp_path):
     for bad in ("x", "0,,1", "-1"):
         p = subprocess.run([oracle_bin, "--ibf", config1["ibf"], "--single-reads", config1["fq"], "-o", str(tmp_path / "e"), "--device", bad],
-                           capture_output=True, text=True)
+                           capture_output=True, text=True, timeout=900)
         assert p.returncode == 1 and "ERROR" in p.stderr
 
 
@@ -411,7 +411,7 @@ def test_host_lca_on_reference_vectors(tmp_path):
     ncbi = [("1224", "366602,470"), ("2", "366602,470,1406"), ("2290931", "2223,51589"), ("10239", "2025595,491893"),
             ("1", "366602,470,1406,2223,51589,2025595,491893")]
     for fn, cases in (("lca_tree.tax", tree), ("lca_ncbi.tax", ncbi)):
-        out = subprocess.run([exe, os.path.join(gold, fn), "1"] + [q for _, q in cases], capture_output=True, text=True, check=True)
+        out = subprocess.run([exe, os.path.join(gold, fn), "1"] + [q for _, q in cases], capture_output=True, text=True, check=True, timeout=900)
         assert out.stdout.split() == [w for w, _ in cases]
     # robustness: a self-parent row cannot hang the walk; a node outside the rooted tree resolves to the root
     bad = tmp_path / "bad.tax"

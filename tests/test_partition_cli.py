@@ -24,7 +24,7 @@ def _run(binary, db, out, extra=(), env=None, check=True):
     e.update(env or {})
     cutoff = [] if "--rel-cutoff" in extra else ["--rel-cutoff", "0.5"]
     p = subprocess.run([binary, "--ibf", db["ibf"], "--single-reads", db["fq"], "-o", out, "--output-all", "--output-unclassified",
-                        "--quiet"] + cutoff + list(extra), capture_output=True, text=True, env=e)
+                        "--quiet"] + cutoff + list(extra), capture_output=True, text=True, env=e, timeout=900)
     if check:
         assert p.returncode == 0, p.stderr
     return p
@@ -82,7 +82,7 @@ def test_level_with_a_replicated_and_a_partitioned_filter(oracle_bin, wide_db, c
     ora, got = str(tmp_path / "ora"), str(tmp_path / "got")
     cu.run(oracle_bin, args(ora))
     env = dict(os.environ, GANON_DEVICE_BUDGET="2800000", GANON_HOST_TIMING="1", GANON_HOST_BATCH_READS="3000")
-    p = subprocess.run([cu.BIN_HIP] + args(got) + ["--device", "0,0,0"], capture_output=True, text=True, env=env)
+    p = subprocess.run([cu.BIN_HIP] + args(got) + ["--device", "0,0,0"], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr
     assert "replicated on 1 device(s)" in p.stderr and "partitioned by bin range" in p.stderr, p.stderr
     _same(got, ora, EXTS + (".sta",))
@@ -106,5 +106,5 @@ def test_hibf_over_budget_is_refused(tmp_path):
     fq = str(tmp_path / "r.fq")
     gf.write_fastq(fq, [("r0", "ACGT" * 40)])
     p = subprocess.run([cu.BIN_HIP, "--ibf", path, "--hibf", "--single-reads", fq, "-o", str(tmp_path / "o"), "--quiet", "--device", "0,0"],
-                       capture_output=True, text=True, env=dict(os.environ, GANON_DEVICE_BUDGET="1000"))
+                       capture_output=True, text=True, env=dict(os.environ, GANON_DEVICE_BUDGET="1000"), timeout=900)
     assert p.returncode != 0 and "cannot be partitioned" in p.stderr, p.stderr

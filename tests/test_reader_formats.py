@@ -249,10 +249,10 @@ def _fastq_text(recs, wrap=0, crlf=False, blank_after=None):
     return "".join(out)
 
 
-def _run_reader_case(binary, ibf, files, out, paired, env):
-    args = ["--ibf", ibf, "-o", out, "--output-all", "--output-unclassified", "--rel-cutoff", "0.3", "--quiet"]
+def _run_reader_case(binary, ibf, files, out, paired, env, extra_args=()):
+    args = ["--ibf", ibf, "-o", out, "--output-all", "--output-unclassified", "--rel-cutoff", "0.3", "--quiet"] + list(extra_args)
     args += ["--paired-reads", ",".join(files)] if paired else ["--single-reads", files[0]]
-    p = subprocess.run([binary] + args, capture_output=True, text=True, env=dict(os.environ, **env))
+    p = subprocess.run([binary] + args, capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)  # (a hang fails the test)
     assert p.returncode == 0, p.stderr
     return p.stderr, {e: open(out + e, "rb").read() for e in (".all", ".unc", ".rep")}
 
@@ -293,6 +293,77 @@ def test_parallel_fastq_equals_sequential_reader(oracle_bin, sim_db, tmp_path, p
         assert par_out == seq_out, (variant, slab)
         assert ("Error parsing" in par_err) == ("Error parsing" in seq_err) == (variant in ("bad_letter", "mate_bad"))
     assert seq_out[".all"].count(b"\n") > 100
+
+
+RAW_VARIANTS = ["plain", "crlf", "wrapped", "blank_line", "bad_letter", "no_final_newline", "truncated", "cr_letters", "empty_reads", "tiny_records"]
+
+
+def _raw_case_file(variant, sim_db, tmp_path):
+    import numpy as np
+    rng = np.random.default_rng(23)
+    n = 4000
+    g = list(sim_db["targets"].values())
+    recs = []
+    for i in range(n):
+        src = g[i % len(g)] if i % 3 else "".join("ACGT"[x] for x in rng.integers(0, 4, size=400))
+        p = int(rng.integers(0, len(src) - 310))
+        L = int(rng.integers(40, 152)) if variant != "tiny_records" else int(rng.integers(0, 6))
+        if variant == "empty_reads" and i % 11 == 0:
+            L = 0
+        recs.append((f"read{i} extra words" if variant != "tiny_records" else f"{i}", src[p:p + L]))
+    if variant == "bad_letter":
+        recs[n // 2] = (recs[n // 2][0], recs[n // 2][1][:20] + "!" + recs[n // 2][1][21:])
+    kw = dict(crlf=variant == "crlf", wrap=40 if variant == "wrapped" else 0, blank_after=n // 4 if variant == "blank_line" else None)
+    text = _fastq_text(recs, **kw)
+    if variant == "no_final_newline":
+        text = text[:-1]
+    if variant == "truncated":
+        text = text[: len(text) * 2 // 3 + 17]
+    if variant == "cr_letters":
+        text = "".join(f"@{rid}\n{s}\r\n+\n{'I' * len(s)}\n" for rid, s in recs)
+    f1 = str(tmp_path / "r1.fq")
+    open(f1, "w", newline="").write(text)
+    return f1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", RAW_VARIANTS)
+def test_device_tokenised_fastq_equals_sequential_reader(oracle_bin, sim_db, tmp_path, variant):
+    """Uncompressed single-end FASTQ reaches the HIP backend as pieces of the file; the records are found on the device
+    (csrc/gn_fastq.hip) and the file's pieces are accepted in file order.  Output and messages are those of the sequential reader
+    (checker backend, one thread), of the host's slab parser, and do not depend on piece size or worker count."""
+    f1 = _raw_case_file(variant, sim_db, tmp_path)
+    seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / "seq"), False, {"GANON_HOST_PARSE_THREADS": "0"})
+    common = {"GANON_HOST_PARSE_THREADS": "3", "GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_TIMING": "1", "GANON_HOST_DEVICE_FASTQ": "1"}
+    for slab, extra in (("65536", ()), ("200000", ("--device", "0")), ("1048576", ("--device", "0,0"))):
+        err, out = _run_reader_case(cu.BIN_HIP, sim_db["ibf"], [f1], str(tmp_path / ("dev" + slab)), False, dict(common, GANON_HOST_SLAB_BYTES=slab), extra)
+        assert out == seq_out, (variant, slab)
+        assert ("Error parsing" in err) == ("Error parsing" in seq_err)
+        assert "pieces of FASTQ text tokenised on the device" in err, err[-600:]
+    # ... and with the host's slab parser instead
+    err, out = _run_reader_case(cu.BIN_HIP, sim_db["ibf"], [f1], str(tmp_path / "host"), False,
+                                dict(common, GANON_HOST_SLAB_BYTES="65536", GANON_HOST_DEVICE_FASTQ="0"))
+    assert out == seq_out and "tokenised on the device" not in err
+    if variant in ("plain", "cr_letters", "empty_reads"):
+        assert seq_out[".all"].count(b"\n") > 300
+
+
+@pytest.mark.parametrize("variant", RAW_VARIANTS)
+def test_raw_pieces_and_worker_lanes_with_the_checker_backend(oracle_bin, sim_db, tmp_path, variant):
+    """The host side of the same machinery without a GPU: the checker backend finds the records of raw pieces by the slab parser's
+    rule and offers twin contexts, so the reader's raw mode, the in-file-order acceptance of pieces (a piece that is not records
+    from end to end stops its file, later pieces are dropped, the sequential reader goes on there) and the worker threads' lanes
+    run here with many small batches and several workers -- same bytes as the sequential reader, and no run may hang."""
+    f1 = _raw_case_file(variant, sim_db, tmp_path)
+    seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / "seq"), False, {"GANON_HOST_PARSE_THREADS": "0"})
+    for raw, lanes, slab, dev in (("1", "2", "65536", "0,0,0"), ("1", "3", "70000", "0,0"), ("1", "1", "200000", "0"), ("0", "2", "65536", "0,0,0,0"),
+                                  ("0", "3", "65536", "0")):
+        env = {"GANON_HOST_PARSE_THREADS": "3", "GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_TIMING": "1", "GANON_HOST_DEVICE_FASTQ": raw,
+               "GANON_HOST_LANES": lanes, "GANON_HOST_SLAB_BYTES": slab, "GANON_HOST_BATCH_READS": "97", "GANON_HOST_POST_THREADS": "2"}
+        err, out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / f"o{raw}{lanes}{slab}"), False, env, ("--device", dev))
+        assert out == seq_out, (variant, raw, lanes, slab, dev)
+        assert ("Error parsing" in err) == ("Error parsing" in seq_err)
+        assert ("tokenised on the device" in err) == (raw == "1"), err[-400:]
 
 
 def _fasta_text(recs, variant):

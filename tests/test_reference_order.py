@@ -23,7 +23,7 @@ def tap():
     exe = os.path.join(HERE, "host_oracle", "robin_check")
 
     def ask(text: str):
-        p = subprocess.run([exe], input=text, capture_output=True, text=True, check=True)
+        p = subprocess.run([exe], input=text, capture_output=True, text=True, check=True, timeout=900)
         return p.stdout.splitlines()
     return ask
 
@@ -163,7 +163,7 @@ def test_pipeline_follows_the_replayed_maps(oracle_bin, sim_db, tmp_path):
     # the order is a property of the input, not of how the pipeline cut it into batches or how many device workers ran
     for tag, env, dev in (("b7", {"GANON_HOST_BATCH_READS": "7"}, "0"), ("w3", {"GANON_HOST_BATCH_READS": "11"}, "0,0,0")):
         p = subprocess.run([oracle_bin] + base + ["-o", out + tag, "--reference-order", "--threads", "1", "--device", dev],
-                           capture_output=True, text=True, env=dict(os.environ, **env))
+                           capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
         assert p.returncode == 0, p.stderr
         for ext in (".all", ".rep", ".unc"):
             assert open(out + tag + ext, "rb").read() == open(out + ext, "rb").read(), (tag, ext)
