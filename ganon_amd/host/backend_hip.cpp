@@ -69,11 +69,20 @@ public:
     }
     // from here on batches are on the device: a block locked now stalls them ($GANON_HOST_TIMING reports how many were)
     void mark_running() { running_ = true; }
-    std::string tally() const
+    std::string tally()
     {
+        std::lock_guard<std::mutex> lk(m_);
         std::ostringstream os;
         os << "page-locked on demand before the first batch: " << early_.n << " blocks, " << (early_.bytes >> 20) << " MiB, " << early_.sec
-           << " s; after it: " << late_.n << " blocks, " << (late_.bytes >> 20) << " MiB, " << late_.sec << " s";
+           << " s; after it: " << late_.n << " blocks, " << (late_.bytes >> 20) << " MiB, " << late_.sec << " s; blocks per size (MiB: all / free now)";
+        std::map<size_t, size_t> all;
+        for (auto const& kv : size_of_)
+            all[kv.second]++;
+        for (auto const& kv : all)
+        {
+            auto it = free_.find(kv.first);
+            os << ' ' << (kv.first >> 20) << ": " << kv.second << " / " << (it == free_.end() ? 0 : it->second.size());
+        }
         return os.str();
     }
     void give(void* p)
@@ -651,16 +660,15 @@ public:
 
     std::string placement() const override { return index_ ? std::string() : set_->placement(); }
 
-    // Uncompressed FASTQ as text, records found on the device (csrc/gn_fastq.hip)?  It takes the parse -- the largest share of the
+    // Uncompressed FASTQ as text, records found on the device (csrc/gn_fastq.hip): it takes the parse -- the largest share of the
     // host's CPU seconds -- off the host and costs 2.1x the bytes over the link.  Measured on one MI355X behind a 16-core host
-    // (DESIGN 7-5): the link-bound device side delivers 151-157 Mreads/s on its own, the whole binary 85-100 against 97-117 with
-    // the host's slab parser -- one GPU is better off with the parser.  Several GPUs have a link each but share the host's cores:
-    // there the text goes to the devices.  $GANON_HOST_DEVICE_FASTQ=1 / 0 decides by hand.
+    // (DESIGN 7-5): the link-bound device side alone delivers 151-157 Mreads/s, the whole binary 125-130 against 109-116 with the
+    // host's slab parser on its default 8 threads (134 on 12), for 5 instead of 7.5 CPU seconds per 64 M reads.  Several GPUs have
+    // a link each but share the host's cores: there it matters more.  $GANON_HOST_DEVICE_FASTQ=0 keeps the parse on the host.
     bool tokenises_fastq() const override
     {
-        if (const char* e = std::getenv("GANON_HOST_DEVICE_FASTQ"))
-            return e[0] == '1';
-        return set_->n_devices() >= 2;
+        const char* e = std::getenv("GANON_HOST_DEVICE_FASTQ");
+        return !(e && e[0] == '0');
     }
 
     // Raw batch: the text goes to the first stream of every device the level's filters live on (the stream that takes a parsed
@@ -1017,7 +1025,7 @@ public:
             // is in flight behind the queue (device contexts, post pool, writer) needs blocks of its own.  Locking a block while
             // batches are on the device stalls ALL device work for its duration (50 ms holes in the device timeline of the first
             // hundred milliseconds, profiles/r03_e2e_timeline.txt): every block is locked before the first batch.
-            PinnedPool::get().reserve(tokenises_fastq() ? hint_bases_ : hint_bases_ / 2 + (1u << 20), 5);
+            PinnedPool::get().reserve(tokenises_fastq() ? hint_bases_ : hint_bases_ / 2 + (1u << 20), 3);
         }
         // (the per-read arrays of the results are sized by the first real batch: classify_end)
         warmed_ = true;

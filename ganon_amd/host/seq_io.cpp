@@ -890,7 +890,8 @@ struct ParallelFastq::Impl
     void parse(RangeLines& in, size_t begin, size_t end, Slab& out) const
     {
         out.ids.reserve((end - begin) / 8);
-        const size_t expect = fasta ? (end - begin) + 4096 : (end - begin) / 2; // bases of this slab, roughly
+        // bases of this slab, roughly -- by the slab size, not by this slab's few bytes more or less: the buffers are page-locked blocks that go round
+        const size_t expect = fasta ? std::max(end - begin, slab_bytes) + 4096 : std::max((end - begin) / 2, slab_bytes / 2 + slab_bytes / 32 + 65536);
         out.bases.reserve(mate_room ? 2 * expect + expect / 8 : expect);
         out.rec_at.reserve((end - begin) / 256);
         if (fasta)
@@ -959,6 +960,9 @@ struct ParallelFastq::Impl
     void read_text(size_t begin, size_t end, Slab& out) const
     {
         out.text_at = begin;
+        // (one capacity for every piece: the buffers are page-locked blocks that go round -- a piece a few bytes longer than the last
+        //  must not need a block of another size)
+        out.text.reserve(std::max(end - begin, slab_bytes + slab_bytes / 16 + 65536));
         out.text.resize(end - begin);
         size_t got = 0;
         while (got < end - begin)

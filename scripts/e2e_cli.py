@@ -105,10 +105,18 @@ if os.environ.get("E2E_HIBF"):  # a two-level raptor-style HIBF (4096 user bins)
     gf.write_hibf(ibf, hb, [[f"/x/U{u}.minimiser"] for u in range(4096)], wl.k, wl.w, 0.05)
     EXTRA = EXTRA + ["--hibf"]
     out["hibf"] = {"user_bins": 4096, "file_mib": round(os.path.getsize(ibf) / 2**20, 1), "built_s": round(time.time() - t0, 1)}
+# (the first reader of a file numpy has just written pays for it: 10 s of system time on 19 GiB in /dev/shm; a reader, then the runs)
+for path in READS[1].split(","):
+    with open(path, "rb") as fh:
+        while fh.read(1 << 26):
+            pass
 exe = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
 runs = [("one_worker", "0", None), ("two_workers_one_gpu", "0,0", None), ("three_workers_one_gpu", "0,0,0", None), ("default_no_device_flag", None, None)]
 if os.environ.get("E2E_GZ"):  # ... and with the parallel inflate switched off (one zlib stream, as before) / other thread counts
     runs += [("gz_sequential_inflate", "0,0", "seq"), ("gz_inflate_8", "0,0", "i8"), ("gz_inflate_12", "0,0", "i12"), ("gz_inflate_24", "0,0", "i24")]
+if not (os.environ.get("E2E_GZ") or os.environ.get("E2E_FASTA") or os.environ.get("E2E_PAIRED")):
+    # the same file parsed on the host (slab parsers) instead of tokenised on the device, on 8 and on 12 parser threads; one context per worker
+    runs += [("host_slab_parser", None, "h8"), ("host_slab_parser_12_threads", None, "h12"), ("one_lane_per_worker", None, "l1")]
 if os.environ.get("E2E_SWEEP"):  # parser threads x device workers, to see which stage limits the pipeline on this host
     runs += [(f"sweep_parse{pt}_workers{len(dev.split(','))}", dev, pt) for pt in (4, 6, 8, 10, 12) for dev in ("0", "0,0", "0,0,0")]
 for label, dev, parse_threads in runs:
@@ -117,6 +125,11 @@ for label, dev, parse_threads in runs:
     env = dict(os.environ, GANON_HOST_TIMING="1")
     if parse_threads == "seq":
         env["GANON_HOST_NO_PGZIP"] = "1"
+    elif isinstance(parse_threads, str) and parse_threads.startswith("h"):
+        env["GANON_HOST_DEVICE_FASTQ"] = "0"
+        env["GANON_HOST_PARSE_THREADS"] = parse_threads[1:]
+    elif parse_threads == "l1":
+        env["GANON_HOST_LANES"] = "1"
     elif isinstance(parse_threads, str) and parse_threads.startswith("i"):
         env["GANON_HOST_INFLATE_THREADS"] = parse_threads[1:]
     elif parse_threads:
@@ -142,6 +155,10 @@ for label, dev, parse_threads in runs:
     m = re.search(r"\[host stalls\] (.*)", p.stderr)
     if m:
         r["host_stalls"] = m.group(1)
+    for key in ("host cpu", "host input", "host pipeline", "pinned pool"):
+        m = re.search(r"\[" + key + r"\] (.*)", p.stderr)
+        if m:
+            r[key.replace(" ", "_")] = m.group(1)
     if "classify_print_s" in r:
         r["mreads_per_s_classify_print"] = round(n / r["classify_print_s"] / 1e6, 2)
     if p.returncode == 0 and parse_threads is None:

@@ -19,6 +19,6 @@ for rep in 1 2 3; do
 run "host slab parser (default)" --
 run "device tokeniser" GANON_HOST_DEVICE_FASTQ=1 --
 done
-run "host slab parser, 1 lane" GANON_HOST_LANES=1 --
 run "host slab parser, 12 parsers" GANON_HOST_PARSE_THREADS=12 --
 run "host slab parser, no pre-pass" GANON_HOST_NO_PREFILTER=1 --
+run "device tokeniser, no pre-pass" GANON_HOST_DEVICE_FASTQ=1 GANON_HOST_NO_PREFILTER=1 --
