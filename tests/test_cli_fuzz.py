@@ -121,9 +121,18 @@ def test_random_hierarchies_hip_equals_oracle_backend(oracle_bin, world, tmp_pat
         args += ["--hibf"]
     args += ["--output-all", "--output-lca", "--output-unclassified", "--output-stats", "--quiet"]
     outs = {}
-    for tag, binary, env in (("hip", cu.BIN_HIP, None), ("host_only", cu.BIN_HIP, "1"), ("oracle", oracle_bin, None)):
+    # "pieces": the same command line with the input cut into many small pieces -- uncompressed single-end FASTQ then reaches the
+    # device as text (records found there, pieces accepted in file order), everything else goes through the slab parsers, and
+    # every worker thread keeps two batches in flight
+    pieces = {"GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_SLAB_BYTES": "65536", "GANON_HOST_PARSE_THREADS": "3", "GANON_HOST_BATCH_READS": "211"}
+    for tag, binary, env in (("hip", cu.BIN_HIP, None), ("host_only", cu.BIN_HIP, "1"), ("pieces", cu.BIN_HIP, None), ("oracle", oracle_bin, None)):
         d = tmp_path / tag
         d.mkdir()
+        for k_, v_ in pieces.items():
+            if tag == "pieces":
+                monkeypatch.setenv(k_, v_)
+            else:
+                monkeypatch.delenv(k_, raising=False)
         if env:
             monkeypatch.setenv("GANON_HOST_NO_PREFILTER", env)
         else:
@@ -137,8 +146,9 @@ def test_random_hierarchies_hip_equals_oracle_backend(oracle_bin, world, tmp_pat
             kind = "disjoint" if disjoint else "shared between filters"
             assert f"pre-pass on the device on ({n_f} filter(s), targets {kind})" in p.stderr, p.stderr[-500:]
         outs[tag] = {f: open(d / f, "rb").read() for f in sorted(os.listdir(d))}
-    assert list(outs["hip"]) == list(outs["oracle"]) == list(outs["host_only"]) and len(outs["hip"]) >= 2
+    assert list(outs["hip"]) == list(outs["oracle"]) == list(outs["host_only"]) == list(outs["pieces"]) and len(outs["hip"]) >= 2
     for f in outs["hip"]:
         assert outs["hip"][f] == outs["oracle"][f], (seed, f, args)
         assert outs["hip"][f] == outs["host_only"][f], (seed, f, args)
+        assert outs["pieces"][f] == outs["oracle"][f], (seed, f, args)
     assert any(len(v) > 0 for f, v in outs["hip"].items() if f.endswith(".all") or ".all" in f or f.endswith(".rep"))
