@@ -544,8 +544,15 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     auto                tracker = std::make_shared<RawFileTracker>();
                     size_t              pieces  = 0;
                     ParallelFastq::Slab a;
+                    bool                gave_up = false; // the slab readers do not take the piece at gave_up_at (and nothing behind it)
+                    uint64_t            gave_up_at = 0;
                     while (pfr->next(a))
                     {
+                        if (a.irregular)
+                        {
+                            gave_up    = true;
+                            gave_up_at = a.resume_at;
+                        }
                         if (!a.text.empty())
                         {
                             rb.raw = true;
@@ -563,13 +570,23 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     // every piece is records from end to end: done.  Otherwise the sequential reader goes on at the first byte that is
                     // not (a wrapped or damaged record, a last line without its newline, ...) -- pieces behind it were dropped.
                     uint64_t at = 0;
-                    if (tracker->wait_all(pieces, at) || at == UINT64_MAX) // (UINT64_MAX: the pipeline is going down)
-                        file_done = true;
-                    else
+                    if (!tracker->wait_all(pieces, at))
                     {
-                        resume1  = at;
+                        if (at == UINT64_MAX) // (the pipeline is going down)
+                            file_done = true;
+                        else
+                        {
+                            resume1  = at;
+                            fallback = true;
+                        }
+                    }
+                    else if (gave_up)
+                    {
+                        resume1  = gave_up_at;
                         fallback = true;
                     }
+                    else
+                        file_done = true;
                 }
             }
             if (!file_done && !fallback)

@@ -1017,7 +1017,13 @@ struct ParallelFastq::Impl
                 //  first byte, so this slab is the last, and empty)
                 last = gz && b >= end_size();
                 const size_t e = (!gz && i + 1 == n_slabs) || last ? end_size() : record_at_or_after(in, (i + 1) * slab_bytes);
-                if (b < e && raw)
+                if (b < e && raw && e - b >= (3ull << 30))
+                {
+                    // (a record of gigabytes: offsets inside a piece are 32 bits wide -- the sequential reader's case)
+                    s.irregular = true;
+                    s.resume_at = b;
+                }
+                else if (b < e && raw)
                     read_text(b, e, s);
                 else if (b < e)
                     parse(in, b, e, s);
