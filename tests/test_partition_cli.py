@@ -45,13 +45,18 @@ def test_filter_over_budget_is_partitioned_and_changes_no_output_byte(oracle_bin
     spread = {"GANON_DEVICE_BUDGET": "2500000", "GANON_HOST_TIMING": "1"}
     for name, devs, env in (("three", "0,0,0", {}), ("four", "0,0,0,0", {}), ("copies", "0,0,0", {"GANON_HIP_GATHER_COPY": "1"}),
                             ("batches", "0,0,0", {"GANON_HOST_BATCH_READS": "37"}),
-                            ("one_worker", "0,0,0", {"GANON_PARTITION_WORKERS": "1", "GANON_HOST_BATCH_READS": "100"})):
+                            ("one_worker", "0,0,0", {"GANON_PARTITION_WORKERS": "1", "GANON_HOST_BATCH_READS": "100"}),
+                            # the reads as pieces of FASTQ text, records found on the device (the part that takes a batch takes the text)
+                            ("text", "0,0,0", {"GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_SLAB_BYTES": "65536", "GANON_HOST_PARSE_THREADS": "3"}),
+                            ("parsed", "0,0,0", {"GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_SLAB_BYTES": "65536", "GANON_HOST_PARSE_THREADS": "3",
+                                                 "GANON_HOST_DEVICE_FASTQ": "0"})):
         out = str(tmp_path / name)
         p = _run(cu.BIN_HIP, wide_db, out, ["--device", devs], dict(spread, **env))
         assert "partitioned by bin range" in p.stderr and p.stderr.count("-> device 0") == len(devs.split(",")), p.stderr
         _same(out, whole)
         if "GANON_HIP_GATHER_COPY" in env:
             assert "moved between devices" in p.stderr
+        assert ("tokenised on the device" in p.stderr) == (name == "text"), p.stderr[-500:]
     # without the budget the same command line replicates (one copy: the entries name one GPU)
     p = _run(cu.BIN_HIP, wide_db, str(tmp_path / "repl"), ["--device", "0,0,0"], {"GANON_HOST_TIMING": "1"})
     assert "replicated on 1 device(s)" in p.stderr and "partitioned" not in p.stderr
