@@ -880,6 +880,7 @@ extern "C" int gn_stream_upload_reads(gn_stream* s, const uint8_t* bases, uint64
     s->paired     = off2 != nullptr;
     s->have_reads = true;
     s->classified = false;
+    s->ctr_copied = false;
     s->hashed     = false;
     s->build_distinct = ~0ull;
     return GN_OK;
@@ -1110,6 +1111,9 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
         p.work_list  = s->d_deferred;
         p.work_count = s->d_ctr + 4;
     }
+    if ((fast || split) && s->prev_count_deferred != ~0ull && lo == 0 && hi == s->n_reads && !getenv("GANON_HIP_FULL_DEFERRED_GRIDS"))
+        // the generic kernel only takes what the fast / split kernel deferred: a grid for twice the last batch's list (one block per read)
+        p.max_blocks = (uint32_t)std::min<uint64_t>(p.max_blocks, std::max<uint64_t>((uint64_t)f->n_cu, s->prev_count_deferred * 2));
     GN_HIP(gn_launch_count(p, f->geom, f->ibf.h, s->st));
     if (s->long_reads) // reads the kernels above skipped as GN_READ_BIG: 32-bit counters, one workgroup each
     {
@@ -1189,6 +1193,7 @@ static int gn_run_minimisers_range(gn_stream* s, uint32_t lo, uint32_t hi, hipSt
     mp.status       = s->d_status;
     mp.total_hashes = s->d_ctr + 8; // 64 shards
     mp.force_generic = getenv("GANON_HIP_MINIMISER_GENERIC") ? 1u : 0u;
+    mp.work_hint     = ~0u;
     if (w - k + 1 <= 65 && !mp.force_generic && !getenv("GANON_HIP_NO_LPR"))
     {
         // short reads: lane-per-read kernel; longer ones are deferred to the wave-per-read kernel below
@@ -1200,6 +1205,8 @@ static int gn_run_minimisers_range(gn_stream* s, uint32_t lo, uint32_t hi, hipSt
         GN_HIP(gn_launch_minimiser_lpr(mp, st));
         mp.work_list  = s->d_mdeferred;
         mp.work_count = s->d_ctr + 5;
+        if (s->prev_min_deferred != ~0ull && lo == 0 && hi == s->n_reads && !getenv("GANON_HIP_FULL_DEFERRED_GRIDS"))
+            mp.work_hint = (uint32_t)std::min<uint64_t>(s->prev_min_deferred * 2, 0x7FFFFFFFull); // (twice what the last batch deferred)
     }
     GN_HIP(gn_launch_minimiser(mp, f->n_cu, st));
     return GN_OK;
@@ -1298,6 +1305,7 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
         return rc;
     GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
     GN_HIP(hipEventRecord(s->ev[3], s->st));
+    s->ctr_copied = true;
     s->n_chunks   = nc;
     s->classified = true;
     s->pf_joint_done = false;
@@ -1366,6 +1374,7 @@ extern "C" int gn_stream_classify_shared(gn_stream* s, gn_stream* source, double
         return rc;
     GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
     GN_HIP(hipEventRecord(s->ev[3], s->st));
+    s->ctr_copied    = true;
     s->n_chunks      = 1;
     s->classified    = true;
     s->pf_joint_done = false;
@@ -1381,8 +1390,11 @@ static int gn_finish(gn_stream* s)
     for (int attempt = 0; attempt < 4; ++attempt)
     {
         GN_HIP(hipStreamSynchronize(s->st));
-        // blocking read-back of the counters (the async copy into h_ctr is only used for timing-free fast paths)
-        GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        // the counters were copied to pinned memory behind the batch's last kernel; only a joint pre-pass, which runs after that
+        // copy was queued, makes a second read-back necessary
+        const bool stale = !s->ctr_copied || (s->pf_joint && s->pf_joint_done);
+        if (stale)
+            GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         const uint64_t need = s->h_ctr[0];
         if (getenv("GANON_HIP_DEBUG"))
             fprintf(stderr, "[gn_finish] attempt %d need %llu cap %llu nh %llu\n", attempt, (unsigned long long)need,
@@ -1392,8 +1404,15 @@ static int gn_finish(gn_stream* s)
             s->n_matches = s->h_ctr[6]; // exact (the cursor `need` counts allocated space including chunk holes)
             if (s->pf_on && (!s->pf_joint || s->pf_joint_done)) // the batch's result is what the device-side filter_matches pre-pass left
             {
-                GN_HIP(hipMemcpy(s->h_pf_ctr, s->d_pf_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                if (stale)
+                    GN_HIP(hipMemcpy(s->h_pf_ctr, s->d_pf_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
                 s->n_matches = s->h_pf_ctr[2];
+            }
+            if (!s->f->is_hibf)
+            {
+                s->prev_count_deferred = s->h_ctr[4];
+                if (!s->src)
+                    s->prev_min_deferred = s->h_ctr[5];
             }
             return GN_OK;
         }
@@ -1429,6 +1448,7 @@ static int gn_finish(gn_stream* s)
         if (rc)
             return rc;
         GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
+        s->ctr_copied = true;
     }
     return gn_fail(GN_ENODEV, "match buffer kept overflowing");
 }

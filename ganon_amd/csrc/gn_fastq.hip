@@ -289,6 +289,7 @@ extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_
     s->fq_bytes   = n_bytes;
     s->have_reads = false;
     s->classified = false;
+    s->ctr_copied = false;
     s->hashed     = false;
     return GN_OK;
 }

@@ -42,6 +42,7 @@ struct GnMinimiserParams
     unsigned long long*       defer_count;
     const uint32_t*           work_list;  // nullptr = every read
     const unsigned long long* work_count;
+    uint32_t                  work_hint;  // launch only: reads the previous batch's list held (~0u: unknown -> full grid)
 };
 
 hipError_t gn_launch_minimiser_lpr(const GnMinimiserParams& p, hipStream_t st);
@@ -342,6 +343,10 @@ struct gn_stream
     uint64_t n_bases = 0;
     bool     paired  = false;
     bool     have_reads = false, classified = false, hashed = false;
+    bool     ctr_copied = false; // the batch's counters are on their way to h_ctr / h_pf_ctr (queued behind its last kernel)
+    // reads the previous batch left to the deferred launches (count stage, minimiser stage): their lists are usually empty and a
+    // chip-filling persistent grid that finds nothing costs 0.1-0.2 ms per launch; ~0: unknown
+    uint64_t prev_count_deferred = ~0ull, prev_min_deferred = ~0ull;
     uint32_t k = 0, w = 0;
     double   rel_cutoff = 0;
     uint64_t n_matches = 0;

@@ -380,7 +380,9 @@ hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t
     const uint32_t per_wave = fastp ? 128u * 8u : (GN_WAVE + K) * 8 + ((GN_WAVE + p.w + 15) & ~15u);
     const size_t   lds      = (size_t)per_wave * 4;
     uint32_t       blocks   = (p.n_reads - p.read_begin + 3) / 4;
-    const uint32_t cap      = (uint32_t)n_cu * 16;
+    uint32_t       cap      = (uint32_t)n_cu * 16;
+    if (p.work_list && p.work_hint != ~0u) // a deferred list that is usually empty: a grid for about as many reads as the last batch left
+        cap = std::min<uint32_t>(cap, std::max<uint32_t>((uint32_t)n_cu, p.work_hint / 2 + 1));
     if (blocks > cap)
         blocks = cap;
     hipLaunchKernelGGL(gn_minimiser_kernel, dim3(blocks), dim3(256), lds, st, p);

@@ -15,10 +15,8 @@ run() { # label, env..., -- args
   echo "$label: classify+print $t s = $(python -c "print(round($N/$t/1e6,1))") Mreads/s"
   echo "$out" | grep -E "host stalls|backend timing|host cpu|host timing|host input|host pipeline|hip call|pinned pool|ERROR|rror" | sed 's/^/      /' | cut -c1-420
 }
-for rep in 1 2 3; do
-run "host slab parser (default)" --
-run "device tokeniser" GANON_HOST_DEVICE_FASTQ=1 --
+for rep in 1 2; do
+run "device tokeniser (default)" --
+run "device tokeniser, full deferred grids" GANON_HIP_FULL_DEFERRED_GRIDS=1 --
+run "host slab parser" GANON_HOST_DEVICE_FASTQ=0 --
 done
-run "host slab parser, 12 parsers" GANON_HOST_PARSE_THREADS=12 --
-run "host slab parser, no pre-pass" GANON_HOST_NO_PREFILTER=1 --
-run "device tokeniser, no pre-pass" GANON_HOST_DEVICE_FASTQ=1 GANON_HOST_NO_PREFILTER=1 --
