@@ -58,11 +58,13 @@ public:
         return first_stop_ >= idx;
     }
     // the reader, after the file's last piece: waits for all `count` pieces; false when one stopped the file (then resume_at)
-    bool wait_all(size_t count, uint64_t& resume_at)
+    bool wait_all(size_t count, uint64_t& resume_at, size_t* stopped_by = nullptr)
     {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return published_ >= count; });
         resume_at = resume_at_;
+        if (stopped_by)
+            *stopped_by = first_stop_;
         return first_stop_ == SIZE_MAX;
     }
 

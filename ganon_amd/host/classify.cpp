@@ -96,6 +96,12 @@ public:
         not_full_.notify_one();
         return true;
     }
+    size_t size()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        return q_.size();
+    }
+    size_t capacity() const { return cap_; }
     // 1 = got one, 0 = nothing there right now, -1 = the producer is done and nothing is left
     int try_pop(T& b)
     {
@@ -539,20 +545,23 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             // ---- raw pieces: the backend finds the records (single-end, uncompressed four-line FASTQ) ------------------------
             if (raw_fastq && !paired)
             {
-                if (auto pfr = ParallelFastq::open(pair.mate1, std::min(par_threads, 6u), slab_bytes, par_min, false, true)) // (six readers copy faster than the link takes)
+                // Text for the device, or parsed here after all?  With $GANON_HOST_HYBRID=1 a slab reader that finds the batch queue full
+                // (the device side is not keeping up with the text: the link is its limit) parses its slab instead of waiting -- half
+                // the bytes for the link, paid with cores that had nothing to do.  Measured: 101-115 Mreads/s against 120-130 with text
+                // only on the same box (profiles/r03_e2e_ab_tokeniser.txt) -- the cores are not idle enough; off by default.
+                std::function<bool()> slack;
+                if (env_size("GANON_HOST_HYBRID", 0))
+                    slack = [&queue] { return queue.size() + 1 >= queue.capacity(); };
+                if (auto pfr = ParallelFastq::open(pair.mate1, slack ? par_threads : std::min(par_threads, 6u), slab_bytes, par_min, false, true, slack))
                 {
                     auto                tracker = std::make_shared<RawFileTracker>();
                     size_t              pieces  = 0;
                     ParallelFastq::Slab a;
                     bool                gave_up = false; // the slab readers do not take the piece at gave_up_at (and nothing behind it)
                     uint64_t            gave_up_at = 0;
+                    std::map<size_t, std::string> errors; // piece -> the ParseError that ended it (a piece parsed here)
                     while (pfr->next(a))
                     {
-                        if (a.irregular)
-                        {
-                            gave_up    = true;
-                            gave_up_at = a.resume_at;
-                        }
                         if (!a.text.empty())
                         {
                             rb.raw = true;
@@ -564,16 +573,46 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                             copier.deliver(std::move(rb)); // (input is counted by the worker, once the records are known)
                             fresh();
                         }
+                        else if (a.size() != 0 || !a.error.empty() || (a.irregular && !a.rec_at.empty()))
+                        {
+                            // a piece parsed here: its records are a batch like the host parser's, but it has its place among the file's
+                            // pieces -- it says right away whether it is records from end to end, and is dropped with the others if a
+                            // piece before it was not
+                            rb.id_buf.swap(a.ids);
+                            rb.id_off.swap(a.id_off);
+                            rb.bases.swap(a.bases);
+                            rb.off1.swap(a.off);
+                            rb.ticket.reset(new RawTicket{ tracker, pieces });
+                            if (!a.error.empty())
+                                errors[pieces] = a.error;
+                            const bool whole = a.error.empty() && !a.irregular;
+                            rb.ticket->publish(whole, a.irregular ? a.resume_at : (a.rec_at.empty() ? 0 : a.rec_at.back()));
+                            ++pieces;
+                            rb.seq = seq++;
+                            copier.deliver(std::move(rb));
+                            fresh();
+                        }
+                        else if (a.irregular) // (the slab readers do not take this piece at all)
+                        {
+                            gave_up    = true;
+                            gave_up_at = a.resume_at;
+                        }
                         pfr->recycle(std::move(a));
                         a = ParallelFastq::Slab();
                     }
                     // every piece is records from end to end: done.  Otherwise the sequential reader goes on at the first byte that is
                     // not (a wrapped or damaged record, a last line without its newline, ...) -- pieces behind it were dropped.
                     uint64_t at = 0;
-                    if (!tracker->wait_all(pieces, at))
+                    size_t   stopped_by = 0;
+                    if (!tracker->wait_all(pieces, at, &stopped_by))
                     {
                         if (at == UINT64_MAX) // (the pipeline is going down)
                             file_done = true;
+                        else if (errors.count(stopped_by)) // a piece parsed here ended with a parse error: the file ends there (:1278-1283)
+                        {
+                            report_error(errors[stopped_by]);
+                            file_done = true;
+                        }
                         else
                         {
                             resume1  = at;
@@ -1119,7 +1158,7 @@ static bool ganon_classify(Config config)
         // target names they also replay the level's merge (the larger count wins, :531-537) and hand over the winners
         bool shared_targets = false;
         std::atomic<uint64_t> diag_unmerged{ 0 }, diag_fpr_evals{ 0 }; // (GANON_HOST_TIMING: what was left to the host)
-        std::atomic<uint64_t> diag_raw_pieces{ 0 }, diag_raw_reads{ 0 }, diag_raw_void{ 0 };
+        std::atomic<uint64_t> diag_raw_pieces{ 0 }, diag_raw_reads{ 0 }, diag_raw_void{ 0 }, diag_parsed_pieces{ 0 };
         {
             PostFilterSpec spec;
             spec.rel_filter = level.rel_filter;
@@ -1584,15 +1623,19 @@ static bool ganon_classify(Config config)
                         if (!timed([&] { return x.be->classify_end(x.cb.rb, level.kmer_size, level.window_size, rel_cutoffs, x.cb.res, e); }))
                             return fail(e);
                         ReadBatch& rb = x.cb.rb;
-                        if (rb.raw && rb.ticket)
+                        if (rb.ticket) // a piece of a file whose pieces are accepted in file order (text for the device, or parsed by a slab reader)
                         {
-                            const uint32_t n = rb.raw_keep;
+                            const size_t n = rb.size();
                             if (!rb.ticket->tracker->wait_prefix(rb.ticket->idx)) // a piece before this one stopped the file: none of this is input
                             {
                                 rb.raw_keep = 0;
                                 rb.rec_at.clear();
                                 rb.seq_at.clear();
                                 rb.seq_len.clear();
+                                rb.id_buf.clear();
+                                rb.id_off.assign(1, 0);
+                                rb.bases.clear();
+                                rb.off1.assign(1, 0);
                                 x.cb.res.n_hashes.clear();
                                 x.cb.res.status.clear();
                                 x.cb.res.max_count.clear();
@@ -1605,13 +1648,13 @@ static bool ganon_classify(Config config)
                                     fr.fpr_ok.clear();
                                 }
                             }
-                            diag_raw_pieces++;
-                            diag_raw_reads += rb.raw_keep;
-                            diag_raw_void += rb.raw_keep == n ? 0 : 1;
-                            if (rb.raw_keep)
+                            (rb.raw ? diag_raw_pieces : diag_parsed_pieces)++;
+                            diag_raw_reads += rb.raw ? rb.size() : 0;
+                            diag_raw_void += rb.size() == n ? 0 : 1;
+                            if (rb.size())
                             {
                                 std::lock_guard<std::mutex> lk(report_mutex);
-                                report.count_input(rb.prefix, rb.raw_keep); // :1253,1272
+                                report.count_input(rb.prefix, rb.size()); // :1253,1272
                             }
                         }
                         x.st = St::idle;
@@ -1758,7 +1801,8 @@ static bool ganon_classify(Config config)
             }
             if (std::getenv("GANON_HOST_TIMING") && diag_raw_pieces.load())
                 std::cerr << "[host input] level " << level.label << ": " << diag_raw_pieces.load() << " pieces of FASTQ text tokenised on the device ("
-                          << diag_raw_reads.load() << " reads), " << diag_raw_void.load() << " dropped behind a piece that stopped its file" << std::endl;
+                          << diag_raw_reads.load() << " reads), " << diag_parsed_pieces.load() << " parsed by the slab readers while the device side had text waiting, "
+                          << diag_raw_void.load() << " dropped behind a piece that stopped its file" << std::endl;
         }
         carried.swap(next_carried);
 

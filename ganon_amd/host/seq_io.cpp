@@ -782,6 +782,7 @@ struct ParallelFastq::Impl
     bool                     mate_room = false;
     bool                     fasta = false; // records start at lines that begin with '>' (no sequence line can: '>' is no legal letter)
     bool                     raw = false;   // slabs are delivered as text (Slab::text)
+    std::function<bool()>    want_parsed;   // raw mode: parse this slab here after all?
 
     // first byte of the first record at or after p (== size when there is none): a line that begins with '@' and whose
     // next-but-one line begins with '+'
@@ -891,7 +892,9 @@ struct ParallelFastq::Impl
     {
         out.ids.reserve((end - begin) / 8);
         // bases of this slab, roughly -- by the slab size, not by this slab's few bytes more or less: the buffers are page-locked blocks that go round
-        const size_t expect = fasta ? std::max(end - begin, slab_bytes) + 4096 : std::max((end - begin) / 2, slab_bytes / 2 + slab_bytes / 32 + 65536);
+        const size_t expect = fasta ? std::max(end - begin, slab_bytes) + 4096
+                              : raw ? std::max(end - begin, slab_bytes + slab_bytes / 16 + 65536) // (one size of page-locked block for text and bases)
+                                    : std::max((end - begin) / 2, slab_bytes / 2 + slab_bytes / 32 + 65536);
         out.bases.reserve(mate_room ? 2 * expect + expect / 8 : expect);
         out.rec_at.reserve((end - begin) / 256);
         if (fasta)
@@ -978,7 +981,7 @@ struct ParallelFastq::Impl
     void work()
     {
         // (raw slabs: the lines read here are the few around a slab's borders)
-        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get(), raw ? (64u << 10) : (4u << 20));
+        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get(), raw && !want_parsed ? (64u << 10) : (4u << 20));
         for (;;)
         {
             size_t i;
@@ -1023,7 +1026,7 @@ struct ParallelFastq::Impl
                     s.irregular = true;
                     s.resume_at = b;
                 }
-                else if (b < e && raw)
+                else if (b < e && raw && !(want_parsed && want_parsed()))
                     read_text(b, e, s);
                 else if (b < e)
                     parse(in, b, e, s);
@@ -1055,7 +1058,7 @@ struct ParallelFastq::Impl
 ParallelFastq::ParallelFastq(Impl* i) : impl_(i) {}
 
 std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
-                                                   bool mate_room, bool raw)
+                                                   bool mate_room, bool raw, std::function<bool()> want_parsed)
 {
     std::string base = path;
     bool        gz_name = false;
@@ -1121,6 +1124,7 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     im->mate_room  = mate_room;
     im->fasta      = fasta;
     im->raw        = raw;
+    im->want_parsed = raw ? std::move(want_parsed) : std::function<bool()>();
     if (gz)
     {
         gz->set_retain_limit((uint64_t)(im->window + 3) * im->slab_bytes);

@@ -13,10 +13,12 @@ run() { # label, env..., -- args
   out=$( env GANON_HOST_TIMING=1 "${envs[@]}" timeout 90 $EXE --ibf ${IBF:-$D/keep.ibf} --single-reads $D/keep.fq -o $D/ab_out ${NOOUT:+--quiet} $( [ -z "${NOOUT:-}" ] && echo --output-all ) --rel-cutoff 0.75 --verbose "$@" 2>&1 )
   t=$(echo "$out" | grep -o "classifying+printing elapsed (s): [0-9.e+-]*" | grep -o "[0-9.e+-]*$")
   echo "$label: classify+print $t s = $(python -c "print(round($N/$t/1e6,1))") Mreads/s"
-  echo "$out" | grep -E "host stalls|backend timing|host cpu|host timing|host input|host pipeline|hip call|pinned pool|ERROR|rror" | sed 's/^/      /' | cut -c1-420
+  echo "$out" | grep -E "host stalls|backend timing|host cpu|host timing|host input|host input|pinned pool|host cpu|ERROR|rror" | sed 's/^/      /' | cut -c1-420
 }
-for rep in 1 2; do
-run "device tokeniser (default)" --
-run "device tokeniser, full deferred grids" GANON_HIP_FULL_DEFERRED_GRIDS=1 --
+for rep in 1 2 3; do
+run "text + parse-when-slack (default)" --
+run "text only" GANON_HOST_HYBRID=0 --
 run "host slab parser" GANON_HOST_DEVICE_FASTQ=0 --
 done
+run "text + parse-when-slack, 12 threads" GANON_HOST_PARSE_THREADS=12 --
+run "text + parse-when-slack, 6 threads" GANON_HOST_PARSE_THREADS=6 --
