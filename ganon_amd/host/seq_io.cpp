@@ -970,7 +970,9 @@ struct ParallelFastq::Impl
         size_t got = 0;
         while (got < end - begin)
         {
-            const ssize_t k = ::pread(fd, out.text.data() + got, end - begin - got, (off_t)(begin + got));
+            // (a gzip file: bytes of the decompressed stream, which the inflate threads produce -- a damaged stream throws, see work())
+            const ssize_t k = gz ? (ssize_t)gz->pread(reinterpret_cast<char*>(out.text.data()) + got, end - begin - got, begin + got)
+                                 : ::pread(fd, out.text.data() + got, end - begin - got, (off_t)(begin + got));
             if (k <= 0)
                 break; // (the file shrank under us: what is there is delivered; the records end where the text ends)
             got += (size_t)k;
@@ -980,8 +982,9 @@ struct ParallelFastq::Impl
 
     void work()
     {
-        // (raw slabs: the lines read here are the few around a slab's borders)
-        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get(), raw && !want_parsed ? (64u << 10) : (4u << 20));
+        // (raw slabs of a plain file: the lines read here are the few around a slab's borders.  Of a gzip stream: the same read-ahead as
+        //  the parsing slabs have, so that a damaged stream ends the slabs at the same place whichever way they are delivered)
+        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get(), raw && !want_parsed && !gz ? (64u << 10) : (4u << 20));
         for (;;)
         {
             size_t i;
@@ -1043,6 +1046,7 @@ struct ParallelFastq::Impl
                 s.bases.clear();
                 s.off.assign(1, 0);
                 s.rec_at.clear();
+                s.text.clear();
                 s.irregular = true;
                 s.resume_at = have_b ? b : 0;
             }
@@ -1085,7 +1089,7 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     }
     const bool is_gzip = magic[0] == 0x1F && magic[1] == 0x8B;
     std::unique_ptr<ParallelGzip> gz;
-    if (raw && (is_gzip || fasta))
+    if (raw && fasta)
     {
         ::close(fd);
         return nullptr;
