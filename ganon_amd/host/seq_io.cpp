@@ -1089,7 +1089,10 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     }
     const bool is_gzip = magic[0] == 0x1F && magic[1] == 0x8B;
     std::unique_ptr<ParallelGzip> gz;
-    if (raw && fasta)
+    // (text for the device only from plain files.  An ordinary gzip file's decompressed stream can go the same way -- read_text and the
+    //  border search below take it -- but measured it is slower: 15-18 against 23-30 Mreads/s; the run is bound by the inflate threads,
+    //  which the parse does not hold up, and the raw mode's short window makes them pause)
+    if (raw && (is_gzip || fasta))
     {
         ::close(fd);
         return nullptr;

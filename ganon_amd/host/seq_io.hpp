@@ -70,7 +70,7 @@ public:
     // nullptr when the file is not eligible (compressed, not FASTQ by extension, smaller than min_bytes, cannot be mapped)
     // mate_room: the slabs' base buffers are reserved with room for as many bases again (the first file of a pair: the
     // mates are appended behind them when the slab becomes a batch -- without the room that append re-locks pages)
-    // raw: FASTQ (uncompressed, or ordinary gzip: the decompressed stream) -- the slabs are cut by the same rule but delivered as text (Slab::text), unparsed
+    // raw: uncompressed FASTQ only -- the slabs are cut by the same rule but delivered as text (Slab::text), unparsed
     // want_parsed (raw mode): asked per slab, by the thread that is about to read it -- true: parse this one here after all (the slab
     // then arrives parsed, `text` empty).  The caller says so while the device side has more text waiting than it takes: the cores are
     // idle then, and a parsed slab is half the bytes over the link.
