@@ -136,8 +136,11 @@ struct Match
 struct FilterResult
 {
     U64Buf                match_off; // n+1 (the per-read arrays are written by the device: page-locked under the HIP backend)
-    std::vector<Match>    matches;   // grouped by read, ascending target
+    std::vector<Match, ArenaAllocator<Match>> matches; // grouped by read, ascending target
     std::vector<uint8_t>  fpr_ok;    // empty, or per match: 1 = the backend already verified q <= fpr_query (see set_postfilter)
+    // ... or that flag is bit 31 of Match::count (kMatchFprOk), as the device writes it: the records are used as they arrive
+    bool                  flag_in_count = false;
+    static constexpr uint32_t kMatchFprOk = 0x80000000u;
 };
 
 struct BatchResult

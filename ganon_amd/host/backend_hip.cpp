@@ -885,7 +885,7 @@ public:
             fr.fpr_ok.clear();
             if (lf.parts.size() == 1)
             {
-                if (!fetch_part(lf.parts[0], n, out, !have_reads, fr.match_off, fr.matches, err, pf_active_ ? &fr.fpr_ok : nullptr))
+                if (!fetch_part(lf.parts[0], n, out, !have_reads, fr, err))
                     return false;
                 have_reads = true;
             }
@@ -918,16 +918,17 @@ public:
                     err = gn_last_error();
                     return false;
                 }
-                tmp_.resize(need ? need : 1);
-                if (gn_gather_fetch(lf.gather, nullptr, tmp_.data(), tmp_.size(), &need) != GN_OK)
+                fr.matches.resize(need ? need : 1);
+                if (gn_gather_fetch(lf.gather, nullptr, reinterpret_cast<gn_match*>(fr.matches.data()), fr.matches.size(), &need) != GN_OK)
                 {
                     err = gn_last_error();
                     return false;
                 }
+                fr.matches.resize(need);
+                fr.flag_in_count = pf_active_; // (the gather rewrote part-local target ids on the device)
                 uint64_t moved = 0;
                 if (gn_gather_device_matches(lf.gather, nullptr, nullptr, nullptr, &moved) == GN_OK)
                     gathered_bytes_ += moved;
-                unpack(need, nullptr, fr.matches, pf_active_ ? &fr.fpr_ok : nullptr);
                 if (!have_reads)
                 {
                     Part& home = lf.parts[lf.home];
@@ -1220,70 +1221,65 @@ private:
         filters_.clear();
     }
 
-    // tmp_[0..need) -> matches (+ the pre-pass's "surely passes --fpr-query" flags), target ids translated
-    bool unpack(uint64_t need, const std::vector<uint32_t>* to_target, std::vector<Match>& matches, std::vector<uint8_t>* fpr_ok)
+    using Matches = std::vector<Match, ArenaAllocator<Match>>;
+    static_assert(sizeof(Match) == sizeof(gn_match) && offsetof(Match, target) == offsetof(gn_match, target) && offsetof(Match, count) == offsetof(gn_match, count),
+                  "the device's match records are used as they arrive");
+
+    // records as they came from the device -> the caller's: target ids translated (HIBF: user bin -> target; a part of a partitioned
+    // filter: part-local -> the filter's); true when some belong to no target.  The "surely passes --fpr-query" flag stays where the
+    // device put it, bit 31 of the count (FilterResult::flag_in_count).
+    static bool translate(Matches& matches, const std::vector<uint32_t>* to_target)
     {
-        matches.resize(need);
         bool drop = false;
-        for (uint64_t j = 0; j < need; ++j)
-        {
-            uint32_t t = tmp_[j].target;
-            if (to_target)
+        if (to_target)
+            for (auto& m : matches)
             {
-                t = (*to_target)[t]; // HIBF: user bin -> target
-                drop |= t == 0xFFFFFFFFu;
+                m.target = (*to_target)[m.target];
+                drop |= m.target == 0xFFFFFFFFu;
             }
-            matches[j] = Match{ tmp_[j].read, t, tmp_[j].count & ~GN_MATCH_FPR_OK };
-        }
-        if (fpr_ok)
-        {
-            fpr_ok->resize(need);
-            for (uint64_t j = 0; j < need; ++j)
-                (*fpr_ok)[j] = (tmp_[j].count & GN_MATCH_FPR_OK) ? 1 : 0;
-        }
         return drop;
     }
 
-    // match offsets and matches of one device filter (and, if wanted, n_hashes / status of the batch), target ids translated
-    bool fetch_part(Part& part, uint32_t n, BatchResult& out, bool with_reads, U64Buf& match_off, std::vector<Match>& matches,
-                    std::string& err, std::vector<uint8_t>* fpr_ok = nullptr)
+    // match offsets and matches of one device filter (and, if wanted, n_hashes / status of the batch), straight into the result's
+    // page-locked arrays
+    bool fetch_part(Part& part, uint32_t n, BatchResult& out, bool with_reads, FilterResult& fr, std::string& err)
     {
         uint64_t need = 0;
-        if (gn_fetch_batch(part.s, with_reads ? out.n_hashes.data() : nullptr, with_reads ? out.status.data() : nullptr, match_off.data(),
+        if (gn_fetch_batch(part.s, with_reads ? out.n_hashes.data() : nullptr, with_reads ? out.status.data() : nullptr, fr.match_off.data(),
                            nullptr, 0, &need)
             != GN_OK)
         {
             err = gn_last_error();
             return false;
         }
-        tmp_.resize(need ? need : 1);
-        if (gn_fetch_batch(part.s, nullptr, nullptr, nullptr, tmp_.data(), tmp_.size(), &need) != GN_OK)
+        fr.matches.resize(need ? need : 1);
+        if (gn_fetch_batch(part.s, nullptr, nullptr, nullptr, reinterpret_cast<gn_match*>(fr.matches.data()), fr.matches.size(), &need) != GN_OK)
         {
             err = gn_last_error();
             return false;
         }
-        if (unpack(need, part.dp->to_target.empty() ? nullptr : &part.dp->to_target, matches, fpr_ok))
-        {
-            // user bins that belong to no target (cannot happen with raptor indices) are dropped, and their flags with them
-            std::vector<Match>    keep;
-            std::vector<uint8_t>  keep_ok;
-            U64Buf                off((size_t)n + 1, 0);
-            for (size_t j = 0; j < matches.size(); ++j)
-                if (matches[j].target != 0xFFFFFFFFu)
-                {
-                    keep.push_back(matches[j]);
-                    if (fpr_ok)
-                        keep_ok.push_back((*fpr_ok)[j]);
-                    off[matches[j].read + 1]++;
-                }
-            for (uint32_t r = 0; r < n; ++r)
-                off[r + 1] += off[r];
-            matches.swap(keep);
-            match_off.swap(off);
-            if (fpr_ok)
-                fpr_ok->swap(keep_ok);
-        }
+        fr.matches.resize(need);
+        fr.flag_in_count = pf_active_;
+        if (translate(fr.matches, part.dp->to_target.empty() ? nullptr : &part.dp->to_target))
+            drop_unassigned(n, fr);
         return true;
+    }
+
+    // user bins that belong to no target (cannot happen with raptor indices) are dropped
+    static void drop_unassigned(uint32_t n, FilterResult& fr)
+    {
+        Matches keep;
+        U64Buf  off((size_t)n + 1, 0);
+        for (auto const& m : fr.matches)
+            if (m.target != 0xFFFFFFFFu)
+            {
+                keep.push_back(m);
+                off[m.read + 1]++;
+            }
+        for (uint32_t r = 0; r < n; ++r)
+            off[r + 1] += off[r];
+        fr.matches.swap(keep);
+        fr.match_off.swap(off);
     }
 
     std::shared_ptr<DeviceSet> set_;
@@ -1298,7 +1294,6 @@ private:
     uint64_t              hint_reads_ = 0, hint_bases_ = 0; // largest batch the reader makes (prepare())
     bool                  long_reads_ = false;
     std::vector<Logical>  filters_;
-    std::vector<gn_match, ArenaAllocator<gn_match>> tmp_; // (page-locked: the device writes it)
     std::vector<gn_stream*> tok_sources_; // streams that hold the FASTQ text of the batch being tokenised (one per device)
     PostFilterSpec        pf_spec_;
     std::vector<std::vector<std::vector<double>>> pf_fpr_; // [filter][part]: per device target of that part

@@ -1316,9 +1316,14 @@ static bool ganon_classify(Config config)
                         const FilterResult& fr = res.per_filter[i];
                         for (uint64_t x = fr.match_off[r]; x < fr.match_off[r + 1]; ++x)
                         {
-                            const Match&   m   = fr.matches[x];
+                            Match          m   = fr.matches[x];
                             const uint32_t gid = target_gid[i][m.target];
-                            const bool     ok  = !fr.fpr_ok.empty() && fr.fpr_ok[x] != 0;
+                            bool           ok  = !fr.fpr_ok.empty() && fr.fpr_ok[x] != 0;
+                            if (fr.flag_in_count)
+                            {
+                                ok = (m.count & FilterResult::kMatchFprOk) != 0;
+                                m.count &= ~FilterResult::kMatchFprOk;
+                            }
                             MatchEntry*    e   = nullptr;
                             if (!one_filter) // (one filter reports a target once)
                             {

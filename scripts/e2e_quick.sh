@@ -16,9 +16,7 @@ run() { # label, env..., -- args
   echo "$out" | grep -E "host stalls|backend timing|host cpu|host timing|host input|host input|pinned pool|host cpu|ERROR|rror" | sed 's/^/      /' | cut -c1-420
 }
 for rep in 1 2 3; do
-run "text + parse-when-slack (default)" --
-run "text only" GANON_HOST_HYBRID=0 --
+run "FASTQ text tokenised on the device (default)" --
 run "host slab parser" GANON_HOST_DEVICE_FASTQ=0 --
 done
-run "text + parse-when-slack, 12 threads" GANON_HOST_PARSE_THREADS=12 --
-run "text + parse-when-slack, 6 threads" GANON_HOST_PARSE_THREADS=6 --
+run "text, slab readers parse while the batch queue is full" GANON_HOST_HYBRID=1 --
