@@ -127,7 +127,7 @@ def check_filter(hip, path, seqs, names, k, w, h_req, max_fp, filter_size, mode=
         found = int(dense[i][tb[t]].astype(np.int64).sum())
         # one bin: exactly its minimisers (:80-82); a target split over several bins can see a hash again in a sibling bin as
         # a false positive (the reference only runs this check on one-bin targets)
-        assert found == nh[i] if len(tb[t]) == 1 else nh[i] <= found <= nh[i] * len(tb[t])
+        assert (found == nh[i] if len(tb[t]) == 1 else nh[i] <= found <= nh[i] * len(tb[t])), (i, t, found, int(nh[i]), len(tb[t]), len(s))
     st.destroy()
     flt.free()
     return m
