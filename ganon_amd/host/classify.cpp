@@ -1682,8 +1682,10 @@ static bool ganon_classify(Config config)
                         if (Lane* u = pick(St::uploaded)) // last round's upload: its kernels
                             if (!(good = queue_kernels(*u)))
                                 break;
+                        if (failed) // (another worker gave up: deliver what is in flight, take nothing new)
+                            more = false;
                         bool  took = false;
-                        Lane* x    = more && !failed ? pick(St::idle) : nullptr;
+                        Lane* x    = more ? pick(St::idle) : nullptr;
                         if (x)
                         {
                             ordered.take_free(x->cb);
