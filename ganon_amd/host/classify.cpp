@@ -987,7 +987,8 @@ static bool ganon_classify(Config config)
             if (t.joinable())
             {
                 ReadBatch b; // drain so that a blocked producer can finish after an early error return
-                while (q.pop(b)) {}
+                while (q.pop(b))
+                    b.ticket.reset(); // (a piece nobody will look at: its file must not wait for it)
                 t.join();
             }
         }
@@ -1777,7 +1778,8 @@ static bool ganon_classify(Config config)
             if (failed && first_level)
             {
                 ReadBatch b; // let the reader finish so that the workers blocked on it come back
-                while (queue1.pop(b)) {}
+                while (queue1.pop(b))
+                    b.ticket.reset(); // (a piece nobody will look at: its file must not wait for it)
             }
             for (auto& w : workers)
                 w.join();

@@ -6,6 +6,7 @@
 #include "../../oracle/ganon_oracle.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -131,8 +132,16 @@ public:
     }
 
     bool classify(ReadBatch& b, uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff, BatchResult& out,
-                  std::string&) override
+                  std::string& err) override
     {
+        // $GANON_TEST_FAIL_AT_BATCH=n: the n-th batch of the run fails (the pipeline's way down: no hang, the message on stderr)
+        static std::atomic<long> seen{ 0 };
+        if (const char* e = std::getenv("GANON_TEST_FAIL_AT_BATCH"))
+            if (++seen == std::atol(e))
+            {
+                err = "injected failure (GANON_TEST_FAIL_AT_BATCH)";
+                return false;
+            }
         std::vector<Held>& held_ = origin_ ? origin_->held_ : this->held_;
         if (b.raw) // the first raw_keep records found by tokenise(): described for the pipeline, then classified like parsed reads
         {

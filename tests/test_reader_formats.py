@@ -370,6 +370,20 @@ def test_raw_pieces_and_worker_lanes_with_the_checker_backend(oracle_bin, sim_db
         assert ("tokenised on the device" in err) == (raw == "1"), err[-400:]
 
 
+@pytest.mark.parametrize("raw", ["0", "1"])
+def test_a_failing_batch_ends_the_run_and_nothing_hangs(oracle_bin, sim_db, tmp_path, raw):
+    """A backend error in the middle of a file: every stage lets go (reader waiting for its pieces, workers waiting for their turn or
+    for earlier pieces, post pool, writer) and the binary exits with the message -- with raw pieces and with parsed batches, several
+    workers, two contexts each."""
+    f1 = _raw_case_file("plain", sim_db, tmp_path)
+    for fail_at, dev in (("1", "0"), ("5", "0,0,0"), ("11", "0,0")):  # (the file is 16 raw pieces)
+        env = dict(os.environ, GANON_HOST_PARSE_THREADS="3", GANON_HOST_PARALLEL_MIN="0", GANON_HOST_DEVICE_FASTQ=raw, GANON_HOST_LANES="2",
+                   GANON_HOST_SLAB_BYTES="65536", GANON_HOST_BATCH_READS="97", GANON_TEST_FAIL_AT_BATCH=fail_at)
+        p = subprocess.run([oracle_bin, "--ibf", sim_db["ibf"], "--single-reads", f1, "-o", str(tmp_path / "x"), "--output-all", "--quiet", "--device", dev],
+                           capture_output=True, text=True, env=env, timeout=120)
+        assert p.returncode != 0 and "injected failure" in p.stderr, (fail_at, dev, p.returncode, p.stderr[-300:])
+
+
 def _fasta_text(recs, variant):
     nl = "\r\n" if variant == "crlf" else "\n"
     out = []
