@@ -1343,3 +1343,48 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
         assert np.array_equal(res[0][2][0], res[1][2][0]) and res[0][2][1:] == res[1][2][1:]
     flt.free()
+
+
+def test_deferred_launches_sized_by_the_previous_batch(hip, monkeypatch):
+    # The launches that take what the fast kernels defer (reads with more than 127 minimisers, reads longer than 640 letters) size
+    # their persistent grids by what the stream's PREVIOUS batch deferred.  A batch of short reads (nothing deferred) followed by a
+    # batch of thousands of long reads (everything deferred) must come out like the same batches on fresh streams and with the
+    # full grids -- and so must the short batch after the long one.
+    k, w = 19, 31
+    rng = np.random.default_rng(77)
+    ibf = gf.random_ibf(256, 8191, 3, 0.4, 5)
+    genome = gu.random_seq(rng, 60000)
+    for b in range(256):
+        ibf.emplace_many(np.unique(oracle.minimiser_hash(oracle.to_ranks(genome[b * 200:b * 200 + 2200]), k, w)), b)
+    flt = hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs)
+    short = [genome[p:p + 150] for p in rng.integers(0, 59000, size=3000)]
+    long_ = [genome[p:p + int(L)] for p, L in zip(rng.integers(0, 40000, size=4000), rng.integers(1500, 4000, size=4000))]
+
+    def run(st, reads):
+        bases, off1, _ = gu.pack_reads(reads, None)
+        st.submit(bases, off1, None, k, w, 0.3)
+        nh, status, mo, m = st.fetch()
+        ho, hs = st.fetch_hashes()
+        return nh.copy(), status.copy(), mo.copy(), m.copy(), ho.copy(), hs.copy()
+
+    cap_r, cap_b = 4000, sum(len(x) for x in long_) + 64
+    reused = hip.HipStream(flt, cap_r, cap_b)
+    got = [run(reused, short), run(reused, long_), run(reused, short), run(reused, long_)]
+    monkeypatch.setenv("GANON_HIP_FULL_DEFERRED_GRIDS", "1")
+    want = []
+    for reads in (short, long_):
+        fresh = hip.HipStream(flt, cap_r, cap_b)
+        want.append(run(fresh, reads))
+        fresh.destroy()
+    monkeypatch.delenv("GANON_HIP_FULL_DEFERRED_GRIDS")
+    for g, wnt in zip(got, [want[0], want[1], want[0], want[1]]):
+        for a, b in zip(g, wnt):
+            assert np.array_equal(a, b)
+    assert len(got[1][3]) > 1000 and (got[1][0] > 127).all()
+    # ... and against the oracle on a sample of the long reads
+    for i in range(0, len(long_), 400):
+        exp_m, _ = gu.oracle_matches(ibf, np.arange(256, dtype=np.uint32), 256, oracle.minimiser_hash(oracle.to_ranks(long_[i]), k, w), 0.3)
+        mo, m = got[3][2], got[3][3]
+        assert [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]] == exp_m
+    reused.destroy()
+    flt.free()
