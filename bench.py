@@ -54,6 +54,9 @@ WORKLOADS = {
     "flat32k": dict(kind="flat", bins=32768, rows=1 << 21, h=4, reads=2_000_000, paired=False, config=None),
     # split-bin map (what ganon-build makes of targets larger than max_hashes_bin): two technical bins per target
     "split32k": dict(kind="flat", bins=32768, rows=1 << 21, h=4, reads=2_000_000, paired=False, config=None, bins_per_target=2),
+    # long reads (5 kbp, ~710 minimisers each): every read goes through the generic count kernel (LDS counters), none through the fast one
+    "long8g": dict(kind="flat", bins=4096, rows=1 << 24, h=4, reads=300_000, paired=False, config=None, read_len=5000),
+    "long32k": dict(kind="flat", bins=32768, rows=1 << 21, h=4, reads=300_000, paired=False, config=None, read_len=5000),
     "hibf64k": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, h=3, reads=10_000_000, paired=False, config=2),
     # the same tree with a top-level IBF of 1 GiB (2^25 rows of 32 bytes): level 0 no longer fits the 256 MiB Infinity Cache
     "hibf64k_top1g": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, rows_top=1 << 25, h=3, reads=10_000_000, paired=False, config=2),
@@ -168,9 +171,10 @@ def main() -> int:
             slices = spec.get("slices", 1)
             W_local = (spec["bins"] + 63) >> 6
             sl_idx = rank % slices if kind == "slice" else 0
+            read_len = spec.get("read_len", 150)
             wl = bw.make_device_flat_workload(name, spec["bins"], rows, spec["h"], n_reads, paired, rel_cutoff=args.rel_cutoff,
                                               seed=42, shard=0 if kind == "slice" else rank, word_lo=sl_idx * W_local,
-                                              row_words_total=W_local * slices)
+                                              row_words_total=W_local * slices, read_len=read_len, genome_len=max(3000, 4 * read_len))
             bpt = spec.get("bins_per_target", 1)
             if bpt > 1:
                 flt, n_planted = bw.device_filter(ganon_amd, wl, dev_index, (np.arange(spec["bins"], dtype=np.uint32) // bpt).astype(np.uint32),
@@ -191,7 +195,9 @@ def main() -> int:
                 desc = (f"flat IBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {wl.bins} technical bins (W={W_local}, "
                         f"{row_bytes} B rows), S={rows} rows, h={spec['h']}" + (f", {bpt} bins per target" if bpt > 1 else ""))
             kernel_name = "gn_ibf_count_split_kernel" if bpt > 1 else "gn_ibf_count_fast_kernel"
-        unit_name = "pairs (2x150 bp)" if paired else "reads (150 bp)"
+            if read_len > 1000:
+                kernel_name = "gn_ibf_count_kernel"  # more than 127 minimisers per read: the generic kernel takes them all
+        unit_name = "pairs (2x150 bp)" if paired else f"reads ({spec.get('read_len', 150)} bp)"
         log(f"[rank {rank}] workload {name}: filter {wl.filter_bytes / 2**30:.2f} GiB filled on the device, {n_reads} "
             f"{unit_name}, set up in {time.time() - t0:.1f}s")
 
