@@ -133,6 +133,18 @@ public:
             free_[cls].push_back(p);
         }
     }
+    // blocks that hold n bytes: at least `count` of them are free in the pool right now (locks only what is short)
+    void ensure_free(size_t n, size_t count)
+    {
+        const size_t cls = size_class(n);
+        size_t       have;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            have = free_[cls].size();
+        }
+        if (have < count)
+            reserve(n, count - have);
+    }
     void settle() // before the process lets go of the device: the warm-up thread is not in the middle of a call
     {
         stop_ = true;
@@ -834,12 +846,10 @@ public:
         };
         if (warmed_ && !sets_reserved_ && n)
         {
-            // the first real batch says how large the per-read arrays are: blocks for the result sets that will be in flight between
-            // this context, the post pool and the writer are locked now, in one go, instead of one by one under the next batches
+            // the first real batch says how large the per-read arrays really are: what warm_up()'s guess did not cover is locked now,
+            // in one go, instead of one by one under the next batches
             sets_reserved_ = true;
-            const size_t m = (size_t)n + n / 8;
-            for (size_t bytes : { m * 4, m * 4, m * 8 + 8, m * 12, m * 4, m * 4, m * 4, m })
-                PinnedPool::get().reserve(bytes, 3);
+            reserve_result_sets(n, true);
         }
         out.n_hashes.assign(n, 0);
         out.status.assign(n, 0);
@@ -988,6 +998,17 @@ public:
         sec_create_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 
+    // page-locked blocks for three result sets of batches of n reads (n_hashes, max_count, match_off, matches, rec_at, seq_at, seq_len, status)
+    static void reserve_result_sets(size_t n, bool only_what_is_short)
+    {
+        const size_t m = n + n / 8;
+        for (size_t bytes : { m * 4, m * 4, m * 8 + 8, m * 12, m * 4, m * 4, m * 4, m })
+            if (only_what_is_short)
+                PinnedPool::get().ensure_free(bytes, 3);
+            else
+                PinnedPool::get().reserve(bytes, 3);
+    }
+
     void warm_up(uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff) override
     {
         if (std::getenv("GANON_HOST_NO_WARM_UP"))
@@ -1028,7 +1049,12 @@ public:
             // hundred milliseconds, profiles/r03_e2e_timeline.txt): every block is locked before the first batch.
             PinnedPool::get().reserve(tokenises_fastq() ? hint_bases_ : hint_bases_ / 2 + (1u << 20), 3);
         }
-        // (the per-read arrays of the results are sized by the first real batch: classify_end)
+        // ... and for the per-read arrays of the result sets that will be in flight between this context, the post pool and the writer,
+        // by a guess: reads of 150 letters with a short id line, ~300 bytes of FASTQ each.  (The first real batch checks the guess:
+        // classify_end locks what is short then -- under running batches, which is what this is here to avoid.)
+        {
+            reserve_result_sets(hint_bases_ / 300, false); // (hint_bases_: the reader's slab size, whichever way its slabs arrive)
+        }
         warmed_ = true;
         sec_create_ += sec_submit_ + sec_fetch_ + sec_tok_enqueue_ + sec_tok_wait_;
         sec_submit_ = sec_fetch_ = sec_tok_enqueue_ = sec_tok_wait_ = 0;
