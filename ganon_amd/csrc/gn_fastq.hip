@@ -202,6 +202,18 @@ void gn_fastq_release(gn_stream* s)
             hipFree(p);
     if (s->h_fq)
         hipHostFree(s->h_fq);
+    for (int i = 0; i < 3; ++i)
+    {
+        if (s->fq_up_ev[i])
+            hipEventDestroy(s->fq_up_ev[i]);
+        if (s->fq_up[i])
+        {
+            hipStreamSynchronize(s->fq_up[i]);
+            hipStreamDestroy(s->fq_up[i]);
+        }
+        s->fq_up[i]    = nullptr;
+        s->fq_up_ev[i] = nullptr;
+    }
     s->d_text = nullptr;
     s->d_fq_tile = s->d_fq_nl = s->d_fq_rec = s->d_fq_seq = s->d_fq_len = nullptr;
     s->d_fq = nullptr;
@@ -250,7 +262,33 @@ extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_
     GN_HIP(hipStreamSynchronize(s->st)); // previous batch must be done before its inputs are overwritten
     const double p1 = probe ? now() : 0;
     hipStream_t st = s->st;
-    if (n_bytes)
+    // $GANON_HIP_SPLIT_UPLOAD=<parts>: the text goes up in that many pieces on streams of their own (do concurrent copies of one batch
+    // find a second copy engine?  A/B switch; the default is one copy)
+    static const int split = getenv("GANON_HIP_SPLIT_UPLOAD") ? std::max(1, std::min(4, atoi(getenv("GANON_HIP_SPLIT_UPLOAD")))) : 1;
+    if (n_bytes && split > 1 && n_bytes >= (8u << 20))
+    {
+        const uint64_t part = ((n_bytes / split) + 4095) & ~4095ull;
+        for (int i = 0; i < split; ++i)
+        {
+            const uint64_t lo = (uint64_t)i * part, hi = std::min<uint64_t>(n_bytes, lo + part);
+            if (lo >= hi)
+                break;
+            if (i == 0)
+            {
+                GN_HIP(hipMemcpyAsync(s->d_text, text, hi, hipMemcpyHostToDevice, st));
+                continue;
+            }
+            if (!s->fq_up[i - 1])
+            {
+                GN_HIP(hipStreamCreateWithFlags(&s->fq_up[i - 1], hipStreamNonBlocking));
+                GN_HIP(hipEventCreateWithFlags(&s->fq_up_ev[i - 1], hipEventDisableTiming));
+            }
+            GN_HIP(hipMemcpyAsync(s->d_text + lo, text + lo, hi - lo, hipMemcpyHostToDevice, s->fq_up[i - 1]));
+            GN_HIP(hipEventRecord(s->fq_up_ev[i - 1], s->fq_up[i - 1]));
+            GN_HIP(hipStreamWaitEvent(st, s->fq_up_ev[i - 1], 0));
+        }
+    }
+    else if (n_bytes)
         GN_HIP(hipMemcpyAsync(s->d_text, text, n_bytes, hipMemcpyHostToDevice, st));
     const double p2 = probe ? now() : 0;
     const uint32_t tiles = (uint32_t)((n_bytes + GN_FQ_TILE - 1) / GN_FQ_TILE);

@@ -15,8 +15,11 @@ run() { # label, env..., -- args
   echo "$label: classify+print $t s = $(python -c "print(round($N/$t/1e6,1))") Mreads/s"
   echo "$out" | grep -E "host stalls|backend timing|host cpu|host timing|host input|host input|pinned pool|host cpu|ERROR|rror" | sed 's/^/      /' | cut -c1-420
 }
-for rep in 1 2 3; do
-run "FASTQ text tokenised on the device (default)" --
-run "host slab parser" GANON_HOST_DEVICE_FASTQ=0 --
+for rep in 1 2; do
+run "text, one copy per piece" --
+run "text, 2 copies per piece" GANON_HIP_SPLIT_UPLOAD=2 --
+run "text, 4 copies per piece" GANON_HIP_SPLIT_UPLOAD=4 --
 done
-run "text, slab readers parse while the batch queue is full" GANON_HOST_HYBRID=1 --
+run "one worker, one copy" -- --device 0
+run "one worker, 4 copies" GANON_HIP_SPLIT_UPLOAD=4 -- --device 0
+run "two workers, 4 copies" GANON_HIP_SPLIT_UPLOAD=4 -- --device 0,0
