@@ -124,18 +124,20 @@ static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* by
                 return gn_fail(GN_ENODEV, "filter upload failed: %s", hipGetErrorString(e));
             }
         }
-        GN_HIP(hipMemset(reinterpret_cast<uint8_t*>(dp) + bytes, 0, 64));
+        GN_HIP(hipMemsetAsync(reinterpret_cast<uint8_t*>(dp) + bytes, 0, 64, nullptr));
     }
     else
     {
-        GN_HIP(hipMemset(dp, 0, bytes + 64));
+        GN_HIP(hipMemsetAsync(dp, 0, bytes + 64, nullptr));
     }
     if (d->rows && (d->bins & 63))
-    {
         hipLaunchKernelGGL(gn_clear_padding_kernel, dim3((unsigned)((d->bin_size + 255) / 256)), dim3(256), 0, nullptr, dp,
                            d->bin_size, d->bin_words, (1ull << (d->bins & 63)) - 1ull);
-        GN_HIP(hipDeviceSynchronize());
-    }
+    // A memset of device memory returns before the fill has run, and everything that touches the filter afterwards --
+    // gn_filter_write_rows' load stream, every gn_stream -- runs on streams created hipStreamNonBlocking, which take no
+    // implicit order against the null stream the fill is queued on.  Without this wait the zero fill of a streamed filter
+    // could land AFTER the first row chunks (round 3's intermittent "0 of 7 minimisers found": DESIGN 7-5b).
+    GN_HIP(hipDeviceSynchronize());
     out->d_rows = dp;
     out->S      = d->bin_size;
     out->W      = d->bin_words;
@@ -1636,6 +1638,7 @@ extern "C" int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_
     const size_t nel = (size_t)(read_end - read_begin) * f->ibf.B;
     uint16_t*    dd  = nullptr;
     GN_HIP(gn_dmalloc(&dd, nel));
+    hipMemsetAsync(dd, 0, nel * 2, s->st); // (skipped reads write nothing)
     // re-run the count kernel with the dense tap on (matches of this run are discarded)
     unsigned long long saved[GN_NCTR];
     memcpy(saved, s->h_ctr, sizeof(saved));

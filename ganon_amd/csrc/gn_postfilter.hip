@@ -909,7 +909,11 @@ extern "C" int gn_stream_set_postfilter(gn_stream* s, const gn_postfilter* pf)
     if (pf->target_fpr && nt)
         GN_HIP(hipMemcpy(s->d_pf_fpr, pf->target_fpr, nt * sizeof(double), hipMemcpyHostToDevice));
     else if (nt)
-        GN_HIP(hipMemset(s->d_pf_fpr, 0, nt * sizeof(double)));
+    {
+        // (stream-ordered: s->st is a non-blocking stream, a null-stream fill would be unordered against its kernels)
+        GN_HIP(hipMemsetAsync(s->d_pf_fpr, 0, nt * sizeof(double), s->st));
+        GN_HIP(hipStreamSynchronize(s->st));
+    }
     s->pf_rel_filter = pf->rel_filter;
     s->pf_fpr_query  = pf->fpr_query;
     s->pf_joint      = pf->joint != 0;

@@ -150,9 +150,12 @@ def _sim_reads():
 
 @pytest.fixture(scope="module")
 def sim_db(tmp_path_factory):
+    return make_sim_db(str(tmp_path_factory.mktemp("sim_db")))
+
+
+def make_sim_db(d):
     """Targets = 40 synthetic genomes, each containing a few of the fixture reads verbatim -> true matches."""
     import numpy as np
-    d = str(tmp_path_factory.mktemp("sim_db"))
     r1, r2 = _sim_reads()
     rng = np.random.default_rng(99)
     targets = {}
