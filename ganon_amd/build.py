@@ -2,6 +2,7 @@
 
   ganon_amd/csrc/libganon_hip.so   HIP kernels + C ABI (include/ganon_hip.h)
   ganon_amd/host/ganon-classify    C++ host binary (drop-in CLI), links libganon_hip.so
+  ganon_amd/host/ganon-build       filter writer, ganon_amd/host/ganon-reassign  the EM over .all
 
 No JIT cache: the .so / binary live next to their sources so they travel with a repo snapshot.
 """
@@ -19,9 +20,11 @@ HOST = os.path.join(HERE, "host")
 LIB = os.path.join(CSRC, "libganon_hip.so")
 BIN = os.path.join(HOST, "ganon-classify")
 BIN_BUILD = os.path.join(HOST, "ganon-build")
+BIN_REASSIGN = os.path.join(HOST, "ganon-reassign")
 BUILD_ONLY = ("build.cpp", "build_params.cpp")  # sources of ganon-build that ganon-classify does not link
+REASSIGN_ONLY = ("reassign.cpp", "reassign_main.cpp")  # ganon-reassign (the EM over .all)
 
-HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_build.hip", "gn_gather.hip", "gn_fastq.hip", "gn_capi.hip"]
+HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_build.hip", "gn_gather.hip", "gn_fastq.hip", "gn_reassign.hip", "gn_capi.hip"]
 HIP_HEADERS = ["gn_internal.h", "gn_scan.h", os.path.join(ROOT, "include", "ganon_hip.h")]
 
 
@@ -76,7 +79,9 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     every = sorted(f for f in os.listdir(HOST) if f.endswith(".cpp"))
     hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "ganon_hip.h")]
     build_hip(force=False, verbose=verbose)
-    for binary, names in ((BIN, [f for f in every if f not in BUILD_ONLY]), (BIN_BUILD, [f for f in every if f in BUILD_ONLY] + ["seq_io.cpp", "pgzip.cpp"])):
+    for binary, names in ((BIN, [f for f in every if f not in BUILD_ONLY + REASSIGN_ONLY]),
+                          (BIN_BUILD, [f for f in every if f in BUILD_ONLY] + ["seq_io.cpp", "pgzip.cpp"]),
+                          (BIN_REASSIGN, [f for f in every if f in REASSIGN_ONLY])):
         srcs = [os.path.join(HOST, f) for f in names]
         if not srcs:
             continue

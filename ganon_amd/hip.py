@@ -23,7 +23,8 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
                "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_classify_shared",
-               "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records"]
+               "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
+               "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -113,6 +114,12 @@ def load_library():
     L.gn_stream_device_offsets.argtypes = [vp, C.POINTER(vp)]
     L.gn_stream_hibf_levels.argtypes = [vp, C.POINTER(u32), vp, vp, vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
+    L.gn_reassign_create.argtypes = [i32, u64, u64, u32, vp, vp, C.POINTER(vp)]
+    L.gn_reassign_run.argtypes = [vp, u32, C.c_double, C.POINTER(u32)]
+    L.gn_reassign_diffs.argtypes = [vp, vp, u32]
+    L.gn_reassign_fetch.argtypes = [vp, vp, vp, vp, vp]
+    L.gn_reassign_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_float), C.POINTER(u64)]
+    L.gn_reassign_free.argtypes = [vp]
     for name in ABI_SYMBOLS:
         if name != "gn_last_error":
             getattr(L, name).restype = i32
@@ -172,6 +179,44 @@ def device_memory(device: int = 0) -> Tuple[int, int]:
     f, t = C.c_uint64(0), C.c_uint64(0)
     _check(load_library().gn_device_memory(device, C.byref(f), C.byref(t)))
     return int(f.value), int(t.value)
+
+
+class HipReassign:
+    """gn_reassign_*: the EM of `ganon reassign` over a CSR table of (read -> entries naming targets), on the device"""
+
+    def __init__(self, off: np.ndarray, target: np.ndarray, n_targets: int, device: int = 0):
+        self._off = np.ascontiguousarray(off, dtype=np.uint64)
+        self._target = np.ascontiguousarray(target, dtype=np.uint32)
+        self.n_reads, self.n_targets = self._off.size - 1, int(n_targets)
+        self._h = C.c_void_p()
+        _check(load_library().gn_reassign_create(device, self.n_reads, self._target.size, self.n_targets, _p(self._off), _p(self._target),
+                                                 C.byref(self._h)))
+
+    def run(self, max_iter: int = 10, threshold: float = 0.0):
+        """-> (diffs float64[iterations], counts uint64[n_targets], unique uint64[n_targets], prob float64[n_targets],
+        choice uint64[n_reads] = entry index per read)"""
+        L = load_library()
+        it = C.c_uint32(0)
+        _check(L.gn_reassign_run(self._h, max_iter, float(threshold), C.byref(it)))
+        diffs = np.zeros(it.value, dtype=np.float64)
+        _check(L.gn_reassign_diffs(self._h, _p(diffs), it.value))
+        counts = np.zeros(self.n_targets, dtype=np.uint64)
+        unique = np.zeros(self.n_targets, dtype=np.uint64)
+        prob = np.zeros(self.n_targets, dtype=np.float64)
+        choice = np.zeros(self.n_reads, dtype=np.uint64)
+        _check(L.gn_reassign_fetch(self._h, _p(counts), _p(unique), _p(prob), _p(choice)))
+        return diffs, counts, unique, prob, choice
+
+    def info(self) -> dict:
+        nu, nm, nw, by = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        ms = C.c_float(0)
+        _check(load_library().gn_reassign_info(self._h, C.byref(nu), C.byref(nm), C.byref(nw), C.byref(ms), C.byref(by)))
+        return dict(unique_reads=nu.value, multi_reads=nm.value, wave_reads=nw.value, ms=ms.value, bytes_per_iteration=by.value)
+
+    def free(self):
+        if self._h:
+            load_library().gn_reassign_free(self._h)
+            self._h = C.c_void_p()
 
 
 class HipGather:

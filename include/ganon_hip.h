@@ -286,6 +286,30 @@ int gn_gather_destroy(gn_gather* g);
 /* free / total memory of a device: the host decides with it whether a filter is replicated or partitioned */
 int gn_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 
+/* ---- reassign: the EM over a classification's .all ---------------------------------------------------
+ * `ganon classify` runs this after the binary by default (/root/reference/src/ganon/classify.py:76-88, --multiple-matches
+ * em); the algorithm is /root/reference/src/ganon/reassign.py:96-145 with get_top_match :226-241.
+ * The table is CSR over reads: off[n_reads+1] into target[n_entries]; a read's entries are in the order its lines appear in
+ * the .all file, reads in first-appearance order, targets numbered 0..n_targets-1 by first appearance (:76-92) -- the
+ * tie-break of get_top_match (first listed entry wins) and the left-to-right double sum of the convergence test depend
+ * on exactly that order.  The table is copied to the device once and every iteration runs there.
+ * gn_reassign_run: max_iter = 0 iterates until diff <= threshold (:141-145); diffs[i] = the i-th iteration's
+ * sum |old prob - new prob| bit for bit as the reference computes it (gn_reassign_diffs copies the first `cap` of them).
+ * gn_reassign_fetch (any pointer may be NULL): counts[t] = reassigned_matches of the LAST iteration (:113-121; the new .rep
+ * holds counts[t] - unique[t] in its lca column, :189-219), unique[t] = reads listing t and nothing else, prob[t] after the
+ * last update, choice[r] = index into target[] of the entry read r is given in the .one file (:153-181). */
+typedef struct gn_reassign gn_reassign;
+int gn_reassign_create(int device, uint64_t n_reads, uint64_t n_entries, uint32_t n_targets, const uint64_t* off,
+                       const uint32_t* target, gn_reassign** out);
+int gn_reassign_run(gn_reassign* g, uint32_t max_iter, double threshold, uint32_t* iterations);
+int gn_reassign_diffs(const gn_reassign* g, double* diffs, uint32_t cap);
+int gn_reassign_fetch(gn_reassign* g, uint64_t* counts, uint64_t* unique, double* prob, uint64_t* choice);
+/* reads with one / several entries, reads long enough to take a wave of their own, device time of the last run (EM +
+ * final choice) and the algorithmic bytes one iteration reads (8 per read + 4 per entry of a read with several) */
+int gn_reassign_info(const gn_reassign* g, uint64_t* n_unique_reads, uint64_t* n_multi_reads, uint64_t* n_wave_reads, float* ms_em,
+                     uint64_t* bytes_per_iteration);
+int gn_reassign_free(gn_reassign* g);
+
 /* Build side (/root/reference/src/ganon-build/GanonBuild.cpp).
  * gn_stream_distinct_hashes: after gn_stream_minimisers, the SET of minimiser hashes of all sequences resident in the
  * stream, ascending -- what count_hashes collects per file in a robin_hood::unordered_set (:184-249; the set's own iteration
