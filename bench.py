@@ -104,6 +104,53 @@ def run_extra(name: str, timeout: int):
         return {"workload": name, "error": repr(e)}
 
 
+def run_e2e(budget: int):
+    """the product binary end to end on generated files that classify (bench_e2e.py), in a child process"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench_e2e.py"), "--budget", str(budget)]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget + 240, cwd=ROOT)
+        line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {"error": f"rc {p.returncode}: " + p.stderr.decode(errors="replace")[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"timeout after {budget + 240}s"}
+    except Exception as e:  # noqa: BLE001 -- never lose the kernel line over the end-to-end leg
+        return {"error": repr(e)}
+
+
+def summarise(result: dict) -> None:
+    """The driver's record keeps scalars of `config` / `roofline` / `cpu_baseline` and lists other top-level objects by name only:
+    the figures of `variants`, `other_workloads` and `e2e` a reader needs are repeated as flat scalars in `config`."""
+    c = result["config"]
+    for key, v in (result.get("variants") or {}).items():
+        if "mreads_per_s" in v:
+            c[f"variant_{key}_mreads_s"] = v["mreads_per_s"]
+        if "frac" in v:
+            c[f"variant_{key}_hbm_frac"] = v["frac"]
+    for o in result.get("other_workloads") or []:
+        w = o.get("workload", "?")
+        if "error" in o:
+            c[f"{w}_error"] = o["error"][:120]
+            continue
+        c[f"{w}_{o['unit'].replace('/s', '_s').lower()}"] = o["value"]
+        c[f"{w}_hbm_frac"] = o["roofline"]["frac"]
+        chk = o["config"].get("oracle_spot_check") or {}
+        if chk:
+            c[f"{w}_mismatching_reads"] = chk.get("mismatching_reads")
+    e2e = result.get("e2e") or {}
+    if "error" in e2e:
+        c["e2e_error"] = e2e["error"][:120]
+    for name, r in (e2e.get("inputs") or {}).items():
+        if "error" in r:
+            c[f"e2e_{name}_error"] = r["error"][:120]
+            continue
+        unit = "mpairs_s" if name == "paired" else "mreads_s"
+        c[f"e2e_{name}_{unit}_median"] = r["rate"]["median"]
+        c[f"e2e_{name}_{unit}_min_max"] = f"{r['rate']['min']}-{r['rate']['max']} over {r['runs']} runs"
+        c[f"e2e_{name}_classified_frac"] = r["classified_frac"]
+
+
 def slim(name: str, r: dict, wall: float) -> dict:
     return {"workload": name, "value": r["value"], "unit": r["unit"], "n_gpus": r["n_gpus"], "scaling": r["scaling"],
             "ms_per_step": r["ms_per_step"], "steps": r["steps"], "config": r["config"], "roofline": r["roofline"],
@@ -123,6 +170,8 @@ def main() -> int:
     ap.add_argument("--no-extra", action="store_true", help="do not run the other BASELINE configs after the headline")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--extra-timeout", type=int, default=420)
+    ap.add_argument("--no-e2e", action="store_true", help="do not run the product binary end to end after the kernels (bench_e2e.py)")
+    ap.add_argument("--e2e-budget", type=int, default=150, help="seconds the end-to-end leg may take")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s)")
     ap.add_argument("--check", type=int, default=2000, help="reads re-checked against the oracle (rank 0)")
     args = ap.parse_args()
@@ -328,8 +377,14 @@ def main() -> int:
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                roof["traffic"] = pmc["hbm_bytes_per_launch"]
-                roof["traffic_source"] = pmc["source"]
+                # evidence about THIS run only if the profile was taken on the same batch: same algorithmic bytes per step
+                same = abs(pmc.get("algo_bytes_per_step", 0) - tm["algo_bytes"]) <= 1e-3 * max(1, tm["algo_bytes"])
+                if same:
+                    roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = pmc["source"]
+                else:
+                    roof["traffic_source"] = (f"none: {os.path.basename(pmc_path)} was taken on a batch of {pmc.get('algo_bytes_per_step')} "
+                                              f"algorithmic bytes, this run's is {tm['algo_bytes']}")
             except Exception as e:  # noqa: BLE001
                 log("bench.py: could not read", pmc_path, repr(e))
 
@@ -392,18 +447,40 @@ def main() -> int:
             result["variants"] = variants
             step(args.rel_cutoff)
 
+        # Every rank re-derives a sample of ITS OWN shard / owned range with the oracle (a wrong shard on rank 5 must not pass
+        # because rank 0's was right); the mismatch counts are summed over the ranks into the line, and so are the per-rank
+        # order-independent checksums of the match records (bench_workload.checksum_matches) -- with the same seed rank 0's
+        # shard is the world-1 shard, so `match_checksum_rank0` of an N-GPU run equals the 1-GPU run's.
+        import bench_cpu
+        detail, ok = None, True
+        if args.check:
+            if kind == "hibf":
+                ok, detail = bench_cpu.spot_check_hibf(wl, flt, nh, status, mo, matches, min(args.check, 600))
+            else:
+                ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check if rank == 0 else max(200, args.check // 4),
+                                                  target_offset=(sl_idx * spec["bins"] if kind == "slice" else 0),
+                                                  bins_per_target=spec.get("bins_per_target", 1),
+                                                  read_range=(lo, hi) if kind == "slice" else None,
+                                                  own_targets_only=kind == "slice" and world > 1)
+            if world > 1:
+                detail = {"reads_checked": int(gdist.sum_over_ranks(detail["reads_checked"], device=red_dev)),
+                          "matches_checked": int(gdist.sum_over_ranks(detail["matches_checked"], device=red_dev)),
+                          "mismatching_reads": int(gdist.sum_over_ranks(detail["mismatching_reads"], device=red_dev)),
+                          "ranks_checked": world}
+                ok = detail["mismatching_reads"] == 0
+        csum = bw.checksum_matches(matches)
+        if world > 1:  # (a 64-bit sum does not fit a float reduction: two 32-bit halves)
+            lo32 = int(gdist.sum_over_ranks(csum & 0xFFFFFFFF, device=red_dev))
+            hi32 = int(gdist.sum_over_ranks(csum >> 32, device=red_dev))
+            csum_all = (lo32 + (hi32 << 32)) & 0xFFFFFFFFFFFFFFFF
+        else:
+            csum_all = csum
         if rank == 0:
-            import bench_cpu
-            if args.check:
-                if kind == "hibf":
-                    ok, detail = bench_cpu.spot_check_hibf(wl, flt, nh, status, mo, matches, min(args.check, 600))
-                else:
-                    ok, detail = bench_cpu.spot_check(wl, flt, nh, status, mo, matches, args.check,
-                                                      target_offset=(sl_idx * spec["bins"] if kind == "slice" else 0),
-                                                      bins_per_target=spec.get("bins_per_target", 1),
-                                                      read_range=(lo, hi) if kind == "slice" else None,
-                                                      own_targets_only=kind == "slice" and world > 1)
+            result["config"]["match_checksum_rank0"] = f"{csum:016x}"
+            result["config"]["match_checksum_all_ranks"] = f"{csum_all:016x}"
+            if detail is not None:
                 result["config"]["oracle_spot_check"] = detail
+                result["config"]["oracle_mismatching_reads"] = detail["mismatching_reads"]   # (flat: survives the driver's record)
                 if not ok:
                     log("bench.py: ORACLE SPOT CHECK FAILED:", detail)
                     result["value"] = None
@@ -430,6 +507,9 @@ def main() -> int:
         default_run = not args.no_extra
     if default_run and world == 1 and rank == 0:
         result["other_workloads"] = [run_extra(w, args.extra_timeout) for w in EXTRA_WORKLOADS]
+        if not args.no_e2e:
+            result["e2e"] = run_e2e(args.e2e_budget)
+        summarise(result)
     elif default_run and world > 1:
         # the configs BASELINE.json quotes its scaling target on, with the real world size (every rank takes part).
         # They run behind a watchdog: if a rank fails inside a collective the others would wait for ever, and the headline

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench_e2e.py -- the product binary end to end (files in, files out), the leg bench.py attaches as `e2e`.
+
+What `ganon-classify` itself times as "classifying+printing elapsed" (/root/reference/src/ganon-classify/GanonClassify.cpp:1047,
+1095-1099): FASTQ text from /dev/shm -> parse / tokenise -> GPU -> filter_matches -> .all / .rep written, with the filter load
+reported beside it.  Four inputs, every one built so that about half of the reads CLASSIFY (reads / pairs cut from the
+genomes the filter holds, mate 2 the reverse strand of the same fragment):
+
+  fastq    plain single-end FASTQ against a 1 GiB flat IBF (4096 bins, h = 4)
+  paired   two FASTQ files, 2 x 150 bp ends of 400 bp fragments, same filter
+  gz       single-end .fq.gz -- ONE gzip member whose deflate blocks reference the 32 KiB before them, as gzip / pigz write it
+           (written here in parallel with zlib's preset-dictionary interface, which produces exactly that), binned qualities
+  hibf     the plain FASTQ against a two-level HIBF (16 384 user bins) that holds the same genomes: level 1 is visited
+
+Every input runs `--runs` times (default 5); median, min and max are reported with `#total_classified` of the .rep.
+usage: python bench_e2e.py [--runs 5] [--reads 8000000] [--dir /dev/shm] [--budget 150]   -> one JSON line
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import json
+import os
+import re
+import struct
+import subprocess
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EXE = os.path.join(ROOT, "ganon_amd", "host", "ganon-classify")
+# what `ganon classify` passes to the binary by default (/root/reference/src/ganon/config.py: --rel-cutoff 0.75 --rel-filter 0.1
+# --fpr-query 1e-5)
+THRESHOLDS = ["--rel-cutoff", "0.75", "--rel-filter", "0.1", "--fpr-query", "1e-5"]
+QUALS = np.frombuffer(b"FFFFFFFFFFFF:FFF,FFFF#", dtype=np.uint8)  # binned qualities as sequencers write them
+
+
+def fastq_matrix(bases: np.ndarray, n: int, L: int, first_id: int = 0, quals: bool = False) -> np.ndarray:
+    """n records `@r%09d \\n bases \\n + \\n qualities \\n` as one byte matrix (fixed width: ids are zero-padded)"""
+    rec = np.empty((n, 2 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0], rec[:, 1] = ord("@"), ord("r")
+    idx = np.arange(first_id, first_id + n, dtype=np.int64)
+    for p in range(9):
+        rec[:, 2 + p] = (idx // 10 ** (8 - p)) % 10 + ord("0")
+    rec[:, 11] = ord("\n")
+    rec[:, 12:12 + L] = bases.reshape(n, L)
+    rec[:, 12 + L:15 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    if quals:
+        rec[:, 15 + L:15 + 2 * L] = QUALS[np.random.default_rng(7).integers(0, len(QUALS), size=(n, L), dtype=np.uint8)]
+    else:
+        rec[:, 15 + L:15 + 2 * L] = ord("I")
+    rec[:, -1] = ord("\n")
+    return rec
+
+
+def write_gzip_one_member(path: str, data: np.ndarray, level: int = 6, chunk: int = 8 << 20, threads: int = 16) -> None:
+    """`data` as ONE gzip member: raw deflate pieces compressed in parallel, every piece primed with the 32 KiB before it
+    (back-references cross the pieces as in a stream written in one go), Z_SYNC_FLUSH between them, Z_FINISH at the end"""
+    mv = memoryview(data.reshape(-1))
+    n = len(mv)
+    starts = list(range(0, n, chunk)) or [0]
+
+    def piece(i):
+        a = starts[i]
+        b = min(n, a + chunk)
+        kw = dict(zdict=bytes(mv[max(0, a - 32768):a])) if a else {}
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_DEFAULT_STRATEGY, **kw)
+        return co.compress(mv[a:b]) + co.flush(zlib.Z_FINISH if b == n else zlib.Z_SYNC_FLUSH)
+
+    with cf.ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(piece, range(len(starts))))
+    crc = 0
+    for a in starts:
+        crc = zlib.crc32(mv[a:min(n, a + chunk)], crc)
+    with open(path, "wb") as f:
+        f.write(b"\x1f\x8b\x08\x00" + struct.pack("<I", 0) + b"\x00\x03")
+        for p in parts:
+            f.write(p)
+        f.write(struct.pack("<II", crc & 0xFFFFFFFF, n & 0xFFFFFFFF))
+
+
+def run_binary(args, n_units, runs, label, deadline):
+    """-> summary of `runs` runs of the binary (fewer when the time budget runs out: the number is reported)"""
+    secs, loads, walls = [], [], []
+    last = {}
+    env = dict(os.environ, GANON_HOST_TIMING="1")
+    prefix = args[args.index("-o") + 1]
+    for i in range(runs):
+        if i >= 1 and time.time() > deadline:
+            break
+        t0 = time.time()
+        p = subprocess.run([EXE] + args, capture_output=True, text=True, env=env, timeout=600)
+        walls.append(time.time() - t0)
+        if p.returncode != 0:
+            return {"error": f"rc {p.returncode}: {p.stderr[-300:]}"}
+        m = re.search(r"classifying\+printing elapsed \(s\): ([0-9.eE+-]+)", p.stderr)
+        if not m:
+            return {"error": "no timing line in the binary's --verbose output"}
+        secs.append(float(m.group(1)))
+        m = re.search(r"loading filter\(s\)\s+elapsed \(s\): ([0-9.eE+-]+)", p.stderr)
+        loads.append(float(m.group(1)) if m else 0.0)
+        last = {"stderr": p.stderr}
+    rep = open(prefix + ".rep").read().splitlines()
+    classified = next((int(l.split("\t")[1]) for l in rep if l.startswith("#total_classified")), 0)
+    unclassified = next((int(l.split("\t")[1]) for l in rep if l.startswith("#total_unclassified")), 0)
+    with open(prefix + ".all", "rb") as f:
+        all_lines = sum(buf.count(b"\n") for buf in iter(lambda: f.read(1 << 24), b""))
+    stalls = re.findall(r"\[host stalls\] (.*)", last.get("stderr", ""))
+    rates = [n_units / s / 1e6 for s in secs]
+    out = {"input": label, "units": n_units, "runs": len(secs),
+           "classify_print_s": {"median": round(float(np.median(secs)), 4), "min": round(min(secs), 4), "max": round(max(secs), 4)},
+           "rate": {"median": round(float(np.median(rates)), 2), "min": round(min(rates), 2), "max": round(max(rates), 2)},
+           "load_filter_s_median": round(float(np.median(loads)), 3), "process_wall_s_median": round(float(np.median(walls)), 2),
+           "total_classified": classified, "total_unclassified": unclassified,
+           "classified_frac": round(classified / max(1, classified + unclassified), 4), "all_lines": all_lines,
+           "host_stalls": "; ".join(stalls)[:400]}
+    for ext in (".all", ".rep"):
+        if os.path.exists(prefix + ext):
+            os.remove(prefix + ext)
+    return out
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=5)
+    ap.add_argument("--reads", type=int, default=8_000_000, help="single-end reads (pairs: half of it, .gz reads: a quarter)")
+    ap.add_argument("--dir", default="/dev/shm")
+    ap.add_argument("--budget", type=float, default=150.0, help="seconds; inputs that no longer fit are left out and named")
+    ap.add_argument("--only", default="", help="comma-separated subset of fastq,paired,gz,hibf")
+    args = ap.parse_args()
+
+    import bench_workload as bw
+    import ganon_amd
+    from ganon_amd import ibf_file
+
+    t_start = time.time()
+    deadline = t_start + args.budget
+    want = [w for w in (args.only.split(",") if args.only else ["fastq", "paired", "gz", "hibf"]) if w]
+    d = os.path.join(args.dir, f"ganon_e2e_{os.getpid()}")
+    os.makedirs(d, exist_ok=True)
+    out = {"thresholds": " ".join(THRESHOLDS), "dir": args.dir, "runs_requested": args.runs, "inputs": {}, "skipped": []}
+    bins, rows, h, L, n_genomes = 4096, 1 << 21, 4, 150, 4096
+    n = args.reads
+    try:
+        # ---- the flat filter (1 GiB) with the genomes planted, written as a ganon-build .ibf
+        wl = bw.make_device_flat_workload("e2e", bins, rows, h, n, paired=False, seed=42)
+        flt, _ = bw.device_filter(ganon_amd, wl)
+        ibf = os.path.join(d, "e2e.ibf")
+        # Bernoulli(0.5) bits = every bin a Bloom filter at its optimal load for h = 4: the header declares the number of
+        # minimisers per bin that gives that rate (n = S ln2 / h), so --fpr-query sees the bits that are there
+        per_bin = int(rows * 0.6931471805599453 / h)
+        cfg = dict(n_bins=bins, max_hashes_bin=per_bin, hash_functions=h, kmer_size=wl.k, window_size=wl.w, bin_size_bits=rows, max_fp=0.0625,
+                   true_max_fp=0.0625, true_avg_fp=0.0625)
+        ibf_file.save_ibf(ibf, flt, cfg, [(f"T{b}", per_bin) for b in range(bins)], [(b, f"T{b}") for b in range(bins)], bins, rows, h)
+        flt.free()
+        out["filter"] = {"kind": "flat IBF", "gib": round(os.path.getsize(ibf) / 2**30, 2), "bins": bins, "hash_funs": h, "planted_genomes": n_genomes}
+
+        fq = os.path.join(d, "single.fq")
+        fastq_matrix(wl.bases, n, L).tofile(fq)
+        out["fastq_gib"] = round(os.path.getsize(fq) / 2**30, 2)
+        with open(fq, "rb") as fh:  # (the first reader of a file just written pays for it; not the runs)
+            while fh.read(1 << 26):
+                pass
+        common = ["--output-all", "--verbose"] + THRESHOLDS
+        if "fastq" in want:
+            out["inputs"]["fastq"] = run_binary(["--ibf", ibf, "--single-reads", fq, "-o", os.path.join(d, "o_fastq")] + common, n, args.runs,
+                                                f"{n} reads x {L} bp, plain FASTQ", deadline)
+        if "gz" in want and time.time() < deadline - 25:
+            ng = n // 4
+            gz = os.path.join(d, "single.fq.gz")
+            t0 = time.time()
+            write_gzip_one_member(gz, fastq_matrix(wl.bases[: ng * L], ng, L, quals=True))
+            r = run_binary(["--ibf", ibf, "--single-reads", gz, "-o", os.path.join(d, "o_gz")] + common, ng, args.runs,
+                           f"{ng} reads x {L} bp, one-member .fq.gz ({os.path.getsize(gz) / 2**30:.2f} GiB, level 6, written in {time.time() - t0:.1f} s)", deadline)
+            out["inputs"]["gz"] = r
+            os.remove(gz)
+        elif "gz" in want:
+            out["skipped"].append("gz")
+        if "paired" in want and time.time() < deadline - 20:
+            npair = n // 2
+            wp = bw.make_device_flat_workload("e2e", bins, rows, h, npair, paired=True, seed=42, shard=1)
+            f1, f2 = os.path.join(d, "pair.1.fq"), os.path.join(d, "pair.2.fq")
+            fastq_matrix(wp.bases[: npair * L], npair, L).tofile(f1)
+            fastq_matrix(wp.bases[npair * L:], npair, L).tofile(f2)
+            del wp
+            out["inputs"]["paired"] = run_binary(["--ibf", ibf, "--paired-reads", f1 + "," + f2, "-o", os.path.join(d, "o_paired")] + common, npair,
+                                                 args.runs, f"{npair} pairs 2 x {L} bp (ends of 400 bp fragments, mate 2 reverse strand), two FASTQ files", deadline)
+            os.remove(f1)
+            os.remove(f2)
+        elif "paired" in want:
+            out["skipped"].append("paired")
+        os.remove(ibf)
+        if "hibf" in want and time.time() < deadline - 25:
+            # two-level HIBF holding the SAME genomes (same seed): 128 merged bins -> 128 children x 128 user bins
+            ub, tmax, rows_top, rows_child, hh = 16384, 128, 1 << 20, 1 << 18, 3
+            hw, hf = bw.make_hibf_device_workload(ganon_amd, "e2e_hibf", ub, tmax, rows_top, rows_child, hh, 1024, seed=42)
+            hp = os.path.join(d, "e2e.hibf")
+            ibf_file.save_hibf(hp, hf, [(b, r, x) for (_, b, r, x) in hw.ibfs], hw.next_ibf_id, hw.bin_to_user, [f"U{u}.1" for u in range(ub)],
+                               hw.k, hw.w, 0.125)
+            hf.free()
+            r = run_binary(["--ibf", hp, "--hibf", "--single-reads", fq, "-o", os.path.join(d, "o_hibf")] + common, n, args.runs,
+                           f"{n} reads x {L} bp, plain FASTQ, against a 2-level HIBF of {ub} user bins ({os.path.getsize(hp) / 2**30:.2f} GiB)", deadline)
+            out["inputs"]["hibf"] = r
+            os.remove(hp)
+        elif "hibf" in want:
+            out["skipped"].append("hibf")
+    finally:
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))
+        os.rmdir(d)
+    out["wall_s"] = round(time.time() - t_start, 1)
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -130,36 +130,73 @@ __global__ void gn_gather_pick_kernel(const uint64_t* seg_off, uint32_t wpr, uin
 
 // direct device-to-device copies need peer access switched on once per ordered pair; without it hipMemcpyPeerAsync still
 // works (the runtime stages the copy), so a refusal is not an error
+// What happened per ordered device pair, for gn_peer_stats: [dst * n + src] = 0 never asked, 1 peer access on (direct copies
+// over the link between the two), 2 not available (the runtime stages the copy through the host); bytes gn_gather moved.
+static std::mutex            g_peer_mu;
+static std::vector<uint8_t>  g_peer_state;
+static std::vector<uint64_t> g_peer_bytes;
+static int                   g_peer_n = 0;
+
+static bool gn_peer_table(int need_a, int need_b)
+{
+    if (g_peer_n == 0)
+    {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            return false;
+        g_peer_n = n;
+        g_peer_state.assign((size_t)n * n, 0);
+        g_peer_bytes.assign((size_t)n * n, 0);
+    }
+    return need_a >= 0 && need_b >= 0 && need_a < g_peer_n && need_b < g_peer_n;
+}
+
 void gn_peer_enable(int dst, int src)
 {
-    static std::mutex           mu;
-    static std::vector<uint8_t> done;
     if (dst == src)
         return;
-    std::lock_guard<std::mutex> lk(mu);
-    int                         n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || dst >= n || src >= n)
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    if (!gn_peer_table(dst, src))
         return;
-    if (done.size() < (size_t)n * n)
-        done.assign((size_t)n * n, 0);
+    const int n = g_peer_n;
     for (int a : { dst, src })
     {
         const int b = a == dst ? src : dst;
-        if (done[(size_t)a * n + b])
+        if (g_peer_state[(size_t)a * n + b])
             continue;
-        done[(size_t)a * n + b] = 1;
+        g_peer_state[(size_t)a * n + b] = 2;
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can)
         {
             int cur = 0;
             hipGetDevice(&cur);
             hipSetDevice(a);
-            hipError_t e = hipDeviceEnablePeerAccess(b, 0);
-            (void)e; // (hipErrorPeerAccessAlreadyEnabled is fine)
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled)
+                g_peer_state[(size_t)a * n + b] = 1;
             (void)hipGetLastError();
             hipSetDevice(cur);
         }
     }
+}
+
+static void gn_peer_count(int dst, int src, uint64_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    if (gn_peer_table(dst, src))
+        g_peer_bytes[(size_t)dst * g_peer_n + src] += bytes;
+}
+
+extern "C" int gn_peer_stats(int dst, int src, int* state, uint64_t* bytes)
+{
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    if (!gn_peer_table(dst, src))
+        return gn_fail(GN_EINVAL, "gn_peer_stats: no device pair (%d, %d)", dst, src);
+    if (state)
+        *state = g_peer_state[(size_t)dst * g_peer_n + src];
+    if (bytes)
+        *bytes = g_peer_bytes[(size_t)dst * g_peer_n + src];
+    return GN_OK;
 }
 
 extern "C" int gn_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes)
@@ -327,6 +364,7 @@ extern "C" int gn_gather_run(gn_gather* g, gn_stream* const* streams, uint32_t n
             if (s->n_matches)
                 GN_HIP(hipMemcpyPeerAsync(g->d_in[i], g->device, src_m, s->device, s->n_matches * sizeof(gn_match), g->st));
             g->peer_bytes += ((uint64_t)n + 1) * 8 + s->n_matches * sizeof(gn_match);
+            gn_peer_count(g->device, s->device, ((uint64_t)n + 1) * 8 + s->n_matches * sizeof(gn_match));
             p.off[i] = g->d_off[i];
             p.in[i]  = g->d_in[i];
         }

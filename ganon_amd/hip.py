@@ -24,7 +24,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
                "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_classify_shared",
                "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
-               "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
+               "gn_peer_stats", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -114,6 +114,7 @@ def load_library():
     L.gn_stream_device_offsets.argtypes = [vp, C.POINTER(vp)]
     L.gn_stream_hibf_levels.argtypes = [vp, C.POINTER(u32), vp, vp, vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
+    L.gn_peer_stats.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(u64)]
     L.gn_reassign_create.argtypes = [i32, u64, u64, u32, vp, vp, C.POINTER(vp)]
     L.gn_reassign_run.argtypes = [vp, u32, C.c_double, C.POINTER(u32)]
     L.gn_reassign_diffs.argtypes = [vp, vp, u32]

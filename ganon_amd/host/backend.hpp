@@ -232,6 +232,9 @@ public:
     virtual std::unique_ptr<Backend> twin() { return nullptr; }
     // Optional.  Where the level's filters were put (replicated / partitioned, which columns on which device), for --verbose.
     virtual std::string placement() const { return std::string(); }
+    // Optional.  What travelled between devices so far (a bin-range partitioned filter's sparse matches on their way to the batch's
+    // home device) and how: one line per device pair, for --verbose.
+    virtual std::string exchange_report() const { return std::string(); }
 };
 
 // devices: indices, or empty = every visible device ("all").  backend_hip.cpp (or the test checker).

@@ -671,6 +671,29 @@ public:
     }
 
     std::string placement() const override { return index_ ? std::string() : set_->placement(); }
+    std::string exchange_report() const override
+    {
+        if (index_ || twin_)
+            return std::string();
+        int n = 0;
+        if (gn_device_count(&n) != GN_OK)
+            return std::string();
+        std::string out;
+        for (int dst = 0; dst < n; ++dst)
+            for (int src = 0; src < n; ++src)
+            {
+                int      state = 0;
+                uint64_t bytes = 0;
+                if (gn_peer_stats(dst, src, &state, &bytes) != GN_OK || (state == 0 && bytes == 0))
+                    continue;
+                out += "device " + std::to_string(src) + " -> " + std::to_string(dst) + ": "
+                       + (dst == src ? "one device (copy path forced by $GANON_HIP_GATHER_COPY)"
+                                     : state == 1 ? "peer access enabled (direct device-to-device copies)" : "no peer access (copies staged by the runtime)")
+                       + ", "
+                       + std::to_string(bytes >> 20) + " MiB of matches gathered\n";
+            }
+        return out;
+    }
 
     // Uncompressed FASTQ as text, records found on the device (csrc/gn_fastq.hip): it takes the parse -- the largest share of the
     // host's CPU seconds -- off the host and costs 2.1x the bytes over the link.  Measured on one MI355X behind a 16-core host

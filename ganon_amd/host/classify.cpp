@@ -1792,6 +1792,18 @@ static bool ganon_classify(Config config)
             }
             if (first_level)
                 read_task.join();
+            if (config.verbose || std::getenv("GANON_HOST_TIMING"))
+                for (auto& b : backends)
+                {
+                    const std::string moved = b->exchange_report();
+                    size_t            at    = 0;
+                    while (at < moved.size())
+                    {
+                        const size_t e = moved.find('\n', at);
+                        std::cerr << "[gather] level " << level.label << ": " << moved.substr(at, e - at) << std::endl;
+                        at = e + 1;
+                    }
+                }
             if (std::getenv("GANON_HOST_TIMING"))
                 std::cerr << "[host stalls] level " << level.label << ": reader blocked on a full batch queue " << queue1.blocked_push()
                           << " s, workers waiting for a batch " << queue1.blocked_pop() << " s (summed), workers waiting for their turn "

@@ -778,6 +778,7 @@ struct ParallelFastq::Impl
     std::map<size_t, Slab>   ready;
     std::vector<Slab>        free_slabs;
     size_t                   next_to_parse = 0, next_to_take = 0, window = 0;
+    uint64_t                 delivered_end = 0; // where the last whole slab handed out by next() ended (= the next slab's first record)
     bool                     stop = false, ended = false;
     bool                     mate_room = false;
     bool                     fasta = false; // records start at lines that begin with '>' (no sequence line can: '>' is no legal letter)
@@ -1011,6 +1012,7 @@ struct ParallelFastq::Impl
             s.rec_at.clear();
             s.error.clear();
             s.irregular = false;
+            s.resume_after_previous = false;
             s.text.clear();
             s.text_at = 0;
             size_t b = 0;
@@ -1039,8 +1041,10 @@ struct ParallelFastq::Impl
             catch (std::exception const&)
             {
                 // the gzip stream is damaged somewhere in this slab's reach: nothing of the slab is kept; the sequential
-                // reader (zlib) takes over at the slab's first record and produces records and message its own way.  (The
-                // first slab in file order that fails has found its first record: that search is the previous slab's end.)
+                // reader (zlib) takes over at the slab's first record and produces records and message its own way.  The
+                // search for that record may itself have run into the damage (it reads ahead in 4 MiB pieces, so whether it
+                // does depends on how those fall): then the record is where the slab before this one ended -- its end IS this
+                // slab's first record -- and next(), which hands slabs out in file order, fills that in.
                 s.ids.clear();
                 s.id_off.assign(1, 0);
                 s.bases.clear();
@@ -1049,6 +1053,7 @@ struct ParallelFastq::Impl
                 s.text.clear();
                 s.irregular = true;
                 s.resume_at = have_b ? b : 0;
+                s.resume_after_previous = !have_b;
             }
             std::lock_guard<std::mutex> lk(m);
             if (last && i + 1 < n_slabs)
@@ -1188,6 +1193,10 @@ bool ParallelFastq::next(Slab& out)
     out     = std::move(it->second);
     s.ready.erase(it);
     ++s.next_to_take;
+    if (out.irregular && out.resume_after_previous)
+        out.resume_at = s.delivered_end; // (0 for the first slab: the file's first record)
+    else if (!out.irregular && out.error.empty())
+        s.delivered_end = !out.text.empty() ? out.text_at + out.text.size() : (out.rec_at.empty() ? s.delivered_end : out.rec_at.back());
     if (!out.error.empty() || out.irregular)
     {
         s.ended = true; // what the other workers parsed beyond this point is dropped

@@ -65,6 +65,7 @@ public:
         std::string           error;       // a ParseError ended the file after the records above
         bool                  irregular = false;
         uint64_t              resume_at = 0; // irregular: byte offset of the first record that was not parsed here
+        bool                  resume_after_previous = false; // (inside the reader: resume_at = where the slab before this one ended)
         size_t                size() const { return off.size() - 1; }
     };
     // nullptr when the file is not eligible (compressed, not FASTQ by extension, smaller than min_bytes, cannot be mapped)

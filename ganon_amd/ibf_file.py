@@ -227,6 +227,57 @@ def save_ibf(path: str, flt, config: dict, hashes_count: Sequence[Tuple[str, int
         stage.free()
 
 
+def save_hibf(path: str, flt, ibfs: Sequence[Tuple[int, int, int]], next_ibf_id, bin_to_user, user_bin_names: Sequence[str], k: int, w: int,
+              fpr: float, chunk_bytes: int = 256 << 20) -> None:
+    """A raptor 3.0.1 index as the reference reads it (GanonClassify.cpp:884-901, hibf.hpp:163-169,293-298) from a
+    device-resident HIBF: ibfs[i] = (bins, rows, hash_funs) of IBF i, rows downloaded chunk by chunk.  user_bin_names[u] becomes the
+    one file of user bin u (`<name>.minimiser`, with '.' spelt '|||' as raptor's callers do)."""
+    L = hip.load_library()
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", 1))
+        f.write(struct.pack("<Q", w))
+        f.write(struct.pack("<QQ", k, (1 << k) - 1))     # seqan3::shape: size, bits
+        f.write(struct.pack("<BB", 1, 0))                # parts, compressed
+        f.write(struct.pack("<Q", len(user_bin_names)))
+        files = []
+        for n in user_bin_names:
+            fn = ("/db/" + n.replace(".", "|||").replace(" ", "---") + ".minimiser").encode()
+            files.append(fn)
+            f.write(struct.pack("<QQ", 1, len(fn)) + fn)
+        f.write(struct.pack("<d", fpr))
+        f.write(struct.pack("<B", 1))                    # is_hibf
+        f.write(struct.pack("<Q", len(ibfs)))
+        stage = None
+        try:
+            for i, (bins, rows, h) in enumerate(ibfs):
+                W = (bins + 63) >> 6
+                f.write(struct.pack("<6Q", bins, W * 64, rows, 64 - int(rows).bit_length(), W, h))
+                f.write(struct.pack("<BfQ", 1, 1.5, W * 64 * rows))
+                row_bytes = W * 8
+                per = max(1, min(chunk_bytes, rows * row_bytes) // row_bytes)
+                if stage is None or stage.arr.size < per * row_bytes:
+                    if stage is not None:
+                        stage.free()
+                    stage = _Pinned(max(per * row_bytes, min(chunk_bytes, 16 << 20)))
+                for row in range(0, rows, per):
+                    n = min(per, rows - row)
+                    buf = stage.arr[: n * row_bytes]
+                    hip._check(L.gn_filter_download_rows(flt._h, i, row, n, buf.ctypes.data_as(C.c_void_p)))
+                    f.write(memoryview(buf))
+        finally:
+            if stage is not None:
+                stage.free()
+        f.write(struct.pack("<Q", len(next_ibf_id)))
+        for a in next_ibf_id:
+            f.write(struct.pack("<Q", len(a)) + np.ascontiguousarray(a, dtype="<i8").tobytes())
+        f.write(struct.pack("<Q", len(files)))
+        for fn in files:
+            f.write(struct.pack("<Q", len(fn)) + fn)
+        f.write(struct.pack("<Q", len(bin_to_user)))
+        for a in bin_to_user:
+            f.write(struct.pack("<Q", len(a)) + np.ascontiguousarray(a, dtype="<i8").tobytes())
+
+
 def bloom_bin_size(n_hashes: int, max_fp: float, hash_funs: int) -> int:
     """bits of one Bloom filter holding n_hashes at false-positive rate max_fp with hash_funs functions (textbook formula)"""
     return int(math.ceil(n_hashes * (-hash_funs / math.log(1.0 - math.exp(math.log(max_fp) / hash_funs)))))

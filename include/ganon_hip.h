@@ -283,6 +283,10 @@ int gn_gather_fetch(gn_gather* g, uint64_t* match_off, gn_match* matches, uint64
 int gn_gather_device_matches(gn_gather* g, const gn_match** d_matches, const uint64_t** d_match_off, uint64_t* n_matches,
                              uint64_t* peer_bytes);
 int gn_gather_destroy(gn_gather* g);
+/* What gn_gather did between devices so far, per ordered pair (dst = the gathering device): *state = 0 never needed, 1 peer
+ * access enabled (hipDeviceEnablePeerAccess: direct copies over the xGMI link of the pair), 2 refused or not available (the
+ * runtime stages the copy); *bytes = what travelled src -> dst.  `ganon-classify --verbose` prints it per pair. */
+int gn_peer_stats(int dst, int src, int* state, uint64_t* bytes);
 /* free / total memory of a device: the host decides with it whether a filter is replicated or partitioned */
 int gn_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 

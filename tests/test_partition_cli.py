@@ -56,6 +56,8 @@ def test_filter_over_budget_is_partitioned_and_changes_no_output_byte(oracle_bin
         _same(out, whole)
         if "GANON_HIP_GATHER_COPY" in env:
             assert "moved between devices" in p.stderr
+            # per device pair: how the matches travelled and how many bytes (on a node with several GPUs: "peer access enabled")
+            assert "[gather] level" in p.stderr and "MiB of matches gathered" in p.stderr, p.stderr[-800:]
         assert ("tokenised on the device" in p.stderr) == (name == "text"), p.stderr[-500:]
     # without the budget the same command line replicates (one copy: the entries name one GPU)
     p = _run(cu.BIN_HIP, wide_db, str(tmp_path / "repl"), ["--device", "0,0,0"], {"GANON_HOST_TIMING": "1"})

@@ -520,3 +520,36 @@ def test_parallel_gzip_equals_sequential_reader(oracle_bin, sim_db, tmp_path, pa
                                             dict(env, GANON_HOST_NO_PGZIP="1"))
         assert off_out == seq_out
     assert broken or seq_out[".all"].count(b"\n") > 300   # (zlib hands out nothing of the buffer an error turns up in)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_gzip_damaged_far_into_the_stream_equals_sequential_reader(oracle_bin, sim_db, tmp_path, paired):
+    # The damage lies more than 8 MiB into the decompressed stream, the slabs are small and two parsers take adjacent ones: a
+    # slab's search for its first record can run into the damage while the slab before it came out whole (the search reads
+    # ahead in 4 MiB pieces).  The sequential reader must then take over where that slab ended -- not at the file's start,
+    # which delivered every read before the damage twice (and misaligned the mates of a pair).
+    import gzip
+    import numpy as np
+    rng = np.random.default_rng(31)
+    g = list(sim_db["targets"].values())
+    n = 52_000
+    recs1, recs2 = [], []
+    for i in range(n):
+        src = g[i % len(g)] if i % 4 else "".join("ACGT"[x] for x in rng.integers(0, 4, size=400))
+        p = int(rng.integers(0, len(src) - 310))
+        recs1.append((f"SRR000009.{i} {i} length=150", src[p:p + 150]))
+        recs2.append((f"SRR000009.{i}/2", src[p + 150:p + 300][::-1].translate(str.maketrans("ACGT", "TGCA"))))
+    t1, t2 = _fastq_text(recs1).encode(), _fastq_text(recs2).encode()
+    assert len(t1) > 14 << 20
+    z1, z2 = gzip.compress(t1, 1), gzip.compress(t2, 1)
+    f1, f2 = str(tmp_path / "r1.fq.gz"), str(tmp_path / "r2.fq.gz")
+    open(f1, "wb").write(z1[: int(len(z1) * 0.9)])                     # truncated ~13 MiB into the text
+    open(f2, "wb").write(z2 if not paired else z2[: int(len(z2) * 0.95)])
+    files = [f1, f2] if paired else [f1]
+    seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], files, str(tmp_path / "seq"), paired, {"GANON_HOST_PARSE_THREADS": "0"})
+    assert "Error parsing" in seq_err and seq_out[".all"].count(b"\n") > 10_000
+    for slab, threads in (("65536", "2"), ("3000000", "2"), ("1000000", "5")):
+        env = {"GANON_HOST_PARSE_THREADS": threads, "GANON_HOST_SLAB_BYTES": slab, "GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_INFLATE_THREADS": "3"}
+        par_err, par_out = _run_reader_case(oracle_bin, sim_db["ibf"], files, str(tmp_path / f"par{slab}_{threads}"), paired, env)
+        assert par_out == seq_out, (slab, threads, par_out[".all"].count(b"\n"), seq_out[".all"].count(b"\n"))
+        assert "Error parsing" in par_err
