@@ -8,6 +8,9 @@ for p in (os.path.dirname(HERE), HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+if len(sys.argv) > 4 and sys.argv[4] == "torch":  # PyTorch's bundled HIP runtime in the process first, as under pytest and in bench.py
+    import torch  # noqa: E402
+    torch.cuda.is_available()
 import ganon_amd  # noqa: E402
 import test_build_gpu as t  # noqa: E402
 
