@@ -171,7 +171,7 @@ def main() -> int:
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--extra-timeout", type=int, default=420)
     ap.add_argument("--no-e2e", action="store_true", help="do not run the product binary end to end after the kernels (bench_e2e.py)")
-    ap.add_argument("--e2e-budget", type=int, default=150, help="seconds the end-to-end leg may take")
+    ap.add_argument("--e2e-budget", type=int, default=200, help="seconds the end-to-end leg may take")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s)")
     ap.add_argument("--check", type=int, default=2000, help="reads re-checked against the oracle (rank 0)")
     args = ap.parse_args()

@@ -10,10 +10,11 @@ genomes the filter holds, mate 2 the reverse strand of the same fragment):
   paired   two FASTQ files, 2 x 150 bp ends of 400 bp fragments, same filter
   gz       single-end .fq.gz -- ONE gzip member whose deflate blocks reference the 32 KiB before them, as gzip / pigz write it
            (written here in parallel with zlib's preset-dictionary interface, which produces exactly that), binned qualities
+  fasta    the same reads as a FASTA file (two lines per record), same filter
   hibf     the plain FASTQ against a two-level HIBF (16 384 user bins) that holds the same genomes: level 1 is visited
 
 Every input runs `--runs` times (default 5); median, min and max are reported with `#total_classified` of the .rep.
-usage: python bench_e2e.py [--runs 5] [--reads 8000000] [--dir /dev/shm] [--budget 150]   -> one JSON line
+usage: python bench_e2e.py [--runs 5] [--reads 16000000] [--dir /dev/shm] [--budget 150]   -> one JSON line
 """
 from __future__ import annotations
 
@@ -129,10 +130,10 @@ def run_binary(args, n_units, runs, label, deadline):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--runs", type=int, default=5)
-    ap.add_argument("--reads", type=int, default=8_000_000, help="single-end reads (pairs: half of it, .gz reads: a quarter)")
+    ap.add_argument("--reads", type=int, default=16_000_000, help="single-end reads (pairs: half of it, .gz reads: a quarter)")
     ap.add_argument("--dir", default="/dev/shm")
-    ap.add_argument("--budget", type=float, default=150.0, help="seconds; inputs that no longer fit are left out and named")
-    ap.add_argument("--only", default="", help="comma-separated subset of fastq,paired,gz,hibf")
+    ap.add_argument("--budget", type=float, default=200.0, help="seconds; inputs that no longer fit are left out and named")
+    ap.add_argument("--only", default="", help="comma-separated subset of fastq,paired,gz,fasta,hibf")
     args = ap.parse_args()
 
     import bench_workload as bw
@@ -141,7 +142,7 @@ def main() -> int:
 
     t_start = time.time()
     deadline = t_start + args.budget
-    want = [w for w in (args.only.split(",") if args.only else ["fastq", "paired", "gz", "hibf"]) if w]
+    want = [w for w in (args.only.split(",") if args.only else ["fastq", "paired", "gz", "fasta", "hibf"]) if w]
     d = os.path.join(args.dir, f"ganon_e2e_{os.getpid()}")
     os.makedirs(d, exist_ok=True)
     out = {"thresholds": " ".join(THRESHOLDS), "dir": args.dir, "runs_requested": args.runs, "inputs": {}, "skipped": []}
@@ -171,6 +172,17 @@ def main() -> int:
         if "fastq" in want:
             out["inputs"]["fastq"] = run_binary(["--ibf", ibf, "--single-reads", fq, "-o", os.path.join(d, "o_fastq")] + common, n, args.runs,
                                                 f"{n} reads x {L} bp, plain FASTQ", deadline)
+        if "fasta" in want and time.time() < deadline - 15:
+            fa = os.path.join(d, "single.fa")
+            m = fastq_matrix(wl.bases, n, L)[:, :12 + L + 1].copy()   # `@id \n letters \n` of every record, '@' -> '>'
+            m[:, 0] = ord(">")
+            m.tofile(fa)
+            del m
+            out["inputs"]["fasta"] = run_binary(["--ibf", ibf, "--single-reads", fa, "-o", os.path.join(d, "o_fasta")] + common, n, args.runs,
+                                                f"{n} reads x {L} bp, FASTA (one line of letters per record)", deadline)
+            os.remove(fa)
+        elif "fasta" in want:
+            out["skipped"].append("fasta")
         if "gz" in want and time.time() < deadline - 25:
             ng = n // 4
             gz = os.path.join(d, "single.fq.gz")

@@ -110,16 +110,22 @@ __global__ __launch_bounds__(256) void gn_fq_lines_kernel(const uint8_t* __restr
 }
 
 // fq: [0] lines [1] first record that does not pass [2] records of the batch [3] their bases [4] bytes they cover [5] lines past capacity
+// FASTA = false: groups of four lines  @id / letters / +... / quality.
+// FASTA = true:  groups of two lines   >id / letters  -- a record whose letters are on ONE line, followed by the next record's '>'
+//                (or by the end of the text); wrapped sequences, blank lines, ';' headers end the batch like any other record
+//                the rule does not cover (the host's sequential reader takes it from there, white space, digits and all).
+template <bool FASTA>
 __global__ __launch_bounds__(256) void gn_fq_records_kernel(const uint8_t* __restrict__ text, const uint32_t* __restrict__ nl,
                                                             const uint32_t* __restrict__ n_lines_at, uint32_t max_reads, uint32_t n_threads,
-                                                            uint32_t* __restrict__ rec_at, uint32_t* __restrict__ seq_at,
+                                                            uint64_t n_bytes, uint32_t* __restrict__ rec_at, uint32_t* __restrict__ seq_at,
                                                             uint32_t* __restrict__ seq_len, unsigned long long* __restrict__ fq)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t LPR = FASTA ? 2u : 4u; // lines per record
+    const uint32_t     r   = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_threads)
         return;
     const uint32_t n_lines = *n_lines_at;
-    uint32_t       n_rec   = n_lines >> 2;
+    uint32_t       n_rec   = n_lines / LPR;
     if (n_rec > max_reads)
         n_rec = max_reads;
     if (r == 0)
@@ -129,12 +135,22 @@ __global__ __launch_bounds__(256) void gn_fq_records_kernel(const uint8_t* __res
         seq_len[r] = 0; // (scan input up to n_threads)
         return;
     }
-    const uint32_t p0 = r ? nl[4 * r - 1] + 1u : 0u;
-    const uint32_t a = nl[4 * r], b = nl[4 * r + 1], c = nl[4 * r + 2], d = nl[4 * r + 3];
+    const uint32_t p0 = r ? nl[LPR * r - 1] + 1u : 0u;
+    const uint32_t a = nl[LPR * r], b = nl[LPR * r + 1];
     uint32_t       slen = b - a - 1u;
     if (slen && text[b - 1] == '\r')
         --slen;
-    const bool ok = a > p0 && text[p0] == '@' && c > b + 1u && text[b + 1] == '+' && d - c - 1u == slen;
+    bool ok;
+    if (FASTA)
+    {
+        const uint8_t first = a + 1u < b ? text[a + 1] : (uint8_t)'A';
+        ok = a > p0 && text[p0] == '>' && first != '>' && first != ';' && ((uint64_t)b + 1u >= n_bytes || text[b + 1] == '>');
+    }
+    else
+    {
+        const uint32_t c = nl[4 * r + 2], d = nl[4 * r + 3];
+        ok = a > p0 && text[p0] == '@' && c > b + 1u && text[b + 1] == '+' && d - c - 1u == slen;
+    }
     rec_at[r]  = p0;
     seq_at[r]  = a + 1u;
     seq_len[r] = ok ? slen : 0u;
@@ -150,15 +166,20 @@ __global__ __launch_bounds__(256) void gn_fq_records_kernel(const uint8_t* __res
 // one wave per record: letters back to back into `bases`, checked on the way
 __global__ __launch_bounds__(256) void gn_fq_copy_kernel(const uint8_t* __restrict__ text, const uint32_t* __restrict__ seq_at,
                                                          const uint32_t* __restrict__ seq_len, const uint64_t* __restrict__ off,
-                                                         const unsigned long long* fq_lines, uint32_t max_reads,
+                                                         const unsigned long long* fq_lines, uint32_t max_reads, uint32_t bound, uint32_t lpr,
                                                          uint8_t* __restrict__ bases, unsigned long long* fq)
 {
     const uint32_t lane    = threadIdx.x & 63u;
     const uint32_t wave    = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    uint32_t       n_rec   = (uint32_t)(fq_lines[0] >> 2);
+    uint32_t       n_rec   = (uint32_t)(fq_lines[0] / lpr);
     if (n_rec > max_reads)
         n_rec = max_reads;
+    // The records kernel and the scan looked at `bound` groups of four lines (no more records of >= 6 bytes fit the text).  Text
+    // that is mostly blank lines has more groups than that; one of the first `bound` is then too short to be a record and has
+    // ended the batch already -- what lies beyond was never written (seq_len / seq_at / off) and is not touched here.
+    if (n_rec > bound)
+        n_rec = bound;
     for (uint32_t r = wave; r < n_rec; r += n_waves)
     {
         const uint32_t len = seq_len[r];
@@ -178,16 +199,16 @@ __global__ __launch_bounds__(256) void gn_fq_copy_kernel(const uint8_t* __restri
 }
 
 __global__ void gn_fq_finish_kernel(const uint32_t* __restrict__ nl, const uint64_t* __restrict__ off, uint32_t max_reads, uint64_t n_bytes,
-                                    unsigned long long* __restrict__ fq)
+                                    uint32_t lpr, unsigned long long* __restrict__ fq)
 {
     const uint64_t n_lines = fq[0];
-    uint64_t       n_rec   = n_lines >> 2;
+    uint64_t       n_rec   = n_lines / lpr;
     if (n_rec > max_reads)
         n_rec = max_reads;
     const uint64_t v = fq[1] < n_rec ? fq[1] : n_rec;
     fq[2]            = v;
     fq[3]            = off[v];
-    fq[4]            = v ? (uint64_t)nl[4 * v - 1] + 1u : 0u;
+    fq[4]            = v ? (uint64_t)nl[lpr * v - 1] + 1u : 0u;
     fq[5]            = n_bytes;
 }
 
@@ -247,8 +268,17 @@ static int gn_fastq_prepare(gn_stream* s)
 
 extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_t n_bytes)
 {
+    return gn_stream_upload_text(s, text, n_bytes, GN_TEXT_FASTQ);
+}
+
+extern "C" int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t n_bytes, int format)
+{
     if (!s || (!text && n_bytes))
-        return gn_fail(GN_EINVAL, "gn_stream_upload_fastq: null argument");
+        return gn_fail(GN_EINVAL, "gn_stream_upload_text: null argument");
+    if (format != GN_TEXT_FASTQ && format != GN_TEXT_FASTA)
+        return gn_fail(GN_EINVAL, "gn_stream_upload_text: format %d", format);
+    const bool     fasta = format == GN_TEXT_FASTA;
+    const uint32_t lpr   = fasta ? 2u : 4u;
     if (n_bytes > s->max_bases || n_bytes >= 0xFFFFFFF0ull)
         return gn_fail(GN_EINVAL, "FASTQ text of %llu bytes exceeds the stream capacity (%llu bytes)", (unsigned long long)n_bytes,
                        (unsigned long long)s->max_bases);
@@ -303,16 +333,20 @@ extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_
     GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_fq_scan, tmp, cnt, toff, (int)(tiles + 1), st));
     if (tiles)
         hipLaunchKernelGGL(gn_fq_lines_kernel, dim3(tiles), dim3(256), 0, st, s->d_text, n_bytes, toff, s->d_fq_nl, s->fq_nl_cap);
-    // a four-line record is at least 6 bytes ("@\n\n+\n\n" is not even legal): bound of the per-record launches
-    const uint32_t bound = (uint32_t)std::min<uint64_t>(s->max_reads, n_bytes / 6) + 1u;
-    hipLaunchKernelGGL(gn_fq_records_kernel, dim3((bound + 255) / 256), dim3(256), 0, st, s->d_text, s->d_fq_nl, toff + tiles, s->max_reads, bound,
-                       s->d_fq_rec, s->d_fq_seq, s->d_fq_len, s->d_fq);
+    // a four-line record is at least 6 bytes ("@\n\n+\n\n" is not even legal), a two-line one 3 (">\n\n"): bound of the per-record launches
+    const uint32_t bound = (uint32_t)std::min<uint64_t>(s->max_reads, n_bytes / (fasta ? 3 : 6)) + 1u;
+    if (fasta)
+        hipLaunchKernelGGL(gn_fq_records_kernel<true>, dim3((bound + 255) / 256), dim3(256), 0, st, s->d_text, s->d_fq_nl, toff + tiles, s->max_reads,
+                           bound, n_bytes, s->d_fq_rec, s->d_fq_seq, s->d_fq_len, s->d_fq);
+    else
+        hipLaunchKernelGGL(gn_fq_records_kernel<false>, dim3((bound + 255) / 256), dim3(256), 0, st, s->d_text, s->d_fq_nl, toff + tiles, s->max_reads,
+                           bound, n_bytes, s->d_fq_rec, s->d_fq_seq, s->d_fq_len, s->d_fq);
     tmp = s->fq_scan_bytes;
     GN_HIP(gn_scan_counts(s->d_fq_scan, tmp, s->d_fq_len, s->d_off1, (int)bound, st));
     const uint32_t blocks = std::min<uint32_t>((bound + 3) / 4, (uint32_t)s->f->n_cu * 8u);
-    hipLaunchKernelGGL(gn_fq_copy_kernel, dim3(blocks), dim3(256), 0, st, s->d_text, s->d_fq_seq, s->d_fq_len, s->d_off1, s->d_fq, s->max_reads,
+    hipLaunchKernelGGL(gn_fq_copy_kernel, dim3(blocks), dim3(256), 0, st, s->d_text, s->d_fq_seq, s->d_fq_len, s->d_off1, s->d_fq, s->max_reads, bound, lpr,
                        s->d_bases, s->d_fq);
-    hipLaunchKernelGGL(gn_fq_finish_kernel, dim3(1), dim3(1), 0, st, s->d_fq_nl, s->d_off1, s->max_reads, n_bytes, s->d_fq);
+    hipLaunchKernelGGL(gn_fq_finish_kernel, dim3(1), dim3(1), 0, st, s->d_fq_nl, s->d_off1, s->max_reads, n_bytes, lpr, s->d_fq);
     GN_HIP(hipMemcpyAsync(s->h_fq, s->d_fq, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     GN_HIP(hipGetLastError());
     if (probe)

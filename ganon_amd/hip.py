@@ -24,7 +24,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
                "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_classify_shared",
                "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
-               "gn_peer_stats", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
+               "gn_peer_stats", "gn_stream_upload_text", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -91,6 +91,7 @@ def load_library():
     L.gn_stream_sync.argtypes = [vp]
     L.gn_stream_classify_shared.argtypes = [vp, vp, C.c_double]
     L.gn_stream_upload_fastq.argtypes = [vp, vp, u64]
+    L.gn_stream_upload_text.argtypes = [vp, vp, u64, i32]
     L.gn_stream_fastq_index.argtypes = [vp, C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
     L.gn_stream_fastq_keep.argtypes = [vp, u32]
     L.gn_stream_fastq_records.argtypes = [vp, vp, vp, vp]
@@ -393,13 +394,13 @@ class HipStream:
         self.upload(bases, off1, off2)
         self.classify(k, w, rel_cutoff)
 
-    def upload_fastq(self, text) -> Tuple[int, int, int]:
-        """four-line FASTQ text, tokenised on the device (gn_stream_upload_fastq + gn_stream_fastq_index):
+    def upload_fastq(self, text, fasta: bool = False) -> Tuple[int, int, int]:
+        """four-line FASTQ text (or two-line FASTA text), tokenised on the device (gn_stream_upload_text + gn_stream_fastq_index):
         -> (reads, bases, parsed_bytes); the stream then holds the reads like after upload()"""
         text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text, dtype=np.uint8)
         self._keep = (text,)
         L = load_library()
-        _check(L.gn_stream_upload_fastq(self._h, _p(text), text.size))
+        _check(L.gn_stream_upload_text(self._h, _p(text), text.size, 1 if fasta else 0))
         n, nb, pb = C.c_uint32(), C.c_uint64(), C.c_uint64()
         _check(L.gn_stream_fastq_index(self._h, C.byref(n), C.byref(nb), C.byref(pb)))
         self.n_reads = n.value

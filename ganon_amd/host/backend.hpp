@@ -106,6 +106,7 @@ struct ReadBatch
     // the file that begins with a record; Backend::tokenise finds the records, Backend::classify fills rec_at / seq_at / seq_len
     // for the `raw_keep` records the batch consists of.  Ids and letters are read where they lie in `text`.
     bool                       raw = false;
+    bool                       raw_fasta = false; // the text is two-line FASTA (>id / letters), not four-line FASTQ
     ByteBuf                    text;
     uint64_t                   text_at = 0;  // offset of text[0] in the file
     uint32_t                   raw_keep = 0; // records of the batch (set by the pipeline between tokenise and classify)

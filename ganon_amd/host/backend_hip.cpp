@@ -738,7 +738,7 @@ public:
                     sec_create_ += std::chrono::duration<double>(now - t).count();
                     t = now;
                 }
-                if (gn_stream_upload_fastq(part.s, b.text.data(), nb) != GN_OK)
+                if (gn_stream_upload_text(part.s, b.text.data(), nb, b.raw_fasta ? GN_TEXT_FASTA : GN_TEXT_FASTQ) != GN_OK)
                 {
                     err = gn_last_error();
                     return false;

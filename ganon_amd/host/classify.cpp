@@ -506,6 +506,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     rb.id_off.assign(1, 0);
                     rb.bases.clear();
                     rb.raw = false;
+                    rb.raw_fasta = false;
                     rb.text.clear();
                     rb.rec_at.clear();
                     rb.seq_at.clear();
@@ -565,6 +566,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                         if (!a.text.empty())
                         {
                             rb.raw = true;
+                            rb.raw_fasta = pfr->fasta();
                             rb.text.swap(a.text); // (a recycled batch's buffer goes back to the slab readers)
                             rb.text_at  = a.text_at;
                             rb.raw_keep = 0;

@@ -1097,7 +1097,7 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     // (text for the device only from plain files.  An ordinary gzip file's decompressed stream can go the same way -- read_text and the
     //  border search below take it -- but measured it is slower: 15-18 against 23-30 Mreads/s; the run is bound by the inflate threads,
     //  which the parse does not hold up, and the raw mode's short window makes them pause)
-    if (raw && (is_gzip || fasta))
+    if (raw && is_gzip)
     {
         ::close(fd);
         return nullptr;
@@ -1172,6 +1172,8 @@ ParallelFastq::~ParallelFastq()
         ::munmap(const_cast<char*>(s.map), s.size);
     ::close(s.fd);
 }
+
+bool ParallelFastq::fasta() const { return impl_->fasta; }
 
 void ParallelFastq::recycle(Slab&& used)
 {

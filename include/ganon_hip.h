@@ -185,6 +185,12 @@ int gn_stream_classify_shared(gn_stream* s, gn_stream* source, double rel_cutoff
  *   gn_stream_fastq_records per read: offset of its record ('@'), of its first letter, and its number of letters, in `text`
  *                           (any may be NULL; waits for the stream) -- ids and letters stay where they are, in the caller's text */
 int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_t n_bytes);
+/* The same for either text format.  GN_TEXT_FASTA: records of two lines,  >id / letters  -- every record's letters on one line and
+ * the next line a '>' (or the end of the text); a wrapped sequence, a blank line or a ';' header ends the batch before its record,
+ * like a FASTQ record the four-line rule does not cover.  gn_stream_fastq_index / _keep / _records apply unchanged (rec_at = the '>'). */
+#define GN_TEXT_FASTQ 0
+#define GN_TEXT_FASTA 1
+int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t n_bytes, int format);
 int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* n_bases, uint64_t* parsed_bytes);
 int gn_stream_fastq_keep(gn_stream* s, uint32_t n_reads);
 int gn_stream_fastq_records(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len);

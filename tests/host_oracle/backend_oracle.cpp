@@ -99,7 +99,28 @@ public:
             const void* q = p < n ? std::memchr(t + p, '\n', n - p) : nullptr;
             return q ? (size_t)((const uint8_t*)q - t) : n;
         };
-        while (pos < n)
+        while (pos < n && b.raw_fasta) // two-line records: >id / letters, then a '>' or the end of the text
+        {
+            const size_t a = line_end(pos);
+            if (a == n || a == pos || t[pos] != '>')
+                break;
+            const size_t bnl = line_end(a + 1);
+            if (bnl == n)
+                break;
+            size_t len = bnl - a - 1;
+            if (len && t[bnl - 1] == '\r')
+                --len;
+            bool ok = !(bnl > a + 1 && (t[a + 1] == '>' || t[a + 1] == ';')) && (bnl + 1 >= n || t[bnl + 1] == '>');
+            for (size_t i = 0; i < len && ok; ++i)
+                ok = legal.ok[t[a + 1 + i]];
+            if (!ok)
+                break;
+            tok_rec_.push_back((uint32_t)pos);
+            tok_seq_.push_back((uint32_t)(a + 1));
+            tok_len_.push_back((uint32_t)len);
+            pos = bnl + 1;
+        }
+        while (pos < n && !b.raw_fasta)
         {
             const size_t a = line_end(pos);
             if (a == n || a == pos || t[pos] != '@')

@@ -122,7 +122,7 @@ def test_regular_text_and_what_follows_equals_the_packed_upload(hip):
 
 @pytest.mark.parametrize("case", ["crlf", "no_final_newline", "truncated", "illegal_letter", "wrapped", "blank_line", "plus_missing", "quality_short",
                                   "quality_long", "at_missing", "empty_text", "only_newlines", "first_record_bad", "empty_sequences",
-                                  "cr_in_letters_only", "text_is_one_line", "lone_at"])
+                                  "cr_in_letters_only", "text_is_one_line", "lone_at", "trailing_newlines"])
 def test_stops_where_the_slab_parser_stops(hip, case):
     rng = np.random.default_rng(11)
     flt, _ = (hip.HipFilter.ibf(*(lambda i: (i.data, i.bins, i.bin_size, i.hash_funs))(gf.random_ibf(64, 257, 3, 0.3, 1))), None)
@@ -168,9 +168,15 @@ def test_stops_where_the_slab_parser_stops(hip, case):
         text = b"".join(b"@" + i + b"\n" + s + b"\r\n+\n" + q + b"\n" for i, s, p, q in recs)
     elif case == "text_is_one_line":
         text = b"@" + b"A" * 10000
+    elif case == "trailing_newlines":
+        # more groups of four lines than records of six bytes fit the text: the per-record arrays beyond that bound are never
+        # written, and nothing may be read from them (the stream is large enough for every group to count as a record)
+        text = fastq(recs[:50]) + b"\n" * 300_000
     else:
         text = fastq(recs[:5]) + b"@\n"
-    st, exp = check(hip, flt, text, note=case)
+    st, exp = check(hip, flt, text, max_reads=200_000 if case == "trailing_newlines" else None, note=case)
+    if case == "trailing_newlines":
+        assert len(exp[0]) == 50 and exp[3] == len(fastq(recs[:50]))
     if case in ("truncated", "illegal_letter", "wrapped", "blank_line", "plus_missing", "quality_short", "quality_long", "at_missing"):
         assert len(exp[0]) == 120 and exp[3] == cut
     if case in ("crlf", "first_record_bad", "empty_text", "only_newlines", "text_is_one_line"):
@@ -207,4 +213,108 @@ def test_large_text_tile_borders_and_the_stream_capacity(hip):
     with pytest.raises(Exception):
         s.upload_fastq(text)
     s.destroy()
+    flt.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------- FASTA
+def expected_fasta_records(text: bytes, max_reads: int = 1 << 30):
+    """the two-line rule of GN_TEXT_FASTA: >id / letters on one line / then a '>' or the end of the text"""
+    rec, seq, ln = [], [], []
+    pos, n = 0, len(text)
+    while pos < n and len(rec) < max_reads:
+        a = text.find(b"\n", pos)
+        if a < 0 or a == pos or text[pos] != ord(">"):
+            break
+        b = text.find(b"\n", a + 1)
+        if b < 0:
+            break
+        end = b - 1 if b > a + 1 and text[b - 1] == 0x0D else b
+        letters = text[a + 1:end]
+        if b > a + 1 and text[a + 1] in b">;":
+            break
+        if any(c not in LEGAL for c in letters):
+            break
+        if b + 1 < n and text[b + 1] != ord(">"):
+            break
+        rec.append(pos)
+        seq.append(a + 1)
+        ln.append(len(letters))
+        pos = b + 1
+    return np.array(rec, dtype=np.uint32), np.array(seq, dtype=np.uint32), np.array(ln, dtype=np.uint32), pos
+
+
+def fasta(records, eol=b"\n"):
+    return b"".join(b">" + i + eol + s + eol for i, s in records)
+
+
+@pytest.mark.parametrize("case", ["plain", "crlf_ids_only", "crlf", "wrapped_in_the_middle", "blank_line", "semicolon", "illegal_letter", "no_final_newline",
+                                  "empty_sequences", "header_only_at_end", "first_line_no_header", "digits_and_spaces", "empty_text", "capacity"])
+def test_fasta_text_two_line_records(hip, case):
+    rng = np.random.default_rng(17)
+    ibf = gf.random_ibf(64, 4099, 3, 0.4, 2)
+    flt = hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs)
+    recs = [(b"read%d some words" % i, gu.random_seq(rng, int(rng.integers(1, 300)), b"ACGTNacgtRYKM")) for i in range(2500)]
+    good = fasta(recs)
+    cut = len(fasta(recs[:1200]))
+    max_reads = None
+    if case == "plain":
+        text = good
+    elif case == "crlf":
+        text = fasta(recs, b"\r\n")
+    elif case == "crlf_ids_only":
+        text = b"".join(b">" + i + b"\r\n" + s + b"\n" for i, s in recs)
+    elif case == "wrapped_in_the_middle":
+        i, s = recs[1200]
+        s = s + b"ACGTACGTAC"
+        text = fasta(recs[:1200]) + b">" + i + b"\n" + s[:5] + b"\n" + s[5:] + b"\n" + fasta(recs[1201:])
+    elif case == "blank_line":
+        text = fasta(recs[:1201]) + b"\n" + fasta(recs[1201:])   # the record BEFORE the blank line is not followed by '>': not taken
+    elif case == "semicolon":
+        text = fasta(recs[:1201]) + b";comment\nACGT\n" + fasta(recs[1201:])
+    elif case == "illegal_letter":
+        i, s = recs[1200]
+        text = fasta(recs[:1200]) + fasta([(i, s[:1] + b"!" + s[1:])]) + fasta(recs[1201:])
+    elif case == "no_final_newline":
+        text = good[:-1]
+    elif case == "empty_sequences":
+        text = fasta([(b"a", b""), (b"b", b"ACGT"), (b"c", b"")] * 100)
+    elif case == "header_only_at_end":
+        text = fasta(recs[:10]) + b">lonely\n"
+    elif case == "first_line_no_header":
+        text = b"ACGT\n" + good
+    elif case == "digits_and_spaces":
+        i, s = recs[1200]
+        text = fasta(recs[:1200]) + b">" + i + b"\n" + s[:4] + b" 10 " + s[4:] + b"\n" + fasta(recs[1201:])
+    elif case == "empty_text":
+        text = b""
+    else:
+        text, max_reads = good, 700
+    exp = expected_fasta_records(text, max_reads if max_reads else 1 << 30)
+    st = hip.HipStream(flt, max_reads if max_reads else max(len(exp[0]) + 8, 16), max(len(text) + 64, 256))
+    n, nb, parsed = st.upload_fastq(text, fasta=True)
+    assert (n, parsed, nb) == (len(exp[0]), exp[3], int(exp[2].sum())), case
+    rec_at, seq_at, seq_len = st.fastq_records()
+    assert np.array_equal(rec_at, exp[0]) and np.array_equal(seq_at, exp[1]) and np.array_equal(seq_len, exp[2]), case
+    if case in ("wrapped_in_the_middle", "semicolon", "illegal_letter", "digits_and_spaces"):
+        assert n == 1200 and parsed == cut
+    if case == "blank_line":
+        assert n == 1200   # (record 1200 is followed by a blank line, not by a header)
+    if case in ("plain", "crlf", "crlf_ids_only", "empty_sequences"):
+        assert parsed == len(text)
+    if case == "no_final_newline":
+        assert n == 2499
+    if case in ("first_line_no_header", "empty_text"):
+        assert n == 0 and parsed == 0
+    if case == "header_only_at_end":
+        assert n == 10
+    if case == "plain":   # what is classified afterwards equals the packed upload of the same reads
+        st.classify(19, 31, 0.1)
+        nh, status, mo, m = st.fetch()
+        bases, off1, _ = gu.pack_reads([s for _, s in recs], None)
+        s2 = hip.HipStream(flt, len(recs), bases.size)
+        s2.submit(bases, off1, None, 19, 31, 0.1)
+        nh2, status2, mo2, m2 = s2.fetch()
+        assert np.array_equal(nh, nh2) and np.array_equal(status, status2) and np.array_equal(mo, mo2) and np.array_equal(m, m2) and len(m) > 0
+        s2.destroy()
+    st.destroy()
     flt.free()

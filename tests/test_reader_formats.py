@@ -404,6 +404,76 @@ def _fasta_text(recs, variant):
     return "".join(out)
 
 
+FASTA_RAW_VARIANTS = ["plain", "wrapped", "crlf", "blank_lines", "lower_iupac", "spaces_digits", "semicolon", "bad_letter", "empty_records",
+                      "leading_blank", "one_wrapped_record", "no_final_newline"]
+
+
+def _fasta_raw_case_file(variant, sim_db, tmp_path):
+    import numpy as np
+    rng = np.random.default_rng(37)
+    g = list(sim_db["targets"].values())
+    recs = []
+    for i in range(4000):
+        src = g[i % len(g)] if i % 3 else "".join("ACGT"[x] for x in rng.integers(0, 4, size=400))
+        p = int(rng.integers(0, len(src) - 310))
+        L = int(rng.integers(40, 152))
+        if variant == "empty_records" and i % 9 == 0:
+            L = 0
+        recs.append((f"read{i} extra words", src[p:p + L]))
+    if variant == "bad_letter":
+        recs[2000] = (recs[2000][0], recs[2000][1][:20] + "!" + recs[2000][1][21:])
+    if variant == "one_wrapped_record":   # two-line records all over, one record in the middle with its letters on three lines
+        text = _fasta_text(recs[:2100], "plain") + ">wrapped one\n" + recs[2100][1][:30] + "\n" + recs[2100][1][30:60] + "\n" + recs[2100][1][60:] + "\n" \
+            + _fasta_text(recs[2101:], "plain")
+    else:
+        text = _fasta_text(recs, variant if variant not in ("empty_records", "bad_letter", "leading_blank", "no_final_newline") else "plain")
+    if variant == "leading_blank":
+        text = "\n" + text
+    if variant == "no_final_newline":
+        text = text[:-1]
+    f1 = str(tmp_path / "r1.fasta")
+    open(f1, "w", newline="").write(text)
+    return f1
+
+
+@pytest.mark.parametrize("variant", FASTA_RAW_VARIANTS)
+def test_raw_fasta_pieces_with_the_checker_backend(oracle_bin, sim_db, tmp_path, variant):
+    """FASTA text as raw pieces (records of two lines found by the backend; whatever the two-line rule does not cover -- wrapped
+    letters, blank lines, ';' headers, white space and digits among the letters -- stops the file's pieces there and continues in
+    the sequential reader): the host side with the checker backend, small pieces, several workers and lanes."""
+    f1 = _fasta_raw_case_file(variant, sim_db, tmp_path)
+    seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / "seq"), False, {"GANON_HOST_PARSE_THREADS": "0"})
+    for raw, lanes, slab, dev in (("1", "2", "65536", "0,0,0"), ("1", "1", "200000", "0"), ("1", "3", "70000", "0,0"), ("0", "2", "65536", "0,0")):
+        env = {"GANON_HOST_PARSE_THREADS": "3", "GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_TIMING": "1", "GANON_HOST_DEVICE_FASTQ": raw,
+               "GANON_HOST_LANES": lanes, "GANON_HOST_SLAB_BYTES": slab, "GANON_HOST_BATCH_READS": "97", "GANON_HOST_POST_THREADS": "2"}
+        err, out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / f"o{raw}{lanes}{slab}"), False, env, ("--device", dev))
+        assert out == seq_out, (variant, raw, lanes, slab, dev)
+        assert ("Error parsing" in err) == ("Error parsing" in seq_err)
+        if variant != "leading_blank":  # (a first line that is no header: how far the pieces get is the reader's business)
+            assert ("tokenised on the device" in err) == (raw == "1"), err[-400:]
+    if variant in ("plain", "lower_iupac", "empty_records", "one_wrapped_record"):
+        assert seq_out[".all"].count(b"\n") > 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", FASTA_RAW_VARIANTS)
+def test_device_tokenised_fasta_equals_sequential_reader(oracle_bin, sim_db, tmp_path, variant):
+    """the same through the HIP binary: the two-line records are found on the device (csrc/gn_fastq.hip, GN_TEXT_FASTA)"""
+    f1 = _fasta_raw_case_file(variant, sim_db, tmp_path)
+    seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / "seq"), False, {"GANON_HOST_PARSE_THREADS": "0"})
+    common = {"GANON_HOST_PARSE_THREADS": "3", "GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_TIMING": "1", "GANON_HOST_DEVICE_FASTQ": "1"}
+    for slab, extra in (("65536", ()), ("200000", ("--device", "0")), ("1048576", ("--device", "0,0")), ("65536", ("--device", "0,0"))):
+        err, out = _run_reader_case(cu.BIN_HIP, sim_db["ibf"], [f1], str(tmp_path / ("dev" + slab + str(len(extra)))), False,
+                                    dict(common, GANON_HOST_SLAB_BYTES=slab), extra)
+        assert out == seq_out, (variant, slab)
+        assert ("Error parsing" in err) == ("Error parsing" in seq_err)
+        if variant != "leading_blank":
+            assert "tokenised on the device" in err, err[-600:]
+    err, out = _run_reader_case(cu.BIN_HIP, sim_db["ibf"], [f1], str(tmp_path / "host"), False,
+                                dict(common, GANON_HOST_SLAB_BYTES="65536", GANON_HOST_DEVICE_FASTQ="0"))
+    assert out == seq_out and "tokenised on the device" not in err
+
+
 @pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("variant", ["plain", "wrapped", "crlf", "blank_lines", "lower_iupac", "spaces_digits", "semicolon", "bad_letter",
                                      "empty_records", "leading_blank"])
