@@ -121,6 +121,8 @@ def run_binary(args, n_units, runs, label, deadline):
            "total_classified": classified, "total_unclassified": unclassified,
            "classified_frac": round(classified / max(1, classified + unclassified), 4), "all_lines": all_lines,
            "host_stalls": "; ".join(stalls)[:400]}
+    if os.environ.get("E2E_DIAG"):  # every timing line of the last run (GANON_HOST_TIMING=1)
+        out["timing_lines"] = [l[:600] for l in last.get("stderr", "").splitlines() if l.startswith("[")]
     for ext in (".all", ".rep"):
         if os.path.exists(prefix + ext):
             os.remove(prefix + ext)

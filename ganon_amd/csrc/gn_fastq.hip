@@ -114,13 +114,15 @@ __global__ __launch_bounds__(256) void gn_fq_lines_kernel(const uint8_t* __restr
 // FASTA = true:  groups of two lines   >id / letters  -- a record whose letters are on ONE line, followed by the next record's '>'
 //                (or by the end of the text); wrapped sequences, blank lines, ';' headers end the batch like any other record
 //                the rule does not cover (the host's sequential reader takes it from there, white space, digits and all).
-template <bool FASTA>
+template <int FMT>
 __global__ __launch_bounds__(256) void gn_fq_records_kernel(const uint8_t* __restrict__ text, const uint32_t* __restrict__ nl,
                                                             const uint32_t* __restrict__ n_lines_at, uint32_t max_reads, uint32_t n_threads,
                                                             uint64_t n_bytes, uint32_t* __restrict__ rec_at, uint32_t* __restrict__ seq_at,
                                                             uint32_t* __restrict__ seq_len, unsigned long long* __restrict__ fq)
 {
-    constexpr uint32_t LPR = FASTA ? 2u : 4u; // lines per record
+    constexpr bool     FASTA = FMT == GN_TEXT_FASTA;
+    constexpr uint8_t  HDR   = '>';
+    constexpr uint32_t LPR   = FASTA ? 2u : 4u; // lines per record
     const uint32_t     r   = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_threads)
         return;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void gn_fq_records_kernel(const uint8_t* __res
     if (FASTA)
     {
         const uint8_t first = a + 1u < b ? text[a + 1] : (uint8_t)'A';
-        ok = a > p0 && text[p0] == '>' && first != '>' && first != ';' && ((uint64_t)b + 1u >= n_bytes || text[b + 1] == '>');
+        ok = a > p0 && text[p0] == HDR && first != '>' && first != ';' && ((uint64_t)b + 1u >= n_bytes || text[b + 1] == HDR);
     }
     else
     {
@@ -198,92 +200,131 @@ __global__ __launch_bounds__(256) void gn_fq_copy_kernel(const uint8_t* __restri
     }
 }
 
+// One text (fq2 = nullptr) or the two mate files of a pair: the batch is the records BOTH texts hold before their first
+// group of lines that is no record -- fq[2]; fq[4] / fq2[4] = the bytes of each text those records cover.
 __global__ void gn_fq_finish_kernel(const uint32_t* __restrict__ nl, const uint64_t* __restrict__ off, uint32_t max_reads, uint64_t n_bytes,
-                                    uint32_t lpr, unsigned long long* __restrict__ fq)
+                                    uint32_t lpr, unsigned long long* __restrict__ fq, const uint32_t* __restrict__ nl2,
+                                    unsigned long long* __restrict__ fq2, uint64_t bases_bound)
 {
-    const uint64_t n_lines = fq[0];
-    uint64_t       n_rec   = n_lines / lpr;
-    if (n_rec > max_reads)
-        n_rec = max_reads;
-    const uint64_t v = fq[1] < n_rec ? fq[1] : n_rec;
-    fq[2]            = v;
-    fq[3]            = off[v];
-    fq[4]            = v ? (uint64_t)nl[lpr * v - 1] + 1u : 0u;
-    fq[5]            = n_bytes;
+    auto taken = [&](const unsigned long long* f) {
+        uint64_t n_rec = f[0] / lpr;
+        if (n_rec > max_reads)
+            n_rec = max_reads;
+        return f[1] < n_rec ? (uint64_t)f[1] : n_rec;
+    };
+    uint64_t v = taken(fq);
+    if (fq2)
+    {
+        const uint64_t v2 = taken(fq2);
+        v                 = v2 < v ? v2 : v;
+        fq2[2]            = v;
+        fq2[4]            = v ? (uint64_t)nl2[lpr * v - 1] + 1u : 0u;
+    }
+    fq[2] = v;
+    fq[3] = fq2 ? bases_bound : off[v];
+    fq[4] = v ? (uint64_t)nl[lpr * v - 1] + 1u : 0u;
+    fq[5] = n_bytes;
 }
 
 void gn_fastq_release(gn_stream* s)
 {
     if (s->fq_probe[3] > 0)
-        fprintf(stderr, "[hip call timing] gn_stream_upload_fastq x%.0f: initial sync %.3f ms, copy call %.3f ms, other calls %.3f ms per batch\n", s->fq_probe[3],
+        fprintf(stderr, "[hip call timing] gn_stream_upload_text x%.0f: initial sync %.3f ms, copy call %.3f ms, other calls %.3f ms per batch\n", s->fq_probe[3],
                 s->fq_probe[0] / s->fq_probe[3] * 1e3, s->fq_probe[1] / s->fq_probe[3] * 1e3, s->fq_probe[2] / s->fq_probe[3] * 1e3);
     for (void* p : { (void*)s->d_text, (void*)s->d_fq_tile, (void*)s->d_fq_nl, (void*)s->d_fq_rec, (void*)s->d_fq_seq, (void*)s->d_fq_len, (void*)s->d_fq,
-                     (void*)s->d_fq_scan })
+                     (void*)s->d_fq_scan, (void*)s->d_fq2_tile, (void*)s->d_fq2_nl, (void*)s->d_fq2_rec, (void*)s->d_fq2_seq, (void*)s->d_fq2_len })
         if (p)
             hipFree(p);
     if (s->h_fq)
         hipHostFree(s->h_fq);
-    for (int i = 0; i < 3; ++i)
-    {
-        if (s->fq_up_ev[i])
-            hipEventDestroy(s->fq_up_ev[i]);
-        if (s->fq_up[i])
-        {
-            hipStreamSynchronize(s->fq_up[i]);
-            hipStreamDestroy(s->fq_up[i]);
-        }
-        s->fq_up[i]    = nullptr;
-        s->fq_up_ev[i] = nullptr;
-    }
     s->d_text = nullptr;
     s->d_fq_tile = s->d_fq_nl = s->d_fq_rec = s->d_fq_seq = s->d_fq_len = nullptr;
+    s->d_fq2_tile = s->d_fq2_nl = s->d_fq2_rec = s->d_fq2_seq = s->d_fq2_len = nullptr;
     s->d_fq = nullptr;
     s->d_fq_scan = nullptr;
     s->h_fq = nullptr;
 }
 
-static int gn_fastq_prepare(gn_stream* s)
+static int gn_fastq_prepare(gn_stream* s, bool pair)
 {
-    if (s->d_text)
-        return GN_OK;
-    // the text never holds more bytes than the stream holds bases (every base is a byte of it)
-    s->fq_text_cap  = s->max_bases;
-    s->fq_tiles_cap = (uint32_t)((s->fq_text_cap + GN_FQ_TILE - 1) / GN_FQ_TILE) + 1u;
-    s->fq_nl_cap    = 4u * s->max_reads + 4u;
-    GN_HIP(hipMalloc(&s->d_text, s->fq_text_cap + 64));
-    GN_HIP(hipMalloc(&s->d_fq_tile, ((size_t)s->fq_tiles_cap + 1) * 2 * sizeof(uint32_t)));
-    GN_HIP(hipMalloc(&s->d_fq_nl, (size_t)s->fq_nl_cap * sizeof(uint32_t)));
-    GN_HIP(hipMalloc(&s->d_fq_rec, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
-    GN_HIP(hipMalloc(&s->d_fq_seq, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
-    GN_HIP(hipMalloc(&s->d_fq_len, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
-    GN_HIP(hipMalloc(&s->d_fq, 8 * sizeof(unsigned long long)));
-    GN_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_fq), 8 * sizeof(unsigned long long), hipHostMallocDefault));
-    size_t t1 = 0, t2 = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, t1, s->d_fq_tile, s->d_fq_tile, (int)(s->fq_tiles_cap + 1), s->st);
-    gn_scan_counts(nullptr, t2, s->d_fq_len, s->d_off1, (int)(s->max_reads + 1), s->st);
-    s->fq_scan_bytes = std::max(t1, t2) + 256;
-    GN_HIP(hipMalloc(&s->d_fq_scan, s->fq_scan_bytes));
+    if (!s->d_text)
+    {
+        // the text never holds more bytes than the stream holds bases (every base is a byte of it)
+        s->fq_text_cap  = s->max_bases;
+        s->fq_tiles_cap = (uint32_t)((s->fq_text_cap + GN_FQ_TILE - 1) / GN_FQ_TILE) + 1u;
+        s->fq_nl_cap    = 4u * s->max_reads + 4u;
+        GN_HIP(hipMalloc(&s->d_text, s->fq_text_cap + 64));
+        GN_HIP(hipMalloc(&s->d_fq_tile, ((size_t)s->fq_tiles_cap + 1) * 2 * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq_nl, (size_t)s->fq_nl_cap * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq_rec, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq_seq, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq_len, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq, 16 * sizeof(unsigned long long))); // [0..7] the text, [8..15] the mates' text
+        GN_HIP(hipHostMalloc(reinterpret_cast<void**>(&s->h_fq), 16 * sizeof(unsigned long long), hipHostMallocDefault));
+        size_t t1 = 0, t2 = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, t1, s->d_fq_tile, s->d_fq_tile, (int)(s->fq_tiles_cap + 1), s->st);
+        gn_scan_counts_from(nullptr, t2, s->d_fq_len, s->d_off1, (uint64_t)0, (int)(s->max_reads + 1), s->st);
+        s->fq_scan_bytes = std::max(t1, t2) + 256;
+        GN_HIP(hipMalloc(&s->d_fq_scan, s->fq_scan_bytes));
+    }
+    if (pair && !s->d_fq2_nl) // the mates' text has line and record tables of its own
+    {
+        GN_HIP(hipMalloc(&s->d_fq2_tile, ((size_t)s->fq_tiles_cap + 1) * 2 * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq2_nl, (size_t)s->fq_nl_cap * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq2_rec, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq2_seq, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq2_len, ((size_t)s->max_reads + 1) * sizeof(uint32_t)));
+    }
     return GN_OK;
 }
 
-extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_t n_bytes)
+// the kernels of one text, queued on st: lines -> records -> offsets (starting at off_init: where its letters begin in d_bases) -> letters
+static int gn_fq_enqueue(gn_stream* s, const uint8_t* d_text, uint64_t n_bytes, int format, uint32_t* d_tile, uint32_t* d_nl, uint32_t* d_rec,
+                         uint32_t* d_seq, uint32_t* d_len, unsigned long long* d_fq, uint64_t* d_off, uint64_t off_init, hipStream_t st)
 {
-    return gn_stream_upload_text(s, text, n_bytes, GN_TEXT_FASTQ);
+    const bool     fasta = format != GN_TEXT_FASTQ; // (two lines per record)
+    const uint32_t lpr   = fasta ? 2u : 4u;
+    const uint32_t tiles = (uint32_t)((n_bytes + GN_FQ_TILE - 1) / GN_FQ_TILE);
+    uint32_t*      cnt   = d_tile;
+    uint32_t*      toff  = d_tile + s->fq_tiles_cap + 1;
+    GN_HIP(hipMemsetAsync(cnt + tiles, 0, sizeof(uint32_t), st));
+    GN_HIP(hipMemsetAsync(d_fq, 0, 8 * sizeof(unsigned long long), st));
+    GN_HIP(hipMemsetAsync(d_fq + 1, 0xFF, sizeof(unsigned long long), st));
+    if (tiles)
+        hipLaunchKernelGGL(gn_fq_count_kernel, dim3(tiles), dim3(256), 0, st, d_text, n_bytes, cnt);
+    size_t tmp = s->fq_scan_bytes;
+    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_fq_scan, tmp, cnt, toff, (int)(tiles + 1), st));
+    if (tiles)
+        hipLaunchKernelGGL(gn_fq_lines_kernel, dim3(tiles), dim3(256), 0, st, d_text, n_bytes, toff, d_nl, s->fq_nl_cap);
+    // a four-line record is at least 6 bytes ("@\n\n+\n\n" is not even legal), a two-line one 3 (">\n\n"): bound of the per-record launches
+    const uint32_t bound = (uint32_t)std::min<uint64_t>(s->max_reads, n_bytes / (fasta ? 3 : 6)) + 1u;
+    if (format == GN_TEXT_FASTA)
+        hipLaunchKernelGGL(gn_fq_records_kernel<1>, dim3((bound + 255) / 256), dim3(256), 0, st, d_text, d_nl, toff + tiles, s->max_reads, bound,
+                           n_bytes, d_rec, d_seq, d_len, d_fq);
+    else
+        hipLaunchKernelGGL(gn_fq_records_kernel<0>, dim3((bound + 255) / 256), dim3(256), 0, st, d_text, d_nl, toff + tiles, s->max_reads, bound,
+                           n_bytes, d_rec, d_seq, d_len, d_fq);
+    tmp = s->fq_scan_bytes;
+    GN_HIP(gn_scan_counts_from(s->d_fq_scan, tmp, d_len, d_off, off_init, (int)bound, st));
+    const uint32_t blocks = std::min<uint32_t>((bound + 3) / 4, (uint32_t)s->f->n_cu * 8u);
+    hipLaunchKernelGGL(gn_fq_copy_kernel, dim3(blocks), dim3(256), 0, st, d_text, d_seq, d_len, d_off, d_fq, s->max_reads, bound, lpr, s->d_bases, d_fq);
+    return GN_OK;
 }
 
-extern "C" int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t n_bytes, int format)
+static int gn_upload_texts(gn_stream* s, const uint8_t* text, uint64_t n_bytes, const uint8_t* text2, uint64_t n_bytes2, bool pair, int format)
 {
-    if (!s || (!text && n_bytes))
+    if (!s || (!text && n_bytes) || (pair && !text2 && n_bytes2))
         return gn_fail(GN_EINVAL, "gn_stream_upload_text: null argument");
     if (format != GN_TEXT_FASTQ && format != GN_TEXT_FASTA)
         return gn_fail(GN_EINVAL, "gn_stream_upload_text: format %d", format);
-    const bool     fasta = format == GN_TEXT_FASTA;
-    const uint32_t lpr   = fasta ? 2u : 4u;
-    if (n_bytes > s->max_bases || n_bytes >= 0xFFFFFFF0ull)
-        return gn_fail(GN_EINVAL, "FASTQ text of %llu bytes exceeds the stream capacity (%llu bytes)", (unsigned long long)n_bytes,
+    const bool     fasta = format != GN_TEXT_FASTQ; // (two lines per record)
+    const uint64_t at2   = (n_bytes + 15) & ~15ull; // the mates' text begins on a 16-byte lane of the device buffer
+    const uint64_t total = pair ? at2 + n_bytes2 : n_bytes;
+    if (total > s->max_bases || n_bytes >= 0xFFFFFFF0ull || n_bytes2 >= 0xFFFFFFF0ull)
+        return gn_fail(GN_EINVAL, "text of %llu bytes exceeds the stream capacity (%llu bytes)", (unsigned long long)total,
                        (unsigned long long)s->max_bases);
     GN_HIP(hipSetDevice(s->f->device));
-    int rc = gn_fastq_prepare(s);
+    int rc = gn_fastq_prepare(s, pair);
     if (rc)
         return rc;
     static const bool probe = getenv("GANON_HIP_CALL_TIMING") != nullptr;
@@ -291,63 +332,25 @@ extern "C" int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t
     const double      p0    = probe ? now() : 0;
     GN_HIP(hipStreamSynchronize(s->st)); // previous batch must be done before its inputs are overwritten
     const double p1 = probe ? now() : 0;
-    hipStream_t st = s->st;
-    // $GANON_HIP_SPLIT_UPLOAD=<parts>: the text goes up in that many pieces on streams of their own (do concurrent copies of one batch
-    // find a second copy engine?  A/B switch; the default is one copy)
-    static const int split = getenv("GANON_HIP_SPLIT_UPLOAD") ? std::max(1, std::min(4, atoi(getenv("GANON_HIP_SPLIT_UPLOAD")))) : 1;
-    if (n_bytes && split > 1 && n_bytes >= (8u << 20))
-    {
-        const uint64_t part = ((n_bytes / split) + 4095) & ~4095ull;
-        for (int i = 0; i < split; ++i)
-        {
-            const uint64_t lo = (uint64_t)i * part, hi = std::min<uint64_t>(n_bytes, lo + part);
-            if (lo >= hi)
-                break;
-            if (i == 0)
-            {
-                GN_HIP(hipMemcpyAsync(s->d_text, text, hi, hipMemcpyHostToDevice, st));
-                continue;
-            }
-            if (!s->fq_up[i - 1])
-            {
-                GN_HIP(hipStreamCreateWithFlags(&s->fq_up[i - 1], hipStreamNonBlocking));
-                GN_HIP(hipEventCreateWithFlags(&s->fq_up_ev[i - 1], hipEventDisableTiming));
-            }
-            GN_HIP(hipMemcpyAsync(s->d_text + lo, text + lo, hi - lo, hipMemcpyHostToDevice, s->fq_up[i - 1]));
-            GN_HIP(hipEventRecord(s->fq_up_ev[i - 1], s->fq_up[i - 1]));
-            GN_HIP(hipStreamWaitEvent(st, s->fq_up_ev[i - 1], 0));
-        }
-    }
-    else if (n_bytes)
+    hipStream_t  st = s->st;
+    if (n_bytes)
         GN_HIP(hipMemcpyAsync(s->d_text, text, n_bytes, hipMemcpyHostToDevice, st));
+    if (pair && n_bytes2)
+        GN_HIP(hipMemcpyAsync(s->d_text + at2, text2, n_bytes2, hipMemcpyHostToDevice, st));
     const double p2 = probe ? now() : 0;
-    const uint32_t tiles = (uint32_t)((n_bytes + GN_FQ_TILE - 1) / GN_FQ_TILE);
-    uint32_t*      cnt   = s->d_fq_tile;
-    uint32_t*      toff  = s->d_fq_tile + s->fq_tiles_cap + 1;
-    GN_HIP(hipMemsetAsync(cnt + tiles, 0, sizeof(uint32_t), st));
-    GN_HIP(hipMemsetAsync(s->d_fq, 0, 8 * sizeof(unsigned long long), st));
-    GN_HIP(hipMemsetAsync(s->d_fq + 1, 0xFF, sizeof(unsigned long long), st));
-    if (tiles)
-        hipLaunchKernelGGL(gn_fq_count_kernel, dim3(tiles), dim3(256), 0, st, s->d_text, n_bytes, cnt);
-    size_t tmp = s->fq_scan_bytes;
-    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_fq_scan, tmp, cnt, toff, (int)(tiles + 1), st));
-    if (tiles)
-        hipLaunchKernelGGL(gn_fq_lines_kernel, dim3(tiles), dim3(256), 0, st, s->d_text, n_bytes, toff, s->d_fq_nl, s->fq_nl_cap);
-    // a four-line record is at least 6 bytes ("@\n\n+\n\n" is not even legal), a two-line one 3 (">\n\n"): bound of the per-record launches
-    const uint32_t bound = (uint32_t)std::min<uint64_t>(s->max_reads, n_bytes / (fasta ? 3 : 6)) + 1u;
-    if (fasta)
-        hipLaunchKernelGGL(gn_fq_records_kernel<true>, dim3((bound + 255) / 256), dim3(256), 0, st, s->d_text, s->d_fq_nl, toff + tiles, s->max_reads,
-                           bound, n_bytes, s->d_fq_rec, s->d_fq_seq, s->d_fq_len, s->d_fq);
-    else
-        hipLaunchKernelGGL(gn_fq_records_kernel<false>, dim3((bound + 255) / 256), dim3(256), 0, st, s->d_text, s->d_fq_nl, toff + tiles, s->max_reads,
-                           bound, n_bytes, s->d_fq_rec, s->d_fq_seq, s->d_fq_len, s->d_fq);
-    tmp = s->fq_scan_bytes;
-    GN_HIP(gn_scan_counts(s->d_fq_scan, tmp, s->d_fq_len, s->d_off1, (int)bound, st));
-    const uint32_t blocks = std::min<uint32_t>((bound + 3) / 4, (uint32_t)s->f->n_cu * 8u);
-    hipLaunchKernelGGL(gn_fq_copy_kernel, dim3(blocks), dim3(256), 0, st, s->d_text, s->d_fq_seq, s->d_fq_len, s->d_off1, s->d_fq, s->max_reads, bound, lpr,
-                       s->d_bases, s->d_fq);
-    hipLaunchKernelGGL(gn_fq_finish_kernel, dim3(1), dim3(1), 0, st, s->d_fq_nl, s->d_off1, s->max_reads, n_bytes, lpr, s->d_fq);
-    GN_HIP(hipMemcpyAsync(s->h_fq, s->d_fq, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    rc = gn_fq_enqueue(s, s->d_text, n_bytes, format, s->d_fq_tile, s->d_fq_nl, s->d_fq_rec, s->d_fq_seq, s->d_fq_len, s->d_fq, s->d_off1, 0, st);
+    if (rc)
+        return rc;
+    if (pair) // mate i's letters: behind every letter the first text can hold (off2 starts at the second text's place in the buffer)
+    {
+        rc = gn_fq_enqueue(s, s->d_text + at2, n_bytes2, format, s->d_fq2_tile, s->d_fq2_nl, s->d_fq2_rec, s->d_fq2_seq, s->d_fq2_len, s->d_fq + 8,
+                           s->d_off2, at2, st);
+        if (rc)
+            return rc;
+    }
+    hipLaunchKernelGGL(gn_fq_finish_kernel, dim3(1), dim3(1), 0, st, s->d_fq_nl, s->d_off1, s->max_reads, n_bytes, fasta ? 2u : 4u, s->d_fq,
+                       pair ? s->d_fq2_nl : nullptr, pair ? s->d_fq + 8 : nullptr, total);
+    GN_HIP(hipMemcpyAsync(s->h_fq, s->d_fq, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     GN_HIP(hipGetLastError());
     if (probe)
     {
@@ -358,6 +361,7 @@ extern "C" int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t
         s->fq_probe[3] += 1;
     }
     s->fq_pending = true;
+    s->fq_pair    = pair;
     s->fq_bytes   = n_bytes;
     s->have_reads = false;
     s->classified = false;
@@ -366,12 +370,28 @@ extern "C" int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t
     return GN_OK;
 }
 
-extern "C" int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* n_bases, uint64_t* parsed_bytes)
+extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_t n_bytes)
+{
+    return gn_upload_texts(s, text, n_bytes, nullptr, 0, false, GN_TEXT_FASTQ);
+}
+
+extern "C" int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t n_bytes, int format)
+{
+    return gn_upload_texts(s, text, n_bytes, nullptr, 0, false, format);
+}
+
+extern "C" int gn_stream_upload_text_pair(gn_stream* s, const uint8_t* text1, uint64_t n_bytes1, const uint8_t* text2, uint64_t n_bytes2, int format)
+{
+    return gn_upload_texts(s, text1, n_bytes1, text2, n_bytes2, true, format);
+}
+
+static int gn_text_index(gn_stream* s, bool pair, uint32_t* n_reads, uint64_t* n_bases, uint64_t* parsed_bytes, uint64_t* parsed_bytes2)
 {
     if (!s)
         return gn_fail(GN_EINVAL, "null stream");
-    if (!s->fq_pending)
-        return gn_fail(GN_EINVAL, "gn_stream_fastq_index: no FASTQ text was uploaded on this stream");
+    if (!s->fq_pending || s->fq_pair != pair)
+        return gn_fail(GN_EINVAL, pair ? "gn_stream_text_pair_index: no pair of texts was uploaded on this stream"
+                                       : "gn_stream_fastq_index: no text was uploaded on this stream");
     GN_HIP(hipSetDevice(s->f->device));
     GN_HIP(hipStreamSynchronize(s->st));
     s->fq_pending = false;
@@ -383,7 +403,7 @@ extern "C" int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* 
     s->n_reads    = (uint32_t)s->h_fq[2];
     s->n_bases    = s->h_fq[3];
     s->fq_reads   = s->n_reads;
-    s->paired     = false;
+    s->paired     = pair;
     s->have_reads = true;
     s->classified = false;
     s->hashed     = false;
@@ -394,7 +414,19 @@ extern "C" int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* 
         *n_bases = s->n_bases;
     if (parsed_bytes)
         *parsed_bytes = s->h_fq[4];
+    if (parsed_bytes2)
+        *parsed_bytes2 = s->h_fq[8 + 4];
     return GN_OK;
+}
+
+extern "C" int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* n_bases, uint64_t* parsed_bytes)
+{
+    return gn_text_index(s, false, n_reads, n_bases, parsed_bytes, nullptr);
+}
+
+extern "C" int gn_stream_text_pair_index(gn_stream* s, uint32_t* n_reads, uint64_t* parsed_bytes1, uint64_t* parsed_bytes2)
+{
+    return gn_text_index(s, true, n_reads, nullptr, parsed_bytes1, parsed_bytes2);
 }
 
 extern "C" int gn_stream_fastq_keep(gn_stream* s, uint32_t n_reads)
@@ -407,21 +439,34 @@ extern "C" int gn_stream_fastq_keep(gn_stream* s, uint32_t n_reads)
     return GN_OK;
 }
 
-extern "C" int gn_stream_fastq_records(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len)
+static int gn_text_records(gn_stream* s, const uint32_t* d_rec, const uint32_t* d_seq, const uint32_t* d_len, uint32_t* rec_at, uint32_t* seq_at,
+                           uint32_t* seq_len)
 {
-    if (!s || !s->have_reads || !s->d_text)
-        return gn_fail(GN_EINVAL, "gn_stream_fastq_records: not a tokenised batch");
     GN_HIP(hipSetDevice(s->f->device));
     const size_t nb = (size_t)s->n_reads * sizeof(uint32_t);
     if (nb)
     {
         if (rec_at)
-            GN_HIP(hipMemcpyAsync(rec_at, s->d_fq_rec, nb, hipMemcpyDeviceToHost, s->st));
+            GN_HIP(hipMemcpyAsync(rec_at, d_rec, nb, hipMemcpyDeviceToHost, s->st));
         if (seq_at)
-            GN_HIP(hipMemcpyAsync(seq_at, s->d_fq_seq, nb, hipMemcpyDeviceToHost, s->st));
+            GN_HIP(hipMemcpyAsync(seq_at, d_seq, nb, hipMemcpyDeviceToHost, s->st));
         if (seq_len)
-            GN_HIP(hipMemcpyAsync(seq_len, s->d_fq_len, nb, hipMemcpyDeviceToHost, s->st));
+            GN_HIP(hipMemcpyAsync(seq_len, d_len, nb, hipMemcpyDeviceToHost, s->st));
     }
     GN_HIP(hipStreamSynchronize(s->st));
     return GN_OK;
+}
+
+extern "C" int gn_stream_fastq_records(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len)
+{
+    if (!s || !s->have_reads || !s->d_text)
+        return gn_fail(GN_EINVAL, "gn_stream_fastq_records: not a tokenised batch");
+    return gn_text_records(s, s->d_fq_rec, s->d_fq_seq, s->d_fq_len, rec_at, seq_at, seq_len);
+}
+
+extern "C" int gn_stream_text_pair_records2(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len)
+{
+    if (!s || !s->have_reads || !s->d_fq2_rec || !s->fq_pair)
+        return gn_fail(GN_EINVAL, "gn_stream_text_pair_records2: not a tokenised pair of texts");
+    return gn_text_records(s, s->d_fq2_rec, s->d_fq2_seq, s->d_fq2_len, rec_at, seq_at, seq_len);
 }

@@ -334,8 +334,8 @@ struct gn_stream
     size_t              fq_scan_bytes = 0;
     uint64_t            fq_text_cap = 0, fq_bytes = 0;
     uint32_t            fq_tiles_cap = 0, fq_nl_cap = 0, fq_reads = 0;
-    hipStream_t         fq_up[3]{};    // $GANON_HIP_SPLIT_UPLOAD: streams of the text's further pieces
-    hipEvent_t          fq_up_ev[3]{};
+    uint32_t *          d_fq2_tile = nullptr, *d_fq2_nl = nullptr, *d_fq2_rec = nullptr, *d_fq2_seq = nullptr, *d_fq2_len = nullptr; // the mates' text
+    bool                fq_pair = false; // the resident text batch is a pair of texts (gn_stream_upload_text_pair)
     double              fq_probe[4]{}; // $GANON_HIP_CALL_TIMING: seconds in the calls of gn_stream_upload_fastq, batches
     bool                fq_pending = false;  // text uploaded, gn_stream_fastq_index not yet called
     // pinned host

@@ -9,3 +9,10 @@ static inline hipError_t gn_scan_counts(void* tmp, size_t& tmp_bytes, const uint
 {
     return hipcub::DeviceScan::ExclusiveScan(tmp, tmp_bytes, counts, offsets, hipcub::Sum(), (uint64_t)0, n, st);
 }
+
+// ... the same with offsets that start at `first` (the mates' letters lie behind the first file's in the stream's buffer)
+static inline hipError_t gn_scan_counts_from(void* tmp, size_t& tmp_bytes, const uint32_t* counts, uint64_t* offsets, uint64_t first, int n,
+                                             hipStream_t st)
+{
+    return hipcub::DeviceScan::ExclusiveScan(tmp, tmp_bytes, counts, offsets, hipcub::Sum(), first, n, st);
+}

@@ -24,7 +24,8 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
                "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_classify_shared",
                "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
-               "gn_peer_stats", "gn_stream_upload_text", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
+               "gn_peer_stats", "gn_stream_upload_text", "gn_stream_upload_text_pair", "gn_stream_text_pair_index", "gn_stream_text_pair_records2",
+               "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -92,6 +93,9 @@ def load_library():
     L.gn_stream_classify_shared.argtypes = [vp, vp, C.c_double]
     L.gn_stream_upload_fastq.argtypes = [vp, vp, u64]
     L.gn_stream_upload_text.argtypes = [vp, vp, u64, i32]
+    L.gn_stream_upload_text_pair.argtypes = [vp, vp, u64, vp, u64, i32]
+    L.gn_stream_text_pair_index.argtypes = [vp, C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
+    L.gn_stream_text_pair_records2.argtypes = [vp, vp, vp, vp]
     L.gn_stream_fastq_index.argtypes = [vp, C.POINTER(u32), C.POINTER(u64), C.POINTER(u64)]
     L.gn_stream_fastq_keep.argtypes = [vp, u32]
     L.gn_stream_fastq_records.argtypes = [vp, vp, vp, vp]
@@ -394,17 +398,33 @@ class HipStream:
         self.upload(bases, off1, off2)
         self.classify(k, w, rel_cutoff)
 
-    def upload_fastq(self, text, fasta: bool = False) -> Tuple[int, int, int]:
+    def upload_fastq(self, text, fasta=False) -> Tuple[int, int, int]:
         """four-line FASTQ text (or two-line FASTA text), tokenised on the device (gn_stream_upload_text + gn_stream_fastq_index):
         -> (reads, bases, parsed_bytes); the stream then holds the reads like after upload()"""
         text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else text, dtype=np.uint8)
         self._keep = (text,)
         L = load_library()
-        _check(L.gn_stream_upload_text(self._h, _p(text), text.size, 1 if fasta else 0))
+        _check(L.gn_stream_upload_text(self._h, _p(text), text.size, int(fasta)))
         n, nb, pb = C.c_uint32(), C.c_uint64(), C.c_uint64()
         _check(L.gn_stream_fastq_index(self._h, C.byref(n), C.byref(nb), C.byref(pb)))
         self.n_reads = n.value
         return n.value, nb.value, pb.value
+
+    def upload_text_pair(self, text1, text2, fasta=False) -> Tuple[int, int, int]:
+        """the two mate files' pieces as text -> (pairs, parsed_bytes1, parsed_bytes2); the stream then holds the pairs like after upload()"""
+        t1, t2 = (np.ascontiguousarray(np.frombuffer(t, dtype=np.uint8) if isinstance(t, (bytes, bytearray)) else t, dtype=np.uint8) for t in (text1, text2))
+        self._keep = (t1, t2)
+        L = load_library()
+        _check(L.gn_stream_upload_text_pair(self._h, _p(t1), t1.size, _p(t2), t2.size, int(fasta)))
+        n, p1, p2 = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(L.gn_stream_text_pair_index(self._h, C.byref(n), C.byref(p1), C.byref(p2)))
+        self.n_reads = n.value
+        return n.value, p1.value, p2.value
+
+    def text_pair_records2(self):
+        out = [np.empty(self.n_reads, dtype=np.uint32) for _ in range(3)]
+        _check(load_library().gn_stream_text_pair_records2(self._h, _p(out[0]), _p(out[1]), _p(out[2])))
+        return tuple(out)
 
     def fastq_keep(self, n_reads: int) -> None:
         _check(load_library().gn_stream_fastq_keep(self._h, n_reads))

@@ -32,7 +32,7 @@ class RawFileTracker
 {
 public:
     // piece `idx` was tokenised: all of it is records (complete), or the first byte that is not part of one is resume_at
-    void publish(size_t idx, bool complete, uint64_t resume_at)
+    void publish(size_t idx, bool complete, uint64_t resume_at, uint64_t resume_at2 = 0)
     {
         std::lock_guard<std::mutex> lk(m_);
         if (state_.size() <= idx)
@@ -47,6 +47,7 @@ public:
         {
             first_stop_ = idx;
             resume_at_  = resume_at;
+            resume_at2_ = resume_at2;
         }
         cv_.notify_all();
     }
@@ -58,11 +59,14 @@ public:
         return first_stop_ >= idx;
     }
     // the reader, after the file's last piece: waits for all `count` pieces; false when one stopped the file (then resume_at)
-    bool wait_all(size_t count, uint64_t& resume_at, size_t* stopped_by = nullptr)
+    // (resume_at2: the same place in the mate file of a pair whose pieces travel as text)
+    bool wait_all(size_t count, uint64_t& resume_at, size_t* stopped_by = nullptr, uint64_t* resume_at2 = nullptr)
     {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return published_ >= count; });
         resume_at = resume_at_;
+        if (resume_at2)
+            *resume_at2 = resume_at2_;
         if (stopped_by)
             *stopped_by = first_stop_;
         return first_stop_ == SIZE_MAX;
@@ -73,7 +77,7 @@ private:
     std::condition_variable cv_;
     std::vector<uint8_t>    state_;
     size_t                  published_ = 0, first_stop_ = SIZE_MAX, known_below_ = 0; // (every piece below known_below_ has been published)
-    uint64_t                resume_at_ = 0;
+    uint64_t                resume_at_ = 0, resume_at2_ = 0;
 };
 
 // a raw batch's place in its file; a batch that is dropped before anyone tokenised it stops the file (nobody waits for ever)
@@ -82,10 +86,10 @@ struct RawTicket
     std::shared_ptr<RawFileTracker> tracker;
     size_t                          idx  = 0;
     bool                            done = false;
-    void publish(bool complete, uint64_t resume_at)
+    void publish(bool complete, uint64_t resume_at, uint64_t resume_at2 = 0)
     {
         if (tracker && !done)
-            tracker->publish(idx, complete, resume_at);
+            tracker->publish(idx, complete, resume_at, resume_at2);
         done = true;
     }
     ~RawTicket() { publish(false, UINT64_MAX); }
@@ -111,6 +115,12 @@ struct ReadBatch
     uint64_t                   text_at = 0;  // offset of text[0] in the file
     uint32_t                   raw_keep = 0; // records of the batch (set by the pipeline between tokenise and classify)
     U32Buf                     rec_at, seq_at, seq_len;
+    // ... of a pair: the piece of the mate file that holds the same records by number (cut by the reader at the line count of `text`);
+    // mate i is record i of text2, its letters are read where they lie
+    ByteBuf                    text2;
+    uint64_t                   text2_at = 0;
+    uint64_t                   raw_parsed2 = 0; // set by tokenise: bytes of text2 the batch's mates cover
+    U32Buf                     seq_at2, seq_len2;
     std::unique_ptr<RawTicket> ticket;
     size_t size() const { return raw ? rec_at.size() : id_off.size() - 1; }
     std::string_view id(size_t i) const
@@ -124,9 +134,9 @@ struct ReadBatch
         return { b, n };
     }
     uint64_t       len1(size_t i) const { return raw ? seq_len[i] : off1[i + 1] - off1[i]; }
-    uint64_t       len2(size_t i) const { return paired ? off2[i + 1] - off2[i] : 0; }
+    uint64_t       len2(size_t i) const { return !paired ? 0 : raw ? seq_len2[i] : off2[i + 1] - off2[i]; }
     const uint8_t* seq1(size_t i) const { return raw ? text.data() + seq_at[i] : bases.data() + off1[i]; }
-    const uint8_t* seq2(size_t i) const { return bases.data() + off2[i]; }
+    const uint8_t* seq2(size_t i) const { return raw ? text2.data() + seq_at2[i] : bases.data() + off2[i]; }
 };
 
 struct Match
@@ -186,6 +196,8 @@ public:
     virtual bool tokenises_fastq() const { return false; }
     // Raw batches: takes batch.text, finds the records.  n_reads = records before the first that is not a plain four-line
     // record (or the end of the text inside one); parsed_bytes = where that one begins (== text.size(): all of it is records).
+    // A paired raw batch (batch.paired, batch.text2 = the mate file's piece with the same records by number): the pairs both
+    // texts hold before either's first non-record; parsed_bytes is text's, batch.raw_parsed2 is set to text2's.
     virtual bool tokenise(ReadBatch& /*batch*/, uint32_t& /*n_reads*/, uint64_t& /*parsed_bytes*/, std::string& err)
     {
         err = "this backend does not tokenise";

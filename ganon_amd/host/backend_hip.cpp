@@ -718,8 +718,9 @@ public:
         if (!resolve(err))
             return false;
         auto t = std::chrono::steady_clock::now();
-        const uint64_t nb    = b.text.size();
-        const uint64_t reads = std::max<uint64_t>(hint_reads_, nb / 40); // (records shorter than 40 bytes on average: the rest goes the slow way)
+        const bool     pair  = b.paired && b.raw;
+        const uint64_t nb    = pair ? ((b.text.size() + 15) & ~15ull) + b.text2.size() : b.text.size();
+        const uint64_t reads = std::max<uint64_t>(hint_reads_, b.text.size() / 40); // (records shorter than 40 bytes on average: the rest goes the slow way)
         // (prepare() sized the streams by the same rule: no re-creation unless a piece is larger than the reader said)
         std::vector<gn_stream*>& sources = tok_sources_;
         sources.clear();
@@ -738,7 +739,10 @@ public:
                     sec_create_ += std::chrono::duration<double>(now - t).count();
                     t = now;
                 }
-                if (gn_stream_upload_text(part.s, b.text.data(), nb, b.raw_fasta ? GN_TEXT_FASTA : GN_TEXT_FASTQ) != GN_OK)
+                const int fmt = b.raw_fasta ? GN_TEXT_FASTA : GN_TEXT_FASTQ;
+                if ((pair ? gn_stream_upload_text_pair(part.s, b.text.data(), b.text.size(), b.text2.data(), b.text2.size(), fmt)
+                          : gn_stream_upload_text(part.s, b.text.data(), nb, fmt))
+                    != GN_OK)
                 {
                     err = gn_last_error();
                     return false;
@@ -749,25 +753,27 @@ public:
         return !sources.empty();
     }
 
-    bool tokenise_end(ReadBatch&, uint32_t& n_reads, uint64_t& parsed_bytes, std::string& err) override
+    bool tokenise_end(ReadBatch& b, uint32_t& n_reads, uint64_t& parsed_bytes, std::string& err) override
     {
         auto                     t       = std::chrono::steady_clock::now();
         std::vector<gn_stream*>& sources = tok_sources_;
+        const bool               pair    = b.paired && b.raw;
         for (size_t i = 0; i < sources.size(); ++i)
         {
             uint32_t n  = 0;
-            uint64_t pb = 0;
-            if (gn_stream_fastq_index(sources[i], &n, nullptr, &pb) != GN_OK)
+            uint64_t pb = 0, pb2 = 0;
+            if ((pair ? gn_stream_text_pair_index(sources[i], &n, &pb, &pb2) : gn_stream_fastq_index(sources[i], &n, nullptr, &pb)) != GN_OK)
             {
                 err = gn_last_error();
                 return false;
             }
             if (i == 0)
             {
-                n_reads      = n;
-                parsed_bytes = pb;
+                n_reads       = n;
+                parsed_bytes  = pb;
+                b.raw_parsed2 = pb2;
             }
-            else if (n != n_reads || pb != parsed_bytes)
+            else if (n != n_reads || pb != parsed_bytes || pb2 != b.raw_parsed2)
             {
                 err = "devices disagree about the records of a FASTQ piece";
                 return false;
@@ -885,6 +891,11 @@ public:
             b.rec_at.resize(n);
             b.seq_at.resize(n);
             b.seq_len.resize(n);
+            if (b.paired)
+            {
+                b.seq_at2.resize(n);
+                b.seq_len2.resize(n);
+            }
             if (n == 0) // a piece behind the one that stopped its file: nothing of it is input
             {
                 for (auto& fr : out.per_filter)
@@ -994,7 +1005,8 @@ public:
         if (b.raw) // where the records lie in the batch's text (ids and letters are read there)
         {
             gn_stream* first = filters_.front().parts.front().s;
-            if (gn_stream_fastq_records(first, b.rec_at.data(), b.seq_at.data(), b.seq_len.data()) != GN_OK)
+            if (gn_stream_fastq_records(first, b.rec_at.data(), b.seq_at.data(), b.seq_len.data()) != GN_OK
+                || (b.paired && gn_stream_text_pair_records2(first, nullptr, b.seq_at2.data(), b.seq_len2.data()) != GN_OK))
             {
                 err = gn_last_error();
                 return false;

@@ -30,7 +30,9 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
+#include <sys/stat.h>
 #include <deque>
+#include <functional>
 #include <filesystem>
 #include <fstream>
 #include <iostream>
@@ -401,6 +403,16 @@ public:
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return q_.size() + busy_ < 2 * th_.size() + 2; });
         q_.emplace_back(std::move(rb), std::move(parts));
+        loaders_.emplace_back();
+        cv_.notify_all();
+    }
+    // a batch whose second half is fetched by `load` on one of the threads (the mate file's piece of a pair that travels as text)
+    void submit(ReadBatch&& rb, std::function<void(ReadBatch&)> load)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return q_.size() + busy_ < 2 * th_.size() + 2; });
+        q_.emplace_back(std::move(rb), std::vector<Part>());
+        loaders_.push_back(std::move(load));
         cv_.notify_all();
     }
     void drain() // every submitted batch is in the queue
@@ -441,6 +453,7 @@ private:
         for (;;)
         {
             std::pair<ReadBatch, std::vector<Part>> job;
+            std::function<void(ReadBatch&)>         load;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return !q_.empty() || stop_; });
@@ -451,13 +464,20 @@ private:
                 }
                 job = std::move(q_.front());
                 q_.pop_front();
+                load = std::move(loaders_.front());
+                loaders_.pop_front();
                 ++busy_;
             }
             ReadBatch& rb = job.first;
-            rb.off2.assign(1, rb.bases.size()); // mates follow the first mates in the same buffer (finalize_batch's layout)
-            rb.off2.reserve(rb.size() + 1);
-            materialise(job.second, rb.bases, rb.off2);
-            job.second.clear(); // (releases the slabs: the last user hands a slab back to its parser)
+            if (load)
+                load(rb);
+            else
+            {
+                rb.off2.assign(1, rb.bases.size()); // mates follow the first mates in the same buffer (finalize_batch's layout)
+                rb.off2.reserve(rb.size() + 1);
+                materialise(job.second, rb.bases, rb.off2);
+                job.second.clear(); // (releases the slabs: the last user hands a slab back to its parser)
+            }
             deliver(std::move(rb));
             {
                 std::lock_guard<std::mutex> lk(m_);
@@ -473,6 +493,7 @@ private:
     std::mutex                                          m_;
     std::condition_variable                             cv_;
     std::deque<std::pair<ReadBatch, std::vector<Part>>> q_;
+    std::deque<std::function<void(ReadBatch&)>>         loaders_; // (one per entry of q_; empty: the parts are copied)
     size_t                                              busy_ = 0;
     bool                                                stop_ = false;
     std::vector<std::thread>                            th_;
@@ -508,6 +529,9 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     rb.raw = false;
                     rb.raw_fasta = false;
                     rb.text.clear();
+                    rb.text2.clear();
+                    rb.seq_at2.clear();
+                    rb.seq_len2.clear();
                     rb.rec_at.clear();
                     rb.seq_at.clear();
                     rb.seq_len.clear();
@@ -628,6 +652,100 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     }
                     else
                         file_done = true;
+                }
+            }
+            // ---- raw pieces of a pair: both mate files travel as text ----------------------------------------------------------------
+            // File 1 is cut into pieces as above (half as large: a batch holds two of them); a piece of n records -- its lines are
+            // counted while it is read -- goes with the next 4 n lines (2 n for FASTA) of file 2, which a line index of that file
+            // locates (GanonClassify.cpp:1240-1252: file 2 is consumed with take(n_reads)) and a helper thread reads.  The backend
+            // finds the records of both texts; the batch is the pairs both hold, and the first piece that is not records from end
+            // to end IN BOTH FILES stops the pair of files there: the sequential readers go on at those two bytes.
+            // When: measured on 16 host cores, one GPU (profiles/r04_e2e_pair_text_*.json) the two ways are level at 32 M pairs -- 58-62 Mpairs/s,
+            // both at what the link and the workers' lanes carry -- with a third of the user CPU time for the text (1.6 against 5.0 s; the
+            // kernel's copies out of the page cache are what is left), but the text's pieces are twice the page-locked memory, which has to
+            // be locked while the first batches run: below some ten million pairs the parsed way finishes first.  So: text from 4 GiB of
+            // first mate file on ($GANON_HOST_PAIR_TEXT=1 / 0: always / never).
+            struct stat st1;
+            const char* force     = std::getenv("GANON_HOST_PAIR_TEXT");
+            const bool  pair_text = raw_fastq && paired
+                                   && (force ? force[0] != '0' : (::stat(pair.mate1.c_str(), &st1) == 0 && (uint64_t)st1.st_size >= (4ull << 30)));
+            if (pair_text)
+            {
+                auto pfr = ParallelFastq::open(pair.mate1, std::min(par_threads, 6u), std::max<size_t>(slab_bytes / 2, 1 << 16), par_min, false, true);
+                std::shared_ptr<LineIndex> idx2(pfr ? LineIndex::open(pair.mate2, 3, 0).release() : nullptr);
+                if (pfr && idx2)
+                {
+                    const uint64_t      lpr     = pfr->fasta() ? 2 : 4;
+                    auto                tracker = std::make_shared<RawFileTracker>();
+                    size_t              pieces  = 0;
+                    uint64_t            records = 0; // of the pieces handed out so far
+                    ParallelFastq::Slab a;
+                    bool                gave_up = false;
+                    uint64_t            gave_up_at = 0, gave_up_at2 = 0;
+                    while (pfr->next(a))
+                    {
+                        if (a.text.empty() || a.text_lines < lpr)
+                        {
+                            // a piece the slab readers do not deliver as text (a record of gigabytes), or one without a whole record:
+                            // the sequential readers take it, from its first byte and from the mate file's matching line
+                            if (a.text.empty() && !a.irregular)
+                                break; // (an empty last slab: the file ended with the piece before)
+                            gave_up     = true;
+                            gave_up_at  = a.text.empty() ? a.resume_at : a.text_at;
+                            gave_up_at2 = idx2->line_begin(records * lpr);
+                            break;
+                        }
+                        const uint64_t n  = a.text_lines / lpr;
+                        const uint64_t b0 = idx2->line_begin(records * lpr);
+                        uint64_t       b1 = b0 == LineIndex::kNoSuchLine ? b0 : idx2->line_begin((records + n) * lpr);
+                        if (b0 == LineIndex::kNoSuchLine)
+                        {
+                            // file 2 has ended: from here on the mates are empty, which is the sequential reader's business
+                            gave_up     = true;
+                            gave_up_at  = a.text_at;
+                            gave_up_at2 = UINT64_MAX;
+                            break;
+                        }
+                        if (b1 == LineIndex::kNoSuchLine)
+                            b1 = idx2->size(); // fewer mates than records: the batch ends where they do, the piece is not whole
+                        rb.raw       = true;
+                        rb.raw_fasta = pfr->fasta();
+                        rb.text.swap(a.text);
+                        rb.text_at  = a.text_at;
+                        rb.text2_at = b0;
+                        rb.raw_keep = 0;
+                        rb.ticket.reset(new RawTicket{ tracker, pieces++ });
+                        rb.seq = seq++;
+                        records += n;
+                        const size_t room = std::max<size_t>(slab_bytes / 2, 1 << 16) + slab_bytes / 32 + 65536;
+                        copier.submit(std::move(rb), [idx2, b0, b1, room](ReadBatch& x) {
+                            if (!idx2->read(b0, b1, x.text2, room))
+                                x.text2.clear(); // (the file shrank under us: the batch comes out short, the piece is not whole)
+                        });
+                        fresh();
+                        pfr->recycle(std::move(a));
+                        a = ParallelFastq::Slab();
+                    }
+                    uint64_t at = 0, at2 = 0;
+                    if (!tracker->wait_all(pieces, at, nullptr, &at2))
+                    {
+                        if (at == UINT64_MAX) // (the pipeline is going down)
+                            file_done = true;
+                        else
+                        {
+                            resume1  = at;
+                            resume2  = at2;
+                            fallback = true;
+                        }
+                    }
+                    else if (gave_up)
+                    {
+                        resume1  = gave_up_at;
+                        resume2  = gave_up_at2;
+                        fallback = true;
+                    }
+                    else
+                        file_done = true; // (whatever file 2 holds beyond file 1's records is not input: take(n_reads))
                 }
             }
             if (!file_done && !fallback)
@@ -1616,7 +1734,7 @@ static bool ganon_classify(Config config)
                                 return fail(e);
                             // the piece says what it is right away; whether the pieces before it were all records is asked when its
                             // results arrive (they always are, unless the file is damaged: then this batch's results are dropped there)
-                            rb.ticket->publish(parsed == rb.text.size(), rb.text_at + parsed);
+                            rb.ticket->publish(parsed == rb.text.size(), rb.text_at + parsed, rb.text2_at + rb.raw_parsed2);
                             rb.raw_keep = n;
                         }
                         if (!timed([&] { return x.be->classify_begin(rb, level.kmer_size, level.window_size, rel_cutoffs, e); }))
@@ -1640,6 +1758,8 @@ static bool ganon_classify(Config config)
                                 rb.rec_at.clear();
                                 rb.seq_at.clear();
                                 rb.seq_len.clear();
+                                rb.seq_at2.clear();
+                                rb.seq_len2.clear();
                                 rb.id_buf.clear();
                                 rb.id_off.assign(1, 0);
                                 rb.bases.clear();

@@ -979,6 +979,7 @@ struct ParallelFastq::Impl
             got += (size_t)k;
         }
         out.text.resize(got);
+        out.text_lines = count_newlines(out.text.data(), got);
     }
 
     void work()
@@ -1015,6 +1016,7 @@ struct ParallelFastq::Impl
             s.resume_after_previous = false;
             s.text.clear();
             s.text_at = 0;
+            s.text_lines = 0;
             size_t b = 0;
             bool   have_b = false, last = false;
             try
@@ -1142,16 +1144,6 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
         gz->set_retain_limit((uint64_t)(im->window + 3) * im->slab_bytes);
         im->gz = std::move(gz);
     }
-    else if (const char* how = std::getenv("GANON_HOST_READ"); how && std::string(how) == "mmap")
-    {
-        // the parsers scan the page cache in place instead of copying it into their buffers first (pread)
-        void* m = ::mmap(nullptr, im->size, PROT_READ, MAP_SHARED, fd, 0);
-        if (m != MAP_FAILED)
-        {
-            ::madvise(m, im->size, MADV_SEQUENTIAL);
-            im->map = static_cast<const char*>(m);
-        }
-    }
     std::unique_ptr<ParallelFastq> pf(new ParallelFastq(im));
     for (unsigned t = 0; t < threads; ++t)
         im->workers.emplace_back([im] { im->work(); });
@@ -1174,7 +1166,6 @@ ParallelFastq::~ParallelFastq()
 }
 
 bool ParallelFastq::fasta() const { return impl_->fasta; }
-
 void ParallelFastq::recycle(Slab&& used)
 {
     std::lock_guard<std::mutex> lk(impl_->m);
@@ -1207,6 +1198,226 @@ bool ParallelFastq::next(Slab& out)
     if (s.gz && s.next_to_take * s.slab_bytes > 0) // the slabs still in work begin their search one byte before their range
         s.gz->release_below((uint64_t)s.next_to_take * s.slab_bytes - 1);
     s.cv.notify_all();
+    return true;
+}
+
+// ---- lines of a plain text file --------------------------------------------------------------------------------------------
+uint64_t count_newlines(const uint8_t* p, size_t n)
+{
+    const __m128i nl = _mm_set1_epi8('\n');
+    uint64_t      c  = 0;
+    size_t        i  = 0;
+    for (; i + 64 <= n; i += 64)
+    {
+        const unsigned m0 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i)), nl));
+        const unsigned m1 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i + 16)), nl));
+        const unsigned m2 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i + 32)), nl));
+        const unsigned m3 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i + 48)), nl));
+        c += (uint64_t)__builtin_popcountll((uint64_t)m0 | (uint64_t)m1 << 16 | (uint64_t)m2 << 32 | (uint64_t)m3 << 48);
+    }
+    for (; i < n; ++i)
+        c += p[i] == '\n';
+    return c;
+}
+
+// offset (inside [p, p + n)) of the k-th newline, k >= 1; n when there are fewer
+static size_t nth_newline(const uint8_t* p, size_t n, uint64_t k)
+{
+    const __m128i nl = _mm_set1_epi8('\n');
+    size_t        i  = 0;
+    for (; i + 16 <= n; i += 16)
+    {
+        unsigned       m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i)), nl));
+        const unsigned c = (unsigned)__builtin_popcount(m);
+        if (c < k)
+        {
+            k -= c;
+            continue;
+        }
+        for (;; m &= m - 1)
+            if (--k == 0)
+                return i + (size_t)__builtin_ctz(m);
+    }
+    for (; i < n; ++i)
+        if (p[i] == '\n' && --k == 0)
+            return i;
+    return n;
+}
+
+struct LineIndex::Impl
+{
+    static constexpr size_t kChunk = 4u << 20;
+    int                     fd = -1;
+    uint64_t                size = 0;
+    size_t                  n_chunks = 0;
+    std::vector<uint64_t>   count;      // newlines of chunk c
+    std::vector<uint8_t>    have;       // chunk c is counted
+    std::vector<uint64_t>   before;     // newlines before chunk c, for c <= known
+    size_t                  known = 0;  // chunks [0, known) are counted and summed
+    size_t                  next = 0;   // next chunk a thread takes
+    size_t                  asked = 0;  // the chunk the caller's last question fell into (the counters stay a window ahead of it)
+    size_t                  window = 512; // 2 GiB
+    bool                    stop = false;
+    std::mutex              m;
+    std::condition_variable cv;
+    std::vector<std::thread> threads;
+    std::vector<uint8_t>    scratch;    // line_begin's chunk (one caller)
+    const uint8_t*          map = nullptr; // the file mapped read-only: counted and copied from the page cache in place
+
+    void work()
+    {
+        std::vector<uint8_t> buf(kChunk);
+        for (;;)
+        {
+            size_t c;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || next >= n_chunks || next < asked + window; });
+                if (stop || next >= n_chunks)
+                    return;
+                c = next++;
+            }
+            const uint64_t at  = (uint64_t)c * kChunk;
+            const size_t   len = (size_t)std::min<uint64_t>(kChunk, size - at);
+            size_t         got = 0;
+            while (!map && got < len)
+            {
+                const ssize_t k = ::pread(fd, buf.data() + got, len - got, (off_t)(at + got));
+                if (k <= 0)
+                    break; // (the file shrank under us: what is there is counted)
+                got += (size_t)k;
+            }
+            const uint64_t lines = map ? count_newlines(map + at, len) : count_newlines(buf.data(), got);
+            std::lock_guard<std::mutex> lk(m);
+            count[c] = lines;
+            have[c]  = 1;
+            while (known < n_chunks && have[known])
+            {
+                before[known + 1] = before[known] + count[known];
+                ++known;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+LineIndex::LineIndex(Impl* i) : impl_(i) {}
+
+std::unique_ptr<LineIndex> LineIndex::open(const std::string& path, unsigned threads, size_t min_bytes)
+{
+    bool by_name = false;
+    for (const char* e : { ".fq", ".fastq", ".fa", ".fasta", ".fna", ".ffn", ".faa", ".frn", ".fas" })
+        by_name = by_name || ends_with(path, e);
+    if (!by_name || threads == 0)
+        return nullptr;
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0)
+        return nullptr;
+    struct stat   st;
+    unsigned char magic[2] = { 0, 0 };
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < std::max<size_t>(min_bytes, 2) || pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1F && magic[1] == 0x8B)
+        || (magic[0] == 'B' && magic[1] == 'Z'))
+    {
+        ::close(fd);
+        return nullptr;
+    }
+    Impl* im     = new Impl;
+    im->fd       = fd;
+    im->size     = (uint64_t)st.st_size;
+    im->n_chunks = (size_t)((im->size + Impl::kChunk - 1) / Impl::kChunk);
+    im->count.assign(im->n_chunks, 0);
+    im->have.assign(im->n_chunks, 0);
+    im->before.assign(im->n_chunks + 1, 0);
+    im->scratch.resize(Impl::kChunk);
+    {
+        // (the counters read the page cache in place: nothing is copied to count a file's lines)
+        void* m = ::mmap(nullptr, im->size, PROT_READ, MAP_SHARED, fd, 0);
+        if (m != MAP_FAILED)
+        {
+            ::madvise(m, im->size, MADV_SEQUENTIAL);
+            im->map = static_cast<const uint8_t*>(m);
+        }
+    }
+    for (unsigned t = 0; t < threads; ++t)
+        im->threads.emplace_back([im] {
+            im->work();
+            g_cpu.parse.add_this_thread();
+        });
+    return std::unique_ptr<LineIndex>(new LineIndex(im));
+}
+
+LineIndex::~LineIndex()
+{
+    Impl& s = *impl_;
+    {
+        std::lock_guard<std::mutex> lk(s.m);
+        s.stop = true;
+    }
+    s.cv.notify_all();
+    for (auto& t : s.threads)
+        t.join();
+    if (s.map)
+        ::munmap(const_cast<uint8_t*>(s.map), s.size);
+    ::close(s.fd);
+}
+
+uint64_t LineIndex::size() const { return impl_->size; }
+
+uint64_t LineIndex::line_begin(uint64_t line)
+{
+    Impl& s = *impl_;
+    if (line == 0)
+        return 0;
+    size_t   c = 0;
+    uint64_t k = 0; // the line begins behind the k-th newline of chunk c
+    {
+        std::unique_lock<std::mutex> lk(s.m);
+        // the chunk that holds newline number `line` (1-based): the first c with before[c + 1] >= line
+        for (;;)
+        {
+            if (s.before[s.known] >= line)
+                break;
+            if (s.known >= s.n_chunks)
+                return kNoSuchLine;
+            s.asked = s.known; // (keeps the counters going)
+            s.cv.notify_all();
+            const size_t was = s.known;
+            s.cv.wait(lk, [&] { return s.known > was; });
+        }
+        c = (size_t)(std::lower_bound(s.before.begin() + 1, s.before.begin() + s.known + 1, line) - (s.before.begin() + 1));
+        k = line - s.before[c];
+        if (c > s.asked)
+        {
+            s.asked = c;
+            s.cv.notify_all();
+        }
+    }
+    const uint64_t at  = (uint64_t)c * Impl::kChunk;
+    const size_t   len = (size_t)std::min<uint64_t>(Impl::kChunk, s.size - at);
+    size_t         got = s.map ? len : 0;
+    while (got < len)
+    {
+        const ssize_t r = ::pread(s.fd, s.scratch.data() + got, len - got, (off_t)(at + got));
+        if (r <= 0)
+            break;
+        got += (size_t)r;
+    }
+    const size_t p = nth_newline(s.map ? s.map + at : s.scratch.data(), got, k);
+    return p >= got ? kNoSuchLine : at + p + 1;
+}
+
+bool LineIndex::read(uint64_t begin, uint64_t end, ByteBuf& dst, size_t reserve) const
+{
+    dst.reserve(std::max<size_t>(reserve, (size_t)(end - begin)));
+    dst.resize((size_t)(end - begin));
+    size_t got = 0;
+    while (got < dst.size())
+    {
+        const ssize_t k = ::pread(impl_->fd, dst.data() + got, dst.size() - got, (off_t)(begin + got));
+        if (k <= 0)
+            return false;
+        got += (size_t)k;
+    }
     return true;
 }
 

@@ -62,6 +62,7 @@ public:
         // takes the slab finds the records itself (the HIP backend does, on the device: csrc/gn_fastq.hip)
         ByteBuf               text;
         uint64_t              text_at = 0; // offset of text[0] in the file (the first byte of a record, by the slab rule below)
+        uint64_t              text_lines = 0; // raw mode: number of '\n' in `text`
         std::string           error;       // a ParseError ended the file after the records above
         bool                  irregular = false;
         uint64_t              resume_at = 0; // irregular: byte offset of the first record that was not parsed here
@@ -86,6 +87,34 @@ private:
     struct Impl;
     std::unique_ptr<Impl> impl_;
     explicit ParallelFastq(Impl* i);
+};
+
+// number of '\n' in [p, p + n)
+uint64_t count_newlines(const uint8_t* p, size_t n);
+
+
+// Where the lines of a plain (uncompressed) text file begin: threads count the newlines of fixed chunks ahead of the caller, and
+// line_begin(L) answers with the byte offset of line L's first byte (line 0 begins at byte 0) as soon as the chunks up to it are
+// counted.  The mate file of a pair whose pieces travel as text is cut with it: file 1's piece holds n records, the mates are the
+// next 4 n lines of file 2 (GanonClassify.cpp:1240-1252: file 2 is consumed with take(n_reads)).
+class LineIndex
+{
+public:
+    // nullptr: not a plain FASTQ/FASTA file by name and magic bytes, or smaller than min_bytes
+    static std::unique_ptr<LineIndex> open(const std::string& path, unsigned threads, size_t min_bytes);
+    ~LineIndex();
+    static constexpr uint64_t kNoSuchLine = ~0ull;
+    // byte offset of line L's first byte; the file's size when L is exactly the number of lines it has and its last byte is a
+    // newline (the line that would begin behind the end); kNoSuchLine when the file has fewer lines
+    uint64_t line_begin(uint64_t line);
+    uint64_t size() const;
+    // bytes [begin, end) of the file into dst (page-locked under the HIP backend)
+    bool read(uint64_t begin, uint64_t end, ByteBuf& dst, size_t reserve) const;
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+    explicit LineIndex(Impl* i);
 };
 
 } // namespace gnhost

@@ -191,6 +191,16 @@ int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_t n_bytes);
 #define GN_TEXT_FASTQ 0
 #define GN_TEXT_FASTA 1
 int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t n_bytes, int format);
+/* Paired input as text: a piece of each mate file, both beginning with a record and holding the SAME records by number (the caller
+ * cuts the second file where the first file's piece ends, counted in records: parse_reads takes file 2 with take(n_reads),
+ * GanonClassify.cpp:1240-1252).  Both texts are tokenised; the batch is the pairs BOTH hold before the first group of lines
+ * that is no record in either: read i = record i of text1 with record i of text2 as its mate (its id is text1's, :1244).
+ * n_bytes1 rounded up to 16, plus n_bytes2, must fit the stream's max_bases.
+ *   gn_stream_text_pair_index     waits; the pairs taken and the bytes of each text they cover (== n_bytes: all of it)
+ *   gn_stream_fastq_keep / gn_stream_fastq_records (text1's records) apply; gn_stream_text_pair_records2 = the mates' in text2 */
+int gn_stream_upload_text_pair(gn_stream* s, const uint8_t* text1, uint64_t n_bytes1, const uint8_t* text2, uint64_t n_bytes2, int format);
+int gn_stream_text_pair_index(gn_stream* s, uint32_t* n_reads, uint64_t* parsed_bytes1, uint64_t* parsed_bytes2);
+int gn_stream_text_pair_records2(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len);
 int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* n_bases, uint64_t* parsed_bytes);
 int gn_stream_fastq_keep(gn_stream* s, uint32_t n_reads);
 int gn_stream_fastq_records(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len);

@@ -86,23 +86,25 @@ public:
         t->origin_ = origin_ ? origin_ : this;
         return t;
     }
-    bool tokenise(ReadBatch& b, uint32_t& n_reads, uint64_t& parsed_bytes, std::string&) override
+    // the records of one text by the slab parser's rule (four-line FASTQ) or the two-line FASTA rule; -> first byte behind them
+    static size_t find_records(const uint8_t* t, size_t n, int format, std::vector<uint32_t>& rec, std::vector<uint32_t>& seq,
+                               std::vector<uint32_t>& len_out)
     {
+        const bool    fasta_text = format != 0;      // two lines per record
+        const uint8_t hdr        = format == 1 ? '>' : '@';
         static const LegalLetters legal;
-        tok_rec_.clear();
-        tok_seq_.clear();
-        tok_len_.clear();
-        const uint8_t* t = b.text.data();
-        const size_t   n = b.text.size();
-        size_t         pos = 0;
+        rec.clear();
+        seq.clear();
+        len_out.clear();
+        size_t pos = 0;
         auto line_end = [&](size_t p) -> size_t { // index of the '\n' that ends the line at p, or n
             const void* q = p < n ? std::memchr(t + p, '\n', n - p) : nullptr;
             return q ? (size_t)((const uint8_t*)q - t) : n;
         };
-        while (pos < n && b.raw_fasta) // two-line records: >id / letters, then a '>' or the end of the text
+        while (pos < n && fasta_text) // two-line records: >id / letters, then a '>' or the end of the text
         {
             const size_t a = line_end(pos);
-            if (a == n || a == pos || t[pos] != '>')
+            if (a == n || a == pos || t[pos] != hdr)
                 break;
             const size_t bnl = line_end(a + 1);
             if (bnl == n)
@@ -110,17 +112,17 @@ public:
             size_t len = bnl - a - 1;
             if (len && t[bnl - 1] == '\r')
                 --len;
-            bool ok = !(bnl > a + 1 && (t[a + 1] == '>' || t[a + 1] == ';')) && (bnl + 1 >= n || t[bnl + 1] == '>');
+            bool ok = !(bnl > a + 1 && (t[a + 1] == '>' || t[a + 1] == ';')) && (bnl + 1 >= n || t[bnl + 1] == hdr);
             for (size_t i = 0; i < len && ok; ++i)
                 ok = legal.ok[t[a + 1 + i]];
             if (!ok)
                 break;
-            tok_rec_.push_back((uint32_t)pos);
-            tok_seq_.push_back((uint32_t)(a + 1));
-            tok_len_.push_back((uint32_t)len);
+            rec.push_back((uint32_t)pos);
+            seq.push_back((uint32_t)(a + 1));
+            len_out.push_back((uint32_t)len);
             pos = bnl + 1;
         }
-        while (pos < n && !b.raw_fasta)
+        while (pos < n && !fasta_text)
         {
             const size_t a = line_end(pos);
             if (a == n || a == pos || t[pos] != '@')
@@ -142,10 +144,33 @@ public:
             const size_t d = line_end(c + 1);
             if (d == n || d - c - 1 != len)
                 break;
-            tok_rec_.push_back((uint32_t)pos);
-            tok_seq_.push_back((uint32_t)(a + 1));
-            tok_len_.push_back((uint32_t)len);
+            rec.push_back((uint32_t)pos);
+            seq.push_back((uint32_t)(a + 1));
+            len_out.push_back((uint32_t)len);
             pos = d + 1;
+        }
+        return pos;
+    }
+
+    bool tokenise(ReadBatch& b, uint32_t& n_reads, uint64_t& parsed_bytes, std::string&) override
+    {
+        const int fmt = b.raw_fasta ? 1 : 0;
+        size_t    pos = find_records(b.text.data(), b.text.size(), fmt, tok_rec_, tok_seq_, tok_len_);
+        if (b.paired) // the pairs BOTH texts hold before either's first non-record
+        {
+            std::vector<uint32_t> rec2;
+            size_t                pos2 = find_records(b.text2.data(), b.text2.size(), fmt, rec2, tok_seq2_, tok_len2_);
+            const size_t          v    = std::min(tok_rec_.size(), rec2.size());
+            if (v < tok_rec_.size())
+                pos = tok_rec_[v];
+            if (v < rec2.size())
+                pos2 = rec2[v];
+            tok_rec_.resize(v);
+            tok_seq_.resize(v);
+            tok_len_.resize(v);
+            tok_seq2_.resize(v);
+            tok_len2_.resize(v);
+            b.raw_parsed2 = pos2;
         }
         n_reads      = (uint32_t)tok_rec_.size();
         parsed_bytes = pos;
@@ -169,6 +194,11 @@ public:
             b.rec_at.assign(tok_rec_.begin(), tok_rec_.begin() + b.raw_keep);
             b.seq_at.assign(tok_seq_.begin(), tok_seq_.begin() + b.raw_keep);
             b.seq_len.assign(tok_len_.begin(), tok_len_.begin() + b.raw_keep);
+            if (b.paired)
+            {
+                b.seq_at2.assign(tok_seq2_.begin(), tok_seq2_.begin() + b.raw_keep);
+                b.seq_len2.assign(tok_len2_.begin(), tok_len2_.begin() + b.raw_keep);
+            }
         }
         const size_t n = b.size();
         out.n_hashes.assign(n, 0);
@@ -280,7 +310,7 @@ private:
     };
     std::vector<Held>     held_;
     OracleBackend*        origin_ = nullptr; // a twin classifies against its origin's filters
-    std::vector<uint32_t> tok_rec_, tok_seq_, tok_len_;
+    std::vector<uint32_t> tok_rec_, tok_seq_, tok_len_, tok_seq2_, tok_len2_;
 };
 } // namespace
 

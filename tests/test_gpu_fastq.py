@@ -318,3 +318,65 @@ def test_fasta_text_two_line_records(hip, case):
         s2.destroy()
     st.destroy()
     flt.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------- pairs
+@pytest.mark.parametrize("case", ["plain", "bad_mate", "bad_first", "file2_shorter", "file2_longer", "empty", "fasta"])
+def test_text_pair_is_the_packed_paired_upload(hip, case):
+    rng = np.random.default_rng(23)
+    ibf = gf.random_ibf(64, 4099, 3, 0.4, 2)
+    flt = hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs)
+    n = 3000
+    r1 = random_records(rng, n, 0, 300, b"ACGTNacgtn")
+    r2 = [(b"mate%d/2 with an id of another length" % i, gu.random_seq(rng, int(rng.integers(0, 300)), b"ACGT"), b"", None) for i in range(n)]
+    r2 = [(i, s, p, b"J" * len(s)) for i, s, p, _ in r2]
+    cut = n
+    if case == "bad_mate":      # mate 1700 has a quality line one character short: the batch is the 1700 pairs before it
+        i, s, p, q = r2[1700]
+        r2[1700] = (i, s + b"A", p, q)
+        cut = 1700
+    if case == "bad_first":
+        i, s, p, q = r1[900]
+        r1[900] = (i, s[:2] + b"!" + s[2:], p, q + b"I")
+        cut = 900
+    if case == "fasta":
+        t1, t2 = fasta([(i, s) for i, s, _, _ in r1]), fasta([(i, s) for i, s, _, _ in r2])
+        sizes1 = np.cumsum([0] + [len(fasta([(i, s)])) for i, s, _, _ in r1])
+        sizes2 = np.cumsum([0] + [len(fasta([(i, s)])) for i, s, _, _ in r2])
+    else:
+        t1, t2 = fastq(r1), fastq(r2)
+        sizes1 = np.cumsum([0] + [len(fastq([r])) for r in r1])
+        sizes2 = np.cumsum([0] + [len(fastq([r])) for r in r2])
+    if case == "file2_shorter":
+        t2, cut = t2[: int(sizes2[2000])], 2000
+    if case == "file2_longer":
+        t1, cut = t1[: int(sizes1[2500])], 2500
+    if case == "empty":
+        t1, t2, cut = b"", b"", 0
+    st = hip.HipStream(flt, n + 8, len(t1) + len(t2) + 256)
+    got, p1, p2 = st.upload_text_pair(t1, t2, fasta=case == "fasta")
+    assert (got, p1, p2) == (cut, int(sizes1[cut]), int(sizes2[cut])), case
+    if cut:
+        rec1, seq1, len1 = st.fastq_records()
+        rec2, seq2, len2 = st.text_pair_records2()
+        assert np.array_equal(rec1, sizes1[:cut]) and np.array_equal(rec2, sizes2[:cut])
+        assert np.array_equal(len1, [len(r[1]) for r in r1[:cut]]) and np.array_equal(len2, [len(r[1]) for r in r2[:cut]])
+        assert all(t1[a:a + l] == r[1] for a, l, r in zip(seq1[:50], len1[:50], r1)) and all(t2[a:a + l] == r[1] for a, l, r in zip(seq2[:50], len2[:50], r2))
+        st.classify(19, 31, 0.1)
+        nh, status, mo, m = st.fetch()
+        ho, hs = st.fetch_hashes()
+        bases, off1, off2 = gu.pack_reads([r[1] for r in r1[:cut]], [r[1] for r in r2[:cut]])
+        s2 = hip.HipStream(flt, cut, bases.size)
+        s2.submit(bases, off1, off2, 19, 31, 0.1)
+        nh2, status2, mo2, m2 = s2.fetch()
+        ho2, hs2 = s2.fetch_hashes()
+        assert np.array_equal(nh, nh2) and np.array_equal(status, status2) and np.array_equal(mo, mo2) and np.array_equal(m, m2)
+        assert np.array_equal(ho, ho2) and np.array_equal(hs, hs2) and len(m) > 0
+        # a single text on the same stream afterwards, and a pair again
+        st.upload_fastq(t1[: int(sizes1[min(cut, 500)])], fasta=case == "fasta")
+        st.classify(19, 31, 0.1)
+        assert len(st.fetch()[0]) == min(cut, 500)
+        assert st.upload_text_pair(t1, t2, fasta=case == "fasta")[0] == cut
+        s2.destroy()
+    st.destroy()
+    flt.free()
