@@ -60,12 +60,16 @@ WORKLOADS = {
     "hibf64k": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, h=3, reads=10_000_000, paired=False, config=2),
     # the same tree with a top-level IBF of 1 GiB (2^25 rows of 32 bytes): level 0 no longer fits the 256 MiB Infinity Cache
     "hibf64k_top1g": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, rows_top=1 << 25, h=3, reads=10_000_000, paired=False, config=2),
+    # raptor-like layout: log-normal user-bin sizes -> split user bins at the top, merged bins of different cardinality, children of 2 ... 1024
+    # technical bins with different numbers of rows, three levels; Bernoulli(3/8) bits (p^h = 0.053); a tenth of the reads descends into two children
+    "hibf64k_skew": dict(kind="hibf", skew=True, user_bins=65536, h=3, reads=10_000_000, paired=False, config=2),
+    "hibf_skew_tiny": dict(kind="hibf", skew=True, user_bins=8192, h=3, reads=100_000, paired=False, config=None, rows_scale=0.01),
     "hibf_tiny": dict(kind="hibf", user_bins=4096, tmax=64, rows=1 << 12, h=3, reads=100_000, paired=False, config=None),
     "flat128g": dict(kind="flat", bins=32768, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=3),
     "slice1t": dict(kind="slice", bins=32768, slices=8, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=4),
     "slice_tiny": dict(kind="slice", bins=4096, slices=8, rows=1 << 14, h=4, reads=100_000, paired=True, config=None),
 }
-EXTRA_WORKLOADS = ["hibf64k", "hibf64k_top1g", "flat128g", "slice1t"]   # N = 1: child processes
+EXTRA_WORKLOADS = ["hibf64k", "hibf64k_top1g", "hibf64k_skew", "flat128g", "slice1t"]   # N = 1: child processes
 EXTRA_WORKLOADS_MULTI = ["flat128g", "slice1t"]                           # N > 1: in this job (BASELINE's scaling configs)
 
 # What a random gather of 128-byte lines reaches on MI355X by residency of the table (scripts/calib_gather.hip, measured:
@@ -202,11 +206,22 @@ def main() -> int:
             gdist.init(dist_backend, torch.device("cuda", dev_index))
 
         n_reads = (args.reads if headline else 0) or spec["reads"]
-        rows = (args.rows if headline else 0) or spec["rows"]
+        rows = (args.rows if headline else 0) or spec.get("rows", 0)
         paired = spec["paired"]
         t0 = time.time()
         part = None
-        if kind == "hibf":
+        if kind == "hibf" and spec.get("skew"):
+            wl, flt = bw.make_hibf_skew_device_workload(ganon_amd, name, spec["user_bins"], spec["h"], n_reads, rel_cutoff=args.rel_cutoff, seed=42,
+                                                        shard=rank, device=dev_index, rows_scale=spec.get("rows_scale", 1.0))
+            off2 = None
+            lay = wl.layout
+            desc = (f"{lay['depth']}-level HIBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {spec['user_bins']} user bins of log-normal size: top IBF "
+                    f"{lay['top_bins']} bins ({lay['top_split_user_bins']} user bins split over {lay['top_split_technical_bins']}, the rest merged), "
+                    f"{lay['ibfs'] - 1} lower IBFs of {lay['child_bins_min']}..{lay['child_bins_max']} bins (median {lay['child_bins_median']}) and "
+                    f"{lay['rows_min']}..{lay['rows_max']} rows, h={spec['h']}, {lay['fill']} bits, {lay['genomes_in_two_user_bins']} genomes in two user bins")
+            kernel_name = "gn_hibf_reg_kernel"
+            row_bytes = ((lay["top_bins"] + 63) >> 6) * 8
+        elif kind == "hibf":
             rows_top = spec.get("rows_top", rows) if not (headline and args.rows) else rows
             wl, flt = bw.make_hibf_device_workload(ganon_amd, name, spec["user_bins"], spec["tmax"], rows_top, rows, spec["h"],
                                                    n_reads, rel_cutoff=args.rel_cutoff, seed=42, shard=rank, device=dev_index)
@@ -328,7 +343,7 @@ def main() -> int:
             levels = []
             for li, lv in enumerate(st.hibf_levels()):
                 rb = max(1, lv["row_bytes"])
-                line = lv["algo_bytes"] // rb * max(128, rb)
+                line = lv["line_bytes"]   # the level's row requests in the 128-byte lines they occupy (counted by the kernels: widths differ inside a level)
                 roof_gbs, where = gather_roof(lv["table_bytes"])
                 sec = max(lv["ms"], 1e-6) * 1e-3
                 levels.append({"level": li, "ms": round(lv["ms"], 4), "row_bytes": rb, "table_bytes": lv["table_bytes"], "resident_in": where,
@@ -358,7 +373,7 @@ def main() -> int:
             "config": {
                 "workload": f"{name} (BASELINE.json configs[{spec['config']}]): {desc}, k={wl.k} w={wl.w}, {n_reads} synthetic "
                             f"{unit_name} per GPU (50% cut from {4096} planted genomes), rel_cutoff={args.rel_cutoff}, seeded "
-                            f"Bernoulli(0.5) fill generated on the device, seed 42",
+                            f"{'Bernoulli(3/8)' if spec.get('skew') else 'Bernoulli(0.5)'} fill generated on the device, seed 42",
                 "reads_per_gpu": n_reads,
                 "parallelism": (f"bin-range partitioned x{world} of {spec.get('slices')} slices" if kind == "slice"
                                 else f"read-sharded x{world}, filter replicated"),

@@ -431,3 +431,140 @@ def download_hibf(flt, wl: HibfWorkload) -> None:
         W = (bins + 63) >> 6
         out.append((flt.download_rows(0, rows, W, ibf_idx=i).reshape(-1), bins, rows, h))
     wl.ibfs = out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# An HIBF that looks like raptor's output on real reference sets (bench.py workload hibf64k_skew): user-bin sizes are
+# log-normal, so the layout has SPLIT user bins in the top level (the few huge ones), merged bins of very different
+# cardinality (equal total size each), child IBFs of different widths (64 ... 1024 technical bins, not multiples of 64) and
+# different numbers of rows, and a third level under the merged bins that hold more user bins than a child may have
+# technical bins.  Bits are Bernoulli(3/8) -- 0.375^3 = 0.053, BASELINE.md's p^h ~ 0.05 for h = 3; the planted genomes'
+# minimisers are emplaced on the device along their path (every merged bin above a user bin holds its content,
+# hibf.hpp:124-136), a split user bin's content round-robin over its technical bins, and every fifth genome lives in a
+# second user bin under another merged bin, so that a tenth of the reads descends into two children.
+# ---------------------------------------------------------------------------------------------------------------
+def skew_layout(n_user_bins: int, seed: int, top_bins: int = 512, n_top_split: int = 24, child_max: int = 1024, sigma: float = 1.6):
+    """-> (ibfs [(bins, rows)], next_ibf_id, bin_to_user, paths {user bin: [(ibf, [technical bins])] from the top down}, summary)"""
+    rng = np.random.default_rng([seed, 7])
+    sizes = rng.lognormal(0.0, sigma, n_user_bins)
+    order = np.argsort(-sizes, kind="stable")
+    ibfs, nxt, b2u = [], [], []
+    paths = {}
+
+    def rows_for(largest: float, lo=1 << 18, hi=1 << 23) -> int:
+        # an IBF is sized by its largest technical bin (odd numbers of rows on purpose: the row map is a 128-bit multiply, not a mask)
+        return int(min(hi, max(lo, largest * 48001.0))) | 1
+
+    def new_ibf():
+        ibfs.append(None)
+        nxt.append([])
+        b2u.append([])
+        return len(ibfs) - 1
+
+    def leaf_or_deeper(members, above):
+        """child IBF of the merged bin that holds `members` (user bins, descending size); `above` = path prefix of its user bins"""
+        idx = new_ibf()
+        m = len(members)
+        if m <= child_max:
+            for b, u in enumerate(members):
+                nxt[idx].append(idx)
+                b2u[idx].append(int(u))
+                paths[int(u)] = above + [(idx, [b])]
+            ibfs[idx] = (m, rows_for(sizes[members[0]]))
+            return idx
+        # more user bins than technical bins: the largest stay here, the tail goes under merged bins of this IBF (a third level)
+        n_merged = int(np.ceil((m - child_max) / (child_max - 1))) + 1
+        n_single = child_max - n_merged
+        for b, u in enumerate(members[:n_single]):
+            nxt[idx].append(idx)
+            b2u[idx].append(int(u))
+            paths[int(u)] = above + [(idx, [b])]
+        tail = members[n_single:]
+        cuts = np.linspace(0, len(tail), n_merged + 1).astype(int)
+        for g in range(n_merged):
+            b = n_single + g
+            nxt[idx].append(-1)
+            b2u[idx].append(-1)
+            nxt[idx][b] = leaf_or_deeper(tail[cuts[g]:cuts[g + 1]], above + [(idx, [b])])
+        ibfs[idx] = (child_max, rows_for(sizes[members[0]]))
+        return idx
+
+    top = new_ibf()
+    split = order[:n_top_split]
+    unit = sizes[order[n_top_split]]
+    b = 0
+    for u in split:
+        k = int(min(8, max(2, np.ceil(sizes[u] / unit / 1.5))))
+        for _ in range(k):
+            nxt[top].append(top)
+            b2u[top].append(int(u))
+        paths[int(u)] = [(top, list(range(b, b + k)))]
+        b += k
+    rest = order[n_top_split:]
+    n_merged = top_bins - b
+    csum = np.cumsum(sizes[rest])
+    cuts = np.searchsorted(csum, np.linspace(0, csum[-1], n_merged + 1)[1:-1])
+    groups = np.split(rest, cuts)
+    for g in groups:
+        if len(g) == 0:
+            continue
+        bb = len(b2u[top])
+        nxt[top].append(-1)
+        b2u[top].append(-1)
+        nxt[top][bb] = leaf_or_deeper(g, [(top, [bb])])
+    ibfs[top] = (len(b2u[top]), (1 << 22) | 1)
+    depth = max(len(p) for p in paths.values())
+    widths = sorted(bn for bn, _ in ibfs[1:])
+    summary = dict(ibfs=len(ibfs), depth=depth, top_bins=ibfs[top][0], top_split_user_bins=int(n_top_split), top_split_technical_bins=int(b),
+                   child_bins_min=int(widths[0]), child_bins_median=int(widths[len(widths) // 2]), child_bins_max=int(widths[-1]),
+                   rows_min=int(min(r for _, r in ibfs)), rows_max=int(max(r for _, r in ibfs)),
+                   user_bins_at_depth={d: int(sum(1 for p in paths.values() if len(p) == d)) for d in range(1, depth + 1)})
+    return ibfs, nxt, b2u, paths, summary
+
+
+def make_hibf_skew_device_workload(hip, name: str, n_user_bins: int, hash_funs: int, n_reads: int, read_len: int = 150, k: int = 19, w: int = 31,
+                                   rel_cutoff: float = 0.75, planted_fraction: float = 0.5, genome_len: int = 3000, n_genomes: int = 4096,
+                                   seed: int = 42, shard: int = 0, device: int = 0, rows_scale: float = 1.0):
+    """-> (HibfWorkload, HipFilter); workload.layout = skew_layout's summary.  rows_scale < 1 shrinks every IBF (dry runs, tests)."""
+    shapes, nxt, b2u, paths, summary = skew_layout(n_user_bins, seed)
+    shapes = [(b, max(1031, int(r * rows_scale)) | 1) for b, r in shapes]
+    rd = make_device_flat_workload(name, 64, 64, hash_funs, n_reads, False, read_len, k, w, rel_cutoff, planted_fraction, genome_len, n_genomes,
+                                   seed=seed, shard=shard)
+    ibfs = [(None, b, r, hash_funs) for b, r in shapes]
+    next_ids = [np.asarray(a, dtype=np.int64) for a in nxt]
+    bin_user = [np.asarray(a, dtype=np.int64) for a in b2u]
+    flt = hip.HipFilter.hibf(ibfs, next_ids, bin_user, n_user_bins, device=device)
+    for i in range(len(ibfs)):
+        flt.fill_random(seed + i, hip.FILL_3_OF_8, ibf_idx=i)
+    # genomes -> user bins: the first ones are the huge split user bins of the top level, the others spread over the rest; every fifth one
+    # also lives in a second user bin (another strain of it) somewhere else in the tree
+    grng = np.random.default_rng([seed, 8])
+    split_users = [u for u, p in paths.items() if len(p) == 1]
+    others = np.array([u for u in paths if len(paths[u]) > 1], dtype=np.int64)
+    pick = grng.permutation(others)
+    g_user = np.empty(n_genomes, dtype=np.int64)
+    ns = min(len(split_users), n_genomes // 8)
+    g_user[:ns] = split_users[:ns]
+    g_user[ns:] = pick[: n_genomes - ns]
+    second = {g: int(pick[n_genomes + i]) for i, g in enumerate(range(ns, n_genomes, 5))}
+    st = hip.HipStream(flt, n_genomes, n_genomes * genome_len)
+    st.upload(rd.genomes.reshape(-1), np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(genome_len), None)
+    st.minimisers(k, w)
+    ho, hs = st.fetch_hashes()
+    st.destroy()
+    per_ibf = {}
+    for g in range(n_genomes):
+        hv = hs[int(ho[g]):int(ho[g + 1])]
+        for u in [int(g_user[g])] + ([second[g]] if g in second else []):
+            for ibf_idx, tb in paths[u]:
+                bins = np.asarray(tb, dtype=np.uint32)[np.arange(len(hv)) % len(tb)]   # a split user bin: round-robin over its technical bins
+                per_ibf.setdefault(ibf_idx, []).append((hv, bins))
+    for ibf_idx, lst in per_ibf.items():
+        flt.emplace(np.concatenate([a for a, _ in lst]), np.concatenate([b for _, b in lst]).astype(np.uint32), ibf_idx=ibf_idx)
+    fbytes = sum(r * ((b + 63) >> 6) * 8 for (_, b, r, _) in ibfs)
+    wl = HibfWorkload(name, k, w, rel_cutoff, read_len, n_reads, ibfs, next_ids, bin_user, n_user_bins, rd.bases, rd.off, fbytes)
+    wl.planted_genome = rd.planted_genome
+    wl.genome_user_bin = g_user
+    wl.genome_second_user_bin = second
+    wl.layout = dict(summary, filter_gib=round(fbytes / 2**30, 2), genomes_in_two_user_bins=len(second), fill="Bernoulli(3/8)")
+    return wl, flt

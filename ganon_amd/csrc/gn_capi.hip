@@ -675,15 +675,18 @@ __global__ __launch_bounds__(256) void gn_fill_random_kernel(uint64_t* __restric
     const uint64_t total  = S * W;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t       keys[8];
-    for (uint32_t a = 0; a < and_words; ++a)
+    for (uint32_t a = 0; a < (and_words == GN_FILL_3_OF_8 ? 3u : and_words); ++a)
         keys[a] = gn_mix64(seed + a);
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride)
     {
         const uint64_t r = idx / W, j = idx - r * W;
         const uint64_t g = (r * row_words_total + word_lo + j) * 0x9E3779B97F4A7C15ULL;
         uint64_t       v = ~0ULL;
-        for (uint32_t a = 0; a < and_words; ++a)
-            v &= gn_mix64(keys[a] + g);
+        if (and_words == GN_FILL_3_OF_8) // a & (b | c): density 3/8, i.e. p^3 = 0.053 for three hash functions
+            v = gn_mix64(keys[0] + g) & (gn_mix64(keys[1] + g) | gn_mix64(keys[2] + g));
+        else
+            for (uint32_t a = 0; a < and_words; ++a)
+                v &= gn_mix64(keys[a] + g);
         if (j == W - 1)
             v &= last_mask;
         rows[idx] = v;
@@ -696,8 +699,8 @@ extern "C" int gn_filter_fill_random(gn_filter* f, uint32_t ibf_idx, uint64_t se
     GnIbfHost* ib = gn_filter_ibf(f, ibf_idx);
     if (!ib)
         return GN_EINVAL;
-    if (and_words < 1 || and_words > 8)
-        return gn_fail(GN_EINVAL, "and_words must be 1..8");
+    if ((and_words < 1 || and_words > 8) && and_words != GN_FILL_3_OF_8)
+        return gn_fail(GN_EINVAL, "and_words must be 1..8 (or GN_FILL_3_OF_8)");
     if (row_words_total == 0)
         row_words_total = ib->W;
     if (word_lo + ib->W > row_words_total)
@@ -838,8 +841,8 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
         ok(gn_dmalloc(&s->d_work[1], s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer, s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer2, s->work_cap));
-        ok(gn_dmalloc(&s->d_hctr, 4 * (GN_HIBF_MAXDEPTH + 1) + 2));
-        ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), 4 * (GN_HIBF_MAXDEPTH + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+        ok(gn_dmalloc(&s->d_hctr, 5 * (GN_HIBF_MAXDEPTH + 1) + 2));
+        ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), (5 * (GN_HIBF_MAXDEPTH + 1) + 2) * sizeof(unsigned long long), hipHostMallocDefault));
     }
     ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), GN_NCTR * sizeof(unsigned long long), hipHostMallocDefault));
     if (e != hipSuccess)

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
         return;
 
     GnHibfAppender     app;
-    unsigned long long my_bytes = 0;
+    unsigned long long my_bytes = 0, my_lines = 0;
 
     // per-lane view of an item (the Gp lanes of a group hold identical copies)
     struct Item
@@ -416,7 +416,10 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
                 consume(B, it + 1);
         }
         if (n && gl == 0)
+        {
             my_bytes += (unsigned long long)n * HF * cur.W * 8ull; // algorithmic bytes of this visit (once per item)
+            my_lines += (unsigned long long)n * HF * ((cur.W * 8ull + 127ull) & ~127ull); // ... in the 128-byte lines the rows occupy
+        }
 
         // ---- threshold my own 64 bins; every bin of these IBFs is a run of its own (:445-458 with a run of length one) ----
         // threshold_cutoff = max(1, ceil(n * rel_cutoff))  (GanonClassify.cpp:492-495,720-724); passed to bulk_count (:553)
@@ -482,9 +485,15 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
     app.finish(p, (int)lane);
     // one atomic per wave
     for (int off = 32; off >= 1; off >>= 1)
+    {
         my_bytes += __shfl_xor(my_bytes, off);
+        my_lines += __shfl_xor(my_lines, off);
+    }
     if (lane == 0 && my_bytes)
+    {
         atomicAdd(&p.ctr[2], my_bytes);
+        atomicAdd(&p.ctr[1], my_lines);
+    }
 }
 
 // ================================================================================================
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
         return;
 
     GnHibfAppender     app;
-    unsigned long long my_bytes = 0;
+    unsigned long long my_bytes = 0, my_lines = 0;
 
     // ---- software pipeline over a wave's items (item, item + stride, ...) ------------------------------------------
     // Everything an item needs arrives before the item is reached: its queue entry is fetched four items ahead, its
@@ -690,6 +699,7 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
                     issue(m0, hash_of(it + 3), RB);
             }
             my_bytes += (unsigned long long)n * HF * m0.W * 8ull; // algorithmic bytes of this visit
+            my_lines += (unsigned long long)n * HF * ((m0.W * 8ull + 127ull) & ~127ull);
         }
         // the row registers are free: request the next item's first two row sets, then the hashes of the one after
         if (more && reg_ok(m1))
@@ -833,7 +843,10 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
     }
     app.finish(p, lane);
     if (lane == 0 && my_bytes)
+    {
         atomicAdd(&p.ctr[2], my_bytes);
+        atomicAdd(&p.ctr[1], my_lines);
+    }
 }
 
 // ================================================================================================
@@ -851,7 +864,7 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
     const uint32_t     n_work = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
 
     GnHibfAppender     app;
-    unsigned long long my_bytes = 0;
+    unsigned long long my_bytes = 0, my_lines = 0;
 
     for (uint32_t item = blockIdx.x * (blockDim.x >> 6) + wave; item < n_work; item += nwaves)
     {
@@ -930,10 +943,14 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
             app.push(p, lane, hit && merged, hit && !merged, read, (uint32_t)tgt, sum);
         }
         my_bytes += (unsigned long long)n * f.h * f.W * 8ull; // algorithmic bytes of this visit
+        my_lines += (unsigned long long)n * f.h * ((f.W * 8ull + 127ull) & ~127ull);
     }
     app.finish(p, lane);
     if (lane == 0 && my_bytes)
+    {
         atomicAdd(&p.ctr[2], my_bytes);
+        atomicAdd(&p.ctr[1], my_lines);
+    }
 }
 
 __global__ void gn_hibf_seed_kernel(uint2* work, const uint8_t* status, uint32_t read_base, uint32_t n_reads, unsigned long long* count,
@@ -1334,9 +1351,9 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     const uint32_t rd_bits = std::max(1u, gn_bits_for(n)); // a read index is < n <= 2^rd_bits - 1: below the all-ones sentinel
     if (ub_bits + rd_bits > 64)
         return gn_fail(GN_ERANGE, "read index and user bin do not fit one 64-bit sort key");
-    GN_HIP(hipMemsetAsync(s->d_ctr + 2, 0, 2 * sizeof(unsigned long long), st)); // algo bytes, (unused)
+    GN_HIP(hipMemsetAsync(s->d_ctr + 1, 0, 3 * sizeof(unsigned long long), st)); // line bytes, algo bytes, (unused)
     GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
-    GN_HIP(hipMemsetAsync(s->d_hctr, 0, (4 * NL + 2) * sizeof(unsigned long long), st)); // queues, per-level bytes, [4NL] output base
+    GN_HIP(hipMemsetAsync(s->d_hctr, 0, (5 * NL + 2) * sizeof(unsigned long long), st)); // queues, per-level bytes, [4NL] output base, [4NL+2..] per-level line bytes
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
     unsigned long long* d_out_base = s->d_hctr + 4 * NL;
     const uint32_t h      = f->ibfs[0].h;
@@ -1381,7 +1398,10 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                 GN_HIP(hipEventRecord(s->ev_lvl[lvl], st));
             }
             if (lvl > 0) // algorithmic bytes so far (cumulative), for the per-level figures
+            {
                 GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (lvl - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+                GN_HIP(hipMemcpyAsync(s->d_hctr + 4 * NL + 2 + (lvl - 1), s->d_ctr + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+            }
             GnHibfLevelParams p{};
             p.ibfs        = f->d_hibf;
             p.hashes      = s->v_hashes;
@@ -1453,8 +1473,9 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                 GN_HIP(hipEventCreate(&s->ev_lvl[last]));
             GN_HIP(hipEventRecord(s->ev_lvl[last], st));
             GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (depth - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+            GN_HIP(hipMemcpyAsync(s->d_hctr + 4 * NL + 2 + (depth - 1), s->d_ctr + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         }
-        GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, 4 * NL * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, (5 * NL + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         GN_HIP(hipStreamSynchronize(st));
         return GN_OK;
@@ -1463,7 +1484,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     s->hibf_levels_run = 0;
     uint64_t need_cap = 0;       // capacity the caller has to provide if this run does not fit (-> d_ctr[0], see gn_finish)
     uint64_t out_upper = 0;      // matches appended so far, holes of the sorted ranges included (an upper bound of *d_out_base)
-    uint64_t done_bytes = 0, done_exact = 0; // ctr[2] / ctr[6] after the ranges that are through (a range that is run again starts from them)
+    uint64_t done_bytes = 0, done_exact = 0, done_lines = 0; // ctr[2] / ctr[6] / ctr[1] after the ranges that are through (a range that is run again starts from them)
     uint32_t n_ranges = 0;
     uint32_t step = s->hibf_range_reads && s->hibf_range_reads < n ? s->hibf_range_reads : n; // (what fitted the last batch)
     uint32_t lo = 0;
@@ -1479,6 +1500,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         const uint64_t nm = s->h_ctr[0];
         auto restore = [&]() -> int { // the range is run again: what it added to the batch totals goes
             GN_HIP(hipMemcpyAsync(s->d_ctr + 2, &done_bytes, 8, hipMemcpyHostToDevice, st));
+            GN_HIP(hipMemcpyAsync(s->d_ctr + 1, &done_lines, 8, hipMemcpyHostToDevice, st));
             GN_HIP(hipMemcpyAsync(s->d_ctr + 6, &done_exact, 8, hipMemcpyHostToDevice, st));
             GN_HIP(hipStreamSynchronize(st));
             return GN_OK;
@@ -1567,6 +1589,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
             out_upper += ns;
         }
         done_bytes = s->h_ctr[2];
+        done_lines = s->h_ctr[1];
         done_exact = s->h_ctr[6];
         ++n_ranges;
         if (n_ranges == 1 && cnt == n)
@@ -1625,6 +1648,27 @@ int gn_hibf_dense(gn_stream* s, uint32_t rb, uint32_t re, uint16_t* counts)
 // Per tree level of the last HIBF batch: time of the level's kernels (hipEvents on the stream), algorithmic row bytes
 // n*h*W*8 summed over the items of the level, the bytes of the IBFs at that depth (a level whose tables fit the 256 MiB
 // Infinity Cache is not HBM bound) and their usual row width.  Levels beyond GN_HIBF_TIMED_LEVELS share the last stamp.
+extern "C" int gn_stream_hibf_level_lines(gn_stream* s, uint64_t* line_bytes, uint32_t cap)
+{
+    if (!s || !line_bytes)
+        return gn_fail(GN_EINVAL, "null argument");
+    if (!s->f->is_hibf)
+        return gn_fail(GN_EINVAL, "gn_stream_hibf_level_lines: the stream's filter is not an HIBF");
+    int rc = gn_finish_batch(s);
+    if (rc)
+        return rc;
+    const uint32_t NL = GN_HIBF_MAXDEPTH + 1;
+    const uint32_t timed = s->hibf_levels_run < GN_HIBF_TIMED_LEVELS ? s->hibf_levels_run : GN_HIBF_TIMED_LEVELS;
+    uint64_t       prev = 0;
+    for (uint32_t l = 0; l < timed && l < cap; ++l)
+    {
+        const uint64_t cum = s->h_hctr[4 * NL + 2 + (l + 1 == timed ? s->hibf_levels_run - 1 : l)];
+        line_bytes[l]      = cum - prev;
+        prev               = cum;
+    }
+    return GN_OK;
+}
+
 extern "C" int gn_stream_hibf_levels(gn_stream* s, uint32_t* n_levels, float* ms, uint64_t* algo_bytes, uint64_t* table_bytes,
                                      uint32_t* row_bytes, uint32_t cap)
 {

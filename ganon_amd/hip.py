@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("GANON_HIP_LIB") or os.path.join(_HERE, "csrc", "libganon_hip.so")  # override: A/B builds
 
 READ_OK, READ_SMALL, READ_BIG = 0, 1, 2
+FILL_3_OF_8 = 0x38  # gn_filter_fill_random: density 3/8 (GN_FILL_3_OF_8)
 MATCH_DTYPE = np.dtype([("read", "<u4"), ("target", "<u4"), ("count", "<u4")])
 
 # every symbol include/ganon_hip.h declares (tests check the library exports all of them)
@@ -22,7 +23,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_fetch_postfilter", "gn_streams_postfilter_joint", "gn_stream_set_long_reads", "gn_stream_device_matches",
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
-               "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_classify_shared",
+               "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_hibf_level_lines", "gn_stream_classify_shared",
                "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
                "gn_peer_stats", "gn_stream_upload_text", "gn_stream_upload_text_pair", "gn_stream_text_pair_index", "gn_stream_text_pair_records2",
                "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
@@ -118,6 +119,7 @@ def load_library():
     L.gn_gather_run_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp, u32, u32]
     L.gn_stream_device_offsets.argtypes = [vp, C.POINTER(vp)]
     L.gn_stream_hibf_levels.argtypes = [vp, C.POINTER(u32), vp, vp, vp, vp, u32]
+    L.gn_stream_hibf_level_lines.argtypes = [vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
     L.gn_peer_stats.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(u64)]
     L.gn_reassign_create.argtypes = [i32, u64, u64, u32, vp, vp, C.POINTER(vp)]
@@ -172,9 +174,12 @@ def fill_random_words(seed: int, rows: np.ndarray, n_words: int, and_words: int 
     with np.errstate(over="ignore"):
         g = (rows * total + np.uint64(word_lo) + np.arange(n_words, dtype=np.uint64)[None, :]) * np.uint64(0x9E3779B97F4A7C15)
         v = np.full(g.shape, np.uint64(0xFFFFFFFFFFFFFFFF))
-        for a in range(and_words):
-            key = _mix64(np.array([(seed + a) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
-            v &= _mix64(key + g)
+        key = [_mix64(np.array([(seed + a) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0] for a in range(3 if and_words == FILL_3_OF_8 else and_words)]
+        if and_words == FILL_3_OF_8:
+            v = _mix64(key[0] + g) & (_mix64(key[1] + g) | _mix64(key[2] + g))
+        else:
+            for a in range(and_words):
+                v &= _mix64(key[a] + g)
     if bins & 63:
         v[:, -1] &= np.uint64((1 << (bins & 63)) - 1)
     return v
@@ -547,7 +552,7 @@ class HipStream:
                     fetched_bytes=t.fetched_bytes)
 
     def hibf_levels(self):
-        """per tree level of the last HIBF batch: [dict(ms, algo_bytes, table_bytes, row_bytes)] (gn_stream_hibf_levels)"""
+        """per tree level of the last HIBF batch: [dict(ms, algo_bytes, table_bytes, row_bytes, line_bytes)] (gn_stream_hibf_levels / _level_lines)"""
         cap = 8
         n = C.c_uint32(0)
         ms = np.zeros(cap, dtype=np.float32)
@@ -555,7 +560,9 @@ class HipStream:
         tb = np.zeros(cap, dtype=np.uint64)
         rb = np.zeros(cap, dtype=np.uint32)
         _check(load_library().gn_stream_hibf_levels(self._h, C.byref(n), _p(ms), _p(ab), _p(tb), _p(rb), cap))
-        return [dict(ms=float(ms[i]), algo_bytes=int(ab[i]), table_bytes=int(tb[i]), row_bytes=int(rb[i])) for i in range(min(cap, n.value))]
+        lb = np.zeros(cap, dtype=np.uint64)
+        _check(load_library().gn_stream_hibf_level_lines(self._h, _p(lb), cap))
+        return [dict(ms=float(ms[i]), algo_bytes=int(ab[i]), table_bytes=int(tb[i]), row_bytes=int(rb[i]), line_bytes=int(lb[i])) for i in range(min(cap, n.value))]
 
     def destroy(self) -> None:
         if self._h:

@@ -132,7 +132,10 @@ int gn_filter_finalize(gn_filter* f);
  *   word(r, j) = AND_{a < and_words} mix64(mix64(seed + a) + (r * row_words_total + word_lo + j) * 0x9E3779B97F4A7C15)
  * with mix64 = the splitmix64 finaliser, i.e. iid Bernoulli(2^-and_words) bits that depend only on the GLOBAL word
  * position -- a column slice (word_lo, row_words_total of the whole filter) holds exactly the bits the unsliced
- * filter has there.  Padding bins are cleared.  Not part of the reference's interface. */
+ * filter has there.  Padding bins are cleared.  Not part of the reference's interface.
+ * and_words = GN_FILL_3_OF_8: word = m0 & (m1 | m2) with m_a = the mixes above, density 3/8 -- what a Bloom filter built for a
+ * false-positive rate of 0.05 with three hash functions looks like (0.375^3 = 0.053). */
+#define GN_FILL_3_OF_8 0x38u
 int gn_filter_fill_random(gn_filter* f, uint32_t ibf_idx, uint64_t seed, uint32_t and_words, uint64_t word_lo,
                           uint64_t row_words_total);
 
@@ -355,6 +358,10 @@ int gn_stream_timings(gn_stream* s, gn_timings* t);
  * reason.  Arrays of `cap` entries; *n_levels = levels of the filter's tree (at most 8 are timed separately). */
 int gn_stream_hibf_levels(gn_stream* s, uint32_t* n_levels, float* ms, uint64_t* algo_bytes, uint64_t* table_bytes,
                           uint32_t* row_bytes, uint32_t cap);
+
+/* ... and the same row requests in the 128-byte lines the rows occupy (a 32-byte row moves a line, a 136-byte row two): with IBFs of
+ * different widths on one level this, not row_bytes, is what the level's physical rate is computed from. */
+int gn_stream_hibf_level_lines(gn_stream* s, uint64_t* line_bytes, uint32_t cap);
 
 #ifdef __cplusplus
 }

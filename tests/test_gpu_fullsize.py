@@ -246,3 +246,74 @@ def test_hibf_low_cutoff_at_full_size_runs_in_read_ranges(hibf_full, monkeypatch
         got = {int(x["target"]): int(x["count"]) & 0x7FFFFFFF for x in m[int(mo[r]):int(mo[r + 1])]}
         assert set(got) <= keep and all(got[u] == counts[u] for u in got), r      # survivors of --rel-filter, minus what --fpr-query took
         assert int(a[5][r]) == mx_
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The same 65 536 user bins in a layout like raptor's on log-normal user-bin sizes (bench.py: hibf64k_skew): split user bins in the
+# top level, merged bins of different cardinality, children of 2 ... 1024 technical bins with different numbers of rows, three
+# levels; a tenth of the reads descends into two children.  Every read of a sample == the oracle's counting agent (hibf.hpp:432-460).
+# ---------------------------------------------------------------------------------------------------------------
+def _check_against_oracle_hibf(wl, flt, nh, mo, m, sample, seed):
+    bw.download_hibf(flt, wl)
+    hb = oracle.Hibf([oracle.Ibf(b, s, h, r) for (r, b, s, h) in wl.ibfs], wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)
+    rng = np.random.default_rng(seed)
+    multi = 0
+    for r in np.unique(rng.integers(0, wl.n_reads, size=sample)).tolist():
+        seq = wl.bases[int(wl.off[r]):int(wl.off[r + 1])]
+        hh = oracle.minimiser_hash(oracle.to_ranks(seq), wl.k, wl.w)
+        thr = oracle.threshold_cutoff(len(hh), wl.rel_cutoff)
+        counts = hb.bulk_count(hh, thr)
+        exp = [(int(u), int(min(c, len(hh)))) for u, c in zip(np.nonzero(counts)[0], counts[np.nonzero(counts)[0]])]
+        got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[r]):int(mo[r + 1])]]
+        assert nh[r] == len(hh) and got == exp, (r, got, exp)
+        multi += len(exp) >= 2
+    return multi
+
+
+@pytest.mark.parametrize("rel_cutoff", [0.75, 0.3])
+def test_hibf_skewed_layout_small_equals_oracle(rel_cutoff):
+    import ganon_amd
+    wl, flt = bw.make_hibf_skew_device_workload(ganon_amd, "skew_small", 16384, 3, 40_000, rel_cutoff=rel_cutoff, seed=7, rows_scale=0.004)
+    lay = wl.layout
+    assert lay["depth"] == 3 and lay["top_split_technical_bins"] > lay["top_split_user_bins"] and lay["child_bins_max"] == 1024
+    st = ganon_amd.HipStream(flt, wl.n_reads, wl.bases.size, wl.n_reads * 8)
+    st.upload(wl.bases, wl.off, None)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    nh, status, mo, m = st.fetch()
+    multi = _check_against_oracle_hibf(wl, flt, nh, mo, m, 3000, 11)
+    assert multi > 30           # reads that matched in two user bins (two children) were among the sample
+    # dense user-bin counts of a few reads == the agent's result vector
+    dense = st.dense_counts(0, 64, wl.n_user_bins)
+    hb = oracle.Hibf([oracle.Ibf(b, s, h, r) for (r, b, s, h) in wl.ibfs], wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)
+    for r in range(64):
+        hh = oracle.minimiser_hash(oracle.to_ranks(wl.bases[int(wl.off[r]):int(wl.off[r + 1])]), wl.k, wl.w)
+        assert np.array_equal(dense[r], hb.bulk_count(hh, oracle.threshold_cutoff(len(hh), wl.rel_cutoff)))
+    st.destroy()
+    flt.free()
+
+
+def test_hibf_skewed_layout_fullsize():
+    import ganon_amd
+    n = int(os.environ.get("GANON_FULLSIZE_HIBF_READS", 10_000_000))
+    wl, flt = bw.make_hibf_skew_device_workload(ganon_amd, "hibf64k_skew", 65536, 3, n, seed=99)
+    assert flt.info()["n_targets"] == 65536 and wl.layout["depth"] == 3
+    st = ganon_amd.HipStream(flt, n, wl.bases.size, n * 2)
+    st.upload(wl.bases, wl.off, None)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    nh, status, mo, m = st.fetch()
+    cnt = np.diff(mo.astype(np.int64))
+    pl = np.nonzero(wl.planted_genome >= 0)[0]
+    # every planted read reports its genome's user bin(s); the genomes that live in two user bins give two matches
+    assert (cnt[pl] >= 1).all()
+    two = np.isin(wl.planted_genome[pl], np.fromiter(wl.genome_second_user_bin.keys(), dtype=np.int64))
+    assert (cnt[pl][two] >= 2).mean() > 0.999 and 0.07 < two.mean() * len(pl) / n < 0.13
+    levels = st.hibf_levels()
+    assert len(levels) == 3 and all(lv["ms"] > 0 for lv in levels[:2])
+    # the top level's rows are 64 bytes (512 bins): a line each; the lower levels mix widths: lines >= rows, a multiple of 128
+    assert levels[0]["line_bytes"] == 2 * levels[0]["algo_bytes"] and all(lv["line_bytes"] >= lv["algo_bytes"] and lv["line_bytes"] % 128 == 0 for lv in levels)
+    ck = bw.checksum_matches(m)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    assert bw.checksum_matches(st.fetch()[3]) == ck
+    _check_against_oracle_hibf(wl, flt, nh, mo, m, 600, 5)
+    st.destroy()
+    flt.free()
