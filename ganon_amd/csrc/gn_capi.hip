@@ -841,7 +841,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
         ok(gn_dmalloc(&s->d_work[1], s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer, s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer2, s->work_cap));
-        ok(gn_dmalloc(&s->d_hctr, 5 * (GN_HIBF_MAXDEPTH + 1) + 2));
+        ok(gn_dmalloc(&s->d_hctr, 29 * (GN_HIBF_MAXDEPTH + 1) + 2));
         ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), (5 * (GN_HIBF_MAXDEPTH + 1) + 2) * sizeof(unsigned long long), hipHostMallocDefault));
     }
     ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), GN_NCTR * sizeof(unsigned long long), hipHostMallocDefault));

@@ -97,6 +97,7 @@ struct GnHibfLevelParams
     uint32_t                  n_reads;   // level 0 of the register-counter kernels: the reads are the items ...
     uint32_t                  read_base; // ... reads [read_base, read_base + n_reads) of the batch (a batch may be run in read ranges)
     const uint8_t*            status;
+    const unsigned long long* work_base; // packed kernel: its items begin at work_in[*work_base] (a class of the level's sorted list); nullptr = 0
     uint32_t                  pack_gp;   // packed kernel: log2 of the lanes per row every item of the launch must have
     uint32_t                  wide;      // the reference's -DLONGREADS build (value_t = uint32_t): sums do not wrap at 2^16 and reads
                                          // of more than 65535 minimisers (GN_READ_BIG) are counted like the others
@@ -208,7 +209,10 @@ struct GnHibfAppender
 // function i, the others fetch it with a lane permute).  Per iteration a wave still issues h coalesced requests that
 // touch 64/Gp different rows, so the memory system sees the same parallelism.
 // All items of a launch must use the same Gp (p.pack_gp: the most common lane width of the level's IBFs); items whose
-// IBF differs, has multi-bin runs, or whose read has more than 127 minimisers go to the per-item kernel's list.
+// IBF differs or whose read has more than 127 minimisers go to the per-item kernel's list.  Multi-bin runs (split user
+// bins: raptor puts the largest user bins of a level there, so the TOP IBF of a real index has them and every read visits
+// it) are summed from a per-wave LDS image of the byte counters, as in the per-item kernel: a group's lanes share the
+// item's runs.
 __device__ __forceinline__ uint32_t gn_hibf_row_seed(uint64_t v, uint64_t seed, uint32_t shift, uint32_t S)
 {
     uint64_t x = v * seed;
@@ -220,6 +224,7 @@ __device__ __forceinline__ uint32_t gn_hibf_row_seed(uint64_t v, uint64_t seed, 
 template <int HF, bool LEVEL0>
 __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
 {
+    __shared__ uint32_t img_all[4][GN_WAVE * 16]; // per wave: the 16 byte-counter registers of every lane (multi-bin runs)
     const uint32_t lane   = threadIdx.x & (GN_WAVE - 1);
     const uint32_t wave   = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t gpl    = p.pack_gp;
@@ -231,13 +236,20 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
     const bool     share  = Gp >= (uint32_t)HF;      // lane i of a group hashes function i for the whole group
     const uint64_t my_seed = GN_HIBF_SEEDS[gl < (uint32_t)HF ? gl : 0u];
 
-    uint32_t n_work;
+    uint32_t           n_work;
+    unsigned long long work_first = 0;
     if constexpr (LEVEL0)
         n_work = p.n_reads;
     else
     {
         const unsigned long long nw64 = *p.count_in;
         n_work                        = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
+        if (p.work_base)
+        {
+            work_first = *p.work_base;
+            if (work_first + n_work > p.work_cap)
+                n_work = work_first < p.work_cap ? (uint32_t)(p.work_cap - work_first) : 0u;
+        }
     }
     const uint32_t n_batches = (n_work + H - 1) / H;
     const uint32_t stride    = gridDim.x * (blockDim.x >> 6);
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
     // per-lane view of an item (the Gp lanes of a group hold identical copies)
     struct Item
     {
-        uint32_t read, ibf, n, W, shift, S;
+        uint32_t read, ibf, n, W, shift, S, nm; // nm: multi-bin runs of the item's IBF
         uint64_t slot;
         const __attribute__((address_space(1))) uint64_t* rows;
         bool     ok;    // counted here
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
                            : 0xFFFFFFFFu;
             else
             {
-                const uint2 e = p.work_in[idx];
+                const uint2 e = p.work_in[work_first + idx];
                 read = e.x;
                 ibf  = e.y;
             }
@@ -286,7 +298,8 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
             m.shift = f->shift;
             m.rows  = gn_global(f->rows);
             uint32_t g = m.W <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(m.W - 1);
-            m.ok    = m.W <= GN_WAVE && g == gpl && f->n_mruns == 0 && m.n >= 1 && m.n <= 127u;
+            m.nm    = f->n_mruns;
+            m.ok    = m.W <= GN_WAVE && g == gpl && m.n >= 1 && m.n <= 127u;
             m.defer = !m.ok && m.n >= 1;
         }
         return m;
@@ -475,6 +488,42 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
                 }
                 app.push(p, (int)lane, merged, leaf, cur.read, tgt, sum);
             } while (__ballot((c0 | c1) != 0));
+        }
+
+        // ---- multi-bin runs (split user bins, :445-458 with the running sum over the run): the group's lanes share the item's runs ----
+        const uint32_t nm = cur.ok ? cur.nm : 0u;
+        if (__ballot(nm != 0))
+        {
+            uint32_t* img = img_all[wave];
+            gn_hibf_wave_sync(); // (the readers of the batch before are through)
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp)
+                        img[lane * 16 + (d * 4 + j) * 2 + pp] = (n && col) ? byt[d][j][pp] : 0u;
+            gn_hibf_wave_sync();
+            const auto* mruns = nm ? gn_global(p.ibfs[cur.ibf].mruns) : gn_global((const uint4*)nullptr);
+            for (uint32_t r = gl; __ballot(r < nm); r += Gp)
+            {
+                bool     leaf = false;
+                uint32_t tgt = 0, sum = 0;
+                if (r < nm)
+                {
+                    const uint4 run = *reinterpret_cast<const uint4*>((uintptr_t)(mruns + r)); // first bin, n bins, user bin, -
+                    for (uint32_t b = run.x; b < run.x + run.y; ++b)
+                    {
+                        const uint32_t t = b & 63u, d = t >> 5, tt = t & 31u;
+                        const uint32_t v = img[(gbase + (b >> 6)) * 16 + (d * 4 + (tt & 3u)) * 2 + ((tt >> 2) & 1u)];
+                        sum              = sum + ((v >> (8 * (tt >> 3))) & 0xFFu);
+                        sum              = p.wide ? sum : (sum & 0xFFFFu); // value_t = uint16_t wraps (hibf.hpp:438,442)
+                    }
+                    leaf = sum >= T; // :455
+                    tgt  = run.z;
+                }
+                app.push(p, (int)lane, false, leaf, cur.read, tgt, sum);
+            }
         }
 
         batch += stride;
@@ -1243,8 +1292,19 @@ int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const i
                     ++g;
                 votes[depth[i] - 1][g]++;
             }
+        f->level_gps.assign(deepest, std::vector<uint32_t>());
         for (uint32_t l = 0; l < deepest; ++l)
+        {
             f->level_gp[l] = (uint32_t)(std::max_element(votes[l].begin(), votes[l].end()) - votes[l].begin());
+            // every lane width the level's IBFs have, most common first: the packed kernel runs once per width, each pass on what
+            // the pass before left (raptor's lower levels mix IBFs of 64 ... 1024 bins)
+            std::vector<uint32_t> order;
+            for (uint32_t g = 0; g < 7; ++g)
+                if (votes[l][g])
+                    order.push_back(g);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return votes[l][a] > votes[l][b]; });
+            f->level_gps[l] = order;
+        }
         f->level_bytes.assign(deepest, 0ull);
         f->level_row_bytes.assign(deepest, 0u);
         for (uint32_t i = 0; i < n_ibf; ++i)
@@ -1330,6 +1390,139 @@ static void gn_hibf_launch_pack(const GnHibfLevelParams& p, bool level0, uint32_
         gn_hibf_launch_pack2<HF, false>(p, n_cu, bpc, st);
 }
 
+// ---- a level's items sorted by the lane width of their IBF ------------------------------------------------------------------
+// raptor's lower levels mix IBFs of 64 ... 1024 technical bins; the packed kernel wants every item of a launch to have the same
+// lanes per row.  Two passes over the level's queue (8 bytes per item): count per class, then scatter -- class c = the c-th most
+// common width of the level (cls_of_gp), class 7 = what the packed kernel does not take (wider than 64 words, more than 127
+// minimisers), which goes straight to the per-item kernels' list.  Holes of the chunked queue are dropped on the way.
+struct GnHibfBucketParams
+{
+    const GnHibfIbfDev*       ibfs;
+    const uint32_t*           n_hashes;
+    const uint2*              work_in;
+    const unsigned long long* count_in;
+    uint32_t                  work_cap;
+    uint8_t                   cls_of_gp[8];
+    unsigned long long*       cls_count; // [8]
+    unsigned long long*       cls_base;  // [8] exclusive prefix of cls_count[0..6]
+    unsigned long long*       cls_cursor; // [8]
+    uint2*                    sorted_out;
+    uint2*                    rest_out;  // class 7
+    unsigned long long*       rest_count;
+};
+
+__device__ __forceinline__ uint32_t gn_hibf_item_class(const GnHibfBucketParams& p, uint2 e)
+{
+    if (e.x == 0xFFFFFFFFu)
+        return 8u; // a hole
+    const uint32_t W = p.ibfs[e.y].W, n = p.n_hashes[e.x];
+    if (n == 0)
+        return 8u;
+    if (W > GN_WAVE || n > 127u)
+        return 7u;
+    const uint32_t g = W <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(W - 1);
+    return p.cls_of_gp[g];
+}
+
+// A workgroup takes the queue in chunks of 4096 items; per chunk ONE atomic per class (a counter address sustains only ~90 atomics
+// per microsecond: per-wave atomics made these two passes the most expensive kernels of the level).
+#define GN_HIBF_BUCKET_ROUNDS 16u
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void gn_hibf_bucket_kernel(GnHibfBucketParams p)
+{
+    __shared__ uint32_t           wave_cnt[4][8];
+    __shared__ unsigned long long chunk_base[8];
+    const unsigned long long      nw64 = *p.count_in;
+    const uint32_t                n    = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
+    const uint32_t                lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t                chunk = 256u * GN_HIBF_BUCKET_ROUNDS;
+    const uint32_t                n_chunks = (n + chunk - 1) / chunk;
+    for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
+    {
+        const uint32_t first = ch * chunk + wave * 64u * GN_HIBF_BUCKET_ROUNDS; // this wave's 1024 items
+        uint32_t       mine[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            mine[c] = 0;
+        for (uint32_t k = 0; k < GN_HIBF_BUCKET_ROUNDS; ++k)
+        {
+            const uint32_t i = first + k * 64u + lane;
+            const uint32_t c = gn_hibf_item_class(p, i < n ? p.work_in[i] : make_uint2(0xFFFFFFFFu, 0u));
+#pragma unroll
+            for (uint32_t cc = 0; cc < 8; ++cc)
+                mine[cc] += (uint32_t)__popcll(__ballot(c == cc)); // (wave-uniform)
+        }
+        if (lane < 8)
+        {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t cc = 0; cc < 8; ++cc)
+                v = lane == cc ? mine[cc] : v;
+            wave_cnt[wave][lane] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8)
+        {
+            const uint32_t c     = threadIdx.x;
+            const uint32_t total = wave_cnt[0][c] + wave_cnt[1][c] + wave_cnt[2][c] + wave_cnt[3][c];
+            if (!SCATTER)
+            {
+                if (total)
+                    atomicAdd(&p.cls_count[c], (unsigned long long)total);
+            }
+            else
+                chunk_base[c] = total ? atomicAdd(c == 7 ? p.rest_count : &p.cls_cursor[c], (unsigned long long)total) : 0ull;
+        }
+        __syncthreads();
+        if (SCATTER)
+        {
+            unsigned long long at[8];
+#pragma unroll
+            for (uint32_t cc = 0; cc < 8; ++cc)
+            {
+                at[cc] = chunk_base[cc] + (cc == 7 ? 0ull : p.cls_base[cc]);
+                for (uint32_t w = 0; w < wave; ++w)
+                    at[cc] += wave_cnt[w][cc];
+            }
+            for (uint32_t k = 0; k < GN_HIBF_BUCKET_ROUNDS; ++k)
+            {
+                const uint32_t i = first + k * 64u + lane;
+                const uint2    e = i < n ? p.work_in[i] : make_uint2(0xFFFFFFFFu, 0u);
+                const uint32_t c = gn_hibf_item_class(p, e);
+#pragma unroll
+                for (uint32_t cc = 0; cc < 8; ++cc)
+                {
+                    const uint64_t m = __ballot(c == cc);
+                    if (c == cc)
+                    {
+                        const unsigned long long o = at[cc] + __popcll(m & ((1ULL << lane) - 1ULL));
+                        if (cc == 7)
+                        {
+                            if (o < p.work_cap)
+                                p.rest_out[o] = e;
+                        }
+                        else
+                            p.sorted_out[o] = e;
+                    }
+                    at[cc] += __popcll(m);
+                }
+            }
+        }
+        __syncthreads(); // (wave_cnt / chunk_base are reused by the next chunk)
+    }
+}
+
+__global__ void gn_hibf_bucket_bases_kernel(const unsigned long long* __restrict__ cnt, unsigned long long* __restrict__ base)
+{
+    unsigned long long at = 0;
+    for (int c = 0; c < 7; ++c)
+    {
+        base[c] = at;
+        at += cnt[c];
+    }
+    base[7] = at;
+}
+
 // Runs all levels back to back (queue lengths stay on the device), synchronises ONCE, then sorts/groups the matches.
 int gn_finish_batch(gn_stream* s); // gn_capi.hip
 
@@ -1353,7 +1546,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         return gn_fail(GN_ERANGE, "read index and user bin do not fit one 64-bit sort key");
     GN_HIP(hipMemsetAsync(s->d_ctr + 1, 0, 3 * sizeof(unsigned long long), st)); // line bytes, algo bytes, (unused)
     GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
-    GN_HIP(hipMemsetAsync(s->d_hctr, 0, (5 * NL + 2) * sizeof(unsigned long long), st)); // queues, per-level bytes, [4NL] output base, [4NL+2..] per-level line bytes
+    GN_HIP(hipMemsetAsync(s->d_hctr, 0, (29 * NL + 2) * sizeof(unsigned long long), st)); // queues, per-level bytes, [4NL] output base, [4NL+2..] per-level line bytes, [5NL+2..] per level: 8 class counts, bases, cursors
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
     unsigned long long* d_out_base = s->d_hctr + 4 * NL;
     const uint32_t h      = f->ibfs[0].h;
@@ -1386,6 +1579,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     auto run_levels = [&](uint32_t lo, uint32_t cnt, bool stamp) -> int {
         GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
         GN_HIP(hipMemsetAsync(s->d_hctr, 0, 3 * NL * sizeof(unsigned long long), st));
+        GN_HIP(hipMemsetAsync(s->d_hctr + 5 * NL + 2, 0, 24 * NL * sizeof(unsigned long long), st));
         if (cnt && no_reg) // (the register-counter kernels take level 0 straight from the batch)
             hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, s->d_work[0], s->v_status, lo, cnt, s->d_hctr,
                                s->long_reads ? 1u : 0u);
@@ -1425,10 +1619,8 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
             p.status      = s->v_status;
             p.pack_gp     = lvl < f->level_gp.size() ? f->level_gp[lvl] : 0u;
             bool level0   = lvl == 0; // the first register kernel of level 0 takes the reads themselves as its items
-            if (!no_pack)
-            {
-                p.defer_out   = s->d_hdefer;
-                p.defer_count = s->d_hctr + NL + lvl;
+            uint2* defer_next = s->d_hdefer; // the list the next kernel of this level writes what it leaves
+            auto   launch_pack = [&]() {
                 switch (h)
                 {
                     case 1: gn_hibf_launch_pack<1>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
@@ -1437,14 +1629,64 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                     case 4: gn_hibf_launch_pack<4>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
                     default: gn_hibf_launch_pack<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
                 }
+            };
+            const bool one_pass = getenv("GANON_HIP_HIBF_ONE_PACK") != nullptr; // tests: the level's most common width only
+            const std::vector<uint32_t>& gps = lvl < f->level_gps.size() ? f->level_gps[lvl] : std::vector<uint32_t>();
+            if (!no_pack && !level0 && gps.size() > 1 && !one_pass)
+            {
+                // IBFs of several widths on this level: the queue is sorted by width first, then one packed launch per width over its
+                // part of the sorted list; what those do not take (and the widths beyond 64 words) is the per-item kernels' list
+                GnHibfBucketParams bp{};
+                bp.ibfs     = f->d_hibf;
+                bp.n_hashes = s->v_nh;
+                bp.work_in  = p.work_in;
+                bp.count_in = p.count_in;
+                bp.work_cap = s->work_cap;
+                for (uint32_t g = 0; g < 8; ++g)
+                    bp.cls_of_gp[g] = 7;
+                for (size_t c = 0; c < gps.size() && c < 7; ++c)
+                    bp.cls_of_gp[gps[c]] = (uint8_t)c;
+                bp.cls_count  = s->d_hctr + 5 * NL + 2 + (size_t)lvl * 8;
+                bp.cls_base   = s->d_hctr + 13 * NL + 2 + (size_t)lvl * 8;
+                bp.cls_cursor = s->d_hctr + 21 * NL + 2 + (size_t)lvl * 8;
+                bp.sorted_out = s->d_hdefer;
+                bp.rest_out   = s->d_hdefer2;
+                bp.rest_count = s->d_hctr + NL + lvl;
+                const dim3 grid((uint32_t)f->n_cu * 8u);
+                hipLaunchKernelGGL(gn_hibf_bucket_kernel<false>, grid, dim3(256), 0, st, bp);
+                hipLaunchKernelGGL(gn_hibf_bucket_bases_kernel, dim3(1), dim3(1), 0, st, bp.cls_count, bp.cls_base);
+                hipLaunchKernelGGL(gn_hibf_bucket_kernel<true>, grid, dim3(256), 0, st, bp);
                 GN_HIP(hipGetLastError());
-                p.work_in  = s->d_hdefer;
-                p.count_in = s->d_hctr + NL + lvl;
+                p.work_in     = s->d_hdefer;
+                p.defer_out   = s->d_hdefer2;
+                p.defer_count = s->d_hctr + NL + lvl;
+                for (size_t c = 0; c < gps.size() && c < 7; ++c)
+                {
+                    p.pack_gp   = gps[c];
+                    p.count_in  = bp.cls_count + c;
+                    p.work_base = bp.cls_base + c;
+                    launch_pack();
+                    GN_HIP(hipGetLastError());
+                }
+                p.work_base = nullptr;
+                p.work_in   = s->d_hdefer2;
+                p.count_in  = s->d_hctr + NL + lvl;
+                defer_next  = s->d_hdefer; // (the sorted list is done with)
+            }
+            else if (!no_pack)
+            {
+                p.defer_out   = defer_next;
+                p.defer_count = s->d_hctr + NL + lvl;
+                launch_pack();
+                GN_HIP(hipGetLastError());
+                p.work_in  = p.defer_out;
+                p.count_in = p.defer_count;
+                defer_next = s->d_hdefer2;
                 level0     = false;
             }
             if (!no_reg)
             {
-                p.defer_out   = s->d_hdefer2;
+                p.defer_out   = defer_next;
                 p.defer_count = s->d_hctr + 2 * NL + lvl;
                 switch (h)
                 {
@@ -1455,7 +1697,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                     default: gn_hibf_launch_reg<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
                 }
                 GN_HIP(hipGetLastError());
-                p.work_in  = s->d_hdefer2;
+                p.work_in  = p.defer_out;
                 p.count_in = s->d_hctr + 2 * NL + lvl;
             }
             // LDS-counter kernel: what the register kernels left (or, with the switch above, the whole level)

@@ -226,6 +226,7 @@ struct gn_filter
     uint32_t               max_bins = 0;
     uint32_t               max_depth = 0;
     std::vector<uint32_t>  level_gp;  // per tree level: log2(lanes per row) most of its IBFs have (packed kernel)
+    std::vector<std::vector<uint32_t>> level_gps; // ... and every width that occurs there, most common first
     std::vector<uint64_t>  level_bytes; // per tree level: bytes of the IBFs at that depth (is the level's table cache resident?)
     std::vector<uint32_t>  level_row_bytes; // per tree level: row bytes most of its IBFs have
 };

@@ -282,6 +282,15 @@ def test_hibf_skewed_layout_small_equals_oracle(rel_cutoff):
     nh, status, mo, m = st.fetch()
     multi = _check_against_oracle_hibf(wl, flt, nh, mo, m, 3000, 11)
     assert multi > 30           # reads that matched in two user bins (two children) were among the sample
+    # the same batch through the other kernel paths: no packed kernel, LDS kernel only, no sorting of a level's queue by IBF width
+    for switch in ("GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG", "GANON_HIP_HIBF_ONE_PACK"):
+        os.environ[switch] = "1"
+        try:
+            st.classify(wl.k, wl.w, wl.rel_cutoff)
+            nh2, _, mo2, m2 = st.fetch()
+        finally:
+            del os.environ[switch]
+        assert np.array_equal(nh, nh2) and np.array_equal(mo, mo2) and np.array_equal(m, m2), switch
     # dense user-bin counts of a few reads == the agent's result vector
     dense = st.dense_counts(0, 64, wl.n_user_bins)
     hb = oracle.Hibf([oracle.Ibf(b, s, h, r) for (r, b, s, h) in wl.ibfs], wl.next_ibf_id, wl.bin_to_user, wl.n_user_bins)

@@ -106,7 +106,7 @@ def test_hibf_randomised_layouts(seed, monkeypatch):
         paired = bool(cfg % 2)
         bases, off1, off2 = gu.pack_reads(s1, s2 if paired else None)
         outs = []
-        for sw in (None, "GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG"):
+        for sw in (None, "GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG", "GANON_HIP_HIBF_ONE_PACK"):
             if sw:
                 monkeypatch.setenv(sw, "1")
             st = hip.HipStream(flt, len(s1), max(bases.size, 1))

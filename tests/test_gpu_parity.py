@@ -270,7 +270,7 @@ def test_hibf_register_kernel_vs_lds_kernel_vs_oracle(hip, monkeypatch, n_ub, tm
     st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
     assert nh.max() > 127 and (nh[nh > 0] <= 127).any()
     tm = st.timings()
-    for switch in ("GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG"):  # per-item register kernel first / LDS kernel only
+    for switch in ("GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG", "GANON_HIP_HIBF_ONE_PACK"):  # per-item register kernel first / LDS kernel only / no sorting of a level by IBF width
         monkeypatch.setenv(switch, "1")
         st2, nh2, status2, mo2, m2 = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
         monkeypatch.delenv(switch)
