@@ -799,11 +799,12 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
             e = x;
     };
     ok(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-    // The minimiser kernels may run on a side stream, one chunk ahead of the count kernels ($GANON_HIP_CHUNK, $GANON_HIP_SIDE_STREAM=1).
+    // The minimiser kernels may run on a side stream, one chunk ahead of the count kernels ($GANON_HIP_CHUNK: the tests' way of running a
+    // batch in read ranges).
     // With one chunk per batch -- the default: chunking gained nothing, see gn_stream_classify -- a second stream per batch context
     // only costs: the runtime maps all streams of a process onto a few hardware queues (4 by default), and streams that share a
     // queue wait for each other's copies and kernels.  One stream per context keeps a worker's batches independent of the others'.
-    if (getenv("GANON_HIP_SIDE_STREAM") || getenv("GANON_HIP_CHUNK"))
+    if (getenv("GANON_HIP_CHUNK"))
         ok(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
     else
         s->st2 = s->st;
@@ -1066,9 +1067,9 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.dense      = nullptr;
     p.max_blocks = (uint32_t)f->n_cu * 16u;
     // persistent grid = a whole number of resident rounds: 8-byte-lane variant holds 4 blocks per CU, 16-byte one 3
-    p.max_blocks_fast = (uint32_t)f->n_cu * (getenv("GANON_HIP_FAST_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_FAST_BPC")) : (f->geom.lw == 1 ? 8u : 6u));
-    p.nt_loads = getenv("GANON_HIP_NT") ? (uint32_t)atoi(getenv("GANON_HIP_NT")) : 0u;
-    p.early_exit = getenv("GANON_HIP_NO_EARLY_EXIT") ? 0u : (getenv("GANON_HIP_EE") ? (uint32_t)atoi(getenv("GANON_HIP_EE")) : 1u);
+    p.max_blocks_fast = (uint32_t)f->n_cu * (f->geom.lw == 1 ? 8u : 6u);
+    p.nt_loads = 0u;
+    p.early_exit = getenv("GANON_HIP_NO_EARLY_EXIT") ? 0u : 1u; // (the switch: bench.py's variant and the parity tests of the exit)
     p.skip_ctr   = s->d_ctr + 7;
     if (lo == 0) // (a re-run after a match-buffer regrow starts the tally again)
         GN_HIP(hipMemsetAsync(s->d_ctr + 7, 0, sizeof(unsigned long long), s->st));

@@ -1553,7 +1553,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     // tests / A-B: skip the packed kernel (the per-item register kernel takes whole levels), or both (LDS kernel only)
     const bool     no_reg  = getenv("GANON_HIP_HIBF_NO_REG") != nullptr;
     const bool     no_pack = no_reg || getenv("GANON_HIP_HIBF_NO_PACK") != nullptr;
-    const uint32_t reg_bpc = getenv("GANON_HIP_HIBF_BPC") ? (uint32_t)atoi(getenv("GANON_HIP_HIBF_BPC")) : 0u; // 0 = occupancy
+    const uint32_t reg_bpc = 0u; // workgroups per CU of the register kernels: what the occupancy query says
     // with a filter_matches pre-pass on the stream, what it is bound to drop does not reach the sort
     const bool may_predrop = s->pf_on && !s->pf_merge && s->d_pf_segmin && s->d_pf_rmax && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
                              (uint64_t)n + 1 <= s->pf_segmin_cap && !getenv("GANON_HIP_NO_PREDROP");

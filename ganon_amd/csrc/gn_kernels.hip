@@ -419,9 +419,6 @@ bool gn_count_geometry(uint64_t W, uint32_t hash_funs, GnCountGeometry* g, const
     // one wave: no hash groups to add up, fewer registers (one more wave per SIMD) and a shuffle-free early-exit
     // check (measured on the 4096-bin headline shape: same speed without early exit, 8 % faster with it)
     g->lw                 = (W % 2 == 0 && W != 64) ? 2u : 1u;
-    if (const char* e = getenv("GANON_HIP_LW")) // experiments: force the lane width
-        if ((atoi(e) == 1) || (atoi(e) == 2 && W % 2 == 0))
-            g->lw = (uint32_t)atoi(e);
     const uint64_t per_wv = 64ull * g->lw; // words per wave slice
     // waves per read = column slices of the row, exactly (rounding up to a power of two left 3 of 8 waves -- and
     // their LDS -- idle on a 640-word row)

@@ -487,7 +487,7 @@ static void gn_launch_lprk(const GnMinimiserParams& p, hipStream_t st)
 {
     const dim3 grid((p.n_reads - p.read_begin + GN_WAVE - 1) / GN_WAVE);
     // keys are (value << 16) | position with value < 4^k: below 2^56 -- the range gn_key_min's float form needs -- up to k = 20
-    if (p.k <= 20 && !getenv("GANON_HIP_MINIMISER_INTMIN"))
+    if (p.k <= 20)
         hipLaunchKernelGGL((gn_minimiser_lprk_kernel<KW, true>), grid, dim3(GN_WAVE), 0, st, p);
     else
         hipLaunchKernelGGL((gn_minimiser_lprk_kernel<KW, false>), grid, dim3(GN_WAVE), 0, st, p);

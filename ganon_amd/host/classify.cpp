@@ -570,21 +570,13 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             // ---- raw pieces: the backend finds the records (single-end, uncompressed four-line FASTQ) ------------------------
             if (raw_fastq && !paired)
             {
-                // Text for the device, or parsed here after all?  With $GANON_HOST_HYBRID=1 a slab reader that finds the batch queue full
-                // (the device side is not keeping up with the text: the link is its limit) parses its slab instead of waiting -- half
-                // the bytes for the link, paid with cores that had nothing to do.  Measured: 101-115 Mreads/s against 120-130 with text
-                // only on the same box (profiles/r03_e2e_ab_tokeniser.txt) -- the cores are not idle enough; off by default.
-                std::function<bool()> slack;
-                if (env_size("GANON_HOST_HYBRID", 0))
-                    slack = [&queue] { return queue.size() + 1 >= queue.capacity(); };
-                if (auto pfr = ParallelFastq::open(pair.mate1, slack ? par_threads : std::min(par_threads, 6u), slab_bytes, par_min, false, true, slack))
+                if (auto pfr = ParallelFastq::open(pair.mate1, std::min(par_threads, 6u), slab_bytes, par_min, false, true))
                 {
                     auto                tracker = std::make_shared<RawFileTracker>();
                     size_t              pieces  = 0;
                     ParallelFastq::Slab a;
                     bool                gave_up = false; // the slab readers do not take the piece at gave_up_at (and nothing behind it)
                     uint64_t            gave_up_at = 0;
-                    std::map<size_t, std::string> errors; // piece -> the ParseError that ended it (a piece parsed here)
                     while (pfr->next(a))
                     {
                         if (!a.text.empty())
@@ -597,25 +589,6 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                             rb.ticket.reset(new RawTicket{ tracker, pieces++ });
                             rb.seq = seq++;
                             copier.deliver(std::move(rb)); // (input is counted by the worker, once the records are known)
-                            fresh();
-                        }
-                        else if (a.size() != 0 || !a.error.empty() || (a.irregular && !a.rec_at.empty()))
-                        {
-                            // a piece parsed here: its records are a batch like the host parser's, but it has its place among the file's
-                            // pieces -- it says right away whether it is records from end to end, and is dropped with the others if a
-                            // piece before it was not
-                            rb.id_buf.swap(a.ids);
-                            rb.id_off.swap(a.id_off);
-                            rb.bases.swap(a.bases);
-                            rb.off1.swap(a.off);
-                            rb.ticket.reset(new RawTicket{ tracker, pieces });
-                            if (!a.error.empty())
-                                errors[pieces] = a.error;
-                            const bool whole = a.error.empty() && !a.irregular;
-                            rb.ticket->publish(whole, a.irregular ? a.resume_at : (a.rec_at.empty() ? 0 : a.rec_at.back()));
-                            ++pieces;
-                            rb.seq = seq++;
-                            copier.deliver(std::move(rb));
                             fresh();
                         }
                         else if (a.irregular) // (the slab readers do not take this piece at all)
@@ -634,11 +607,6 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     {
                         if (at == UINT64_MAX) // (the pipeline is going down)
                             file_done = true;
-                        else if (errors.count(stopped_by)) // a piece parsed here ended with a parse error: the file ends there (:1278-1283)
-                        {
-                            report_error(errors[stopped_by]);
-                            file_done = true;
-                        }
                         else
                         {
                             resume1  = at;

@@ -783,7 +783,6 @@ struct ParallelFastq::Impl
     bool                     mate_room = false;
     bool                     fasta = false; // records start at lines that begin with '>' (no sequence line can: '>' is no legal letter)
     bool                     raw = false;   // slabs are delivered as text (Slab::text)
-    std::function<bool()>    want_parsed;   // raw mode: parse this slab here after all?
 
     // first byte of the first record at or after p (== size when there is none): a line that begins with '@' and whose
     // next-but-one line begins with '+'
@@ -986,7 +985,7 @@ struct ParallelFastq::Impl
     {
         // (raw slabs of a plain file: the lines read here are the few around a slab's borders.  Of a gzip stream: the same read-ahead as
         //  the parsing slabs have, so that a damaged stream ends the slabs at the same place whichever way they are delivered)
-        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get(), raw && !want_parsed && !gz ? (64u << 10) : (4u << 20));
+        RangeLines in = map ? RangeLines(map, size) : RangeLines(fd, gz ? ~0ull : size, gz.get(), raw && !gz ? (64u << 10) : (4u << 20));
         for (;;)
         {
             size_t i;
@@ -1033,7 +1032,7 @@ struct ParallelFastq::Impl
                     s.irregular = true;
                     s.resume_at = b;
                 }
-                else if (b < e && raw && !(want_parsed && want_parsed()))
+                else if (b < e && raw)
                     read_text(b, e, s);
                 else if (b < e)
                     parse(in, b, e, s);
@@ -1069,7 +1068,7 @@ struct ParallelFastq::Impl
 ParallelFastq::ParallelFastq(Impl* i) : impl_(i) {}
 
 std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
-                                                   bool mate_room, bool raw, std::function<bool()> want_parsed)
+                                                   bool mate_room, bool raw)
 {
     std::string base = path;
     bool        gz_name = false;
@@ -1138,7 +1137,6 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
     im->mate_room  = mate_room;
     im->fasta      = fasta;
     im->raw        = raw;
-    im->want_parsed = raw ? std::move(want_parsed) : std::function<bool()>();
     if (gz)
     {
         gz->set_retain_limit((uint64_t)(im->window + 3) * im->slab_bytes);

@@ -73,11 +73,8 @@ public:
     // mate_room: the slabs' base buffers are reserved with room for as many bases again (the first file of a pair: the
     // mates are appended behind them when the slab becomes a batch -- without the room that append re-locks pages)
     // raw: uncompressed FASTQ or FASTA only -- the slabs are cut by the same rule but delivered as text (Slab::text), unparsed
-    // want_parsed (raw mode): asked per slab, by the thread that is about to read it -- true: parse this one here after all (the slab
-    // then arrives parsed, `text` empty).  The caller says so while the device side has more text waiting than it takes: the cores are
-    // idle then, and a parsed slab is half the bytes over the link.
     static std::unique_ptr<ParallelFastq> open(const std::string& path, unsigned threads, size_t slab_bytes, size_t min_bytes,
-                                               bool mate_room = false, bool raw = false, std::function<bool()> want_parsed = {});
+                                               bool mate_room = false, bool raw = false);
     ~ParallelFastq();
     bool fasta() const;   // the file is FASTA by its name (raw slabs: two-line records, >id / letters)
     bool next(Slab& out); // slabs in file order; false at the end of the file (or after an error / irregular slab)

@@ -335,9 +335,9 @@ def test_device_tokenised_fastq_equals_sequential_reader(oracle_bin, sim_db, tmp
     f1 = _raw_case_file(variant, sim_db, tmp_path)
     seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / "seq"), False, {"GANON_HOST_PARSE_THREADS": "0"})
     common = {"GANON_HOST_PARSE_THREADS": "3", "GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_TIMING": "1", "GANON_HOST_DEVICE_FASTQ": "1"}
-    for slab, extra, hybrid in (("65536", (), "1"), ("200000", ("--device", "0"), "0"), ("1048576", ("--device", "0,0"), "1"), ("65536", ("--device", "0,0"), "0")):
-        err, out = _run_reader_case(cu.BIN_HIP, sim_db["ibf"], [f1], str(tmp_path / ("dev" + slab + hybrid)), False,
-                                    dict(common, GANON_HOST_SLAB_BYTES=slab, GANON_HOST_HYBRID=hybrid), extra)
+    for slab, extra, tag in (("65536", (), "a"), ("200000", ("--device", "0"), "b"), ("1048576", ("--device", "0,0"), "c"), ("65536", ("--device", "0,0"), "d")):
+        err, out = _run_reader_case(cu.BIN_HIP, sim_db["ibf"], [f1], str(tmp_path / ("dev" + slab + tag)), False,
+                                    dict(common, GANON_HOST_SLAB_BYTES=slab), extra)
         assert out == seq_out, (variant, slab)
         assert ("Error parsing" in err) == ("Error parsing" in seq_err)
         if variant not in ("crlf", "wrapped"):
@@ -358,14 +358,11 @@ def test_raw_pieces_and_worker_lanes_with_the_checker_backend(oracle_bin, sim_db
     run here with many small batches and several workers -- same bytes as the sequential reader, and no run may hang."""
     f1 = _raw_case_file(variant, sim_db, tmp_path)
     seq_err, seq_out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / "seq"), False, {"GANON_HOST_PARSE_THREADS": "0"})
-    # (raw pieces are text for the backend unless the batch queue is full -- then the slab reader parses its piece itself, and it takes
-    #  its place among the file's pieces as a parsed batch; hybrid "0": text always)
-    for raw, lanes, slab, dev, hybrid in (("1", "2", "65536", "0,0,0", "1"), ("1", "3", "70000", "0,0", "1"), ("1", "1", "200000", "0", "1"),
-                                          ("1", "2", "65536", "0,0", "0"), ("0", "2", "65536", "0,0,0,0", "1"), ("0", "3", "65536", "0", "1")):
+    for raw, lanes, slab, dev in (("1", "2", "65536", "0,0,0"), ("1", "3", "70000", "0,0"), ("1", "1", "200000", "0"),
+                                  ("1", "2", "65536", "0,0"), ("0", "2", "65536", "0,0,0,0"), ("0", "3", "65536", "0")):
         env = {"GANON_HOST_PARSE_THREADS": "3", "GANON_HOST_PARALLEL_MIN": "0", "GANON_HOST_TIMING": "1", "GANON_HOST_DEVICE_FASTQ": raw,
-               "GANON_HOST_LANES": lanes, "GANON_HOST_SLAB_BYTES": slab, "GANON_HOST_BATCH_READS": "97", "GANON_HOST_POST_THREADS": "2",
-               "GANON_HOST_HYBRID": hybrid}
-        err, out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / f"o{raw}{lanes}{slab}{hybrid}"), False, env, ("--device", dev))
+               "GANON_HOST_LANES": lanes, "GANON_HOST_SLAB_BYTES": slab, "GANON_HOST_BATCH_READS": "97", "GANON_HOST_POST_THREADS": "2"}
+        err, out = _run_reader_case(oracle_bin, sim_db["ibf"], [f1], str(tmp_path / f"o{raw}{lanes}{slab}{dev.count(',')}"), False, env, ("--device", dev))
         assert out == seq_out, (variant, raw, lanes, slab, dev)
         assert ("Error parsing" in err) == ("Error parsing" in seq_err)
         if variant not in ("crlf", "wrapped"):  # (a file whose FIRST record is not taken never delivers a piece)
