@@ -20,7 +20,7 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
 dst = os.path.join(ROOT, "profiles")
 # kernels whose launches make up one "count/select" step of the workload
 HIBF = ["gn_hibf_pack_kernel", "gn_hibf_reg_kernel", "gn_hibf_level_kernel"]
-KERNELS = {"hibf64k": HIBF, "hibf64k_top1g": HIBF, "split32k": ["gn_ibf_count_split_kernel"]}.get(wl, ["gn_ibf_count_fast_kernel"])
+KERNELS = {"hibf64k": HIBF, "hibf64k_top1g": HIBF, "hibf64k_skew": HIBF, "split32k": ["gn_ibf_count_split_kernel"]}.get(wl, ["gn_ibf_count_fast_kernel"])
 
 
 def find(sub, suffix):
