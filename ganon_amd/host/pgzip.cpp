@@ -586,7 +586,8 @@ struct ParallelGzip::Impl
     // input
     int            fd = -1;
     const uint8_t* data = nullptr;
-    size_t         size = 0, chunk_bytes = 0, n_chunks = 0;
+    size_t         size = 0, chunk_bytes = 0;
+    std::atomic<size_t> n_chunks{ 0 }; // (grows by one per early hand-over, see stitch(): the slot is filled before the count moves)
     unsigned       n_threads = 1;
 
     struct Chunk
@@ -604,7 +605,9 @@ struct ParallelGzip::Impl
         std::vector<uint32_t> seg_crc; // CRC-32 of the pieces between member ends
         bool                  resolved = false;
     };
-    std::deque<Chunk> chunks; // (deque: elements never move; once_flag is not movable)
+    // One slot per chunk of the file plus spare slots for the chunks stitch() appends; the array of slots never moves (workers index it
+    // without the lock), a spare's Chunk is created under the lock before n_chunks says it is there.
+    std::vector<std::unique_ptr<Chunk>> chunks;
 
     std::mutex              m;
     std::condition_variable cv_work, cv_done, cv_read;
@@ -634,7 +637,7 @@ struct ParallelGzip::Impl
 
     uint64_t start_of(size_t k)
     {
-        Chunk& c = chunks[k];
+        Chunk& c = *chunks[k];
         std::call_once(c.once_start, [&] {
             if (k == 0)
                 c.found_start = 0;
@@ -680,7 +683,7 @@ struct ParallelGzip::Impl
                     what = 1;
                 }
             }
-            Chunk& c = chunks[k];
+            Chunk& c = *chunks[k];
             if (what == 1)
             {
                 const uint64_t s = start_of(k);
@@ -751,15 +754,21 @@ struct ParallelGzip::Impl
             {
                 // every chunk is settled but the stream is not at its end: the last decode handed over early (the cap on the
                 // symbols one decode keeps).  One more chunk, behind the file's last, that continues from `pos`.
+                const size_t at = n_chunks.load();
+                if (at >= chunks.size())
+                {
+                    fail("more early hand-overs than a deflate stream of this size can need");
+                    break;
+                }
                 std::lock_guard<std::mutex> lk(m);
-                chunks.emplace_back();
-                chunks.back().decoded = true; // (no speculative decode: the "does not begin at pos" path below decodes it)
-                ++n_chunks;
-                next_decode = n_chunks;
+                chunks[at].reset(new Chunk());
+                chunks[at]->decoded = true; // (no speculative decode: the "does not begin at pos" path below decodes it)
+                n_chunks.store(at + 1);
+                next_decode = at + 1;
             }
             if (k < n_chunks)
             {
-                Chunk* c = &chunks[k];
+                Chunk* c = chunks[k].get();
                 bool   ready;
                 {
                     std::unique_lock<std::mutex> lk(m);
@@ -839,7 +848,7 @@ struct ParallelGzip::Impl
             // publish in order
             for (;;)
             {
-                Chunk* c = pub < n_chunks ? &chunks[pub] : nullptr;
+                Chunk* c = pub < n_chunks ? chunks[pub].get() : nullptr;
                 if (!c || pub >= k)
                     break;
                 {
@@ -946,8 +955,10 @@ std::unique_ptr<ParallelGzip> ParallelGzip::open(const std::string& path, unsign
     im->n_chunks    = (im->size + im->chunk_bytes - 1) / im->chunk_bytes;
     im->n_threads   = std::max(1u, threads);
     im->window_chunks = 2 * im->n_threads + 2;
+    // (deflate expands at most 1032-fold; a decode hands over after 96 M symbols at the latest: the spare slots cover every hand-over)
+    im->chunks.resize(im->n_chunks + (size_t)(((uint64_t)im->size * 1032ull) / (96ull << 20)) + 16);
     for (size_t i = 0; i < im->n_chunks; ++i)
-        im->chunks.emplace_back();
+        im->chunks[i].reset(new Impl::Chunk());
     std::unique_ptr<ParallelGzip> pg(new ParallelGzip(im));
     for (unsigned t = 0; t < im->n_threads; ++t)
         im->workers.emplace_back([im] { im->worker(); });
