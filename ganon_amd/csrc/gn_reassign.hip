@@ -13,9 +13,8 @@
 //     logged value see the reference's bits.
 // The choice of a read is the FIRST entry whose probability is strictly larger than every earlier one's and than 0, else
 // the first entry (:226-241) -- an arg-max with first-listed tie-break; reads of up to GN_RA_LIGHT entries take one lane,
-// longer ones one wave (list built once at creation).  Counts are integers: lanes of a wave that chose the same target add
-// once (ballot), into an LDS histogram per workgroup when the target table is small (<= GN_RA_LDS_TARGETS), else into the
-// global counters; either way order-independent.
+// longer ones one wave (list built once at creation).  Counts are integers and the passes compare counts, not probabilities (see
+// gn_ra_pick_lane); from the second pass on a read only touches the counters when its choice changed.
 #include "gn_internal.h"
 
 #include <cstdlib>
@@ -23,7 +22,6 @@
 #include <vector>
 
 #define GN_RA_LIGHT 32u
-#define GN_RA_LDS_TARGETS 4096u // an LDS histogram of at most 16 KiB per workgroup: eight or more workgroups stay resident per CU
 #define GN_RA_BLOCK 256u
 
 struct gn_reassign
@@ -38,7 +36,9 @@ struct gn_reassign
     unsigned long long* d_n_heavy = nullptr;
     uint64_t    n_heavy = 0;
     unsigned long long* d_uniq   = nullptr; // per target: reads that list it and nothing else (:96-103)
-    unsigned long long* d_counts = nullptr; // reassigned_matches of the running iteration (:113-121)
+    unsigned long long* d_counts = nullptr; // reassigned_matches of the last iteration (:113-121), widened for the fetch call
+    uint32_t*   d_w[2]   = { nullptr, nullptr }; // counts of the pass before (what a pass compares) / of the running pass
+    uint32_t*   d_chosen = nullptr; // per read: the target it chose in the pass before
     double*     d_prob   = nullptr;
     double*     d_absd   = nullptr; // |old - new| per target
     double*     d_diff   = nullptr; // [0] the iteration's diff
@@ -106,24 +106,27 @@ __global__ void gn_ra_first_prob_kernel(const unsigned long long* __restrict__ u
 }
 
 // ---- the choice of a read (:226-241) ----------------------------------------------------------------------------------
-// Entries in groups of four: the four target loads, then the four probability gathers, are independent of each other, so a
-// lane has eight loads in flight instead of a chain of two per entry (the pass is latency-bound otherwise).
-__device__ __forceinline__ uint64_t gn_ra_pick_lane(const uint32_t* __restrict__ target, const double* __restrict__ prob, uint64_t b,
+// get_top_match compares probabilities; every probability of a pass is the same pass's count divided by one number (unique / number
+// of unique reads before the first pass, count / number of reads afterwards), and a correctly rounded division by a constant keeps
+// the order of integers below 2^32 apart (neighbouring quotients differ by a relative 2^-32 at least), zero stays zero.  So the
+// passes compare the COUNTS the probabilities were made from -- 4-byte gathers instead of 8, no floating point in the pass.
+// Entries in groups of four: the four target loads, then the four count gathers, are independent of each other, so a lane has
+// eight loads in flight instead of a chain of two per entry (the pass is latency-bound otherwise).
+__device__ __forceinline__ uint64_t gn_ra_pick_lane(const uint32_t* __restrict__ target, const uint32_t* __restrict__ weight, uint64_t b,
                                                     uint64_t e)
 {
-    double   best = 0.0;
+    uint32_t best = 0;
     uint64_t at   = b;
     uint64_t i    = b;
     for (; i + 4 <= e; i += 4)
     {
-        uint32_t t[4];
-        double   p[4];
+        uint32_t t[4], p[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             t[j] = target[i + j];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            p[j] = prob[t[j]];
+            p[j] = weight[t[j]];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (p[j] > best)
@@ -134,14 +137,13 @@ __device__ __forceinline__ uint64_t gn_ra_pick_lane(const uint32_t* __restrict__
     }
     if (i < e)
     {
-        uint32_t t[3];
-        double   p[3];
+        uint32_t t[3], p[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             t[j] = target[i + j < e ? i + j : i];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            p[j] = prob[t[j]];
+            p[j] = weight[t[j]];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             if (i + j < e && p[j] > best)
@@ -157,8 +159,7 @@ __device__ __forceinline__ uint64_t gn_ra_pick_lane(const uint32_t* __restrict__
 // broadcast, the lanes holding the same one are counted with a ballot and leave; what is left adds on its own.  Abundance
 // profiles are skewed (a few targets take most reads), which is exactly where per-lane atomics on one address serialise.
 #define GN_RA_AGG_ROUNDS 4
-template <typename CTR>
-__device__ __forceinline__ void gn_ra_add_aggregated(CTR* __restrict__ ctr, uint32_t t, bool active)
+__device__ __forceinline__ void gn_ra_add_aggregated(uint32_t* __restrict__ ctr, uint32_t t, bool active)
 {
     unsigned long long todo = __ballot(active);
 #pragma unroll 1
@@ -168,24 +169,24 @@ __device__ __forceinline__ void gn_ra_add_aggregated(CTR* __restrict__ ctr, uint
         const uint32_t lt   = (uint32_t)__shfl((int)t, lead);
         const unsigned long long same = __ballot(active && t == lt);
         if ((int)(threadIdx.x & 63u) == lead)
-            atomicAdd(&ctr[lt], (CTR)__popcll(same));
+            atomicAdd(&ctr[lt], (uint32_t)__popcll(same));
         if (active && t == lt)
             active = false;
         todo &= ~same;
     }
     if (active)
-        atomicAdd(&ctr[t], (CTR)1);
+        atomicAdd(&ctr[t], 1u);
 }
 
 // one wave, entries strided over its lanes: the first entry holding the read's maximum if that is positive
-__device__ __forceinline__ uint64_t gn_ra_pick_wave(const uint32_t* __restrict__ target, const double* __restrict__ prob, uint64_t b,
+__device__ __forceinline__ uint64_t gn_ra_pick_wave(const uint32_t* __restrict__ target, const uint32_t* __restrict__ weight, uint64_t b,
                                                     uint64_t e, unsigned lane)
 {
-    double   best = 0.0;
+    uint32_t best = 0;
     uint64_t at   = ~0ull;
     for (uint64_t i = b + lane; i < e; i += 64)
     {
-        const double p = prob[target[i]];
+        const uint32_t p = weight[target[i]];
         if (p > best) // ascending i inside a lane: the lane's first entry at its maximum
         {
             best = p;
@@ -194,7 +195,7 @@ __device__ __forceinline__ uint64_t gn_ra_pick_wave(const uint32_t* __restrict__
     }
     for (int s = 32; s; s >>= 1)
     {
-        const double   ob = __shfl_xor(best, s);
+        const uint32_t ob = (uint32_t)__shfl_xor((int)best, s);
         const uint64_t oa = __shfl_xor(at, s);
         if (ob > best || (ob == best && oa < at))
         {
@@ -202,23 +203,20 @@ __device__ __forceinline__ uint64_t gn_ra_pick_wave(const uint32_t* __restrict__
             at   = oa;
         }
     }
-    return best > 0.0 ? at : b;
+    return best > 0 ? at : b;
 }
 
-// MODE 0: an EM iteration -- add one to the chosen target of every read with more than one entry (:115-121)
-// MODE 1: the final choice of every read (:153-181); a read with one entry keeps it
-template <int MODE, bool LDS_HIST>
+// MODE 0: an EM iteration (:115-121).  `counts` enters as a copy of the counts the pass before ended with (of the unique counts
+//         before the first pass) and every read with several entries moves its ONE from the target it chose last time (chosen[r];
+//         none before the first pass) to the one it chooses now -- after the first pass few reads change their mind, so the atomics,
+//         which bound the first pass, all but vanish from the later ones.  The sums are what a recount from the unique counts gives.
+// MODE 1: the final choice of every read (:153-181): the entry index; a read with one entry keeps it
+template <int MODE>
 __global__ void __launch_bounds__(GN_RA_BLOCK) gn_ra_pick_kernel(const uint64_t* __restrict__ off, const uint32_t* __restrict__ target,
-                                                                const double* __restrict__ prob, uint64_t n_reads, uint32_t n_targets,
-                                                                unsigned long long* __restrict__ counts, uint64_t* __restrict__ choice)
+                                                                const uint32_t* __restrict__ weight, uint64_t n_reads,
+                                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ chosen, int first_pass,
+                                                                uint64_t* __restrict__ choice)
 {
-    extern __shared__ uint32_t hist[]; // n_targets counters when LDS_HIST
-    if (MODE == 0 && LDS_HIST)
-    {
-        for (uint32_t t = threadIdx.x; t < n_targets; t += blockDim.x)
-            hist[t] = 0;
-        __syncthreads();
-    }
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t rounds = (n_reads + stride - 1) / stride; // every lane of a wave walks the same number of rounds (ballots below)
     for (uint64_t k = 0; k < rounds; ++k)
@@ -230,32 +228,34 @@ __global__ void __launch_bounds__(GN_RA_BLOCK) gn_ra_pick_kernel(const uint64_t*
         if (MODE == 0)
         {
             const bool     mine = d >= 2 && d <= GN_RA_LIGHT;
-            const uint32_t t    = mine ? target[gn_ra_pick_lane(target, prob, b, e)] : 0u;
-            if (LDS_HIST)
-                gn_ra_add_aggregated(hist, t, mine);
-            else
+            const uint32_t t    = mine ? target[gn_ra_pick_lane(target, weight, b, e)] : 0u;
+            if (first_pass)
+            {
                 gn_ra_add_aggregated(counts, t, mine);
+                if (mine)
+                    chosen[r] = t;
+            }
+            else if (mine)
+            {
+                const uint32_t was = chosen[r];
+                if (was != t)
+                {
+                    atomicAdd(&counts[t], 1u);
+                    atomicSub(&counts[was], 1u);
+                    chosen[r] = t;
+                }
+            }
         }
         else if (in && d <= GN_RA_LIGHT)
-            choice[r] = d <= 1 ? b : gn_ra_pick_lane(target, prob, b, e);
-    }
-    if (MODE == 0 && LDS_HIST)
-    {
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < n_targets; t += blockDim.x)
-        {
-            const uint32_t c = hist[t];
-            if (c)
-                atomicAdd(&counts[t], (unsigned long long)c);
-        }
+            choice[r] = d <= 1 ? b : gn_ra_pick_lane(target, weight, b, e);
     }
 }
 
 template <int MODE>
 __global__ void __launch_bounds__(GN_RA_BLOCK) gn_ra_pick_heavy_kernel(const uint64_t* __restrict__ off, const uint32_t* __restrict__ target,
-                                                                      const double* __restrict__ prob, const uint32_t* __restrict__ heavy,
-                                                                      uint64_t n_heavy, unsigned long long* __restrict__ counts,
-                                                                      uint64_t* __restrict__ choice)
+                                                                      const uint32_t* __restrict__ weight, const uint32_t* __restrict__ heavy,
+                                                                      uint64_t n_heavy, uint32_t* __restrict__ counts,
+                                                                      uint32_t* __restrict__ chosen, int first_pass, uint64_t* __restrict__ choice)
 {
     const unsigned lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -263,24 +263,42 @@ __global__ void __launch_bounds__(GN_RA_BLOCK) gn_ra_pick_heavy_kernel(const uin
     for (uint64_t i = wave; i < n_heavy; i += n_waves)
     {
         const uint32_t r  = heavy[i];
-        const uint64_t at = gn_ra_pick_wave(target, prob, off[r], off[r + 1], lane);
+        const uint64_t at = gn_ra_pick_wave(target, weight, off[r], off[r + 1], lane);
         if (lane == 0)
         {
             if (MODE == 0)
-                atomicAdd(&counts[target[at]], 1ull);
+            {
+                const uint32_t t = target[at], was = first_pass ? 0xFFFFFFFFu : chosen[r];
+                if (was != t)
+                {
+                    atomicAdd(&counts[t], 1u);
+                    if (!first_pass)
+                        atomicSub(&counts[was], 1u);
+                    chosen[r] = t;
+                }
+            }
             else
                 choice[r] = at;
         }
     }
 }
 
+// unique counts (64-bit, what the fetch call hands out) as the 32-bit weights of the first pass
+__global__ void gn_ra_narrow_kernel(const unsigned long long* __restrict__ uniq, uint32_t n_targets, uint32_t* __restrict__ w)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_targets)
+        w[t] = (uint32_t)uniq[t];
+}
+
 // ---- the update (:123-129) --------------------------------------------------------------------------------------------
-__global__ void gn_ra_update_kernel(const unsigned long long* __restrict__ counts, uint32_t n_targets, double total, double* __restrict__ prob,
-                                    double* __restrict__ absd)
+__global__ void gn_ra_update_kernel(const uint32_t* __restrict__ counts, uint32_t n_targets, double total, double* __restrict__ prob,
+                                    double* __restrict__ absd, unsigned long long* __restrict__ counts64)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_targets)
     {
+        counts64[t]     = counts[t];
         const double np = __ddiv_rn((double)counts[t], total);
         absd[t] = fabs(__dsub_rn(prob[t], np));
         prob[t] = np;
@@ -317,6 +335,9 @@ static int ra_free(gn_reassign* g)
     hipFree(g->d_n_heavy);
     hipFree(g->d_uniq);
     hipFree(g->d_counts);
+    hipFree(g->d_w[0]);
+    hipFree(g->d_w[1]);
+    hipFree(g->d_chosen);
     hipFree(g->d_prob);
     hipFree(g->d_absd);
     hipFree(g->d_diff);
@@ -380,6 +401,9 @@ extern "C" int gn_reassign_create(int device, uint64_t n_reads, uint64_t n_entri
     ok(ra_malloc(&g->d_n_heavy, 4));
     ok(ra_malloc(&g->d_uniq, n_targets));
     ok(ra_malloc(&g->d_counts, n_targets));
+    ok(ra_malloc(&g->d_w[0], n_targets));
+    ok(ra_malloc(&g->d_w[1], n_targets));
+    ok(ra_malloc(&g->d_chosen, n_reads));
     ok(ra_malloc(&g->d_prob, n_targets));
     ok(ra_malloc(&g->d_absd, n_targets));
     ok(ra_malloc(&g->d_diff, 1));
@@ -414,22 +438,17 @@ extern "C" int gn_reassign_create(int device, uint64_t n_reads, uint64_t n_entri
     return GN_OK;
 }
 
+// weight = the counts a pass compares; counts = the running pass's (MODE 0)
 template <int MODE>
-static void ra_launch_pick(gn_reassign* g)
+static void ra_launch_pick(gn_reassign* g, const uint32_t* weight, uint32_t* counts, bool first_pass)
 {
     const unsigned grid = ra_grid(g->n_reads, GN_RA_BLOCK * 4);
     if (g->n_reads)
-    {
-        if (MODE == 0 && g->n_targets <= GN_RA_LDS_TARGETS)
-            hipLaunchKernelGGL((gn_ra_pick_kernel<MODE, true>), dim3(grid), dim3(GN_RA_BLOCK), (size_t)g->n_targets * 4, g->st, g->d_off, g->d_target, g->d_prob,
-                               g->n_reads, g->n_targets, g->d_counts, g->d_choice);
-        else
-            hipLaunchKernelGGL((gn_ra_pick_kernel<MODE, false>), dim3(grid), dim3(GN_RA_BLOCK), 0, g->st, g->d_off, g->d_target, g->d_prob,
-                               g->n_reads, g->n_targets, g->d_counts, g->d_choice);
-    }
+        hipLaunchKernelGGL((gn_ra_pick_kernel<MODE>), dim3(grid), dim3(GN_RA_BLOCK), 0, g->st, g->d_off, g->d_target, weight, g->n_reads, counts,
+                           g->d_chosen, first_pass ? 1 : 0, g->d_choice);
     if (g->n_heavy)
         hipLaunchKernelGGL((gn_ra_pick_heavy_kernel<MODE>), dim3(ra_grid(g->n_heavy, GN_RA_BLOCK / 64)), dim3(GN_RA_BLOCK), 0, g->st, g->d_off,
-                           g->d_target, g->d_prob, g->d_heavy, g->n_heavy, g->d_counts, g->d_choice);
+                           g->d_target, weight, g->d_heavy, g->n_heavy, counts, g->d_chosen, first_pass ? 1 : 0, g->d_choice);
 }
 
 extern "C" int gn_reassign_run(gn_reassign* g, uint32_t max_iter, double threshold, uint32_t* iterations)
@@ -446,20 +465,26 @@ extern "C" int gn_reassign_run(gn_reassign* g, uint32_t max_iter, double thresho
     if (g->n_targets)
         hipLaunchKernelGGL(gn_ra_first_prob_kernel, dim3(tb), dim3(256), 0, g->st, g->d_uniq, g->n_targets, denom, g->d_prob);
     GN_HIP(hipEventRecord(g->ev0, g->st));
+    // d_w[a]: the counts the running pass compares (before the first pass: the unique counts, whose order is that of :106-107's
+    // probabilities), d_w[1 - a]: the counts it builds, starting as a copy
+    int a = 0;
+    if (g->n_targets)
+        hipLaunchKernelGGL(gn_ra_narrow_kernel, dim3(tb), dim3(256), 0, g->st, g->d_uniq, g->n_targets, g->d_w[0]);
     uint32_t it = 0;
     for (;;)
     {
-        GN_HIP(hipMemcpyAsync(g->d_counts, g->d_uniq, (size_t)g->n_targets * sizeof(unsigned long long), hipMemcpyDeviceToDevice, g->st));
-        ra_launch_pick<0>(g);
+        GN_HIP(hipMemcpyAsync(g->d_w[1 - a], g->d_w[a], (size_t)g->n_targets * sizeof(uint32_t), hipMemcpyDeviceToDevice, g->st));
+        ra_launch_pick<0>(g, g->d_w[a], g->d_w[1 - a], it == 0);
         if (g->n_targets)
-            hipLaunchKernelGGL(gn_ra_update_kernel, dim3(tb), dim3(256), 0, g->st, g->d_counts, g->n_targets, (double)g->n_reads, g->d_prob,
-                               g->d_absd);
+            hipLaunchKernelGGL(gn_ra_update_kernel, dim3(tb), dim3(256), 0, g->st, g->d_w[1 - a], g->n_targets, (double)g->n_reads, g->d_prob,
+                               g->d_absd, g->d_counts);
         hipLaunchKernelGGL(gn_ra_sum_in_order_kernel, dim3(1), dim3(64), 0, g->st, g->d_absd, g->n_targets, g->d_diff);
         double diff = 0.0;
         GN_HIP(hipMemcpyAsync(&diff, g->d_diff, sizeof(double), hipMemcpyDeviceToHost, g->st));
         GN_HIP(hipStreamSynchronize(g->st));
         GN_HIP(hipGetLastError());
         g->diffs.push_back(diff);
+        a = 1 - a; // the counts just built are what the next pass (and the final choice) compares
         if (diff <= threshold) // :141
             break;
         if (max_iter > 0 && it == max_iter - 1) // :143
@@ -467,7 +492,7 @@ extern "C" int gn_reassign_run(gn_reassign* g, uint32_t max_iter, double thresho
         ++it;
     }
     // :170-181 -- the choice under the probabilities of the last update
-    ra_launch_pick<1>(g);
+    ra_launch_pick<1>(g, g->d_w[a], nullptr, false);
     GN_HIP(hipEventRecord(g->ev1, g->st));
     GN_HIP(hipStreamSynchronize(g->st));
     GN_HIP(hipGetLastError());
@@ -518,8 +543,8 @@ extern "C" int gn_reassign_info(const gn_reassign* g, uint64_t* n_unique_reads, 
         *n_wave_reads = g->n_heavy;
     if (ms_em)
         *ms_em = g->ms_em;
-    if (bytes_per_iteration) // algorithmic: every read's two offsets' worth (8 B) + 4 B per entry of a read with more than one
-        *bytes_per_iteration = (g->n_reads + 1) * 8 + (g->n_entries - g->n_unique) * 4;
+    if (bytes_per_iteration) // algorithmic: every read's offset (8 B), 4 B per entry of a read with several, 4 B for its last choice
+        *bytes_per_iteration = (g->n_reads + 1) * 8 + (g->n_entries - g->n_unique) * 4 + g->n_multi * 4;
     return GN_OK;
 }
 

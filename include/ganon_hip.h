@@ -328,7 +328,7 @@ int gn_reassign_run(gn_reassign* g, uint32_t max_iter, double threshold, uint32_
 int gn_reassign_diffs(const gn_reassign* g, double* diffs, uint32_t cap);
 int gn_reassign_fetch(gn_reassign* g, uint64_t* counts, uint64_t* unique, double* prob, uint64_t* choice);
 /* reads with one / several entries, reads long enough to take a wave of their own, device time of the last run (EM +
- * final choice) and the algorithmic bytes one iteration reads (8 per read + 4 per entry of a read with several) */
+ * final choice) and the algorithmic bytes one iteration reads (8 per read, 4 per entry of a read with several + 4 for its last choice) */
 int gn_reassign_info(const gn_reassign* g, uint64_t* n_unique_reads, uint64_t* n_multi_reads, uint64_t* n_wave_reads, float* ms_em,
                      uint64_t* bytes_per_iteration);
 int gn_reassign_free(gn_reassign* g);
