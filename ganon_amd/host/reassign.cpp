@@ -24,6 +24,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 
 namespace fs = std::filesystem;
@@ -168,57 +169,172 @@ struct Table // :76-92
     std::vector<long long>                         count;
 };
 
+// The table of one .all file (:76-92).  The lines are parsed by several threads -- chunks of the text cut at line ends; per chunk the
+// fields, the count, the target's number among the CHUNK's targets, and the runs of consecutive lines with one read id -- and put
+// together in chunk order by one: targets numbered by first appearance over the chunks in order, one hash-map insert per RUN (a read's
+// lines follow each other in what ganon-classify writes, so that is one per read, the same the one-thread version paid; a run whose id
+// was seen before makes the table "not grouped" and its entries are gathered behind the read's earlier ones, as Python's dict of lists
+// would hold them).
 void read_table(const std::string& path, Table& tb)
 {
     tb.text = slurp(path);
-    std::unordered_map<std::string_view, uint32_t> reads;
-    std::vector<uint32_t>                          line_read;
-    const size_t                                   guess = tb.text.size() / 24 + 16;
-    line_read.reserve(guess);
-    tb.target.reserve(guess);
-    tb.count.reserve(guess);
-    reads.reserve(guess / 2);
-    std::string_view last_id;
-    uint32_t         last_read = 0;
-    bool             grouped   = true; // every read's lines follow each other: the table is in CSR order as it stands
-    size_t           line_no   = 0;
-    each_line(tb.text, [&](std::string_view raw) {
-        ++line_no;
-        const std::string_view line = rstrip(raw);
-        const size_t           t1   = line.find('\t');
-        const size_t           t2   = t1 == std::string_view::npos ? t1 : line.find('\t', t1 + 1);
-        if (t2 == std::string_view::npos || line.find('\t', t2 + 1) != std::string_view::npos)
-            throw std::runtime_error(path + ": line " + std::to_string(line_no) + " is not `read <tab> target <tab> count`");
-        const std::string_view rid = line.substr(0, t1), tname = line.substr(t1 + 1, t2 - t1 - 1);
-        long long              c = 0;
-        if (!py_int(line.substr(t2 + 1), c))
-            throw std::runtime_error(path + ": line " + std::to_string(line_no) + ": the count is no integer");
-        uint32_t r;
-        if (!tb.read_ids.empty() && rid == last_id)
-            r = last_read;
-        else
+    const std::string& text = tb.text;
+    struct Run
+    {
+        std::string_view id;
+        size_t           lines;
+    };
+    struct Chunk
+    {
+        size_t                                         begin = 0, end = 0, n_lines = 0;
+        std::vector<std::string_view>                  targets;
+        std::unordered_map<std::string_view, uint32_t> index;
+        std::vector<uint32_t>                          tgt; // per line: number among this chunk's targets
+        std::vector<long long>                         cnt;
+        std::vector<Run>                               runs;
+        std::string                                    error; // first line of the chunk that is no entry
+        size_t                                         error_line = 0;
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t   nt = std::max<size_t>(1, std::min<size_t>({ (size_t)hw, 16, text.size() / (1u << 20) + 1 }));
+    std::vector<Chunk> ch(nt);
+    for (size_t c = 0; c < nt; ++c)
+    {
+        size_t b = c == 0 ? 0 : ch[c - 1].end;
+        size_t e = c + 1 == nt ? text.size() : std::max(b, text.size() / nt * (c + 1));
+        if (e < text.size())
         {
-            auto [it, fresh] = reads.try_emplace(rid, (uint32_t)tb.read_ids.size());
-            if (fresh)
-            {
-                if (tb.read_ids.size() >= 0xffffffffull)
-                    throw std::runtime_error(path + ": more than 2^32 - 1 reads");
-                tb.read_ids.push_back(rid);
-            }
-            else
-                grouped = false;
-            r = it->second;
+            const size_t nl = text.find('\n', e);
+            e               = nl == std::string::npos ? text.size() : nl + 1;
         }
-        last_id   = rid;
-        last_read = r;
-        auto [tt, tfresh] = tb.target_index.try_emplace(tname, (uint32_t)tb.target_names.size());
-        if (tfresh)
-            tb.target_names.push_back(tname);
-        line_read.push_back(r);
-        tb.target.push_back(tt->second);
-        tb.count.push_back(c);
-    });
-    const size_t n_reads = tb.read_ids.size(), n = line_read.size();
+        ch[c].begin = b;
+        ch[c].end   = e;
+    }
+    auto parse = [&](Chunk& k) {
+        const size_t guess = (k.end - k.begin) / 24 + 16;
+        k.tgt.reserve(guess);
+        k.cnt.reserve(guess);
+        k.runs.reserve(guess / 2);
+        size_t at = k.begin;
+        while (at < k.end)
+        {
+            size_t e = text.find('\n', at);
+            e        = e == std::string::npos || e >= k.end ? k.end : e + 1;
+            const std::string_view raw(text.data() + at, e - at);
+            at = e;
+            ++k.n_lines;
+            const std::string_view line = rstrip(raw);
+            const size_t           t1   = line.find('\t');
+            const size_t           t2   = t1 == std::string_view::npos ? t1 : line.find('\t', t1 + 1);
+            long long              c    = 0;
+            if (t2 == std::string_view::npos || line.find('\t', t2 + 1) != std::string_view::npos)
+                k.error = " is not `read <tab> target <tab> count`";
+            else if (!py_int(line.substr(t2 + 1), c))
+                k.error = ": the count is no integer";
+            if (!k.error.empty())
+            {
+                k.error_line = k.n_lines;
+                return;
+            }
+            const std::string_view rid = line.substr(0, t1), tname = line.substr(t1 + 1, t2 - t1 - 1);
+            if (!k.runs.empty() && k.runs.back().id == rid)
+                ++k.runs.back().lines;
+            else
+                k.runs.push_back(Run{ rid, 1 });
+            auto [tt, fresh] = k.index.try_emplace(tname, (uint32_t)k.targets.size());
+            if (fresh)
+                k.targets.push_back(tname);
+            k.tgt.push_back(tt->second);
+            k.cnt.push_back(c);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t c = 1; c < nt; ++c)
+            th.emplace_back([&, c] { parse(ch[c]); });
+        parse(ch[0]);
+        for (auto& t : th)
+            t.join();
+    }
+    size_t lines_before = 0, n = 0;
+    for (auto& k : ch)
+    {
+        if (!k.error.empty())
+            throw std::runtime_error(path + ": line " + std::to_string(lines_before + k.error_line) + k.error);
+        lines_before += k.n_lines;
+        n += k.tgt.size();
+    }
+    // targets in first-appearance order; the chunks' numbers become the table's
+    std::vector<std::vector<uint32_t>> remap(nt);
+    for (size_t c = 0; c < nt; ++c)
+    {
+        remap[c].resize(ch[c].targets.size());
+        for (size_t t = 0; t < ch[c].targets.size(); ++t)
+        {
+            auto [it, fresh] = tb.target_index.try_emplace(ch[c].targets[t], (uint32_t)tb.target_names.size());
+            if (fresh)
+                tb.target_names.push_back(ch[c].targets[t]);
+            remap[c][t] = it->second;
+        }
+    }
+    // reads: one insert per run
+    std::unordered_map<std::string_view, uint32_t> reads;
+    size_t                                         n_runs = 0;
+    for (auto& k : ch)
+        n_runs += k.runs.size();
+    reads.reserve(n_runs);
+    tb.read_ids.reserve(n_runs);
+    std::vector<uint32_t> line_read(n);
+    bool                  grouped = true; // every read's lines follow each other: the table is in CSR order as it stands
+    size_t                at      = 0;
+    std::string_view      last_id;
+    uint32_t              last_read = 0;
+    for (auto& k : ch)
+        for (const Run& run : k.runs)
+        {
+            uint32_t r;
+            if (!tb.read_ids.empty() && run.id == last_id) // (a read whose lines straddle two chunks)
+                r = last_read;
+            else
+            {
+                auto [it, fresh] = reads.try_emplace(run.id, (uint32_t)tb.read_ids.size());
+                if (fresh)
+                {
+                    if (tb.read_ids.size() >= 0xffffffffull)
+                        throw std::runtime_error(path + ": more than 2^32 - 1 reads");
+                    tb.read_ids.push_back(run.id);
+                }
+                else
+                    grouped = false;
+                r = it->second;
+            }
+            last_id   = run.id;
+            last_read = r;
+            std::fill(line_read.begin() + at, line_read.begin() + at + run.lines, r);
+            at += run.lines;
+        }
+    // the entries, in file order
+    tb.target.resize(n);
+    tb.count.resize(n);
+    {
+        std::vector<size_t> first(nt, 0);
+        for (size_t c = 1; c < nt; ++c)
+            first[c] = first[c - 1] + ch[c - 1].tgt.size();
+        auto place = [&](size_t c) {
+            for (size_t i = 0; i < ch[c].tgt.size(); ++i)
+            {
+                tb.target[first[c] + i] = remap[c][ch[c].tgt[i]];
+                tb.count[first[c] + i]  = ch[c].cnt[i];
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t c = 1; c < nt; ++c)
+            th.emplace_back(place, c);
+        place(0);
+        for (auto& t : th)
+            t.join();
+    }
+    const size_t n_reads = tb.read_ids.size();
     tb.off.assign(n_reads + 1, 0);
     for (uint32_t r : line_read)
         ++tb.off[r + 1];
@@ -231,9 +347,9 @@ void read_table(const std::string& path, Table& tb)
         std::vector<long long> c2(n);
         for (size_t i = 0; i < n; ++i)
         {
-            const uint64_t at = cur[line_read[i]]++;
-            t2[at]            = tb.target[i];
-            c2[at]            = tb.count[i];
+            const uint64_t o = cur[line_read[i]]++;
+            t2[o]            = tb.target[i];
+            c2[o]            = tb.count[i];
         }
         tb.target.swap(t2);
         tb.count.swap(c2);

@@ -122,7 +122,7 @@ def test_round_repr_of_the_log_is_pythons(checker):
     open(src, "w").write('#include "../../ganon_amd/host/reassign.hpp"\n#include <cstdio>\n#include <cstdlib>\n'
                          'int main(int c, char** v) { for (int i = 1; i < c; ++i) std::puts(gnhost::py_round6_repr(std::strtod(v[i], nullptr)).c_str()); }\n')
     try:
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", exe, src,
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", exe, src,
                                os.path.join(ROOT, "ganon_amd", "host", "reassign.cpp"), os.path.join(ROOT, "tests", "host_oracle", "reassign_checker.cpp")])
         rng = np.random.default_rng(3)
         vals = [0.0, 1.0, 2.0, 0.5, 1e-7, 4e-7, 5e-7, 5.000001e-7, 1e-6, 1.5e-6, 9.9999995e-5, 1e-4, 0.000123456, 0.816327, 1.0000005, 1.9999995,
@@ -230,3 +230,41 @@ def test_reassign_after_classify_end_to_end(hip, tmp_path):
     # the same vectors the golden maker derived from this classification (sim_em_mode): same input -> same output
     assert open(pre + ".all").read() == open(os.path.join(GOLD, "sim_em_mode", "in.all")).read()
     assert open(pre + "_em.one").read() == open(os.path.join(GOLD, "sim_em_mode", "out.one")).read()
+
+
+@pytest.mark.parametrize("split_reads", [False, True])
+def test_table_read_by_several_threads_equals_the_oracle(checker, tmp_path, split_reads):
+    # an .all of ~20 MB is parsed in several chunks (reassign.cpp read_table): a read's lines straddle chunk borders, targets appear first
+    # in different chunks, and -- split_reads -- some reads are listed again far from their first lines (then one read, entries in file order)
+    rng = np.random.default_rng(19)
+    n_reads, n_targets = 250_000, 3000
+    names = [f"GCF_{rng.integers(10**8, 10**9)}.{t % 7}" for t in range(n_targets)]
+    deg = np.where(rng.random(n_reads) < 0.4, 1, rng.integers(2, 9, size=n_reads))
+    w = rng.random(n_targets) ** 3 + 1e-3
+    tg = rng.choice(n_targets, size=int(deg.sum()), p=w / w.sum())
+    lines, later, at = [], [], 0
+    for r in range(n_reads):
+        rid = f"A00000:12:HXXXXXXX:1:{1101 + r % 50}:{r}:{(r * 7919) % 100000} 1:N:0:ACGTACGT"
+        for j in range(int(deg[r])):
+            line = f"{rid}\t{names[tg[at]]}\t{10 + (at & 63)}\n"
+            (later if split_reads and j >= 2 and r % 1000 == 3 else lines).append(line)
+            at += 1
+    text = "".join(lines) + "".join(later)
+    assert len(text) > 16 << 20
+    (tmp_path / "big.all").write_text(text)
+    used = sorted(set(tg.tolist()))
+    (tmp_path / "big.rep").write_text("".join(f"H1\t{names[t]}\t{3 + t % 5}\t{t % 3}\t0\tspecies\tname of {t}\n" for t in used)
+                                      + f"#total_classified\t{n_reads}\n#total_unclassified\t0\n")
+    want = orr.reassign_files(str(tmp_path / "big.rep"), 10, 0)
+    p = subprocess.run([checker, "-i", "big", "-o", "out", "--quiet"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    assert open(tmp_path / "out.rep").read() == want[0]
+    assert open(tmp_path / "out.one").read() == want[1][""]
+    # a bad line deep in the file is reported with its number in the file
+    bad_at = text.count("\n") // 2
+    parts = text.split("\n")
+    parts[bad_at] = parts[bad_at].replace("\t", " ", 1)
+    (tmp_path / "bad.all").write_text("\n".join(parts))
+    (tmp_path / "bad.rep").write_text((tmp_path / "big.rep").read_text())
+    p = subprocess.run([checker, "-i", "bad", "-o", "x", "--quiet"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1 and f"line {bad_at + 1} " in p.stderr, p.stderr[-300:]
