@@ -23,6 +23,8 @@
 #define GN_SPLIT_CHUNK 256u
 #define GN_SPLIT_CHUNK_MAX 8192u
 
+#define GN_SPLIT_RUN_SELECT(MAXT) ((MAXT) <= 512) // (the 1024-thread variants have 128 registers a lane: not there)
+
 namespace
 {
 
@@ -59,7 +61,9 @@ struct GnSpRows
 
 } // namespace
 
-template <int HF, int LW, int MAXT>
+// RS: the variant for maps the run select applies to (p.run_select): no bins-per-target registers (the prefilter takes every bin for one
+// of four), the running-sum select instead of the scan.
+template <int HF, int LW, int MAXT, bool RS>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512 ? 4 : (LW == 2 || MAXT > 256 ? 2 : 3)))) void gn_ibf_count_split_kernel(GnCountParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_sp_lds[];
@@ -67,6 +71,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
     constexpr int      HFP  = HF <= 4 ? 4 : 8;
     constexpr uint32_t NMAX = 127;
     constexpr uint32_t IMG  = 8 * ND * 64; // dwords of one wave's byte image
+    constexpr bool     RUNSEL = RS;
 
     const int      lane   = threadIdx.x & (GN_WAVE - 1);
     const int      wave   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -91,7 +96,43 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
     uint32_t nbreg[8 * ND];
 #pragma unroll
     for (int r = 0; r < 8 * ND; ++r)
-        nbreg[r] = p.sl_nbr[((size_t)slice * 8 * ND + r) * 64 + lane];
+        nbreg[r] = RS ? 0u : p.sl_nbr[((size_t)slice * 8 * ND + r) * 64 + lane]; // (RS: every bin counts as one of four, see the prefilter)
+
+    // Run select (p.run_select: every bin has a target, targets own consecutive bins in target order, none more than four, not all the
+    // same number): which of my bins CONTINUE the target of the bin before (ns), and in one word (tbx) the first target that ends among my
+    // bins, how many bins it has before my first one (at most three, bits 29-30) and whether the bin after my last continues (bit 31).
+    // Static for the persistent wave, like nbreg.
+    uint32_t ns[ND], tbx = 0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+        ns[d] = 0;
+    if (RUNSEL && col_act)
+    {
+        constexpr uint32_t NONE = 0xFFFFFFFFu;
+        const uint32_t     b0   = wi * 64u;
+        uint32_t           prev = b0 && b0 - 1 < p.B ? p.bin_tgt[b0 - 1] : NONE;
+        uint32_t           cur  = b0 < p.B ? p.bin_tgt[b0] : NONE;
+        uint32_t           first_end = NONE;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+        {
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < 32u; ++i)
+            {
+                const uint32_t b   = b0 + 32u * (uint32_t)d + i;
+                const uint32_t nxt = b + 1 < p.B ? p.bin_tgt[b + 1] : NONE;
+                if (cur != NONE && cur == prev)
+                    m |= 1u << i;
+                if (cur != NONE && nxt != cur && first_end == NONE)
+                    first_end = cur;
+                prev = cur;
+                cur  = nxt;
+            }
+            ns[d] = m;
+        }
+        const uint32_t back = (ns[0] & 1u) ? b0 - p.tgt_off[p.bin_tgt[b0]] : 0u;
+        tbx = (first_end == NONE ? 0u : first_end) | (back << 29) | (cur != NONE && cur == prev ? 0x80000000u : 0u);
+    }
 
     const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads - p.read_begin;
     unsigned long long chunk_base = 0;
@@ -232,6 +273,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     for (int pp = 0; pp < 2; ++pp)
                     {
                         const uint32_t x  = byt[d][j][pp];
+                        if constexpr (RS) // count * 4 >= T  <=>  count >= ceil(T / 4), bytes compared in place (counts <= 127: no carry)
+                        {
+                            m |= (((x + (0x80u - ((T + 3u) >> 2)) * 0x01010101u) & 0x80808080u) >> 7) << (4 * pp + j);
+                            continue;
+                        }
                         const uint32_t nb = nbreg[(d * 4 + j) * 2 + pp];
                         // bytes (0,1) and (2,3) as u16 pairs: count * nb <= 127 * 255
                         const gn_u16x2 lo = __builtin_bit_cast(gn_u16x2, __builtin_amdgcn_perm(0u, x, 0x0C010C00u))
@@ -473,6 +519,124 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     tot += in_all;
                     return tot;
                 }
+                if (RUNSEL && scan_all)
+                {
+                    // Targets of one to four consecutive bins, widths mixed: a lane judges the targets that END among its own bins from
+                    // its own registers -- a running sum over its bins in bin order that starts again where a target starts (ns), looked
+                    // at where a target ends -- ~9 instructions a bin and no memory access, where the scan below spends ~60 a
+                    // target on offsets, LDS gathers and shifts.  The smallest sum under the bar comes out of the same loop; only
+                    // targets at or above the bar are looked at one by one afterwards (from the image, no global loads either).
+                    // (the masks are static for the wave: without the barrier the compiler keeps all the per-bin masks derived from them
+                    // in registers across the reads)
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        asm volatile("" : "+v"(ns[d]));
+                    const uint32_t tb = tbx & 0x1FFFFFFFu, back = (tbx >> 29) & 3u;
+                    const uint32_t backbits = (back >= 2u ? 0x80000000u : 0u) | (back >= 3u ? 0x40000000u : 0u); // "continues" of the bins before mine
+                    uint32_t       run      = 0;
+                    for (uint32_t q = 1; q <= back; ++q) // the bins my first target has in the lane (or slice) before me
+                        run += cnt_of(wi * 64u - q);
+                    // min(sum, n) >= bar (:525-526)  <=>  bar <= n and sum >= bar; sums stay below 1024, so a bar of 2^16 never passes
+                    const uint32_t selb = Tsel <= n ? Tsel : 0x10000u, tbar = T <= n ? T : 0x10000u;
+                    uint32_t       hit[ND], low = 0xFFFFFFFFu, n_mid = 0;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                    {
+                        // a bin ends its target where the next bin does not continue it (every bin below B has a target)
+                        const uint32_t b0d   = wi * 64u + 32u * (uint32_t)d;
+                        const uint32_t valid = !col_act || b0d >= p.B ? 0u : (p.B - b0d >= 32u ? 0xFFFFFFFFu : (1u << (p.B - b0d)) - 1u);
+                        const uint32_t nextc = d + 1 < ND ? ns[d + 1 < ND ? d + 1 : 0] << 31 : tbx & 0x80000000u;
+                        const uint32_t en    = ~((ns[d] >> 1) | nextc) & valid;
+                        const uint32_t nen   = ~en;
+                        uint32_t       hm = 0, tm = 0; // sign bits shifted in from below: bin 0 ends up on top, 1 = under the bar
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                        {
+                            const uint32_t y = (uint32_t)k >> 1, pp = (uint32_t)k & 1u;
+                            const uint32_t sel = 0x0C0C0000u | ((4u + y) << 8) | y;
+                            const uint32_t x   = __builtin_amdgcn_perm(byt[d][1][pp], byt[d][0][pp], sel)
+                                               | (__builtin_amdgcn_perm(byt[d][3][pp], byt[d][2][pp], sel) << 16); // bins 4k .. 4k+3
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                            {
+                                const int      pos = 4 * k + j;
+                                const uint32_t c   = (x >> (8 * j)) & 0xFFu;
+                                run                = (run & (uint32_t)((int32_t)(ns[d] << (31 - pos)) >> 31)) + c; // starts again where a target starts
+                                const uint32_t xs  = run - selb, xt = run - tbar;                                    // sign set: under the bar
+                                hm                 = __builtin_amdgcn_alignbit(hm, xs, 31);
+                                tm                 = __builtin_amdgcn_alignbit(tm, xt, 31);
+                                const uint32_t v   = xt | (uint32_t)((int32_t)(nen << (31 - pos)) >> 31); // all ones unless a target ends here
+                                low                = v < low ? v : low;
+                            }
+                            __builtin_amdgcn_sched_barrier(0); // (one chain of dependent adds: nothing to gain from looking ahead, registers to lose)
+                        }
+                        hm = ~__builtin_bitreverse32(hm);
+                        tm = ~__builtin_bitreverse32(tm);
+                        hit[d] = hm & en;
+                        n_mid += (uint32_t)__popc(tm & ~hm & en);
+                    }
+                    if (counting && n_mid) // (the smallest sum that reached T is one under the bar: they all lie below the hits)
+                    {
+                        const uint32_t cv = low + tbar > n ? n : low + tbar;
+                        drop1 += n_mid;
+                        mnd = cv < mnd ? cv : mnd;
+                    }
+                    uint32_t mine_hits = 0;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        mine_hits += (uint32_t)__popc(hit[d]);
+                    uint32_t inc = mine_hits;
+#pragma unroll
+                    for (int off = 1; off < GN_WAVE; off <<= 1)
+                    {
+                        const uint32_t y = (uint32_t)__shfl_up((int)inc, off);
+                        inc += lane >= off ? y : 0u;
+                    }
+                    uint32_t       o      = inc - mine_hits;
+                    const uint32_t in_all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    uint32_t       ended  = 0; // targets that end in my groups before d
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                    {
+                        const uint32_t b0d   = wi * 64u + 32u * (uint32_t)d;
+                        const uint32_t valid = !col_act || b0d >= p.B ? 0u : (p.B - b0d >= 32u ? 0xFFFFFFFFu : (1u << (p.B - b0d)) - 1u);
+                        const uint32_t nextc = d + 1 < ND ? ns[d + 1 < ND ? d + 1 : 0] << 31 : tbx & 0x80000000u;
+                        const uint32_t en    = ~((ns[d] >> 1) | nextc) & valid;
+                        const uint64_t flags = ((uint64_t)ns[d] << 32) | (d ? ns[d > 0 ? d - 1 : 0] : backbits);
+                        while (hit[d])
+                        {
+                            const uint32_t pos = (uint32_t)__builtin_ctz(hit[d]);
+                            hit[d] &= hit[d] - 1;
+                            const uint32_t f3 = (uint32_t)(flags >> (30u + pos)) & 7u; // "continues" of the bins pos, pos-1, pos-2
+                            const uint32_t nb = f3 == 7u ? 4u : (f3 >= 6u ? 3u : (f3 >= 4u ? 2u : 1u));
+                            const uint32_t b  = b0d + pos;
+                            uint32_t       cv = 0;
+                            for (uint32_t q = 0; q < nb; ++q)
+                                cv += cnt_of(b - q);
+                            cv = cv > n ? n : cv;
+                            const uint32_t tgt = tb + ended + (uint32_t)__popc(en & ((1u << pos) - 1u));
+                            mxl = cv > mxl ? cv : mxl;
+                            mne = cv < mne ? cv : mne;
+                            if (direct)
+                            {
+                                gn_match mt;
+                                mt.read   = read;
+                                mt.target = tgt;
+                                mt.count  = cv;
+                                out[o]    = mt;
+                            }
+                            else if (o < GN_SPLIT_STAGE)
+                            {
+                                stage[2 * o]     = tgt;
+                                stage[2 * o + 1] = cv;
+                            }
+                            ++o;
+                        }
+                        ended += (uint32_t)__popc(en);
+                    }
+                    tot += in_all;
+                    return tot;
+                }
                 if (scan_all)
                 {
                     // too many candidates (tiny T, dense hits): every target, this wave takes its share
@@ -642,7 +806,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                             const uint32_t bx = p.tgt_bins[rec.x + x];
                             if (bx >= b)
                                 break;
-                            if (cnt_of(bx) * rec.y >= T)
+                            if (cnt_of(bx) * (RS ? 4u : rec.y) >= T) // (the very rule of the prefilter: who is a candidate)
                             {
                                 lowest = false;
                                 break;
@@ -784,17 +948,26 @@ size_t gn_split_lds_bytes(const GnCountGeometry& g, uint32_t hash_funs)
     return ((size_t)g.rpb * g.wpr * 8 * nd * 64 + (size_t)nwaves * (128 * hfp + 2 * GN_SPLIT_STAGE) + 2 * nwaves) * 4;
 }
 
-template <int HF, int LW, int MAXT>
-static hipError_t gn_launch_split_one(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
+template <int HF, int LW, int MAXT, bool RS>
+static hipError_t gn_launch_split_rs(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
 {
     uint32_t blocks = (p.n_reads - p.read_begin + g.rpb - 1) / g.rpb;
     if (blocks > p.max_blocks)
         blocks = p.max_blocks;
     const size_t lds = gn_split_lds_bytes(g, HF);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_ibf_count_split_kernel<HF, LW, MAXT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gn_ibf_count_split_kernel<HF, LW, MAXT, RS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((gn_ibf_count_split_kernel<HF, LW, MAXT>), dim3(blocks), dim3(g.block), lds, st, p);
+    hipLaunchKernelGGL((gn_ibf_count_split_kernel<HF, LW, MAXT, RS>), dim3(blocks), dim3(g.block), lds, st, p);
     return hipGetLastError();
+}
+
+template <int HF, int LW, int MAXT>
+static hipError_t gn_launch_split_one(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
+{
+    if constexpr (GN_SPLIT_RUN_SELECT(MAXT))
+        if (p.run_select)
+            return gn_launch_split_rs<HF, LW, MAXT, true>(p, g, st);
+    return gn_launch_split_rs<HF, LW, MAXT, false>(p, g, st);
 }
 
 template <int HF>

@@ -16,7 +16,8 @@ for c in range(n_cfg):
     cutoff = float(rng.choice([0.05, 0.1, 0.2, 0.3, 0.5, 0.75, 0.9, 1.0]))
     contiguous = bool(rng.integers(0, 2)); paired = bool(rng.integers(0, 2))
     choices = [[1, 1, 2], [1, 1, 1, 2, 2, 3, 4], [1, 2, 3, 4, 5, 9, 40, 300], [2, 2, 2]][int(rng.integers(0, 4))]
-    sizes, left = [], bins - int(rng.integers(0, bins // 8))
+    full = bool(rng.integers(0, 2))  # every bin has a target (with `contiguous`: the CSR is the identity, the uniform / run selects apply)
+    sizes, left = [], bins - (0 if full else int(rng.integers(0, bins // 8)))
     while left > 0:
         s = min(int(rng.choice(choices)), left); sizes.append(s); left -= s
     order = np.arange(bins) if contiguous else rng.permutation(bins)
@@ -60,7 +61,7 @@ for c in range(n_cfg):
         exp_m, _ = gu.oracle_matches(ibf, b2t, nt, hs[int(ho[i]):int(ho[i + 1])], cutoff)
         got = [(int(x["target"]), int(x["count"])) for x in out[0][1][int(out[0][0][i]):int(out[0][0][i + 1])]]
         okc &= got == exp_m
-    print(f"cfg {c}: bins {bins} h {h} fill {fill:.2f} w {w} cutoff {cutoff} contiguous {contiguous} paired {paired} sizes {choices}: "
+    print(f"cfg {c}: bins {bins} h {h} fill {fill:.2f} w {w} cutoff {cutoff} contiguous {contiguous} full {full} paired {paired} sizes {choices}: "
           f"targets {nt} matches {len(out[0][1])} same {same} oracle {okc}", flush=True)
     bad += (not same) or (not okc)
     flt.free()

@@ -1,5 +1,6 @@
 """The split-bin kernel at the low-cutoff thresholds, alone (for rocprofv3 passes): split32k workload, --rel-cutoff 0.2 with the
-filter_matches pre-pass set (--rel-filter 0.1 --fpr-query 1e-5), N steps.  usage: split_lowcut.py [steps=5] [reads=2000000] [cutoff=0.2]"""
+filter_matches pre-pass set (--rel-filter 0.1 --fpr-query 1e-5), N steps.  usage: split_lowcut.py [steps=5] [reads=2000000] [cutoff=0.2]
+MIX=1: targets of 1 .. 4 consecutive bins (seeded draw from 1,1,1,2,2,3,4) instead of two bins each."""
 import os
 import sys
 
@@ -15,14 +16,26 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
 cutoff = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2
 bins, rows, h, bpt = 32768, 1 << 21, 4, 2
 wl = bw.make_device_flat_workload("split32k", bins, rows, h, n, False, rel_cutoff=cutoff, seed=42)
-flt, _ = bw.device_filter(ganon_amd, wl, 0, (np.arange(bins, dtype=np.uint32) // bpt).astype(np.uint32), bins // bpt)
+if os.environ.get("MIX"):
+    sizes = np.random.default_rng(7).choice(np.array([1, 1, 1, 2, 2, 3, 4]), size=bins)
+    sizes = sizes[: int(np.searchsorted(np.cumsum(sizes), bins, side="right"))]
+    b2t = np.repeat(np.arange(sizes.size, dtype=np.uint32), sizes)
+    b2t = np.concatenate([b2t, np.full(bins - b2t.size, sizes.size, dtype=np.uint32)])  # the remainder: one last target
+    lens = np.bincount(b2t).astype(np.float64)
+    nt = int(lens.size)
+else:
+    b2t, nt, lens = (np.arange(bins, dtype=np.uint32) // bpt).astype(np.uint32), bins // bpt, np.full(bins // bpt, float(bpt))
+flt, _ = bw.device_filter(ganon_amd, wl, 0, b2t, nt)
 st = ganon_amd.HipStream(flt, n, wl.bases.size, max_matches=n * 2)
 st.upload(wl.bases, wl.off, None)
 if not os.environ.get("NO_PREPASS"):
-    st.set_postfilter(0.1, 1e-5, np.full(bins // bpt, 1.0 - (1.0 - 0.5 ** h) ** bpt, dtype=np.float64))
+    st.set_postfilter(0.1, 1e-5, 1.0 - (1.0 - 0.5 ** h) ** lens)
 ms = []
 for _ in range(steps + 1):
     st.classify(wl.k, wl.w, cutoff)
     st.sync()
     ms.append(st.timings()["ms_count"])
-print("count+select ms per step:", [round(x, 2) for x in ms[1:]], "matches", st.timings()["n_matches"])
+mo, m = st.fetch()[2:4]
+import zlib
+print("count+select ms per step:", [round(x, 2) for x in ms[1:]], "matches", st.timings()["n_matches"],
+      "crc", zlib.crc32(np.ascontiguousarray(m).tobytes()), zlib.crc32(np.ascontiguousarray(mo).tobytes()))

@@ -1345,6 +1345,73 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
     flt.free()
 
 
+@pytest.mark.parametrize("bins,rows,h", [(4096, 4001, 4), (4160, 3001, 3), (8192, 3001, 2), (32768, 1201, 4), (36864, 701, 5), (65536, 601, 3)])
+def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h):
+    # every bin has a target, targets own one to four consecutive bins (what ganon-build makes of targets of different sizes above
+    # max_hashes_bin): at low cutoffs the split kernel judges them with a running sum over each lane's own bins (targets straddle
+    # lanes, dwords and column slices).  Same matches as the general scan (GANON_HIP_NO_RUN_SELECT), as the oracle, and -- with the
+    # pre-pass -- the same survivors and dropped totals.
+    k, w = 19, 31
+    rng = np.random.default_rng(bins + h)
+    sizes = []
+    while sum(sizes) < bins:
+        sizes.append(min(int(rng.choice([1, 1, 1, 2, 2, 3, 4])), bins - sum(sizes)))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n_targets = len(sizes)
+    b2t = np.repeat(np.arange(n_targets, dtype=np.uint32), sizes)
+    ibf = gf.random_ibf(bins, rows, h, 0.5, seed=bins + h)
+    genomes = []
+    for gi in range(48):
+        # (some at the very ends of the map and around the borders of lanes and slices)
+        t = [0, n_targets - 1, int(b2t[63]), int(b2t[64]), int(b2t[min(bins - 1, 64 * 64 - 1)]), int(b2t[min(bins - 1, 64 * 64)])][gi] if gi < 6 else int(rng.integers(0, n_targets))
+        g = gu.random_seq(rng, 1500)
+        hs = np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w))
+        for pi, part in enumerate(np.array_split(hs, sizes[t])):
+            ibf.emplace_many(part, int(off[t]) + pi)
+        if gi % 4 == 0:
+            for x in range(sizes[t]):       # all of it in every bin of the target: the sum passes n and is capped
+                ibf.emplace_many(hs, int(off[t]) + x)
+        genomes.append(g)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
+    reads = []
+    for i in range(800):
+        g = genomes[i % 48]
+        p = int(rng.integers(0, 1300))
+        reads.append(g[p:p + 150] if i % 3 else gu.random_seq(rng, int(rng.choice([60, 150]))))
+    tfpr = rng.choice([1e-4, 0.01, 0.05, 0.2], size=n_targets)
+    for cutoff in (0.05, 0.15, 0.3, 0.8):
+        st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
+        ho, hs = st.fetch_hashes()
+        monkeypatch.setenv("GANON_HIP_NO_RUN_SELECT", "1")
+        st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
+        monkeypatch.delenv("GANON_HIP_NO_RUN_SELECT")
+        assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
+        for i in range(0, len(reads), 5):
+            exp_m, _ = gu.oracle_matches(ibf, b2t, n_targets, hs[int(ho[i]):int(ho[i + 1])], cutoff)
+            got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+            assert got == exp_m, (cutoff, i, got[:3], exp_m[:3])
+        if cutoff == 0.05:
+            assert np.diff(mo.astype(np.int64)).max() > 128     # reads with more hits than a wave's staging list
+        st.destroy()
+        st2.destroy()
+        # with the filter_matches pre-pass (the select leaves unwritten what the rule is bound to drop)
+        res = []
+        for off_ in (False, True):
+            if off_:
+                monkeypatch.setenv("GANON_HIP_NO_RUN_SELECT", "1")
+            bases, off1, _ = gu.pack_reads(reads, None)
+            sp = hip.HipStream(flt, len(reads), bases.size)
+            sp.set_postfilter(0.1, 1e-3, tfpr)
+            sp.submit(bases, off1, None, k, w, cutoff)
+            r = sp.fetch()
+            res.append((r[2].copy(), r[3].copy(), sp.fetch_postfilter()))
+            sp.destroy()
+            monkeypatch.delenv("GANON_HIP_NO_RUN_SELECT", raising=False)
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert np.array_equal(res[0][2][0], res[1][2][0]) and res[0][2][1:] == res[1][2][1:]
+    flt.free()
+
+
 def test_deferred_launches_sized_by_the_previous_batch(hip, monkeypatch):
     # The launches that take what the fast kernels defer (reads with more than 127 minimisers, reads longer than 640 letters) size
     # their persistent grids by what the stream's PREVIOUS batch deferred.  A batch of short reads (nothing deferred) followed by a
