@@ -824,6 +824,61 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                 return tot;
             };
 
+            if constexpr (RS)
+                if (p.pre_mode) // (the same for every wave of the launch: the barrier below is met by all)
+                {
+                    // The read's true maximum before any target is judged: the largest running sum over the bins (a partial sum never
+                    // exceeds the sum of its target, which some lane sees whole).  The bar it allows goes into the first select;
+                    // without it a read with many targets between the two bars is scanned up to three times (bar of the largest bin,
+                    // bar of the maximum, direct output).  4 instructions a bin.
+                    uint32_t mx = 0;
+                    if (work && scan_all && col_act)
+                    {
+#pragma unroll
+                        for (int d = 0; d < ND; ++d)
+                            asm volatile("" : "+v"(ns[d]));
+                        const uint32_t back = (tbx >> 29) & 3u;
+                        uint32_t       run  = 0;
+                        for (uint32_t q = 1; q <= back; ++q)
+                            run += cnt_of(wi * 64u - q);
+#pragma unroll
+                        for (int d = 0; d < ND; ++d)
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                            {
+                                const uint32_t y = (uint32_t)k >> 1, pp = (uint32_t)k & 1u;
+                                const uint32_t sel = 0x0C0C0000u | ((4u + y) << 8) | y;
+                                const uint32_t x   = __builtin_amdgcn_perm(byt[d][1][pp], byt[d][0][pp], sel)
+                                                   | (__builtin_amdgcn_perm(byt[d][3][pp], byt[d][2][pp], sel) << 16); // bins 4k .. 4k+3
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                {
+                                    const int pos = 4 * k + j;
+                                    run = (run & (uint32_t)((int32_t)(ns[d] << (31 - pos)) >> 31)) + ((x >> (8 * j)) & 0xFFu);
+                                    mx  = run > mx ? run : mx;
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
+                    for (int off = 32; off > 0; off >>= 1)
+                    {
+                        const uint32_t y = (uint32_t)__shfl_xor((int)mx, off);
+                        mx = y > mx ? y : mx;
+                    }
+                    if (lane == 0)
+                        candcnt[wave] = mx; // (the candidate counts were read before the image's barrier)
+                    __syncthreads();
+                    if (work && scan_all)
+                    {
+                        uint32_t mx_r = 0;
+                        for (uint32_t sl = 0; sl < wpr; ++sl)
+                            mx_r = candcnt[rslot * wpr + sl] > mx_r ? candcnt[rslot * wpr + sl] : mx_r;
+                        mx_r = mx_r > n ? n : mx_r; // :525-526
+                        const uint32_t t2 = mx_r ? gn_pf_threshold(mx_r, p.pre_mode == 1 ? T : 0u, p.pre_rel) : 0u;
+                        if (t2 > Tsel && t2 <= mx_r)
+                            Tsel = t2;
+                    }
+                }
             if (work)
                 total = select(false, nullptr);
             if (p.pre_mode)
