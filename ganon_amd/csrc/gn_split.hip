@@ -824,15 +824,38 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                 return tot;
             };
 
-            if constexpr (RS)
-                if (p.pre_mode) // (the same for every wave of the launch: the barrier below is met by all)
+            if (p.pre_mode && p.max_first && (RS || p.uniform_nb)) // (the same for every wave of the launch: the barrier below is met by all)
                 {
-                    // The read's true maximum before any target is judged: the largest running sum over the bins (a partial sum never
-                    // exceeds the sum of its target, which some lane sees whole).  The bar it allows goes into the first select;
-                    // without it a read with many targets between the two bars is scanned up to three times (bar of the largest bin,
-                    // bar of the maximum, direct output).  4 instructions a bin.
+                    // The read's true maximum before any target is judged -- where targets are runs of bins a lane sees in its own
+                    // registers.  The bar it allows goes into the first select; without it a read with many targets between the two
+                    // bars is scanned up to three times (bar of the largest bin, bar of the maximum, direct output).
+                    // RS: the largest running sum over the bins (a partial sum never exceeds the sum of its target, which some lane
+                    // sees whole), 4 instructions a bin.
                     uint32_t mx = 0;
-                    if (work && scan_all && col_act)
+                    if (!RS && work && scan_all && col_act)
+                    {
+                        // uniform two- or four-bin targets: the sums as u16 halves, as the packed select forms them
+                        typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
+                        const bool two = p.uniform_nb == 2;
+                        gn_u16x2   m2  = __builtin_bit_cast(gn_u16x2, 0u);
+#pragma unroll
+                        for (int d = 0; d < ND; ++d)
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                            {
+                                const uint32_t y = (uint32_t)k >> 1, pp = (uint32_t)k & 1u;
+                                const uint32_t sel = 0x0C0C0000u | ((4u + y) << 8) | y;
+                                const uint32_t x   = __builtin_amdgcn_perm(byt[d][1][pp], byt[d][0][pp], sel)
+                                                   | (__builtin_amdgcn_perm(byt[d][3][pp], byt[d][2][pp], sel) << 16); // bins 4k .. 4k+3
+                                uint32_t s2 = (x & 0x00FF00FFu) + ((x >> 8) & 0x00FF00FFu);
+                                if (!two)
+                                    s2 = (s2 & 0xFFFFu) + (s2 >> 16);
+                                m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(gn_u16x2, s2));
+                            }
+                        const uint32_t mm = __builtin_bit_cast(uint32_t, m2);
+                        mx = (mm & 0xFFFFu) > (mm >> 16) ? (mm & 0xFFFFu) : (mm >> 16);
+                    }
+                    if (RS && work && scan_all && col_act)
                     {
 #pragma unroll
                         for (int d = 0; d < ND; ++d)
