@@ -1076,7 +1076,7 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.sl_nbr = f->d_sl_nbr;
     p.csr_identity = f->csr_identity && !getenv("GANON_HIP_NO_CSR_IDENTITY") ? 1u : 0u;
     p.uniform_nb   = p.csr_identity && !getenv("GANON_HIP_NO_UNIFORM_SELECT") ? f->uniform_nb : 0u;
-    p.run_select   = p.csr_identity && !p.uniform_nb && f->n_big == 0 && !getenv("GANON_HIP_NO_RUN_SELECT") ? 1u : 0u;
+    p.run_select   = p.csr_identity && !p.uniform_nb && !getenv("GANON_HIP_NO_RUN_SELECT") ? 1u : 0u;
     p.max_first    = getenv("GANON_HIP_NO_MAX_FIRST") ? 0u : 1u;
     const bool split = !f->identity && f->d_sl_nbr != nullptr && !getenv("GANON_HIP_NO_SPLIT_KERNEL");
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");

@@ -100,13 +100,13 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 
     // Run select (p.run_select: every bin has a target, targets own consecutive bins in target order, none more than four, not all the
     // same number): which of my bins CONTINUE the target of the bin before (ns), and in one word (tbx) the first target that ends among my
-    // bins, how many bins it has before my first one (at most three, bits 29-30) and whether the bin after my last continues (bit 31).
+    // bins, what it has before my first one (bits 28-30, below) and whether the bin after my last continues (bit 31).
     // Static for the persistent wave, like nbreg.
     uint32_t ns[ND], tbx = 0;
 #pragma unroll
     for (int d = 0; d < ND; ++d)
         ns[d] = 0;
-    if (RUNSEL && col_act)
+    if (RUNSEL && !p.uniform_nb && col_act)
     {
         constexpr uint32_t NONE = 0xFFFFFFFFu;
         const uint32_t     b0   = wi * 64u;
@@ -130,8 +130,17 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             }
             ns[d] = m;
         }
-        const uint32_t back = (ns[0] & 1u) ? b0 - p.tgt_off[p.bin_tgt[b0]] : 0u;
-        tbx = (first_end == NONE ? 0u : first_end) | (back << 29) | (cur != NONE && cur == prev ? 0x80000000u : 0u);
+        // What the target that reaches into the lane brings along: up to three bins (bits 29-30), or "more than that" (bit 28: three
+        // bins or more lie before mine and it is one of the list -- targets with more than GN_CAND_NBIG bins are not judged here).
+        uint32_t back = 0, bigc = 0;
+        if (ns[0] & 1u)
+        {
+            const uint32_t t = p.bin_tgt[b0];
+            back             = b0 - p.tgt_off[t];
+            bigc             = p.tgt_off[t + 1] - p.tgt_off[t] > GN_CAND_NBIG ? 1u : 0u;
+            back             = bigc ? 0u : back;
+        }
+        tbx = (first_end == NONE ? 0u : first_end) | (bigc << 28) | (back << 29) | (cur != NONE && cur == prev ? 0x80000000u : 0u);
     }
 
     const uint32_t n_work = p.work_list ? (uint32_t)*p.work_count : p.n_reads - p.read_begin;
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             // `direct` = second pass of a (read, slice) with more hits than the staging list holds
             auto select = [&](bool direct, gn_match* out) -> uint32_t {
                 uint32_t tot = 0;
-                if (scan_all && p.uniform_nb)
+                if (!RS && scan_all && p.uniform_nb) // (RS is never launched for uniform maps)
                 {
                     // Every target owns the same power-of-two number of consecutive bins (2 or 4) in target order: a target is
                     // half a dword (or a dword) of the lane's own bin-ordered counters, so the lane judges its 64*LW/nb targets
@@ -531,11 +540,34 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 #pragma unroll
                     for (int d = 0; d < ND; ++d)
                         asm volatile("" : "+v"(ns[d]));
-                    const uint32_t tb = tbx & 0x1FFFFFFFu, back = (tbx >> 29) & 3u;
-                    const uint32_t backbits = (back >= 2u ? 0x80000000u : 0u) | (back >= 3u ? 0x40000000u : 0u); // "continues" of the bins before mine
+                    // (likewise what follows from the lane's number and its word: recomputed here, a few instructions, instead of being
+                    // kept across the reads -- beside the counters such values end up in scratch and are read back before every use)
+                    uint32_t tbx_o = tbx, lane_o = (uint32_t)lane, wi_o = wi;
+                    asm volatile("" : "+v"(tbx_o), "+v"(lane_o), "+v"(wi_o));
+                    // targets with more than GN_CAND_NBIG bins first: this wave's share of the list, summed from the image
+                    {
+                        const uint32_t per = (p.n_big + wpr - 1) / wpr;
+                        const uint32_t lo = min(p.n_big, slice * per), hi = min(p.n_big, lo + per);
+                        for (uint32_t i0 = lo; i0 < hi; i0 += GN_WAVE)
+                        {
+                            const uint32_t i    = i0 + lane;
+                            bool           emit = false;
+                            uint32_t       tgt = 0, cv = 0;
+                            if (i < hi)
+                            {
+                                tgt  = p.big_list[i];
+                                cv   = target_sum(p.tgt_rec[tgt]);
+                                emit = judge(cv);
+                            }
+                            emit_hits(emit, tgt, cv, tot, direct, out);
+                        }
+                    }
+                    const uint32_t tb = tbx_o & 0x0FFFFFFFu, back = (tbx_o >> 29) & 3u;
+                    // "continues" of the three bins before mine (all three for a target of the list that reaches into the lane)
+                    const uint32_t backbits = (tbx_o & 0x10000000u) ? 0xE0000000u : (back >= 2u ? 0x80000000u : 0u) | (back >= 3u ? 0x40000000u : 0u);
                     uint32_t       run      = 0;
                     for (uint32_t q = 1; q <= back; ++q) // the bins my first target has in the lane (or slice) before me
-                        run += cnt_of(wi * 64u - q);
+                        run += cnt_of(wi_o * 64u - q);
                     // min(sum, n) >= bar (:525-526)  <=>  bar <= n and sum >= bar; sums stay below 1024, so a bar of 2^16 never passes
                     const uint32_t selb = Tsel <= n ? Tsel : 0x10000u, tbar = T <= n ? T : 0x10000u;
                     uint32_t       hit[ND], low = 0xFFFFFFFFu, n_mid = 0;
@@ -543,10 +575,15 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     for (int d = 0; d < ND; ++d)
                     {
                         // a bin ends its target where the next bin does not continue it (every bin below B has a target)
-                        const uint32_t b0d   = wi * 64u + 32u * (uint32_t)d;
+                        const uint32_t b0d   = wi_o * 64u + 32u * (uint32_t)d;
                         const uint32_t valid = !col_act || b0d >= p.B ? 0u : (p.B - b0d >= 32u ? 0xFFFFFFFFu : (1u << (p.B - b0d)) - 1u);
-                        const uint32_t nextc = d + 1 < ND ? ns[d + 1 < ND ? d + 1 : 0] << 31 : tbx & 0x80000000u;
-                        const uint32_t en    = ~((ns[d] >> 1) | nextc) & valid;
+                        const uint32_t nextc = d + 1 < ND ? ns[d + 1 < ND ? d + 1 : 0] << 31 : tbx_o & 0x80000000u;
+                        // ... and a bin that continues three bins in a row is the fifth of its target, or later: where such a bin ends a
+                        // target, the target is one of the list and is not judged here
+                        const uint32_t below = d ? ns[d > 0 ? d - 1 : 0] : backbits;
+                        const uint32_t fifth = ns[d] & __builtin_amdgcn_alignbit(ns[d], below, 31) & __builtin_amdgcn_alignbit(ns[d], below, 30)
+                                             & __builtin_amdgcn_alignbit(ns[d], below, 29);
+                        const uint32_t en    = ~((ns[d] >> 1) | nextc) & valid & ~fifth;
                         const uint32_t nen   = ~en;
                         uint32_t       hm = 0, tm = 0; // sign bits shifted in from below: bin 0 ends up on top, 1 = under the bar
 #pragma unroll
@@ -589,19 +626,19 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 #pragma unroll
                     for (int off = 1; off < GN_WAVE; off <<= 1)
                     {
-                        const uint32_t y = (uint32_t)__shfl_up((int)inc, off);
-                        inc += lane >= off ? y : 0u;
+                        const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane_o - (uint32_t)off) & 63u) << 2), (int)inc);
+                        inc += lane_o >= (uint32_t)off ? y : 0u;
                     }
-                    uint32_t       o      = inc - mine_hits;
+                    uint32_t       o      = tot + inc - mine_hits;
                     const uint32_t in_all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                     uint32_t       ended  = 0; // targets that end in my groups before d
 #pragma unroll
                     for (int d = 0; d < ND; ++d)
                     {
-                        const uint32_t b0d   = wi * 64u + 32u * (uint32_t)d;
+                        const uint32_t b0d   = wi_o * 64u + 32u * (uint32_t)d;
                         const uint32_t valid = !col_act || b0d >= p.B ? 0u : (p.B - b0d >= 32u ? 0xFFFFFFFFu : (1u << (p.B - b0d)) - 1u);
-                        const uint32_t nextc = d + 1 < ND ? ns[d + 1 < ND ? d + 1 : 0] << 31 : tbx & 0x80000000u;
-                        const uint32_t en    = ~((ns[d] >> 1) | nextc) & valid;
+                        const uint32_t nextc = d + 1 < ND ? ns[d + 1 < ND ? d + 1 : 0] << 31 : tbx_o & 0x80000000u;
+                        const uint32_t en    = ~((ns[d] >> 1) | nextc) & valid; // (every target's end: the numbering counts them all)
                         const uint64_t flags = ((uint64_t)ns[d] << 32) | (d ? ns[d > 0 ? d - 1 : 0] : backbits);
                         while (hit[d])
                         {
@@ -637,7 +674,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     tot += in_all;
                     return tot;
                 }
-                if (scan_all)
+                if (!RS && scan_all)
                 {
                     // too many candidates (tiny T, dense hits): every target, this wave takes its share
                     const uint32_t per = (p.n_targets + wpr - 1) / wpr;
@@ -800,8 +837,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         const uint32_t b   = wi * 64 + tp;
                         const uint32_t t   = p.bin_tgt[b];
                         const uint4    rec = p.tgt_rec[t];
-                        bool           lowest = true;
-                        for (uint32_t x = 0; x < rec.y; ++x) // bins of a target ascend in the CSR
+                        bool           lowest = !(RS && rec.y > GN_CAND_NBIG); // (RS: bins of the list's targets pass the prefilter too)
+                        for (uint32_t x = 0; lowest && x < rec.y; ++x) // bins of a target ascend in the CSR
                         {
                             const uint32_t bx = p.tgt_bins[rec.x + x];
                             if (bx >= b)
@@ -860,10 +897,12 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 #pragma unroll
                         for (int d = 0; d < ND; ++d)
                             asm volatile("" : "+v"(ns[d]));
-                        const uint32_t back = (tbx >> 29) & 3u;
+                        uint32_t tbx_o = tbx, wi_o = wi; // (not kept across the reads, cf. the select)
+                        asm volatile("" : "+v"(tbx_o), "+v"(wi_o));
+                        const uint32_t back = (tbx_o >> 29) & 3u;
                         uint32_t       run  = 0;
                         for (uint32_t q = 1; q <= back; ++q)
-                            run += cnt_of(wi * 64u - q);
+                            run += cnt_of(wi_o * 64u - q);
 #pragma unroll
                         for (int d = 0; d < ND; ++d)
 #pragma unroll

@@ -1,6 +1,6 @@
 """The split-bin kernel at the low-cutoff thresholds, alone (for rocprofv3 passes): split32k workload, --rel-cutoff 0.2 with the
 filter_matches pre-pass set (--rel-filter 0.1 --fpr-query 1e-5), N steps.  usage: split_lowcut.py [steps=5] [reads=2000000] [cutoff=0.2]
-MIX=1: targets of 1 .. 4 consecutive bins (seeded draw from 1,1,1,2,2,3,4) instead of two bins each."""
+MIX=1: targets of 1 .. 4 consecutive bins (seeded draw from 1,1,1,2,2,3,4) instead of two bins each; MIX=2: one in a hundred of 5 .. 200 bins."""
 import os
 import sys
 
@@ -18,6 +18,9 @@ bins, rows, h, bpt = 32768, 1 << 21, 4, 2
 wl = bw.make_device_flat_workload("split32k", bins, rows, h, n, False, rel_cutoff=cutoff, seed=42)
 if os.environ.get("MIX"):
     sizes = np.random.default_rng(7).choice(np.array([1, 1, 1, 2, 2, 3, 4]), size=bins)
+    if os.environ["MIX"] == "2":  # ... and one target in a hundred of 5 .. 200 bins
+        r7 = np.random.default_rng(8)
+        sizes = np.where(r7.random(bins) < 0.01, r7.choice(np.array([5, 9, 40, 70, 200]), size=bins), sizes)
     sizes = sizes[: int(np.searchsorted(np.cumsum(sizes), bins, side="right"))]
     b2t = np.repeat(np.arange(sizes.size, dtype=np.uint32), sizes)
     b2t = np.concatenate([b2t, np.full(bins - b2t.size, sizes.size, dtype=np.uint32)])  # the remainder: one last target

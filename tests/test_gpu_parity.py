@@ -1345,17 +1345,20 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
     flt.free()
 
 
-@pytest.mark.parametrize("bins,rows,h", [(4096, 4001, 4), (4160, 3001, 3), (8192, 3001, 2), (32768, 1201, 4), (36864, 701, 5), (65536, 601, 3)])
-def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h):
+@pytest.mark.parametrize("bins,rows,h,big", [(4096, 4001, 4, False), (4160, 3001, 3, True), (8192, 3001, 2, False), (32768, 1201, 4, True),
+                                             (36864, 701, 5, False), (65536, 601, 3, True), (8192, 2001, 4, True)])
+def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h, big):
     # every bin has a target, targets own one to four consecutive bins (what ganon-build makes of targets of different sizes above
     # max_hashes_bin): at low cutoffs the split kernel judges them with a running sum over each lane's own bins (targets straddle
     # lanes, dwords and column slices).  Same matches as the general scan (GANON_HIP_NO_RUN_SELECT), as the oracle, and -- with the
     # pre-pass -- the same survivors and dropped totals.
     k, w = 19, 31
     rng = np.random.default_rng(bins + h)
+    # (big: a few targets of more than four bins among them -- up to several lanes long; those are judged from a list)
     sizes = []
     while sum(sizes) < bins:
-        sizes.append(min(int(rng.choice([1, 1, 1, 2, 2, 3, 4])), bins - sum(sizes)))
+        pick = int(rng.choice([5, 9, 40, 70, 200])) if big and rng.random() < 0.02 else int(rng.choice([1, 1, 1, 2, 2, 3, 4]))
+        sizes.append(min(pick, bins - sum(sizes)))
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n_targets = len(sizes)
     b2t = np.repeat(np.arange(n_targets, dtype=np.uint32), sizes)
@@ -1364,12 +1367,14 @@ def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h)
     for gi in range(48):
         # (some at the very ends of the map and around the borders of lanes and slices)
         t = [0, n_targets - 1, int(b2t[63]), int(b2t[64]), int(b2t[min(bins - 1, 64 * 64 - 1)]), int(b2t[min(bins - 1, 64 * 64)])][gi] if gi < 6 else int(rng.integers(0, n_targets))
+        if big and gi in (6, 7, 8, 9):       # some of the long targets too
+            t = int(np.flatnonzero(np.asarray(sizes) > 4)[gi - 6])
         g = gu.random_seq(rng, 1500)
         hs = np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w))
-        for pi, part in enumerate(np.array_split(hs, sizes[t])):
+        for pi, part in enumerate(np.array_split(hs, min(sizes[t], 8))):
             ibf.emplace_many(part, int(off[t]) + pi)
         if gi % 4 == 0:
-            for x in range(sizes[t]):       # all of it in every bin of the target: the sum passes n and is capped
+            for x in range(min(sizes[t], 8)):  # all of it in every bin of the target: the sum passes n and is capped
                 ibf.emplace_many(hs, int(off[t]) + x)
         genomes.append(g)
     flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
