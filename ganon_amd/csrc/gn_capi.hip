@@ -1078,6 +1078,7 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.uniform_nb   = p.csr_identity && !getenv("GANON_HIP_NO_UNIFORM_SELECT") ? f->uniform_nb : 0u;
     p.run_select   = p.csr_identity && !p.uniform_nb && !getenv("GANON_HIP_NO_RUN_SELECT") ? 1u : 0u;
     p.max_first    = getenv("GANON_HIP_NO_MAX_FIRST") ? 0u : 1u;
+    p.const_nb     = p.uniform_nb && !getenv("GANON_HIP_NO_CONST_NB") ? p.uniform_nb : (p.run_select ? 4u : 0u);
     const bool split = !f->identity && f->d_sl_nbr != nullptr && !getenv("GANON_HIP_NO_SPLIT_KERNEL");
     const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
     // with a filter_matches pre-pass on the stream the fast and the split-bin kernel do not write matches the --rel-filter rule is bound to

@@ -107,6 +107,7 @@ struct GnCountParams
     // of the read's matches), 2: nothing known about the minimum (other filters of the level may report smaller counts)
     uint32_t            uniform_nb;   // csr_identity and every target owns exactly this many bins (2 or 4): packed select of the split kernel; else 0
     uint32_t            max_first;    // split kernel, pre-pass mode, uniform_nb or run_select: the read's true maximum is found before the first select
+    uint32_t            const_nb;     // 0, or the bins-per-target the split kernel's RS variant takes for every bin: uniform_nb, or 4 with run_select
     uint32_t            run_select;   // csr_identity, no target of more than four bins, widths differ: the split kernel judges targets from a running sum over a lane's own bins
     uint32_t            csr_identity; // tgt_bins[i] == i: target t owns the bins [tgt_off[t], tgt_off[t+1]) (what ganon-build writes)
     uint32_t            pre_mode;

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
         {
             typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
             const gn_u16x2 tm1 = __builtin_bit_cast(gn_u16x2, (T - 1) * 0x00010001u);
+            const uint32_t tq  = (T + p.const_nb - 1u) >> (p.const_nb == 2u ? 1 : 2); // (RS: every bin is one of const_nb, 2 or 4)
 #pragma unroll
             for (int d = 0; d < ND; ++d)
             {
@@ -282,9 +283,9 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     for (int pp = 0; pp < 2; ++pp)
                     {
                         const uint32_t x  = byt[d][j][pp];
-                        if constexpr (RS) // count * 4 >= T  <=>  count >= ceil(T / 4), bytes compared in place (counts <= 127: no carry)
+                        if constexpr (RS) // count * nb >= T  <=>  count >= ceil(T / nb), bytes compared in place (counts <= 127: no carry)
                         {
-                            m |= (((x + (0x80u - ((T + 3u) >> 2)) * 0x01010101u) & 0x80808080u) >> 7) << (4 * pp + j);
+                            m |= (((x + (0x80u - tq) * 0x01010101u) & 0x80808080u) >> 7) << (4 * pp + j);
                             continue;
                         }
                         const uint32_t nb = nbreg[(d * 4 + j) * 2 + pp];
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             // `direct` = second pass of a (read, slice) with more hits than the staging list holds
             auto select = [&](bool direct, gn_match* out) -> uint32_t {
                 uint32_t tot = 0;
-                if (!RS && scan_all && p.uniform_nb) // (RS is never launched for uniform maps)
+                if (scan_all && p.uniform_nb)
                 {
                     // Every target owns the same power-of-two number of consecutive bins (2 or 4) in target order: a target is
                     // half a dword (or a dword) of the lane's own bin-ordered counters, so the lane judges its 64*LW/nb targets
@@ -483,6 +484,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     }
                     // emission in target order: lane after lane (a lane's targets are consecutive), each lane at the offset the
                     // wave's prefix sum of hit counts gives it -- the grouping pass (gn_gather_kernel) wants ascending targets
+                    uint32_t lane_o = (uint32_t)lane; // (not kept across the reads: the shuffle addresses end in scratch otherwise)
+                    asm volatile("" : "+v"(lane_o));
                     uint32_t mine_hits = 0;
 #pragma unroll
                     for (int d = 0; d < ND; ++d)
@@ -491,8 +494,8 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 #pragma unroll
                     for (int off = 1; off < GN_WAVE; off <<= 1)
                     {
-                        const uint32_t y = (uint32_t)__shfl_up((int)inc, off);
-                        inc += lane >= off ? y : 0u;
+                        const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane_o - (uint32_t)off) & 63u) << 2), (int)inc);
+                        inc += lane_o >= (uint32_t)off ? y : 0u;
                     }
                     uint32_t       o      = inc - mine_hits;
                     const uint32_t in_all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                             const uint32_t bx = p.tgt_bins[rec.x + x];
                             if (bx >= b)
                                 break;
-                            if (cnt_of(bx) * (RS ? 4u : rec.y) >= T) // (the very rule of the prefilter: who is a candidate)
+                            if (cnt_of(bx) * (RS ? p.const_nb : rec.y) >= T) // (the very rule of the prefilter: who is a candidate)
                             {
                                 lowest = false;
                                 break;
@@ -869,7 +872,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     // RS: the largest running sum over the bins (a partial sum never exceeds the sum of its target, which some lane
                     // sees whole), 4 instructions a bin.
                     uint32_t mx = 0;
-                    if (!RS && work && scan_all && col_act)
+                    if (p.uniform_nb && work && scan_all && col_act)
                     {
                         // uniform two- or four-bin targets: the sums as u16 halves, as the packed select forms them
                         typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
@@ -892,7 +895,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         const uint32_t mm = __builtin_bit_cast(uint32_t, m2);
                         mx = (mm & 0xFFFFu) > (mm >> 16) ? (mm & 0xFFFFu) : (mm >> 16);
                     }
-                    if (RS && work && scan_all && col_act)
+                    if (RS && !p.uniform_nb && work && scan_all && col_act)
                     {
 #pragma unroll
                         for (int d = 0; d < ND; ++d)
@@ -1082,7 +1085,7 @@ template <int HF, int LW, int MAXT>
 static hipError_t gn_launch_split_one(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
 {
     if constexpr (GN_SPLIT_RUN_SELECT(MAXT))
-        if (p.run_select)
+        if (p.const_nb)
             return gn_launch_split_rs<HF, LW, MAXT, true>(p, g, st);
     return gn_launch_split_rs<HF, LW, MAXT, false>(p, g, st);
 }
