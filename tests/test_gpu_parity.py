@@ -93,6 +93,7 @@ SHAPES = [  # bins, rows, h
     (1, 97, 1), (3, 211, 2), (64, 1000, 3), (100, 1531, 4), (128, 900, 5), (130, 777, 3), (500, 2048, 4),
     (4096, 4099, 4), (4100, 1200, 2), (8192, 1024, 3), (8256, 700, 4), (20000, 300, 2), (32768, 257, 4),
     (65536, 130, 3),
+    (40000, 197, 3), (51264, 131, 2), (47168, 167, 4),    # rows of an odd number of words, 10 / 13 / 12 column slices: the 1024-thread shapes
 ]
 
 
@@ -475,7 +476,7 @@ def test_early_exit_is_exact(hip, monkeypatch, bins, rows, h):
 @pytest.mark.parametrize("bins,rows,h,contiguous", [(4096, 4001, 4, True), (4096, 4001, 3, False), (1024, 9001, 4, False),
                                                     (16384, 1501, 4, True), (16384, 1501, 2, False), (704, 9001, 5, False),
                                                     (4096, 2001, 2, False), (36864, 701, 4, True), (36864, 701, 3, False),
-                                                    (20480, 1201, 4, False)])
+                                                    (20480, 1201, 4, False), (51264, 401, 3, True), (40000, 401, 4, False)])
 def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, contiguous):
     # Split-bin maps of every kind (targets of 1..300 bins, contiguous runs or scattered bins, bins of no target, rows
     # of one to several column slices and rows narrower than a wave): the generic kernel's candidate-driven select
@@ -1284,7 +1285,7 @@ def test_hibf_batch_in_read_ranges_equals_one_pass(hip, monkeypatch, limit, prep
     flt.free()
 
 
-@pytest.mark.parametrize("bins,rows,h,nb", [(4096, 4001, 4, 2), (8192, 3001, 3, 4), (32768, 1201, 4, 2), (16384, 1501, 2, 4), (36864, 701, 4, 2)])
+@pytest.mark.parametrize("bins,rows,h,nb", [(4096, 4001, 4, 2), (8192, 3001, 3, 4), (32768, 1201, 4, 2), (16384, 1501, 2, 4), (36864, 701, 4, 2), (51264, 401, 3, 2)])
 def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, rows, h, nb):
     # every target owns the same 2 or 4 consecutive bins (what a database of equally sized, over-sized targets looks like): at low
     # cutoffs the split kernel judges them with packed 16-bit arithmetic over its bin-ordered counters.  Same matches as the general
@@ -1346,7 +1347,7 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
 
 
 @pytest.mark.parametrize("bins,rows,h,big", [(4096, 4001, 4, False), (4160, 3001, 3, True), (8192, 3001, 2, False), (32768, 1201, 4, True),
-                                             (36864, 701, 5, False), (65536, 601, 3, True), (8192, 2001, 4, True)])
+                                             (36864, 701, 5, False), (65536, 601, 3, True), (8192, 2001, 4, True), (51264, 401, 3, True)])
 def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h, big):
     # every bin has a target, targets own one to four consecutive bins (what ganon-build makes of targets of different sizes above
     # max_hashes_bin): at low cutoffs the split kernel judges them with a running sum over each lane's own bins (targets straddle
