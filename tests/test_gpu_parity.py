@@ -1418,6 +1418,61 @@ def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h,
     flt.free()
 
 
+@pytest.mark.parametrize("kind", ["uniform2", "uniform4", "mixed", "mixed_long"])
+def test_split_kernel_switches_give_the_same_survivors(hip, monkeypatch, kind):
+    # the A/B switches of the split kernel's selects (DESIGN "Switches"): the round-3 instantiation for uniform maps, no maximum before
+    # the first select, the scan instead of the packed / running-sum select -- with a filter_matches pre-pass to follow every one of
+    # them leaves the same matches, the same survivors and the same dropped totals
+    k, w, bins, rows, h = 19, 31, 16384, 1801, 3
+    rng = np.random.default_rng(len(kind))
+    if kind.startswith("uniform"):
+        nb = int(kind[-1])
+        sizes = [nb] * (bins // nb)
+    else:
+        sizes = []
+        while sum(sizes) < bins:
+            pick = int(rng.choice([6, 30, 150])) if kind == "mixed_long" and rng.random() < 0.02 else int(rng.choice([1, 1, 2, 3, 4]))
+            sizes.append(min(pick, bins - sum(sizes)))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n_targets = len(sizes)
+    b2t = np.repeat(np.arange(n_targets, dtype=np.uint32), sizes)
+    ibf = gf.random_ibf(bins, rows, h, 0.5, seed=77)
+    genomes = []
+    for gi in range(32):
+        t = int(rng.integers(0, n_targets))
+        g = gu.random_seq(rng, 1500)
+        hs = np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w))
+        for pi, part in enumerate(np.array_split(hs, min(sizes[t], 6))):
+            ibf.emplace_many(part, int(off[t]) + pi)
+        genomes.append(g)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
+    reads = [genomes[i % 32][(i * 37) % 1300:(i * 37) % 1300 + 150] if i % 3 else gu.random_seq(rng, 150) for i in range(600)]
+    bases, off1, _ = gu.pack_reads(reads, None)
+    tfpr = rng.choice([1e-4, 0.01, 0.05, 0.2], size=n_targets)
+    switches = [None, "GANON_HIP_NO_MAX_FIRST", "GANON_HIP_NO_CONST_NB", "GANON_HIP_NO_UNIFORM_SELECT", "GANON_HIP_NO_RUN_SELECT", "GANON_HIP_NO_SPLIT_KERNEL"]
+    for cutoff in (0.1, 0.25, 0.75):
+        res = []
+        for sw in switches:
+            for e in switches[1:]:
+                monkeypatch.delenv(e, raising=False)
+            if sw:
+                monkeypatch.setenv(sw, "1")
+            sp = hip.HipStream(flt, len(reads), bases.size)
+            sp.set_postfilter(0.1, 1e-3, tfpr)
+            sp.submit(bases, off1, None, k, w, cutoff)
+            r = sp.fetch()
+            res.append((r[2].copy(), r[3].copy(), sp.fetch_postfilter()))
+            sp.destroy()
+        for e in switches[1:]:
+            monkeypatch.delenv(e, raising=False)
+        for sw, x in zip(switches[1:], res[1:]):
+            assert np.array_equal(res[0][0], x[0]) and np.array_equal(res[0][1], x[1]), (kind, cutoff, sw)
+            assert np.array_equal(res[0][2][0], x[2][0]) and res[0][2][1:] == x[2][1:], (kind, cutoff, sw)
+        if cutoff == 0.1:
+            assert len(res[0][1]) > 0
+    flt.free()
+
+
 def test_deferred_launches_sized_by_the_previous_batch(hip, monkeypatch):
     # The launches that take what the fast kernels defer (reads with more than 127 minimisers, reads longer than 640 letters) size
     # their persistent grids by what the stream's PREVIOUS batch deferred.  A batch of short reads (nothing deferred) followed by a
