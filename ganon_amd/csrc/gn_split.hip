@@ -61,9 +61,10 @@ struct GnSpRows
 
 } // namespace
 
-// RS: the variant for maps the run select applies to (p.run_select): no bins-per-target registers (the prefilter takes every bin for one
-// of four), the running-sum select instead of the scan.
-template <int HF, int LW, int MAXT, bool RS>
+// RS: 0 = the general instantiation (bins-per-target registers, candidate select, scan); 1 = maps whose targets own runs of consecutive
+// bins of mixed lengths (p.run_select: running-sum select); 2 = uniform maps (p.uniform_nb: packed select).  1 and 2 carry no
+// bins-per-target registers -- the prefilter takes every bin for one of p.const_nb, a byte compare -- and not the selects they never run.
+template <int HF, int LW, int MAXT, int RS>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512 ? 4 : (LW == 2 || MAXT > 256 ? 2 : 3)))) void gn_ibf_count_split_kernel(GnCountParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_sp_lds[];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
     constexpr int      HFP  = HF <= 4 ? 4 : 8;
     constexpr uint32_t NMAX = 127;
     constexpr uint32_t IMG  = 8 * ND * 64; // dwords of one wave's byte image
-    constexpr bool     RUNSEL = RS;
+    constexpr bool     RUNSEL = RS == 1; // 1: maps of mixed widths (run select), 2: uniform maps (packed select), both without nbreg
 
     const int      lane   = threadIdx.x & (GN_WAVE - 1);
     const int      wave   = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 #pragma unroll
     for (int d = 0; d < ND; ++d)
         ns[d] = 0;
-    if (RUNSEL && !p.uniform_nb && col_act)
+    if (RUNSEL && col_act)
     {
         constexpr uint32_t NONE = 0xFFFFFFFFu;
         const uint32_t     b0   = wi * 64u;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             // `direct` = second pass of a (read, slice) with more hits than the staging list holds
             auto select = [&](bool direct, gn_match* out) -> uint32_t {
                 uint32_t tot = 0;
-                if (scan_all && p.uniform_nb)
+                if (RS != 1 && scan_all && p.uniform_nb)
                 {
                     // Every target owns the same power-of-two number of consecutive bins (2 or 4) in target order: a target is
                     // half a dword (or a dword) of the lane's own bin-ordered counters, so the lane judges its 64*LW/nb targets
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     tot += in_all;
                     return tot;
                 }
-                if (!RS && scan_all)
+                if (RS == 0 && scan_all)
                 {
                     // too many candidates (tiny T, dense hits): every target, this wave takes its share
                     const uint32_t per = (p.n_targets + wpr - 1) / wpr;
@@ -840,7 +841,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         const uint32_t b   = wi * 64 + tp;
                         const uint32_t t   = p.bin_tgt[b];
                         const uint4    rec = p.tgt_rec[t];
-                        bool           lowest = !(RS && rec.y > GN_CAND_NBIG); // (RS: bins of the list's targets pass the prefilter too)
+                        bool           lowest = !(RS == 1 && rec.y > GN_CAND_NBIG); // (RS: bins of the list's targets pass the prefilter too)
                         for (uint32_t x = 0; lowest && x < rec.y; ++x) // bins of a target ascend in the CSR
                         {
                             const uint32_t bx = p.tgt_bins[rec.x + x];
@@ -864,7 +865,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                 return tot;
             };
 
-            if (p.pre_mode && p.max_first && (RS || p.uniform_nb)) // (the same for every wave of the launch: the barrier below is met by all)
+            if (p.pre_mode && p.max_first && (RS == 1 || p.uniform_nb)) // (the same for every wave of the launch: the barrier below is met by all)
                 {
                     // The read's true maximum before any target is judged -- where targets are runs of bins a lane sees in its own
                     // registers.  The bar it allows goes into the first select; without it a read with many targets between the two
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                     // RS: the largest running sum over the bins (a partial sum never exceeds the sum of its target, which some lane
                     // sees whole), 4 instructions a bin.
                     uint32_t mx = 0;
-                    if (p.uniform_nb && work && scan_all && col_act)
+                    if (RS != 1 && p.uniform_nb && work && scan_all && col_act)
                     {
                         // uniform two- or four-bin targets: the sums as u16 halves, as the packed select forms them
                         typedef unsigned short gn_u16x2 __attribute__((ext_vector_type(2)));
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
                         const uint32_t mm = __builtin_bit_cast(uint32_t, m2);
                         mx = (mm & 0xFFFFu) > (mm >> 16) ? (mm & 0xFFFFu) : (mm >> 16);
                     }
-                    if (RS && !p.uniform_nb && work && scan_all && col_act)
+                    if (RUNSEL && work && scan_all && col_act)
                     {
 #pragma unroll
                         for (int d = 0; d < ND; ++d)
@@ -1068,7 +1069,7 @@ size_t gn_split_lds_bytes(const GnCountGeometry& g, uint32_t hash_funs)
     return ((size_t)g.rpb * g.wpr * 8 * nd * 64 + (size_t)nwaves * (128 * hfp + 2 * GN_SPLIT_STAGE) + 2 * nwaves) * 4;
 }
 
-template <int HF, int LW, int MAXT, bool RS>
+template <int HF, int LW, int MAXT, int RS>
 static hipError_t gn_launch_split_rs(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
 {
     uint32_t blocks = (p.n_reads - p.read_begin + g.rpb - 1) / g.rpb;
@@ -1085,9 +1086,13 @@ template <int HF, int LW, int MAXT>
 static hipError_t gn_launch_split_one(const GnCountParams& p, const GnCountGeometry& g, hipStream_t st)
 {
     if constexpr (GN_SPLIT_RUN_SELECT(MAXT))
+    {
+        if (p.const_nb && p.uniform_nb)
+            return gn_launch_split_rs<HF, LW, MAXT, 2>(p, g, st);
         if (p.const_nb)
-            return gn_launch_split_rs<HF, LW, MAXT, true>(p, g, st);
-    return gn_launch_split_rs<HF, LW, MAXT, false>(p, g, st);
+            return gn_launch_split_rs<HF, LW, MAXT, 1>(p, g, st);
+    }
+    return gn_launch_split_rs<HF, LW, MAXT, 0>(p, g, st);
 }
 
 template <int HF>
