@@ -1023,8 +1023,11 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 #define GN_FAST_WPE_LW1 4 // waves per SIMD the register allocator must reach, 8-byte lanes
 #endif
 #ifndef GN_FAST_WPE_LW2
-#define GN_FAST_WPE_LW2 2 // same, 16-byte lanes
+#define GN_FAST_WPE_LW2 2 // same, 16-byte lanes, five hash functions
 #endif
+#ifndef GN_FAST_WPE_LW2_H4
+#define GN_FAST_WPE_LW2_H4 3 // same, 16-byte lanes, up to four hash functions: 168 registers and 2 .. 15 of them in scratch (the epilogue's), measured
+#endif                       // +4 % at the headline thresholds, +5 .. 7 % at low cutoffs on 32 768 bins / 8 GiB, +0.3 % on 128 GiB (round 4)
 
 // ================================================================================================
 // fast count + select kernel: identity bin->target map, reads with at most 127 minimisers
@@ -1038,7 +1041,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 // EE = with the exact early exit (instantiated separately: its check costs registers, and the variant without it
 // must keep the occupancy it had).
 template <int HF, int LW, bool EE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW == 1 ? GN_FAST_WPE_LW1 : GN_FAST_WPE_LW2) : 1))) void gn_ibf_count_fast_kernel(GnCountParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW == 1 ? GN_FAST_WPE_LW1 : (HF <= 4 ? GN_FAST_WPE_LW2_H4 : GN_FAST_WPE_LW2)) : 1))) void gn_ibf_count_fast_kernel(GnCountParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_lds[];
     constexpr int      ND   = 2 * LW;
