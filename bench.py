@@ -17,13 +17,22 @@ resident in HBM; the filter is resident too.  Workloads (BASELINE.json `configs`
                         every pair, sparse matches go to the read's owner over RCCL (world 1 on one GPU)
 
 The 128 GiB filters are generated on the device (gn_filter_fill_random); nothing that large exists on the host.
-Rank 0 prints ONE JSON line (driver contract) with extra objects:
-  roofline         dominant kernel: `achieved` = HBM row bytes the kernel actually requested per launch / its average
-                   duration (hipEvents on the library's own stream); `frac` = achieved / 8000 GB/s.  The algorithmic
-                   rate (n*h*W*8 per read) is reported beside it as `effective_gbs`: the exact early
-                   exit makes the kernel fetch fewer rows than the algorithm names, so only `achieved` is physical.
+Output (rank 0): everything measured goes to `bench_detail.json` (next to this file, and under gpurun_out/ when that
+exists) and to ONE EARLIER stdout line `bench_detail: {...}`; the LAST stdout line is the driver's record -- one
+compact JSON object (a few KB, never more than 8 KB: tests/test_bench_line.py) holding exactly
+  metric value unit n_gpus steps warmup ms_per_step higher_is_better scaling vs_baseline dtype data
+  config        {workload, reads_per_gpu, parallelism, oracle_mismatching_reads, <= 20 flat scalars}
+  roofline      dominant kernel, three named fractions of the 8000 GB/s HBM peak (hipEvent times on the library's stream):
+                  frac           SURVEY 8(d) algorithmic bytes (n*h*W*8 per read) / kernel time, measured on the
+                                 instantiation that FETCHES EVERY ALGORITHMIC ROW (exact early exit ablated) = `achieved`
+                  frac_fetched   the product kernel (early exit on): row bytes it really requested / its time
+                  algo_over_peak the product kernel: algorithmic bytes / its time; may exceed 1 because rows the exact
+                                 early exit skips are never fetched and cost nothing
+                traffic = HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE pass (profiles/pmc_fetch_*.json)
+  cpu_baseline  {value, unit, cores, kind, sample}: the real ganon-classify when one that is not ours is on PATH
+                (kind "reference"), else the CPU oracle (kind "port"), on a bounded sample of the same reads
+The detail file holds, besides the full headline objects:
   variants         the same resident batch with the early exit disabled and at the binary's default --rel-cutoff 0.2
-  cpu_baseline     the CPU oracle (kind "port") on a bounded sample of the same reads against the same filter bits
   other_workloads  the other BASELINE configs at full size: at N=1 each in a child process (hibf64k, its variant with an
                    HBM-resident top level, flat128g, slice1t); at N>1 in this job, one after the other: flat128g (configs[3]:
                    12.5 M pairs PER RANK against a replica, weak) and slice1t (configs[4]: rank r holds column slice r, every
@@ -97,7 +106,7 @@ def run_extra(name: str, timeout: int):
     t0 = time.time()
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
-        line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{\"metric\"")]
+        line = [ln[len("bench_detail: "):] for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("bench_detail: ")]
         if p.returncode == 0 and line:
             r = json.loads(line[-1])
             return slim(name, r, time.time() - t0)
@@ -123,36 +132,101 @@ def run_e2e(budget: int):
         return {"error": repr(e)}
 
 
-def summarise(result: dict) -> None:
-    """The driver's record keeps scalars of `config` / `roofline` / `cpu_baseline` and lists other top-level objects by name only:
-    the figures of `variants`, `other_workloads` and `e2e` a reader needs are repeated as flat scalars in `config`."""
-    c = result["config"]
-    for key, v in (result.get("variants") or {}).items():
-        if "mreads_per_s" in v:
-            c[f"variant_{key}_mreads_s"] = v["mreads_per_s"]
-        if "frac" in v:
-            c[f"variant_{key}_hbm_frac"] = v["frac"]
+LINE_CAP = 8192      # the driver keeps ~9 KB of stdout tail: a longer last line is cut and cannot be parsed (BENCH_r04.json)
+LINE_TARGET = 4096
+
+
+def _short(text, n: int) -> str:
+    text = str(text)
+    return text if len(text) <= n else text[: n - 3] + "..."
+
+
+def compact_line(result: dict) -> dict:
+    """The driver's record: the headline scalars, `config` with <= 20 flat scalars after the four named ones, `roofline` and
+    `cpu_baseline` as flat objects of scalars.  Everything else lives in bench_detail.json.  Pure (tests/test_bench_line.py
+    feeds it the 22.7 KB line of round 4)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    line = {k: result.get(k) for k in keep}
+    c = result.get("config") or {}
+    chk = c.get("oracle_spot_check") or {}
+    cfg = {"workload": _short(c.get("workload_short") or c.get("workload", "?"), 240),
+           "reads_per_gpu": c.get("reads_per_gpu"), "parallelism": _short(c.get("parallelism", "?"), 80),
+           "oracle_mismatching_reads": c.get("oracle_mismatching_reads", chk.get("mismatching_reads"))}
+    extra = []   # (name, scalar), in order of importance; cut at 20
+    extra.append(("oracle_reads_checked", chk.get("reads_checked")))
+    for k in ("mean_minimisers_per_read", "classified_reads_rank0", "matches_rank0", "match_checksum_all_ranks"):
+        extra.append((k, c.get(k)))
+    km = c.get("kernel_ms") or {}
+    extra.append(("minimiser_ms", km.get("minimiser")))
+    extra.append(("count_select_ms", km.get("count_select")))
     for o in result.get("other_workloads") or []:
         w = o.get("workload", "?")
         if "error" in o:
-            c[f"{w}_error"] = o["error"][:120]
+            extra.append((f"{w}_error", _short(o["error"], 80)))
             continue
-        c[f"{w}_{o['unit'].replace('/s', '_s').lower()}"] = o["value"]
-        c[f"{w}_hbm_frac"] = o["roofline"]["frac"]
-        chk = o["config"].get("oracle_spot_check") or {}
-        if chk:
-            c[f"{w}_mismatching_reads"] = chk.get("mismatching_reads")
+        extra.append((f"{w}_{str(o.get('unit', 'Mreads/s')).replace('/s', '_s').lower()}", o.get("value")))
+    bad_extra = sum(int(((o.get("config") or {}).get("oracle_spot_check") or {}).get("mismatching_reads") or 0)
+                    for o in result.get("other_workloads") or [] if "error" not in o)
+    if result.get("other_workloads"):
+        extra.append(("other_workloads_mismatching_reads", bad_extra))
     e2e = result.get("e2e") or {}
     if "error" in e2e:
-        c["e2e_error"] = e2e["error"][:120]
+        extra.append(("e2e_error", _short(e2e["error"], 80)))
     for name, r in (e2e.get("inputs") or {}).items():
         if "error" in r:
-            c[f"e2e_{name}_error"] = r["error"][:120]
-            continue
-        unit = "mpairs_s" if name == "paired" else "mreads_s"
-        c[f"e2e_{name}_{unit}_median"] = r["rate"]["median"]
-        c[f"e2e_{name}_{unit}_min_max"] = f"{r['rate']['min']}-{r['rate']['max']} over {r['runs']} runs"
-        c[f"e2e_{name}_classified_frac"] = r["classified_frac"]
+            extra.append((f"e2e_{name}_error", _short(r["error"], 80)))
+        else:
+            extra.append((f"e2e_{name}_{'mpairs_s' if name == 'paired' else 'mreads_s'}_median", (r.get("rate") or {}).get("median")))
+    for k, v in [(k, v) for k, v in extra if v is not None][:20]:
+        cfg[k] = v
+    line["config"] = cfg
+
+    r = result.get("roofline") or {}
+    roof = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_fetched", "algo_over_peak", "traffic",
+                                  "achieved_fetched", "avg_launch_ms", "avg_launch_ms_every_row", "launches_per_step",
+                                  "algo_bytes_per_launch", "fetched_bytes_per_launch")}
+    roof["frac_measured_on"] = _short(r.get("frac_measured_on", ""), 120)
+    roof["note"] = _short(r.get("note", ""), 200)
+    if r.get("traffic") is not None and r.get("fetched_bytes_per_launch"):
+        roof["traffic_over_fetched"] = round(r["traffic"] / r["fetched_bytes_per_launch"], 4)
+    line["roofline"] = roof
+
+    cb = result.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": _short(cb.get("sample", ""), 300)}
+        for k in ("port_value", "agrees_with_ours"):
+            if k in cb:
+                line["cpu_baseline"][k] = cb[k]
+    else:
+        line["cpu_baseline"] = None
+    line["detail"] = "bench_detail.json"
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_TARGET:      # never expected; shed prose before scalars
+        line["roofline"].pop("note", None)
+        line["roofline"].pop("frac_measured_on", None)
+        if line["cpu_baseline"]:
+            line["cpu_baseline"]["sample"] = _short(line["cpu_baseline"]["sample"], 120)
+        line["config"]["workload"] = _short(line["config"]["workload"], 120)
+    return line
+
+
+def emit(result: dict, write_files: bool = True) -> None:
+    """detail file + an earlier stdout line, then the compact record as the LAST stdout line"""
+    detail = json.dumps(result)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if write_files else ():
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+            except OSError as e:
+                log("bench.py: could not write", os.path.join(d, "bench_detail.json"), repr(e))
+    sys.stdout.write("bench_detail: " + detail + "\n")
+    text = json.dumps(compact_line(result), separators=(",", ":"))
+    assert len(text) < LINE_CAP, f"driver line is {len(text)} bytes"
+    sys.stdout.write(text + "\n")
+    sys.stdout.flush()
 
 
 def slim(name: str, r: dict, wall: float) -> dict:
@@ -178,7 +252,13 @@ def main() -> int:
     ap.add_argument("--e2e-budget", type=int, default=200, help="seconds the end-to-end leg may take")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s)")
     ap.add_argument("--check", type=int, default=2000, help="reads re-checked against the oracle (rank 0)")
+    ap.add_argument("--emit-from", default="", help="dry run without a GPU: read a full result (a bench_detail.json) and print it the "
+                                                     "way a real run does (tests/test_bench_line.py)")
     args = ap.parse_args()
+    if args.emit_from:
+        with open(args.emit_from) as f:
+            emit(json.loads(f.read()), write_files=False)
+        return 0
 
     import torch
 
@@ -301,19 +381,29 @@ def main() -> int:
             barrier()
             return time.perf_counter() - t_begin, cms, mms, tms, st.timings()
 
-        def roofline_of(tm, cms):
+        def rates(tm, cms):
+            """one measurement of the count+select kernel(s): hipEvent time per step, row bytes requested, algorithmic bytes"""
             avg = float(np.mean(cms))
             nl = max(1, tm["n_count_launches"])
-            fetched = tm["fetched_bytes"] / (avg * 1e-3) / 1e9
-            return {
-                "achieved": round(fetched, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fetched / HBM_PEAK_GBS, 4),
-                "effective_gbs": round(tm["algo_bytes"] / (avg * 1e-3) / 1e9, 1),
-                "avg_launch_ms": round(avg / nl, 4), "launches_per_step": int(nl),
-                "fetched_bytes_per_launch": int(tm["fetched_bytes"] // nl), "algo_bytes_per_launch": int(tm["algo_bytes"] // nl),
-            }
+            return {"ms": avg, "launches": int(nl), "fetched_bytes": int(tm["fetched_bytes"]), "algo_bytes": int(tm["algo_bytes"]),
+                    "fetched_gbs": tm["fetched_bytes"] / (avg * 1e-3) / 1e9, "algo_gbs": tm["algo_bytes"] / (avg * 1e-3) / 1e9}
+
+        def variant_of(rt, tms):
+            return {"achieved": round(rt["fetched_gbs"], 1), "frac": round(rt["fetched_gbs"] / HBM_PEAK_GBS, 4),
+                    "effective_gbs": round(rt["algo_gbs"], 1), "avg_launch_ms": round(rt["ms"] / rt["launches"], 4),
+                    "ms_per_step": round(float(np.mean(tms)), 3), "mreads_per_s": round(n_reads / float(np.mean(tms)) / 1e3, 2)}
 
         elapsed, count_ms, mini_ms, total_ms, tm = timed(args.rel_cutoff, steps, warmup)
         elapsed = gdist.max_over_ranks(elapsed, device=red_dev)       # slowest rank defines the step time
+        ee = rates(tm, count_ms)                                      # the product kernel: exact early exit on
+        # SURVEY 8(d)'s fraction belongs to the instantiation that fetches every algorithmic row: the same resident batch
+        # with the early exit ablated (3 steps, outside `value`).  Split-bin and HIBF kernels have no early exit.
+        full, full_tms = ee, total_ms
+        if kind in ("flat", "slice") and spec.get("bins_per_target", 1) == 1:
+            with ganon_amd.ablate("early_exit"):
+                _, cms0, _, full_tms, tm0 = timed(args.rel_cutoff, 3, 1)
+            full = rates(tm0, cms0)
+            step(args.rel_cutoff)                                     # the product result is what the checks below fetch
         if kind == "slice":
             total_reads = n_reads                                      # every rank classifies the same reads against its columns
         else:
@@ -329,12 +419,20 @@ def main() -> int:
         ms_per_step = elapsed * 1e3 / max(1, steps)
         value = total_reads / (elapsed / max(1, steps)) / 1e6  # Mreads/s (M pairs/s for paired workloads), whole job
 
-        roof = {"bound": "hbm", "kernel": kernel_name}
-        roof.update(roofline_of(tm, count_ms))
-        roof["note"] = ("achieved/frac = HBM row bytes the kernel requested (gn_timings.fetched_bytes: algorithmic bytes minus the rows the "
-                        "exact early exit skips; the PMC FETCH_SIZE pass in `traffic` agrees within 3 %) / hipEvent kernel time / peak; "
-                        "effective_gbs = algorithmic bytes n*h*W*8 (SURVEY 8d) / the same time, which may exceed the peak because skipped "
-                        "rows cost nothing")
+        roof = {"bound": "hbm", "kernel": kernel_name,
+                "achieved": round(full["algo_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(full["algo_gbs"] / HBM_PEAK_GBS, 4),
+                "frac_fetched": round(ee["fetched_gbs"] / HBM_PEAK_GBS, 4),
+                "algo_over_peak": round(ee["algo_gbs"] / HBM_PEAK_GBS, 4),
+                "achieved_fetched": round(ee["fetched_gbs"], 1),
+                "avg_launch_ms": round(ee["ms"] / ee["launches"], 4),
+                "avg_launch_ms_every_row": round(full["ms"] / full["launches"], 4),
+                "launches_per_step": ee["launches"],
+                "algo_bytes_per_launch": ee["algo_bytes"] // ee["launches"],
+                "fetched_bytes_per_launch": ee["fetched_bytes"] // ee["launches"],
+                "frac_measured_on": ("early exit ablated (every algorithmic row fetched), 3 steps on the same resident batch" if full is not ee
+                                     else "the product kernel (it has no early exit)"),
+                "note": "algo_over_peak may exceed 1: rows the exact early exit skips are never fetched"}
         if kind == "hibf":
             # The roofline per tree level: a level's rows are gathered from the IBFs at that depth, and whether those sit in
             # the 256 MiB Infinity Cache or in HBM decides the roof.  A row narrower than a 128-byte line still moves the line
@@ -352,9 +450,8 @@ def main() -> int:
                                "gather_roof_gbs": roof_gbs, "frac_of_gather_roof": round(line / sec / 1e9 / roof_gbs, 4),
                                "line_frac_of_hbm_peak": round(line / sec / 1e9 / HBM_PEAK_GBS, 4)})
             roof["levels"] = levels
-            roof["note"] += ("; HIBF rows are 32 B (256-bin IBFs): `levels` gives, per tree level of the last step, the rate in 128-byte lines "
-                             "against the measured gather roof for a table of that size (profiles/r03_calib_gather.json) -- level 0's tables "
-                             "fit the Infinity Cache unless the workload says otherwise, so HBM is not its roof")
+            roof["note"] = ("HIBF rows are narrower than a 128-byte line: `levels` (detail file) gives per tree level the rate in lines against "
+                            "the measured gather roof for a table of that size (profiles/r03_calib_gather.json)")
         roof["traffic"] = None
 
         result = {
@@ -371,9 +468,12 @@ def main() -> int:
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"{name} (BASELINE.json configs[{spec['config']}]): {desc}, k={wl.k} w={wl.w}, {n_reads} synthetic "
-                            f"{unit_name} per GPU (50% cut from {4096} planted genomes), rel_cutoff={args.rel_cutoff}, seeded "
-                            f"{'Bernoulli(3/8)' if spec.get('skew') else 'Bernoulli(0.5)'} fill generated on the device, seed 42",
+                "workload": (f"{name} (BASELINE.json configs[{spec['config']}]): {wl.filter_bytes / 2**30:.2f} GiB "
+                             f"{'HIBF, ' + str(spec.get('user_bins')) + ' user bins' if kind == 'hibf' else ('column slice of a flat IBF, ' if kind == 'slice' else 'flat IBF, ') + str(spec.get('bins')) + ' technical bins'}"
+                             f", h={spec['h']}, k={wl.k} w={wl.w}, {n_reads} synthetic {unit_name} per GPU, rel_cutoff={args.rel_cutoff}"),
+                "workload_detail": f"{desc}, k={wl.k} w={wl.w}, {n_reads} synthetic "
+                                   f"{unit_name} per GPU (50% cut from {4096} planted genomes), rel_cutoff={args.rel_cutoff}, seeded "
+                                   f"{'Bernoulli(3/8)' if spec.get('skew') else 'Bernoulli(0.5)'} fill generated on the device, seed 42",
                 "reads_per_gpu": n_reads,
                 "parallelism": (f"bin-range partitioned x{world} of {spec.get('slices')} slices" if kind == "slice"
                                 else f"read-sharded x{world}, filter replicated"),
@@ -407,23 +507,17 @@ def main() -> int:
         if headline and not args.no_variants and part is None and kind == "flat":
             variants = {}
             bpt = spec.get("bins_per_target", 1)
-            if bpt == 1:  # (the split-bin kernel has no early exit)
-                os.environ["GANON_HIP_NO_EARLY_EXIT"] = "1"   # read by the library at every launch
-                _, cms, _, tms, tmv = timed(args.rel_cutoff, 3, 1)
-                del os.environ["GANON_HIP_NO_EARLY_EXIT"]
-                variants["no_early_exit"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
-                                                 mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2))
+            if bpt == 1:  # (the split-bin kernel has no early exit); measured above for the roofline
+                variants["no_early_exit"] = variant_of(full, full_tms)
             _, cms, _, tms, tmv = timed(0.2, 3, 1)        # ganon-classify's own default (Config.hpp:32): T ~ 4, nothing to exit from
-            variants["rel_cutoff_0.2"] = dict(roofline_of(tmv, cms), ms_per_step=round(float(np.mean(tms)), 3),
-                                              mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), matches=int(tmv["n_matches"]))
+            variants["rel_cutoff_0.2"] = dict(variant_of(rates(tmv, cms), tms), matches=int(tmv["n_matches"]))
             # ... and with the binary's low cutoff under the filter rules `ganon classify` passes by default (--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5,
             # /root/reference/src/ganon/config.py), the pre-pass of filter_matches running on the device (gn_stream_set_postfilter);
             # per-target fpr 0.5^h = what the Bernoulli(0.5) bits are
             st.set_postfilter(0.1, 1e-5, np.full(wl.bins // bpt, 1.0 - (1.0 - 0.5 ** spec["h"]) ** bpt, dtype=np.float64))
             if os.environ.get("GANON_BENCH_AB_PREDROP"):  # A/B: every match written, then judged
-                os.environ["GANON_HIP_NO_PREDROP"] = "1"
-                _, cms, _, tms, tmv = timed(0.2, 3, 1)
-                del os.environ["GANON_HIP_NO_PREDROP"]
+                with ganon_amd.ablate("predrop"):
+                    _, cms, _, tms, tmv = timed(0.2, 3, 1)
                 _, d_fil, d_fpr = st.fetch_postfilter()
                 variants["wrapper_defaults_every_match_written"] = dict(ms_per_step=round(float(np.mean(tms)), 3),
                                                                         count_select_ms=round(float(np.mean(cms)), 3), dropped_rel_filter=d_fil,
@@ -449,10 +543,8 @@ def main() -> int:
                 variants["rel_cutoff_0.2"] = dict(ms_per_step=round(float(np.mean(tms)), 3), matches=int(tmv["n_matches"]))
             st.set_postfilter(0.1, 1e-5, np.full(spec["user_bins"], 0.05, dtype=np.float64))
             for tag, env in ((("every_pair_sorted", "1"),) if small else ()) + (("device_filter_matches", None),):
-                if env:
-                    os.environ["GANON_HIP_NO_PREDROP"] = env
-                _, cms, _, tms, tmv = timed(0.2, 3 if small else 2, 1)
-                os.environ.pop("GANON_HIP_NO_PREDROP", None)
+                with ganon_amd.ablate("predrop" if env else ""):
+                    _, cms, _, tms, tmv = timed(0.2, 3 if small else 2, 1)
                 _, d_fil, d_fpr = st.fetch_postfilter()
                 variants["low_cutoff_" + tag] = dict(thresholds="--rel-cutoff 0.2 --rel-filter 0.1 --fpr-query 1e-5", ms_per_step=round(float(np.mean(tms)), 3),
                                                      mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2), dropped_rel_filter=d_fil,
@@ -524,7 +616,6 @@ def main() -> int:
         result["other_workloads"] = [run_extra(w, args.extra_timeout) for w in EXTRA_WORKLOADS]
         if not args.no_e2e:
             result["e2e"] = run_e2e(args.e2e_budget)
-        summarise(result)
     elif default_run and world > 1:
         # the configs BASELINE.json quotes its scaling target on, with the real world size (every rank takes part).
         # They run behind a watchdog: if a rank fails inside a collective the others would wait for ever, and the headline
@@ -537,8 +628,7 @@ def main() -> int:
             log(f"[rank {rank}] bench.py: the in-job extras did not finish within {args.extra_timeout} s -- leaving without them")
             if rank == 0:
                 result["other_workloads"] = others + [{"workload": "(in-job extras)", "error": f"timeout after {args.extra_timeout}s"}]
-                sys.stdout.write(json.dumps(result) + "\n")
-                sys.stdout.flush()
+                emit(result)
             os._exit(0)
 
         watchdog = threading.Timer(args.extra_timeout, give_up)
@@ -569,13 +659,13 @@ def main() -> int:
         out_of_step = any("error" in o for o in result.get("other_workloads", [])) if world > 1 else False
         if out_of_step:   # (an extra failed on some rank: a barrier could wait for ever)
             if rank == 0:
-                print(json.dumps(result), flush=True)
+                emit(result)
             sys.stdout.flush()
             os._exit(0)
         gdist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     return 0
 
 

@@ -32,18 +32,96 @@ extern "C" const char* gn_last_error(void)
     return g_err;
 }
 
+// ---- switches: $GANON_HIP_ABLATE, parsed once at load; gn_ablate() for in-process cross-checks (gn_internal.h) ----------------
+static GnSwitches g_sw;
+
+static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_t bad_len)
+{
+    GnSwitches sw;
+    struct
+    {
+        const char* name;
+        bool GnSwitches::* flag;
+    } static const flags[] = {{"early_exit", &GnSwitches::early_exit},       {"cand_select", &GnSwitches::cand_select},
+                              {"csr_identity", &GnSwitches::csr_identity},   {"uniform_select", &GnSwitches::uniform_select},
+                              {"run_select", &GnSwitches::run_select},       {"max_first", &GnSwitches::max_first},
+                              {"const_nb", &GnSwitches::const_nb},           {"split_kernel", &GnSwitches::split_kernel},
+                              {"predrop", &GnSwitches::predrop},             {"deferred_grids", &GnSwitches::deferred_grids},
+                              {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
+                              {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent},
+                              {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
+                              {"debug", &GnSwitches::debug}};
+    for (const char* p = list ? list : ""; *p;)
+    {
+        const char* e = strchr(p, ',');
+        size_t      n = e ? (size_t)(e - p) : strlen(p);
+        while (n && (*p == ' ' || *p == '\t'))
+            ++p, --n;
+        while (n && (p[n - 1] == ' ' || p[n - 1] == '\t'))
+            --n;
+        bool known = n == 0;
+        for (const auto& f : flags)
+            if (!known && strlen(f.name) == n && !strncmp(p, f.name, n))
+                sw.*(f.flag) = true, known = true;
+        if (!known && n > 6 && !strncmp(p, "chunk=", 6))
+            sw.chunk = (uint32_t)strtoul(p + 6, nullptr, 10), known = true;
+        if (!known && n > 16 && !strncmp(p, "hibf_pair_limit=", 16))
+            sw.hibf_pair_limit = std::max<uint64_t>(64, strtoull(p + 16, nullptr, 10)), known = true;
+        if (!known && n > 5 && !strncmp(p, "sync=", 5))
+        {
+            const char* m = p + 5;
+            const size_t l = n - 5;
+            sw.sync_mode = (l == 4 && !strncmp(m, "spin", 4)) ? 1 : (l == 5 && !strncmp(m, "yield", 5)) ? 2 : (l == 5 && !strncmp(m, "block", 5)) ? 3 : -1;
+            known = sw.sync_mode > 0;
+        }
+        if (!known)
+        {
+            snprintf(bad, bad_len, "%.*s", (int)std::min<size_t>(n, 60), p);
+            return GN_EINVAL;
+        }
+        p = e ? e + 1 : p + strlen(p);
+    }
+    *out = sw;
+    return GN_OK;
+}
+
+namespace
+{
+struct GnSwitchesInit
+{
+    GnSwitchesInit()
+    {
+        char bad[64];
+        if (gn_parse_switches(getenv("GANON_HIP_ABLATE"), &g_sw, bad, sizeof(bad)) != GN_OK)
+            fprintf(stderr, "libganon_hip: $GANON_HIP_ABLATE names an unknown switch '%s' -- the whole list is ignored\n", bad);
+    }
+} g_sw_init;
+} // namespace
+
+const GnSwitches& gn_sw()
+{
+    return g_sw;
+}
+
+extern "C" int gn_ablate(const char* list)
+{
+    char bad[64];
+    if (gn_parse_switches(list, &g_sw, bad, sizeof(bad)) != GN_OK)
+        return gn_fail(GN_EINVAL, "gn_ablate: unknown switch '%s'", bad);
+    return GN_OK;
+}
+
 // How host threads wait for the device.  HIP's default spins: a worker thread that waits for its batch burns a core, and the
-// host pipeline (parsers, post pool) has a use for that core ($GANON_HIP_SYNC=spin|yield|block; set before anything touches a device).
+// host pipeline (parsers, post pool) has a use for that core (switch sync=spin|yield|block; read before anything touches a device).
 static void gn_apply_sync_mode(int n_devices)
 {
     static bool done = false;
     if (done)
         return;
     done = true;
-    const char* m = getenv("GANON_HIP_SYNC");
-    if (!m || !*m)
+    if (gn_sw().sync_mode <= 0)
         return;
-    const unsigned flag = !strcmp(m, "block") ? hipDeviceScheduleBlockingSync : !strcmp(m, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleSpin;
+    const unsigned flag = gn_sw().sync_mode == 3 ? hipDeviceScheduleBlockingSync : gn_sw().sync_mode == 2 ? hipDeviceScheduleYield : hipDeviceScheduleSpin;
     for (int d = 0; d < n_devices; ++d)
         if (hipSetDevice(d) == hipSuccess)
             (void)hipSetDeviceFlags(flag);
@@ -225,6 +303,9 @@ extern "C" int gn_filter_upload_ibf(int device, const gn_ibf_desc* ibf, const ui
         f->csr_identity = off[n_targets] == ibf->bins;
         for (size_t x = 0; x < bins.size() && f->csr_identity; ++x)
             f->csr_identity = bins[x] == (uint32_t)x;
+        f->run_ok = f->csr_identity && n_targets < (1u << 28);
+        for (uint32_t t = 0; t < n_targets && f->run_ok; ++t)
+            f->run_ok = off[t + 1] > off[t];
         f->uniform_nb = 0;
         if (f->csr_identity && n_targets)
         {
@@ -804,7 +885,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
     // With one chunk per batch -- the default: chunking gained nothing, see gn_stream_classify -- a second stream per batch context
     // only costs: the runtime maps all streams of a process onto a few hardware queues (4 by default), and streams that share a
     // queue wait for each other's copies and kernels.  One stream per context keeps a worker's batches independent of the others'.
-    if (getenv("GANON_HIP_CHUNK"))
+    if (gn_sw().chunk)
         ok(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
     else
         s->st2 = s->st;
@@ -1042,7 +1123,7 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.tgt_lds    = f->d_tgt_lds;
     p.tgt_rec    = f->d_tgt_rec;
     p.bin_tgt    = f->d_bin_tgt;
-    p.bin_nb2    = getenv("GANON_HIP_NO_CAND_SELECT") ? nullptr : f->d_bin_nb2;
+    p.bin_nb2    = gn_sw().cand_select ? nullptr : f->d_bin_nb2;
     p.nbtab_off  = (uint32_t)f->geom.nbtab_off;
     p.candcnt_off = (uint32_t)f->geom.candcnt_off;
     p.big_list   = f->d_big_list;
@@ -1069,22 +1150,22 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     // persistent grid = a whole number of resident rounds: 8-byte-lane variant holds 4 blocks per CU, 16-byte one 3
     p.max_blocks_fast = (uint32_t)f->n_cu * (f->geom.lw == 1 ? 8u : 6u);
     p.nt_loads = 0u;
-    p.early_exit = getenv("GANON_HIP_NO_EARLY_EXIT") ? 0u : 1u; // (the switch: bench.py's variant and the parity tests of the exit)
+    p.early_exit = gn_sw().early_exit ? 0u : 1u; // (bench.py's every-row measurement and the parity tests of the exit)
     p.skip_ctr   = s->d_ctr + 7;
     if (lo == 0) // (a re-run after a match-buffer regrow starts the tally again)
         GN_HIP(hipMemsetAsync(s->d_ctr + 7, 0, sizeof(unsigned long long), s->st));
     p.sl_nbr = f->d_sl_nbr;
-    p.csr_identity = f->csr_identity && !getenv("GANON_HIP_NO_CSR_IDENTITY") ? 1u : 0u;
-    p.uniform_nb   = p.csr_identity && !getenv("GANON_HIP_NO_UNIFORM_SELECT") ? f->uniform_nb : 0u;
-    p.run_select   = p.csr_identity && !p.uniform_nb && !getenv("GANON_HIP_NO_RUN_SELECT") ? 1u : 0u;
-    p.max_first    = getenv("GANON_HIP_NO_MAX_FIRST") ? 0u : 1u;
-    p.const_nb     = p.uniform_nb && !getenv("GANON_HIP_NO_CONST_NB") ? p.uniform_nb : (p.run_select ? 4u : 0u);
-    const bool split = !f->identity && f->d_sl_nbr != nullptr && !getenv("GANON_HIP_NO_SPLIT_KERNEL");
-    const bool fast = f->identity && !getenv("GANON_HIP_NO_FAST");
+    p.csr_identity = f->csr_identity && !gn_sw().csr_identity ? 1u : 0u;
+    p.uniform_nb   = p.csr_identity && !gn_sw().uniform_select ? f->uniform_nb : 0u;
+    p.run_select   = p.csr_identity && f->run_ok && !p.uniform_nb && !gn_sw().run_select ? 1u : 0u;
+    p.max_first    = gn_sw().max_first ? 0u : 1u;
+    p.const_nb     = p.uniform_nb && !gn_sw().const_nb ? p.uniform_nb : (p.run_select ? 4u : 0u);
+    const bool split = !f->identity && f->d_sl_nbr != nullptr && !gn_sw().split_kernel;
+    const bool fast = f->identity;
     // with a filter_matches pre-pass on the stream the fast and the split-bin kernel do not write matches the --rel-filter rule is bound to
     // drop (not for a merging level: there the minimum follows the entries that got in, which only the merge knows)
     const bool predrop = (fast || split) && s->pf_on && !s->pf_merge && s->d_pf_segmin && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
-                         (uint64_t)hi * f->geom.wpr <= s->pf_segmin_cap && !getenv("GANON_HIP_NO_PREDROP");
+                         (uint64_t)hi * f->geom.wpr <= s->pf_segmin_cap && !gn_sw().predrop;
     if (lo == 0)
         s->pf_predrop = predrop;
     if (predrop)
@@ -1120,7 +1201,7 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
         p.work_list  = s->d_deferred;
         p.work_count = s->d_ctr + 4;
     }
-    if ((fast || split) && s->prev_count_deferred != ~0ull && lo == 0 && hi == s->n_reads && !getenv("GANON_HIP_FULL_DEFERRED_GRIDS"))
+    if ((fast || split) && s->prev_count_deferred != ~0ull && lo == 0 && hi == s->n_reads && !gn_sw().deferred_grids)
         // the generic kernel only takes what the fast / split kernel deferred: a grid for twice the last batch's list (one block per read)
         p.max_blocks = (uint32_t)std::min<uint64_t>(p.max_blocks, std::max<uint64_t>((uint64_t)f->n_cu, s->prev_count_deferred * 2));
     GN_HIP(gn_launch_count(p, f->geom, f->ibf.h, s->st));
@@ -1201,20 +1282,18 @@ static int gn_run_minimisers_range(gn_stream* s, uint32_t lo, uint32_t hi, hipSt
     mp.n_hashes     = s->d_nh;
     mp.status       = s->d_status;
     mp.total_hashes = s->d_ctr + 8; // 64 shards
-    mp.force_generic = getenv("GANON_HIP_MINIMISER_GENERIC") ? 1u : 0u;
     mp.work_hint     = ~0u;
-    if (w - k + 1 <= 65 && !mp.force_generic && !getenv("GANON_HIP_NO_LPR"))
+    if (w - k + 1 <= 65)
     {
         // short reads: lane-per-read kernel; longer ones are deferred to the wave-per-read kernel below
         GN_HIP(hipMemsetAsync(s->d_ctr + 5, 0, sizeof(unsigned long long), st));
         mp.lpr_max_len = 640;
-        mp.force_lds   = getenv("GANON_HIP_MINIMISER_LDS") ? 1u : 0u; // A/B: the LDS-window variant for every width
         mp.defer_list  = s->d_mdeferred;
         mp.defer_count = s->d_ctr + 5;
         GN_HIP(gn_launch_minimiser_lpr(mp, st));
         mp.work_list  = s->d_mdeferred;
         mp.work_count = s->d_ctr + 5;
-        if (s->prev_min_deferred != ~0ull && lo == 0 && hi == s->n_reads && !getenv("GANON_HIP_FULL_DEFERRED_GRIDS"))
+        if (s->prev_min_deferred != ~0ull && lo == 0 && hi == s->n_reads && !gn_sw().deferred_grids)
             mp.work_hint = (uint32_t)std::min<uint64_t>(s->prev_min_deferred * 2, 0x7FFFFFFFull); // (twice what the last batch deferred)
     }
     GN_HIP(gn_launch_minimiser(mp, f->n_cu, st));
@@ -1265,7 +1344,7 @@ extern "C" int gn_stream_classify(gn_stream* s, uint32_t k, uint32_t w, double r
     s->rel_cutoff = rel_cutoff;
     const uint32_t n = s->n_reads;
 
-    uint32_t chunk = getenv("GANON_HIP_CHUNK") ? (uint32_t)atoi(getenv("GANON_HIP_CHUNK")) : 0u;
+    uint32_t chunk = gn_sw().chunk;
     if (chunk == 0 || f->is_hibf)
         chunk = n ? n : 1;
     const uint32_t n_chunks = n ? (n + chunk - 1) / chunk : 1;
@@ -1405,7 +1484,7 @@ static int gn_finish(gn_stream* s)
         if (stale)
             GN_HIP(hipMemcpy(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         const uint64_t need = s->h_ctr[0];
-        if (getenv("GANON_HIP_DEBUG"))
+        if (gn_sw().debug)
             fprintf(stderr, "[gn_finish] attempt %d need %llu cap %llu nh %llu\n", attempt, (unsigned long long)need,
                     (unsigned long long)s->match_cap, (unsigned long long)s->h_ctr[1]);
         if (need <= s->match_cap)
@@ -1645,7 +1724,11 @@ extern "C" int gn_stream_dense_counts(gn_stream* s, uint32_t read_begin, uint32_
     const size_t nel = (size_t)(read_end - read_begin) * f->ibf.B;
     uint16_t*    dd  = nullptr;
     GN_HIP(gn_dmalloc(&dd, nel));
-    hipMemsetAsync(dd, 0, nel * 2, s->st); // (skipped reads write nothing)
+    if (hipMemsetAsync(dd, 0, nel * 2, s->st) != hipSuccess) // (skipped reads write nothing)
+    {
+        (void)hipFree(dd);
+        return gn_fail(GN_ENODEV, "gn_stream_dense_counts: clearing the count matrix failed");
+    }
     // re-run the count kernel with the dense tap on (matches of this run are discarded)
     unsigned long long saved[GN_NCTR];
     memcpy(saved, s->h_ctr, sizeof(saved));

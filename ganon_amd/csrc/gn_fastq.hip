@@ -327,7 +327,7 @@ static int gn_upload_texts(gn_stream* s, const uint8_t* text, uint64_t n_bytes, 
     int rc = gn_fastq_prepare(s, pair);
     if (rc)
         return rc;
-    static const bool probe = getenv("GANON_HIP_CALL_TIMING") != nullptr;
+    const bool        probe = gn_sw().debug;
     auto              now   = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double      p0    = probe ? now() : 0;
     GN_HIP(hipStreamSynchronize(s->st)); // previous batch must be done before its inputs are overwritten

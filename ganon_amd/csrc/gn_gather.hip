@@ -303,7 +303,7 @@ extern "C" int gn_gather_run(gn_gather* g, gn_stream* const* streams, uint32_t n
     if (!g || !streams || n_streams != g->n_parts)
         return gn_fail(GN_EINVAL, "gn_gather_run: the gather was created for %u parts", g ? g->n_parts : 0u);
     g->ran = false;
-    const bool force_copy = getenv("GANON_HIP_GATHER_COPY") != nullptr; // tests: same-device parts take the peer-copy path too
+    const bool force_copy = gn_sw().gather_copy; // tests: same-device parts take the peer-copy path too
     // every part's batch is complete (a match buffer that overflowed is grown and the part re-run first)
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_streams; ++i)

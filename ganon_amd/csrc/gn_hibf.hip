@@ -1551,12 +1551,12 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     unsigned long long* d_out_base = s->d_hctr + 4 * NL;
     const uint32_t h      = f->ibfs[0].h;
     // tests / A-B: skip the packed kernel (the per-item register kernel takes whole levels), or both (LDS kernel only)
-    const bool     no_reg  = getenv("GANON_HIP_HIBF_NO_REG") != nullptr;
-    const bool     no_pack = no_reg || getenv("GANON_HIP_HIBF_NO_PACK") != nullptr;
+    const bool     no_reg  = gn_sw().hibf_reg;
+    const bool     no_pack = no_reg || gn_sw().hibf_pack;
     const uint32_t reg_bpc = 0u; // workgroups per CU of the register kernels: what the occupancy query says
     // with a filter_matches pre-pass on the stream, what it is bound to drop does not reach the sort
     const bool may_predrop = s->pf_on && !s->pf_merge && s->d_pf_segmin && s->d_pf_rmax && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
-                             (uint64_t)n + 1 <= s->pf_segmin_cap && !getenv("GANON_HIP_NO_PREDROP");
+                             (uint64_t)n + 1 <= s->pf_segmin_cap && !gn_sw().predrop;
     s->pf_predrop = false;
     if (may_predrop)
     {
@@ -1565,14 +1565,14 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         GN_HIP(hipMemsetAsync(s->d_pf_pre, 0, 2 * sizeof(unsigned long long), st)); // [0] pairs left out [1] output cursor
     }
     // pairs one range may have: the sort's int, and what the device could hold if the buffers were grown for it (two pair
-    // buffers, two match buffers, the sort's scratch: ~64 bytes a pair) -- $GANON_HIP_HIBF_PAIR_LIMIT for tests
+    // buffers, two match buffers, the sort's scratch: ~64 bytes a pair) -- switch hibf_pair_limit=N for tests
     uint64_t pair_limit = 0x7FFFFFF0ull;
     {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess)
             pair_limit = std::min<uint64_t>(pair_limit, std::max<uint64_t>(1u << 20, ((uint64_t)fr + s->match_cap * 64ull) / 80ull));
-        if (getenv("GANON_HIP_HIBF_PAIR_LIMIT"))
-            pair_limit = std::max<uint64_t>(64, strtoull(getenv("GANON_HIP_HIBF_PAIR_LIMIT"), nullptr, 10));
+        if (gn_sw().hibf_pair_limit)
+            pair_limit = gn_sw().hibf_pair_limit;
     }
 
     // the levels of reads [lo, lo + cnt): queue lengths and the match cursor come back to the host (one sync)
@@ -1630,7 +1630,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                     default: gn_hibf_launch_pack<5>(p, level0, (uint32_t)f->n_cu, reg_bpc, st); break;
                 }
             };
-            const bool one_pass = getenv("GANON_HIP_HIBF_ONE_PACK") != nullptr; // tests: the level's most common width only
+            const bool one_pass = gn_sw().hibf_one_pack; // tests: the level's most common width only
             const std::vector<uint32_t>& gps = lvl < f->level_gps.size() ? f->level_gps[lvl] : std::vector<uint32_t>();
             if (!no_pack && !level0 && gps.size() > 1 && !one_pass)
             {

@@ -20,6 +20,40 @@
 #define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
                    // [6] exact match total [8..71] total-hashes shards
 
+// ---- switches ---------------------------------------------------------------------------------
+// The ONE place the library reads its environment: $GANON_HIP_ABLATE, a comma list of the names below, parsed once when
+// the library is loaded into this struct (gn_capi.hip).  Everything is off by default = the product path.  Tests and
+// bench.py cross-check a fast path against the path it replaces by switching it off in-process with gn_ablate()
+// (include/ganon_hip.h); nothing else changes the struct, and no launch path calls getenv().
+struct GnSwitches
+{
+    // count + select (flat IBF)
+    bool early_exit = false;      // fast kernel: fetch every row (no exact early exit)
+    bool cand_select = false;     // generic kernel: scan every target instead of the candidate-driven select
+    bool csr_identity = false;    // split-bin kernel family: treat an ordered CSR map as a general one
+    bool uniform_select = false;  // ... no packed select for equal bins-per-target
+    bool run_select = false;      // ... no run-sum select for ordered unequal targets
+    bool max_first = false;       // ... per-read maximum computed in the second pass
+    bool const_nb = false;        // ... bins-per-target read from the table, not from the template constant
+    bool split_kernel = false;    // split-bin maps go to the generic kernel
+    bool predrop = false;         // with a filter_matches pre-pass: write every match, judge afterwards
+    bool deferred_grids = false;  // grids of the deferred-list kernels sized for the whole batch, not from the last batch's list
+    // HIBF
+    bool hibf_reg = false;        // no per-item register kernel (LDS-counter level kernel instead)
+    bool hibf_pack = false;       // no packed-items kernel either
+    bool hibf_one_pack = false;   // only the level's most common width takes the packed kernel (no sorting by width)
+    bool hibf_persistent = false; // one launch per width class instead of one persistent launch per level
+    uint64_t hibf_pair_limit = 0; // >0: (read, user bin) pairs per round of a batch (tests make a batch take several rounds)
+    // multi-device
+    bool gather_copy = false;     // same-device parts take the peer-copy path too
+    bool joint_apart = false;     // joint pre-pass: every stream is treated as a device of its own
+    // batch pipeline
+    uint32_t chunk = 0;           // >0: reads per pipeline chunk (minimiser || count on two HIP streams)
+    int      sync_mode = 0;       // 0 runtime default, 1 spin, 2 yield, 3 block: how host threads wait for the device
+    bool     debug = false;       // chatter on stderr
+};
+const GnSwitches& gn_sw();
+
 // ---- minimiser kernel -----------------------------------------------------------------------
 struct GnMinimiserParams
 {
@@ -34,10 +68,8 @@ struct GnMinimiserParams
     uint32_t*           n_hashes;  // per read
     uint8_t*            status;    // per read GN_READ_*
     unsigned long long* total_hashes; // 64 shards (indexed by blockIdx & 63): sum of n over GN_READ_OK reads
-    uint32_t            force_generic; // tests: take the byte-staged path even for narrow windows
     // lane-per-read kernel: reads longer than lpr_max_len go to defer_list; wave-per-read kernel: work_list input
     uint32_t                  lpr_max_len;
-    uint32_t                  force_lds; // tests: lane-per-read kernel with the LDS tables even for templated widths
     uint32_t*                 defer_list;
     unsigned long long*       defer_count;
     const uint32_t*           work_list;  // nullptr = every read
@@ -220,6 +252,8 @@ struct gn_filter
     bool            identity   = false;
     uint32_t        uniform_nb = 0;       // see GnCountParams::uniform_nb
     bool            csr_identity = false; // bins of the targets, target after target, are 0, 1, 2, ... (GnCountParams::csr_identity)
+    bool            run_ok       = false; // csr_identity, every target id owns at least one bin, n_targets < 2^28: the run select may number
+                                          // targets by counting target ends (an id without bins would shift every later id)
     GnCountGeometry geom{};
     // hibf
     std::vector<GnIbfHost> ibfs;

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void gn_minimiser_kernel(GnMinimiserParams p)
     const int      lane      = threadIdx.x & (GN_WAVE - 1);
     const int      wave      = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform -> SGPRs
     const uint32_t K         = p.w - p.k + 1;
-    const bool     fastp     = K <= 65 && !p.force_generic; // two-chunk LDS ring + bit-plane k-mers
+    const bool     fastp     = K <= 65; // two-chunk LDS ring + bit-plane k-mers
     const uint32_t vv_bytes  = fastp ? 128u * 8u : (GN_WAVE + K) * 8;
     const uint32_t rk_bytes  = fastp ? 0u : ((GN_WAVE + p.w + 15) & ~15u);
     uint8_t*       base      = gn_smem + (size_t)wave * (vv_bytes + rk_bytes);
@@ -376,7 +376,7 @@ hipError_t gn_launch_minimiser(const GnMinimiserParams& p, int n_cu, hipStream_t
     if (p.n_reads <= p.read_begin)
         return hipSuccess;
     const uint32_t K        = p.w - p.k + 1;
-    const bool     fastp    = K <= 65 && !p.force_generic;
+    const bool     fastp    = K <= 65;
     const uint32_t per_wave = fastp ? 128u * 8u : (GN_WAVE + K) * 8 + ((GN_WAVE + p.w + 15) & ~15u);
     const size_t   lds      = (size_t)per_wave * 4;
     uint32_t       blocks   = (p.n_reads - p.read_begin + 3) / 4;

@@ -498,7 +498,7 @@ hipError_t gn_launch_minimiser_lpr(const GnMinimiserParams& p, hipStream_t st)
     if (p.n_reads <= p.read_begin)
         return hipSuccess;
     const uint32_t K   = p.w - p.k + 1;
-    if (K <= 16 && p.k <= 24 && !p.force_lds)
+    if (K <= 16 && p.k <= 24)
     {
         switch (K)
         {

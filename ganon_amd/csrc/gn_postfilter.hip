@@ -745,7 +745,7 @@ extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n
         std::vector<uint32_t> idx;
     };
     std::vector<Group> groups;
-    const bool apart = getenv("GANON_HIP_JOINT_APART") != nullptr; // tests on one GPU: every stream is treated as a device of its own
+    const bool apart = gn_sw().joint_apart; // tests on one GPU: every stream is treated as a device of its own
     for (uint32_t i = 0; i < n_streams; ++i)
     {
         size_t g = 0;

@@ -372,8 +372,9 @@ extern "C" int gn_reassign_create(int device, uint64_t n_reads, uint64_t n_entri
         return gn_fail(GN_EINVAL, "gn_reassign_create: off[0] = %llu, off[n_reads] = %llu, n_entries = %llu", (unsigned long long)off[0],
                        (unsigned long long)off[n_reads], (unsigned long long)n_entries);
     for (uint64_t r = 0; r < n_reads; ++r)
-        if (off[r + 1] < off[r])
-            return gn_fail(GN_EINVAL, "gn_reassign_create: off descends at read %llu", (unsigned long long)r);
+        if (off[r + 1] <= off[r]) // (the reference's dict holds a read only once it has a match: reassign.py reads .all lines)
+            return gn_fail(GN_EINVAL, "gn_reassign_create: read %llu has %s", (unsigned long long)r,
+                           off[r + 1] < off[r] ? "a descending offset" : "no entries (a read without matches is not part of the EM)");
     for (uint64_t i = 0; i < n_entries; ++i)
         if (target[i] >= n_targets)
             return gn_fail(GN_EINVAL, "gn_reassign_create: entry %llu names target %u of %u", (unsigned long long)i, target[i], n_targets);
@@ -455,8 +456,8 @@ extern "C" int gn_reassign_run(gn_reassign* g, uint32_t max_iter, double thresho
 {
     if (!g)
         return gn_fail(GN_EINVAL, "gn_reassign_run: NULL handle");
-    if (!(threshold >= 0.0))
-        return gn_fail(GN_EINVAL, "gn_reassign_run: threshold %g", threshold);
+    if (threshold != threshold) // any number is taken as the reference's argparse takes it: a negative one never stops before max_iter
+        return gn_fail(GN_EINVAL, "gn_reassign_run: threshold is not a number");
     GN_HIP(hipSetDevice(g->device));
     g->diffs.clear();
     const unsigned tb = (g->n_targets + 255u) / 256u;

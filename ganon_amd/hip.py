@@ -26,7 +26,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_hibf_level_lines", "gn_stream_classify_shared",
                "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
                "gn_peer_stats", "gn_stream_upload_text", "gn_stream_upload_text_pair", "gn_stream_text_pair_index", "gn_stream_text_pair_records2",
-               "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
+               "gn_ablate", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -52,6 +52,44 @@ class Timings(C.Structure):
 
 
 _lib = None
+
+
+_ablated: Tuple[str, ...] = tuple(x.strip() for x in os.environ.get("GANON_HIP_ABLATE", "").split(",") if x.strip())
+
+
+def set_ablation(names) -> None:
+    """gn_ablate(): replace the library's switch list (include/ganon_hip.h); "" = the product path"""
+    global _ablated
+    if isinstance(names, str):
+        names = [x.strip() for x in names.split(",") if x.strip()]
+    names = tuple(names)
+    L = load_library()
+    rc = L.gn_ablate(",".join(names).encode())
+    if rc:
+        raise GanonHipError(rc, L.gn_last_error().decode())
+    _ablated = names
+
+
+def ablation() -> Tuple[str, ...]:
+    return _ablated
+
+
+class ablate:
+    """context manager: the named switches on top of the current list, the previous list back on exit
+    (`with ganon_amd.ablate("early_exit"): ...`; an empty name list changes nothing)"""
+
+    def __init__(self, *names: str):
+        self.names = [x.strip() for n in names for x in n.split(",") if x.strip()]
+
+    def __enter__(self):
+        self.prev = _ablated
+        key = lambda s: s.split("=")[0]
+        set_ablation([p for p in self.prev if key(p) not in {key(n) for n in self.names}] + self.names)
+        return self
+
+    def __exit__(self, *exc):
+        set_ablation(self.prev)
+        return False
 
 
 def library_path() -> str:
@@ -118,6 +156,7 @@ def load_library():
     L.gn_gather_destroy.argtypes = [vp]
     L.gn_gather_run_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp, u32, u32]
     L.gn_stream_device_offsets.argtypes = [vp, C.POINTER(vp)]
+    L.gn_ablate.argtypes = [C.c_char_p]
     L.gn_stream_hibf_levels.argtypes = [vp, C.POINTER(u32), vp, vp, vp, vp, u32]
     L.gn_stream_hibf_level_lines.argtypes = [vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
@@ -228,6 +267,19 @@ class HipReassign:
         if self._h:
             load_library().gn_reassign_free(self._h)
             self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+        return False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class HipGather:

@@ -1891,6 +1891,8 @@ static bool ganon_classify(Config config)
                     {
                         const size_t e = moved.find('\n', at);
                         std::cerr << "[gather] level " << level.label << ": " << moved.substr(at, e - at) << std::endl;
+                        if (e == std::string::npos)
+                            break;
                         at = e + 1;
                     }
                 }

@@ -101,7 +101,7 @@ int main(int argc, char** argv)
             if (!value(s))
                 return fail("argument -s/--threshold: expected one argument");
             const double x = std::strtod(s.c_str(), &end);
-            if (s.empty() || *end || !(x >= 0))
+            if (s.empty() || *end || x != x) // (any float, as argparse: a negative threshold runs to --max-iter)
                 return fail("argument -s/--threshold: invalid value: '" + s + "'");
             cfg.threshold = x;
         }

@@ -306,6 +306,15 @@ int gn_gather_destroy(gn_gather* g);
  * access enabled (hipDeviceEnablePeerAccess: direct copies over the xGMI link of the pair), 2 refused or not available (the
  * runtime stages the copy); *bytes = what travelled src -> dst.  `ganon-classify --verbose` prints it per pair. */
 int gn_peer_stats(int dst, int src, int* state, uint64_t* bytes);
+
+/* Switches (test and measurement hook; no counterpart in the reference).  The library reads its environment in ONE place:
+ * $GANON_HIP_ABLATE, a comma list parsed once when the library is loaded.  gn_ablate() replaces that list in-process so a
+ * test can cross-check a fast path against the path it replaces (NULL or "" = the product path).  Call it only while no
+ * launch is in flight.  Names that switch a path OFF: early_exit cand_select csr_identity uniform_select run_select
+ * max_first const_nb split_kernel predrop deferred_grids hibf_reg hibf_pack hibf_one_pack hibf_persistent; test set-ups:
+ * gather_copy joint_apart chunk=N hibf_pair_limit=N; runtime: sync=spin|yield|block debug.  Unknown name -> GN_EINVAL and
+ * the previous list stays. */
+int gn_ablate(const char* list);
 /* free / total memory of a device: the host decides with it whether a filter is replicated or partitioned */
 int gn_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 

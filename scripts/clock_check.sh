@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 ROOT=$PWD; OUT=$ROOT/gpurun_out/clock_check.txt; mkdir -p $ROOT/gpurun_out; : > $OUT
 cd /tmp
 for ee in 1 0; do
-  if [ $ee = 0 ]; then export GANON_HIP_NO_EARLY_EXIT=1; else unset GANON_HIP_NO_EARLY_EXIT; fi
+  if [ $ee = 0 ]; then export GANON_HIP_ABLATE=early_exit; else unset GANON_HIP_ABLATE; fi
   echo "### early exit $ee, untraced" >> $OUT
   python $ROOT/scripts/clock_check.py 2>&1 | grep step >> $OUT
   echo "### early exit $ee, under rocprofv3 --kernel-trace --stats" >> $OUT

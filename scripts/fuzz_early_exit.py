@@ -32,11 +32,10 @@ for c in range(n_cfg):
     bases, off1, off2 = gu.pack_reads(s1, s2 if paired else None)
     res = []
     for env in (None, "1"):
-        if env: os.environ["GANON_HIP_NO_EARLY_EXIT"] = env
-        else: os.environ.pop("GANON_HIP_NO_EARLY_EXIT", None)
+        hip.set_ablation("early_exit" if env else "")
         st = hip.HipStream(flt, len(s1), max(bases.size, 1)); st.submit(bases, off1, off2, k, w, cutoff)
         nh, status, mo, m = st.fetch(); tm = st.timings(); ho, hs = st.fetch_hashes(); res.append((mo.copy(), m.copy(), tm)); st.destroy()
-    os.environ.pop("GANON_HIP_NO_EARLY_EXIT", None)
+    hip.set_ablation("")
     same = np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     b2t = np.arange(bins, dtype=np.uint32); okc = True
     for i in range(0, len(s1), 7):

@@ -1,5 +1,5 @@
 """Randomised check of the count kernels' pre-drop (matches that a filter_matches pre-pass is bound to drop are not written,
-gn_kernels.hip / gn_split.hip / gn_hibf.hip): with GANON_HIP_NO_PREDROP the same batch must give the same survivors in the same
+gn_kernels.hip / gn_split.hip / gn_hibf.hip): with the switch `predrop` (gn_ablate) the same batch must give the same survivors in the same
 order with the same marks, the same maxima and the same two totals.  Flat filters with identity, consecutive and permuted
 split-bin maps, one to nine column slices per read, joint and single mode; HIBFs of random layout.  Not part of the test-suite
 as a whole (tests/test_gpu_fuzz.py runs bounded samples).   env: SEED, N_CFG"""
@@ -53,10 +53,7 @@ for c in range(n_cfg):
     st = hip.HipStream(flt, len(seqs), bases.size)
     res = {}
     for tag in ("predrop", "plain"):
-        if tag == "plain":
-            os.environ["GANON_HIP_NO_PREDROP"] = "1"
-        else:
-            os.environ.pop("GANON_HIP_NO_PREDROP", None)
+        hip.set_ablation("predrop" if tag == "plain" else "")
         st.set_postfilter(rel_filter, fpr_query, tfpr, joint=joint)
         st.submit(bases, off1, off2, k, w, cutoff)
         if joint:
@@ -64,7 +61,7 @@ for c in range(n_cfg):
         _, _, mo, m = st.fetch()
         mx, a, b = st.fetch_postfilter()
         res[tag] = (mo.copy(), m.copy(), mx.copy(), int(a), int(b))
-    os.environ.pop("GANON_HIP_NO_PREDROP", None)
+    hip.set_ablation("")
     same = (np.array_equal(res["predrop"][0], res["plain"][0]) and np.array_equal(res["predrop"][1], res["plain"][1])
             and np.array_equal(res["predrop"][2], res["plain"][2]) and res["predrop"][3:] == res["plain"][3:])
     print(f"cfg {c}: {desc} w {w} cutoff {cutoff} rel_filter {rel_filter} fpr_query {fpr_query} joint {joint}: survivors {len(res['plain'][1])} "

@@ -49,12 +49,11 @@ for c in range(n_cfg):
         s1.append(bytes(a) if i % 4 else gu.random_seq(rng, 150)); s2.append(g[p + 100:p + 250])
     bases, off1, off2 = gu.pack_reads(s1, s2 if paired else None)
     out = []
-    for envs in ((), ("GANON_HIP_NO_SPLIT_KERNEL",), ("GANON_HIP_NO_SPLIT_KERNEL", "GANON_HIP_NO_CAND_SELECT")):
-        for e in ("GANON_HIP_NO_SPLIT_KERNEL", "GANON_HIP_NO_CAND_SELECT"): os.environ.pop(e, None)
-        for e in envs: os.environ[e] = "1"
+    for envs in ((), ("split_kernel",), ("split_kernel", "cand_select")):
+        hip.set_ablation(envs)
         st = hip.HipStream(flt, len(s1), max(bases.size, 1)); st.submit(bases, off1, off2, k, w, cutoff)
         nh, status, mo, m = st.fetch(); ho, hs = st.fetch_hashes(); out.append((mo.copy(), m.copy())); st.destroy()
-    for e in ("GANON_HIP_NO_SPLIT_KERNEL", "GANON_HIP_NO_CAND_SELECT"): os.environ.pop(e, None)
+    hip.set_ablation("")
     same = all(np.array_equal(out[0][0], o[0]) and np.array_equal(out[0][1], o[1]) for o in out[1:])
     okc = True
     for i in range(0, len(s1), 9):

@@ -31,6 +31,14 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _product_path_after_each_test():
+    """a test that switched a kernel path off (gpu_util.SW) never leaks that into the next test"""
+    yield
+    import gpu_util
+    gpu_util.SW.clear()
+
+
 @pytest.fixture(scope="session")
 def kat():
     import json

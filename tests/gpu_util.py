@@ -8,6 +8,36 @@ import numpy as np
 import oracle
 
 
+class _Switches:
+    """The library's switch list (gn_ablate, include/ganon_hip.h) as a set the tests add to and take from; conftest.py clears
+    it after every test.  on("chunk=333") replaces an earlier "chunk=..."."""
+
+    def __init__(self):
+        self.names: List[str] = []
+
+    def _apply(self):
+        import ganon_amd
+        ganon_amd.set_ablation(self.names)
+
+    def on(self, name: str):
+        key = name.split("=")[0]
+        self.names = [n for n in self.names if n.split("=")[0] != key] + [name]
+        self._apply()
+
+    def off(self, name: str):
+        key = name.split("=")[0]
+        self.names = [n for n in self.names if n.split("=")[0] != key]
+        self._apply()
+
+    def clear(self):
+        if self.names:
+            self.names = []
+            self._apply()
+
+
+SW = _Switches()
+
+
 def pack_reads(seqs1: Sequence[bytes], seqs2: Optional[Sequence[bytes]] = None):
     """-> (bases uint8[], off1 u64[n+1], off2 u64[n+1] | None): mate-1 block then mate-2 block."""
     n = len(seqs1)

@@ -4,6 +4,8 @@ Set GANON_FULLSIZE_ROWS / GANON_FULLSIZE_READS to shrink it for a quick run."""
 import os
 
 import numpy as np
+
+import gpu_util as gu
 import pytest
 
 import bench_workload as bw
@@ -113,13 +115,13 @@ def test_filter_matches_prepass_at_full_size(full, monkeypatch):
     res = {}
     for tag in ("predrop", "plain"):
         if tag == "plain":
-            monkeypatch.setenv("GANON_HIP_NO_PREDROP", "1")
+            gu.SW.on("predrop")
         st.set_postfilter(0.1, 1e-5, tfpr)
         st.classify(wl.k, wl.w, 0.2)
         nh, status, mo, m = st.fetch()
         mx, d_fil, d_fpr = st.fetch_postfilter()
         res[tag] = (mo, m, mx, d_fil, d_fpr)
-        monkeypatch.delenv("GANON_HIP_NO_PREDROP", raising=False)
+        gu.SW.off("predrop")
     mo, m, mx, d_fil, d_fpr = res["predrop"]
     assert np.array_equal(mo, res["plain"][0]) and np.array_equal(m, res["plain"][1]) and np.array_equal(mx, res["plain"][2])
     assert (d_fil, d_fpr) == res["plain"][3:]
@@ -220,7 +222,7 @@ def test_hibf_low_cutoff_at_full_size_runs_in_read_ranges(hibf_full, monkeypatch
     runs = []
     for limit in (None, "600000000"):
         if limit:
-            monkeypatch.setenv("GANON_HIP_HIBF_PAIR_LIMIT", limit)
+            gu.SW.on(f"hibf_pair_limit={limit}")
         st.set_postfilter(0.1, 1e-5, tfpr)
         st.classify(wl.k, wl.w, 0.2)
         nh, status, mo, m = st.fetch()
@@ -283,13 +285,13 @@ def test_hibf_skewed_layout_small_equals_oracle(rel_cutoff):
     multi = _check_against_oracle_hibf(wl, flt, nh, mo, m, 3000, 11)
     assert multi > 30           # reads that matched in two user bins (two children) were among the sample
     # the same batch through the other kernel paths: no packed kernel, LDS kernel only, no sorting of a level's queue by IBF width
-    for switch in ("GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG", "GANON_HIP_HIBF_ONE_PACK"):
-        os.environ[switch] = "1"
+    for switch in ("hibf_pack", "hibf_reg", "hibf_one_pack"):
+        gu.SW.on(switch)
         try:
             st.classify(wl.k, wl.w, wl.rel_cutoff)
             nh2, _, mo2, m2 = st.fetch()
         finally:
-            del os.environ[switch]
+            gu.SW.off(switch)
         assert np.array_equal(nh, nh2) and np.array_equal(mo, mo2) and np.array_equal(m, m2), switch
     # dense user-bin counts of a few reads == the agent's result vector
     dense = st.dense_counts(0, 64, wl.n_user_bins)

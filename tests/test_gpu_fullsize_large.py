@@ -13,6 +13,8 @@ import os
 import socket
 
 import numpy as np
+
+import gpu_util as gu
 import pytest
 
 import bench_workload as bw
@@ -111,7 +113,7 @@ def test_config3_idempotent_and_order_independent(flat128g):
 
 def test_config3_early_exit_changes_nothing(flat128g, monkeypatch):
     hip, wl, flt, st, (nh, status, mo, m) = flat128g
-    monkeypatch.setenv("GANON_HIP_NO_EARLY_EXIT", "1")
+    gu.SW.on("early_exit")
     st.classify(wl.k, wl.w, wl.rel_cutoff)
     nh2, status2, mo2, m2 = st.fetch()
     tm = st.timings()
@@ -197,7 +199,7 @@ def test_config3_filter_as_two_64g_parts_gathered_equals_the_whole(flat128g, mon
         st.upload(wl0.bases, wl0.off, wl0.off2)
         st.classify(wl0.k, wl0.w, wl0.rel_cutoff)
         streams.append(st)
-    monkeypatch.setenv("GANON_HIP_GATHER_COPY", "1")   # one GPU: take the device-to-device copy path all the same
+    gu.SW.on("gather_copy")   # one GPU: take the device-to-device copy path all the same
     g = hip.HipGather(0, [None, np.arange(BINS // 2, dtype=np.uint32) + np.uint32(BINS // 2)])
     g.run(streams)
     mo2, m2 = g.fetch()

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import bench_workload as bw
+import gpu_util as gu
 import oracle
 
 pytestmark = pytest.mark.gpu
@@ -19,8 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                                ("fuzz_split.py", 22, 8), ("fuzz_predrop.py", 31, 16)])
 def test_randomised_cross_checks(script, seed, n_cfg):
     env = dict(os.environ, SEED=str(seed), N_CFG=str(n_cfg))
-    for k in ("GANON_HIP_NO_EARLY_EXIT", "GANON_HIP_NO_SPLIT_KERNEL", "GANON_HIP_NO_CAND_SELECT", "GANON_HIP_NO_PREDROP"):
-        env.pop(k, None)
+    env.pop("GANON_HIP_ABLATE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "BAD 0" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
 
@@ -36,14 +36,14 @@ def test_split_bins_one_million_reads(monkeypatch):
     st = ganon_amd.HipStream(flt, n, wl.bases.size, n * 2)
     st.upload(wl.bases, wl.off, None)
     outs = []
-    for envs in ((), ("GANON_HIP_NO_SPLIT_KERNEL",), ("GANON_HIP_NO_SPLIT_KERNEL", "GANON_HIP_NO_CAND_SELECT")):
+    for envs in ((), ("split_kernel",), ("split_kernel", "cand_select")):
         for e in envs:
-            monkeypatch.setenv(e, "1")
+            gu.SW.on(e)
         st.classify(wl.k, wl.w, 0.5)
         nh, status, mo, m = st.fetch()
         outs.append((mo.copy(), m.copy()))
         for e in envs:
-            monkeypatch.delenv(e)
+            gu.SW.off(e)
     for mo2, m2 in outs[1:]:
         assert np.array_equal(outs[0][0], mo2) and np.array_equal(outs[0][1], m2)
     mo, m = outs[0]
@@ -106,9 +106,9 @@ def test_hibf_randomised_layouts(seed, monkeypatch):
         paired = bool(cfg % 2)
         bases, off1, off2 = gu.pack_reads(s1, s2 if paired else None)
         outs = []
-        for sw in (None, "GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG", "GANON_HIP_HIBF_ONE_PACK"):
+        for sw in (None, "hibf_pack", "hibf_reg", "hibf_one_pack"):
             if sw:
-                monkeypatch.setenv(sw, "1")
+                gu.SW.on(sw)
             st = hip.HipStream(flt, len(s1), max(bases.size, 1))
             st.submit(bases, off1, off2, k, w, cutoff)
             nh, status, mo, m = st.fetch()
@@ -116,7 +116,7 @@ def test_hibf_randomised_layouts(seed, monkeypatch):
             outs.append((mo.copy(), m.copy(), st.timings()["algo_bytes"]))
             st.destroy()
             if sw:
-                monkeypatch.delenv(sw)
+                gu.SW.off(sw)
         for o in outs[1:]:
             assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) and outs[0][2] == o[2], (seed, cfg)
         mo, m, _ = outs[0]

@@ -2,7 +2,7 @@
 the column parts of a filter, each a flat IBF of its own, classify the same batch; put back together on the owner
 device they must give what the unpartitioned filter gives -- and that is checked against the oracle as well.
 
-One GPU here, so the parts share it; $GANON_HIP_GATHER_COPY / $GANON_HIP_JOINT_APART make the library treat them as if
+One GPU here, so the parts share it; $switch gather_copy / $switch joint_apart make the library treat them as if
 they sat on different devices (device-to-device copies of offsets, matches and per-read max/min through the same
 hipMemcpyPeerAsync calls the multi-GPU placement uses)."""
 import numpy as np
@@ -90,7 +90,7 @@ def test_gather_of_column_parts_equals_the_whole_filter_and_the_oracle(hip, monk
     exp = _oracle_matches(ibf, b2t, n_targets, seqs, rel_cutoff)
     assert [(int(x["read"]), int(x["target"]), int(x["count"])) for x in m_full] == exp and len(exp) > 100
     if copy_path:
-        monkeypatch.setenv("GANON_HIP_GATHER_COPY", "1")
+        gu.SW.on("gather_copy")
     for world in (2, 3, 7):
         parts = _parts(hip, ibf, b2t, world)
         sts = [hip.HipStream(f, len(seqs), bases.size) for f, _ in parts]
@@ -138,8 +138,8 @@ def test_prepass_over_parts_then_gather_equals_the_prepass_on_the_whole_filter(h
     nh, status, mo, m_full = st.fetch()
     mx, d_fil, d_fpr = st.fetch_postfilter()
     if apart:
-        monkeypatch.setenv("GANON_HIP_JOINT_APART", "1")
-        monkeypatch.setenv("GANON_HIP_GATHER_COPY", "1")
+        gu.SW.on("joint_apart")
+        gu.SW.on("gather_copy")
     for world in (2, 5):
         parts = _parts(hip, ibf, b2t, world)
         sts = [hip.HipStream(f, len(seqs), bases.size) for f, _ in parts]

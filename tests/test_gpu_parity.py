@@ -271,10 +271,10 @@ def test_hibf_register_kernel_vs_lds_kernel_vs_oracle(hip, monkeypatch, n_ub, tm
     st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
     assert nh.max() > 127 and (nh[nh > 0] <= 127).any()
     tm = st.timings()
-    for switch in ("GANON_HIP_HIBF_NO_PACK", "GANON_HIP_HIBF_NO_REG", "GANON_HIP_HIBF_ONE_PACK"):  # per-item register kernel first / LDS kernel only / no sorting of a level by IBF width
-        monkeypatch.setenv(switch, "1")
+    for switch in ("hibf_pack", "hibf_reg", "hibf_one_pack"):  # per-item register kernel first / LDS kernel only / no sorting of a level by IBF width
+        gu.SW.on(switch)
         st2, nh2, status2, mo2, m2 = _classify(hip, flt, seqs, None, k, w, rel_cutoff)
-        monkeypatch.delenv(switch)
+        gu.SW.off(switch)
         assert np.array_equal(nh, nh2) and np.array_equal(mo, mo2) and np.array_equal(m, m2), switch
         assert st2.timings()["algo_bytes"] == tm["algo_bytes"], switch
     ho, hs = st.fetch_hashes()
@@ -392,7 +392,7 @@ def test_planted_matches_many_reads(hip, bins, rows, h, paired):
 
 
 def test_chunked_pipeline_parity(hip, monkeypatch):
-    # $GANON_HIP_CHUNK cuts the batch into chunks pipelined over two HIP streams (minimiser || count); results must
+    # switch chunk=N cuts the batch into chunks pipelined over two HIP streams (minimiser || count); results must
     # not depend on the chunking
     k, w = 19, 31
     bins, rows, h = 4096, 4099, 4
@@ -406,7 +406,7 @@ def test_chunked_pipeline_parity(hip, monkeypatch):
             for i in range(5000)]
     outs = []
     for chunk in ("0", "1", "333", "4096"):
-        monkeypatch.setenv("GANON_HIP_CHUNK", chunk)
+        gu.SW.on(f"chunk={chunk}")
         st, nh, status, mo, m = _classify(hip, flt, seqs, None, k, w, 0.6)
         outs.append((nh.copy(), status.copy(), mo.copy(), m.copy(), st.timings()["n_count_launches"]))
         st.destroy()
@@ -443,11 +443,11 @@ def test_early_exit_is_exact(hip, monkeypatch, bins, rows, h):
         reads.append(bytes(s) if i % 5 else gu.random_seq(rng, 150))
     b2t = np.arange(bins, dtype=np.uint32)
     for cutoff in (0.0, 0.3, 0.55, 0.75, 0.9, 1.0):
-        monkeypatch.delenv("GANON_HIP_NO_EARLY_EXIT", raising=False)
+        gu.SW.off("early_exit")
         st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
         tm = st.timings()
         ho, hs = st.fetch_hashes()
-        monkeypatch.setenv("GANON_HIP_NO_EARLY_EXIT", "1")
+        gu.SW.on("early_exit")
         st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
         tm2 = st2.timings()
         assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
@@ -526,18 +526,18 @@ def test_candidate_select_matches_target_scan(hip, monkeypatch, bins, rows, h, c
         reads.append(bytes(s) if i % 4 else gu.random_seq(rng, 150))
     reads.append(g[:640])                      # a long read (n > 64: several row-table chunks)
     for cutoff in (0.05, 0.1, 0.3, 0.75, 1.0):
-        monkeypatch.delenv("GANON_HIP_NO_CAND_SELECT", raising=False)
+        gu.SW.off("cand_select")
         st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
         ho, hs = st.fetch_hashes()
         # default = split kernel (register counters, byte image) for reads of up to 127 minimisers; without it the
         # generic kernel's candidate select; without that the plain scan over every target
-        monkeypatch.setenv("GANON_HIP_NO_SPLIT_KERNEL", "1")
+        gu.SW.on("split_kernel")
         st3, nh3, status3, mo3, m3 = _classify(hip, flt, reads, None, k, w, cutoff)
         assert np.array_equal(mo, mo3) and np.array_equal(m, m3), cutoff
         st3.destroy()
-        monkeypatch.setenv("GANON_HIP_NO_CAND_SELECT", "1")
+        gu.SW.on("cand_select")
         st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
-        monkeypatch.delenv("GANON_HIP_NO_SPLIT_KERNEL", raising=False)
+        gu.SW.off("split_kernel")
         assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
         per_read = np.diff(mo.astype(np.int64))
         assert (m["count"] <= nh[m["read"]]).all()
@@ -1158,7 +1158,7 @@ def test_merging_postfilter_over_filters_that_share_targets(hip, rel_filter, fpr
 def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, monkeypatch, bins, joint, split):
     # with a filter_matches pre-pass on the stream the fast kernel does not write bins that the --rel-filter rule is bound to
     # drop (threshold from the unit's own maximum and a lower bound of the read's minimum); switching that off
-    # (GANON_HIP_NO_PREDROP) must change nothing: survivors, their order and marks, every read's maximum, both totals.
+    # (switch predrop) must change nothing: survivors, their order and marks, every read's maximum, both totals.
     # 9000 bins = three column slices per read: a slice only knows its own maximum.  joint: the minimum bound is 0.
     # split: targets own one to four bins (the split-bin kernel: the waves of a read share their maxima).
     k, w = 19, 31
@@ -1189,13 +1189,13 @@ def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, mon
     for rel_filter, fpr_query in ((0.1, 1e-5), (0.5, 1.0), (0.0, 1.0), (0.99, 0.5)):
         for tag in ("predrop", "plain", "bin_lists"):
             if tag == "plain":
-                monkeypatch.setenv("GANON_HIP_NO_PREDROP", "1")
+                gu.SW.on("predrop")
             else:
-                monkeypatch.delenv("GANON_HIP_NO_PREDROP", raising=False)
+                gu.SW.off("predrop")
             if tag == "bin_lists":  # split maps whose targets own consecutive bins: without the shortcut that needs no bin lists
-                monkeypatch.setenv("GANON_HIP_NO_CSR_IDENTITY", "1")
+                gu.SW.on("csr_identity")
             else:
-                monkeypatch.delenv("GANON_HIP_NO_CSR_IDENTITY", raising=False)
+                gu.SW.off("csr_identity")
             st.set_postfilter(rel_filter, fpr_query, tfpr, joint=joint)
             st.submit(bases, off1, off2, k, w, 0.1)
             if joint:
@@ -1203,8 +1203,8 @@ def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, mon
             _, _, mo2, m2 = st.fetch()
             mx, a, b = st.fetch_postfilter()
             res[tag] = (mo2.copy(), m2.copy(), mx.copy(), a, b)
-        monkeypatch.delenv("GANON_HIP_NO_PREDROP", raising=False)
-        monkeypatch.delenv("GANON_HIP_NO_CSR_IDENTITY", raising=False)
+        gu.SW.off("predrop")
+        gu.SW.off("csr_identity")
         assert np.array_equal(res["predrop"][0], res["bin_lists"][0]) and np.array_equal(res["predrop"][1], res["bin_lists"][1])
         assert np.array_equal(res["predrop"][0], res["plain"][0]) and np.array_equal(res["predrop"][1], res["plain"][1])
         assert np.array_equal(res["predrop"][2], res["plain"][2]) and res["predrop"][3:] == res["plain"][3:]
@@ -1227,7 +1227,7 @@ def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, mon
 @pytest.mark.parametrize("limit", [200, 3000, 40000])
 def test_hibf_batch_in_read_ranges_equals_one_pass(hip, monkeypatch, limit, prepass):
     # A batch with more raw (read, user bin) pairs than one radix sort (2^31 items) or the device takes is run in read ranges,
-    # each with its own levels / pre-drop / sort / finish, appended in read order.  $GANON_HIP_HIBF_PAIR_LIMIT makes that happen
+    # each with its own levels / pre-drop / sort / finish, appended in read order.  switch hibf_pair_limit=N makes that happen
     # at toy size: the result must be the one-pass result record for record -- and the oracle's.
     k, w = 19, 31
     rng = np.random.default_rng(41)
@@ -1266,7 +1266,7 @@ def test_hibf_batch_in_read_ranges_equals_one_pass(hip, monkeypatch, limit, prep
         return out
 
     whole = run()
-    monkeypatch.setenv("GANON_HIP_HIBF_PAIR_LIMIT", str(limit))
+    gu.SW.on(f"hibf_pair_limit={limit}")
     split = run()
     for (nh, status, mo, m, ex), (nh2, status2, mo2, m2, ex2) in zip(whole, split):
         assert np.array_equal(nh, nh2) and np.array_equal(status, status2) and np.array_equal(mo, mo2) and np.array_equal(m, m2)
@@ -1289,7 +1289,7 @@ def test_hibf_batch_in_read_ranges_equals_one_pass(hip, monkeypatch, limit, prep
 def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, rows, h, nb):
     # every target owns the same 2 or 4 consecutive bins (what a database of equally sized, over-sized targets looks like): at low
     # cutoffs the split kernel judges them with packed 16-bit arithmetic over its bin-ordered counters.  Same matches as the general
-    # scan (GANON_HIP_NO_UNIFORM_SELECT), as the oracle, and -- with the pre-pass -- the same survivors and dropped totals.
+    # scan (switch uniform_select), as the oracle, and -- with the pre-pass -- the same survivors and dropped totals.
     k, w = 19, 31
     rng = np.random.default_rng(bins + nb)
     n_targets = bins // nb
@@ -1316,9 +1316,9 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
     for cutoff in (0.05, 0.15, 0.3, 0.8):
         st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
         ho, hs = st.fetch_hashes()
-        monkeypatch.setenv("GANON_HIP_NO_UNIFORM_SELECT", "1")
+        gu.SW.on("uniform_select")
         st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
-        monkeypatch.delenv("GANON_HIP_NO_UNIFORM_SELECT")
+        gu.SW.off("uniform_select")
         assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
         for i in range(0, len(reads), 5):
             exp_m, _ = gu.oracle_matches(ibf, b2t, n_targets, hs[int(ho[i]):int(ho[i + 1])], cutoff)
@@ -1332,7 +1332,7 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
         res = []
         for off in (False, True):
             if off:
-                monkeypatch.setenv("GANON_HIP_NO_UNIFORM_SELECT", "1")
+                gu.SW.on("uniform_select")
             bases, off1, _ = gu.pack_reads(reads, None)
             sp = hip.HipStream(flt, len(reads), bases.size)
             sp.set_postfilter(0.1, 1e-3, tfpr)
@@ -1340,7 +1340,7 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
             r = sp.fetch()
             res.append((r[2].copy(), r[3].copy(), sp.fetch_postfilter()))
             sp.destroy()
-            monkeypatch.delenv("GANON_HIP_NO_UNIFORM_SELECT", raising=False)
+            gu.SW.off("uniform_select")
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
         assert np.array_equal(res[0][2][0], res[1][2][0]) and res[0][2][1:] == res[1][2][1:]
     flt.free()
@@ -1351,7 +1351,7 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
 def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h, big):
     # every bin has a target, targets own one to four consecutive bins (what ganon-build makes of targets of different sizes above
     # max_hashes_bin): at low cutoffs the split kernel judges them with a running sum over each lane's own bins (targets straddle
-    # lanes, dwords and column slices).  Same matches as the general scan (GANON_HIP_NO_RUN_SELECT), as the oracle, and -- with the
+    # lanes, dwords and column slices).  Same matches as the general scan (switch run_select), as the oracle, and -- with the
     # pre-pass -- the same survivors and dropped totals.
     k, w = 19, 31
     rng = np.random.default_rng(bins + h)
@@ -1388,9 +1388,9 @@ def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h,
     for cutoff in (0.05, 0.15, 0.3, 0.8):
         st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
         ho, hs = st.fetch_hashes()
-        monkeypatch.setenv("GANON_HIP_NO_RUN_SELECT", "1")
+        gu.SW.on("run_select")
         st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
-        monkeypatch.delenv("GANON_HIP_NO_RUN_SELECT")
+        gu.SW.off("run_select")
         assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
         for i in range(0, len(reads), 5):
             exp_m, _ = gu.oracle_matches(ibf, b2t, n_targets, hs[int(ho[i]):int(ho[i + 1])], cutoff)
@@ -1404,7 +1404,7 @@ def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h,
         res = []
         for off_ in (False, True):
             if off_:
-                monkeypatch.setenv("GANON_HIP_NO_RUN_SELECT", "1")
+                gu.SW.on("run_select")
             bases, off1, _ = gu.pack_reads(reads, None)
             sp = hip.HipStream(flt, len(reads), bases.size)
             sp.set_postfilter(0.1, 1e-3, tfpr)
@@ -1412,9 +1412,50 @@ def test_run_select_for_targets_of_mixed_widths(hip, monkeypatch, bins, rows, h,
             r = sp.fetch()
             res.append((r[2].copy(), r[3].copy(), sp.fetch_postfilter()))
             sp.destroy()
-            monkeypatch.delenv("GANON_HIP_NO_RUN_SELECT", raising=False)
+            gu.SW.off("run_select")
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
         assert np.array_equal(res[0][2][0], res[1][2][0]) and res[0][2][1:] == res[1][2][1:]
+    flt.free()
+
+
+def test_target_id_without_bins_does_not_shift_later_targets(hip):
+    # bin2target [0,0,2,2,2,...] with n_targets covering an id (1, and a few more) that owns no bin: accepted by gn_filter_upload_ibf
+    # (every bin has a target, bins in target order), but the run select numbers targets by counting target ends, so an empty id
+    # would shift every later one -- such a map takes the general scan instead (gn_capi.hip run_ok)
+    k, w, bins, rows, h = 19, 31, 4096, 1201, 4
+    rng = np.random.default_rng(99)
+    sizes, ids, nxt = [], [], 0
+    while sum(sizes) < bins:
+        if rng.random() < 0.1 or nxt == 1:
+            nxt += 1                                  # this id gets no bin
+        sizes.append(min(int(rng.choice([1, 2, 3, 4])), bins - sum(sizes)))
+        ids.append(nxt)
+        nxt += 1
+    n_targets = nxt + 2                               # two unused ids at the very end as well
+    b2t = np.repeat(np.asarray(ids, dtype=np.uint32), sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ibf = gf.random_ibf(bins, rows, h, 0.5, seed=7)
+    genomes = []
+    for gi in range(32):
+        t = int(rng.integers(0, len(sizes)))
+        g = gu.random_seq(rng, 1500)
+        hs = np.unique(oracle.minimiser_hash(oracle.to_ranks(g), k, w))
+        for pi, part in enumerate(np.array_split(hs, sizes[t])):
+            ibf.emplace_many(part, int(off[t]) + pi)
+        genomes.append(g)
+    flt = hip.HipFilter.ibf(ibf.data, bins, rows, h, b2t, n_targets)
+    reads = [genomes[i % 32][(i * 31) % 1300:(i * 31) % 1300 + 150] if i % 3 else gu.random_seq(rng, 150) for i in range(600)]
+    for cutoff in (0.05, 0.3, 0.8):
+        st, nh, status, mo, m = _classify(hip, flt, reads, None, k, w, cutoff)
+        ho, hs = st.fetch_hashes()
+        n_match = 0
+        for i in range(0, len(reads), 2):
+            exp_m, _ = gu.oracle_matches(ibf, b2t, n_targets, hs[int(ho[i]):int(ho[i + 1])], cutoff)
+            got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
+            assert got == exp_m, (cutoff, i, got[:3], exp_m[:3])
+            n_match += len(exp_m)
+        assert n_match > 100
+        st.destroy()
     flt.free()
 
 
@@ -1449,14 +1490,14 @@ def test_split_kernel_switches_give_the_same_survivors(hip, monkeypatch, kind):
     reads = [genomes[i % 32][(i * 37) % 1300:(i * 37) % 1300 + 150] if i % 3 else gu.random_seq(rng, 150) for i in range(600)]
     bases, off1, _ = gu.pack_reads(reads, None)
     tfpr = rng.choice([1e-4, 0.01, 0.05, 0.2], size=n_targets)
-    switches = [None, "GANON_HIP_NO_MAX_FIRST", "GANON_HIP_NO_CONST_NB", "GANON_HIP_NO_UNIFORM_SELECT", "GANON_HIP_NO_RUN_SELECT", "GANON_HIP_NO_SPLIT_KERNEL"]
+    switches = [None, "max_first", "const_nb", "uniform_select", "run_select", "split_kernel"]
     for cutoff in (0.1, 0.25, 0.75):
         res = []
         for sw in switches:
             for e in switches[1:]:
-                monkeypatch.delenv(e, raising=False)
+                gu.SW.off(e)
             if sw:
-                monkeypatch.setenv(sw, "1")
+                gu.SW.on(sw)
             sp = hip.HipStream(flt, len(reads), bases.size)
             sp.set_postfilter(0.1, 1e-3, tfpr)
             sp.submit(bases, off1, None, k, w, cutoff)
@@ -1464,7 +1505,7 @@ def test_split_kernel_switches_give_the_same_survivors(hip, monkeypatch, kind):
             res.append((r[2].copy(), r[3].copy(), sp.fetch_postfilter()))
             sp.destroy()
         for e in switches[1:]:
-            monkeypatch.delenv(e, raising=False)
+            gu.SW.off(e)
         for sw, x in zip(switches[1:], res[1:]):
             assert np.array_equal(res[0][0], x[0]) and np.array_equal(res[0][1], x[1]), (kind, cutoff, sw)
             assert np.array_equal(res[0][2][0], x[2][0]) and res[0][2][1:] == x[2][1:], (kind, cutoff, sw)
@@ -1498,13 +1539,13 @@ def test_deferred_launches_sized_by_the_previous_batch(hip, monkeypatch):
     cap_r, cap_b = 4000, sum(len(x) for x in long_) + 64
     reused = hip.HipStream(flt, cap_r, cap_b)
     got = [run(reused, short), run(reused, long_), run(reused, short), run(reused, long_)]
-    monkeypatch.setenv("GANON_HIP_FULL_DEFERRED_GRIDS", "1")
+    gu.SW.on("deferred_grids")
     want = []
     for reads in (short, long_):
         fresh = hip.HipStream(flt, cap_r, cap_b)
         want.append(run(fresh, reads))
         fresh.destroy()
-    monkeypatch.delenv("GANON_HIP_FULL_DEFERRED_GRIDS")
+    gu.SW.off("deferred_grids")
     for g, wnt in zip(got, [want[0], want[1], want[0], want[1]]):
         for a, b in zip(g, wnt):
             assert np.array_equal(a, b)

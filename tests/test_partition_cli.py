@@ -43,7 +43,7 @@ def test_filter_over_budget_is_partitioned_and_changes_no_output_byte(oracle_bin
     _same(whole, ora)
     assert os.path.getsize(whole + ".all") > 1000
     spread = {"GANON_DEVICE_BUDGET": "2500000", "GANON_HOST_TIMING": "1"}
-    for name, devs, env in (("three", "0,0,0", {}), ("four", "0,0,0,0", {}), ("copies", "0,0,0", {"GANON_HIP_GATHER_COPY": "1"}),
+    for name, devs, env in (("three", "0,0,0", {}), ("four", "0,0,0,0", {}), ("copies", "0,0,0", {"GANON_HIP_ABLATE": "gather_copy"}),
                             ("batches", "0,0,0", {"GANON_HOST_BATCH_READS": "37"}),
                             ("one_worker", "0,0,0", {"GANON_PARTITION_WORKERS": "1", "GANON_HOST_BATCH_READS": "100"}),
                             # the reads as pieces of FASTQ text, records found on the device (the part that takes a batch takes the text)
@@ -54,7 +54,7 @@ def test_filter_over_budget_is_partitioned_and_changes_no_output_byte(oracle_bin
         p = _run(cu.BIN_HIP, wide_db, out, ["--device", devs], dict(spread, **env))
         assert "partitioned by bin range" in p.stderr and p.stderr.count("-> device 0") == len(devs.split(",")), p.stderr
         _same(out, whole)
-        if "GANON_HIP_GATHER_COPY" in env:
+        if "GANON_HIP_ABLATE" in env:
             assert "moved between devices" in p.stderr
             # per device pair: how the matches travelled and how many bytes (on a node with several GPUs: "peer access enabled")
             assert "[gather] level" in p.stderr and "MiB of matches gathered" in p.stderr, p.stderr[-800:]
@@ -72,7 +72,7 @@ def test_partitioned_filter_with_the_filter_matches_prepass(oracle_bin, wide_db,
     # them), survivors only are gathered; .sta carries the discarded-match totals
     ora, got = str(tmp_path / "ora"), str(tmp_path / "got")
     _run(oracle_bin, wide_db, ora, thr + ["--output-stats"])
-    env = {"GANON_DEVICE_BUDGET": "2500000", "GANON_HOST_TIMING": "1", "GANON_HIP_GATHER_COPY": "1", "GANON_HIP_JOINT_APART": "1"}
+    env = {"GANON_DEVICE_BUDGET": "2500000", "GANON_HOST_TIMING": "1", "GANON_HIP_ABLATE": "gather_copy,joint_apart"}
     p = _run(cu.BIN_HIP, wide_db, got, thr + ["--output-stats", "--device", "0,0,0"], env)
     assert "partitioned by bin range" in p.stderr and "pre-pass on the device on (1 filter(s)" in p.stderr
     _same(got, ora, EXTS + (".sta",))

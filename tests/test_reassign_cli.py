@@ -208,6 +208,20 @@ def test_abi_refuses_a_broken_table(hip):
         hip.HipReassign(np.array([0, 1], dtype=np.uint64), np.array([3], dtype=np.uint32), 2)
     with pytest.raises(hip.GanonHipError):
         hip.HipReassign(np.array([0, 1], dtype=np.uint64), np.array([0], dtype=np.uint32), 1, device=99)
+    # a read without entries is not part of the reference's dict (reassign.py builds it from .all lines): refused, not run past the table
+    with pytest.raises(hip.GanonHipError, match="no entries"):
+        hip.HipReassign(np.array([0, 1, 1, 2], dtype=np.uint64), np.array([0, 1], dtype=np.uint32), 2)
+
+
+@pytest.mark.gpu
+def test_negative_threshold_runs_to_max_iter_as_the_reference_does(hip):
+    # argparse takes any float for -s; `diff <= threshold` (reassign.py:141) never holds for a negative one
+    off, tgt = random_table(3, 4000, 64, 0.5, 6)
+    want = orr.em(oracle_table(off, tgt, 64), 7, -1.0)
+    with hip.HipReassign(off, tgt, 64) as g:
+        diffs, counts, _, prob, _ = g.run(7, -1.0)
+    assert want.iterations == 7 and len(diffs) == 7
+    assert diffs.tobytes() == np.asarray(want.diffs, dtype=np.float64).tobytes() and prob.tobytes() == want.prob.tobytes()
 
 
 @pytest.mark.gpu
