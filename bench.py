@@ -593,7 +593,7 @@ def main() -> int:
                     result["value"] = None
             if headline and not args.no_cpu_baseline and world == 1 and kind == "flat" and wl.filter_bytes <= (16 << 30) and spec.get("bins_per_target", 1) == 1:
                 try:  # the CPU baseline is an N=1 measurement on a filter the host can hold
-                    result["cpu_baseline"] = bench_cpu.cpu_baseline(wl, flt, args.cpu_sample)
+                    result["cpu_baseline"] = bench_cpu.cpu_baseline(wl, flt, args.cpu_sample, gpu_result=(nh, mo, matches))
                 except Exception as e:  # noqa: BLE001 -- a reported extra; never lose the GPU line over it
                     log("bench.py: cpu_baseline failed:", repr(e))
                     result["cpu_baseline"] = None

@@ -2,7 +2,9 @@
 
   spot_check    re-derives a random sample of the GPU results with the CPU oracle (parity gate on the bench data)
   cpu_baseline  times the oracle (OpenMP port of the reference's per-read loop) on a bounded sample of the same
-                workload on this box's host cores
+                workload on this box's host cores -- and, when a REAL `ganon-classify` (one that is not this repo's) is on PATH
+                or named by $GANON_REFERENCE_CLASSIFY, runs that on the same reads against an .ibf of the same bits (BASELINE.md
+                3.1), diffs its .all with the GPU's matches and reports it as `"kind": "reference"`
 """
 from __future__ import annotations
 
@@ -147,7 +149,84 @@ def _reset_mempolicy():
         pass
 
 
-def cpu_baseline(wl, flt, n_sample: int = 0):
+OUR_CLASSIFY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ganon_amd", "host", "ganon-classify")
+
+
+def find_reference_classify():
+    """-> (path, why_not): a ganon-classify that is not this repo's.  $GANON_REFERENCE_CLASSIFY names one explicitly (the test suite
+    points it at our own binary to exercise this leg: there is no SeqAn3 build in the image); otherwise PATH is searched and a binary
+    whose --version carries this repo's tag is refused."""
+    import shutil
+    import subprocess
+    forced = os.environ.get("GANON_REFERENCE_CLASSIFY")
+    cand = forced or shutil.which("ganon-classify")
+    if not cand or not os.access(cand, os.X_OK):
+        return None, "no ganon-classify on PATH"
+    if not forced:
+        try:
+            if os.path.exists(OUR_CLASSIFY) and os.path.samefile(cand, OUR_CLASSIFY):
+                return None, "the ganon-classify on PATH is this repo's"
+            v = subprocess.run([cand, "--version"], capture_output=True, text=True, timeout=30)
+            if "mi355x" in (v.stdout + v.stderr):
+                return None, "the ganon-classify on PATH is this repo's"
+        except Exception as e:  # noqa: BLE001
+            return None, f"could not run {cand}: {e!r}"
+    return cand, ""
+
+
+def reference_baseline(binary: str, wl, flt, nh, mo, matches, n: int, threads: int, workdir: str = ""):
+    """the given ganon-classify with `--threads <cores> --output-all` on the first n reads of the workload (FASTQ,
+    ids r<idx>) and an .ibf of the SAME bits written by this repo's writer (ibf_file.save_ibf: bin b is target "b"); its own
+    "classifying+printing elapsed" line (GanonClassify.cpp:1047) -> Mreads/s; its .all is compared with the GPU's matches."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    from ganon_amd import ibf_file
+    n = int(min(n, wl.n_reads))
+    base = workdir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+    need = wl.filter_bytes + n * 2 * (wl.read_len + 16) + (64 << 20)
+    if shutil.disk_usage(base).free < need:
+        raise RuntimeError(f"{base} has less than {need >> 20} MiB free for the .ibf and the FASTQ")
+    d = tempfile.mkdtemp(prefix="ganon_ref_baseline_", dir=base)
+    try:
+        import bench_e2e
+        L = wl.read_len
+        if getattr(wl, "paired", False) or int(wl.off[n]) != n * L:
+            raise RuntimeError("the reference leg takes single-end reads of one length")
+        fq = os.path.join(d, "reads.fq")
+        step = 1 << 20
+        with open(fq, "wb") as f:
+            for a in range(0, n, step):
+                b = min(n, a + step)
+                f.write(bench_e2e.fastq_matrix(wl.bases[a * L:b * L], b - a, L, first_id=a).tobytes())
+        ibf = os.path.join(d, "filter.ibf")
+        cfg = dict(n_bins=wl.bins, max_hashes_bin=1, hash_functions=wl.hash_funs, kmer_size=wl.k, window_size=wl.w, bin_size_bits=wl.rows,
+                   max_fp=0.05, true_max_fp=0.05, true_avg_fp=0.05)
+        ibf_file.save_ibf(ibf, flt, cfg, [], [(b, str(b)) for b in range(wl.bins)], wl.bins, wl.rows, wl.hash_funs)
+        out = os.path.join(d, "out")
+        cmd = [binary, "--ibf", ibf, "--single-reads", fq, "--output-prefix", out, "--output-all", "--threads", str(threads),
+               "--rel-cutoff", repr(float(wl.rel_cutoff)), "--rel-filter", "1", "--skip-lca"]
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            raise RuntimeError(f"{binary} rc {p.returncode}: {p.stderr[-300:]}")
+        m = re.search(r"classifying\+printing elapsed \(s\): ([0-9.eE+-]+)", p.stderr)
+        sec = float(m.group(1)) if m else wall
+        # its .all (read id, target, count) against the device's matches of the same reads
+        got = np.loadtxt(out + ".all", dtype=str, delimiter="\t", ndmin=2) if os.path.getsize(out + ".all") else np.zeros((0, 3), dtype=str)
+        theirs = sorted((int(r[0][1:]), int(r[1]), int(r[2])) for r in got)
+        ours = sorted((int(x["read"]), int(x["target"]), int(x["count"])) for x in matches[: int(mo[n])])
+        return {"value": round(n / sec / 1e6, 4), "seconds": round(sec, 3), "process_wall_s": round(wall, 2), "reads": n,
+                "matches": len(theirs), "agrees_with_ours": theirs == ours, "timed_by": "its classifying+printing line" if m else "process wall",
+                "binary": binary}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def cpu_baseline(wl, flt, n_sample: int = 0, gpu_result=None):
     import bench_workload as bw
     import oracle
 
@@ -178,7 +257,7 @@ def cpu_baseline(wl, flt, n_sample: int = 0):
         rate = n / max(dt, 1e-6)
         n_sample = int(min(wl.n_reads, max(200_000, rate * 20.0)))  # ~20 s of CPU work
     n, dt, total = run(n_sample)
-    return {
+    port = {
         "value": round(n / dt / 1e6, 4),
         "unit": "Mreads/s",
         "cores": threads,
@@ -189,3 +268,19 @@ def cpu_baseline(wl, flt, n_sample: int = 0):
                   f"{dt:.1f} s, oracle build: {build}, filter memory: {mem_note}, rows software-prefetched per read; "
                   f"minimiser + bulk_count + select per read (GanonClassify.cpp:676-735), {total} matches",
     }
+    # the real binary when there is one; the port's figure stays beside it
+    binary, why_not = find_reference_classify()
+    if binary and gpu_result is not None:
+        try:
+            nh, mo, matches = gpu_result
+            ref = reference_baseline(binary, wl, flt, nh, mo, matches, min(n, max(100_000, int(port["value"] * 1e6 * 10))), threads)
+            return {"value": ref["value"], "unit": "Mreads/s", "cores": threads, "kind": "reference", "agrees_with_ours": ref["agrees_with_ours"],
+                    "port_value": port["value"],
+                    "sample": f"{ref['binary']} --threads {threads} --output-all on the first {ref['reads']} reads of the same workload (FASTQ) and an .ibf of the "
+                              f"same bits written by this repo's writer: {ref['seconds']} s by {ref['timed_by']} (process wall {ref['process_wall_s']} s), "
+                              f"{ref['matches']} .all lines {'==' if ref['agrees_with_ours'] else '!='} the GPU's matches; the CPU port: {port['value']} Mreads/s"}
+        except Exception as e:  # noqa: BLE001 -- the port's figure is still a baseline
+            port["sample"] += f"; reference binary {binary} failed: {e!r}"[:300]
+    else:
+        port["sample"] += f"; no reference binary ({why_not})" if not binary else ""
+    return port

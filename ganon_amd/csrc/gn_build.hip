@@ -201,3 +201,101 @@ extern "C" int gn_filter_emplace_split(gn_filter* f, const uint64_t* hashes, uin
     }
     return GN_OK;
 }
+
+// ---- gn_filter_probe: the check of the reference's build test (tests/ganon-build/GanonBuild.test.cpp:53-98) on the device ------
+// For every hash: in how many of the given technical bins are all h of its bits set?  hits = the sum over hashes (what the
+// reference compares with hashes.size() after bulk_count: the target's bins' counts added up), missing = hashes that are in
+// none of the bins (a false negative: the filter was not built from this sequence, or it is read with the wrong row / bin
+// arithmetic), first = the smallest index of such a hash.  One lane per hash; h row words per (hash, bin) -- a few MB of
+// gathered words per genome, nothing to tune.
+__global__ void gn_probe_kernel(const uint64_t* __restrict__ rows, uint64_t S, uint32_t W, uint32_t shift, uint32_t h,
+                                const uint64_t* __restrict__ hashes, uint64_t n, const uint32_t* __restrict__ bins, uint32_t n_bins,
+                                uint64_t index_base, unsigned long long* __restrict__ out /* hits, missing, first */)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n)
+        return;
+    uint32_t row[5];
+    for (uint32_t i = 0; i < h; ++i)
+        row[i] = gn_build_row(hashes[q], i, shift, S);
+    uint32_t found = 0;
+    for (uint32_t b = 0; b < n_bins; ++b)
+    {
+        const uint32_t bin = bins[b];
+        uint64_t       all = 1;
+        for (uint32_t i = 0; i < h; ++i)
+            all &= rows[(uint64_t)row[i] * W + (bin >> 6)] >> (bin & 63);
+        found += (uint32_t)(all & 1);
+    }
+    if (found)
+        atomicAdd(out, (unsigned long long)found);
+    else
+    {
+        atomicAdd(out + 1, 1ull);
+        atomicMin(out + 2, (unsigned long long)(index_base + q));
+    }
+}
+
+extern "C" int gn_filter_probe(gn_filter* f, const uint64_t* hashes, uint64_t n, const uint32_t* bins, uint32_t n_bins, uint64_t* hits,
+                               uint64_t* missing, uint64_t* first_missing)
+{
+    if (!f || f->is_hibf)
+        return gn_fail(GN_EINVAL, "gn_filter_probe needs a flat IBF filter");
+    if (!hits || !missing || !first_missing || (n && !hashes) || (n_bins && !bins))
+        return gn_fail(GN_EINVAL, "gn_filter_probe: null argument");
+    *hits = *missing = 0;
+    *first_missing = ~0ull;
+    if (n == 0)
+        return GN_OK;
+    GnIbfHost& ib = f->ibf;
+    for (uint32_t b = 0; b < n_bins; ++b)
+        if (bins[b] >= ib.B)
+            return gn_fail(GN_EINVAL, "gn_filter_probe: bin %u of a filter with %llu bins", bins[b], (unsigned long long)ib.B);
+    GN_HIP(hipSetDevice(f->device));
+    if (!f->load_st)
+        GN_HIP(hipStreamCreateWithFlags(&f->load_st, hipStreamNonBlocking));
+    const uint64_t step = n < (32ull << 20) ? n : (32ull << 20);
+    if (f->emplace_stage_cap < step)
+    {
+        if (f->d_emplace_stage)
+            hipFree(f->d_emplace_stage);
+        f->d_emplace_stage   = nullptr;
+        f->emplace_stage_cap = 0;
+        GN_HIP(hipMalloc(reinterpret_cast<void**>(&f->d_emplace_stage), step * 8));
+        f->emplace_stage_cap = step;
+    }
+    uint32_t*           d_bins = nullptr;
+    unsigned long long* d_out  = nullptr;
+    unsigned long long  init[3] = { 0, 0, ~0ull };
+    hipError_t          e = hipMalloc(reinterpret_cast<void**>(&d_bins), (size_t)(n_bins ? n_bins : 1) * 4);
+    if (e == hipSuccess)
+        e = hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(init));
+    if (e == hipSuccess && n_bins)
+        e = hipMemcpyAsync(d_bins, bins, (size_t)n_bins * 4, hipMemcpyHostToDevice, f->load_st);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_out, init, sizeof(init), hipMemcpyHostToDevice, f->load_st);
+    for (uint64_t done = 0; done < n && e == hipSuccess; done += step)
+    {
+        const uint64_t c = n - done < step ? n - done : step;
+        e = hipMemcpyAsync(f->d_emplace_stage, hashes + done, c * 8, hipMemcpyHostToDevice, f->load_st);
+        if (e != hipSuccess)
+            break;
+        hipLaunchKernelGGL(gn_probe_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, f->load_st, ib.d_rows, ib.S, (uint32_t)ib.W, ib.shift,
+                           ib.h, f->d_emplace_stage, c, d_bins, n_bins, done, d_out);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(f->load_st); // (the staging buffer is reused, and `hashes` may be pageable)
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(init, d_out, sizeof(init), hipMemcpyDeviceToHost);
+    if (d_bins)
+        (void)hipFree(d_bins);
+    if (d_out)
+        (void)hipFree(d_out);
+    if (e != hipSuccess)
+        return gn_fail(GN_ENODEV, "gn_filter_probe: %s", hipGetErrorString(e));
+    *hits          = init[0];
+    *missing       = init[1];
+    *first_missing = init[2];
+    return GN_OK;
+}

@@ -26,7 +26,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_hibf_level_lines", "gn_stream_classify_shared",
                "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
                "gn_peer_stats", "gn_stream_upload_text", "gn_stream_upload_text_pair", "gn_stream_text_pair_index", "gn_stream_text_pair_records2",
-               "gn_ablate", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
+               "gn_ablate", "gn_filter_probe", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -157,6 +157,7 @@ def load_library():
     L.gn_gather_run_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), vp, u32, u32]
     L.gn_stream_device_offsets.argtypes = [vp, C.POINTER(vp)]
     L.gn_ablate.argtypes = [C.c_char_p]
+    L.gn_filter_probe.argtypes = [vp, vp, u64, vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.gn_stream_hibf_levels.argtypes = [vp, C.POINTER(u32), vp, vp, vp, vp, u32]
     L.gn_stream_hibf_level_lines.argtypes = [vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
@@ -376,6 +377,14 @@ class HipFilter:
         bins = np.ascontiguousarray(bins, dtype=np.uint32)
         assert len(hashes) == len(bins)
         _check(load_library().gn_filter_emplace_ibf(self._h, ibf_idx, _p(hashes), _p(bins), len(hashes)))
+
+    def probe(self, hashes: np.ndarray, bins: np.ndarray) -> Tuple[int, int, int]:
+        """gn_filter_probe -> (hits summed over the bins, hashes in none of the bins, index of the first such hash or -1)"""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        bins = np.ascontiguousarray(bins, dtype=np.uint32)
+        hits, missing, first = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(load_library().gn_filter_probe(self._h, _p(hashes), len(hashes), _p(bins), len(bins), C.byref(hits), C.byref(missing), C.byref(first)))
+        return hits.value, missing.value, -1 if first.value == 0xFFFFFFFFFFFFFFFF else first.value
 
     def fill_random(self, seed: int, and_words: int = 1, word_lo: int = 0, row_words_total: int = 0, ibf_idx: int = 0) -> None:
         """device-side seeded Bernoulli(2**-and_words) fill (gn_filter_fill_random); fill_random_words() is its numpy twin"""

@@ -61,6 +61,12 @@ const Opt kOpts[] = {
       "Write .all lines and .rep rows in the order the reference's robin_hood hash maps iterate, instead of ascending target (needs "
       "--threads 1, where the reference's own order is deterministic). Restated from robin_hood 3.11 and libstdc++; UNVERIFIED against a "
       "run of the reference." },
+    { 0, "inspect-filter", Kind::Str,
+      "Parse this .ibf (or .hibf with --hibf) without loading it: print every header field with its offset and every consistency check "
+      "(S*W*8 against the file size, hash_shift, technical bins, map sizes), exit 1 naming the first inconsistent field. No GPU needed." },
+    { 0, "verify-filter", Kind::Str,
+      "With one --ibf: a ganon-build input file (file <tab> target). Every minimiser of every listed file must be found in its target's bins "
+      "(the check of the reference's build test); the first false negative is printed with hash, rows and bits. Exit 1 on any." },
     { 0, "skip-lca", Kind::Bool, "Skip LCA step." },
     { 0, "tax-root-node", Kind::Str, "Define alternative root node for LCA. Default: 1" },
     { 't', "threads", Kind::U16, "Number of threads" },
@@ -262,6 +268,10 @@ std::optional<Config> parse_command_line(int argc, char** argv, int& exit_code)
                 case Kind::Str:
                     if (n == "output-prefix")
                         cfg.output_prefix = value;
+                    else if (n == "inspect-filter")
+                        cfg.inspect_filter = value;
+                    else if (n == "verify-filter")
+                        cfg.verify_filter = value;
                     else
                         cfg.tax_root_node = value;
                     break;

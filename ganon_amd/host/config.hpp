@@ -44,6 +44,9 @@ struct Config
     size_t   n_reads   = 400;  // accepted for compatibility
     bool     verbose = false, quiet = false;
     std::vector<int> devices{ 0 }; // extension: --device 0,1,.. | all (default $GANON_DEVICE or 0); empty = every visible GPU
+    // extensions for a first contact with files written by the reference (filter_io.hpp, verify.cpp); both end the run
+    std::string inspect_filter; // --inspect-filter F [--hibf]: parse the metadata only, print every field and check, no device
+    std::string verify_filter;  // --ibf F --verify-filter refs.tsv: every minimiser of every reference file is in its target's bins
     bool             devices_given = false; // --device / $GANON_DEVICE was used (else --threads decides the workers on GPU 0)
 
     // checks + broadcasting; prints the reference's message to stderr and returns false on the first violation

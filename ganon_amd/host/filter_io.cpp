@@ -30,6 +30,30 @@ struct Reader
     std::ifstream is;
     std::string   path;
     uint64_t      size = 0, pos = 0;
+    std::ostream* trace = nullptr; // --inspect-filter: every named field is printed with its offset as it is read
+
+    template <typename V>
+    void note(uint64_t at, const char* name, const V& value, const char* what = "")
+    {
+        if (!trace)
+            return;
+        std::ostringstream o;
+        o << "@" << at;
+        std::string left = o.str();
+        left.resize(std::max<size_t>(left.size(), 12), ' ');
+        left += name;
+        left.resize(std::max<size_t>(left.size(), 48), ' ');
+        *trace << left << " = " << value << (what[0] ? "   " : "") << what << "\n";
+    }
+    void check(const char* what, bool ok, const std::string& detail = std::string())
+    {
+        if (trace)
+        {
+            std::string left = std::string("check       ") + what;
+            left.resize(std::max<size_t>(left.size(), 72), ' ');
+            *trace << left << (ok ? " ok" : " MISMATCH") << (detail.empty() ? "" : "   ") << detail << "\n";
+        }
+    }
 
     explicit Reader(const std::string& p) : is(p, std::ios::binary), path(p)
     {
@@ -62,10 +86,18 @@ struct Reader
         is.seekg((std::streamoff)pos);
     }
     template <typename T>
-    T get()
+    T get(const char* name = nullptr)
     {
-        T v;
+        const uint64_t at = pos;
+        T              v;
         raw(&v, sizeof(T));
+        if (name)
+        {
+            if constexpr (sizeof(T) == 1)
+                note(at, name, (unsigned)v);
+            else
+                note(at, name, v);
+        }
         return v;
     }
     std::string str()
@@ -93,12 +125,17 @@ struct Reader
 // (all size_t), then the sdsl::bit_vector `data`.
 void read_ibf_fields(Reader& r, IbfShape& m)
 {
-    m.bins           = r.get<uint64_t>();
-    m.technical_bins = r.get<uint64_t>();
-    m.bin_size       = r.get<uint64_t>();
-    m.hash_shift     = r.get<uint64_t>();
-    m.bin_words      = r.get<uint64_t>();
-    m.hash_funs      = r.get<uint64_t>();
+    m.bins           = r.get<uint64_t>("ibf.bins");
+    m.technical_bins = r.get<uint64_t>("ibf.technical_bins");
+    m.bin_size       = r.get<uint64_t>("ibf.bin_size (rows S)");
+    m.hash_shift     = r.get<uint64_t>("ibf.hash_shift");
+    m.bin_words      = r.get<uint64_t>("ibf.bin_words (W)");
+    m.hash_funs      = r.get<uint64_t>("ibf.hash_funs");
+    r.check("bin_words == ceil(bins / 64)", m.bin_words == ((m.bins + 63) >> 6), std::to_string((m.bins + 63) >> 6));
+    r.check("technical_bins == 64 * bin_words", m.technical_bins == m.bin_words * 64, std::to_string(m.bin_words * 64));
+    r.check("hash_shift == countl_zero(bin_size)", m.bin_size != 0 && m.hash_shift == (uint64_t)__builtin_clzll(m.bin_size),
+            m.bin_size ? std::to_string(__builtin_clzll(m.bin_size)) : std::string("bin_size 0"));
+    r.check("hash_funs in 1..5", m.hash_funs >= 1 && m.hash_funs <= 5);
     std::ostringstream why;
     if (m.bins == 0 || m.bin_size == 0)
         why << "empty filter (bins=" << m.bins << ", bin_size=" << m.bin_size << ")";
@@ -123,6 +160,8 @@ void read_ibf_fields(Reader& r, IbfShape& m)
 // Returns with r positioned at the first payload byte.  `exact_len` = -1 when the file size cannot decide.
 void read_bitvector_header(Reader& r, const IbfShape& m, int64_t exact_len)
 {
+    if (r.trace && exact_len >= 0)
+        r.note(r.pos, "bytes between the IBF fields and the payload", exact_len, "(file size - S*W*8 - offset: the bit_vector header must be this long)");
     const uint64_t bits  = m.technical_bins * m.bin_size;
     const uint64_t start = r.pos;
     struct Variant
@@ -146,10 +185,21 @@ void read_bitvector_header(Reader& r, const IbfShape& m, int64_t exact_len)
             (void)r.get<float>();
         const uint64_t size = r.get<uint64_t>();
         if (width == 1 && (size == bits || size * 64 == bits))
+        {
+            if (r.trace)
+            {
+                std::string how = std::string(v.width ? "width byte, " : "") + (v.growth ? "growth factor (float), " : "") + "size (u64) in "
+                                  + (size == bits ? "bits" : "64-bit words");
+                r.note(start, "sdsl bit_vector header", how, "");
+                r.note(start + (uint64_t)len - 8, "bit_vector.size", size);
+                r.check("bit_vector size == technical_bins * bin_size", true, std::to_string(bits) + " bits");
+            }
             return;
+        }
         seen += " [width " + std::to_string(width) + ", size " + std::to_string(size) + "]";
     }
     r.seek(start);
+    r.check("bit_vector size == technical_bins * bin_size", false, "candidates read:" + seen);
     throw std::runtime_error(r.path + ": unexpected sdsl bit_vector header at offset " + std::to_string(start) + " (expected "
                              + std::to_string(bits) + " bits; candidates read:" + seen + ")");
 }
@@ -245,48 +295,62 @@ void stream_matrix(const std::string& path, int fd, uint64_t offset, const IbfSh
         throw std::runtime_error(path + ": " + err);
 }
 
-void load_ibf(const std::string& path, FilterMeta& out, FilterSink& sink)
+// everything of a .ibf but the bits (GanonClassify.cpp:949-986); returns the offset of the first payload byte
+uint64_t parse_ibf(Reader& r, FilterMeta& out)
 {
-    Reader r(path);
+    const std::string& path = r.path;
     out.is_hibf = false;
     int version[3];
+    const uint64_t at0 = r.pos;
     r.raw(version, sizeof(version)); // std::tuple<int,int,int>
+    r.note(at0, "version (tuple<int,int,int>)", std::to_string(version[0]) + "." + std::to_string(version[1]) + "." + std::to_string(version[2]));
     IBFConfig& c     = out.ibf_config;
-    c.n_bins         = r.get<uint64_t>();
-    c.max_hashes_bin = r.get<uint64_t>();
-    c.hash_functions = r.get<uint8_t>();
-    c.kmer_size      = r.get<uint8_t>();
-    c.window_size    = r.get<uint16_t>();
-    c.bin_size_bits  = r.get<uint64_t>();
-    c.max_fp         = r.get<double>();
-    c.true_max_fp    = r.get<double>();
-    c.true_avg_fp    = r.get<double>();
+    c.n_bins         = r.get<uint64_t>("IBFConfig.n_bins");
+    c.max_hashes_bin = r.get<uint64_t>("IBFConfig.max_hashes_bin");
+    c.hash_functions = r.get<uint8_t>("IBFConfig.hash_functions");
+    c.kmer_size      = r.get<uint8_t>("IBFConfig.kmer_size");
+    c.window_size    = r.get<uint16_t>("IBFConfig.window_size");
+    c.bin_size_bits  = r.get<uint64_t>("IBFConfig.bin_size_bits");
+    c.max_fp         = r.get<double>("IBFConfig.max_fp");
+    c.true_max_fp    = r.get<double>("IBFConfig.true_max_fp");
+    c.true_avg_fp    = r.get<double>("IBFConfig.true_avg_fp");
 
     std::vector<std::pair<std::string, uint64_t>> hashes_count;
-    const uint64_t                                nhc = r.count(16);
+    const uint64_t                                at_hc = r.pos;
+    const uint64_t                                nhc   = r.count(16);
     for (uint64_t i = 0; i < nhc; ++i)
     {
         std::string t = r.str();
         uint64_t    n = r.get<uint64_t>();
         hashes_count.emplace_back(std::move(t), n);
     }
+    r.note(at_hc, "hashes_count (vector<tuple<string,u64>>)", nhc,
+           nhc ? ("entries, first: \"" + hashes_count.front().first + "\" -> " + std::to_string(hashes_count.front().second)).c_str() : "entries");
     std::vector<std::pair<uint64_t, std::string>> bin_map;
-    const uint64_t                                nbm = r.count(16);
+    const uint64_t                                at_bm = r.pos;
+    const uint64_t                                nbm   = r.count(16);
     for (uint64_t i = 0; i < nbm; ++i)
     {
         uint64_t    b = r.get<uint64_t>();
         std::string t = r.str();
         bin_map.emplace_back(b, std::move(t));
     }
+    r.note(at_bm, "bin_map (vector<tuple<u64,string>>)", nbm,
+           nbm ? ("entries, first: bin " + std::to_string(bin_map.front().first) + " -> \"" + bin_map.front().second + "\"").c_str() : "entries");
     IbfShape m;
     read_ibf_fields(r, m);
     // the payload is the last thing in the file: whatever precedes it is the bit_vector header
     const uint64_t payload = m.payload_bytes();
+    r.check("payload S*W*8 (+ an 8..13 byte header) fits the bytes left", r.size >= r.pos + 8 + payload,
+            std::to_string(payload) + " payload bytes, " + std::to_string(r.size - r.pos) + " bytes left");
     if (r.size < r.pos + 8 + payload)
         throw std::runtime_error(path + ": truncated (the IBF payload needs " + std::to_string(payload) + " bytes, the file has "
                                  + std::to_string(r.size - r.pos) + " left)");
     read_bitvector_header(r, m, (int64_t)(r.size - r.pos - payload));
     const uint64_t payload_at = r.pos;
+    r.note(payload_at, "payload (S rows of W little-endian words)", payload, "bytes, to the end of the file");
+    r.check("IBFConfig n_bins / bin_size_bits / hash_functions == the stored IBF's", m.bins == c.n_bins && m.bin_size == c.bin_size_bits && m.hash_funs == c.hash_functions);
+    r.check("1 <= kmer_size <= 32, window_size >= kmer_size", !(c.kmer_size == 0 || c.kmer_size > 32 || c.window_size < c.kmer_size));
     if (m.bins != c.n_bins || m.bin_size != c.bin_size_bits || m.hash_funs != c.hash_functions)
         throw std::runtime_error(path + ": IBFConfig (n_bins/bin_size_bits/hash_functions) disagrees with the stored IBF");
     if (c.kmer_size == 0 || c.kmer_size > 32 || c.window_size < c.kmer_size)
@@ -298,6 +362,8 @@ void load_ibf(const std::string& path, FilterMeta& out, FilterSink& sink)
     std::map<std::string, size_t> idx;
     for (auto const& [binno, target] : bin_map)
     {
+        if (binno >= m.bins)
+            r.check("every bin_map entry names a bin < bins", false, "bin " + std::to_string(binno));
         if (binno >= m.bins)
             throw std::runtime_error(path + ": bin_map references bin " + std::to_string(binno) + " >= bins");
         auto it = idx.find(target);
@@ -326,6 +392,26 @@ void load_ibf(const std::string& path, FilterMeta& out, FilterSink& sink)
     }
     out.bin_count = m.bins;
     out.shapes.assign(1, m);
+    if (r.trace)
+    {
+        r.check("every bin_map entry names a bin < bins", true);
+        uint64_t mapped = 0, no_count = 0;
+        for (auto const& b : out.target_bins)
+            mapped += b.size();
+        for (auto const& t : out.targets)
+            no_count += fpr.find(t) == fpr.end();
+        r.note(at_bm, "targets (distinct names in bin_map)", out.targets.size(),
+               (std::to_string(mapped) + " of " + std::to_string(m.bins) + " bins mapped; " + std::to_string(no_count)
+                + " target(s) without a hashes_count entry (fpr 0 then, GanonClassify.cpp:533)").c_str());
+    }
+    return payload_at;
+}
+
+void load_ibf(const std::string& path, FilterMeta& out, FilterSink& sink)
+{
+    Reader         r(path);
+    const uint64_t payload_at = parse_ibf(r, out);
+    const IbfShape m          = out.shapes.at(0);
 
     std::string err;
     if (!sink.begin(out, err))
@@ -338,18 +424,20 @@ void load_ibf(const std::string& path, FilterMeta& out, FilterSink& sink)
         throw std::runtime_error(path + ": " + err);
 }
 
-void load_hibf(const std::string& path, FilterMeta& out, FilterSink& sink)
+// everything of a raptor .hibf but the bits (GanonClassify.cpp:875-938); payload_at[i] = first payload byte of IBF i
+void parse_hibf(Reader& r, FilterMeta& out, std::vector<uint64_t>& payload_at)
 {
-    Reader r(path);
+    const std::string& path = r.path;
     out.is_hibf = true;
-    (void)r.get<uint32_t>();                     // parsed_version
-    const uint64_t window_size = r.get<uint64_t>();
-    const uint64_t shape_size  = r.get<uint64_t>(); // seqan3::shape (dynamic_bitset<58>): size, bits
-    const uint64_t shape_bits  = r.get<uint64_t>();
+    (void)r.get<uint32_t>("raptor index: parsed_version");
+    const uint64_t window_size = r.get<uint64_t>("window_size");
+    const uint64_t shape_size  = r.get<uint64_t>("shape.size (dynamic_bitset<58>)"); // seqan3::shape: size, bits
+    const uint64_t shape_bits  = r.get<uint64_t>("shape.bits");
     (void)shape_size;
-    (void)r.get<uint8_t>(); // parts
-    (void)r.get<uint8_t>(); // compressed
+    (void)r.get<uint8_t>("parts");
+    (void)r.get<uint8_t>("compressed");
     std::vector<std::vector<std::string>> bin_path;
+    const uint64_t                        at_bp = r.pos;
     const uint64_t                        nbp = r.count(8);
     bin_path.resize(nbp);
     for (auto& lst : bin_path)
@@ -359,21 +447,40 @@ void load_hibf(const std::string& path, FilterMeta& out, FilterSink& sink)
         for (auto& s : lst)
             s = r.str();
     }
-    const double fpr = r.get<double>();
-    (void)r.get<uint8_t>(); // is_hibf
+    r.note(at_bp, "bin_path (vector<vector<string>>)", nbp, nbp && !bin_path[0].empty() ? ("lists, first: \"" + bin_path[0][0] + "\"").c_str() : "lists");
+    const double fpr = r.get<double>("fpr");
+    (void)r.get<uint8_t>("is_hibf");
     // hierarchical_interleaved_bloom_filter: ibf_vector, next_ibf_id, user_bins{user_bin_filenames, ibf_bin_to_filename_position}.
     // The tables FOLLOW the matrices: first pass over the IBF headers only (payloads skipped), matrices in a second pass.
-    const uint64_t nibf = r.count(48);
+    const uint64_t nibf = r.get<uint64_t>("ibf_vector.size");
+    if (nibf > (r.size - r.pos) / 48)
+        throw std::runtime_error(path + ": implausible container size " + std::to_string(nibf) + " at offset " + std::to_string(r.pos));
     if (nibf == 0)
         throw std::runtime_error(path + ": HIBF without IBFs");
     out.shapes.resize(nibf);
-    std::vector<uint64_t> payload_at(nibf);
+    payload_at.assign(nibf, 0);
+    std::ostream* const trace = r.trace;
     for (uint64_t i = 0; i < nibf; ++i)
     {
+        if (trace)
+        {
+            r.trace = i < 2 ? trace : nullptr; // (the first two IBFs in full, the rest summarised below)
+            if (r.trace)
+                *trace << "--- ibf_vector[" << i << "]\n";
+        }
         read_ibf_fields(r, out.shapes[i]);
         read_bitvector_header(r, out.shapes[i], -1);
         payload_at[i] = r.pos;
+        r.note(r.pos, "payload", out.shapes[i].payload_bytes(), "bytes");
         r.skip(out.shapes[i].payload_bytes());
+    }
+    r.trace = trace;
+    if (trace)
+    {
+        uint64_t bytes = 0, bmin = UINT64_MAX, bmax = 0;
+        for (auto const& m : out.shapes)
+            bytes += m.payload_bytes(), bmin = std::min(bmin, m.bins), bmax = std::max(bmax, m.bins);
+        *trace << "--- " << nibf << " IBFs parsed, " << bytes << " payload bytes, " << bmin << ".." << bmax << " bins each\n";
     }
     auto read_vv = [&](std::vector<std::vector<int64_t>>& vv) {
         const uint64_t n = r.count(8);
@@ -387,13 +494,18 @@ void load_hibf(const std::string& path, FilterMeta& out, FilterSink& sink)
         }
     };
     read_vv(out.next_ibf_id);
-    const uint64_t           nub = r.count(8);
+    const uint64_t           nub = r.get<uint64_t>("user_bin_filenames.size (user bins)");
+    if (nub > (r.size - r.pos) / 8)
+        throw std::runtime_error(path + ": implausible container size " + std::to_string(nub) + " at offset " + std::to_string(r.pos));
     std::vector<std::string> user_bin_filenames(nub);
     for (auto& s : user_bin_filenames)
         s = r.str();
     read_vv(out.bin_to_user);
+    r.note(r.pos, "end of the archive", r.pos, "");
+    r.check("no bytes left after user_bins", r.pos == r.size, std::to_string(r.size - r.pos) + " left");
     if (r.pos != r.size)
         throw std::runtime_error(path + ": " + std::to_string(r.size - r.pos) + " trailing bytes after the HIBF");
+    r.check("next_ibf_id and ibf_bin_to_filename_position have one entry per IBF", out.next_ibf_id.size() == nibf && out.bin_to_user.size() == nibf);
     if (out.next_ibf_id.size() != nibf || out.bin_to_user.size() != nibf)
         throw std::runtime_error(path + ": next_ibf_id / ibf_bin_to_filename_position do not cover every IBF");
     for (uint64_t i = 0; i < nibf; ++i)
@@ -437,6 +549,19 @@ void load_hibf(const std::string& path, FilterMeta& out, FilterSink& sink)
         if (b[0] >= nub)
             throw std::runtime_error(path + ": bin_path has more entries than user bins");
     out.bin_count = nub;
+    if (r.trace)
+    {
+        r.check("per-bin tables cover every IBF's bins; bin_path entries name user bins", true);
+        r.note(at_bp, "targets (distinct names in bin_path)", out.targets.size(), ("k = popcount(shape) = " + std::to_string((unsigned)out.ibf_config.kmer_size)).c_str());
+    }
+}
+
+void load_hibf(const std::string& path, FilterMeta& out, FilterSink& sink)
+{
+    Reader                r(path);
+    std::vector<uint64_t> payload_at;
+    parse_hibf(r, out, payload_at);
+    const uint64_t nibf = out.shapes.size();
 
     std::string err;
     if (!sink.begin(out, err))
@@ -464,6 +589,37 @@ void load_filter_file(const std::string& path, bool hibf, FilterMeta& meta, Filt
         load_hibf(path, meta, sink);
     else
         load_ibf(path, meta, sink);
+}
+
+bool inspect_filter_file(const std::string& path, bool hibf, std::ostream& out)
+{
+    FilterMeta meta;
+    try
+    {
+        Reader r(path);
+        r.trace = &out;
+        out << "file        " << path << " (" << r.size << " bytes), read as " << (hibf ? "a raptor .hibf (--hibf)" : "a ganon-build .ibf")
+            << "; cereal binary archive, little-endian\n";
+        if (hibf)
+        {
+            std::vector<uint64_t> payload_at;
+            parse_hibf(r, meta, payload_at);
+        }
+        else
+            parse_ibf(r, meta);
+    }
+    catch (const std::exception& e)
+    {
+        out << "result      INCONSISTENT -- first inconsistency: " << e.what() << "\n";
+        return false;
+    }
+    uint64_t bytes = 0;
+    for (auto const& m : meta.shapes)
+        bytes += m.payload_bytes();
+    out << "result      CONSISTENT: " << (hibf ? "HIBF" : "IBF") << ", k=" << (unsigned)meta.ibf_config.kmer_size << " w=" << meta.ibf_config.window_size << ", "
+        << meta.shapes.size() << " IBF(s), " << meta.bin_count << (hibf ? " user bins, " : " bins, ") << meta.targets.size() << " targets, " << bytes
+        << " bytes of bits (not read)\n";
+    return true;
 }
 
 std::map<std::string, TaxNode> load_tax(const std::string& path)

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <cstdint>
+#include <iosfwd>
 #include <map>
 #include <string>
 #include <vector>
@@ -75,6 +76,12 @@ public:
 // Parse `path` (.ibf, or .hibf when `hibf`), fill `meta`, stream the bits into `sink`.  Throws std::runtime_error
 // with a descriptive message on malformed input or when the sink reports an error.
 void load_filter_file(const std::string& path, bool hibf, FilterMeta& meta, FilterSink& sink);
+
+// `ganon-classify --inspect-filter`: parse the file's metadata only (no device, no bits), print every header field with its
+// offset and every redundancy check (technical_bins == 64*bin_words, hash_shift == countl_zero(bin_size), the bit_vector
+// header variant, S*W*8 against the bytes left, map sizes); false -- with the first inconsistent field named -- when the file
+// is not what load_filter_file would accept.  First contact with a file written by SeqAn3 / raptor starts here.
+bool inspect_filter_file(const std::string& path, bool hibf, std::ostream& out);
 
 // GanonClassify.cpp:940-947
 double false_positive(uint64_t bin_size_bits, uint8_t hash_functions, uint64_t n_hashes);

@@ -352,6 +352,12 @@ int gn_reassign_free(gn_reassign* g);
  * run of bins with equal shares, create_bin_map_hash (:619-653) + build (:655-698). */
 int gn_stream_distinct_hashes(gn_stream* s, uint64_t* out, uint64_t cap, uint64_t* n_distinct);
 int gn_filter_emplace_split(gn_filter* f, const uint64_t* hashes, uint64_t n, uint32_t first_bin, uint64_t hashes_per_bin);
+/* The membership check of the reference's build test (validate_elements, /root/reference/tests/ganon-build/GanonBuild.test.cpp:53-98:
+ * hash a sequence, bulk_count, add up the counts of its target's bins, compare with the number of hashes) for a flat IBF on the
+ * device: *hits = sum over the n hashes (host memory) of the number of `bins` that contain the hash, *missing = hashes no bin
+ * contains, *first_missing = the smallest index of one (~0 when none).  `ganon-classify --verify-filter` calls it per target. */
+int gn_filter_probe(gn_filter* f, const uint64_t* hashes, uint64_t n, const uint32_t* bins, uint32_t n_bins, uint64_t* hits,
+                    uint64_t* missing, uint64_t* first_missing);
 
 /* Parity / debugging taps (tests only): minimiser hashes of the resident batch in emission order
  * (hash_off[n_reads+1]; hashes[cap]) and dense per-bin counts of reads [read_begin, read_end)

@@ -4,6 +4,9 @@
 // tests/host_oracle/ganon-classify-oracle; the product binary links ganon_amd/host/backend_hip.cpp instead.
 #include "../../ganon_amd/host/backend.hpp"
 #include "../../oracle/ganon_oracle.h"
+#include "../../ganon_amd/host/config.hpp"
+
+#include <iostream>
 
 #include <algorithm>
 #include <atomic>
@@ -321,5 +324,15 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
     for (size_t i = 0; i < std::max<size_t>(devices.size(), 1); ++i)
         out.emplace_back(new OracleBackend());
     return out;
+}
+} // namespace gnhost
+
+namespace gnhost
+{
+// main.cpp's --verify-filter lives in verify.cpp (device lookups through libganon_hip.so); the checker binary has no device
+bool verify_filter(const Config&)
+{
+    std::cerr << "--verify-filter needs the HIP backend (ganon-classify), not the test checker" << std::endl;
+    return false;
 }
 } // namespace gnhost

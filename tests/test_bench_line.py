@@ -88,3 +88,20 @@ def test_real_run_ends_with_a_short_parsable_line():
     r = line["roofline"]
     assert 0 < r["frac"] and 0 < r["frac_fetched"] and r["algo_over_peak"] >= r["frac_fetched"] * 0.99
     assert os.path.exists(os.path.join(ROOT, "bench_detail.json"))
+
+
+@pytest.mark.gpu
+def test_reference_binary_leg_with_our_binary_standing_in():
+    # a real ganon-classify on PATH is timed on the same reads and an .ibf of the same bits, its .all diffed with the
+    # GPU's matches, and reported as kind "reference".  No SeqAn3 build exists in this image: $GANON_REFERENCE_CLASSIFY points the
+    # probe at this repo's binary, which takes the same command line and prints the same timing line.
+    import bench_cpu
+    assert bench_cpu.find_reference_classify()[0] is None or "mi355x" not in bench_cpu.find_reference_classify()[0]
+    env = dict(os.environ, GANON_REFERENCE_CLASSIFY=os.path.join(ROOT, "ganon_amd", "host", "ganon-classify"))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-e2e", "--no-extra"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.splitlines()[-1])
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "reference" and cb["agrees_with_ours"] is True and cb["value"] > 0 and cb["port_value"] > 0, cb
+    assert "--threads" in cb["sample"] and "== the GPU's matches" in cb["sample"]
