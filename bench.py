@@ -72,13 +72,20 @@ WORKLOADS = {
     # raptor-like layout: log-normal user-bin sizes -> split user bins at the top, merged bins of different cardinality, children of 2 ... 1024
     # technical bins with different numbers of rows, three levels; Bernoulli(3/8) bits (p^h = 0.053); a tenth of the reads descends into two children
     "hibf64k_skew": dict(kind="hibf", skew=True, user_bins=65536, h=3, reads=10_000_000, paired=False, config=2),
+    # The HIBF at the reference's own defaults: `ganon build --filter-type hibf` passes --max-fp 0.001 --hash-functions 4 to raptor
+    # (/root/reference/src/ganon/config.py:140-143,1258-1260, build_update.py:487-489): h = 4, bits Bernoulli(3/16) (0.1875^4 = 0.0012),
+    # the uniform 256 x 256 tree and the raptor-like skewed one.  The h=3 workloads above are 50 x that false-positive rate.
+    "hibf64k_p001": dict(kind="hibf", user_bins=65536, tmax=256, rows=1 << 20, h=4, fill="3/16", reads=10_000_000, paired=False, config=2),
+    "hibf64k_skew_p001": dict(kind="hibf", skew=True, user_bins=65536, h=4, fill="3/16", reads=10_000_000, paired=False, config=2),
+    "hibf_p001_tiny": dict(kind="hibf", user_bins=4096, tmax=64, rows=1 << 12, h=4, fill="3/16", reads=100_000, paired=False, config=None),
+    "hibf_skew_p001_tiny": dict(kind="hibf", skew=True, user_bins=8192, h=4, fill="3/16", reads=100_000, paired=False, config=None, rows_scale=0.01),
     "hibf_skew_tiny": dict(kind="hibf", skew=True, user_bins=8192, h=3, reads=100_000, paired=False, config=None, rows_scale=0.01),
     "hibf_tiny": dict(kind="hibf", user_bins=4096, tmax=64, rows=1 << 12, h=3, reads=100_000, paired=False, config=None),
     "flat128g": dict(kind="flat", bins=32768, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=3),
     "slice1t": dict(kind="slice", bins=32768, slices=8, rows=1 << 25, h=4, reads=12_500_000, paired=True, config=4),
     "slice_tiny": dict(kind="slice", bins=4096, slices=8, rows=1 << 14, h=4, reads=100_000, paired=True, config=None),
 }
-EXTRA_WORKLOADS = ["hibf64k", "hibf64k_top1g", "hibf64k_skew", "flat128g", "slice1t"]   # N = 1: child processes
+EXTRA_WORKLOADS = ["hibf64k", "hibf64k_p001", "hibf64k_skew", "hibf64k_skew_p001", "flat128g", "slice1t"]   # N = 1: child processes
 EXTRA_WORKLOADS_MULTI = ["flat128g", "slice1t"]                           # N > 1: in this job (BASELINE's scaling configs)
 
 # What a random gather of 128-byte lines reaches on MI355X by residency of the table (scripts/calib_gather.hip, measured:
@@ -155,7 +162,7 @@ def compact_line(result: dict) -> dict:
            "oracle_mismatching_reads": c.get("oracle_mismatching_reads", chk.get("mismatching_reads"))}
     extra = []   # (name, scalar), in order of importance; cut at 20
     extra.append(("oracle_reads_checked", chk.get("reads_checked")))
-    for k in ("mean_minimisers_per_read", "classified_reads_rank0", "matches_rank0", "match_checksum_all_ranks"):
+    for k in ("mean_minimisers_per_read", "match_checksum_all_ranks"):
         extra.append((k, c.get(k)))
     km = c.get("kernel_ms") or {}
     extra.append(("minimiser_ms", km.get("minimiser")))
@@ -166,6 +173,9 @@ def compact_line(result: dict) -> dict:
             extra.append((f"{w}_error", _short(o["error"], 80)))
             continue
         extra.append((f"{w}_{str(o.get('unit', 'Mreads/s')).replace('/s', '_s').lower()}", o.get("value")))
+        low = (o.get("variants") or {}).get("low_cutoff_device_filter_matches")
+        if low:   # the binary's --rel-cutoff 0.2 under the wrapper's filter rules
+            extra.append((f"{w}_cutoff0.2_mreads_s", low.get("mreads_per_s")))
     bad_extra = sum(int(((o.get("config") or {}).get("oracle_spot_check") or {}).get("mismatching_reads") or 0)
                     for o in result.get("other_workloads") or [] if "error" not in o)
     if result.get("other_workloads"):
@@ -230,9 +240,12 @@ def emit(result: dict, write_files: bool = True) -> None:
 
 
 def slim(name: str, r: dict, wall: float) -> dict:
-    return {"workload": name, "value": r["value"], "unit": r["unit"], "n_gpus": r["n_gpus"], "scaling": r["scaling"],
-            "ms_per_step": r["ms_per_step"], "steps": r["steps"], "config": r["config"], "roofline": r["roofline"],
-            "wall_s": round(wall, 1)}
+    out = {"workload": name, "value": r["value"], "unit": r["unit"], "n_gpus": r["n_gpus"], "scaling": r["scaling"],
+           "ms_per_step": r["ms_per_step"], "steps": r["steps"], "config": r["config"], "roofline": r["roofline"],
+           "wall_s": round(wall, 1)}
+    if r.get("variants"):
+        out["variants"] = r["variants"]
+    return out
 
 
 def main() -> int:
@@ -292,7 +305,8 @@ def main() -> int:
         part = None
         if kind == "hibf" and spec.get("skew"):
             wl, flt = bw.make_hibf_skew_device_workload(ganon_amd, name, spec["user_bins"], spec["h"], n_reads, rel_cutoff=args.rel_cutoff, seed=42,
-                                                        shard=rank, device=dev_index, rows_scale=spec.get("rows_scale", 1.0))
+                                                        shard=rank, device=dev_index, rows_scale=spec.get("rows_scale", 1.0),
+                                                        fill=ganon_amd.FILL_3_OF_16 if spec.get("fill") == "3/16" else 0)
             off2 = None
             lay = wl.layout
             desc = (f"{lay['depth']}-level HIBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU, {spec['user_bins']} user bins of log-normal size: top IBF "
@@ -304,7 +318,8 @@ def main() -> int:
         elif kind == "hibf":
             rows_top = spec.get("rows_top", rows) if not (headline and args.rows) else rows
             wl, flt = bw.make_hibf_device_workload(ganon_amd, name, spec["user_bins"], spec["tmax"], rows_top, rows, spec["h"],
-                                                   n_reads, rel_cutoff=args.rel_cutoff, seed=42, shard=rank, device=dev_index)
+                                                   n_reads, rel_cutoff=args.rel_cutoff, seed=42, shard=rank, device=dev_index,
+                                                   fill=ganon_amd.FILL_3_OF_16 if spec.get("fill") == "3/16" else 1)
             off2 = None
             desc = (f"2-level HIBF {wl.filter_bytes / 2**30:.2f} GiB replicated per GPU: top IBF {spec['tmax']} merged bins -> "
                     f"{spec['tmax']} child IBFs x {spec['user_bins'] // spec['tmax']} user bins = {spec['user_bins']} user bins, "
@@ -473,7 +488,7 @@ def main() -> int:
                              f", h={spec['h']}, k={wl.k} w={wl.w}, {n_reads} synthetic {unit_name} per GPU, rel_cutoff={args.rel_cutoff}"),
                 "workload_detail": f"{desc}, k={wl.k} w={wl.w}, {n_reads} synthetic "
                                    f"{unit_name} per GPU (50% cut from {4096} planted genomes), rel_cutoff={args.rel_cutoff}, seeded "
-                                   f"{'Bernoulli(3/8)' if spec.get('skew') else 'Bernoulli(0.5)'} fill generated on the device, seed 42",
+                                   f"{'Bernoulli(3/16)' if spec.get('fill') == '3/16' else 'Bernoulli(3/8)' if spec.get('skew') else 'Bernoulli(0.5)'} fill generated on the device, seed 42",
                 "reads_per_gpu": n_reads,
                 "parallelism": (f"bin-range partitioned x{world} of {spec.get('slices')} slices" if kind == "slice"
                                 else f"read-sharded x{world}, filter replicated"),
@@ -533,15 +548,19 @@ def main() -> int:
             result["variants"] = variants
             step(args.rel_cutoff)  # leave the headline batch in the stream for the checks below
 
-        if headline and not args.no_variants and kind == "hibf" and os.environ.get("GANON_BENCH_HIBF_LOW_CUTOFF"):
-            # A/B on request (needs --reads <= 500000: 3 000 chance matches per read at this cutoff): --rel-cutoff 0.2 plain, with the
-            # filter_matches pre-pass judging every pair after the sort, and with the pairs it is bound to drop left out of the sort
+        p001 = kind == "hibf" and spec.get("fill") == "3/16"
+        if kind == "hibf" and (p001 or (headline and not args.no_variants and os.environ.get("GANON_BENCH_HIBF_LOW_CUTOFF"))):
+            # The binary's own --rel-cutoff 0.2, plain and under the filter rules `ganon classify` passes.  At the reference's HIBF defaults
+            # (p^h = 0.0012) chance matches are rare and this always runs; on the h = 3 / p^h = 0.05..0.125 workloads it is an A/B on request
+            # (needs --reads <= 500000: 3 000 chance matches per read there): --rel-cutoff 0.2 plain, with the filter_matches pre-pass judging
+            # every pair after the sort, and with the pairs it is bound to drop left out of the sort
             variants = {}
-            small = n_reads <= 500_000   # (without the pre-pass the RESULT of 10 M reads is 27 G matches = 330 GB: only the pre-pass run fits)
+            small = p001 or n_reads <= 500_000   # (h = 3 without the pre-pass: the RESULT of 10 M reads is 27 G matches = 330 GB: only the pre-pass run fits)
             if small:
                 _, cms, _, tms, tmv = timed(0.2, 3, 1)
-                variants["rel_cutoff_0.2"] = dict(ms_per_step=round(float(np.mean(tms)), 3), matches=int(tmv["n_matches"]))
-            st.set_postfilter(0.1, 1e-5, np.full(spec["user_bins"], 0.05, dtype=np.float64))
+                variants["rel_cutoff_0.2"] = dict(ms_per_step=round(float(np.mean(tms)), 3), matches=int(tmv["n_matches"]),
+                                                  mreads_per_s=round(n_reads / float(np.mean(tms)) / 1e3, 2))
+            st.set_postfilter(0.1, 1e-5, np.full(spec["user_bins"], 0.001 if p001 else 0.05, dtype=np.float64))
             for tag, env in ((("every_pair_sorted", "1"),) if small else ()) + (("device_filter_matches", None),):
                 with ganon_amd.ablate("predrop" if env else ""):
                     _, cms, _, tms, tmv = timed(0.2, 3 if small else 2, 1)

@@ -388,8 +388,10 @@ def make_hibf_workload(hip, name: str, n_user_bins: int, tmax: int, rows_top: in
 def make_hibf_device_workload(hip, name: str, n_user_bins: int, tmax: int, rows_top: int, rows_child: int, hash_funs: int,
                               n_reads: int, read_len: int = 150, k: int = 19, w: int = 31, rel_cutoff: float = 0.75,
                               planted_fraction: float = 0.5, genome_len: int = 3000, n_genomes: int = 4096, seed: int = 42,
-                              shard: int = 0, device: int = 0):
-    """Same 2-level HIBF as make_hibf_workload, but built on the device: every IBF is allocated empty, filled by
+                              shard: int = 0, device: int = 0, fill: int = 1):
+    """`fill` = gn_filter_fill_random's and_words code: 1 = Bernoulli(1/2), hip.FILL_3_OF_16 = the density of an HIBF at the reference's
+    defaults (--max-fp 0.001, four hash functions).
+    Same 2-level HIBF as make_hibf_workload, but built on the device: every IBF is allocated empty, filled by
     gn_filter_fill_random (seed + ibf index) and the genomes' minimisers are emplaced with gn_filter_emplace_ibf.
     Returns (workload, filter); workload.ibfs holds (None, bins, rows, h) until download_hibf() fetches the bits."""
     per_child = n_user_bins // tmax
@@ -402,7 +404,7 @@ def make_hibf_device_workload(hip, name: str, n_user_bins: int, tmax: int, rows_
     b2u = [np.full(tmax, -1, dtype=np.int64)] + [np.arange(c * per_child, (c + 1) * per_child, dtype=np.int64) for c in range(tmax)]
     flt = hip.HipFilter.hibf(ibfs, next_ids, b2u, n_user_bins, device=device)
     for i in range(len(ibfs)):
-        flt.fill_random(seed + i, 1, ibf_idx=i)
+        flt.fill_random(seed + i, fill, ibf_idx=i)
     st = hip.HipStream(flt, n_genomes, n_genomes * genome_len)
     st.upload(rd.genomes.reshape(-1), np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(genome_len), None)
     st.minimisers(k, w)
@@ -524,8 +526,9 @@ def skew_layout(n_user_bins: int, seed: int, top_bins: int = 512, n_top_split: i
 
 def make_hibf_skew_device_workload(hip, name: str, n_user_bins: int, hash_funs: int, n_reads: int, read_len: int = 150, k: int = 19, w: int = 31,
                                    rel_cutoff: float = 0.75, planted_fraction: float = 0.5, genome_len: int = 3000, n_genomes: int = 4096,
-                                   seed: int = 42, shard: int = 0, device: int = 0, rows_scale: float = 1.0):
-    """-> (HibfWorkload, HipFilter); workload.layout = skew_layout's summary.  rows_scale < 1 shrinks every IBF (dry runs, tests)."""
+                                   seed: int = 42, shard: int = 0, device: int = 0, rows_scale: float = 1.0, fill: int = 0):
+    """`fill`: gn_filter_fill_random's code, 0 = hip.FILL_3_OF_8 (p^3 = 0.053), hip.FILL_3_OF_16 for the reference's HIBF defaults (p^4 = 0.0012).
+    -> (HibfWorkload, HipFilter); workload.layout = skew_layout's summary.  rows_scale < 1 shrinks every IBF (dry runs, tests)."""
     shapes, nxt, b2u, paths, summary = skew_layout(n_user_bins, seed)
     shapes = [(b, max(1031, int(r * rows_scale)) | 1) for b, r in shapes]
     rd = make_device_flat_workload(name, 64, 64, hash_funs, n_reads, False, read_len, k, w, rel_cutoff, planted_fraction, genome_len, n_genomes,
@@ -534,8 +537,9 @@ def make_hibf_skew_device_workload(hip, name: str, n_user_bins: int, hash_funs: 
     next_ids = [np.asarray(a, dtype=np.int64) for a in nxt]
     bin_user = [np.asarray(a, dtype=np.int64) for a in b2u]
     flt = hip.HipFilter.hibf(ibfs, next_ids, bin_user, n_user_bins, device=device)
+    fill = fill or hip.FILL_3_OF_8
     for i in range(len(ibfs)):
-        flt.fill_random(seed + i, hip.FILL_3_OF_8, ibf_idx=i)
+        flt.fill_random(seed + i, fill, ibf_idx=i)
     # genomes -> user bins: the first ones are the huge split user bins of the top level, the others spread over the rest; every fifth one
     # also lives in a second user bin (another strain of it) somewhere else in the tree
     grng = np.random.default_rng([seed, 8])
@@ -566,5 +570,6 @@ def make_hibf_skew_device_workload(hip, name: str, n_user_bins: int, hash_funs: 
     wl.planted_genome = rd.planted_genome
     wl.genome_user_bin = g_user
     wl.genome_second_user_bin = second
-    wl.layout = dict(summary, filter_gib=round(fbytes / 2**30, 2), genomes_in_two_user_bins=len(second), fill="Bernoulli(3/8)")
+    wl.layout = dict(summary, filter_gib=round(fbytes / 2**30, 2), genomes_in_two_user_bins=len(second),
+                     fill="Bernoulli(3/16)" if fill == hip.FILL_3_OF_16 else "Bernoulli(3/8)")
     return wl, flt

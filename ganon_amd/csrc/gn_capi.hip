@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void gn_fill_random_kernel(uint64_t* __restric
     const uint64_t total  = S * W;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t       keys[8];
-    for (uint32_t a = 0; a < (and_words == GN_FILL_3_OF_8 ? 3u : and_words); ++a)
+    for (uint32_t a = 0; a < (and_words == GN_FILL_3_OF_8 ? 3u : and_words == GN_FILL_3_OF_16 ? 4u : and_words); ++a)
         keys[a] = gn_mix64(seed + a);
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride)
     {
@@ -765,6 +765,8 @@ __global__ __launch_bounds__(256) void gn_fill_random_kernel(uint64_t* __restric
         uint64_t       v = ~0ULL;
         if (and_words == GN_FILL_3_OF_8) // a & (b | c): density 3/8, i.e. p^3 = 0.053 for three hash functions
             v = gn_mix64(keys[0] + g) & (gn_mix64(keys[1] + g) | gn_mix64(keys[2] + g));
+        else if (and_words == GN_FILL_3_OF_16) // a & b & (c | d): density 3/16, i.e. p^4 = 0.0012 for four hash functions
+            v = gn_mix64(keys[0] + g) & gn_mix64(keys[1] + g) & (gn_mix64(keys[2] + g) | gn_mix64(keys[3] + g));
         else
             for (uint32_t a = 0; a < and_words; ++a)
                 v &= gn_mix64(keys[a] + g);
@@ -780,8 +782,8 @@ extern "C" int gn_filter_fill_random(gn_filter* f, uint32_t ibf_idx, uint64_t se
     GnIbfHost* ib = gn_filter_ibf(f, ibf_idx);
     if (!ib)
         return GN_EINVAL;
-    if ((and_words < 1 || and_words > 8) && and_words != GN_FILL_3_OF_8)
-        return gn_fail(GN_EINVAL, "and_words must be 1..8 (or GN_FILL_3_OF_8)");
+    if ((and_words < 1 || and_words > 8) && and_words != GN_FILL_3_OF_8 && and_words != GN_FILL_3_OF_16)
+        return gn_fail(GN_EINVAL, "and_words must be 1..8 (or GN_FILL_3_OF_8 / GN_FILL_3_OF_16)");
     if (row_words_total == 0)
         row_words_total = ib->W;
     if (word_lo + ib->W > row_words_total)

@@ -12,6 +12,7 @@ _LIB_PATH = os.environ.get("GANON_HIP_LIB") or os.path.join(_HERE, "csrc", "libg
 
 READ_OK, READ_SMALL, READ_BIG = 0, 1, 2
 FILL_3_OF_8 = 0x38  # gn_filter_fill_random: density 3/8 (GN_FILL_3_OF_8)
+FILL_3_OF_16 = 0x3F  # density 3/16: m0 & m1 & (m2 | m3) (GN_FILL_3_OF_16)
 MATCH_DTYPE = np.dtype([("read", "<u4"), ("target", "<u4"), ("count", "<u4")])
 
 # every symbol include/ganon_hip.h declares (tests check the library exports all of them)
@@ -214,9 +215,11 @@ def fill_random_words(seed: int, rows: np.ndarray, n_words: int, and_words: int 
     with np.errstate(over="ignore"):
         g = (rows * total + np.uint64(word_lo) + np.arange(n_words, dtype=np.uint64)[None, :]) * np.uint64(0x9E3779B97F4A7C15)
         v = np.full(g.shape, np.uint64(0xFFFFFFFFFFFFFFFF))
-        key = [_mix64(np.array([(seed + a) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0] for a in range(3 if and_words == FILL_3_OF_8 else and_words)]
+        key = [_mix64(np.array([(seed + a) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0] for a in range(3 if and_words == FILL_3_OF_8 else 4 if and_words == FILL_3_OF_16 else and_words)]
         if and_words == FILL_3_OF_8:
             v = _mix64(key[0] + g) & (_mix64(key[1] + g) | _mix64(key[2] + g))
+        elif and_words == FILL_3_OF_16:
+            v = _mix64(key[0] + g) & _mix64(key[1] + g) & (_mix64(key[2] + g) | _mix64(key[3] + g))
         else:
             for a in range(and_words):
                 v &= _mix64(key[a] + g)

@@ -328,3 +328,62 @@ def test_hibf_skewed_layout_fullsize():
     _check_against_oracle_hibf(wl, flt, nh, mo, m, 600, 5)
     st.destroy()
     flt.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[2] at the REFERENCE'S HIBF defaults (bench.py: hibf64k_p001 / hibf64k_skew_p001): `ganon build --filter-type hibf` hands raptor
+# --max-fp 0.001 and four hash functions (/root/reference/src/ganon/config.py:140-143,1258-1260, build_update.py:487-489) -> h = 4, bits
+# Bernoulli(3/16) (0.1875^4 = 0.0012), both layouts, at --rel-cutoff 0.75 and at the binary's 0.2 under the wrapper's filter rules.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["uniform", "skew"])
+def test_hibf_at_the_references_defaults_fullsize(layout):
+    import ganon_amd
+    n = int(os.environ.get("GANON_FULLSIZE_HIBF_READS", 10_000_000))
+    if layout == "skew":
+        wl, flt = bw.make_hibf_skew_device_workload(ganon_amd, "hibf64k_skew_p001", 65536, 4, n, seed=99, fill=ganon_amd.FILL_3_OF_16)
+        assert wl.layout["fill"] == "Bernoulli(3/16)"
+    else:
+        wl, flt = bw.make_hibf_device_workload(ganon_amd, "hibf64k_p001", 65536, 256, HIBF_ROWS, HIBF_ROWS, 4, n, seed=99, fill=ganon_amd.FILL_3_OF_16)
+    assert flt.info()["n_targets"] == 65536
+    st = ganon_amd.HipStream(flt, n, wl.bases.size, n * 2)
+    st.upload(wl.bases, wl.off, None)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    nh, status, mo, m = st.fetch()
+    cnt = np.diff(mo.astype(np.int64))
+    pl = np.nonzero(wl.planted_genome >= 0)[0]
+    assert (cnt[pl] >= 1).all()
+    # at p^h = 0.0012 a random read matches nothing at 0.75: the matches are the planted ones (one or, for a genome in two user bins, two)
+    not_pl = np.nonzero(wl.planted_genome < 0)[0]
+    assert cnt[not_pl].sum() == 0 and cnt[pl].max() <= 3
+    ck = bw.checksum_matches(m)
+    st.classify(wl.k, wl.w, wl.rel_cutoff)
+    assert bw.checksum_matches(st.fetch()[3]) == ck
+    _check_against_oracle_hibf(wl, flt, nh, mo, m, 600, 5)
+    # the binary's own cutoff 0.2 (T ~ 4 of 17.5 minimisers): plain, then with the device pre-pass of filter_matches under the wrapper's rules
+    # (--rel-filter 0.1 --fpr-query 1e-5, user-bin fpr 0.001).  The raw pair count stays within a few per read -- at h = 3 / p^h = 0.05 it
+    # was 2 700 per read -- so one pass sorts it; dropped + survivors = the plain run's matches; the switches change nothing.
+    wl.rel_cutoff = 0.2
+    st.classify(wl.k, wl.w, 0.2)
+    nh2, _, mo2, m2 = st.fetch()
+    assert len(m2) < 4 * n and len(m2) >= len(m)
+    _check_against_oracle_hibf(wl, flt, nh2, mo2, m2, 600, 6)
+    st.set_postfilter(0.1, 1e-5, np.full(65536, 0.001))
+    res = []
+    for sw in (None, "predrop", "hibf_pack"):
+        if sw:
+            gu.SW.on(sw)
+        st.classify(wl.k, wl.w, 0.2)
+        _, _, mo3, m3 = st.fetch()
+        mx, d_fil, d_fpr = st.fetch_postfilter()
+        res.append((bw.checksum_matches(m3), len(m3), d_fil, d_fpr, mo3.copy(), mx.copy()))
+        if sw:
+            gu.SW.off(sw)
+    st.set_postfilter(None)
+    assert res[0][1] + res[0][2] + res[0][3] == len(m2)
+    for r in res[1:]:
+        assert r[:4] == res[0][:4] and np.array_equal(r[4], res[0][4]) and np.array_equal(r[5], res[0][5])
+    # per-level line bytes are reported (bench.py prints them against the gather roof)
+    levels = st.hibf_levels()
+    assert len(levels) >= 2 and all(lv["line_bytes"] >= lv["algo_bytes"] > 0 for lv in levels[:2])
+    st.destroy()
+    flt.free()
