@@ -99,6 +99,15 @@ struct GnHibfLevelParams
     const uint8_t*            status;
     const unsigned long long* work_base; // packed kernel: its items begin at work_in[*work_base] (a class of the level's sorted list); nullptr = 0
     uint32_t                  pack_gp;   // packed kernel: log2 of the lanes per row every item of the launch must have
+    // packed kernel, ONE launch for a level whose queue was sorted by row width: class c (c < n_cls) holds cls_count[c] items from
+    // work_in[cls_base[c]] on, all of cls_gp[c] lanes per row; the persistent waves walk the classes one after the other (n_cls = 0:
+    // the single class described by pack_gp / count_in / work_base)
+    uint32_t                  n_cls;
+    uint8_t                   cls_gp[8];
+    const unsigned long long* cls_count;
+    const unsigned long long* cls_base;
+    unsigned long long*       lvl_bytes; // this level's algorithmic bytes / line bytes (beside the batch totals ctr[2] / ctr[1]): the
+    unsigned long long*       lvl_lines; // per-level figures of gn_stream_hibf_levels need no copy between the levels
     uint32_t                  wide;      // the reference's -DLONGREADS build (value_t = uint32_t): sums do not wrap at 2^16 and reads
                                          // of more than 65535 minimisers (GN_READ_BIG) are counted like the others
 };
@@ -227,7 +236,18 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
     __shared__ uint32_t img_all[4][GN_WAVE * 16]; // per wave: the 16 byte-counter registers of every lane (multi-bin runs)
     const uint32_t lane   = threadIdx.x & (GN_WAVE - 1);
     const uint32_t wave   = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t gpl    = p.pack_gp;
+    const uint32_t stride = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_id = (uint32_t)blockIdx.x * (blockDim.x >> 6) + wave;
+
+    GnHibfAppender     app;
+    unsigned long long my_bytes = 0, my_lines = 0;
+    uint32_t           rot = 0; // batches of the classes before this one (mod the grid's waves): every class starts where the last one ended,
+                                // so a small class does not land on the same few waves as the small class before it
+
+  const uint32_t n_cls = LEVEL0 || p.n_cls == 0 ? 1u : p.n_cls;
+  for (uint32_t cls = 0; cls < n_cls; ++cls)
+  {
+    const uint32_t gpl    = (LEVEL0 || p.n_cls == 0) ? p.pack_gp : (uint32_t)p.cls_gp[cls];
     const uint32_t Gp     = 1u << gpl;
     const uint32_t H      = GN_WAVE >> gpl;          // items per wave
     const uint32_t gl     = lane & (Gp - 1);         // my word of the row
@@ -242,23 +262,20 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
         n_work = p.n_reads;
     else
     {
-        const unsigned long long nw64 = *p.count_in;
+        const unsigned long long nw64 = p.n_cls ? p.cls_count[cls] : *p.count_in;
         n_work                        = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
-        if (p.work_base)
+        if (p.n_cls || p.work_base)
         {
-            work_first = *p.work_base;
+            work_first = p.n_cls ? p.cls_base[cls] : *p.work_base;
             if (work_first + n_work > p.work_cap)
                 n_work = work_first < p.work_cap ? (uint32_t)(p.work_cap - work_first) : 0u;
         }
     }
     const uint32_t n_batches = (n_work + H - 1) / H;
-    const uint32_t stride    = gridDim.x * (blockDim.x >> 6);
-    uint32_t       batch     = (uint32_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    uint32_t       batch     = wave_id >= rot ? wave_id - rot : wave_id + stride - rot;
+    rot                      = (uint32_t)(((uint64_t)rot + n_batches) % stride);
     if (batch >= n_batches)
-        return;
-
-    GnHibfAppender     app;
-    unsigned long long my_bytes = 0, my_lines = 0;
+        continue;
 
     // per-lane view of an item (the Gp lanes of a group hold identical copies)
     struct Item
@@ -531,6 +548,7 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
             break;
         cur = nxt;
     }
+  } // classes
     app.finish(p, (int)lane);
     // one atomic per wave
     for (int off = 32; off >= 1; off >>= 1)
@@ -542,6 +560,8 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
     {
         atomicAdd(&p.ctr[2], my_bytes);
         atomicAdd(&p.ctr[1], my_lines);
+        atomicAdd(p.lvl_bytes, my_bytes);
+        atomicAdd(p.lvl_lines, my_lines);
     }
 }
 
@@ -895,6 +915,8 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
     {
         atomicAdd(&p.ctr[2], my_bytes);
         atomicAdd(&p.ctr[1], my_lines);
+        atomicAdd(p.lvl_bytes, my_bytes);
+        atomicAdd(p.lvl_lines, my_lines);
     }
 }
 
@@ -999,6 +1021,8 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
     {
         atomicAdd(&p.ctr[2], my_bytes);
         atomicAdd(&p.ctr[1], my_lines);
+        atomicAdd(p.lvl_bytes, my_bytes);
+        atomicAdd(p.lvl_lines, my_lines);
     }
 }
 
@@ -1553,7 +1577,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     // tests / A-B: skip the packed kernel (the per-item register kernel takes whole levels), or both (LDS kernel only)
     const bool     no_reg  = gn_sw().hibf_reg;
     const bool     no_pack = no_reg || gn_sw().hibf_pack;
-    const uint32_t reg_bpc = 0u; // workgroups per CU of the register kernels: what the occupancy query says
+    const uint32_t reg_bpc = gn_sw().hibf_bpc; // workgroups per CU of the register kernels: 0 = what the occupancy query says
     // with a filter_matches pre-pass on the stream, what it is bound to drop does not reach the sort
     const bool may_predrop = s->pf_on && !s->pf_merge && s->d_pf_segmin && s->d_pf_rmax && s->pf_rel_filter >= 0.0 && s->pf_rel_filter < 1.0 &&
                              (uint64_t)n + 1 <= s->pf_segmin_cap && !gn_sw().predrop;
@@ -1591,12 +1615,9 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                     GN_HIP(hipEventCreate(&s->ev_lvl[lvl]));
                 GN_HIP(hipEventRecord(s->ev_lvl[lvl], st));
             }
-            if (lvl > 0) // algorithmic bytes so far (cumulative), for the per-level figures
-            {
-                GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (lvl - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
-                GN_HIP(hipMemcpyAsync(s->d_hctr + 4 * NL + 2 + (lvl - 1), s->d_ctr + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
-            }
             GnHibfLevelParams p{};
+            p.lvl_bytes   = s->d_hctr + 3 * NL + lvl;     // (the level's kernels add to their own slots: no copy between the levels)
+            p.lvl_lines   = s->d_hctr + 4 * NL + 2 + lvl;
             p.ibfs        = f->d_hibf;
             p.hashes      = s->v_hashes;
             p.slot_off    = s->v_slot_off;
@@ -1660,14 +1681,28 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                 p.work_in     = s->d_hdefer;
                 p.defer_out   = s->d_hdefer2;
                 p.defer_count = s->d_hctr + NL + lvl;
-                for (size_t c = 0; c < gps.size() && c < 7; ++c)
+                if (!gn_sw().hibf_persistent)
                 {
-                    p.pack_gp   = gps[c];
-                    p.count_in  = bp.cls_count + c;
-                    p.work_base = bp.cls_base + c;
+                    // ONE persistent launch walks the classes of the sorted list one after the other (a launch per width left the chip
+                    // draining five times a level, and the narrow classes took a launch each for a few thousand items)
+                    p.n_cls     = (uint32_t)std::min<size_t>(gps.size(), 7);
+                    for (uint32_t c = 0; c < p.n_cls; ++c)
+                        p.cls_gp[c] = (uint8_t)gps[c];
+                    p.cls_count = bp.cls_count;
+                    p.cls_base  = bp.cls_base;
                     launch_pack();
                     GN_HIP(hipGetLastError());
+                    p.n_cls = 0;
                 }
+                else
+                    for (size_t c = 0; c < gps.size() && c < 7; ++c)
+                    {
+                        p.pack_gp   = gps[c];
+                        p.count_in  = bp.cls_count + c;
+                        p.work_base = bp.cls_base + c;
+                        launch_pack();
+                        GN_HIP(hipGetLastError());
+                    }
                 p.work_base = nullptr;
                 p.work_in   = s->d_hdefer2;
                 p.count_in  = s->d_hctr + NL + lvl;
@@ -1714,12 +1749,16 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
             if (!s->ev_lvl[last])
                 GN_HIP(hipEventCreate(&s->ev_lvl[last]));
             GN_HIP(hipEventRecord(s->ev_lvl[last], st));
-            GN_HIP(hipMemcpyAsync(s->d_hctr + 3 * NL + (depth - 1), s->d_ctr + 2, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
-            GN_HIP(hipMemcpyAsync(s->d_hctr + 4 * NL + 2 + (depth - 1), s->d_ctr + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         }
         GN_HIP(hipMemcpyAsync(s->h_hctr, s->d_hctr, (5 * NL + 2) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         GN_HIP(hipMemcpyAsync(s->h_ctr, s->d_ctr, GN_NCTR * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         GN_HIP(hipStreamSynchronize(st));
+        // per-level byte counts -> cumulative over the levels (what gn_stream_hibf_levels / _level_lines subtract from each other)
+        for (uint32_t l = 1; l < NL - 1; ++l)
+        {
+            s->h_hctr[3 * NL + l] += s->h_hctr[3 * NL + l - 1];
+            s->h_hctr[4 * NL + 2 + l] += s->h_hctr[4 * NL + 2 + l - 1];
+        }
         return GN_OK;
     };
 

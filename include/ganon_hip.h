@@ -134,7 +134,7 @@ int gn_filter_finalize(gn_filter* f);
  * position -- a column slice (word_lo, row_words_total of the whole filter) holds exactly the bits the unsliced
  * filter has there.  Padding bins are cleared.  Not part of the reference's interface.
  * and_words = GN_FILL_3_OF_8: word = m0 & (m1 | m2) with m_a = the mixes above, density 3/8 -- what a Bloom filter built for a
- * false-positive rate of 0.05 with three hash functions looks like (0.375^3 = 0.053). */
+ * false-positive rate of 0.05 with three hash functions looks like (0.375^3 = 0.053).
  * and_words = GN_FILL_3_OF_16: word = m0 & m1 & (m2 | m3), density 3/16 -- an HIBF at the reference's defaults: `ganon build
  * --filter-type hibf` passes --max-fp 0.001 and --hash-functions 4 to raptor (/root/reference/src/ganon/config.py:140-143,
  * 1258-1260, build_update.py:487-489); 0.1875^4 = 0.0012. */

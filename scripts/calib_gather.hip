@@ -9,7 +9,7 @@
 //     counter can be calibrated against the algorithmic bytes for this access pattern.
 //
 //   hipcc --offload-arch=gfx950 -O3 -o scripts/calib_gather scripts/calib_gather.hip
-//   scripts/calib_gather <table MiB> <row bytes: 32|64|128|256|512> <row requests (millions)> [loads in flight per lane = 8] [blocks per CU = 8]
+//   scripts/calib_gather <table MiB> <row bytes: 8|16|32|64|128|256|512> <row requests (millions)> [loads in flight per lane = 8] [blocks per CU = 8]
 // prints one JSON line.
 #include <hip/hip_runtime.h>
 
@@ -126,12 +126,14 @@ int main(int argc, char** argv)
         int rc = 1;
         switch (lpr)
         {
+            case 1: rc = run<1>(U, table, n_rows, trips, sink, blocks, st); break;
+            case 2: rc = run<2>(U, table, n_rows, trips, sink, blocks, st); break;
             case 4: rc = run<4>(U, table, n_rows, trips, sink, blocks, st); break;
             case 8: rc = run<8>(U, table, n_rows, trips, sink, blocks, st); break;
             case 16: rc = run<16>(U, table, n_rows, trips, sink, blocks, st); break;
             case 32: rc = run<32>(U, table, n_rows, trips, sink, blocks, st); break;
             case 64: rc = run<64>(U, table, n_rows, trips, sink, blocks, st); break;
-            default: fprintf(stderr, "row bytes: 32 64 128 256 512\n");
+            default: fprintf(stderr, "row bytes: 8 16 32 64 128 256 512\n");
         }
         if (rc)
             return 1;
