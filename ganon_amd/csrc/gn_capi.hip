@@ -49,7 +49,7 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                               {"predrop", &GnSwitches::predrop},             {"deferred_grids", &GnSwitches::deferred_grids},
                               {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
                               {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent},
-                              {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
+                              {"hibf_fake_hashes", &GnSwitches::hibf_fake_hashes}, {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
                               {"debug", &GnSwitches::debug}};
     for (const char* p = list ? list : ""; *p;)
     {

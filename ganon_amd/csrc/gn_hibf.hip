@@ -106,6 +106,7 @@ struct GnHibfLevelParams
     uint8_t                   cls_gp[8];
     const unsigned long long* cls_count;
     const unsigned long long* cls_base;
+    uint32_t                  fake_hashes;
     unsigned long long*       lvl_bytes; // this level's algorithmic bytes / line bytes (beside the batch totals ctr[2] / ctr[1]): the
     unsigned long long*       lvl_lines; // per-level figures of gn_stream_hibf_levels need no copy between the levels
     uint32_t                  wide;      // the reference's -DLONGREADS build (value_t = uint32_t): sums do not wrap at 2^16 and reads
@@ -373,10 +374,15 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
             uint64_t m[HF];
         };
         const uint64_t hs_at = cur.slot; // (index into p.hashes)
+        const uint64_t fake0 = p.fake_hashes ? p.hashes[n ? hs_at : 0ull] : 0ull;
         auto issue = [&](uint32_t it, Rows& R) {
             // every lane issues its loads unconditionally: finished / invalid items re-read their last (or any) row
             const uint32_t q = n ? (it < n ? it : n - 1) : 0u;
-            const uint64_t v = p.hashes[n ? hs_at + q : 0ull]; // (unconditional: element 0 always exists)
+            uint64_t v;
+            if (p.fake_hashes) // timing experiment: one load per item, the other "hashes" derived from it
+                v = fake0 * (2ull * q + 1ull);
+            else
+                v = p.hashes[n ? hs_at + q : 0ull]; // (unconditional: element 0 always exists)
             uint32_t       row[HF];
             if (share)
             {
@@ -1624,6 +1630,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
             p.n_hashes    = s->v_nh;
             p.rel_cutoff  = s->rel_cutoff;
             p.wide        = s->long_reads ? 1u : 0u;
+            p.fake_hashes = gn_sw().hibf_fake_hashes && lvl > 0 ? 1u : 0u; // (level 0 keeps its real hashes: the lower levels get their real items)
             p.work_in     = s->d_work[lvl & 1];
             p.count_in    = s->d_hctr + lvl;
             p.work_out    = s->d_work[(lvl + 1) & 1];

@@ -43,6 +43,7 @@ struct GnSwitches
     bool hibf_pack = false;       // no packed-items kernel either
     bool hibf_one_pack = false;   // only the level's most common width takes the packed kernel (no sorting by width)
     bool hibf_persistent = false; // one launch per width class instead of one persistent launch per level
+    bool hibf_fake_hashes = false; // TIMING EXPERIMENT ONLY (wrong results): the packed kernel loads one hash per item and derives the others
     uint32_t hibf_bpc = 0;        // >0: workgroups per CU of the HIBF register kernels (0: what the occupancy query says)
     uint64_t hibf_pair_limit = 0; // >0: (read, user bin) pairs per round of a batch (tests make a batch take several rounds)
     // multi-device

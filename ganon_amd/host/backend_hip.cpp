@@ -783,7 +783,16 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
     int                                   n = 0;
     // worker threads BLOCK while they wait for the device instead of spinning (HIP's default): the cores are needed by the
     // parsers and the post pool (2-4 device workers on a 16-core quota: +2 .. +17 % end to end, profiles/r03_e2e_ab_sync.txt)
-    setenv("GANON_HIP_SYNC", "block", 0);
+    // (the library's switches: $GANON_HIP_ABLATE, read once when it was loaded -- a list that names no sync mode gets "sync=block")
+    {
+        const char* e  = std::getenv("GANON_HIP_ABLATE");
+        std::string sw = e ? e : "";
+        if (sw.find("sync=") == std::string::npos)
+        {
+            sw += (sw.empty() ? "" : ",") + std::string("sync=block");
+            (void)gn_ablate(sw.c_str()); // before the first device call (gn_device_count applies the mode)
+        }
+    }
     if (gn_device_count(&n) != GN_OK || n <= 0)
     {
         err = std::string("no usable MI355X/HIP device (") + gn_last_error() + "); ganon-classify has no CPU fallback";

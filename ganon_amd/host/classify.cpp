@@ -23,6 +23,7 @@
 #include "plan.hpp"
 #include "report.hpp"
 #include "seq_io.hpp"
+#include "startup.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -1012,8 +1013,10 @@ static bool ganon_classify(Config config)
     std::vector<int> devices = config.devices;
     if (!config.devices_given)
         devices.assign(std::min<size_t>(4, std::max<size_t>(3, config.threads)), 0);
-    std::string err;
-    auto        backends = make_backends(devices, err);
+    std::string  err;
+    const double t_rt     = StartupLog::now();
+    auto         backends = make_backends(devices, err);
+    StartupLog::get().span("HIP runtime up, devices opened (first device call)", t_rt);
     if (backends.empty())
     {
         std::cerr << "ERROR: " << err << std::endl;
@@ -1108,7 +1111,18 @@ static bool ganon_classify(Config config)
         {
             try
             {
+                const double t_f = StartupLog::now();
                 load_filter_file(level.filters[i].ibf_file, config.hibf, filters[i], sink);
+                {
+                    const LoadTiming& lt = last_load_timing();
+                    char              note[400];
+                    std::snprintf(note, sizeof(note),
+                                  "%.3f GiB: header %.3f s, device allocation %.3f s, page-locking the staging buffers %.3f s, file -> staging %.3f s (%.1f GB/s), "
+                                  "staging -> HBM (waits) %.3f s, finalise %.3f s",
+                                  lt.payload_bytes / 1073741824.0, lt.parse_s, lt.begin_s, lt.staging_s, lt.pread_s,
+                                  lt.pread_s > 0 ? lt.payload_bytes / lt.pread_s / 1e9 : 0.0, lt.sink_s, lt.end_s);
+                    StartupLog::get().span("level " + level.label + ": filter " + std::to_string(i) + " into HBM", t_f, note);
+                }
                 if (!level.filters[i].tax_file.empty())
                     filter_tax[i] = load_tax(level.filters[i].tax_file);
             }
@@ -1274,6 +1288,7 @@ static bool ganon_classify(Config config)
                           << (spec.disjoint_targets ? "disjoint" : "shared between filters") << ")" << std::endl;
         }
 
+        const double t_setup = StartupLog::now();
         loading.start(); // (device-side setup belongs to loading: the reference's agents exist once its filters are read)
         // device streams for the largest batch, and one tiny batch through every worker context: buffers are allocated and the
         // kernels' code is loaded here, not with the first reads (the reader is parsing its first slabs meanwhile)
@@ -1292,6 +1307,9 @@ static bool ganon_classify(Config config)
                 t.join();
         }
         loading.stop();
+        StartupLog::get().span("level " + level.label + ": device streams and the warm-up batch (all worker contexts at once)", t_setup);
+        if (config.verbose)
+            StartupLog::get().print(std::cerr);
         std::vector<ReadBatch> next_carried;
         classifying.start();
         const auto level_t0 = std::chrono::steady_clock::now();

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -252,6 +253,12 @@ void parallel_pread(int fd, uint8_t* dst, uint64_t bytes, uint64_t offset, const
         throw std::runtime_error(path + ": read error / unexpected end of file in the filter payload");
 }
 
+thread_local LoadTiming g_load_timing;
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct Fd
 {
     int fd = -1;
@@ -271,7 +278,10 @@ void stream_matrix(const std::string& path, int fd, uint64_t offset, const IbfSh
     const uint64_t want      = std::min<uint64_t>(total, 256ull << 20);
     const uint64_t per       = std::max<uint64_t>(1, want / row_bytes); // rows per chunk
     const uint64_t cap       = per * row_bytes;
+    const double   t_stage   = now_s();
     uint64_t*      stage[2]  = { sink.staging(0, cap), sink.staging(1, cap) };
+    g_load_timing.staging_s += now_s() - t_stage;
+    g_load_timing.payload_bytes += total;
     std::unique_ptr<uint64_t[]> own[2];
     for (int i = 0; i < 2; ++i)
         if (!stage[i])
@@ -285,14 +295,20 @@ void stream_matrix(const std::string& path, int fd, uint64_t offset, const IbfSh
     {
         const uint64_t n   = std::min(per, m.bin_size - row);
         uint64_t*      buf = stage[chunk & 1];
+        const double t0 = now_s();
         parallel_pread(fd, reinterpret_cast<uint8_t*>(buf), n * row_bytes, offset + row * row_bytes, path);
+        const double t1 = now_s();
+        g_load_timing.pread_s += t1 - t0;
         // the copy of the previous chunk ran while this one was read; it used the OTHER buffer, but the buffer filled
         // next is that one again, so it has to be finished before the next round
         if (!sink.drain(err) || !sink.rows(ibf, row, n, buf, err))
             throw std::runtime_error(path + ": " + err);
+        g_load_timing.sink_s += now_s() - t1;
     }
+    const double t2 = now_s();
     if (!sink.drain(err))
         throw std::runtime_error(path + ": " + err);
+    g_load_timing.sink_s += now_s() - t2;
 }
 
 // everything of a .ibf but the bits (GanonClassify.cpp:949-986); returns the offset of the first payload byte
@@ -409,19 +425,25 @@ uint64_t parse_ibf(Reader& r, FilterMeta& out)
 
 void load_ibf(const std::string& path, FilterMeta& out, FilterSink& sink)
 {
+    const double   t0 = now_s();
     Reader         r(path);
     const uint64_t payload_at = parse_ibf(r, out);
     const IbfShape m          = out.shapes.at(0);
+    const double   t1 = now_s();
+    g_load_timing.parse_s += t1 - t0;
 
     std::string err;
     if (!sink.begin(out, err))
         throw std::runtime_error(path + ": " + err);
+    g_load_timing.begin_s += now_s() - t1;
     Fd fd(path);
     if (fd.fd < 0)
         throw std::runtime_error("cannot open filter file " + path);
     stream_matrix(path, fd.fd, payload_at, m, 0, sink);
+    const double t_end = now_s();
     if (!sink.end(err))
         throw std::runtime_error(path + ": " + err);
+    g_load_timing.end_s += now_s() - t_end;
 }
 
 // everything of a raptor .hibf but the bits (GanonClassify.cpp:875-938); payload_at[i] = first payload byte of IBF i
@@ -560,19 +582,25 @@ void load_hibf(const std::string& path, FilterMeta& out, FilterSink& sink)
 {
     Reader                r(path);
     std::vector<uint64_t> payload_at;
+    const double t0 = now_s();
     parse_hibf(r, out, payload_at);
     const uint64_t nibf = out.shapes.size();
+    const double   t1   = now_s();
+    g_load_timing.parse_s += t1 - t0;
 
     std::string err;
     if (!sink.begin(out, err))
         throw std::runtime_error(path + ": " + err);
+    g_load_timing.begin_s += now_s() - t1;
     Fd fd(path);
     if (fd.fd < 0)
         throw std::runtime_error("cannot open filter file " + path);
     for (uint64_t i = 0; i < nibf; ++i)
         stream_matrix(path, fd.fd, payload_at[i], out.shapes[i], (uint32_t)i, sink);
+    const double t_end = now_s();
     if (!sink.end(err))
         throw std::runtime_error(path + ": " + err);
+    g_load_timing.end_s += now_s() - t_end;
 }
 
 } // namespace
@@ -582,8 +610,14 @@ double false_positive(uint64_t bin_size_bits, uint8_t hash_functions, uint64_t n
     return std::pow(1 - std::exp(-hash_functions / (bin_size_bits / static_cast<double>(n_hashes))), hash_functions);
 }
 
+const LoadTiming& last_load_timing()
+{
+    return g_load_timing;
+}
+
 void load_filter_file(const std::string& path, bool hibf, FilterMeta& meta, FilterSink& sink)
 {
+    g_load_timing = LoadTiming();
     meta = FilterMeta();
     if (hibf)
         load_hibf(path, meta, sink);

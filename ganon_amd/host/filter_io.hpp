@@ -73,6 +73,14 @@ public:
     virtual bool end(std::string& err)   = 0;
 };
 
+// Where the last load_filter_file() of this thread spent its time (`ganon-classify --verbose` prints it under [startup])
+struct LoadTiming
+{
+    double   parse_s = 0, staging_s = 0, pread_s = 0, sink_s = 0, begin_s = 0, end_s = 0;
+    uint64_t payload_bytes = 0;
+};
+const LoadTiming& last_load_timing();
+
 // Parse `path` (.ibf, or .hibf when `hibf`), fill `meta`, stream the bits into `sink`.  Throws std::runtime_error
 // with a descriptive message on malformed input or when the sink reports an error.
 void load_filter_file(const std::string& path, bool hibf, FilterMeta& meta, FilterSink& sink);

@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "filter_io.hpp"
+#include "startup.hpp"
 
 #include <iostream>
 
@@ -15,6 +16,7 @@ bool verify_filter(const Config& config); // verify.cpp
 
 int main(int argc, char** argv)
 {
+    gnhost::StartupLog::get(); // (time zero of the [startup] lines)
     int  exit_code = 0;
     auto config    = gnhost::parse_command_line(argc, argv, exit_code);
     if (!config.has_value())

@@ -4,6 +4,8 @@
 
 #include <ganon_hip.h>
 
+#include "startup.hpp"
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -97,15 +99,18 @@ public:
         if (total == 0)
             return;
         warm_ = std::thread([this, total, block] {
-            for (size_t done = 0; done < total && !stop_; done += block)
+            const double t0 = StartupLog::now();
+            size_t       done = 0;
+            for (; done < total && !stop_; done += block)
             {
                 void* p = nullptr;
                 if (gn_pinned_alloc(block, &p) != GN_OK)
-                    return;
+                    break;
                 std::lock_guard<std::mutex> lk(m_);
                 size_of_[p] = block;
                 free_[block].push_back(p);
             }
+            StartupLog::get().span("page-locking the batch pool (background thread)", t0, std::to_string(done >> 20) + " MiB in 32 MiB blocks");
         });
     }
     // `count` more blocks that hold n bytes each go into the pool (locked now, handed out later)

@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """which HIP runtime the in-process kernels run under: PyTorch's bundled libamdhip64 is mapped first and serves libganon_hip.so
+    too; the product binaries map /opt/rocm's (tests/test_runtime72.py runs the full-size workloads under both)"""
+    try:
+        import torch
+        libs = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+        return [f"HIP runtime mapped by this process: {', '.join(libs) or 'none yet'} (torch {torch.__version__}, hip {torch.version.hip}); "
+                f"the product binaries use /opt/rocm ({os.path.realpath('/opt/rocm')})"]
+    except Exception as e:  # noqa: BLE001
+        return [f"HIP runtime: unknown ({e!r})"]
+
+
 def pytest_collection_modifyitems(config, items):
     # gpu tests are skipped (not failed) when no GPU is visible and the user did not ask for -m gpu
     try:

@@ -51,14 +51,16 @@ def test_filter_of_our_builder_passes_and_wrong_ones_fail(hip, tmp_path):
     open(unknown, "w").write(f"{files[0]}\tnot_there\n")
     rc, out, _ = _verify(ibf, unknown)
     assert rc == 1 and "no such target" in out
-    # (3) the file claims another window size: other minimisers, looked up in vain
-    data = bytearray(open(ibf, "rb").read())
-    assert struct.unpack_from("<H", data, 30)[0] == 32
-    struct.pack_into("<H", data, 30, 35)
-    wrong_w = str(tmp_path / "wrong_w.ibf")
-    open(wrong_w, "wb").write(bytes(data))
-    rc, out, _ = _verify(wrong_w, inp)
-    assert rc == 1 and "first false negative" in out
+    # (3) the file claims another k: other hashes, looked up in vain.  (A LARGER window would pass: the minimisers of a larger window are a
+    # subset of the smaller window's; a smaller one fails like a smaller k.)
+    for at, fmt, was, now in ((29, "<B", 19, 17), (30, "<H", 32, 24)):
+        data = bytearray(open(ibf, "rb").read())
+        assert struct.unpack_from(fmt, data, at)[0] == was
+        struct.pack_into(fmt, data, at, now)
+        wrong = str(tmp_path / f"wrong_{at}.ibf")
+        open(wrong, "wb").write(bytes(data))
+        rc, out, _ = _verify(wrong, inp)
+        assert rc == 1 and "first false negative" in out, (at, out[-500:])
     # (4) one payload byte cleared where a hash of the first file lives: exactly the files that own the bit fail
     from ganon_amd import ibf_file
     m = ibf_file.read_ibf_meta(ibf)
