@@ -48,7 +48,7 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                               {"const_nb", &GnSwitches::const_nb},           {"split_kernel", &GnSwitches::split_kernel},
                               {"predrop", &GnSwitches::predrop},             {"deferred_grids", &GnSwitches::deferred_grids},
                               {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
-                              {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent},
+                              {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent}, {"hibf_stage", &GnSwitches::hibf_stage}, {"hibf_reread", &GnSwitches::hibf_reread},
                               {"hibf_fake_hashes", &GnSwitches::hibf_fake_hashes}, {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
                               {"debug", &GnSwitches::debug}};
     for (const char* p = list ? list : ""; *p;)

@@ -107,6 +107,10 @@ struct GnHibfLevelParams
     const unsigned long long* cls_count;
     const unsigned long long* cls_base;
     uint32_t                  fake_hashes;
+    uint32_t                  reread;
+    uint32_t                  lds_region;   // packed kernel: 8-byte words of dynamic LDS per wave
+    uint32_t                  stage_hashes; // packed kernel: the first GN_HIBF_NQ minimisers of every item are staged in LDS (classes of at
+                                            // most 4 lanes per row; lds_region holds (64 >> narrowest class) items' worth)
     unsigned long long*       lvl_bytes; // this level's algorithmic bytes / line bytes (beside the batch totals ctr[2] / ctr[1]): the
     unsigned long long*       lvl_lines; // per-level figures of gn_stream_hibf_levels need no copy between the levels
     uint32_t                  wide;      // the reference's -DLONGREADS build (value_t = uint32_t): sums do not wrap at 2^16 and reads
@@ -231,12 +235,33 @@ __device__ __forceinline__ uint32_t gn_hibf_row_seed(uint64_t v, uint64_t seed, 
     return (uint32_t)__umul64hi(x, (uint64_t)S);
 }
 
+// Minimisers of an item staged in LDS.  With one to four lanes per row a wave holds 64 .. 16 items and every lane (group) used to fetch
+// its item's next hash from global memory in every iteration: 64 different lines per wave and iteration, far more than the L1 and L2
+// keep until the next iteration -- measured, a fifth of a level's fabric requests (profiles/r05_hibf_probe_fake2.jsonl: 9.88 -> 7.80 ms
+// with the loads taken out).  Now the lanes of a group copy the item's first GN_HIBF_NQ hashes (24: a 150 bp read has 12 .. 25) into LDS
+// before the row loop -- all loads in flight at once, two lines per item -- and the loop reads LDS; hashes beyond come from global memory.
+#define GN_HIBF_NQ 24u
+#define GN_HIBF_NQ_STRIDE 25u // (odd stride in 8-byte words)
+
+// Four waves a SIMD: with the class loop and the staging the allocator takes 140 registers (three waves) unless told otherwise; held to
+// 128 it spills a few dwords and the lower levels of the skewed tree run 11 % faster (profiles/r05_probe3_skew_w4.jsonl).  -DGN_PACK_WAVES3
+// builds the other variant for A/B runs.
+#ifdef GN_PACK_WAVES3
+#define GN_PACK_ATTR
+#else
+#define GN_PACK_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
+#endif
 template <int HF, bool LEVEL0>
-__global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
+__global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLevelParams p)
 {
-    __shared__ uint32_t img_all[4][GN_WAVE * 16]; // per wave: the 16 byte-counter registers of every lane (multi-bin runs)
+    // Dynamic LDS, one region per wave: the 16 byte-counter registers of every lane (multi-bin runs, 4 KB) -- and, on launches with
+    // narrow classes, the staged minimisers of the wave's items (GN_HIBF_NQ per item; the image is written after the row loop, when
+    // the staged values are done with, and the next batch is staged after the image's readers)
+    extern __shared__ uint64_t gn_pack_lds[];
     const uint32_t lane   = threadIdx.x & (GN_WAVE - 1);
     const uint32_t wave   = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t region = p.lds_region; // 8-byte words per wave (gn_hibf_pack_region)
+    uint64_t* const hst   = gn_pack_lds + (size_t)wave * region;
     const uint32_t stride = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave_id = (uint32_t)blockIdx.x * (blockDim.x >> 6) + wave;
 
@@ -375,33 +400,78 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
         };
         const uint64_t hs_at = cur.slot; // (index into p.hashes)
         const uint64_t fake0 = p.fake_hashes ? p.hashes[n ? hs_at : 0ull] : 0ull;
-        auto issue = [&](uint32_t it, Rows& R) {
-            // every lane issues its loads unconditionally: finished / invalid items re-read their last (or any) row
-            const uint32_t q = n ? (it < n ? it : n - 1) : 0u;
-            uint64_t v;
+        const bool     staged = p.stage_hashes && gpl >= 1 && gpl <= 2; // (wave-uniform; see gn_hibf_pack_region)
+        if (staged)
+        {
+            // lane gl of a group takes the hashes q = gl, gl + Gp, ...; every load is issued before the first one is waited for
+            gn_hibf_wave_sync(); // (the previous batch's image readers are through)
+            // One load instruction per ITEM: lanes 0 .. 23 fetch the item's hashes 0 .. 23 -- 192 contiguous bytes, two or three line
+            // requests -- instead of every lane (group) fetching its own item's hashes one by one (a request per hash: what limits a
+            // level of narrow IBFs is the number of line requests, profiles/README.md).  Eight items in flight per round.
+            const uint32_t lim  = n < GN_HIBF_NQ ? n : GN_HIBF_NQ; // (mine; the item loop reads the others' through readlane)
+            const auto*    hsrc = gn_global(p.hashes);
+            for (uint32_t i0 = 0; i0 < H; i0 += 8u)
+            {
+                uint64_t tmp[8];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j)
+                {
+                    const uint32_t src_lane = (i0 + j) << gpl; // (i0 + j < H: H is 16, 32 or 64)
+                    const uint32_t lim_i    = (uint32_t)__builtin_amdgcn_readlane((int)lim, (int)src_lane);
+                    const uint64_t at_i     = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hs_at >> 32), (int)src_lane) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hs_at, (int)src_lane);
+                    tmp[j] = lane < lim_i ? hsrc[at_i + lane] : 0ull;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j)
+                {
+                    const uint32_t src_lane = (i0 + j) << gpl;
+                    const uint32_t lim_i    = (uint32_t)__builtin_amdgcn_readlane((int)lim, (int)src_lane);
+                    if (lane < lim_i)
+                        hst[(i0 + j) * GN_HIBF_NQ_STRIDE + lane] = tmp[j];
+                }
+            }
+            gn_hibf_wave_sync();
+        }
+        // hash `it` of my item, requested two iterations before the rows that depend on it: the row loop's chain per iteration is then one
+        // memory latency (the rows), not two (hash, then rows) -- taken out of the chain in an experiment a level of narrow IBFs ran 21 %
+        // faster (profiles/r05_hibf_probe_fake2.jsonl)
+        auto fetch = [&](uint32_t it) -> uint64_t {
+            if (!(it < n || (p.reread && n)))
+                return 0ull;
+            const uint32_t q = it < n ? it : n - 1;
             if (p.fake_hashes) // timing experiment: one load per item, the other "hashes" derived from it
-                v = fake0 * (2ull * q + 1ull);
-            else
-                v = p.hashes[n ? hs_at + q : 0ull]; // (unconditional: element 0 always exists)
-            uint32_t       row[HF];
-            if (share)
+                return fake0 * (2ull * q + 1ull);
+            if (staged && q < GN_HIBF_NQ)
+                return hst[grp * GN_HIBF_NQ_STRIDE + q];
+            return p.hashes[hs_at + q];
+        };
+        auto issue = [&](uint32_t it, Rows& R, uint64_t v) {
+            // Lanes whose item is through (or is not counted here) issue nothing.  They used to re-read their last row "for free": with 64
+            // items a wave the longest item has 1.29 x the mean number of minimisers, and a re-read row was long gone from the L1 and L2 --
+            // a quarter of the level's row requests went to the fabric for nothing.  (A group's lanes share n: the branch is group-uniform,
+            // the permutes below stay inside the group.)
+            if (it < n || (p.reread && n))
             {
-                const uint32_t mine = gn_hibf_row_seed(v, my_seed, cur.shift, cur.S ? cur.S : 1u);
+                // (A/B switch hibf_reread: finished lanes read their last row again, as up to round 4 -- fetch() repeats the last hash)
+                uint32_t row[HF];
+                if (share)
+                {
+                    const uint32_t mine = gn_hibf_row_seed(v, my_seed, cur.shift, cur.S);
+#pragma unroll
+                    for (int i = 0; i < HF; ++i)
+                        row[i] = (uint32_t)__shfl((int)mine, (int)(gbase + (uint32_t)i));
+                }
+                else
+                {
+#pragma unroll
+                    for (int i = 0; i < HF; ++i)
+                        row[i] = gn_hibf_row_seed(v, GN_HIBF_SEEDS[i], cur.shift, cur.S);
+                }
 #pragma unroll
                 for (int i = 0; i < HF; ++i)
-                    row[i] = (uint32_t)__shfl((int)mine, (int)(gbase + (uint32_t)i));
+                    R.m[i] = cur.rows[(uint64_t)row[i] * cur.W + gl_ld];
             }
-            else
-            {
-#pragma unroll
-                for (int i = 0; i < HF; ++i)
-                    row[i] = gn_hibf_row_seed(v, GN_HIBF_SEEDS[i], cur.shift, cur.S ? cur.S : 1u);
-            }
-            const auto* base = n ? cur.rows : gn_global(p.hashes); // items that are not counted: a readable address (element 0)
-            const uint32_t Wl = n ? cur.W : 0u;
-#pragma unroll
-            for (int i = 0; i < HF; ++i)
-                R.m[i] = base[(uint64_t)(n ? row[i] : 0u) * Wl + (n ? gl_ld : 0u)];
         };
         uint32_t acc_n = 0;
         auto consume = [&](const Rows& R, uint32_t it) {
@@ -434,19 +504,23 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
         };
         if (n_max)
         {
-            Rows A, B;
-            issue(0, A);
+            Rows     A, B;
+            uint64_t ha = fetch(0), hb = fetch(1);
+            issue(0, A, ha);
+            ha          = fetch(2);
             uint32_t it = 0;
             for (; it + 2 < n_max; it += 2)
             {
-                issue(it + 1, B);
+                issue(it + 1, B, hb);
+                hb = fetch(it + 3);
                 consume(A, it);
-                issue(it + 2, A);
+                issue(it + 2, A, ha);
+                ha = fetch(it + 4);
                 consume(B, it + 1);
             }
             const bool two = it + 1 < n_max;
             if (two)
-                issue(it + 1, B);
+                issue(it + 1, B, hb);
             consume(A, it);
             if (two)
                 consume(B, it + 1);
@@ -517,7 +591,7 @@ __global__ __launch_bounds__(256) void gn_hibf_pack_kernel(GnHibfLevelParams p)
         const uint32_t nm = cur.ok ? cur.nm : 0u;
         if (__ballot(nm != 0))
         {
-            uint32_t* img = img_all[wave];
+            uint32_t* img = reinterpret_cast<uint32_t*>(hst);
             gn_hibf_wave_sync(); // (the readers of the batch before are through)
 #pragma unroll
             for (int d = 0; d < 2; ++d)
@@ -1399,17 +1473,39 @@ static void gn_hibf_launch_reg(const GnHibfLevelParams& p, bool level0, uint32_t
         gn_hibf_launch_reg2<HF, false>(p, n_cu, bpc, st);
 }
 
-template <int HF, bool LEVEL0>
-static void gn_hibf_launch_pack2(const GnHibfLevelParams& p, uint32_t n_cu, uint32_t bpc, hipStream_t st)
+// dynamic LDS of a packed launch: per wave the 4 KB counter image, or the staged hashes of the items a wave of the narrowest class holds
+static uint32_t gn_hibf_pack_region(GnHibfLevelParams& p, bool level0)
 {
+    // Staged are the classes of two and four lanes per row (32 and 16 items a wave: 6.4 and 3.2 KB of LDS a wave).  One lane per row
+    // would need 12.8 KB a wave -- three workgroups a CU instead of four, which costs more than the staging gains there (measured:
+    // profiles/r05_probe3_skew*.jsonl); those classes prefetch their hashes two iterations ahead instead.
+    uint32_t min_gp = 8;
+    auto     take   = [&](uint32_t g) {
+        if (g >= 1 && g <= 2)
+            min_gp = std::min(min_gp, g);
+    };
+    if (level0 || p.n_cls == 0)
+        take(p.pack_gp);
+    else
+        for (uint32_t c = 0; c < p.n_cls; ++c)
+            take(p.cls_gp[c]);
+    p.stage_hashes = min_gp <= 2 && !gn_sw().hibf_stage ? 1u : 0u;
+    p.lds_region   = std::max<uint32_t>(GN_WAVE * 8u, p.stage_hashes ? (GN_WAVE >> min_gp) * GN_HIBF_NQ_STRIDE : 0u);
+    return p.lds_region * 8u * 4u; // bytes per workgroup of four waves
+}
+
+template <int HF, bool LEVEL0>
+static void gn_hibf_launch_pack2(GnHibfLevelParams p, uint32_t n_cu, uint32_t bpc, hipStream_t st)
+{
+    const uint32_t lds = gn_hibf_pack_region(p, LEVEL0);
     if (bpc == 0)
     {
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_hibf_pack_kernel<HF, LEVEL0>, 256, 0) != hipSuccess || per_cu < 1)
-            per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gn_hibf_pack_kernel<HF, LEVEL0>, 256, lds) != hipSuccess || per_cu < 1)
+            per_cu = 2;
         bpc = (uint32_t)per_cu;
     }
-    hipLaunchKernelGGL((gn_hibf_pack_kernel<HF, LEVEL0>), dim3(n_cu * bpc), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gn_hibf_pack_kernel<HF, LEVEL0>), dim3(n_cu * bpc), dim3(256), lds, st, p);
 }
 template <int HF>
 static void gn_hibf_launch_pack(const GnHibfLevelParams& p, bool level0, uint32_t n_cu, uint32_t bpc, hipStream_t st)
@@ -1630,6 +1726,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
             p.n_hashes    = s->v_nh;
             p.rel_cutoff  = s->rel_cutoff;
             p.wide        = s->long_reads ? 1u : 0u;
+            p.reread      = gn_sw().hibf_reread ? 1u : 0u;
             p.fake_hashes = gn_sw().hibf_fake_hashes && lvl > 0 ? 1u : 0u; // (level 0 keeps its real hashes: the lower levels get their real items)
             p.work_in     = s->d_work[lvl & 1];
             p.count_in    = s->d_hctr + lvl;

@@ -42,6 +42,8 @@ struct GnSwitches
     bool hibf_reg = false;        // no per-item register kernel (LDS-counter level kernel instead)
     bool hibf_pack = false;       // no packed-items kernel either
     bool hibf_one_pack = false;   // only the level's most common width takes the packed kernel (no sorting by width)
+    bool hibf_reread = false;     // A/B: lanes whose item is through read their last row again (as up to round 4)
+    bool hibf_stage = false;      // the packed kernel fetches every hash from global memory (no staging in LDS)
     bool hibf_persistent = false; // one launch per width class instead of one persistent launch per level
     bool hibf_fake_hashes = false; // TIMING EXPERIMENT ONLY (wrong results): the packed kernel loads one hash per item and derives the others
     uint32_t hibf_bpc = 0;        // >0: workgroups per CU of the HIBF register kernels (0: what the occupancy query says)

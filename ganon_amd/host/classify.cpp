@@ -1297,8 +1297,12 @@ static bool ganon_classify(Config config)
             auto warm = [&](Backend* be) {
                 if (!be->active())
                     return;
+                const double t_p = StartupLog::now();
                 be->prepare(std::min<size_t>(kBatchReads, 1u << 20), std::min<size_t>(kBatchBases, env_size("GANON_HOST_SLAB_BYTES", 48u << 20)));
+                StartupLog::get().span("  a worker context: device streams", t_p);
+                const double t_w = StartupLog::now();
                 be->warm_up(level.kmer_size, level.window_size, std::vector<double>(filters.size(), 1.0));
+                StartupLog::get().span("  a worker context: warm-up batch + page-locking its batch and result buffers", t_w);
             };
             for (auto& b : backends)
                 setup.emplace_back(warm, b.get());

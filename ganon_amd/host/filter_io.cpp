@@ -220,7 +220,7 @@ void replace_all(std::string& str, const std::string& from, const std::string& t
 void parallel_pread(int fd, uint8_t* dst, uint64_t bytes, uint64_t offset, const std::string& path)
 {
     const unsigned    hw     = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned    nth    = (unsigned)std::min<uint64_t>(std::min(16u, hw), std::max<uint64_t>(1, bytes >> 23)); // >= 8 MiB each
+    const unsigned    nth    = (unsigned)std::min<uint64_t>(std::min(16u, hw), std::max<uint64_t>(1, bytes >> 21)); // >= 2 MiB each
     std::atomic<bool> failed{ false };
     auto              work = [&](uint64_t lo, uint64_t hi) {
         while (lo < hi && !failed)
@@ -275,7 +275,9 @@ void stream_matrix(const std::string& path, int fd, uint64_t offset, const IbfSh
 {
     const uint64_t row_bytes = m.bin_words * 8;
     const uint64_t total     = m.payload_bytes();
-    const uint64_t want      = std::min<uint64_t>(total, 256ull << 20);
+    // two staging buffers of 1/32 of the matrix each, 32 .. 256 MiB: page-locking them is what a small filter's load consists of
+    // (2 x 256 MiB took 0.21 s of the 0.41 s a 1 GiB filter needed, profiles/r05_e2e_startup1.json); a 128 GiB filter still gets 256 MiB pieces
+    const uint64_t want      = std::min<uint64_t>(total, std::min<uint64_t>(256ull << 20, std::max<uint64_t>(32ull << 20, total >> 5)));
     const uint64_t per       = std::max<uint64_t>(1, want / row_bytes); // rows per chunk
     const uint64_t cap       = per * row_bytes;
     const double   t_stage   = now_s();
