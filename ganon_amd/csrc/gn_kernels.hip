@@ -1040,8 +1040,10 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 // gn_ibf_count_kernel.  One wave per (read, column slice); no LDS counters, no block barriers.
 // EE = with the exact early exit (instantiated separately: its check costs registers, and the variant without it
 // must keep the occupancy it had).
-template <int HF, int LW, bool EE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW == 1 ? GN_FAST_WPE_LW1 : (HF <= 4 ? GN_FAST_WPE_LW2_H4 : GN_FAST_WPE_LW2)) : 1))) void gn_ibf_count_fast_kernel(GnCountParams p)
+// WIDE = rows of more than 128 words (1 KiB) with 16-byte lanes: there the third wave a SIMD bought +0.3 % (128 GiB filter, 4 KiB rows) for
+// 64 bytes of scratch per lane, so those rows get the two-wave build with nothing spilled; narrower rows keep three waves (+4 .. 7 %).
+template <int HF, int LW, bool EE, bool WIDE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW == 1 ? GN_FAST_WPE_LW1 : (HF <= 4 && !WIDE ? GN_FAST_WPE_LW2_H4 : GN_FAST_WPE_LW2)) : 1))) void gn_ibf_count_fast_kernel(GnCountParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t gn_lds[];
     constexpr int      ND   = 2 * LW;
@@ -1705,7 +1707,9 @@ static hipError_t gn_launch_fast_one(const GnCountParams& p, hipStream_t st)
     if (blocks > p.max_blocks_fast)
         blocks = p.max_blocks_fast;
     const size_t   lds    = 4 * 128 * (HF <= 4 ? 4 : 8) * 4;
-    if (ee)
+    if (ee && LW == 2 && p.W > 128)
+        hipLaunchKernelGGL((gn_ibf_count_fast_kernel<HF, LW, true, LW == 2>), dim3(blocks), dim3(256), lds, st, p);
+    else if (ee)
         hipLaunchKernelGGL((gn_ibf_count_fast_kernel<HF, LW, true>), dim3(blocks), dim3(256), lds, st, p);
     else
         hipLaunchKernelGGL((gn_ibf_count_fast_kernel<HF, LW, false>), dim3(blocks), dim3(256), lds, st, p);
