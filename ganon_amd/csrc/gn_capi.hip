@@ -10,8 +10,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
+
+#include <sys/mman.h>
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -50,7 +54,7 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                               {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
                               {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent}, {"hibf_stage", &GnSwitches::hibf_stage}, {"hibf_reread", &GnSwitches::hibf_reread},
                               {"hibf_fake_hashes", &GnSwitches::hibf_fake_hashes}, {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
-                              {"debug", &GnSwitches::debug}};
+                              {"pinned_malloc", &GnSwitches::pinned_malloc}, {"debug", &GnSwitches::debug}};
     for (const char* p = list ? list : ""; *p;)
     {
         const char* e = strchr(p, ',');
@@ -647,6 +651,21 @@ extern "C" int gn_filter_download_row_list(const gn_filter* f, uint32_t ibf_idx,
 }
 
 // ---- streaming load ------------------------------------------------------------------------------
+// Page-locked host memory.  hipHostMalloc locks 4 KiB pages at ~5 GB/s; an anonymous mapping backed by transparent huge pages,
+// touched and then registered (hipHostRegister), is ready at ~26 GB/s and copies to the device just as fast (57 GB/s) --
+// scripts/pin_thp_probe.cpp, profiles/r05_pin_thp_probe.jsonl.  A run of a few seconds locks gigabytes (batch pool, staging, result
+// sets), so this is most of its start-up.  Falls back to hipHostMalloc where the mapping or the registration is refused.
+namespace
+{
+struct GnPinned
+{
+    void*  raw;
+    size_t raw_bytes;
+};
+std::mutex                           g_pinned_mutex;
+std::unordered_map<void*, GnPinned> g_pinned; // blocks that came from mmap + hipHostRegister
+} // namespace
+
 extern "C" int gn_pinned_alloc(size_t bytes, void** out)
 {
     if (!out || bytes == 0)
@@ -655,6 +674,28 @@ extern "C" int gn_pinned_alloc(size_t bytes, void** out)
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
         return gn_fail(GN_ENODEV, "no HIP device available (libganon_hip has no CPU fallback)");
+    constexpr size_t huge = 2u << 20;
+    if (bytes >= huge && !gn_sw().pinned_malloc)
+    {
+        const size_t len = (bytes + huge - 1) & ~(huge - 1);
+        void*        raw = mmap(nullptr, len + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (raw != MAP_FAILED)
+        {
+            void* p = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(raw) + huge - 1) & ~(uintptr_t)(huge - 1));
+            (void)madvise(p, len, MADV_HUGEPAGE);
+            for (size_t i = 0; i < len; i += 4096) // fault the pages in (one fault per huge page where they are granted)
+                static_cast<volatile char*>(p)[i] = 0;
+            if (hipHostRegister(p, len, hipHostRegisterPortable) == hipSuccess)
+            {
+                std::lock_guard<std::mutex> lk(g_pinned_mutex);
+                g_pinned[p] = GnPinned{ raw, len + huge };
+                *out        = p;
+                return GN_OK;
+            }
+            (void)hipGetLastError();
+            munmap(raw, len + huge);
+        }
+    }
     hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
     if (e != hipSuccess)
         return gn_fail(GN_ENOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -663,7 +704,24 @@ extern "C" int gn_pinned_alloc(size_t bytes, void** out)
 
 extern "C" int gn_pinned_free(void* p)
 {
-    if (p)
+    if (!p)
+        return GN_OK;
+    GnPinned blk{ nullptr, 0 };
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mutex);
+        auto                        it = g_pinned.find(p);
+        if (it != g_pinned.end())
+        {
+            blk = it->second;
+            g_pinned.erase(it);
+        }
+    }
+    if (blk.raw)
+    {
+        (void)hipHostUnregister(p);
+        munmap(blk.raw, blk.raw_bytes);
+    }
+    else
         hipHostFree(p);
     return GN_OK;
 }

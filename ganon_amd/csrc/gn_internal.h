@@ -54,6 +54,7 @@ struct GnSwitches
     // batch pipeline
     uint32_t chunk = 0;           // >0: reads per pipeline chunk (minimiser || count on two HIP streams)
     int      sync_mode = 0;       // 0 runtime default, 1 spin, 2 yield, 3 block: how host threads wait for the device
+    bool     pinned_malloc = false; // gn_pinned_alloc: hipHostMalloc as up to round 4 (no huge-page mapping + hipHostRegister)
     bool     debug = false;       // chatter on stderr
 };
 const GnSwitches& gn_sw();

@@ -818,7 +818,9 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
     {
         g_host_arena.alloc   = [](size_t n) -> void* { return PinnedPool::get().take(n); };
         g_host_arena.release = [](void* p) { PinnedPool::get().give(p); };
-        PinnedPool::get().warm_up();
+        // (uncompressed FASTQ / FASTA travels as text: a 48 MiB slab plus the slack prepare() adds, i.e. the 56 MiB class)
+        const size_t slab = 48u << 20;
+        PinnedPool::get().warm_up(out.front()->tokenises_fastq() ? slab + slab / 16 + 65536 : (32u << 20));
     }
     return out;
 }

@@ -92,10 +92,11 @@ public:
         std::free(p); // (the malloc fallback of take())
     }
     // blocks for the first slabs of the reader (32 MiB holds the bases of a 48 MiB FASTQ slab), locked in the background
-    void warm_up()
+    // block_bytes: what the reader will ask for (32 MiB holds the bases of a parsed 48 MiB slab; a slab that travels as text needs 56)
+    void warm_up(size_t block_bytes = 32u << 20)
     {
         const char* e = std::getenv("GANON_HOST_PRELOCK_MIB");
-        const size_t total = (e ? (size_t)std::atol(e) : 512) << 20, block = 32u << 20;
+        const size_t total = (e ? (size_t)std::atol(e) : 512) << 20, block = size_class(block_bytes);
         if (total == 0)
             return;
         warm_ = std::thread([this, total, block] {
@@ -110,7 +111,7 @@ public:
                 size_of_[p] = block;
                 free_[block].push_back(p);
             }
-            StartupLog::get().span("page-locking the batch pool (background thread)", t0, std::to_string(done >> 20) + " MiB in 32 MiB blocks");
+            StartupLog::get().span("page-locking the batch pool (background thread)", t0, std::to_string(done >> 20) + " MiB in " + std::to_string(block >> 20) + " MiB blocks");
         });
     }
     // `count` more blocks that hold n bytes each go into the pool (locked now, handed out later)

@@ -75,8 +75,8 @@ def test_bench_prints_detail_first_and_the_compact_record_last():
 
 @pytest.mark.gpu
 def test_real_run_ends_with_a_short_parsable_line():
-    env = dict(os.environ, GANON_BENCH_EXTRAS="tiny,hibf_tiny")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-e2e"],
+    env = dict(os.environ, GANON_BENCH_EXTRAS="hibf_tiny")   # (one child process stands for the five of a default run)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-e2e", "--cpu-sample", "20000"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = p.stdout.splitlines()
