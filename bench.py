@@ -260,6 +260,8 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="do not run the other BASELINE configs after the headline")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-every-row", action="store_true", help="skip the 3-step measurement with the early exit ablated (profile passes: every launch of the "
+                                                                "count kernel is then one of the timed steps; roofline.frac falls back to the product kernel)")
     ap.add_argument("--extra-timeout", type=int, default=420)
     ap.add_argument("--no-e2e", action="store_true", help="do not run the product binary end to end after the kernels (bench_e2e.py)")
     ap.add_argument("--e2e-budget", type=int, default=200, help="seconds the end-to-end leg may take")
@@ -414,7 +416,7 @@ def main() -> int:
         # SURVEY 8(d)'s fraction belongs to the instantiation that fetches every algorithmic row: the same resident batch
         # with the early exit ablated (3 steps, outside `value`).  Split-bin and HIBF kernels have no early exit.
         full, full_tms = ee, total_ms
-        if kind in ("flat", "slice") and spec.get("bins_per_target", 1) == 1:
+        if kind in ("flat", "slice") and spec.get("bins_per_target", 1) == 1 and not args.no_every_row:
             with ganon_amd.ablate("early_exit"):
                 _, cms0, _, full_tms, tm0 = timed(args.rel_cutoff, 3, 1)
             full = rates(tm0, cms0)
@@ -446,7 +448,7 @@ def main() -> int:
                 "algo_bytes_per_launch": ee["algo_bytes"] // ee["launches"],
                 "fetched_bytes_per_launch": ee["fetched_bytes"] // ee["launches"],
                 "frac_measured_on": ("early exit ablated (every algorithmic row fetched), 3 steps on the same resident batch" if full is not ee
-                                     else "the product kernel (it has no early exit)"),
+                                     else ("the product kernel (--no-every-row)" if args.no_every_row else "the product kernel (it has no early exit)")),
                 "note": "algo_over_peak may exceed 1: rows the exact early exit skips are never fetched"}
         if kind == "hibf":
             # The roofline per tree level: a level's rows are gathered from the IBFs at that depth, and whether those sit in

@@ -52,7 +52,7 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                               {"const_nb", &GnSwitches::const_nb},           {"split_kernel", &GnSwitches::split_kernel},
                               {"predrop", &GnSwitches::predrop},             {"deferred_grids", &GnSwitches::deferred_grids},
                               {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
-                              {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent}, {"hibf_stage", &GnSwitches::hibf_stage}, {"hibf_reread", &GnSwitches::hibf_reread},
+                              {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent}, {"hibf_stage", &GnSwitches::hibf_stage}, {"hibf_nsort", &GnSwitches::hibf_nsort}, {"hibf_reread", &GnSwitches::hibf_reread},
                               {"hibf_fake_hashes", &GnSwitches::hibf_fake_hashes}, {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
                               {"pinned_malloc", &GnSwitches::pinned_malloc}, {"debug", &GnSwitches::debug}};
     for (const char* p = list ? list : ""; *p;)
@@ -879,7 +879,7 @@ extern "C" int gn_stream_destroy(gn_stream* s)
         hipStreamSynchronize(s->st);
     void* ptrs[] = { s->d_bases,  s->d_off1,    s->d_off2,      s->d_slot_cnt,  s->d_slot_off, s->d_hashes, s->d_nh,
                      s->d_status, s->d_matches, s->d_sorted,    s->d_ctr,       s->d_seg_begin, s->d_seg_count,
-                     s->d_seg_off, s->d_deferred, s->d_mdeferred, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_hdefer, s->d_hdefer2, s->d_hctr, s->d_keys[0], s->d_keys[1], s->d_vals[0],
+                     s->d_seg_off, s->d_deferred, s->d_mdeferred, s->d_scan_tmp, s->d_work[0], s->d_work[1], s->d_hdefer, s->d_hdefer2, s->d_hctr, s->d_hsub, s->d_keys[0], s->d_keys[1], s->d_vals[0],
                      s->d_vals[1], s->d_sort_tmp };
     for (void* p : ptrs)
         if (p)
@@ -986,6 +986,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
         ok(gn_dmalloc(&s->d_hdefer, s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer2, s->work_cap));
         ok(gn_dmalloc(&s->d_hctr, 29 * (GN_HIBF_MAXDEPTH + 1) + 2));
+        ok(gn_dmalloc(&s->d_hsub, 384 * (GN_HIBF_MAXDEPTH + 1))); // per level: counts, bases, cursors of the 128 (class, n-bin) keys
         ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), (5 * (GN_HIBF_MAXDEPTH + 1) + 2) * sizeof(unsigned long long), hipHostMallocDefault));
     }
     ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_ctr), GN_NCTR * sizeof(unsigned long long), hipHostMallocDefault));

@@ -246,6 +246,8 @@ __device__ __forceinline__ uint32_t gn_hibf_row_seed(uint64_t v, uint64_t seed, 
 // Four waves a SIMD: with the class loop and the staging the allocator takes 140 registers (three waves) unless told otherwise; held to
 // 128 it spills a few dwords and the lower levels of the skewed tree run 11 % faster (profiles/r05_probe3_skew_w4.jsonl).  -DGN_PACK_WAVES3
 // builds the other variant for A/B runs.
+// (A third row set in flight per lane was tried -- six more registers instead of a fourth wave -- and changed nothing:
+// profiles/r05_probe5_skew_rs3.jsonl.)
 #ifdef GN_PACK_WAVES3
 #define GN_PACK_ATTR
 #else
@@ -1638,6 +1640,126 @@ __global__ __launch_bounds__(256) void gn_hibf_bucket_kernel(GnHibfBucketParams 
     }
 }
 
+// ---- ... and, inside a width class, by the number of minimisers ---------------------------------------------------------------------
+// A wave of the packed kernel holds up to 64 items and runs as many iterations as its LONGEST item has minimisers: reads of 150 bp have
+// 12 .. 25 (mean 17.6), the longest of 64 has 22.6 -- in a fifth of a wave's iterations part of its lanes have nothing in flight, on
+// levels that are bound by the requests a wave keeps outstanding.  The same two passes therefore sort by (class, n / 2): 16 bins of
+// two, everything from 30 minimisers up in the last.  Counting and scattering go through an LDS histogram per 4096-item chunk (one
+// global atomic per key and chunk); the order inside a key is whatever the LDS atomics give -- the matches are sorted at the end anyway.
+#define GN_HIBF_NBINS 16u
+#define GN_HIBF_NKEYS (7u * GN_HIBF_NBINS) // key 112 = what the packed kernel does not take (class 7), 113 = holes
+struct GnHibfSubParams
+{
+    unsigned long long* sub_count;  // [128] of this level
+    unsigned long long* sub_base;   // [128]
+    unsigned long long* sub_cursor; // [128]
+};
+
+__device__ __forceinline__ uint32_t gn_hibf_item_key(const GnHibfBucketParams& p, uint2 e)
+{
+    if (e.x == 0xFFFFFFFFu)
+        return GN_HIBF_NKEYS + 1u;
+    const uint32_t W = p.ibfs[e.y].W, n = p.n_hashes[e.x];
+    if (n == 0)
+        return GN_HIBF_NKEYS + 1u;
+    if (W > GN_WAVE || n > 127u)
+        return GN_HIBF_NKEYS;
+    const uint32_t g = W <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(W - 1);
+    const uint32_t c = p.cls_of_gp[g];
+    if (c >= 7u)
+        return GN_HIBF_NKEYS;
+    const uint32_t nb = (n >> 1) < GN_HIBF_NBINS ? (n >> 1) : GN_HIBF_NBINS - 1u;
+    return c * GN_HIBF_NBINS + nb;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void gn_hibf_nsort_kernel(GnHibfBucketParams p, GnHibfSubParams q)
+{
+    __shared__ uint32_t           hist[128];
+    __shared__ unsigned long long chunk_base[128];
+    const unsigned long long      nw64 = *p.count_in;
+    const uint32_t                n    = (uint32_t)(nw64 < p.work_cap ? nw64 : p.work_cap);
+    const uint32_t                chunk = 256u * GN_HIBF_BUCKET_ROUNDS;
+    const uint32_t                n_chunks = (n + chunk - 1) / chunk;
+    for (uint32_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x)
+    {
+        if (threadIdx.x < 128)
+            hist[threadIdx.x] = 0;
+        __syncthreads();
+        uint2    mine[GN_HIBF_BUCKET_ROUNDS];
+        uint8_t  key[GN_HIBF_BUCKET_ROUNDS];
+#pragma unroll
+        for (uint32_t k = 0; k < GN_HIBF_BUCKET_ROUNDS; ++k)
+        {
+            const uint32_t i = ch * chunk + k * 256u + threadIdx.x;
+            mine[k]          = i < n ? p.work_in[i] : make_uint2(0xFFFFFFFFu, 0u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < GN_HIBF_BUCKET_ROUNDS; ++k)
+        {
+            key[k] = (uint8_t)gn_hibf_item_key(p, mine[k]);
+            if (key[k] <= GN_HIBF_NKEYS)
+                atomicAdd(&hist[key[k]], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x <= GN_HIBF_NKEYS)
+        {
+            const uint32_t k = threadIdx.x, total = hist[k];
+            if (!SCATTER)
+            {
+                if (total)
+                    atomicAdd(&q.sub_count[k], (unsigned long long)total);
+            }
+            else
+            {
+                chunk_base[k] = total ? (k == GN_HIBF_NKEYS ? atomicAdd(p.rest_count, (unsigned long long)total)
+                                                            : q.sub_base[k] + atomicAdd(&q.sub_cursor[k], (unsigned long long)total))
+                                      : 0ull;
+                hist[k] = 0; // (the chunk's cursor inside the key from here on)
+            }
+        }
+        __syncthreads();
+        if (SCATTER)
+        {
+#pragma unroll
+            for (uint32_t k = 0; k < GN_HIBF_BUCKET_ROUNDS; ++k)
+                if (key[k] <= GN_HIBF_NKEYS)
+                {
+                    const unsigned long long o = chunk_base[key[k]] + atomicAdd(&hist[key[k]], 1u);
+                    if (key[k] == GN_HIBF_NKEYS)
+                    {
+                        if (o < p.work_cap)
+                            p.rest_out[o] = mine[k];
+                    }
+                    else
+                        p.sorted_out[o] = mine[k];
+                }
+            __syncthreads();
+        }
+    }
+}
+
+// bases of the 112 (class, n-bin) keys in key order, and the eight per-class counts / bases the packed kernel reads
+__global__ void gn_hibf_nsort_bases_kernel(const unsigned long long* __restrict__ sub_count, unsigned long long* __restrict__ sub_base,
+                                           unsigned long long* __restrict__ cls_count, unsigned long long* __restrict__ cls_base)
+{
+    unsigned long long at = 0;
+    for (uint32_t c = 0; c < 7; ++c)
+    {
+        cls_base[c]           = at;
+        unsigned long long in = 0;
+        for (uint32_t b = 0; b < GN_HIBF_NBINS; ++b)
+        {
+            sub_base[c * GN_HIBF_NBINS + b] = at;
+            at += sub_count[c * GN_HIBF_NBINS + b];
+            in += sub_count[c * GN_HIBF_NBINS + b];
+        }
+        cls_count[c] = in;
+    }
+    cls_base[7]  = at;
+    cls_count[7] = sub_count[GN_HIBF_NKEYS];
+}
+
 __global__ void gn_hibf_bucket_bases_kernel(const unsigned long long* __restrict__ cnt, unsigned long long* __restrict__ base)
 {
     unsigned long long at = 0;
@@ -1706,6 +1828,8 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
         GN_HIP(hipMemsetAsync(s->d_hctr, 0, 3 * NL * sizeof(unsigned long long), st));
         GN_HIP(hipMemsetAsync(s->d_hctr + 5 * NL + 2, 0, 24 * NL * sizeof(unsigned long long), st));
+        if (s->d_hsub)
+            GN_HIP(hipMemsetAsync(s->d_hsub, 0, (size_t)NL * 384 * sizeof(unsigned long long), st));
         if (cnt && no_reg) // (the register-counter kernels take level 0 straight from the batch)
             hipLaunchKernelGGL(gn_hibf_seed_kernel, dim3((cnt + 255) / 256), dim3(256), 0, st, s->d_work[0], s->v_status, lo, cnt, s->d_hctr,
                                s->long_reads ? 1u : 0u);
@@ -1778,9 +1902,19 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                 bp.rest_out   = s->d_hdefer2;
                 bp.rest_count = s->d_hctr + NL + lvl;
                 const dim3 grid((uint32_t)f->n_cu * 8u);
-                hipLaunchKernelGGL(gn_hibf_bucket_kernel<false>, grid, dim3(256), 0, st, bp);
-                hipLaunchKernelGGL(gn_hibf_bucket_bases_kernel, dim3(1), dim3(1), 0, st, bp.cls_count, bp.cls_base);
-                hipLaunchKernelGGL(gn_hibf_bucket_kernel<true>, grid, dim3(256), 0, st, bp);
+                if (!gn_sw().hibf_nsort && s->d_hsub)
+                {
+                    GnHibfSubParams sp{ s->d_hsub + (size_t)lvl * 384, s->d_hsub + (size_t)lvl * 384 + 128, s->d_hsub + (size_t)lvl * 384 + 256 };
+                    hipLaunchKernelGGL(gn_hibf_nsort_kernel<false>, grid, dim3(256), 0, st, bp, sp);
+                    hipLaunchKernelGGL(gn_hibf_nsort_bases_kernel, dim3(1), dim3(1), 0, st, sp.sub_count, sp.sub_base, bp.cls_count, bp.cls_base);
+                    hipLaunchKernelGGL(gn_hibf_nsort_kernel<true>, grid, dim3(256), 0, st, bp, sp);
+                }
+                else
+                {
+                    hipLaunchKernelGGL(gn_hibf_bucket_kernel<false>, grid, dim3(256), 0, st, bp);
+                    hipLaunchKernelGGL(gn_hibf_bucket_bases_kernel, dim3(1), dim3(1), 0, st, bp.cls_count, bp.cls_base);
+                    hipLaunchKernelGGL(gn_hibf_bucket_kernel<true>, grid, dim3(256), 0, st, bp);
+                }
                 GN_HIP(hipGetLastError());
                 p.work_in     = s->d_hdefer;
                 p.defer_out   = s->d_hdefer2;

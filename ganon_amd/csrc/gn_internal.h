@@ -43,6 +43,7 @@ struct GnSwitches
     bool hibf_pack = false;       // no packed-items kernel either
     bool hibf_one_pack = false;   // only the level's most common width takes the packed kernel (no sorting by width)
     bool hibf_reread = false;     // A/B: lanes whose item is through read their last row again (as up to round 4)
+    bool hibf_nsort = false;      // a level's queue is sorted by row width only, not by (width, number of minimisers)
     bool hibf_stage = false;      // the packed kernel fetches every hash from global memory (no staging in LDS)
     bool hibf_persistent = false; // one launch per width class instead of one persistent launch per level
     bool hibf_fake_hashes = false; // TIMING EXPERIMENT ONLY (wrong results): the packed kernel loads one hash per item and derives the others
@@ -316,6 +317,7 @@ struct gn_stream
     uint2*        d_work[2]{ nullptr, nullptr };
     uint2*        d_hdefer = nullptr;  // (read, ibf) items the packed kernel leaves to the per-item register-counter kernel
     uint2*        d_hdefer2 = nullptr; // ... and those that one leaves to the LDS-counter kernel
+    unsigned long long* d_hsub = nullptr; // per level 3 x 128: counts, bases, cursors of the (width class, n-bin) keys of the level's sorted queue
     unsigned long long* d_hctr = nullptr; // NL = GN_HIBF_MAXDEPTH+1 per row: [l] queue length of level l, [NL+l] / [2NL+l] deferred items
     unsigned long long* h_hctr = nullptr; // pinned copy
     uint32_t      work_cap = 0;

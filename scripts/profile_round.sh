@@ -12,7 +12,7 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_${TAG}_$WL
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline --no-extra --no-variants --check 0"
+BENCH="python $ROOT/bench.py --workload $WL --steps 5 --warmup 1 --no-cpu-baseline --no-extra --no-variants --no-every-row --check 0"
 cd /tmp
 python $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --no-extra > $OUT/bench.json 2> $OUT/bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1

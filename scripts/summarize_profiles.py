@@ -20,7 +20,7 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
 dst = os.path.join(ROOT, "profiles")
 # kernels whose launches make up one "count/select" step of the workload
 HIBF = ["gn_hibf_pack_kernel", "gn_hibf_reg_kernel", "gn_hibf_level_kernel"]
-KERNELS = {"hibf64k": HIBF, "hibf64k_top1g": HIBF, "hibf64k_skew": HIBF, "split32k": ["gn_ibf_count_split_kernel"]}.get(wl, ["gn_ibf_count_fast_kernel"])
+KERNELS = {"hibf64k": HIBF, "hibf64k_top1g": HIBF, "hibf64k_skew": HIBF, "hibf64k_p001": HIBF, "hibf64k_skew_p001": HIBF, "split32k": ["gn_ibf_count_split_kernel"]}.get(wl, ["gn_ibf_count_fast_kernel"])
 
 
 def find(sub, suffix):
@@ -61,8 +61,9 @@ def copy(sub, suffix, name, only_ours=False):
     return p
 
 
-line = [ln for ln in open(os.path.join(src, "bench.json")).read().splitlines() if ln.startswith('{"metric"')][-1]
-bench = json.loads(line)
+_lines = open(os.path.join(src, "bench.json")).read().splitlines()
+_detail = [ln[len("bench_detail: "):] for ln in _lines if ln.startswith("bench_detail: ")]   # (round 5: the full result is the earlier line)
+bench = json.loads(_detail[-1] if _detail else [ln for ln in _lines if ln.startswith('{"metric"')][-1])
 with open(os.path.join(dst, f"{tag}_bench_{wl}.json"), "w") as f:
     json.dump(bench, f, indent=1)
 copy("trace", "kernel_stats.csv", f"{tag}_{wl}_kernel_stats.csv")
