@@ -24,7 +24,7 @@ BIN_REASSIGN = os.path.join(HOST, "ganon-reassign")
 BUILD_ONLY = ("build.cpp", "build_params.cpp")  # sources of ganon-build that ganon-classify does not link
 REASSIGN_ONLY = ("reassign.cpp", "reassign_main.cpp")  # ganon-reassign (the EM over .all)
 
-HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_build.hip", "gn_gather.hip", "gn_fastq.hip", "gn_reassign.hip", "gn_capi.hip"]
+HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_build.hip", "gn_gather.hip", "gn_fastq.hip", "gn_reassign.hip", "gn_inflate.hip", "gn_capi.hip"]
 HIP_HEADERS = ["gn_internal.h", "gn_scan.h", os.path.join(ROOT, "include", "ganon_hip.h")]
 
 

@@ -1,0 +1,1778 @@
+// gn_inflate.hip -- a gzip file (RFC 1952 members of RFC 1951 DEFLATE data) inflated on the device.
+//
+// Where it sits: the reference reads `reads.fq.gz` through ONE zlib stream per file (seqan3::sequence_file_input over a gz
+// stream, /root/reference/src/ganon-classify/GanonClassify.cpp:1220-1287; one decompression thread, :1433).  The host side of
+// this repo already inflates such a file on several threads (host/pgzip.cpp: speculative block starts + 16-bit symbols with
+// window markers, the scheme of pugz / rapidgzip); on the 16-core hosts of the GPU boxes that is what bounds a `.fq.gz` run
+// (47 Mreads/s against 113-125 for plain FASTQ and 230 for the kernels alone).  Here the same scheme runs on the device, and
+// the compressed bytes -- a quarter of the text -- are what crosses the link:
+//
+//   1. the compressed file is cut into CHUNKS of `chunk_bytes` (32 KiB).  One wave per chunk (gi_chunk_kernel):
+//      * SEARCH: 64 lanes test 64 consecutive bit positions at a time for a non-final dynamic-Huffman block header (BFINAL = 0,
+//        BTYPE = 2, HLIT/HDIST in range, a COMPLETE code-length code); every survivor is parsed by the whole wave (code lengths,
+//        complete literal/length code with an end-of-block code, legal distance code) and its block is decoded in strict mode
+//        (printable text only: the inputs are FASTQ/FASTA) -- the first position that passes is the chunk's start;
+//      * DECODE from there to the first block boundary at or after the next chunk's nominal start.  The loop is wave-uniform
+//        (bit buffer, table lookups and branches are scalar; the Huffman tables live in LDS, the input window in a register
+//        that is refilled with one coalesced 256-byte load per 2048 bits); the 64 lanes do the work that is parallel: table
+//        construction, LZ77 copies (one symbol per lane), stores.  Output = 16-bit symbols: a byte, or a MARKER 256 + i for
+//        "byte i of the 32 KiB before this chunk".  The last 1024 symbols live in an LDS ring (most match sources are there,
+//        and nothing is read from global memory before the line that holds it has been written completely); older sources
+//        are read back from the chunk's own output, which is allocated in pieces of 32 Ki symbols from a pool (no bound on a
+//        chunk's expansion has to be guessed);
+//   2. CHAIN (gi_chain_kernel, one workgroup, in stream order): the chunk that starts exactly where its predecessor ended is
+//      the continuation; its incoming window is saved, its outgoing window (last 32 KiB with markers resolved) computed, its
+//      text offset assigned, the members' ISIZE checked.  A position at which no chunk starts (a false start, a block of a
+//      kind the search does not look for) stops the chain with GAP: one wave decodes from the true position (gi_chunk_kernel
+//      in fix-up mode) and the chain goes on;
+//   3. RESOLVE (gi_resolve_kernel): symbols -> bytes of the text, markers through the chunk's saved window, all chunks in parallel.
+//
+// What the search cannot find (stored and fixed blocks, final blocks) is simply decoded by the chunk before.  Data this
+// scheme does not suit (hardly any dynamic blocks; expansion above the pool; members without end) makes gn_inflate_step
+// fail with GN_ERANGE: the caller takes its host path (pgzip.cpp / zlib) -- the device never guesses, and never returns text
+// it has not decoded bit-exactly.  CRC-32: see gi_crc_kernel.
+#include "gn_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace
+{
+
+constexpr uint32_t GI_WINDOW     = 32768u;
+constexpr uint32_t GI_PIECE_LOG2 = 15u; // symbols per output piece (>= the window: a match source is in this piece or the one before)
+constexpr uint32_t GI_PIECE      = 1u << GI_PIECE_LOG2;
+constexpr uint32_t GI_MAX_PIECES = 64u; // per chunk: 2 Mi symbols
+constexpr uint32_t GI_LIT_ROOT   = 9u, GI_LIT_CAP = 1024u; // (zlib's ENOUGH_LENS for a 9-bit root is 852)
+constexpr uint32_t GI_DIST_ROOT  = 6u, GI_DIST_CAP = 640u; // (ENOUGH_DISTS for a 6-bit root is 592)
+constexpr uint32_t GI_PRE_ROOT   = 7u;
+constexpr uint32_t GI_RING       = 1024u;
+constexpr uint32_t GI_MEND       = 32u; // member ends one chunk may hold
+constexpr uint64_t GI_NONE       = ~0ull;
+
+enum : uint32_t
+{
+    GI_F_END      = 1u,  // the stream ended in this chunk (last member's trailer, nothing that is a member behind it)
+    GI_F_FAILED   = 2u,  // data error after the chunk's symbols
+    GI_F_SHORT    = 4u,  // ran out of the bytes fed so far (not an error while more are to come)
+    GI_F_OVERFLOW = 8u,  // pool / pieces-per-chunk / member-end capacity
+    GI_F_FRESH    = 16u, // begins at a member header
+    GI_F_MEMBERS  = 32u, // members end or begin inside
+};
+
+enum : uint32_t
+{
+    GI_R_RANGE = 0, // every chunk of the range is consumed
+    GI_R_GAP,       // no chunk starts at the stream's position
+    GI_R_INPUT,     // the next chunk needs bytes that are not fed yet
+    GI_R_END,       // end of the gzip stream
+    GI_R_DATA,      // damaged data
+    GI_R_OVERFLOW,
+    GI_R_MEMBER,    // a member's ISIZE is not its length
+};
+
+struct GiChunk
+{
+    uint64_t start_bit, end_bit;
+    uint32_t out_len, flags, n_mend, markers;
+    uint32_t members_begun, pad;
+    uint32_t prof[8]; // 10 ns ticks: [0] screen [1] headers of candidates [2] headers [3] phase A [4] phase B [5] flush [6] whole chunk
+    uint32_t mend_sym[GI_MEND], mend_crc[GI_MEND], mend_isize[GI_MEND];
+    uint32_t piece[GI_MAX_PIECES];
+};
+
+struct GiReal // a chunk the chain took
+{
+    uint32_t slot, out_len;
+    uint64_t text_off;
+    uint32_t wbase, pad; // its first item in the resolve pass's work list
+};
+
+struct GiState
+{
+    uint64_t pos_bit;   // the stream is decoded up to here
+    uint64_t run_len;   // bytes of the current member so far
+    uint64_t text_off;  // bytes of text of this step so far
+    uint64_t gap_stop;  // GAP: where the fix-up decode may stop (the next found start behind pos_bit)
+    uint32_t cursor;    // next slot of the range to look at
+    uint32_t n_real;
+    uint32_t n_work;    // (real chunk, piece) items for the resolve kernel
+    uint32_t reason;
+    uint32_t fix_slot;  // ~0u, or the slot a fix-up decode filled: taken first
+    uint32_t members;   // members begun so far
+    uint64_t markers;
+    // what gi_order_kernel found (the fields above it only reads: pos_bit, run_len)
+    uint64_t res_pos, res_run_len, res_markers;
+    uint32_t res_members, pad;
+    unsigned long long prof[8]; // sums of the chain chunks' GiChunk::prof
+};
+
+struct GiLds
+{
+    uint32_t lit[GI_LIT_CAP];
+    uint32_t dst[GI_DIST_CAP];
+    uint16_t ring[GI_RING];
+    uint32_t piece[GI_MAX_PIECES];
+    uint16_t tok_len[64], tok_val[64]; // the batch's tokens (gi_codes)
+    uint8_t  lens[320];
+};
+
+struct GiParams
+{
+    const uint32_t* comp;      // compressed file as dwords (padded with zeros)
+    uint64_t        avail_bits; // fed so far
+    uint64_t        total_bits; // the file
+    uint32_t        chunk_bytes;
+    uint32_t        j0, n;      // chunks j0 .. j0+n of the file -> slots 0..n
+    GiChunk*        chunks;
+    uint16_t*       pool;
+    uint32_t*       pool_next;
+    uint32_t        pool_cap;
+    uint32_t*       work_next;  // atomic chunk counter
+    // fix-up mode (n == 1): decode from fix_start (no search) into slot fix_slot, stop at the first boundary >= fix_stop
+    uint64_t fix_start, fix_stop;
+    uint32_t fix_slot;
+    uint32_t strict;            // search mode: the first block must be text
+};
+
+__device__ const uint16_t kLenBase[32]  = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0, 0 };
+__device__ const uint8_t  kLenExtra[32] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0, 0 };
+__device__ const uint16_t kDistBase[32] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 0, 0 };
+__device__ const uint8_t  kDistExtra[32] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0 };
+__device__ const uint8_t  kClOrder[19]  = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+
+__device__ __forceinline__ uint32_t gi_rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t gi_lane() { return threadIdx.x & 63u; }
+// Results of functions the compiler may leave as calls come back in vector registers: say that they are wave-uniform, or every
+// branch on them counts as divergent and the decode loop's state (bit buffer, positions) ends up in vector registers.
+__device__ __forceinline__ bool     gi_ub(bool v) { return gi_rfl(v ? 1u : 0u) != 0u; }
+__device__ __forceinline__ uint64_t gi_u64(uint64_t v) { return ((uint64_t)gi_rfl((uint32_t)(v >> 32)) << 32) | gi_rfl((uint32_t)v); }
+
+// ---- input: least-significant-bit-first reader over the dword view of the file; every value is wave-uniform -------------------
+struct GiIn
+{
+    const uint32_t* base;
+    uint64_t        n_dw;  // dwords that hold fed bytes (beyond: zeros)
+    uint32_t        cur, nxt; // lane l: dword win + l / win + 64 + l
+    uint64_t        win;
+    uint32_t        idx;
+    uint64_t        buf;
+    uint32_t        cnt;
+
+    __device__ __forceinline__ uint32_t load(uint64_t i) const { return i < n_dw ? __builtin_nontemporal_load(base + i) : 0u; }
+    __device__ __forceinline__ void     seek(uint64_t bit)
+    {
+        win = bit >> 5;
+        idx = 0;
+        cur = load(win + gi_lane());
+        nxt = load(win + 64 + gi_lane());
+        buf = 0;
+        cnt = 0;
+        refill();
+        drop((uint32_t)(bit & 31u));
+        refill();
+    }
+    __device__ __forceinline__ uint64_t pos() const { return ((win + idx) << 5) - cnt; }
+    // at least 33 valid bits afterwards
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32u)
+        {
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)idx);
+            buf |= (uint64_t)d << cnt;
+            cnt += 32u;
+            if (++idx == 64u)
+            {
+                cur = nxt;
+                win += 64;
+                idx = 0;
+                nxt = load(win + 64 + gi_lane());
+            }
+        }
+    }
+    __device__ __forceinline__ void     drop(uint32_t n) { buf >>= n; cnt -= n; }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+    __device__ __forceinline__ uint32_t get(uint32_t n) // n <= 16, after a refill
+    {
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+};
+
+// ---- output: 16-bit symbols; the newest GI_RING of them in LDS, everything before `flushed` in the chunk's pieces ---------------
+struct GiOut
+{
+    uint32_t  pos, flushed;
+    uint32_t  markers;
+    bool      ovf;
+    uint32_t  tA, tB, tF; // profile: ticks in phase A / B / flushes
+    bool      have0; // piece 0 was allocated by an earlier attempt of this chunk (a false start): taken again
+    uint16_t* pool;
+    uint32_t* pool_next;
+    uint32_t  pool_cap;
+};
+
+__device__ __forceinline__ uint16_t* gi_sym_addr(uint16_t* pool, const uint32_t* piece, uint32_t p)
+{
+    return pool + (((uint64_t)piece[p >> GI_PIECE_LOG2] << GI_PIECE_LOG2) | (p & (GI_PIECE - 1u)));
+}
+
+__device__ __forceinline__ bool gi_new_piece(GiLds& L, GiOut& o, uint32_t q)
+{
+    if (q >= GI_MAX_PIECES)
+    {
+        o.ovf = true;
+        return false;
+    }
+    if (q == 0u && o.have0)
+        return true;
+    uint32_t id = 0;
+    if (gi_lane() == 0)
+        id = atomicAdd(o.pool_next, 1u);
+    id = gi_rfl(id);
+    if (id >= o.pool_cap)
+    {
+        o.ovf = true;
+        return false;
+    }
+    L.piece[q] = id;
+    if (q == 0u)
+        o.have0 = true;
+    __syncthreads();
+    return true;
+}
+
+// 256 symbols (whole 128-byte lines) from the ring to the chunk's output
+__device__ __forceinline__ void gi_flush256(GiLds& L, GiOut& o)
+{
+    if ((o.flushed & (GI_PIECE - 1u)) == 0u && !gi_new_piece(L, o, o.flushed >> GI_PIECE_LOG2))
+        return;
+    uint16_t*   dst = gi_sym_addr(o.pool, L.piece, o.flushed);
+    const uint2 v   = *reinterpret_cast<const uint2*>(&L.ring[(o.flushed + 4u * gi_lane()) & (GI_RING - 1u)]);
+    *reinterpret_cast<uint2*>(dst + 4u * gi_lane()) = v;
+    o.flushed += 256u;
+}
+
+__device__ __forceinline__ void gi_flush_rest(GiLds& L, GiOut& o)
+{
+    while (o.pos - o.flushed >= 256u && !o.ovf)
+        gi_flush256(L, o);
+    if (o.ovf)
+        return;
+    const uint32_t rest = o.pos - o.flushed; // < 256: inside one piece
+    if (rest)
+    {
+        if ((o.flushed & (GI_PIECE - 1u)) == 0u && !gi_new_piece(L, o, o.flushed >> GI_PIECE_LOG2))
+            return;
+        uint16_t* dst = gi_sym_addr(o.pool, L.piece, o.flushed);
+        for (uint32_t i = gi_lane(); i < rest; i += 64u)
+            dst[i] = L.ring[(o.flushed + i) & (GI_RING - 1u)];
+        o.flushed = o.pos;
+    }
+}
+
+__device__ __forceinline__ void gi_emit(GiLds& L, GiOut& o, uint32_t sym)
+{
+    L.ring[o.pos & (GI_RING - 1u)] = (uint16_t)sym;
+    ++o.pos;
+}
+
+// LZ77 copy of `len` symbols from `dist` back.  lo_limit: how far before the chunk a source may lie (32768 with markers, 0 at a
+// member start); base: first symbol of the current member inside the chunk.  false = a source outside what exists.
+__device__ __forceinline__ bool gi_copy(GiLds& L, GiOut& o, uint32_t len, uint32_t dist, uint32_t base, bool markers_ok)
+{
+    const int32_t s0 = (int32_t)o.pos - (int32_t)dist;
+    if (s0 < (int32_t)base && (!markers_ok || base != 0u || s0 < -(int32_t)GI_WINDOW))
+        return false;
+    const int32_t ring_lo = (int32_t)o.pos + (int32_t)len - (int32_t)GI_RING; // positions from here on are in the ring for the whole copy
+    const bool    far     = s0 < ring_lo;
+    if (far)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores of the lines read below have left this wave long ago: make it certain
+    for (uint32_t t = 0; t < len; t += 64u)
+    {
+        const uint32_t i = t + gi_lane();
+        if (i < len)
+        {
+            const uint32_t off = dist >= len ? i : (dist == 1u ? 0u : i % dist);
+            const int32_t  sp  = s0 + (int32_t)off;
+            uint32_t       v;
+            if (sp < 0)
+                v = 256u + (uint32_t)((int32_t)GI_WINDOW + sp);
+            else if (sp >= ring_lo)
+                v = L.ring[(uint32_t)sp & (GI_RING - 1u)];
+            else
+                v = *gi_sym_addr(o.pool, L.piece, (uint32_t)sp);
+            if (v >= 256u)
+                o.markers += 1u; // (per-lane tally, summed at the end of the chunk)
+            L.ring[(o.pos + i) & (GI_RING - 1u)] = (uint16_t)v;
+        }
+    }
+    o.pos += len;
+    return true;
+}
+
+// ---- canonical Huffman tables in LDS -------------------------------------------------------------------------------------------
+// entry: [31:16] value (literal / base length / base distance / subtable offset)  [9:8] kind (0 literal, 1 base+extra, 2 end of
+// block, 3 link to a subtable)  [7:4] extra bits (link: index bits of the subtable)  [3:0] bits to drop (0 = no such code)
+template <int KIND> // 0 code-length code, 1 literal/length, 2 distance
+__device__ __forceinline__ uint32_t gi_payload(uint32_t s)
+{
+    if (KIND == 0)
+        return s << 16;
+    if (KIND == 1)
+    {
+        if (s < 256u)
+            return s << 16;
+        if (s == 256u)
+            return 0x200u;
+        if (s > 285u)
+            return ~0u; // (a code that must not occur)
+        return ((uint32_t)kLenBase[s - 257u] << 16) | 0x100u | ((uint32_t)kLenExtra[s - 257u] << 4);
+    }
+    if (s > 29u)
+        return ~0u;
+    return ((uint32_t)kDistBase[s] << 16) | 0x100u | ((uint32_t)kDistExtra[s] << 4);
+}
+
+// lens[0..n) in LDS -> tab.  incomplete: 0 never accepted, 1 a single code of length 1 is, 2 any (the fixed distance code).
+// NG = ceil(n / 64).  Returns false for an over-subscribed / incomplete / empty set or a table beyond cap (wave-uniform).
+template <int KIND, int NG>
+__device__ bool gi_build(uint32_t* tab, uint32_t cap, const uint8_t* lens, uint32_t n, uint32_t root, int incomplete)
+{
+    const uint32_t lane = gi_lane();
+    const uint64_t lt   = (1ull << lane) - 1ull;
+    __syncthreads();
+    uint32_t l[NG], rank[NG];
+    uint32_t cnt = 0; // lane i: codes of length i seen so far
+    for (int g = 0; g < NG; ++g)
+    {
+        const uint32_t s = (uint32_t)g * 64u + lane;
+        l[g]             = s < n ? lens[s] : 0u;
+        rank[g]          = 0;
+        uint64_t rem     = __ballot(l[g] != 0u);
+        while (rem)
+        {
+            const int      src = __builtin_ctzll(rem);
+            const uint32_t lv  = (uint32_t)__builtin_amdgcn_readlane((int)l[g], src);
+            const uint64_t m   = __ballot(l[g] == lv);
+            const uint32_t b   = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)lv);
+            if (l[g] == lv)
+                rank[g] = b + (uint32_t)__popcll(m & lt);
+            if (lane == lv)
+                cnt += (uint32_t)__popcll(m);
+            rem &= ~m;
+        }
+    }
+    // first code of every length (lane i: of length i), completeness
+    int      left = 1;
+    uint32_t code = 0, first = 0, used = 0, prev = 0;
+    for (uint32_t i = 1; i <= 15u; ++i)
+    {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)i);
+        code             = (code + prev) << 1;
+        if (lane == i)
+            first = code;
+        prev = c;
+        used += c;
+        left = (left << 1) - (int)c;
+        if (left < 0)
+            return false;
+    }
+    if (used == 0u)
+        return false;
+    if (left > 0 && !(incomplete == 2 || (incomplete == 1 && used == 1u && (uint32_t)__builtin_amdgcn_readlane((int)cnt, 1) == 1u)))
+        return false;
+    const uint32_t P = 1u << root;
+    for (uint32_t x = lane; x < P; x += 64u)
+        tab[x] = 0u;
+    __syncthreads();
+    uint32_t r[NG];
+    for (int g = 0; g < NG; ++g)
+    {
+        r[g] = 0;
+        const uint32_t f = (uint32_t)__shfl((int)first, (int)(l[g] & 15u));
+        if (l[g])
+        {
+            r[g] = __brev(f + rank[g]) >> (32u - l[g]);
+            if (l[g] > root)
+                atomicMax(&tab[r[g] & (P - 1u)], l[g] - root);
+        }
+    }
+    __syncthreads();
+    // subtables: lane owns P/64 consecutive root entries
+    const uint32_t E = P >= 64u ? P / 64u : 1u;
+    uint32_t       mine = 0;
+    if (lane * E < P)
+        for (uint32_t x = lane * E; x < lane * E + E; ++x)
+            mine += tab[x] ? 1u << tab[x] : 0u;
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if ((int)lane >= o)
+            incl += up;
+    }
+    const uint32_t total = P + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total > cap)
+        return false;
+    uint32_t at = P + incl - mine;
+    if (lane * E < P)
+        for (uint32_t x = lane * E; x < lane * E + E; ++x)
+        {
+            const uint32_t sb = tab[x];
+            if (sb)
+            {
+                tab[x] = (at << 16) | 0x300u | (sb << 4) | root;
+                at += 1u << sb;
+            }
+        }
+    for (uint32_t x = P + lane; x < total; x += 64u)
+        tab[x] = 0u;
+    __syncthreads();
+    for (int g = 0; g < NG; ++g)
+    {
+        const uint32_t s = (uint32_t)g * 64u + lane;
+        if (!l[g])
+            continue;
+        const uint32_t pay = gi_payload<KIND>(s);
+        const bool     ok  = pay != ~0u; // (a code that fills code space but must not be used keeps "no such code" entries)
+        if (l[g] <= root)
+        {
+            const uint32_t e = ok ? (pay | l[g]) : 0u;
+            for (uint32_t x = r[g]; x < P; x += 1u << l[g])
+                tab[x] = e;
+        }
+        else
+        {
+            const uint32_t link = tab[r[g] & (P - 1u)];
+            const uint32_t off = link >> 16, sb = (link >> 4) & 15u, hl = l[g] - root;
+            const uint32_t e = ok ? (pay | hl) : 0u;
+            for (uint32_t x = r[g] >> root; x < (1u << sb); x += 1u << hl)
+                tab[off + x] = e;
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// one symbol of the code in `tab`; 0 = no such code.  The caller has refilled (>= 33 bits: root + subtable <= 15).
+__device__ __forceinline__ uint32_t gi_decode(const uint32_t* tab, uint32_t root_mask, GiIn& in)
+{
+    uint32_t e = gi_rfl(tab[(uint32_t)in.buf & root_mask]);
+    if ((e & 0x300u) == 0x300u)
+    {
+        in.drop(e & 15u);
+        e = gi_rfl(tab[(e >> 16) + ((uint32_t)in.buf & ((1u << ((e >> 4) & 15u)) - 1u))]);
+    }
+    in.drop(e & 15u);
+    return e;
+}
+
+struct GiBlockCtx
+{
+    bool have_dist;
+};
+
+// dynamic block header behind BFINAL/BTYPE: tables into L.lit / L.dst
+__device__ bool gi_dynamic_header(GiLds& L, GiIn& in, GiBlockCtx& bc)
+{
+    const uint32_t lane = gi_lane();
+    in.refill();
+    const uint32_t hlit = in.get(5) + 257u, hdist = in.get(5) + 1u, hclen = in.get(4) + 4u;
+    if (hlit > 286u || hdist > 30u)
+        return false;
+    __syncthreads();
+    if (lane < 19u)
+        L.lens[lane] = 0;
+    __syncthreads();
+    for (uint32_t i = 0; i < hclen; ++i)
+    {
+        in.refill();
+        L.lens[kClOrder[i]] = (uint8_t)in.get(3);
+    }
+    uint32_t* pre = L.dst; // (the distance table is built after the lengths are read)
+    if (!gi_ub(gi_build<0, 1>(pre, 128u, L.lens, 19u, GI_PRE_ROOT, 0)))
+        return false;
+    const uint32_t tot = hlit + hdist;
+    uint32_t       i = 0, prev = 0;
+    __syncthreads();
+    while (i < tot)
+    {
+        in.refill();
+        const uint32_t e = gi_rfl(pre[(uint32_t)in.buf & 127u]);
+        if ((e & 15u) == 0u)
+            return false;
+        in.drop(e & 15u);
+        const uint32_t s = e >> 16;
+        if (s < 16u)
+        {
+            L.lens[i++] = (uint8_t)s;
+            prev        = s;
+            continue;
+        }
+        uint32_t rep, val;
+        if (s == 16u)
+        {
+            if (i == 0u)
+                return false;
+            rep = 3u + in.get(2);
+            val = prev;
+        }
+        else if (s == 17u)
+        {
+            rep = 3u + in.get(3);
+            val = 0u;
+            prev = 0u;
+        }
+        else
+        {
+            rep = 11u + in.get(7);
+            val = 0u;
+            prev = 0u;
+        }
+        if (i + rep > tot)
+            return false;
+        for (uint32_t t = lane; t < rep; t += 64u)
+            L.lens[i + t] = (uint8_t)val;
+        i += rep;
+    }
+    __syncthreads();
+    if (gi_rfl(L.lens[256]) == 0u)
+        return false;
+    // the distance lengths move behind the literal/length lengths' 288 slots so that both builds see arrays that begin at 0
+    uint8_t dl = 0;
+    if (lane < hdist)
+        dl = L.lens[hlit + lane];
+    __syncthreads();
+    if (!gi_ub(gi_build<1, 5>(L.lit, GI_LIT_CAP, L.lens, hlit, GI_LIT_ROOT, 0)))
+        return false;
+    if (lane < 32u)
+        L.lens[lane] = lane < hdist ? dl : 0;
+    __syncthreads();
+    bc.have_dist = __ballot(dl != 0) != 0ull;
+    if (bc.have_dist && !gi_ub(gi_build<2, 1>(L.dst, GI_DIST_CAP, L.lens, hdist, GI_DIST_ROOT, 1)))
+        return false;
+    return true;
+}
+
+__device__ bool gi_fixed_header(GiLds& L, GiBlockCtx& bc)
+{
+    const uint32_t lane = gi_lane();
+    __syncthreads();
+    for (uint32_t s = lane; s < 288u; s += 64u)
+        L.lens[s] = s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8;
+    __syncthreads();
+    if (!gi_ub(gi_build<1, 5>(L.lit, GI_LIT_CAP, L.lens, 288u, GI_LIT_ROOT, 0)))
+        return false;
+    if (lane < 32u)
+        L.lens[lane] = 5;
+    __syncthreads();
+    bc.have_dist = true;
+    return gi_ub(gi_build<2, 1>(L.dst, GI_DIST_CAP, L.lens, 32u, GI_DIST_ROOT, 2));
+}
+
+// One symbol of the chunk's output by position (a marker before the chunk, the ring, or the chunk's flushed pieces)
+__device__ __forceinline__ uint32_t gi_fetch(const GiLds& L, const GiOut& o, int32_t sp, int32_t ring_lo)
+{
+    if (sp < 0)
+        return 256u + (uint32_t)((int32_t)GI_WINDOW + sp);
+    if (sp >= ring_lo)
+        return L.ring[(uint32_t)sp & (GI_RING - 1u)];
+    return *gi_sym_addr(o.pool, L.piece, (uint32_t)sp);
+}
+
+// The symbols of one Huffman-coded block.  0 = ended with its end-of-block code, 1 = data error, 2 = capacity.
+//
+// What bounds this kernel is not latency but instruction issue (a SIMD issues one scalar and one vector instruction per four clocks
+// whatever the number of waves; a token decoded by a wave-uniform loop costs ~75 of them).  So the 64 lanes do the decoding as well:
+//   A. a ROUND looks at the next 64 bit positions: lane l decodes the whole token that would begin at position l (literal/length
+//      code, extra bits, distance code, extra bits: two LDS lookups, rarely four) from its own 64 bits of the input window (a
+//      register that holds 64 dwords of the file; five of them, taken as scalars, cover a round); then the wave follows the chain
+//      from position 0 -- position + bits of the token there is the next token -- with one v_readlane per token, and the lanes on
+//      the chain drop their tokens into a list in LDS.  Rounds repeat until the list holds about 64 tokens (or the block ends);
+//   B. the lanes place the list's tokens: output offsets by a prefix sum over the lengths; literals are one LDS store; every short
+//      match whose source lies before the batch's first symbol is copied by ITS lane from the ring or from the chunk's flushed output
+//      (the far loads of up to 64 matches are in flight together); long ones, and matches that read what the batch itself produces
+//      (or overlap their own output), follow in token order, each spread over the lanes.  A batch adds at most 512 symbols, so
+//      everything it reads near-by is still in the 1024-symbol ring.
+#define GI_SHORT_MATCH 12u
+template <bool STRICT>
+__device__ int gi_codes(GiLds& L, GiIn& in, GiOut& o, const GiBlockCtx& bc, uint32_t base, bool markers_ok, uint64_t limit_dw)
+{
+    const uint32_t lane = gi_lane();
+    const uint64_t lt   = (1ull << lane) - 1ull;
+    // the round's input window: dwords [32 a, 32 a + 64) in wcur, the 64 from 32 (a + 1) on in wnxt
+    uint64_t pos = in.pos();
+    uint64_t a32 = (pos >> 5) & ~31ull;
+    uint32_t wcur = in.load(a32 + lane), wnxt = in.load(a32 + 32u + lane);
+    int      end = -1; // 0: end of block seen, 1: error
+    while (end < 0)
+    {
+        // ---- A ---------------------------------------------------------------------------------------------------------------------
+        const uint64_t t_a = wall_clock64();
+        uint32_t       nt = 0, cum = 0;
+        bool           full = false;
+        while (end < 0 && !full && nt <= 52u)
+        {
+            uint32_t k0 = (uint32_t)((pos >> 5) - a32);
+            if (k0 >= 32u)
+            {
+                a32 += 32u;
+                k0 -= 32u;
+                wcur = wnxt;
+                wnxt = in.load(a32 + 32u + lane);
+            }
+            const uint32_t u0 = (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)k0), u1 = (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)k0 + 1),
+                           u2 = (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)k0 + 2), u3 = (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)k0 + 3),
+                           u4 = (uint32_t)__builtin_amdgcn_readlane((int)wcur, (int)k0 + 4);
+            const uint32_t sh = (uint32_t)(pos & 31u) + lane, q = sh >> 5, r = sh & 31u;
+            const uint32_t d0 = q == 0u ? u0 : q == 1u ? u1 : u2, d1 = q == 0u ? u1 : q == 1u ? u2 : u3, d2 = q == 0u ? u2 : q == 1u ? u3 : u4;
+            const uint32_t xl = __funnelshift_r(d0, d1, r), xh = __funnelshift_r(d1, d2, r);
+            const uint64_t x  = ((uint64_t)xh << 32) | xl;
+            // the token at this lane's position: pk = bits | kind << 6 | length << 8  (kind 0 literal, 1 match, 2 end of block, 3 no such code)
+            uint32_t e = L.lit[xl & ((1u << GI_LIT_ROOT) - 1u)], clen = e & 15u;
+            if ((e & 0x300u) == 0x300u)
+            {
+                e    = L.lit[(e >> 16) + ((xl >> GI_LIT_ROOT) & ((1u << ((e >> 4) & 15u)) - 1u))];
+                clen = (e & 15u) ? GI_LIT_ROOT + (e & 15u) : 0u;
+            }
+            uint32_t kind = (e >> 8) & 3u, bits = clen, tlen = 1u, tval = e >> 16;
+            if (clen == 0u)
+                kind = 3u;
+            if (kind == 0u && STRICT && !((tval >= 32u && tval < 127u) || tval == '\n' || tval == '\r' || tval == '\t'))
+                kind = 3u;
+            if (kind == 1u)
+            {
+                const uint32_t xb = (e >> 4) & 15u;
+                tlen              = tval + ((uint32_t)(x >> clen) & ((1u << xb) - 1u));
+                const uint32_t n1 = clen + xb;
+                const uint32_t y  = (uint32_t)(x >> n1);
+                uint32_t       d = L.dst[y & ((1u << GI_DIST_ROOT) - 1u)], dlen = d & 15u;
+                if ((d & 0x300u) == 0x300u)
+                {
+                    d    = L.dst[(d >> 16) + ((y >> GI_DIST_ROOT) & ((1u << ((d >> 4) & 15u)) - 1u))];
+                    dlen = (d & 15u) ? GI_DIST_ROOT + (d & 15u) : 0u;
+                }
+                const uint32_t db = (d >> 4) & 15u;
+                tval              = (d >> 16) + ((y >> dlen) & ((1u << db) - 1u));
+                bits              = n1 + dlen + db;
+                if (dlen == 0u || !bc.have_dist)
+                    kind = 3u;
+            }
+            const uint32_t pk = bits | (kind << 6) | (tlen << 8);
+            // the chain from position 0
+            uint64_t M = 0;
+            uint32_t at = 0, cnt = 0;
+            while (at < 64u)
+            {
+                const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)at);
+                const uint32_t k = (info >> 6) & 3u, b = info & 63u, tl1 = info >> 8;
+                if (k >= 2u)
+                {
+                    end = k == 2u ? 0 : 1;
+                    if (k == 2u)
+                        at += b;
+                    break;
+                }
+                if (nt + cnt >= 64u || cum + tl1 > 512u)
+                {
+                    full = true;
+                    break;
+                }
+                M |= 1ull << at;
+                cum += tl1;
+                ++cnt;
+                at += b;
+            }
+            pos += at;
+            if ((M >> lane) & 1ull)
+            {
+                const uint32_t slot = nt + (uint32_t)__popcll(M & lt);
+                L.tok_len[slot]     = (uint16_t)tlen;
+                L.tok_val[slot]     = (uint16_t)(kind == 1u ? tval - 1u : (0x8000u | tval)); // distance - 1 (0..32767), or bit 15 + the literal
+            }
+            nt += cnt;
+        }
+        // ---- B ---------------------------------------------------------------------------------------------------------------------
+        const uint64_t t_b = wall_clock64();
+        o.tA += (uint32_t)(t_b - t_a);
+        if (nt)
+        {
+            __syncthreads();
+            const bool mine = lane < nt;
+            uint32_t   tl = 0, td = 0, tv = 0;
+            if (mine)
+            {
+                tl                 = L.tok_len[lane];
+                const uint32_t raw = L.tok_val[lane];
+                if (raw & 0x8000u)
+                    tv = raw & 0xFFu;
+                else
+                    td = raw + 1u;
+            }
+            __syncthreads();
+            uint32_t incl = tl;
+            for (int s = 1; s < 64; s <<= 1)
+            {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, s);
+                if ((int)lane >= s)
+                    incl += up;
+            }
+            const uint32_t my      = o.pos + incl - tl;
+            const int32_t  bstart  = (int32_t)o.pos;
+            const int32_t  bend    = (int32_t)(o.pos + cum);
+            const int32_t  ring_lo = bend - (int32_t)GI_RING;
+            const bool     is_m    = mine && td != 0u;
+            const int32_t  src     = (int32_t)my - (int32_t)td;
+            // a source outside what exists: before the member's first symbol, or further before the chunk than a window
+            const bool bad = is_m && src < (int32_t)base && (!markers_ok || base != 0u || src < -(int32_t)GI_WINDOW);
+            if (__ballot(bad))
+                return 1;
+            if (mine && td == 0u)
+                L.ring[my & (GI_RING - 1u)] = (uint16_t)tv;
+            const bool indep = is_m && td >= tl && src + (int32_t)tl <= bstart;
+            // short independent matches, by their lanes: sources all in the ring ...
+            const bool in_ring = indep && tl <= GI_SHORT_MATCH && src >= ring_lo && src >= 0;
+            // ... or all in the flushed output, inside one piece
+            const bool in_out = indep && tl <= GI_SHORT_MATCH && src >= 0 && src + (int32_t)tl <= ring_lo &&
+                                ((uint32_t)src >> GI_PIECE_LOG2) == (((uint32_t)src + tl - 1u) >> GI_PIECE_LOG2);
+            if (__ballot(is_m && src < ring_lo))
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the lines read below were stored long ago: make it certain)
+            if (__ballot(in_out))
+            {
+                const uint16_t* g = in_out ? gi_sym_addr(o.pool, L.piece, (uint32_t)src) : o.pool;
+                uint32_t        v[GI_SHORT_MATCH];
+#pragma unroll
+                for (uint32_t i = 0; i < GI_SHORT_MATCH; ++i)
+                    v[i] = (in_out && i < tl) ? g[i] : 0u;
+#pragma unroll
+                for (uint32_t i = 0; i < GI_SHORT_MATCH; ++i)
+                    if (in_out && i < tl)
+                    {
+                        L.ring[(my + i) & (GI_RING - 1u)] = (uint16_t)v[i];
+                        o.markers += v[i] >= 256u ? 1u : 0u;
+                    }
+            }
+            if (__ballot(in_ring))
+            {
+#pragma unroll
+                for (uint32_t i = 0; i < GI_SHORT_MATCH; ++i)
+                    if (in_ring && i < tl)
+                    {
+                        const uint32_t v = L.ring[((uint32_t)src + i) & (GI_RING - 1u)];
+                        L.ring[(my + i) & (GI_RING - 1u)] = (uint16_t)v;
+                        o.markers += v >= 256u ? 1u : 0u;
+                    }
+            }
+            // everything else in token order, one match spread over the lanes
+            uint64_t rest = __ballot(is_m && !in_ring && !in_out);
+            while (rest)
+            {
+                const int      t    = __builtin_ctzll(rest);
+                const uint32_t len  = (uint32_t)__builtin_amdgcn_readlane((int)tl, t);
+                const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)td, t);
+                const uint32_t at   = (uint32_t)__builtin_amdgcn_readlane((int)my, t);
+                const int32_t  s0   = (int32_t)at - (int32_t)dist;
+                for (uint32_t u = 0; u < len; u += 64u)
+                {
+                    const uint32_t i = u + lane;
+                    if (i < len)
+                    {
+                        const uint32_t off = dist >= len ? i : (dist == 1u ? 0u : i % dist);
+                        const uint32_t v   = gi_fetch(L, o, s0 + (int32_t)off, ring_lo);
+                        o.markers += v >= 256u ? 1u : 0u;
+                        L.ring[(at + i) & (GI_RING - 1u)] = (uint16_t)v;
+                    }
+                }
+                rest &= rest - 1ull;
+            }
+            o.pos += cum;
+            const uint64_t t_f = wall_clock64();
+            o.tB += (uint32_t)(t_f - t_b);
+            while (o.pos - o.flushed >= 512u)
+            {
+                gi_flush256(L, o);
+                if (o.ovf)
+                    return 2;
+            }
+            o.tF += (uint32_t)(wall_clock64() - t_f);
+            if ((pos >> 5) > limit_dw) // (reading zeros beyond the fed bytes: whatever this is, it ends here)
+                return 1;
+        }
+    }
+    in.seek(pos);
+    return end;
+}
+
+// (every caller's p is wave-uniform; the readfirstlane says so to the compiler: a branch on a loaded value would otherwise count as
+//  divergent, and with it every value the decode loop carries -- bit buffer, positions -- would live in vector registers)
+__device__ __forceinline__ uint32_t gi_byte(const uint32_t* comp, uint64_t p) { return gi_rfl((comp[p >> 2] >> ((p & 3u) * 8u)) & 0xFFu); }
+
+// gzip member header at byte p; offset of the deflate data behind it, 0 = no (complete) member header there
+__device__ uint64_t gi_gzip_header(const uint32_t* comp, uint64_t size, uint64_t p)
+{
+    if (p + 18u > size || gi_byte(comp, p) != 0x1Fu || gi_byte(comp, p + 1) != 0x8Bu || gi_byte(comp, p + 2) != 8u || (gi_byte(comp, p + 3) & 0xE0u))
+        return 0;
+    const uint32_t flg = gi_byte(comp, p + 3);
+    uint64_t       q   = p + 10u;
+    if (flg & 4u)
+    {
+        if (q + 2u > size)
+            return 0;
+        q += 2u + (gi_byte(comp, q) | (gi_byte(comp, q + 1) << 8));
+    }
+    for (uint32_t bit = 8u; bit <= 16u; bit <<= 1)
+        if (flg & bit)
+        {
+            while (q < size && gi_byte(comp, q))
+                ++q;
+            ++q;
+        }
+    if (flg & 2u)
+        q += 2u;
+    return q < size ? q : 0;
+}
+
+// candidate screen of the search: is there, in the 128 bits d0..d3 from bit `sh` (< 32) on, BFINAL = 0, BTYPE = 2, HLIT/HDIST in range and
+// a complete code-length code?  (per lane)
+__device__ __forceinline__ bool gi_screen(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t sh)
+{
+    const uint32_t x0 = __funnelshift_r(d0, d1, sh), x1 = __funnelshift_r(d1, d2, sh), x2 = __funnelshift_r(d2, d3, sh);
+    if ((x0 & 7u) != 4u || ((x0 >> 3) & 31u) > 29u || ((x0 >> 8) & 31u) > 29u)
+        return false;
+    const uint32_t hclen = ((x0 >> 13) & 15u) + 4u;
+    uint64_t       p     = (uint64_t)__funnelshift_r(x0, x1, 17) | ((uint64_t)__funnelshift_r(x1, x2, 17) << 32);
+    p &= (1ull << (3u * hclen)) - 1ull;
+    // Kraft sum in units of 2^-7: a length l > 0 weighs 128 >> l
+    const uint64_t weigh = 0x0102040810204000ull; // byte l = 128 >> l, byte 0 = 0
+    uint32_t       sum   = 0;
+#pragma unroll
+    for (int i = 0; i < 19; ++i)
+        sum += (uint32_t)(weigh >> (8u * ((uint32_t)(p >> (3 * i)) & 7u))) & 0xFFu;
+    return sum == 128u;
+}
+
+} // namespace
+
+// One wave per chunk; a launch takes its chunks from an atomic counter (searches and decodes differ in length).
+__global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
+{
+    __shared__ GiLds L;
+    const uint32_t   lane = gi_lane();
+    const uint64_t   n_dw = (p.avail_bits + 31u) >> 5;
+    for (;;)
+    {
+        uint32_t slot = 0;
+        if (p.fix_start == GI_NONE)
+        {
+            if (lane == 0)
+                slot = atomicAdd(p.work_next, 1u);
+            slot = gi_rfl(slot);
+            if (slot >= p.n)
+                return;
+        }
+        const uint32_t j       = p.j0 + slot;
+        const bool     fix     = p.fix_start != GI_NONE;
+        GiChunk&       C       = p.chunks[fix ? p.fix_slot : slot];
+        const uint64_t nominal = (uint64_t)j * p.chunk_bytes * 8u;
+        uint64_t       stop    = fix ? p.fix_stop : nominal + (uint64_t)p.chunk_bytes * 8u;
+        if (stop > p.total_bits)
+            stop = p.total_bits;
+        const bool all_fed = p.avail_bits >= p.total_bits;
+
+        GiIn in;
+        in.base = p.comp;
+        in.n_dw = n_dw;
+        GiOut o;
+        o.pool      = p.pool;
+        o.pool_next = p.pool_next;
+        o.pool_cap  = p.pool_cap;
+        o.have0     = false;
+        o.tA = o.tB = o.tF = 0;
+        uint32_t       t_screen = 0, t_cand = 0, t_hdr = 0;
+        const uint64_t t_chunk  = wall_clock64();
+        GiBlockCtx bc;
+        bc.have_dist = false;
+
+        uint64_t start      = GI_NONE;
+        uint64_t search_at  = fix ? GI_NONE : nominal; // next position the search looks at (GI_NONE: no search)
+        bool     at_header  = false;
+        uint32_t flags      = 0;
+        if (!fix && j == 0)
+        {
+            start     = 0;
+            at_header = true;
+            search_at = GI_NONE;
+        }
+        else if (fix)
+            start = p.fix_start;
+
+        uint32_t n_mend = 0, members = 0;
+        uint64_t end_bit = 0;
+        bool     done    = false;
+        while (!done)
+        {
+            // ---- the chunk's start -----------------------------------------------------------------------------------------------
+            bool probation = false; // the first block runs in strict mode and a failure resumes the search
+            if (search_at != GI_NONE)
+            {
+                start = GI_NONE;
+                const uint64_t t_s = wall_clock64();
+                // the file's dwords around the search position live in one register (lane l: dword sw_base + l); the six dwords the 64
+                // positions of a round need are taken from it as scalars, every lane picks its four
+                uint64_t sw_base = ~0ull;
+                uint32_t sw      = 0;
+                while (search_at < stop && start == GI_NONE)
+                {
+                    const uint64_t d = search_at >> 5;
+                    if (sw_base == ~0ull || d < sw_base || d + 6u > sw_base + 64u)
+                    {
+                        sw_base = d;
+                        sw      = sw_base + lane < n_dw ? p.comp[sw_base + lane] : 0u;
+                    }
+                    const int      i0 = (int)(d - sw_base);
+                    const uint32_t u0 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0), u1 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 1),
+                                   u2 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 2), u3 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 3),
+                                   u4 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 4), u5 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 5);
+                    const uint32_t sh = (uint32_t)(search_at & 31u) + lane, q = sh >> 5;
+                    const uint32_t d0 = q == 0u ? u0 : q == 1u ? u1 : u2, d1 = q == 0u ? u1 : q == 1u ? u2 : u3, d2 = q == 0u ? u2 : q == 1u ? u3 : u4,
+                                   d3 = q == 0u ? u3 : q == 1u ? u4 : u5;
+                    const uint64_t bit = search_at + lane;
+                    const bool     ok  = bit < stop && bit + 64u <= p.avail_bits && gi_screen(d0, d1, d2, d3, sh & 31u);
+                    const uint64_t m   = __ballot(ok);
+                    if (m)
+                    {
+                        start     = search_at + (uint64_t)__builtin_ctzll(m);
+                        search_at = start + 1u;
+                    }
+                    else
+                        search_at += 64u;
+                }
+                t_screen += (uint32_t)(wall_clock64() - t_s);
+                if (start == GI_NONE)
+                {
+                    flags = 0;
+                    break; // nothing in this chunk's range
+                }
+                probation = true;
+            }
+            // ---- decode ----------------------------------------------------------------------------------------------------------
+            o.pos = o.flushed = 0;
+            o.markers = 0;
+            o.ovf     = false;
+            n_mend    = 0;
+            members   = 0;
+            flags     = 0;
+            uint32_t base         = 0;     // first symbol of the current member
+            bool     fresh_member = false; // a member began inside this chunk: no markers
+            uint64_t pos          = start;
+            bool     failed       = false;
+            if (at_header)
+            {
+                const uint64_t q = gi_u64(gi_gzip_header(p.comp, p.total_bits >> 3, start >> 3));
+                if (!q)
+                {
+                    flags   = GI_F_FAILED;
+                    end_bit = start;
+                    done    = true;
+                    break;
+                }
+                pos          = q * 8u;
+                fresh_member = true;
+                members      = 1;
+                flags |= GI_F_FRESH;
+            }
+            in.seek(pos);
+            bool first_block = true;
+            for (;;)
+            {
+                const uint64_t here = in.pos();
+                if (here + 3u > p.avail_bits)
+                {
+                    if (!all_fed)
+                        flags |= GI_F_SHORT;
+                    else
+                        failed = true;
+                    end_bit = here;
+                    break;
+                }
+                in.refill();
+                // A chunk ends at the first block boundary at or behind the next chunk's nominal start at which a block begins that
+                // the next chunk's search can find (not final, dynamic): stored, fixed and final blocks there are this chunk's.
+                if (!first_block && here >= stop && in.peek(3) == 4u)
+                {
+                    end_bit = here;
+                    break;
+                }
+                const uint32_t bfinal = in.get(1), btype = in.get(2);
+                const bool     mk     = !fresh_member;
+                int            rc     = 0;
+                if (btype == 0u)
+                {
+                    in.drop(in.cnt & 7u);
+                    in.refill();
+                    const uint32_t len = in.get(16);
+                    in.refill();
+                    const uint32_t nlen = in.get(16);
+                    if ((len ^ 0xFFFFu) != nlen || in.pos() + (uint64_t)len * 8u > p.avail_bits)
+                        rc = (in.pos() + (uint64_t)len * 8u > p.avail_bits && !all_fed && (len ^ 0xFFFFu) == nlen) ? 3 : 1;
+                    else
+                        for (uint32_t i = 0; i < len && !o.ovf; ++i)
+                        {
+                            in.refill();
+                            gi_emit(L, o, in.get(8));
+                            if (o.pos - o.flushed >= 512u)
+                                gi_flush256(L, o);
+                        }
+                    if (o.ovf)
+                        rc = 2;
+                }
+                else if (btype == 3u)
+                    rc = 1;
+                else
+                {
+                    const uint64_t t_h = wall_clock64();
+                    const bool hdr = gi_ub(btype == 2u ? gi_dynamic_header(L, in, bc) : gi_fixed_header(L, bc));
+                    if (probation && first_block)
+                        t_cand += (uint32_t)(wall_clock64() - t_h);
+                    else
+                        t_hdr += (uint32_t)(wall_clock64() - t_h);
+                    if (!hdr)
+                        rc = 1;
+                    else if (probation && first_block && p.strict)
+                        rc = (int)gi_rfl((uint32_t)gi_codes<true>(L, in, o, bc, base, mk, n_dw + 2u));
+                    else
+                        rc = (int)gi_rfl((uint32_t)gi_codes<false>(L, in, o, bc, base, mk, n_dw + 2u));
+                }
+                if (rc == 0 && in.pos() > p.avail_bits)
+                    rc = all_fed ? 1 : 3;
+                if (rc == 3)
+                {
+                    flags |= GI_F_SHORT;
+                    end_bit = here;
+                    break;
+                }
+                if (rc == 2)
+                {
+                    flags |= GI_F_OVERFLOW;
+                    end_bit = here;
+                    break;
+                }
+                if (rc == 1)
+                {
+                    // (beyond the fed bytes a decode sees zeros: that is "short", not "damaged", while more is to come)
+                    if (!all_fed && in.pos() + 64u > p.avail_bits)
+                        flags |= GI_F_SHORT;
+                    else
+                        failed = true;
+                    end_bit = in.pos();
+                    break;
+                }
+                first_block = false;
+                if (bfinal)
+                {
+                    in.drop(in.cnt & 7u);
+                    const uint64_t at = in.pos() >> 3;
+                    if ((at + 8u) * 8u > p.avail_bits)
+                    {
+                        if (!all_fed)
+                            flags |= GI_F_SHORT;
+                        else
+                            failed = true;
+                        end_bit = in.pos();
+                        break;
+                    }
+                    if (n_mend >= GI_MEND)
+                    {
+                        flags |= GI_F_OVERFLOW;
+                        end_bit = in.pos();
+                        break;
+                    }
+                    if (lane == 0)
+                    {
+                        C.mend_sym[n_mend]   = o.pos;
+                        C.mend_crc[n_mend]   = gi_byte(p.comp, at) | (gi_byte(p.comp, at + 1) << 8) | (gi_byte(p.comp, at + 2) << 16) | (gi_byte(p.comp, at + 3) << 24);
+                        C.mend_isize[n_mend] = gi_byte(p.comp, at + 4) | (gi_byte(p.comp, at + 5) << 8) | (gi_byte(p.comp, at + 6) << 16) | (gi_byte(p.comp, at + 7) << 24);
+                    }
+                    ++n_mend;
+                    const uint64_t next = at + 8u;
+                    // (the next member's header must lie inside what is fed, or the file must be at its end)
+                    if (!all_fed && (next + 4096u) * 8u > p.avail_bits)
+                    {
+                        flags |= GI_F_SHORT;
+                        end_bit = here;
+                        // the member end just recorded belongs to a decode that will be repeated
+                        break;
+                    }
+                    const uint64_t q = next < (p.total_bits >> 3) ? gi_u64(gi_gzip_header(p.comp, p.total_bits >> 3, next)) : 0;
+                    if (!q)
+                    {
+                        flags |= GI_F_END;
+                        end_bit = next * 8u;
+                        break;
+                    }
+                    in.seek(q * 8u);
+                    base         = o.pos;
+                    fresh_member = true;
+                    ++members;
+                }
+            }
+            if (failed && probation && first_block)
+                continue; // a false start: the search goes on behind it
+            if (failed)
+                flags |= GI_F_FAILED;
+            done = true;
+        }
+        if (start != GI_NONE && !(flags & GI_F_OVERFLOW))
+        {
+            gi_flush_rest(L, o);
+            if (o.ovf)
+                flags |= GI_F_OVERFLOW;
+        }
+        uint32_t mk = start != GI_NONE ? o.markers : 0u;
+        for (int s = 32; s > 0; s >>= 1)
+            mk += (uint32_t)__shfl_xor((int)mk, s);
+        __syncthreads();
+        if (start != GI_NONE)
+            for (uint32_t q = lane; q < GI_MAX_PIECES; q += 64u)
+                C.piece[q] = L.piece[q];
+        if (lane == 0)
+        {
+            C.start_bit     = start;
+            C.end_bit       = end_bit;
+            C.out_len       = start != GI_NONE ? o.pos : 0u;
+            C.flags         = flags | ((n_mend || members) ? GI_F_MEMBERS : 0u);
+            C.n_mend        = n_mend;
+            C.markers       = mk;
+            C.members_begun = members;
+            C.prof[0] = t_screen;
+            C.prof[1] = t_cand;
+            C.prof[2] = t_hdr;
+            C.prof[3] = o.tA;
+            C.prof[4] = o.tB;
+            C.prof[5] = o.tF;
+            C.prof[6] = (uint32_t)(wall_clock64() - t_chunk);
+        }
+        __syncthreads();
+        if (fix)
+            return;
+    }
+}
+
+// ---- the stream's order -------------------------------------------------------------------------------------------------------------
+// One workgroup.  The slots' key fields go to LDS; thread 0 walks from the stream's position: a chunk that starts at a position lies in
+// the slot of that position's nominal range (or in a fix-up slot), so every step is a lookup, not a search.  Everything else (work list)
+// is filled in parallel afterwards.  The kernel only READS the step's initial state (pos_bit, run_len) and writes its result fields, so
+// the host can run it again after a fix-up decode.
+#define GI_ORDER_MAX 8256u // regular slots of a step (<= 8192) + fix-up slots (<= 64); 16 bytes of LDS each
+__global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChunk* chunks, uint32_t n_slots, uint32_t slots_cap, uint32_t n_fix, uint32_t j0,
+                                                        uint32_t chunk_bytes, uint64_t range_end_bits, uint64_t total_bits, GiReal* real, uint2* work,
+                                                        uint32_t real_cap, uint32_t work_cap, uint64_t text_cap)
+{
+    extern __shared__ uint64_t gi_order_lds[];
+    const uint32_t             n_all   = n_slots + n_fix;
+    uint64_t*                  s_start = gi_order_lds;
+    uint32_t*                  s_span  = reinterpret_cast<uint32_t*>(s_start + n_all); // end_bit - start_bit
+    uint32_t*                  s_lf    = s_span + n_all;                               // out_len | flags << 24
+    __shared__ uint32_t        s_R;
+    const uint32_t             tid = threadIdx.x;
+    for (uint32_t i = tid; i < n_all; i += 1024u)
+    {
+        const GiChunk& c = chunks[i < n_slots ? i : slots_cap + (i - n_slots)];
+        s_start[i]       = c.start_bit;
+        s_span[i]        = (uint32_t)(c.end_bit - c.start_bit);
+        s_lf[i]          = c.out_len | (c.flags << 24);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        const uint64_t cbits = (uint64_t)chunk_bytes * 8u;
+        uint64_t       pos = st->pos_bit, text = 0, run_len = st->run_len, gap_stop = 0;
+        uint32_t       r = 0, w = 0, reason = GI_R_RANGE, cursor = n_slots, members = 0;
+        for (;;)
+        {
+            uint32_t idx = ~0u;
+            for (uint32_t f = 0; f < n_fix; ++f)
+                if (s_start[n_slots + f] == pos)
+                    idx = n_slots + f;
+            const uint64_t sj = pos / cbits;
+            uint32_t       s  = sj >= j0 ? (uint32_t)(sj - j0 < n_slots ? sj - j0 : n_slots) : 0u;
+            if (idx == ~0u && sj >= j0 && s < n_slots && s_start[s] == pos)
+                idx = s;
+            if (idx == ~0u)
+            {
+                // nothing starts here: a gap up to the next start behind pos, or the end of the range's chunks
+                while (s < n_slots && (s_start[s] == GI_NONE || s_start[s] <= pos))
+                    ++s;
+                if (s < n_slots)
+                {
+                    reason   = GI_R_GAP;
+                    gap_stop = s_start[s];
+                }
+                else if (pos < range_end_bits && pos < total_bits)
+                {
+                    reason   = GI_R_GAP;
+                    gap_stop = range_end_bits < total_bits ? range_end_bits : total_bits;
+                }
+                else
+                    reason = GI_R_RANGE;
+                cursor = s;
+                break;
+            }
+            const uint32_t fl = s_lf[idx] >> 24, n = s_lf[idx] & 0xFFFFFFu;
+            if (fl & GI_F_SHORT)
+            {
+                reason = GI_R_INPUT;
+                if (idx < n_slots)
+                    cursor = idx;
+                else
+                {
+                    // a fix-up decode ran short: the next step begins with the chunk in whose range the stream stands
+                    cursor = sj >= j0 ? (uint32_t)(sj - j0 < n_slots ? sj - j0 : n_slots) : 0u;
+                }
+                break;
+            }
+            if ((fl & GI_F_OVERFLOW) || r >= real_cap || text + n > text_cap || w + (n >> GI_PIECE_LOG2) + 1u > work_cap)
+            {
+                reason = GI_R_OVERFLOW;
+                break;
+            }
+            const uint32_t slot = idx < n_slots ? idx : slots_cap + (idx - n_slots);
+            real[r].wbase       = w;
+            real[r].slot        = slot;
+            real[r].out_len     = n;
+            real[r].text_off    = text;
+            w += (n + GI_PIECE - 1u) >> GI_PIECE_LOG2;
+            ++r;
+            bool bad_member = false;
+            if (fl & GI_F_MEMBERS)
+            {
+                const GiChunk& c = chunks[slot];
+                uint32_t       at = 0;
+                for (uint32_t e = 0; e < c.n_mend; ++e)
+                {
+                    run_len += c.mend_sym[e] - at;
+                    if ((uint32_t)run_len != c.mend_isize[e])
+                        bad_member = true;
+                    run_len = 0;
+                    at      = c.mend_sym[e];
+                }
+                run_len += n - at;
+                members += c.members_begun;
+            }
+            else
+                run_len += n;
+            text += n;
+            pos = s_start[idx] + s_span[idx];
+            if (bad_member)
+            {
+                reason = GI_R_MEMBER;
+                break;
+            }
+            if (fl & GI_F_FAILED)
+            {
+                reason = GI_R_DATA;
+                break;
+            }
+            if (fl & GI_F_END)
+            {
+                reason = GI_R_END;
+                break;
+            }
+        }
+        st->reason      = reason;
+        st->n_real      = r;
+        st->n_work      = w;
+        st->text_off    = text;
+        st->cursor      = cursor;
+        st->gap_stop    = gap_stop;
+        st->res_pos     = pos;
+        st->res_run_len = run_len;
+        st->res_members = members;
+        s_R             = r;
+    }
+    __syncthreads();
+    const uint32_t R = s_R;
+    unsigned long long mk = 0;
+    for (uint32_t r = tid; r < R; r += 1024u)
+    {
+        const GiReal   rr = real[r];
+        for (uint32_t q = 0; (q << GI_PIECE_LOG2) < rr.out_len; ++q)
+            work[rr.wbase + q] = make_uint2(r, q);
+        const GiChunk& c = chunks[rr.slot];
+        mk += c.markers;
+        for (int k = 0; k < 7; ++k)
+            atomicAdd(&st->prof[k], (unsigned long long)c.prof[k]);
+    }
+    if (mk)
+        atomicAdd(reinterpret_cast<unsigned long long*>(&st->res_markers), mk);
+}
+
+#define GI_GROUP 32u // chain chunks whose windows one workgroup composes
+
+__device__ __forceinline__ uint32_t gi_tail_sym(const GiChunk& c, const uint16_t* pool, uint32_t n, uint32_t i)
+{
+    // entry i of the chunk's tail function: the symbol that ends up at byte i of the window BEHIND the chunk, in terms of the window before it
+    if (n >= GI_WINDOW || i >= GI_WINDOW - n)
+    {
+        const uint32_t sp = n >= GI_WINDOW ? n - GI_WINDOW + i : i - (GI_WINDOW - n);
+        return pool[((uint64_t)c.piece[sp >> GI_PIECE_LOG2] << GI_PIECE_LOG2) | (sp & (GI_PIECE - 1u))];
+    }
+    return 256u + i + n;
+}
+
+// Windows, level 1: workgroup g composes the tail functions of chain chunks [32 g, 32 g + 32).  P_r = "window before chunk r in terms
+// of the window before the group" (u16[32768]: a byte, or 256 + index) is stored for every chunk (the resolve pass reads markers through
+// it), the group's whole function G_g at the end.
+__global__ __launch_bounds__(1024) void gi_window_kernel(const GiState* st, const GiChunk* chunks, const GiReal* real, const uint16_t* pool,
+                                                         uint16_t* p_store, uint16_t* g_store)
+{
+    __shared__ uint16_t P[GI_WINDOW];
+    const uint32_t      tid = threadIdx.x, R = st->n_real;
+    const uint32_t      r0 = blockIdx.x * GI_GROUP, r1 = min(R, r0 + GI_GROUP);
+    if (r0 >= R)
+        return;
+#pragma unroll
+    for (uint32_t t = 0; t < GI_WINDOW / 1024u; ++t)
+        P[t * 1024u + tid] = (uint16_t)(256u + t * 1024u + tid);
+    __syncthreads();
+    for (uint32_t r = r0; r < r1; ++r)
+    {
+        const GiChunk& c = chunks[real[r].slot];
+        const uint32_t n = real[r].out_len;
+        if (c.markers)
+        {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(p_store + (uint64_t)r * GI_WINDOW);
+            for (uint32_t i = tid; i < GI_WINDOW / 2u; i += 1024u)
+                dst[i] = reinterpret_cast<const uint32_t*>(P)[i];
+        }
+        uint16_t nw[GI_WINDOW / 1024u];
+#pragma unroll
+        for (uint32_t t = 0; t < GI_WINDOW / 1024u; ++t)
+        {
+            uint32_t v = gi_tail_sym(c, pool, n, t * 1024u + tid);
+            if (v >= 256u)
+                v = P[v - 256u];
+            nw[t] = (uint16_t)v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t t = 0; t < GI_WINDOW / 1024u; ++t)
+            P[t * 1024u + tid] = nw[t];
+        __syncthreads();
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(g_store + (uint64_t)blockIdx.x * GI_WINDOW);
+    for (uint32_t i = tid; i < GI_WINDOW / 2u; i += 1024u)
+        dst[i] = reinterpret_cast<const uint32_t*>(P)[i];
+}
+
+// Windows, level 2: one workgroup, group after group: W_g = the stream's window (bytes) before group g; the window behind the last group
+// becomes the stream's.
+__global__ __launch_bounds__(1024) void gi_wchain_kernel(const GiState* st, const uint16_t* g_store, uint8_t* window, uint8_t* w_store)
+{
+    __shared__ uint8_t W[GI_WINDOW];
+    const uint32_t     tid = threadIdx.x, R = st->n_real, n_groups = (R + GI_GROUP - 1u) / GI_GROUP;
+    for (uint32_t i = tid; i < GI_WINDOW / 16u; i += 1024u)
+        reinterpret_cast<uint4*>(W)[i] = reinterpret_cast<const uint4*>(window)[i];
+    __syncthreads();
+    uint16_t cur[GI_WINDOW / 1024u], nxt[GI_WINDOW / 1024u];
+    if (n_groups)
+#pragma unroll
+        for (uint32_t t = 0; t < GI_WINDOW / 1024u; ++t)
+            cur[t] = g_store[t * 1024u + tid];
+    for (uint32_t g = 0; g < n_groups; ++g)
+    {
+        if (g + 1 < n_groups)
+#pragma unroll
+            for (uint32_t t = 0; t < GI_WINDOW / 1024u; ++t)
+                nxt[t] = g_store[(uint64_t)(g + 1) * GI_WINDOW + t * 1024u + tid];
+        for (uint32_t i = tid; i < GI_WINDOW / 16u; i += 1024u)
+            reinterpret_cast<uint4*>(w_store + (uint64_t)g * GI_WINDOW)[i] = reinterpret_cast<const uint4*>(W)[i];
+        uint8_t nw[GI_WINDOW / 1024u];
+#pragma unroll
+        for (uint32_t t = 0; t < GI_WINDOW / 1024u; ++t)
+        {
+            const uint32_t v = cur[t];
+            nw[t]            = (uint8_t)(v < 256u ? v : W[v - 256u]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t t = 0; t < GI_WINDOW / 1024u; ++t)
+        {
+            W[t * 1024u + tid] = nw[t];
+            cur[t]             = nxt[t];
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < GI_WINDOW / 16u; i += 1024u)
+        reinterpret_cast<uint4*>(window)[i] = reinterpret_cast<const uint4*>(W)[i];
+}
+
+// symbols -> bytes.  One work item = one piece of one chain chunk; a marker goes through the chunk's P (level 1) and, if that is a
+// marker still, through its group's window (level 2).
+__global__ __launch_bounds__(256) void gi_resolve_kernel(const GiState* st, const GiChunk* chunks, const GiReal* real, const uint2* work,
+                                                         const uint16_t* pool, const uint16_t* p_store, const uint8_t* w_store, uint8_t* text)
+{
+    const uint32_t n_work = st->n_work;
+    for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x)
+    {
+        const uint2     it = work[w];
+        const GiReal    R  = real[it.x];
+        const GiChunk&  c  = chunks[R.slot];
+        const uint32_t  lo = it.y << GI_PIECE_LOG2, hi = min(R.out_len, lo + GI_PIECE);
+        const uint16_t* s  = pool + ((uint64_t)c.piece[it.y] << GI_PIECE_LOG2);
+        const uint16_t* pr = p_store + (uint64_t)it.x * GI_WINDOW;
+        const uint8_t*  wg = w_store + (uint64_t)(it.x / GI_GROUP) * GI_WINDOW;
+        uint8_t*        d  = text + R.text_off + lo;
+        for (uint32_t i = threadIdx.x; i < hi - lo; i += 256u)
+        {
+            uint32_t v = s[i];
+            if (v >= 256u)
+            {
+                v = pr[v - 256u];
+                if (v >= 256u)
+                    v = wg[v - 256u];
+            }
+            d[i] = (uint8_t)v;
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+struct gn_inflate
+{
+    int         device = 0;
+    int         n_cu   = 256;
+    hipStream_t st = nullptr, st_copy = nullptr, st_out = nullptr;
+    uint64_t    total = 0, fed = 0;
+    uint32_t    chunk_bytes = 32768;
+    uint64_t    step_bytes  = 256ull << 20;
+    uint32_t    n_chunks_file = 0;
+    uint32_t    next_chunk = 0; // first chunk of the file the next step decodes
+    uint8_t*    d_comp = nullptr;
+    // per step
+    uint32_t  slots_cap = 0, fix_cap = 64;
+    GiChunk*  d_chunks = nullptr;
+    uint16_t* d_pool   = nullptr;
+    uint32_t  pool_cap = 0;
+    uint32_t* d_ctr    = nullptr; // [0] pool_next [1] work_next
+    GiState*  d_state  = nullptr;
+    GiState*  h_state  = nullptr; // page-locked
+    uint8_t*  d_window = nullptr;
+    uint16_t* d_p_store = nullptr; // per chain chunk: its P (64 KiB)
+    uint16_t* d_g_store = nullptr; // per group: its function
+    uint8_t*  d_w_store = nullptr; // per group: the window before it
+    GiReal*   d_real = nullptr;
+    uint2*    d_work = nullptr;
+    uint32_t  work_cap = 0;
+    uint8_t*  d_text[2] = { nullptr, nullptr };
+    uint64_t  text_cap = 0;
+    int       cur = 1; // buffer of the last step
+    uint64_t  n_text_last = 0;
+    bool      ended = false;
+    // totals
+    gn_inflate_stats stats{};
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+};
+
+static void gi_free(gn_inflate* z)
+{
+    if (!z)
+        return;
+    hipSetDevice(z->device);
+    for (void* p : { (void*)z->d_comp, (void*)z->d_chunks, (void*)z->d_pool, (void*)z->d_ctr, (void*)z->d_state, (void*)z->d_window, (void*)z->d_p_store, (void*)z->d_g_store, (void*)z->d_w_store,
+                     (void*)z->d_real, (void*)z->d_work, (void*)z->d_text[0], (void*)z->d_text[1] })
+        if (p)
+            hipFree(p);
+    if (z->h_state)
+        hipHostFree(z->h_state);
+    for (hipStream_t s : { z->st, z->st_copy, z->st_out })
+        if (s)
+            hipStreamDestroy(s);
+    for (hipEvent_t e : z->ev)
+        if (e)
+            hipEventDestroy(e);
+    delete z;
+}
+
+extern "C" int gn_inflate_create(int device, uint64_t compressed_bytes, uint32_t chunk_bytes, uint64_t step_bytes, gn_inflate** out)
+{
+    if (!out || compressed_bytes < 18)
+        return gn_fail(GN_EINVAL, "gn_inflate_create: a gzip file has at least 18 bytes");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev)
+        return gn_fail(GN_ENODEV, "gn_inflate_create: no usable HIP device %d", device);
+    if (compressed_bytes >= (1ull << 36))
+        return gn_fail(GN_ERANGE, "gn_inflate_create: compressed files of 64 GiB and more are not taken");
+    GN_HIP(hipSetDevice(device));
+    gn_inflate* z = new (std::nothrow) gn_inflate();
+    if (!z)
+        return gn_fail(GN_ENOMEM, "gn_inflate_create: out of memory");
+    z->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        z->n_cu = prop.multiProcessorCount;
+    z->total       = compressed_bytes;
+    z->chunk_bytes = chunk_bytes ? std::max<uint32_t>(chunk_bytes & ~3u, 256u) : 32768u;
+    z->step_bytes  = step_bytes ? std::max<uint64_t>(step_bytes, z->chunk_bytes) : (256ull << 20);
+    z->step_bytes  = (z->step_bytes + z->chunk_bytes - 1) / z->chunk_bytes * z->chunk_bytes;
+    z->step_bytes  = std::min<uint64_t>(z->step_bytes, 8192ull * z->chunk_bytes); // (gi_order_kernel keeps a step's slots in LDS)
+    z->n_chunks_file = (uint32_t)((compressed_bytes + z->chunk_bytes - 1) / z->chunk_bytes);
+    const uint64_t step = std::min<uint64_t>(z->step_bytes, (uint64_t)z->n_chunks_file * z->chunk_bytes);
+    z->slots_cap        = (uint32_t)(step / z->chunk_bytes);
+    // text of a step: up to 12 x its compressed bytes (FASTQ: 3.5-6 x); beyond that the caller's host path takes the file
+    z->text_cap = std::max<uint64_t>(step * 12u, 1u << 20) + (4u << 20);
+    z->pool_cap = (uint32_t)(z->text_cap / GI_PIECE) + 2u * (z->slots_cap + z->fix_cap) + 64u;
+    z->work_cap = z->pool_cap;
+    auto fail = [&](hipError_t e, const char* what) {
+        gi_free(z);
+        return gn_fail(e == hipErrorOutOfMemory ? GN_ENOMEM : GN_ENODEV, "gn_inflate_create: %s: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+#define GI_TRY(x, what)                                                                                                                  \
+    if ((e = (x)) != hipSuccess)                                                                                                         \
+        return fail(e, what);
+    GI_TRY(hipStreamCreateWithFlags(&z->st, hipStreamNonBlocking), "stream");
+    GI_TRY(hipStreamCreateWithFlags(&z->st_copy, hipStreamNonBlocking), "stream");
+    GI_TRY(hipStreamCreateWithFlags(&z->st_out, hipStreamNonBlocking), "stream");
+    for (auto& ev : z->ev)
+        GI_TRY(hipEventCreate(&ev), "event");
+    const uint64_t comp_alloc = ((compressed_bytes + 3) & ~3ull) + 1024;
+    GI_TRY(hipMalloc((void**)&z->d_comp, comp_alloc), "compressed bytes");
+    GI_TRY(hipMemsetAsync(z->d_comp + (compressed_bytes & ~3ull), 0, comp_alloc - (compressed_bytes & ~3ull), z->st), "memset");
+    GI_TRY(hipMalloc((void**)&z->d_chunks, (size_t)(z->slots_cap + z->fix_cap) * sizeof(GiChunk)), "chunk records");
+    GI_TRY(hipMalloc((void**)&z->d_pool, (size_t)z->pool_cap * GI_PIECE * 2u), "symbol pool");
+    GI_TRY(hipMalloc((void**)&z->d_ctr, 64), "counters");
+    GI_TRY(hipMalloc((void**)&z->d_state, sizeof(GiState)), "state");
+    GI_TRY(hipHostMalloc((void**)&z->h_state, sizeof(GiState), hipHostMallocDefault), "state (host)");
+    GI_TRY(hipMalloc((void**)&z->d_window, GI_WINDOW), "window");
+    GI_TRY(hipMemsetAsync(z->d_window, 0, GI_WINDOW, z->st), "memset");
+    {
+        const size_t real_cap = z->slots_cap + z->fix_cap, groups = (real_cap + GI_GROUP - 1) / GI_GROUP;
+        GI_TRY(hipMalloc((void**)&z->d_p_store, real_cap * GI_WINDOW * 2u), "windows");
+        GI_TRY(hipMalloc((void**)&z->d_g_store, groups * GI_WINDOW * 2u), "windows");
+        GI_TRY(hipMalloc((void**)&z->d_w_store, groups * GI_WINDOW), "windows");
+    }
+    GI_TRY(hipMalloc((void**)&z->d_real, (size_t)(z->slots_cap + z->fix_cap) * sizeof(GiReal)), "chain");
+    GI_TRY(hipMalloc((void**)&z->d_work, (size_t)z->work_cap * sizeof(uint2)), "work list");
+    for (int b = 0; b < 2; ++b)
+        GI_TRY(hipMalloc((void**)&z->d_text[b], z->text_cap + 64), "text");
+    std::memset(z->h_state, 0, sizeof(GiState));
+    z->h_state->fix_slot = ~0u;
+    GI_TRY(hipMemcpyAsync(z->d_state, z->h_state, sizeof(GiState), hipMemcpyHostToDevice, z->st), "state");
+    GI_TRY(hipStreamSynchronize(z->st), "sync");
+    GI_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gi_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GI_ORDER_MAX * 16u)), "LDS size");
+#undef GI_TRY
+    *out = z;
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_destroy(gn_inflate* z)
+{
+    gi_free(z);
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_feed(gn_inflate* z, const uint8_t* data, uint64_t n)
+{
+    if (!z || (!data && n))
+        return gn_fail(GN_EINVAL, "gn_inflate_feed: null argument");
+    if (z->fed + n > z->total)
+        return gn_fail(GN_EINVAL, "gn_inflate_feed: more bytes than the file was announced with");
+    GN_HIP(hipSetDevice(z->device));
+    GN_HIP(hipMemcpyAsync(z->d_comp + z->fed, data, n, hipMemcpyHostToDevice, z->st_copy));
+    GN_HIP(hipStreamSynchronize(z->st_copy));
+    z->fed += n;
+    return GN_OK;
+}
+
+static int gi_launch_chunks(gn_inflate* z, uint32_t j0, uint32_t n, uint64_t fix_start, uint64_t fix_stop, uint32_t fix_slot)
+{
+    GiParams p;
+    p.comp        = reinterpret_cast<const uint32_t*>(z->d_comp);
+    p.avail_bits  = z->fed * 8u;
+    p.total_bits  = z->total * 8u;
+    p.chunk_bytes = z->chunk_bytes;
+    p.j0          = j0;
+    p.n           = n;
+    p.chunks      = z->d_chunks;
+    p.pool        = z->d_pool;
+    p.pool_next   = z->d_ctr;
+    p.pool_cap    = z->pool_cap;
+    p.work_next   = z->d_ctr + 1;
+    p.fix_start   = fix_start;
+    p.fix_stop    = fix_stop;
+    p.fix_slot    = fix_slot;
+    p.strict      = 1;
+    const uint32_t grid = fix_start != GI_NONE ? 1u : std::min<uint32_t>(n, (uint32_t)z->n_cu * 16u);
+    hipLaunchKernelGGL(gi_chunk_kernel, dim3(grid), dim3(64), 0, z->st, p);
+    GN_HIP(hipGetLastError());
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
+{
+    if (!z || !n_text || !done)
+        return gn_fail(GN_EINVAL, "gn_inflate_step: null argument");
+    *n_text = 0;
+    *done   = z->ended ? 1 : 0;
+    if (z->ended)
+        return GN_OK;
+    GN_HIP(hipSetDevice(z->device));
+    const bool all_fed = z->fed >= z->total;
+    // chunks this step may decode: those whose range and a margin behind it are fed
+    const uint64_t margin = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(z->step_bytes / 4u, 2ull * z->chunk_bytes)); // (too little only costs a repeat)
+    uint32_t       j1;
+    if (all_fed)
+        j1 = z->n_chunks_file;
+    else
+    {
+        const uint64_t usable = z->fed > margin ? z->fed - margin : 0;
+        j1                    = (uint32_t)(usable / z->chunk_bytes);
+    }
+    j1 = std::min<uint32_t>(j1, z->next_chunk + z->slots_cap);
+    if (j1 <= z->next_chunk)
+    {
+        if (all_fed)
+            return gn_fail(GN_ERANGE, "gn_inflate_step: the gzip stream does not end inside the file");
+        return gn_fail(GN_EINVAL, "gn_inflate_step: feed more bytes first (a step needs its chunks and a margin behind them -- 4 MiB at the default sizes -- or the whole file)");
+    }
+    const uint32_t j0 = z->next_chunk, n = j1 - j0;
+    const int      buf = 1 - z->cur;
+    auto           t0 = std::chrono::steady_clock::now();
+    GN_HIP(hipMemsetAsync(z->d_ctr, 0, 64, z->st));
+    GN_HIP(hipEventRecord(z->ev[0], z->st));
+    int rc = gi_launch_chunks(z, j0, n, GI_NONE, 0, 0);
+    if (rc != GN_OK)
+        return rc;
+    GN_HIP(hipEventRecord(z->ev[1], z->st));
+    // order of the stream: the host copy of the state is what the last step left; the kernel reads pos_bit / run_len and writes results
+    uint32_t       fixes = 0;
+    const uint64_t range_end = (uint64_t)j1 * z->chunk_bytes * 8u;
+    for (;;)
+    {
+        z->h_state->res_markers = 0;
+        std::memset(z->h_state->prof, 0, sizeof(z->h_state->prof));
+        GN_HIP(hipMemcpyAsync(z->d_state, z->h_state, sizeof(GiState), hipMemcpyHostToDevice, z->st));
+        const size_t lds = (size_t)(n + fixes) * 16u;
+        hipLaunchKernelGGL(gi_order_kernel, dim3(1), dim3(1024), lds, z->st, z->d_state, z->d_chunks, n, z->slots_cap, fixes, j0, z->chunk_bytes, range_end,
+                           z->total * 8u, z->d_real, z->d_work, z->slots_cap + z->fix_cap, z->work_cap, z->text_cap);
+        GN_HIP(hipGetLastError());
+        GN_HIP(hipMemcpyAsync(z->h_state, z->d_state, sizeof(GiState), hipMemcpyDeviceToHost, z->st));
+        GN_HIP(hipStreamSynchronize(z->st));
+        const GiState& s = *z->h_state;
+        if (s.reason != GI_R_GAP)
+            break;
+        if (fixes >= z->fix_cap || z->stats.fixups + fixes > 16u + z->stats.chunks / 8u)
+            return gn_fail(GN_ERANGE, "gn_inflate_step: too many positions the block search does not find (%u in this step): not a file for this decoder",
+                           fixes);
+        rc = gi_launch_chunks(z, 0, 1, s.res_pos, s.gap_stop, z->slots_cap + fixes);
+        if (rc != GN_OK)
+            return rc;
+        ++fixes;
+    }
+    GN_HIP(hipEventRecord(z->ev[2], z->st));
+    const GiState s = *z->h_state;
+    if (s.reason == GI_R_DATA)
+        return gn_fail(GN_ERANGE, "gn_inflate_step: damaged or truncated gzip stream near compressed byte %llu", (unsigned long long)(s.res_pos >> 3));
+    if (s.reason == GI_R_MEMBER)
+        return gn_fail(GN_ERANGE, "gn_inflate_step: gzip member with a wrong length (ISIZE)");
+    if (s.reason == GI_R_OVERFLOW)
+        return gn_fail(GN_ERANGE, "gn_inflate_step: the data expands beyond what a step holds (more than 12-fold, or a chunk beyond 2 Mi symbols)");
+    if (s.n_real)
+    {
+        const uint32_t groups = (s.n_real + GI_GROUP - 1u) / GI_GROUP;
+        hipLaunchKernelGGL(gi_window_kernel, dim3(groups), dim3(1024), 0, z->st, z->d_state, z->d_chunks, z->d_real, z->d_pool, z->d_p_store, z->d_g_store);
+        GN_HIP(hipGetLastError());
+        hipLaunchKernelGGL(gi_wchain_kernel, dim3(1), dim3(1024), 0, z->st, z->d_state, z->d_g_store, z->d_window, z->d_w_store);
+        GN_HIP(hipGetLastError());
+    }
+    if (s.n_work)
+    {
+        hipLaunchKernelGGL(gi_resolve_kernel, dim3(std::min<uint32_t>(s.n_work, (uint32_t)z->n_cu * 8u)), dim3(256), 0, z->st, z->d_state, z->d_chunks, z->d_real,
+                           z->d_work, z->d_pool, z->d_p_store, z->d_w_store, z->d_text[buf]);
+        GN_HIP(hipGetLastError());
+    }
+    GN_HIP(hipEventRecord(z->ev[3], z->st));
+    GN_HIP(hipStreamSynchronize(z->st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, z->ev[0], z->ev[1]) == hipSuccess)
+        z->stats.ms_decode += ms;
+    if (hipEventElapsedTime(&ms, z->ev[1], z->ev[2]) == hipSuccess)
+        z->stats.ms_chain += ms;
+    if (hipEventElapsedTime(&ms, z->ev[2], z->ev[3]) == hipSuccess)
+        z->stats.ms_resolve += ms;
+    z->stats.ms_step_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    z->stats.steps += 1;
+    z->stats.chunks += s.n_real;
+    z->stats.fixups += fixes;
+    for (int k = 0; k < 8; ++k)
+        z->stats.prof_ms[k] += (double)s.prof[k] * 1e-5; // 10 ns ticks
+    z->stats.markers += s.res_markers;
+    z->stats.members += s.res_members;
+    z->h_state->pos_bit = s.res_pos;
+    z->h_state->run_len = s.res_run_len;
+    z->stats.text_bytes += s.text_off;
+    z->cur         = buf;
+    z->n_text_last = s.text_off;
+    *n_text        = s.text_off;
+    if (s.reason == GI_R_END)
+    {
+        z->ended = true;
+        *done    = 1;
+        return GN_OK;
+    }
+    if (s.reason == GI_R_INPUT)
+    {
+        // cursor = the slot that has to be decoded again with more bytes
+        if (all_fed)
+            return gn_fail(GN_ERANGE, "gn_inflate_step: truncated gzip stream");
+        z->next_chunk = j0 + std::min<uint32_t>(s.cursor, n);
+        return GN_OK;
+    }
+    // the range is done
+    z->next_chunk = j1;
+    if (j1 >= z->n_chunks_file)
+    {
+        if (s.res_pos >= z->total * 8u)
+            return gn_fail(GN_ERANGE, "gn_inflate_step: truncated gzip stream");
+        // (the stream stands before the file's end with every chunk consumed: handled above as a gap)
+    }
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_text(gn_inflate* z, uint8_t* dst, uint64_t off, uint64_t n)
+{
+    if (!z || (!dst && n))
+        return gn_fail(GN_EINVAL, "gn_inflate_text: null argument");
+    if (off + n > z->n_text_last)
+        return gn_fail(GN_EINVAL, "gn_inflate_text: beyond the text of the last step");
+    GN_HIP(hipSetDevice(z->device));
+    GN_HIP(hipMemcpyAsync(dst, z->d_text[z->cur] + off, n, hipMemcpyDeviceToHost, z->st_out));
+    GN_HIP(hipStreamSynchronize(z->st_out));
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_text_device(gn_inflate* z, const uint8_t** text, uint64_t* n)
+{
+    if (!z || !text || !n)
+        return gn_fail(GN_EINVAL, "gn_inflate_text_device: null argument");
+    *text = z->d_text[z->cur];
+    *n    = z->n_text_last;
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_get_stats(gn_inflate* z, gn_inflate_stats* out)
+{
+    if (!z || !out)
+        return gn_fail(GN_EINVAL, "gn_inflate_get_stats: null argument");
+    *out = z->stats;
+    return GN_OK;
+}

@@ -27,7 +27,9 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_hibf_level_lines", "gn_stream_classify_shared",
                "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
                "gn_peer_stats", "gn_stream_upload_text", "gn_stream_upload_text_pair", "gn_stream_text_pair_index", "gn_stream_text_pair_records2",
-               "gn_ablate", "gn_filter_probe", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free"]
+               "gn_ablate", "gn_filter_probe", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free",
+               "gn_inflate_create", "gn_inflate_destroy", "gn_inflate_feed", "gn_inflate_step", "gn_inflate_text", "gn_inflate_text_device",
+               "gn_inflate_get_stats"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -50,6 +52,12 @@ class Timings(C.Structure):
     _fields_ = [("ms_minimiser", C.c_float), ("ms_count", C.c_float), ("ms_total", C.c_float),
                 ("n_hashes", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_matches", C.c_uint64),
                 ("n_count_launches", C.c_uint32), ("fetched_bytes", C.c_uint64)]
+
+
+class InflateStats(C.Structure):  # gn_inflate_stats
+    _fields_ = [("steps", C.c_uint64), ("chunks", C.c_uint64), ("fixups", C.c_uint64), ("markers", C.c_uint64), ("members", C.c_uint64),
+                ("text_bytes", C.c_uint64), ("ms_decode", C.c_double), ("ms_chain", C.c_double), ("ms_resolve", C.c_double),
+                ("ms_step_wall", C.c_double), ("prof_ms", C.c_double * 8)]
 
 
 _lib = None
@@ -169,6 +177,13 @@ def load_library():
     L.gn_reassign_fetch.argtypes = [vp, vp, vp, vp, vp]
     L.gn_reassign_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_float), C.POINTER(u64)]
     L.gn_reassign_free.argtypes = [vp]
+    L.gn_inflate_create.argtypes = [i32, u64, u32, u64, C.POINTER(vp)]
+    L.gn_inflate_destroy.argtypes = [vp]
+    L.gn_inflate_feed.argtypes = [vp, vp, u64]
+    L.gn_inflate_step.argtypes = [vp, C.POINTER(u64), C.POINTER(i32)]
+    L.gn_inflate_text.argtypes = [vp, vp, u64, u64]
+    L.gn_inflate_text_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.gn_inflate_get_stats.argtypes = [vp, C.POINTER(InflateStats)]
     for name in ABI_SYMBOLS:
         if name != "gn_last_error":
             getattr(L, name).restype = i32
@@ -233,6 +248,72 @@ def device_memory(device: int = 0) -> Tuple[int, int]:
     f, t = C.c_uint64(0), C.c_uint64(0)
     _check(load_library().gn_device_memory(device, C.byref(f), C.byref(t)))
     return int(f.value), int(t.value)
+
+
+class HipInflate:
+    """gn_inflate_*: a gzip file inflated on the device (include/ganon_hip.h).  `inflate(data)` = the whole file at once."""
+
+    def __init__(self, compressed_bytes: int, device: int = 0, chunk_bytes: int = 0, step_bytes: int = 0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        _check(self._L.gn_inflate_create(device, compressed_bytes, chunk_bytes, step_bytes, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            self._L.gn_inflate_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        _check(self._L.gn_inflate_feed(self._h, _p(data), data.size))
+
+    def step(self) -> Tuple[int, bool]:
+        n, done = C.c_uint64(0), C.c_int(0)
+        _check(self._L.gn_inflate_step(self._h, C.byref(n), C.byref(done)))
+        return int(n.value), bool(done.value)
+
+    def text(self, n: int, off: int = 0) -> np.ndarray:
+        out = np.empty(n, dtype=np.uint8)
+        _check(self._L.gn_inflate_text(self._h, _p(out), off, n))
+        return out
+
+    def stats(self) -> dict:
+        st = InflateStats()
+        _check(self._L.gn_inflate_get_stats(self._h, C.byref(st)))
+        return {k: (list(getattr(st, k)) if k == "prof_ms" else getattr(st, k)) for k, _ in InflateStats._fields_}
+
+    def inflate_all(self, data: np.ndarray, feed_bytes: int = 0, fetch: bool = True):
+        """feeds `data` (the whole file) in pieces of feed_bytes (0: at once), steps until the stream ends; returns the text
+        (fetch=False: only its length -- timing runs)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        parts, total, fed = [], 0, 0
+        fb = feed_bytes or data.size
+        done = False
+        while not done:
+            if fed < data.size:
+                self.feed(data[fed:fed + fb])
+                fed = min(data.size, fed + fb)
+                if fed < data.size and fed < 2 * fb + (4 << 20):
+                    continue
+            n, done = self.step()
+            if fetch and n:
+                parts.append(self.text(n))
+            total += n
+        if not fetch:
+            return total
+        return np.concatenate(parts) if parts else np.empty(0, dtype=np.uint8)
 
 
 class HipReassign:

@@ -382,6 +382,41 @@ int gn_stream_hibf_levels(gn_stream* s, uint32_t* n_levels, float* ms, uint64_t*
  * different widths on one level this, not row_bytes, is what the level's physical rate is computed from. */
 int gn_stream_hibf_level_lines(gn_stream* s, uint64_t* line_bytes, uint32_t cap);
 
+/* ---- gzip input inflated on the device (csrc/gn_inflate.hip) ------------------------------------------------------------------
+ * Replaces, for `reads.fq.gz` / `reads.fa.gz`, the zlib stream the reference reads its input through
+ * (seqan3::sequence_file_input over a gz stream in parse_reads, /root/reference/src/ganon-classify/GanonClassify.cpp:1220-1287;
+ * its one decompression thread, :1433): the caller feeds the file's bytes as they are, the device finds deflate block starts,
+ * decodes the chunks between them in parallel and returns the text -- the same bytes zlib's inflate() yields for the file
+ * (every member; what follows the last member is ignored like gzip does).  Members' ISIZE is checked.
+ *   gn_inflate_create   compressed_bytes = size of the file; chunk_bytes = compressed bytes per parallel chunk (0: 32 KiB);
+ *                       step_bytes = compressed bytes decoded per gn_inflate_step (0: 256 MiB; at most 8192 chunks).  The whole compressed file
+ *                       stays resident in HBM (files of 64 GiB and more: GN_ERANGE).
+ *   gn_inflate_feed     appends the next n bytes of the file (host memory; returns when `data` may be reused)
+ *   gn_inflate_step     decodes the next step: every chunk whose bytes, and 4 MiB behind them, are fed -- all of the rest once the
+ *                       whole file is.  *n_text = bytes of text this step produced (they follow the previous step's), *done = 1
+ *                       after the last member's trailer.  Blocks until the text is complete in device memory.
+ *   gn_inflate_text     copies [off, off + n) of the LAST step's text to host memory
+ *   gn_inflate_text_device   the last step's text in device memory (valid until the step after the next one begins)
+ * GN_ERANGE from gn_inflate_step: damaged / truncated data, a wrong ISIZE, or data this decoder is not made for (more than
+ * 12-fold expansion, hardly any dynamic-Huffman blocks): the caller reads the file with its host inflater instead -- nothing
+ * that was returned before is wrong, and nothing is returned that was not decoded. */
+typedef struct gn_inflate gn_inflate;
+typedef struct gn_inflate_stats
+{
+    uint64_t steps, chunks, fixups, markers, members, text_bytes;
+    double   ms_decode, ms_chain, ms_resolve, ms_step_wall;
+    /* summed over the chunks (wave-milliseconds): block search screen, headers of search candidates, block headers, Huffman decoding,
+     * placing the tokens (LZ77 copies), flushes, whole chunk; [7] unused */
+    double   prof_ms[8];
+} gn_inflate_stats;
+int gn_inflate_create(int device, uint64_t compressed_bytes, uint32_t chunk_bytes, uint64_t step_bytes, gn_inflate** out);
+int gn_inflate_destroy(gn_inflate* z);
+int gn_inflate_feed(gn_inflate* z, const uint8_t* data, uint64_t n);
+int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done);
+int gn_inflate_text(gn_inflate* z, uint8_t* dst, uint64_t off, uint64_t n);
+int gn_inflate_text_device(gn_inflate* z, const uint8_t** text, uint64_t* n);
+int gn_inflate_get_stats(gn_inflate* z, gn_inflate_stats* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,159 @@
+"""gn_inflate_* (csrc/gn_inflate.hip): a gzip file inflated on the device must be zlib's bytes.
+
+The checker is zlib itself (what the reference reads `.gz` input through: seqan3 over zlib, GanonClassify.cpp:1220-1287)."""
+import gzip
+import io
+import zlib
+
+import numpy as np
+import pytest
+
+from ganon_amd import hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _fastq(n, seed=3, read_len=100):
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, size=300_000, dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for i in range(n):
+        p = int(rng.integers(0, genome.size - read_len))
+        b = lut[genome[p:p + read_len]].copy()
+        e = rng.random(read_len) < 0.01
+        b[e] = lut[rng.integers(0, 4, size=int(e.sum()))]
+        q = rng.choice(np.frombuffer(b"FFFFFFF:,#", dtype=np.uint8), size=read_len)
+        out.append(b"@M01:%d:000000000-ABCDE:1:%d:%d:%d 1:N:0:7\n" % (seed, 1101 + i % 900, int(rng.integers(1000, 30000)), int(rng.integers(1000, 30000))))
+        out.append(b.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    return b"".join(out)
+
+
+def _gz(text, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, memlevel=8):
+    co = zlib.compressobj(level, zlib.DEFLATED, 31, memlevel, strategy)
+    return co.compress(text) + co.flush()
+
+
+def _inflate(gz, chunk=0, step=0, feed=0):
+    data = np.frombuffer(gz, dtype=np.uint8)
+    with hip.HipInflate(data.size, chunk_bytes=chunk, step_bytes=step) as z:
+        out = z.inflate_all(data, feed_bytes=feed)
+        return out.tobytes(), z.stats()
+
+
+TEXT = _fastq(20000)
+
+
+@pytest.mark.parametrize("level", [1, 4, 6, 9])
+@pytest.mark.parametrize("chunk", [0, 4096, 1024])
+def test_levels_and_chunk_sizes(level, chunk):
+    gz = _gz(TEXT, level)
+    got, st = _inflate(gz, chunk=chunk)
+    assert got == TEXT
+    if chunk:
+        assert st["chunks"] > 4  # really decoded in parallel pieces
+
+
+def test_default_sizes_use_markers_and_chunks():
+    gz = _gz(TEXT * 8, 6)
+    got, st = _inflate(gz)
+    assert got == TEXT * 8
+    assert st["chunks"] >= len(gz) // 32768 // 2 and st["markers"] > 0
+
+
+@pytest.mark.parametrize("text", [b"", b"A", b"@r\nACGT\n+\nIIII\n", b"N" * 100000, bytes(range(256)) * 40])
+def test_small_and_odd_texts(text):
+    got, _ = _inflate(_gz(text))
+    assert got == text
+
+
+def test_binary_data_goes_through_the_fixups_or_is_refused():
+    rng = np.random.default_rng(5)
+    text = rng.integers(0, 256, size=300_000, dtype=np.uint8).tobytes() + TEXT[:200_000]
+    gz = _gz(text)
+    try:
+        got, _ = _inflate(gz, chunk=4096)
+    except hip.GanonHipError as e:
+        assert e.code == -34
+    else:
+        assert got == text
+
+
+@pytest.mark.parametrize("strategy", [zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])
+def test_strategies(strategy):
+    text = TEXT[:400_000]
+    gz = _gz(text, 6, strategy)
+    try:
+        got, _ = _inflate(gz, chunk=8192)
+    except hip.GanonHipError as e:  # (a file of fixed blocks only has nothing for the search: refused, not wrong)
+        assert strategy == zlib.Z_FIXED and e.code == -34
+    else:
+        assert got == text
+
+
+def test_stored_blocks():
+    text = TEXT[:300_000]
+    gz = _gz(text, 0)
+    try:
+        got, _ = _inflate(gz, chunk=65536)
+    except hip.GanonHipError as e:
+        assert e.code == -34
+    else:
+        assert got == text
+
+
+def test_flush_points_and_mixed_blocks():
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts, text = [], []
+    for i in range(40):
+        t = TEXT[i * 50_000:(i + 1) * 50_000]
+        text.append(t)
+        parts.append(co.compress(t))
+        parts.append(co.flush(zlib.Z_FULL_FLUSH if i % 3 == 0 else zlib.Z_SYNC_FLUSH if i % 3 == 1 else zlib.Z_NO_FLUSH))
+    parts.append(co.flush())
+    got, _ = _inflate(b"".join(parts), chunk=4096)
+    assert got == b"".join(text)
+
+
+def test_members_with_header_fields_and_trailing_garbage():
+    a, b, c = TEXT[:500_000], TEXT[500_000:1_200_000], b""
+    bio = io.BytesIO()
+    with gzip.GzipFile(filename="reads_with_a_name.fq", mode="wb", fileobj=bio, compresslevel=6, mtime=0) as f:
+        f.write(a)
+    m1 = bio.getvalue()
+    # FEXTRA + FCOMMENT + FHCRC by hand around a raw deflate body
+    co = zlib.compressobj(9, zlib.DEFLATED, -15)
+    body = co.compress(b) + co.flush()
+    hdr = bytes([0x1F, 0x8B, 8, 4 | 16 | 2, 0, 0, 0, 0, 0, 255]) + (5).to_bytes(2, "little") + b"extra" + b"a comment\0"
+    hdr += (zlib.crc32(hdr) & 0xFFFF).to_bytes(2, "little")
+    m2 = hdr + body + zlib.crc32(b).to_bytes(4, "little") + (len(b) & 0xFFFFFFFF).to_bytes(4, "little")
+    m3 = _gz(c)
+    gz = m1 + m2 + m3 + b"\0\0\0garbage that is no member"
+    assert zlib.decompressobj(31).decompress(m1) == a
+    got, st = _inflate(gz, chunk=8192)
+    assert got == a + b + c
+    assert st["members"] == 3
+
+
+def test_many_steps_and_partial_feeds():
+    gz = _gz(TEXT * 4, 6)
+    got, st = _inflate(gz, chunk=2048, step=65536, feed=50_000)
+    assert got == TEXT * 4
+    assert st["steps"] > 4
+
+
+def test_truncated_and_damaged():
+    gz = _gz(TEXT, 6)
+    with pytest.raises(hip.GanonHipError):
+        _inflate(gz[:len(gz) // 2], chunk=4096)
+    bad = bytearray(gz)
+    for i in range(len(gz) // 3, len(gz) // 3 + 64):
+        bad[i] ^= 0x5A
+    try:
+        got, _ = _inflate(bytes(bad), chunk=4096)
+    except hip.GanonHipError:
+        pass
+    else:  # (whatever decodes must not be passed off as the file's text when zlib refuses it)
+        with pytest.raises(zlib.error):
+            zlib.decompress(bytes(bad), 31)
+        pytest.fail("damaged stream was accepted")
