@@ -86,11 +86,12 @@ def write_gzip_one_member(path: str, data: np.ndarray, level: int = 6, chunk: in
         f.write(struct.pack("<II", crc & 0xFFFFFFFF, n & 0xFFFFFFFF))
 
 
-def run_binary(args, n_units, runs, label, deadline):
+def run_binary(args, n_units, runs, label, deadline, env_extra=None):
     """-> summary of `runs` runs of the binary (fewer when the time budget runs out: the number is reported)"""
     secs, loads, walls = [], [], []
     last = {}
     env = dict(os.environ, GANON_HOST_TIMING="1")
+    env.update(env_extra or {})
     prefix = args[args.index("-o") + 1]
     for i in range(runs):
         if i >= 1 and time.time() > deadline:
@@ -132,7 +133,7 @@ def run_binary(args, n_units, runs, label, deadline):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--runs", type=int, default=5)
-    ap.add_argument("--reads", type=int, default=16_000_000, help="single-end reads (pairs: half of it, .gz reads: a quarter)")
+    ap.add_argument("--reads", type=int, default=16_000_000, help="single-end reads (pairs and .gz reads: half of it)")
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--budget", type=float, default=200.0, help="seconds; inputs that no longer fit are left out and named")
     ap.add_argument("--only", default="", help="comma-separated subset of fastq,paired,gz,fasta,hibf")
@@ -186,13 +187,19 @@ def main() -> int:
         elif "fasta" in want:
             out["skipped"].append("fasta")
         if "gz" in want and time.time() < deadline - 25:
-            ng = n // 4
+            ng = n // 2
             gz = os.path.join(d, "single.fq.gz")
             t0 = time.time()
             write_gzip_one_member(gz, fastq_matrix(wl.bases[: ng * L], ng, L, quals=True))
             r = run_binary(["--ibf", ibf, "--single-reads", gz, "-o", os.path.join(d, "o_gz")] + common, ng, args.runs,
                            f"{ng} reads x {L} bp, one-member .fq.gz ({os.path.getsize(gz) / 2**30:.2f} GiB, level 6, written in {time.time() - t0:.1f} s)", deadline)
             out["inputs"]["gz"] = r
+            m = re.search(r"\[host input\] .*(device inflate: .*)", "\n".join(r.get("timing_lines", [])) or "")
+            # the same file through the host's parallel inflater (pgzip.cpp), as up to round 4
+            if time.time() < deadline - 10:
+                out["inputs"]["gz_host_inflate"] = run_binary(["--ibf", ibf, "--single-reads", gz, "-o", os.path.join(d, "o_gzh")] + common, ng, max(1, args.runs // 2),
+                                                              "the same file, inflated by the host's threads ($GANON_HOST_DEVICE_INFLATE=0)", deadline,
+                                                              {"GANON_HOST_DEVICE_INFLATE": "0"})
             os.remove(gz)
         elif "gz" in want:
             out["skipped"].append("gz")

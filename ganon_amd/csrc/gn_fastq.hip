@@ -232,7 +232,7 @@ void gn_fastq_release(gn_stream* s)
         fprintf(stderr, "[hip call timing] gn_stream_upload_text x%.0f: initial sync %.3f ms, copy call %.3f ms, other calls %.3f ms per batch\n", s->fq_probe[3],
                 s->fq_probe[0] / s->fq_probe[3] * 1e3, s->fq_probe[1] / s->fq_probe[3] * 1e3, s->fq_probe[2] / s->fq_probe[3] * 1e3);
     for (void* p : { (void*)s->d_text, (void*)s->d_fq_tile, (void*)s->d_fq_nl, (void*)s->d_fq_rec, (void*)s->d_fq_seq, (void*)s->d_fq_len, (void*)s->d_fq,
-                     (void*)s->d_fq_scan, (void*)s->d_fq2_tile, (void*)s->d_fq2_nl, (void*)s->d_fq2_rec, (void*)s->d_fq2_seq, (void*)s->d_fq2_len })
+                     (void*)s->d_fq_scan, (void*)s->d_fq_hoff, (void*)s->d_fq_hdr, s->d_fq_hscan, (void*)s->d_fq2_tile, (void*)s->d_fq2_nl, (void*)s->d_fq2_rec, (void*)s->d_fq2_seq, (void*)s->d_fq2_len })
         if (p)
             hipFree(p);
     if (s->h_fq)
@@ -242,6 +242,9 @@ void gn_fastq_release(gn_stream* s)
     s->d_fq2_tile = s->d_fq2_nl = s->d_fq2_rec = s->d_fq2_seq = s->d_fq2_len = nullptr;
     s->d_fq = nullptr;
     s->d_fq_scan = nullptr;
+    s->d_fq_hoff = nullptr;
+    s->d_fq_hdr = nullptr;
+    s->d_fq_hscan = nullptr;
     s->h_fq = nullptr;
 }
 
@@ -311,7 +314,8 @@ static int gn_fq_enqueue(gn_stream* s, const uint8_t* d_text, uint64_t n_bytes, 
     return GN_OK;
 }
 
-static int gn_upload_texts(gn_stream* s, const uint8_t* text, uint64_t n_bytes, const uint8_t* text2, uint64_t n_bytes2, bool pair, int format)
+// src_device < 0: the texts are host memory; otherwise device memory of that device (one text only)
+static int gn_upload_texts(gn_stream* s, const uint8_t* text, uint64_t n_bytes, const uint8_t* text2, uint64_t n_bytes2, bool pair, int format, int src_device = -1)
 {
     if (!s || (!text && n_bytes) || (pair && !text2 && n_bytes2))
         return gn_fail(GN_EINVAL, "gn_stream_upload_text: null argument");
@@ -333,8 +337,13 @@ static int gn_upload_texts(gn_stream* s, const uint8_t* text, uint64_t n_bytes, 
     GN_HIP(hipStreamSynchronize(s->st)); // previous batch must be done before its inputs are overwritten
     const double p1 = probe ? now() : 0;
     hipStream_t  st = s->st;
-    if (n_bytes)
-        GN_HIP(hipMemcpyAsync(s->d_text, text, n_bytes, hipMemcpyHostToDevice, st));
+    if (n_bytes && src_device >= 0 && src_device != s->f->device)
+    {
+        gn_peer_enable(s->f->device, src_device);
+        GN_HIP(hipMemcpyPeerAsync(s->d_text, s->f->device, text, src_device, n_bytes, st));
+    }
+    else if (n_bytes)
+        GN_HIP(hipMemcpyAsync(s->d_text, text, n_bytes, src_device >= 0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     if (pair && n_bytes2)
         GN_HIP(hipMemcpyAsync(s->d_text + at2, text2, n_bytes2, hipMemcpyHostToDevice, st));
     const double p2 = probe ? now() : 0;
@@ -378,6 +387,13 @@ extern "C" int gn_stream_upload_fastq(gn_stream* s, const uint8_t* text, uint64_
 extern "C" int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t n_bytes, int format)
 {
     return gn_upload_texts(s, text, n_bytes, nullptr, 0, false, format);
+}
+
+extern "C" int gn_stream_upload_text_device(gn_stream* s, const uint8_t* d_text, uint64_t n_bytes, int format, int src_device)
+{
+    if (src_device < 0)
+        return gn_fail(GN_EINVAL, "gn_stream_upload_text_device: device %d", src_device);
+    return gn_upload_texts(s, d_text, n_bytes, nullptr, 0, false, format, src_device);
 }
 
 extern "C" int gn_stream_upload_text_pair(gn_stream* s, const uint8_t* text1, uint64_t n_bytes1, const uint8_t* text2, uint64_t n_bytes2, int format)
@@ -469,4 +485,63 @@ extern "C" int gn_stream_text_pair_records2(gn_stream* s, uint32_t* rec_at, uint
     if (!s || !s->have_reads || !s->d_fq2_rec || !s->fq_pair)
         return gn_fail(GN_EINVAL, "gn_stream_text_pair_records2: not a tokenised pair of texts");
     return gn_text_records(s, s->d_fq2_rec, s->d_fq2_seq, s->d_fq2_len, rec_at, seq_at, seq_len);
+}
+
+// ---- header lines of the batch's records, for a caller that does not hold the text (gn_stream_upload_text_device) ----------------------
+__global__ void gn_fq_hlen_kernel(const uint32_t* __restrict__ rec, const uint32_t* __restrict__ seq, uint32_t n, uint32_t* __restrict__ hlen)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n)
+        hlen[i] = i < n ? seq[i] - rec[i] : 0u; // (from the '@' or '>' to the newline, both included)
+}
+
+// one wave per 64 records; a record's header is copied by its lane eight bytes at a time where both ends allow it
+__global__ void gn_fq_hcopy_kernel(const uint8_t* __restrict__ text, const uint32_t* __restrict__ rec, const uint32_t* __restrict__ hoff, uint32_t n,
+                                   uint8_t* __restrict__ dst)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint8_t* a = text + rec[i];
+    uint8_t*       b = dst + hoff[i];
+    const uint32_t len = hoff[i + 1] - hoff[i];
+    for (uint32_t k = 0; k < len; ++k)
+        b[k] = a[k];
+}
+
+extern "C" int gn_stream_fastq_headers(gn_stream* s, uint8_t* dst, uint64_t cap, uint32_t* hdr_off, uint64_t* n_bytes)
+{
+    if (!s || !s->have_reads || !s->d_text || !hdr_off || !n_bytes || (!dst && cap))
+        return gn_fail(GN_EINVAL, "gn_stream_fastq_headers: not a tokenised batch, or null argument");
+    GN_HIP(hipSetDevice(s->f->device));
+    const uint32_t n = s->n_reads;
+    *n_bytes         = 0;
+    hdr_off[0]       = 0;
+    if (n == 0)
+        return GN_OK;
+    if (!s->d_fq_hoff)
+    {
+        GN_HIP(hipMalloc(&s->d_fq_hoff, ((size_t)s->max_reads + 2) * 2 * sizeof(uint32_t)));
+        GN_HIP(hipMalloc(&s->d_fq_hdr, s->fq_text_cap + 64));
+        size_t tmp = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, s->d_fq_hoff, s->d_fq_hoff, (int)(s->max_reads + 1), s->st);
+        s->fq_hscan_bytes = tmp + 256;
+        GN_HIP(hipMalloc(&s->d_fq_hscan, s->fq_hscan_bytes));
+    }
+    uint32_t* hlen = s->d_fq_hoff;
+    uint32_t* hoff = s->d_fq_hoff + s->max_reads + 2;
+    hipLaunchKernelGGL(gn_fq_hlen_kernel, dim3((n + 256) / 256), dim3(256), 0, s->st, s->d_fq_rec, s->d_fq_seq, n, hlen);
+    size_t tmp = s->fq_hscan_bytes;
+    GN_HIP(hipcub::DeviceScan::ExclusiveSum(s->d_fq_hscan, tmp, hlen, hoff, (int)(n + 1), s->st));
+    hipLaunchKernelGGL(gn_fq_hcopy_kernel, dim3((n + 255) / 256), dim3(256), 0, s->st, s->d_text, s->d_fq_rec, hoff, n, s->d_fq_hdr);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipMemcpyAsync(hdr_off, hoff, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->st));
+    GN_HIP(hipStreamSynchronize(s->st));
+    const uint64_t total = hdr_off[n];
+    *n_bytes             = total;
+    if (total > cap)
+        return gn_fail(GN_EOVERFLOW, "gn_stream_fastq_headers: %llu bytes of header lines, room for %llu", (unsigned long long)total, (unsigned long long)cap);
+    GN_HIP(hipMemcpyAsync(dst, s->d_fq_hdr, total, hipMemcpyDeviceToHost, s->st));
+    GN_HIP(hipStreamSynchronize(s->st));
+    return GN_OK;
 }

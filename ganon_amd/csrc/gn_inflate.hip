@@ -34,8 +34,10 @@
 #include "gn_internal.h"
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -1445,13 +1447,106 @@ __global__ __launch_bounds__(256) void gi_resolve_kernel(const GiState* st, cons
     }
 }
 
+
+// ---- where the records of a step's text begin: cut points for the caller's batches ----------------------------------------------------
+#define GI_CUT_TILE 4096u
+__device__ __forceinline__ uint32_t gi_nl_count(uint32_t x)
+{
+    const uint32_t t = x ^ 0x0A0A0A0Au; // a byte of t is 0 where the text has '\n'
+    return (uint32_t)__popc(~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu));
+}
+
+__global__ __launch_bounds__(256) void gi_nl_tiles_kernel(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ cnt)
+{
+    __shared__ uint32_t part[4];
+    const uint64_t      p = (uint64_t)blockIdx.x * GI_CUT_TILE + threadIdx.x * 16u;
+    uint32_t            c = 0;
+    if (p + 16u <= n)
+    {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + p);
+        c             = gi_nl_count(v.x) + gi_nl_count(v.y) + gi_nl_count(v.z) + gi_nl_count(v.w);
+    }
+    else
+        for (uint64_t q = p; q < n; ++q)
+            c += text[q] == '\n';
+    for (int o = 32; o > 0; o >>= 1)
+        c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63u) == 0)
+        part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// thread j < m: the first record boundary at or behind (j + 1) * piece; thread m: the last record boundary of the text.  A record
+// boundary = the byte behind newline number l (from 0) with (l + 1) % lpr == 0.  ~0 = none.
+__global__ void gi_cuts_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ pre /* tiles + 1: exclusive sums */, uint32_t tiles,
+                               uint32_t lpr, uint64_t piece, uint32_t m, unsigned long long* __restrict__ cuts)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > m)
+        return;
+    const uint64_t total = pre[tiles];
+    uint64_t       want; // the newline behind which the cut lies
+    if (j == m)
+    {
+        if (total < lpr)
+        {
+            cuts[j] = ~0ull;
+            return;
+        }
+        want = total / lpr * lpr - 1u;
+    }
+    else
+    {
+        const uint64_t T = (uint64_t)(j + 1) * piece; // (>= 1)
+        if (T > n)
+        {
+            cuts[j] = ~0ull;
+            return;
+        }
+        const uint64_t P  = T - 1u; // newlines in [0, P)
+        const uint64_t t0 = P / GI_CUT_TILE;
+        uint64_t       lmin = pre[t0];
+        for (uint64_t q = t0 * GI_CUT_TILE; q < P; ++q)
+            lmin += text[q] == '\n';
+        want = (lmin + lpr) / lpr * lpr - 1u;
+        if (want >= total)
+        {
+            cuts[j] = ~0ull;
+            return;
+        }
+    }
+    uint32_t lo = 0, hi = tiles; // the last tile whose exclusive sum is <= want
+    while (hi - lo > 1u)
+    {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (pre[mid] <= want)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    uint64_t left = want - pre[lo];
+    uint64_t q    = (uint64_t)lo * GI_CUT_TILE;
+    for (; q < n; ++q)
+        if (text[q] == '\n')
+        {
+            if (left == 0)
+                break;
+            --left;
+        }
+    cuts[j] = q + 1u;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 struct gn_inflate
 {
     int         device = 0;
     int         n_cu   = 256;
     hipStream_t st = nullptr, st_copy = nullptr, st_out = nullptr;
-    uint64_t    total = 0, fed = 0;
+    uint64_t    total = 0;
+    std::atomic<uint64_t> fed{ 0 }; // (gn_inflate_feed may run on another host thread than gn_inflate_step)
+    uint64_t    fed_step = 0;       // what the running step sees of it
     uint32_t    chunk_bytes = 32768;
     uint64_t    step_bytes  = 256ull << 20;
     uint32_t    n_chunks_file = 0;
@@ -1476,6 +1571,12 @@ struct gn_inflate
     uint64_t  text_cap = 0;
     int       cur = 1; // buffer of the last step
     uint64_t  n_text_last = 0;
+    uint64_t  carry = 0; // bytes at the end of the last step's text that the next step's text begins with (gn_inflate_set_carry)
+    uint32_t* d_cut_cnt = nullptr; // newline counts per tile, then their exclusive sums
+    void*     d_cut_tmp = nullptr;
+    size_t    cut_tmp_bytes = 0;
+    unsigned long long* d_cuts = nullptr;
+    uint32_t  cut_tiles_cap = 0, cuts_cap = 0;
     bool      ended = false;
     // totals
     gn_inflate_stats stats{};
@@ -1488,7 +1589,7 @@ static void gi_free(gn_inflate* z)
         return;
     hipSetDevice(z->device);
     for (void* p : { (void*)z->d_comp, (void*)z->d_chunks, (void*)z->d_pool, (void*)z->d_ctr, (void*)z->d_state, (void*)z->d_window, (void*)z->d_p_store, (void*)z->d_g_store, (void*)z->d_w_store,
-                     (void*)z->d_real, (void*)z->d_work, (void*)z->d_text[0], (void*)z->d_text[1] })
+                     (void*)z->d_real, (void*)z->d_work, (void*)z->d_cut_cnt, z->d_cut_tmp, (void*)z->d_cuts, (void*)z->d_text[0], (void*)z->d_text[1] })
         if (p)
             hipFree(p);
     if (z->h_state)
@@ -1584,12 +1685,13 @@ extern "C" int gn_inflate_feed(gn_inflate* z, const uint8_t* data, uint64_t n)
 {
     if (!z || (!data && n))
         return gn_fail(GN_EINVAL, "gn_inflate_feed: null argument");
-    if (z->fed + n > z->total)
+    const uint64_t fed0 = z->fed.load();
+    if (fed0 + n > z->total)
         return gn_fail(GN_EINVAL, "gn_inflate_feed: more bytes than the file was announced with");
     GN_HIP(hipSetDevice(z->device));
-    GN_HIP(hipMemcpyAsync(z->d_comp + z->fed, data, n, hipMemcpyHostToDevice, z->st_copy));
+    GN_HIP(hipMemcpyAsync(z->d_comp + fed0, data, n, hipMemcpyHostToDevice, z->st_copy));
     GN_HIP(hipStreamSynchronize(z->st_copy));
-    z->fed += n;
+    z->fed.store(fed0 + n);
     return GN_OK;
 }
 
@@ -1597,7 +1699,7 @@ static int gi_launch_chunks(gn_inflate* z, uint32_t j0, uint32_t n, uint64_t fix
 {
     GiParams p;
     p.comp        = reinterpret_cast<const uint32_t*>(z->d_comp);
-    p.avail_bits  = z->fed * 8u;
+    p.avail_bits  = z->fed_step * 8u;
     p.total_bits  = z->total * 8u;
     p.chunk_bytes = z->chunk_bytes;
     p.j0          = j0;
@@ -1626,7 +1728,8 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     if (z->ended)
         return GN_OK;
     GN_HIP(hipSetDevice(z->device));
-    const bool all_fed = z->fed >= z->total;
+    z->fed_step        = z->fed.load();
+    const bool all_fed = z->fed_step >= z->total;
     // chunks this step may decode: those whose range and a margin behind it are fed
     const uint64_t margin = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(z->step_bytes / 4u, 2ull * z->chunk_bytes)); // (too little only costs a repeat)
     uint32_t       j1;
@@ -1634,7 +1737,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         j1 = z->n_chunks_file;
     else
     {
-        const uint64_t usable = z->fed > margin ? z->fed - margin : 0;
+        const uint64_t usable = z->fed_step > margin ? z->fed_step - margin : 0;
         j1                    = (uint32_t)(usable / z->chunk_bytes);
     }
     j1 = std::min<uint32_t>(j1, z->next_chunk + z->slots_cap);
@@ -1646,6 +1749,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     }
     const uint32_t j0 = z->next_chunk, n = j1 - j0;
     const int      buf = 1 - z->cur;
+    const uint64_t carry = z->carry; // (<= n_text_last, checked by gn_inflate_set_carry)
     auto           t0 = std::chrono::steady_clock::now();
     GN_HIP(hipMemsetAsync(z->d_ctr, 0, 64, z->st));
     GN_HIP(hipEventRecord(z->ev[0], z->st));
@@ -1663,7 +1767,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         GN_HIP(hipMemcpyAsync(z->d_state, z->h_state, sizeof(GiState), hipMemcpyHostToDevice, z->st));
         const size_t lds = (size_t)(n + fixes) * 16u;
         hipLaunchKernelGGL(gi_order_kernel, dim3(1), dim3(1024), lds, z->st, z->d_state, z->d_chunks, n, z->slots_cap, fixes, j0, z->chunk_bytes, range_end,
-                           z->total * 8u, z->d_real, z->d_work, z->slots_cap + z->fix_cap, z->work_cap, z->text_cap);
+                           z->total * 8u, z->d_real, z->d_work, z->slots_cap + z->fix_cap, z->work_cap, z->text_cap - carry);
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(z->h_state, z->d_state, sizeof(GiState), hipMemcpyDeviceToHost, z->st));
         GN_HIP(hipStreamSynchronize(z->st));
@@ -1694,10 +1798,12 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         hipLaunchKernelGGL(gi_wchain_kernel, dim3(1), dim3(1024), 0, z->st, z->d_state, z->d_g_store, z->d_window, z->d_w_store);
         GN_HIP(hipGetLastError());
     }
+    if (carry)
+        GN_HIP(hipMemcpyAsync(z->d_text[buf], z->d_text[z->cur] + (z->n_text_last - carry), carry, hipMemcpyDeviceToDevice, z->st));
     if (s.n_work)
     {
         hipLaunchKernelGGL(gi_resolve_kernel, dim3(std::min<uint32_t>(s.n_work, (uint32_t)z->n_cu * 8u)), dim3(256), 0, z->st, z->d_state, z->d_chunks, z->d_real,
-                           z->d_work, z->d_pool, z->d_p_store, z->d_w_store, z->d_text[buf]);
+                           z->d_work, z->d_pool, z->d_p_store, z->d_w_store, z->d_text[buf] + carry);
         GN_HIP(hipGetLastError());
     }
     GN_HIP(hipEventRecord(z->ev[3], z->st));
@@ -1721,8 +1827,9 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     z->h_state->run_len = s.res_run_len;
     z->stats.text_bytes += s.text_off;
     z->cur         = buf;
-    z->n_text_last = s.text_off;
-    *n_text        = s.text_off;
+    z->n_text_last = carry + s.text_off;
+    z->carry       = 0;
+    *n_text        = carry + s.text_off;
     if (s.reason == GI_R_END)
     {
         z->ended = true;
@@ -1774,5 +1881,76 @@ extern "C" int gn_inflate_get_stats(gn_inflate* z, gn_inflate_stats* out)
     if (!z || !out)
         return gn_fail(GN_EINVAL, "gn_inflate_get_stats: null argument");
     *out = z->stats;
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_set_carry(gn_inflate* z, uint64_t n_tail)
+{
+    if (!z)
+        return gn_fail(GN_EINVAL, "gn_inflate_set_carry: null argument");
+    if (n_tail > z->n_text_last || n_tail > z->text_cap / 4u)
+        return gn_fail(GN_EINVAL, "gn_inflate_set_carry: %llu bytes are more than the last step's text (or a quarter of a step's capacity) holds",
+                       (unsigned long long)n_tail);
+    z->carry = n_tail;
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_cuts(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_bytes, uint64_t* cuts, uint32_t cap, uint32_t* n_cuts)
+{
+    if (!z || !cuts || !n_cuts || lines_per_record == 0 || piece_bytes == 0)
+        return gn_fail(GN_EINVAL, "gn_inflate_cuts: bad argument");
+    *n_cuts = 0;
+    const uint64_t n = z->n_text_last;
+    if (n == 0)
+        return GN_OK;
+    GN_HIP(hipSetDevice(z->device));
+    const uint32_t tiles = (uint32_t)((n + GI_CUT_TILE - 1) / GI_CUT_TILE);
+    const uint32_t m     = (uint32_t)(n / piece_bytes);
+    if (m + 1u > cap)
+        return gn_fail(GN_EINVAL, "gn_inflate_cuts: room for %u cuts, %u needed", cap, m + 1u);
+    if (tiles + 1u > z->cut_tiles_cap)
+    {
+        if (z->d_cut_cnt)
+            hipFree(z->d_cut_cnt);
+        if (z->d_cut_tmp)
+            hipFree(z->d_cut_tmp);
+        z->d_cut_cnt = nullptr;
+        z->d_cut_tmp = nullptr;
+        const uint32_t want = (uint32_t)((z->text_cap + GI_CUT_TILE - 1) / GI_CUT_TILE) + 2u;
+        GN_HIP(hipMalloc((void**)&z->d_cut_cnt, (size_t)want * 2u * sizeof(uint32_t)));
+        size_t tmp = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, z->d_cut_cnt, z->d_cut_cnt, (int)want, z->st);
+        z->cut_tmp_bytes = tmp + 256;
+        GN_HIP(hipMalloc(&z->d_cut_tmp, z->cut_tmp_bytes));
+        z->cut_tiles_cap = want;
+    }
+    if (m + 1u > z->cuts_cap)
+    {
+        if (z->d_cuts)
+            hipFree(z->d_cuts);
+        z->d_cuts = nullptr;
+        GN_HIP(hipMalloc((void**)&z->d_cuts, (size_t)(m + 64u) * sizeof(unsigned long long)));
+        z->cuts_cap = m + 64u;
+    }
+    uint32_t* cnt = z->d_cut_cnt;
+    uint32_t* pre = z->d_cut_cnt + z->cut_tiles_cap;
+    GN_HIP(hipMemsetAsync(cnt + tiles, 0, sizeof(uint32_t), z->st));
+    hipLaunchKernelGGL(gi_nl_tiles_kernel, dim3(tiles), dim3(256), 0, z->st, z->d_text[z->cur], n, cnt);
+    size_t tmp = z->cut_tmp_bytes;
+    GN_HIP(hipcub::DeviceScan::ExclusiveSum(z->d_cut_tmp, tmp, cnt, pre, (int)(tiles + 1u), z->st));
+    hipLaunchKernelGGL(gi_cuts_kernel, dim3((m + 1u + 63u) / 64u), dim3(64), 0, z->st, z->d_text[z->cur], n, pre, tiles, lines_per_record, piece_bytes, m, z->d_cuts);
+    GN_HIP(hipGetLastError());
+    std::vector<unsigned long long> h(m + 1u);
+    GN_HIP(hipMemcpyAsync(h.data(), z->d_cuts, (size_t)(m + 1u) * sizeof(unsigned long long), hipMemcpyDeviceToHost, z->st));
+    GN_HIP(hipStreamSynchronize(z->st));
+    uint64_t last = 0;
+    uint32_t k    = 0;
+    for (uint32_t j = 0; j <= m; ++j)
+        if (h[j] != ~0ull && h[j] > last && h[j] <= n)
+        {
+            cuts[k++] = h[j];
+            last      = h[j];
+        }
+    *n_cuts = k;
     return GN_OK;
 }

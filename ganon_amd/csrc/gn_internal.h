@@ -374,6 +374,10 @@ struct gn_stream
     uint32_t*           d_fq_seq  = nullptr;
     uint32_t*           d_fq_len  = nullptr;
     unsigned long long* d_fq      = nullptr; // see gn_fq_records_kernel
+    uint32_t*           d_fq_hoff = nullptr; // gn_stream_fastq_headers: header length per record, then the exclusive sums
+    uint8_t*            d_fq_hdr  = nullptr; // ... the header lines back to back
+    void*               d_fq_hscan = nullptr;
+    size_t              fq_hscan_bytes = 0;
     unsigned long long* h_fq      = nullptr; // pinned copy
     void*               d_fq_scan = nullptr;
     size_t              fq_scan_bytes = 0;

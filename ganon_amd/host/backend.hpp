@@ -121,6 +121,14 @@ struct ReadBatch
     uint64_t                   text2_at = 0;
     uint64_t                   raw_parsed2 = 0; // set by tokenise: bytes of text2 the batch's mates cover
     U32Buf                     seq_at2, seq_len2;
+    // ... or the text lies in device memory (a piece of a gzip file inflated there: DeviceTextSource): `text` is empty until the batch is
+    // classified, then holds the header lines of its records back to back (rec_at / seq_at are rewritten to fit: ids are read as ever,
+    // letters are not on the host at all -- such batches only exist on runs with one hierarchy level, where nothing needs them)
+    const uint8_t*        dev_text   = nullptr;
+    uint64_t              dev_bytes  = 0;
+    int                   dev_device = -1;
+    std::shared_ptr<void> dev_hold;  // keeps the device buffer alive; dropped once the text is copied into the worker's stream
+    uint64_t raw_bytes() const { return dev_text ? dev_bytes : text.size(); }
     std::unique_ptr<RawTicket> ticket;
     size_t size() const { return raw ? rec_at.size() : id_off.size() - 1; }
     std::string_view id(size_t i) const
@@ -182,6 +190,31 @@ struct PostFilterSpec
     std::vector<std::vector<uint32_t>> target_gid;
 };
 
+// Text of a compressed input file that is produced in device memory (backend_hip: a gzip file inflated by csrc/gn_inflate.hip), piece by
+// piece; every piece begins with a record and ends behind one (the file's last piece ends where the stream does).
+struct DeviceTextPiece
+{
+    const uint8_t*        dev = nullptr;
+    uint64_t              bytes = 0;
+    uint64_t              at = 0; // offset of the piece's first byte in the decompressed stream
+    int                   device = -1;
+    std::shared_ptr<void> hold;
+};
+class DeviceTextSource
+{
+public:
+    virtual ~DeviceTextSource() = default;
+    // the next piece; false at the end of the stream (err empty) or when the device path gives the file up (err says why): a host
+    // reader then continues at decompressed offset delivered()
+    virtual bool        next(DeviceTextPiece& out, std::string& err) = 0;
+    virtual uint64_t    delivered() const = 0;
+    virtual bool        fasta() const = 0;
+    virtual std::string report() const { return std::string(); }
+};
+
+// devgzip.cpp (binaries linked with libganon_hip.so only): nullptr when the file is not one for the device inflater
+std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, int device, size_t piece_bytes, size_t min_bytes);
+
 // One device (or the test checker): receives filters, classifies batches.  Not thread-safe; one host thread each.
 class Backend : public FilterSink
 {
@@ -194,6 +227,9 @@ public:
     // Optional.  Does this backend find the records of uncompressed four-line FASTQ itself?  Then the reader hands such files
     // over as raw batches (pieces of the file in page-locked memory) instead of parsing them.
     virtual bool tokenises_fastq() const { return false; }
+    // Optional.  A gzip-compressed FASTQ / FASTA file as text pieces in this backend's device memory; nullptr: not a file for that (not
+    // gzip, blocked gzip, too small, no room) or not a backend that does it.  piece_bytes = text per piece, about.
+    virtual std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& /*path*/, size_t /*piece_bytes*/, size_t /*min_bytes*/) { return nullptr; }
     // Raw batches: takes batch.text, finds the records.  n_reads = records before the first that is not a plain four-line
     // record (or the end of the text inside one); parsed_bytes = where that one begins (== text.size(): all of it is records).
     // A paired raw batch (batch.paired, batch.text2 = the mate file's piece with the same records by number): the pairs both

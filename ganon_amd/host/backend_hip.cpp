@@ -123,14 +123,19 @@ public:
         return tokenise_begin(b, err) && tokenise_end(b, n_reads, parsed_bytes, err);
     }
 
+    std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& path, size_t piece_bytes, size_t min_bytes) override
+    {
+        return open_device_gzip(path, device_, piece_bytes, min_bytes);
+    }
+
     bool tokenise_begin(ReadBatch& b, std::string& err) override
     {
         if (!resolve(err))
             return false;
         auto t = std::chrono::steady_clock::now();
         const bool     pair  = b.paired && b.raw;
-        const uint64_t nb    = pair ? ((b.text.size() + 15) & ~15ull) + b.text2.size() : b.text.size();
-        const uint64_t reads = std::max<uint64_t>(hint_reads_, b.text.size() / 40); // (records shorter than 40 bytes on average: the rest goes the slow way)
+        const uint64_t nb    = pair ? ((b.text.size() + 15) & ~15ull) + b.text2.size() : b.raw_bytes();
+        const uint64_t reads = std::max<uint64_t>(hint_reads_, b.raw_bytes() / 40); // (records shorter than 40 bytes on average: the rest goes the slow way)
         // (prepare() sized the streams by the same rule: no re-creation unless a piece is larger than the reader said)
         std::vector<gn_stream*>& sources = tok_sources_;
         sources.clear();
@@ -150,8 +155,9 @@ public:
                     t = now;
                 }
                 const int fmt = b.raw_fasta ? GN_TEXT_FASTA : GN_TEXT_FASTQ;
-                if ((pair ? gn_stream_upload_text_pair(part.s, b.text.data(), b.text.size(), b.text2.data(), b.text2.size(), fmt)
-                          : gn_stream_upload_text(part.s, b.text.data(), nb, fmt))
+                if ((b.dev_text ? gn_stream_upload_text_device(part.s, b.dev_text, nb, fmt, b.dev_device)
+                     : pair     ? gn_stream_upload_text_pair(part.s, b.text.data(), b.text.size(), b.text2.data(), b.text2.size(), fmt)
+                                : gn_stream_upload_text(part.s, b.text.data(), nb, fmt))
                     != GN_OK)
                 {
                     err = gn_last_error();
@@ -189,6 +195,7 @@ public:
                 return false;
             }
         }
+        b.dev_hold.reset(); // (the text is in every stream now: the inflater may write that buffer again)
         sec_tok_wait_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
         return !sources.empty();
     }
@@ -420,6 +427,29 @@ public:
             {
                 err = gn_last_error();
                 return false;
+            }
+            if (b.dev_text) // the text stayed on the device: the header lines come over, ids are read from them (ReadBatch::id)
+            {
+                hdr_off_.resize((size_t)n + 1);
+                uint64_t hb = 0;
+                if (b.text.size() < (size_t)n * 64 + 4096)
+                    b.text.resize((size_t)n * 64 + 4096);
+                int rc = gn_stream_fastq_headers(first, b.text.data(), b.text.size(), hdr_off_.data(), &hb);
+                if (rc == GN_EOVERFLOW)
+                {
+                    b.text.resize((size_t)hb + 4096);
+                    rc = gn_stream_fastq_headers(first, b.text.data(), b.text.size(), hdr_off_.data(), &hb);
+                }
+                if (rc != GN_OK)
+                {
+                    err = gn_last_error();
+                    return false;
+                }
+                for (size_t i = 0; i < n; ++i)
+                {
+                    b.rec_at[i] = hdr_off_[i];
+                    b.seq_at[i] = hdr_off_[i + 1];
+                }
             }
         }
         lap(sec_fetch_);
@@ -765,6 +795,7 @@ private:
     uint64_t              hint_reads_ = 0, hint_bases_ = 0; // largest batch the reader makes (prepare())
     bool                  long_reads_ = false;
     std::vector<Logical>  filters_;
+    std::vector<uint32_t>   hdr_off_;     // gn_stream_fastq_headers: offsets of a device-text batch's header lines
     std::vector<gn_stream*> tok_sources_; // streams that hold the FASTQ text of the batch being tokenised (one per device)
     PostFilterSpec        pf_spec_;
     std::vector<std::vector<std::vector<double>>> pf_fpr_; // [filter][part]: per device target of that part

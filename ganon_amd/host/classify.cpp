@@ -505,7 +505,7 @@ private:
 // slab IS the batch (no copy); for pairs the slabs of file 1 become batches and the mates are copied next to them from
 // the slabs of file 2.  Everything else -- compressed input, FASTA, wrapped records, and whatever follows the first
 // record the parallel parser does not take -- goes through the sequential reader, from the byte where the slabs stopped.
-void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq)
+void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq, Backend* device_text)
 {
     uint64_t       seq = 0;
     MateCopier     copier(queue, (unsigned)env_size("GANON_HOST_MATE_THREADS", 3));
@@ -537,6 +537,9 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     rb.seq_at.clear();
                     rb.seq_len.clear();
                     rb.ticket.reset();
+                    rb.dev_text = nullptr;
+                    rb.dev_bytes = 0;
+                    rb.dev_hold.reset();
                 }
                 else
                     rb = ReadBatch();
@@ -568,8 +571,55 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             // ---- parallel slabs ----------------------------------------------------------------------------------
             uint64_t resume1 = 0, resume2 = 0; // where the sequential reader takes over (0 = from the start)
             bool     file_done = false, fallback = false;
+            // ---- a gzip file inflated on the device: pieces of text that never leave it (single-end; devgzip.cpp) ---------------------
+            if (raw_fastq && !paired && device_text)
+            {
+                if (auto src = device_text->open_gzip_text(pair.mate1, slab_bytes, env_size("GANON_HOST_DEVICE_INFLATE_MIN", 1u << 20)))
+                {
+                    auto            tracker = std::make_shared<RawFileTracker>();
+                    size_t          pieces  = 0;
+                    DeviceTextPiece pc;
+                    std::string     why;
+                    while (src->next(pc, why))
+                    {
+                        rb.raw        = true;
+                        rb.raw_fasta  = src->fasta();
+                        rb.text.clear();
+                        rb.dev_text   = pc.dev;
+                        rb.dev_bytes  = pc.bytes;
+                        rb.dev_device = pc.device;
+                        rb.dev_hold   = std::move(pc.hold);
+                        rb.text_at    = pc.at;
+                        rb.raw_keep   = 0;
+                        rb.ticket.reset(new RawTicket{ tracker, pieces++ });
+                        rb.seq = seq++;
+                        copier.deliver(std::move(rb));
+                        fresh();
+                    }
+                    if (std::getenv("GANON_HOST_TIMING") || !why.empty())
+                        std::cerr << "[host input] " << pair.mate1 << ": " << src->report() << (why.empty() ? std::string() : "; given up: " + why) << std::endl;
+                    uint64_t at = 0;
+                    if (!tracker->wait_all(pieces, at))
+                    {
+                        if (at == UINT64_MAX) // (the pipeline is going down)
+                            file_done = true;
+                        else
+                        {
+                            resume1  = at;
+                            fallback = true;
+                        }
+                    }
+                    else if (!why.empty()) // the device path gave the file up behind the pieces it delivered: zlib goes on from there
+                    {
+                        resume1  = src->delivered();
+                        fallback = true;
+                    }
+                    else
+                        file_done = true;
+                }
+            }
             // ---- raw pieces: the backend finds the records (single-end, uncompressed four-line FASTQ) ------------------------
-            if (raw_fastq && !paired)
+            if (raw_fastq && !paired && !file_done && !fallback)
             {
                 if (auto pfr = ParallelFastq::open(pair.mate1, std::min(par_threads, 6u), slab_bytes, par_min, false, true))
                 {
@@ -1068,7 +1118,11 @@ static bool ganon_classify(Config config)
     BatchQueue  queue1(2 + 2 * n_workers);
     // uncompressed single-end FASTQ goes to the workers as it lies in the file when the backend finds the records itself
     const bool  raw_fastq = backends.front()->tokenises_fastq();
-    std::thread read_task(parse_reads, std::ref(queue1), std::ref(report), std::ref(report_mutex), std::cref(reads), raw_fastq);
+    // ... and gzip files are inflated on the device, their text handed to the workers there, when nothing needs the letters on the host
+    // (one hierarchy level: reads left unclassified are not passed on) -- $GANON_HOST_DEVICE_INFLATE=0 keeps the host inflater
+    const char* di = std::getenv("GANON_HOST_DEVICE_INFLATE");
+    Backend*    device_text = raw_fastq && levels.size() == 1 && !(di && di[0] == '0') ? backends.front().get() : nullptr;
+    std::thread read_task(parse_reads, std::ref(queue1), std::ref(report), std::ref(report_mutex), std::cref(reads), raw_fastq, device_text);
     struct Joiner
     {
         std::thread& t;
@@ -1724,7 +1778,7 @@ static bool ganon_classify(Config config)
                                 return fail(e);
                             // the piece says what it is right away; whether the pieces before it were all records is asked when its
                             // results arrive (they always are, unless the file is damaged: then this batch's results are dropped there)
-                            rb.ticket->publish(parsed == rb.text.size(), rb.text_at + parsed, rb.text2_at + rb.raw_parsed2);
+                            rb.ticket->publish(parsed == rb.raw_bytes(), rb.text_at + parsed, rb.text2_at + rb.raw_parsed2);
                             rb.raw_keep = n;
                         }
                         if (!timed([&] { return x.be->classify_begin(rb, level.kmer_size, level.window_size, rel_cutoffs, e); }))

@@ -1,0 +1,346 @@
+// devgzip.cpp -- a gzip-compressed FASTQ / FASTA file as pieces of text in device memory (DeviceTextSource, backend.hpp).
+//
+// The reference reads `reads.fq.gz` through one zlib stream (seqan3::sequence_file_input in parse_reads,
+// /root/reference/src/ganon-classify/GanonClassify.cpp:1220-1287,1433).  Here the file's bytes go to the device as they are -- a
+// quarter of the text --, libganon_hip's gn_inflate_* (csrc/gn_inflate.hip) inflates them there, gn_inflate_cuts says where records
+// begin, and the pieces between cuts are handed to the workers as device pointers: the text never crosses the link, the host sees
+// the records' header lines only (gn_stream_fastq_headers).
+//
+//   reader threads: pread() the file in 8 MiB blocks into page-locked buffers, ahead of the feeder
+//   feeder thread:  gn_inflate_feed in file order (the whole compressed file becomes resident)
+//   stepper thread: gn_inflate_step when a step's bytes are there, gn_inflate_cuts, pieces into a queue; the record the step's end
+//                   cuts is carried into the next step's text (gn_inflate_set_carry); a step's buffer is written again two steps
+//                   later, so the stepper waits until every piece of step k is released before it runs step k + 2
+// Anything the device path refuses (GN_ERANGE: damaged data, a wrong ISIZE, expansion beyond its buffers, ...) ends the source with
+// an error text; the caller's sequential zlib reader continues at delivered() and produces the records and the message from there.
+#include "backend.hpp"
+
+#include "../../include/ganon_hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <thread>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace gnhost
+{
+namespace
+{
+
+bool ends_with(const std::string& s, const char* e)
+{
+    const size_t n = std::strlen(e);
+    return s.size() >= n && s.compare(s.size() - n, n, e) == 0;
+}
+
+class DeviceGzip final : public DeviceTextSource
+{
+public:
+    DeviceGzip() = default;
+    ~DeviceGzip() override
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : readers_)
+            if (t.joinable())
+                t.join();
+        if (feeder_.joinable())
+            feeder_.join();
+        if (stepper_.joinable())
+            stepper_.join();
+        // pieces still out there keep their hold; the device buffers go with the inflater: wait for them
+        {
+            std::deque<DeviceTextPiece> mine;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                mine.swap(q_);
+            }
+        }
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return held_[0] == 0 && held_[1] == 0; });
+        }
+        if (z_)
+            gn_inflate_destroy(z_);
+        for (void* p : blocks_)
+            gn_pinned_free(p);
+        if (fd_ >= 0)
+            ::close(fd_);
+    }
+
+    bool start(const std::string& path, int device, size_t piece_bytes, size_t min_bytes)
+    {
+        std::string base = path;
+        if (!ends_with(base, ".gz"))
+            return false;
+        base = base.substr(0, base.size() - 3);
+        for (const char* e : { ".fa", ".fasta", ".fna", ".ffn", ".faa", ".frn", ".fas" })
+            fasta_ = fasta_ || ends_with(base, e);
+        if (!(fasta_ || ends_with(base, ".fq") || ends_with(base, ".fastq")))
+            return false;
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0)
+            return false;
+        struct stat st;
+        uint8_t     h[18];
+        if (fstat(fd_, &st) != 0 || (size_t)st.st_size < std::max<size_t>(min_bytes, 64) || pread(fd_, h, 18, 0) != 18)
+            return false;
+        if (h[0] != 0x1F || h[1] != 0x8B || h[2] != 8)
+            return false;
+        if ((h[3] & 4) && h[12] == 'B' && h[13] == 'C') // blocked gzip: has a reader of its own (seq_io.cpp, BgzfSource)
+            return false;
+        size_     = (uint64_t)st.st_size;
+        device_   = device;
+        piece_    = std::max<size_t>(piece_bytes, 1 << 16);
+        const char* sb = std::getenv("GANON_HOST_DEVICE_INFLATE_STEP");
+        const char* cb = std::getenv("GANON_HOST_DEVICE_INFLATE_CHUNK");
+        if (gn_inflate_create(device, size_, cb ? (uint32_t)std::atoll(cb) : 0, sb ? (uint64_t)std::atoll(sb) : 0, &z_) != GN_OK)
+        {
+            z_ = nullptr;
+            return false; // (no room for the file and the step buffers beside the filters: the host inflater takes it)
+        }
+        n_blocks_ = (size_ + kBlock - 1) / kBlock;
+        for (unsigned i = 0; i < kRing; ++i)
+        {
+            void* p = nullptr;
+            if (gn_pinned_alloc(kBlock, &p) != GN_OK)
+                return false;
+            blocks_.push_back(p);
+        }
+        const unsigned n_readers = (unsigned)std::min<uint64_t>(3, n_blocks_);
+        for (unsigned t = 0; t < n_readers; ++t)
+            readers_.emplace_back([this] { read_loop(); });
+        feeder_  = std::thread([this] { feed_loop(); });
+        stepper_ = std::thread([this] { step_loop(); });
+        return true;
+    }
+
+    bool next(DeviceTextPiece& out, std::string& err) override
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !q_.empty() || finished_ || stop_; });
+        if (q_.empty())
+        {
+            err = error_;
+            return false;
+        }
+        out = std::move(q_.front());
+        q_.pop_front();
+        delivered_ = out.at + out.bytes;
+        cv_.notify_all();
+        return true;
+    }
+    uint64_t    delivered() const override { return delivered_; }
+    bool        fasta() const override { return fasta_; }
+    std::string report() const override
+    {
+        gn_inflate_stats st;
+        std::memset(&st, 0, sizeof(st));
+        if (z_)
+            gn_inflate_get_stats(z_, &st);
+        std::ostringstream o;
+        o << "device inflate: " << st.steps << " steps, " << st.chunks << " chunks, " << st.fixups << " fix-ups, " << st.members << " members, "
+          << st.text_bytes << " bytes of text; device ms: decode " << st.ms_decode << ", order " << st.ms_chain << ", windows+resolve " << st.ms_resolve
+          << "; step calls " << st.ms_step_wall << " ms";
+        return o.str();
+    }
+
+private:
+    static constexpr size_t   kBlock = 8u << 20;
+    static constexpr unsigned kRing  = 8;
+
+    void read_loop()
+    {
+        for (;;)
+        {
+            uint64_t b;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                // block b uses ring slot b % kRing: free once block b - kRing is fed
+                cv_.wait(lk, [&] { return stop_ || next_read_ >= n_blocks_ || next_read_ < fed_blocks_ + kRing; });
+                if (stop_ || next_read_ >= n_blocks_)
+                    return;
+                b = next_read_++;
+            }
+            const uint64_t off = b * kBlock, n = std::min<uint64_t>(kBlock, size_ - off);
+            uint8_t*       dst = static_cast<uint8_t*>(blocks_[b % kRing]);
+            uint64_t       got = 0;
+            bool           ok  = true;
+            while (got < n)
+            {
+                const ssize_t r = pread(fd_, dst + got, n - got, (off_t)(off + got));
+                if (r <= 0)
+                {
+                    ok = false;
+                    break;
+                }
+                got += (uint64_t)r;
+            }
+            std::lock_guard<std::mutex> lk(m_);
+            if (!ok)
+                fail_locked("cannot read the file");
+            read_done_[b] = true;
+            cv_.notify_all();
+        }
+    }
+
+    void feed_loop()
+    {
+        for (uint64_t b = 0; b < n_blocks_; ++b)
+        {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || finished_ || read_done_.count(b); });
+                if (stop_ || finished_)
+                    return;
+                read_done_.erase(b);
+            }
+            const uint64_t off = b * kBlock, n = std::min<uint64_t>(kBlock, size_ - off);
+            const int      rc  = gn_inflate_feed(z_, static_cast<const uint8_t*>(blocks_[b % kRing]), n);
+            std::lock_guard<std::mutex> lk(m_);
+            if (rc != GN_OK)
+            {
+                fail_locked(gn_last_error());
+                return;
+            }
+            fed_blocks_ = b + 1;
+            fed_bytes_  = off + n;
+            cv_.notify_all();
+        }
+    }
+
+    void fail_locked(const std::string& why)
+    {
+        if (error_.empty())
+            error_ = why;
+        finished_ = true;
+        cv_.notify_all();
+    }
+
+    void step_loop()
+    {
+        const uint32_t        lpr = fasta_ ? 2u : 4u;
+        uint64_t              stream_at = 0; // decompressed offset of the next step's text[0] (the carried bytes included)
+        std::vector<uint64_t> cuts;
+        unsigned              step_no = 0;
+        const char*           sb   = std::getenv("GANON_HOST_DEVICE_INFLATE_STEP");
+        const uint64_t        step = sb ? (uint64_t)std::atoll(sb) : (256ull << 20);
+        uint64_t              want = 0; // compressed bytes the next step should find
+        for (;;)
+        {
+            want = std::min<uint64_t>(size_, want + step + (4ull << 20));
+            const int buf = (int)(step_no & 1u);
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || finished_ || (fed_bytes_ >= want && held_[buf] == 0); });
+                if (stop_ || finished_)
+                    return;
+            }
+            uint64_t n_text = 0;
+            int      done   = 0;
+            if (gn_inflate_step(z_, &n_text, &done) != GN_OK)
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                fail_locked(gn_last_error());
+                return;
+            }
+            const uint8_t* dtext = nullptr;
+            uint64_t       dn    = 0;
+            gn_inflate_text_device(z_, &dtext, &dn);
+            uint32_t n_cuts = 0;
+            cuts.resize((size_t)(n_text / piece_) + 2);
+            if (n_text && gn_inflate_cuts(z_, lpr, piece_, cuts.data(), (uint32_t)cuts.size(), &n_cuts) != GN_OK)
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                fail_locked(gn_last_error());
+                return;
+            }
+            cuts.resize(n_cuts);
+            uint64_t last = n_cuts ? cuts.back() : 0;
+            if (done && last < n_text) // the file's last bytes are no whole record: the tokeniser says so, the sequential reader takes them
+            {
+                cuts.push_back(n_text);
+                last = n_text;
+            }
+            const uint64_t tail = n_text - last;
+            if (!done && gn_inflate_set_carry(z_, tail) != GN_OK)
+            {
+                // (a "record" larger than a quarter of a step's buffer: not four-line FASTQ; the sequential reader says what it is)
+                std::lock_guard<std::mutex> lk(m_);
+                fail_locked(gn_last_error());
+                return;
+            }
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                uint64_t                     from = 0;
+                for (uint64_t c : cuts)
+                {
+                    DeviceTextPiece p;
+                    p.dev    = dtext + from;
+                    p.bytes  = c - from;
+                    p.at     = stream_at + from;
+                    p.device = device_;
+                    ++held_[buf];
+                    p.hold = std::shared_ptr<void>(nullptr, [this, buf](void*) {
+                        std::lock_guard<std::mutex> lk2(m_);
+                        --held_[buf];
+                        cv_.notify_all();
+                    });
+                    q_.push_back(std::move(p));
+                    from = c;
+                }
+                stream_at += last;
+                if (done)
+                    finished_ = true;
+                cv_.notify_all();
+                if (done)
+                    return;
+            }
+            ++step_no;
+        }
+    }
+
+    int                   fd_ = -1;
+    uint64_t              size_ = 0, n_blocks_ = 0;
+    int                   device_ = 0;
+    size_t                piece_ = 48u << 20;
+    bool                  fasta_ = false;
+    gn_inflate*           z_ = nullptr;
+    std::vector<void*>    blocks_;
+    std::vector<std::thread> readers_;
+    std::thread           feeder_, stepper_;
+    mutable std::mutex    m_;
+    std::condition_variable cv_;
+    bool                  stop_ = false, finished_ = false;
+    std::string           error_;
+    uint64_t              next_read_ = 0, fed_blocks_ = 0, fed_bytes_ = 0;
+    std::map<uint64_t, bool> read_done_;
+    std::deque<DeviceTextPiece> q_;
+    uint64_t              held_[2] = { 0, 0 };
+    std::atomic<uint64_t> delivered_{ 0 };
+};
+
+} // namespace
+
+std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, int device, size_t piece_bytes, size_t min_bytes)
+{
+    std::unique_ptr<DeviceGzip> g(new DeviceGzip());
+    if (!g->start(path, device, piece_bytes, min_bytes))
+        return nullptr;
+    return g;
+}
+
+} // namespace gnhost

@@ -206,6 +206,14 @@ int gn_stream_upload_text(gn_stream* s, const uint8_t* text, uint64_t n_bytes, i
  *   gn_stream_text_pair_index     waits; the pairs taken and the bytes of each text they cover (== n_bytes: all of it)
  *   gn_stream_fastq_keep / gn_stream_fastq_records (text1's records) apply; gn_stream_text_pair_records2 = the mates' in text2 */
 int gn_stream_upload_text_pair(gn_stream* s, const uint8_t* text1, uint64_t n_bytes1, const uint8_t* text2, uint64_t n_bytes2, int format);
+/* The same for a text that is in device memory already (of device src_device; the stream's own or a peer): the piece of a gzip file
+ * that gn_inflate_step left there (gn_inflate_text_device + the offsets of gn_inflate_cuts).  The caller does not hold the text, so
+ *   gn_stream_fastq_headers   (after gn_stream_fastq_index / _keep) copies the batch's header lines -- '@' or '>' to the newline, both
+ *                             included -- back to back to dst, record i's at hdr_off[i] (hdr_off has n_reads + 1 entries; *n_bytes =
+ *                             hdr_off[n_reads]; GN_EOVERFLOW with *n_bytes set when cap is too small): ids as in parse_reads
+ *                             (GanonClassify.cpp:1244,1262: the whole header line) without the text crossing the link */
+int gn_stream_upload_text_device(gn_stream* s, const uint8_t* d_text, uint64_t n_bytes, int format, int src_device);
+int gn_stream_fastq_headers(gn_stream* s, uint8_t* dst, uint64_t cap, uint32_t* hdr_off, uint64_t* n_bytes);
 int gn_stream_text_pair_index(gn_stream* s, uint32_t* n_reads, uint64_t* parsed_bytes1, uint64_t* parsed_bytes2);
 int gn_stream_text_pair_records2(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len);
 int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* n_bases, uint64_t* parsed_bytes);
@@ -416,6 +424,15 @@ int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done);
 int gn_inflate_text(gn_inflate* z, uint8_t* dst, uint64_t off, uint64_t n);
 int gn_inflate_text_device(gn_inflate* z, const uint8_t** text, uint64_t* n);
 int gn_inflate_get_stats(gn_inflate* z, gn_inflate_stats* out);
+/* Batches for the classifier straight from the device: where do records begin in the last step's text?
+ *   gn_inflate_cuts       cuts[0 .. *n_cuts): ascending offsets into the last step's text, each the first byte behind a newline whose
+ *                         number (from 1, counted from the text's first byte) is a multiple of lines_per_record (4: FASTQ, 2: two-line
+ *                         FASTA) -- the first such offset at or behind every multiple of piece_bytes, and the last one of the text.
+ *                         The text's first byte must begin a record (true for a file's first step; later: gn_inflate_set_carry).
+ *   gn_inflate_set_carry  the last n_tail bytes of the last step's text (the record the step's end cuts) are what the NEXT step's text
+ *                         begins with: its n_text counts them, its text holds them in front. */
+int gn_inflate_cuts(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_bytes, uint64_t* cuts, uint32_t cap, uint32_t* n_cuts);
+int gn_inflate_set_carry(gn_inflate* z, uint64_t n_tail);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,131 @@
+"""`reads.fq.gz` inflated on the device and classified from there (host/devgzip.cpp + csrc/gn_inflate.hip): every output file must
+be what the host inflater's run writes, byte for byte -- and what the oracle backend writes (same host code, CPU hot path, zlib).
+
+Reference behaviour: parse_reads reads gzip input through one zlib stream (GanonClassify.cpp:1220-1287); a parse error reports,
+keeps what was read and goes on with the next file (:1278-1283)."""
+import gzip
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import cli_util as cu
+from test_cli_kat import _sim_reads, oracle_bin, sim_db  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+EXTS = (".all", ".one", ".unc", ".rep", ".sta")
+
+
+def _records(n, seed=7, line_end="\n"):
+    """n single-end records: the fixture reads (true matches in sim_db) under fresh ids, mixed with random reads"""
+    r1, r2 = _sim_reads()
+    pool = [s for _, s in r1] + [s for _, s in r2]
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        if rng.random() < 0.6:
+            s = pool[int(rng.integers(0, len(pool)))]
+        else:
+            s = "".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(60, 151))))
+        q = "".join(chr(33 + int(x)) for x in rng.choice([2, 11, 25, 37], size=len(s), p=[0.05, 0.1, 0.25, 0.6]))
+        out.append(f"@read{i}:{int(rng.integers(1, 99999))} some description {i % 7}{line_end}{s}{line_end}+{line_end}{q}{line_end}")
+    return out
+
+
+def _run(binary, sim_db, reads, out_prefix, env=None, extra=()):
+    args = ["--ibf", sim_db["ibf"], "--tax", sim_db["tax"], "--single-reads", reads, "-o", out_prefix, "--output-all", "--output-lca",
+            "--output-unclassified", "--output-stats", "--quiet", "--rel-cutoff", "0.25", "--rel-filter", "0.1"] + list(extra)
+    e = dict(os.environ)
+    e.update(env or {})
+    import subprocess
+    p = subprocess.run([binary] + args, capture_output=True, text=True, timeout=600, env=e)
+    assert p.returncode == 0, p.stderr
+    return p
+
+
+DEV = {"GANON_HOST_DEVICE_INFLATE_MIN": "0", "GANON_HOST_TIMING": "1"}
+HOST = {"GANON_HOST_DEVICE_INFLATE": "0"}
+
+
+def _same_files(a, b, exts=EXTS):
+    for ext in exts:
+        x, y = open(a + ext, "rb").read(), open(b + ext, "rb").read()
+        if ext == ".sta":  # (the row holds run times)
+            x, y = x.split(b"\n")[0], y.split(b"\n")[0]
+        assert x == y, ext
+
+
+def _device_path_taken(p):
+    return "device inflate:" in p.stderr and "given up" not in p.stderr
+
+
+@pytest.mark.parametrize("level,env_extra", [(6, {}), (1, {}), (9, {"GANON_HOST_DEVICE_INFLATE_CHUNK": "4096", "GANON_HOST_DEVICE_INFLATE_STEP": "262144"}),
+                                             (6, {"GANON_HOST_SLAB_BYTES": "300000"})])
+def test_device_inflate_outputs_equal_host_inflate(sim_db, oracle_bin, tmp_path, level, env_extra):
+    text = "".join(_records(30000, seed=level)).encode()
+    fq = str(tmp_path / "reads.fq.gz")
+    with open(fq, "wb") as f:
+        co = zlib.compressobj(level, zlib.DEFLATED, 31)
+        f.write(co.compress(text) + co.flush())
+    a, b = str(tmp_path / "dev"), str(tmp_path / "host")
+    pa = _run(cu.BIN_HIP, sim_db, fq, a, dict(DEV, **env_extra))
+    _run(cu.BIN_HIP, sim_db, fq, b, HOST)
+    assert _device_path_taken(pa), pa.stderr
+    _same_files(a, b)
+    res = cu.Res(a)
+    assert res.total_classified > 1000 and res.total_classified + res.total_unclassified == 30000
+    if level == 6 and not env_extra:
+        c = str(tmp_path / "ora")
+        _run(oracle_bin, sim_db, fq, c)
+        _same_files(a, c, (".all", ".one", ".unc", ".rep"))
+
+
+def test_members_and_fasta(sim_db, tmp_path):
+    recs = _records(9000, seed=11)
+    fq = str(tmp_path / "reads.fastq.gz")
+    with open(fq, "wb") as f:  # three members, the cut inside a record
+        t = "".join(recs).encode()
+        for part in (t[:400_001], t[400_001:900_000], t[900_000:]):
+            f.write(gzip.compress(part, 6))
+    a, b = str(tmp_path / "dev"), str(tmp_path / "host")
+    pa = _run(cu.BIN_HIP, sim_db, fq, a, DEV)
+    _run(cu.BIN_HIP, sim_db, fq, b, HOST)
+    assert _device_path_taken(pa) and "3 members" in pa.stderr, pa.stderr
+    _same_files(a, b)
+    fa = str(tmp_path / "reads.fa.gz")
+    with open(fa, "wb") as f:
+        f.write(gzip.compress("".join(">" + r.split("\n")[0][1:] + "\n" + r.split("\n")[1] + "\n" for r in recs).encode(), 6))
+    a, b = str(tmp_path / "deva"), str(tmp_path / "hosta")
+    pa = _run(cu.BIN_HIP, sim_db, fa, a, DEV)
+    _run(cu.BIN_HIP, sim_db, fa, b, HOST)
+    assert _device_path_taken(pa), pa.stderr
+    _same_files(a, b)
+
+
+@pytest.mark.parametrize("case", ["no_final_newline", "wrapped_record", "crlf", "bad_letter", "truncated_gz"])
+def test_irregular_input_ends_like_the_host_path(sim_db, tmp_path, case):
+    recs = _records(6000, seed=23, line_end="\r\n" if case == "crlf" else "\n")
+    if case == "wrapped_record":
+        h, s, p, q = recs[3000].split("\n")[:4]
+        recs[3000] = f"{h}\n{s[:40]}\n{s[40:]}\n{p}\n{q[:40]}\n{q[40:]}\n"
+    if case == "bad_letter":
+        h, s, p, q = recs[4000].split("\n")[:4]
+        recs[4000] = f"{h}\n{s[:10]}!{s[11:]}\n{p}\n{q}\n"
+    text = "".join(recs).encode()
+    if case == "no_final_newline":
+        text = text[:-1]
+    gz = gzip.compress(text, 6)
+    if case == "truncated_gz":
+        gz = gz[:len(gz) * 2 // 3]
+    fq = str(tmp_path / "reads.fq.gz")
+    open(fq, "wb").write(gz)
+    a, b = str(tmp_path / "dev"), str(tmp_path / "host")
+    pa = _run(cu.BIN_HIP, sim_db, fq, a, DEV)
+    pb = _run(cu.BIN_HIP, sim_db, fq, b, HOST)
+    _same_files(a, b)
+    err = lambda p: [l for l in p.stderr.split("\n") if l.startswith("Error parsing")]  # noqa: E731
+    assert err(pa) == err(pb)
+    if case in ("bad_letter", "truncated_gz"):
+        assert err(pa)
