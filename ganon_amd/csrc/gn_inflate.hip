@@ -111,7 +111,7 @@ struct GiState
     uint64_t markers;
     // what gi_order_kernel found (the fields above it only reads: pos_bit, run_len)
     uint64_t res_pos, res_run_len, res_markers;
-    uint32_t res_members, pad;
+    uint32_t res_members, n_mlist; // member ends of the step, in stream order (gi_order_kernel's mlist_*)
     unsigned long long prof[8]; // sums of the chain chunks' GiChunk::prof
 };
 
@@ -122,6 +122,8 @@ struct GiLds
     uint16_t ring[GI_RING];
     uint32_t piece[GI_MAX_PIECES];
     uint16_t tok_len[64], tok_val[64]; // the batch's tokens (gi_codes)
+    uint32_t cand_q[128];              // the search: positions (relative to the chunk's nominal start) that passed the first screen
+    uint32_t cand_q2[144];             // ... and the second
     uint8_t  lens[320];
 };
 
@@ -504,6 +506,9 @@ __device__ bool gi_dynamic_header(GiLds& L, GiIn& in, GiBlockCtx& bc)
         return false;
     const uint32_t tot = hlit + hdist;
     uint32_t       i = 0, prev = 0;
+    // (the Kraft sum of the literal/length code, in units of 2^-15, is kept while the lengths are read: a position that is no block
+    //  start -- the search tries dozens per chunk -- over-subscribes the code after a few symbols and is dropped there)
+    uint32_t kraft = 0;
     __syncthreads();
     while (i < tot)
     {
@@ -515,8 +520,13 @@ __device__ bool gi_dynamic_header(GiLds& L, GiIn& in, GiBlockCtx& bc)
         const uint32_t s = e >> 16;
         if (s < 16u)
         {
+            if (i == hlit)
+                kraft = 0;
             L.lens[i++] = (uint8_t)s;
             prev        = s;
+            kraft += s ? 32768u >> s : 0u;
+            if (kraft > 32768u)
+                return false;
             continue;
         }
         uint32_t rep, val;
@@ -543,6 +553,27 @@ __device__ bool gi_dynamic_header(GiLds& L, GiIn& in, GiBlockCtx& bc)
             return false;
         for (uint32_t t = lane; t < rep; t += 64u)
             L.lens[i + t] = (uint8_t)val;
+        if (val)
+        {
+            // (a run may cross from the literal/length lengths into the distance lengths: each side counts its own)
+            const uint32_t in_lit = i < hlit ? (i + rep <= hlit ? rep : hlit - i) : 0u;
+            if (i < hlit)
+            {
+                kraft += in_lit * (32768u >> val);
+                if (kraft > 32768u)
+                    return false;
+            }
+            if (i + rep > hlit)
+            {
+                if (i <= hlit)
+                    kraft = 0;
+                kraft += (rep - in_lit) * (32768u >> val);
+                if (kraft > 32768u)
+                    return false;
+            }
+        }
+        else if (i <= hlit && i + rep > hlit)
+            kraft = 0;
         i += rep;
     }
     __syncthreads();
@@ -669,30 +700,49 @@ __device__ int gi_codes(GiLds& L, GiIn& in, GiOut& o, const GiBlockCtx& bc, uint
                     kind = 3u;
             }
             const uint32_t pk = bits | (kind << 6) | (tlen << 8);
-            // the chain from position 0
+            // the chain from position 0: one v_readlane per token.  The plain walk takes every token up to an end-of-block code or a
+            // position that holds no code; only if the batch cannot take them all (64 tokens, 512 symbols) is it walked again with the caps.
             uint64_t M = 0;
-            uint32_t at = 0, cnt = 0;
-            while (at < 64u)
+            uint32_t at = 0, cnt = 0, info = 0, cumr = 0;
+            do
             {
-                const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)at);
-                const uint32_t k = (info >> 6) & 3u, b = info & 63u, tl1 = info >> 8;
-                if (k >= 2u)
-                {
-                    end = k == 2u ? 0 : 1;
-                    if (k == 2u)
-                        at += b;
+                info = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)at);
+                if (info & 0x80u) // kind 2 or 3
                     break;
-                }
-                if (nt + cnt >= 64u || cum + tl1 > 512u)
-                {
-                    full = true;
-                    break;
-                }
                 M |= 1ull << at;
-                cum += tl1;
-                ++cnt;
-                at += b;
+                cumr += info >> 8;
+                at += info & 63u;
+            } while (at < 64u);
+            cnt = (uint32_t)__popcll(M);
+            if (nt + cnt > 64u || cum + cumr > 512u)
+            {
+                M    = 0;
+                at   = 0;
+                cnt  = 0;
+                cumr = 0;
+                info = 0;
+                while (at < 64u)
+                {
+                    info = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)at);
+                    if ((info & 0x80u) || nt + cnt >= 64u || cum + cumr + (info >> 8) > 512u)
+                        break;
+                    M |= 1ull << at;
+                    cumr += info >> 8;
+                    ++cnt;
+                    at += info & 63u;
+                }
+                if (!(at < 64u && (info & 0x80u)))
+                    full = true;
+                if (at >= 64u)
+                    info = 0;
             }
+            if (at < 64u && (info & 0x80u))
+            {
+                end = (info & 0x40u) ? 1 : 0; // kind 3: no such code; kind 2: the end-of-block code, whose bits are consumed
+                if (end == 0)
+                    at += info & 63u;
+            }
+            cum += cumr;
             pos += at;
             if ((M >> lane) & 1ull)
             {
@@ -842,13 +892,15 @@ __device__ uint64_t gi_gzip_header(const uint32_t* comp, uint64_t size, uint64_t
     return q < size ? q : 0;
 }
 
-// candidate screen of the search: is there, in the 128 bits d0..d3 from bit `sh` (< 32) on, BFINAL = 0, BTYPE = 2, HLIT/HDIST in range and
-// a complete code-length code?  (per lane)
-__device__ __forceinline__ bool gi_screen(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t sh)
+// The search's screens (per lane).  First: BFINAL = 0, BTYPE = 2, HLIT / HDIST in range -- 17 bits, passed by one position in nine.
+__device__ __forceinline__ bool gi_screen_bits(uint32_t x0)
+{
+    return (x0 & 7u) == 4u && ((x0 >> 3) & 31u) <= 29u && ((x0 >> 8) & 31u) <= 29u;
+}
+// Second, for the positions that passed, 64 of them at a time: is the code-length code complete?  (96 bits d0..d2 from bit sh < 32 on)
+__device__ __forceinline__ bool gi_screen_kraft(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t sh)
 {
     const uint32_t x0 = __funnelshift_r(d0, d1, sh), x1 = __funnelshift_r(d1, d2, sh), x2 = __funnelshift_r(d2, d3, sh);
-    if ((x0 & 7u) != 4u || ((x0 >> 3) & 31u) > 29u || ((x0 >> 8) & 31u) > 29u)
-        return false;
     const uint32_t hclen = ((x0 >> 13) & 15u) + 4u;
     uint64_t       p     = (uint64_t)__funnelshift_r(x0, x1, 17) | ((uint64_t)__funnelshift_r(x1, x2, 17) << 32);
     p &= (1ull << (3u * hclen)) - 1ull;
@@ -859,6 +911,159 @@ __device__ __forceinline__ bool gi_screen(uint32_t d0, uint32_t d1, uint32_t d2,
     for (int i = 0; i < 19; ++i)
         sum += (uint32_t)(weigh >> (8u * ((uint32_t)(p >> (3 * i)) & 7u))) & 0xFFu;
     return sum == 128u;
+}
+
+
+// Third screen, per lane as well: the whole dynamic block header at `bit` (BFINAL/BTYPE included), without tables -- the code-length code is
+// decoded canonically from counts held in registers.  true = the code lengths decode, the literal/length code is complete and has an
+// end-of-block code, the distance code is complete, a single code, or absent.  (Stricter than the decoder where zlib is lenient; what the
+// search misses the chunk before simply decodes.)  A chunk's search tries some sixty positions that pass the first two screens; this
+// drops all but the real block start for the price of one header, 64 positions at a time.
+__device__ __noinline__ bool gi_screen_header(const uint32_t* __restrict__ comp, uint64_t n_dw, uint64_t bit)
+{
+    uint64_t di = bit >> 5;
+    auto     ld = [&](uint64_t i) -> uint64_t { return i < n_dw ? comp[i] : 0u; };
+    uint64_t buf = (ld(di) | (ld(di + 1) << 32)) >> (bit & 31u);
+    uint32_t cnt = 64u - (uint32_t)(bit & 31u);
+    di += 2;
+    auto need = [&](uint32_t n) { // n <= 32
+        if (cnt < n)
+        {
+            buf |= ld(di) << cnt;
+            cnt += 32u;
+            ++di;
+        }
+    };
+    auto get = [&](uint32_t n) -> uint32_t {
+        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
+        buf >>= n;
+        cnt -= n;
+        return v;
+    };
+    need(17);
+    get(3);
+    const uint32_t hlit = get(5) + 257u, hdist = get(5) + 1u, hclen = get(4) + 4u;
+    // the code-length code's lengths, 3 bits per symbol, and how many symbols have each length (a byte per length)
+    uint64_t clp = 0, cpk = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 19u; ++i)
+        if (i < hclen)
+        {
+            need(3);
+            const uint64_t l = get(3);
+            clp |= l << (3u * kClOrder[i]);
+            cpk += 1ull << (8u * l);
+        }
+    // canonical code: first code and first position in the sorted symbol list, per length
+    uint32_t first[8], offs[8], num[8];
+    {
+        uint32_t code = 0, off = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 7u; ++l)
+        {
+            const uint32_t c = (uint32_t)(cpk >> (8u * l)) & 0xFFu;
+            first[l] = code;
+            offs[l]  = off;
+            num[l]   = c;
+            code     = (code + c) << 1;
+            off += c;
+        }
+    }
+    // symbols sorted by (length, symbol), 5 bits each
+    uint64_t s_lo = 0, s_hi = 0; // entries 0..11, 12..18
+    {
+        uint32_t at = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 7u; ++l)
+#pragma unroll
+            for (uint32_t sy = 0; sy < 19u; ++sy)
+                if (((uint32_t)(clp >> (3u * sy)) & 7u) == l)
+                {
+                    if (at < 12u)
+                        s_lo |= (uint64_t)sy << (5u * at);
+                    else
+                        s_hi |= (uint64_t)sy << (5u * (at - 12u));
+                    ++at;
+                }
+    }
+    const uint32_t tot = hlit + hdist;
+    uint32_t       i = 0, prev = 0, kraft = 0, used = 0;
+    bool           eob = false;
+    while (i < tot)
+    {
+        need(14); // a code of up to 7 bits and up to 7 extra bits
+        uint32_t code = 0, sym = 32u, len = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 7u; ++l)
+        {
+            code = (code << 1) | ((uint32_t)(buf >> (l - 1u)) & 1u);
+            const uint32_t idx = code - first[l];
+            if (sym == 32u && idx < num[l])
+            {
+                const uint32_t at = offs[l] + idx;
+                sym = at < 12u ? (uint32_t)(s_lo >> (5u * at)) & 31u : (uint32_t)(s_hi >> (5u * (at - 12u))) & 31u;
+                len = l;
+            }
+        }
+        if (sym == 32u)
+            return false;
+        get(len);
+        uint32_t rep = 1, val = sym;
+        if (sym == 16u)
+        {
+            if (i == 0u)
+                return false;
+            rep = 3u + get(2);
+            val = prev;
+        }
+        else if (sym == 17u)
+        {
+            rep = 3u + get(3);
+            val = 0;
+        }
+        else if (sym == 18u)
+        {
+            rep = 11u + get(7);
+            val = 0;
+        }
+        if (i + rep > tot)
+            return false;
+        prev = val;
+        if (i < hlit && i + rep > hlit) // a run across the two codes' lengths: the literal/length side first
+        {
+            const uint32_t a = hlit - i;
+            if (val)
+            {
+                kraft += a * (32768u >> val);
+                eob = eob || (i <= 256u);
+            }
+            if (kraft != 32768u || !eob)
+                return false;
+            kraft = 0;
+            used  = 0;
+            i += a;
+            rep -= a;
+        }
+        else if (i == hlit)
+        {
+            if (kraft != 32768u || !eob)
+                return false;
+            kraft = 0;
+            used  = 0;
+        }
+        if (val)
+        {
+            kraft += rep * (32768u >> val);
+            used += rep;
+            if (i < hlit && i <= 256u && i + rep > 256u)
+                eob = true;
+            if (kraft > 32768u)
+                return false;
+        }
+        i += rep;
+    }
+    // (hdist >= 1: the loop passed i == hlit or crossed it, so the literal/length code has been judged; here: the distance code)
+    return kraft == 32768u || used <= 1u;
 }
 
 } // namespace
@@ -898,13 +1103,15 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
         o.pool_cap  = p.pool_cap;
         o.have0     = false;
         o.tA = o.tB = o.tF = 0;
-        uint32_t       t_screen = 0, t_cand = 0, t_hdr = 0;
+        uint32_t       t_screen = 0, t_cand = 0, t_hdr = 0, n_cand = 0;
         const uint64_t t_chunk  = wall_clock64();
         GiBlockCtx bc;
         bc.have_dist = false;
 
         uint64_t start      = GI_NONE;
         uint64_t search_at  = fix ? GI_NONE : nominal; // next position the search looks at (GI_NONE: no search)
+        uint64_t sw_base = ~0ull, sq_m = 0; // search: base dword of the register window; candidates of the running batch that passed both screens
+        uint32_t sw = 0, sq_n = 0, sq2_n = 0, sq_pos = 0; // ... the window; positions queued behind the first / second screen; the running batch's (per lane)
         bool     at_header  = false;
         uint32_t flags      = 0;
         if (!fix && j == 0)
@@ -925,37 +1132,82 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
             bool probation = false; // the first block runs in strict mode and a failure resumes the search
             if (search_at != GI_NONE)
             {
+                // Two screens: 64 positions a round take the cheap one, the survivors queue up in LDS; when 64 are queued (or the range
+                // is through) they take the second screen together, and what is left is tried in position order.
                 start = GI_NONE;
                 const uint64_t t_s = wall_clock64();
-                // the file's dwords around the search position live in one register (lane l: dword sw_base + l); the six dwords the 64
-                // positions of a round need are taken from it as scalars, every lane picks its four
-                uint64_t sw_base = ~0ull;
-                uint32_t sw      = 0;
-                while (search_at < stop && start == GI_NONE)
+                for (;;)
                 {
+                    if (sq_m)
+                    {
+                        const int t = __builtin_ctzll(sq_m);
+                        sq_m &= sq_m - 1ull;
+                        start = nominal + (uint32_t)__builtin_amdgcn_readlane((int)sq_pos, t);
+                        break;
+                    }
+                    if (sq2_n >= 16u || (search_at >= stop && sq_n == 0u && sq2_n))
+                    {
+                        // third screen: the whole header, for up to 64 positions that passed the second (sixteen wait for one another: a
+                        // wave pays for the longest header among its lanes whatever their number)
+                        const uint32_t take = sq2_n < 64u ? sq2_n : 64u;
+                        __syncthreads();
+                        sq_pos = lane < take ? L.cand_q2[lane] : 0u;
+                        const uint32_t keep = lane + 64u < sq2_n ? L.cand_q2[lane + 64u] : 0u;
+                        __syncthreads();
+                        if (lane + 64u < sq2_n)
+                            L.cand_q2[lane] = keep;
+                        sq2_n -= take;
+                        const bool ok = lane < take && gi_screen_header(p.comp, n_dw, nominal + sq_pos);
+                        sq_m          = __ballot(ok);
+                        __syncthreads();
+                        continue;
+                    }
+                    if (sq_n >= 64u || (search_at >= stop && sq_n))
+                    {
+                        const uint32_t take = sq_n < 64u ? sq_n : 64u;
+                        __syncthreads();
+                        const uint32_t mypos = lane < take ? L.cand_q[lane] : 0u;
+                        const uint32_t keep  = lane + 64u < sq_n ? L.cand_q[lane + 64u] : 0u;
+                        __syncthreads();
+                        if (lane + 64u < sq_n)
+                            L.cand_q[lane] = keep;
+                        sq_n -= take;
+                        const uint64_t bit = nominal + mypos;
+                        const uint64_t di  = bit >> 5;
+                        bool           ok  = false;
+                        if (lane < take)
+                        {
+                            const uint32_t d0 = di < n_dw ? p.comp[di] : 0u, d1 = di + 1 < n_dw ? p.comp[di + 1] : 0u, d2 = di + 2 < n_dw ? p.comp[di + 2] : 0u,
+                                           d3 = di + 3 < n_dw ? p.comp[di + 3] : 0u;
+                            ok = gi_screen_kraft(d0, d1, d2, d3, (uint32_t)(bit & 31u));
+                        }
+                        const uint64_t m2 = __ballot(ok);
+                        if (ok)
+                            L.cand_q2[sq2_n + (uint32_t)__popcll(m2 & ((1ull << lane) - 1ull))] = mypos;
+                        sq2_n += (uint32_t)__popcll(m2);
+                        __syncthreads();
+                        continue;
+                    }
+                    if (search_at >= stop)
+                        break;
                     const uint64_t d = search_at >> 5;
-                    if (sw_base == ~0ull || d < sw_base || d + 6u > sw_base + 64u)
+                    if (sw_base == ~0ull || d < sw_base || d + 3u > sw_base + 64u)
                     {
                         sw_base = d;
                         sw      = sw_base + lane < n_dw ? p.comp[sw_base + lane] : 0u;
                     }
                     const int      i0 = (int)(d - sw_base);
                     const uint32_t u0 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0), u1 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 1),
-                                   u2 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 2), u3 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 3),
-                                   u4 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 4), u5 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 5);
+                                   u2 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 2), u3 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 3);
                     const uint32_t sh = (uint32_t)(search_at & 31u) + lane, q = sh >> 5;
-                    const uint32_t d0 = q == 0u ? u0 : q == 1u ? u1 : u2, d1 = q == 0u ? u1 : q == 1u ? u2 : u3, d2 = q == 0u ? u2 : q == 1u ? u3 : u4,
-                                   d3 = q == 0u ? u3 : q == 1u ? u4 : u5;
+                    const uint32_t d0 = q == 0u ? u0 : q == 1u ? u1 : u2, d1 = q == 0u ? u1 : q == 1u ? u2 : u3;
                     const uint64_t bit = search_at + lane;
-                    const bool     ok  = bit < stop && bit + 64u <= p.avail_bits && gi_screen(d0, d1, d2, d3, sh & 31u);
+                    const bool     ok  = bit < stop && bit + 96u <= p.avail_bits && gi_screen_bits(__funnelshift_r(d0, d1, sh & 31u));
                     const uint64_t m   = __ballot(ok);
-                    if (m)
-                    {
-                        start     = search_at + (uint64_t)__builtin_ctzll(m);
-                        search_at = start + 1u;
-                    }
-                    else
-                        search_at += 64u;
+                    if (ok)
+                        L.cand_q[sq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(bit - nominal);
+                    sq_n += (uint32_t)__popcll(m);
+                    search_at += 64u;
                 }
                 t_screen += (uint32_t)(wall_clock64() - t_s);
                 if (start == GI_NONE)
@@ -1043,7 +1295,10 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                     const uint64_t t_h = wall_clock64();
                     const bool hdr = gi_ub(btype == 2u ? gi_dynamic_header(L, in, bc) : gi_fixed_header(L, bc));
                     if (probation && first_block)
+                    {
                         t_cand += (uint32_t)(wall_clock64() - t_h);
+                        ++n_cand;
+                    }
                     else
                         t_hdr += (uint32_t)(wall_clock64() - t_h);
                     if (!hdr)
@@ -1161,6 +1416,7 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
             C.prof[4] = o.tB;
             C.prof[5] = o.tF;
             C.prof[6] = (uint32_t)(wall_clock64() - t_chunk);
+            C.prof[7] = n_cand * 100000u; // (shown as a count by the /1e5 of the millisecond conversion)
         }
         __syncthreads();
         if (fix)
@@ -1176,7 +1432,8 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
 #define GI_ORDER_MAX 8256u // regular slots of a step (<= 8192) + fix-up slots (<= 64); 16 bytes of LDS each
 __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChunk* chunks, uint32_t n_slots, uint32_t slots_cap, uint32_t n_fix, uint32_t j0,
                                                         uint32_t chunk_bytes, uint64_t range_end_bits, uint64_t total_bits, GiReal* real, uint2* work,
-                                                        uint32_t real_cap, uint32_t work_cap, uint64_t text_cap)
+                                                        uint32_t real_cap, uint32_t work_cap, uint64_t text_cap, unsigned long long* mlist_pos,
+                                                        uint32_t* mlist_crc, uint32_t mlist_cap)
 {
     extern __shared__ uint64_t gi_order_lds[];
     const uint32_t             n_all   = n_slots + n_fix;
@@ -1197,7 +1454,7 @@ __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChu
     {
         const uint64_t cbits = (uint64_t)chunk_bytes * 8u;
         uint64_t       pos = st->pos_bit, text = 0, run_len = st->run_len, gap_stop = 0;
-        uint32_t       r = 0, w = 0, reason = GI_R_RANGE, cursor = n_slots, members = 0;
+        uint32_t       r = 0, w = 0, reason = GI_R_RANGE, cursor = n_slots, members = 0, n_ml = 0;
         for (;;)
         {
             uint32_t idx = ~0u;
@@ -1263,6 +1520,12 @@ __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChu
                     run_len += c.mend_sym[e] - at;
                     if ((uint32_t)run_len != c.mend_isize[e])
                         bad_member = true;
+                    if (n_ml < mlist_cap)
+                    {
+                        mlist_pos[n_ml] = text + c.mend_sym[e];
+                        mlist_crc[n_ml] = c.mend_crc[e];
+                    }
+                    ++n_ml;
                     run_len = 0;
                     at      = c.mend_sym[e];
                 }
@@ -1298,6 +1561,9 @@ __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChu
         st->res_pos     = pos;
         st->res_run_len = run_len;
         st->res_members = members;
+        st->n_mlist     = n_ml;
+        if (n_ml > mlist_cap && reason != GI_R_DATA && reason != GI_R_MEMBER)
+            st->reason = GI_R_OVERFLOW;
         s_R             = r;
     }
     __syncthreads();
@@ -1310,7 +1576,7 @@ __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChu
             work[rr.wbase + q] = make_uint2(r, q);
         const GiChunk& c = chunks[rr.slot];
         mk += c.markers;
-        for (int k = 0; k < 7; ++k)
+        for (int k = 0; k < 8; ++k)
             atomicAdd(&st->prof[k], (unsigned long long)c.prof[k]);
     }
     if (mk)
@@ -1538,6 +1804,105 @@ __global__ void gi_cuts_kernel(const uint8_t* __restrict__ text, uint64_t n, con
     cuts[j] = q + 1u;
 }
 
+
+// ---- CRC-32 of the members (RFC 1952: the trailer's first field) ------------------------------------------------------------------------
+// The text of a step is cut on a 4 KiB grid and at the member ends; a thread takes a piece, computes its CRC-32 (byte-wise, table in LDS)
+// and moves it to where its member ends: crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] mod the CRC polynomial (what zlib's
+// crc32_combine computes; restated from its definition, checked against zlib in tests/test_gpu_inflate.py), so the pieces' values,
+// each multiplied by x^(8 * bytes between its end and the member's end), XOR into the member's CRC in any order.  A member that began in
+// an earlier step arrives as the CRC of what it had so far; one that goes on leaves the same behind.
+__device__ const uint32_t kX2n[32] = { 0x40000000u, 0x20000000u, 0x08000000u, 0x00800000u, 0x00008000u, 0xedb88320u, 0xb1e6b092u, 0xa06a2517u, 0xed627daeu, 0x88d14467u, 0xd7bbfe6au, 0xec447f11u, 0x8e7ea170u, 0x6427800eu, 0x4d47bae0u, 0x09fe548fu, 0x83852d0fu, 0x30362f1au, 0x7b5a9cc3u, 0x31fec169u, 0x9fec022au, 0x6c8dedc4u, 0x15d6874du, 0x5fde7a4eu, 0xbad90e37u, 0x2e4e5eefu, 0x4eaba214u, 0xa8a472c0u, 0x429a969eu, 0x148d302au, 0xc40ba6d0u, 0xc4e22c3cu }; // x^(2^k) mod p, reflected
+
+__device__ __forceinline__ uint32_t gi_multmodp(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;)
+    {
+        if (a & m)
+        {
+            p ^= b;
+            if ((a & (m - 1u)) == 0u)
+                break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+    }
+    return p;
+}
+
+// x^(n * 2^k) mod p
+__device__ __forceinline__ uint32_t gi_x2nmodp(uint64_t n, uint32_t k)
+{
+    uint32_t p = 1u << 31;
+    while (n)
+    {
+        if (n & 1u)
+            p = gi_multmodp(kX2n[k & 31u], p);
+        n >>= 1;
+        ++k;
+    }
+    return p;
+}
+
+#define GI_CRC_PIECE 4096u
+__global__ __launch_bounds__(256) void gi_crc_kernel(const uint8_t* __restrict__ text, uint64_t n, const unsigned long long* __restrict__ mend_pos,
+                                                     uint32_t n_mend, uint32_t carry_crc, uint32_t* __restrict__ acc)
+{
+    __shared__ uint32_t tab[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k)
+            c = (c & 1u) ? (c >> 1) ^ 0xedb88320u : c >> 1;
+        tab[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint64_t b  = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t lo = b * GI_CRC_PIECE;
+    if (b == 0 && carry_crc) // the member that was open when the step began
+        atomicXor(&acc[0], gi_multmodp(gi_x2nmodp(n_mend ? mend_pos[0] : n, 3), carry_crc));
+    if (lo >= n)
+        return;
+    const uint64_t hi = min(n, lo + GI_CRC_PIECE);
+    // member of byte lo: the number of member ends at or before it
+    uint32_t m = 0;
+    {
+        uint32_t a = 0, z = n_mend;
+        while (a < z)
+        {
+            const uint32_t mid = a + (z - a) / 2u;
+            if (mend_pos[mid] <= lo)
+                a = mid + 1u;
+            else
+                z = mid;
+        }
+        m = a;
+    }
+    uint64_t cur = lo;
+    while (cur < hi)
+    {
+        const uint64_t mend = m < n_mend ? mend_pos[m] : n;
+        const uint64_t end  = min(hi, mend);
+        uint32_t       c    = 0xFFFFFFFFu;
+        for (uint64_t q = cur; q < end; ++q)
+            c = tab[(c ^ text[q]) & 0xFFu] ^ (c >> 8);
+        c = ~c;
+        if (end > cur)
+            atomicXor(&acc[m], gi_multmodp(gi_x2nmodp(mend - end, 3), c));
+        cur = end;
+        if (m < n_mend && cur == mend)
+            ++m;
+    }
+}
+
+__global__ void gi_crc_check_kernel(const uint32_t* __restrict__ acc, const uint32_t* __restrict__ want, uint32_t n_mend, uint32_t* __restrict__ result /* [0] bad [1] carry */)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_mend && acc[i] != want[i])
+        atomicOr(&result[0], 1u);
+    if (i == 0)
+        result[1] = acc[n_mend];
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
 struct gn_inflate
 {
@@ -1554,7 +1919,22 @@ struct gn_inflate
     uint8_t*    d_comp = nullptr;
     // per step
     uint32_t  slots_cap = 0, fix_cap = 64;
-    GiChunk*  d_chunks = nullptr;
+    // Two sets of what a step's decode writes (chunk records, symbol pool, counters): the NEXT step's decode is launched on a stream
+    // of its own as soon as its range is known, and runs beside this step's tail, order, window and resolve passes.
+    GiChunk*  d_chunks_set[2] = { nullptr, nullptr };
+    uint16_t* d_pool_set[2]   = { nullptr, nullptr };
+    uint32_t* d_ctr_set[2]    = { nullptr, nullptr };
+    hipStream_t st_dec[2] = { nullptr, nullptr }; // (one per set: two decodes run side by side, the later one fills what the tail of the earlier leaves idle)
+    hipEvent_t  ev_dec[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
+    int       next_set = 0;
+    struct Pend // a decode in flight (or done): q[0] is what the next gn_inflate_step finishes, q[1] what the one after it does --
+    {           // launched on the assumption that q[0]'s step ends where its range does (almost always; otherwise it is dropped)
+        bool     valid = false;
+        uint32_t j0 = 0, j1 = 0;
+        uint64_t fed = 0;
+        int      set = 0;
+    } q[2];
+    GiChunk*  d_chunks = nullptr; // (the set of the step being finished)
     uint16_t* d_pool   = nullptr;
     uint32_t  pool_cap = 0;
     uint32_t* d_ctr    = nullptr; // [0] pool_next [1] work_next
@@ -1572,6 +1952,11 @@ struct gn_inflate
     int       cur = 1; // buffer of the last step
     uint64_t  n_text_last = 0;
     uint64_t  carry = 0; // bytes at the end of the last step's text that the next step's text begins with (gn_inflate_set_carry)
+    unsigned long long* d_mlist_pos = nullptr;
+    uint32_t* d_mlist_crc = nullptr; // [mlist_cap] wanted, then [mlist_cap + 1] accumulated, then [2] result
+    uint32_t  mlist_cap = 65536;
+    uint32_t  crc_carry = 0; // CRC-32 of the open member's bytes so far
+    uint32_t* h_crc = nullptr;
     uint32_t* d_cut_cnt = nullptr; // newline counts per tile, then their exclusive sums
     void*     d_cut_tmp = nullptr;
     size_t    cut_tmp_bytes = 0;
@@ -1588,18 +1973,25 @@ static void gi_free(gn_inflate* z)
     if (!z)
         return;
     hipSetDevice(z->device);
-    for (void* p : { (void*)z->d_comp, (void*)z->d_chunks, (void*)z->d_pool, (void*)z->d_ctr, (void*)z->d_state, (void*)z->d_window, (void*)z->d_p_store, (void*)z->d_g_store, (void*)z->d_w_store,
-                     (void*)z->d_real, (void*)z->d_work, (void*)z->d_cut_cnt, z->d_cut_tmp, (void*)z->d_cuts, (void*)z->d_text[0], (void*)z->d_text[1] })
+    hipDeviceSynchronize();
+    for (void* p : { (void*)z->d_comp, (void*)z->d_chunks_set[0], (void*)z->d_pool_set[0], (void*)z->d_ctr_set[0], (void*)z->d_chunks_set[1], (void*)z->d_pool_set[1], (void*)z->d_ctr_set[1], (void*)z->d_state, (void*)z->d_window, (void*)z->d_p_store, (void*)z->d_g_store, (void*)z->d_w_store,
+                     (void*)z->d_real, (void*)z->d_work, (void*)z->d_mlist_pos, (void*)z->d_mlist_crc, (void*)z->d_cut_cnt, z->d_cut_tmp, (void*)z->d_cuts, (void*)z->d_text[0], (void*)z->d_text[1] })
         if (p)
             hipFree(p);
     if (z->h_state)
         hipHostFree(z->h_state);
-    for (hipStream_t s : { z->st, z->st_copy, z->st_out })
+    if (z->h_crc)
+        hipHostFree(z->h_crc);
+    for (hipStream_t s : { z->st, z->st_copy, z->st_out, z->st_dec[0], z->st_dec[1] })
         if (s)
             hipStreamDestroy(s);
     for (hipEvent_t e : z->ev)
         if (e)
             hipEventDestroy(e);
+    for (auto& pair : z->ev_dec)
+        for (hipEvent_t e : pair)
+            if (e)
+                hipEventDestroy(e);
     delete z;
 }
 
@@ -1648,9 +2040,18 @@ extern "C" int gn_inflate_create(int device, uint64_t compressed_bytes, uint32_t
     const uint64_t comp_alloc = ((compressed_bytes + 3) & ~3ull) + 1024;
     GI_TRY(hipMalloc((void**)&z->d_comp, comp_alloc), "compressed bytes");
     GI_TRY(hipMemsetAsync(z->d_comp + (compressed_bytes & ~3ull), 0, comp_alloc - (compressed_bytes & ~3ull), z->st), "memset");
-    GI_TRY(hipMalloc((void**)&z->d_chunks, (size_t)(z->slots_cap + z->fix_cap) * sizeof(GiChunk)), "chunk records");
-    GI_TRY(hipMalloc((void**)&z->d_pool, (size_t)z->pool_cap * GI_PIECE * 2u), "symbol pool");
-    GI_TRY(hipMalloc((void**)&z->d_ctr, 64), "counters");
+    for (int k = 0; k < 2; ++k)
+    {
+        // (a file of one step needs one set)
+        if (k == 1 && (uint64_t)z->n_chunks_file * z->chunk_bytes <= step)
+            break;
+        GI_TRY(hipMalloc((void**)&z->d_chunks_set[k], (size_t)(z->slots_cap + z->fix_cap) * sizeof(GiChunk)), "chunk records");
+        GI_TRY(hipMalloc((void**)&z->d_pool_set[k], (size_t)z->pool_cap * GI_PIECE * 2u), "symbol pool");
+        GI_TRY(hipMalloc((void**)&z->d_ctr_set[k], 64), "counters");
+        GI_TRY(hipStreamCreateWithFlags(&z->st_dec[k], hipStreamNonBlocking), "stream");
+        for (auto& e2 : z->ev_dec[k])
+            GI_TRY(hipEventCreate(&e2), "event");
+    }
     GI_TRY(hipMalloc((void**)&z->d_state, sizeof(GiState)), "state");
     GI_TRY(hipHostMalloc((void**)&z->h_state, sizeof(GiState), hipHostMallocDefault), "state (host)");
     GI_TRY(hipMalloc((void**)&z->d_window, GI_WINDOW), "window");
@@ -1663,6 +2064,9 @@ extern "C" int gn_inflate_create(int device, uint64_t compressed_bytes, uint32_t
     }
     GI_TRY(hipMalloc((void**)&z->d_real, (size_t)(z->slots_cap + z->fix_cap) * sizeof(GiReal)), "chain");
     GI_TRY(hipMalloc((void**)&z->d_work, (size_t)z->work_cap * sizeof(uint2)), "work list");
+    GI_TRY(hipMalloc((void**)&z->d_mlist_pos, (size_t)z->mlist_cap * sizeof(unsigned long long)), "member list");
+    GI_TRY(hipMalloc((void**)&z->d_mlist_crc, ((size_t)z->mlist_cap * 2u + 8u) * sizeof(uint32_t)), "member list");
+    GI_TRY(hipHostMalloc((void**)&z->h_crc, 2 * sizeof(uint32_t), hipHostMallocDefault), "crc result");
     for (int b = 0; b < 2; ++b)
         GI_TRY(hipMalloc((void**)&z->d_text[b], z->text_cap + 64), "text");
     std::memset(z->h_state, 0, sizeof(GiState));
@@ -1695,27 +2099,73 @@ extern "C" int gn_inflate_feed(gn_inflate* z, const uint8_t* data, uint64_t n)
     return GN_OK;
 }
 
-static int gi_launch_chunks(gn_inflate* z, uint32_t j0, uint32_t n, uint64_t fix_start, uint64_t fix_stop, uint32_t fix_slot)
+static int gi_launch_chunks(gn_inflate* z, int set, hipStream_t st, uint64_t fed, uint32_t j0, uint32_t n, uint64_t fix_start, uint64_t fix_stop, uint32_t fix_slot)
 {
     GiParams p;
     p.comp        = reinterpret_cast<const uint32_t*>(z->d_comp);
-    p.avail_bits  = z->fed_step * 8u;
+    p.avail_bits  = fed * 8u;
     p.total_bits  = z->total * 8u;
     p.chunk_bytes = z->chunk_bytes;
     p.j0          = j0;
     p.n           = n;
-    p.chunks      = z->d_chunks;
-    p.pool        = z->d_pool;
-    p.pool_next   = z->d_ctr;
+    p.chunks      = z->d_chunks_set[set];
+    p.pool        = z->d_pool_set[set];
+    p.pool_next   = z->d_ctr_set[set];
     p.pool_cap    = z->pool_cap;
-    p.work_next   = z->d_ctr + 1;
+    p.work_next   = z->d_ctr_set[set] + 1;
     p.fix_start   = fix_start;
     p.fix_stop    = fix_stop;
     p.fix_slot    = fix_slot;
     p.strict      = 1;
     const uint32_t grid = fix_start != GI_NONE ? 1u : std::min<uint32_t>(n, (uint32_t)z->n_cu * 16u);
-    hipLaunchKernelGGL(gi_chunk_kernel, dim3(grid), dim3(64), 0, z->st, p);
+    hipLaunchKernelGGL(gi_chunk_kernel, dim3(grid), dim3(64), 0, st, p);
     GN_HIP(hipGetLastError());
+    return GN_OK;
+}
+
+// Plans a step's chunk range, from chunk `from` on, out of what is fed, and launches its decode on the stream of set `set` (which no
+// step still reads: the caller's business); the range
+// goes to the first free entry of z->q.  must: nothing to launch is an error (the caller is gn_inflate_step itself, with nothing
+// pending); otherwise it is simply not launched yet.
+static int gi_start_decode(gn_inflate* z, bool must, uint32_t from, int set)
+{
+    gn_inflate::Pend& slot = z->q[0].valid ? z->q[1] : z->q[0];
+    if (slot.valid)
+        return GN_OK;
+    const uint64_t fed     = z->fed.load();
+    const bool     all_fed = fed >= z->total;
+    // chunks a step may decode: those whose range and a margin behind it are fed
+    const uint64_t margin = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(z->step_bytes / 4u, 2ull * z->chunk_bytes)); // (too little only costs a repeat)
+    uint32_t       j1;
+    if (all_fed)
+        j1 = z->n_chunks_file;
+    else
+    {
+        const uint64_t usable = fed > margin ? fed - margin : 0;
+        j1                    = (uint32_t)(usable / z->chunk_bytes);
+    }
+    j1 = std::min<uint32_t>(j1, from + z->slots_cap);
+    if (j1 <= from)
+    {
+        if (!must)
+            return GN_OK;
+        if (all_fed)
+            return gn_fail(GN_ERANGE, "gn_inflate_step: the gzip stream does not end inside the file");
+        return gn_fail(GN_EINVAL, "gn_inflate_step: feed more bytes first (a step needs its chunks and a margin behind them -- 4 MiB at the default sizes -- or the whole file)");
+    }
+    if (!z->d_chunks_set[set])
+        return must ? gn_fail(GN_EINVAL, "gn_inflate_step: no decode set %d", set) : GN_OK; // (a one-step file has one set: nothing runs beside a step)
+    GN_HIP(hipMemsetAsync(z->d_ctr_set[set], 0, 64, z->st_dec[set]));
+    GN_HIP(hipEventRecord(z->ev_dec[set][0], z->st_dec[set]));
+    const int rc = gi_launch_chunks(z, set, z->st_dec[set], fed, from, j1 - from, GI_NONE, 0, 0);
+    if (rc != GN_OK)
+        return rc;
+    GN_HIP(hipEventRecord(z->ev_dec[set][1], z->st_dec[set]));
+    slot.valid  = true;
+    slot.j0     = from;
+    slot.j1     = j1;
+    slot.fed    = fed;
+    slot.set    = set;
     return GN_OK;
 }
 
@@ -1728,35 +2178,31 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     if (z->ended)
         return GN_OK;
     GN_HIP(hipSetDevice(z->device));
-    z->fed_step        = z->fed.load();
+    if (!z->q[0].valid)
+    {
+        const int rc0 = gi_start_decode(z, true, z->next_chunk, z->next_set);
+        if (rc0 != GN_OK)
+            return rc0;
+    }
+    // this step's decode is in flight (launched by an earlier step, or just now); the one behind it starts beside it
+    const gn_inflate::Pend A = z->q[0];
+    z->q[0]                  = z->q[1];
+    z->q[1].valid            = false;
+    z->next_set              = A.set; // (the set this step frees when it is through)
+    if (!z->q[0].valid && A.j1 < z->n_chunks_file)
+        gi_start_decode(z, false, A.j1, 1 - A.set);
+    const int set      = A.set;
+    z->fed_step        = A.fed;
     const bool all_fed = z->fed_step >= z->total;
-    // chunks this step may decode: those whose range and a margin behind it are fed
-    const uint64_t margin = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(z->step_bytes / 4u, 2ull * z->chunk_bytes)); // (too little only costs a repeat)
-    uint32_t       j1;
-    if (all_fed)
-        j1 = z->n_chunks_file;
-    else
-    {
-        const uint64_t usable = z->fed_step > margin ? z->fed_step - margin : 0;
-        j1                    = (uint32_t)(usable / z->chunk_bytes);
-    }
-    j1 = std::min<uint32_t>(j1, z->next_chunk + z->slots_cap);
-    if (j1 <= z->next_chunk)
-    {
-        if (all_fed)
-            return gn_fail(GN_ERANGE, "gn_inflate_step: the gzip stream does not end inside the file");
-        return gn_fail(GN_EINVAL, "gn_inflate_step: feed more bytes first (a step needs its chunks and a margin behind them -- 4 MiB at the default sizes -- or the whole file)");
-    }
-    const uint32_t j0 = z->next_chunk, n = j1 - j0;
+    const uint32_t j0 = A.j0, j1 = A.j1, n = j1 - j0;
+    z->d_chunks       = z->d_chunks_set[set];
+    z->d_pool         = z->d_pool_set[set];
     const int      buf = 1 - z->cur;
     const uint64_t carry = z->carry; // (<= n_text_last, checked by gn_inflate_set_carry)
     auto           t0 = std::chrono::steady_clock::now();
-    GN_HIP(hipMemsetAsync(z->d_ctr, 0, 64, z->st));
-    GN_HIP(hipEventRecord(z->ev[0], z->st));
-    int rc = gi_launch_chunks(z, j0, n, GI_NONE, 0, 0);
-    if (rc != GN_OK)
-        return rc;
+    GN_HIP(hipStreamWaitEvent(z->st, z->ev_dec[set][1], 0));
     GN_HIP(hipEventRecord(z->ev[1], z->st));
+    int rc = GN_OK;
     // order of the stream: the host copy of the state is what the last step left; the kernel reads pos_bit / run_len and writes results
     uint32_t       fixes = 0;
     const uint64_t range_end = (uint64_t)j1 * z->chunk_bytes * 8u;
@@ -1767,7 +2213,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         GN_HIP(hipMemcpyAsync(z->d_state, z->h_state, sizeof(GiState), hipMemcpyHostToDevice, z->st));
         const size_t lds = (size_t)(n + fixes) * 16u;
         hipLaunchKernelGGL(gi_order_kernel, dim3(1), dim3(1024), lds, z->st, z->d_state, z->d_chunks, n, z->slots_cap, fixes, j0, z->chunk_bytes, range_end,
-                           z->total * 8u, z->d_real, z->d_work, z->slots_cap + z->fix_cap, z->work_cap, z->text_cap - carry);
+                           z->total * 8u, z->d_real, z->d_work, z->slots_cap + z->fix_cap, z->work_cap, z->text_cap - carry, z->d_mlist_pos, z->d_mlist_crc, z->mlist_cap);
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(z->h_state, z->d_state, sizeof(GiState), hipMemcpyDeviceToHost, z->st));
         GN_HIP(hipStreamSynchronize(z->st));
@@ -1777,7 +2223,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         if (fixes >= z->fix_cap || z->stats.fixups + fixes > 16u + z->stats.chunks / 8u)
             return gn_fail(GN_ERANGE, "gn_inflate_step: too many positions the block search does not find (%u in this step): not a file for this decoder",
                            fixes);
-        rc = gi_launch_chunks(z, 0, 1, s.res_pos, s.gap_stop, z->slots_cap + fixes);
+        rc = gi_launch_chunks(z, set, z->st, z->fed_step, 0, 1, s.res_pos, s.gap_stop, z->slots_cap + fixes);
         if (rc != GN_OK)
             return rc;
         ++fixes;
@@ -1790,6 +2236,13 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         return gn_fail(GN_ERANGE, "gn_inflate_step: gzip member with a wrong length (ISIZE)");
     if (s.reason == GI_R_OVERFLOW)
         return gn_fail(GN_ERANGE, "gn_inflate_step: the data expands beyond what a step holds (more than 12-fold, or a chunk beyond 2 Mi symbols)");
+    // where the next step begins is known now: its decode starts beside this step's remaining passes
+    z->next_chunk = s.reason == GI_R_INPUT ? j0 + std::min<uint32_t>(s.cursor, n) : j1;
+    if (z->q[0].valid && z->q[0].j0 != z->next_chunk) // the decode that ran ahead assumed another start: dropped (its set is free again when it is through)
+    {
+        z->q[0]       = z->q[1];
+        z->q[1].valid = false;
+    }
     if (s.n_real)
     {
         const uint32_t groups = (s.n_real + GI_GROUP - 1u) / GI_GROUP;
@@ -1806,10 +2259,31 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
                            z->d_work, z->d_pool, z->d_p_store, z->d_w_store, z->d_text[buf] + carry);
         GN_HIP(hipGetLastError());
     }
+    {
+        uint32_t*      acc    = z->d_mlist_crc + z->mlist_cap;
+        uint32_t*      result = acc + z->mlist_cap + 1u;
+        const uint32_t M      = s.n_mlist;
+        GN_HIP(hipMemsetAsync(acc, 0, ((size_t)z->mlist_cap + 3u) * sizeof(uint32_t), z->st));
+        const uint32_t blocks = (uint32_t)((s.text_off + (uint64_t)GI_CRC_PIECE * 256u - 1u) / ((uint64_t)GI_CRC_PIECE * 256u));
+        hipLaunchKernelGGL(gi_crc_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, z->st, z->d_text[buf] + carry, s.text_off, z->d_mlist_pos, M, z->crc_carry, acc);
+        hipLaunchKernelGGL(gi_crc_check_kernel, dim3((M + 256u) / 256u), dim3(256), 0, z->st, acc, z->d_mlist_crc, M, result);
+        GN_HIP(hipGetLastError());
+        GN_HIP(hipMemcpyAsync(z->h_crc, result, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, z->st));
+    }
     GN_HIP(hipEventRecord(z->ev[3], z->st));
     GN_HIP(hipStreamSynchronize(z->st));
+    if (z->h_crc[0])
+        return gn_fail(GN_ERANGE, "gn_inflate_step: gzip member with a wrong CRC-32");
+    z->crc_carry = z->h_crc[1];
+    // this step's set is free: the decode after the one in flight starts now
+    if (s.reason != GI_R_END && !(s.reason == GI_R_INPUT && all_fed))
+    {
+        const uint32_t from = z->q[0].valid ? z->q[0].j1 : z->next_chunk;
+        if (from < z->n_chunks_file)
+            gi_start_decode(z, false, from, set);
+    }
     float ms = 0;
-    if (hipEventElapsedTime(&ms, z->ev[0], z->ev[1]) == hipSuccess)
+    if (hipEventElapsedTime(&ms, z->ev_dec[set][0], z->ev_dec[set][1]) == hipSuccess)
         z->stats.ms_decode += ms;
     if (hipEventElapsedTime(&ms, z->ev[1], z->ev[2]) == hipSuccess)
         z->stats.ms_chain += ms;
@@ -1841,11 +2315,9 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         // cursor = the slot that has to be decoded again with more bytes
         if (all_fed)
             return gn_fail(GN_ERANGE, "gn_inflate_step: truncated gzip stream");
-        z->next_chunk = j0 + std::min<uint32_t>(s.cursor, n);
         return GN_OK;
     }
     // the range is done
-    z->next_chunk = j1;
     if (j1 >= z->n_chunks_file)
     {
         if (s.res_pos >= z->total * 8u)

@@ -395,7 +395,7 @@ int gn_stream_hibf_level_lines(gn_stream* s, uint64_t* line_bytes, uint32_t cap)
  * (seqan3::sequence_file_input over a gz stream in parse_reads, /root/reference/src/ganon-classify/GanonClassify.cpp:1220-1287;
  * its one decompression thread, :1433): the caller feeds the file's bytes as they are, the device finds deflate block starts,
  * decodes the chunks between them in parallel and returns the text -- the same bytes zlib's inflate() yields for the file
- * (every member; what follows the last member is ignored like gzip does).  Members' ISIZE is checked.
+ * (every member; what follows the last member is ignored like gzip does).  Every member's CRC-32 and ISIZE are checked.
  *   gn_inflate_create   compressed_bytes = size of the file; chunk_bytes = compressed bytes per parallel chunk (0: 32 KiB);
  *                       step_bytes = compressed bytes decoded per gn_inflate_step (0: 256 MiB; at most 8192 chunks).  The whole compressed file
  *                       stays resident in HBM (files of 64 GiB and more: GN_ERANGE).
@@ -405,7 +405,7 @@ int gn_stream_hibf_level_lines(gn_stream* s, uint64_t* line_bytes, uint32_t cap)
  *                       after the last member's trailer.  Blocks until the text is complete in device memory.
  *   gn_inflate_text     copies [off, off + n) of the LAST step's text to host memory
  *   gn_inflate_text_device   the last step's text in device memory (valid until the step after the next one begins)
- * GN_ERANGE from gn_inflate_step: damaged / truncated data, a wrong ISIZE, or data this decoder is not made for (more than
+ * GN_ERANGE from gn_inflate_step: damaged / truncated data, a wrong CRC-32 or ISIZE, or data this decoder is not made for (more than
  * 12-fold expansion, hardly any dynamic-Huffman blocks): the caller reads the file with its host inflater instead -- nothing
  * that was returned before is wrong, and nothing is returned that was not decoded. */
 typedef struct gn_inflate gn_inflate;

@@ -157,3 +157,31 @@ def test_truncated_and_damaged():
         with pytest.raises(zlib.error):
             zlib.decompress(bytes(bad), 31)
         pytest.fail("damaged stream was accepted")
+
+
+def test_wrong_crc_or_length_in_a_trailer_is_refused():
+    gz = bytearray(_gz(TEXT, 6))
+    for at in (len(gz) - 8, len(gz) - 4):  # CRC-32, then ISIZE
+        bad = bytearray(gz)
+        bad[at] ^= 1
+        with pytest.raises(hip.GanonHipError) as e:
+            _inflate(bytes(bad), chunk=4096)
+        assert e.value.code == -34
+    # ... in the first of two members, with the steps cutting the members anywhere
+    two = bytearray(_gz(TEXT[:700_001], 6) + _gz(TEXT[700_001:], 9))
+    assert _inflate(bytes(two), chunk=2048, step=65536, feed=30_000)[0] == TEXT
+    first_len = len(_gz(TEXT[:700_001], 6))
+    two[first_len - 7] ^= 0x80
+    with pytest.raises(hip.GanonHipError):
+        _inflate(bytes(two), chunk=2048, step=65536, feed=30_000)
+
+
+def test_a_flipped_bit_that_still_decodes_is_caught_by_the_crc():
+    # stored blocks: a flipped data bit changes no code, no length -- only the CRC notices
+    text = TEXT[:200_000]
+    gz = bytearray(_gz(text, 0))
+    gz[len(gz) // 2] ^= 0x04
+    assert zlib.decompressobj(31).decompress(bytes(gz[:-8]))  # (the deflate data itself is fine)
+    with pytest.raises(hip.GanonHipError) as e:
+        _inflate(bytes(gz), chunk=65536)
+    assert e.value.code == -34
