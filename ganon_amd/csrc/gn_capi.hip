@@ -54,7 +54,7 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                               {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
                               {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent}, {"hibf_stage", &GnSwitches::hibf_stage}, {"hibf_nsort", &GnSwitches::hibf_nsort}, {"hibf_reread", &GnSwitches::hibf_reread},
                               {"hibf_fake_hashes", &GnSwitches::hibf_fake_hashes}, {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
-                              {"pinned_malloc", &GnSwitches::pinned_malloc}, {"debug", &GnSwitches::debug}};
+                              {"pinned_malloc", &GnSwitches::pinned_malloc}, {"inflate_ahead", &GnSwitches::inflate_ahead}, {"debug", &GnSwitches::debug}};
     for (const char* p = list ? list : ""; *p;)
     {
         const char* e = strchr(p, ',');
@@ -71,6 +71,8 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
             sw.chunk = (uint32_t)strtoul(p + 6, nullptr, 10), known = true;
         if (!known && n > 9 && !strncmp(p, "hibf_bpc=", 9))
             sw.hibf_bpc = (uint32_t)strtoul(p + 9, nullptr, 10), known = true;
+        if (!known && n > 12 && !strncmp(p, "inflate_bpc=", 12))
+            sw.inflate_bpc = (uint32_t)strtoul(p + 12, nullptr, 10), known = true;
         if (!known && n > 16 && !strncmp(p, "hibf_pair_limit=", 16))
             sw.hibf_pair_limit = std::max<uint64_t>(64, strtoull(p + 16, nullptr, 10)), known = true;
         if (!known && n > 5 && !strncmp(p, "sync=", 5))

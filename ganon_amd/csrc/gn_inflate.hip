@@ -122,8 +122,8 @@ struct GiLds
     uint16_t ring[GI_RING];
     uint32_t piece[GI_MAX_PIECES];
     uint16_t tok_len[64], tok_val[64]; // the batch's tokens (gi_codes)
-    uint32_t cand_q[128];              // the search: positions (relative to the chunk's nominal start) that passed the first screen
-    uint32_t cand_q2[144];             // ... and the second
+    uint32_t cand_q[256];              // the search: positions (relative to the chunk's nominal start) that passed the first screen (a ring)
+    uint32_t cand_q2[128];             // ... and the second
     uint8_t  lens[320];
 };
 
@@ -1111,6 +1111,7 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
         uint64_t start      = GI_NONE;
         uint64_t search_at  = fix ? GI_NONE : nominal; // next position the search looks at (GI_NONE: no search)
         uint64_t sw_base = ~0ull, sq_m = 0; // search: base dword of the register window; candidates of the running batch that passed both screens
+        uint32_t sq_h = 0, sq2_h = 0; // (heads of the two rings)
         uint32_t sw = 0, sq_n = 0, sq2_n = 0, sq_pos = 0; // ... the window; positions queued behind the first / second screen; the running batch's (per lane)
         bool     at_header  = false;
         uint32_t flags      = 0;
@@ -1151,26 +1152,19 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                         // wave pays for the longest header among its lanes whatever their number)
                         const uint32_t take = sq2_n < 64u ? sq2_n : 64u;
                         __syncthreads();
-                        sq_pos = lane < take ? L.cand_q2[lane] : 0u;
-                        const uint32_t keep = lane + 64u < sq2_n ? L.cand_q2[lane + 64u] : 0u;
-                        __syncthreads();
-                        if (lane + 64u < sq2_n)
-                            L.cand_q2[lane] = keep;
+                        sq_pos = lane < take ? L.cand_q2[(sq2_h + lane) & 127u] : 0u;
+                        sq2_h += take;
                         sq2_n -= take;
                         const bool ok = lane < take && gi_screen_header(p.comp, n_dw, nominal + sq_pos);
                         sq_m          = __ballot(ok);
-                        __syncthreads();
                         continue;
                     }
                     if (sq_n >= 64u || (search_at >= stop && sq_n))
                     {
                         const uint32_t take = sq_n < 64u ? sq_n : 64u;
                         __syncthreads();
-                        const uint32_t mypos = lane < take ? L.cand_q[lane] : 0u;
-                        const uint32_t keep  = lane + 64u < sq_n ? L.cand_q[lane + 64u] : 0u;
-                        __syncthreads();
-                        if (lane + 64u < sq_n)
-                            L.cand_q[lane] = keep;
+                        const uint32_t mypos = lane < take ? L.cand_q[(sq_h + lane) & 255u] : 0u;
+                        sq_h += take;
                         sq_n -= take;
                         const uint64_t bit = nominal + mypos;
                         const uint64_t di  = bit >> 5;
@@ -1183,31 +1177,46 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                         }
                         const uint64_t m2 = __ballot(ok);
                         if (ok)
-                            L.cand_q2[sq2_n + (uint32_t)__popcll(m2 & ((1ull << lane) - 1ull))] = mypos;
+                            L.cand_q2[(sq2_h + sq2_n + (uint32_t)__popcll(m2 & ((1ull << lane) - 1ull))) & 127u] = mypos;
                         sq2_n += (uint32_t)__popcll(m2);
-                        __syncthreads();
                         continue;
                     }
                     if (search_at >= stop)
                         break;
+                    // first screen: 256 positions a round, four to a lane, out of the register that holds 64 dwords of the file
                     const uint64_t d = search_at >> 5;
-                    if (sw_base == ~0ull || d < sw_base || d + 3u > sw_base + 64u)
+                    if (sw_base == ~0ull || d < sw_base || d + 10u > sw_base + 64u)
                     {
                         sw_base = d;
                         sw      = sw_base + lane < n_dw ? p.comp[sw_base + lane] : 0u;
                     }
-                    const int      i0 = (int)(d - sw_base);
-                    const uint32_t u0 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0), u1 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 1),
-                                   u2 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 2), u3 = (uint32_t)__builtin_amdgcn_readlane((int)sw, i0 + 3);
-                    const uint32_t sh = (uint32_t)(search_at & 31u) + lane, q = sh >> 5;
-                    const uint32_t d0 = q == 0u ? u0 : q == 1u ? u1 : u2, d1 = q == 0u ? u1 : q == 1u ? u2 : u3;
-                    const uint64_t bit = search_at + lane;
-                    const bool     ok  = bit < stop && bit + 96u <= p.avail_bits && gi_screen_bits(__funnelshift_r(d0, d1, sh & 31u));
-                    const uint64_t m   = __ballot(ok);
-                    if (ok)
-                        L.cand_q[sq_n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(bit - nominal);
-                    sq_n += (uint32_t)__popcll(m);
-                    search_at += 64u;
+                    const uint32_t off = (uint32_t)(search_at - (sw_base << 5)) + 4u * lane;
+                    const uint32_t d0 = (uint32_t)__shfl((int)sw, (int)(off >> 5)), d1 = (uint32_t)__shfl((int)sw, (int)(off >> 5) + 1);
+                    const uint32_t x  = __funnelshift_r(d0, d1, off & 31u);
+                    const uint64_t bit = search_at + 4u * lane;
+                    const uint64_t lim = stop < p.avail_bits - 96u ? stop : p.avail_bits - 96u; // (a position is looked at with 96 bits behind it)
+                    bool     okj[4];
+                    uint64_t mj[4];
+                    uint32_t before = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j)
+                    {
+                        okj[j] = bit + j < lim && gi_screen_bits(x >> j);
+                        mj[j]  = __ballot(okj[j]);
+                        before += (uint32_t)__popcll(mj[j] & ((1ull << lane) - 1ull));
+                    }
+                    uint32_t total = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j)
+                    {
+                        const uint32_t slot = sq_n + before;
+                        if (okj[j] && slot < 256u) // (a ring of 256: what does not fit is dropped -- the chunk before decodes what the search misses)
+                            L.cand_q[(sq_h + slot) & 255u] = (uint32_t)(bit + j - nominal);
+                        before += okj[j] ? 1u : 0u;
+                        total += (uint32_t)__popcll(mj[j]);
+                    }
+                    sq_n = sq_n + total < 256u ? sq_n + total : 256u;
+                    search_at += 256u;
                 }
                 t_screen += (uint32_t)(wall_clock64() - t_s);
                 if (start == GI_NONE)
@@ -1425,11 +1434,14 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
 }
 
 // ---- the stream's order -------------------------------------------------------------------------------------------------------------
-// One workgroup.  The slots' key fields go to LDS; thread 0 walks from the stream's position: a chunk that starts at a position lies in
-// the slot of that position's nominal range (or in a fix-up slot), so every step is a lookup, not a search.  Everything else (work list)
-// is filled in parallel afterwards.  The kernel only READS the step's initial state (pos_bit, run_len) and writes its result fields, so
-// the host can run it again after a fix-up decode.
+// One workgroup, the slots' key fields in LDS.  A chunk that starts at a position lies in the slot of that position's nominal range (or
+// in a fix-up slot), so "which chunk continues this one" is a lookup, done for every slot at once; thread 0 then only follows the
+// successor links from the stream's position (two LDS reads a chunk), and everything else -- text offsets and work-list offsets by
+// prefix sums over the chain, the chain records, the work list -- is done by all threads again.  The kernel only READS the step's
+// initial state (pos_bit, run_len) and writes its result fields, so the host can run it again after a fix-up decode.
 #define GI_ORDER_MAX 8256u // regular slots of a step (<= 8192) + fix-up slots (<= 64); 16 bytes of LDS each
+#define GI_NOIDX 0xFFFFu
+
 __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChunk* chunks, uint32_t n_slots, uint32_t slots_cap, uint32_t n_fix, uint32_t j0,
                                                         uint32_t chunk_bytes, uint64_t range_end_bits, uint64_t total_bits, GiReal* real, uint2* work,
                                                         uint32_t real_cap, uint32_t work_cap, uint64_t text_cap, unsigned long long* mlist_pos,
@@ -1437,150 +1449,195 @@ __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChu
 {
     extern __shared__ uint64_t gi_order_lds[];
     const uint32_t             n_all   = n_slots + n_fix;
-    uint64_t*                  s_start = gi_order_lds;
-    uint32_t*                  s_span  = reinterpret_cast<uint32_t*>(s_start + n_all); // end_bit - start_bit
-    uint32_t*                  s_lf    = s_span + n_all;                               // out_len | flags << 24
-    __shared__ uint32_t        s_R;
-    const uint32_t             tid = threadIdx.x;
+    uint64_t*                  s_start = gi_order_lds;                                  // (a prefix-sum buffer once the links exist)
+    uint32_t*                  s_lf    = reinterpret_cast<uint32_t*>(s_start + n_all); // out_len | flags << 24
+    uint16_t*                  s_succ  = reinterpret_cast<uint16_t*>(s_lf + n_all);    // the chunk that starts where this one ends
+    uint16_t*                  s_order = s_succ + n_all;                                // chain order
+    __shared__ uint32_t        s_R, s_head;
+    __shared__ uint64_t        s_part[1024];
+    const uint32_t             tid   = threadIdx.x;
+    const uint64_t             cbits = (uint64_t)chunk_bytes * 8u;
+    auto slot_of = [&](uint32_t idx) { return idx < n_slots ? idx : slots_cap + (idx - n_slots); };
     for (uint32_t i = tid; i < n_all; i += 1024u)
     {
-        const GiChunk& c = chunks[i < n_slots ? i : slots_cap + (i - n_slots)];
+        const GiChunk& c = chunks[slot_of(i)];
         s_start[i]       = c.start_bit;
-        s_span[i]        = (uint32_t)(c.end_bit - c.start_bit);
         s_lf[i]          = c.out_len | (c.flags << 24);
     }
     __syncthreads();
+    // the chunk (index) that starts at pos; GI_NOIDX: none
+    auto lookup = [&](uint64_t pos) -> uint32_t {
+        for (uint32_t f = 0; f < n_fix; ++f)
+            if (s_start[n_slots + f] == pos)
+                return n_slots + f;
+        const uint64_t sj = pos / cbits;
+        if (sj >= j0 && sj - j0 < n_slots && s_start[sj - j0] == pos)
+            return (uint32_t)(sj - j0);
+        return GI_NOIDX;
+    };
+    for (uint32_t i = tid; i < n_all; i += 1024u)
+        s_succ[i] = s_start[i] == GI_NONE ? (uint16_t)GI_NOIDX : (uint16_t)lookup(chunks[slot_of(i)].end_bit);
+    if (tid == 0)
+        s_head = lookup(st->pos_bit);
+    __syncthreads();
     if (tid == 0)
     {
-        const uint64_t cbits = (uint64_t)chunk_bytes * 8u;
-        uint64_t       pos = st->pos_bit, text = 0, run_len = st->run_len, gap_stop = 0;
-        uint32_t       r = 0, w = 0, reason = GI_R_RANGE, cursor = n_slots, members = 0, n_ml = 0;
-        for (;;)
+        uint32_t r = 0, reason = ~0u, cursor = n_slots, idx = s_head;
+        bool     is_short = false;
+        while (idx != GI_NOIDX)
         {
-            uint32_t idx = ~0u;
-            for (uint32_t f = 0; f < n_fix; ++f)
-                if (s_start[n_slots + f] == pos)
-                    idx = n_slots + f;
-            const uint64_t sj = pos / cbits;
-            uint32_t       s  = sj >= j0 ? (uint32_t)(sj - j0 < n_slots ? sj - j0 : n_slots) : 0u;
-            if (idx == ~0u && sj >= j0 && s < n_slots && s_start[s] == pos)
-                idx = s;
-            if (idx == ~0u)
+            const uint32_t fl = s_lf[idx] >> 24;
+            if (fl & (GI_F_SHORT | GI_F_OVERFLOW))
             {
-                // nothing starts here: a gap up to the next start behind pos, or the end of the range's chunks
-                while (s < n_slots && (s_start[s] == GI_NONE || s_start[s] <= pos))
-                    ++s;
-                if (s < n_slots)
-                {
-                    reason   = GI_R_GAP;
-                    gap_stop = s_start[s];
-                }
-                else if (pos < range_end_bits && pos < total_bits)
-                {
-                    reason   = GI_R_GAP;
-                    gap_stop = range_end_bits < total_bits ? range_end_bits : total_bits;
-                }
-                else
-                    reason = GI_R_RANGE;
-                cursor = s;
+                reason   = (fl & GI_F_SHORT) ? GI_R_INPUT : GI_R_OVERFLOW;
+                is_short = (fl & GI_F_SHORT) != 0u;
                 break;
             }
-            const uint32_t fl = s_lf[idx] >> 24, n = s_lf[idx] & 0xFFFFFFu;
-            if (fl & GI_F_SHORT)
-            {
-                reason = GI_R_INPUT;
-                if (idx < n_slots)
-                    cursor = idx;
-                else
-                {
-                    // a fix-up decode ran short: the next step begins with the chunk in whose range the stream stands
-                    cursor = sj >= j0 ? (uint32_t)(sj - j0 < n_slots ? sj - j0 : n_slots) : 0u;
-                }
-                break;
-            }
-            if ((fl & GI_F_OVERFLOW) || r >= real_cap || text + n > text_cap || w + (n >> GI_PIECE_LOG2) + 1u > work_cap)
+            if (r >= real_cap)
             {
                 reason = GI_R_OVERFLOW;
                 break;
             }
-            const uint32_t slot = idx < n_slots ? idx : slots_cap + (idx - n_slots);
-            real[r].wbase       = w;
-            real[r].slot        = slot;
-            real[r].out_len     = n;
-            real[r].text_off    = text;
-            w += (n + GI_PIECE - 1u) >> GI_PIECE_LOG2;
-            ++r;
-            bool bad_member = false;
-            if (fl & GI_F_MEMBERS)
+            s_order[r++] = (uint16_t)idx;
+            if (fl & (GI_F_FAILED | GI_F_END))
             {
-                const GiChunk& c = chunks[slot];
-                uint32_t       at = 0;
-                for (uint32_t e = 0; e < c.n_mend; ++e)
-                {
-                    run_len += c.mend_sym[e] - at;
-                    if ((uint32_t)run_len != c.mend_isize[e])
-                        bad_member = true;
-                    if (n_ml < mlist_cap)
-                    {
-                        mlist_pos[n_ml] = text + c.mend_sym[e];
-                        mlist_crc[n_ml] = c.mend_crc[e];
-                    }
-                    ++n_ml;
-                    run_len = 0;
-                    at      = c.mend_sym[e];
-                }
-                run_len += n - at;
-                members += c.members_begun;
+                reason = (fl & GI_F_FAILED) ? GI_R_DATA : GI_R_END;
+                break;
+            }
+            idx = s_succ[idx];
+        }
+        // where the stream stands: behind the last chunk taken
+        const uint64_t pos = r ? chunks[slot_of(s_order[r - 1u])].end_bit : st->pos_bit;
+        if (is_short) // the next step begins with this chunk (a fix-up decode that ran short: with the chunk in whose range the stream stands)
+        {
+            const uint64_t sj = pos / cbits;
+            cursor = idx < n_slots ? idx : (sj >= j0 ? (uint32_t)(sj - j0 < n_slots ? sj - j0 : n_slots) : 0u);
+        }
+        uint64_t gap_stop = 0;
+        if (reason == ~0u)
+        {
+            // nothing starts at pos: a gap up to the next start behind pos, or the end of the range's chunks
+            const uint64_t sj = pos / cbits;
+            uint32_t       s  = sj >= j0 ? (uint32_t)(sj - j0 < n_slots ? sj - j0 : n_slots) : 0u;
+            while (s < n_slots && (s_start[s] == GI_NONE || s_start[s] <= pos))
+                ++s;
+            if (s < n_slots)
+            {
+                reason   = GI_R_GAP;
+                gap_stop = s_start[s];
+            }
+            else if (pos < range_end_bits && pos < total_bits)
+            {
+                reason   = GI_R_GAP;
+                gap_stop = range_end_bits < total_bits ? range_end_bits : total_bits;
             }
             else
-                run_len += n;
-            text += n;
-            pos = s_start[idx] + s_span[idx];
-            if (bad_member)
-            {
-                reason = GI_R_MEMBER;
-                break;
-            }
-            if (fl & GI_F_FAILED)
-            {
-                reason = GI_R_DATA;
-                break;
-            }
-            if (fl & GI_F_END)
-            {
-                reason = GI_R_END;
-                break;
-            }
+                reason = GI_R_RANGE;
+            cursor = s;
         }
-        st->reason      = reason;
-        st->n_real      = r;
-        st->n_work      = w;
-        st->text_off    = text;
-        st->cursor      = cursor;
-        st->gap_stop    = gap_stop;
-        st->res_pos     = pos;
-        st->res_run_len = run_len;
-        st->res_members = members;
-        st->n_mlist     = n_ml;
-        if (n_ml > mlist_cap && reason != GI_R_DATA && reason != GI_R_MEMBER)
-            st->reason = GI_R_OVERFLOW;
-        s_R             = r;
+        st->reason   = reason;
+        st->cursor   = cursor;
+        st->gap_stop = gap_stop;
+        st->res_pos  = pos;
+        s_R          = r;
     }
     __syncthreads();
     const uint32_t R = s_R;
-    unsigned long long mk = 0;
-    for (uint32_t r = tid; r < R; r += 1024u)
+    // text offsets and work-list offsets: exclusive prefix sums over the chain (both in one 64-bit sum: pieces << 40 | symbols)
+    const uint32_t per = (R + 1023u) / 1024u;
+    uint64_t       mine = 0;
+    for (uint32_t k = 0; k < per; ++k)
     {
-        const GiReal   rr = real[r];
-        for (uint32_t q = 0; (q << GI_PIECE_LOG2) < rr.out_len; ++q)
-            work[rr.wbase + q] = make_uint2(r, q);
-        const GiChunk& c = chunks[rr.slot];
-        mk += c.markers;
-        for (int k = 0; k < 8; ++k)
-            atomicAdd(&st->prof[k], (unsigned long long)c.prof[k]);
+        const uint32_t r = tid * per + k;
+        if (r < R)
+        {
+            const uint64_t n = s_lf[s_order[r]] & 0xFFFFFFu;
+            mine += n | (((n + GI_PIECE - 1u) >> GI_PIECE_LOG2) << 40);
+        }
+    }
+    s_part[tid] = mine;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1)
+    {
+        const uint64_t v = tid >= o ? s_part[tid - o] : 0ull;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    const uint64_t all = s_part[1023];
+    uint64_t       run = s_part[tid] - mine;
+    unsigned long long mk = 0;
+    for (uint32_t k = 0; k < per; ++k)
+    {
+        const uint32_t r = tid * per + k;
+        if (r < R)
+        {
+            const uint32_t idx = s_order[r], n = s_lf[idx] & 0xFFFFFFu;
+            const uint64_t text = run & ((1ull << 40) - 1ull);
+            const uint32_t w    = (uint32_t)(run >> 40);
+            real[r].slot     = slot_of(idx);
+            real[r].out_len  = n;
+            real[r].text_off = text;
+            real[r].wbase    = w;
+            if ((all >> 40) <= work_cap)
+                for (uint32_t q = 0; (q << GI_PIECE_LOG2) < n; ++q)
+                    work[w + q] = make_uint2(r, q);
+            const GiChunk& c = chunks[slot_of(idx)];
+            mk += c.markers;
+            for (int kk = 0; kk < 8; ++kk)
+                atomicAdd(&st->prof[kk], (unsigned long long)c.prof[kk]);
+            run += n | (((uint64_t)(n + GI_PIECE - 1u) >> GI_PIECE_LOG2) << 40);
+        }
     }
     if (mk)
         atomicAdd(reinterpret_cast<unsigned long long*>(&st->res_markers), mk);
+    __syncthreads();
+    if (tid == 0)
+    {
+        const uint64_t text_all = all & ((1ull << 40) - 1ull);
+        uint32_t       reason   = st->reason;
+        if (text_all > text_cap || (all >> 40) > work_cap)
+            reason = GI_R_OVERFLOW;
+        // members that end in the step: lengths against ISIZE, the list for the CRC pass (chunks that hold member ends say so)
+        uint64_t run_len = st->run_len, last_end = 0;
+        uint32_t members = 0, n_ml = 0;
+        bool     bad     = false;
+        for (uint32_t r = 0; r < R; ++r)
+        {
+            const uint32_t idx = s_order[r];
+            if (!((s_lf[idx] >> 24) & GI_F_MEMBERS))
+                continue;
+            const GiChunk& c = chunks[slot_of(idx)];
+            const uint64_t t = real[r].text_off;
+            for (uint32_t e = 0; e < c.n_mend; ++e)
+            {
+                const uint64_t end = t + c.mend_sym[e];
+                if ((uint32_t)(run_len + (end - last_end)) != c.mend_isize[e])
+                    bad = true;
+                run_len  = 0;
+                last_end = end;
+                if (n_ml < mlist_cap)
+                {
+                    mlist_pos[n_ml] = end;
+                    mlist_crc[n_ml] = c.mend_crc[e];
+                }
+                ++n_ml;
+            }
+            members += c.members_begun;
+        }
+        run_len += text_all - last_end;
+        if (bad && reason != GI_R_OVERFLOW)
+            reason = GI_R_MEMBER;
+        if (n_ml > mlist_cap && reason != GI_R_DATA && reason != GI_R_MEMBER)
+            reason = GI_R_OVERFLOW;
+        st->reason      = reason;
+        st->n_real      = R;
+        st->n_work      = (uint32_t)(all >> 40);
+        st->text_off    = text_all;
+        st->res_run_len = run_len;
+        st->res_members = members;
+        st->n_mlist     = n_ml;
+    }
 }
 
 #define GI_GROUP 32u // chain chunks whose windows one workgroup composes
@@ -1699,7 +1756,31 @@ __global__ __launch_bounds__(256) void gi_resolve_kernel(const GiState* st, cons
         const uint16_t* pr = p_store + (uint64_t)it.x * GI_WINDOW;
         const uint8_t*  wg = w_store + (uint64_t)(it.x / GI_GROUP) * GI_WINDOW;
         uint8_t*        d  = text + R.text_off + lo;
-        for (uint32_t i = threadIdx.x; i < hi - lo; i += 256u)
+        const uint32_t cnt4 = (hi - lo) & ~3u;
+        for (uint32_t i = threadIdx.x * 4u; i < cnt4; i += 1024u)
+        {
+            const uint2 two = *reinterpret_cast<const uint2*>(s + i); // (a piece begins on a 64 KiB boundary of the pool)
+            uint32_t    v[4] = { two.x & 0xFFFFu, two.x >> 16, two.y & 0xFFFFu, two.y >> 16 };
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k] >= 256u)
+                {
+                    v[k] = pr[v[k] - 256u];
+                    if (v[k] >= 256u)
+                        v[k] = wg[v[k] - 256u];
+                }
+            const uint32_t packed = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            if (((uintptr_t)(d + i) & 3u) == 0u)
+                *reinterpret_cast<uint32_t*>(d + i) = packed;
+            else
+            {
+                d[i]     = (uint8_t)v[0];
+                d[i + 1] = (uint8_t)v[1];
+                d[i + 2] = (uint8_t)v[2];
+                d[i + 3] = (uint8_t)v[3];
+            }
+        }
+        for (uint32_t i = cnt4 + threadIdx.x; i < hi - lo; i += 256u)
         {
             uint32_t v = s[i];
             if (v >= 256u)
@@ -1848,14 +1929,20 @@ __device__ __forceinline__ uint32_t gi_x2nmodp(uint64_t n, uint32_t k)
 __global__ __launch_bounds__(256) void gi_crc_kernel(const uint8_t* __restrict__ text, uint64_t n, const unsigned long long* __restrict__ mend_pos,
                                                      uint32_t n_mend, uint32_t carry_crc, uint32_t* __restrict__ acc)
 {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[4][256]; // slicing by four: tab[k][i] = CRC of byte i followed by k zero bytes
     {
         uint32_t c = threadIdx.x;
         for (int k = 0; k < 8; ++k)
             c = (c & 1u) ? (c >> 1) ^ 0xedb88320u : c >> 1;
-        tab[threadIdx.x] = c;
+        tab[0][threadIdx.x] = c;
     }
     __syncthreads();
+    for (int k = 1; k < 4; ++k)
+    {
+        const uint32_t c = tab[k - 1][threadIdx.x];
+        tab[k][threadIdx.x] = (c >> 8) ^ tab[0][c & 0xFFu];
+        __syncthreads();
+    }
     const uint64_t b  = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint64_t lo = b * GI_CRC_PIECE;
     if (b == 0 && carry_crc) // the member that was open when the step began
@@ -1883,8 +1970,16 @@ __global__ __launch_bounds__(256) void gi_crc_kernel(const uint8_t* __restrict__
         const uint64_t mend = m < n_mend ? mend_pos[m] : n;
         const uint64_t end  = min(hi, mend);
         uint32_t       c    = 0xFFFFFFFFu;
-        for (uint64_t q = cur; q < end; ++q)
-            c = tab[(c ^ text[q]) & 0xFFu] ^ (c >> 8);
+        uint64_t q = cur;
+        for (; q < end && ((uintptr_t)(text + q) & 3u); ++q)
+            c = tab[0][(c ^ text[q]) & 0xFFu] ^ (c >> 8);
+        for (; q + 4u <= end; q += 4u)
+        {
+            c ^= *reinterpret_cast<const uint32_t*>(text + q);
+            c = tab[3][c & 0xFFu] ^ tab[2][(c >> 8) & 0xFFu] ^ tab[1][(c >> 16) & 0xFFu] ^ tab[0][c >> 24];
+        }
+        for (; q < end; ++q)
+            c = tab[0][(c ^ text[q]) & 0xFFu] ^ (c >> 8);
         c = ~c;
         if (end > cur)
             atomicXor(&acc[m], gi_multmodp(gi_x2nmodp(mend - end, 3), c));
@@ -1927,6 +2022,7 @@ struct gn_inflate
     hipStream_t st_dec[2] = { nullptr, nullptr }; // (one per set: two decodes run side by side, the later one fills what the tail of the earlier leaves idle)
     hipEvent_t  ev_dec[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
     int       next_set = 0;
+    uint32_t  launches = 0; // decodes launched so far (the first ones are smaller)
     struct Pend // a decode in flight (or done): q[0] is what the next gn_inflate_step finishes, q[1] what the one after it does --
     {           // launched on the assumption that q[0]'s step ends where its range does (almost always; otherwise it is dropped)
         bool     valid = false;
@@ -2099,6 +2195,9 @@ extern "C" int gn_inflate_feed(gn_inflate* z, const uint8_t* data, uint64_t n)
     return GN_OK;
 }
 
+// decode waves per CU of one launch (each loops over chunks until the launch's are taken); $GANON_HIP_ABLATE inflate_bpc=N overrides
+#define GI_DECODE_BPC 16u
+
 static int gi_launch_chunks(gn_inflate* z, int set, hipStream_t st, uint64_t fed, uint32_t j0, uint32_t n, uint64_t fix_start, uint64_t fix_stop, uint32_t fix_slot)
 {
     GiParams p;
@@ -2117,7 +2216,8 @@ static int gi_launch_chunks(gn_inflate* z, int set, hipStream_t st, uint64_t fed
     p.fix_stop    = fix_stop;
     p.fix_slot    = fix_slot;
     p.strict      = 1;
-    const uint32_t grid = fix_start != GI_NONE ? 1u : std::min<uint32_t>(n, (uint32_t)z->n_cu * 16u);
+    const uint32_t bpc  = gn_sw().inflate_bpc ? gn_sw().inflate_bpc : GI_DECODE_BPC;
+    const uint32_t grid = fix_start != GI_NONE ? 1u : std::min<uint32_t>(n, (uint32_t)z->n_cu * bpc);
     hipLaunchKernelGGL(gi_chunk_kernel, dim3(grid), dim3(64), 0, st, p);
     GN_HIP(hipGetLastError());
     return GN_OK;
@@ -2144,7 +2244,10 @@ static int gi_start_decode(gn_inflate* z, bool must, uint32_t from, int set)
         const uint64_t usable = fed > margin ? fed - margin : 0;
         j1                    = (uint32_t)(usable / z->chunk_bytes);
     }
-    j1 = std::min<uint32_t>(j1, from + z->slots_cap);
+    // the first steps are small (an eighth of a step, then doubling): the caller's pipeline gets its first text after a few milliseconds
+    // instead of after a third of a gigabyte
+    const uint32_t ramp = std::max<uint32_t>(64u, std::min<uint32_t>(z->slots_cap, (z->slots_cap / 8u) << std::min<uint32_t>(z->launches, 3u)));
+    j1 = std::min<uint32_t>(j1, from + ramp);
     if (j1 <= from)
     {
         if (!must)
@@ -2166,6 +2269,7 @@ static int gi_start_decode(gn_inflate* z, bool must, uint32_t from, int set)
     slot.j1     = j1;
     slot.fed    = fed;
     slot.set    = set;
+    ++z->launches;
     return GN_OK;
 }
 
@@ -2189,7 +2293,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     z->q[0]                  = z->q[1];
     z->q[1].valid            = false;
     z->next_set              = A.set; // (the set this step frees when it is through)
-    if (!z->q[0].valid && A.j1 < z->n_chunks_file)
+    if (!z->q[0].valid && A.j1 < z->n_chunks_file && !gn_sw().inflate_ahead)
         gi_start_decode(z, false, A.j1, 1 - A.set);
     const int set      = A.set;
     z->fed_step        = A.fed;
@@ -2279,7 +2383,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     if (s.reason != GI_R_END && !(s.reason == GI_R_INPUT && all_fed))
     {
         const uint32_t from = z->q[0].valid ? z->q[0].j1 : z->next_chunk;
-        if (from < z->n_chunks_file)
+        if (from < z->n_chunks_file && !gn_sw().inflate_ahead)
             gi_start_decode(z, false, from, set);
     }
     float ms = 0;

@@ -508,6 +508,7 @@ private:
 void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq, Backend* device_text)
 {
     uint64_t       seq = 0;
+    std::vector<std::thread> cleanups; // ends of device text sources, joined behind the queue's end
     MateCopier     copier(queue, (unsigned)env_size("GANON_HOST_MATE_THREADS", 3));
     // slab parsers: half of the cores this process may use, between 4 and 12 (the other half: reader, mate copier, device
     // workers, post pool); 8 on the 16-core quota of the boxes the numbers in DESIGN.md come from
@@ -616,6 +617,9 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     }
                     else
                         file_done = true;
+                    // (the source's end -- threads joined, gigabytes of device buffers freed -- takes some ten milliseconds the last batches
+                    //  need not wait for: it waits for its own pieces' holders anyway)
+                    cleanups.emplace_back([s = std::shared_ptr<DeviceTextSource>(std::move(src))]() mutable { s.reset(); });
                 }
             }
             // ---- raw pieces: the backend finds the records (single-end, uncompressed four-line FASTQ) ------------------------
@@ -1003,6 +1007,8 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
     }
     copier.drain();
     queue.done();
+    for (auto& t : cleanups)
+        t.join();
     g_cpu.reader.add_this_thread();
 }
 
