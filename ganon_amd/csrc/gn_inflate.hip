@@ -1740,12 +1740,14 @@ __global__ __launch_bounds__(1024) void gi_wchain_kernel(const GiState* st, cons
         reinterpret_cast<uint4*>(window)[i] = reinterpret_cast<const uint4*>(W)[i];
 }
 
-// symbols -> bytes.  One work item = one piece of one chain chunk; a marker goes through the chunk's P (level 1) and, if that is a
-// marker still, through its group's window (level 2).
-__global__ __launch_bounds__(256) void gi_resolve_kernel(const GiState* st, const GiChunk* chunks, const GiReal* real, const uint2* work,
+// symbols -> bytes.  One work item = one piece of one chain chunk; a marker goes through the chunk's P (level 1: staged in LDS, four
+// markers in five symbols of FASTQ text take this turn) and, if that is a marker still, through its group's window (level 2).
+__global__ __launch_bounds__(512) void gi_resolve_kernel(const GiState* st, const GiChunk* chunks, const GiReal* real, const uint2* work,
                                                          const uint16_t* pool, const uint16_t* p_store, const uint8_t* w_store, uint8_t* text)
 {
-    const uint32_t n_work = st->n_work;
+    __shared__ uint16_t P[GI_WINDOW];
+    const uint32_t      n_work = st->n_work;
+    uint32_t            have = ~0u; // the chain chunk whose P is in LDS
     for (uint32_t w = blockIdx.x; w < n_work; w += gridDim.x)
     {
         const uint2     it = work[w];
@@ -1753,11 +1755,19 @@ __global__ __launch_bounds__(256) void gi_resolve_kernel(const GiState* st, cons
         const GiChunk&  c  = chunks[R.slot];
         const uint32_t  lo = it.y << GI_PIECE_LOG2, hi = min(R.out_len, lo + GI_PIECE);
         const uint16_t* s  = pool + ((uint64_t)c.piece[it.y] << GI_PIECE_LOG2);
-        const uint16_t* pr = p_store + (uint64_t)it.x * GI_WINDOW;
         const uint8_t*  wg = w_store + (uint64_t)(it.x / GI_GROUP) * GI_WINDOW;
         uint8_t*        d  = text + R.text_off + lo;
+        if (c.markers && have != it.x)
+        {
+            __syncthreads();
+            const uint4* src = reinterpret_cast<const uint4*>(p_store + (uint64_t)it.x * GI_WINDOW);
+            for (uint32_t i = threadIdx.x; i < GI_WINDOW / 8u; i += 512u)
+                reinterpret_cast<uint4*>(P)[i] = src[i];
+            have = it.x;
+            __syncthreads();
+        }
         const uint32_t cnt4 = (hi - lo) & ~3u;
-        for (uint32_t i = threadIdx.x * 4u; i < cnt4; i += 1024u)
+        for (uint32_t i = threadIdx.x * 4u; i < cnt4; i += 2048u)
         {
             const uint2 two = *reinterpret_cast<const uint2*>(s + i); // (a piece begins on a 64 KiB boundary of the pool)
             uint32_t    v[4] = { two.x & 0xFFFFu, two.x >> 16, two.y & 0xFFFFu, two.y >> 16 };
@@ -1765,7 +1775,7 @@ __global__ __launch_bounds__(256) void gi_resolve_kernel(const GiState* st, cons
             for (int k = 0; k < 4; ++k)
                 if (v[k] >= 256u)
                 {
-                    v[k] = pr[v[k] - 256u];
+                    v[k] = P[v[k] - 256u];
                     if (v[k] >= 256u)
                         v[k] = wg[v[k] - 256u];
                 }
@@ -1780,12 +1790,12 @@ __global__ __launch_bounds__(256) void gi_resolve_kernel(const GiState* st, cons
                 d[i + 3] = (uint8_t)v[3];
             }
         }
-        for (uint32_t i = cnt4 + threadIdx.x; i < hi - lo; i += 256u)
+        for (uint32_t i = cnt4 + threadIdx.x; i < hi - lo; i += 512u)
         {
             uint32_t v = s[i];
             if (v >= 256u)
             {
-                v = pr[v - 256u];
+                v = P[v - 256u];
                 if (v >= 256u)
                     v = wg[v - 256u];
             }
@@ -1793,7 +1803,6 @@ __global__ __launch_bounds__(256) void gi_resolve_kernel(const GiState* st, cons
         }
     }
 }
-
 
 // ---- where the records of a step's text begin: cut points for the caller's batches ----------------------------------------------------
 #define GI_CUT_TILE 4096u
@@ -1973,6 +1982,23 @@ __global__ __launch_bounds__(256) void gi_crc_kernel(const uint8_t* __restrict__
         uint64_t q = cur;
         for (; q < end && ((uintptr_t)(text + q) & 3u); ++q)
             c = tab[0][(c ^ text[q]) & 0xFFu] ^ (c >> 8);
+        for (; q < end && ((uintptr_t)(text + q) & 15u) && q + 4u <= end; q += 4u)
+        {
+            c ^= *reinterpret_cast<const uint32_t*>(text + q);
+            c = tab[3][c & 0xFFu] ^ tab[2][(c >> 8) & 0xFFu] ^ tab[1][(c >> 16) & 0xFFu] ^ tab[0][c >> 24];
+        }
+        // (sixteen bytes a load: a lane's piece is its own, so every load of a wave touches 64 lines -- four times fewer of them this way)
+        for (; q + 16u <= end; q += 16u)
+        {
+            const uint4    v = *reinterpret_cast<const uint4*>(text + q);
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                c ^= w[k];
+                c = tab[3][c & 0xFFu] ^ tab[2][(c >> 8) & 0xFFu] ^ tab[1][(c >> 16) & 0xFFu] ^ tab[0][c >> 24];
+            }
+        }
         for (; q + 4u <= end; q += 4u)
         {
             c ^= *reinterpret_cast<const uint32_t*>(text + q);
@@ -2359,7 +2385,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         GN_HIP(hipMemcpyAsync(z->d_text[buf], z->d_text[z->cur] + (z->n_text_last - carry), carry, hipMemcpyDeviceToDevice, z->st));
     if (s.n_work)
     {
-        hipLaunchKernelGGL(gi_resolve_kernel, dim3(std::min<uint32_t>(s.n_work, (uint32_t)z->n_cu * 8u)), dim3(256), 0, z->st, z->d_state, z->d_chunks, z->d_real,
+        hipLaunchKernelGGL(gi_resolve_kernel, dim3(std::min<uint32_t>(s.n_work, (uint32_t)z->n_cu * 2u)), dim3(512), 0, z->st, z->d_state, z->d_chunks, z->d_real,
                            z->d_work, z->d_pool, z->d_p_store, z->d_w_store, z->d_text[buf] + carry);
         GN_HIP(hipGetLastError());
     }

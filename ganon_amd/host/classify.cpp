@@ -505,10 +505,32 @@ private:
 // slab IS the batch (no copy); for pairs the slabs of file 1 become batches and the mates are copied next to them from
 // the slabs of file 2.  Everything else -- compressed input, FASTA, wrapped records, and whatever follows the first
 // record the parallel parser does not take -- goes through the sequential reader, from the byte where the slabs stopped.
+// Ends of device text sources (threads joined, gigabytes of device buffers freed: some twenty milliseconds): they run beside the last
+// batches and are waited for when ganon_classify leaves, not by the reader.
+struct Cleanups
+{
+    std::mutex               m;
+    std::vector<std::thread> th;
+    void add(std::thread t)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        th.push_back(std::move(t));
+    }
+    void join_all()
+    {
+        std::vector<std::thread> mine;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            mine.swap(th);
+        }
+        for (auto& t : mine)
+            t.join();
+    }
+} g_cleanups;
+
 void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq, Backend* device_text)
 {
     uint64_t       seq = 0;
-    std::vector<std::thread> cleanups; // ends of device text sources, joined behind the queue's end
     MateCopier     copier(queue, (unsigned)env_size("GANON_HOST_MATE_THREADS", 3));
     // slab parsers: half of the cores this process may use, between 4 and 12 (the other half: reader, mate copier, device
     // workers, post pool); 8 on the 16-core quota of the boxes the numbers in DESIGN.md come from
@@ -619,7 +641,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                         file_done = true;
                     // (the source's end -- threads joined, gigabytes of device buffers freed -- takes some ten milliseconds the last batches
                     //  need not wait for: it waits for its own pieces' holders anyway)
-                    cleanups.emplace_back([s = std::shared_ptr<DeviceTextSource>(std::move(src))]() mutable { s.reset(); });
+                    g_cleanups.add(std::thread([s = std::shared_ptr<DeviceTextSource>(std::move(src))]() mutable { s.reset(); }));
                 }
             }
             // ---- raw pieces: the backend finds the records (single-end, uncompressed four-line FASTQ) ------------------------
@@ -1007,8 +1029,6 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
     }
     copier.drain();
     queue.done();
-    for (auto& t : cleanups)
-        t.join();
     g_cpu.reader.add_this_thread();
 }
 
@@ -1040,6 +1060,10 @@ void append_line(std::string& dst, std::string_view id, std::string_view target,
 // ---- the classifier (GanonClassify.cpp:1375-1674) -------------------------------------------------------------
 static bool ganon_classify(Config config)
 {
+    struct JoinCleanups
+    {
+        ~JoinCleanups() { g_cleanups.join_all(); }
+    } join_cleanups;
     Stopwatch whole_run, loading, classifying;
     whole_run.start();
 
