@@ -293,6 +293,23 @@ class HipInflate:
         _check(self._L.gn_inflate_text(self._h, _p(out), off, n))
         return out
 
+    def text_device(self) -> Tuple[int, int]:
+        """(device pointer, bytes) of the last step's text"""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _check(self._L.gn_inflate_text_device(self._h, C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
+
+    def cuts(self, lines_per_record: int, piece_bytes: int) -> np.ndarray:
+        """gn_inflate_cuts: record boundaries of the last step's text, one at or behind every multiple of piece_bytes + the last one"""
+        _, n = self.text_device()
+        out = np.empty(n // max(1, piece_bytes) + 2, dtype=np.uint64)
+        k = C.c_uint32()
+        _check(self._L.gn_inflate_cuts(self._h, lines_per_record, piece_bytes, _p(out), out.size, C.byref(k)))
+        return out[:k.value].copy()
+
+    def set_carry(self, n_tail: int) -> None:
+        _check(self._L.gn_inflate_set_carry(self._h, n_tail))
+
     def stats(self) -> dict:
         st = InflateStats()
         _check(self._L.gn_inflate_get_stats(self._h, C.byref(st)))
@@ -563,6 +580,31 @@ class HipStream:
         _check(L.gn_stream_fastq_index(self._h, C.byref(n), C.byref(nb), C.byref(pb)))
         self.n_reads = n.value
         return n.value, nb.value, pb.value
+
+    def upload_text_device(self, d_text: int, n_bytes: int, fasta=False, src_device: int = 0) -> Tuple[int, int, int]:
+        """the same for a text that lies in device memory (gn_stream_upload_text_device): -> (reads, bases, parsed_bytes)"""
+        L = load_library()
+        _check(L.gn_stream_upload_text_device(self._h, C.c_void_p(d_text), n_bytes, int(fasta), src_device))
+        n, nb, pb = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(L.gn_stream_fastq_index(self._h, C.byref(n), C.byref(nb), C.byref(pb)))
+        self.n_reads = n.value
+        return n.value, nb.value, pb.value
+
+    def fastq_headers(self) -> Tuple[bytes, np.ndarray]:
+        """gn_stream_fastq_headers: the batch's header lines back to back, and record i's offset (n_reads + 1 entries)"""
+        L = load_library()
+        off = np.empty(self.n_reads + 1, dtype=np.uint32)
+        cap = max(4096, 64 * self.n_reads)
+        for _ in range(2):
+            dst = np.empty(cap, dtype=np.uint8)
+            nb = C.c_uint64()
+            rc = L.gn_stream_fastq_headers(self._h, _p(dst), cap, _p(off), C.byref(nb))
+            if rc == -75:
+                cap = int(nb.value) + 64
+                continue
+            _check(rc)
+            return dst[:nb.value].tobytes(), off
+        raise GanonHipError(-75, "gn_stream_fastq_headers: the header lines did not fit twice")
 
     def upload_text_pair(self, text1, text2, fasta=False) -> Tuple[int, int, int]:
         """the two mate files' pieces as text -> (pairs, parsed_bytes1, parsed_bytes2); the stream then holds the pairs like after upload()"""

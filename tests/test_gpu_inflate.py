@@ -185,3 +185,53 @@ def test_a_flipped_bit_that_still_decodes_is_caught_by_the_crc():
     with pytest.raises(hip.GanonHipError) as e:
         _inflate(bytes(gz), chunk=65536)
     assert e.value.code == -34
+
+
+def test_cuts_carry_and_batches_from_device_text():
+    """the C ABI of the compressed-input path: gn_inflate_step -> gn_inflate_cuts -> gn_stream_upload_text_device ->
+    gn_stream_fastq_headers must yield exactly the records of the text, step after step, with the record a step's end cuts carried over"""
+    import ganon_fixtures as gf
+    recs = [TEXT[i:j] for i, j in zip(*(lambda nl: ([0] + [nl[k] + 1 for k in range(3, len(nl) - 1, 4)], [nl[k] + 1 for k in range(3, len(nl), 4)]))(
+        [i for i, b in enumerate(TEXT) if b == 10]))]
+    assert b"".join(recs) == TEXT
+    gz = np.frombuffer(_gz(TEXT, 6), dtype=np.uint8)
+    ibf = gf.random_ibf(64, 257, 3, 0.3, 1)
+    flt = hip.HipFilter.ibf(ibf.data, ibf.bins, ibf.bin_size, ibf.hash_funs)
+    with hip.HipInflate(gz.size, chunk_bytes=4096, step_bytes=262144) as z:
+        z.feed(gz)
+        seen, done, steps = [], False, 0
+        stream = None
+        while not done:
+            n, done = z.step()
+            steps += 1
+            if n == 0:
+                continue
+            cuts = z.cuts(4, 100_000)
+            text = z.text(n)
+            assert cuts.size and all(text[int(c) - 1] == 10 for c in cuts) and list(cuts) == sorted(set(int(c) for c in cuts))
+            # every cut is a record boundary: the number of newlines before it is a multiple of four
+            nl_before = np.cumsum(text == 10)
+            assert all(int(nl_before[int(c) - 1]) % 4 == 0 for c in cuts)
+            last = int(cuts[-1])
+            assert last == (int(np.nonzero(text == 10)[0][(int(nl_before[-1]) // 4) * 4 - 1]) + 1 if nl_before[-1] >= 4 else 0)
+            ptr, nb = z.text_device()
+            assert nb == n
+            if flt is not None:
+                if stream is None:
+                    stream = hip.HipStream(flt, 200_000, 4 << 20)
+                a = 0
+                for c in cuts:
+                    c = int(c)
+                    k, _, parsed = stream.upload_text_device(ptr + a, c - a)
+                    assert parsed == c - a
+                    hdr, off = stream.fastq_headers()
+                    for i in range(k):
+                        seen.append(hdr[off[i]:off[i + 1]])
+                    a = c
+            if not done:
+                z.set_carry(n - last)
+            else:
+                assert last == n
+        assert steps > 2
+        if flt is not None:
+            assert seen == [r[:r.index(b"\n") + 1] for r in recs]
