@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(256) void gi_nl_tiles_kernel(const uint8_t* __restr
 // thread j < m: the first record boundary at or behind (j + 1) * piece; thread m: the last record boundary of the text.  A record
 // boundary = the byte behind newline number l (from 0) with (l + 1) % lpr == 0.  ~0 = none.
 __global__ void gi_cuts_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ pre /* tiles + 1: exclusive sums */, uint32_t tiles,
-                               uint32_t lpr, uint64_t piece, uint32_t m, unsigned long long* __restrict__ cuts)
+                               uint32_t lpr, uint64_t piece, uint32_t m, unsigned long long* __restrict__ cuts /* m + 1 offsets, then m + 1 line counts */)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > m)
@@ -1891,7 +1891,43 @@ __global__ void gi_cuts_kernel(const uint8_t* __restrict__ text, uint64_t n, con
                 break;
             --left;
         }
-    cuts[j] = q + 1u;
+    cuts[j]          = q + 1u;
+    cuts[m + 1u + j] = want + 1u; // lines (newlines) in front of the cut
+}
+
+// thread j: the offset behind line number lines[j] (a count of newlines from the text's first byte; > 0), ~0 when the text holds fewer
+__global__ void gi_cut_lines_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ pre, uint32_t tiles,
+                                    const unsigned long long* __restrict__ lines, uint32_t m, unsigned long long* __restrict__ out)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m)
+        return;
+    const uint64_t total = pre[tiles];
+    if (lines[j] == 0 || lines[j] > total)
+    {
+        out[j] = lines[j] == 0 ? 0ull : ~0ull;
+        return;
+    }
+    const uint64_t want = lines[j] - 1u;
+    uint32_t       lo = 0, hi = tiles;
+    while (hi - lo > 1u)
+    {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (pre[mid] <= want)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    uint64_t left = want - pre[lo];
+    uint64_t q    = (uint64_t)lo * GI_CUT_TILE;
+    for (; q < n; ++q)
+        if (text[q] == '\n')
+        {
+            if (left == 0)
+                break;
+            --left;
+        }
+    out[j] = q + 1u;
 }
 
 
@@ -2084,6 +2120,7 @@ struct gn_inflate
     size_t    cut_tmp_bytes = 0;
     unsigned long long* d_cuts = nullptr;
     uint32_t  cut_tiles_cap = 0, cuts_cap = 0;
+    uint64_t  lines_of_step = ~0ull; // the step whose text the line index in d_cut_cnt describes
     bool      ended = false;
     // totals
     gn_inflate_stats stats{};
@@ -2497,19 +2534,11 @@ extern "C" int gn_inflate_set_carry(gn_inflate* z, uint64_t n_tail)
     return GN_OK;
 }
 
-extern "C" int gn_inflate_cuts(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_bytes, uint64_t* cuts, uint32_t cap, uint32_t* n_cuts)
+// newline counts per 4 KiB tile of the last step's text and their exclusive sums (once per step)
+static int gi_line_index(gn_inflate* z, uint32_t m_cuts)
 {
-    if (!z || !cuts || !n_cuts || lines_per_record == 0 || piece_bytes == 0)
-        return gn_fail(GN_EINVAL, "gn_inflate_cuts: bad argument");
-    *n_cuts = 0;
-    const uint64_t n = z->n_text_last;
-    if (n == 0)
-        return GN_OK;
-    GN_HIP(hipSetDevice(z->device));
+    const uint64_t n     = z->n_text_last;
     const uint32_t tiles = (uint32_t)((n + GI_CUT_TILE - 1) / GI_CUT_TILE);
-    const uint32_t m     = (uint32_t)(n / piece_bytes);
-    if (m + 1u > cap)
-        return gn_fail(GN_EINVAL, "gn_inflate_cuts: room for %u cuts, %u needed", cap, m + 1u);
     if (tiles + 1u > z->cut_tiles_cap)
     {
         if (z->d_cut_cnt)
@@ -2526,33 +2555,93 @@ extern "C" int gn_inflate_cuts(gn_inflate* z, uint32_t lines_per_record, uint64_
         GN_HIP(hipMalloc(&z->d_cut_tmp, z->cut_tmp_bytes));
         z->cut_tiles_cap = want;
     }
-    if (m + 1u > z->cuts_cap)
+    if (3u * m_cuts + 8u > z->cuts_cap)
     {
         if (z->d_cuts)
             hipFree(z->d_cuts);
         z->d_cuts = nullptr;
-        GN_HIP(hipMalloc((void**)&z->d_cuts, (size_t)(m + 64u) * sizeof(unsigned long long)));
-        z->cuts_cap = m + 64u;
+        GN_HIP(hipMalloc((void**)&z->d_cuts, (size_t)(3u * m_cuts + 256u) * sizeof(unsigned long long)));
+        z->cuts_cap = 3u * m_cuts + 256u;
     }
+    if (z->lines_of_step == z->stats.steps)
+        return GN_OK;
     uint32_t* cnt = z->d_cut_cnt;
     uint32_t* pre = z->d_cut_cnt + z->cut_tiles_cap;
     GN_HIP(hipMemsetAsync(cnt + tiles, 0, sizeof(uint32_t), z->st));
-    hipLaunchKernelGGL(gi_nl_tiles_kernel, dim3(tiles), dim3(256), 0, z->st, z->d_text[z->cur], n, cnt);
+    if (tiles)
+        hipLaunchKernelGGL(gi_nl_tiles_kernel, dim3(tiles), dim3(256), 0, z->st, z->d_text[z->cur], n, cnt);
     size_t tmp = z->cut_tmp_bytes;
     GN_HIP(hipcub::DeviceScan::ExclusiveSum(z->d_cut_tmp, tmp, cnt, pre, (int)(tiles + 1u), z->st));
+    GN_HIP(hipGetLastError());
+    z->lines_of_step = z->stats.steps;
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_cuts_lines(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_bytes, uint64_t* cuts, uint64_t* cut_lines, uint32_t cap,
+                                     uint32_t* n_cuts)
+{
+    if (!z || !cuts || !n_cuts || lines_per_record == 0 || piece_bytes == 0)
+        return gn_fail(GN_EINVAL, "gn_inflate_cuts: bad argument");
+    *n_cuts = 0;
+    const uint64_t n = z->n_text_last;
+    if (n == 0)
+        return GN_OK;
+    GN_HIP(hipSetDevice(z->device));
+    const uint32_t tiles = (uint32_t)((n + GI_CUT_TILE - 1) / GI_CUT_TILE);
+    const uint32_t m     = (uint32_t)(n / piece_bytes);
+    if (m + 1u > cap)
+        return gn_fail(GN_EINVAL, "gn_inflate_cuts: room for %u cuts, %u needed", cap, m + 1u);
+    const int rc = gi_line_index(z, m + 1u);
+    if (rc != GN_OK)
+        return rc;
+    uint32_t* pre = z->d_cut_cnt + z->cut_tiles_cap;
     hipLaunchKernelGGL(gi_cuts_kernel, dim3((m + 1u + 63u) / 64u), dim3(64), 0, z->st, z->d_text[z->cur], n, pre, tiles, lines_per_record, piece_bytes, m, z->d_cuts);
     GN_HIP(hipGetLastError());
-    std::vector<unsigned long long> h(m + 1u);
-    GN_HIP(hipMemcpyAsync(h.data(), z->d_cuts, (size_t)(m + 1u) * sizeof(unsigned long long), hipMemcpyDeviceToHost, z->st));
+    std::vector<unsigned long long> h(2u * (m + 1u));
+    GN_HIP(hipMemcpyAsync(h.data(), z->d_cuts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, z->st));
     GN_HIP(hipStreamSynchronize(z->st));
     uint64_t last = 0;
     uint32_t k    = 0;
     for (uint32_t j = 0; j <= m; ++j)
         if (h[j] != ~0ull && h[j] > last && h[j] <= n)
         {
+            if (cut_lines)
+                cut_lines[k] = h[m + 1u + j];
             cuts[k++] = h[j];
             last      = h[j];
         }
     *n_cuts = k;
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_cuts(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_bytes, uint64_t* cuts, uint32_t cap, uint32_t* n_cuts)
+{
+    return gn_inflate_cuts_lines(z, lines_per_record, piece_bytes, cuts, nullptr, cap, n_cuts);
+}
+
+extern "C" int gn_inflate_cut_at_lines(gn_inflate* z, const uint64_t* lines, uint32_t n_lines, uint64_t* offsets, uint64_t* total_lines)
+{
+    if (!z || (!lines && n_lines) || (!offsets && n_lines) || !total_lines)
+        return gn_fail(GN_EINVAL, "gn_inflate_cut_at_lines: null argument");
+    *total_lines     = 0;
+    const uint64_t n = z->n_text_last;
+    GN_HIP(hipSetDevice(z->device));
+    const uint32_t tiles = (uint32_t)((n + GI_CUT_TILE - 1) / GI_CUT_TILE);
+    const int      rc    = gi_line_index(z, n_lines + 1u);
+    if (rc != GN_OK)
+        return rc;
+    uint32_t*           pre  = z->d_cut_cnt + z->cut_tiles_cap;
+    unsigned long long* d_in = z->d_cuts + (n_lines + 8u);
+    if (n_lines)
+    {
+        GN_HIP(hipMemcpyAsync(d_in, lines, (size_t)n_lines * sizeof(unsigned long long), hipMemcpyHostToDevice, z->st));
+        hipLaunchKernelGGL(gi_cut_lines_kernel, dim3((n_lines + 63u) / 64u), dim3(64), 0, z->st, z->d_text[z->cur], n, pre, tiles, d_in, n_lines, z->d_cuts);
+        GN_HIP(hipGetLastError());
+        GN_HIP(hipMemcpyAsync(offsets, z->d_cuts, (size_t)n_lines * sizeof(unsigned long long), hipMemcpyDeviceToHost, z->st));
+    }
+    uint32_t total32 = 0;
+    GN_HIP(hipMemcpyAsync(&total32, pre + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, z->st));
+    GN_HIP(hipStreamSynchronize(z->st));
+    *total_lines = total32;
     return GN_OK;
 }

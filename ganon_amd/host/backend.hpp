@@ -128,6 +128,9 @@ struct ReadBatch
     uint64_t              dev_bytes  = 0;
     int                   dev_device = -1;
     std::shared_ptr<void> dev_hold;  // keeps the device buffer alive; dropped once the text is copied into the worker's stream
+    const uint8_t*        dev_text2  = nullptr; // ... of a pair: the mate file's piece (the same records by number), same device
+    uint64_t              dev_bytes2 = 0;
+    std::shared_ptr<void> dev_hold2;
     uint64_t raw_bytes() const { return dev_text ? dev_bytes : text.size(); }
     std::unique_ptr<RawTicket> ticket;
     size_t size() const { return raw ? rec_at.size() : id_off.size() - 1; }
@@ -197,6 +200,7 @@ struct DeviceTextPiece
     const uint8_t*        dev = nullptr;
     uint64_t              bytes = 0;
     uint64_t              at = 0; // offset of the piece's first byte in the decompressed stream
+    uint64_t              lines = 0; // lines (newlines) of the piece; ~0: the file's last bytes, not a whole record
     int                   device = -1;
     std::shared_ptr<void> hold;
 };
@@ -207,13 +211,20 @@ public:
     // the next piece; false at the end of the stream (err empty) or when the device path gives the file up (err says why): a host
     // reader then continues at decompressed offset delivered()
     virtual bool        next(DeviceTextPiece& out, std::string& err) = 0;
+    // a source opened by_lines (the mate file of a pair): the next `lines` lines as one piece -- fewer (out.lines says) where the stream
+    // ends; ~0: what is left of the text at hand
+    virtual bool        next_lines(uint64_t /*lines*/, DeviceTextPiece& /*out*/, std::string& err)
+    {
+        err = "not a source by lines";
+        return false;
+    }
     virtual uint64_t    delivered() const = 0;
     virtual bool        fasta() const = 0;
     virtual std::string report() const { return std::string(); }
 };
 
 // devgzip.cpp (binaries linked with libganon_hip.so only): nullptr when the file is not one for the device inflater
-std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, int device, size_t piece_bytes, size_t min_bytes);
+std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, int device, size_t piece_bytes, size_t min_bytes, bool by_lines);
 
 // One device (or the test checker): receives filters, classifies batches.  Not thread-safe; one host thread each.
 class Backend : public FilterSink
@@ -229,7 +240,10 @@ public:
     virtual bool tokenises_fastq() const { return false; }
     // Optional.  A gzip-compressed FASTQ / FASTA file as text pieces in this backend's device memory; nullptr: not a file for that (not
     // gzip, blocked gzip, too small, no room) or not a backend that does it.  piece_bytes = text per piece, about.
-    virtual std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& /*path*/, size_t /*piece_bytes*/, size_t /*min_bytes*/) { return nullptr; }
+    virtual std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& /*path*/, size_t /*piece_bytes*/, size_t /*min_bytes*/, bool /*by_lines*/ = false)
+    {
+        return nullptr;
+    }
     // Raw batches: takes batch.text, finds the records.  n_reads = records before the first that is not a plain four-line
     // record (or the end of the text inside one); parsed_bytes = where that one begins (== text.size(): all of it is records).
     // A paired raw batch (batch.paired, batch.text2 = the mate file's piece with the same records by number): the pairs both

@@ -123,9 +123,9 @@ public:
         return tokenise_begin(b, err) && tokenise_end(b, n_reads, parsed_bytes, err);
     }
 
-    std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& path, size_t piece_bytes, size_t min_bytes) override
+    std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& path, size_t piece_bytes, size_t min_bytes, bool by_lines) override
     {
-        return open_device_gzip(path, device_, piece_bytes, min_bytes);
+        return open_device_gzip(path, device_, piece_bytes, min_bytes, by_lines);
     }
 
     bool tokenise_begin(ReadBatch& b, std::string& err) override
@@ -134,7 +134,7 @@ public:
             return false;
         auto t = std::chrono::steady_clock::now();
         const bool     pair  = b.paired && b.raw;
-        const uint64_t nb    = pair ? ((b.text.size() + 15) & ~15ull) + b.text2.size() : b.raw_bytes();
+        const uint64_t nb    = pair ? ((b.raw_bytes() + 15) & ~15ull) + (b.dev_text ? b.dev_bytes2 : b.text2.size()) : b.raw_bytes();
         const uint64_t reads = std::max<uint64_t>(hint_reads_, b.raw_bytes() / 40); // (records shorter than 40 bytes on average: the rest goes the slow way)
         // (prepare() sized the streams by the same rule: no re-creation unless a piece is larger than the reader said)
         std::vector<gn_stream*>& sources = tok_sources_;
@@ -155,7 +155,8 @@ public:
                     t = now;
                 }
                 const int fmt = b.raw_fasta ? GN_TEXT_FASTA : GN_TEXT_FASTQ;
-                if ((b.dev_text ? gn_stream_upload_text_device(part.s, b.dev_text, nb, fmt, b.dev_device)
+                if ((b.dev_text && pair ? gn_stream_upload_text_pair_device(part.s, b.dev_text, b.dev_bytes, b.dev_text2, b.dev_bytes2, fmt, b.dev_device)
+                     : b.dev_text      ? gn_stream_upload_text_device(part.s, b.dev_text, nb, fmt, b.dev_device)
                      : pair     ? gn_stream_upload_text_pair(part.s, b.text.data(), b.text.size(), b.text2.data(), b.text2.size(), fmt)
                                 : gn_stream_upload_text(part.s, b.text.data(), nb, fmt))
                     != GN_OK)
@@ -196,6 +197,7 @@ public:
             }
         }
         b.dev_hold.reset(); // (the text is in every stream now: the inflater may write that buffer again)
+        b.dev_hold2.reset();
         sec_tok_wait_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
         return !sources.empty();
     }

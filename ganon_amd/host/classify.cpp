@@ -563,6 +563,9 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     rb.dev_text = nullptr;
                     rb.dev_bytes = 0;
                     rb.dev_hold.reset();
+                    rb.dev_text2 = nullptr;
+                    rb.dev_bytes2 = 0;
+                    rb.dev_hold2.reset();
                 }
                 else
                     rb = ReadBatch();
@@ -644,6 +647,96 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     g_cleanups.add(std::thread([s = std::shared_ptr<DeviceTextSource>(std::move(src))]() mutable { s.reset(); }));
                 }
             }
+            // ---- both gzip files of a pair inflated on the device: file 1 in pieces, file 2 cut where the same records end ---------------
+            // (GanonClassify.cpp:1240-1252: ids from file 1, file 2 consumed with take(n_reads) -- pairs go by record number)
+            if (raw_fastq && paired && device_text)
+            {
+                const size_t piece = std::max<size_t>(slab_bytes / 2, 1 << 16), dmin = env_size("GANON_HOST_DEVICE_INFLATE_MIN", 1u << 20);
+                auto         src1  = device_text->open_gzip_text(pair.mate1, piece, dmin);
+                auto         src2  = src1 ? device_text->open_gzip_text(pair.mate2, piece, 0, true) : nullptr;
+                if (src1 && src2)
+                {
+                    auto            tracker = std::make_shared<RawFileTracker>();
+                    size_t          pieces  = 0;
+                    DeviceTextPiece p1, p2;
+                    std::string     why;
+                    bool            stopped = false; // a piece of file 1 was taken but could not be paired: the sequential readers start there
+                    uint64_t        stop1 = 0, stop2 = 0;
+                    while (src1->next(p1, why))
+                    {
+                        std::string why2;
+                        p2 = DeviceTextPiece();
+                        if (!src2->next_lines(p1.lines, p2, why2) && !why2.empty())
+                        {
+                            why     = "mate file: " + why2;
+                            stopped = true;
+                            stop1   = p1.at;
+                            stop2   = src2->delivered();
+                            break;
+                        }
+                        if (p2.bytes == 0 && why2.empty() && p2.hold == nullptr) // file 2 has ended: the mates stay empty, the sequential reader's business
+                        {
+                            stopped = true;
+                            stop1   = p1.at;
+                            stop2   = UINT64_MAX;
+                            break;
+                        }
+                        rb.raw        = true;
+                        rb.raw_fasta  = src1->fasta();
+                        rb.text.clear();
+                        rb.text2.clear();
+                        rb.dev_text   = p1.dev;
+                        rb.dev_bytes  = p1.bytes;
+                        rb.dev_device = p1.device;
+                        rb.dev_hold   = std::move(p1.hold);
+                        rb.dev_text2  = p2.dev;
+                        rb.dev_bytes2 = p2.bytes;
+                        rb.dev_hold2  = std::move(p2.hold);
+                        rb.text_at    = p1.at;
+                        rb.text2_at   = p2.at;
+                        rb.raw_keep   = 0;
+                        rb.ticket.reset(new RawTicket{ tracker, pieces++ });
+                        rb.seq = seq++;
+                        copier.deliver(std::move(rb));
+                        fresh();
+                    }
+                    p1 = DeviceTextPiece();
+                    p2 = DeviceTextPiece();
+                    if (std::getenv("GANON_HOST_TIMING") || !why.empty())
+                        std::cerr << "[host input] " << pair.mate1 << ": " << src1->report() << "; " << pair.mate2 << ": " << src2->report()
+                                  << (why.empty() ? std::string() : "; given up: " + why) << std::endl;
+                    uint64_t at = 0, at2 = 0;
+                    if (!tracker->wait_all(pieces, at, nullptr, &at2))
+                    {
+                        if (at == UINT64_MAX) // (the pipeline is going down)
+                            file_done = true;
+                        else
+                        {
+                            resume1  = at;
+                            resume2  = at2;
+                            fallback = true;
+                        }
+                    }
+                    else if (stopped)
+                    {
+                        resume1  = stop1;
+                        resume2  = stop2;
+                        fallback = true;
+                    }
+                    else if (!why.empty()) // file 1's device path gave up behind the pieces it delivered
+                    {
+                        resume1  = src1->delivered();
+                        resume2  = src2->delivered();
+                        fallback = true;
+                    }
+                    else
+                        file_done = true; // (whatever file 2 holds beyond file 1's records is not input: take(n_reads))
+                }
+                if (src1)
+                    g_cleanups.add(std::thread([s = std::shared_ptr<DeviceTextSource>(std::move(src1))]() mutable { s.reset(); }));
+                if (src2)
+                    g_cleanups.add(std::thread([s = std::shared_ptr<DeviceTextSource>(std::move(src2))]() mutable { s.reset(); }));
+            }
             // ---- raw pieces: the backend finds the records (single-end, uncompressed four-line FASTQ) ------------------------
             if (raw_fastq && !paired && !file_done && !fallback)
             {
@@ -712,7 +805,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             // first mate file on ($GANON_HOST_PAIR_TEXT=1 / 0: always / never).
             struct stat st1;
             const char* force     = std::getenv("GANON_HOST_PAIR_TEXT");
-            const bool  pair_text = raw_fastq && paired
+            const bool  pair_text = raw_fastq && paired && !file_done && !fallback
                                    && (force ? force[0] != '0' : (::stat(pair.mate1.c_str(), &st1) == 0 && (uint64_t)st1.st_size >= (4ull << 30)));
             if (pair_text)
             {

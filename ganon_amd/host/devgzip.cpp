@@ -11,6 +11,8 @@
 //   stepper thread: gn_inflate_step when a step's bytes are there, gn_inflate_cuts, pieces into a queue; the record the step's end
 //                   cuts is carried into the next step's text (gn_inflate_set_carry); a step's buffer is written again two steps
 //                   later, so the stepper waits until every piece of step k is released before it runs step k + 2
+// The mate file of a pair is opened `by_lines`: no stepper thread; the caller asks for "the next n lines" (the lines the first file's
+// piece holds: parse_reads pairs records by number, GanonClassify.cpp:1240-1252) and the step that has to run for it runs in that call.
 // Anything the device path refuses (GN_ERANGE: damaged data, a wrong ISIZE, expansion beyond its buffers, ...) ends the source with
 // an error text; the caller's sequential zlib reader continues at delivered() and produces the records and the message from there.
 #include "backend.hpp"
@@ -81,8 +83,9 @@ public:
             ::close(fd_);
     }
 
-    bool start(const std::string& path, int device, size_t piece_bytes, size_t min_bytes)
+    bool start(const std::string& path, int device, size_t piece_bytes, size_t min_bytes, bool by_lines)
     {
+        by_lines_ = by_lines;
         std::string base = path;
         if (!ends_with(base, ".gz"))
             return false;
@@ -112,6 +115,8 @@ public:
             z_ = nullptr;
             return false; // (no room for the file and the step buffers beside the filters: the host inflater takes it)
         }
+        if (sb)
+            l_step_ = (uint64_t)std::atoll(sb);
         n_blocks_ = (size_ + kBlock - 1) / kBlock;
         for (unsigned i = 0; i < kRing; ++i)
         {
@@ -124,7 +129,8 @@ public:
         for (unsigned t = 0; t < n_readers; ++t)
             readers_.emplace_back([this] { read_loop(); });
         feeder_  = std::thread([this] { feed_loop(); });
-        stepper_ = std::thread([this] { step_loop(); });
+        if (!by_lines_)
+            stepper_ = std::thread([this] { step_loop(); });
         return true;
     }
 
@@ -142,6 +148,106 @@ public:
         delivered_ = out.at + out.bytes;
         cv_.notify_all();
         return true;
+    }
+    // by_lines: the step that is needed runs here, on the caller's thread
+    bool next_lines(uint64_t lines, DeviceTextPiece& out, std::string& err) override
+    {
+        if (!by_lines_)
+        {
+            err = "not a source by lines";
+            return false;
+        }
+        for (;;)
+        {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!error_.empty())
+                {
+                    err = error_;
+                    return false;
+                }
+            }
+            if (l_eof_)
+                return false;
+            if (!l_have_)
+            {
+                l_want_       = std::min<uint64_t>(size_, l_want_ + l_step_ + (4ull << 20));
+                const int buf = (int)(l_step_no_ & 1u);
+                {
+                    std::unique_lock<std::mutex> lk(m_);
+                    cv_.wait(lk, [&] { return stop_ || finished_ || (fed_bytes_ >= l_want_ && held_[buf] == 0); });
+                    if (stop_ || finished_)
+                    {
+                        err = error_;
+                        return false;
+                    }
+                }
+                uint64_t n_text = 0;
+                int      done   = 0;
+                if (gn_inflate_step(z_, &n_text, &done) != GN_OK)
+                {
+                    std::lock_guard<std::mutex> lk(m_);
+                    fail_locked(gn_last_error());
+                    err = error_;
+                    return false;
+                }
+                uint64_t dn = 0;
+                gn_inflate_text_device(z_, &l_text_, &dn);
+                l_n_      = n_text;
+                l_served_ = 0;
+                l_lines_  = 0;
+                l_done_   = done != 0;
+                l_buf_    = buf;
+                l_have_   = true;
+                ++l_step_no_;
+            }
+            uint64_t off = 0, total = 0;
+            const uint64_t ask = lines == ~0ull ? ~0ull : l_lines_ + lines;
+            if (gn_inflate_cut_at_lines(z_, &ask, lines == ~0ull ? 0u : 1u, &off, &total) != GN_OK)
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                fail_locked(gn_last_error());
+                err = error_;
+                return false;
+            }
+            const bool whole = lines != ~0ull && off != ~0ull;
+            if (!whole && !l_done_ && lines != ~0ull)
+            {
+                // the text at hand ends before the lines do: what is left of it begins the next step's text
+                if (gn_inflate_set_carry(z_, l_n_ - l_served_) != GN_OK)
+                {
+                    std::lock_guard<std::mutex> lk(m_);
+                    fail_locked(gn_last_error());
+                    err = error_;
+                    return false;
+                }
+                l_at_ += l_served_;
+                l_have_ = false;
+                continue;
+            }
+            const uint64_t end = whole ? off : l_n_;
+            out.dev    = l_text_ + l_served_;
+            out.bytes  = end - l_served_;
+            out.at     = l_at_ + l_served_;
+            out.device = device_;
+            out.lines  = whole ? lines : total - l_lines_;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                const int buf = l_buf_;
+                ++held_[buf];
+                out.hold = std::shared_ptr<void>(nullptr, [this, buf](void*) {
+                    std::lock_guard<std::mutex> lk2(m_);
+                    --held_[buf];
+                    cv_.notify_all();
+                });
+            }
+            l_lines_ += whole ? lines : total - l_lines_;
+            l_served_ = end;
+            delivered_ = out.at + out.bytes;
+            if (!whole)
+                l_eof_ = true; // (the stream's end, or the caller asked for whatever is left)
+            return out.bytes != 0 || whole;
+        }
     }
     uint64_t    delivered() const override { return delivered_; }
     bool        fasta() const override { return fasta_; }
@@ -234,7 +340,7 @@ private:
     {
         const uint32_t        lpr = fasta_ ? 2u : 4u;
         uint64_t              stream_at = 0; // decompressed offset of the next step's text[0] (the carried bytes included)
-        std::vector<uint64_t> cuts;
+        std::vector<uint64_t> cuts, cut_lines;
         unsigned              step_no = 0;
         const char*           sb   = std::getenv("GANON_HOST_DEVICE_INFLATE_STEP");
         const uint64_t        step = sb ? (uint64_t)std::atoll(sb) : (256ull << 20);
@@ -262,17 +368,20 @@ private:
             gn_inflate_text_device(z_, &dtext, &dn);
             uint32_t n_cuts = 0;
             cuts.resize((size_t)(n_text / piece_) + 2);
-            if (n_text && gn_inflate_cuts(z_, lpr, piece_, cuts.data(), (uint32_t)cuts.size(), &n_cuts) != GN_OK)
+            cut_lines.resize(cuts.size());
+            if (n_text && gn_inflate_cuts_lines(z_, lpr, piece_, cuts.data(), cut_lines.data(), (uint32_t)cuts.size(), &n_cuts) != GN_OK)
             {
                 std::lock_guard<std::mutex> lk(m_);
                 fail_locked(gn_last_error());
                 return;
             }
             cuts.resize(n_cuts);
+            cut_lines.resize(n_cuts);
             uint64_t last = n_cuts ? cuts.back() : 0;
             if (done && last < n_text) // the file's last bytes are no whole record: the tokeniser says so, the sequential reader takes them
             {
                 cuts.push_back(n_text);
+                cut_lines.push_back(~0ull);
                 last = n_text;
             }
             const uint64_t tail = n_text - last;
@@ -285,14 +394,17 @@ private:
             }
             {
                 std::unique_lock<std::mutex> lk(m_);
-                uint64_t                     from = 0;
-                for (uint64_t c : cuts)
+                uint64_t                     from = 0, lines_before = 0;
+                for (size_t ci = 0; ci < cuts.size(); ++ci)
                 {
+                    const uint64_t  c = cuts[ci];
                     DeviceTextPiece p;
                     p.dev    = dtext + from;
                     p.bytes  = c - from;
                     p.at     = stream_at + from;
                     p.device = device_;
+                    p.lines  = cut_lines[ci] == ~0ull ? ~0ull : cut_lines[ci] - lines_before;
+                    lines_before = cut_lines[ci] == ~0ull ? lines_before : cut_lines[ci];
                     ++held_[buf];
                     p.hold = std::shared_ptr<void>(nullptr, [this, buf](void*) {
                         std::lock_guard<std::mutex> lk2(m_);
@@ -331,14 +443,21 @@ private:
     std::deque<DeviceTextPiece> q_;
     uint64_t              held_[2] = { 0, 0 };
     std::atomic<uint64_t> delivered_{ 0 };
+    // by_lines state (the caller's thread only)
+    bool           by_lines_ = false, l_have_ = false, l_done_ = false, l_eof_ = false;
+    const uint8_t* l_text_ = nullptr;
+    uint64_t       l_n_ = 0, l_served_ = 0, l_lines_ = 0, l_at_ = 0, l_want_ = 0;
+    uint64_t       l_step_ = 256ull << 20;
+    unsigned       l_step_no_ = 0;
+    int            l_buf_ = 0;
 };
 
 } // namespace
 
-std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, int device, size_t piece_bytes, size_t min_bytes)
+std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, int device, size_t piece_bytes, size_t min_bytes, bool by_lines)
 {
     std::unique_ptr<DeviceGzip> g(new DeviceGzip());
-    if (!g->start(path, device, piece_bytes, min_bytes))
+    if (!g->start(path, device, piece_bytes, min_bytes, by_lines))
         return nullptr;
     return g;
 }

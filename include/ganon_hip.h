@@ -213,6 +213,9 @@ int gn_stream_upload_text_pair(gn_stream* s, const uint8_t* text1, uint64_t n_by
  *                             hdr_off[n_reads]; GN_EOVERFLOW with *n_bytes set when cap is too small): ids as in parse_reads
  *                             (GanonClassify.cpp:1244,1262: the whole header line) without the text crossing the link */
 int gn_stream_upload_text_device(gn_stream* s, const uint8_t* d_text, uint64_t n_bytes, int format, int src_device);
+/* both mate files' pieces in device memory (as gn_stream_upload_text_pair otherwise) */
+int gn_stream_upload_text_pair_device(gn_stream* s, const uint8_t* d_text1, uint64_t n_bytes1, const uint8_t* d_text2, uint64_t n_bytes2, int format,
+                                      int src_device);
 int gn_stream_fastq_headers(gn_stream* s, uint8_t* dst, uint64_t cap, uint32_t* hdr_off, uint64_t* n_bytes);
 int gn_stream_text_pair_index(gn_stream* s, uint32_t* n_reads, uint64_t* parsed_bytes1, uint64_t* parsed_bytes2);
 int gn_stream_text_pair_records2(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len);
@@ -432,6 +435,12 @@ int gn_inflate_get_stats(gn_inflate* z, gn_inflate_stats* out);
  *   gn_inflate_set_carry  the last n_tail bytes of the last step's text (the record the step's end cuts) are what the NEXT step's text
  *                         begins with: its n_text counts them, its text holds them in front. */
 int gn_inflate_cuts(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_bytes, uint64_t* cuts, uint32_t cap, uint32_t* n_cuts);
+/* ... for the two files of paired reads (parse_reads takes file 2 with take(n_reads), GanonClassify.cpp:1240-1252: pairs go by record
+ * NUMBER): gn_inflate_cuts_lines also says how many lines lie in front of every cut (cut_lines[i], counted from the text's first byte);
+ * gn_inflate_cut_at_lines answers, for the mate file's text, where those many lines end: offsets[i] = first byte behind line number
+ * lines[i] (0 for 0 lines, ~0 when the text holds fewer), *total_lines = newlines in the text. */
+int gn_inflate_cuts_lines(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_bytes, uint64_t* cuts, uint64_t* cut_lines, uint32_t cap, uint32_t* n_cuts);
+int gn_inflate_cut_at_lines(gn_inflate* z, const uint64_t* lines, uint32_t n_lines, uint64_t* offsets, uint64_t* total_lines);
 int gn_inflate_set_carry(gn_inflate* z, uint64_t n_tail);
 
 #ifdef __cplusplus

@@ -129,3 +129,66 @@ def test_irregular_input_ends_like_the_host_path(sim_db, tmp_path, case):
     assert err(pa) == err(pb)
     if case in ("bad_letter", "truncated_gz"):
         assert err(pa)
+
+
+def _pair_records(n, seed=5):
+    r1, r2 = _sim_reads()
+    rng = np.random.default_rng(seed)
+    a, b = [], []
+    for i in range(n):
+        if rng.random() < 0.6:
+            j = int(rng.integers(0, len(r1)))
+            s1, s2 = r1[j][1], r2[j][1]
+        else:
+            s1 = "".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(60, 151))))
+            s2 = "".join("ACGT"[x] for x in rng.integers(0, 4, size=int(rng.integers(40, 151))))
+        q1 = "".join(chr(33 + int(x)) for x in rng.choice([2, 11, 25, 37], size=len(s1)))
+        q2 = "".join(chr(33 + int(x)) for x in rng.choice([2, 11, 25, 37], size=len(s2)))
+        a.append(f"@pair{i}:{int(rng.integers(1, 99999))}/1\n{s1}\n+\n{q1}\n")
+        b.append(f"@pair{i}:{int(rng.integers(1, 99999))}/2 mate\n{s2}\n+\n{q2}\n")
+    return a, b
+
+
+def _run_pair(binary, sim_db, f1, f2, out_prefix, env=None):
+    import subprocess
+    args = ["--ibf", sim_db["ibf"], "--tax", sim_db["tax"], "--paired-reads", f1 + "," + f2, "-o", out_prefix, "--output-all", "--output-lca",
+            "--output-unclassified", "--output-stats", "--quiet", "--rel-cutoff", "0.25", "--rel-filter", "0.1"]
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([binary] + args, capture_output=True, text=True, timeout=600, env=e)
+    assert p.returncode == 0, p.stderr
+    return p
+
+
+@pytest.mark.parametrize("case", ["equal", "small_steps", "mates_short", "mates_long", "mate_wrapped", "first_truncated_gz"])
+def test_paired_gzip_files_from_the_device(sim_db, oracle_bin, tmp_path, case):
+    a, b = _pair_records(24000, seed=len(case))
+    if case == "mates_short":
+        b = b[:15000]
+    if case == "mates_long":
+        b = b + _pair_records(500, seed=99)[1]
+    if case == "mate_wrapped":
+        h, s, p, q = b[9000].split("\n")[:4]
+        b[9000] = f"{h}\n{s[:20]}\n{s[20:]}\n{p}\n{q[:20]}\n{q[20:]}\n"
+    f1, f2 = str(tmp_path / "r.1.fq.gz"), str(tmp_path / "r.2.fq.gz")
+    g1, g2 = gzip.compress("".join(a).encode(), 6), gzip.compress("".join(b).encode(), 3)
+    if case == "first_truncated_gz":
+        g1 = g1[:len(g1) * 3 // 5]
+    open(f1, "wb").write(g1)
+    open(f2, "wb").write(g2)
+    env = dict(DEV)
+    if case == "small_steps":
+        env.update({"GANON_HOST_DEVICE_INFLATE_CHUNK": "4096", "GANON_HOST_DEVICE_INFLATE_STEP": "262144", "GANON_HOST_SLAB_BYTES": "400000"})
+    x, y = str(tmp_path / "dev"), str(tmp_path / "host")
+    px = _run_pair(cu.BIN_HIP, sim_db, f1, f2, x, env)
+    py = _run_pair(cu.BIN_HIP, sim_db, f1, f2, y, HOST)
+    assert "device inflate:" in px.stderr, px.stderr
+    _same_files(x, y)
+    err = lambda p: [l for l in p.stderr.split("\n") if l.startswith("Error parsing")]  # noqa: E731
+    assert err(px) == err(py)
+    if case == "equal":
+        z = str(tmp_path / "ora")
+        _run_pair(oracle_bin, sim_db, f1, f2, z)
+        _same_files(x, z, (".all", ".one", ".unc", ".rep"))
+        res = cu.Res(x)
+        assert res.total_classified > 1000 and res.total_classified + res.total_unclassified == 24000
