@@ -187,7 +187,7 @@ def compact_line(result: dict) -> dict:
         if "error" in r:
             extra.append((f"e2e_{name}_error", _short(r["error"], 80)))
         else:
-            extra.append((f"e2e_{name}_{'mpairs_s' if name == 'paired' else 'mreads_s'}_median", (r.get("rate") or {}).get("median")))
+            extra.append((f"e2e_{name}_{'mpairs_s' if name.startswith('paired') else 'mreads_s'}_median", (r.get("rate") or {}).get("median")))
     for k, v in [(k, v) for k, v in extra if v is not None][:20]:
         cfg[k] = v
     line["config"] = cfg

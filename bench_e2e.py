@@ -209,9 +209,25 @@ def main() -> int:
             f1, f2 = os.path.join(d, "pair.1.fq"), os.path.join(d, "pair.2.fq")
             fastq_matrix(wp.bases[: npair * L], npair, L).tofile(f1)
             fastq_matrix(wp.bases[npair * L:], npair, L).tofile(f2)
+            nz = npair // 2
+            zb1, zb2 = wp.bases[: nz * L].copy(), wp.bases[npair * L: (npair + nz) * L].copy()  # (the first half of the pairs, for the .fq.gz leg)
             del wp
             out["inputs"]["paired"] = run_binary(["--ibf", ibf, "--paired-reads", f1 + "," + f2, "-o", os.path.join(d, "o_paired")] + common, npair,
                                                  args.runs, f"{npair} pairs 2 x {L} bp (ends of 400 bp fragments, mate 2 reverse strand), two FASTQ files", deadline)
+            if "gz" in want and time.time() < deadline - 40:
+                # the same pairs as two one-member .fq.gz files (half of them: the compression is this script's, and slow)
+                z1, z2 = os.path.join(d, "pair.1.fq.gz"), os.path.join(d, "pair.2.fq.gz")
+                t0 = time.time()
+                write_gzip_one_member(z1, fastq_matrix(zb1, nz, L, quals=True))
+                write_gzip_one_member(z2, fastq_matrix(zb2, nz, L, quals=True))
+                lab = f"{nz} pairs 2 x {L} bp, two one-member .fq.gz files (level 6, written in {time.time() - t0:.1f} s)"
+                out["inputs"]["paired_gz"] = run_binary(["--ibf", ibf, "--paired-reads", z1 + "," + z2, "-o", os.path.join(d, "o_pgz")] + common, nz, args.runs, lab, deadline)
+                if time.time() < deadline - 15:
+                    out["inputs"]["paired_gz_host_inflate"] = run_binary(["--ibf", ibf, "--paired-reads", z1 + "," + z2, "-o", os.path.join(d, "o_pgzh")] + common, nz,
+                                                                         max(1, args.runs // 2), "the same files, inflated by the host's threads", deadline,
+                                                                         {"GANON_HOST_DEVICE_INFLATE": "0"})
+                os.remove(z1)
+                os.remove(z2)
             os.remove(f1)
             os.remove(f2)
         elif "paired" in want:
