@@ -635,7 +635,12 @@ __device__ __forceinline__ uint32_t gi_fetch(const GiLds& L, const GiOut& o, int
 //      (the far loads of up to 64 matches are in flight together); long ones, and matches that read what the batch itself produces
 //      (or overlap their own output), follow in token order, each spread over the lanes.  A batch adds at most 512 symbols, so
 //      everything it reads near-by is still in the 1024-symbol ring.
+#ifndef GI_BATCH_FILL
+#define GI_BATCH_FILL 52u // a batch takes rounds until it holds more tokens than this (a round adds seven or so; 64 is the limit)
+#endif
+#ifndef GI_SHORT_MATCH
 #define GI_SHORT_MATCH 12u
+#endif
 template <bool STRICT>
 __device__ int gi_codes(GiLds& L, GiIn& in, GiOut& o, const GiBlockCtx& bc, uint32_t base, bool markers_ok, uint64_t limit_dw)
 {
@@ -652,7 +657,7 @@ __device__ int gi_codes(GiLds& L, GiIn& in, GiOut& o, const GiBlockCtx& bc, uint
         const uint64_t t_a = wall_clock64();
         uint32_t       nt = 0, cum = 0;
         bool           full = false;
-        while (end < 0 && !full && nt <= 52u)
+        while (end < 0 && !full && nt <= GI_BATCH_FILL)
         {
             uint32_t k0 = (uint32_t)((pos >> 5) - a32);
             if (k0 >= 32u)

@@ -240,6 +240,8 @@ public:
     virtual bool tokenises_fastq() const { return false; }
     // Optional.  A gzip-compressed FASTQ / FASTA file as text pieces in this backend's device memory; nullptr: not a file for that (not
     // gzip, blocked gzip, too small, no room) or not a backend that does it.  piece_bytes = text per piece, about.
+    // Optional.  Free memory of the device open_gzip_text would use, now (0: not a backend with device memory).
+    virtual uint64_t free_device_bytes() const { return 0; }
     virtual std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& /*path*/, size_t /*piece_bytes*/, size_t /*min_bytes*/, bool /*by_lines*/ = false)
     {
         return nullptr;

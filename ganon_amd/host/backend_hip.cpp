@@ -123,6 +123,12 @@ public:
         return tokenise_begin(b, err) && tokenise_end(b, n_reads, parsed_bytes, err);
     }
 
+    uint64_t free_device_bytes() const override
+    {
+        uint64_t fr = 0, tot = 0;
+        return gn_device_memory(device_, &fr, &tot) == GN_OK ? fr : 0;
+    }
+
     std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& path, size_t piece_bytes, size_t min_bytes, bool by_lines) override
     {
         return open_device_gzip(path, device_, piece_bytes, min_bytes, by_lines);

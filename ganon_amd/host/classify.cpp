@@ -1245,6 +1245,30 @@ static bool ganon_classify(Config config)
     // (one hierarchy level: reads left unclassified are not passed on) -- $GANON_HOST_DEVICE_INFLATE=0 keeps the host inflater
     const char* di = std::getenv("GANON_HOST_DEVICE_INFLATE");
     Backend*    device_text = raw_fastq && levels.size() == 1 && !(di && di[0] == '0') ? backends.front().get() : nullptr;
+    if (device_text)
+    {
+        // ... and when the device has the room beside what is still to come: the filters are loaded AFTER the reader starts, and an
+        // inflater takes its buffers (19 GB at the default sizes, twice for a pair) the moment a file is opened.  Room = free memory now
+        // - the filter files' sizes - a share for the workers' batch buffers (as placement.hpp keeps: an eighth, 16 GiB at most of half)
+        uint64_t filter_bytes = 0;
+        for (auto const& l : levels)
+            for (auto const& f : l.filters)
+            {
+                std::error_code ec;
+                const auto      sz = std::filesystem::file_size(f.ibf_file, ec);
+                filter_bytes += ec ? 0 : (uint64_t)sz;
+            }
+        const uint64_t fr      = device_text->free_device_bytes();
+        const uint64_t reserve = std::max<uint64_t>(fr / 8, std::min<uint64_t>(fr / 2, 16ull << 30)) + (24ull << 30);
+        const uint64_t need    = env_size("GANON_HOST_DEVICE_INFLATE_ROOM", 44ull << 30);
+        if (fr < filter_bytes + reserve + need)
+        {
+            if (config.verbose)
+                std::cerr << "[host input] gzip input is inflated by the host: " << (fr >> 20) << " MiB free on the device, " << (filter_bytes >> 20)
+                          << " MiB of filters to come" << std::endl;
+            device_text = nullptr;
+        }
+    }
     std::thread read_task(parse_reads, std::ref(queue1), std::ref(report), std::ref(report_mutex), std::cref(reads), raw_fastq, device_text);
     struct Joiner
     {

@@ -36,7 +36,7 @@ def _records(n, seed=7, line_end="\n"):
 
 def _run(binary, sim_db, reads, out_prefix, env=None, extra=()):
     args = ["--ibf", sim_db["ibf"], "--tax", sim_db["tax"], "--single-reads", reads, "-o", out_prefix, "--output-all", "--output-lca",
-            "--output-unclassified", "--output-stats", "--quiet", "--rel-cutoff", "0.25", "--rel-filter", "0.1"] + list(extra)
+            "--output-unclassified", "--output-stats", "--rel-cutoff", "0.25", "--rel-filter", "0.1"] + (list(extra) if "--verbose" in extra else ["--quiet"] + list(extra))
     e = dict(os.environ)
     e.update(env or {})
     import subprocess
@@ -192,3 +192,14 @@ def test_paired_gzip_files_from_the_device(sim_db, oracle_bin, tmp_path, case):
         _same_files(x, z, (".all", ".one", ".unc", ".rep"))
         res = cu.Res(x)
         assert res.total_classified > 1000 and res.total_classified + res.total_unclassified == 24000
+
+
+def test_no_room_on_the_device_means_the_host_inflater(sim_db, tmp_path):
+    # the filters are loaded after the reader starts: an inflater must not take what they need ($GANON_HOST_DEVICE_INFLATE_ROOM = what to keep free for it)
+    fq = str(tmp_path / "reads.fq.gz")
+    open(fq, "wb").write(gzip.compress("".join(_records(8000, seed=3)).encode(), 6))
+    a, b = str(tmp_path / "dev"), str(tmp_path / "host")
+    pa = _run(cu.BIN_HIP, sim_db, fq, a, dict(DEV, GANON_HOST_DEVICE_INFLATE_ROOM=str(1 << 50)), extra=["--verbose"])
+    _run(cu.BIN_HIP, sim_db, fq, b, HOST)
+    assert "device inflate:" not in pa.stderr and "inflated by the host" in pa.stderr
+    _same_files(a, b)
