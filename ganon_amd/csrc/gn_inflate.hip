@@ -2447,6 +2447,9 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     if (z->h_crc[0])
         return gn_fail(GN_ERANGE, "gn_inflate_step: gzip member with a wrong CRC-32");
     z->crc_carry = z->h_crc[1];
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, z->ev_dec[set][0], z->ev_dec[set][1]) == hipSuccess)
+        z->stats.ms_decode += ms;
     // this step's set is free: the decode after the one in flight starts now
     if (s.reason != GI_R_END && !(s.reason == GI_R_INPUT && all_fed))
     {
@@ -2454,9 +2457,6 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         if (from < z->n_chunks_file && !gn_sw().inflate_ahead)
             gi_start_decode(z, false, from, set);
     }
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, z->ev_dec[set][0], z->ev_dec[set][1]) == hipSuccess)
-        z->stats.ms_decode += ms;
     if (hipEventElapsedTime(&ms, z->ev[1], z->ev[2]) == hipSuccess)
         z->stats.ms_chain += ms;
     if (hipEventElapsedTime(&ms, z->ev[2], z->ev[3]) == hipSuccess)

@@ -235,3 +235,47 @@ def test_cuts_carry_and_batches_from_device_text():
         assert steps > 2
         if flt is not None:
             assert seen == [r[:r.index(b"\n") + 1] for r in recs]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_compressor_settings_against_zlib(seed):
+    """random compressor settings (level, strategy, window, memLevel: block sizes from a few hundred symbols to 64 Ki), random flush
+    points, random mixtures of FASTQ text, long runs and bytes -- the device's text is zlib's, or the file is refused (GN_ERANGE), never wrong"""
+    rng = np.random.default_rng(1000 + seed)
+    parts = []
+    for _ in range(int(rng.integers(3, 9))):
+        kind = int(rng.integers(0, 4))
+        n = int(rng.integers(1_000, 400_000))
+        if kind == 0:
+            a = int(rng.integers(0, len(TEXT) - n))
+            parts.append(TEXT[a:a + n])
+        elif kind == 1:
+            parts.append(bytes([int(rng.integers(65, 91))]) * n)
+        elif kind == 2:
+            parts.append(rng.integers(32, 127, size=n, dtype=np.uint8).tobytes())
+        else:
+            parts.append((b"@id%d\nACGTNNNN\n+\nIIIIIIII\n" % seed) * (n // 28))
+    level = int(rng.integers(1, 10))
+    strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_DEFAULT_STRATEGY][int(rng.integers(0, 4))]
+    wbits = 16 + int(rng.integers(9, 16))
+    mem = int(rng.integers(1, 10))
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits, mem, strategy)
+    gz = b""
+    for t in parts:
+        gz += co.compress(t)
+        f = int(rng.integers(0, 4))
+        if f == 1:
+            gz += co.flush(zlib.Z_SYNC_FLUSH)
+        elif f == 2:
+            gz += co.flush(zlib.Z_FULL_FLUSH)
+    gz += co.flush()
+    text = b"".join(parts)
+    assert zlib.decompress(gz, 31) == text
+    chunk = [0, 1024, 4096, 16384][int(rng.integers(0, 4))]
+    step = [0, 65536, 1 << 20][int(rng.integers(0, 3))]
+    try:
+        got, _ = _inflate(gz, chunk=chunk, step=step, feed=[0, 70_000][int(rng.integers(0, 2))])
+    except hip.GanonHipError as e:
+        assert e.code == -34, e
+    else:
+        assert got == text
