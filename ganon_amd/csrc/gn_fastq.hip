@@ -555,3 +555,23 @@ extern "C" int gn_stream_fastq_headers(gn_stream* s, uint8_t* dst, uint64_t cap,
     GN_HIP(hipStreamSynchronize(s->st));
     return GN_OK;
 }
+
+extern "C" int gn_stream_fetch_letters(gn_stream* s, uint8_t* bases, uint64_t cap, uint64_t* off1, uint64_t* off2, uint64_t* n_bytes)
+{
+    if (!s || !s->have_reads || !off1 || !n_bytes || (s->paired && !off2) || (!bases && cap))
+        return gn_fail(GN_EINVAL, "gn_stream_fetch_letters: no batch, or null argument");
+    GN_HIP(hipSetDevice(s->f->device));
+    const size_t nb = ((size_t)s->n_reads + 1) * sizeof(uint64_t);
+    GN_HIP(hipMemcpyAsync(off1, s->d_off1, nb, hipMemcpyDeviceToHost, s->st));
+    if (s->paired)
+        GN_HIP(hipMemcpyAsync(off2, s->d_off2, nb, hipMemcpyDeviceToHost, s->st));
+    GN_HIP(hipStreamSynchronize(s->st));
+    const uint64_t end = s->paired ? off2[s->n_reads] : off1[s->n_reads];
+    *n_bytes           = end;
+    if (end > cap)
+        return gn_fail(GN_EOVERFLOW, "gn_stream_fetch_letters: %llu bytes of letters, room for %llu", (unsigned long long)end, (unsigned long long)cap);
+    if (end)
+        GN_HIP(hipMemcpyAsync(bases, s->d_bases, end, hipMemcpyDeviceToHost, s->st));
+    GN_HIP(hipStreamSynchronize(s->st));
+    return GN_OK;
+}

@@ -30,7 +30,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_ablate", "gn_filter_probe", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free",
                "gn_inflate_create", "gn_inflate_destroy", "gn_inflate_feed", "gn_inflate_step", "gn_inflate_text", "gn_inflate_text_device",
                "gn_inflate_get_stats", "gn_inflate_cuts", "gn_inflate_set_carry", "gn_stream_upload_text_device", "gn_stream_fastq_headers",
-               "gn_inflate_cuts_lines", "gn_inflate_cut_at_lines", "gn_stream_upload_text_pair_device"]
+               "gn_inflate_cuts_lines", "gn_inflate_cut_at_lines", "gn_stream_upload_text_pair_device", "gn_stream_fetch_letters"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -190,6 +190,7 @@ def load_library():
     L.gn_inflate_cuts_lines.argtypes = [vp, u32, u64, vp, vp, u32, C.POINTER(u32)]
     L.gn_inflate_cut_at_lines.argtypes = [vp, vp, u32, vp, C.POINTER(u64)]
     L.gn_stream_upload_text_pair_device.argtypes = [vp, vp, u64, vp, u64, i32, i32]
+    L.gn_stream_fetch_letters.argtypes = [vp, vp, u64, vp, vp, C.POINTER(u64)]
     L.gn_stream_upload_text_device.argtypes = [vp, vp, u64, i32, i32]
     L.gn_stream_fastq_headers.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
     for name in ABI_SYMBOLS:

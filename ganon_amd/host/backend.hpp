@@ -131,6 +131,8 @@ struct ReadBatch
     const uint8_t*        dev_text2  = nullptr; // ... of a pair: the mate file's piece (the same records by number), same device
     uint64_t              dev_bytes2 = 0;
     std::shared_ptr<void> dev_hold2;
+    bool                  dev_need_letters = false; // the run has further hierarchy levels: classify() also brings the letters (bases, off1, off2)
+    bool                  dev_letters = false;      // ... and they are there
     uint64_t raw_bytes() const { return dev_text ? dev_bytes : text.size(); }
     std::unique_ptr<RawTicket> ticket;
     size_t size() const { return raw ? rec_at.size() : id_off.size() - 1; }
@@ -146,8 +148,8 @@ struct ReadBatch
     }
     uint64_t       len1(size_t i) const { return raw ? seq_len[i] : off1[i + 1] - off1[i]; }
     uint64_t       len2(size_t i) const { return !paired ? 0 : raw ? seq_len2[i] : off2[i + 1] - off2[i]; }
-    const uint8_t* seq1(size_t i) const { return raw ? text.data() + seq_at[i] : bases.data() + off1[i]; }
-    const uint8_t* seq2(size_t i) const { return raw ? text2.data() + seq_at2[i] : bases.data() + off2[i]; }
+    const uint8_t* seq1(size_t i) const { return raw && !dev_letters ? text.data() + seq_at[i] : bases.data() + off1[i]; }
+    const uint8_t* seq2(size_t i) const { return raw && !dev_letters ? text2.data() + seq_at2[i] : bases.data() + off2[i]; }
 };
 
 struct Match

@@ -458,6 +458,28 @@ public:
                     b.rec_at[i] = hdr_off_[i];
                     b.seq_at[i] = hdr_off_[i + 1];
                 }
+                b.dev_letters = false;
+                if (b.dev_need_letters) // reads this level leaves unclassified go on with their letters (:811-820)
+                {
+                    b.off1.resize((size_t)n + 1);
+                    if (b.paired)
+                        b.off2.resize((size_t)n + 1);
+                    uint64_t lb = 0;
+                    if (b.bases.size() < (size_t)n * 160)
+                        b.bases.resize((size_t)n * 160 + 4096);
+                    rc = gn_stream_fetch_letters(first, b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr, &lb);
+                    if (rc == GN_EOVERFLOW)
+                    {
+                        b.bases.resize((size_t)lb + 4096);
+                        rc = gn_stream_fetch_letters(first, b.bases.data(), b.bases.size(), b.off1.data(), b.paired ? b.off2.data() : nullptr, &lb);
+                    }
+                    if (rc != GN_OK)
+                    {
+                        err = gn_last_error();
+                        return false;
+                    }
+                    b.dev_letters = true;
+                }
             }
         }
         lap(sec_fetch_);

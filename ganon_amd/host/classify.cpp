@@ -528,7 +528,8 @@ struct Cleanups
     }
 } g_cleanups;
 
-void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq, Backend* device_text)
+void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq, Backend* device_text,
+                 bool further_levels)
 {
     uint64_t       seq = 0;
     MateCopier     copier(queue, (unsigned)env_size("GANON_HOST_MATE_THREADS", 3));
@@ -566,6 +567,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     rb.dev_text2 = nullptr;
                     rb.dev_bytes2 = 0;
                     rb.dev_hold2.reset();
+                    rb.dev_need_letters = rb.dev_letters = false;
                 }
                 else
                     rb = ReadBatch();
@@ -615,6 +617,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                         rb.dev_bytes  = pc.bytes;
                         rb.dev_device = pc.device;
                         rb.dev_hold   = std::move(pc.hold);
+                        rb.dev_need_letters = further_levels;
                         rb.text_at    = pc.at;
                         rb.raw_keep   = 0;
                         rb.ticket.reset(new RawTicket{ tracker, pieces++ });
@@ -692,6 +695,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                         rb.dev_text2  = p2.dev;
                         rb.dev_bytes2 = p2.bytes;
                         rb.dev_hold2  = std::move(p2.hold);
+                        rb.dev_need_letters = further_levels;
                         rb.text_at    = p1.at;
                         rb.text2_at   = p2.at;
                         rb.raw_keep   = 0;
@@ -1241,10 +1245,10 @@ static bool ganon_classify(Config config)
     BatchQueue  queue1(2 + 2 * n_workers);
     // uncompressed single-end FASTQ goes to the workers as it lies in the file when the backend finds the records itself
     const bool  raw_fastq = backends.front()->tokenises_fastq();
-    // ... and gzip files are inflated on the device, their text handed to the workers there, when nothing needs the letters on the host
-    // (one hierarchy level: reads left unclassified are not passed on) -- $GANON_HOST_DEVICE_INFLATE=0 keeps the host inflater
+    // ... and gzip files are inflated on the device, their text handed to the workers there (with further hierarchy levels the letters
+    // come back with the results: reads left unclassified are passed on with them) -- $GANON_HOST_DEVICE_INFLATE=0 keeps the host inflater
     const char* di = std::getenv("GANON_HOST_DEVICE_INFLATE");
-    Backend*    device_text = raw_fastq && levels.size() == 1 && !(di && di[0] == '0') ? backends.front().get() : nullptr;
+    Backend*    device_text = raw_fastq && !(di && di[0] == '0') ? backends.front().get() : nullptr;
     if (device_text)
     {
         // ... and when the device has the room beside what is still to come: the filters are loaded AFTER the reader starts, and an
@@ -1269,7 +1273,7 @@ static bool ganon_classify(Config config)
             device_text = nullptr;
         }
     }
-    std::thread read_task(parse_reads, std::ref(queue1), std::ref(report), std::ref(report_mutex), std::cref(reads), raw_fastq, device_text);
+    std::thread read_task(parse_reads, std::ref(queue1), std::ref(report), std::ref(report_mutex), std::cref(reads), raw_fastq, device_text, levels.size() > 1);
     struct Joiner
     {
         std::thread& t;

@@ -217,6 +217,11 @@ int gn_stream_upload_text_device(gn_stream* s, const uint8_t* d_text, uint64_t n
 int gn_stream_upload_text_pair_device(gn_stream* s, const uint8_t* d_text1, uint64_t n_bytes1, const uint8_t* d_text2, uint64_t n_bytes2, int format,
                                       int src_device);
 int gn_stream_fastq_headers(gn_stream* s, uint8_t* dst, uint64_t cap, uint32_t* hdr_off, uint64_t* n_bytes);
+/* The resident batch's letters as the kernels see them (ASCII, mate-1 block then mate-2 block: the layout of gn_stream_upload_reads) with
+ * off1 / off2 (n_reads + 1 entries each; off2 only for pairs): for a caller that classified a text it does not hold and needs the letters
+ * after all -- reads left unclassified go on to the next hierarchy level (GanonClassify.cpp:811-820).  *n_bytes = bytes copied
+ * (GN_EOVERFLOW with *n_bytes set when cap is too small). */
+int gn_stream_fetch_letters(gn_stream* s, uint8_t* bases, uint64_t cap, uint64_t* off1, uint64_t* off2, uint64_t* n_bytes);
 int gn_stream_text_pair_index(gn_stream* s, uint32_t* n_reads, uint64_t* parsed_bytes1, uint64_t* parsed_bytes2);
 int gn_stream_text_pair_records2(gn_stream* s, uint32_t* rec_at, uint32_t* seq_at, uint32_t* seq_len);
 int gn_stream_fastq_index(gn_stream* s, uint32_t* n_reads, uint64_t* n_bases, uint64_t* parsed_bytes);

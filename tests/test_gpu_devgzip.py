@@ -203,3 +203,51 @@ def test_no_room_on_the_device_means_the_host_inflater(sim_db, tmp_path):
     _run(cu.BIN_HIP, sim_db, fq, b, HOST)
     assert "device inflate:" not in pa.stderr and "inflated by the host" in pa.stderr
     _same_files(a, b)
+
+
+def test_two_workers_on_one_device_take_the_pieces(sim_db, tmp_path):
+    # --device 0,0: two device entries (two workers, each with streams of its own) share the inflater's pieces
+    fq = str(tmp_path / "reads.fq.gz")
+    open(fq, "wb").write(gzip.compress("".join(_records(20000, seed=13)).encode(), 6))
+    a, b = str(tmp_path / "dev"), str(tmp_path / "host")
+    pa = _run(cu.BIN_HIP, sim_db, fq, a, dict(DEV, GANON_HOST_SLAB_BYTES="500000"), extra=["--device", "0,0"])
+    _run(cu.BIN_HIP, sim_db, fq, b, HOST)
+    assert _device_path_taken(pa), pa.stderr
+    _same_files(a, b)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_two_hierarchy_levels_get_their_letters_from_the_device(sim_db, tmp_path, paired):
+    # reads the first level leaves unclassified go on to the second with their letters (GanonClassify.cpp:811-820): for a text the host
+    # never held they come back with the results (gn_stream_fetch_letters).  Level 1 = the HIBF (strict cutoff), level 2 = the flat filter.
+    import subprocess
+    if paired:
+        a, b = _pair_records(12000, seed=21)
+        f1, f2 = str(tmp_path / "r.1.fq.gz"), str(tmp_path / "r.2.fq.gz")
+        open(f1, "wb").write(gzip.compress("".join(a).encode(), 6))
+        open(f2, "wb").write(gzip.compress("".join(b).encode(), 6))
+        reads = ["--paired-reads", f1 + "," + f2]
+    else:
+        fq = str(tmp_path / "reads.fq.gz")
+        open(fq, "wb").write(gzip.compress("".join(_records(15000, seed=17)).encode(), 6))
+        reads = ["--single-reads", fq]
+
+    def run(prefix, env):
+        args = ["--ibf", sim_db["ibf"] + "," + sim_db["ibf"], "--tax", sim_db["tax"] + "," + sim_db["tax"], "--hierarchy-labels", "first,second",
+                "--rel-cutoff", "0.9,0.25", "--rel-filter", "0.1,0.1", "-o", prefix, "--output-all", "--output-lca", "--output-unclassified", "--quiet"] + reads
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([cu.BIN_HIP] + args, capture_output=True, text=True, timeout=600, env=e)
+        assert p.returncode == 0, p.stderr
+        return p
+
+    x, y = str(tmp_path / "dev"), str(tmp_path / "host")
+    px = run(x, DEV)
+    run(y, HOST)
+    assert "device inflate:" in px.stderr and "given up" not in px.stderr, px.stderr
+    names = sorted(f for f in os.listdir(tmp_path) if f.startswith("dev."))
+    assert any(".second." in f or "second" in f for f in names) or len(names) >= 3, names
+    for f in names:
+        assert open(os.path.join(tmp_path, f), "rb").read() == open(os.path.join(tmp_path, "host" + f[3:]), "rb").read(), f
+    rep = open(x + ".rep").read()
+    assert "second" in rep  # the second level classified reads: it got their letters
