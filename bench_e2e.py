@@ -136,6 +136,7 @@ def main() -> int:
     ap.add_argument("--reads", type=int, default=16_000_000, help="single-end reads (pairs and .gz reads: half of it)")
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--budget", type=float, default=200.0, help="seconds; inputs that no longer fit are left out and named")
+    ap.add_argument("--keep-gz", default="", help="copy the filter and the single-end .fq.gz into this directory before they are removed (profiling runs)")
     ap.add_argument("--only", default="", help="comma-separated subset of fastq,paired,gz,fasta,hibf")
     args = ap.parse_args()
 
@@ -194,6 +195,11 @@ def main() -> int:
             r = run_binary(["--ibf", ibf, "--single-reads", gz, "-o", os.path.join(d, "o_gz")] + common, ng, args.runs,
                            f"{ng} reads x {L} bp, one-member .fq.gz ({os.path.getsize(gz) / 2**30:.2f} GiB, level 6, written in {time.time() - t0:.1f} s)", deadline)
             out["inputs"]["gz"] = r
+            if args.keep_gz:
+                import shutil
+                os.makedirs(args.keep_gz, exist_ok=True)
+                shutil.copy(gz, os.path.join(args.keep_gz, "single.fq.gz"))
+                shutil.copy(ibf, os.path.join(args.keep_gz, "e2e.ibf"))
             m = re.search(r"\[host input\] .*(device inflate: .*)", "\n".join(r.get("timing_lines", [])) or "")
             # the same file through the host's parallel inflater (pgzip.cpp), as up to round 4
             if time.time() < deadline - 10:

@@ -1839,102 +1839,113 @@ __global__ __launch_bounds__(256) void gi_nl_tiles_kernel(const uint8_t* __restr
         cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
-// thread j < m: the first record boundary at or behind (j + 1) * piece; thread m: the last record boundary of the text.  A record
-// boundary = the byte behind newline number l (from 0) with (l + 1) % lpr == 0.  ~0 = none.
-__global__ void gi_cuts_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ pre /* tiles + 1: exclusive sums */, uint32_t tiles,
-                               uint32_t lpr, uint64_t piece, uint32_t m, unsigned long long* __restrict__ cuts /* m + 1 offsets, then m + 1 line counts */)
+// One wave per cut; its lanes look at 64 bytes at a time.
+// newlines in text[from, to)
+__device__ __forceinline__ uint64_t gi_count_nl_wave(const uint8_t* __restrict__ text, uint64_t from, uint64_t to)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > m)
-        return;
+    uint64_t c = 0;
+    for (uint64_t q = from; q < to; q += 64u)
+    {
+        const uint64_t i = q + gi_lane();
+        c += (uint64_t)__popcll(__ballot(i < to && text[i] == '\n'));
+    }
+    return c;
+}
+// offset of newline number `left` (from 0) at or behind text[from] (n: the text's size); n when there is none
+__device__ __forceinline__ uint64_t gi_find_nl_wave(const uint8_t* __restrict__ text, uint64_t n, uint64_t from, uint64_t left)
+{
+    for (uint64_t q = from; q < n; q += 64u)
+    {
+        const uint64_t i = q + gi_lane();
+        uint64_t       m = __ballot(i < n && text[i] == '\n');
+        const uint64_t c = (uint64_t)__popcll(m);
+        if (left < c)
+        {
+            for (uint64_t k = 0; k < left; ++k)
+                m &= m - 1ull;
+            return q + (uint64_t)__builtin_ctzll(m);
+        }
+        left -= c;
+    }
+    return n;
+}
+// the tile (index into pre, the exclusive sums of the tiles' newline counts) that holds newline number want
+__device__ __forceinline__ uint32_t gi_tile_of(const uint32_t* __restrict__ pre, uint32_t tiles, uint64_t want)
+{
+    uint32_t lo = 0, hi = tiles;
+    while (hi - lo > 1u)
+    {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (pre[mid] <= want)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// wave j < m: the first record boundary at or behind (j + 1) * piece; wave m: the last record boundary of the text.  A record
+// boundary = the byte behind newline number l (from 0) with (l + 1) % lpr == 0.  ~0 = none.
+__global__ __launch_bounds__(64) void gi_cuts_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ pre /* tiles + 1: exclusive sums */,
+                                                     uint32_t tiles, uint32_t lpr, uint64_t piece, uint32_t m,
+                                                     unsigned long long* __restrict__ cuts /* m + 1 offsets, then m + 1 line counts */)
+{
+    const uint32_t j     = blockIdx.x;
     const uint64_t total = pre[tiles];
     uint64_t       want; // the newline behind which the cut lies
+    bool           none = false;
     if (j == m)
     {
-        if (total < lpr)
-        {
-            cuts[j] = ~0ull;
-            return;
-        }
-        want = total / lpr * lpr - 1u;
+        none = total < lpr;
+        want = none ? 0 : total / lpr * lpr - 1u;
     }
     else
     {
         const uint64_t T = (uint64_t)(j + 1) * piece; // (>= 1)
-        if (T > n)
+        none             = T > n;
+        want             = 0;
+        if (!none)
         {
-            cuts[j] = ~0ull;
-            return;
-        }
-        const uint64_t P  = T - 1u; // newlines in [0, P)
-        const uint64_t t0 = P / GI_CUT_TILE;
-        uint64_t       lmin = pre[t0];
-        for (uint64_t q = t0 * GI_CUT_TILE; q < P; ++q)
-            lmin += text[q] == '\n';
-        want = (lmin + lpr) / lpr * lpr - 1u;
-        if (want >= total)
-        {
-            cuts[j] = ~0ull;
-            return;
+            const uint64_t P    = T - 1u; // newlines in [0, P)
+            const uint64_t t0   = P / GI_CUT_TILE;
+            const uint64_t lmin = pre[t0] + gi_count_nl_wave(text, t0 * GI_CUT_TILE, P);
+            want                = (lmin + lpr) / lpr * lpr - 1u;
+            none                = want >= total;
         }
     }
-    uint32_t lo = 0, hi = tiles; // the last tile whose exclusive sum is <= want
-    while (hi - lo > 1u)
+    uint64_t q = 0;
+    if (!none)
     {
-        const uint32_t mid = lo + (hi - lo) / 2u;
-        if (pre[mid] <= want)
-            lo = mid;
-        else
-            hi = mid;
+        const uint32_t lo = gi_tile_of(pre, tiles, want);
+        q                 = gi_find_nl_wave(text, n, (uint64_t)lo * GI_CUT_TILE, want - pre[lo]);
     }
-    uint64_t left = want - pre[lo];
-    uint64_t q    = (uint64_t)lo * GI_CUT_TILE;
-    for (; q < n; ++q)
-        if (text[q] == '\n')
-        {
-            if (left == 0)
-                break;
-            --left;
-        }
-    cuts[j]          = q + 1u;
-    cuts[m + 1u + j] = want + 1u; // lines (newlines) in front of the cut
+    if (gi_lane() == 0)
+    {
+        cuts[j]          = none ? ~0ull : q + 1u;
+        cuts[m + 1u + j] = none ? 0ull : want + 1u; // lines (newlines) in front of the cut
+    }
 }
 
-// thread j: the offset behind line number lines[j] (a count of newlines from the text's first byte; > 0), ~0 when the text holds fewer
-__global__ void gi_cut_lines_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ pre, uint32_t tiles,
-                                    const unsigned long long* __restrict__ lines, uint32_t m, unsigned long long* __restrict__ out)
+// wave j: the offset behind line number lines[j] (a count of newlines from the text's first byte; 0 -> 0), ~0 when the text holds fewer
+__global__ __launch_bounds__(64) void gi_cut_lines_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ pre, uint32_t tiles,
+                                                          const unsigned long long* __restrict__ lines, uint32_t m, unsigned long long* __restrict__ out)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.x;
     if (j >= m)
         return;
-    const uint64_t total = pre[tiles];
-    if (lines[j] == 0 || lines[j] > total)
+    const uint64_t total = pre[tiles], ask = lines[j];
+    uint64_t       r;
+    if (ask == 0 || ask > total)
+        r = ask == 0 ? 0ull : ~0ull;
+    else
     {
-        out[j] = lines[j] == 0 ? 0ull : ~0ull;
-        return;
+        const uint64_t want = ask - 1u;
+        const uint32_t lo   = gi_tile_of(pre, tiles, want);
+        r                   = gi_find_nl_wave(text, n, (uint64_t)lo * GI_CUT_TILE, want - pre[lo]) + 1u;
     }
-    const uint64_t want = lines[j] - 1u;
-    uint32_t       lo = 0, hi = tiles;
-    while (hi - lo > 1u)
-    {
-        const uint32_t mid = lo + (hi - lo) / 2u;
-        if (pre[mid] <= want)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    uint64_t left = want - pre[lo];
-    uint64_t q    = (uint64_t)lo * GI_CUT_TILE;
-    for (; q < n; ++q)
-        if (text[q] == '\n')
-        {
-            if (left == 0)
-                break;
-            --left;
-        }
-    out[j] = q + 1u;
+    if (gi_lane() == 0)
+        out[j] = r;
 }
-
 
 // ---- CRC-32 of the members (RFC 1952: the trailer's first field) ------------------------------------------------------------------------
 // The text of a step is cut on a 4 KiB grid and at the member ends; a thread takes a piece, computes its CRC-32 (byte-wise, table in LDS)
@@ -2600,7 +2611,7 @@ extern "C" int gn_inflate_cuts_lines(gn_inflate* z, uint32_t lines_per_record, u
     if (rc != GN_OK)
         return rc;
     uint32_t* pre = z->d_cut_cnt + z->cut_tiles_cap;
-    hipLaunchKernelGGL(gi_cuts_kernel, dim3((m + 1u + 63u) / 64u), dim3(64), 0, z->st, z->d_text[z->cur], n, pre, tiles, lines_per_record, piece_bytes, m, z->d_cuts);
+    hipLaunchKernelGGL(gi_cuts_kernel, dim3(m + 1u), dim3(64), 0, z->st, z->d_text[z->cur], n, pre, tiles, lines_per_record, piece_bytes, m, z->d_cuts);
     GN_HIP(hipGetLastError());
     std::vector<unsigned long long> h(2u * (m + 1u));
     GN_HIP(hipMemcpyAsync(h.data(), z->d_cuts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, z->st));
@@ -2640,7 +2651,7 @@ extern "C" int gn_inflate_cut_at_lines(gn_inflate* z, const uint64_t* lines, uin
     if (n_lines)
     {
         GN_HIP(hipMemcpyAsync(d_in, lines, (size_t)n_lines * sizeof(unsigned long long), hipMemcpyHostToDevice, z->st));
-        hipLaunchKernelGGL(gi_cut_lines_kernel, dim3((n_lines + 63u) / 64u), dim3(64), 0, z->st, z->d_text[z->cur], n, pre, tiles, d_in, n_lines, z->d_cuts);
+        hipLaunchKernelGGL(gi_cut_lines_kernel, dim3(n_lines), dim3(64), 0, z->st, z->d_text[z->cur], n, pre, tiles, d_in, n_lines, z->d_cuts);
         GN_HIP(hipGetLastError());
         GN_HIP(hipMemcpyAsync(offsets, z->d_cuts, (size_t)n_lines * sizeof(unsigned long long), hipMemcpyDeviceToHost, z->st));
     }
