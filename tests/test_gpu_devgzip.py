@@ -251,3 +251,27 @@ def test_two_hierarchy_levels_get_their_letters_from_the_device(sim_db, tmp_path
         assert open(os.path.join(tmp_path, f), "rb").read() == open(os.path.join(tmp_path, "host" + f[3:]), "rb").read(), f
     rep = open(x + ".rep").read()
     assert "second" in rep  # the second level classified reads: it got their letters
+
+
+def test_several_files_in_one_run(sim_db, tmp_path):
+    # gzip, plain, gzip again (three members), a file too small for the device path: every file's source is opened and ended in turn
+    import subprocess
+    recs = _records(26000, seed=29)
+    files = []
+    for i, (a, b, how) in enumerate([(0, 9000, "gz"), (9000, 14000, "plain"), (14000, 25990, "gz3"), (25990, 26000, "gz")]):
+        t = "".join(recs[a:b]).encode()
+        f = str(tmp_path / (f"part{i}.fq" + ("" if how == "plain" else ".gz")))
+        if how == "plain":
+            open(f, "wb").write(t)
+        elif how == "gz3":
+            open(f, "wb").write(gzip.compress(t[:len(t) // 3], 6) + gzip.compress(t[len(t) // 3:len(t) // 2], 1) + gzip.compress(t[len(t) // 2:], 9))
+        else:
+            open(f, "wb").write(gzip.compress(t, 6))
+        files.append(f)
+    x, y = str(tmp_path / "dev"), str(tmp_path / "host")
+    px = _run(cu.BIN_HIP, sim_db, ",".join(files), x, dict(DEV, GANON_HOST_DEVICE_INFLATE_MIN="4096"))
+    _run(cu.BIN_HIP, sim_db, ",".join(files), y, HOST)
+    assert px.stderr.count("device inflate:") == 2, px.stderr
+    _same_files(x, y)
+    res = cu.Res(x)
+    assert res.total_classified + res.total_unclassified == 26000
