@@ -1127,7 +1127,14 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
             search_at = GI_NONE;
         }
         else if (fix)
+        {
             start = p.fix_start;
+            // (the stream may stand in front of a member header -- a chunk ends there when the header lies behind the next chunk's nominal
+            //  start; no block begins with 1f on a byte boundary: final + reserved type)
+            const uint64_t sb = start >> 3;
+            at_header = (start & 7u) == 0u && (sb + 18u) * 8u <= p.avail_bits && gi_byte(p.comp, sb) == 0x1Fu && gi_byte(p.comp, sb + 1) == 0x8Bu
+                        && gi_byte(p.comp, sb + 2) == 8u;
+        }
 
         uint32_t n_mend = 0, members = 0;
         uint64_t end_bit = 0;
@@ -1148,7 +1155,9 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                     {
                         const int t = __builtin_ctzll(sq_m);
                         sq_m &= sq_m - 1ull;
-                        start = nominal + (uint32_t)__builtin_amdgcn_readlane((int)sq_pos, t);
+                        const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)sq_pos, t);
+                        start     = nominal + (cand & 0x7FFFFFFFu);
+                        at_header = (cand >> 31) != 0u; // a gzip member header, not a block header
                         break;
                     }
                     if (sq2_n >= 16u || (search_at >= stop && sq_n == 0u && sq2_n))
@@ -1160,7 +1169,7 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                         sq_pos = lane < take ? L.cand_q2[(sq2_h + lane) & 127u] : 0u;
                         sq2_h += take;
                         sq2_n -= take;
-                        const bool ok = lane < take && gi_screen_header(p.comp, n_dw, nominal + sq_pos);
+                        const bool ok = lane < take && ((sq_pos >> 31) || gi_screen_header(p.comp, n_dw, nominal + sq_pos));
                         sq_m          = __ballot(ok);
                         continue;
                     }
@@ -1171,10 +1180,10 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                         const uint32_t mypos = lane < take ? L.cand_q[(sq_h + lane) & 255u] : 0u;
                         sq_h += take;
                         sq_n -= take;
-                        const uint64_t bit = nominal + mypos;
+                        const uint64_t bit = nominal + (mypos & 0x7FFFFFFFu);
                         const uint64_t di  = bit >> 5;
-                        bool           ok  = false;
-                        if (lane < take)
+                        bool           ok  = lane < take && (mypos >> 31);
+                        if (lane < take && !(mypos >> 31))
                         {
                             const uint32_t d0 = di < n_dw ? p.comp[di] : 0u, d1 = di + 1 < n_dw ? p.comp[di + 1] : 0u, d2 = di + 2 < n_dw ? p.comp[di + 2] : 0u,
                                            d3 = di + 3 < n_dw ? p.comp[di + 3] : 0u;
@@ -1200,13 +1209,16 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                     const uint32_t x  = __funnelshift_r(d0, d1, off & 31u);
                     const uint64_t bit = search_at + 4u * lane;
                     const uint64_t lim = stop < p.avail_bits - 96u ? stop : p.avail_bits - 96u; // (a position is looked at with 96 bits behind it)
-                    bool     okj[4];
+                    bool     okj[4], isj[4];
                     uint64_t mj[4];
                     uint32_t before = 0;
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j)
                     {
-                        okj[j] = bit + j < lim && gi_screen_bits(x >> j);
+                        // a block header -- or, on a byte boundary, a gzip member header (1f 8b 08: what follows is checked when it is tried)
+                        const bool member = ((bit + j) & 7u) == 0u && ((x >> j) & 0xFFFFFFu) == 0x088B1Fu;
+                        okj[j] = bit + j < lim && (gi_screen_bits(x >> j) || member);
+                        isj[j] = member;
                         mj[j]  = __ballot(okj[j]);
                         before += (uint32_t)__popcll(mj[j] & ((1ull << lane) - 1ull));
                     }
@@ -1216,7 +1228,7 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                     {
                         const uint32_t slot = sq_n + before;
                         if (okj[j] && slot < 256u) // (a ring of 256: what does not fit is dropped -- the chunk before decodes what the search misses)
-                            L.cand_q[(sq_h + slot) & 255u] = (uint32_t)(bit + j - nominal);
+                            L.cand_q[(sq_h + slot) & 255u] = (uint32_t)(bit + j - nominal) | (isj[j] ? 0x80000000u : 0u);
                         before += okj[j] ? 1u : 0u;
                         total += (uint32_t)__popcll(mj[j]);
                     }
@@ -1245,6 +1257,8 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
             if (at_header)
             {
                 const uint64_t q = gi_u64(gi_gzip_header(p.comp, p.total_bits >> 3, start >> 3));
+                if (!q && probation)
+                    continue; // (three bytes that look like a member's first: the search goes on)
                 if (!q)
                 {
                     flags   = GI_F_FAILED;
@@ -1386,6 +1400,11 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                     if (!q)
                     {
                         flags |= GI_F_END;
+                        end_bit = next * 8u;
+                        break;
+                    }
+                    if (next * 8u >= stop) // the next chunk's search finds this header: the chunk ends in front of it
+                    {
                         end_bit = next * 8u;
                         break;
                     }
@@ -1596,6 +1615,72 @@ __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChu
     }
     if (mk)
         atomicAdd(reinterpret_cast<unsigned long long*>(&st->res_markers), mk);
+    // members that end in the step: lengths against ISIZE, the list for the CRC pass.  A blocked-gzip file ends a member every 64 KiB of
+    // text, so this is done by all threads as well: per chain chunk the number of member ends and the position of its last one, summed /
+    // max-ed over the chain (an exclusive scan of both), then every thread judges the member ends of its own chunks.
+    __shared__ uint64_t s_last[1024];
+    __shared__ uint32_t s_bad, s_members;
+    if (tid == 0)
+    {
+        s_bad     = 0;
+        s_members = 0;
+    }
+    __syncthreads();
+    uint64_t cnt_mine = 0, last_mine = 0; // member ends in this thread's chunks; position + 1 of the last of them (0: none)
+    for (uint32_t k = 0; k < per; ++k)
+    {
+        const uint32_t r = tid * per + k;
+        if (r < R && ((s_lf[s_order[r]] >> 24) & GI_F_MEMBERS))
+        {
+            const GiChunk& c = chunks[slot_of(s_order[r])];
+            if (c.n_mend)
+            {
+                cnt_mine += c.n_mend;
+                last_mine = real[r].text_off + c.mend_sym[c.n_mend - 1u] + 1u;
+            }
+            atomicAdd(&s_members, c.members_begun);
+        }
+    }
+    __syncthreads(); // (s_part is read above)
+    s_part[tid] = cnt_mine;
+    s_last[tid] = last_mine;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024u; o <<= 1)
+    {
+        const uint64_t v = tid >= o ? s_part[tid - o] : 0ull, w = tid >= o ? s_last[tid - o] : 0ull;
+        __syncthreads();
+        s_part[tid] += v;
+        s_last[tid] = s_last[tid] > w ? s_last[tid] : w;
+        __syncthreads();
+    }
+    {
+        uint64_t       at_list = s_part[tid] - cnt_mine;                // index of this thread's first member end in the step's list
+        uint64_t       prev    = tid ? s_last[tid - 1u] : 0ull;         // position + 1 of the last member end before this thread's chunks
+        const uint64_t run_in  = st->run_len;                           // bytes the open member had before the step
+        for (uint32_t k = 0; k < per; ++k)
+        {
+            const uint32_t r = tid * per + k;
+            if (r < R && ((s_lf[s_order[r]] >> 24) & GI_F_MEMBERS))
+            {
+                const GiChunk& c = chunks[slot_of(s_order[r])];
+                const uint64_t t = real[r].text_off;
+                for (uint32_t e = 0; e < c.n_mend; ++e)
+                {
+                    const uint64_t end = t + c.mend_sym[e];
+                    const uint64_t len = prev ? end - (prev - 1u) : run_in + end;
+                    if ((uint32_t)len != c.mend_isize[e])
+                        atomicOr(&s_bad, 1u);
+                    if (at_list < mlist_cap)
+                    {
+                        mlist_pos[at_list] = end;
+                        mlist_crc[at_list] = c.mend_crc[e];
+                    }
+                    ++at_list;
+                    prev = end + 1u;
+                }
+            }
+        }
+    }
     __syncthreads();
     if (tid == 0)
     {
@@ -1603,35 +1688,8 @@ __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChu
         uint32_t       reason   = st->reason;
         if (text_all > text_cap || (all >> 40) > work_cap)
             reason = GI_R_OVERFLOW;
-        // members that end in the step: lengths against ISIZE, the list for the CRC pass (chunks that hold member ends say so)
-        uint64_t run_len = st->run_len, last_end = 0;
-        uint32_t members = 0, n_ml = 0;
-        bool     bad     = false;
-        for (uint32_t r = 0; r < R; ++r)
-        {
-            const uint32_t idx = s_order[r];
-            if (!((s_lf[idx] >> 24) & GI_F_MEMBERS))
-                continue;
-            const GiChunk& c = chunks[slot_of(idx)];
-            const uint64_t t = real[r].text_off;
-            for (uint32_t e = 0; e < c.n_mend; ++e)
-            {
-                const uint64_t end = t + c.mend_sym[e];
-                if ((uint32_t)(run_len + (end - last_end)) != c.mend_isize[e])
-                    bad = true;
-                run_len  = 0;
-                last_end = end;
-                if (n_ml < mlist_cap)
-                {
-                    mlist_pos[n_ml] = end;
-                    mlist_crc[n_ml] = c.mend_crc[e];
-                }
-                ++n_ml;
-            }
-            members += c.members_begun;
-        }
-        run_len += text_all - last_end;
-        if (bad && reason != GI_R_OVERFLOW)
+        const uint64_t n_ml = s_part[1023], last = s_last[1023];
+        if (s_bad && reason != GI_R_OVERFLOW)
             reason = GI_R_MEMBER;
         if (n_ml > mlist_cap && reason != GI_R_DATA && reason != GI_R_MEMBER)
             reason = GI_R_OVERFLOW;
@@ -1639,9 +1697,9 @@ __global__ __launch_bounds__(1024) void gi_order_kernel(GiState* st, const GiChu
         st->n_real      = R;
         st->n_work      = (uint32_t)(all >> 40);
         st->text_off    = text_all;
-        st->res_run_len = run_len;
-        st->res_members = members;
-        st->n_mlist     = n_ml;
+        st->res_run_len = last ? text_all - (last - 1u) : st->run_len + text_all;
+        st->res_members = s_members;
+        st->n_mlist     = (uint32_t)(n_ml < 0xFFFFFFFFull ? n_ml : 0xFFFFFFFFull);
     }
 }
 

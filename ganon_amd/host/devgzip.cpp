@@ -103,8 +103,7 @@ public:
             return false;
         if (h[0] != 0x1F || h[1] != 0x8B || h[2] != 8)
             return false;
-        if ((h[3] & 4) && h[12] == 'B' && h[13] == 'C') // blocked gzip: has a reader of its own (seq_io.cpp, BgzfSource)
-            return false;
+        // (blocked gzip -- BGZF, members of at most 64 KiB -- goes the same way: the search finds member headers as well as block headers)
         size_     = (uint64_t)st.st_size;
         device_   = device;
         piece_    = std::max<size_t>(piece_bytes, 1 << 16);

@@ -49,15 +49,34 @@ def main():
     ap.add_argument("--step", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--tile", type=int, default=1, help="repeat the compressed member this many times (multi-member file)")
+    ap.add_argument("--bgzf", action="store_true", help="blocked gzip (members of 64 KiB text with the BC field, as bgzip writes) instead of one member")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     text = synth_fastq(a.reads)
     t0 = time.time()
-    co = zlib.compressobj(a.level, zlib.DEFLATED, 31)
-    gz = co.compress(text) + co.flush()
+    if a.bgzf:
+        out = []
+        for at in list(range(0, len(text), 65280)) + [None]:
+            piece = b"" if at is None else text[at:at + 65280]
+            co = zlib.compressobj(a.level, zlib.DEFLATED, -15)
+            body = co.compress(piece) + co.flush()
+            out.append(bytes([0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 66, 67, 2, 0]) + (12 + 6 + len(body) + 8 - 1).to_bytes(2, "little") + body
+                       + zlib.crc32(piece).to_bytes(4, "little") + (len(piece) & 0xFFFFFFFF).to_bytes(4, "little"))
+        gz = b"".join(out)
+    else:
+        co = zlib.compressobj(a.level, zlib.DEFLATED, 31)
+        gz = co.compress(text) + co.flush()
     t_c = time.time() - t0
     t0 = time.time()
-    back = zlib.decompress(gz, 31)
+    if a.bgzf:
+        d, back, rest = zlib.decompressobj(31), [], gz
+        while rest:
+            back.append(d.decompress(rest))
+            rest = d.unused_data
+            d = zlib.decompressobj(31)
+        back = b"".join(back)
+    else:
+        back = zlib.decompress(gz, 31)
     t_z = time.time() - t0
     assert back == text
     if a.tile > 1:

@@ -275,3 +275,15 @@ def test_several_files_in_one_run(sim_db, tmp_path):
     _same_files(x, y)
     res = cu.Res(x)
     assert res.total_classified + res.total_unclassified == 26000
+
+
+def test_blocked_gzip_input(sim_db, tmp_path):
+    # bgzip's output (members of 64 KiB, BC field): on the device the members are the chunk starts; the host path has its own BGZF reader
+    from test_gpu_inflate import _bgzf
+    fq = str(tmp_path / "reads.fq.gz")
+    open(fq, "wb").write(_bgzf("".join(_records(25000, seed=31)).encode()))
+    a, b = str(tmp_path / "dev"), str(tmp_path / "host")
+    pa = _run(cu.BIN_HIP, sim_db, fq, a, DEV)
+    _run(cu.BIN_HIP, sim_db, fq, b, HOST)
+    assert _device_path_taken(pa) and "0 fix-ups" in pa.stderr, pa.stderr
+    _same_files(a, b)

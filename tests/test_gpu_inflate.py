@@ -279,3 +279,39 @@ def test_fuzz_compressor_settings_against_zlib(seed):
         assert e.code == -34, e
     else:
         assert got == text
+
+
+def _bgzf(text, block=65280, level=6):
+    """blocked gzip as bgzip writes it: members of at most 64 KiB with the BC extra field, an empty member at the end"""
+    out = []
+    for a in list(range(0, len(text), block)) + [None]:
+        piece = b"" if a is None else text[a:a + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(piece) + co.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out.append(bytes([0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 66, 67, 2, 0]) + bsize.to_bytes(2, "little") + body
+                   + zlib.crc32(piece).to_bytes(4, "little") + (len(piece) & 0xFFFFFFFF).to_bytes(4, "little"))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("chunk,step", [(0, 0), (4096, 262144), (65536, 0)])
+def test_blocked_gzip_members_are_chunk_starts(chunk, step):
+    text = TEXT * 3
+    gz = _bgzf(text)
+    assert zlib.decompressobj(31).decompress(gz[:gz.index(b"\x1f\x8b\x08\x04", 10)]) == text[:65280]
+    got, st = _inflate(gz, chunk=chunk, step=step)
+    assert got == text
+    assert st["members"] == len(text) // 65280 + 2 and st["markers"] == 0  # every chunk began at a member: nothing refers across
+    assert st["chunks"] > 8
+
+
+def test_many_small_members_and_a_wrong_crc_among_them():
+    parts = [TEXT[i:i + 7000] for i in range(0, 700_000, 7000)]
+    gz = b"".join(gzip.compress(t, 6) for t in parts)
+    got, st = _inflate(gz, chunk=4096)
+    assert got == b"".join(parts) and st["members"] == len(parts)
+    bad = bytearray(gz)
+    at = len(b"".join(gzip.compress(t, 6) for t in parts[:37])) - 8  # the CRC-32 of member 37
+    bad[at] ^= 0x10
+    with pytest.raises(hip.GanonHipError):
+        _inflate(bytes(bad), chunk=4096)
