@@ -8,29 +8,35 @@
 // the compressed bytes -- a quarter of the text -- are what crosses the link:
 //
 //   1. the compressed file is cut into CHUNKS of `chunk_bytes` (32 KiB).  One wave per chunk (gi_chunk_kernel):
-//      * SEARCH: 64 lanes test 64 consecutive bit positions at a time for a non-final dynamic-Huffman block header (BFINAL = 0,
-//        BTYPE = 2, HLIT/HDIST in range, a COMPLETE code-length code); every survivor is parsed by the whole wave (code lengths,
-//        complete literal/length code with an end-of-block code, legal distance code) and its block is decoded in strict mode
-//        (printable text only: the inputs are FASTQ/FASTA) -- the first position that passes is the chunk's start;
-//      * DECODE from there to the first block boundary at or after the next chunk's nominal start.  The loop is wave-uniform
-//        (bit buffer, table lookups and branches are scalar; the Huffman tables live in LDS, the input window in a register
-//        that is refilled with one coalesced 256-byte load per 2048 bits); the 64 lanes do the work that is parallel: table
-//        construction, LZ77 copies (one symbol per lane), stores.  Output = 16-bit symbols: a byte, or a MARKER 256 + i for
-//        "byte i of the 32 KiB before this chunk".  The last 1024 symbols live in an LDS ring (most match sources are there,
-//        and nothing is read from global memory before the line that holds it has been written completely); older sources
-//        are read back from the chunk's own output, which is allocated in pieces of 32 Ki symbols from a pool (no bound on a
-//        chunk's expansion has to be guessed);
-//   2. CHAIN (gi_chain_kernel, one workgroup, in stream order): the chunk that starts exactly where its predecessor ended is
-//      the continuation; its incoming window is saved, its outgoing window (last 32 KiB with markers resolved) computed, its
-//      text offset assigned, the members' ISIZE checked.  A position at which no chunk starts (a false start, a block of a
-//      kind the search does not look for) stops the chain with GAP: one wave decodes from the true position (gi_chunk_kernel
-//      in fix-up mode) and the chain goes on;
-//   3. RESOLVE (gi_resolve_kernel): symbols -> bytes of the text, markers through the chunk's saved window, all chunks in parallel.
+//      * SEARCH for the chunk's start: a non-final dynamic-Huffman block header, or a gzip member header, at or behind the chunk's nominal
+//        position.  Three screens, each over many positions at once: 256 bit positions a round take a 17-bit test (BFINAL = 0, BTYPE = 2,
+//        HLIT / HDIST in range; on byte boundaries also 1f 8b 08); the survivors, 64 at a time, the Kraft sum of the code-length code;
+//        what is left, 16+ at a time, a table-free decode of the whole header per lane (code lengths decode, literal/length code
+//        complete with an end-of-block code, distance code legal).  What passes is tried in position order: its first block is decoded
+//        in strict mode (printable text only: the inputs are FASTQ/FASTA), and the first position that passes is the chunk's start;
+//      * DECODE from there to the first block (or member) boundary at or behind the next chunk's nominal position at which something
+//        begins that the next chunk's search can find.  The Huffman tables live in LDS.  A ROUND decodes 64 bit positions at once -- lane
+//        l the whole token that would begin at position l -- and follows the chain of real tokens with one v_readlane each; batches of
+//        up to 64 tokens are placed by their lanes (output offsets by a prefix sum; the far sources of all matches in flight together).
+//        Output = 16-bit symbols: a byte, or a MARKER 256 + i for "byte i of the 32 KiB before this chunk".  The last 1024 symbols live
+//        in an LDS ring (nothing is read from global memory before the line that holds it has been written completely); older sources are
+//        read back from the chunk's own output, which is allocated in pieces of 32 Ki symbols from a pool (no bound on a chunk's
+//        expansion has to be guessed).  Two steps' decodes run ahead of the step that is being put together, on streams of their own;
+//   2. ORDER (gi_order_kernel, one workgroup): a chunk that starts at a position lies in the slot of that position's nominal range, so
+//      "which chunk continues this one" is a lookup for every slot at once; one thread follows the links from the stream's position; text
+//      offsets, the work list, the members' lengths (ISIZE) and the list for the CRC pass come from prefix sums over the chain.  A
+//      position at which no chunk starts (a false start, a block of a kind the search does not look for) stops the chain with GAP: one
+//      wave decodes from the true position (gi_chunk_kernel in fix-up mode) and the order is taken again;
+//   3. WINDOWS: a chunk's last 32 KiB as a FUNCTION of the window before it (a byte, or a reference into that window); gi_window_kernel
+//      composes the functions of 32 chain chunks per workgroup (and keeps every chunk's "window before me in terms of the window before
+//      my group"), gi_wchain_kernel goes through the groups in stream order -- a sequential depth of 32 + chunks / 32 instead of chunks;
+//   4. RESOLVE (gi_resolve_kernel): symbols -> bytes of the text, markers through the chunk's table (in LDS) and its group's window;
+//   5. gi_crc_kernel: CRC-32 of every member from pieces of 4 KiB, shifted to the member's end in GF(2) (crc32_combine restated) and
+//      XOR-ed together; gi_cuts_kernel / gi_cut_lines_kernel: where records begin, for the caller's batches.
 //
-// What the search cannot find (stored and fixed blocks, final blocks) is simply decoded by the chunk before.  Data this
-// scheme does not suit (hardly any dynamic blocks; expansion above the pool; members without end) makes gn_inflate_step
-// fail with GN_ERANGE: the caller takes its host path (pgzip.cpp / zlib) -- the device never guesses, and never returns text
-// it has not decoded bit-exactly.  CRC-32: see gi_crc_kernel.
+// What the search cannot find (stored and fixed blocks, final blocks) is simply decoded by the chunk before.  Data this scheme does not
+// suit (hardly anything the search finds; expansion above the pool) makes gn_inflate_step fail with GN_ERANGE: the caller takes its host
+// path (pgzip.cpp / zlib) -- the device never guesses, and never returns text it has not decoded bit-exactly.
 #include "gn_internal.h"
 
 #include <hip/hip_runtime.h>
