@@ -2252,7 +2252,7 @@ extern "C" int gn_inflate_create(int device, uint64_t compressed_bytes, uint32_t
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         z->n_cu = prop.multiProcessorCount;
     z->total       = compressed_bytes;
-    z->chunk_bytes = chunk_bytes ? std::max<uint32_t>(chunk_bytes & ~3u, 256u) : 32768u;
+    z->chunk_bytes = chunk_bytes ? std::min<uint32_t>(std::max<uint32_t>(chunk_bytes & ~3u, 256u), 16u << 20) : 32768u; // (positions inside a chunk are 31-bit numbers)
     z->step_bytes  = step_bytes ? std::max<uint64_t>(step_bytes, z->chunk_bytes) : (256ull << 20);
     z->step_bytes  = (z->step_bytes + z->chunk_bytes - 1) / z->chunk_bytes * z->chunk_bytes;
     z->step_bytes  = std::min<uint64_t>(z->step_bytes, 8192ull * z->chunk_bytes); // (gi_order_kernel keeps a step's slots in LDS)
