@@ -58,6 +58,12 @@ public:
         cv_.wait(lk, [&] { return first_stop_ < idx || known_below_ >= idx; });
         return first_stop_ >= idx;
     }
+    // has a piece stopped the file already?  (the reader need not cut further pieces then)
+    bool stopped()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        return first_stop_ != SIZE_MAX;
+    }
     // the reader, after the file's last piece: waits for all `count` pieces; false when one stopped the file (then resume_at)
     // (resume_at2: the same place in the mate file of a pair whose pieces travel as text)
     bool wait_all(size_t count, uint64_t& resume_at, size_t* stopped_by = nullptr, uint64_t* resume_at2 = nullptr)

@@ -608,7 +608,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     size_t          pieces  = 0;
                     DeviceTextPiece pc;
                     std::string     why;
-                    while (src->next(pc, why))
+                    while (!tracker->stopped() && src->next(pc, why)) // (a piece that is no records ends the device's part of the file: no point in inflating on)
                     {
                         rb.raw        = true;
                         rb.raw_fasta  = src->fasta();
@@ -665,7 +665,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     std::string     why;
                     bool            stopped = false; // a piece of file 1 was taken but could not be paired: the sequential readers start there
                     uint64_t        stop1 = 0, stop2 = 0;
-                    while (src1->next(p1, why))
+                    while (!tracker->stopped() && src1->next(p1, why))
                     {
                         std::string why2;
                         p2 = DeviceTextPiece();
