@@ -50,6 +50,17 @@
 #include <new>
 #include <vector>
 
+// Phase timers inside the decode kernel (gn_inflate_stats::prof_ms): s_memrealtime is a scalar memory read the wave waits for, four of
+// them a batch -- measured cost in scripts/inflate_variants.sh; off unless built with -DGI_PROF=1.
+#ifndef GI_PROF
+#define GI_PROF 0
+#endif
+#if GI_PROF
+#define GI_NOW() wall_clock64()
+#else
+#define GI_NOW() 0ull
+#endif
+
 namespace
 {
 
@@ -660,7 +671,7 @@ __device__ int gi_codes(GiLds& L, GiIn& in, GiOut& o, const GiBlockCtx& bc, uint
     while (end < 0)
     {
         // ---- A ---------------------------------------------------------------------------------------------------------------------
-        const uint64_t t_a = wall_clock64();
+        const uint64_t t_a = GI_NOW();
         uint32_t       nt = 0, cum = 0;
         bool           full = false;
         while (end < 0 && !full && nt <= GI_BATCH_FILL)
@@ -764,7 +775,7 @@ __device__ int gi_codes(GiLds& L, GiIn& in, GiOut& o, const GiBlockCtx& bc, uint
             nt += cnt;
         }
         // ---- B ---------------------------------------------------------------------------------------------------------------------
-        const uint64_t t_b = wall_clock64();
+        const uint64_t t_b = GI_NOW();
         o.tA += (uint32_t)(t_b - t_a);
         if (nt)
         {
@@ -857,7 +868,7 @@ __device__ int gi_codes(GiLds& L, GiIn& in, GiOut& o, const GiBlockCtx& bc, uint
                 rest &= rest - 1ull;
             }
             o.pos += cum;
-            const uint64_t t_f = wall_clock64();
+            const uint64_t t_f = GI_NOW();
             o.tB += (uint32_t)(t_f - t_b);
             while (o.pos - o.flushed >= 512u)
             {
@@ -865,7 +876,7 @@ __device__ int gi_codes(GiLds& L, GiIn& in, GiOut& o, const GiBlockCtx& bc, uint
                 if (o.ovf)
                     return 2;
             }
-            o.tF += (uint32_t)(wall_clock64() - t_f);
+            o.tF += (uint32_t)(GI_NOW() - t_f);
             if ((pos >> 5) > limit_dw) // (reading zeros beyond the fed bytes: whatever this is, it ends here)
                 return 1;
         }
@@ -1115,7 +1126,7 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
         o.have0     = false;
         o.tA = o.tB = o.tF = 0;
         uint32_t       t_screen = 0, t_cand = 0, t_hdr = 0, n_cand = 0;
-        const uint64_t t_chunk  = wall_clock64();
+        const uint64_t t_chunk  = GI_NOW();
         GiBlockCtx bc;
         bc.have_dist = false;
 
@@ -1154,7 +1165,7 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                 // Two screens: 64 positions a round take the cheap one, the survivors queue up in LDS; when 64 are queued (or the range
                 // is through) they take the second screen together, and what is left is tried in position order.
                 start = GI_NONE;
-                const uint64_t t_s = wall_clock64();
+                const uint64_t t_s = GI_NOW();
                 for (;;)
                 {
                     if (sq_m)
@@ -1241,7 +1252,7 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                     sq_n = sq_n + total < 256u ? sq_n + total : 256u;
                     search_at += 256u;
                 }
-                t_screen += (uint32_t)(wall_clock64() - t_s);
+                t_screen += (uint32_t)(GI_NOW() - t_s);
                 if (start == GI_NONE)
                 {
                     flags = 0;
@@ -1326,15 +1337,15 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                     rc = 1;
                 else
                 {
-                    const uint64_t t_h = wall_clock64();
+                    const uint64_t t_h = GI_NOW();
                     const bool hdr = gi_ub(btype == 2u ? gi_dynamic_header(L, in, bc) : gi_fixed_header(L, bc));
                     if (probation && first_block)
                     {
-                        t_cand += (uint32_t)(wall_clock64() - t_h);
+                        t_cand += (uint32_t)(GI_NOW() - t_h);
                         ++n_cand;
                     }
                     else
-                        t_hdr += (uint32_t)(wall_clock64() - t_h);
+                        t_hdr += (uint32_t)(GI_NOW() - t_h);
                     if (!hdr)
                         rc = 1;
                     else if (probation && first_block && p.strict)
@@ -1454,7 +1465,7 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
             C.prof[3] = o.tA;
             C.prof[4] = o.tB;
             C.prof[5] = o.tF;
-            C.prof[6] = (uint32_t)(wall_clock64() - t_chunk);
+            C.prof[6] = (uint32_t)(GI_NOW() - t_chunk);
             C.prof[7] = n_cand * 100000u; // (shown as a count by the /1e5 of the millisecond conversion)
         }
         __syncthreads();

@@ -421,7 +421,7 @@ typedef struct gn_inflate_stats
 {
     uint64_t steps, chunks, fixups, markers, members, text_bytes;
     double   ms_decode, ms_chain, ms_resolve, ms_step_wall;
-    /* summed over the chunks (wave-milliseconds): block search screen, headers of search candidates, block headers, Huffman decoding,
+    /* a library built with -DGI_PROF=1 (scripts/inflate_variants.sh; zeros otherwise), summed over the chunks (wave-milliseconds): block search screen, headers of search candidates, block headers, Huffman decoding,
      * placing the tokens (LZ77 copies), flushes, whole chunk; [7] unused */
     double   prof_ms[8];
 } gn_inflate_stats;
