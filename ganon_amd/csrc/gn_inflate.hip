@@ -123,9 +123,7 @@ struct GiState
     uint32_t n_real;
     uint32_t n_work;    // (real chunk, piece) items for the resolve kernel
     uint32_t reason;
-    uint32_t fix_slot;  // ~0u, or the slot a fix-up decode filled: taken first
-    uint32_t members;   // members begun so far
-    uint64_t markers;
+    uint32_t pad0;
     // what gi_order_kernel found (the fields above it only reads: pos_bit, run_len)
     uint64_t res_pos, res_run_len, res_markers;
     uint32_t res_members, n_mlist; // member ends of the step, in stream order (gi_order_kernel's mlist_*)
@@ -303,40 +301,6 @@ __device__ __forceinline__ void gi_emit(GiLds& L, GiOut& o, uint32_t sym)
 {
     L.ring[o.pos & (GI_RING - 1u)] = (uint16_t)sym;
     ++o.pos;
-}
-
-// LZ77 copy of `len` symbols from `dist` back.  lo_limit: how far before the chunk a source may lie (32768 with markers, 0 at a
-// member start); base: first symbol of the current member inside the chunk.  false = a source outside what exists.
-__device__ __forceinline__ bool gi_copy(GiLds& L, GiOut& o, uint32_t len, uint32_t dist, uint32_t base, bool markers_ok)
-{
-    const int32_t s0 = (int32_t)o.pos - (int32_t)dist;
-    if (s0 < (int32_t)base && (!markers_ok || base != 0u || s0 < -(int32_t)GI_WINDOW))
-        return false;
-    const int32_t ring_lo = (int32_t)o.pos + (int32_t)len - (int32_t)GI_RING; // positions from here on are in the ring for the whole copy
-    const bool    far     = s0 < ring_lo;
-    if (far)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores of the lines read below have left this wave long ago: make it certain
-    for (uint32_t t = 0; t < len; t += 64u)
-    {
-        const uint32_t i = t + gi_lane();
-        if (i < len)
-        {
-            const uint32_t off = dist >= len ? i : (dist == 1u ? 0u : i % dist);
-            const int32_t  sp  = s0 + (int32_t)off;
-            uint32_t       v;
-            if (sp < 0)
-                v = 256u + (uint32_t)((int32_t)GI_WINDOW + sp);
-            else if (sp >= ring_lo)
-                v = L.ring[(uint32_t)sp & (GI_RING - 1u)];
-            else
-                v = *gi_sym_addr(o.pool, L.piece, (uint32_t)sp);
-            if (v >= 256u)
-                o.markers += 1u; // (per-lane tally, summed at the end of the chunk)
-            L.ring[(o.pos + i) & (GI_RING - 1u)] = (uint16_t)v;
-        }
-    }
-    o.pos += len;
-    return true;
 }
 
 // ---- canonical Huffman tables in LDS -------------------------------------------------------------------------------------------
@@ -2320,7 +2284,6 @@ extern "C" int gn_inflate_create(int device, uint64_t compressed_bytes, uint32_t
     for (int b = 0; b < 2; ++b)
         GI_TRY(hipMalloc((void**)&z->d_text[b], z->text_cap + 64), "text");
     std::memset(z->h_state, 0, sizeof(GiState));
-    z->h_state->fix_slot = ~0u;
     GI_TRY(hipMemcpyAsync(z->d_state, z->h_state, sizeof(GiState), hipMemcpyHostToDevice, z->st), "state");
     GI_TRY(hipStreamSynchronize(z->st), "sync");
     GI_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gi_order_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(GI_ORDER_MAX * 16u)), "LDS size");
