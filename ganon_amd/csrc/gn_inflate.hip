@@ -2361,9 +2361,9 @@ static int gi_start_decode(gn_inflate* z, bool must, uint32_t from, int set)
         const uint64_t usable = fed > margin ? fed - margin : 0;
         j1                    = (uint32_t)(usable / z->chunk_bytes);
     }
-    // the first steps are small (an eighth of a step, then doubling): the caller's pipeline gets its first text after a few milliseconds
-    // instead of after a third of a gigabyte
-    const uint32_t ramp = std::max<uint32_t>(64u, std::min<uint32_t>(z->slots_cap, (z->slots_cap / 8u) << std::min<uint32_t>(z->launches, 3u)));
+    // the first step is half a step: as many chunks as the device holds waves of this kernel (a chunk takes its six milliseconds whatever
+    // runs beside it, so fewer chunks would not bring the first text any sooner), and the caller's pipeline gets text after a sixth of a gigabyte
+    const uint32_t ramp = z->launches == 0 ? std::max<uint32_t>(64u, z->slots_cap / 2u) : z->slots_cap;
     j1 = std::min<uint32_t>(j1, from + ramp);
     if (j1 <= from)
     {
