@@ -71,8 +71,6 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
             sw.chunk = (uint32_t)strtoul(p + 6, nullptr, 10), known = true;
         if (!known && n > 9 && !strncmp(p, "hibf_bpc=", 9))
             sw.hibf_bpc = (uint32_t)strtoul(p + 9, nullptr, 10), known = true;
-        if (!known && n > 12 && !strncmp(p, "inflate_bpc=", 12))
-            sw.inflate_bpc = (uint32_t)strtoul(p + 12, nullptr, 10), known = true;
         if (!known && n > 16 && !strncmp(p, "hibf_pair_limit=", 16))
             sw.hibf_pair_limit = std::max<uint64_t>(64, strtoull(p + 16, nullptr, 10)), known = true;
         if (!known && n > 5 && !strncmp(p, "sync=", 5))

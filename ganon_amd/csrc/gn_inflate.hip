@@ -1054,7 +1054,7 @@ __device__ __noinline__ bool gi_screen_header(const uint32_t* __restrict__ comp,
 
 } // namespace
 
-// One wave per chunk; a launch takes its chunks from an atomic counter (searches and decodes differ in length).
+// One wave per chunk, one chunk per workgroup (the slot comes from an atomic counter: chunks start in file order whatever the dispatcher does).
 __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
 {
     __shared__ GiLds L;
@@ -1433,8 +1433,9 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
             C.prof[7] = n_cand * 100000u; // (shown as a count by the /1e5 of the millisecond conversion)
         }
         __syncthreads();
-        if (fix)
-            return;
+        // One chunk a workgroup: waves that ran on for a whole launch kept every other kernel -- the filter loader's copies, the
+        // classification's -- waiting for a launch's length; the hardware's dispatcher hands out the slots as well as the counter did.
+        return;
     }
 }
 
@@ -2116,6 +2117,8 @@ __global__ void gi_crc_check_kernel(const uint32_t* __restrict__ acc, const uint
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
+#define GI_SETS 3 // decodes that may be in flight: the one a step is putting together and two ahead
+
 struct gn_inflate
 {
     int         device = 0;
@@ -2133,20 +2136,23 @@ struct gn_inflate
     uint32_t  slots_cap = 0, fix_cap = 64;
     // Two sets of what a step's decode writes (chunk records, symbol pool, counters): the NEXT step's decode is launched on a stream
     // of its own as soon as its range is known, and runs beside this step's tail, order, window and resolve passes.
-    GiChunk*  d_chunks_set[2] = { nullptr, nullptr };
-    uint16_t* d_pool_set[2]   = { nullptr, nullptr };
-    uint32_t* d_ctr_set[2]    = { nullptr, nullptr };
-    hipStream_t st_dec[2] = { nullptr, nullptr }; // (one per set: two decodes run side by side, the later one fills what the tail of the earlier leaves idle)
-    hipEvent_t  ev_dec[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
-    int       next_set = 0;
+    GiChunk*  d_chunks_set[GI_SETS] = {};
+    uint16_t* d_pool_set[GI_SETS]   = {};
+    uint32_t* d_ctr_set[GI_SETS]    = {};
+    hipStream_t st_dec[GI_SETS] = {}; // (one per set: the decodes run side by side, a later one fills what the tail of an earlier one leaves idle)
+    hipEvent_t  ev_dec[GI_SETS][2] = {};
+    int       n_sets = 0;
     uint32_t  launches = 0; // decodes launched so far (the first ones are smaller)
-    struct Pend // a decode in flight (or done): q[0] is what the next gn_inflate_step finishes, q[1] what the one after it does --
-    {           // launched on the assumption that q[0]'s step ends where its range does (almost always; otherwise it is dropped)
+    struct Pend // a decode in flight (or done): q[0] is what the next gn_inflate_step finishes, q[1] what the one after it does, ... --
+    {           // each launched on the assumption that the step before ends where its range does (almost always; otherwise dropped)
         bool     valid = false;
         uint32_t j0 = 0, j1 = 0;
         uint64_t fed = 0;
         int      set = 0;
-    } q[2];
+    } q[GI_SETS];
+    int nq = 0;
+    int  set_in_use = -1;        // the set the running step reads
+    bool ahead_from_next = false; // the step's true end is known: decodes ahead begin there
     GiChunk*  d_chunks = nullptr; // (the set of the step being finished)
     uint16_t* d_pool   = nullptr;
     uint32_t  pool_cap = 0;
@@ -2188,7 +2194,8 @@ static void gi_free(gn_inflate* z)
         return;
     hipSetDevice(z->device);
     hipDeviceSynchronize();
-    for (void* p : { (void*)z->d_comp, (void*)z->d_chunks_set[0], (void*)z->d_pool_set[0], (void*)z->d_ctr_set[0], (void*)z->d_chunks_set[1], (void*)z->d_pool_set[1], (void*)z->d_ctr_set[1], (void*)z->d_state, (void*)z->d_window, (void*)z->d_p_store, (void*)z->d_g_store, (void*)z->d_w_store,
+    for (void* p : { (void*)z->d_comp, (void*)z->d_chunks_set[0], (void*)z->d_pool_set[0], (void*)z->d_ctr_set[0], (void*)z->d_chunks_set[1], (void*)z->d_pool_set[1], (void*)z->d_ctr_set[1],
+                     (void*)z->d_chunks_set[2], (void*)z->d_pool_set[2], (void*)z->d_ctr_set[2], (void*)z->d_state, (void*)z->d_window, (void*)z->d_p_store, (void*)z->d_g_store, (void*)z->d_w_store,
                      (void*)z->d_real, (void*)z->d_work, (void*)z->d_mlist_pos, (void*)z->d_mlist_crc, (void*)z->d_cut_cnt, z->d_cut_tmp, (void*)z->d_cuts, (void*)z->d_text[0], (void*)z->d_text[1] })
         if (p)
             hipFree(p);
@@ -2196,7 +2203,7 @@ static void gi_free(gn_inflate* z)
         hipHostFree(z->h_state);
     if (z->h_crc)
         hipHostFree(z->h_crc);
-    for (hipStream_t s : { z->st, z->st_copy, z->st_out, z->st_dec[0], z->st_dec[1] })
+    for (hipStream_t s : { z->st, z->st_copy, z->st_out, z->st_dec[0], z->st_dec[1], z->st_dec[2] })
         if (s)
             hipStreamDestroy(s);
     for (hipEvent_t e : z->ev)
@@ -2254,15 +2261,23 @@ extern "C" int gn_inflate_create(int device, uint64_t compressed_bytes, uint32_t
     const uint64_t comp_alloc = ((compressed_bytes + 3) & ~3ull) + 1024;
     GI_TRY(hipMalloc((void**)&z->d_comp, comp_alloc), "compressed bytes");
     GI_TRY(hipMemsetAsync(z->d_comp + (compressed_bytes & ~3ull), 0, comp_alloc - (compressed_bytes & ~3ull), z->st), "memset");
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < GI_SETS; ++k)
     {
-        // (a file of one step needs one set)
-        if (k == 1 && (uint64_t)z->n_chunks_file * z->chunk_bytes <= step)
+        // (a file of k steps needs k sets at most)
+        if (k >= 1 && (uint64_t)z->n_chunks_file * z->chunk_bytes <= (uint64_t)k * step)
             break;
+        z->n_sets = k + 1;
         GI_TRY(hipMalloc((void**)&z->d_chunks_set[k], (size_t)(z->slots_cap + z->fix_cap) * sizeof(GiChunk)), "chunk records");
         GI_TRY(hipMalloc((void**)&z->d_pool_set[k], (size_t)z->pool_cap * GI_PIECE * 2u), "symbol pool");
         GI_TRY(hipMalloc((void**)&z->d_ctr_set[k], 64), "counters");
-        GI_TRY(hipStreamCreateWithFlags(&z->st_dec[k], hipStreamNonBlocking), "stream");
+        {
+            // the decodes run at the lowest stream priority: whatever else the device has to do (the step's own small passes, the
+            // classification, a filter being loaded) goes first when a slot frees up
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess)
+                lo = 0;
+            GI_TRY(hipStreamCreateWithPriority(&z->st_dec[k], hipStreamNonBlocking, lo), "stream");
+        }
         for (auto& e2 : z->ev_dec[k])
             GI_TRY(hipEventCreate(&e2), "event");
     }
@@ -2312,9 +2327,6 @@ extern "C" int gn_inflate_feed(gn_inflate* z, const uint8_t* data, uint64_t n)
     return GN_OK;
 }
 
-// decode waves per CU of one launch (each loops over chunks until the launch's are taken); $GANON_HIP_ABLATE inflate_bpc=N overrides
-#define GI_DECODE_BPC 16u
-
 static int gi_launch_chunks(gn_inflate* z, int set, hipStream_t st, uint64_t fed, uint32_t j0, uint32_t n, uint64_t fix_start, uint64_t fix_stop, uint32_t fix_slot)
 {
     GiParams p;
@@ -2333,8 +2345,7 @@ static int gi_launch_chunks(gn_inflate* z, int set, hipStream_t st, uint64_t fed
     p.fix_stop    = fix_stop;
     p.fix_slot    = fix_slot;
     p.strict      = 1;
-    const uint32_t bpc  = gn_sw().inflate_bpc ? gn_sw().inflate_bpc : GI_DECODE_BPC;
-    const uint32_t grid = fix_start != GI_NONE ? 1u : std::min<uint32_t>(n, (uint32_t)z->n_cu * bpc);
+    const uint32_t grid = fix_start != GI_NONE ? 1u : n;
     hipLaunchKernelGGL(gi_chunk_kernel, dim3(grid), dim3(64), 0, st, p);
     GN_HIP(hipGetLastError());
     return GN_OK;
@@ -2346,9 +2357,9 @@ static int gi_launch_chunks(gn_inflate* z, int set, hipStream_t st, uint64_t fed
 // pending); otherwise it is simply not launched yet.
 static int gi_start_decode(gn_inflate* z, bool must, uint32_t from, int set)
 {
-    gn_inflate::Pend& slot = z->q[0].valid ? z->q[1] : z->q[0];
-    if (slot.valid)
+    if (z->nq >= GI_SETS)
         return GN_OK;
+    gn_inflate::Pend& slot = z->q[z->nq];
     const uint64_t fed     = z->fed.load();
     const bool     all_fed = fed >= z->total;
     // chunks a step may decode: those whose range and a margin behind it are fed
@@ -2373,7 +2384,7 @@ static int gi_start_decode(gn_inflate* z, bool must, uint32_t from, int set)
             return gn_fail(GN_ERANGE, "gn_inflate_step: the gzip stream does not end inside the file");
         return gn_fail(GN_EINVAL, "gn_inflate_step: feed more bytes first (a step needs its chunks and a margin behind them -- 4 MiB at the default sizes -- or the whole file)");
     }
-    if (!z->d_chunks_set[set])
+    if (set < 0 || set >= GI_SETS || !z->d_chunks_set[set])
         return must ? gn_fail(GN_EINVAL, "gn_inflate_step: no decode set %d", set) : GN_OK; // (a one-step file has one set: nothing runs beside a step)
     GN_HIP(hipMemsetAsync(z->d_ctr_set[set], 0, 64, z->st_dec[set]));
     GN_HIP(hipEventRecord(z->ev_dec[set][0], z->st_dec[set]));
@@ -2386,6 +2397,7 @@ static int gi_start_decode(gn_inflate* z, bool must, uint32_t from, int set)
     slot.j1     = j1;
     slot.fed    = fed;
     slot.set    = set;
+    ++z->nq;
     ++z->launches;
     return GN_OK;
 }
@@ -2399,19 +2411,42 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     if (z->ended)
         return GN_OK;
     GN_HIP(hipSetDevice(z->device));
-    if (!z->q[0].valid)
+    // a set no pending decode uses and no step reads (-1: none)
+    auto free_set = [&](int busy) {
+        for (int k = 0; k < z->n_sets; ++k)
+        {
+            bool used = k == busy;
+            for (int i = 0; i < z->nq; ++i)
+                used = used || z->q[i].set == k;
+            if (!used)
+                return k;
+        }
+        return -1;
+    };
+    if (z->nq == 0)
     {
-        const int rc0 = gi_start_decode(z, true, z->next_chunk, z->next_set);
+        const int rc0 = gi_start_decode(z, true, z->next_chunk, free_set(-1));
         if (rc0 != GN_OK)
             return rc0;
     }
-    // this step's decode is in flight (launched by an earlier step, or just now); the one behind it starts beside it
+    // this step's decode is in flight (launched by an earlier step, or just now); the ones behind it start beside it
     const gn_inflate::Pend A = z->q[0];
-    z->q[0]                  = z->q[1];
-    z->q[1].valid            = false;
-    z->next_set              = A.set; // (the set this step frees when it is through)
-    if (!z->q[0].valid && A.j1 < z->n_chunks_file && !gn_sw().inflate_ahead)
-        gi_start_decode(z, false, A.j1, 1 - A.set);
+    for (int i = 1; i < z->nq; ++i)
+        z->q[i - 1] = z->q[i];
+    --z->nq;
+    auto launch_ahead = [&]() {
+        while (!gn_sw().inflate_ahead)
+        {
+            const uint32_t from = z->nq ? z->q[z->nq - 1].j1 : (z->ahead_from_next ? z->next_chunk : A.j1);
+            const int      k    = free_set(z->set_in_use);
+            const int      had  = z->nq;
+            if (from >= z->n_chunks_file || k < 0 || gi_start_decode(z, false, from, k) != GN_OK || z->nq == had)
+                break;
+        }
+    };
+    z->set_in_use      = A.set;
+    z->ahead_from_next = false;
+    launch_ahead();
     const int set      = A.set;
     z->fed_step        = A.fed;
     const bool all_fed = z->fed_step >= z->total;
@@ -2459,11 +2494,9 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         return gn_fail(GN_ERANGE, "gn_inflate_step: the data expands beyond what a step holds (more than 12-fold, or a chunk beyond 2 Mi symbols)");
     // where the next step begins is known now: its decode starts beside this step's remaining passes
     z->next_chunk = s.reason == GI_R_INPUT ? j0 + std::min<uint32_t>(s.cursor, n) : j1;
-    if (z->q[0].valid && z->q[0].j0 != z->next_chunk) // the decode that ran ahead assumed another start: dropped (its set is free again when it is through)
-    {
-        z->q[0]       = z->q[1];
-        z->q[1].valid = false;
-    }
+    if (z->nq && z->q[0].j0 != z->next_chunk) // the decodes that ran ahead assumed another start: dropped (their sets are free again when they are through)
+        z->nq = 0;
+    z->ahead_from_next = true;
     if (s.n_real)
     {
         const uint32_t groups = (s.n_real + GI_GROUP - 1u) / GI_GROUP;
@@ -2499,13 +2532,10 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     float ms = 0;
     if (hipEventElapsedTime(&ms, z->ev_dec[set][0], z->ev_dec[set][1]) == hipSuccess)
         z->stats.ms_decode += ms;
-    // this step's set is free: the decode after the one in flight starts now
+    // this step's set is free: one more decode ahead
+    z->set_in_use = -1;
     if (s.reason != GI_R_END && !(s.reason == GI_R_INPUT && all_fed))
-    {
-        const uint32_t from = z->q[0].valid ? z->q[0].j1 : z->next_chunk;
-        if (from < z->n_chunks_file && !gn_sw().inflate_ahead)
-            gi_start_decode(z, false, from, set);
-    }
+        launch_ahead();
     if (hipEventElapsedTime(&ms, z->ev[1], z->ev[2]) == hipSuccess)
         z->stats.ms_chain += ms;
     if (hipEventElapsedTime(&ms, z->ev[2], z->ev[3]) == hipSuccess)

@@ -49,7 +49,6 @@ struct GnSwitches
     bool hibf_fake_hashes = false; // TIMING EXPERIMENT ONLY (wrong results): the packed kernel loads one hash per item and derives the others
     uint32_t hibf_bpc = 0;        // >0: workgroups per CU of the HIBF register kernels (0: what the occupancy query says)
     // device inflate
-    uint32_t inflate_bpc = 0;     // >0: decode waves per CU of one gn_inflate_step launch (0: the default, see gn_inflate.hip)
     bool     inflate_ahead = false; // no decode launched ahead of the step that needs it
     uint64_t hibf_pair_limit = 0; // >0: (read, user bin) pairs per round of a batch (tests make a batch take several rounds)
     // multi-device

@@ -524,7 +524,10 @@ struct Cleanups
             mine.swap(th);
         }
         for (auto& t : mine)
-            t.join();
+            if (fast_exit()) // (the process ends with _Exit in a moment: nobody needs the memory they are still freeing)
+                t.detach();
+            else
+                t.join();
     }
 } g_cleanups;
 
@@ -1252,7 +1255,7 @@ static bool ganon_classify(Config config)
     if (device_text)
     {
         // ... and when the device has the room beside what is still to come: the filters are loaded AFTER the reader starts, and an
-        // inflater takes its buffers (19 GB at the default sizes, twice for a pair) the moment a file is opened.  Room = free memory now
+        // inflater takes its buffers (25 GB at the default sizes, twice for a pair) the moment a file is opened.  Room = free memory now
         // - the filter files' sizes - a share for the workers' batch buffers (as placement.hpp keeps: an eighth, 16 GiB at most of half)
         uint64_t filter_bytes = 0;
         for (auto const& l : levels)
@@ -1264,7 +1267,7 @@ static bool ganon_classify(Config config)
             }
         const uint64_t fr      = device_text->free_device_bytes();
         const uint64_t reserve = std::max<uint64_t>(fr / 8, std::min<uint64_t>(fr / 2, 16ull << 30)) + (24ull << 30);
-        const uint64_t need    = env_size("GANON_HOST_DEVICE_INFLATE_ROOM", 44ull << 30);
+        const uint64_t need    = env_size("GANON_HOST_DEVICE_INFLATE_ROOM", 56ull << 30);
         if (fr < filter_bytes + reserve + need)
         {
             if (config.verbose)

@@ -44,9 +44,7 @@ int main(int argc, char** argv)
     std::cerr.flush();
     std::fflush(nullptr);
     // (a profiler that writes its trace from an exit handler needs the normal return: rocprofv3 preloads its tool library)
-    const char* preload  = std::getenv("LD_PRELOAD");
-    const bool  profiled = (preload && std::strstr(preload, "rocprof")) || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_LIBRARY");
-    if (!std::getenv("GANON_HOST_FULL_TEARDOWN") && !profiled)
+    if (gnhost::fast_exit())
         std::_Exit(ok ? EXIT_SUCCESS : EXIT_FAILURE);
     return ok ? EXIT_SUCCESS : EXIT_FAILURE;
 }

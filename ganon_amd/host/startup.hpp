@@ -4,6 +4,8 @@
 // read and a push under a mutex) and always taken; printing is --verbose only.  The reference's counterpart is its
 // "loading filter(s) elapsed" line (timeLoadFilters, GanonClassify.cpp:1470-1477).
 #pragma once
+#include <cstdlib>
+#include <cstring>
 
 #include <chrono>
 #include <cstdio>
@@ -76,5 +78,14 @@ private:
     std::vector<Span> spans_;
     double            origin_, before_main_ = 0;
 };
+
+// main() leaves with _Exit once every output is closed (see main.cpp) unless a profiler's exit handler or $GANON_HOST_FULL_TEARDOWN wants
+// the normal return: whoever would only free memory on the way out asks here and does not bother
+inline bool fast_exit()
+{
+    const char* preload  = std::getenv("LD_PRELOAD");
+    const bool  profiled = (preload && std::strstr(preload, "rocprof")) || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_LIBRARY");
+    return !std::getenv("GANON_HOST_FULL_TEARDOWN") && !profiled;
+}
 
 } // namespace gnhost

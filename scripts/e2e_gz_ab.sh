@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 OUT=${1:-gpurun_out/r05_e2e_gz_ab.txt}
 : > $OUT
-for sw in "" "inflate_ahead" "inflate_bpc=8"; do
+for sw in "" "inflate_ahead"; do
   echo "### GANON_HIP_ABLATE=$sw" >> $OUT
   GANON_HIP_ABLATE=$sw E2E_DIAG=1 timeout 600 python bench_e2e.py --only gz --runs 5 --budget 200 2>/dev/null | python -c "
 import sys,json
