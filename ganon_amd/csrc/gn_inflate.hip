@@ -2235,14 +2235,16 @@ extern "C" int gn_inflate_create(int device, uint64_t compressed_bytes, uint32_t
         z->n_cu = prop.multiProcessorCount;
     z->total       = compressed_bytes;
     z->chunk_bytes = chunk_bytes ? std::min<uint32_t>(std::max<uint32_t>(chunk_bytes & ~3u, 256u), 16u << 20) : 32768u; // (positions inside a chunk are 31-bit numbers)
-    z->step_bytes  = step_bytes ? std::max<uint64_t>(step_bytes, z->chunk_bytes) : (256ull << 20);
+    // (device memory is cleared when it is allocated -- 27 GB took 0.15 s, and several times that beside other allocations: the buffers of a
+    //  file are sized to the file; steps of 128 MiB for files below 1.5 GB, 256 MiB above, where a tenth of a second does not count)
+    z->step_bytes  = step_bytes ? std::max<uint64_t>(step_bytes, z->chunk_bytes) : (compressed_bytes < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
     z->step_bytes  = (z->step_bytes + z->chunk_bytes - 1) / z->chunk_bytes * z->chunk_bytes;
     z->step_bytes  = std::min<uint64_t>(z->step_bytes, 8192ull * z->chunk_bytes); // (gi_order_kernel keeps a step's slots in LDS)
     z->n_chunks_file = (uint32_t)((compressed_bytes + z->chunk_bytes - 1) / z->chunk_bytes);
     const uint64_t step = std::min<uint64_t>(z->step_bytes, (uint64_t)z->n_chunks_file * z->chunk_bytes);
     z->slots_cap        = (uint32_t)(step / z->chunk_bytes);
-    // text of a step: up to 12 x its compressed bytes (FASTQ: 3.5-6 x); beyond that the caller's host path takes the file
-    z->text_cap = std::max<uint64_t>(step * 12u, 1u << 20) + (4u << 20);
+    // text of a step: up to 8 x its compressed bytes (FASTQ: 3.5-6 x); beyond that the caller's host path takes the file
+    z->text_cap = std::max<uint64_t>(step * 8u, 1u << 20) + (4u << 20);
     z->pool_cap = (uint32_t)(z->text_cap / GI_PIECE) + 2u * (z->slots_cap + z->fix_cap) + 64u;
     z->work_cap = z->pool_cap;
     auto fail = [&](hipError_t e, const char* what) {
@@ -2491,7 +2493,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     if (s.reason == GI_R_MEMBER)
         return gn_fail(GN_ERANGE, "gn_inflate_step: gzip member with a wrong length (ISIZE)");
     if (s.reason == GI_R_OVERFLOW)
-        return gn_fail(GN_ERANGE, "gn_inflate_step: the data expands beyond what a step holds (more than 12-fold, or a chunk beyond 2 Mi symbols)");
+        return gn_fail(GN_ERANGE, "gn_inflate_step: the data expands beyond what a step holds (more than 8-fold, or a chunk beyond 2 Mi symbols)");
     // where the next step begins is known now: its decode starts beside this step's remaining passes
     z->next_chunk = s.reason == GI_R_INPUT ? j0 + std::min<uint32_t>(s.cursor, n) : j1;
     if (z->nq && z->q[0].j0 != z->next_chunk) // the decodes that ran ahead assumed another start: dropped (their sets are free again when they are through)

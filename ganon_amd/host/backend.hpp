@@ -14,6 +14,7 @@
 #include "filter_io.hpp"
 #include "hostmem.hpp"
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <memory>
@@ -226,6 +227,9 @@ public:
         err = "not a source by lines";
         return false;
     }
+    // Opening a source allocates and feeds; nothing is decoded before go(), and no new step is begun while *run is false (the caller
+    // says when the device may take that work on: device allocations of others crawl beside it)
+    virtual void        go(const std::atomic<bool>* /*run*/ = nullptr) {}
     virtual uint64_t    delivered() const = 0;
     virtual bool        fasta() const = 0;
     virtual std::string report() const { return std::string(); }

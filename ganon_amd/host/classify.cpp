@@ -531,6 +531,14 @@ struct Cleanups
     }
 } g_cleanups;
 
+// The device inflaters decode from the moment their file is open -- beside the filters being read and uploaded -- but begin no new step
+// while a level's worker contexts are set up: every device allocation of those waits for the decode kernels then (six contexts 0.03 ->
+// 0.4-0.9 s, profiles/r05_e2e_device_inflate_run8: the whole process got slower although the timed part got faster).
+struct DeviceGate
+{
+    std::atomic<bool> run{ true };
+} g_devices_ready;
+
 void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq, Backend* device_text,
                  bool further_levels)
 {
@@ -607,6 +615,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             {
                 if (auto src = device_text->open_gzip_text(pair.mate1, slab_bytes, env_size("GANON_HOST_DEVICE_INFLATE_MIN", 1u << 20)))
                 {
+                    src->go(&g_devices_ready.run);
                     auto            tracker = std::make_shared<RawFileTracker>();
                     size_t          pieces  = 0;
                     DeviceTextPiece pc;
@@ -662,6 +671,8 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                 auto         src2  = src1 ? device_text->open_gzip_text(pair.mate2, piece, 0, true) : nullptr;
                 if (src1 && src2)
                 {
+                    src1->go(&g_devices_ready.run);
+                    src2->go(&g_devices_ready.run);
                     auto            tracker = std::make_shared<RawFileTracker>();
                     size_t          pieces  = 0;
                     DeviceTextPiece p1, p2;
@@ -1255,7 +1266,7 @@ static bool ganon_classify(Config config)
     if (device_text)
     {
         // ... and when the device has the room beside what is still to come: the filters are loaded AFTER the reader starts, and an
-        // inflater takes its buffers (25 GB at the default sizes, twice for a pair) the moment a file is opened.  Room = free memory now
+        // inflater takes its buffers (9 GB for a file below 1.5 GB, 18 GB above, twice for a pair) the moment a file is opened.  Room = free memory now
         // - the filter files' sizes - a share for the workers' batch buffers (as placement.hpp keeps: an eighth, 16 GiB at most of half)
         uint64_t filter_bytes = 0;
         for (auto const& l : levels)
@@ -1267,7 +1278,7 @@ static bool ganon_classify(Config config)
             }
         const uint64_t fr      = device_text->free_device_bytes();
         const uint64_t reserve = std::max<uint64_t>(fr / 8, std::min<uint64_t>(fr / 2, 16ull << 30)) + (24ull << 30);
-        const uint64_t need    = env_size("GANON_HOST_DEVICE_INFLATE_ROOM", 56ull << 30);
+        const uint64_t need    = env_size("GANON_HOST_DEVICE_INFLATE_ROOM", 40ull << 30);
         if (fr < filter_bytes + reserve + need)
         {
             if (config.verbose)
@@ -1283,6 +1294,7 @@ static bool ganon_classify(Config config)
         BatchQueue&  q;
         ~Joiner()
         {
+            g_devices_ready.run = true; // (an early error return: nobody must wait for a level that never comes)
             if (t.joinable())
             {
                 ReadBatch b; // drain so that a blocked producer can finish after an early error return
@@ -1497,6 +1509,7 @@ static bool ganon_classify(Config config)
         }
 
         const double t_setup = StartupLog::now();
+        g_devices_ready.run = false; // (no new inflate step beside the stream set-up, see DeviceGate)
         loading.start(); // (device-side setup belongs to loading: the reference's agents exist once its filters are read)
         // device streams for the largest batch, and one tiny batch through every worker context: buffers are allocated and the
         // kernels' code is loaded here, not with the first reads (the reader is parsing its first slabs meanwhile)
@@ -1519,6 +1532,7 @@ static bool ganon_classify(Config config)
                 t.join();
         }
         loading.stop();
+        g_devices_ready.run = true;
         StartupLog::get().span("level " + level.label + ": device streams and the warm-up batch (all worker contexts at once)", t_setup);
         if (config.verbose)
             StartupLog::get().print(std::cerr);

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -109,13 +110,15 @@ public:
         piece_    = std::max<size_t>(piece_bytes, 1 << 16);
         const char* sb = std::getenv("GANON_HOST_DEVICE_INFLATE_STEP");
         const char* cb = std::getenv("GANON_HOST_DEVICE_INFLATE_CHUNK");
+        const auto t_open = std::chrono::steady_clock::now();
+        t0_ = t_open;
         if (gn_inflate_create(device, size_, cb ? (uint32_t)std::atoll(cb) : 0, sb ? (uint64_t)std::atoll(sb) : 0, &z_) != GN_OK)
         {
             z_ = nullptr;
             return false; // (no room for the file and the step buffers beside the filters: the host inflater takes it)
         }
-        if (sb)
-            l_step_ = (uint64_t)std::atoll(sb);
+        l_step_ = sb ? (uint64_t)std::atoll(sb) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
+        sec_create_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         n_blocks_ = (size_ + kBlock - 1) / kBlock;
         for (unsigned i = 0; i < kRing; ++i)
         {
@@ -124,6 +127,7 @@ public:
                 return false;
             blocks_.push_back(p);
         }
+        sec_pinned_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count() - sec_create_;
         const unsigned n_readers = (unsigned)std::min<uint64_t>(3, n_blocks_);
         for (unsigned t = 0; t < n_readers; ++t)
             readers_.emplace_back([this] { read_loop(); });
@@ -174,7 +178,8 @@ public:
                 const int buf = (int)(l_step_no_ & 1u);
                 {
                     std::unique_lock<std::mutex> lk(m_);
-                    cv_.wait(lk, [&] { return stop_ || finished_ || (fed_bytes_ >= l_want_ && held_[buf] == 0); });
+                    while (!cv_.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop_ || finished_ || (may_run() && fed_bytes_ >= l_want_ && held_[buf] == 0); }))
+                        ;
                     if (stop_ || finished_)
                     {
                         err = error_;
@@ -190,6 +195,8 @@ public:
                     err = error_;
                     return false;
                 }
+                if (sec_first_ == 0)
+                    sec_first_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
                 uint64_t dn = 0;
                 gn_inflate_text_device(z_, &l_text_, &dn);
                 l_n_      = n_text;
@@ -248,6 +255,14 @@ public:
             return out.bytes != 0 || whole;
         }
     }
+    void go(const std::atomic<bool>* run) override
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        go_  = true;
+        run_ = run;
+        cv_.notify_all();
+    }
+    bool may_run() const { return !run_ || run_->load(); }
     uint64_t    delivered() const override { return delivered_; }
     bool        fasta() const override { return fasta_; }
     std::string report() const override
@@ -259,7 +274,8 @@ public:
         std::ostringstream o;
         o << "device inflate: " << st.steps << " steps, " << st.chunks << " chunks, " << st.fixups << " fix-ups, " << st.members << " members, "
           << st.text_bytes << " bytes of text; device ms: decode " << st.ms_decode << ", order " << st.ms_chain << ", windows+resolve " << st.ms_resolve
-          << "; step calls " << st.ms_step_wall << " ms";
+          << "; step calls " << st.ms_step_wall << " ms; opening: device buffers " << sec_create_ << " s, page-locked blocks " << sec_pinned_
+          << " s, first text after " << sec_first_ << " s, all fed after " << sec_fed_ << " s";
         return o.str();
     }
 
@@ -323,6 +339,8 @@ private:
             }
             fed_blocks_ = b + 1;
             fed_bytes_  = off + n;
+            if (b + 1 == n_blocks_)
+                sec_fed_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
             cv_.notify_all();
         }
     }
@@ -342,7 +360,7 @@ private:
         std::vector<uint64_t> cuts, cut_lines;
         unsigned              step_no = 0;
         const char*           sb   = std::getenv("GANON_HOST_DEVICE_INFLATE_STEP");
-        const uint64_t        step = sb ? (uint64_t)std::atoll(sb) : (256ull << 20);
+        const uint64_t        step = sb ? (uint64_t)std::atoll(sb) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
         uint64_t              want = 0; // compressed bytes the next step should find
         for (;;)
         {
@@ -350,7 +368,8 @@ private:
             const int buf = (int)(step_no & 1u);
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || finished_ || (fed_bytes_ >= want && held_[buf] == 0); });
+                while (!cv_.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop_ || finished_ || (go_ && may_run() && fed_bytes_ >= want && held_[buf] == 0); }))
+                    ;
                 if (stop_ || finished_)
                     return;
             }
@@ -362,6 +381,8 @@ private:
                 fail_locked(gn_last_error());
                 return;
             }
+            if (sec_first_ == 0)
+                sec_first_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
             const uint8_t* dtext = nullptr;
             uint64_t       dn    = 0;
             gn_inflate_text_device(z_, &dtext, &dn);
@@ -435,13 +456,16 @@ private:
     std::thread           feeder_, stepper_;
     mutable std::mutex    m_;
     std::condition_variable cv_;
-    bool                  stop_ = false, finished_ = false;
+    bool                  stop_ = false, finished_ = false, go_ = false;
+    const std::atomic<bool>* run_ = nullptr;
     std::string           error_;
     uint64_t              next_read_ = 0, fed_blocks_ = 0, fed_bytes_ = 0;
     std::map<uint64_t, bool> read_done_;
     std::deque<DeviceTextPiece> q_;
     uint64_t              held_[2] = { 0, 0 };
     std::atomic<uint64_t> delivered_{ 0 };
+    std::chrono::steady_clock::time_point t0_;
+    double sec_create_ = 0, sec_pinned_ = 0, sec_first_ = 0, sec_fed_ = 0;
     // by_lines state (the caller's thread only)
     bool           by_lines_ = false, l_have_ = false, l_done_ = false, l_eof_ = false;
     const uint8_t* l_text_ = nullptr;

@@ -405,7 +405,7 @@ int gn_stream_hibf_level_lines(gn_stream* s, uint64_t* line_bytes, uint32_t cap)
  * decodes the chunks between them in parallel and returns the text -- the same bytes zlib's inflate() yields for the file
  * (every member; what follows the last member is ignored like gzip does).  Every member's CRC-32 and ISIZE are checked.
  *   gn_inflate_create   compressed_bytes = size of the file; chunk_bytes = compressed bytes per parallel chunk (0: 32 KiB);
- *                       step_bytes = compressed bytes decoded per gn_inflate_step (0: 256 MiB; at most 8192 chunks).  The whole compressed file
+ *                       step_bytes = compressed bytes decoded per gn_inflate_step (0: 128 MiB for files below 1.5 GB, 256 MiB above; at most 8192 chunks).  The whole compressed file
  *                       stays resident in HBM (files of 64 GiB and more: GN_ERANGE).
  *   gn_inflate_feed     appends the next n bytes of the file (host memory; returns when `data` may be reused)
  *   gn_inflate_step     decodes the next step: every chunk whose bytes, and 4 MiB behind them, are fed -- all of the rest once the
@@ -414,7 +414,7 @@ int gn_stream_hibf_level_lines(gn_stream* s, uint64_t* line_bytes, uint32_t cap)
  *   gn_inflate_text     copies [off, off + n) of the LAST step's text to host memory
  *   gn_inflate_text_device   the last step's text in device memory (valid until the step after the next one begins)
  * GN_ERANGE from gn_inflate_step: damaged / truncated data, a wrong CRC-32 or ISIZE, or data this decoder is not made for (more than
- * 12-fold expansion, hardly any dynamic-Huffman blocks): the caller reads the file with its host inflater instead -- nothing
+ * 8-fold expansion, hardly any dynamic-Huffman blocks): the caller reads the file with its host inflater instead -- nothing
  * that was returned before is wrong, and nothing is returned that was not decoded. */
 typedef struct gn_inflate gn_inflate;
 typedef struct gn_inflate_stats
