@@ -134,11 +134,17 @@ struct GiLds
 {
     uint32_t lit[GI_LIT_CAP];
     uint32_t dst[GI_DIST_CAP];
-    uint16_t ring[GI_RING];
+    union // (the search's queues hold nothing a decode attempt needs, and an attempt that fails starts the search again behind its position)
+    {
+        uint16_t ring[GI_RING];
+        struct
+        {
+            uint32_t cand_q[256]; // the search: positions (relative to the chunk's nominal start) that passed the first screen (a ring)
+            uint32_t cand_q2[128]; // ... and the second
+        };
+    };
     uint32_t piece[GI_MAX_PIECES];
     uint16_t tok_len[64], tok_val[64]; // the batch's tokens (gi_codes)
-    uint32_t cand_q[256];              // the search: positions (relative to the chunk's nominal start) that passed the first screen (a ring)
-    uint32_t cand_q2[128];             // ... and the second
     uint8_t  lens[320];
 };
 
@@ -1238,8 +1244,13 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
             if (at_header)
             {
                 const uint64_t q = gi_u64(gi_gzip_header(p.comp, p.total_bits >> 3, start >> 3));
-                if (!q && probation)
-                    continue; // (three bytes that look like a member's first: the search goes on)
+                if (!q && probation) // (three bytes that look like a member's first: the search goes on behind them)
+                {
+                    search_at = start + 1u;
+                    sq_n = sq2_n = sq_h = sq2_h = 0;
+                    sq_m      = 0;
+                    continue;
+                }
                 if (!q)
                 {
                     flags   = GI_F_FAILED;
@@ -1395,8 +1406,13 @@ __global__ __launch_bounds__(64) void gi_chunk_kernel(GiParams p)
                     ++members;
                 }
             }
-            if (failed && probation && first_block)
-                continue; // a false start: the search goes on behind it
+            if (failed && probation && first_block) // a false start: the search goes on behind it (its queues shared the ring's memory: from scratch)
+            {
+                search_at = start + 1u;
+                sq_n = sq2_n = sq_h = sq2_h = 0;
+                sq_m      = 0;
+                continue;
+            }
             if (failed)
                 flags |= GI_F_FAILED;
             done = true;
