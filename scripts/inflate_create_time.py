@@ -1,5 +1,6 @@
 import time, sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ganon_amd import hip
 import numpy as np
 hip.load_library()
