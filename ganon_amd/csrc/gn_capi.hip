@@ -50,7 +50,7 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                               {"csr_identity", &GnSwitches::csr_identity},   {"uniform_select", &GnSwitches::uniform_select},
                               {"run_select", &GnSwitches::run_select},       {"max_first", &GnSwitches::max_first},
                               {"const_nb", &GnSwitches::const_nb},           {"split_kernel", &GnSwitches::split_kernel},
-                              {"predrop", &GnSwitches::predrop},             {"deferred_grids", &GnSwitches::deferred_grids},
+                              {"predrop", &GnSwitches::predrop},             {"deferred_grids", &GnSwitches::deferred_grids}, {"on_demand", &GnSwitches::on_demand},
                               {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
                               {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent}, {"hibf_stage", &GnSwitches::hibf_stage}, {"hibf_nsort", &GnSwitches::hibf_nsort}, {"hibf_reread", &GnSwitches::hibf_reread},
                               {"hibf_fake_hashes", &GnSwitches::hibf_fake_hashes}, {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
@@ -985,7 +985,7 @@ extern "C" int gn_stream_create(gn_filter* f, uint32_t max_reads, uint64_t max_b
         ok(gn_dmalloc(&s->d_work[1], s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer, s->work_cap));
         ok(gn_dmalloc(&s->d_hdefer2, s->work_cap));
-        ok(gn_dmalloc(&s->d_hctr, 29 * (GN_HIBF_MAXDEPTH + 1) + 2));
+        ok(gn_dmalloc(&s->d_hctr, 37 * (GN_HIBF_MAXDEPTH + 1) + 2));
         ok(gn_dmalloc(&s->d_hsub, 384 * (GN_HIBF_MAXDEPTH + 1))); // per level: counts, bases, cursors of the 128 (class, n-bin) keys
         ok(hipHostMalloc(reinterpret_cast<void**>(&s->h_hctr), (5 * (GN_HIBF_MAXDEPTH + 1) + 2) * sizeof(unsigned long long), hipHostMallocDefault));
     }
@@ -1260,6 +1260,11 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
         GN_HIP(hipMemsetAsync(s->d_ctr + 4, 0, sizeof(unsigned long long), s->st));
         p.work_list_out  = s->d_deferred;
         p.work_count_out = s->d_ctr + 4;
+        if (!gn_sw().on_demand)
+        {
+            GN_HIP(hipMemsetAsync(s->d_ctr + 72, 0, sizeof(unsigned long long), s->st));
+            p.grab = s->d_ctr + 72;
+        }
         GN_HIP(gn_launch_count_fast(p, f->geom, f->ibf.h, s->st));
         p.work_list  = s->d_deferred;
         p.work_count = s->d_ctr + 4;
@@ -1835,7 +1840,7 @@ extern "C" int gn_stream_timings(gn_stream* s, gn_timings* t)
     hipEventElapsedTime(&tm.ms_count, s->ev_count0, s->ev[2]); // first count kernel start -> last count kernel end
     hipEventElapsedTime(&tm.ms_total, s->ev[0], s->ev[3]);
     tm.n_hashes = 0;
-    for (int i = 8; i < GN_NCTR; ++i) // (the minimiser kernels of the batch ran on the stream the reads were uploaded to)
+    for (int i = 8; i < 8 + 64; ++i) // 64 shards (the minimiser kernels of the batch ran on the stream the reads were uploaded to)
         tm.n_hashes += (s->src ? s->src : s)->h_ctr[i];
     tm.n_matches = s->n_matches;
     tm.n_count_launches = s->n_chunks;

@@ -106,6 +106,7 @@ struct GnHibfLevelParams
     uint8_t                   cls_gp[8];
     const unsigned long long* cls_count;
     const unsigned long long* cls_base;
+    unsigned long long*       grab;      // packed kernel: per class the cursor its waves take their later batches from (zero at launch)
     uint32_t                  fake_hashes;
     uint32_t                  reread;
     uint32_t                  lds_region;   // packed kernel: 8-byte words of dynamic LDS per wave
@@ -253,6 +254,14 @@ __device__ __forceinline__ uint32_t gn_hibf_row_seed(uint64_t v, uint64_t seed, 
 #else
 #define GN_PACK_ATTR __attribute__((amdgpu_waves_per_eu(4, 8)))
 #endif
+#ifdef GN_PACK_PROF
+// (profiling build only: per class -- wave cycles in the class / row loop / staging / tail, batches, iterations, item iterations, lines)
+__device__ unsigned long long gn_pack_prof_buf[8][8];
+__device__ unsigned long long gn_pack_prof_wave[8192][2]; // per wave: first and last tick of the 100 MHz clock
+#define GN_PP_NOW() clock64()
+#else
+#define GN_PP_NOW() 0ull
+#endif
 template <int HF, bool LEVEL0>
 __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLevelParams p)
 {
@@ -267,14 +276,34 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
     const uint32_t stride = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave_id = (uint32_t)blockIdx.x * (blockDim.x >> 6) + wave;
 
+#ifdef GN_PACK_PROF
+    const unsigned long long pp_wall0 = wall_clock64();
+#endif
     GnHibfAppender     app;
     unsigned long long my_bytes = 0, my_lines = 0;
     uint32_t           rot = 0; // batches of the classes before this one (mod the grid's waves): every class starts where the last one ended,
                                 // so a small class does not land on the same few waves as the small class before it
 
   const uint32_t n_cls = LEVEL0 || p.n_cls == 0 ? 1u : p.n_cls;
-  for (uint32_t cls = 0; cls < n_cls; ++cls)
+  // The class with the most batches comes last: it is the one whose batches are handed out on demand (below), so whatever lead or lag a
+  // wave has collected in the classes before is evened out there.
+  uint32_t big = 0;
+  if (n_cls > 1)
   {
+      unsigned long long most = 0;
+      for (uint32_t c = 0; c < n_cls; ++c)
+      {
+          const unsigned long long b = (p.cls_count[c] + (GN_WAVE >> p.cls_gp[c]) - 1) >> (6u - p.cls_gp[c]);
+          if (b > most)
+          {
+              most = b;
+              big  = c;
+          }
+      }
+  }
+  for (uint32_t ci = 0; ci < n_cls; ++ci)
+  {
+    const uint32_t cls    = ci + 1 == n_cls ? big : (ci < big ? ci : ci + 1);
     const uint32_t gpl    = (LEVEL0 || p.n_cls == 0) ? p.pack_gp : (uint32_t)p.cls_gp[cls];
     const uint32_t Gp     = 1u << gpl;
     const uint32_t H      = GN_WAVE >> gpl;          // items per wave
@@ -300,10 +329,34 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
         }
     }
     const uint32_t n_batches = (n_work + H - 1) / H;
-    uint32_t       batch     = wave_id >= rot ? wave_id - rot : wave_id + stride - rot;
+    const uint32_t first     = wave_id >= rot ? wave_id - rot : wave_id + stride - rot;
     rot                      = (uint32_t)(((uint64_t)rot + n_batches) % stride);
+    // Which batches a wave takes.  Up to round 5 wave i took batches i, i + waves, ... of every class: the same count for every wave -- and
+    // the waves of a launch ended between 0.59 and 1.0 of its duration (level 1 of the skewed tree: first wave through after 4.9 ms, the
+    // median after 6.4, the last after 8.3; level 0: 8.3 / 9.3 / 9.9, the XCDs with odd numbers 11 % behind the even ones:
+    // profiles/r05_pack_prof_skew.txt).  That stays for the small classes.  In the LAST class of a launch (the largest; level 0 has one) a
+    // wave starts with a chunk of its own and takes every later chunk from the class's cursor -- asked for one chunk ahead, so that the
+    // answer is there when it is needed; about six chunks a wave, half-size ones for the last quarter of the class, quarter-size ones for
+    // its last eighth.  (A counter address
+    // takes ~90 atomics a microsecond: chunks, not batches, and not for classes of a few batches a wave -- tried: level 2 lost 0.35 ms.)
+    const bool dyn = ci + 1 == n_cls && n_batches >= 8u * stride && p.grab != nullptr;
+    uint32_t   G0  = dyn ? n_batches / (stride * 6u) : 1u;
+    G0             = G0 < 1u ? 1u : (G0 > 16u ? 16u : G0);
+    uint32_t batch = first * G0;
     if (batch >= n_batches)
         continue;
+    uint32_t       end       = batch + G0 < n_batches ? batch + G0 : n_batches;
+    const uint32_t dyn_from  = stride * G0; // the cursor counts from here
+    const uint32_t tail_from = n_batches - n_batches / 4u, tail2_from = n_batches - n_batches / 8u;
+    unsigned long long* const gctr = p.grab + cls;
+    uint32_t g_next = 0, g_size = G0; // (lane 0: what the cursor answered; the size asked for)
+    auto     ask    = [&](uint32_t from) {
+        g_size = from < tail_from ? G0 : (from < tail2_from ? (G0 >= 2u ? G0 / 2u : 1u) : (G0 >= 8u ? G0 / 4u : (G0 >= 2u ? 2u : 1u)));
+        if (lane == 0)
+            g_next = (uint32_t)atomicAdd(gctr, (unsigned long long)g_size);
+    };
+    if (dyn)
+        ask(batch);
 
     // per-lane view of an item (the Gp lanes of a group hold identical copies)
     struct Item
@@ -350,10 +403,27 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
         return m;
     };
 
+#ifdef GN_PACK_PROF
+    unsigned long long pp_row = 0, pp_stage = 0, pp_tail = 0, pp_batches = 0, pp_iters = 0, pp_items = 0, pp_lines0 = my_lines;
+    const unsigned long long pp_t0 = GN_PP_NOW();
+#endif
     Item cur = load_item(batch);
     for (;;)
     {
-        const Item nxt = load_item(batch + stride); // its loads fly behind this batch's row loop
+        uint32_t next_batch = batch + 1u;
+        if (next_batch >= end)
+        {
+            next_batch = batch + stride; // (a small class: batches i, i + waves, ...)
+            end        = next_batch + 1u;
+            if (dyn)
+            {
+                next_batch = dyn_from + (uint32_t)__builtin_amdgcn_readfirstlane((int)g_next); // (asked for a chunk ago)
+                end        = next_batch + g_size < n_batches ? next_batch + g_size : n_batches;
+                if (next_batch < n_batches)
+                    ask(next_batch);
+            }
+        }
+        const Item nxt = load_item(next_batch); // its loads fly behind this batch's row loop
 
         // items this kernel does not count: one entry per group (lane gl == 0) on the per-item kernel's list
         {
@@ -403,6 +473,9 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
         const uint64_t hs_at = cur.slot; // (index into p.hashes)
         const uint64_t fake0 = p.fake_hashes ? p.hashes[n ? hs_at : 0ull] : 0ull;
         const bool     staged = p.stage_hashes && gpl >= 1 && gpl <= 2; // (wave-uniform; see gn_hibf_pack_region)
+#ifdef GN_PACK_PROF
+        const unsigned long long pp_t1 = GN_PP_NOW();
+#endif
         if (staged)
         {
             // lane gl of a group takes the hashes q = gl, gl + Gp, ...; every load is issued before the first one is waited for
@@ -435,6 +508,10 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
             }
             gn_hibf_wave_sync();
         }
+#ifdef GN_PACK_PROF
+        const unsigned long long pp_t2 = GN_PP_NOW();
+        pp_stage += pp_t2 - pp_t1;
+#endif
         // hash `it` of my item, requested two iterations before the rows that depend on it: the row loop's chain per iteration is then one
         // memory latency (the rows), not two (hash, then rows) -- taken out of the chain in an experiment a level of narrow IBFs ran 21 %
         // faster (profiles/r05_hibf_probe_fake2.jsonl)
@@ -527,6 +604,13 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
             if (two)
                 consume(B, it + 1);
         }
+#ifdef GN_PACK_PROF
+        const unsigned long long pp_t3 = GN_PP_NOW();
+        pp_row += pp_t3 - pp_t2;
+        ++pp_batches;
+        pp_iters += n_max;
+        pp_items += gl == 0 ? n : 0u;
+#endif
         if (n && gl == 0)
         {
             my_bytes += (unsigned long long)n * HF * cur.W * 8ull; // algorithmic bytes of this visit (once per item)
@@ -625,12 +709,43 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
             }
         }
 
-        batch += stride;
+#ifdef GN_PACK_PROF
+        pp_tail += GN_PP_NOW() - pp_t3;
+#endif
+        batch = next_batch;
         if (batch >= n_batches)
             break;
         cur = nxt;
     }
+#ifdef GN_PACK_PROF
+    {
+        unsigned long long it_sum = pp_items, ln = my_lines - pp_lines0;
+        for (int off = 32; off >= 1; off >>= 1)
+        {
+            it_sum += __shfl_xor(it_sum, off);
+            ln += __shfl_xor(ln, off);
+        }
+        if (lane == 0)
+        {
+            atomicAdd(&gn_pack_prof_buf[cls][0], (unsigned long long)(GN_PP_NOW() - pp_t0));
+            atomicAdd(&gn_pack_prof_buf[cls][1], pp_row);
+            atomicAdd(&gn_pack_prof_buf[cls][2], pp_stage);
+            atomicAdd(&gn_pack_prof_buf[cls][3], pp_tail);
+            atomicAdd(&gn_pack_prof_buf[cls][4], pp_batches);
+            atomicAdd(&gn_pack_prof_buf[cls][5], pp_iters);
+            atomicAdd(&gn_pack_prof_buf[cls][6], it_sum);
+            atomicAdd(&gn_pack_prof_buf[cls][7], ln);
+        }
+    }
+#endif
   } // classes
+#ifdef GN_PACK_PROF
+    if (lane == 0 && wave_id < 8192u)
+    {
+        gn_pack_prof_wave[wave_id][0] = pp_wall0;
+        gn_pack_prof_wave[wave_id][1] = wall_clock64();
+    }
+#endif
     app.finish(p, (int)lane);
     // one atomic per wave
     for (int off = 32; off >= 1; off >>= 1)
@@ -1508,6 +1623,56 @@ static void gn_hibf_launch_pack2(GnHibfLevelParams p, uint32_t n_cu, uint32_t bp
         bpc = (uint32_t)per_cu;
     }
     hipLaunchKernelGGL((gn_hibf_pack_kernel<HF, LEVEL0>), dim3(n_cu * bpc), dim3(256), lds, st, p);
+#ifdef GN_PACK_PROF
+    {
+        unsigned long long h[8][8] = {};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(gn_pack_prof_buf), sizeof(h));
+        const uint32_t nc = LEVEL0 || p.n_cls == 0 ? 1u : p.n_cls;
+        for (uint32_t c = 0; c < nc; ++c)
+            fprintf(stderr, "[pack prof] level0=%d waves=%u cls=%u gp=%u wave_cycles=%llu row=%llu stage=%llu tail=%llu batches=%llu iters=%llu item_iters=%llu lines=%llu\n",
+                    (int)LEVEL0, n_cu * bpc * 4u, c, (LEVEL0 || p.n_cls == 0) ? p.pack_gp : (uint32_t)p.cls_gp[c], h[c][0], h[c][1], h[c][2], h[c][3], h[c][4],
+                    h[c][5], h[c][6], h[c][7]);
+        unsigned long long z[8][8] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(gn_pack_prof_buf), z, sizeof(z));
+        {
+            static std::vector<unsigned long long> w(8192 * 2);
+            (void)hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(gn_pack_prof_wave), w.size() * 8);
+            const uint32_t nw = std::min<uint32_t>(n_cu * bpc * 4u, 8192u);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (uint32_t i = 0; i < nw; ++i)
+                if (w[2 * i + 1])
+                {
+                    t0 = std::min(t0, w[2 * i]);
+                    t1 = std::max(t1, w[2 * i + 1]);
+                }
+            std::vector<double> ends;
+            double              xs[8] = {}, xm[8] = {};
+            uint32_t            xn[8] = {};
+            for (uint32_t i = 0; i < nw; ++i)
+                if (w[2 * i + 1])
+                {
+                    const double e = (double)(w[2 * i + 1] - t0) / 100.0; // microseconds
+                    ends.push_back(e);
+                    const uint32_t x = (i / 4u) % 8u; // workgroup -> XCD (round robin)
+                    xs[x] += e;
+                    xm[x] = std::max(xm[x], e);
+                    ++xn[x];
+                }
+            std::sort(ends.begin(), ends.end());
+            if (!ends.empty())
+            {
+                fprintf(stderr, "[pack prof] level0=%d wave end times (us): span %.1f  min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f;  per XCD mean/max:", (int)LEVEL0,
+                        (double)(t1 - t0) / 100.0, ends.front(), ends[ends.size() / 10], ends[ends.size() / 2], ends[ends.size() * 9 / 10], ends.back());
+                for (int x = 0; x < 8; ++x)
+                    fprintf(stderr, " %.0f/%.0f", xn[x] ? xs[x] / xn[x] : 0.0, xm[x]);
+                fprintf(stderr, "\n");
+            }
+            std::fill(w.begin(), w.end(), 0ull);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(gn_pack_prof_wave), w.data(), w.size() * 8);
+        }
+    }
+#endif
 }
 template <int HF>
 static void gn_hibf_launch_pack(const GnHibfLevelParams& p, bool level0, uint32_t n_cu, uint32_t bpc, hipStream_t st)
@@ -1794,7 +1959,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
         return gn_fail(GN_ERANGE, "read index and user bin do not fit one 64-bit sort key");
     GN_HIP(hipMemsetAsync(s->d_ctr + 1, 0, 3 * sizeof(unsigned long long), st)); // line bytes, algo bytes, (unused)
     GN_HIP(hipMemsetAsync(s->d_ctr + 6, 0, sizeof(unsigned long long), st));     // exact match count
-    GN_HIP(hipMemsetAsync(s->d_hctr, 0, (29 * NL + 2) * sizeof(unsigned long long), st)); // queues, per-level bytes, [4NL] output base, [4NL+2..] per-level line bytes, [5NL+2..] per level: 8 class counts, bases, cursors
+    GN_HIP(hipMemsetAsync(s->d_hctr, 0, (37 * NL + 2) * sizeof(unsigned long long), st)); // queues, per-level bytes, [4NL] output base, [4NL+2..] per-level line bytes, [5NL+2..] per level: 8 class counts, bases, cursors, [29NL+2..] batch cursors of the packed kernel
     GN_HIP(hipMemsetAsync(s->d_seg_count, 0, ((size_t)n + 1) * 4, st));
     unsigned long long* d_out_base = s->d_hctr + 4 * NL;
     const uint32_t h      = f->ibfs[0].h;
@@ -1827,7 +1992,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
     auto run_levels = [&](uint32_t lo, uint32_t cnt, bool stamp) -> int {
         GN_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(unsigned long long), st));
         GN_HIP(hipMemsetAsync(s->d_hctr, 0, 3 * NL * sizeof(unsigned long long), st));
-        GN_HIP(hipMemsetAsync(s->d_hctr + 5 * NL + 2, 0, 24 * NL * sizeof(unsigned long long), st));
+        GN_HIP(hipMemsetAsync(s->d_hctr + 5 * NL + 2, 0, 32 * NL * sizeof(unsigned long long), st));
         if (s->d_hsub)
             GN_HIP(hipMemsetAsync(s->d_hsub, 0, (size_t)NL * 384 * sizeof(unsigned long long), st));
         if (cnt && no_reg) // (the register-counter kernels take level 0 straight from the batch)
@@ -1867,6 +2032,7 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
             p.read_base   = lo;
             p.status      = s->v_status;
             p.pack_gp     = lvl < f->level_gp.size() ? f->level_gp[lvl] : 0u;
+            p.grab        = gn_sw().on_demand ? nullptr : s->d_hctr + 29 * NL + 2 + (size_t)lvl * 8;
             bool level0   = lvl == 0; // the first register kernel of level 0 takes the reads themselves as its items
             uint2* defer_next = s->d_hdefer; // the list the next kernel of this level writes what it leaves
             auto   launch_pack = [&]() {
@@ -1938,10 +2104,12 @@ int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st)
                         p.pack_gp   = gps[c];
                         p.count_in  = bp.cls_count + c;
                         p.work_base = bp.cls_base + c;
+                        p.grab      = gn_sw().on_demand ? nullptr : s->d_hctr + 29 * NL + 2 + (size_t)lvl * 8 + c; // (a launch per width: a cursor per launch)
                         launch_pack();
                         GN_HIP(hipGetLastError());
                     }
                 p.work_base = nullptr;
+                p.grab      = gn_sw().on_demand ? nullptr : s->d_hctr + 29 * NL + 2 + (size_t)lvl * 8 + 7;
                 p.work_in   = s->d_hdefer2;
                 p.count_in  = s->d_hctr + NL + lvl;
                 defer_next  = s->d_hdefer; // (the sorted list is done with)

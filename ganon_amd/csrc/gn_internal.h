@@ -17,8 +17,8 @@
 #define GN_PF_MAX_JOINT 16   // filters of one hierarchy level in a joint filter_matches pre-pass, per device
 #define GN_PF_MAX_DEVICES 16 // devices a joint pass spans (column parts of a bin-range partitioned filter)
 #define GN_LONG_BLOCKS 128u // workgroups (and uint32 count slabs) of the long-read kernel
-#define GN_NCTR 72 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
-                   // [6] exact match total [8..71] total-hashes shards
+#define GN_NCTR 73 // device counters: [0] match cursor [2] algo bytes [3] hibf work [4] count-deferred [5] minimiser-deferred
+                   // [6] exact match total [8..71] total-hashes shards [72] unit cursor of the fast count kernel
 
 // ---- switches ---------------------------------------------------------------------------------
 // The ONE place the library reads its environment: $GANON_HIP_ABLATE, a comma list of the names below, parsed once when
@@ -38,6 +38,7 @@ struct GnSwitches
     bool split_kernel = false;    // split-bin maps go to the generic kernel
     bool predrop = false;         // with a filter_matches pre-pass: write every match, judge afterwards
     bool deferred_grids = false;  // grids of the deferred-list kernels sized for the whole batch, not from the last batch's list
+    bool on_demand = false;       // fast kernel and HIBF packed kernel: every wave takes units i, i + waves, ... (no cursor: as up to round 5)
     // HIBF
     bool hibf_reg = false;        // no per-item register kernel (LDS-counter level kernel instead)
     bool hibf_pack = false;       // no packed-items kernel either
@@ -142,6 +143,7 @@ struct GnCountParams
     const uint32_t*           sl_nbr;          // split kernel: bins-per-target bytes in the layout of the byte counters
     uint32_t                  early_exit;      // fast kernel: stop fetching rows of reads that cannot reach the cutoff
     unsigned long long*       skip_ctr;        // row bytes not fetched thanks to early exits
+    unsigned long long*       grab;            // fast kernel: the cursor its waves take their later units from (zero at launch; nullptr: units i, i + waves, ...)
     // fast kernel, with a filter_matches pre-pass set on the stream: matches that the --rel-filter rule is bound to drop are
     // not written at all (see the epilogue).  0 off, 1: the read's minimum is at least its cutoff count T (this filter sees all
     // of the read's matches), 2: nothing known about the minimum (other filters of the level may report smaller counts)

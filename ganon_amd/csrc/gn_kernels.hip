@@ -1070,6 +1070,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     uint64_t       unit    = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (unit >= n_units)
         return;
+    // Which units a wave takes.  Wave i used to take units i, i + waves, ...: the same count for every wave.  But the waves of a launch do
+    // not run at the same pace (the HIBF's packed kernel, which hands out its batches the same way: first wave through after 0.84 of the
+    // launch, the XCDs with odd numbers 11 % behind the even ones -- gn_hibf.hip), and the launch ends with its slowest wave.  With 64 or
+    // more units a wave, a wave starts with 16 units of its own and takes every later chunk from a cursor -- asked for one chunk ahead,
+    // so that the answer is there when it is needed; 16 units a chunk, 8 in the last quarter of the launch, 4 in its last sixteenth
+    // (a counter address takes ~90 atomics a microsecond).
+    const bool     dyn      = p.grab != nullptr && n_units >= 64u * stride;
+    const uint64_t dyn_from = stride * 16u; // the cursor counts from here
+    uint64_t       chunk_end = unit + 1;
+    if (dyn)
+    {
+        unit *= 16u;
+        chunk_end = unit + 16u;
+    }
+    unsigned long long g_next = 0; // (lane 0: what the cursor answered)
+    uint32_t           g_size = 16u;
+    auto               ask    = [&](uint64_t from) {
+        g_size = from < n_units - n_units / 4u ? 16u : (from < n_units - n_units / 16u ? 8u : 4u);
+        if (lane == 0)
+            g_next = atomicAdd(p.grab, (unsigned long long)g_size);
+    };
+    if (dyn)
+        ask(unit);
     // hash q of a unit feeds row-table entries idx = lane and lane + 64 (idx = q*HF + i)
     const uint32_t q0 = (uint32_t)lane / HF, q1 = ((uint32_t)lane + GN_WAVE) / HF;
     auto load_meta = [&](uint64_t u, uint32_t& rd, uint32_t& nn, uint64_t& so) {
@@ -1100,8 +1123,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     {
     const uint32_t slice = (uint32_t)(unit - (uint64_t)(read - p.read_begin) * wpr);
     // prefetch the next unit's metadata (consumed after the main loop)
-    const uint64_t unit_n = unit + stride;
-    const bool     more   = unit_n < n_units;
+    uint64_t unit_n = unit + 1;
+    if (unit_n >= chunk_end)
+    {
+        if (dyn)
+        {
+            const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)g_next);
+            const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(g_next >> 32));
+            unit_n              = dyn_from + (((uint64_t)hi32 << 32) | lo32); // (asked for a chunk ago)
+            chunk_end           = unit_n + g_size;
+            if (unit_n < n_units)
+                ask(unit_n);
+        }
+        else
+        {
+            unit_n    = unit + stride;
+            chunk_end = unit_n + 1;
+        }
+    }
+    const bool more = unit_n < n_units;
     uint32_t       read_n = 0, n_n = 0;
     uint64_t       slot_n = 0, hA_n = 0, hB_n = 0;
     if (more)
