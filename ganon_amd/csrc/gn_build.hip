@@ -194,7 +194,7 @@ extern "C" int gn_filter_emplace_split(gn_filter* f, const uint64_t* hashes, uin
         GN_HIP(hipMemcpyAsync(f->d_emplace_stage, hashes + done, c * 8, hipMemcpyHostToDevice, f->load_st));
         const uint64_t total  = c * ib.h;
         const unsigned blocks = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(gn_emplace_split_kernel, dim3(blocks), dim3(256), 0, f->load_st, ib.d_rows, ib.S, (uint32_t)ib.W, ib.shift,
+        hipLaunchKernelGGL(gn_emplace_split_kernel, dim3(blocks), dim3(256), 0, f->load_st, ib.d_rows, ib.S, (uint32_t)ib.Ws, ib.shift,
                            ib.h, f->d_emplace_stage, c, first_bin, hashes_per_bin, done);
         GN_HIP(hipGetLastError());
         GN_HIP(hipStreamSynchronize(f->load_st)); // (the staging buffer is reused, and `hashes` may be pageable)
@@ -280,7 +280,7 @@ extern "C" int gn_filter_probe(gn_filter* f, const uint64_t* hashes, uint64_t n,
         e = hipMemcpyAsync(f->d_emplace_stage, hashes + done, c * 8, hipMemcpyHostToDevice, f->load_st);
         if (e != hipSuccess)
             break;
-        hipLaunchKernelGGL(gn_probe_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, f->load_st, ib.d_rows, ib.S, (uint32_t)ib.W, ib.shift,
+        hipLaunchKernelGGL(gn_probe_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, f->load_st, ib.d_rows, ib.S, (uint32_t)ib.Ws, ib.shift,
                            ib.h, f->d_emplace_stage, c, d_bins, n_bins, done, d_out);
         e = hipGetLastError();
         if (e == hipSuccess)

@@ -50,7 +50,7 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                               {"csr_identity", &GnSwitches::csr_identity},   {"uniform_select", &GnSwitches::uniform_select},
                               {"run_select", &GnSwitches::run_select},       {"max_first", &GnSwitches::max_first},
                               {"const_nb", &GnSwitches::const_nb},           {"split_kernel", &GnSwitches::split_kernel},
-                              {"predrop", &GnSwitches::predrop},             {"deferred_grids", &GnSwitches::deferred_grids}, {"on_demand", &GnSwitches::on_demand},
+                              {"predrop", &GnSwitches::predrop},             {"deferred_grids", &GnSwitches::deferred_grids}, {"on_demand", &GnSwitches::on_demand}, {"hibf_dense_rows", &GnSwitches::hibf_dense_rows},
                               {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
                               {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent}, {"hibf_stage", &GnSwitches::hibf_stage}, {"hibf_nsort", &GnSwitches::hibf_nsort}, {"hibf_reread", &GnSwitches::hibf_reread},
                               {"hibf_fake_hashes", &GnSwitches::hibf_fake_hashes}, {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
@@ -167,14 +167,14 @@ static int gn_set_device(int dev)
 
 // Padding bins (>= bins) of the last word are never set by emplace and never reported by the reference
 // (counting_vector has `bins` entries); clear them in the device copy so kernels need no per-word mask.
-__global__ void gn_clear_padding_kernel(uint64_t* rows, uint64_t S, uint64_t W, uint64_t mask)
+__global__ void gn_clear_padding_kernel(uint64_t* rows, uint64_t S, uint64_t W, uint64_t Ws, uint64_t mask)
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < S)
-        rows[r * W + (W - 1)] &= mask;
+        rows[r * Ws + (W - 1)] &= mask;
 }
 
-static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* bytes_acc)
+static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* bytes_acc, bool pad_rows = false)
 {
     if (!d || d->bin_size == 0 || d->bins == 0)
         return gn_fail(GN_EINVAL, "empty IBF description");
@@ -190,10 +190,28 @@ static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* by
         return gn_fail(GN_ERANGE, "bin_size > 2^32 rows is not supported");
     if (d->bin_words > 0xFFFFFFFFull || d->bins > 0xFFFFFFF0ull)
         return gn_fail(GN_ERANGE, "too many bins");
-    const uint64_t bytes = d->bin_size * d->bin_words * 8ull;
+    const uint64_t Ws    = pad_rows ? gn_pad_row_words(d->bin_words) : d->bin_words;
+    const uint64_t bytes = d->bin_size * Ws * 8ull;
     uint64_t*      dp    = nullptr;
     GN_HIP(hipMalloc(reinterpret_cast<void**>(&dp), bytes + 64)); // +64: tail pad for 16-byte loads
-    if (d->rows)
+    if (d->rows && Ws != d->bin_words)
+    {
+        // padded rows: zero everything, then the source's words row by row (in rounds of <= 1 GiB of source)
+        GN_HIP(hipMemsetAsync(dp, 0, bytes + 64, nullptr));
+        GN_HIP(hipDeviceSynchronize());
+        const uint64_t per = std::max<uint64_t>(1, (1ull << 30) / (d->bin_words * 8));
+        for (uint64_t r = 0; r < d->bin_size; r += per)
+        {
+            const uint64_t nr = std::min(per, d->bin_size - r);
+            hipError_t     e  = hipMemcpy2D(dp + r * Ws, Ws * 8, d->rows + r * d->bin_words, d->bin_words * 8, d->bin_words * 8, nr, hipMemcpyHostToDevice);
+            if (e != hipSuccess)
+            {
+                hipFree(dp);
+                return gn_fail(GN_ENODEV, "filter upload failed: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    else if (d->rows)
     {
         // chunked copy keeps pinned-staging pressure low for multi-GiB filters
         const uint64_t chunk = 1ull << 30;
@@ -216,7 +234,7 @@ static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* by
     }
     if (d->rows && (d->bins & 63))
         hipLaunchKernelGGL(gn_clear_padding_kernel, dim3((unsigned)((d->bin_size + 255) / 256)), dim3(256), 0, nullptr, dp,
-                           d->bin_size, d->bin_words, (1ull << (d->bins & 63)) - 1ull);
+                           d->bin_size, d->bin_words, Ws, (1ull << (d->bins & 63)) - 1ull);
     // A memset of device memory returns before the fill has run, and everything that touches the filter afterwards --
     // gn_filter_write_rows' load stream, every gn_stream -- runs on streams created hipStreamNonBlocking, which take no
     // implicit order against the null stream the fill is queued on.  Without this wait the zero fill of a streamed filter
@@ -225,6 +243,7 @@ static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* by
     out->d_rows = dp;
     out->S      = d->bin_size;
     out->W      = d->bin_words;
+    out->Ws     = Ws;
     out->B      = d->bins;
     out->h      = d->hash_funs;
     out->shift  = d->hash_shift;
@@ -444,7 +463,7 @@ extern "C" int gn_filter_upload_hibf(int device, uint32_t n_ibf, const gn_ibf_de
     f->ibfs.resize(n_ibf);
     for (uint32_t i = 0; i < n_ibf; ++i)
     {
-        rc = gn_upload_ibf_rows(&ibfs[i], &f->ibfs[i], &f->device_bytes);
+        rc = gn_upload_ibf_rows(&ibfs[i], &f->ibfs[i], &f->device_bytes, !gn_sw().hibf_dense_rows);
         if (rc)
         {
             gn_filter_free(f);
@@ -563,7 +582,7 @@ extern "C" int gn_filter_emplace_ibf(gn_filter* f, uint32_t ibf_idx, const uint6
     }
     hipMemcpy(dh, hashes, n * 8, hipMemcpyHostToDevice);
     hipMemcpy(db, bins, n * 4, hipMemcpyHostToDevice);
-    e = gn_launch_emplace(ib->d_rows, ib->S, (uint32_t)ib->W, ib->shift, ib->h, dh, db, n, nullptr);
+    e = gn_launch_emplace(ib->d_rows, ib->S, (uint32_t)ib->Ws, ib->shift, ib->h, dh, db, n, nullptr); // (the kernel's W is the row stride)
     hipError_t e2 = hipDeviceSynchronize();
     hipFree(dh);
     hipFree(db);
@@ -599,16 +618,19 @@ extern "C" int gn_filter_download_rows(const gn_filter* f, uint32_t ibf_idx, uin
     if (row_begin + n_rows > ib->S)
         return gn_fail(GN_EINVAL, "row range out of bounds");
     GN_HIP(hipSetDevice(f->device));
-    GN_HIP(hipMemcpy(out, ib->d_rows + row_begin * ib->W, n_rows * ib->W * 8, hipMemcpyDeviceToHost));
+    if (ib->Ws == ib->W)
+        GN_HIP(hipMemcpy(out, ib->d_rows + row_begin * ib->W, n_rows * ib->W * 8, hipMemcpyDeviceToHost));
+    else
+        GN_HIP(hipMemcpy2D(out, ib->W * 8, ib->d_rows + row_begin * ib->Ws, ib->Ws * 8, ib->W * 8, n_rows, hipMemcpyDeviceToHost));
     return GN_OK;
 }
 
-__global__ void gn_gather_rows_kernel(const uint64_t* __restrict__ rows, uint64_t W, const uint64_t* __restrict__ idx,
+__global__ void gn_gather_rows_kernel(const uint64_t* __restrict__ rows, uint64_t W, uint64_t Ws, const uint64_t* __restrict__ idx,
                                       uint64_t* __restrict__ out)
 {
     const uint64_t r = idx[blockIdx.x];
     for (uint64_t j = threadIdx.x; j < W; j += blockDim.x)
-        out[(uint64_t)blockIdx.x * W + j] = rows[r * W + j];
+        out[(uint64_t)blockIdx.x * W + j] = rows[r * Ws + j];
 }
 
 extern "C" int gn_filter_download_row_list(const gn_filter* f, uint32_t ibf_idx, const uint64_t* row_idx, uint64_t n, uint64_t* out)
@@ -640,7 +662,7 @@ extern "C" int gn_filter_download_row_list(const gn_filter* f, uint32_t ibf_idx,
         e                = hipMemcpy(d_idx, row_idx + o, m * 8, hipMemcpyHostToDevice);
         if (e != hipSuccess)
             break;
-        hipLaunchKernelGGL(gn_gather_rows_kernel, dim3((unsigned)m), dim3(64), 0, nullptr, ib->d_rows, ib->W, d_idx, d_out);
+        hipLaunchKernelGGL(gn_gather_rows_kernel, dim3((unsigned)m), dim3(64), 0, nullptr, ib->d_rows, ib->W, ib->Ws, d_idx, d_out);
         e = hipMemcpy(out + o * ib->W, d_out, m * ib->W * 8, hipMemcpyDeviceToHost);
     }
     hipFree(d_idx);
@@ -752,11 +774,11 @@ extern "C" int gn_filter_write_rows(gn_filter* f, uint32_t ibf_idx, uint64_t row
     int rc = gn_filter_load_stream(f);
     if (rc)
         return rc;
-    uint64_t* dst = ib->d_rows + row_begin * ib->W;
-    if (src_row_words == ib->W)
+    uint64_t* dst = ib->d_rows + row_begin * ib->Ws;
+    if (src_row_words == ib->W && ib->Ws == ib->W)
         GN_HIP(hipMemcpyAsync(dst, src, n_rows * ib->W * 8, hipMemcpyHostToDevice, f->load_st));
     else
-        GN_HIP(hipMemcpy2DAsync(dst, ib->W * 8, src + word_lo, src_row_words * 8, ib->W * 8, n_rows, hipMemcpyHostToDevice,
+        GN_HIP(hipMemcpy2DAsync(dst, ib->Ws * 8, src + word_lo, src_row_words * 8, ib->W * 8, n_rows, hipMemcpyHostToDevice,
                                 f->load_st));
     return GN_OK;
 }
@@ -776,7 +798,7 @@ static int gn_clear_padding(gn_filter* f, GnIbfHost* ib, hipStream_t st)
     if (ib->B & 63)
     {
         hipLaunchKernelGGL(gn_clear_padding_kernel, dim3((unsigned)((ib->S + 255) / 256)), dim3(256), 0, st, ib->d_rows, ib->S,
-                           ib->W, (1ull << (ib->B & 63)) - 1ull);
+                           ib->W, ib->Ws, (1ull << (ib->B & 63)) - 1ull);
         GN_HIP(hipGetLastError());
     }
     return GN_OK;
@@ -809,7 +831,7 @@ __device__ __forceinline__ uint64_t gn_mix64(uint64_t z)
     return z ^ (z >> 31);
 }
 
-__global__ __launch_bounds__(256) void gn_fill_random_kernel(uint64_t* __restrict__ rows, uint64_t S, uint64_t W, uint64_t seed,
+__global__ __launch_bounds__(256) void gn_fill_random_kernel(uint64_t* __restrict__ rows, uint64_t S, uint64_t W, uint64_t Ws, uint64_t seed,
                                                              uint32_t and_words, uint64_t word_lo, uint64_t row_words_total,
                                                              uint64_t last_mask)
 {
@@ -832,7 +854,7 @@ __global__ __launch_bounds__(256) void gn_fill_random_kernel(uint64_t* __restric
                 v &= gn_mix64(keys[a] + g);
         if (j == W - 1)
             v &= last_mask;
-        rows[idx] = v;
+        rows[r * Ws + j] = v; // (Ws: the device's row stride; the words beyond W of a padded row stay zero)
     }
 }
 
@@ -854,7 +876,7 @@ extern "C" int gn_filter_fill_random(gn_filter* f, uint32_t ibf_idx, uint64_t se
     const uint64_t want   = (total + 255) / 256;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(want, (uint64_t)f->n_cu * 32);
     const uint64_t mask   = (ib->B & 63) ? (1ull << (ib->B & 63)) - 1ull : ~0ull;
-    hipLaunchKernelGGL(gn_fill_random_kernel, dim3(blocks), dim3(256), 0, nullptr, ib->d_rows, ib->S, ib->W, seed, and_words,
+    hipLaunchKernelGGL(gn_fill_random_kernel, dim3(blocks), dim3(256), 0, nullptr, ib->d_rows, ib->S, ib->W, ib->Ws, seed, and_words,
                        word_lo, row_words_total, mask);
     GN_HIP(hipGetLastError());
     GN_HIP(hipDeviceSynchronize());

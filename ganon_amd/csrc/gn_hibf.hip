@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
 #endif
         if (n && gl == 0)
         {
-            my_bytes += (unsigned long long)n * HF * cur.W * 8ull; // algorithmic bytes of this visit (once per item)
+            my_bytes += (unsigned long long)n * HF * gn_global(p.ibfs)[cur.ibf].Wl * 8ull; // algorithmic bytes of this visit (once per item)
             my_lines += (unsigned long long)n * HF * ((cur.W * 8ull + 127ull) & ~127ull); // ... in the 128-byte lines the rows occupy
         }
 
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void gn_hibf_reg_kernel(GnHibfLevelParams p)
                 if (it + 3 < iters)
                     issue(m0, hash_of(it + 3), RB);
             }
-            my_bytes += (unsigned long long)n * HF * m0.W * 8ull; // algorithmic bytes of this visit
+            my_bytes += (unsigned long long)n * HF * gn_sload(&p.ibfs[m0.ibf].Wl) * 8ull; // algorithmic bytes of this visit
             my_lines += (unsigned long long)n * HF * ((m0.W * 8ull + 127ull) & ~127ull);
         }
         // the row registers are free: request the next item's first two row sets, then the hashes of the one after
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256) void gn_hibf_level_kernel(GnHibfLevelParams p)
             }
             app.push(p, lane, hit && merged, hit && !merged, read, (uint32_t)tgt, sum);
         }
-        my_bytes += (unsigned long long)n * f.h * f.W * 8ull; // algorithmic bytes of this visit
+        my_bytes += (unsigned long long)n * f.h * f.Wl * 8ull; // algorithmic bytes of this visit
         my_lines += (unsigned long long)n * f.h * ((f.W * 8ull + 127ull) & ~127ull);
     }
     app.finish(p, lane);
@@ -1417,7 +1417,7 @@ int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const i
     {
         const uint64_t B = ibfs[i].bins;
         std::vector<uint4>    runs, mruns;
-        std::vector<uint32_t> tab((size_t)f->ibfs[i].W * 64, 0xFFFFFFFFu);
+        std::vector<uint32_t> tab((size_t)f->ibfs[i].Ws * 64, 0xFFFFFFFFu); // (the kernels see the padded row: its extra bins lead nowhere)
         uint64_t b = 0;
         while (b < B)
         {
@@ -1464,7 +1464,8 @@ int gn_hibf_build(gn_filter* f, uint32_t n_ibf, const gn_ibf_desc* ibfs, const i
         GN_HIP(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         dev[i].rows    = f->ibfs[i].d_rows;
         dev[i].S       = f->ibfs[i].S;
-        dev[i].W       = (uint32_t)f->ibfs[i].W;
+        dev[i].W       = (uint32_t)f->ibfs[i].Ws; // width = stride on the device: the words a row is padded with are zero
+        dev[i].Wl      = (uint32_t)f->ibfs[i].W;
         dev[i].B       = (uint32_t)f->ibfs[i].B;
         dev[i].shift   = f->ibfs[i].shift;
         dev[i].h       = f->ibfs[i].h;

@@ -47,6 +47,7 @@ struct GnSwitches
     bool hibf_nsort = false;      // a level's queue is sorted by row width only, not by (width, number of minimisers)
     bool hibf_stage = false;      // the packed kernel fetches every hash from global memory (no staging in LDS)
     bool hibf_persistent = false; // one launch per width class instead of one persistent launch per level
+    bool hibf_dense_rows = false; // (read when an HIBF is created) rows of ceil(bins / 64) words on the device, as up to round 5: no padding to whole lines
     bool hibf_fake_hashes = false; // TIMING EXPERIMENT ONLY (wrong results): the packed kernel loads one hash per item and derives the others
     uint32_t hibf_bpc = 0;        // >0: workgroups per CU of the HIBF register kernels (0: what the occupancy query says)
     // device inflate
@@ -197,7 +198,8 @@ struct GnHibfIbfDev
 {
     const uint64_t* rows;
     uint64_t        S;
-    uint32_t        W, B, shift, h;
+    uint32_t        W, B, shift, h; // W: words from one row to the next = the width the kernels count (GnIbfHost::Ws: the padding words are zero)
+    uint32_t        Wl;             // ceil(B / 64): the words of a row that hold bins (the algorithmic bytes of a row request)
     const uint4*    runs;   // per run: first bin, n bins, user bin (0xFFFFFFFF = merged), child ibf
     uint32_t        n_runs;
     // register-counter level kernel (W <= 64): per technical bin (64*W entries) what a single-bin run leads to --
@@ -233,8 +235,25 @@ struct GnIbfHost
 {
     uint64_t* d_rows = nullptr;
     uint64_t  S = 0, W = 0, B = 0;
+    uint64_t  Ws = 0; // words from one row to the next on the device: W, or -- the IBFs of an HIBF -- W padded so that no row straddles a 128-byte
+                      // line (gn_pad_row_words); the words beyond W are zero.  Everything the C ABI takes or returns is W words a row.
     uint32_t  h = 0, shift = 0;
 };
+
+// Row stride of an HIBF's IBF.  raptor lays an IBF out with ceil(bins / 64) words a row: 3, 5, 9 ... 15 words for most lower IBFs, and a row
+// of 72 .. 120 bytes lies across two 128-byte lines more often than not -- a row request then moves two lines.  Measured on the skewed
+// tree (rocprofv3 FETCH_SIZE per launch): level 1 fetched 47.9 GB for 40.1 GB of rows counted in lines of their own, level 2 10.4 GB for
+// 6.9 -- and moved them at 0.98 / 0.90 of the gather roof: the levels were short of lines, not of speed.  Padded to the next power of two
+// (up to 16 words = one line) or to whole lines beyond, a row never straddles.  Costs memory (at most 2x for an IBF, ~1.3x for a tree).
+static inline uint64_t gn_pad_row_words(uint64_t w)
+{
+    if (w >= 16)
+        return (w + 15) & ~15ull;
+    uint64_t p = 1;
+    while (p < w)
+        p <<= 1;
+    return p;
+}
 
 struct gn_filter
 {

@@ -332,7 +332,7 @@ int gn_peer_stats(int dst, int src, int* state, uint64_t* bytes);
  * test can cross-check a fast path against the path it replaces (NULL or "" = the product path).  Call it only while no
  * launch is in flight.  Names that switch a path OFF: early_exit cand_select csr_identity uniform_select run_select
  * max_first const_nb split_kernel predrop deferred_grids hibf_reg hibf_pack hibf_one_pack hibf_persistent; test set-ups:
- * hibf_stage hibf_reread pinned_malloc gather_copy joint_apart inflate_ahead on_demand chunk=N hibf_pair_limit=N hibf_bpc=N; runtime: sync=spin|yield|block debug.  Unknown name -> GN_EINVAL and
+ * hibf_stage hibf_reread pinned_malloc gather_copy joint_apart inflate_ahead on_demand hibf_dense_rows chunk=N hibf_pair_limit=N hibf_bpc=N; runtime: sync=spin|yield|block debug.  Unknown name -> GN_EINVAL and
  * the previous list stays. */
 int gn_ablate(const char* list);
 /* free / total memory of a device: the host decides with it whether a filter is replicated or partitioned */
