@@ -174,6 +174,11 @@ __global__ void gn_clear_padding_kernel(uint64_t* rows, uint64_t S, uint64_t W, 
         rows[r * Ws + (W - 1)] &= mask;
 }
 
+extern "C" uint64_t gn_hibf_row_stride_words(uint64_t bin_words)
+{
+    return gn_sw().hibf_dense_rows ? bin_words : gn_pad_row_words(bin_words);
+}
+
 static int gn_upload_ibf_rows(const gn_ibf_desc* d, GnIbfHost* out, uint64_t* bytes_acc, bool pad_rows = false)
 {
     if (!d || d->bin_size == 0 || d->bins == 0)
@@ -463,7 +468,7 @@ extern "C" int gn_filter_upload_hibf(int device, uint32_t n_ibf, const gn_ibf_de
     f->ibfs.resize(n_ibf);
     for (uint32_t i = 0; i < n_ibf; ++i)
     {
-        rc = gn_upload_ibf_rows(&ibfs[i], &f->ibfs[i], &f->device_bytes, !gn_sw().hibf_dense_rows);
+        rc = gn_upload_ibf_rows(&ibfs[i], &f->ibfs[i], &f->device_bytes, gn_hibf_row_stride_words(ibfs[i].bin_words) != ibfs[i].bin_words);
         if (rc)
         {
             gn_filter_free(f);

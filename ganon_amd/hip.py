@@ -24,7 +24,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_fetch_postfilter", "gn_streams_postfilter_joint", "gn_stream_set_long_reads", "gn_stream_device_matches",
                "gn_stream_distinct_hashes", "gn_filter_emplace_split", "gn_stream_fetch_hashes", "gn_stream_dense_counts",
                "gn_stream_timings", "gn_gather_create", "gn_gather_run", "gn_gather_fetch", "gn_gather_device_matches",
-               "gn_gather_destroy", "gn_device_memory", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_hibf_level_lines", "gn_stream_classify_shared",
+               "gn_gather_destroy", "gn_device_memory", "gn_hibf_row_stride_words", "gn_gather_run_buffers", "gn_stream_device_offsets", "gn_stream_hibf_levels", "gn_stream_hibf_level_lines", "gn_stream_classify_shared",
                "gn_stream_upload_fastq", "gn_stream_fastq_index", "gn_stream_fastq_keep", "gn_stream_fastq_records",
                "gn_peer_stats", "gn_stream_upload_text", "gn_stream_upload_text_pair", "gn_stream_text_pair_index", "gn_stream_text_pair_records2",
                "gn_ablate", "gn_filter_probe", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free",
@@ -171,6 +171,8 @@ def load_library():
     L.gn_stream_hibf_levels.argtypes = [vp, C.POINTER(u32), vp, vp, vp, vp, u32]
     L.gn_stream_hibf_level_lines.argtypes = [vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
+    L.gn_hibf_row_stride_words.argtypes = [u64]
+    L.gn_hibf_row_stride_words.restype = u64
     L.gn_peer_stats.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(u64)]
     L.gn_reassign_create.argtypes = [i32, u64, u64, u32, vp, vp, C.POINTER(vp)]
     L.gn_reassign_run.argtypes = [vp, u32, C.c_double, C.POINTER(u32)]

@@ -132,8 +132,8 @@ public:
         for (auto const& m : f.shapes)
             sf.row_words.push_back(m.bin_words);
         uint64_t bytes = 0;
-        for (auto const& m : f.shapes)
-            bytes += m.payload_bytes();
+        for (auto const& m : f.shapes) // (an HIBF's rows are padded to whole lines on the device: what it takes there, not the file's payload)
+            bytes += f.is_hibf ? m.bin_size * gn_hibf_row_stride_words(m.bin_words) * 8 : m.payload_bytes();
         bool fits = true;
         for (auto const& v : vdev_)
             fits = fits && v.used + bytes <= v.budget;

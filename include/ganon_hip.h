@@ -337,6 +337,12 @@ int gn_peer_stats(int dst, int src, int* state, uint64_t* bytes);
 int gn_ablate(const char* list);
 /* free / total memory of a device: the host decides with it whether a filter is replicated or partitioned */
 int gn_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
+/* Words from one row to the next that gn_filter_upload_hibf gives an IBF of `bin_words` = ceil(bins / 64) words a row on the
+ * device: rows are padded to whole 128-byte lines there (3 -> 4, 5..8 -> 8, 9..16 -> 16 words, multiples of 16 beyond), so that
+ * no row request moves two lines.  An IBF of bin_size rows takes bin_size * this * 8 bytes -- what the host's placement must
+ * count instead of the file's payload.  Everything the ABI takes or returns stays bin_words words a row.  (No counterpart in the
+ * reference: /root/reference/src/ganon-classify/GanonClassify.cpp:949-986 reads the filter into host memory as it is.) */
+uint64_t gn_hibf_row_stride_words(uint64_t bin_words);
 
 /* ---- reassign: the EM over a classification's .all ---------------------------------------------------
  * `ganon classify` runs this after the binary by default (/root/reference/src/ganon/classify.py:76-88, --multiple-matches

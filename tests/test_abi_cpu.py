@@ -47,3 +47,15 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"ganon_oracle|import oracle|from oracle|libganon_oracle|gno_", txt):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_hibf_row_stride_words():
+    # host-side arithmetic of the ABI (no device): the row stride gn_filter_upload_hibf gives an IBF of ceil(bins / 64) words a row --
+    # the next power of two up to one 128-byte line, whole lines beyond -- is what ganon-classify's placement counts
+    import ganon_amd
+    L = ganon_amd.load_library()
+    got = [int(L.gn_hibf_row_stride_words(w)) for w in (1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 32, 33, 64, 100)]
+    assert got == [1, 2, 4, 4, 8, 8, 16, 16, 16, 32, 32, 48, 64, 112]
+    for w in range(1, 200):
+        s = int(L.gn_hibf_row_stride_words(w))
+        assert s >= w and s < 2 * w + 16 and (128 % (s * 8) == 0 or (s * 8) % 128 == 0)
