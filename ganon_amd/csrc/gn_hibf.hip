@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) GN_PACK_ATTR void gn_hibf_pack_kernel(GnHibfLe
     uint32_t       end       = batch + G0 < n_batches ? batch + G0 : n_batches;
     const uint32_t dyn_from  = stride * G0; // the cursor counts from here
     const uint32_t tail_from = n_batches - n_batches / 4u, tail2_from = n_batches - n_batches / 8u;
-    unsigned long long* const gctr = p.grab + cls;
+    unsigned long long* const gctr = p.grab ? p.grab + cls : nullptr;
     uint32_t g_next = 0, g_size = G0; // (lane 0: what the cursor answered; the size asked for)
     auto     ask    = [&](uint32_t from) {
         g_size = from < tail_from ? G0 : (from < tail2_from ? (G0 >= 2u ? G0 / 2u : 1u) : (G0 >= 8u ? G0 / 4u : (G0 >= 2u ? 2u : 1u)));
