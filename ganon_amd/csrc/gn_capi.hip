@@ -1293,6 +1293,7 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
             p.grab = s->d_ctr + 72;
         }
         GN_HIP(gn_launch_count_fast(p, f->geom, f->ibf.h, s->st));
+        p.grab       = nullptr; // (the generic kernel that takes the deferred reads hands out its rounds as before)
         p.work_list  = s->d_deferred;
         p.work_count = s->d_ctr + 4;
     }
