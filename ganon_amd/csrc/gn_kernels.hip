@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     const uint32_t hsub  = lane >> p.gp_log2;
     uint32_t*      rowtab = gn_lds + (size_t)wave * 128 * HFP;
 
-    // Persistent waves: unit = (read, column slice), strided over the grid.  The metadata of the NEXT unit
+    // Persistent waves: unit = (read, column slice), handed out in chunks (below).  The metadata of the NEXT unit
     // (status, n, hash slot) is loaded at the top of the current one and its hashes right after the current
     // main loop, so the chain status -> n -> slot -> hashes -> rows of dependent HBM latencies that a fresh
     // wave would pay before its first row load is hidden behind the previous read's work.
