@@ -124,9 +124,17 @@ def run_extra(name: str, timeout: int):
         return {"workload": name, "error": repr(e)}
 
 
-def run_e2e(budget: int):
-    """the product binary end to end on generated files that classify (bench_e2e.py), in a child process"""
+def run_e2e(budget: int, devices: str = "", only: str = "", reads: int = 0):
+    """the product binary end to end on generated files that classify (bench_e2e.py), in a child process.  `devices` = the binary's
+    --device list: an N-GPU job ends with `ganon-classify --device all` on plain FASTQ and .fq.gz, so that a scaling curve shows the
+    BINARY (one reader, N workers, ordered post stage) and not only resident batches"""
     cmd = [sys.executable, os.path.join(ROOT, "bench_e2e.py"), "--budget", str(budget)]
+    if devices:
+        cmd += ["--devices", devices]
+    if only:
+        cmd += ["--only", only]
+    if reads:
+        cmd += ["--reads", str(reads)]
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget + 240, cwd=ROOT)
         line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
@@ -141,6 +149,7 @@ def run_e2e(budget: int):
 
 LINE_CAP = 8192      # the driver keeps ~9 KB of stdout tail: a longer last line is cut and cannot be parsed (BENCH_r04.json)
 LINE_TARGET = 4096
+MAX_EXTRA = 44       # flat scalars in `config` after the four named ones
 
 
 def _short(text, n: int) -> str:
@@ -160,13 +169,19 @@ def compact_line(result: dict) -> dict:
     cfg = {"workload": _short(c.get("workload_short") or c.get("workload", "?"), 240),
            "reads_per_gpu": c.get("reads_per_gpu"), "parallelism": _short(c.get("parallelism", "?"), 80),
            "oracle_mismatching_reads": c.get("oracle_mismatching_reads", chk.get("mismatching_reads"))}
-    extra = []   # (name, scalar), in order of importance; cut at 20
+    extra = []   # (name, scalar), in order of importance; cut at MAX_EXTRA
     extra.append(("oracle_reads_checked", chk.get("reads_checked")))
     for k in ("mean_minimisers_per_read", "match_checksum_all_ranks"):
         extra.append((k, c.get(k)))
     km = c.get("kernel_ms") or {}
     extra.append(("minimiser_ms", km.get("minimiser")))
     extra.append(("count_select_ms", km.get("count_select")))
+    hw = str(c.get("workload_short") or c.get("workload", "")).split(" ")[0] or "headline"
+    va = result.get("variants") or {}
+    # the headline batch at the BINARY's own default --rel-cutoff 0.2 (Config.hpp:32), plain and under the wrapper's filter rules
+    extra.append((f"{hw}_cutoff0.2_mreads_s", (va.get("rel_cutoff_0.2") or {}).get("mreads_per_s")))
+    extra.append((f"{hw}_cutoff0.2_count_select_ms", (va.get("rel_cutoff_0.2") or {}).get("count_select_ms")))
+    extra.append((f"{hw}_wrapper_defaults_mreads_s", (va.get("wrapper_defaults_device_filter_matches") or {}).get("mreads_per_s")))
     for o in result.get("other_workloads") or []:
         w = o.get("workload", "?")
         if "error" in o:
@@ -176,6 +191,17 @@ def compact_line(result: dict) -> dict:
         low = (o.get("variants") or {}).get("low_cutoff_device_filter_matches")
         if low:   # the binary's --rel-cutoff 0.2 under the wrapper's filter rules
             extra.append((f"{w}_cutoff0.2_mreads_s", low.get("mreads_per_s")))
+        orf = o.get("roofline") or {}
+        # SURVEY 8(d) fraction of every workload: algorithmic bytes / count kernels' time / 8000 GB/s; HIBF: plus the levels' LINE rates
+        # over the calibrated gather roofs ("0.99/0.84/0.67", top level first) and traffic / algorithmic bytes when a PMC pass exists
+        extra.append((f"{w}_frac", orf.get("frac")))
+        if orf.get("levels"):
+            extra.append((f"{w}_level_line_fracs", "/".join(f"{lv.get('frac_of_gather_roof', 0):.2f}" for lv in orf["levels"])))
+        if orf.get("traffic") and orf.get("algo_bytes_per_step"):
+            extra.append((f"{w}_traffic_over_algo", round(orf["traffic"] / orf["algo_bytes_per_step"], 3)))
+        ex = (o.get("ranks") or {}).get("exchange_ms_max")
+        if ex is not None:
+            extra.append((f"{w}_exchange_ms", ex))
     bad_extra = sum(int(((o.get("config") or {}).get("oracle_spot_check") or {}).get("mismatching_reads") or 0)
                     for o in result.get("other_workloads") or [] if "error" not in o)
     if result.get("other_workloads"):
@@ -183,12 +209,14 @@ def compact_line(result: dict) -> dict:
     e2e = result.get("e2e") or {}
     if "error" in e2e:
         extra.append(("e2e_error", _short(e2e["error"], 80)))
+    if e2e.get("devices"):
+        extra.append(("e2e_devices", e2e["devices"]))
     for name, r in (e2e.get("inputs") or {}).items():
         if "error" in r:
             extra.append((f"e2e_{name}_error", _short(r["error"], 80)))
         else:
             extra.append((f"e2e_{name}_{'mpairs_s' if name.startswith('paired') else 'mreads_s'}_median", (r.get("rate") or {}).get("median")))
-    for k, v in [(k, v) for k, v in extra if v is not None][:20]:
+    for k, v in [(k, v) for k, v in extra if v is not None][:MAX_EXTRA]:
         cfg[k] = v
     line["config"] = cfg
 
@@ -200,7 +228,15 @@ def compact_line(result: dict) -> dict:
     roof["note"] = _short(r.get("note", ""), 200)
     if r.get("traffic") is not None and r.get("fetched_bytes_per_launch"):
         roof["traffic_over_fetched"] = round(r["traffic"] / r["fetched_bytes_per_launch"], 4)
+    # `traffic` is NOT measured in this run: counters cannot share a run with timing, so it is read from the committed summary of a
+    # separate `rocprofv3 --pmc FETCH_SIZE` pass over the same batch (same algorithmic bytes, checked) -- say so, and which file
+    roof["traffic_measured_in_this_run"] = False
+    roof["traffic_from"] = ("none" if r.get("traffic") is None else
+                            _short(r.get("traffic_from") or str(r.get("traffic_source", "?")).split(" ")[0].rstrip(":"), 100))
     line["roofline"] = roof
+    rk = result.get("ranks")
+    if isinstance(rk, dict):   # the proof that n_gpus ranks on n_gpus devices measured the line (flat scalars)
+        line["ranks"] = {k: (_short(v, 260) if isinstance(v, str) else v) for k, v in rk.items() if not isinstance(v, (dict, list))}
 
     cb = result.get("cpu_baseline")
     if isinstance(cb, dict):
@@ -216,9 +252,17 @@ def compact_line(result: dict) -> dict:
     if len(text) > LINE_TARGET:      # never expected; shed prose before scalars
         line["roofline"].pop("note", None)
         line["roofline"].pop("frac_measured_on", None)
+        (line.get("ranks") or {}).pop("ms_per_step_by_rank", None)
         if line["cpu_baseline"]:
             line["cpu_baseline"]["sample"] = _short(line["cpu_baseline"]["sample"], 120)
         line["config"]["workload"] = _short(line["config"]["workload"], 120)
+        named = ("workload", "reads_per_gpu", "parallelism", "oracle_mismatching_reads")
+        while len(json.dumps(line, separators=(",", ":"))) > LINE_TARGET - 64:   # then the least important scalars, last first
+            last = [k for k in line["config"] if k not in named]
+            if not last:
+                break
+            line["config"].pop(last[-1])
+            line["config_scalars_dropped"] = line.get("config_scalars_dropped", 0) + 1
     return line
 
 
@@ -243,14 +287,84 @@ def slim(name: str, r: dict, wall: float) -> dict:
     out = {"workload": name, "value": r["value"], "unit": r["unit"], "n_gpus": r["n_gpus"], "scaling": r["scaling"],
            "ms_per_step": r["ms_per_step"], "steps": r["steps"], "config": r["config"], "roofline": r["roofline"],
            "wall_s": round(wall, 1)}
+    if r.get("ranks"):
+        out["ranks"] = r["ranks"]
     if r.get("variants"):
         out["variants"] = r["variants"]
     return out
 
 
+def ALLOW_SHARED_GPU() -> bool:
+    return os.environ.get("GANON_BENCH_ALLOW_SHARED_GPU", "") == "1"
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher: become the launcher.  N ranks of this script, one per GPU, with the
+    environment torch.distributed.run would give them (RANK, LOCAL_RANK, WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR/PORT on 127.0.0.1);
+    rank 0 keeps this process's stdout (its last line is the record), the other ranks' stdout goes to stderr.  A rank that fails
+    takes the job down (the others are sent SIGTERM by PID) and its exit code is returned: no line is better than a line from fewer
+    ranks.  The N-worker structure mirrors the reference's N classify threads over additive totals (GanonClassify.cpp:1579-1597,
+    :475-490)."""
+    import socket
+    try:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:  # noqa: BLE001
+        have = 0
+    if have < n and not ALLOW_SHARED_GPU():
+        log(f"bench.py: --gpus {n} but {have} GPU(s) visible -- refusing to run {n} ranks on fewer GPUs "
+            f"(GANON_BENCH_ALLOW_SHARED_GPU=1 permits it for a dry run)")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GANON_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, cwd=ROOT,
+                                      stdout=None if r == 0 else sys.stderr))
+    log(f"bench.py: started {n} ranks myself (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                log(f"bench.py: rank {r} (pid {procs[r].pid}) left with code {c}: stopping the other ranks")
+                for o in sorted(live):
+                    procs[o].terminate()
+        time.sleep(0.2)
+    return rc
+
+
+def rank_proof(torch, gdist, world: int, dev_index: int, red_dev: str, backend: str) -> dict:
+    """What shows that a line with n_gpus = N was measured by N ranks on N GPUs: the number of ranks that answered an all-reduce
+    of ones over the job's backend (nccl = RCCL), and every rank's device identity (PCI domain:bus:device + uuid)."""
+    p = torch.cuda.get_device_properties(dev_index)
+    try:
+        ident = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
+    except Exception:  # noqa: BLE001
+        ident = f"cuda{dev_index}"
+    uuid = str(getattr(p, "uuid", "") or "")
+    ident += "/" + uuid.replace("-", "")[:12]
+    idents = gdist.all_gather_text(ident, device=red_dev)
+    seen = gdist.sum_over_ranks(1, device=red_dev)
+    return {"ranks_seen": int(seen), "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none (one rank)",
+            "launcher": os.environ.get("GANON_BENCH_LAUNCHER") or ("torchrun/env" if "WORLD_SIZE" in os.environ else "none"),
+            "devices": ",".join(sorted(idents)), "distinct_devices": len(set(idents)),
+            "shared_gpu_dry_run": bool(len(set(idents)) < world)}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: $WORLD_SIZE, else 1).  N > 1 without a launcher "
+                                                          "(no $WORLD_SIZE): this process starts the N ranks itself")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("GANON_BENCH_WORKLOAD", "flat8g"), choices=sorted(WORKLOADS))
@@ -275,6 +389,11 @@ def main() -> int:
             emit(json.loads(f.read()), write_files=False)
         return 0
 
+    # ---- how many ranks, and who starts them.  `--gpus N` is a REQUEST for N ranks on N distinct GPUs and is checked against
+    # what the job really is; it is never just a label (a bare `python bench.py --gpus 8` measured one GPU).
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus or 1) > 1:
+        return self_launch(args.gpus, sys.argv[1:])
     import torch
 
     import ganon_amd
@@ -283,15 +402,30 @@ def main() -> int:
     from ganon_amd import partition as gp
 
     rank, local_rank, world = gdist.env_rank_world()
+    if args.gpus is not None and args.gpus != world:
+        log(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks -- refusing to print a line whose n_gpus "
+            f"would not be what was asked for")
+        return 2
     if not torch.cuda.is_available():
         log("bench.py: no GPU visible -- the hot path has no CPU fallback")
         return 2
-    dev_index = local_rank % torch.cuda.device_count()   # == local_rank on a real N-GPU node
+    n_visible = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if n_visible < local_world and not ALLOW_SHARED_GPU():
+        log(f"bench.py: {local_world} ranks on this node but only {n_visible} GPU(s) visible -- ranks would share a GPU and the line would "
+            f"not be a {world}-GPU measurement.  (GANON_BENCH_ALLOW_SHARED_GPU=1 permits it for a dry run; the line then says so.)")
+        return 2
+    dev_index = local_rank % n_visible   # == local_rank on a real N-GPU node
     torch.cuda.set_device(dev_index)
-    dist_backend = os.environ.get("GANON_BENCH_DIST", "nccl")   # nccl == RCCL; "gloo" only for 1-GPU dry runs
+    # nccl == RCCL.  RCCL refuses two ranks on one device ("duplicate GPU"), so the shared-GPU dry run -- and only it -- talks gloo
+    dist_backend = os.environ.get("GANON_BENCH_DIST", "gloo" if n_visible < local_world else "nccl")
     red_dev = "cuda" if dist_backend == "nccl" else "cpu"
     if world > 1:
         gdist.init(dist_backend, torch.device("cuda", dev_index))
+    proof = rank_proof(torch, gdist, world, dev_index, red_dev, dist_backend)
+    if proof["ranks_seen"] != world or (proof["distinct_devices"] < min(world, local_world) and not ALLOW_SHARED_GPU()):
+        log(f"bench.py: the process group does not hold {world} ranks on distinct GPUs: {proof}")
+        return 2
 
     def run_one(name: str, headline: bool) -> dict:
         spec = dict(WORKLOADS[name])
@@ -315,7 +449,7 @@ def main() -> int:
                     f"{lay['top_bins']} bins ({lay['top_split_user_bins']} user bins split over {lay['top_split_technical_bins']}, the rest merged), "
                     f"{lay['ibfs'] - 1} lower IBFs of {lay['child_bins_min']}..{lay['child_bins_max']} bins (median {lay['child_bins_median']}) and "
                     f"{lay['rows_min']}..{lay['rows_max']} rows, h={spec['h']}, {lay['fill']} bits, {lay['genomes_in_two_user_bins']} genomes in two user bins")
-            kernel_name = "gn_hibf_reg_kernel"
+            kernel_name = "gn_hibf_pack_kernel"   # 69 % of the device time of the skewed tree (profiles/r05_hibf64k_skew_kernel_stats.csv)
             row_bytes = ((lay["top_bins"] + 63) >> 6) * 8
         elif kind == "hibf":
             rows_top = spec.get("rows_top", rows) if not (headline and args.rows) else rows
@@ -411,7 +545,12 @@ def main() -> int:
                     "ms_per_step": round(float(np.mean(tms)), 3), "mreads_per_s": round(n_reads / float(np.mean(tms)) / 1e3, 2)}
 
         elapsed, count_ms, mini_ms, total_ms, tm = timed(args.rel_cutoff, steps, warmup)
+        per_rank_ms = [e * 1e3 / max(1, steps) for e in gdist.all_gather_float(elapsed, device=red_dev)]   # every rank's own clock
         elapsed = gdist.max_over_ranks(elapsed, device=red_dev)       # slowest rank defines the step time
+        exchange = None
+        if part is not None:   # the partitioned filter's exchange step (variable all-to-all over RCCL + merge on the owner), per step
+            ex = [gdist.all_gather_float(float(np.mean(v[-steps:])), device=red_dev) for v in (part.exchange_ms, part.merge_ms)]
+            exchange = {"exchange_ms_max": round(max(ex[0]), 3), "exchange_ms_min": round(min(ex[0]), 3), "merge_ms_max": round(max(ex[1]), 3)}
         ee = rates(tm, count_ms)                                      # the product kernel: exact early exit on
         # SURVEY 8(d)'s fraction belongs to the instantiation that fetches every algorithmic row: the same resident batch
         # with the early exit ablated (3 steps, outside `value`).  Split-bin and HIBF kernels have no early exit.
@@ -445,6 +584,7 @@ def main() -> int:
                 "avg_launch_ms": round(ee["ms"] / ee["launches"], 4),
                 "avg_launch_ms_every_row": round(full["ms"] / full["launches"], 4),
                 "launches_per_step": ee["launches"],
+                "algo_bytes_per_step": ee["algo_bytes"],
                 "algo_bytes_per_launch": ee["algo_bytes"] // ee["launches"],
                 "fetched_bytes_per_launch": ee["fetched_bytes"] // ee["launches"],
                 "frac_measured_on": ("early exit ablated (every algorithmic row fetched), 3 steps on the same resident batch" if full is not ee
@@ -475,7 +615,7 @@ def main() -> int:
             "metric": "Mreads/s classified (150 bp) + IBF-lookup GB/s vs HBM roofline",
             "value": round(value, 3),
             "unit": "Mpairs/s" if paired else "Mreads/s",
-            "n_gpus": world,
+            "n_gpus": gdist.group_size(),        # from the process group, not from the command line
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -501,6 +641,9 @@ def main() -> int:
                               "device_total": round(float(np.mean(total_ms)), 3)},
             },
             "roofline": roof,
+            # the proof that n_gpus ranks on n_gpus devices measured this (rank_proof) + every rank's own step time
+            "ranks": dict(proof, ms_per_step_min=round(min(per_rank_ms), 3), ms_per_step_max=round(max(per_rank_ms), 3),
+                          ms_per_step_by_rank=",".join(f"{x:.2f}" for x in per_rank_ms), **(exchange or {})),
         }
 
         # HBM traffic of the dominant kernel comes from a SEPARATE rocprofv3 --pmc FETCH_SIZE pass (counter collection
@@ -514,6 +657,7 @@ def main() -> int:
                 if same:
                     roof["traffic"] = pmc["hbm_bytes_per_launch"]
                     roof["traffic_source"] = pmc["source"]
+                    roof["traffic_from"] = pmc.get("file") or str(pmc["source"]).split(" ")[0].rstrip(":")
                 else:
                     roof["traffic_source"] = (f"none: {os.path.basename(pmc_path)} was taken on a batch of {pmc.get('algo_bytes_per_step')} "
                                               f"algorithmic bytes, this run's is {tm['algo_bytes']}")
@@ -686,6 +830,15 @@ def main() -> int:
         gdist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if default_run and world > 1 and not args.no_e2e:
+            # The N-GPU end-to-end leg, after the ranks have left the job (the barrier above was their last act; their device memory
+            # goes with their processes): this process frees what it holds and runs the product binary over every GPU of the node.
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            time.sleep(3.0)
+            dev_list = "all" if not proof["shared_gpu_dry_run"] else ",".join(["0"] * world)
+            result["e2e"] = run_e2e(args.e2e_budget, devices=dev_list, only="fastq,gz", reads=int(os.environ.get("GANON_BENCH_E2E_READS", "0")) or 32_000_000)
         emit(result)
     return 0
 

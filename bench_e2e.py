@@ -138,6 +138,9 @@ def main() -> int:
     ap.add_argument("--budget", type=float, default=200.0, help="seconds; inputs that no longer fit are left out and named")
     ap.add_argument("--keep-gz", default="", help="copy the filter and the single-end .fq.gz into this directory before they are removed (profiling runs)")
     ap.add_argument("--only", default="", help="comma-separated subset of fastq,paired,gz,fasta,hibf")
+    ap.add_argument("--devices", default="", help="passed to the binary as --device (e.g. `all`, `0,1,2,3`, `0,0` = two workers on one GPU): one "
+                                                  "classify worker per entry over ONE reader, as the reference runs N threads over one parser "
+                                                  "(GanonClassify.cpp:1436-1441,1579-1597)")
     args = ap.parse_args()
 
     import bench_workload as bw
@@ -172,7 +175,9 @@ def main() -> int:
         with open(fq, "rb") as fh:  # (the first reader of a file just written pays for it; not the runs)
             while fh.read(1 << 26):
                 pass
-        common = ["--output-all", "--verbose"] + THRESHOLDS
+        common = ["--output-all", "--verbose"] + THRESHOLDS + (["--device", args.devices] if args.devices else [])
+        if args.devices:
+            out["devices"] = args.devices
         if "fastq" in want:
             out["inputs"]["fastq"] = run_binary(["--ibf", ibf, "--single-reads", fq, "-o", os.path.join(d, "o_fastq")] + common, n, args.runs,
                                                 f"{n} reads x {L} bp, plain FASTQ", deadline)

@@ -25,7 +25,7 @@ BUILD_ONLY = ("build.cpp", "build_params.cpp")  # sources of ganon-build that ga
 REASSIGN_ONLY = ("reassign.cpp", "reassign_main.cpp")  # ganon-reassign (the EM over .all)
 
 HIP_SOURCES = ["gn_kernels.hip", "gn_split.hip", "gn_minimiser_lpr.hip", "gn_hibf.hip", "gn_postfilter.hip", "gn_build.hip", "gn_gather.hip", "gn_fastq.hip", "gn_reassign.hip", "gn_inflate.hip", "gn_capi.hip"]
-HIP_HEADERS = ["gn_internal.h", "gn_scan.h", os.path.join(ROOT, "include", "ganon_hip.h")]
+HIP_HEADERS = ["gn_internal.h", "gn_scan.h", os.path.join(ROOT, "include", "ganon_hip.h"), os.path.join(ROOT, "include", "ganon_ibf_hash.h")]
 
 
 def _hipcc() -> str:
@@ -77,7 +77,7 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     if not os.path.isdir(HOST):
         return ""
     every = sorted(f for f in os.listdir(HOST) if f.endswith(".cpp"))
-    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "ganon_hip.h")]
+    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "ganon_hip.h"), os.path.join(ROOT, "include", "ganon_ibf_hash.h")]
     build_hip(force=False, verbose=verbose)
     for binary, names in ((BIN, [f for f in every if f not in BUILD_ONLY + REASSIGN_ONLY]),
                           (BIN_BUILD, [f for f in every if f in BUILD_ONLY] + ["seq_io.cpp", "pgzip.cpp"]),

@@ -9,13 +9,12 @@
 #include <hipcub/hipcub.hpp>
 
 // seqan3::interleaved_bloom_filter hash seeds and hash_and_fit, as in gn_kernels.hip
-__constant__ uint64_t GN_BUILD_SEEDS[5] = { 13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL,
-                                            16499269484942379435ULL, 4893150838803335377ULL };
+__constant__ uint64_t GN_BUILD_SEEDS[GN_IBF_MAX_HASH_FUNS] = GN_IBF_SEED_LIST;   // include/ganon_ibf_hash.h
 __device__ __forceinline__ uint32_t gn_build_row(uint64_t v, uint32_t i, uint32_t shift, uint64_t S)
 {
     uint64_t x = v * GN_BUILD_SEEDS[i];
     x ^= x >> shift;
-    x *= 11400714819323198485ULL;
+    x *= GN_IBF_MULTIPLIER;
     return (uint32_t)__umul64hi(x, S);
 }
 

@@ -134,6 +134,17 @@ static void gn_apply_sync_mode(int n_devices)
     (void)hipGetLastError();
 }
 
+extern "C" int gn_ibf_hash_constants(uint64_t seeds[5], uint64_t* multiplier)
+{
+    if (!seeds || !multiplier)
+        return gn_fail(GN_EINVAL, "gn_ibf_hash_constants: null argument");
+    static const uint64_t list[GN_IBF_MAX_HASH_FUNS] = GN_IBF_SEED_LIST;
+    for (int i = 0; i < GN_IBF_MAX_HASH_FUNS; ++i)
+        seeds[i] = list[i];
+    *multiplier = GN_IBF_MULTIPLIER;
+    return GN_OK;
+}
+
 extern "C" int gn_device_count(int* n)
 {
     if (!n)

@@ -33,14 +33,13 @@
 
 #define GN_WAVE 64
 
-__constant__ uint64_t GN_HIBF_SEEDS[5] = { 13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL,
-                                           16499269484942379435ULL, 4893150838803335377ULL };
+__constant__ uint64_t GN_HIBF_SEEDS[GN_IBF_MAX_HASH_FUNS] = GN_IBF_SEED_LIST;   // include/ganon_ibf_hash.h
 
 __device__ __forceinline__ uint32_t gn_hibf_row(uint64_t v, uint32_t i, uint32_t shift, uint64_t S)
 {
     uint64_t x = v * GN_HIBF_SEEDS[i];
     x ^= x >> shift;
-    x *= 11400714819323198485ULL;
+    x *= GN_IBF_MULTIPLIER;
     return (uint32_t)__umul64hi(x, S);
 }
 
@@ -232,7 +231,7 @@ __device__ __forceinline__ uint32_t gn_hibf_row_seed(uint64_t v, uint64_t seed, 
 {
     uint64_t x = v * seed;
     x ^= x >> shift;
-    x *= 11400714819323198485ULL;
+    x *= GN_IBF_MULTIPLIER;
     return (uint32_t)__umul64hi(x, (uint64_t)S);
 }
 

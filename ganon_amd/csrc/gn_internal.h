@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/ganon_hip.h"
+#include "../../include/ganon_ibf_hash.h"
 
 #define GN_MAX_CHUNKS 64 // pipeline chunks per batch (minimiser on the side stream || count on the main stream)
 // candidate-driven select of the generic count kernel: targets with more bins than this are scanned from a list

@@ -50,8 +50,7 @@ struct GnRankLut
 __constant__ GnRankLut GN_RANK_LUT = GnRankLut();
 
 // seqan3::interleaved_bloom_filter hash seeds
-__constant__ uint64_t GN_IBF_SEEDS[5] = { 13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL,
-                                          16499269484942379435ULL, 4893150838803335377ULL };
+__constant__ uint64_t GN_IBF_SEEDS[GN_IBF_MAX_HASH_FUNS] = GN_IBF_SEED_LIST;   // include/ganon_ibf_hash.h
 
 // LDS written by some lanes of a wave and read by other lanes of the SAME wave: the LDS unit executes a
 // wave's DS instructions in issue order, so only compiler reordering has to be prevented.
@@ -74,7 +73,7 @@ __device__ __forceinline__ uint32_t gn_ibf_row(uint64_t v, uint32_t i, uint32_t 
 {
     uint64_t x = v * GN_IBF_SEEDS[i];
     x ^= x >> shift;
-    x *= 11400714819323198485ULL;
+    x *= GN_IBF_MULTIPLIER;
     return (uint32_t)__umul64hi(x, S);
 }
 

@@ -45,11 +45,10 @@ __device__ __forceinline__ uint64_t gn_sp_readlane64(uint64_t v, uint32_t l)
 // IBF row of hash v for hash function i (seqan3 hash_and_fit) -- same as gn_kernels.hip
 __device__ __forceinline__ uint32_t gn_sp_row(uint64_t v, uint32_t i, uint32_t shift, uint64_t S)
 {
-    constexpr uint64_t seeds[5] = { 13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL,
-                                    16499269484942379435ULL, 4893150838803335377ULL };
+    constexpr uint64_t seeds[GN_IBF_MAX_HASH_FUNS] = GN_IBF_SEED_LIST;   // include/ganon_ibf_hash.h
     uint64_t x = v * seeds[i];
     x ^= x >> shift;
-    x *= 11400714819323198485ULL;
+    x *= GN_IBF_MULTIPLIER;
     return (uint32_t)__umul64hi(x, S);
 }
 

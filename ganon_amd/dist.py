@@ -37,6 +37,12 @@ def init(backend: str, device=None) -> None:
         dist.init_process_group(backend=backend, **kw)
 
 
+def group_size() -> int:
+    """ranks in the initialised process group (1 without one): what a record's n_gpus is taken from"""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def barrier() -> None:
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -61,3 +67,28 @@ def sum_over_ranks(x: int, device="cpu") -> int:
     t = torch.tensor([x], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def all_gather_float(x: float, device="cpu"):
+    """every rank's value, by rank"""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def all_gather_text(text: str, device="cpu", width: int = 96):
+    """every rank's short string, by rank (fixed-width byte tensors: the same call on RCCL and gloo, no pickling)"""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [text]
+    raw = text.encode()[:width].ljust(width, b"\0")
+    t = torch.tensor(list(raw), dtype=torch.uint8, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [bytes(o.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for o in out]

@@ -30,7 +30,8 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_ablate", "gn_filter_probe", "gn_reassign_create", "gn_reassign_run", "gn_reassign_diffs", "gn_reassign_fetch", "gn_reassign_info", "gn_reassign_free",
                "gn_inflate_create", "gn_inflate_destroy", "gn_inflate_feed", "gn_inflate_step", "gn_inflate_text", "gn_inflate_text_device",
                "gn_inflate_get_stats", "gn_inflate_cuts", "gn_inflate_set_carry", "gn_stream_upload_text_device", "gn_stream_fastq_headers",
-               "gn_inflate_cuts_lines", "gn_inflate_cut_at_lines", "gn_stream_upload_text_pair_device", "gn_stream_fetch_letters"]
+               "gn_inflate_cuts_lines", "gn_inflate_cut_at_lines", "gn_stream_upload_text_pair_device", "gn_stream_fetch_letters",
+               "gn_ibf_hash_constants"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -171,6 +172,7 @@ def load_library():
     L.gn_stream_hibf_levels.argtypes = [vp, C.POINTER(u32), vp, vp, vp, vp, u32]
     L.gn_stream_hibf_level_lines.argtypes = [vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
+    L.gn_ibf_hash_constants.argtypes = [vp, C.POINTER(u64)]
     L.gn_hibf_row_stride_words.argtypes = [u64]
     L.gn_hibf_row_stride_words.restype = u64
     L.gn_peer_stats.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(u64)]
@@ -196,7 +198,7 @@ def load_library():
     L.gn_stream_upload_text_device.argtypes = [vp, vp, u64, i32, i32]
     L.gn_stream_fastq_headers.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
     for name in ABI_SYMBOLS:
-        if name != "gn_last_error":
+        if name not in ("gn_last_error", "gn_hibf_row_stride_words"):   # (const char* and uint64_t returns, set above)
             getattr(L, name).restype = i32
     _lib = L
     return L
@@ -252,6 +254,14 @@ def fill_random_words(seed: int, rows: np.ndarray, n_words: int, and_words: int 
     if bins & 63:
         v[:, -1] &= np.uint64((1 << (bins & 63)) - 1)
     return v
+
+
+def ibf_hash_constants() -> Tuple[list, int]:
+    """(five seeds, multiplier) of hash_and_fit as libganon_hip.so was built (gn_ibf_hash_constants; no device needed)"""
+    seeds = np.zeros(5, dtype=np.uint64)
+    mul = C.c_uint64(0)
+    _check(load_library().gn_ibf_hash_constants(_p(seeds), C.byref(mul)))
+    return [int(x) for x in seeds], int(mul.value)
 
 
 def device_memory(device: int = 0) -> Tuple[int, int]:

@@ -14,6 +14,7 @@
 #include "seq_io.hpp"
 
 #include "ganon_hip.h"
+#include "ganon_ibf_hash.h"
 
 #include <fstream>
 #include <iostream>
@@ -108,11 +109,10 @@ private:
 // seqan3::interleaved_bloom_filter::hash_and_fit, for the report of a false negative only
 uint64_t ibf_row(uint64_t v, unsigned i, const IbfShape& m)
 {
-    static const uint64_t seeds[5] = { 13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL, 16499269484942379435ULL,
-                                       4893150838803335377ULL };
+    static const uint64_t seeds[GN_IBF_MAX_HASH_FUNS] = GN_IBF_SEED_LIST; // include/ganon_ibf_hash.h
     uint64_t              x = v * seeds[i];
     x ^= x >> m.hash_shift;
-    x *= 11400714819323198485ULL;
+    x *= GN_IBF_MULTIPLIER;
     return (uint64_t)(((unsigned __int128)x * m.bin_size) >> 64);
 }
 

@@ -24,6 +24,7 @@ gn_filter_write_rows, or filled on the device); `from_host_rows` slices a host m
 """
 from __future__ import annotations
 
+import time
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
 
@@ -238,6 +239,8 @@ class PartitionedIbf:
         self.local = local
         self.comm_device = comm_device
         self.group = group
+        self.exchange_ms: List[float] = []   # per classify(): the exchange step (collectives + the sync before the merge), wall clock
+        self.merge_ms: List[float] = []      # per classify(): merge of what arrived on the owner
         self._maps = None     # every rank's local -> global target table (exchanged once)
         self._gather = None   # device merge (gn_gather) of what the exchange delivered
         self._last = None
@@ -279,14 +282,18 @@ class PartitionedIbf:
             # device-resident: the library's own match buffer and offsets are what RCCL sends; what arrives is merged per
             # read by gn_gather_run_buffers on this rank's GPU
             off = self.local.device_offsets()
+            t_ex = time.perf_counter()
             parts_off, parts_rec = exchange_grouped(off, rec, n_reads, self.rank, self.world, self.group)
             torch.cuda.current_stream().synchronize()   # the receive buffers are complete before the library reads them
+            t_mg = time.perf_counter()
+            self.exchange_ms.append((t_mg - t_ex) * 1e3)
             if self._gather is None:
                 from . import HipGather
                 self._gather = HipGather(rec.device.index or 0, [m if len(m) else None for m in maps])
             self._keep = (parts_off, parts_rec)
             self._gather.run_buffers([t.data_ptr() for t in parts_off], [t.data_ptr() if t.numel() else 0 for t in parts_rec],
                                      [t.shape[0] for t in parts_rec], hi - lo)
+            self.merge_ms.append((time.perf_counter() - t_mg) * 1e3)
             self._last = ("device", out)
             if not fetch:
                 return lo, hi, None, None, None
@@ -295,10 +302,14 @@ class PartitionedIbf:
         nh, status, mo, m = out.fetch() if hasattr(out, "fetch") else out
         off = torch.from_numpy(np.ascontiguousarray(mo).astype(np.int64)).to(self.comm_device)
         flat = np.ascontiguousarray(m).view(np.uint32).reshape(-1, 3).view(np.int32)
+        t_ex = time.perf_counter()
         parts_off, parts_rec = exchange_grouped(off, torch.from_numpy(flat).to(self.comm_device), n_reads, self.rank, self.world, self.group)
+        t_mg = time.perf_counter()
+        self.exchange_ms.append((t_mg - t_ex) * 1e3)
         offs = [t.cpu().numpy() for t in parts_off]
         recs = [np.ascontiguousarray(t.cpu().numpy()).view(np.uint32).reshape(-1, 3).view(MATCH_DTYPE).reshape(-1) for t in parts_rec]
         _, mine = merge_parts_numpy(offs, recs, [mp if len(mp) else None for mp in maps])
+        self.merge_ms.append((time.perf_counter() - t_mg) * 1e3)
         self._last = ("host", mine)
         return lo, hi, nh, status, mine
 

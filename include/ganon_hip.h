@@ -83,6 +83,10 @@ typedef struct
 
 int         gn_device_count(int* n);
 const char* gn_last_error(void);
+/* The constants of seqan3's hash_and_fit this library was BUILT with (include/ganon_ibf_hash.h: five seeds, the multiplier), so that a
+ * caller or a test can compare them with its own; needs no device.  Replaces nothing in the reference: the numbers live inside SeqAn3
+ * (GanonClassify.cpp:514 -> bulk_count -> hash_and_fit). */
+int         gn_ibf_hash_constants(uint64_t seeds[5], uint64_t* multiplier);
 
 /* ---- filters ------------------------------------------------------------------------------- */
 

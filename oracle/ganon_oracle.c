@@ -150,6 +150,7 @@ uint64_t gno_threshold_cutoff(uint64_t n_hashes, double p)
  * ------------------------------------------------------------------------------------------ */
 const uint64_t GNO_IBF_SEEDS[5] = { 13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL,
                                     16499269484942379435ULL, 4893150838803335377ULL };
+const uint64_t GNO_IBF_MULTIPLIER = 11400714819323198485ULL; /* floor(2^64 / golden ratio); tests/test_oracle_kat.py derives all six */
 
 uint64_t gno_ibf_hash_shift(uint64_t bin_size)
 {
@@ -162,7 +163,7 @@ uint64_t gno_ibf_row(const gno_ibf* f, uint64_t v, uint32_t i)
 {
     uint64_t x = v * GNO_IBF_SEEDS[i];
     x ^= x >> f->hash_shift;
-    x *= 11400714819323198485ULL;
+    x *= GNO_IBF_MULTIPLIER;
     return (uint64_t)(((__uint128_t)x * (__uint128_t)f->bin_size) >> 64);
 }
 

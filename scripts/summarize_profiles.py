@@ -78,7 +78,7 @@ STEPS = 6  # the counter passes run `bench.py --steps 5 --warmup 1`
 rf = bench["roofline"]
 algo = rf["algo_bytes_per_launch"] * rf.get("launches_per_step", 1)
 fetched = rf.get("fetched_bytes_per_launch", rf["algo_bytes_per_launch"]) * rf.get("launches_per_step", 1)
-out = {"workload": wl, "tag": tag, "algo_bytes_per_step": algo, "kernel_fetched_bytes_per_step": fetched,
+out = {"workload": wl, "tag": tag, "file": f"profiles/{tag}_{wl}_pmc_FETCH_SIZE.csv", "algo_bytes_per_step": algo, "kernel_fetched_bytes_per_step": fetched,
        "count_ms_bench": bench["config"]["kernel_ms"]["count_select"]}
 if p_f:
     raw, n, names = counter_per_step(p_f, "FETCH_SIZE", STEPS)

@@ -23,6 +23,72 @@ def test_adjust_seed():
     assert oracle.adjust_seed(19) == 0x8F3F73B5CF1C9ADE >> 26
 
 
+def _ibf_constants_from_their_closed_forms():
+    """The six constants of seqan3::interleaved_bloom_filter::hash_and_fit (SURVEY App. A.2) are restated from memory -- SeqAn3 is not in
+    /root/reference -- but they are not arbitrary 20-digit numbers: each follows from a closed form over 2^64 (80-digit decimal
+    arithmetic; every quotient is far enough from an integer that 80 digits decide the floor)."""
+    from decimal import Decimal, getcontext, ROUND_FLOOR
+    getcontext().prec = 80
+    two64 = Decimal(2) ** 64
+
+    def exp1():   # e = sum 1/k!
+        s, t = Decimal(0), Decimal(1)
+        for k in range(1, 80):
+            s += t
+            t /= k
+        return s
+
+    def pi():     # Machin: pi = 16 atan(1/5) - 4 atan(1/239)
+        def atan_inv(n):
+            x = Decimal(1) / n
+            s, t, k = Decimal(0), x, 0
+            while abs(t) > Decimal(10) ** -78:
+                s += t / (2 * k + 1) * (-1 if k & 1 else 1)
+                t *= x * x
+                k += 1
+            return s
+        return 16 * atan_inv(5) - 4 * atan_inv(239)
+
+    def fl(x):
+        return int(x.to_integral_value(rounding=ROUND_FLOOR))
+
+    seeds = [fl(two64 / (exp1() / 2)),
+             fl(two64 / Decimal(2).sqrt()) | 1,                 # made odd: the floor is even (...212), the constant is ...213
+             fl(two64 / Decimal(3).sqrt()),
+             fl(two64 / (Decimal(5).sqrt() / 2)),
+             fl(two64 / 2 / (3 * pi() / 5))]                    # half of the documented form: 2^63
+    golden = (1 + Decimal(5).sqrt()) / 2
+    return seeds, fl(two64 / golden)
+
+
+def test_ibf_hash_constants_follow_from_their_closed_forms_everywhere():
+    """... and the oracle (oracle/ganon_oracle.c GNO_IBF_SEEDS / GNO_IBF_MULTIPLIER), the product's ONE definition
+    (include/ganon_ibf_hash.h, read as text) and what libganon_hip.so was built with (gn_ibf_hash_constants) all hold exactly those.  A
+    mis-remembered digit would not survive this; what it cannot show is that SeqAn3 uses these forms (first contact)."""
+    import ctypes as C
+    import os
+    import re
+    import ganon_amd
+    seeds, mul = _ibf_constants_from_their_closed_forms()
+    assert seeds == [13572355802537770549, 13043817825332782213, 10650232656628343401, 16499269484942379435, 4893150838803335377]
+    assert mul == 0x9E3779B97F4A7C15 == 11400714819323198485
+    assert all(s & 1 for s in seeds) and mul & 1          # odd: multiplication by them is a bijection on 64-bit words
+    L = oracle.lib()
+    assert list((C.c_uint64 * 5).in_dll(L, "GNO_IBF_SEEDS")) == seeds
+    assert C.c_uint64.in_dll(L, "GNO_IBF_MULTIPLIER").value == mul
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "ganon_ibf_hash.h")).read()
+    assert [int(x) for x in re.findall(r"(\d+)ULL", re.search(r"#define GN_IBF_SEED_LIST \{([^}]*)\}", hdr).group(1))] == seeds
+    assert int(re.search(r"#define GN_IBF_MULTIPLIER (\d+)ULL", hdr).group(1)) == mul
+    assert ganon_amd.hip.ibf_hash_constants() == (seeds, mul)
+    # one definition: no other literal copy of a seed or of the multiplier under ganon_amd/ (round 5 had five)
+    for d, _, files in os.walk(os.path.join(root, "ganon_amd")):
+        for f in files:
+            if f.endswith((".hip", ".h", ".hpp", ".cpp", ".py")):
+                text = open(os.path.join(d, f), errors="replace").read()
+                assert not any(str(c) in text for c in seeds + [mul]), os.path.join(d, f)
+
+
 def test_golden_ibf_config(kat, builds):
     for name, want in kat["golden_ibf_config"].items():
         if name.startswith("_"):
