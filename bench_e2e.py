@@ -86,11 +86,15 @@ def write_gzip_one_member(path: str, data: np.ndarray, level: int = 6, chunk: in
         f.write(struct.pack("<II", crc & 0xFFFFFFFF, n & 0xFFFFFFFF))
 
 
+EXTRA_ENV = {}   # --env K=V
+
+
 def run_binary(args, n_units, runs, label, deadline, env_extra=None):
     """-> summary of `runs` runs of the binary (fewer when the time budget runs out: the number is reported)"""
     secs, loads, walls = [], [], []
     last = {}
     env = dict(os.environ, GANON_HOST_TIMING="1")
+    env.update(EXTRA_ENV)
     env.update(env_extra or {})
     prefix = args[args.index("-o") + 1]
     for i in range(runs):
@@ -114,6 +118,7 @@ def run_binary(args, n_units, runs, label, deadline, env_extra=None):
     with open(prefix + ".all", "rb") as f:
         all_lines = sum(buf.count(b"\n") for buf in iter(lambda: f.read(1 << 24), b""))
     stalls = re.findall(r"\[host stalls\] (.*)", last.get("stderr", ""))
+    cpu = re.findall(r"\[host cpu\] seconds user \+ system: (.*)", last.get("stderr", ""))
     rates = [n_units / s / 1e6 for s in secs]
     out = {"input": label, "units": n_units, "runs": len(secs),
            "classify_print_s": {"median": round(float(np.median(secs)), 4), "min": round(min(secs), 4), "max": round(max(secs), 4)},
@@ -122,6 +127,12 @@ def run_binary(args, n_units, runs, label, deadline, env_extra=None):
            "total_classified": classified, "total_unclassified": unclassified,
            "classified_frac": round(classified / max(1, classified + unclassified), 4), "all_lines": all_lines,
            "host_stalls": "; ".join(stalls)[:400]}
+    if cpu:   # CPU seconds (user + system) per group of host threads over the LAST run, and per million units
+        groups = {}
+        for name, u, sy in re.findall(r"([a-z ]+?) ([0-9.eE+-]+) \+ ([0-9.eE+-]+)(?:,|;| on)", cpu[-1]):
+            groups[name.strip().replace(" ", "_")] = round(float(u) + float(sy), 4)
+        out["host_cpu_s"] = groups
+        out["host_cpu_s_per_munit"] = {k: round(v / (n_units / 1e6), 5) for k, v in groups.items()}
     if os.environ.get("E2E_DIAG"):  # every timing line of the last run (GANON_HOST_TIMING=1)
         out["timing_lines"] = [l[:600] for l in last.get("stderr", "").splitlines() if l.startswith("[")]
     for ext in (".all", ".rep"):
@@ -138,6 +149,7 @@ def main() -> int:
     ap.add_argument("--budget", type=float, default=200.0, help="seconds; inputs that no longer fit are left out and named")
     ap.add_argument("--keep-gz", default="", help="copy the filter and the single-end .fq.gz into this directory before they are removed (profiling runs)")
     ap.add_argument("--only", default="", help="comma-separated subset of fastq,paired,gz,fasta,hibf")
+    ap.add_argument("--env", action="append", default=[], help="K=V for the binary's environment, e.g. GANON_HIP_ABLATE=fake_count (scripts/host_ceiling.py)")
     ap.add_argument("--devices", default="", help="passed to the binary as --device (e.g. `all`, `0,1,2,3`, `0,0` = two workers on one GPU): one "
                                                   "classify worker per entry over ONE reader, as the reference runs N threads over one parser "
                                                   "(GanonClassify.cpp:1436-1441,1579-1597)")
@@ -147,6 +159,7 @@ def main() -> int:
     import ganon_amd
     from ganon_amd import ibf_file
 
+    EXTRA_ENV.update(dict(kv.split("=", 1) for kv in args.env))
     t_start = time.time()
     deadline = t_start + args.budget
     want = [w for w in (args.only.split(",") if args.only else ["fastq", "paired", "gz", "fasta", "hibf"]) if w]
@@ -178,6 +191,8 @@ def main() -> int:
         common = ["--output-all", "--verbose"] + THRESHOLDS + (["--device", args.devices] if args.devices else [])
         if args.devices:
             out["devices"] = args.devices
+        if EXTRA_ENV:
+            out["env"] = dict(EXTRA_ENV)
         if "fastq" in want:
             out["inputs"]["fastq"] = run_binary(["--ibf", ibf, "--single-reads", fq, "-o", os.path.join(d, "o_fastq")] + common, n, args.runs,
                                                 f"{n} reads x {L} bp, plain FASTQ", deadline)

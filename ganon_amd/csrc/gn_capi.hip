@@ -54,7 +54,8 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                               {"hibf_reg", &GnSwitches::hibf_reg},           {"hibf_pack", &GnSwitches::hibf_pack},
                               {"hibf_one_pack", &GnSwitches::hibf_one_pack}, {"hibf_persistent", &GnSwitches::hibf_persistent}, {"hibf_stage", &GnSwitches::hibf_stage}, {"hibf_nsort", &GnSwitches::hibf_nsort}, {"hibf_reread", &GnSwitches::hibf_reread},
                               {"hibf_fake_hashes", &GnSwitches::hibf_fake_hashes}, {"gather_copy", &GnSwitches::gather_copy},     {"joint_apart", &GnSwitches::joint_apart},
-                              {"pinned_malloc", &GnSwitches::pinned_malloc}, {"inflate_ahead", &GnSwitches::inflate_ahead}, {"debug", &GnSwitches::debug}};
+                              {"pinned_malloc", &GnSwitches::pinned_malloc}, {"inflate_ahead", &GnSwitches::inflate_ahead}, {"debug", &GnSwitches::debug},
+                              {"fake_count", &GnSwitches::fake_count}, {"seg_result", &GnSwitches::seg_result}};
     for (const char* p = list ? list : ""; *p;)
     {
         const char* e = strchr(p, ',');
@@ -943,6 +944,9 @@ extern "C" int gn_stream_destroy(gn_stream* s)
             hipEventDestroy(e);
     if (s->ev_sync)
         hipEventDestroy(s->ev_sync);
+    for (auto& e : s->ev_cmp)
+        if (e)
+            hipEventDestroy(e);
     if (s->ev_count0)
         hipEventDestroy(s->ev_count0);
     if (s->st2 && s->st2 != s->st)
@@ -1207,7 +1211,72 @@ __global__ void gn_gather_kernel(const gn_match* __restrict__ in, gn_match* __re
     }
 }
 
+// Segmented results (gn_run_group): the reads of `list` (what the fast kernel deferred to the generic one) may hold their matches in any
+// order; one wave per read checks and, where needed, ranks them by target through the scratch buffer (a target occurs once per read).
+__global__ void gn_seg_order_kernel(const uint32_t* __restrict__ list, const unsigned long long* __restrict__ n_list, gn_match* m, gn_match* scratch,
+                                    const uint64_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_count,
+                                    const uint64_t* __restrict__ seg_off, const unsigned long long* __restrict__ cursor, uint64_t cap)
+{
+    if (*cursor > cap)
+        return;
+    const uint32_t lane   = threadIdx.x & 63u;
+    const uint64_t waves  = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t n      = *n_list;
+    for (uint64_t i = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += waves)
+    {
+        const uint32_t r = list[i];
+        const uint32_t c = seg_count[r];
+        if (c < 2)
+            continue;
+        gn_match* seg = m + seg_begin[r];
+        bool      bad = false;
+        for (uint32_t j = lane; j + 1 < c; j += 64)
+            bad = bad || seg[j].target > seg[j + 1].target;
+        if (!__ballot(bad))
+            continue;
+        gn_match* tmp = scratch + seg_off[r];
+        for (uint32_t j = lane; j < c; j += 64)
+        {
+            const gn_match x    = seg[j];
+            uint32_t       rank = 0;
+            for (uint32_t e = 0; e < c; ++e)
+                rank += seg[e].target < x.target ? 1u : 0u;
+            tmp[rank] = x;
+        }
+        __threadfence();
+        for (uint32_t j = lane; j < c; j += 64)
+            seg[j] = tmp[j];
+    }
+}
+
 int gn_hibf_classify(gn_stream* s, gn_filter* f, hipStream_t st); // gn_hibf.hip
+
+// $GANON_HIP_ABLATE=fake_count (host-ceiling measurement, include/ganon_hip.h): the result of a count + select that was never run -- every
+// second read that has minimisers gets one match (target read % n_targets, count = its minimisers), so that the host's post stage has
+// the usual share of classified reads to write
+__global__ void gn_fake_count_kernel(gn_match* matches, uint64_t* seg_begin, uint32_t* seg_count, const uint8_t* status, const uint32_t* n_hashes,
+                                     uint32_t lo, uint32_t hi, uint32_t wpr, uint32_t n_targets, unsigned long long* cursor)
+{
+    const uint32_t r = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= hi)
+        return;
+    const bool hit = (r & 1u) && status[r] == GN_READ_OK && n_hashes[r] != 0;
+    for (uint32_t sl = 0; sl < wpr; ++sl)
+    {
+        seg_begin[(size_t)r * wpr + sl] = r >> 1;
+        seg_count[(size_t)r * wpr + sl] = hit && sl == 0 ? 1u : 0u;
+    }
+    if (hit)
+    {
+        gn_match m;
+        m.read   = r;
+        m.target = r % n_targets;
+        m.count  = n_hashes[r];
+        matches[r >> 1] = m;
+    }
+    if (r + 1 == hi)
+        atomicMax(cursor, (unsigned long long)((hi + 1) >> 1));
+}
 
 // count + select over reads [lo, hi) on the stream's main HIP stream (the match cursor is NOT reset here)
 static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
@@ -1238,6 +1307,16 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.n_reads    = hi;
     p.read_begin = lo;
     p.rel_cutoff = s->rel_cutoff;
+    if (gn_sw().fake_count)
+    {
+        if (lo == 0)
+            s->pf_predrop = false; // (every match is "written": a pre-pass judges them like any others)
+        if ((uint64_t)(hi + 1) / 2 <= s->match_cap && hi > lo)
+            hipLaunchKernelGGL(gn_fake_count_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, s->st, s->d_matches, s->d_seg_begin, s->d_seg_count,
+                               s->v_status, s->v_nh, lo, hi, (uint32_t)f->geom.wpr, f->n_targets ? f->n_targets : 1u, s->d_ctr);
+        GN_HIP(hipGetLastError());
+        return GN_OK;
+    }
     p.wpr        = f->geom.wpr;
     p.gp_log2    = f->geom.gp_log2;
     p.slice_dwords = f->geom.slice_dwords;
@@ -1339,7 +1418,18 @@ static int gn_run_group(gn_stream* s)
     GN_HIP(hipMemsetAsync(s->d_seg_count + nseg, 0, 4, s->st));
     size_t tmp = s->scan_tmp_bytes;
     GN_HIP(gn_scan_counts(s->d_scan_tmp, tmp, s->d_seg_count, s->d_seg_off, (int)(nseg + 1), s->st));
-    if (nseg)
+    // One unit per read: a read's matches are one segment of d_matches already (the fast kernel's and the generic kernel's select emit
+    // ascending targets) -- nothing to move.  Several column slices per read: their segments are put behind each other now.
+    // (identity maps only: the fast kernel writes a read's matches by ascending target; the reads it defers to the generic kernel
+    // -- more than 127 minimisers -- come out of a candidate-driven select in no particular order and are put right below)
+    s->segmented = s->f->identity && s->f->geom.wpr == 1 && !s->long_reads && !gn_sw().seg_result;
+    s->compacted = !s->segmented;
+    s->cmp_timed = false;
+    s->pf_out    = nullptr;
+    if (nseg && s->segmented)
+        hipLaunchKernelGGL(gn_seg_order_kernel, dim3(64), dim3(256), 0, s->st, s->d_deferred, s->d_ctr + 4, s->d_matches, s->d_sorted, s->d_seg_begin,
+                           s->d_seg_count, s->d_seg_off, s->d_ctr, s->match_cap);
+    if (nseg && !s->segmented)
         hipLaunchKernelGGL(gn_gather_kernel, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, s->st, s->d_matches,
                            s->d_sorted, s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)s->n_reads,
                            (uint32_t)s->f->geom.wpr, s->d_ctr, s->match_cap);
@@ -1347,6 +1437,32 @@ static int gn_run_group(gn_stream* s)
     // exact number of matches = scan total (the cursor counts allocated space including chunk holes)
     GN_HIP(hipMemcpyAsync(s->d_ctr + 6, s->d_seg_off + nseg, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->st));
     return GN_OK;
+}
+
+// The contiguous (CSR) copy of a segmented result, for the consumers that want one: gn_fetch_batch(matches), gn_stream_device_matches,
+// the merge of a partitioned filter, a joint pre-pass.  Queued on the stream, once per batch; callers come after gn_finish (no overflow).
+int gn_result_compact(gn_stream* s)
+{
+    if (!s->segmented || s->compacted || s->f->is_hibf || s->pf_out)
+        return GN_OK;
+    GN_HIP(hipSetDevice(s->f->device));
+    if (!s->ev_cmp[0])
+        for (auto& e : s->ev_cmp)
+            GN_HIP(hipEventCreate(&e));
+    GN_HIP(hipEventRecord(s->ev_cmp[0], s->st));
+    if (s->n_reads)
+        hipLaunchKernelGGL(gn_gather_kernel, dim3((unsigned)((s->n_reads + 255) / 256)), dim3(256), 0, s->st, s->d_matches, s->d_sorted,
+                           s->d_seg_begin, s->d_seg_count, s->d_seg_off, (uint64_t)s->n_reads, 1u, s->d_ctr, s->match_cap);
+    GN_HIP(hipGetLastError());
+    GN_HIP(hipEventRecord(s->ev_cmp[1], s->st));
+    s->compacted = true;
+    s->cmp_timed = true;
+    return GN_OK;
+}
+
+const gn_match* gn_result_matches(gn_stream* s)
+{
+    return s->pf_out ? s->pf_out : s->d_sorted;
 }
 
 static int gn_check_shape(gn_stream* s, uint32_t k, uint32_t w)
@@ -1709,9 +1825,10 @@ extern "C" int gn_fetch_batch(gn_stream* s, uint32_t* n_hashes, uint8_t* status,
             return gn_fail(GN_EOVERFLOW, "match buffer too small: need %llu, have %llu", (unsigned long long)s->n_matches,
                            (unsigned long long)cap);
         }
+        if ((rc = gn_result_compact(s)) != GN_OK)
+            return rc;
         if (s->n_matches)
-            GN_HIP(hipMemcpyAsync(matches, s->pf_on ? s->d_matches : s->d_sorted, s->n_matches * sizeof(gn_match), hipMemcpyDeviceToHost,
-                                  s->st));
+            GN_HIP(hipMemcpyAsync(matches, gn_result_matches(s), s->n_matches * sizeof(gn_match), hipMemcpyDeviceToHost, s->st));
     }
     GN_HIP(hipStreamSynchronize(s->st));
     if (status && s->long_reads) // the long kernel classified them (the device keeps GN_READ_BIG: a re-run after a
@@ -1771,7 +1888,9 @@ extern "C" int gn_stream_device_matches(gn_stream* s, const gn_match** d_matches
     int rc = gn_finish(s);
     if (rc)
         return rc;
-    *d_matches = s->pf_on ? s->d_matches : s->d_sorted;
+    if ((rc = gn_result_compact(s)) != GN_OK)
+        return rc;
+    *d_matches = gn_result_matches(s);
     *n_matches = s->n_matches;
     return GN_OK;
 }
@@ -1888,6 +2007,8 @@ extern "C" int gn_stream_timings(gn_stream* s, gn_timings* t)
     else
         tm.algo_bytes = tm.n_hashes * (uint64_t)s->f->ibf.h * s->f->ibf.W * 8ull;
     tm.fetched_bytes = tm.algo_bytes - (s->f->is_hibf ? 0ull : (uint64_t)s->h_ctr[7]);
+    if (s->cmp_timed && hipEventSynchronize(s->ev_cmp[1]) == hipSuccess)
+        hipEventElapsedTime(&tm.ms_compact, s->ev_cmp[0], s->ev_cmp[1]);
     *t = tm;
     return GN_OK;
 }

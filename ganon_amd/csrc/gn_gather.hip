@@ -344,7 +344,12 @@ extern "C" int gn_gather_run(gn_gather* g, gn_stream* const* streams, uint32_t n
             GN_HIP(hipStreamSynchronize(s->st));
             src_off = s->d_slot_cnt;
         }
-        const gn_match* src_m = s->pf_on ? s->d_matches : s->d_sorted;
+        int rc_c = gn_result_compact(s); // (a segmented result that no pre-pass has compacted)
+        if (rc_c)
+            return rc_c;
+        if (s->cmp_timed)
+            GN_HIP(hipStreamSynchronize(s->st)); // (the copy was queued on the part's stream just now; the merge runs on the gather's)
+        const gn_match* src_m = gn_result_matches(s);
         if (s->device == g->device && !force_copy)
         {
             p.off[i] = src_off;

@@ -39,6 +39,7 @@ struct GnSwitches
     bool split_kernel = false;    // split-bin maps go to the generic kernel
     bool predrop = false;         // with a filter_matches pre-pass: write every match, judge afterwards
     bool deferred_grids = false;  // grids of the deferred-list kernels sized for the whole batch, not from the last batch's list
+    bool seg_result = false;      // a flat IBF's matches are copied behind each other after every batch (as up to round 5), not left in their segments
     bool on_demand = false;       // fast kernel and HIBF packed kernel: every wave takes units i, i + waves, ... (no cursor: as up to round 5)
     // HIBF
     bool hibf_reg = false;        // no per-item register kernel (LDS-counter level kernel instead)
@@ -62,8 +63,15 @@ struct GnSwitches
     int      sync_mode = 0;       // 0 runtime default, 1 spin, 2 yield, 3 block: how host threads wait for the device
     bool     pinned_malloc = false; // gn_pinned_alloc: hipHostMalloc as up to round 4 (no huge-page mapping + hipHostRegister)
     bool     debug = false;       // chatter on stderr
+    // host-ceiling measurement
+    bool     fake_count = false;  // MEASUREMENT ONLY (wrong results): upload, record index and minimisers run, the count + select kernels do not; every
+                                  // second read of a flat IBF gets one made-up match (read % targets, its number of minimisers) -- the device
+                                  // step costs next to nothing and what is left is what the host's reader, workers and post stage sustain
 };
 const GnSwitches& gn_sw();
+struct gn_stream;
+int             gn_result_compact(gn_stream* s);  // gn_capi.hip: the contiguous copy of a segmented result, queued on the stream (no-op otherwise)
+const gn_match* gn_result_matches(gn_stream* s);  // the batch's final matches, contiguous by read (after gn_result_compact / the pre-pass)
 
 // ---- minimiser kernel -----------------------------------------------------------------------
 struct GnMinimiserParams
@@ -329,6 +337,14 @@ struct gn_stream
     gn_stream*          src        = nullptr; // the stream shared from (nullptr: own batch)
     gn_match*           d_matches  = nullptr; // unordered (reservation order)
     gn_match*           d_sorted   = nullptr; // grouped by read
+    // A flat IBF whose reads are one unit each (wpr == 1) leaves every read's matches as ONE contiguous segment of d_matches
+    // (seg_begin[r], seg_count[r]): that IS the grouped result, written once.  The pre-pass of filter_matches reads the segments
+    // where they lie; the contiguous copy (d_sorted, CSR) is made only when a consumer asks for it (gn_result_compact), not per batch.
+    bool                segmented  = false;   // the batch's matches lie in segments of d_matches
+    bool                compacted  = true;    // ... and d_sorted holds their contiguous copy
+    gn_match*           pf_out     = nullptr; // where the pre-pass put its survivors (d_matches, or d_sorted when it read segments)
+    hipEvent_t          ev_cmp[2]{};          // around the last contiguous copy (gn_timings.ms_compact)
+    bool                cmp_timed  = false;
     unsigned long long* d_ctr      = nullptr; // [0] cursor [1] total_hashes [2] algo_bytes [3] work count
     uint64_t*           d_seg_begin = nullptr;
     uint32_t*           d_seg_count = nullptr;

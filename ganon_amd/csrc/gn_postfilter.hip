@@ -39,6 +39,7 @@ struct GnPostfilterParams
 {
     gn_match*           m;          // grouped matches, filtered in place (survivors move to the front of the read's range)
     const uint64_t*     off;        // read r owns [off[r*stride], off[(r+1)*stride])
+    const uint64_t*     begin;      // segmented result (gn_run_group): read r's off[r+1] - off[r] matches lie at m + begin[r]; nullptr: at m + off[r*stride]
     uint32_t            stride;
     uint32_t            n_reads;
     const uint32_t*     nh;         // minimisers per read
@@ -110,6 +111,8 @@ __global__ __launch_bounds__(256) void gn_postfilter_kernel(GnPostfilterParams p
     {
         o = p.off[r * p.stride];
         c = (uint32_t)(p.off[(r + 1) * p.stride] - o);
+        if (p.begin)
+            o = p.begin[r];
         n = p.nh[r];
     }
     if (valid && c <= GN_PF_SMALL)
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void gn_postfilter_kernel(GnPostfilterParams p
 
 // survivors of read r: in[off[r*stride] + i], i < keep[r]  ->  out[new_off[r] + i]
 __global__ void gn_postfilter_compact_kernel(const gn_match* __restrict__ in, gn_match* __restrict__ out, const uint64_t* __restrict__ off,
-                                             uint32_t stride, const uint32_t* __restrict__ keep, const uint64_t* __restrict__ new_off,
+                                             const uint64_t* __restrict__ begin, uint32_t stride, const uint32_t* __restrict__ keep, const uint64_t* __restrict__ new_off,
                                              uint32_t n_reads, const unsigned long long* __restrict__ cursor, uint64_t cap)
 {
     if (*cursor > cap)
@@ -356,7 +359,7 @@ __global__ void gn_postfilter_compact_kernel(const gn_match* __restrict__ in, gn
     uint32_t       c = 0;
     if (valid)
     {
-        o  = off[r * stride];
+        o  = begin ? begin[r] : off[r * stride];
         no = new_off[r];
         c  = keep[r];
     }
@@ -383,8 +386,11 @@ __global__ void gn_postfilter_compact_kernel(const gn_match* __restrict__ in, gn
 static GnPostfilterParams gn_pf_params(gn_stream* s)
 {
     GnPostfilterParams p{};
-    p.m          = s->d_sorted;
+    // a segmented result is judged where it lies (one read of every match, no copy before the pre-pass)
+    const bool seg = s->segmented && !s->compacted && !s->f->is_hibf;
+    p.m          = seg ? s->d_matches : s->d_sorted;
     p.off        = s->d_seg_off;
+    p.begin      = seg ? s->d_seg_begin : nullptr;
     p.stride     = s->f->is_hibf ? 1u : (uint32_t)s->f->geom.wpr;
     p.n_reads    = s->n_reads;
     p.nh         = s->v_nh;
@@ -410,8 +416,11 @@ static int gn_pf_finish(gn_stream* s, const GnPostfilterParams& p)
     const unsigned blocks = (unsigned)(((uint64_t)n + 1 + 255) / 256);
     size_t         tmp    = s->pf_scan_bytes;
     GN_HIP(gn_scan_counts(s->d_pf_scan, tmp, s->d_pf_keep, s->d_slot_cnt, (int)(n + 1), s->st));
-    hipLaunchKernelGGL(gn_postfilter_compact_kernel, dim3(blocks), dim3(256), 0, s->st, s->d_sorted, s->d_matches, s->d_seg_off, p.stride,
+    // survivors go to the buffer the pre-pass did not read: d_matches after a contiguous copy, d_sorted after segments
+    gn_match* out = p.m == s->d_sorted ? s->d_matches : s->d_sorted;
+    hipLaunchKernelGGL(gn_postfilter_compact_kernel, dim3(blocks), dim3(256), 0, s->st, p.m, out, s->d_seg_off, p.begin, p.stride,
                        s->d_pf_keep, s->d_slot_cnt, n, s->d_ctr, s->match_cap);
+    s->pf_out = out;
     GN_HIP(hipGetLastError());
     GN_HIP(hipMemcpyAsync(s->d_pf_ctr + 2, s->d_slot_cnt + n, sizeof(unsigned long long), hipMemcpyDeviceToDevice, s->st));
     GN_HIP(hipMemcpyAsync(s->h_pf_ctr, s->d_pf_ctr, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st));
@@ -696,6 +705,8 @@ extern "C" int gn_streams_postfilter_joint(gn_stream* const* streams, uint32_t n
             if (rc)
                 return rc;
             GN_HIP(hipMemsetAsync(s->d_pf_ctr, 0, 4 * sizeof(unsigned long long), s->st));
+            if ((rc = gn_result_compact(s)) != GN_OK) // (the merge kernel walks contiguous per-read ranges)
+                return rc;
             mp.m[i]         = s->d_sorted;
             mp.off[i]       = s->d_seg_off;
             mp.stride[i]    = s->f->is_hibf ? 1u : (uint32_t)s->f->geom.wpr;

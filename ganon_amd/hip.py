@@ -53,7 +53,7 @@ class IbfDesc(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("ms_minimiser", C.c_float), ("ms_count", C.c_float), ("ms_total", C.c_float),
                 ("n_hashes", C.c_uint64), ("algo_bytes", C.c_uint64), ("n_matches", C.c_uint64),
-                ("n_count_launches", C.c_uint32), ("fetched_bytes", C.c_uint64)]
+                ("n_count_launches", C.c_uint32), ("fetched_bytes", C.c_uint64), ("ms_compact", C.c_float)]
 
 
 class InflateStats(C.Structure):  # gn_inflate_stats
@@ -757,7 +757,7 @@ class HipStream:
         _check(load_library().gn_stream_timings(self._h, C.byref(t)))
         return dict(ms_minimiser=t.ms_minimiser, ms_count=t.ms_count, ms_total=t.ms_total, n_hashes=t.n_hashes,
                     algo_bytes=t.algo_bytes, n_matches=t.n_matches, n_count_launches=t.n_count_launches,
-                    fetched_bytes=t.fetched_bytes)
+                    fetched_bytes=t.fetched_bytes, ms_compact=t.ms_compact)
 
     def hibf_levels(self):
         """per tree level of the last HIBF batch: [dict(ms, algo_bytes, table_bytes, row_bytes, line_bytes)] (gn_stream_hibf_levels / _level_lines)"""

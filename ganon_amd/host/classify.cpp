@@ -1873,7 +1873,16 @@ static bool ganon_classify(Config config)
 
         // ---- reader -> [one device worker per GPU] -> post stage (this thread), results consumed in input order
         {
-            const size_t             n_post = (size_t)env_size("GANON_HOST_POST_THREADS", 3);
+            // post pool: three threads keep up with one GPU; a node's worth of GPUs needs a node's worth of post threads -- two per
+            // distinct device, within half of the usable cores (scripts/host_ceiling.py: ~CPU seconds per million reads and group)
+            size_t n_distinct_dev = 0;
+            {
+                std::vector<int> d = devices;
+                std::sort(d.begin(), d.end());
+                n_distinct_dev = (size_t)(std::unique(d.begin(), d.end()) - d.begin());
+            }
+            const size_t             n_post = (size_t)env_size("GANON_HOST_POST_THREADS",
+                                                               std::max<size_t>(3, std::min<size_t>(2 * n_distinct_dev, std::max<size_t>(3, usable_cores() / 2))));
             // (what may pile up in front of the writer while one batch is late: every batch held there is page-locked memory that is missing elsewhere)
             InOrder                  ordered(env_size("GANON_HOST_LANES", 2) * n_workers + n_post + 2); // (more than what workers, post pool and queues hold at once)
             BoundedQueue<ClassifiedBatch> classified(n_post + 1);
@@ -2095,6 +2104,8 @@ static bool ganon_classify(Config config)
                     ordered.producer_done();
                 });
             ClassifiedBatch cb;
+            uint64_t        merge_u0, merge_s0;
+            CpuTally::thread_now(merge_u0, merge_s0);
             while (ordered.take(cb, n_post))
             {
                 merge_stage(cb);
@@ -2109,6 +2120,7 @@ static bool ganon_classify(Config config)
                 ordered.recycle(std::move(cb));
                 cb = ClassifiedBatch();
             }
+            g_cpu.merge.add_since(merge_u0, merge_s0);
             if (failed && first_level)
             {
                 ReadBatch b; // let the reader finish so that the workers blocked on it come back
@@ -2257,6 +2269,8 @@ static bool ganon_classify(Config config)
         g_cpu.mate.print(std::cerr, ", mate copiers");
         g_cpu.worker.print(std::cerr, ", device workers");
         g_cpu.post.print(std::cerr, ", post pool");
+        g_cpu.merge.print(std::cerr, ", merge and write");
+        g_cpu.inflate.print(std::cerr, ", device inflate feeders");
         std::cerr << "; whole process " << ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6 << " + " << ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6
                   << " on " << usable_cores() << " usable cores" << std::endl;
     }

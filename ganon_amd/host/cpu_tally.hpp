@@ -25,6 +25,24 @@ struct CpuTally
             sys_us += (uint64_t)r.ru_stime.tv_sec * 1000000u + (uint64_t)r.ru_stime.tv_usec;
         }
     }
+    // ... or what it used between two points (a thread that does other things too: the main thread's merge + write loop)
+    static void thread_now(uint64_t& user, uint64_t& sys)
+    {
+        rusage r;
+        user = sys = 0;
+        if (getrusage(RUSAGE_THREAD, &r) == 0)
+        {
+            user = (uint64_t)r.ru_utime.tv_sec * 1000000u + (uint64_t)r.ru_utime.tv_usec;
+            sys  = (uint64_t)r.ru_stime.tv_sec * 1000000u + (uint64_t)r.ru_stime.tv_usec;
+        }
+    }
+    void add_since(uint64_t user0, uint64_t sys0)
+    {
+        uint64_t u, s;
+        thread_now(u, s);
+        user_us += u - user0;
+        sys_us += s - sys0;
+    }
     void print(std::ostream& os, const char* name) const
     {
         os << name << ' ' << user_us.load() * 1e-6 << " + " << sys_us.load() * 1e-6;
@@ -58,7 +76,7 @@ struct EventSpan
 
 struct CpuTallies
 {
-    CpuTally parse, inflate, reader, mate, worker, post;
+    CpuTally parse, inflate, reader, mate, worker, post, merge;
 };
 inline CpuTallies g_cpu;
 

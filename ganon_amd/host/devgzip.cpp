@@ -16,6 +16,7 @@
 // Anything the device path refuses (GN_ERANGE: damaged data, a wrong ISIZE, expansion beyond its buffers, ...) ends the source with
 // an error text; the caller's sequential zlib reader continues at delivered() and produces the records and the message from there.
 #include "backend.hpp"
+#include "cpu_tally.hpp"
 
 #include "../../include/ganon_hip.h"
 
@@ -130,10 +131,10 @@ public:
         sec_pinned_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count() - sec_create_;
         const unsigned n_readers = (unsigned)std::min<uint64_t>(3, n_blocks_);
         for (unsigned t = 0; t < n_readers; ++t)
-            readers_.emplace_back([this] { read_loop(); });
-        feeder_  = std::thread([this] { feed_loop(); });
+            readers_.emplace_back([this] { read_loop(); g_cpu.inflate.add_this_thread(); });
+        feeder_  = std::thread([this] { feed_loop(); g_cpu.inflate.add_this_thread(); });
         if (!by_lines_)
-            stepper_ = std::thread([this] { step_loop(); });
+            stepper_ = std::thread([this] { step_loop(); g_cpu.inflate.add_this_thread(); });
         return true;
     }
 

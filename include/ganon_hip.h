@@ -79,6 +79,9 @@ typedef struct
     uint32_t n_count_launches; /* count/select launches of the batch (chunks of the minimiser||count pipeline); ms_count spans all */
     uint64_t fetched_bytes;    /* row bytes actually requested: algo_bytes minus the rows skipped by the exact early exit
                                   of reads that can no longer reach their cutoff (flat IBF fast path) */
+    float    ms_compact;       /* 0, or the contiguous copy of a segmented result that a consumer asked for after the batch (a flat IBF with
+                                  one unit per read leaves a read's matches where the count kernel wrote them; gn_fetch_batch(matches),
+                                  gn_stream_device_matches and the merges make the copy on demand): not part of ms_total */
 } gn_timings;
 
 int         gn_device_count(int* n);
@@ -336,7 +339,8 @@ int gn_peer_stats(int dst, int src, int* state, uint64_t* bytes);
  * test can cross-check a fast path against the path it replaces (NULL or "" = the product path).  Call it only while no
  * launch is in flight.  Names that switch a path OFF: early_exit cand_select csr_identity uniform_select run_select
  * max_first const_nb split_kernel predrop deferred_grids hibf_reg hibf_pack hibf_one_pack hibf_persistent; test set-ups:
- * hibf_stage hibf_reread pinned_malloc gather_copy joint_apart inflate_ahead on_demand hibf_dense_rows chunk=N hibf_pair_limit=N hibf_bpc=N; runtime: sync=spin|yield|block debug.  Unknown name -> GN_EINVAL and
+ * hibf_stage hibf_reread pinned_malloc gather_copy joint_apart inflate_ahead on_demand hibf_dense_rows chunk=N hibf_pair_limit=N hibf_bpc=N; runtime: sync=spin|yield|block debug; measurement with WRONG results: fake_count (flat IBF: the count +
+ * select kernels are not run, every second read gets one made-up match -- what is left is what the host around the device sustains).  Unknown name -> GN_EINVAL and
  * the previous list stays. */
 int gn_ablate(const char* list);
 /* free / total memory of a device: the host decides with it whether a filter is replicated or partitioned */
