@@ -3,6 +3,7 @@
 #include "backend.hpp"
 #include "pinned_pool.hpp"
 #include "placement.hpp"
+#include "tunables.hpp"
 
 #include <ganon_hip.h>
 
@@ -35,9 +36,9 @@ public:
     ~HipBackend() override
     {
         PinnedPool::get().settle();
-        if (std::getenv("GANON_HOST_TIMING") && index_ == 0 && !twin_)
+        if (tun().is_set(Knob::timing) && index_ == 0 && !twin_)
             std::cerr << "[pinned pool] " << PinnedPool::get().tally() << std::endl;
-        if (std::getenv("GANON_HOST_TIMING") && n_create_)
+        if (tun().is_set(Knob::timing) && n_create_)
             std::cerr << "[backend timing] device " << device_ << ": stream (re)creation " << sec_create_ << " s (" << n_create_
                       << "x), submit calls " << sec_submit_ << " s, waiting for + fetching the results " << sec_fetch_ << " s, FASTQ text: upload calls "
                       << sec_tok_enqueue_ << " s + waiting for the records " << sec_tok_wait_ << " s"
@@ -75,8 +76,7 @@ public:
     {
         if (!set_->any_spread())
             return true;
-        const char*  e = std::getenv("GANON_PARTITION_WORKERS");
-        const size_t k = e ? (size_t)std::max(1L, std::atol(e)) : 2;
+        const size_t k = std::max<size_t>(1, tun().size(Knob::partition_workers, 2));
         return index_ < k;
     }
 
@@ -97,7 +97,7 @@ public:
                 if (gn_peer_stats(dst, src, &state, &bytes) != GN_OK || (state == 0 && bytes == 0))
                     continue;
                 out += "device " + std::to_string(src) + " -> " + std::to_string(dst) + ": "
-                       + (dst == src ? "one device (copy path forced by $GANON_HIP_GATHER_COPY)"
+                       + (dst == src ? "one device (copy path forced by the library switch gather_copy)"
                                      : state == 1 ? "peer access enabled (direct device-to-device copies)" : "no peer access (copies staged by the runtime)")
                        + ", "
                        + std::to_string(bytes >> 20) + " MiB of matches gathered\n";
@@ -112,8 +112,7 @@ public:
     // a link each but share the host's cores: there it matters more.  $GANON_HOST_DEVICE_FASTQ=0 keeps the parse on the host.
     bool tokenises_fastq() const override
     {
-        const char* e = std::getenv("GANON_HOST_DEVICE_FASTQ");
-        return !(e && e[0] == '0');
+        return !tun().off(Knob::device_fastq);
     }
 
     // Raw batch: the text goes to the first stream of every device the level's filters live on (the stream that takes a parsed
@@ -234,7 +233,7 @@ public:
         // submit to every stream first (asynchronous), then fetch
         const uint64_t nb = std::max<uint64_t>(b.bases.size(), 1);
         std::map<int, gn_stream*> source_of; // device -> the stream that holds this batch there
-        const bool                share_hashes = !std::getenv("GANON_HOST_NO_SHARED_HASHES");
+        const bool                share_hashes = !tun().is_set(Knob::no_shared_hashes);
         for (size_t i = 0; i < filters_.size(); ++i)
             for (size_t g = 0; g < filters_[i].parts.size(); ++g)
             {
@@ -516,7 +515,7 @@ public:
 
     void warm_up(uint32_t k, uint32_t w, const std::vector<double>& rel_cutoff) override
     {
-        if (std::getenv("GANON_HOST_NO_WARM_UP"))
+        if (tun().is_set(Knob::no_warm_up))
             return;
         // eight reads of 2 w letters, as a parsed batch or as text -- whichever way the run's batches will come
         ReadBatch   b;
@@ -846,8 +845,8 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
     // parsers and the post pool (2-4 device workers on a 16-core quota: +2 .. +17 % end to end, profiles/r03_e2e_ab_sync.txt)
     // (the library's switches: $GANON_HIP_ABLATE, read once when it was loaded -- a list that names no sync mode gets "sync=block")
     {
-        const char* e  = std::getenv("GANON_HIP_ABLATE");
-        std::string sw = e ? e : "";
+        const std::string* e  = tun().str(Knob::hip_ablate);
+        std::string        sw = e ? *e : "";
         if (sw.find("sync=") == std::string::npos)
         {
             sw += (sw.empty() ? "" : ",") + std::string("sync=block");
@@ -875,7 +874,7 @@ std::vector<std::unique_ptr<Backend>> make_backends(const std::vector<int>& devi
     for (size_t i = 0; i < use.size(); ++i)
         out.emplace_back(new HipBackend(set, i));
     // device-bound host buffers (read batches) come from page-locked memory from now on (hostmem.hpp)
-    if (!std::getenv("GANON_HOST_PAGEABLE"))
+    if (!tun().is_set(Knob::pageable))
     {
         g_host_arena.alloc   = [](size_t n) -> void* { return PinnedPool::get().take(n); };
         g_host_arena.release = [](void* p) { PinnedPool::get().give(p); };

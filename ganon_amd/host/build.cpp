@@ -24,6 +24,7 @@
 #include "hasher.hpp"
 #include "hostmem.hpp"
 #include "seq_io.hpp"
+#include "tunables.hpp"
 
 #include "ganon_hip.h"
 
@@ -719,6 +720,7 @@ bool run(Config c)
 
 int main(int argc, char** argv)
 {
+    gnhost::HostTunables::init();
     Config    c;
     const int r = parse_args(argc, argv, c);
     if (r == 1)

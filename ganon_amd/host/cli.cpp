@@ -4,6 +4,7 @@
 // hand-written parser here: "--name value", "--name=value", "-n value", comma-separated vectors that append when
 // an option is repeated, boolean switches with an optional "=true/false").
 #include "config.hpp"
+#include "tunables.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -175,9 +176,9 @@ std::optional<Config> parse_command_line(int argc, char** argv, int& exit_code)
     bool want_help = false, want_version = false;
     try
     {
-        if (const char* d = std::getenv("GANON_DEVICE"))
+        if (const std::string* d = tun().str(Knob::device))
         {
-            cfg.devices       = parse_devices(d);
+            cfg.devices       = parse_devices(*d);
             cfg.devices_given = true;
         }
         for (int i = 1; i < argc; ++i)

@@ -17,6 +17,7 @@
 // an error text; the caller's sequential zlib reader continues at delivered() and produces the records and the message from there.
 #include "backend.hpp"
 #include "cpu_tally.hpp"
+#include "tunables.hpp"
 
 #include "../../include/ganon_hip.h"
 
@@ -109,16 +110,16 @@ public:
         size_     = (uint64_t)st.st_size;
         device_   = device;
         piece_    = std::max<size_t>(piece_bytes, 1 << 16);
-        const char* sb = std::getenv("GANON_HOST_DEVICE_INFLATE_STEP");
-        const char* cb = std::getenv("GANON_HOST_DEVICE_INFLATE_CHUNK");
+        const std::string* sb = tun().str(Knob::device_inflate_step);
+        const std::string* cb = tun().str(Knob::device_inflate_chunk);
         const auto t_open = std::chrono::steady_clock::now();
         t0_ = t_open;
-        if (gn_inflate_create(device, size_, cb ? (uint32_t)std::atoll(cb) : 0, sb ? (uint64_t)std::atoll(sb) : 0, &z_) != GN_OK)
+        if (gn_inflate_create(device, size_, cb ? (uint32_t)std::atoll(cb->c_str()) : 0, sb ? (uint64_t)std::atoll(sb->c_str()) : 0, &z_) != GN_OK)
         {
             z_ = nullptr;
             return false; // (no room for the file and the step buffers beside the filters: the host inflater takes it)
         }
-        l_step_ = sb ? (uint64_t)std::atoll(sb) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
+        l_step_ = sb ? (uint64_t)std::atoll(sb->c_str()) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
         sec_create_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         n_blocks_ = (size_ + kBlock - 1) / kBlock;
         for (unsigned i = 0; i < kRing; ++i)
@@ -360,8 +361,8 @@ private:
         uint64_t              stream_at = 0; // decompressed offset of the next step's text[0] (the carried bytes included)
         std::vector<uint64_t> cuts, cut_lines;
         unsigned              step_no = 0;
-        const char*           sb   = std::getenv("GANON_HOST_DEVICE_INFLATE_STEP");
-        const uint64_t        step = sb ? (uint64_t)std::atoll(sb) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
+        const std::string*    sb   = tun().str(Knob::device_inflate_step);
+        const uint64_t        step = sb ? (uint64_t)std::atoll(sb->c_str()) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
         uint64_t              want = 0; // compressed bytes the next step should find
         for (;;)
         {

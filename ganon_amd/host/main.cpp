@@ -7,6 +7,7 @@
 
 #include "filter_io.hpp"
 #include "startup.hpp"
+#include "tunables.hpp"
 
 #include <iostream>
 
@@ -19,6 +20,7 @@ bool verify_filter(const Config& config); // verify.cpp
 int main(int argc, char** argv)
 {
     gnhost::StartupLog::get(); // (time zero of the [startup] lines)
+    gnhost::HostTunables::init(); // the environment is read here, once (tunables.hpp); --verbose lists what was set
     int  exit_code = 0;
     auto config    = gnhost::parse_command_line(argc, argv, exit_code);
     if (!config.has_value())

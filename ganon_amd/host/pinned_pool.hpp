@@ -5,6 +5,7 @@
 #include <ganon_hip.h>
 
 #include "startup.hpp"
+#include "tunables.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -95,8 +96,7 @@ public:
     // block_bytes: what the reader will ask for (32 MiB holds the bases of a parsed 48 MiB slab; a slab that travels as text needs 56)
     void warm_up(size_t block_bytes = 32u << 20)
     {
-        const char* e = std::getenv("GANON_HOST_PRELOCK_MIB");
-        const size_t total = (e ? (size_t)std::atol(e) : 512) << 20, block = size_class(block_bytes);
+        const size_t total = tun().size(Knob::prelock_mib, 512) << 20, block = size_class(block_bytes);
         if (total == 0)
             return;
         warm_ = std::thread([this, total, block] {

@@ -72,10 +72,10 @@ public:
         for (int d : entries)
             if (std::find(uniq_.begin(), uniq_.end(), d) == uniq_.end())
                 uniq_.push_back(d);
-        const char* e = std::getenv("GANON_DEVICE_BUDGET");
-        if (e && *e)
+        const std::string* e = tun().str(Knob::device_budget);
+        if (e && !e->empty())
         {
-            const uint64_t b = parse_bytes(e);
+            const uint64_t b = parse_bytes(e->c_str());
             for (int d : entries)
                 vdev_.push_back(VDev{ d, b, 0 });
             virtual_ = true;

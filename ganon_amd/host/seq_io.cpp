@@ -2,6 +2,7 @@
 #include "seq_io.hpp"
 #include "pgzip.hpp"
 #include "cpu_tally.hpp"
+#include "tunables.hpp"
 
 #include <tmmintrin.h>
 #include <zlib.h>
@@ -551,7 +552,7 @@ SeqReader::SeqReader(const std::string& path, uint64_t start_offset) : impl_(new
             throw ParseError(why);
         return;
     }
-    if (!std::getenv("GANON_HOST_NO_BGZF") && start_offset == 0)
+    if (!tun().is_set(Knob::no_bgzf) && start_offset == 0)
         impl_->bgzf = BgzfSource::open(path); // blocked gzip: members inflated in parallel
     if (impl_->bgzf)
         return;
@@ -1108,20 +1109,19 @@ std::unique_ptr<ParallelFastq> ParallelFastq::open(const std::string& path, unsi
         // An ordinary gzip file (blocked gzip has a reader of its own, BgzfSource): inflated by several threads (pgzip.hpp),
         // and the slab parsers work on the decompressed stream as on a file.  The name must say .gz: the sequential reader that
         // takes over at irregular records opens the file by name.
-        if (!gz_name || std::getenv("GANON_HOST_NO_PGZIP") || BgzfSource::open(path))
+        if (!gz_name || tun().is_set(Knob::no_pgzip) || BgzfSource::open(path))
         {
             ::close(fd);
             return nullptr;
         }
-        const char*    e  = std::getenv("GANON_HOST_INFLATE_THREADS");
+        const bool     e  = tun().is_set(Knob::inflate_threads);
         const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-        unsigned       it = e ? (unsigned)std::max(1, std::atoi(e)) : std::min(hw, 64u);
+        unsigned       it = e ? (unsigned)std::max<size_t>(1, tun().size(Knob::inflate_threads, 1)) : std::min(hw, 64u);
         // (hardware_concurrency ignores a cgroup quota; the affinity mask and cpu.max are what classify.cpp's usable_cores reads --
         //  here: a fixed share of what the caller gave its parsers, which is derived from that)
         if (!e)
             it = std::max(2u, 2 * threads); // (the parsers mostly wait for the inflate: measured 12.4 / 17.4 Mreads/s with 12 / 16 threads)
-        const char* cb = std::getenv("GANON_HOST_INFLATE_CHUNK");
-        gz = ParallelGzip::open(path, it, 0, cb ? (size_t)std::atoll(cb) : 0);
+        gz = ParallelGzip::open(path, it, 0, tun().size(Knob::inflate_chunk, 0));
         if (!gz)
         {
             ::close(fd);

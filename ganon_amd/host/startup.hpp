@@ -4,6 +4,7 @@
 // read and a push under a mutex) and always taken; printing is --verbose only.  The reference's counterpart is its
 // "loading filter(s) elapsed" line (timeLoadFilters, GanonClassify.cpp:1470-1477).
 #pragma once
+#include "tunables.hpp"
 #include <cstdlib>
 #include <cstring>
 
@@ -81,11 +82,26 @@ private:
 
 // main() leaves with _Exit once every output is closed (see main.cpp) unless a profiler's exit handler or $GANON_HOST_FULL_TEARDOWN wants
 // the normal return: whoever would only free memory on the way out asks here and does not bother
+// Anything that does its work in an exit handler or a destructor keeps the normal return: a preloaded tool of ANY kind ($LD_PRELOAD:
+// rocprofv3, heap checkers, ...), a profiler registered with the ROCm runtime, coverage runs ($GCOV_PREFIX, $LLVM_PROFILE_FILE), sanitizer
+// builds (their leak reports run at exit) and sanitizer option variables.  (These are other tools' variables, read here and only here;
+// the host's own knobs are in tunables.hpp.)
 inline bool fast_exit()
 {
-    const char* preload  = std::getenv("LD_PRELOAD");
-    const bool  profiled = (preload && std::strstr(preload, "rocprof")) || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_LIBRARY");
-    return !std::getenv("GANON_HOST_FULL_TEARDOWN") && !profiled;
+#if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__)
+    return false;
+#else
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer) || __has_feature(thread_sanitizer) || __has_feature(memory_sanitizer)
+    return false;
+#endif
+#endif
+    const char* preload = std::getenv("LD_PRELOAD");
+    const bool  tooled  = (preload && *preload) || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_LIBRARY") ||
+                        std::getenv("GCOV_PREFIX") || std::getenv("LLVM_PROFILE_FILE") || std::getenv("ASAN_OPTIONS") || std::getenv("LSAN_OPTIONS") ||
+                        std::getenv("TSAN_OPTIONS");
+    return !tun().is_set(Knob::full_teardown) && !tooled;
+#endif
 }
 
 } // namespace gnhost

@@ -1210,7 +1210,7 @@ def test_count_kernel_leaves_unwritten_only_what_the_prepass_would_drop(hip, mon
         assert np.array_equal(res["predrop"][2], res["plain"][2]) and res["predrop"][3:] == res["plain"][3:]
         # ... and it is the reference's rule: every read against _exact_filter_matches on the unfiltered matches
         tot = 0
-        for i in range(0, len(seqs), 7):
+        for i in range(0, len(seqs), 7 if bins < 20000 else 31):   # (32 768 bins: 4 000 chance matches a read through Python lists)
             raw = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
             kept, nf, nq, emx = _exact_filter_matches(raw, nh[i], rel_filter, 1.0, tfpr)
             got = [(int(x["target"]), int(x["count"]) & 0x7FFFFFFF) for x in res["predrop"][1][int(res["predrop"][0][i]):int(res["predrop"][0][i + 1])]]
@@ -1320,7 +1320,7 @@ def test_packed_select_for_uniform_power_of_two_targets(hip, monkeypatch, bins, 
         st2, nh2, status2, mo2, m2 = _classify(hip, flt, reads, None, k, w, cutoff)
         gu.SW.off("uniform_select")
         assert np.array_equal(mo, mo2) and np.array_equal(m, m2), cutoff
-        for i in range(0, len(reads), 5):
+        for i in range(0, len(reads), 5 if bins < 50000 else 13):
             exp_m, _ = gu.oracle_matches(ibf, b2t, n_targets, hs[int(ho[i]):int(ho[i + 1])], cutoff)
             got = [(int(x["target"]), int(x["count"])) for x in m[int(mo[i]):int(mo[i + 1])]]
             assert got == exp_m, (cutoff, i, got[:3], exp_m[:3])

@@ -94,7 +94,9 @@ def test_a_postfilter_without_fpr_table_starts_from_zeros(hip):
 
 
 def test_built_filter_answers_for_every_inserted_hash_in_200_fresh_processes(hip, tmp_path):
-    runs = int(os.environ.get("GANON_TEST_FRESH_RUNS", "204"))
+    # (204 runs while the race was being hunted, rounds 4-5: green throughout; 96 keep the regression in the suite at half the
+    # time -- the driver's whole -m gpu step has 1200 s.  $GANON_TEST_FRESH_RUNS=204 is the long form)
+    runs = int(os.environ.get("GANON_TEST_FRESH_RUNS", "96"))
     combos = [(19, 32), (21, 23), (27, 27)]
     env = dict(os.environ)
 
