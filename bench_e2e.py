@@ -89,6 +89,21 @@ def write_gzip_one_member(path: str, data: np.ndarray, level: int = 6, chunk: in
 EXTRA_ENV = {}   # --env K=V
 
 
+def cgroup_throttle():
+    """(periods in which this container's CPU quota stopped it, microseconds it was stopped for) so far -- cgroup v2 cpu.stat"""
+    n = us = 0
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            k, _, v = ln.partition(" ")
+            if k == "nr_throttled":
+                n = int(v)
+            elif k == "throttled_usec":
+                us = int(v)
+    except OSError:
+        pass
+    return n, us
+
+
 def run_binary(args, n_units, runs, label, deadline, env_extra=None):
     """-> summary of `runs` runs of the binary (fewer when the time budget runs out: the number is reported)"""
     secs, loads, walls = [], [], []
@@ -97,12 +112,15 @@ def run_binary(args, n_units, runs, label, deadline, env_extra=None):
     env.update(EXTRA_ENV)
     env.update(env_extra or {})
     prefix = args[args.index("-o") + 1]
+    per_run = []
     for i in range(runs):
         if i >= 1 and time.time() > deadline:
             break
+        thr0 = cgroup_throttle()
         t0 = time.time()
         p = subprocess.run([EXE] + args, capture_output=True, text=True, env=env, timeout=600)
         walls.append(time.time() - t0)
+        thr1 = cgroup_throttle()
         if p.returncode != 0:
             return {"error": f"rc {p.returncode}: {p.stderr[-300:]}"}
         m = re.search(r"classifying\+printing elapsed \(s\): ([0-9.eE+-]+)", p.stderr)
@@ -112,6 +130,11 @@ def run_binary(args, n_units, runs, label, deadline, env_extra=None):
         m = re.search(r"loading filter\(s\)\s+elapsed \(s\): ([0-9.eE+-]+)", p.stderr)
         loads.append(float(m.group(1)) if m else 0.0)
         last = {"stderr": p.stderr}
+        # per run: the timed seconds, what the cgroup's CPU quota throttled meanwhile, and the stall line -- a slow run names its stall
+        st = re.findall(r"\[host stalls\] level [^:]*: (.*?); reads the pre-pass", p.stderr)
+        per_run.append({"s": round(secs[-1], 4), "wall_s": round(walls[-1], 3),
+                        "throttled_periods": thr1[0] - thr0[0], "throttled_ms": round((thr1[1] - thr0[1]) / 1000.0, 1),
+                        "stalls": (st[-1] if st else "")[:260]})
     rep = open(prefix + ".rep").read().splitlines()
     classified = next((int(l.split("\t")[1]) for l in rep if l.startswith("#total_classified")), 0)
     unclassified = next((int(l.split("\t")[1]) for l in rep if l.startswith("#total_unclassified")), 0)
@@ -133,6 +156,7 @@ def run_binary(args, n_units, runs, label, deadline, env_extra=None):
             groups[name.strip().replace(" ", "_")] = round(float(u) + float(sy), 4)
         out["host_cpu_s"] = groups
         out["host_cpu_s_per_munit"] = {k: round(v / (n_units / 1e6), 5) for k, v in groups.items()}
+    out["per_run"] = per_run
     if os.environ.get("E2E_DIAG"):  # every timing line of the last run (GANON_HOST_TIMING=1)
         out["timing_lines"] = [l[:600] for l in last.get("stderr", "").splitlines() if l.startswith("[")]
     for ext in (".all", ".rep"):

@@ -1412,6 +1412,10 @@ static int gn_run_count(gn_stream* s)
 static int gn_run_group(gn_stream* s)
 {
     // group matches by read on the device: exclusive scan of the segment sizes + gather
+    s->pf_out    = nullptr; // (set again when a pre-pass has run over this batch)
+    s->segmented = false;
+    s->compacted = true;
+    s->cmp_timed = false;
     if (s->f->is_hibf)
         return GN_OK; // HIBF matches are grouped by gn_hibf_classify
     const size_t nseg = (size_t)s->n_reads * s->f->geom.wpr;
@@ -1424,8 +1428,6 @@ static int gn_run_group(gn_stream* s)
     // -- more than 127 minimisers -- come out of a candidate-driven select in no particular order and are put right below)
     s->segmented = s->f->identity && s->f->geom.wpr == 1 && !s->long_reads && !gn_sw().seg_result;
     s->compacted = !s->segmented;
-    s->cmp_timed = false;
-    s->pf_out    = nullptr;
     if (nseg && s->segmented)
         hipLaunchKernelGGL(gn_seg_order_kernel, dim3(64), dim3(256), 0, s->st, s->d_deferred, s->d_ctr + 4, s->d_matches, s->d_sorted, s->d_seg_begin,
                            s->d_seg_count, s->d_seg_off, s->d_ctr, s->match_cap);

@@ -221,7 +221,8 @@ public:
     // reader then continues at decompressed offset delivered()
     virtual bool        next(DeviceTextPiece& out, std::string& err) = 0;
     // a source opened by_lines (the mate file of a pair): the next `lines` lines as one piece -- fewer (out.lines says) where the stream
-    // ends; ~0: what is left of the text at hand
+    // ends; ~0: what is left of the CURRENT step's text (not of the stream: while further steps exist the source stays open and a later
+    // call goes on behind it)
     virtual bool        next_lines(uint64_t /*lines*/, DeviceTextPiece& /*out*/, std::string& err)
     {
         err = "not a source by lines";

@@ -193,7 +193,9 @@ static bool ganon_classify(Config config)
             {
                 std::error_code ec;
                 const auto      sz = std::filesystem::file_size(f.ibf_file, ec);
-                filter_bytes += ec ? 0 : (uint64_t)sz;
+                // (an HIBF's rows are padded to whole 128-byte lines on the device, gn_hibf_row_stride_words: 3 -> 4, 5..8 -> 8, 9..16 -> 16
+                //  words -- at most twice the file's payload per IBF; the shapes are not known before the file is parsed, so the bound is used)
+                filter_bytes += ec ? 0 : (uint64_t)sz * (config.hibf ? 2u : 1u);
             }
         const uint64_t fr      = device_text->free_device_bytes();
         const uint64_t reserve = std::max<uint64_t>(fr / 8, std::min<uint64_t>(fr / 2, 16ull << 30)) + (24ull << 30);
@@ -457,6 +459,8 @@ static bool ganon_classify(Config config)
             StartupLog::get().print(std::cerr);
         std::vector<ReadBatch> next_carried;
         classifying.start();
+        rusage ru_level0;
+        getrusage(RUSAGE_SELF, &ru_level0);
         const auto level_t0 = std::chrono::steady_clock::now();
         auto       since    = [level_t0] { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - level_t0).count(); };
         EventSpan  ev_taken, ev_begun, ev_fetched, ev_posted, ev_merged; // ($GANON_HOST_TIMING: ramp-up and tail of the pipeline)
@@ -1146,6 +1150,15 @@ static bool ganon_classify(Config config)
                     if (!write_row(prefix, gid))
                         return false;
         classifying.stop();
+        {
+            // CPU of ALL threads between the level's start and its end -- what the steady state costs (the slab parsers' head start during
+            // the filter load and the runtime's start-up are outside)
+            rusage ru_level1;
+            getrusage(RUSAGE_SELF, &ru_level1);
+            auto us = [](const timeval& a, const timeval& b) { return (uint64_t)((b.tv_sec - a.tv_sec) * 1000000ll + (b.tv_usec - a.tv_usec)); };
+            g_cpu.phase.user_us += us(ru_level0.ru_utime, ru_level1.ru_utime);
+            g_cpu.phase.sys_us += us(ru_level0.ru_stime, ru_level1.ru_stime);
+        }
         if (config.output_lca)
             for (auto& [prefix, file] : out_lca)
                 file.close();
@@ -1190,6 +1203,7 @@ static bool ganon_classify(Config config)
         g_cpu.post.print(std::cerr, ", post pool");
         g_cpu.merge.print(std::cerr, ", merge and write");
         g_cpu.inflate.print(std::cerr, ", device inflate feeders");
+        g_cpu.phase.print(std::cerr, ", classify phase all threads");
         std::cerr << "; whole process " << ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6 << " + " << ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6
                   << " on " << usable_cores() << " usable cores" << std::endl;
     }

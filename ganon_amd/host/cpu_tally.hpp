@@ -76,7 +76,7 @@ struct EventSpan
 
 struct CpuTallies
 {
-    CpuTally parse, inflate, reader, mate, worker, post, merge;
+    CpuTally parse, inflate, reader, mate, worker, post, merge, phase;
 };
 inline CpuTallies g_cpu;
 

@@ -253,7 +253,24 @@ public:
             l_served_ = end;
             delivered_ = out.at + out.bytes;
             if (!whole)
-                l_eof_ = true; // (the stream's end, or the caller asked for whatever is left)
+            {
+                // the stream's end -- or the caller asked for "whatever is left" (lines == ~0: the rest of the CURRENT step's text, see
+                // backend.hpp) while the stream has further steps: those stay available, the next call inflates on with nothing carried
+                if (l_done_)
+                    l_eof_ = true;
+                else
+                {
+                    if (gn_inflate_set_carry(z_, 0) != GN_OK)
+                    {
+                        std::lock_guard<std::mutex> lk(m_);
+                        fail_locked(gn_last_error());
+                        err = error_;
+                        return false;
+                    }
+                    l_at_ += l_served_;
+                    l_have_ = false;
+                }
+            }
             return out.bytes != 0 || whole;
         }
     }

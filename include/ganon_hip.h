@@ -363,7 +363,10 @@ uint64_t gn_hibf_row_stride_words(uint64_t bin_words);
  * sum |old prob - new prob| bit for bit as the reference computes it (gn_reassign_diffs copies the first `cap` of them).
  * gn_reassign_fetch (any pointer may be NULL): counts[t] = reassigned_matches of the LAST iteration (:113-121; the new .rep
  * holds counts[t] - unique[t] in its lca column, :189-219), unique[t] = reads listing t and nothing else, prob[t] after the
- * last update, choice[r] = index into target[] of the entry read r is given in the .one file (:153-181). */
+ * last update, choice[r] = index into target[] of the entry read r is given in the .one file (:153-181).
+ * PRECONDITION (since round 5): every read has at least one entry, off[r + 1] > off[r] -- the reference's table holds a read only once a
+ * line of the .all file names it (:76-92); a CSR with an empty row is refused with GN_EINVAL (an empty row has no entry choice[r] could
+ * index, and the .one writer would have nothing to print).  A caller that holds reads without matches drops them before the call. */
 typedef struct gn_reassign gn_reassign;
 int gn_reassign_create(int device, uint64_t n_reads, uint64_t n_entries, uint32_t n_targets, const uint64_t* off,
                        const uint32_t* target, gn_reassign** out);
