@@ -1890,8 +1890,11 @@ extern "C" int gn_stream_device_matches(gn_stream* s, const gn_match** d_matches
     int rc = gn_finish(s);
     if (rc)
         return rc;
+    const bool was_compact = s->compacted || s->pf_out;
     if ((rc = gn_result_compact(s)) != GN_OK)
         return rc;
+    if (!was_compact) // (the caller reads the buffer on a stream of its own: the copy queued just now has to be through)
+        GN_HIP(hipStreamSynchronize(s->st));
     *d_matches = gn_result_matches(s);
     *n_matches = s->n_matches;
     return GN_OK;

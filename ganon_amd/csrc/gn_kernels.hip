@@ -1018,6 +1018,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
 }
 
 // build-time tuning knobs of the fast kernel (defaults = what was measured best on MI355X)
+#define GN_FAST_LIST 512u // matches of a unit the fast kernel's epilogue lists in LDS before it writes them out (2 KiB a wave)
 #ifndef GN_FAST_WPE_LW1
 #define GN_FAST_WPE_LW1 4 // waves per SIMD the register allocator must reach, 8-byte lanes
 #endif
@@ -1059,6 +1060,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
     const uint32_t gl    = lane & (Gp - 1);
     const uint32_t hsub  = lane >> p.gp_log2;
     uint32_t*      rowtab = gn_lds + (size_t)wave * 128 * HFP;
+    uint32_t*      mlist  = gn_lds + (size_t)(blockDim.x >> 6) * 128 * HFP + (size_t)wave * GN_FAST_LIST; // the epilogue's match list (low cutoffs)
 
     // Persistent waves: unit = (read, column slice), handed out in chunks (below).  The metadata of the NEXT unit
     // (status, n, hash slot) is loaded at the top of the current one and its hashes right after the current
@@ -1639,12 +1641,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         const bool fits = base + total <= p.match_cap;
         if (__popcll(hm) > 6)
         {
-            // many lanes report (low cutoffs): the lane's count bytes go through the wave's row table, which is idle during
-            // the epilogue, 32 bins (8 dwords) at a time, and the hit bits are walked in ascending order -- one short loop
-            // per dword instead of sixteen nested ones, and the count of a bin is one ds_read_u8
-            gn_match*      out = p.matches + base + my_off;
-            uint32_t       k   = 0;
-            const uint8_t* tabb = reinterpret_cast<const uint8_t*>(rowtab);
+            // Many lanes report (low cutoffs: ~100 chance matches a read at --rel-cutoff 0.2 on 4096 bins).  Up to round 5 every lane
+            // stored its own matches straight to the segment: a store instruction then carried 64 twelve-byte records at 64 unrelated
+            // offsets, and the address unit of the CU -- which the row loads of the other waves share -- took them one line at a time
+            // (78.7 M such instructions per 10 M reads: the kernel ran 11 ms over its every-row time, profiles/r06_cutoff_counters).
+            // Now the lanes put their matches, in segment order, into a list in LDS (bin in the unit << 8 | count; the lane's count bytes
+            // go through the wave's row table, idle during the epilogue, 32 bins at a time as before) and the wave writes the list out
+            // with lane i holding record i: whole lines per store.  Lists longer than GN_FAST_LIST (an eighth of the bins and more:
+            // cutoffs near zero) keep the direct stores.
+            const uint8_t* tabb   = reinterpret_cast<const uint8_t*>(rowtab);
+            const bool     listed = total <= GN_FAST_LIST;
+            gn_match*      out    = p.matches + base + my_off;
+            uint32_t       k      = 0;
 #pragma unroll
             for (int d = 0; d < ND; ++d)
             {
@@ -1663,14 +1671,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                 {
                     const uint32_t b = (uint32_t)__builtin_ctz(mbits);
                     mbits &= mbits - 1;
-                    gn_match mt;
-                    mt.read   = read;
-                    mt.target = wi * 64 + 32 * d + b; // bit b = 8y + 4pp + j of dword d is byte y of byt[d][j][pp]
-                    mt.count  = tabb[(uint32_t)lane * 32u + (((b & 3u) << 1) + ((b >> 2) & 1u)) * 4u + (b >> 3)];
-                    out[k++]  = mt;
+                    // bit b = 8y + 4pp + j of dword d is byte y of byt[d][j][pp]
+                    const uint32_t cnt = tabb[(uint32_t)lane * 32u + (((b & 3u) << 1) + ((b >> 2) & 1u)) * 4u + (b >> 3)];
+                    const uint32_t bin = (uint32_t)(gl * LW) * 64u + 32u * (uint32_t)d + b; // bin inside the unit's column slice
+                    if (listed)
+                        mlist[my_off + k] = (bin << 8) | cnt;
+                    else
+                    {
+                        gn_match mt;
+                        mt.read   = read;
+                        mt.target = slice * 64u * LW * 64u + bin;
+                        mt.count  = cnt;
+                        out[k]    = mt;
+                    }
+                    ++k;
                 }
             }
-            gn_wave_lds_sync(); // the next unit refills the row table
+            gn_wave_lds_sync(); // the list is complete; the next unit refills the row table
+            if (listed && fits)
+            {
+                gn_match* seg = p.matches + base;
+                for (uint32_t m = (uint32_t)lane; m < total; m += GN_WAVE)
+                {
+                    const uint32_t e = mlist[m];
+                    gn_match       mt;
+                    mt.read   = read;
+                    mt.target = slice * 64u * LW * 64u + (e >> 8);
+                    mt.count  = e & 0xFFu;
+                    seg[m]    = mt;
+                }
+                gn_wave_lds_sync(); // (the next unit's list must not overtake these reads)
+            }
         }
         else if (fits && owner && any)
         {
@@ -1745,7 +1776,7 @@ static hipError_t gn_launch_fast_one(const GnCountParams& p, hipStream_t st)
     uint32_t       blocks = (uint32_t)((units + 3) / 4);
     if (blocks > p.max_blocks_fast)
         blocks = p.max_blocks_fast;
-    const size_t   lds    = 4 * 128 * (HF <= 4 ? 4 : 8) * 4;
+    const size_t   lds    = 4 * (128 * (HF <= 4 ? 4 : 8) + GN_FAST_LIST) * 4; // per wave: the row table + the epilogue's match list
     if (ee && LW == 2 && p.W > 128)
         hipLaunchKernelGGL((gn_ibf_count_fast_kernel<HF, LW, true, LW == 2>), dim3(blocks), dim3(256), lds, st, p);
     else if (ee)

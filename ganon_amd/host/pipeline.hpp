@@ -235,6 +235,10 @@ extern DeviceGate g_devices_ready;
 // appends the mates-2 region behind the mates-1 region and rebases its offsets (the reader's pairs; the post stage's carried reads)
 void finalize_batch(ReadBatch& rb, ByteBuf& bases2);
 
+// distinct GPUs of the run (set by ganon_classify before the reader starts): the reader sizes its helper threads by it -- one link takes
+// what ~8 slab readers copy out of the page cache (5 GB/s each, scripts/host_ceiling.py), and what fed one GPU does not feed eight
+extern std::atomic<unsigned> g_distinct_devices;
+
 // the reader thread (reader.cpp)
 void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq, Backend* device_text,
                  bool further_levels);

@@ -309,6 +309,7 @@ void Cleanups::join_all()
 
 
 DeviceGate g_devices_ready;
+std::atomic<unsigned> g_distinct_devices{ 1 };
 
 void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex, const ReadPlan& plan, bool raw_fastq, Backend* device_text,
                  bool further_levels)
@@ -317,7 +318,11 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
     MateCopier     copier(queue, (unsigned)tun().size(Knob::mate_threads, 3));
     // slab parsers: half of the cores this process may use, between 4 and 12 (the other half: reader, mate copier, device
     // workers, post pool); 8 on the 16-core quota of the boxes the numbers in DESIGN.md come from
-    const unsigned par_threads = (unsigned)tun().size(Knob::parse_threads, std::min(12u, std::max(4u, usable_cores() / 2)));
+    // ... per GPU: a node's worth of GPUs gets a node's worth of readers, within half of the usable cores (round 5 stopped at 12 parsers / 6
+    // raw-slab readers whatever the node: ~130 Mreads/s of plain FASTQ for ANY number of GPUs, profiles/r06_host_ceiling_48m.json)
+    const unsigned n_dev       = std::max(1u, g_distinct_devices.load());
+    const unsigned par_threads = (unsigned)tun().size(Knob::parse_threads, std::min(12u * n_dev, std::max(4u, usable_cores() / 2)));
+    const unsigned raw_threads = std::min(par_threads, 6u * n_dev);
     const size_t   slab_bytes  = tun().size(Knob::slab_bytes, 48u << 20);
     const size_t   par_min     = tun().size(Knob::parallel_min, 32u << 20);
     for (auto const& [prefix, files] : plan)
@@ -529,7 +534,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             // ---- raw pieces: the backend finds the records (single-end, uncompressed four-line FASTQ) ------------------------
             if (raw_fastq && !paired && !file_done && !fallback)
             {
-                if (auto pfr = ParallelFastq::open(pair.mate1, std::min(par_threads, 6u), slab_bytes, par_min, false, true))
+                if (auto pfr = ParallelFastq::open(pair.mate1, raw_threads, slab_bytes, par_min, false, true))
                 {
                     auto                tracker = std::make_shared<RawFileTracker>();
                     size_t              pieces  = 0;
@@ -598,7 +603,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                                    && (force ? !tun().off(Knob::pair_text) : (::stat(pair.mate1.c_str(), &st1) == 0 && (uint64_t)st1.st_size >= (4ull << 30)));
             if (pair_text)
             {
-                auto pfr = ParallelFastq::open(pair.mate1, std::min(par_threads, 6u), std::max<size_t>(slab_bytes / 2, 1 << 16), par_min, false, true);
+                auto pfr = ParallelFastq::open(pair.mate1, raw_threads, std::max<size_t>(slab_bytes / 2, 1 << 16), par_min, false, true);
                 std::shared_ptr<LineIndex> idx2(pfr ? LineIndex::open(pair.mate2, 3, 0).release() : nullptr);
                 if (pfr && idx2)
                 {
