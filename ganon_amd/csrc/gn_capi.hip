@@ -70,6 +70,8 @@ static int gn_parse_switches(const char* list, GnSwitches* out, char* bad, size_
                 sw.*(f.flag) = true, known = true;
         if (!known && n > 6 && !strncmp(p, "chunk=", 6))
             sw.chunk = (uint32_t)strtoul(p + 6, nullptr, 10), known = true;
+        if (!known && n > 11 && !strncmp(p, "emit_probe=", 11))
+            sw.emit_probe = (uint32_t)strtoul(p + 11, nullptr, 10) & (64u | 128u), known = true;
         if (!known && n > 9 && !strncmp(p, "hibf_bpc=", 9))
             sw.hibf_bpc = (uint32_t)strtoul(p + 9, nullptr, 10), known = true;
         if (!known && n > 16 && !strncmp(p, "hibf_pair_limit=", 16))
@@ -1329,7 +1331,7 @@ static int gn_run_count_range(gn_stream* s, uint32_t lo, uint32_t hi)
     p.max_blocks = (uint32_t)f->n_cu * 16u;
     // persistent grid = a whole number of resident rounds: 8-byte-lane variant holds 4 blocks per CU, 16-byte one 3
     p.max_blocks_fast = (uint32_t)f->n_cu * (f->geom.lw == 1 ? 8u : 6u);
-    p.nt_loads = 0u;
+    p.nt_loads = gn_sw().emit_probe; // (0 in the product; bits 6 / 7: the emission probe of the fast kernel's low-cutoff epilogue)
     p.early_exit = gn_sw().early_exit ? 0u : 1u; // (bench.py's every-row measurement and the parity tests of the exit)
     p.skip_ctr   = s->d_ctr + 7;
     if (lo == 0) // (a re-run after a match-buffer regrow starts the tally again)

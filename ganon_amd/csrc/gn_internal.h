@@ -64,6 +64,7 @@ struct GnSwitches
     bool     pinned_malloc = false; // gn_pinned_alloc: hipHostMalloc as up to round 4 (no huge-page mapping + hipHostRegister)
     bool     debug = false;       // chatter on stderr
     // host-ceiling measurement
+    uint32_t emit_probe = 0;      // MEASUREMENT ONLY (wrong results): fast kernel at low cutoffs -- 64: the listed matches are not stored, 128: nor listed
     bool     fake_count = false;  // MEASUREMENT ONLY (wrong results): upload, record index and minimisers run, the count + select kernels do not; every
                                   // second read of a flat IBF gets one made-up match (read % targets, its number of minimisers) -- the device
                                   // step costs next to nothing and what is left is what the host's reader, workers and post stage sustain

@@ -1651,6 +1651,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
             // cutoffs near zero) keep the direct stores.
             const uint8_t* tabb   = reinterpret_cast<const uint8_t*>(rowtab);
             const bool     listed = total <= GN_FAST_LIST;
+            if (p.nt_loads & 128u) // (emit_probe: what the epilogue costs without listing or storing anything)
+                goto emitted;
             gn_match*      out    = p.matches + base + my_off;
             uint32_t       k      = 0;
 #pragma unroll
@@ -1688,7 +1690,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                 }
             }
             gn_wave_lds_sync(); // the list is complete; the next unit refills the row table
-            if (listed && fits)
+            if (listed && fits && !(p.nt_loads & 64u))
             {
                 gn_match* seg = p.matches + base;
                 for (uint32_t m = (uint32_t)lane; m < total; m += GN_WAVE)
@@ -1698,7 +1700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
                     mt.read   = read;
                     mt.target = slice * 64u * LW * 64u + (e >> 8);
                     mt.count  = e & 0xFFu;
-                    seg[m]    = mt;
+                    seg[m] = mt;
                 }
                 gn_wave_lds_sync(); // (the next unit's list must not overtake these reads)
             }
@@ -1734,6 +1736,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
             }
         }
     }
+emitted:
     if (lane == 0)
     {
         p.seg_begin[(size_t)read * wpr + slice] = base;
