@@ -2199,6 +2199,13 @@ struct gn_inflate
     uint32_t  cut_tiles_cap = 0, cuts_cap = 0;
     uint64_t  lines_of_step = ~0ull; // the step whose text the line index in d_cut_cnt describes
     bool      ended = false;
+    // Several inflaters of the SAME file on different devices take its steps in turn (gn_inflate_set_turns / gn_inflate_handoff): the
+    // decode of a step -- nine tenths of the work -- depends on nothing before it; what the next step needs of this one is the stream
+    // position, the member's length and CRC so far, the 32 KiB window and the text the step's end cut off (the carried record).
+    uint32_t  turns = 1, turn = 0;
+    uint8_t*  d_carry_in = nullptr; // the carried text, when it came from another inflater
+    uint64_t  carry_in_cap = 0;
+    bool      carry_in = false;
     // totals
     gn_inflate_stats stats{};
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -2212,7 +2219,8 @@ static void gi_free(gn_inflate* z)
     hipDeviceSynchronize();
     for (void* p : { (void*)z->d_comp, (void*)z->d_chunks_set[0], (void*)z->d_pool_set[0], (void*)z->d_ctr_set[0], (void*)z->d_chunks_set[1], (void*)z->d_pool_set[1], (void*)z->d_ctr_set[1],
                      (void*)z->d_chunks_set[2], (void*)z->d_pool_set[2], (void*)z->d_ctr_set[2], (void*)z->d_state, (void*)z->d_window, (void*)z->d_p_store, (void*)z->d_g_store, (void*)z->d_w_store,
-                     (void*)z->d_real, (void*)z->d_work, (void*)z->d_mlist_pos, (void*)z->d_mlist_crc, (void*)z->d_cut_cnt, z->d_cut_tmp, (void*)z->d_cuts, (void*)z->d_text[0], (void*)z->d_text[1] })
+                     (void*)z->d_real, (void*)z->d_work, (void*)z->d_mlist_pos, (void*)z->d_mlist_crc, (void*)z->d_cut_cnt, z->d_cut_tmp, (void*)z->d_cuts, (void*)z->d_text[0], (void*)z->d_text[1],
+                     (void*)z->d_carry_in })
         if (p)
             hipFree(p);
     if (z->h_state)
@@ -2392,7 +2400,8 @@ static int gi_start_decode(gn_inflate* z, bool must, uint32_t from, int set)
     }
     // the first step is half a step: as many chunks as the device holds waves of this kernel (a chunk takes its six milliseconds whatever
     // runs beside it, so fewer chunks would not bring the first text any sooner), and the caller's pipeline gets text after a sixth of a gigabyte
-    const uint32_t ramp = z->launches == 0 ? std::max<uint32_t>(64u, z->slots_cap / 2u) : z->slots_cap;
+    // (of several inflaters taking turns only the first one's first step is the file's first)
+    const uint32_t ramp = z->launches == 0 && z->turn == 0 ? std::max<uint32_t>(64u, z->slots_cap / 2u) : z->slots_cap;
     j1 = std::min<uint32_t>(j1, from + ramp);
     if (j1 <= from)
     {
@@ -2455,7 +2464,9 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
     auto launch_ahead = [&]() {
         while (!gn_sw().inflate_ahead)
         {
-            const uint32_t from = z->nq ? z->q[z->nq - 1].j1 : (z->ahead_from_next ? z->next_chunk : A.j1);
+            // (taking turns: this inflater's next step begins behind the other inflaters' steps -- a full range each, as far as one can tell
+            //  now; gn_inflate_handoff drops what was decoded from a wrong guess)
+            const uint32_t from = (z->nq ? z->q[z->nq - 1].j1 : (z->ahead_from_next ? z->next_chunk : A.j1)) + (z->turns - 1u) * z->slots_cap;
             const int      k    = free_set(z->set_in_use);
             const int      had  = z->nq;
             if (from >= z->n_chunks_file || k < 0 || gi_start_decode(z, false, from, k) != GN_OK || z->nq == had)
@@ -2512,7 +2523,7 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         return gn_fail(GN_ERANGE, "gn_inflate_step: the data expands beyond what a step holds (more than 8-fold, or a chunk beyond 2 Mi symbols)");
     // where the next step begins is known now: its decode starts beside this step's remaining passes
     z->next_chunk = s.reason == GI_R_INPUT ? j0 + std::min<uint32_t>(s.cursor, n) : j1;
-    if (z->nq && z->q[0].j0 != z->next_chunk) // the decodes that ran ahead assumed another start: dropped (their sets are free again when they are through)
+    if (z->turns == 1 && z->nq && z->q[0].j0 != z->next_chunk) // the decodes that ran ahead assumed another start: dropped (their sets are free again when they are through)
         z->nq = 0;
     z->ahead_from_next = true;
     if (s.n_real)
@@ -2524,7 +2535,8 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
         GN_HIP(hipGetLastError());
     }
     if (carry)
-        GN_HIP(hipMemcpyAsync(z->d_text[buf], z->d_text[z->cur] + (z->n_text_last - carry), carry, hipMemcpyDeviceToDevice, z->st));
+        GN_HIP(hipMemcpyAsync(z->d_text[buf], z->carry_in ? z->d_carry_in : z->d_text[z->cur] + (z->n_text_last - carry), carry, hipMemcpyDeviceToDevice, z->st));
+    z->carry_in = false;
     if (s.n_work)
     {
         hipLaunchKernelGGL(gi_resolve_kernel, dim3(std::min<uint32_t>(s.n_work, (uint32_t)z->n_cu * 2u)), dim3(512), 0, z->st, z->d_state, z->d_chunks, z->d_real,
@@ -2593,6 +2605,60 @@ extern "C" int gn_inflate_step(gn_inflate* z, uint64_t* n_text, int* done)
             return gn_fail(GN_ERANGE, "gn_inflate_step: truncated gzip stream");
         // (the stream stands before the file's end with every chunk consumed: handled above as a gap)
     }
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_set_turns(gn_inflate* z, uint32_t n_turns, uint32_t my_turn)
+{
+    if (!z || n_turns == 0 || my_turn >= n_turns)
+        return gn_fail(GN_EINVAL, "gn_inflate_set_turns: need my_turn < n_turns");
+    if (z->stats.steps || z->launches)
+        return gn_fail(GN_EINVAL, "gn_inflate_set_turns: the inflater has begun");
+    z->turns = n_turns;
+    z->turn  = my_turn;
+    return GN_OK;
+}
+
+extern "C" int gn_inflate_handoff(gn_inflate* from, gn_inflate* to)
+{
+    if (!from || !to || from == to)
+        return gn_fail(GN_EINVAL, "gn_inflate_handoff: two inflaters, please");
+    if (from->total != to->total || from->chunk_bytes != to->chunk_bytes || from->slots_cap != to->slots_cap)
+        return gn_fail(GN_EINVAL, "gn_inflate_handoff: the inflaters were not created for the same file with the same chunk and step sizes");
+    to->ended = from->ended;
+    if (from->ended)
+        return GN_OK;
+    // (the step of `from` is through: gn_inflate_step returns after its stream's last pass)
+    to->h_state->pos_bit = from->h_state->pos_bit;
+    to->h_state->run_len = from->h_state->run_len;
+    to->crc_carry        = from->crc_carry;
+    to->next_chunk       = from->next_chunk;
+    GN_HIP(hipSetDevice(to->device));
+    GN_HIP(hipMemcpyPeer(to->d_window, to->device, from->d_window, from->device, GI_WINDOW));
+    const uint64_t c = from->carry;
+    if (c)
+    {
+        if (c > to->text_cap / 4u)
+            return gn_fail(GN_EINVAL, "gn_inflate_handoff: %llu carried bytes are more than a quarter of a step's capacity", (unsigned long long)c);
+        if (to->carry_in_cap < c)
+        {
+            if (to->d_carry_in)
+                hipFree(to->d_carry_in);
+            to->d_carry_in   = nullptr;
+            to->carry_in_cap = 0;
+            const uint64_t cap = std::max<uint64_t>(c + c / 2u, 1u << 20);
+            if (hipMalloc((void**)&to->d_carry_in, cap) != hipSuccess)
+                return gn_fail(GN_ENOMEM, "gn_inflate_handoff: no room for %llu carried bytes", (unsigned long long)c);
+            to->carry_in_cap = cap;
+        }
+        GN_HIP(hipMemcpyPeer(to->d_carry_in, to->device, from->d_text[from->cur] + (from->n_text_last - c), from->device, c));
+    }
+    to->carry    = c;
+    to->carry_in = c != 0;
+    from->carry  = 0; // (its next step's carry comes from the inflater before it)
+    // what `to` decoded ahead for this step assumed a start: kept only if that is where the stream stands
+    if (to->nq && to->q[0].j0 != to->next_chunk)
+        to->nq = 0;
     return GN_OK;
 }
 

@@ -31,7 +31,7 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_inflate_create", "gn_inflate_destroy", "gn_inflate_feed", "gn_inflate_step", "gn_inflate_text", "gn_inflate_text_device",
                "gn_inflate_get_stats", "gn_inflate_cuts", "gn_inflate_set_carry", "gn_stream_upload_text_device", "gn_stream_fastq_headers",
                "gn_inflate_cuts_lines", "gn_inflate_cut_at_lines", "gn_stream_upload_text_pair_device", "gn_stream_fetch_letters",
-               "gn_ibf_hash_constants"]
+               "gn_ibf_hash_constants", "gn_inflate_set_turns", "gn_inflate_handoff"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -173,6 +173,8 @@ def load_library():
     L.gn_stream_hibf_level_lines.argtypes = [vp, vp, u32]
     L.gn_device_memory.argtypes = [i32, C.POINTER(u64), C.POINTER(u64)]
     L.gn_ibf_hash_constants.argtypes = [vp, C.POINTER(u64)]
+    L.gn_inflate_set_turns.argtypes = [vp, u32, u32]
+    L.gn_inflate_handoff.argtypes = [vp, vp]
     L.gn_hibf_row_stride_words.argtypes = [u64]
     L.gn_hibf_row_stride_words.restype = u64
     L.gn_peer_stats.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(u64)]
@@ -326,6 +328,14 @@ class HipInflate:
 
     def set_carry(self, n_tail: int) -> None:
         _check(self._L.gn_inflate_set_carry(self._h, n_tail))
+
+    def set_turns(self, n_turns: int, my_turn: int) -> None:
+        """gn_inflate_set_turns: this inflater runs steps my_turn, my_turn + n_turns, ... of a file that n_turns inflaters share"""
+        _check(self._L.gn_inflate_set_turns(self._h, n_turns, my_turn))
+
+    def handoff(self, to: "HipInflate") -> None:
+        """gn_inflate_handoff: what the next step needs of the one this inflater just ran goes to `to` (device to device)"""
+        _check(self._L.gn_inflate_handoff(self._h, to._h))
 
     def stats(self) -> dict:
         st = InflateStats()

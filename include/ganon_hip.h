@@ -464,6 +464,18 @@ int gn_inflate_cuts(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_byt
 int gn_inflate_cuts_lines(gn_inflate* z, uint32_t lines_per_record, uint64_t piece_bytes, uint64_t* cuts, uint64_t* cut_lines, uint32_t cap, uint32_t* n_cuts);
 int gn_inflate_cut_at_lines(gn_inflate* z, const uint64_t* lines, uint32_t n_lines, uint64_t* offsets, uint64_t* total_lines);
 int gn_inflate_set_carry(gn_inflate* z, uint64_t n_tail);
+/* One file, several devices.  A step's decode depends on nothing before it; the pieces that put a step's text together need four things
+ * of the step before: the stream's bit position, the open member's length and CRC-32 so far, the 32 KiB window, and the text the step's
+ * end cut off.  So N inflaters created for the SAME file (same sizes), each fed the whole file, can take its steps in turn:
+ *   gn_inflate_set_turns(z_i, N, i)   before the first step: z_i will run steps i, i + N, ... (sizes its decodes-ahead by that; only
+ *                                      turn 0's first step is the file's short first step)
+ *   gn_inflate_handoff(from, to)      after gn_inflate_step(from) [+ gn_inflate_cuts / gn_inflate_set_carry(from)], before
+ *                                      gn_inflate_step(to): copies those four things device to device (32 KiB + the carried record)
+ * The text of step k then lies on device k mod N -- where the worker of that device classifies it without a peer copy.  With one
+ * inflater the file is bound by that device's decode rate (31-37 GB/s of text); with N by the serial passes (order, windows, resolve,
+ * CRC: ~7 ms per 0.9 GB of text).  The reference reads a .gz through one zlib stream (GanonClassify.cpp:1220-1287,1433). */
+int gn_inflate_set_turns(gn_inflate* z, uint32_t n_turns, uint32_t my_turn);
+int gn_inflate_handoff(gn_inflate* from, gn_inflate* to);
 
 #ifdef __cplusplus
 }

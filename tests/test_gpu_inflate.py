@@ -315,3 +315,73 @@ def test_many_small_members_and_a_wrong_crc_among_them():
     bad[at] ^= 0x10
     with pytest.raises(hip.GanonHipError):
         _inflate(bytes(bad), chunk=4096)
+
+
+def _inflate_in_turns(gz, n_turns, chunk, step, lines_per_record=0, piece=100_000):
+    """N inflaters of the same file take its steps in turn (gn_inflate_set_turns / gn_inflate_handoff) -- here all on the one GPU of the
+    box; on a node each sits on its own device and the text of step k lies where worker k mod N classifies it.  lines_per_record != 0:
+    the caller cuts at record boundaries and carries the record a step's end cuts, as devgzip.cpp does."""
+    data = np.frombuffer(gz, dtype=np.uint8)
+    zs = [hip.HipInflate(data.size, chunk_bytes=chunk, step_bytes=step) for _ in range(n_turns)]
+    try:
+        for i, z in enumerate(zs):
+            z.set_turns(n_turns, i)
+            z.feed(data)
+        out, k, done, steps_of = [], 0, False, [0] * n_turns
+        while not done:
+            z = zs[k % n_turns]
+            n, done = z.step()
+            steps_of[k % n_turns] += 1
+            text = z.text(n) if n else np.zeros(0, np.uint8)
+            if lines_per_record and not done:
+                cuts = z.cuts(lines_per_record, piece) if n else np.zeros(0, np.uint64)
+                last = int(cuts[-1]) if cuts.size else 0
+                out.append(text[:last].tobytes())
+                z.set_carry(n - last)
+            else:
+                out.append(text.tobytes())
+            if not done:
+                z.handoff(zs[(k + 1) % n_turns])
+            k += 1
+        return b"".join(out), steps_of, [z.stats() for z in zs]
+    finally:
+        for z in zs:
+            z.close()
+
+
+@pytest.mark.parametrize("n_turns", [2, 3])
+@pytest.mark.parametrize("level,chunk,step,lpr", [(6, 4096, 262144, 0), (6, 4096, 262144, 4), (1, 1024, 65536, 4), (9, 0, 1 << 20, 4)])
+def test_steps_taken_in_turns_by_several_inflaters_give_zlibs_bytes(n_turns, level, chunk, step, lpr):
+    text = TEXT * 6
+    gz = _gz(text, level)
+    got, steps_of, stats = _inflate_in_turns(gz, n_turns, chunk, step, lpr)
+    assert got == text
+    assert min(steps_of) >= 2 and max(steps_of) - min(steps_of) <= 1   # really in turns
+    assert sum(s["text_bytes"] for s in stats) == len(text) and all(s["text_bytes"] > 0 for s in stats)
+    assert sum(s["markers"] for s in stats) > 0                         # back-references crossed chunks and steps (one member)
+
+
+def test_turns_with_many_members_blocked_gzip_and_a_crc_that_crosses_steps():
+    parts = [TEXT[i:i + 50_000] for i in range(0, len(TEXT), 50_000)]
+    gz = b"".join(gzip.compress(t, 6) for t in parts) * 2          # members end inside steps: the open member's CRC is handed on
+    got, steps_of, stats = _inflate_in_turns(gz, 2, 4096, 131072, 4)
+    assert got == TEXT * 2 and sum(s["members"] for s in stats) == 2 * len(parts)
+    got, _, stats = _inflate_in_turns(_bgzf(TEXT * 3), 3, 4096, 262144)
+    assert got == TEXT * 3 and sum(s["markers"] for s in stats) == 0
+    bad = bytearray(gz)
+    bad[len(gz) - 8] ^= 0x01                                           # the last member's CRC-32
+    with pytest.raises(hip.GanonHipError):
+        _inflate_in_turns(bytes(bad), 2, 4096, 131072, 4)
+
+
+def test_handoff_refuses_inflaters_of_different_files_and_late_turns():
+    gz = np.frombuffer(_gz(TEXT, 6), dtype=np.uint8)
+    with hip.HipInflate(gz.size, chunk_bytes=4096, step_bytes=262144) as a, hip.HipInflate(gz.size + 8, chunk_bytes=4096, step_bytes=262144) as b:
+        with pytest.raises(hip.GanonHipError):
+            a.handoff(b)
+        with pytest.raises(hip.GanonHipError):
+            a.set_turns(2, 2)
+        a.feed(gz)
+        a.step()
+        with pytest.raises(hip.GanonHipError):
+            a.set_turns(2, 0)
