@@ -237,7 +237,9 @@ public:
 };
 
 // devgzip.cpp (binaries linked with libganon_hip.so only): nullptr when the file is not one for the device inflater
-std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, int device, size_t piece_bytes, size_t min_bytes, bool by_lines);
+// `devices`: where the file's steps are inflated in turn (gn_inflate_set_turns): the text of step k lies on devices[k mod n], next to the
+// worker that classifies it; a source opened by_lines (a mate file) stays on devices[0]
+std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, const std::vector<int>& devices, size_t piece_bytes, size_t min_bytes, bool by_lines);
 
 // One device (or the test checker): receives filters, classifies batches.  Not thread-safe; one host thread each.
 class Backend : public FilterSink
@@ -255,7 +257,9 @@ public:
     // gzip, blocked gzip, too small, no room) or not a backend that does it.  piece_bytes = text per piece, about.
     // Optional.  Free memory of the device open_gzip_text would use, now (0: not a backend with device memory).
     virtual uint64_t free_device_bytes() const { return 0; }
-    virtual std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& /*path*/, size_t /*piece_bytes*/, size_t /*min_bytes*/, bool /*by_lines*/ = false)
+    // one_device: the text must lie on this backend's device only (the first file of a pair: its pieces travel with the mate file's)
+    virtual std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& /*path*/, size_t /*piece_bytes*/, size_t /*min_bytes*/, bool /*by_lines*/ = false,
+                                                             bool /*one_device*/ = false)
     {
         return nullptr;
     }

@@ -128,9 +128,16 @@ public:
         return gn_device_memory(device_, &fr, &tot) == GN_OK ? fr : 0;
     }
 
-    std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& path, size_t piece_bytes, size_t min_bytes, bool by_lines) override
+    std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& path, size_t piece_bytes, size_t min_bytes, bool by_lines, bool one_device) override
     {
-        return open_device_gzip(path, device_, piece_bytes, min_bytes, by_lines);
+        if (by_lines || one_device)
+            return open_device_gzip(path, std::vector<int>{ device_ }, piece_bytes, min_bytes, by_lines);
+        // every distinct device of the run takes its share of the file's steps, this worker's own device first
+        std::vector<int> devs{ device_ };
+        for (int d : set_->unique_devices())
+            if (d != device_)
+                devs.push_back(d);
+        return open_device_gzip(path, devs, piece_bytes, min_bytes, by_lines);
     }
 
     bool tokenise_begin(ReadBatch& b, std::string& err) override

@@ -13,6 +13,11 @@
 //                   later, so the stepper waits until every piece of step k is released before it runs step k + 2
 // The mate file of a pair is opened `by_lines`: no stepper thread; the caller asks for "the next n lines" (the lines the first file's
 // piece holds: parse_reads pairs records by number, GanonClassify.cpp:1240-1252) and the step that has to run for it runs in that call.
+// Several devices: every distinct device of the run gets an inflater of the file (each is fed the whole compressed file over its own
+// link) and they take the file's steps in turn -- gn_inflate_set_turns / gn_inflate_handoff: a step's decode depends on nothing before
+// it, the step before hands over 32 KiB of window, a position, a CRC and the carried record.  The text of step k lies on device k mod N,
+// where that device's worker classifies it.  With ONE inflating device a .gz file ran at 100-117 Mreads/s whatever the number of GPUs
+// (DESIGN 7).  The mate file of a pair (by_lines) stays on one device.
 // Anything the device path refuses (GN_ERANGE: damaged data, a wrong ISIZE, expansion beyond its buffers, ...) ends the source with
 // an error text; the caller's sequential zlib reader continues at delivered() and produces the records and the message from there.
 #include "backend.hpp"
@@ -22,6 +27,7 @@
 #include "../../include/ganon_hip.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -62,8 +68,9 @@ public:
         for (auto& t : readers_)
             if (t.joinable())
                 t.join();
-        if (feeder_.joinable())
-            feeder_.join();
+        for (auto& t : feeders_)
+            if (t.joinable())
+                t.join();
         if (stepper_.joinable())
             stepper_.join();
         // pieces still out there keep their hold; the device buffers go with the inflater: wait for them
@@ -76,18 +83,26 @@ public:
         }
         {
             std::unique_lock<std::mutex> lk(m_);
-            cv_.wait(lk, [&] { return held_[0] == 0 && held_[1] == 0; });
+            cv_.wait(lk, [&] {
+                for (auto const& h : held_)
+                    if (h[0] || h[1])
+                        return false;
+                return true;
+            });
         }
-        if (z_)
-            gn_inflate_destroy(z_);
+        for (gn_inflate* z : zs_)
+            gn_inflate_destroy(z);
         for (void* p : blocks_)
             gn_pinned_free(p);
         if (fd_ >= 0)
             ::close(fd_);
     }
 
-    bool start(const std::string& path, int device, size_t piece_bytes, size_t min_bytes, bool by_lines)
+    bool start(const std::string& path, const std::vector<int>& devices, size_t piece_bytes, size_t min_bytes, bool by_lines)
     {
+        if (devices.empty())
+            return false;
+        const int device = devices.front();
         by_lines_ = by_lines;
         std::string base = path;
         if (!ends_with(base, ".gz"))
@@ -114,12 +129,29 @@ public:
         const std::string* cb = tun().str(Knob::device_inflate_chunk);
         const auto t_open = std::chrono::steady_clock::now();
         t0_ = t_open;
-        if (gn_inflate_create(device, size_, cb ? (uint32_t)std::atoll(cb->c_str()) : 0, sb ? (uint64_t)std::atoll(sb->c_str()) : 0, &z_) != GN_OK)
-        {
-            z_ = nullptr;
-            return false; // (no room for the file and the step buffers beside the filters: the host inflater takes it)
-        }
         l_step_ = sb ? (uint64_t)std::atoll(sb->c_str()) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
+        // how many inflaters: one per distinct device (a mate file: one), no more than the file has steps; $GANON_HOST_DEVICE_INFLATE_TURNS
+        // says otherwise (tests put several on the one GPU of a box)
+        size_t n_inf = by_lines ? 1 : tun().size(Knob::device_inflate_turns, devices.size());
+        n_inf        = std::max<size_t>(1, std::min<size_t>(n_inf, (size_t)((size_ + l_step_ - 1) / l_step_)));
+        for (size_t i = 0; i < n_inf; ++i)
+        {
+            gn_inflate* z = nullptr;
+            const int   d = devices[i % devices.size()];
+            if (gn_inflate_create(d, size_, cb ? (uint32_t)std::atoll(cb->c_str()) : 0, sb ? (uint64_t)std::atoll(sb->c_str()) : 0, &z) != GN_OK)
+                break; // (no room on that device beside the filters: the ones before it share the file)
+            zs_.push_back(z);
+            devs_.push_back(d);
+        }
+        if (zs_.empty())
+            return false; // (no room for the file and the step buffers beside the filters: the host inflater takes it)
+        for (size_t i = 0; i < zs_.size() && zs_.size() > 1; ++i)
+            if (gn_inflate_set_turns(zs_[i], (uint32_t)zs_.size(), (uint32_t)i) != GN_OK)
+                return false;
+        z_ = zs_.front();
+        held_.assign(zs_.size(), { 0, 0 });
+        fed_blocks_of_.assign(zs_.size(), 0);
+        fed_bytes_of_.assign(zs_.size(), 0);
         sec_create_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         n_blocks_ = (size_ + kBlock - 1) / kBlock;
         for (unsigned i = 0; i < kRing; ++i)
@@ -133,7 +165,8 @@ public:
         const unsigned n_readers = (unsigned)std::min<uint64_t>(3, n_blocks_);
         for (unsigned t = 0; t < n_readers; ++t)
             readers_.emplace_back([this] { read_loop(); g_cpu.inflate.add_this_thread(); });
-        feeder_  = std::thread([this] { feed_loop(); g_cpu.inflate.add_this_thread(); });
+        for (size_t i = 0; i < zs_.size(); ++i)
+            feeders_.emplace_back([this, i] { feed_loop(i); g_cpu.inflate.add_this_thread(); });
         if (!by_lines_)
             stepper_ = std::thread([this] { step_loop(); g_cpu.inflate.add_this_thread(); });
         return true;
@@ -180,7 +213,7 @@ public:
                 const int buf = (int)(l_step_no_ & 1u);
                 {
                     std::unique_lock<std::mutex> lk(m_);
-                    while (!cv_.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop_ || finished_ || (may_run() && fed_bytes_ >= l_want_ && held_[buf] == 0); }))
+                    while (!cv_.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop_ || finished_ || (may_run() && fed_bytes_ >= l_want_ && held_[0][buf] == 0); }))
                         ;
                     if (stop_ || finished_)
                     {
@@ -242,10 +275,10 @@ public:
             {
                 std::lock_guard<std::mutex> lk(m_);
                 const int buf = l_buf_;
-                ++held_[buf];
+                ++held_[0][buf];
                 out.hold = std::shared_ptr<void>(nullptr, [this, buf](void*) {
                     std::lock_guard<std::mutex> lk2(m_);
-                    --held_[buf];
+                    --held_[0][buf];
                     cv_.notify_all();
                 });
             }
@@ -288,10 +321,32 @@ public:
     {
         gn_inflate_stats st;
         std::memset(&st, 0, sizeof(st));
-        if (z_)
-            gn_inflate_get_stats(z_, &st);
+        for (gn_inflate* z : zs_)
+        {
+            gn_inflate_stats one;
+            std::memset(&one, 0, sizeof(one));
+            gn_inflate_get_stats(z, &one);
+            st.steps += one.steps;
+            st.chunks += one.chunks;
+            st.fixups += one.fixups;
+            st.markers += one.markers;
+            st.members += one.members;
+            st.text_bytes += one.text_bytes;
+            st.ms_decode += one.ms_decode;
+            st.ms_chain += one.ms_chain;
+            st.ms_resolve += one.ms_resolve;
+            st.ms_step_wall += one.ms_step_wall;
+        }
         std::ostringstream o;
-        o << "device inflate: " << st.steps << " steps, " << st.chunks << " chunks, " << st.fixups << " fix-ups, " << st.members << " members, "
+        o << "device inflate: ";
+        if (zs_.size() > 1)
+        {
+            o << zs_.size() << " inflaters taking turns on devices";
+            for (int d : devs_)
+                o << ' ' << d;
+            o << ", ";
+        }
+        o << st.steps << " steps, " << st.chunks << " chunks, " << st.fixups << " fix-ups, " << st.members << " members, "
           << st.text_bytes << " bytes of text; device ms: decode " << st.ms_decode << ", order " << st.ms_chain << ", windows+resolve " << st.ms_resolve
           << "; step calls " << st.ms_step_wall << " ms; opening: device buffers " << sec_create_ << " s, page-locked blocks " << sec_pinned_
           << " s, first text after " << sec_first_ << " s, all fed after " << sec_fed_ << " s";
@@ -310,7 +365,7 @@ private:
             {
                 std::unique_lock<std::mutex> lk(m_);
                 // block b uses ring slot b % kRing: free once block b - kRing is fed
-                cv_.wait(lk, [&] { return stop_ || next_read_ >= n_blocks_ || next_read_ < fed_blocks_ + kRing; });
+                cv_.wait(lk, [&] { return stop_ || next_read_ >= n_blocks_ || next_read_ < fed_blocks_ + kRing; }); // (fed_blocks_: by EVERY inflater)
                 if (stop_ || next_read_ >= n_blocks_)
                     return;
                 b = next_read_++;
@@ -337,7 +392,8 @@ private:
         }
     }
 
-    void feed_loop()
+    // one feeder per inflater: the whole compressed file goes to every device, each over its own link
+    void feed_loop(size_t who)
     {
         for (uint64_t b = 0; b < n_blocks_; ++b)
         {
@@ -346,19 +402,23 @@ private:
                 cv_.wait(lk, [&] { return stop_ || finished_ || read_done_.count(b); });
                 if (stop_ || finished_)
                     return;
-                read_done_.erase(b);
             }
             const uint64_t off = b * kBlock, n = std::min<uint64_t>(kBlock, size_ - off);
-            const int      rc  = gn_inflate_feed(z_, static_cast<const uint8_t*>(blocks_[b % kRing]), n);
+            const int      rc  = gn_inflate_feed(zs_[who], static_cast<const uint8_t*>(blocks_[b % kRing]), n);
             std::lock_guard<std::mutex> lk(m_);
             if (rc != GN_OK)
             {
                 fail_locked(gn_last_error());
                 return;
             }
-            fed_blocks_ = b + 1;
-            fed_bytes_  = off + n;
-            if (b + 1 == n_blocks_)
+            fed_blocks_of_[who] = b + 1;
+            fed_bytes_of_[who]  = off + n;
+            // a block's ring slot is free once every inflater has it
+            const uint64_t all_blocks = *std::min_element(fed_blocks_of_.begin(), fed_blocks_of_.end());
+            while (fed_blocks_ < all_blocks)
+                read_done_.erase(fed_blocks_++);
+            fed_bytes_ = *std::min_element(fed_bytes_of_.begin(), fed_bytes_of_.end());
+            if (fed_blocks_ == n_blocks_ && sec_fed_ == 0)
                 sec_fed_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
             cv_.notify_all();
         }
@@ -381,34 +441,46 @@ private:
         const std::string*    sb   = tun().str(Knob::device_inflate_step);
         const uint64_t        step = sb ? (uint64_t)std::atoll(sb->c_str()) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
         uint64_t              want = 0; // compressed bytes the next step should find
+        const size_t          n_inf = zs_.size();
+        std::vector<unsigned> own_steps(n_inf, 0); // (an inflater writes its two text buffers in turn: the buffer of ITS step before last must be released)
         for (;;)
         {
             want = std::min<uint64_t>(size_, want + step + (4ull << 20));
-            const int buf = (int)(step_no & 1u);
+            const size_t who = step_no % n_inf;
+            gn_inflate*  z   = zs_[who];
+            const int    buf = (int)(own_steps[who] & 1u);
             {
                 std::unique_lock<std::mutex> lk(m_);
-                while (!cv_.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop_ || finished_ || (go_ && may_run() && fed_bytes_ >= want && held_[buf] == 0); }))
+                while (!cv_.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop_ || finished_ || (go_ && may_run() && fed_bytes_of_[who] >= want && held_[who][buf] == 0); }))
                     ;
                 if (stop_ || finished_)
                     return;
             }
-            uint64_t n_text = 0;
-            int      done   = 0;
-            if (gn_inflate_step(z_, &n_text, &done) != GN_OK)
+            // what this step needs of the one before it (another inflater's): position, member CRC, window, the carried record
+            if (n_inf > 1 && step_no && gn_inflate_handoff(zs_[(step_no - 1) % n_inf], z) != GN_OK)
             {
                 std::lock_guard<std::mutex> lk(m_);
                 fail_locked(gn_last_error());
                 return;
             }
+            uint64_t n_text = 0;
+            int      done   = 0;
+            if (gn_inflate_step(z, &n_text, &done) != GN_OK)
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                fail_locked(gn_last_error());
+                return;
+            }
+            ++own_steps[who];
             if (sec_first_ == 0)
                 sec_first_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
             const uint8_t* dtext = nullptr;
             uint64_t       dn    = 0;
-            gn_inflate_text_device(z_, &dtext, &dn);
+            gn_inflate_text_device(z, &dtext, &dn);
             uint32_t n_cuts = 0;
             cuts.resize((size_t)(n_text / piece_) + 2);
             cut_lines.resize(cuts.size());
-            if (n_text && gn_inflate_cuts_lines(z_, lpr, piece_, cuts.data(), cut_lines.data(), (uint32_t)cuts.size(), &n_cuts) != GN_OK)
+            if (n_text && gn_inflate_cuts_lines(z, lpr, piece_, cuts.data(), cut_lines.data(), (uint32_t)cuts.size(), &n_cuts) != GN_OK)
             {
                 std::lock_guard<std::mutex> lk(m_);
                 fail_locked(gn_last_error());
@@ -424,7 +496,7 @@ private:
                 last = n_text;
             }
             const uint64_t tail = n_text - last;
-            if (!done && gn_inflate_set_carry(z_, tail) != GN_OK)
+            if (!done && gn_inflate_set_carry(z, tail) != GN_OK)
             {
                 // (a "record" larger than a quarter of a step's buffer: not four-line FASTQ; the sequential reader says what it is)
                 std::lock_guard<std::mutex> lk(m_);
@@ -441,13 +513,13 @@ private:
                     p.dev    = dtext + from;
                     p.bytes  = c - from;
                     p.at     = stream_at + from;
-                    p.device = device_;
+                    p.device = devs_[who];
                     p.lines  = cut_lines[ci] == ~0ull ? ~0ull : cut_lines[ci] - lines_before;
                     lines_before = cut_lines[ci] == ~0ull ? lines_before : cut_lines[ci];
-                    ++held_[buf];
-                    p.hold = std::shared_ptr<void>(nullptr, [this, buf](void*) {
+                    ++held_[who][buf];
+                    p.hold = std::shared_ptr<void>(nullptr, [this, who, buf](void*) {
                         std::lock_guard<std::mutex> lk2(m_);
-                        --held_[buf];
+                        --held_[who][buf];
                         cv_.notify_all();
                     });
                     q_.push_back(std::move(p));
@@ -469,10 +541,13 @@ private:
     int                   device_ = 0;
     size_t                piece_ = 48u << 20;
     bool                  fasta_ = false;
-    gn_inflate*           z_ = nullptr;
+    gn_inflate*           z_ = nullptr;     // the first inflater (the only one of a by_lines source)
+    std::vector<gn_inflate*> zs_;           // every inflater of the file, in turn order
+    std::vector<int>      devs_;            // ... and its device
     std::vector<void*>    blocks_;
     std::vector<std::thread> readers_;
-    std::thread           feeder_, stepper_;
+    std::vector<std::thread> feeders_;
+    std::thread           stepper_;
     mutable std::mutex    m_;
     std::condition_variable cv_;
     bool                  stop_ = false, finished_ = false, go_ = false;
@@ -481,7 +556,8 @@ private:
     uint64_t              next_read_ = 0, fed_blocks_ = 0, fed_bytes_ = 0;
     std::map<uint64_t, bool> read_done_;
     std::deque<DeviceTextPiece> q_;
-    uint64_t              held_[2] = { 0, 0 };
+    std::vector<std::array<uint64_t, 2>> held_;         // per inflater and text buffer: pieces out there
+    std::vector<uint64_t> fed_blocks_of_, fed_bytes_of_; // per inflater; fed_blocks_ / fed_bytes_ = what EVERY inflater has
     std::atomic<uint64_t> delivered_{ 0 };
     std::chrono::steady_clock::time_point t0_;
     double sec_create_ = 0, sec_pinned_ = 0, sec_first_ = 0, sec_fed_ = 0;
@@ -496,10 +572,10 @@ private:
 
 } // namespace
 
-std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, int device, size_t piece_bytes, size_t min_bytes, bool by_lines)
+std::unique_ptr<DeviceTextSource> open_device_gzip(const std::string& path, const std::vector<int>& devices, size_t piece_bytes, size_t min_bytes, bool by_lines)
 {
     std::unique_ptr<DeviceGzip> g(new DeviceGzip());
-    if (!g->start(path, device, piece_bytes, min_bytes, by_lines))
+    if (!g->start(path, devices, piece_bytes, min_bytes, by_lines))
         return nullptr;
     return g;
 }

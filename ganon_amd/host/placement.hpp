@@ -109,6 +109,7 @@ public:
         return false;
     }
     size_t n_devices() const { return uniq_.size(); }
+    const std::vector<int>& unique_devices() const { return uniq_; }
     size_t unique_index(int device) const { return (size_t)(std::find(uniq_.begin(), uniq_.end(), device) - uniq_.begin()); }
 
     void clear()

@@ -443,7 +443,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             if (raw_fastq && paired && device_text)
             {
                 const size_t piece = std::max<size_t>(slab_bytes / 2, 1 << 16), dmin = tun().size(Knob::device_inflate_min, 1u << 20);
-                auto         src1  = device_text->open_gzip_text(pair.mate1, piece, dmin);
+                auto         src1  = device_text->open_gzip_text(pair.mate1, piece, dmin, false, true);
                 auto         src2  = src1 ? device_text->open_gzip_text(pair.mate2, piece, 0, true) : nullptr;
                 if (src1 && src2)
                 {

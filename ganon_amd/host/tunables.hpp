@@ -36,6 +36,7 @@ enum class Knob
     device_inflate_room,
     device_inflate_step,
     device_inflate_chunk,
+    device_inflate_turns,
     no_shared_hashes,
     no_warm_up,
     pageable,
@@ -77,6 +78,7 @@ inline const KnobInfo& knob_info(Knob k)
         { "GANON_HOST_DEVICE_INFLATE_ROOM", "device memory that must be free beside filters and batch buffers for the device inflater (default 40 GiB)" },
         { "GANON_HOST_DEVICE_INFLATE_STEP", "compressed bytes per device inflate step (default 128 / 256 MiB by file size)" },
         { "GANON_HOST_DEVICE_INFLATE_CHUNK", "bytes of compressed data per device chunk (default: the library's 32 KiB)" },
+        { "GANON_HOST_DEVICE_INFLATE_TURNS", "inflaters that take a .gz file's steps in turn (default: one per distinct device; more than the devices: several on one -- tests)" },
         { "GANON_HOST_NO_SHARED_HASHES", "every filter's stream hashes the batch itself" },
         { "GANON_HOST_NO_WARM_UP", "no warm-up batch through the worker contexts" },
         { "GANON_HOST_PAGEABLE", "device-bound host buffers from the heap, not from the page-locked pool" },

@@ -287,3 +287,42 @@ def test_blocked_gzip_input(sim_db, tmp_path):
     _run(cu.BIN_HIP, sim_db, fq, b, HOST)
     assert _device_path_taken(pa) and "0 fix-ups" in pa.stderr, pa.stderr
     _same_files(a, b)
+
+
+TURNS = {"GANON_HOST_DEVICE_INFLATE_CHUNK": "4096", "GANON_HOST_DEVICE_INFLATE_STEP": "131072", "GANON_HOST_SLAB_BYTES": "200000"}
+
+
+@pytest.mark.parametrize("turns,devices", [("2", "0"), ("3", "0,0,0"), ("2", "0,0")])
+def test_steps_of_a_file_inflated_in_turns_by_several_inflaters(sim_db, oracle_bin, tmp_path, turns, devices):
+    """Every distinct device of a run gets an inflater of a .gz file and they take its steps in turn (gn_inflate_set_turns /
+    gn_inflate_handoff; DESIGN 7: one inflating device capped a .gz run at 100-117 Mreads/s for any number of GPUs).  One GPU here:
+    $GANON_HOST_DEVICE_INFLATE_TURNS puts several inflaters on it -- the hand-over of position, window, CRC and carried record is the
+    same peer-copy code.  Outputs: the host inflater's, byte for byte, and the oracle backend's."""
+    text = "".join(_records(40000, seed=41)).encode()
+    fq = str(tmp_path / "reads.fq.gz")
+    with open(fq, "wb") as f:   # two members, the cut inside a record: a member ends inside a step, its CRC is handed over
+        f.write(gzip.compress(text[:3_000_001], 6) + gzip.compress(text[3_000_001:], 6))
+    a, b, c = str(tmp_path / "turns"), str(tmp_path / "host"), str(tmp_path / "ora")
+    pa = _run(cu.BIN_HIP, sim_db, fq, a, dict(DEV, GANON_HOST_DEVICE_INFLATE_TURNS=turns, **TURNS), extra=("--device", devices))
+    _run(cu.BIN_HIP, sim_db, fq, b, HOST)
+    _run(oracle_bin, sim_db, fq, c)
+    assert _device_path_taken(pa) and f"{turns} inflaters taking turns" in pa.stderr and "2 members" in pa.stderr, pa.stderr
+    _same_files(a, b)
+    _same_files(a, c, (".all", ".one", ".unc", ".rep"))
+    assert cu.Res(a).total_classified > 1000
+
+
+def test_turns_with_irregular_input_and_damage_end_like_the_host_path(sim_db, tmp_path):
+    recs = _records(20000, seed=29)
+    h, s, p, q = recs[15000].split("\n")[:4]
+    recs[15000] = f"{h}\n{s[:40]}\n{s[40:]}\n{p}\n{q[:40]}\n{q[40:]}\n"        # a wrapped record late in the file: the sequential reader takes over there
+    gz = gzip.compress("".join(recs).encode(), 6)
+    for tag, data in (("wrapped", gz), ("truncated", gz[:len(gz) * 3 // 5])):
+        fq = str(tmp_path / f"{tag}.fq.gz")
+        open(fq, "wb").write(data)
+        a, b = str(tmp_path / f"{tag}_dev"), str(tmp_path / f"{tag}_host")
+        pa = _run(cu.BIN_HIP, sim_db, fq, a, dict(DEV, GANON_HOST_DEVICE_INFLATE_TURNS="3", **TURNS))
+        pb = _run(cu.BIN_HIP, sim_db, fq, b, HOST)
+        _same_files(a, b)
+        err = lambda p: [l for l in p.stderr.split("\n") if l.startswith("Error parsing")]  # noqa: E731
+        assert err(pa) == err(pb)
