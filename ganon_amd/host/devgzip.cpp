@@ -134,14 +134,29 @@ public:
         // says otherwise (tests put several on the one GPU of a box)
         size_t n_inf = by_lines ? 1 : tun().size(Knob::device_inflate_turns, devices.size());
         n_inf        = std::max<size_t>(1, std::min<size_t>(n_inf, (size_t)((size_ + l_step_ - 1) / l_step_)));
-        for (size_t i = 0; i < n_inf; ++i)
         {
-            gn_inflate* z = nullptr;
-            const int   d = devices[i % devices.size()];
-            if (gn_inflate_create(d, size_, cb ? (uint32_t)std::atoll(cb->c_str()) : 0, sb ? (uint64_t)std::atoll(sb->c_str()) : 0, &z) != GN_OK)
-                break; // (no room on that device beside the filters: the ones before it share the file)
-            zs_.push_back(z);
-            devs_.push_back(d);
+            // (creating an inflater clears gigabytes of device memory, ~0.1 s: every device does that at the same time)
+            std::vector<gn_inflate*> made(n_inf, nullptr);
+            std::vector<std::thread> th;
+            const uint32_t           chunk_b = cb ? (uint32_t)std::atoll(cb->c_str()) : 0;
+            const uint64_t           step_b  = sb ? (uint64_t)std::atoll(sb->c_str()) : 0;
+            for (size_t i = 1; i < n_inf; ++i)
+                th.emplace_back([&, i] { (void)gn_inflate_create(devices[i % devices.size()], size_, chunk_b, step_b, &made[i]); });
+            (void)gn_inflate_create(devices[0], size_, chunk_b, step_b, &made[0]);
+            for (auto& t : th)
+                t.join();
+            for (size_t i = 0; i < n_inf; ++i)
+            {
+                if (!made[i]) // (no room on that device beside the filters: the ones before it share the file)
+                {
+                    for (size_t j = i + 1; j < n_inf; ++j)
+                        if (made[j])
+                            gn_inflate_destroy(made[j]);
+                    break;
+                }
+                zs_.push_back(made[i]);
+                devs_.push_back(devices[i % devices.size()]);
+            }
         }
         if (zs_.empty())
             return false; // (no room for the file and the step buffers beside the filters: the host inflater takes it)
