@@ -34,7 +34,7 @@ def pytest_report_header(config):
 #   2  f-rows (input side, builder, reassign, first contact) and the bench line
 TIERS = (
     ("test_gpu_parity", "test_gpu_fullsize", "test_gpu_fullsize_large", "test_cli_kat", "test_gpu_on_demand", "test_gpu_padded_rows",
-     "test_gpu_fuzz", "test_oracle_kat"),
+     "test_gpu_fuzz", "test_gpu_segmented", "test_oracle_kat"),
     ("test_abi_cpu", "test_gpu_gather", "test_partition_gloo", "test_partition_cli", "test_upload_order", "test_cli_fuzz", "test_ibf_file",
      "test_inspect_filter", "test_verify_filter", "test_reference_order", "test_report_rep", "test_runtime72", "test_reader_formats",
      "test_host_tunables"),
