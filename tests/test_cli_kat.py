@@ -210,10 +210,23 @@ def _check_sim_against_oracle_level(sim_db, prefix, hibf):
     res = cu.Res(prefix)
     res.sanity_check(has_tax=True)
     n_class = n_matches = dis_filter = dis_fpr = 0
+    stats = dict(seqs_processed=0, seqs_classified=0, seqs_unique=0, matches=0, dis_filter=0, dis_fpr=0, kmers_processed=0, kmers_matches=0,
+                 kmers_from_classified_seqs=0)
     for (rid, s1), (_, s2) in zip(r1, r2):
         rr = lvl.classify(oracle.to_ranks(s1), oracle.to_ranks(s2))
         dis_filter += len(rr.discarded_filter)
         dis_fpr += len(rr.discarded_fpr)
+        if rr.status == 0:                                   # :706-714 (reads too short / with too many minimisers are not "processed")
+            stats["seqs_processed"] += 1
+            stats["kmers_processed"] += rr.n_hashes
+        stats["dis_filter"] += len(rr.discarded_filter)
+        stats["dis_fpr"] += len(rr.discarded_fpr)
+        if rr.kept:                                          # :764-768
+            stats["seqs_classified"] += 1
+            stats["seqs_unique"] += 1 if len(rr.kept) == 1 else 0
+            stats["matches"] += len(rr.kept)
+            stats["kmers_from_classified_seqs"] += rr.n_hashes
+            stats["kmers_matches"] += rr.max_count
         if rr.kept:
             n_class += 1
             n_matches += len(rr.kept)
@@ -228,6 +241,27 @@ def _check_sim_against_oracle_level(sim_db, prefix, hibf):
     assert (int(sta["seq_classified"]), int(sta["matches"])) == (n_class, n_matches)
     assert (int(sta["dis_matches_rel_filter"]), int(sta["dis_matches_fpr_query"])) == (dis_filter, dis_fpr)
     assert hibf or dis_filter > 0
+    # ... and the whole file is what write_stats / write_stats_db print (GanonClassify.cpp:1130-1218: 18 tab-separated columns, doubles
+    # `std::fixed << std::setprecision(6)`, one row per hierarchy label, no -total- row for a single label), restated here from the
+    # reference's text and fed the oracle's per-read results -- the writers are pinned by more than "both backends agree" 
+    assert open(prefix + ".sta").read() == _expected_sta("", "H1", stats)
+
+
+def _expected_sta(prefix, label, t):
+    """write_stats (:1167-1218) + write_stats_db (:1130-1165) for ONE hierarchy label; t = the Total of :197-246 as a dict"""
+    head = ["prefix", "hierarchy_label", "seq_processed", "seq_unclassified", "seq_classified", "seq_classified_perc", "seq_unique_matches",
+            "seq_unique_matches_perc", "seq_multiple_matches", "seq_multiple_matches_perc", "matches", "avg_matches_ref_seq", "dis_matches_rel_filter",
+            "dis_matches_fpr_query", "kmers_proccessed", "kmers_matched", "kmers_from_classified_seqs", "kmers_matched_perc"]
+    seq_processed = float(t["seqs_processed"]) if t["seqs_processed"] > 0 else 1.0            # :1195-1196
+    multiple = t["seqs_classified"] - t["seqs_unique"]                                          # :1139
+    avg = t["matches"] / float(t["seqs_classified"]) if t["seqs_classified"] else 0.0            # :1140-1141
+    kperc = t["kmers_matches"] / float(t["kmers_from_classified_seqs"]) * 100 if t["kmers_matches"] else 0.0   # :1142-1144
+    f6 = lambda x: "%.6f" % x                                                                    # noqa: E731  (:1146)
+    row = [prefix, label, str(int(seq_processed)), str(t["seqs_processed"] - t["seqs_classified"]), str(t["seqs_classified"]),
+           f6(t["seqs_classified"] / seq_processed * 100), str(t["seqs_unique"]), f6(t["seqs_unique"] / seq_processed * 100), str(multiple),
+           f6(multiple / seq_processed * 100), str(t["matches"]), f6(avg), str(t["dis_filter"]), str(t["dis_fpr"]), str(t["kmers_processed"]),
+           str(t["kmers_matches"]), str(t["kmers_from_classified_seqs"]), f6(kperc)]
+    return "\t".join(head) + "\n" + "\t".join(row) + "\n"
 
 
 def test_sim_fastq_gz_ibf_oracle_backend(oracle_bin, sim_db, tmp_path):
