@@ -79,6 +79,20 @@ def test_partitioned_filter_gloo(tmp_path):
     assert np.array_equal(got, exp)  # owners hold ascending reads; concatenation == single-filter result
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_proof_helpers_gloo(tmp_path, world):
+    """the collectives behind bench.py's `ranks` object (ranks_seen, devices, per-rank step times): every rank sees every rank's entry,
+    in rank order"""
+    import json
+    out = str(tmp_path / "proof")
+    _run_world("proof", out, world=world)
+    for rank in range(world):
+        r = json.load(open(f"{out}.{rank}.json"))
+        assert r["ranks_seen"] == world and r["group_size"] == world
+        assert r["texts"] == [f"0000:{i:02x}:00/rank{i}" for i in range(world)]
+        assert r["times"] == [40.0 + i for i in range(world)]
+
+
 def test_read_sharding_gloo(tmp_path):
     out = str(tmp_path / "shard")
     _run_world("shard", out)
