@@ -315,7 +315,8 @@ static int gn_fq_enqueue(gn_stream* s, const uint8_t* d_text, uint64_t n_bytes, 
 }
 
 // src_device < 0: the texts are host memory; otherwise device memory of that device
-static int gn_upload_texts(gn_stream* s, const uint8_t* text, uint64_t n_bytes, const uint8_t* text2, uint64_t n_bytes2, bool pair, int format, int src_device = -1)
+static int gn_upload_texts(gn_stream* s, const uint8_t* text, uint64_t n_bytes, const uint8_t* text2, uint64_t n_bytes2, bool pair, int format, int src_device = -1,
+                           int src_device2 = -2 /* -2: where text 1 lies */)
 {
     if (!s || (!text && n_bytes) || (pair && !text2 && n_bytes2))
         return gn_fail(GN_EINVAL, "gn_stream_upload_text: null argument");
@@ -344,10 +345,14 @@ static int gn_upload_texts(gn_stream* s, const uint8_t* text, uint64_t n_bytes, 
     }
     else if (n_bytes)
         GN_HIP(hipMemcpyAsync(s->d_text, text, n_bytes, src_device >= 0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    if (pair && n_bytes2 && src_device >= 0 && src_device != s->f->device)
-        GN_HIP(hipMemcpyPeerAsync(s->d_text + at2, s->f->device, text2, src_device, n_bytes2, st));
+    const int dev2 = src_device2 == -2 ? src_device : src_device2;
+    if (pair && n_bytes2 && dev2 >= 0 && dev2 != s->f->device)
+    {
+        gn_peer_enable(s->f->device, dev2);
+        GN_HIP(hipMemcpyPeerAsync(s->d_text + at2, s->f->device, text2, dev2, n_bytes2, st));
+    }
     else if (pair && n_bytes2)
-        GN_HIP(hipMemcpyAsync(s->d_text + at2, text2, n_bytes2, src_device >= 0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        GN_HIP(hipMemcpyAsync(s->d_text + at2, text2, n_bytes2, dev2 >= 0 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     const double p2 = probe ? now() : 0;
     rc = gn_fq_enqueue(s, s->d_text, n_bytes, format, s->d_fq_tile, s->d_fq_nl, s->d_fq_rec, s->d_fq_seq, s->d_fq_len, s->d_fq, s->d_off1, 0, st);
     if (rc)
@@ -404,6 +409,14 @@ extern "C" int gn_stream_upload_text_pair_device(gn_stream* s, const uint8_t* d_
     if (src_device < 0)
         return gn_fail(GN_EINVAL, "gn_stream_upload_text_pair_device: device %d", src_device);
     return gn_upload_texts(s, d_text1, n_bytes1, d_text2, n_bytes2, true, format, src_device);
+}
+
+extern "C" int gn_stream_upload_text_pair_devices(gn_stream* s, const uint8_t* d_text1, uint64_t n_bytes1, int src_device1, const uint8_t* d_text2, uint64_t n_bytes2,
+                                                  int src_device2, int format)
+{
+    if (src_device1 < 0 || src_device2 < 0)
+        return gn_fail(GN_EINVAL, "gn_stream_upload_text_pair_devices: devices %d, %d", src_device1, src_device2);
+    return gn_upload_texts(s, d_text1, n_bytes1, d_text2, n_bytes2, true, format, src_device1, src_device2);
 }
 
 extern "C" int gn_stream_upload_text_pair(gn_stream* s, const uint8_t* text1, uint64_t n_bytes1, const uint8_t* text2, uint64_t n_bytes2, int format)

@@ -2634,7 +2634,9 @@ extern "C" int gn_inflate_handoff(gn_inflate* from, gn_inflate* to)
     to->crc_carry        = from->crc_carry;
     to->next_chunk       = from->next_chunk;
     GN_HIP(hipSetDevice(to->device));
-    GN_HIP(hipMemcpyPeer(to->d_window, to->device, from->d_window, from->device, GI_WINDOW));
+    // (on the receiving inflater's stream: a device-to-device copy on the null stream returns before it is done and orders nothing against a
+    //  non-blocking stream -- the step's window pass would race it; the source is at rest, its inflater's step has synchronised)
+    GN_HIP(hipMemcpyPeerAsync(to->d_window, to->device, from->d_window, from->device, GI_WINDOW, to->st));
     const uint64_t c = from->carry;
     if (c)
     {
@@ -2651,7 +2653,7 @@ extern "C" int gn_inflate_handoff(gn_inflate* from, gn_inflate* to)
                 return gn_fail(GN_ENOMEM, "gn_inflate_handoff: no room for %llu carried bytes", (unsigned long long)c);
             to->carry_in_cap = cap;
         }
-        GN_HIP(hipMemcpyPeer(to->d_carry_in, to->device, from->d_text[from->cur] + (from->n_text_last - c), from->device, c));
+        GN_HIP(hipMemcpyPeerAsync(to->d_carry_in, to->device, from->d_text[from->cur] + (from->n_text_last - c), from->device, c, to->st));
     }
     to->carry    = c;
     to->carry_in = c != 0;

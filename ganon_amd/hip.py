@@ -31,7 +31,8 @@ ABI_SYMBOLS = ["gn_device_count", "gn_last_error", "gn_filter_upload_ibf", "gn_f
                "gn_inflate_create", "gn_inflate_destroy", "gn_inflate_feed", "gn_inflate_step", "gn_inflate_text", "gn_inflate_text_device",
                "gn_inflate_get_stats", "gn_inflate_cuts", "gn_inflate_set_carry", "gn_stream_upload_text_device", "gn_stream_fastq_headers",
                "gn_inflate_cuts_lines", "gn_inflate_cut_at_lines", "gn_stream_upload_text_pair_device", "gn_stream_fetch_letters",
-               "gn_ibf_hash_constants", "gn_inflate_set_turns", "gn_inflate_handoff"]
+               "gn_ibf_hash_constants", "gn_inflate_set_turns", "gn_inflate_handoff",
+               "gn_stream_upload_text_pair_devices"]
 
 
 class PostFilter(C.Structure):  # gn_postfilter
@@ -175,6 +176,7 @@ def load_library():
     L.gn_ibf_hash_constants.argtypes = [vp, C.POINTER(u64)]
     L.gn_inflate_set_turns.argtypes = [vp, u32, u32]
     L.gn_inflate_handoff.argtypes = [vp, vp]
+    L.gn_stream_upload_text_pair_devices.argtypes = [vp, vp, u64, i32, vp, u64, i32, i32]
     L.gn_hibf_row_stride_words.argtypes = [u64]
     L.gn_hibf_row_stride_words.restype = u64
     L.gn_peer_stats.argtypes = [i32, i32, C.POINTER(i32), C.POINTER(u64)]

@@ -134,6 +134,7 @@ struct ReadBatch
     const uint8_t*        dev_text   = nullptr;
     uint64_t              dev_bytes  = 0;
     int                   dev_device = -1;
+    int                   dev_device2 = -1; // ... of dev_text2 (-1: where dev_text lies)
     std::shared_ptr<void> dev_hold;  // keeps the device buffer alive; dropped once the text is copied into the worker's stream
     const uint8_t*        dev_text2  = nullptr; // ... of a pair: the mate file's piece (the same records by number), same device
     uint64_t              dev_bytes2 = 0;

@@ -130,7 +130,7 @@ public:
 
     std::unique_ptr<DeviceTextSource> open_gzip_text(const std::string& path, size_t piece_bytes, size_t min_bytes, bool by_lines, bool one_device) override
     {
-        if (by_lines || one_device)
+        if (one_device)
             return open_device_gzip(path, std::vector<int>{ device_ }, piece_bytes, min_bytes, by_lines);
         // every distinct device of the run takes its share of the file's steps, this worker's own device first
         std::vector<int> devs{ device_ };
@@ -167,7 +167,8 @@ public:
                     t = now;
                 }
                 const int fmt = b.raw_fasta ? GN_TEXT_FASTA : GN_TEXT_FASTQ;
-                if ((b.dev_text && pair ? gn_stream_upload_text_pair_device(part.s, b.dev_text, b.dev_bytes, b.dev_text2, b.dev_bytes2, fmt, b.dev_device)
+                if ((b.dev_text && pair ? gn_stream_upload_text_pair_devices(part.s, b.dev_text, b.dev_bytes, b.dev_device, b.dev_text2, b.dev_bytes2,
+                                                                           b.dev_device2 >= 0 ? b.dev_device2 : b.dev_device, fmt)
                      : b.dev_text      ? gn_stream_upload_text_device(part.s, b.dev_text, nb, fmt, b.dev_device)
                      : pair     ? gn_stream_upload_text_pair(part.s, b.text.data(), b.text.size(), b.text2.data(), b.text2.size(), fmt)
                                 : gn_stream_upload_text(part.s, b.text.data(), nb, fmt))

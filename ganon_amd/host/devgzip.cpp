@@ -17,7 +17,8 @@
 // link) and they take the file's steps in turn -- gn_inflate_set_turns / gn_inflate_handoff: a step's decode depends on nothing before
 // it, the step before hands over 32 KiB of window, a position, a CRC and the carried record.  The text of step k lies on device k mod N,
 // where that device's worker classifies it.  With ONE inflating device a .gz file ran at 100-117 Mreads/s whatever the number of GPUs
-// (DESIGN 7).  The mate file of a pair (by_lines) stays on one device.
+// (DESIGN 7).  The mate file of a pair (by_lines) is inflated the same way; a pair's two pieces may then lie on two devices
+// (gn_stream_upload_text_pair_devices).
 // Anything the device path refuses (GN_ERANGE: damaged data, a wrong ISIZE, expansion beyond its buffers, ...) ends the source with
 // an error text; the caller's sequential zlib reader continues at delivered() and produces the records and the message from there.
 #include "backend.hpp"
@@ -132,7 +133,7 @@ public:
         l_step_ = sb ? (uint64_t)std::atoll(sb->c_str()) : (size_ < (1536ull << 20) ? 128ull << 20 : 256ull << 20);
         // how many inflaters: one per distinct device (a mate file: one), no more than the file has steps; $GANON_HOST_DEVICE_INFLATE_TURNS
         // says otherwise (tests put several on the one GPU of a box)
-        size_t n_inf = by_lines ? 1 : tun().size(Knob::device_inflate_turns, devices.size());
+        size_t n_inf = tun().size(Knob::device_inflate_turns, devices.size());
         n_inf        = std::max<size_t>(1, std::min<size_t>(n_inf, (size_t)((size_ + l_step_ - 1) / l_step_)));
         {
             // (creating an inflater clears gigabytes of device memory, ~0.1 s: every device does that at the same time)
@@ -225,10 +226,14 @@ public:
             if (!l_have_)
             {
                 l_want_       = std::min<uint64_t>(size_, l_want_ + l_step_ + (4ull << 20));
-                const int buf = (int)(l_step_no_ & 1u);
+                // the inflaters of the file take its steps in turn (as in step_loop)
+                const size_t who = l_step_no_ % zs_.size();
+                if (l_own_steps_.size() != zs_.size())
+                    l_own_steps_.assign(zs_.size(), 0);
+                const int buf = (int)(l_own_steps_[who] & 1u);
                 {
                     std::unique_lock<std::mutex> lk(m_);
-                    while (!cv_.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop_ || finished_ || (may_run() && fed_bytes_ >= l_want_ && held_[0][buf] == 0); }))
+                    while (!cv_.wait_for(lk, std::chrono::milliseconds(1), [&] { return stop_ || finished_ || (may_run() && fed_bytes_of_[who] >= l_want_ && held_[who][buf] == 0); }))
                         ;
                     if (stop_ || finished_)
                     {
@@ -236,9 +241,19 @@ public:
                         return false;
                     }
                 }
+                if (zs_.size() > 1 && l_step_no_ && gn_inflate_handoff(zs_[(l_step_no_ - 1) % zs_.size()], zs_[who]) != GN_OK)
+                {
+                    std::lock_guard<std::mutex> lk(m_);
+                    fail_locked(gn_last_error());
+                    err = error_;
+                    return false;
+                }
+                l_z_ = zs_[who];
+                l_who_ = who;
+                ++l_own_steps_[who];
                 uint64_t n_text = 0;
                 int      done   = 0;
-                if (gn_inflate_step(z_, &n_text, &done) != GN_OK)
+                if (gn_inflate_step(l_z_, &n_text, &done) != GN_OK)
                 {
                     std::lock_guard<std::mutex> lk(m_);
                     fail_locked(gn_last_error());
@@ -248,7 +263,7 @@ public:
                 if (sec_first_ == 0)
                     sec_first_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
                 uint64_t dn = 0;
-                gn_inflate_text_device(z_, &l_text_, &dn);
+                gn_inflate_text_device(l_z_, &l_text_, &dn);
                 l_n_      = n_text;
                 l_served_ = 0;
                 l_lines_  = 0;
@@ -259,7 +274,7 @@ public:
             }
             uint64_t off = 0, total = 0;
             const uint64_t ask = lines == ~0ull ? ~0ull : l_lines_ + lines;
-            if (gn_inflate_cut_at_lines(z_, &ask, lines == ~0ull ? 0u : 1u, &off, &total) != GN_OK)
+            if (gn_inflate_cut_at_lines(l_z_, &ask, lines == ~0ull ? 0u : 1u, &off, &total) != GN_OK)
             {
                 std::lock_guard<std::mutex> lk(m_);
                 fail_locked(gn_last_error());
@@ -270,7 +285,7 @@ public:
             if (!whole && !l_done_ && lines != ~0ull)
             {
                 // the text at hand ends before the lines do: what is left of it begins the next step's text
-                if (gn_inflate_set_carry(z_, l_n_ - l_served_) != GN_OK)
+                if (gn_inflate_set_carry(l_z_, l_n_ - l_served_) != GN_OK)
                 {
                     std::lock_guard<std::mutex> lk(m_);
                     fail_locked(gn_last_error());
@@ -285,15 +300,16 @@ public:
             out.dev    = l_text_ + l_served_;
             out.bytes  = end - l_served_;
             out.at     = l_at_ + l_served_;
-            out.device = device_;
+            out.device = devs_[l_who_];
             out.lines  = whole ? lines : total - l_lines_;
             {
                 std::lock_guard<std::mutex> lk(m_);
-                const int buf = l_buf_;
-                ++held_[0][buf];
-                out.hold = std::shared_ptr<void>(nullptr, [this, buf](void*) {
+                const int    buf = l_buf_;
+                const size_t who = l_who_;
+                ++held_[who][buf];
+                out.hold = std::shared_ptr<void>(nullptr, [this, who, buf](void*) {
                     std::lock_guard<std::mutex> lk2(m_);
-                    --held_[0][buf];
+                    --held_[who][buf];
                     cv_.notify_all();
                 });
             }
@@ -308,7 +324,7 @@ public:
                     l_eof_ = true;
                 else
                 {
-                    if (gn_inflate_set_carry(z_, 0) != GN_OK)
+                    if (gn_inflate_set_carry(l_z_, 0) != GN_OK)
                     {
                         std::lock_guard<std::mutex> lk(m_);
                         fail_locked(gn_last_error());
@@ -582,6 +598,9 @@ private:
     uint64_t       l_n_ = 0, l_served_ = 0, l_lines_ = 0, l_at_ = 0, l_want_ = 0;
     uint64_t       l_step_ = 256ull << 20;
     unsigned       l_step_no_ = 0;
+    gn_inflate*    l_z_ = nullptr;          // the inflater whose step's text is at hand
+    size_t         l_who_ = 0;
+    std::vector<unsigned> l_own_steps_;
     int            l_buf_ = 0;
 };
 

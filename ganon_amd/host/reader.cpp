@@ -351,6 +351,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                     rb.dev_text = nullptr;
                     rb.dev_bytes = 0;
                     rb.dev_hold.reset();
+                    rb.dev_device2 = -1;
                     rb.dev_text2 = nullptr;
                     rb.dev_bytes2 = 0;
                     rb.dev_hold2.reset();
@@ -443,7 +444,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
             if (raw_fastq && paired && device_text)
             {
                 const size_t piece = std::max<size_t>(slab_bytes / 2, 1 << 16), dmin = tun().size(Knob::device_inflate_min, 1u << 20);
-                auto         src1  = device_text->open_gzip_text(pair.mate1, piece, dmin, false, true);
+                auto         src1  = device_text->open_gzip_text(pair.mate1, piece, dmin);
                 auto         src2  = src1 ? device_text->open_gzip_text(pair.mate2, piece, 0, true) : nullptr;
                 if (src1 && src2)
                 {
@@ -482,6 +483,7 @@ void parse_reads(BatchQueue& queue, RunReport& report, std::mutex& report_mutex,
                         rb.dev_bytes  = p1.bytes;
                         rb.dev_device = p1.device;
                         rb.dev_hold   = std::move(p1.hold);
+                        rb.dev_device2 = p2.device;
                         rb.dev_text2  = p2.dev;
                         rb.dev_bytes2 = p2.bytes;
                         rb.dev_hold2  = std::move(p2.hold);

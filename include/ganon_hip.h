@@ -223,6 +223,9 @@ int gn_stream_upload_text_device(gn_stream* s, const uint8_t* d_text, uint64_t n
 /* both mate files' pieces in device memory (as gn_stream_upload_text_pair otherwise) */
 int gn_stream_upload_text_pair_device(gn_stream* s, const uint8_t* d_text1, uint64_t n_bytes1, const uint8_t* d_text2, uint64_t n_bytes2, int format,
                                       int src_device);
+/* ... the two pieces on two devices (the mate files of a pair inflated by different inflaters, gn_inflate_set_turns) */
+int gn_stream_upload_text_pair_devices(gn_stream* s, const uint8_t* d_text1, uint64_t n_bytes1, int src_device1, const uint8_t* d_text2, uint64_t n_bytes2,
+                                       int src_device2, int format);
 int gn_stream_fastq_headers(gn_stream* s, uint8_t* dst, uint64_t cap, uint32_t* hdr_off, uint64_t* n_bytes);
 /* The resident batch's letters as the kernels see them (ASCII, mate-1 block then mate-2 block: the layout of gn_stream_upload_reads) with
  * off1 / off2 (n_reads + 1 entries each; off2 only for pairs): for a caller that classified a text it does not hold and needs the letters

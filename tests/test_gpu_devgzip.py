@@ -326,3 +326,36 @@ def test_turns_with_irregular_input_and_damage_end_like_the_host_path(sim_db, tm
         _same_files(a, b)
         err = lambda p: [l for l in p.stderr.split("\n") if l.startswith("Error parsing")]  # noqa: E731
         assert err(pa) == err(pb)
+
+
+@pytest.mark.parametrize("case,turns", [("equal", "2"), ("equal", "3"), ("mates_short", "2"), ("mate_wrapped", "3"), ("first_truncated_gz", "2")])
+def test_paired_gzip_files_inflated_in_turns(sim_db, oracle_bin, tmp_path, case, turns):
+    """Both files of a pair with their steps taken in turn by several inflaters (file 2 is cut where file 1's records end by number,
+    GanonClassify.cpp:1240-1252): a pair's two pieces may lie on two devices (gn_stream_upload_text_pair_devices) -- on this box
+    the inflaters share the one GPU.  Outputs and messages: the host inflater's run, byte for byte."""
+    a, b = _pair_records(30000, seed=7 + len(case))
+    if case == "mates_short":
+        b = b[:19000]
+    if case == "mate_wrapped":
+        h, s, p, q = b[21000].split("\n")[:4]
+        b[21000] = f"{h}\n{s[:20]}\n{s[20:]}\n{p}\n{q[:20]}\n{q[20:]}\n"
+    f1, f2 = str(tmp_path / "r.1.fq.gz"), str(tmp_path / "r.2.fq.gz")
+    g1, g2 = gzip.compress("".join(a).encode(), 6), gzip.compress("".join(b).encode(), 3)
+    if case == "first_truncated_gz":
+        g1 = g1[:len(g1) * 3 // 5]
+    open(f1, "wb").write(g1)
+    open(f2, "wb").write(g2)
+    env = dict(DEV, GANON_HOST_DEVICE_INFLATE_TURNS=turns, GANON_HOST_DEVICE_INFLATE_CHUNK="4096", GANON_HOST_DEVICE_INFLATE_STEP="131072",
+               GANON_HOST_SLAB_BYTES="300000")
+    x, y = str(tmp_path / "dev"), str(tmp_path / "host")
+    px = _run_pair(cu.BIN_HIP, sim_db, f1, f2, x, env)
+    py = _run_pair(cu.BIN_HIP, sim_db, f1, f2, y, HOST)
+    assert px.stderr.count(f"{turns} inflaters taking turns") == 2, px.stderr    # both files
+    _same_files(x, y)
+    err = lambda p: [l for l in p.stderr.split("\n") if l.startswith("Error parsing")]  # noqa: E731
+    assert err(px) == err(py)
+    if case == "equal":
+        z = str(tmp_path / "ora")
+        _run_pair(oracle_bin, sim_db, f1, f2, z)
+        _same_files(x, z, (".all", ".one", ".unc", ".rep"))
+        assert cu.Res(x).total_classified > 1000
