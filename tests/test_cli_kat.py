@@ -30,6 +30,89 @@ def test_kat_cases_oracle_backend(oracle_bin, kat, files, tmp_path):
     _all_cases(oracle_bin, kat, files, str(tmp_path))
 
 
+def _expected_sta_of_case(kat, files, case):
+    """The .sta file of a KAT scenario as write_stats prints it (GanonClassify.cpp:1167-1218; rows by write_stats_db :1130-1165): one
+    row per hierarchy label in the order of the std::map (sorted), every row with the RUN's seq_processed / seq_unclassified /
+    kmers_processed and the label's own counts (add_totals / add_reports :197-246), a `-total-` row when there are several labels.
+    The per-read results come from the oracle's Level (the hierarchy loop of :1461-1639 as in tests/test_oracle_kat.py)."""
+    import oracle
+    labels = case.get("hierarchy_labels") or ["H1"] * len(case["ibf"])
+    if len(labels) == 1:
+        labels = labels * len(case["ibf"])
+    rel_cutoff = case["rel_cutoff"] * (len(case["ibf"]) if len(case["rel_cutoff"]) == 1 else 1)
+    levels = {}
+    for i, (ibf_name, lab) in enumerate(zip(case["ibf"], labels)):
+        levels.setdefault(lab, []).append(files.built[ibf_name].as_filter(rel_cutoff[i]))
+    uniq = sorted(levels)
+    rel_filter = case["rel_filter"] * (len(uniq) if len(case["rel_filter"]) == 1 else 1)
+    fpr_query = case["fpr_query"] * (len(uniq) if len(case["fpr_query"]) == 1 else 1)
+    reads = [(kat["reads"][r], None) for r in case["single"]] + [(kat["reads"][a], kat["reads"][b]) for a, b in case["paired"]]
+    zero = lambda: dict(seqs_classified=0, seqs_unique=0, matches=0, dis_filter=0, dis_fpr=0, kmers_matches=0, kmers_from_classified_seqs=0)  # noqa: E731
+    run = dict(zero(), seqs_processed=0, kmers_processed=0)
+    per = {}
+    pending = reads
+    for li, lab in enumerate(uniq):
+        b0 = kat["builds"][case["ibf"][labels.index(lab)]]
+        lvl = oracle.Level(levels[lab], b0["k"], b0["w"], rel_filter[li], fpr_query[li])
+        t = per[lab] = zero()
+        nxt = []
+        for s1, s2 in pending:
+            rr = lvl.classify(gf.literal_to_ranks(s1), gf.literal_to_ranks(s2) if s2 else None)
+            if li == 0 and rr.status == 0:          # :706-714 (hierarchy_first)
+                run["seqs_processed"] += 1
+                run["kmers_processed"] += rr.n_hashes
+            if rr.status != 0:                       # :737-747: skipped reads are not passed on
+                continue
+            t["dis_filter"] += len(rr.discarded_filter)
+            t["dis_fpr"] += len(rr.discarded_fpr)
+            if rr.kept:
+                t["seqs_classified"] += 1
+                t["seqs_unique"] += 1 if len(rr.kept) == 1 else 0
+                t["matches"] += len(rr.kept)
+                t["kmers_from_classified_seqs"] += rr.n_hashes
+                t["kmers_matches"] += rr.max_count
+            else:
+                nxt.append((s1, s2))
+        pending = nxt
+        for k2 in t:
+            run[k2] += t[k2]
+    f6 = lambda x: "%.6f" % x                        # noqa: E731  (std::fixed << std::setprecision(6))
+    seq_processed = float(run["seqs_processed"]) if run["seqs_processed"] > 0 else 1.0
+    unclassified = run["seqs_processed"] - run["seqs_classified"]
+
+    def row(label, t):
+        multiple = t["seqs_classified"] - t["seqs_unique"]
+        avg = t["matches"] / float(t["seqs_classified"]) if t["seqs_classified"] else 0.0
+        kperc = t["kmers_matches"] / float(t["kmers_from_classified_seqs"]) * 100 if t["kmers_matches"] else 0.0
+        return "\t".join(["", label, str(int(seq_processed)), str(unclassified), str(t["seqs_classified"]), f6(t["seqs_classified"] / seq_processed * 100),
+                          str(t["seqs_unique"]), f6(t["seqs_unique"] / seq_processed * 100), str(multiple), f6(multiple / seq_processed * 100),
+                          str(t["matches"]), f6(avg), str(t["dis_filter"]), str(t["dis_fpr"]), str(run["kmers_processed"]), str(t["kmers_matches"]),
+                          str(t["kmers_from_classified_seqs"]), f6(kperc)]) + "\n"
+
+    head = "\t".join(["prefix", "hierarchy_label", "seq_processed", "seq_unclassified", "seq_classified", "seq_classified_perc", "seq_unique_matches",
+                      "seq_unique_matches_perc", "seq_multiple_matches", "seq_multiple_matches_perc", "matches", "avg_matches_ref_seq",
+                      "dis_matches_rel_filter", "dis_matches_fpr_query", "kmers_proccessed", "kmers_matched", "kmers_from_classified_seqs",
+                      "kmers_matched_perc"]) + "\n"
+    text = head + "".join(row(lab, per[lab]) for lab in uniq)
+    if len(uniq) > 1:
+        text += row("-total-", run)
+    return text
+
+
+def test_sta_files_of_every_kat_scenario_are_what_write_stats_prints(oracle_bin, kat, files, tmp_path):
+    """31 scenarios of GanonClassify.test.cpp, several with two or three hierarchy labels (one row per label + `-total-`): the bytes of
+    the .sta file against a restatement of the reference's writer -- columns, order of the rows, fixed six-digit doubles, which counts
+    are the run's and which the label's.  (the writers were pinned by "both backends agree" only.)"""
+    multi = 0
+    for case in kat["cases"]:
+        prefix = os.path.join(str(tmp_path), case["name"])
+        cu.run(oracle_bin, files.case_args(case, prefix))
+        want = _expected_sta_of_case(kat, files, case)
+        assert open(prefix + ".sta").read() == want, case["name"]
+        multi += want.count("-total-")
+    assert multi >= 2   # (the scenarios with several hierarchy labels)
+
+
 @pytest.mark.gpu
 def test_kat_cases_hip(kat, files, tmp_path):
     assert os.path.exists(cu.BIN_HIP), "ganon-classify was not built"
