@@ -113,6 +113,79 @@ def test_sta_files_of_every_kat_scenario_are_what_write_stats_prints(oracle_bin,
     assert multi >= 2   # (the scenarios with several hierarchy labels)
 
 
+def _expected_rep_lines_of_case(kat, files, case):
+    """The .rep file of a KAT scenario as write_report / write_report_totals print it (GanonClassify.cpp:834-863), as a sorted list of
+    lines (the reference iterates a robin_hood map: its row order is not defined by the source).  Per hierarchy label and target:
+    matches (filter_matches :579-613 counts every kept match), unique reads (:773-778), lca reads (lca_matches :615-627 -- or the root
+    node without a taxonomy, :794-799); rank and name columns only with a taxonomy; targets the taxonomy lacks hang under the root as
+    "no rank" (:1343-1362).  Totals: classified, and input minus classified (:855-863)."""
+    import oracle
+    labels = case.get("hierarchy_labels") or ["H1"] * len(case["ibf"])
+    if len(labels) == 1:
+        labels = labels * len(case["ibf"])
+    rel_cutoff = case["rel_cutoff"] * (len(case["ibf"]) if len(case["rel_cutoff"]) == 1 else 1)
+    levels, level_ibfs = {}, {}
+    for i, (ibf_name, lab) in enumerate(zip(case["ibf"], labels)):
+        levels.setdefault(lab, []).append(files.built[ibf_name].as_filter(rel_cutoff[i]))
+        level_ibfs.setdefault(lab, []).append(i)
+    uniq = sorted(levels)
+    rel_filter = case["rel_filter"] * (len(uniq) if len(case["rel_filter"]) == 1 else 1)
+    fpr_query = case["fpr_query"] * (len(uniq) if len(case["fpr_query"]) == 1 else 1)
+    reads = [(kat["reads"][r], None) for r in case["single"]] + [(kat["reads"][a], kat["reads"][b]) for a, b in case["paired"]]
+    has_tax = bool(case.get("tax"))
+    lines, classified = [], 0
+    pending = reads
+    for li, lab in enumerate(uniq):
+        b0 = kat["builds"][case["ibf"][labels.index(lab)]]
+        lvl = oracle.Level(levels[lab], b0["k"], b0["w"], rel_filter[li], fpr_query[li])
+        tax = {}
+        if has_tax:   # merge_tax of the level's filters, the first one wins (:1324-1341); root "1" as tests/ganon_fixtures.write_tax writes it
+            tax["1"] = ("0", "root", "root")
+            tnames = case["tax"] if len(case["tax"]) == len(case["ibf"]) else case["tax"] * len(case["ibf"])
+            for i in level_ibfs[lab]:
+                for node, parent in kat["tax"][tnames[i]].items():
+                    tax.setdefault(node, (parent, f"rank-{node}", f"name-{node}"))
+            for i in level_ibfs[lab]:
+                for t in kat["builds"][case["ibf"][i]]["targets"]:
+                    tax.setdefault(t, ("1", "no rank", t))
+        lca = oracle.Lca([(v[0], k2) for k2, v in tax.items()], "1") if has_tax else None
+        rep = {}
+        nxt = []
+        for s1, s2 in pending:
+            rr = lvl.classify(gf.literal_to_ranks(s1), gf.literal_to_ranks(s2) if s2 else None)
+            if rr.status != 0:
+                continue
+            if not rr.kept:
+                nxt.append((s1, s2))
+                continue
+            classified += 1
+            for t in rr.kept:
+                rep.setdefault(t, [0, 0, 0])[0] += 1
+            if len(rr.kept) == 1:
+                rep[list(rr.kept)[0]][1] += 1
+            else:
+                rep.setdefault(lca.lca(list(rr.kept)) if has_tax else "1", [0, 0, 0])[2] += 1
+        pending = nxt
+        for t, (m, u, l) in rep.items():
+            if m or u or l:
+                lines.append("\t".join([lab, t, str(m), str(u), str(l)] + ([tax[t][1], tax[t][2]] if has_tax else [])))
+    lines.append(f"#total_classified\t{classified}")
+    lines.append(f"#total_unclassified\t{len(reads) - classified}")
+    return sorted(lines)
+
+
+def test_rep_files_of_every_kat_scenario_are_what_write_report_prints(oracle_bin, kat, files, tmp_path):
+    n_rows = 0
+    for case in kat["cases"]:
+        prefix = os.path.join(str(tmp_path), case["name"])
+        cu.run(oracle_bin, files.case_args(case, prefix))
+        got = sorted(open(prefix + ".rep").read().splitlines())
+        want = _expected_rep_lines_of_case(kat, files, case)
+        assert got == want, (case["name"], got[:4], want[:4])
+        n_rows += len(want) - 2
+    assert n_rows > 60
+
+
 @pytest.mark.gpu
 def test_kat_cases_hip(kat, files, tmp_path):
     assert os.path.exists(cu.BIN_HIP), "ganon-classify was not built"
