@@ -1428,7 +1428,8 @@ static int gn_run_group(gn_stream* s)
     // ascending targets) -- nothing to move.  Several column slices per read: their segments are put behind each other now.
     // (identity maps only: the fast kernel writes a read's matches by ascending target; the reads it defers to the generic kernel
     // -- more than 127 minimisers -- come out of a candidate-driven select in no particular order and are put right below)
-    s->segmented = s->f->identity && s->f->geom.wpr == 1 && !s->long_reads && !gn_sw().seg_result;
+    // (... and one count range per batch: the list of deferred reads is per range -- the `chunk=N` test switch keeps the copy per batch)
+    s->segmented = s->f->identity && s->f->geom.wpr == 1 && !s->long_reads && !gn_sw().seg_result && gn_sw().chunk == 0;
     s->compacted = !s->segmented;
     if (nseg && s->segmented)
         hipLaunchKernelGGL(gn_seg_order_kernel, dim3(64), dim3(256), 0, s->st, s->d_deferred, s->d_ctr + 4, s->d_matches, s->d_sorted, s->d_seg_begin,
