@@ -497,7 +497,8 @@ def main() -> int:
             f"{unit_name}, set up in {time.time() - t0:.1f}s")
 
         if part is None:
-            st = ganon_amd.HipStream(flt, n_reads, wl.bases.size, max_matches=n_reads * 2)
+            # (matches per read the stream's buffers are made for; low-cutoff probes ask for more up front: $GANON_BENCH_MATCHES_PER_READ)
+            st = ganon_amd.HipStream(flt, n_reads, wl.bases.size, max_matches=n_reads * int(os.environ.get("GANON_BENCH_MATCHES_PER_READ", "2")))
             st.upload(wl.bases, wl.off, off2)
             st.sync()
 
