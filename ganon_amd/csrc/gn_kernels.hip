@@ -25,7 +25,10 @@
 #define GN_NARROW_MAX 4u
 #endif
 #define GN_MATCH_CHUNK 256u      // first wave-private chunk of the match buffer ...
-#define GN_MATCH_CHUNK_MAX 8192u // ... doubling with every further request of the wave (see the fast kernel's epilogue)
+#ifndef GN_MATCH_CHUNK_MAX
+#define GN_MATCH_CHUNK_MAX 8192u
+#endif
+// ... doubling with every further request of the wave (see the fast kernel's epilogue)
 #define GN_STAGE_CAP 128u // per-wave LDS staging of (target, count) hits in the generic select pass
 
 // ------------------------------------------------------------------------------------------------
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT > 512
             if (total > chunk_left)
             {
                 const uint32_t need = total > chunk_size ? total : chunk_size;
-                chunk_size = chunk_size < GN_MATCH_CHUNK_MAX ? chunk_size * 2u : chunk_size;
+                chunk_size = chunk_size * 2u <= GN_MATCH_CHUNK_MAX ? chunk_size * 2u : GN_MATCH_CHUNK_MAX;
                 unsigned long long nb = 0;
                 if (lane == 0)
                     nb = atomicAdd(p.cursor, (unsigned long long)need);
@@ -1628,7 +1631,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EE ? (LW ==
         if (total > chunk_left)
         {
             const uint32_t need = total > chunk_size ? total : chunk_size;
-                chunk_size = chunk_size < GN_MATCH_CHUNK_MAX ? chunk_size * 2u : chunk_size;
+                chunk_size = chunk_size * 2u <= GN_MATCH_CHUNK_MAX ? chunk_size * 2u : GN_MATCH_CHUNK_MAX;
             unsigned long long nb = 0;
             if (lane == 0)
                 nb = atomicAdd(p.cursor, (unsigned long long)need);
