@@ -68,8 +68,10 @@ constexpr uint32_t GI_WINDOW     = 32768u;
 constexpr uint32_t GI_PIECE_LOG2 = 15u; // symbols per output piece (>= the window: a match source is in this piece or the one before)
 constexpr uint32_t GI_PIECE      = 1u << GI_PIECE_LOG2;
 constexpr uint32_t GI_MAX_PIECES = 64u; // per chunk: 2 Mi symbols
-constexpr uint32_t GI_LIT_ROOT   = 9u, GI_LIT_CAP = 1024u; // (zlib's ENOUGH_LENS for a 9-bit root is 852)
-constexpr uint32_t GI_DIST_ROOT  = 6u, GI_DIST_CAP = 640u; // (ENOUGH_DISTS for a 6-bit root is 592)
+// (zlib's ENOUGH_LENS for a 9-bit root is 852, ENOUGH_DISTS for a 6-bit root 592: gi_build sizes sub-tables as inftrees.c does and refuses
+//  over-subscribed and incomplete sets, so no set it accepts needs more.  LDS per wave decides how many chunks a CU decodes at once.)
+constexpr uint32_t GI_LIT_ROOT   = 9u, GI_LIT_CAP = 852u;
+constexpr uint32_t GI_DIST_ROOT  = 6u, GI_DIST_CAP = 592u;
 constexpr uint32_t GI_PRE_ROOT   = 7u;
 constexpr uint32_t GI_RING       = 1024u;
 constexpr uint32_t GI_MEND       = 32u; // member ends one chunk may hold
@@ -144,8 +146,14 @@ struct GiLds
         };
     };
     uint32_t piece[GI_MAX_PIECES];
-    uint16_t tok_len[64], tok_val[64]; // the batch's tokens (gi_codes)
-    uint8_t  lens[320];
+    union // (code lengths are read while a block's tables are built, the token list while its codes are decoded: never at the same time)
+    {
+        struct
+        {
+            uint16_t tok_len[64], tok_val[64]; // the batch's tokens (gi_codes)
+        };
+        uint8_t lens[320];
+    };
 };
 
 struct GiParams
